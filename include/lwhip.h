@@ -1,0 +1,262 @@
+/*
+ * lwhip.h -- C ABI of the MI355X (gfx950) implementation of Lightweaver's
+ * `formal_sol_gamma_matrices` iteration (1D plane-parallel, unpolarised).
+ *
+ * This is the drop-in boundary.  Everything above it (the Lightweaver plugin
+ * `fs_iteration_fns_provider`, the Python ctypes mirror) talks to the HIP
+ * kernels only through the functions declared here: plain pointers and sizes,
+ * no C++ types, no torch types.
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the Lightweaver source tree):
+ *
+ *   lwhip_formal_sol_gamma_matrices  <- FsIterationFns::fs_iter
+ *        (Source/LwFormalInterface.hpp:86,118; trampoline Source/FormalScalar.cpp:678-681;
+ *         scalar body Source/SimdFullIterationTemplates.hpp:588-719)
+ *   lwhip_formal_sol                 <- FsIterationFns::simple_fs
+ *        (Source/LwFormalInterface.hpp:87,119; Source/SimdFullIterationTemplates.hpp:721-781)
+ *   lwhip_stat_equil                 <- FsIterationFns::stat_eq
+ *        (Source/LwFormalInterface.hpp:91,122; Source/UpdatePopulations.cpp:7-47; Source/LuSolve.cpp:8-132)
+ *   lwhip_compute_profiles           <- Transition::compute_phi / compute_wphi
+ *        (Source/FormalScalar.cpp:28-68,106-134)
+ *   lwhip_create / lwhip_destroy     <- FsIterationFns::alloc_global_scratch / free_global_scratch
+ *        (Source/LwFormalInterface.hpp:106-107,131-132; called from Source/ThreadStorage.cpp:480-493,538-566)
+ *   lwhip_upload / lwhip_download    <- (none: the reference shares host memory; these move the
+ *        borrowed numpy buffers of Source/LwMiddleLayer.pyx to/from HBM)
+ *
+ * The problem descriptor is a flat restatement of what `Context&` reaches
+ * (Source/LwContext.hpp:20-46): Atmosphere (Source/LwAtmosphere.hpp:179-221), Spectrum and
+ * Background (Source/LwMisc.hpp:85-110), Atom (Source/LwAtom.hpp:41-80) and Transition
+ * (Source/LwTransition.hpp:21-69).  All arrays are C-contiguous fp64, depth `k` fastest,
+ * exactly as the reference lays them out.
+ *
+ * All host pointers in the descriptor are BORROWED: the library reads them in
+ * lwhip_create/lwhip_upload and writes them in lwhip_download, never otherwise.
+ */
+#ifndef LWHIP_H
+#define LWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LWHIP_ABI_VERSION 1
+
+/* ---- enums (values mirror the reference where one exists) ---------------- */
+
+/* TransitionType, Source/LwTransition.hpp:10-14 */
+enum { LWHIP_LINE = 0, LWHIP_CONTINUUM = 1 };
+
+/* RadiationBc, Source/LwAtmosphere.hpp:6-13 */
+enum {
+    LWHIP_BC_UNINITIALISED = 0,
+    LWHIP_BC_ZERO = 1,
+    LWHIP_BC_THERMALISED = 2,
+    LWHIP_BC_PERIODIC = 3,
+    LWHIP_BC_CALLABLE = 4
+};
+
+/* 1D formal solvers registered in Source/FormalInterface.cpp:30-32 */
+enum {
+    LWHIP_FS_LINEAR_1D = 0,  /* "piecewise_linear_1d"  */
+    LWHIP_FS_BESSER_1D = 1,  /* "piecewise_besser_1d"  */
+    LWHIP_FS_BEZIER3_1D = 2  /* "piecewise_bezier3_1d" (reference default, lightweaver/config.py:12) */
+};
+
+/* status codes */
+enum {
+    LWHIP_OK = 0,
+    LWHIP_ERR_INVALID = 1,      /* bad descriptor / argument                       */
+    LWHIP_ERR_UNSUPPORTED = 2,  /* valid in the reference, not built here (stated)   */
+    LWHIP_ERR_DEVICE = 3,       /* HIP runtime failure or no gfx950 device          */
+    LWHIP_ERR_SINGULAR = 4      /* "Singular Matrix" of Source/LuSolve.cpp:22-23       */
+};
+
+/* array groups for lwhip_upload / lwhip_download (bit mask) */
+enum {
+    LWHIP_ATMOS      = 1 << 0,  /* height, temperature, muz, wmu, vlosMu, wavelength   (up)     */
+    LWHIP_BACKGROUND = 1 << 1,  /* background chi, eta, sca                             (up)     */
+    LWHIP_PROFILES   = 1 << 2,  /* phi, wphi of every line                              (up/down)*/
+    LWHIP_POPS       = 1 << 3,  /* n of every atom                                      (up/down)*/
+    LWHIP_NSTAR      = 1 << 4,  /* nStar, nTotal, vBroad of every atom, aDamp of lines   (up)     */
+    LWHIP_J          = 1 << 5,  /* spect.J                                              (up/down)*/
+    LWHIP_GAMMA      = 1 << 6,  /* Gamma of every active atom (pre-fill in, result out) (up/down)*/
+    LWHIP_BC         = 1 << 7,  /* CALLABLE boundary data                               (up)     */
+    LWHIP_RHOPRD     = 1 << 8,  /* rhoPrd of PRD lines                                  (up)     */
+    LWHIP_I          = 1 << 9,  /* spect.I                                              (down)   */
+    LWHIP_RATES      = 1 << 10, /* Rij, Rji of every transition                         (down)   */
+    LWHIP_DEPTHDATA  = 1 << 11, /* depthData chi, eta, I (only when requested at create)(down)   */
+    LWHIP_COLLISIONS = 1 << 12, /* C of every active atom                               (up)     */
+    LWHIP_ALL_INPUTS = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 6) |
+                       (1 << 7) | (1 << 8) | (1 << 12),
+    LWHIP_ALL_OUTPUTS = (1 << 5) | (1 << 6) | (1 << 9) | (1 << 10)
+};
+
+/* ---- descriptor ----------------------------------------------------------- */
+
+/* One radiative transition; mirrors Transition (Source/LwTransition.hpp:21-69). */
+typedef struct lwhip_transition {
+    int32_t type;          /* LWHIP_LINE | LWHIP_CONTINUUM                                         */
+    int32_t i, j;          /* lower, upper level                                                   */
+    int32_t Nblue, Nred;   /* active for Nblue <= la < Nred of the global grid (is_active, :88-91)   */
+    int32_t prd;           /* non-zero: rhoPrd is valid and multiplies gij (LwAtom.hpp:121-123)    */
+    double Aji, Bji, Bij;  /* Einstein coefficients (lines)                                        */
+    double lambda0;        /* [nm]                                                                 */
+    double dopplerWidth;   /* c/lambda0 for lines, 1.0 for continua (LwMiddleLayer.pyx:1799,1815)  */
+    const double* wavelength; /* [Nred-Nblue] = global wavelength[Nblue:Nred]                      */
+    const double* alpha;   /* [Nred-Nblue] cross-section, continua only                            */
+    double* phi;           /* [Nred-Nblue, Nrays, 2, Nspace] lines only; dir 0 = down, 1 = toObs   */
+    double* wphi;          /* [Nspace] lines only                                                  */
+    const double* aDamp;   /* [Nspace] lines only; needed by lwhip_compute_profiles                */
+    double* rhoPrd;        /* [Nred-Nblue, Nspace] or NULL                                         */
+    double* Rij;           /* [Nspace] out                                                         */
+    double* Rji;           /* [Nspace] out                                                         */
+} lwhip_transition;
+
+/* One atom; mirrors Atom (Source/LwAtom.hpp:41-80). */
+typedef struct lwhip_atom {
+    int32_t Nlevel;
+    int32_t Ntrans;
+    int32_t detailed;      /* non-zero: member of ctx.detailedAtoms (rates only, no Gamma)         */
+    int32_t _pad;
+    double* n;             /* [Nlevel, Nspace] in; out of lwhip_stat_equil                         */
+    const double* nStar;   /* [Nlevel, Nspace]                                                     */
+    const double* nTotal;  /* [Nspace]                                                             */
+    const double* vBroad;  /* [Nspace]                                                             */
+    double* Gamma;         /* [Nlevel, Nlevel, Nspace] index (to, from, k); NULL if detailed       */
+    const double* C;       /* [Nlevel, Nlevel, Nspace] collisional rates; may be NULL              */
+    lwhip_transition* trans; /* [Ntrans]                                                           */
+} lwhip_atom;
+
+/* One z boundary; mirrors AtmosphericBoundaryCondition (Source/LwAtmosphere.hpp:17-43). */
+typedef struct lwhip_boundary {
+    int32_t type;          /* LWHIP_BC_*                                                           */
+    int32_t Nmu;           /* second extent of bcData                                              */
+    const int32_t* idxs;   /* [Nrays, 2] -> row of bcData, or -1 (CALLABLE only)                   */
+    const double* bcData;  /* [Nlambda, Nmu] (third reference extent is 1 in 1D) (CALLABLE only)   */
+} lwhip_boundary;
+
+typedef struct lwhip_problem {
+    int32_t abiVersion;    /* LWHIP_ABI_VERSION                                                    */
+    int32_t Nspace;        /* depth points                                                         */
+    int32_t Nrays;         /* mu quadrature points                                                 */
+    int32_t Nlambda;       /* global wavelength grid                                               */
+    int32_t Natom;         /* active atoms first, then detailed atoms                              */
+    int32_t formalSolver;  /* LWHIP_FS_*                                                           */
+    int32_t storeDepthData;/* non-zero: fill depthChi/depthEta/depthI (DepthData.fill)             */
+    int32_t _pad;
+    const double* height;      /* [Nspace] m, decreasing index 0 = top                              */
+    const double* temperature; /* [Nspace] K                                                        */
+    const double* vlosMu;      /* [Nrays, Nspace]; needed by lwhip_compute_profiles only            */
+    const double* muz;         /* [Nrays]                                                           */
+    const double* wmu;         /* [Nrays]                                                           */
+    const double* wavelength;  /* [Nlambda] nm                                                      */
+    lwhip_boundary zLowerBc;   /* bottom of the atmosphere (k = Nspace-1), feeds up-going rays      */
+    lwhip_boundary zUpperBc;   /* top (k = 0), feeds down-going rays                                */
+    const double* bgChi;       /* [Nlambda, Nspace]                                                 */
+    const double* bgEta;       /* [Nlambda, Nspace]                                                 */
+    const double* bgSca;       /* [Nlambda, Nspace]                                                 */
+    double* J;                 /* [Nlambda, Nspace] in (J-dagger) / out                             */
+    double* I;                 /* [Nlambda, Nrays] out, emergent intensity at k = 0                 */
+    double* depthChi;          /* [Nlambda, Nrays, 2, Nspace] or NULL                               */
+    double* depthEta;          /* [Nlambda, Nrays, 2, Nspace] or NULL                               */
+    double* depthI;            /* [Nlambda, Nrays, 2, Nspace] or NULL                               */
+    lwhip_atom* atoms;         /* [Natom]                                                           */
+} lwhip_problem;
+
+typedef struct lwhip_options {
+    int32_t device;        /* HIP device ordinal                                                   */
+    int32_t laStart;       /* wavelength shard owned by this context: [laStart, laEnd)             */
+    int32_t laEnd;         /* 0,0 = whole grid                                                     */
+    int32_t flags;         /* reserved, 0                                                          */
+    void* stream;          /* hipStream_t to launch on, NULL = the library's own stream            */
+} lwhip_options;
+
+typedef struct lwhip_context lwhip_context; /* opaque */
+
+/* Result of one iteration; the members of IterationResult (Source/LwIterationResult.hpp:6-28)
+ * that fs_iter fills (Source/SimdFullIterationTemplates.hpp:633-637). */
+typedef struct lwhip_iter_result {
+    int32_t updatedJ;
+    int32_t dJMaxIdx;      /* wavelength index of the first maximum of dJ(la)                      */
+    double dJMax;          /* max_la max_k |1 - Jdag/J|                                            */
+} lwhip_iter_result;
+
+/* ---- entry points ----------------------------------------------------------- */
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* lwhip_last_error(void);
+
+/* ABI version the library was built with. */
+int lwhip_abi_version(void);
+
+/* Number of visible gfx950 devices (0 if none / no driver). Never fails. */
+int lwhip_device_count(void);
+
+/* Allocate device state for `prob`, build the per-wavelength activity tables and upload
+ * LWHIP_ALL_INPUTS.  Replaces alloc_global_scratch.  `opts` may be NULL. */
+int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context** out);
+
+/* Free everything lwhip_create allocated.  Replaces free_global_scratch. */
+int lwhip_destroy(lwhip_context* ctx);
+
+/* Copy the host arrays named by `mask` (LWHIP_* bits) from the descriptor given at create
+ * into HBM / back out of it.  Synchronous with respect to the host buffers. */
+int lwhip_upload(lwhip_context* ctx, uint32_t mask);
+int lwhip_download(lwhip_context* ctx, uint32_t mask);
+
+/* Gamma <- crsw * C on the device: the pre-fill LwContext.formal_sol_gamma_matrices performs on
+ * the host before calling the core (Source/LwMiddleLayer.pyx:3198-3203). */
+int lwhip_gamma_prefill_from_C(lwhip_context* ctx, double crsw);
+
+/* One formal_sol_gamma_matrices iteration over the context's wavelength shard:
+ * J, I overwritten, Rij/Rji fresh integrals, Gamma += radiative terms, diagonal finalised.
+ * Pre-condition (as in the reference): Gamma holds the collisional pre-fill.
+ * `lambdaIterate` != 0 sets PsiStar = 0 (FsMode::PureLambdaIteration). */
+int lwhip_formal_sol_gamma_matrices(lwhip_context* ctx, int lambdaIterate, lwhip_iter_result* res);
+
+/* The same iteration split around the cross-GPU reduction (wavelength-sharded runs):
+ *   lwhip_fs_partial   launches the sweep; leaves this shard's Gamma/R partial sums in the
+ *                      reduce buffer and dJMax in its last two slots;
+ *   (caller all-reduces the buffer: sum over the first `nSum` doubles, max over the rest)
+ *   lwhip_fs_finalise  adds the reduced sums into Gamma (which keeps its pre-fill, cf.
+ *                      Source/ThreadStorage.cpp:155-156), finalises the diagonal, writes Rij/Rji. */
+int lwhip_fs_partial(lwhip_context* ctx, int lambdaIterate);
+int lwhip_fs_finalise(lwhip_context* ctx, lwhip_iter_result* res);
+/* Device pointer and layout of the reduce buffer: doubles [0,nSum) are sums, [nSum,nSum+nMax) maxima. */
+int lwhip_reduce_buffer(lwhip_context* ctx, void** devPtr, size_t* nSum, size_t* nMax);
+
+/* formal_sol: chi/S/solve/I only, optionally up-going rays only (FsMode::FsOnly|UpOnly). */
+int lwhip_formal_sol(lwhip_context* ctx, int upOnly);
+
+/* Statistical equilibrium for atom `atom` (index into prob->atoms; -1 = every active atom):
+ * per depth, eliminate the row of the largest population, solve by Crout LU with implicit
+ * scaling, partial pivoting and one refinement pass; n overwritten on the device.
+ * Returns LWHIP_ERR_SINGULAR where the reference throws "Singular Matrix". */
+int lwhip_stat_equil(lwhip_context* ctx, int atom);
+
+/* Voigt profiles phi and weights wphi of every line, on the device. */
+int lwhip_compute_profiles(lwhip_context* ctx);
+
+/* Block until all work queued on the context's stream has finished. */
+int lwhip_synchronize(lwhip_context* ctx);
+
+/* Use `stream` (hipStream_t) for all subsequent launches; NULL = the library's own. */
+int lwhip_set_stream(lwhip_context* ctx, void* stream);
+
+/* Measurement support (bench.py): when enabled, every sweep launch is bracketed by HIP events
+ * on the launch stream; lwhip_sweep_time returns the mean duration (ms) and launch count since
+ * the last reset. */
+int lwhip_profile_enable(lwhip_context* ctx, int enable);
+int lwhip_sweep_time(lwhip_context* ctx, double* meanMs, int* nLaunches);
+
+/* Algorithmic bytes one iteration of this context moves (SURVEY.md 8d / DESIGN.md). */
+int lwhip_algorithmic_bytes(lwhip_context* ctx, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LWHIP_H */

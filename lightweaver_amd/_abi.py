@@ -1,0 +1,127 @@
+"""ctypes mirror of include/lwhip.h (the C-ABI drop-in boundary).
+
+Field order and types must match the header exactly; tests/test_abi.py checks sizes and
+offsets against a C program compiled from the header.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+# enums (include/lwhip.h)
+LINE, CONTINUUM = 0, 1
+BC_UNINITIALISED, BC_ZERO, BC_THERMALISED, BC_PERIODIC, BC_CALLABLE = range(5)
+FS_LINEAR_1D, FS_BESSER_1D, FS_BEZIER3_1D = range(3)
+FS_NAMES = {
+    'piecewise_linear_1d': FS_LINEAR_1D,
+    'piecewise_besser_1d': FS_BESSER_1D,
+    'piecewise_bezier3_1d': FS_BEZIER3_1D,
+}
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_SINGULAR = range(5)
+
+ATMOS = 1 << 0
+BACKGROUND = 1 << 1
+PROFILES = 1 << 2
+POPS = 1 << 3
+NSTAR = 1 << 4
+J = 1 << 5
+GAMMA = 1 << 6
+BC = 1 << 7
+RHOPRD = 1 << 8
+I = 1 << 9
+RATES = 1 << 10
+DEPTHDATA = 1 << 11
+COLLISIONS = 1 << 12
+ALL_INPUTS = ATMOS | BACKGROUND | PROFILES | POPS | NSTAR | J | GAMMA | BC | RHOPRD | COLLISIONS
+ALL_OUTPUTS = J | GAMMA | I | RATES
+
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+
+
+class lwhip_transition(C.Structure):
+    _fields_ = [
+        ('type', C.c_int32), ('i', C.c_int32), ('j', C.c_int32),
+        ('Nblue', C.c_int32), ('Nred', C.c_int32), ('prd', C.c_int32),
+        ('Aji', C.c_double), ('Bji', C.c_double), ('Bij', C.c_double),
+        ('lambda0', C.c_double), ('dopplerWidth', C.c_double),
+        ('wavelength', f64p), ('alpha', f64p), ('phi', f64p), ('wphi', f64p),
+        ('aDamp', f64p), ('rhoPrd', f64p), ('Rij', f64p), ('Rji', f64p),
+    ]
+
+
+class lwhip_atom(C.Structure):
+    _fields_ = [
+        ('Nlevel', C.c_int32), ('Ntrans', C.c_int32), ('detailed', C.c_int32), ('_pad', C.c_int32),
+        ('n', f64p), ('nStar', f64p), ('nTotal', f64p), ('vBroad', f64p),
+        ('Gamma', f64p), ('C', f64p),
+        ('trans', C.POINTER(lwhip_transition)),
+    ]
+
+
+class lwhip_boundary(C.Structure):
+    _fields_ = [
+        ('type', C.c_int32), ('Nmu', C.c_int32),
+        ('idxs', i32p), ('bcData', f64p),
+    ]
+
+
+class lwhip_problem(C.Structure):
+    _fields_ = [
+        ('abiVersion', C.c_int32), ('Nspace', C.c_int32), ('Nrays', C.c_int32),
+        ('Nlambda', C.c_int32), ('Natom', C.c_int32), ('formalSolver', C.c_int32),
+        ('storeDepthData', C.c_int32), ('_pad', C.c_int32),
+        ('height', f64p), ('temperature', f64p), ('vlosMu', f64p), ('muz', f64p),
+        ('wmu', f64p), ('wavelength', f64p),
+        ('zLowerBc', lwhip_boundary), ('zUpperBc', lwhip_boundary),
+        ('bgChi', f64p), ('bgEta', f64p), ('bgSca', f64p),
+        ('J', f64p), ('I', f64p),
+        ('depthChi', f64p), ('depthEta', f64p), ('depthI', f64p),
+        ('atoms', C.POINTER(lwhip_atom)),
+    ]
+
+
+class lwhip_options(C.Structure):
+    _fields_ = [
+        ('device', C.c_int32), ('laStart', C.c_int32), ('laEnd', C.c_int32), ('flags', C.c_int32),
+        ('stream', C.c_void_p),
+    ]
+
+
+class lwhip_iter_result(C.Structure):
+    _fields_ = [('updatedJ', C.c_int32), ('dJMaxIdx', C.c_int32), ('dJMax', C.c_double)]
+
+
+# every symbol include/lwhip.h declares: (name, restype, argtypes)
+ctx_p = C.c_void_p
+SYMBOLS = [
+    ('lwhip_last_error', C.c_char_p, []),
+    ('lwhip_abi_version', C.c_int, []),
+    ('lwhip_device_count', C.c_int, []),
+    ('lwhip_create', C.c_int, [C.POINTER(lwhip_problem), C.POINTER(lwhip_options), C.POINTER(ctx_p)]),
+    ('lwhip_destroy', C.c_int, [ctx_p]),
+    ('lwhip_upload', C.c_int, [ctx_p, C.c_uint32]),
+    ('lwhip_download', C.c_int, [ctx_p, C.c_uint32]),
+    ('lwhip_gamma_prefill_from_C', C.c_int, [ctx_p, C.c_double]),
+    ('lwhip_formal_sol_gamma_matrices', C.c_int, [ctx_p, C.c_int, C.POINTER(lwhip_iter_result)]),
+    ('lwhip_fs_partial', C.c_int, [ctx_p, C.c_int]),
+    ('lwhip_fs_finalise', C.c_int, [ctx_p, C.POINTER(lwhip_iter_result)]),
+    ('lwhip_reduce_buffer', C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_size_t)]),
+    ('lwhip_formal_sol', C.c_int, [ctx_p, C.c_int]),
+    ('lwhip_stat_equil', C.c_int, [ctx_p, C.c_int]),
+    ('lwhip_compute_profiles', C.c_int, [ctx_p]),
+    ('lwhip_synchronize', C.c_int, [ctx_p]),
+    ('lwhip_set_stream', C.c_int, [ctx_p, C.c_void_p]),
+    ('lwhip_profile_enable', C.c_int, [ctx_p, C.c_int]),
+    ('lwhip_sweep_time', C.c_int, [ctx_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    ('lwhip_algorithmic_bytes', C.c_int, [ctx_p, C.POINTER(C.c_double)]),
+]
+
+
+def bind(lib):
+    """Attach restype/argtypes for every declared symbol; raises AttributeError if one is missing."""
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib

@@ -1,0 +1,280 @@
+"""Host-side data model at the `Context` array boundary.
+
+These classes own the numpy buffers that Lightweaver's Cython layer owns in the reference
+(LwAtmosphere / LwSpectrum / LwBackground / LwAtom / LwTransition,
+Source/LwMiddleLayer.pyx:639-689,2724-2732,1571-1597,2389-2406,1804-1825) and flatten them into
+the `lwhip_problem` descriptor of include/lwhip.h.  Shapes follow SURVEY.md Appendix C:
+everything C-contiguous float64, depth `k` fastest.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _abi as abi
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f'expected shape {tuple(shape)}, got {a.shape}')
+    return a
+
+
+def _ptr(a):
+    if a is None:
+        return C.cast(None, abi.f64p)
+    return a.ctypes.data_as(abi.f64p)
+
+
+@dataclass
+class TransitionData:
+    """One line or continuum (Transition, Source/LwTransition.hpp:21-69)."""
+    type: int
+    i: int
+    j: int
+    Nblue: int
+    Nred: int
+    lambda0: float
+    wavelength: np.ndarray                 # [NlaT] = global grid[Nblue:Nred]
+    Aji: float = 0.0
+    Bji: float = 0.0
+    Bij: float = 0.0
+    dopplerWidth: float = 1.0
+    alpha: Optional[np.ndarray] = None     # [NlaT] continua
+    phi: Optional[np.ndarray] = None       # [NlaT, Nrays, 2, Nspace] lines
+    wphi: Optional[np.ndarray] = None      # [Nspace] lines
+    aDamp: Optional[np.ndarray] = None     # [Nspace] lines
+    rhoPrd: Optional[np.ndarray] = None    # [NlaT, Nspace] PRD lines
+    Rij: Optional[np.ndarray] = None       # [Nspace]
+    Rji: Optional[np.ndarray] = None       # [Nspace]
+
+    @property
+    def Nlambda(self):
+        return self.Nred - self.Nblue
+
+    def wlambda(self):
+        """Trapezoid weights of the transition's own grid, Transition::wlambda
+        (Source/LwTransition.hpp:71-81)."""
+        w = self.wavelength
+        out = np.empty_like(w)
+        out[0] = 0.5 * (w[1] - w[0])
+        out[-1] = 0.5 * (w[-1] - w[-2])
+        out[1:-1] = 0.5 * (w[2:] - w[:-2])
+        return out * self.dopplerWidth
+
+
+@dataclass
+class AtomData:
+    """One atom (Atom, Source/LwAtom.hpp:41-80)."""
+    name: str
+    Nlevel: int
+    n: np.ndarray                          # [Nlevel, Nspace]
+    nStar: np.ndarray                      # [Nlevel, Nspace]
+    nTotal: np.ndarray                     # [Nspace]
+    vBroad: np.ndarray                     # [Nspace]
+    trans: List[TransitionData] = field(default_factory=list)
+    detailed: bool = False
+    Gamma: Optional[np.ndarray] = None     # [Nlevel, Nlevel, Nspace] (to, from, k)
+    C: Optional[np.ndarray] = None         # [Nlevel, Nlevel, Nspace]
+
+
+@dataclass
+class Boundary:
+    """AtmosphericBoundaryCondition (Source/LwAtmosphere.hpp:17-43) for one z face."""
+    type: int = abi.BC_ZERO
+    idxs: Optional[np.ndarray] = None      # [Nrays, 2] int32
+    bcData: Optional[np.ndarray] = None    # [Nlambda, Nmu]
+
+
+class Problem:
+    """Everything `Context&` reaches on the hot path, as owned numpy arrays."""
+
+    def __init__(self, height, temperature, muz, wmu, wavelength, bgChi, bgEta, bgSca,
+                 atoms: List[AtomData], vlosMu=None, J=None,
+                 formalSolver=abi.FS_BEZIER3_1D,
+                 zLowerBc: Optional[Boundary] = None, zUpperBc: Optional[Boundary] = None,
+                 storeDepthData=False):
+        self.height = _f64(height)
+        self.Nspace = self.height.shape[0]
+        self.temperature = _f64(temperature, (self.Nspace,))
+        self.muz = _f64(muz)
+        self.Nrays = self.muz.shape[0]
+        self.wmu = _f64(wmu, (self.Nrays,))
+        self.wavelength = _f64(wavelength)
+        self.Nlambda = self.wavelength.shape[0]
+        shp = (self.Nlambda, self.Nspace)
+        self.bgChi = _f64(bgChi, shp)
+        self.bgEta = _f64(bgEta, shp)
+        self.bgSca = _f64(bgSca, shp)
+        self.vlosMu = (_f64(vlosMu, (self.Nrays, self.Nspace)) if vlosMu is not None
+                       else np.zeros((self.Nrays, self.Nspace)))
+        self.J = _f64(J, shp) if J is not None else np.zeros(shp)
+        self.I = np.zeros((self.Nlambda, self.Nrays))
+        self.formalSolver = int(formalSolver)
+        self.zLowerBc = zLowerBc if zLowerBc is not None else Boundary(abi.BC_THERMALISED)
+        self.zUpperBc = zUpperBc if zUpperBc is not None else Boundary(abi.BC_ZERO)
+        self.storeDepthData = bool(storeDepthData)
+        self.depthChi = self.depthEta = self.depthI = None
+        if self.storeDepthData:
+            dshape = (self.Nlambda, self.Nrays, 2, self.Nspace)
+            self.depthChi = np.zeros(dshape)
+            self.depthEta = np.zeros(dshape)
+            self.depthI = np.zeros(dshape)
+        # active atoms first, then detailed (include/lwhip.h: lwhip_problem.Natom)
+        self.atoms = [a for a in atoms if not a.detailed] + [a for a in atoms if a.detailed]
+        for a in self.atoms:
+            self._normalise_atom(a)
+        self._keepalive = None
+
+    # -- normalisation / allocation of outputs -------------------------------------------------
+    def _normalise_atom(self, a: AtomData):
+        Ns, Nr = self.Nspace, self.Nrays
+        a.n = _f64(a.n, (a.Nlevel, Ns))
+        a.nStar = _f64(a.nStar, (a.Nlevel, Ns))
+        a.nTotal = _f64(a.nTotal, (Ns,))
+        a.vBroad = _f64(a.vBroad, (Ns,))
+        if not a.detailed:
+            a.Gamma = (_f64(a.Gamma, (a.Nlevel, a.Nlevel, Ns)) if a.Gamma is not None
+                       else np.zeros((a.Nlevel, a.Nlevel, Ns)))
+            a.C = (_f64(a.C, (a.Nlevel, a.Nlevel, Ns)) if a.C is not None
+                   else np.zeros((a.Nlevel, a.Nlevel, Ns)))
+        for t in a.trans:
+            if not (0 <= t.Nblue < t.Nred <= self.Nlambda):
+                raise ValueError('transition wavelength range outside the global grid')
+            t.wavelength = _f64(t.wavelength, (t.Nlambda,))
+            if not np.array_equal(t.wavelength, self.wavelength[t.Nblue:t.Nred]):
+                raise ValueError('transition grid must equal wavelength[Nblue:Nred]')
+            if t.Nlambda < 2:
+                raise ValueError('a transition needs at least two wavelength points')
+            if t.type == abi.LINE:
+                t.phi = (_f64(t.phi, (t.Nlambda, Nr, 2, Ns)) if t.phi is not None
+                         else np.zeros((t.Nlambda, Nr, 2, Ns)))
+                t.wphi = _f64(t.wphi, (Ns,)) if t.wphi is not None else np.zeros(Ns)
+                t.aDamp = _f64(t.aDamp, (Ns,)) if t.aDamp is not None else np.zeros(Ns)
+                if t.rhoPrd is not None:
+                    t.rhoPrd = _f64(t.rhoPrd, (t.Nlambda, Ns))
+            else:
+                t.alpha = _f64(t.alpha, (t.Nlambda,))
+            t.Rij = np.zeros(Ns)
+            t.Rji = np.zeros(Ns)
+
+    @property
+    def activeAtoms(self):
+        return [a for a in self.atoms if not a.detailed]
+
+    @property
+    def detailedAtoms(self):
+        return [a for a in self.atoms if a.detailed]
+
+    def gamma_prefill(self, crsw=1.0):
+        """Gamma <- crsw * C, the host pre-fill of LwContext.formal_sol_gamma_matrices
+        (Source/LwMiddleLayer.pyx:3198-3203)."""
+        for a in self.activeAtoms:
+            a.Gamma[...] = crsw * a.C
+
+    # -- flattening ------------------------------------------------------------------------------
+    def _boundary(self, b: Boundary, keep):
+        out = abi.lwhip_boundary()
+        out.type = int(b.type)
+        out.Nmu = 0
+        if b.type == abi.BC_CALLABLE:
+            idxs = np.ascontiguousarray(b.idxs, dtype=np.int32)
+            data = _f64(b.bcData)
+            if idxs.shape != (self.Nrays, 2) or data.ndim != 2 or data.shape[0] != self.Nlambda:
+                raise ValueError('CALLABLE boundary needs idxs[Nrays,2] and bcData[Nlambda,Nmu]')
+            b.idxs, b.bcData = idxs, data
+            keep += [idxs, data]
+            out.Nmu = data.shape[1]
+            out.idxs = idxs.ctypes.data_as(abi.i32p)
+            out.bcData = _ptr(data)
+        return out
+
+    def descriptor(self) -> abi.lwhip_problem:
+        """Build the flat C descriptor.  The returned struct borrows this object's arrays: keep
+        the Problem alive for as long as any library context created from it."""
+        keep = []
+        atoms = (abi.lwhip_atom * len(self.atoms))()
+        for ia, a in enumerate(self.atoms):
+            trans = (abi.lwhip_transition * max(len(a.trans), 1))()
+            keep.append(trans)
+            for kr, t in enumerate(a.trans):
+                ct = trans[kr]
+                ct.type, ct.i, ct.j = int(t.type), int(t.i), int(t.j)
+                ct.Nblue, ct.Nred = int(t.Nblue), int(t.Nred)
+                ct.prd = 1 if (t.type == abi.LINE and t.rhoPrd is not None) else 0
+                ct.Aji, ct.Bji, ct.Bij = float(t.Aji), float(t.Bji), float(t.Bij)
+                ct.lambda0, ct.dopplerWidth = float(t.lambda0), float(t.dopplerWidth)
+                ct.wavelength = _ptr(t.wavelength)
+                ct.alpha = _ptr(t.alpha)
+                ct.phi = _ptr(t.phi)
+                ct.wphi = _ptr(t.wphi)
+                ct.aDamp = _ptr(t.aDamp)
+                ct.rhoPrd = _ptr(t.rhoPrd)
+                ct.Rij = _ptr(t.Rij)
+                ct.Rji = _ptr(t.Rji)
+            ca = atoms[ia]
+            ca.Nlevel, ca.Ntrans, ca.detailed = int(a.Nlevel), len(a.trans), int(bool(a.detailed))
+            ca.n = _ptr(a.n)
+            ca.nStar = _ptr(a.nStar)
+            ca.nTotal = _ptr(a.nTotal)
+            ca.vBroad = _ptr(a.vBroad)
+            ca.Gamma = _ptr(a.Gamma)
+            ca.C = _ptr(a.C)
+            ca.trans = C.cast(trans, C.POINTER(abi.lwhip_transition))
+        p = abi.lwhip_problem()
+        p.abiVersion = abi.ABI_VERSION
+        p.Nspace, p.Nrays, p.Nlambda = self.Nspace, self.Nrays, self.Nlambda
+        p.Natom = len(self.atoms)
+        p.formalSolver = self.formalSolver
+        p.storeDepthData = int(self.storeDepthData)
+        p.height = _ptr(self.height)
+        p.temperature = _ptr(self.temperature)
+        p.vlosMu = _ptr(self.vlosMu)
+        p.muz = _ptr(self.muz)
+        p.wmu = _ptr(self.wmu)
+        p.wavelength = _ptr(self.wavelength)
+        p.zLowerBc = self._boundary(self.zLowerBc, keep)
+        p.zUpperBc = self._boundary(self.zUpperBc, keep)
+        p.bgChi, p.bgEta, p.bgSca = _ptr(self.bgChi), _ptr(self.bgEta), _ptr(self.bgSca)
+        p.J, p.I = _ptr(self.J), _ptr(self.I)
+        p.depthChi, p.depthEta, p.depthI = (_ptr(self.depthChi), _ptr(self.depthEta),
+                                            _ptr(self.depthI))
+        p.atoms = C.cast(atoms, C.POINTER(abi.lwhip_atom))
+        keep.append(atoms)
+        self._keepalive = keep
+        return p
+
+    # -- convenience -----------------------------------------------------------------------------
+    def copy(self) -> 'Problem':
+        import copy
+        new = copy.deepcopy(self)
+        new._keepalive = None
+        return new
+
+    def outputs(self):
+        """Dict of the arrays an iteration writes (copies)."""
+        out = {'J': self.J.copy(), 'I': self.I.copy()}
+        for ia, a in enumerate(self.atoms):
+            if not a.detailed:
+                out[f'Gamma{ia}'] = a.Gamma.copy()
+            out[f'n{ia}'] = a.n.copy()
+            for kr, t in enumerate(a.trans):
+                out[f'Rij{ia}_{kr}'] = t.Rij.copy()
+                out[f'Rji{ia}_{kr}'] = t.Rji.copy()
+        return out
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == '_keepalive':
+                setattr(new, k, None)
+            else:
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new

@@ -1,0 +1,181 @@
+"""oracle/bindings.py -- TEST INFRASTRUCTURE: ctypes bindings of the two checkers.
+
+  RefLib    oracle/_ref/liblwref.so  -- the real Lightweaver core behind oracle/ref_driver.cpp
+  OracleLib oracle/liblworacle.so    -- the plain-C restatement oracle/lw_oracle.c
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Both operate in place on the host arrays of a lightweaver_amd.model.Problem.
+"""
+import ctypes as C
+import os
+
+from lightweaver_amd import _abi as abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, '_ref')
+REF_LIB = os.path.join(REF_DIR, 'liblwref.so')
+ORACLE_LIB = os.path.join(HERE, 'liblworacle.so')
+
+
+def ref_available():
+    return os.path.exists(REF_LIB)
+
+
+def oracle_available():
+    return os.path.exists(ORACLE_LIB)
+
+
+def simd_plugin(isa):
+    """Path of a reference SIMD plugin ('SSE2' | 'AVX2FMA' | 'AVX512') if built and runnable."""
+    path = os.path.join(REF_DIR, f'SimdImpl_{isa}.so')
+    if not os.path.exists(path):
+        return None
+    flags = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('flags'):
+                    flags = line
+                    break
+    except OSError:
+        pass
+    need = {'SSE2': ['sse2'], 'AVX2FMA': ['avx2', 'fma'], 'AVX512': ['avx512f', 'avx512dq']}[isa]
+    if not all((' ' + n + ' ') in (flags + ' ') for n in need):
+        return None
+    return path
+
+
+class _Handle:
+    def __init__(self, lib, prob, create, destroy):
+        self.lib = lib
+        self.prob = prob               # keep the Problem (and its arrays) alive
+        self.desc = prob.descriptor()
+        self._destroy = destroy
+        self.h = create(self.desc)
+
+    def close(self):
+        if self.h:
+            self._destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RefContext(_Handle):
+    """The reference core driving `prob` (scheme: None = mali_full_precond_scalar, or a plugin path)."""
+    _lib = None
+
+    @classmethod
+    def lib_(cls):
+        if cls._lib is None:
+            lib = C.CDLL(REF_LIB)
+            lib.lwref_create.restype = C.c_void_p
+            lib.lwref_create.argtypes = [C.POINTER(abi.lwhip_problem), C.c_char_p, C.c_int,
+                                         C.c_char_p, C.c_int]
+            lib.lwref_destroy.argtypes = [C.c_void_p]
+            lib.lwref_scheme_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+            lib.lwref_compute_profiles.argtypes = [C.c_void_p]
+            lib.lwref_formal_sol_gamma_matrices.argtypes = [C.c_void_p, C.c_int,
+                                                            C.POINTER(abi.lwhip_iter_result)]
+            lib.lwref_formal_sol.argtypes = [C.c_void_p, C.c_int]
+            lib.lwref_stat_equil.argtypes = [C.c_void_p, C.c_int]
+            lib.lwref_w2.argtypes = [C.c_double, abi.f64p]
+            lib.lwref_bezier3_coeffs.argtypes = [C.c_double, abi.f64p]
+            lib.lwref_cent_deriv.restype = C.c_double
+            lib.lwref_cent_deriv.argtypes = [C.c_double] * 5
+            lib.lwref_voigt_H.restype = C.c_double
+            lib.lwref_voigt_H.argtypes = [C.c_double, C.c_double]
+            lib.lwref_planck_nu.argtypes = [C.c_int, abi.f64p, C.c_double, abi.f64p]
+            lib.lwref_solve_lin_eq.argtypes = [C.c_int, abi.f64p, abi.f64p, C.c_int]
+            lib.lwref_formal_solver_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                    abi.f64p, abi.f64p, abi.f64p, abi.f64p]
+            cls._lib = lib
+        return cls._lib
+
+    def __init__(self, prob, scheme=None, Nthreads=1):
+        lib = self.lib_()
+        err = C.create_string_buffer(512)
+        sch = scheme.encode() if scheme else None
+
+        def create(desc):
+            h = lib.lwref_create(C.byref(desc), sch, Nthreads, err, 512)
+            if not h:
+                raise RuntimeError('lwref_create: ' + err.value.decode())
+            return h
+        super().__init__(lib, prob, create, lib.lwref_destroy)
+
+    @property
+    def scheme_name(self):
+        buf = C.create_string_buffer(128)
+        self.lib.lwref_scheme_name(self.h, buf, 128)
+        return buf.value.decode()
+
+    def compute_profiles(self):
+        assert self.lib.lwref_compute_profiles(self.h) == 0
+
+    def formal_sol_gamma_matrices(self, lambdaIterate=False):
+        res = abi.lwhip_iter_result()
+        st = self.lib.lwref_formal_sol_gamma_matrices(self.h, int(lambdaIterate), C.byref(res))
+        assert st == 0
+        return res.dJMax, res.dJMaxIdx
+
+    def formal_sol(self, upOnly=True):
+        assert self.lib.lwref_formal_sol(self.h, int(upOnly)) == 0
+
+    def stat_equil(self, atom=-1):
+        return self.lib.lwref_stat_equil(self.h, atom)
+
+
+class OracleContext(_Handle):
+    """The plain-C restatement driving `prob`."""
+    _lib = None
+
+    @classmethod
+    def lib_(cls):
+        if cls._lib is None:
+            lib = C.CDLL(ORACLE_LIB)
+            lib.lworacle_create.restype = C.c_void_p
+            lib.lworacle_create.argtypes = [C.POINTER(abi.lwhip_problem)]
+            lib.lworacle_destroy.argtypes = [C.c_void_p]
+            lib.lworacle_formal_sol_gamma_matrices.argtypes = [
+                C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.lwhip_iter_result), abi.f64p]
+            lib.lworacle_formal_sol.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            lib.lworacle_stat_equil.argtypes = [C.c_void_p, C.c_int]
+            lib.lworacle_w2.argtypes = [C.c_double, abi.f64p]
+            lib.lworacle_bezier3_coeffs.argtypes = [C.c_double, abi.f64p]
+            lib.lworacle_cent_deriv.restype = C.c_double
+            lib.lworacle_cent_deriv.argtypes = [C.c_double] * 5
+            lib.lworacle_planck_nu.argtypes = [C.c_int, abi.f64p, C.c_double, abi.f64p]
+            lib.lworacle_solve_lin_eq.argtypes = [C.c_int, abi.f64p, abi.f64p, C.c_int]
+            lib.lworacle_formal_solver_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                       abi.f64p, abi.f64p, abi.f64p, abi.f64p]
+            cls._lib = lib
+        return cls._lib
+
+    def __init__(self, prob):
+        lib = self.lib_()
+
+        def create(desc):
+            h = lib.lworacle_create(C.byref(desc))
+            if not h:
+                raise RuntimeError('lworacle_create failed')
+            return h
+        super().__init__(lib, prob, create, lib.lworacle_destroy)
+
+    def formal_sol_gamma_matrices(self, lambdaIterate=False, Nthreads=1, dJ=None):
+        res = abi.lwhip_iter_result()
+        dJp = dJ.ctypes.data_as(abi.f64p) if dJ is not None else C.cast(None, abi.f64p)
+        st = self.lib.lworacle_formal_sol_gamma_matrices(self.h, int(lambdaIterate), Nthreads,
+                                                         C.byref(res), dJp)
+        assert st == 0
+        return res.dJMax, res.dJMaxIdx
+
+    def formal_sol(self, upOnly=True, Nthreads=1):
+        assert self.lib.lworacle_formal_sol(self.h, int(upOnly), Nthreads) == 0
+
+    def stat_equil(self, atom=-1):
+        return self.lib.lworacle_stat_equil(self.h, atom)

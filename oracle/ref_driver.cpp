@@ -1,0 +1,435 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// A thin extern "C" driver around the *real* Lightweaver C++ core.  It is compiled together
+// with the reference's own source files, taken from where they lie under /root/reference/Source
+// (see oracle/Makefile; nothing of the reference is copied into this repository), into
+// oracle/_ref/liblwref.so.  The driver builds a reference `Context` whose F64Views point at the
+// host arrays of an `lwhip_problem` (include/lwhip.h) and calls the reference entry points:
+//
+//   lwref_formal_sol_gamma_matrices -> formal_sol_gamma_matrices()   Source/FormalScalar.cpp:678-681
+//   lwref_formal_sol                -> formal_sol()                  Source/FormalScalar.cpp:691-694
+//   lwref_stat_equil                -> stat_eq()                     Source/UpdatePopulations.cpp:49-53
+//   lwref_compute_profiles          -> Transition::compute_phi/wphi  Source/FormalScalar.cpp:53-68,106-134
+//
+// The iteration scheme is the built-in "mali_full_precond_scalar" (Source/FormalInterface.cpp:83-95)
+// or any plugin loaded through the reference's own FsIterationFnsManager::load_fns_from_path
+// (Source/FormalInterface.cpp:62-81) -- the reference SIMD plugins built by oracle/Makefile, or this
+// repository's HIP plugin, which is how the drop-in is exercised against the real core.
+//
+// Used by: tests/ (to pin oracle/lw_oracle.c and to generate tests/golden/*.npz), bench.py's
+// cpu_baseline leg (kind "reference").  Never linked or loaded by the product path.
+
+#include "Lightweaver.hpp"
+#include "Bezier.hpp"
+#include "LuSolve.hpp"
+
+#include "../include/lwhip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace
+{
+struct RefContext
+{
+    Atmosphere atmos;
+    Spectrum spect;
+    Background background;
+    DepthData depthData;
+    std::vector<std::unique_ptr<Atom>> atoms;
+    std::vector<std::unique_ptr<Transition>> transitions;
+    std::vector<std::vector<i8>> activeMasks;
+    FormalSolverManager fsManager;
+    FsIterationFnsManager iterManager;
+    const lwhip_problem* prob;
+    Context ctx;
+    bool threadsInitialised = false;
+
+    ~RefContext()
+    {
+        if (threadsInitialised)
+            ctx.threading.clear(&ctx);
+    }
+};
+
+void set_error(char* err, int errLen, const std::string& msg)
+{
+    if (err && errLen > 0)
+    {
+        std::snprintf(err, errLen, "%s", msg.c_str());
+    }
+}
+
+const char* solver_name(int solver)
+{
+    switch (solver)
+    {
+        case LWHIP_FS_LINEAR_1D: return "piecewise_linear_1d";
+        case LWHIP_FS_BESSER_1D: return "piecewise_besser_1d";
+        case LWHIP_FS_BEZIER3_1D: return "piecewise_bezier3_1d";
+        default: return nullptr;
+    }
+}
+
+void configure_boundary(AtmosphericBoundaryCondition* bc, const lwhip_boundary& b,
+                        int Nwave, int Nrays)
+{
+    BcIdxs idxs;
+    if (b.idxs)
+        idxs = BcIdxs(const_cast<i32*>(b.idxs), Nrays, 2);
+    *bc = AtmosphericBoundaryCondition((RadiationBc)b.type, Nwave, b.Nmu, 1, idxs);
+    if (b.type == LWHIP_BC_CALLABLE && b.bcData)
+    {
+        F64View3D data(const_cast<f64*>(b.bcData), Nwave, b.Nmu, 1);
+        bc->set_bc_data(data);
+    }
+}
+}
+
+extern "C"
+{
+void* lwref_create(const lwhip_problem* p, const char* schemeLib, int Nthreads,
+                   char* err, int errLen)
+{
+    try
+    {
+        if (!p || p->abiVersion != LWHIP_ABI_VERSION)
+        {
+            set_error(err, errLen, "bad descriptor / ABI version");
+            return nullptr;
+        }
+        auto rc = std::make_unique<RefContext>();
+        rc->prob = p;
+        const int Nspace = p->Nspace;
+        const int Nrays = p->Nrays;
+        const int Nla = p->Nlambda;
+
+        auto& a = rc->atmos;
+        a.Nspace = Nspace;
+        a.Nrays = Nrays;
+        a.Ndim = 1;
+        a.Nx = 0;
+        a.Ny = 0;
+        a.Nz = Nspace;
+        a.Noutgoing = 1;
+        a.z = F64View(const_cast<f64*>(p->height), Nspace);
+        a.height = a.z;
+        a.temperature = F64View(const_cast<f64*>(p->temperature), Nspace);
+        a.vlosMu = F64View2D(const_cast<f64*>(p->vlosMu), Nrays, Nspace);
+        a.muz = F64View(const_cast<f64*>(p->muz), Nrays);
+        a.wmu = F64View(const_cast<f64*>(p->wmu), Nrays);
+        configure_boundary(&a.zLowerBc, p->zLowerBc, Nla, Nrays);
+        configure_boundary(&a.zUpperBc, p->zUpperBc, Nla, Nrays);
+
+        auto& s = rc->spect;
+        s.wavelength = F64View(const_cast<f64*>(p->wavelength), Nla);
+        s.I = F64View3D(p->I, Nla, Nrays, 1);
+        s.J = F64View2D(p->J, Nla, Nspace);
+
+        auto& bg = rc->background;
+        bg.chi = F64View2D(const_cast<f64*>(p->bgChi), Nla, Nspace);
+        bg.eta = F64View2D(const_cast<f64*>(p->bgEta), Nla, Nspace);
+        bg.sca = F64View2D(const_cast<f64*>(p->bgSca), Nla, Nspace);
+
+        auto& dd = rc->depthData;
+        dd.fill = false;
+        if (p->storeDepthData && p->depthChi && p->depthEta && p->depthI)
+        {
+            dd.fill = true;
+            dd.chi = F64View4D(p->depthChi, Nla, Nrays, 2, Nspace);
+            dd.eta = F64View4D(p->depthEta, Nla, Nrays, 2, Nspace);
+            dd.I = F64View4D(p->depthI, Nla, Nrays, 2, Nspace);
+        }
+
+        auto& ctx = rc->ctx;
+        ctx.atmos = &rc->atmos;
+        ctx.spect = &rc->spect;
+        ctx.background = &rc->background;
+        ctx.depthData = &rc->depthData;
+        ctx.Nthreads = Nthreads;
+        ctx.methodScratch = nullptr;
+
+        // -- iteration scheme: built-in scalar or a plugin through the reference's own loader
+        if (schemeLib && schemeLib[0])
+        {
+            if (!rc->iterManager.load_fns_from_path(schemeLib))
+            {
+                set_error(err, errLen, std::string("load_fns_from_path failed for ") + schemeLib);
+                return nullptr;
+            }
+            ctx.iterFns = rc->iterManager.fns.back();
+        }
+        else
+        {
+            ctx.iterFns = rc->iterManager.fns[0];
+        }
+
+        const char* fsName = solver_name(p->formalSolver);
+        bool foundFs = false;
+        for (auto& fs : rc->fsManager.formalSolvers)
+        {
+            if (fsName && std::strcmp(fs.name, fsName) == 0)
+            {
+                ctx.formalSolver = fs;
+                foundFs = true;
+            }
+        }
+        if (!foundFs)
+        {
+            set_error(err, errLen, "unknown formal solver");
+            return nullptr;
+        }
+
+        for (int ia = 0; ia < p->Natom; ++ia)
+        {
+            const lwhip_atom& pa = p->atoms[ia];
+            auto atom = std::make_unique<Atom>();
+            atom->Nlevel = pa.Nlevel;
+            atom->Ntrans = pa.Ntrans;
+            atom->atmos = &rc->atmos;
+            atom->n = F64View2D(pa.n, pa.Nlevel, Nspace);
+            atom->nStar = F64View2D(const_cast<f64*>(pa.nStar), pa.Nlevel, Nspace);
+            atom->nTotal = F64View(const_cast<f64*>(pa.nTotal), Nspace);
+            atom->vBroad = F64View(const_cast<f64*>(pa.vBroad), Nspace);
+            atom->methodScratch = nullptr;
+            if (!pa.detailed)
+            {
+                atom->Gamma = F64View3D(pa.Gamma, pa.Nlevel, pa.Nlevel, Nspace);
+                if (pa.C)
+                    atom->C = F64View3D(const_cast<f64*>(pa.C), pa.Nlevel, pa.Nlevel, Nspace);
+            }
+            for (int kr = 0; kr < pa.Ntrans; ++kr)
+            {
+                const lwhip_transition& pt = pa.trans[kr];
+                auto t = std::make_unique<Transition>();
+                const int Nl = pt.Nred - pt.Nblue;
+                t->Nblue = pt.Nblue;
+                t->Nred = pt.Nred;
+                t->type = (pt.type == LWHIP_LINE) ? LINE : CONTINUUM;
+                t->i = pt.i;
+                t->j = pt.j;
+                t->Aji = pt.Aji;
+                t->Bji = pt.Bji;
+                t->Bij = pt.Bij;
+                t->lambda0 = pt.lambda0;
+                t->dopplerWidth = pt.dopplerWidth;
+                t->polarised = false;
+                t->methodScratch = nullptr;
+                t->wavelength = F64View(const_cast<f64*>(pt.wavelength), Nl);
+                if (pt.type == LWHIP_LINE)
+                {
+                    t->phi = F64View4D(pt.phi, Nl, Nrays, 2, Nspace);
+                    t->wphi = F64View(pt.wphi, Nspace);
+                    if (pt.aDamp)
+                        t->aDamp = F64View(const_cast<f64*>(pt.aDamp), Nspace);
+                    if (pt.prd && pt.rhoPrd)
+                        t->rhoPrd = F64View2D(pt.rhoPrd, Nl, Nspace);
+                }
+                else
+                {
+                    t->alpha = F64View(const_cast<f64*>(pt.alpha), Nl);
+                }
+                rc->activeMasks.emplace_back(Nla, (i8)0);
+                auto& mask = rc->activeMasks.back();
+                for (int la = pt.Nblue; la < pt.Nred; ++la)
+                    mask[la] = 1;
+                t->active = BoolView((bool*)mask.data(), Nla);
+                t->Rij = F64View(pt.Rij, Nspace);
+                t->Rji = F64View(pt.Rji, Nspace);
+                atom->trans.push_back(t.get());
+                rc->transitions.emplace_back(std::move(t));
+            }
+            atom->init_scratch(Nspace, (bool)pa.detailed,
+                               ctx.iterFns.defaultWlaGijStorage,
+                               ctx.iterFns.defaultPerAtomStorage);
+            if (pa.detailed)
+                ctx.detailedAtoms.push_back(atom.get());
+            else
+                ctx.activeAtoms.push_back(atom.get());
+            rc->atoms.emplace_back(std::move(atom));
+        }
+
+        ctx.initialise_threads();
+        rc->threadsInitialised = true;
+        return rc.release();
+    }
+    catch (const std::exception& e)
+    {
+        set_error(err, errLen, e.what());
+        return nullptr;
+    }
+}
+
+void lwref_destroy(void* h)
+{
+    delete (RefContext*)h;
+}
+
+int lwref_scheme_name(void* h, char* buf, int n)
+{
+    auto* rc = (RefContext*)h;
+    std::snprintf(buf, n, "%s", rc->ctx.iterFns.name);
+    return 0;
+}
+
+// refresh CALLABLE boundary data from the descriptor (LwAtmosphere.compute_bcs,
+// Source/LwMiddleLayer.pyx:762-829, copies into the core-owned bcData each iteration)
+static void refresh_bcs(RefContext* rc)
+{
+    const lwhip_problem* p = rc->prob;
+    if (p->zLowerBc.type == LWHIP_BC_CALLABLE && p->zLowerBc.bcData)
+    {
+        F64View3D data(const_cast<f64*>(p->zLowerBc.bcData), p->Nlambda, p->zLowerBc.Nmu, 1);
+        rc->atmos.zLowerBc.set_bc_data(data);
+    }
+    if (p->zUpperBc.type == LWHIP_BC_CALLABLE && p->zUpperBc.bcData)
+    {
+        F64View3D data(const_cast<f64*>(p->zUpperBc.bcData), p->Nlambda, p->zUpperBc.Nmu, 1);
+        rc->atmos.zUpperBc.set_bc_data(data);
+    }
+}
+
+int lwref_compute_profiles(void* h)
+{
+    auto* rc = (RefContext*)h;
+    try
+    {
+        for (auto& atom : rc->atoms)
+        {
+            for (auto* t : atom->trans)
+            {
+                if (t->type != LINE)
+                    continue;
+                t->compute_phi(rc->atmos, t->aDamp, atom->vBroad);
+                t->compute_wphi(rc->atmos);
+            }
+        }
+    }
+    catch (const std::exception& e)
+    {
+        return LWHIP_ERR_INVALID;
+    }
+    return LWHIP_OK;
+}
+
+int lwref_formal_sol_gamma_matrices(void* h, int lambdaIterate, lwhip_iter_result* res)
+{
+    auto* rc = (RefContext*)h;
+    try
+    {
+        refresh_bcs(rc);
+        IterationResult r = formal_sol_gamma_matrices(rc->ctx, (bool)lambdaIterate);
+        if (res)
+        {
+            res->updatedJ = r.updatedJ;
+            res->dJMax = r.dJMax;
+            res->dJMaxIdx = r.dJMaxIdx;
+        }
+    }
+    catch (const std::exception& e)
+    {
+        std::fprintf(stderr, "lwref: %s\n", e.what());
+        return LWHIP_ERR_INVALID;
+    }
+    return LWHIP_OK;
+}
+
+int lwref_formal_sol(void* h, int upOnly)
+{
+    auto* rc = (RefContext*)h;
+    try
+    {
+        refresh_bcs(rc);
+        formal_sol(rc->ctx, (bool)upOnly);
+    }
+    catch (const std::exception& e)
+    {
+        std::fprintf(stderr, "lwref: %s\n", e.what());
+        return LWHIP_ERR_INVALID;
+    }
+    return LWHIP_OK;
+}
+
+int lwref_stat_equil(void* h, int atomIdx)
+{
+    auto* rc = (RefContext*)h;
+    try
+    {
+        for (int ia = 0; ia < (int)rc->atoms.size(); ++ia)
+        {
+            if (atomIdx >= 0 && ia != atomIdx)
+                continue;
+            if (rc->prob->atoms[ia].detailed)
+                continue;
+            stat_eq(rc->ctx, rc->atoms[ia].get());
+        }
+    }
+    catch (const std::runtime_error& e)
+    {
+        return LWHIP_ERR_SINGULAR;
+    }
+    return LWHIP_OK;
+}
+
+// ---- leaf known-answer hooks (pin the restatement function by function) ---------------------
+
+void lwref_w2(double dtau, double* w)
+{
+    LwInternal::w2(dtau, w);
+}
+
+void lwref_bezier3_coeffs(double dt, double* out)
+{
+    Bezier::Bezier3_coeffs(dt, &out[0], &out[1], &out[2], &out[3], &out[4]);
+}
+
+double lwref_cent_deriv(double dsuw, double dsdw, double yuw, double y0, double ydw)
+{
+    return Bezier::cent_deriv(dsuw, dsdw, yuw, y0, ydw);
+}
+
+double lwref_voigt_H(double a, double v)
+{
+    return voigt_H(a, v);
+}
+
+void lwref_planck_nu(int n, double* T, double lambda, double* Bnu)
+{
+    planck_nu(n, T, lambda, Bnu);
+}
+
+int lwref_solve_lin_eq(int N, double* A, double* b, int improve)
+{
+    try
+    {
+        solve_lin_eq(F64View2D(A, N, N), F64View(b, N), (bool)improve);
+    }
+    catch (const std::runtime_error& e)
+    {
+        return LWHIP_ERR_SINGULAR;
+    }
+    return LWHIP_OK;
+}
+
+// single-ray formal solve with the reference's own solver on caller-provided chi, S
+// (kernel-level parity for the depth sweep). Psi may be NULL.
+int lwref_formal_solver_ray(void* h, int la, int mu, int toObs,
+                            double* chi, double* S, double* I, double* Psi)
+{
+    auto* rc = (RefContext*)h;
+    LwInternal::FormalData fd;
+    const int Nspace = rc->atmos.Nspace;
+    fd.atmos = &rc->atmos;
+    fd.chi = F64View(chi, Nspace);
+    fd.S = F64View(S, Nspace);
+    fd.I = F64View(I, Nspace);
+    if (Psi)
+        fd.Psi = F64View(Psi, Nspace);
+    refresh_bcs(rc);
+    rc->ctx.formalSolver.solver(&fd, la, mu, (bool)toObs, rc->spect.wavelength);
+    return LWHIP_OK;
+}
+}
