@@ -1,0 +1,82 @@
+"""Build helpers: compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    python -m lightweaver_amd.build          # liblwhip.so (+ plugin when the Lightweaver headers exist)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+LIB = os.path.join(PKG, 'liblwhip.so')
+PLUGIN = os.path.join(PKG, 'LwHipIterScheme.so')
+REF_SRC = os.environ.get('LW_REFERENCE_SOURCE', '/root/reference/Source')
+
+HIP_SOURCES = ['lwhip_api.hip', 'lwhip_kernels.hip', 'lwhip_voigt.hip']
+HIP_HEADERS = ['lwhip_internal.h', os.path.join('..', '..', 'include', 'lwhip.h')]
+
+
+def _hipcc():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found: the HIP library cannot be built')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> lightweaver_amd/liblwhip.so"""
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HIP_HEADERS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-o', LIB] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+def build_plugin(force=False, verbose=False):
+    """The Lightweaver iteration-scheme plugin (fs_iteration_fns_provider).  It is compiled against
+    the Lightweaver headers, so it is only (re)built where they are present; elsewhere a prebuilt
+    copy (it travels with the tree) is used as is."""
+    src = os.path.join(CSRC, 'plugin', 'lwhip_plugin.cpp')
+    if not os.path.exists(src) or not os.path.exists(os.path.join(REF_SRC, 'Lightweaver.hpp')):
+        return PLUGIN if os.path.exists(PLUGIN) else None
+    deps = [src, os.path.join(ROOT, 'include', 'lwhip.h')]
+    if not force and not _stale(PLUGIN, deps):
+        return PLUGIN
+    cmd = ['g++', '-std=c++17', '-O2', '-fPIC', '-shared', '-Wno-sign-compare',
+           '-DENKITS_BUILD_DLL', f'-I{REF_SRC}', f'-I{os.path.join(ROOT, "include")}',
+           '-o', PLUGIN, src, os.path.join(REF_SRC, 'LightweaverAmalgamated.cpp'),
+           os.path.join(REF_SRC, 'TaskScheduler.cpp'),
+           '-ldl', '-lpthread', '-Wl,-Bsymbolic', '-Wl,-rpath,$ORIGIN']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return PLUGIN
+
+
+def build_oracle(verbose=False):
+    """TEST INFRASTRUCTURE: oracle/liblworacle.so and, where /root/reference exists, oracle/_ref."""
+    subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle'), 'all'], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force=force, verbose=verbose)
+    build_plugin(force=force, verbose=verbose)
+
+
+if __name__ == '__main__':
+    build_all(force='--force' in sys.argv, verbose=True)

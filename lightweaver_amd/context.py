@@ -1,0 +1,204 @@
+"""Python host mirror of the reference's `LwContext` entry points for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow Source/LwMiddleLayer.pyx:
+    Context.formal_sol_gamma_matrices  <- LwContext.formal_sol_gamma_matrices  (:3152-3210)
+    Context.formal_sol                 <- LwContext.formal_sol                  (:3212-3242)
+    Context.stat_equil                 <- LwContext.stat_equil                  (:3461-3531)
+    ExplodingMatrixError               <- lightweaver.utils.ExplodingMatrixError (raised :3509-3514)
+
+The HIP library is mandatory: if it cannot be loaded, or no gfx950 device is visible, construction
+raises -- there is no CPU path behind this class.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+from . import _abi as abi
+from .model import Problem
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'liblwhip.so')
+_lib = None
+
+
+class LwHipError(RuntimeError):
+    pass
+
+
+class ExplodingMatrixError(Exception):
+    """Singular Gamma in stat_equil (lightweaver.utils.ExplodingMatrixError)."""
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen liblwhip.so and bind every symbol include/lwhip.h declares."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise LwHipError(f'{path} is missing: build it with `python -m lightweaver_amd.build` '
+                         '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    lib = abi.bind(C.CDLL(path))
+    if lib.lwhip_abi_version() != abi.ABI_VERSION:
+        raise LwHipError('liblwhip.so ABI version does not match lightweaver_amd/_abi.py')
+    _lib = lib
+    return lib
+
+
+def _check(lib, st, what):
+    if st == abi.OK:
+        return
+    msg = lib.lwhip_last_error().decode(errors='replace')
+    if st == abi.ERR_SINGULAR:
+        raise ExplodingMatrixError(msg or 'Singular Matrix')
+    raise LwHipError(f'{what} failed ({st}): {msg}')
+
+
+@dataclass
+class IterationUpdate:
+    """The members of lightweaver.iteration_update.IterationUpdate this path fills."""
+    updatedJ: bool = False
+    dJMax: float = 0.0
+    dJMaxIdx: int = 0
+    crsw: float = 1.0
+    updatedPops: bool = False
+
+
+class Context:
+    """Device-resident context for one `Problem` (optionally one wavelength shard of it)."""
+
+    def __init__(self, prob: Problem, device: int = 0, laStart: int = 0, laEnd: int = 0,
+                 stream: Optional[int] = None, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        self.prob = prob
+        self._desc = prob.descriptor()
+        opts = abi.lwhip_options()
+        opts.device = device
+        opts.laStart, opts.laEnd = laStart, laEnd
+        opts.stream = stream
+        h = C.c_void_p()
+        st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
+        _check(self.lib, st, 'lwhip_create')
+        self._h = h
+        self.laStart = laStart
+        self.laEnd = laEnd if laEnd else prob.Nlambda
+        self.crsw = 1.0
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.lwhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- data movement ------------------------------------------------------------------------------
+    def upload(self, mask=abi.ALL_INPUTS):
+        _check(self.lib, self.lib.lwhip_upload(self._h, mask), 'lwhip_upload')
+
+    def download(self, mask=abi.ALL_OUTPUTS):
+        _check(self.lib, self.lib.lwhip_download(self._h, mask), 'lwhip_download')
+
+    def synchronize(self):
+        _check(self.lib, self.lib.lwhip_synchronize(self._h), 'lwhip_synchronize')
+
+    def set_stream(self, stream: Optional[int]):
+        _check(self.lib, self.lib.lwhip_set_stream(self._h, stream), 'lwhip_set_stream')
+
+    # -- the hot path ---------------------------------------------------------------------------------
+    def formal_sol_gamma_matrices(self, fixCollisionalRates=True, lambdaIterate=False,
+                                  sync_host=True, deviceResident=False) -> IterationUpdate:
+        """One iteration.  Default (drop-in) mode mirrors the reference exactly: the host arrays
+        are authoritative -- Gamma is pre-filled with crsw*C on the host, inputs are uploaded, the
+        kernels run, outputs are downloaded.  With deviceResident=True nothing crosses PCIe: the
+        pre-fill happens on the device from the resident C and results stay in HBM (call
+        `download()` when the host needs them).  Collisional rates are an input here
+        (`fixCollisionalRates` is accepted for signature parity; the harness never recomputes C)."""
+        lib = self.lib
+        if deviceResident:
+            _check(lib, lib.lwhip_gamma_prefill_from_C(self._h, self.crsw), 'lwhip_gamma_prefill_from_C')
+        else:
+            self.prob.gamma_prefill(self.crsw)
+            self.upload(abi.GAMMA | abi.J | abi.POPS | abi.BC | abi.RHOPRD)
+        res = abi.lwhip_iter_result()
+        st = lib.lwhip_formal_sol_gamma_matrices(self._h, int(lambdaIterate),
+                                                 C.byref(res) if sync_host else None)
+        _check(lib, st, 'lwhip_formal_sol_gamma_matrices')
+        if not deviceResident:
+            self.download(abi.ALL_OUTPUTS | (abi.DEPTHDATA if self.prob.storeDepthData else 0))
+        return IterationUpdate(updatedJ=True, dJMax=res.dJMax, dJMaxIdx=res.dJMaxIdx, crsw=self.crsw)
+
+    def formal_sol(self, upOnly=True, deviceResident=False):
+        if not deviceResident:
+            self.upload(abi.J | abi.POPS | abi.BC | abi.RHOPRD)
+        _check(self.lib, self.lib.lwhip_formal_sol(self._h, int(upOnly)), 'lwhip_formal_sol')
+        if not deviceResident:
+            self.download(abi.I)
+
+    def stat_equil(self, deviceResident=False, atom=-1):
+        """Statistical equilibrium for every active atom; raises ExplodingMatrixError on a
+        singular matrix as the reference does."""
+        if not deviceResident:
+            self.upload(abi.GAMMA | abi.POPS)
+        _check(self.lib, self.lib.lwhip_stat_equil(self._h, atom), 'lwhip_stat_equil')
+        if not deviceResident:
+            self.download(abi.POPS)
+        return IterationUpdate(updatedPops=True)
+
+    def compute_profiles(self, deviceResident=False):
+        _check(self.lib, self.lib.lwhip_compute_profiles(self._h), 'lwhip_compute_profiles')
+        if not deviceResident:
+            self.download(abi.PROFILES)
+
+    # -- multi-GPU split ----------------------------------------------------------------------------------
+    def fs_partial(self, lambdaIterate=False):
+        _check(self.lib, self.lib.lwhip_fs_partial(self._h, int(lambdaIterate)), 'lwhip_fs_partial')
+
+    def fs_finalise(self) -> IterationUpdate:
+        res = abi.lwhip_iter_result()
+        _check(self.lib, self.lib.lwhip_fs_finalise(self._h, C.byref(res)), 'lwhip_fs_finalise')
+        return IterationUpdate(updatedJ=True, dJMax=res.dJMax, dJMaxIdx=res.dJMaxIdx, crsw=self.crsw)
+
+    def gamma_prefill_from_C(self, crsw=1.0):
+        _check(self.lib, self.lib.lwhip_gamma_prefill_from_C(self._h, crsw), 'lwhip_gamma_prefill_from_C')
+
+    def reduce_buffer(self):
+        """(device pointer, number of doubles to sum-reduce) of the Gamma/R partial sums."""
+        ptr = C.c_void_p()
+        nsum = C.c_size_t()
+        nmax = C.c_size_t()
+        _check(self.lib, self.lib.lwhip_reduce_buffer(self._h, C.byref(ptr), C.byref(nsum),
+                                                      C.byref(nmax)), 'lwhip_reduce_buffer')
+        return ptr.value, nsum.value
+
+    # -- measurement -----------------------------------------------------------------------------------------
+    def profile_enable(self, enable=True):
+        _check(self.lib, self.lib.lwhip_profile_enable(self._h, int(enable)), 'lwhip_profile_enable')
+
+    def sweep_time(self):
+        ms = C.c_double()
+        n = C.c_int()
+        _check(self.lib, self.lib.lwhip_sweep_time(self._h, C.byref(ms), C.byref(n)), 'lwhip_sweep_time')
+        return ms.value, n.value
+
+    def algorithmic_bytes(self):
+        b = C.c_double()
+        _check(self.lib, self.lib.lwhip_algorithmic_bytes(self._h, C.byref(b)), 'lwhip_algorithmic_bytes')
+        return b.value
+
+
+def device_count():
+    return load_library().lwhip_device_count()

@@ -1,0 +1,1120 @@
+// lwhip_api.hip -- host side of the C ABI declared in include/lwhip.h.
+//
+// Owns the HBM-resident copy of the problem, the per-wavelength activity tables the sweep kernel
+// walks, and the launch sequence of one iteration:
+//
+//     memset dJ -> sweep_kernel (per-chunk partial slabs) -> reduce_kernel (fixed-order slab sum)
+//     [-> caller all-reduces the reduce buffer across GPUs] -> apply_kernel -> djmax_kernel
+//
+// There is no CPU fallback: without a HIP device every compute entry point fails with
+// LWHIP_ERR_DEVICE.
+#include "lwhip_internal.h"
+#include "../../include/lwhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lwhip;
+
+namespace
+{
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do                                                                                                 \
+    {                                                                                                  \
+        hipError_t err__ = (expr);                                                                     \
+        if (err__ != hipSuccess)                                                                       \
+            return fail(LWHIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(err__));       \
+    } while (0)
+
+template <typename T> struct DevBuf
+{
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0)
+            return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty())
+            return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct HostTrans
+{
+    lwhip_transition t;   // borrowed host pointers
+    int atom;
+    int NblueLoc, NredLoc; // clipped to the shard, shard-local indices
+    int ltStart;           // first own-grid index inside the shard
+    int row;               // wphi row (lines) / ratio row (continua)
+    int64_t parOff, phiOff, rhoOff;
+};
+}
+
+struct lwhip_context
+{
+    lwhip_problem prob;             // copy of the descriptor (host pointers borrowed)
+    std::vector<lwhip_atom> atoms;
+    std::vector<HostTrans> trans;   // global transition list, reference order
+    std::vector<int> levelOff, atomTrOff;
+    std::vector<int64_t> gammaOff;
+    int device = 0;
+    int laStart = 0, laEnd = 0, Nla = 0;
+    int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
+    int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, G = 1, P = 8;
+    int64_t gammaTot = 0, phiTot = 0, rhoTot = 0, parTot = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+
+    DevBuf<double> height, temperature, muz, wmu, wavelength, lowerBcData, upperBcData;
+    DevBuf<int32_t> rayAll, rayUp, lowerIdx, upperIdx;
+    DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
+    DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
+    DevBuf<DevTrans> dtrans;
+    DevBuf<DevLaHeader> laHdr;
+    DevBuf<DevLaEntry> laEnt;
+    DevBuf<int32_t> chunkLa, trOff, trRow, atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
+    DevBuf<int64_t> atomGammaOff;
+    DevBuf<double> partial, red, dJ, out2;
+    DevBuf<int32_t> status;
+
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double sweepMs = 0.0;
+    int sweepCount = 0;
+    bool partialPending = false;
+
+    ~lwhip_context()
+    {
+        for (auto& pr : pending)
+        {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        if (ownStream)
+            (void)hipStreamDestroy(ownStream);
+    }
+};
+
+namespace
+{
+int env_int(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v)
+        return dflt;
+    return std::atoi(v);
+}
+
+double trans_wlambda(const lwhip_transition& t, int lt)
+{
+    // Transition::wlambda, LwTransition.hpp:71-81
+    const int len = t.Nred - t.Nblue;
+    if (lt == 0)
+        return 0.5 * (t.wavelength[1] - t.wavelength[0]) * t.dopplerWidth;
+    if (lt == len - 1)
+        return 0.5 * (t.wavelength[len - 1] - t.wavelength[len - 2]) * t.dopplerWidth;
+    return 0.5 * (t.wavelength[lt + 1] - t.wavelength[lt - 1]) * t.dopplerWidth;
+}
+
+int validate(const lwhip_problem* p, std::string& why)
+{
+    if (!p)
+    {
+        why = "null problem";
+        return LWHIP_ERR_INVALID;
+    }
+    if (p->abiVersion != LWHIP_ABI_VERSION)
+    {
+        why = "ABI version mismatch";
+        return LWHIP_ERR_INVALID;
+    }
+    if (p->Nspace < 3 || p->Nrays < 1 || p->Nlambda < 1 || p->Natom < 0)
+    {
+        why = "need Nspace >= 3, Nrays >= 1, Nlambda >= 1";
+        return LWHIP_ERR_INVALID;
+    }
+    if (p->Nspace > 1024)
+    {
+        why = "Nspace > 1024 is not supported by the 1D sweep kernel";
+        return LWHIP_ERR_UNSUPPORTED;
+    }
+    if (p->formalSolver < LWHIP_FS_LINEAR_1D || p->formalSolver > LWHIP_FS_BEZIER3_1D)
+    {
+        why = "unknown formal solver";
+        return LWHIP_ERR_INVALID;
+    }
+    if (!p->height || !p->temperature || !p->muz || !p->wmu || !p->wavelength || !p->bgChi
+        || !p->bgEta || !p->bgSca || !p->J || !p->I)
+    {
+        why = "null atmosphere / spectrum / background array";
+        return LWHIP_ERR_INVALID;
+    }
+    if (p->storeDepthData && (!p->depthChi || !p->depthEta || !p->depthI))
+    {
+        why = "storeDepthData set but depth arrays are null";
+        return LWHIP_ERR_INVALID;
+    }
+    const lwhip_boundary* bcs[2] = { &p->zLowerBc, &p->zUpperBc };
+    for (auto* b : bcs)
+    {
+        if (b->type == LWHIP_BC_CALLABLE && (!b->idxs || !b->bcData || b->Nmu < 1))
+        {
+            why = "CALLABLE boundary needs idxs, bcData, Nmu";
+            return LWHIP_ERR_INVALID;
+        }
+    }
+    bool seenDetailed = false;
+    for (int ia = 0; ia < p->Natom; ++ia)
+    {
+        const lwhip_atom& a = p->atoms[ia];
+        if (a.Nlevel < 1 || a.Nlevel > 32 || a.Ntrans < 0)
+        {
+            why = "atom needs 1 <= Nlevel <= 32";
+            return a.Nlevel > 32 ? LWHIP_ERR_UNSUPPORTED : LWHIP_ERR_INVALID;
+        }
+        if (a.detailed)
+            seenDetailed = true;
+        else if (seenDetailed)
+        {
+            why = "active atoms must precede detailed atoms";
+            return LWHIP_ERR_INVALID;
+        }
+        if (!a.n || !a.nStar || !a.nTotal || !a.vBroad || (!a.detailed && !a.Gamma))
+        {
+            why = "null atom array";
+            return LWHIP_ERR_INVALID;
+        }
+        for (int kr = 0; kr < a.Ntrans; ++kr)
+        {
+            const lwhip_transition& t = a.trans[kr];
+            if (t.i < 0 || t.j < 0 || t.i >= a.Nlevel || t.j >= a.Nlevel || t.i == t.j)
+            {
+                why = "bad transition levels";
+                return LWHIP_ERR_INVALID;
+            }
+            if (t.Nblue < 0 || t.Nred > p->Nlambda || t.Nred - t.Nblue < 2)
+            {
+                why = "bad transition wavelength range (need >= 2 points inside the grid)";
+                return LWHIP_ERR_INVALID;
+            }
+            if (!t.wavelength || !t.Rij || !t.Rji)
+            {
+                why = "null transition array";
+                return LWHIP_ERR_INVALID;
+            }
+            if (t.type == LWHIP_LINE)
+            {
+                if (!t.phi || !t.wphi)
+                {
+                    why = "line without phi/wphi";
+                    return LWHIP_ERR_INVALID;
+                }
+                if (t.prd && !t.rhoPrd)
+                {
+                    why = "prd line without rhoPrd";
+                    return LWHIP_ERR_INVALID;
+                }
+            }
+            else if (t.type == LWHIP_CONTINUUM)
+            {
+                if (!t.alpha)
+                {
+                    why = "continuum without alpha";
+                    return LWHIP_ERR_INVALID;
+                }
+            }
+            else
+            {
+                why = "unknown transition type";
+                return LWHIP_ERR_INVALID;
+            }
+        }
+    }
+    return LWHIP_OK;
+}
+
+int build_tables(lwhip_context* c)
+{
+    const lwhip_problem& p = c->prob;
+    const int Ns = c->Ns;
+    // ---- global transition list, level rows, pools ------------------------------------------
+    c->levelOff.assign(c->Natom + 1, 0);
+    c->atomTrOff.assign(c->Natom + 1, 0);
+    c->gammaOff.assign(c->Natom, 0);
+    c->gammaTot = 0;
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        const lwhip_atom& a = c->atoms[ia];
+        c->levelOff[ia + 1] = c->levelOff[ia] + a.Nlevel;
+        c->atomTrOff[ia + 1] = c->atomTrOff[ia] + a.Ntrans;
+        c->gammaOff[ia] = c->gammaTot;
+        if (!a.detailed)
+            c->gammaTot += (int64_t)a.Nlevel * a.Nlevel * Ns;
+    }
+    c->NlevTot = c->levelOff[c->Natom];
+    c->Ntrans = c->atomTrOff[c->Natom];
+    c->trans.clear();
+    c->Nline = c->Ncont = 0;
+    c->phiTot = c->rhoTot = c->parTot = 0;
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        const lwhip_atom& a = c->atoms[ia];
+        for (int kr = 0; kr < a.Ntrans; ++kr)
+        {
+            HostTrans h;
+            h.t = a.trans[kr];
+            h.atom = ia;
+            const int b = std::max(h.t.Nblue, c->laStart);
+            const int r = std::min(h.t.Nred, c->laEnd);
+            if (r > b)
+            {
+                h.NblueLoc = b - c->laStart;
+                h.NredLoc = r - c->laStart;
+                h.ltStart = b - h.t.Nblue;
+            }
+            else
+            {
+                h.NblueLoc = h.NredLoc = 0;
+                h.ltStart = 0;
+            }
+            const int64_t nlt = h.NredLoc - h.NblueLoc;
+            h.parOff = c->parTot;
+            c->parTot += 4 * nlt;
+            h.phiOff = h.rhoOff = -1;
+            if (h.t.type == LWHIP_LINE)
+            {
+                h.row = c->Nline++;
+                h.phiOff = c->phiTot;
+                c->phiTot += nlt * c->Nrays * 2 * Ns;
+                if (h.t.prd)
+                {
+                    h.rhoOff = c->rhoTot;
+                    c->rhoTot += nlt * Ns;
+                }
+            }
+            else
+            {
+                h.row = c->Ncont++;
+            }
+            c->trans.push_back(h);
+        }
+    }
+
+    // ---- per-(transition, lt) params -----------------------------------------------------------
+    std::vector<double> par((size_t)c->parTot, 0.0);
+    for (auto& h : c->trans)
+    {
+        const lwhip_transition& t = h.t;
+        for (int l = 0; l < h.NredLoc - h.NblueLoc; ++l)
+        {
+            const int lt = h.ltStart + l;
+            double* q = &par[(size_t)h.parOff + 4 * l];
+            const double wlambda = trans_wlambda(t, lt);
+            if (t.type == LWHIP_LINE)
+            {
+                const double hnu_4pi = HC_4PI * (t.lambda0 / t.wavelength[lt]);
+                q[0] = hnu_4pi * t.Bij;
+                q[1] = wlambda;
+                q[2] = t.Bji / t.Bij;
+                q[3] = t.Aji / t.Bji;
+            }
+            else
+            {
+                const double wl = t.wavelength[lt];
+                q[0] = t.alpha[lt];
+                q[1] = (wlambda / wl) * PI4_H;
+                q[2] = TWO_HC_NM3 / (wl * wl * wl);
+                q[3] = 0.0;
+            }
+        }
+    }
+
+    // ---- per-wavelength activity (lines first, then continua; reference order inside each) -------
+    std::vector<DevLaHeader> hdr(c->Nla);
+    std::vector<DevLaEntry> ent;
+    c->maxL = c->maxC = 0;
+    for (int la = 0; la < c->Nla; ++la)
+    {
+        hdr[la].off = (int32_t)ent.size();
+        int nl = 0, nc = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int tr = 0; tr < c->Ntrans; ++tr)
+            {
+                const HostTrans& h = c->trans[tr];
+                if (la < h.NblueLoc || la >= h.NredLoc)
+                    continue;
+                const bool isLine = h.t.type == LWHIP_LINE;
+                if ((pass == 0) != isLine)
+                    continue;
+                ent.push_back(DevLaEntry{ tr, 0 });
+                (isLine ? nl : nc)++;
+            }
+        hdr[la].nLine = (int16_t)nl;
+        hdr[la].nCont = (int16_t)nc;
+        c->maxL = std::max(c->maxL, nl);
+        c->maxC = std::max(c->maxC, nc);
+    }
+    if (c->maxL > 8)
+        return fail(LWHIP_ERR_UNSUPPORTED, "more than 8 lines overlap at one wavelength");
+    if (c->maxC < 1)
+        c->maxC = 1;
+
+    // ---- chunks of wavelengths (one workgroup each), balanced by a simple cost model --------------
+    int numCU = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+        numCU = prop.multiProcessorCount;
+    int target = env_int("LWHIP_CHUNKS", numCU * 2);
+    target = std::max(1, std::min(target, c->Nla));
+    std::vector<double> cost(c->Nla);
+    double total = 0.0;
+    for (int la = 0; la < c->Nla; ++la)
+    {
+        cost[la] = 1.0 + 0.35 * hdr[la].nLine + 0.12 * hdr[la].nCont;
+        total += cost[la];
+    }
+    std::vector<int32_t> chunkLa;
+    chunkLa.push_back(0);
+    {
+        double acc = 0.0;
+        int made = 0;
+        for (int la = 0; la < c->Nla; ++la)
+        {
+            acc += cost[la];
+            const int remainingLa = c->Nla - (la + 1);
+            const int remainingChunks = target - (made + 1);
+            if ((acc >= total * (made + 1) / target || remainingLa <= remainingChunks) && la + 1 < c->Nla
+                && made + 1 < target)
+            {
+                chunkLa.push_back(la + 1);
+                made++;
+            }
+        }
+        chunkLa.push_back(c->Nla);
+    }
+    c->nChunks = (int)chunkLa.size() - 1;
+
+    // accumulator slots per chunk
+    std::vector<std::vector<int>> chunkTrans(c->nChunks);
+    c->maxCT = 1;
+    for (int ch = 0; ch < c->nChunks; ++ch)
+    {
+        std::vector<int> slotOf(c->Ntrans, -1);
+        for (int la = chunkLa[ch]; la < chunkLa[ch + 1]; ++la)
+        {
+            const int n = hdr[la].nLine + hdr[la].nCont;
+            for (int e = 0; e < n; ++e)
+            {
+                DevLaEntry& en = ent[hdr[la].off + e];
+                if (slotOf[en.tr] < 0)
+                {
+                    slotOf[en.tr] = (int)chunkTrans[ch].size();
+                    chunkTrans[ch].push_back(en.tr);
+                }
+                en.cs = slotOf[en.tr];
+            }
+        }
+        c->maxCT = std::max(c->maxCT, (int)chunkTrans[ch].size());
+    }
+    std::vector<int32_t> trOff(c->Ntrans + 1, 0), trRow;
+    for (int tr = 0; tr < c->Ntrans; ++tr)
+    {
+        trOff[tr] = (int32_t)trRow.size();
+        for (int ch = 0; ch < c->nChunks; ++ch)
+            for (int s = 0; s < (int)chunkTrans[ch].size(); ++s)
+                if (chunkTrans[ch][s] == tr)
+                    trRow.push_back(ch * c->maxCT + s);
+    }
+    trOff[c->Ntrans] = (int32_t)trRow.size();
+
+    // ---- rays per pass / scan lanes ------------------------------------------------------------------
+    const int NR2 = 2 * c->Nrays;
+    int G = std::min(NR2, 1024 / Ns);
+    G = std::max(G, 1);
+    const int Genv = env_int("LWHIP_G", 0);
+    if (Genv > 0)
+        G = std::max(1, std::min(Genv, G));
+    c->P = std::max(1, env_int("LWHIP_P", 8));
+    size_t ldsMax = 160 * 1024;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor > 0)
+        ldsMax = prop.maxSharedMemoryPerMultiProcessor;
+    auto ldsFor = [&](int g) {
+        SweepArgs s{};
+        s.Ns = Ns;
+        s.G = g;
+        s.P = c->P;
+        s.Natom = c->Natom;
+        s.NlevTot = c->NlevTot;
+        s.maxC = c->maxC;
+        s.maxCT = c->maxCT;
+        return sweep_lds_bytes(s);
+    };
+    while (G > 1 && ldsFor(G) > ldsMax)
+        --G;
+    if (ldsFor(G) > ldsMax)
+        return fail(LWHIP_ERR_UNSUPPORTED, "problem does not fit the 160 KB LDS budget of one workgroup");
+    c->G = G;
+
+    // ---- device tables ---------------------------------------------------------------------------------
+    std::vector<DevTrans> dt(c->Ntrans);
+    std::vector<int32_t> li(c->Ntrans), lj(c->Ntrans);
+    for (int tr = 0; tr < c->Ntrans; ++tr)
+    {
+        const HostTrans& h = c->trans[tr];
+        DevTrans& d = dt[tr];
+        d.type = h.t.type;
+        d.atom = h.atom;
+        d.gi = c->levelOff[h.atom] + h.t.i;
+        d.gj = c->levelOff[h.atom] + h.t.j;
+        d.Nblue = h.NblueLoc;
+        d.Nred = h.NredLoc;
+        d.prd = (h.t.type == LWHIP_LINE && h.t.prd) ? 1 : 0;
+        d.op = c->atoms[h.atom].detailed ? 0 : 1;
+        d.row = h.row;
+        d._pad = 0;
+        d.parOff = h.parOff;
+        d.phiOff = h.phiOff;
+        d.rhoOff = h.rhoOff;
+        li[tr] = h.t.i;
+        lj[tr] = h.t.j;
+    }
+    std::vector<int32_t> rayAll(NR2), rayUp(c->Nrays);
+    for (int r = 0; r < NR2; ++r)
+        rayAll[r] = r;
+    for (int m = 0; m < c->Nrays; ++m)
+        rayUp[m] = 2 * m + 1;
+    std::vector<int32_t> aNl(c->Natom), aDet(c->Natom);
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        aNl[ia] = c->atoms[ia].Nlevel;
+        aDet[ia] = c->atoms[ia].detailed ? 1 : 0;
+    }
+    std::vector<int32_t> atomTrOff32(c->atomTrOff.begin(), c->atomTrOff.end());
+
+    HIP_TRY(c->par.upload(par));
+    HIP_TRY(c->dtrans.upload(dt));
+    HIP_TRY(c->laHdr.upload(hdr));
+    HIP_TRY(c->laEnt.upload(ent));
+    HIP_TRY(c->chunkLa.upload(chunkLa));
+    HIP_TRY(c->trOff.upload(trOff));
+    HIP_TRY(c->trRow.upload(trRow));
+    HIP_TRY(c->rayAll.upload(rayAll));
+    HIP_TRY(c->rayUp.upload(rayUp));
+    HIP_TRY(c->transLi.upload(li));
+    HIP_TRY(c->transLj.upload(lj));
+    HIP_TRY(c->atomNlevel.upload(aNl));
+    HIP_TRY(c->atomDetailed.upload(aDet));
+    HIP_TRY(c->atomTrOffD.upload(atomTrOff32));
+    HIP_TRY(c->atomGammaOff.upload(c->gammaOff));
+    return LWHIP_OK;
+}
+
+int alloc_state(lwhip_context* c)
+{
+    const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
+    HIP_TRY(c->height.alloc(Ns));
+    HIP_TRY(c->temperature.alloc(Ns));
+    HIP_TRY(c->muz.alloc(Nr));
+    HIP_TRY(c->wmu.alloc(Nr));
+    HIP_TRY(c->wavelength.alloc(Nla));
+    HIP_TRY(c->bgChi.alloc(Nla * Ns));
+    HIP_TRY(c->bgEta.alloc(Nla * Ns));
+    HIP_TRY(c->bgSca.alloc(Nla * Ns));
+    HIP_TRY(c->J.alloc(Nla * Ns));
+    HIP_TRY(c->I.alloc(Nla * Nr));
+    if (c->prob.storeDepthData)
+    {
+        HIP_TRY(c->depthChi.alloc(Nla * Nr * 2 * Ns));
+        HIP_TRY(c->depthEta.alloc(Nla * Nr * 2 * Ns));
+        HIP_TRY(c->depthI.alloc(Nla * Nr * 2 * Ns));
+    }
+    HIP_TRY(c->n.alloc((size_t)c->NlevTot * Ns));
+    HIP_TRY(c->nTotal.alloc((size_t)c->Natom * Ns));
+    HIP_TRY(c->ratio.alloc((size_t)std::max(c->Ncont, 1) * Ns));
+    HIP_TRY(c->wphi.alloc((size_t)std::max(c->Nline, 1) * Ns));
+    HIP_TRY(c->phi.alloc((size_t)std::max<int64_t>(c->phiTot, 1)));
+    HIP_TRY(c->rho.alloc((size_t)std::max<int64_t>(c->rhoTot, 1)));
+    HIP_TRY(c->Gamma.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
+    HIP_TRY(c->Cmat.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
+    HIP_TRY(hipMemset(c->Cmat.p, 0, c->Cmat.n * sizeof(double)));
+    HIP_TRY(c->Rij.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
+    HIP_TRY(c->Rji.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
+    HIP_TRY(c->partial.alloc((size_t)c->nChunks * c->maxCT * 4 * Ns));
+    HIP_TRY(c->red.alloc((size_t)std::max(c->Ntrans, 1) * 4 * Ns));
+    HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
+    HIP_TRY(c->dJ.alloc(Nla));
+    HIP_TRY(c->out2.alloc(2));
+    HIP_TRY(c->status.alloc(1));
+    if (c->prob.zLowerBc.type == LWHIP_BC_CALLABLE)
+    {
+        HIP_TRY(c->lowerBcData.alloc(Nla * c->prob.zLowerBc.Nmu));
+        HIP_TRY(c->lowerIdx.alloc(Nr * 2));
+    }
+    if (c->prob.zUpperBc.type == LWHIP_BC_CALLABLE)
+    {
+        HIP_TRY(c->upperBcData.alloc(Nla * c->prob.zUpperBc.Nmu));
+        HIP_TRY(c->upperIdx.alloc(Nr * 2));
+    }
+    return LWHIP_OK;
+}
+
+#define H2D(dst, src, count)                                                                           \
+    HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyHostToDevice, c->stream))
+#define D2H(dst, src, count)                                                                           \
+    HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyDeviceToHost, c->stream))
+
+SweepArgs make_sweep_args(lwhip_context* c, bool upOnly, int lambdaIterate)
+{
+    SweepArgs a{};
+    a.Ns = c->Ns;
+    a.Nrays = c->Nrays;
+    a.Nla = c->Nla;
+    a.Natom = c->Natom;
+    a.NlevTot = c->NlevTot;
+    a.Ntrans = c->Ntrans;
+    a.nRaysActive = upOnly ? c->Nrays : 2 * c->Nrays;
+    a.G = std::min(c->G, a.nRaysActive);
+    a.P = c->P;
+    a.maxC = c->maxC;
+    a.maxCT = c->maxCT;
+    a.lambdaIterate = lambdaIterate;
+    a.lowerBc = c->prob.zLowerBc.type;
+    a.upperBc = c->prob.zUpperBc.type;
+    a.lowerNmu = c->prob.zLowerBc.Nmu;
+    a.upperNmu = c->prob.zUpperBc.Nmu;
+    a.laShardStart = c->laStart;
+    a.storeDepth = c->prob.storeDepthData ? 1 : 0;
+    a.height = c->height.p;
+    a.temperature = c->temperature.p;
+    a.muz = c->muz.p;
+    a.wmu = c->wmu.p;
+    a.wavelength = c->wavelength.p;
+    a.rayList = upOnly ? c->rayUp.p : c->rayAll.p;
+    a.lowerIdx = c->lowerIdx.p;
+    a.upperIdx = c->upperIdx.p;
+    a.lowerBcData = c->lowerBcData.p;
+    a.upperBcData = c->upperBcData.p;
+    a.bgChi = c->bgChi.p;
+    a.bgEta = c->bgEta.p;
+    a.bgSca = c->bgSca.p;
+    a.J = c->J.p;
+    a.I = c->I.p;
+    a.depthChi = c->depthChi.p;
+    a.depthEta = c->depthEta.p;
+    a.depthI = c->depthI.p;
+    a.n = c->n.p;
+    a.ratio = c->ratio.p;
+    a.wphi = c->wphi.p;
+    a.phi = c->phi.p;
+    a.rho = c->rho.p;
+    a.par = c->par.p;
+    a.trans = c->dtrans.p;
+    a.laHdr = c->laHdr.p;
+    a.laEnt = c->laEnt.p;
+    a.chunkLa = c->chunkLa.p;
+    a.partial = c->partial.p;
+    a.dJ = c->dJ.p;
+    return a;
+}
+
+int collect_profile(lwhip_context* c)
+{
+    for (auto& pr : c->pending)
+    {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->sweepMs += ms;
+        c->sweepCount++;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    c->pending.clear();
+    return LWHIP_OK;
+}
+}
+
+extern "C"
+{
+const char* lwhip_last_error(void)
+{
+    return g_lastError.c_str();
+}
+
+int lwhip_abi_version(void)
+{
+    return LWHIP_ABI_VERSION;
+}
+
+int lwhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context** out)
+{
+    if (!out)
+        return fail(LWHIP_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    std::string why;
+    int st = validate(prob, why);
+    if (st != LWHIP_OK)
+        return fail(st, "lwhip_create: " + why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(LWHIP_ERR_DEVICE, "lwhip_create: no HIP device visible (this library has no CPU path)");
+
+    auto c = new lwhip_context();
+    c->prob = *prob;
+    c->atoms.assign(prob->atoms, prob->atoms + prob->Natom);
+    c->device = opts ? opts->device : 0;
+    if (c->device < 0 || c->device >= ndev)
+    {
+        delete c;
+        return fail(LWHIP_ERR_INVALID, "lwhip_create: bad device ordinal");
+    }
+    c->laStart = 0;
+    c->laEnd = prob->Nlambda;
+    if (opts && !(opts->laStart == 0 && opts->laEnd == 0))
+    {
+        c->laStart = opts->laStart;
+        c->laEnd = opts->laEnd;
+        if (c->laStart < 0 || c->laEnd > prob->Nlambda || c->laEnd <= c->laStart)
+        {
+            delete c;
+            return fail(LWHIP_ERR_INVALID, "lwhip_create: bad wavelength shard");
+        }
+    }
+    c->Nla = c->laEnd - c->laStart;
+    c->Ns = prob->Nspace;
+    c->Nrays = prob->Nrays;
+    c->Natom = prob->Natom;
+
+    auto bail = [&](int code) {
+        delete c;
+        return code;
+    };
+    if (hipSetDevice(c->device) != hipSuccess)
+        return bail(fail(LWHIP_ERR_DEVICE, "hipSetDevice failed"));
+    if (opts && opts->stream)
+        c->stream = (hipStream_t)opts->stream;
+    else
+    {
+        if (hipStreamCreate(&c->ownStream) != hipSuccess)
+            return bail(fail(LWHIP_ERR_DEVICE, "hipStreamCreate failed"));
+        c->stream = c->ownStream;
+    }
+    st = build_tables(c);
+    if (st != LWHIP_OK)
+        return bail(st);
+    st = alloc_state(c);
+    if (st != LWHIP_OK)
+        return bail(st);
+    st = lwhip_upload(c, LWHIP_ALL_INPUTS);
+    if (st != LWHIP_OK)
+        return bail(st);
+    *out = c;
+    return LWHIP_OK;
+}
+
+int lwhip_destroy(lwhip_context* c)
+{
+    if (!c)
+        return LWHIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    delete c;
+    return LWHIP_OK;
+}
+
+int lwhip_upload(lwhip_context* c, uint32_t mask)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    const lwhip_problem& p = c->prob;
+    const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
+    const size_t l0 = c->laStart;
+    if (mask & LWHIP_ATMOS)
+    {
+        H2D(c->height.p, p.height, Ns);
+        H2D(c->temperature.p, p.temperature, Ns);
+        H2D(c->muz.p, p.muz, Nr);
+        H2D(c->wmu.p, p.wmu, Nr);
+        H2D(c->wavelength.p, p.wavelength + l0, Nla);
+    }
+    if (mask & LWHIP_BACKGROUND)
+    {
+        H2D(c->bgChi.p, p.bgChi + l0 * Ns, Nla * Ns);
+        H2D(c->bgEta.p, p.bgEta + l0 * Ns, Nla * Ns);
+        H2D(c->bgSca.p, p.bgSca + l0 * Ns, Nla * Ns);
+    }
+    if (mask & LWHIP_J)
+        H2D(c->J.p, p.J + l0 * Ns, Nla * Ns);
+    if (mask & LWHIP_BC)
+    {
+        if (p.zLowerBc.type == LWHIP_BC_CALLABLE)
+        {
+            H2D(c->lowerBcData.p, p.zLowerBc.bcData + l0 * p.zLowerBc.Nmu, Nla * p.zLowerBc.Nmu);
+            HIP_TRY(hipMemcpyAsync(c->lowerIdx.p, p.zLowerBc.idxs, Nr * 2 * sizeof(int32_t),
+                                   hipMemcpyHostToDevice, c->stream));
+        }
+        if (p.zUpperBc.type == LWHIP_BC_CALLABLE)
+        {
+            H2D(c->upperBcData.p, p.zUpperBc.bcData + l0 * p.zUpperBc.Nmu, Nla * p.zUpperBc.Nmu);
+            HIP_TRY(hipMemcpyAsync(c->upperIdx.p, p.zUpperBc.idxs, Nr * 2 * sizeof(int32_t),
+                                   hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    std::vector<double> ratioHost;
+    if (mask & LWHIP_NSTAR)
+        ratioHost.assign((size_t)std::max(c->Ncont, 1) * Ns, 1.0);
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        const lwhip_atom& a = c->atoms[ia];
+        if (mask & LWHIP_POPS)
+            H2D(c->n.p + (size_t)c->levelOff[ia] * Ns, a.n, (size_t)a.Nlevel * Ns);
+        if (mask & LWHIP_NSTAR)
+            H2D(c->nTotal.p + (size_t)ia * Ns, a.nTotal, Ns);
+        if (!a.detailed && (mask & LWHIP_GAMMA))
+            H2D(c->Gamma.p + c->gammaOff[ia], a.Gamma, (size_t)a.Nlevel * a.Nlevel * Ns);
+        if (!a.detailed && (mask & LWHIP_COLLISIONS) && a.C)
+            H2D(c->Cmat.p + c->gammaOff[ia], a.C, (size_t)a.Nlevel * a.Nlevel * Ns);
+        for (int kr = 0; kr < a.Ntrans; ++kr)
+        {
+            const HostTrans& h = c->trans[c->atomTrOff[ia] + kr];
+            const lwhip_transition& t = h.t;
+            const size_t nlt = h.NredLoc - h.NblueLoc;
+            if (t.type == LWHIP_LINE)
+            {
+                if (mask & LWHIP_PROFILES)
+                {
+                    if (nlt)
+                        H2D(c->phi.p + h.phiOff, t.phi + (size_t)h.ltStart * Nr * 2 * Ns, nlt * Nr * 2 * Ns);
+                    H2D(c->wphi.p + (size_t)h.row * Ns, t.wphi, Ns);
+                }
+                if ((mask & LWHIP_RHOPRD) && t.prd && nlt)
+                    H2D(c->rho.p + h.rhoOff, t.rhoPrd + (size_t)h.ltStart * Ns, nlt * Ns);
+            }
+            else if (mask & LWHIP_NSTAR)
+            {
+                // nStar_i / nStar_j, evaluated exactly as LwAtom.hpp:112 does before the exp factor
+                const double* ni = a.nStar + (size_t)t.i * Ns;
+                const double* nj = a.nStar + (size_t)t.j * Ns;
+                for (size_t k = 0; k < Ns; ++k)
+                    ratioHost[(size_t)h.row * Ns + k] = ni[k] / nj[k];
+            }
+        }
+    }
+    if (mask & LWHIP_NSTAR)
+        H2D(c->ratio.p, ratioHost.data(), ratioHost.size());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LWHIP_OK;
+}
+
+int lwhip_download(lwhip_context* c, uint32_t mask)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    const lwhip_problem& p = c->prob;
+    const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
+    const size_t l0 = c->laStart;
+    if (mask & LWHIP_J)
+        D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
+    if (mask & LWHIP_I)
+        D2H(p.I + l0 * Nr, c->I.p, Nla * Nr);
+    if ((mask & LWHIP_DEPTHDATA) && p.storeDepthData)
+    {
+        D2H(p.depthChi + l0 * Nr * 2 * Ns, c->depthChi.p, Nla * Nr * 2 * Ns);
+        D2H(p.depthEta + l0 * Nr * 2 * Ns, c->depthEta.p, Nla * Nr * 2 * Ns);
+        D2H(p.depthI + l0 * Nr * 2 * Ns, c->depthI.p, Nla * Nr * 2 * Ns);
+    }
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        const lwhip_atom& a = c->atoms[ia];
+        if (mask & LWHIP_POPS)
+            D2H(a.n, c->n.p + (size_t)c->levelOff[ia] * Ns, (size_t)a.Nlevel * Ns);
+        if (!a.detailed && (mask & LWHIP_GAMMA))
+            D2H(a.Gamma, c->Gamma.p + c->gammaOff[ia], (size_t)a.Nlevel * a.Nlevel * Ns);
+        for (int kr = 0; kr < a.Ntrans; ++kr)
+        {
+            const int tr = c->atomTrOff[ia] + kr;
+            const HostTrans& h = c->trans[tr];
+            if (mask & LWHIP_RATES)
+            {
+                D2H(h.t.Rij, c->Rij.p + (size_t)tr * Ns, Ns);
+                D2H(h.t.Rji, c->Rji.p + (size_t)tr * Ns, Ns);
+            }
+            if ((mask & LWHIP_PROFILES) && h.t.type == LWHIP_LINE)
+            {
+                const size_t nlt = h.NredLoc - h.NblueLoc;
+                if (nlt)
+                    D2H(h.t.phi + (size_t)h.ltStart * Nr * 2 * Ns, c->phi.p + h.phiOff, nlt * Nr * 2 * Ns);
+                D2H(h.t.wphi, c->wphi.p + (size_t)h.row * Ns, Ns);
+            }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LWHIP_OK;
+}
+
+int lwhip_gamma_prefill_from_C(lwhip_context* c, double crsw)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->gammaTot > 0)
+        HIP_TRY(launch_prefill(c->Gamma.p, c->Cmat.p, crsw, (size_t)c->gammaTot, c->stream));
+    return LWHIP_OK;
+}
+
+int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->dJ.p, 0, c->dJ.n * sizeof(double), c->stream));
+    SweepArgs a = make_sweep_args(c, false, lambdaIterate);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling)
+    {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    HIP_TRY(launch_sweep(a, c->prob.formalSolver, c->maxL, true, c->nChunks, c->stream));
+    if (c->profiling)
+    {
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        c->pending.emplace_back(e0, e1);
+    }
+    if (c->Ntrans > 0)
+    {
+        ReduceArgs r{};
+        r.Ns = c->Ns;
+        r.Ntrans = c->Ntrans;
+        r.maxCT = c->maxCT;
+        r.trOff = c->trOff.p;
+        r.trRow = c->trRow.p;
+        r.partial = c->partial.p;
+        r.red = c->red.p;
+        HIP_TRY(launch_reduce(r, c->stream));
+    }
+    c->partialPending = true;
+    return LWHIP_OK;
+}
+
+int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (!c->partialPending)
+        return fail(LWHIP_ERR_INVALID, "lwhip_fs_finalise without lwhip_fs_partial");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->Natom > 0)
+    {
+        ApplyArgs a{};
+        a.Ns = c->Ns;
+        a.Natom = c->Natom;
+        a.atomTrOff = c->atomTrOffD.p;
+        a.atomNlevel = c->atomNlevel.p;
+        a.atomDetailed = c->atomDetailed.p;
+        a.atomGammaOff = c->atomGammaOff.p;
+        a.trans = c->dtrans.p;
+        a.transLi = c->transLi.p;
+        a.transLj = c->transLj.p;
+        a.red = c->red.p;
+        a.Gamma = c->Gamma.p;
+        a.Rij = c->Rij.p;
+        a.Rji = c->Rji.p;
+        HIP_TRY(launch_apply(a, c->stream));
+    }
+    HIP_TRY(launch_djmax(c->dJ.p, 0, c->Nla, c->out2.p, c->stream));
+    c->partialPending = false;
+    if (res)
+    {
+        double h2[2] = { 0.0, 0.0 };
+        HIP_TRY(hipMemcpyAsync(h2, c->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        res->updatedJ = 1;
+        res->dJMax = h2[0];
+        res->dJMaxIdx = (int)h2[1] + c->laStart;
+    }
+    return LWHIP_OK;
+}
+
+int lwhip_formal_sol_gamma_matrices(lwhip_context* c, int lambdaIterate, lwhip_iter_result* res)
+{
+    int st = lwhip_fs_partial(c, lambdaIterate);
+    if (st != LWHIP_OK)
+        return st;
+    return lwhip_fs_finalise(c, res);
+}
+
+int lwhip_reduce_buffer(lwhip_context* c, void** devPtr, size_t* nSum, size_t* nMax)
+{
+    if (!c || !devPtr || !nSum || !nMax)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    *devPtr = c->red.p;
+    *nSum = (size_t)c->Ntrans * 4 * c->Ns;
+    *nMax = 0;
+    return LWHIP_OK;
+}
+
+int lwhip_formal_sol(lwhip_context* c, int upOnly)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    SweepArgs a = make_sweep_args(c, upOnly != 0, 0);
+    HIP_TRY(launch_sweep(a, c->prob.formalSolver, c->maxL, false, c->nChunks, c->stream));
+    return LWHIP_OK;
+}
+
+int lwhip_stat_equil(lwhip_context* c, int atom)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        if (atom >= 0 && ia != atom)
+            continue;
+        const lwhip_atom& a = c->atoms[ia];
+        if (a.detailed)
+            continue;
+        HIP_TRY(launch_stat_eq(a.Nlevel, c->Ns, c->n.p + (size_t)c->levelOff[ia] * c->Ns,
+                               c->nTotal.p + (size_t)ia * c->Ns, c->Gamma.p + c->gammaOff[ia],
+                               c->status.p, c->stream));
+    }
+    int32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st == LWHIP_ERR_SINGULAR)
+        return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+    return LWHIP_OK;
+}
+
+int lwhip_compute_profiles(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    return fail(LWHIP_ERR_UNSUPPORTED, "lwhip_compute_profiles: device Voigt kernel not built yet");
+}
+
+int lwhip_synchronize(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LWHIP_OK;
+}
+
+int lwhip_set_stream(lwhip_context* c, void* stream)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stream)
+        c->stream = (hipStream_t)stream;
+    else
+    {
+        if (!c->ownStream)
+            HIP_TRY(hipStreamCreate(&c->ownStream));
+        c->stream = c->ownStream;
+    }
+    return LWHIP_OK;
+}
+
+int lwhip_profile_enable(lwhip_context* c, int enable)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    int st = collect_profile(c);
+    if (st != LWHIP_OK)
+        return st;
+    c->profiling = enable != 0;
+    c->sweepMs = 0.0;
+    c->sweepCount = 0;
+    return LWHIP_OK;
+}
+
+int lwhip_sweep_time(lwhip_context* c, double* meanMs, int* nLaunches)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int st = collect_profile(c);
+    if (st != LWHIP_OK)
+        return st;
+    if (meanMs)
+        *meanMs = c->sweepCount ? c->sweepMs / c->sweepCount : 0.0;
+    if (nLaunches)
+        *nLaunches = c->sweepCount;
+    return LWHIP_OK;
+}
+
+int lwhip_algorithmic_bytes(lwhip_context* c, double* bytes)
+{
+    if (!c || !bytes)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    // SURVEY.md 8(d) / BASELINE.md 4: phi read once, background chi/eta/sca read, J read + write,
+    // emergent I write, Gamma read + write and n read, Rij/Rji write, small replicated terms.
+    const double Ns = c->Ns, Nla = c->Nla, Nmu = c->Nrays;
+    double sumLineLa = 0.0, gam = 0.0, lev = 0.0;
+    for (auto& h : c->trans)
+        if (h.t.type == LWHIP_LINE)
+            sumLineLa += h.NredLoc - h.NblueLoc;
+    for (auto& a : c->atoms)
+    {
+        lev += a.Nlevel;
+        if (!a.detailed)
+            gam += 2.0 * a.Nlevel * a.Nlevel;
+    }
+    double b = 8.0 * Ns * (2.0 * Nmu * sumLineLa + 3.0 * Nla + 2.0 * Nla);
+    b += 8.0 * Nla * Nmu;
+    b += 8.0 * Ns * (gam + lev);
+    b += 8.0 * Ns * 2.0 * c->Ntrans;
+    b += 8.0 * Ns * (lev + 3.0 + Nmu);
+    *bytes = b;
+    return LWHIP_OK;
+}
+}

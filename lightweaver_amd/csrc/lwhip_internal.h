@@ -1,0 +1,141 @@
+// lwhip_internal.h -- device-side tables shared by the host API (lwhip_api.hip) and the kernels
+// (lwhip_kernels.hip).  Not part of the public ABI (that is include/lwhip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lwhip
+{
+// physical constants, bit-identical to the reference (Source/Constants.hpp:6-47)
+constexpr double CLight = 2.99792458E+08;
+constexpr double HPlanck = 6.6260755E-34;
+constexpr double HC = HPlanck * CLight;
+constexpr double KBoltzmann = 1.380658E-23;
+constexpr double Pi = 3.14159265358979323846264338327950288;
+constexpr double NM_TO_M = 1.0E-09;
+constexpr double HC_K = HC / (KBoltzmann * NM_TO_M);           // hc_k, LwAtom.hpp:88
+constexpr double HC_4PI = 0.25 * HC / Pi;                      // hc_4pi, LwAtom.hpp:86
+constexpr double PI4_HC = 1.0 / HC_4PI;                        // pi4_hc, LwAtom.hpp:87
+constexpr double PI4_H = 4.0 * Pi / HPlanck;                   // pi4_h,  LwAtom.hpp:85
+constexpr double TWO_HC_NM3 = 2.0 * HC / (NM_TO_M * NM_TO_M * NM_TO_M); // twoHc, LwTransition.hpp:132
+
+// One radiative transition, global index over all atoms in reference order
+// (atoms in descriptor order, transitions in kr order).
+struct DevTrans
+{
+    int32_t type;       // LWHIP_LINE / LWHIP_CONTINUUM
+    int32_t atom;       // atom index
+    int32_t gi, gj;     // global level rows (levelOff[atom] + i / j) into the n pool
+    int32_t Nblue, Nred;
+    int32_t prd;        // rhoPrd multiplies gij
+    int32_t op;         // 1: atom is active (Gamma accumulated); 0: detailed (rates only)
+    int32_t row;        // lines: row in the wphi pool; continua: row in the nStar-ratio pool
+    int32_t _pad;
+    int64_t parOff;     // offset (doubles) of this transition's per-wavelength params, 4 per lt
+    int64_t phiOff;     // offset (doubles) into the phi pool (lines)
+    int64_t rhoOff;     // offset (doubles) into the rhoPrd pool or -1
+};
+// per-(transition, lt) params, 4 doubles:
+//   line:      { hnu_4pi*Bij, wlambda, Bji/Bij, Aji/Bji }      LwTransition.hpp:107-113,128-131; LwAtom.hpp:97-105
+//   continuum: { alpha(lt),   wlambda/lambda*pi4_h, twoHc/lambda^3, 0 }   LwTransition.hpp:132-142; LwAtom.hpp:107-115
+
+// Per-wavelength activity header + entries.  Entries of one wavelength are stored lines first
+// (reference order) then continua (reference order).
+struct DevLaHeader
+{
+    int32_t off;        // first entry
+    int16_t nLine;
+    int16_t nCont;
+};
+struct DevLaEntry
+{
+    int32_t tr;         // global transition index
+    int32_t cs;         // chunk-local accumulator slot
+};
+
+struct SweepArgs
+{
+    // sizes
+    int32_t Ns, Nrays, Nla, Natom, NlevTot, Ntrans;
+    int32_t nRaysActive;   // 2*Nrays, or Nrays when upOnly
+    int32_t G;             // rays per pass
+    int32_t P;             // scan lanes per ray
+    int32_t maxC;          // max continua active at one wavelength
+    int32_t maxCT;         // accumulator slots per chunk
+    int32_t lambdaIterate;
+    int32_t lowerBc, upperBc, lowerNmu, upperNmu;
+    int32_t laShardStart;  // first wavelength of this context's shard
+    int32_t storeDepth;
+    // atmosphere
+    const double* height;
+    const double* temperature;
+    const double* muz;
+    const double* wmu;
+    const double* wavelength;
+    const int32_t* rayList;        // [nRaysActive] -> r = 2*mu + toObs
+    const int32_t* lowerIdx;       // [Nrays,2] CALLABLE
+    const int32_t* upperIdx;
+    const double* lowerBcData;     // [Nla, lowerNmu]
+    const double* upperBcData;
+    // spectrum / background
+    const double* bgChi;
+    const double* bgEta;
+    const double* bgSca;
+    double* J;
+    double* I;
+    double* depthChi;
+    double* depthEta;
+    double* depthI;
+    // atoms
+    const double* n;               // [NlevTot, Ns] pool
+    const double* ratio;           // [Ncont, Ns]  nStar_i / nStar_j
+    const double* wphi;            // [Nline, Ns]
+    const double* phi;             // pool
+    const double* rho;             // pool
+    const double* par;             // pool, 4 doubles per (transition, lt)
+    const DevTrans* trans;
+    // activity
+    const DevLaHeader* laHdr;      // [Nla]
+    const DevLaEntry* laEnt;
+    const int32_t* chunkLa;        // [nChunks+1] wavelength boundaries
+    // outputs
+    double* partial;               // [nChunks*maxCT, 4, Ns]
+    double* dJ;                    // [Nla]
+};
+
+struct ReduceArgs
+{
+    int32_t Ns, Ntrans, maxCT;
+    const int32_t* trOff;          // [Ntrans+1]
+    const int32_t* trRow;          // slab rows (chunk*maxCT + cs) in chunk order
+    const double* partial;
+    double* red;                   // [Ntrans, 4, Ns]
+};
+
+struct ApplyArgs
+{
+    int32_t Ns, Natom, Nla, laStart, laEnd;
+    const int32_t* atomTrOff;      // [Natom+1] global transition range of each atom
+    const int32_t* atomNlevel;     // [Natom]
+    const int32_t* atomDetailed;   // [Natom]
+    const int64_t* atomGammaOff;   // [Natom] offset into Gamma pool
+    const DevTrans* trans;
+    const int32_t* transLi;        // [Ntrans] local i
+    const int32_t* transLj;        // [Ntrans] local j
+    const double* red;             // [Ntrans,4,Ns] (reduced)
+    double* Gamma;                 // pool
+    double* Rij;                   // [Ntrans, Ns]
+    double* Rji;                   // [Ntrans, Ns]
+};
+
+// launch helpers implemented in lwhip_kernels.hip
+size_t sweep_lds_bytes(const SweepArgs& a);
+hipError_t launch_sweep(const SweepArgs& a, int solver, int maxL, bool rates, int nChunks,
+                        hipStream_t stream);
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);
+hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream);
+hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, double* out2, hipStream_t stream);
+hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
+hipError_t launch_stat_eq(int Nlevel, int Ns, double* n, const double* nTotal, const double* Gamma,
+                          int* status, hipStream_t stream);
+}

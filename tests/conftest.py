@@ -1,0 +1,44 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (gfx950) device')
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _build_checkers():
+    """TEST INFRASTRUCTURE: make sure the C oracle (and, where the reference sources exist, the
+    reference build under oracle/_ref) is compiled before any test runs."""
+    subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle'), 'all'], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope='session')
+def hip_lib():
+    from lightweaver_amd import build, context
+    build.build_hip()
+    return context.load_library()
+
+
+def _gpu_present():
+    try:
+        from lightweaver_amd import context
+        return context.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope='session')
+def gpu(hip_lib):
+    """GPU tests must run the HIP path; with no device they fail (never silently pass)."""
+    if hip_lib.lwhip_device_count() < 1:
+        pytest.fail('no gfx950 device visible: -m gpu tests need a GPU box')
+    return True

@@ -1,0 +1,162 @@
+"""Generate the golden vectors tests/golden/*.npz by running the REAL Lightweaver core.
+
+Runs ONLY in the build container: it needs oracle/_ref/liblwref.so, which oracle/Makefile compiles
+from the reference sources where they lie under /root/reference/Source (nothing is copied).  Each
+fixture holds the complete inputs at the `Context` array boundary (lightweaver_amd.io format) and
+the outputs of the reference's scalar scheme `mali_full_precond_scalar` (Nthreads = 1) for a set
+of variants, so every other box can check the oracle and the HIP path against the reference
+without having it.
+
+    make -C oracle && python tests/golden/make_golden.py
+
+Variants (keys `out/<variant>/...`):
+  iter1      one formal_sol_gamma_matrices from the LTE start (J, I, Gamma, Rij/Rji, dJMax, idx,
+             per-wavelength dJ, depthData chi/eta/I on every 8th wavelength)
+  stateq     n after stat_equil on the iter1 Gamma
+  iter20     J, n after 20 iterations (stat_equil from iteration 3 on, cf. Nscatter in
+             lightweaver/iterate_ctx.py:157-176; no Ng acceleration)
+  linear / besser   iter1 with the other 1D formal solvers
+  lambda     iter1 with lambdaIterate = True
+  fs_up / fs_all    formal_sol(upOnly = True / False): I
+  bc         iter1 with zUpperBc THERMALISED and zLowerBc CALLABLE
+  prd_detailed      iter1 with Ca II as a detailed (rates-only) atom and rhoPrd != 1 on H & K
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from lightweaver_amd import _abi as abi  # noqa: E402
+from lightweaver_amd.harness import models  # noqa: E402
+from lightweaver_amd.io import problem_to_dict  # noqa: E402
+from lightweaver_amd.model import Boundary  # noqa: E402
+from oracle.bindings import OracleContext, RefContext  # noqa: E402
+
+DEPTH_STRIDE = 8
+
+
+def collect(prob, prefix, out, what=('J', 'I', 'Gamma', 'R')):
+    if 'J' in what:
+        out[f'{prefix}/J'] = prob.J.copy()
+    if 'I' in what:
+        out[f'{prefix}/I'] = prob.I.copy()
+    for ia, a in enumerate(prob.atoms):
+        if 'Gamma' in what and not a.detailed:
+            out[f'{prefix}/Gamma{ia}'] = a.Gamma.copy()
+        if 'n' in what:
+            out[f'{prefix}/n{ia}'] = a.n.copy()
+        if 'R' in what:
+            out[f'{prefix}/Rij{ia}'] = np.stack([t.Rij for t in a.trans])
+            out[f'{prefix}/Rji{ia}'] = np.stack([t.Rji for t in a.trans])
+
+
+def ref_iter1(prob, prefix, out, lambdaIterate=False, what=('J', 'I', 'Gamma', 'R'), with_dJ=True):
+    """One reference iteration on a copy; the per-wavelength dJ comes from the C oracle after
+    asserting that it reproduces the reference bit for bit."""
+    p = prob.copy()
+    q = prob.copy()
+    rc = RefContext(p)
+    p.gamma_prefill()
+    dJMax, idx = rc.formal_sol_gamma_matrices(lambdaIterate=lambdaIterate)
+    collect(p, prefix, out, what)
+    out[f'{prefix}/dJMax'] = np.array(dJMax)
+    out[f'{prefix}/dJMaxIdx'] = np.array(idx)
+    oc = OracleContext(q)
+    q.gamma_prefill()
+    dJ = np.zeros(q.Nlambda)
+    oc.formal_sol_gamma_matrices(lambdaIterate=lambdaIterate, dJ=dJ)
+    for k, v in p.outputs().items():
+        assert np.array_equal(v, q.outputs()[k]), f'oracle != reference in {k}'
+    assert dJ.max() == dJMax
+    if with_dJ:
+        out[f'{prefix}/dJ'] = dJ
+    return p, rc
+
+
+def make_fixture(name, prob):
+    out = {}
+    # ---- iter1 / stateq -------------------------------------------------------------------------
+    p, rc = ref_iter1(prob, 'out/iter1', out)
+    sl = slice(None, None, DEPTH_STRIDE)
+    out['out/iter1/depthChi'] = p.depthChi[sl].copy()
+    out['out/iter1/depthEta'] = p.depthEta[sl].copy()
+    out['out/iter1/depthI'] = p.depthI[sl].copy()
+    assert rc.stat_equil() == 0
+    collect(p, 'out/stateq', out, what=('n',))
+    # ---- iter20 ---------------------------------------------------------------------------------
+    p = prob.copy()
+    rc = RefContext(p)
+    for it in range(20):
+        p.gamma_prefill()
+        rc.formal_sol_gamma_matrices()
+        if it >= 3:
+            assert rc.stat_equil() == 0
+    collect(p, 'out/iter20', out, what=('J', 'n'))
+    # ---- other solvers, lambda iteration ---------------------------------------------------------
+    for solver, key in ((abi.FS_LINEAR_1D, 'linear'), (abi.FS_BESSER_1D, 'besser')):
+        p = prob.copy()
+        p.formalSolver = solver
+        ref_iter1(p, f'out/{key}', out, what=('J', 'I', 'Gamma'), with_dJ=False)
+    ref_iter1(prob, 'out/lambda', out, lambdaIterate=True, what=('Gamma',), with_dJ=False)
+    # ---- formal_sol ---------------------------------------------------------------------------------
+    for upOnly, key in ((True, 'fs_up'), (False, 'fs_all')):
+        p = prob.copy()
+        rc = RefContext(p)
+        rc.formal_sol(upOnly=upOnly)
+        out[f'out/{key}/I'] = p.I.copy()
+        assert np.array_equal(p.J, prob.J)
+    # ---- boundary conditions ---------------------------------------------------------------------------
+    p = prob.copy()
+    rng = np.random.default_rng(7)
+    idxs = np.full((p.Nrays, 2), -1, dtype=np.int32)
+    idxs[:, 1] = np.arange(p.Nrays)[::-1]
+    bc = (1.0 + 0.3 * rng.random((p.Nlambda, p.Nrays))) * p.J[:, -1][:, None]
+    p.zLowerBc = Boundary(abi.BC_CALLABLE, idxs=idxs, bcData=bc)
+    p.zUpperBc = Boundary(abi.BC_THERMALISED)
+    out['in/bc/idxs'] = idxs
+    out['in/bc/bcData'] = bc
+    ref_iter1(p, 'out/bc', out, what=('J', 'I', 'Gamma'), with_dJ=False)
+    # ---- PRD rho + detailed atom ------------------------------------------------------------------------
+    if len(prob.atoms) < 2:
+        return finish(name, prob, out)
+    p = prob.copy()
+    ca = p.atoms[1]
+    ca.detailed = True
+    for t in ca.trans[:2]:
+        lam = np.linspace(0.0, 1.0, t.Nlambda)[:, None]
+        dep = np.linspace(0.0, 1.0, p.Nspace)[None, :]
+        t.rhoPrd = 1.0 + 0.2 * np.sin(7.0 * lam + 3.0 * dep)
+        out[f'in/prd/rho{ca.trans.index(t)}'] = t.rhoPrd
+    pd_ = type(p)(height=p.height, temperature=p.temperature, muz=p.muz, wmu=p.wmu,
+                  wavelength=p.wavelength, bgChi=p.bgChi, bgEta=p.bgEta, bgSca=p.bgSca,
+                  atoms=p.atoms, vlosMu=p.vlosMu, J=p.J, formalSolver=p.formalSolver,
+                  storeDepthData=False)
+    pd_.gamma_prefill()
+    ref_iter1(pd_, 'out/prd_detailed', out, what=('J', 'Gamma', 'R'), with_dJ=False)
+
+    return finish(name, prob, out)
+
+
+def finish(name, prob, out):
+    d = problem_to_dict(prob)
+    d.update(out)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **d)
+    print(f'wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, Nlambda={prob.Nlambda}')
+
+
+def main():
+    # FAL-C 82 depths, 3 mu, H(6) + Ca II(6), coarse line grids: small enough to commit
+    make_fixture('falc_h_ca_small', models.falc_h_ca(Nrays=3, lineScale=0.3, storeDepthData=True))
+    # H only with a velocity field (asymmetric profiles, up != down), 2 mu
+    atmos = models.perturbed(models.falc82(), seed=11)
+    make_fixture('falc_h_vel', models.build_problem(atmos, [models.H_6(0.25)], Nrays=2,
+                                                    storeDepthData=True))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,97 @@
+"""Shared test helpers: golden-fixture loading, variant construction, error metrics."""
+import os
+
+import numpy as np
+
+from lightweaver_amd import _abi as abi
+from lightweaver_amd.io import problem_from_dict
+from lightweaver_amd.model import Boundary, Problem
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+FIXTURES = ['falc_h_ca_small', 'falc_h_vel']
+
+# Stated fp64 tolerances: relative, element-wise, against the reference's scalar
+# scheme after one call on identical inputs; 1e-6 on the converged J.
+TOL_ONE_CALL = 1e-9
+TOL_CONVERGED = 1e-6
+
+
+def load_fixture(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz')) as z:
+        d = {k: z[k] for k in z.files}
+    return problem_from_dict(d), d
+
+
+def rebuild(p: Problem, **kw) -> Problem:
+    args = dict(height=p.height, temperature=p.temperature, muz=p.muz, wmu=p.wmu,
+                wavelength=p.wavelength, bgChi=p.bgChi, bgEta=p.bgEta, bgSca=p.bgSca,
+                atoms=p.atoms, vlosMu=p.vlosMu, J=p.J, formalSolver=p.formalSolver,
+                zLowerBc=p.zLowerBc, zUpperBc=p.zUpperBc, storeDepthData=p.storeDepthData)
+    args.update(kw)
+    q = Problem(**args)
+    q.gamma_prefill()
+    return q
+
+
+def variant_problem(base: Problem, d, variant) -> Problem:
+    """The input problem of a golden variant (see tests/golden/make_golden.py)."""
+    p = base.copy()
+    if variant == 'linear':
+        p.formalSolver = abi.FS_LINEAR_1D
+    elif variant == 'besser':
+        p.formalSolver = abi.FS_BESSER_1D
+    elif variant == 'bc':
+        p.zLowerBc = Boundary(abi.BC_CALLABLE, idxs=d['in/bc/idxs'], bcData=d['in/bc/bcData'])
+        p.zUpperBc = Boundary(abi.BC_THERMALISED)
+    elif variant == 'prd_detailed':
+        ca = p.atoms[1]
+        ca.detailed = True
+        for kr in range(2):
+            ca.trans[kr].rhoPrd = d[f'in/prd/rho{kr}']
+        p = rebuild(p, storeDepthData=False)
+    p.gamma_prefill()
+    return p
+
+
+def rel_err(a, b):
+    """max element-wise |a-b|/|b| (elements where the reference is exactly 0 must match exactly)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    nz = b != 0.0
+    err = 0.0
+    if nz.any():
+        err = float(np.max(np.abs(a[nz] - b[nz]) / np.abs(b[nz])))
+    if (~nz).any():
+        err = max(err, float(np.max(np.abs(a[~nz]))))
+    return err
+
+
+def collect(prob, what=('J', 'I', 'Gamma', 'R', 'n')):
+    out = {}
+    if 'J' in what:
+        out['J'] = prob.J
+    if 'I' in what:
+        out['I'] = prob.I
+    for ia, a in enumerate(prob.atoms):
+        if 'Gamma' in what and not a.detailed:
+            out[f'Gamma{ia}'] = a.Gamma
+        if 'n' in what:
+            out[f'n{ia}'] = a.n
+        if 'R' in what:
+            out[f'Rij{ia}'] = np.stack([t.Rij for t in a.trans])
+            out[f'Rji{ia}'] = np.stack([t.Rji for t in a.trans])
+    return out
+
+
+def compare_to_golden(prob, d, variant, keys=None, tol=TOL_ONE_CALL):
+    got = collect(prob)
+    worst = {}
+    for k, v in got.items():
+        gk = f'out/{variant}/{k}'
+        if gk not in d or (keys is not None and k not in keys and k.rstrip('0123456789') not in keys):
+            continue
+        worst[k] = rel_err(v, d[gk])
+    bad = {k: e for k, e in worst.items() if not e <= tol}
+    assert not bad, f'{variant}: beyond tol {tol}: {bad} (all: {worst})'
+    return worst

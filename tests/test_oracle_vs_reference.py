@@ -1,0 +1,175 @@
+"""Pin the C oracle against the REAL Lightweaver core (oracle/_ref, built by oracle/Makefile from
+/root/reference/Source).  Skipped where the reference build is absent."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import load_fixture, rel_err, variant_problem
+from lightweaver_amd import _abi as abi
+from lightweaver_amd.harness import models
+from oracle import bindings
+from oracle.bindings import OracleContext, RefContext
+
+pytestmark = pytest.mark.skipif(not bindings.ref_available(),
+                                reason='oracle/_ref/liblwref.so not built (no reference sources)')
+
+
+def _arr(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(abi.f64p)
+
+
+def test_leaf_known_answers():
+    ref, ora = RefContext.lib_(), OracleContext.lib_()
+    # w2: all three branches (LwInternal.hpp:90-110)
+    for dtau in [1e-9, 4.9e-4, 5.1e-4, 0.3, 7.0, 49.9, 50.1, 1e3]:
+        a, b = np.zeros(2), np.zeros(2)
+        ref.lwref_w2(dtau, _p(a))
+        ora.lworacle_w2(dtau, _p(b))
+        assert np.array_equal(a, b), dtau
+    # Bezier3_coeffs: Taylor / exact / asymptotic branches, incl. the branch points (Bezier.hpp:81-127)
+    for dt in [1e-8, 1e-3, 4.99e-2, 5e-2, 5.01e-2, 0.7, 3.0, 29.9, 30.0, 30.1, 500.0]:
+        a, b = np.zeros(5), np.zeros(5)
+        ref.lwref_bezier3_coeffs(dt, _p(a))
+        ora.lworacle_bezier3_coeffs(dt, _p(b))
+        assert np.array_equal(a, b), dt
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        ds = rng.random(2) + 1e-3
+        y = rng.standard_normal(3)
+        args = (ds[0], ds[1], y[0], y[1], y[2])
+        assert ref.lwref_cent_deriv(*args) == ora.lworacle_cent_deriv(*args)
+    assert ref.lwref_cent_deriv(1.0, 2.0, 1.0, 1.0, 1.0) == ora.lworacle_cent_deriv(1.0, 2.0, 1.0, 1.0, 1.0) == 0.0
+    # planck_nu incl. the exponent cutoff 150 (LwMisc.hpp:29-46)
+    T = _arr([3000.0, 5800.0, 1e5, 50.0])
+    for lam in [20.0, 121.5, 500.0, 2000.0]:
+        a, b = np.zeros(4), np.zeros(4)
+        ref.lwref_planck_nu(4, _p(T), lam, _p(a))
+        ora.lworacle_planck_nu(4, _p(T), lam, _p(b))
+        assert np.array_equal(a, b)
+
+
+def test_lu_solver_known_answers():
+    ref, ora = RefContext.lib_(), OracleContext.lib_()
+    rng = np.random.default_rng(1)
+    for N in (2, 6, 11):
+        for improve in (0, 1):
+            A = rng.standard_normal((N, N)) * 10.0 ** rng.integers(-8, 8, (N, 1))
+            b = rng.standard_normal(N)
+            A1, b1, A2, b2 = A.copy(), b.copy(), A.copy(), b.copy()
+            assert ref.lwref_solve_lin_eq(N, _p(A1), _p(b1), improve) == 0
+            assert ora.lworacle_solve_lin_eq(N, _p(A2), _p(b2), improve) == 0
+            assert np.array_equal(b1, b2) and np.array_equal(A1, A2)
+    # zero pivot -> Tiny guard, all-zero row -> Singular Matrix
+    A = _arr([[0.0, 1.0], [1.0, 0.0]])
+    b = _arr([2.0, 3.0])
+    A2, b2 = A.copy(), b.copy()
+    assert ref.lwref_solve_lin_eq(2, _p(A), _p(b), 1) == ora.lworacle_solve_lin_eq(2, _p(A2), _p(b2), 1) == 0
+    assert np.array_equal(b, b2)
+    Z = np.zeros((3, 3))
+    Z[0, 0] = 1.0
+    b = np.ones(3)
+    assert ref.lwref_solve_lin_eq(3, _p(Z.copy()), _p(b.copy()), 1) == abi.ERR_SINGULAR
+    assert ora.lworacle_solve_lin_eq(3, _p(Z.copy()), _p(b.copy()), 1) == abi.ERR_SINGULAR
+
+
+@pytest.mark.parametrize('solver', [abi.FS_LINEAR_1D, abi.FS_BESSER_1D, abi.FS_BEZIER3_1D])
+def test_single_ray_formal_solvers(solver):
+    """Depth sweep alone on random (positive) chi, S columns, both directions."""
+    base, _ = load_fixture('falc_h_vel')
+    base.formalSolver = solver
+    p, q = base.copy(), base.copy()
+    rc, oc = RefContext(p), OracleContext(q)
+    rng = np.random.default_rng(2)
+    Ns = p.Nspace
+    for trial in range(20):
+        chi = np.exp(rng.uniform(-20, -3, Ns)) if trial % 2 else np.exp(np.linspace(-18, -4, Ns) + 0.3 * rng.standard_normal(Ns))
+        S = np.exp(rng.uniform(-30, -20, Ns))
+        for toObs in (0, 1):
+            I1, P1, I2, P2 = (np.zeros(Ns) for _ in range(4))
+            rc.lib.lwref_formal_solver_ray(rc.h, 3, 1, toObs, _p(chi.copy()), _p(S.copy()), _p(I1), _p(P1))
+            oc.lib.lworacle_formal_solver_ray(oc.h, 3, 1, toObs, _p(chi.copy()), _p(S.copy()), _p(I2), _p(P2))
+            assert np.array_equal(I1, I2) and np.array_equal(P1, P2)
+
+
+def _run_both(prob, n_iter=2, stat_eq=True, **ref_kw):
+    p, q = prob.copy(), prob.copy()
+    rc, oc = RefContext(p, **ref_kw), OracleContext(q)
+    for it in range(n_iter):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        r1 = rc.formal_sol_gamma_matrices()
+        r2 = oc.formal_sol_gamma_matrices()
+        if stat_eq:
+            assert rc.stat_equil() == oc.stat_equil() == 0
+    return p, q, r1, r2
+
+
+def test_full_iteration_bit_exact_on_fresh_inputs():
+    """A configuration that is NOT in the golden set: 5 rays, H + Ca II, 82 depths, velocities."""
+    atmos = models.perturbed(models.falc82(), seed=3)
+    prob = models.build_problem(atmos, [models.H_6(0.4), models.CaII_6(0.4)], Nrays=5)
+    p, q, r1, r2 = _run_both(prob, n_iter=3)
+    assert r1 == r2
+    o1, o2 = p.outputs(), q.outputs()
+    for k in o1:
+        assert np.array_equal(o1[k], o2[k]), k
+
+
+def test_resampled_500_depths():
+    """The reference's own benchmark atmosphere size (lightweaver/benchmark.py:19-45)."""
+    atmos = models.resample(models.falc82(), 500)
+    prob = models.build_problem(atmos, [models.H_6(0.2)], Nrays=3)
+    p, q, r1, r2 = _run_both(prob, n_iter=1, stat_eq=False)
+    o1, o2 = p.outputs(), q.outputs()
+    for k in o1:
+        assert rel_err(o2[k], o1[k]) <= 1e-13, k
+
+
+def test_compute_profiles_matches_host_wofz():
+    """phi/wphi from the reference's Faddeeva.cc equal the harness's SciPy wofz profiles."""
+    prob = models.build_problem(models.perturbed(models.falc82(), 5), [models.CaII_6(0.3)], Nrays=3)
+    p = prob.copy()
+    for a in p.atoms:
+        for t in a.trans:
+            if t.type == abi.LINE:
+                t.phi[...] = 0.0
+                t.wphi[...] = 0.0
+    RefContext(p).compute_profiles()
+    for a, b in zip(p.atoms, prob.atoms):
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                assert rel_err(u.phi, t.phi) <= 1e-14
+                assert rel_err(u.wphi, t.wphi) <= 1e-13
+
+
+@pytest.mark.parametrize('isa', ['SSE2', 'AVX2FMA', 'AVX512'])
+def test_reference_simd_plugins_vs_scalar(isa):
+    """Documents the reference's own internal consistency: its SIMD plugins agree
+    with its scalar scheme except in the remainder lanes (Nspace % width), where uv_opt uses hc/4pi
+    instead of h nu/4pi (SimdImpl_AVX2FMA.cpp:260 vs :269)."""
+    path = bindings.simd_plugin(isa)
+    if path is None:
+        pytest.skip(f'{isa} plugin not built or CPU lacks the ISA')
+    base, d = load_fixture('falc_h_ca_small')
+    p = variant_problem(base, d, 'iter1')
+    rc = RefContext(p, scheme=path)
+    assert rc.scheme_name == f'mali_full_precond_{isa}'
+    rc.formal_sol_gamma_matrices()
+    width = {'SSE2': 2, 'AVX2FMA': 4, 'AVX512': 8}[isa]
+    body = p.Nspace - p.Nspace % width
+    Jg = d['out/iter1/J']
+    assert rel_err(p.J[:, :body - 6], Jg[:, :body - 6]) < 1e-9
+    assert rel_err(p.J, Jg) < 1e-4
+
+
+def test_reference_threads_vs_single():
+    base, d = load_fixture('falc_h_ca_small')
+    p = variant_problem(base, d, 'iter1')
+    RefContext(p, Nthreads=4).formal_sol_gamma_matrices()
+    assert rel_err(p.J, d['out/iter1/J']) == 0.0
+    assert rel_err(p.atoms[0].Gamma, d['out/iter1/Gamma0']) < 1e-10
