@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- formal_sol_gamma_matrices iterations/second on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nlambda 10240]
+
+Workload (BASELINE.json north star): FAL-C, 82 depths, H(6) + Ca II(6) active, 5 mu-angles, fp64,
+Bezier3 short characteristics, wavelength grid densified to ~10 240 points per GPU.  One step =
+one full iteration (Gamma pre-fill from C on the device, sweep over all wavelengths and rays,
+J / I / Gamma / rates updated, Gamma finalised, dJMax returned to the host), inputs resident in
+HBM when the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the global grid has N x 10 240
+wavelengths, sharded contiguously; each iteration does ONE all-reduce (RCCL) of the concatenated
+Gamma / Rij / Rji partial sums and one tiny all-gather of (dJMax, idx).  Per-GPU work is fixed as N
+grows ("weak"); `value` counts 10 240-wavelength shard-iterations per second over all ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--nlambda', type=int, default=10240, help='wavelengths per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(prob, budget_s):
+    """The reference core (oracle/_ref, kind 'reference') -- or, where it is absent, the C oracle
+    (kind 'port') -- timed on the host cores on a bounded number of iterations of the SAME
+    workload.  Reported beside the GPU number; not the optimisation target."""
+    from oracle import bindings
+    ncpu = os.cpu_count() or 1
+    p = prob.copy()
+    if bindings.ref_available():
+        isa = next((i for i in ('AVX512', 'AVX2FMA', 'SSE2') if bindings.simd_plugin(i)), None)
+        threads = min(ncpu, 64)
+        ctx = bindings.RefContext(p, scheme=bindings.simd_plugin(isa) if isa else None,
+                                  Nthreads=threads)
+        kind, name = 'reference', ctx.scheme_name
+        step = lambda: ctx.formal_sol_gamma_matrices()
+    else:
+        threads = min(ncpu, 64)
+        ctx = bindings.OracleContext(p)
+        kind, name = 'port', 'lw_oracle.c (OpenMP)'
+        step = lambda: ctx.formal_sol_gamma_matrices(Nthreads=threads)
+    p.gamma_prefill()
+    step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        p.gamma_prefill()
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 50:
+            break
+    return {'value': n / dt, 'unit': 'iters/s', 'cores': threads, 'kind': kind,
+            'sample': f'{n} iterations of the same {prob.Nlambda}-wavelength workload, scheme {name}, '
+                      f'Nthreads={threads} of {ncpu} host cpus'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from lightweaver_amd.context import Context
+    from lightweaver_amd.distributed import ShardedIteration, shard_bounds
+    from lightweaver_amd.harness import models
+
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    Nla_total = args.nlambda * world
+    prob = models.throughput_grid(NlambdaTarget=Nla_total, Nrays=5)
+    bounds = shard_bounds(prob, world)
+    la0, la1 = bounds[rank], bounds[rank + 1]
+
+    stream = torch.cuda.current_stream()
+    ctx = Context(prob, device=local_rank, laStart=la0, laEnd=la1, stream=stream.cuda_stream,
+                  worldSize=world, worldRank=rank)
+    it = ShardedIteration(ctx, world, rank)
+
+    def step():
+        return it.formal_sol_gamma_matrices(deviceResident=True)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        up = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    sweep_ms, nlaunch = ctx.sweep_time()
+    ctx.profile_enable(False)
+    alg_bytes = ctx.algorithmic_bytes()
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        out = {
+            'metric': 'formal_sol_gamma_matrices iters/sec',
+            'value': value,
+            'unit': 'iters/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic (FAL-C model atmosphere, own H/CaII model atoms, seeded, generated in-process)',
+            'config': {
+                'workload': 'FALC 82-depth H(6)+CaII(6), 5 mu, Bezier3, densified wavelength grid',
+                'Nlambda_per_gpu': la1 - la0,
+                'Nlambda_total': prob.Nlambda,
+                'Nspace': prob.Nspace,
+                'Nrays': prob.Nrays,
+                'active_transitions': sum(len(a.trans) for a in prob.atoms),
+                'parallelism': f'lambda-shard x{world}' if world > 1 else 'single GPU',
+                'final_dJMax': up.dJMax,
+            },
+            'roofline': {
+                'bound': 'hbm',
+                'kernel': 'sweep_kernel',
+                'achieved': achieved,
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS,
+                'traffic': None,
+                'algorithmic_bytes_per_launch': alg_bytes,
+                'kernel_ms': sweep_ms,
+                'launches_timed': nlaunch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                single = prob if prob.Nlambda == args.nlambda else models.throughput_grid(args.nlambda, 5)
+                out['cpu_baseline'] = cpu_baseline(single, args.cpu_seconds)
+            except Exception as e:  # the baseline must never break the bench line
+                out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': 0, 'kind': 'port',
+                                       'sample': f'failed: {e!r}'}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

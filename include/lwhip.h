@@ -172,6 +172,8 @@ typedef struct lwhip_options {
     int32_t laStart;       /* wavelength shard owned by this context: [laStart, laEnd)             */
     int32_t laEnd;         /* 0,0 = whole grid                                                     */
     int32_t flags;         /* reserved, 0                                                          */
+    int32_t worldSize;     /* number of wavelength shards of the job (0 or 1 = unsharded)          */
+    int32_t worldRank;     /* this shard's ordinal: selects its (dJMax, idx) slot in the buffer    */
     void* stream;          /* hipStream_t to launch on, NULL = the library's own stream            */
 } lwhip_options;
 
@@ -219,15 +221,17 @@ int lwhip_gamma_prefill_from_C(lwhip_context* ctx, double crsw);
 int lwhip_formal_sol_gamma_matrices(lwhip_context* ctx, int lambdaIterate, lwhip_iter_result* res);
 
 /* The same iteration split around the cross-GPU reduction (wavelength-sharded runs):
- *   lwhip_fs_partial   launches the sweep; leaves this shard's Gamma/R partial sums in the
- *                      reduce buffer and dJMax in its last two slots;
- *   (caller all-reduces the buffer: sum over the first `nSum` doubles, max over the rest)
+ *   lwhip_fs_partial   launches the sweep; leaves this shard's Gamma/R partial sums in the first
+ *                      `nSum` doubles of the reduce buffer and its (dJMax, idx) in slot `worldRank`
+ *                      of the `nGather` = 2*worldSize trailing doubles (all other slots zero);
+ *   (caller all-reduces -- SUM -- the whole buffer of nSum + nGather doubles: one collective)
  *   lwhip_fs_finalise  adds the reduced sums into Gamma (which keeps its pre-fill, cf.
  *                      Source/ThreadStorage.cpp:155-156), finalises the diagonal, writes Rij/Rji. */
 int lwhip_fs_partial(lwhip_context* ctx, int lambdaIterate);
 int lwhip_fs_finalise(lwhip_context* ctx, lwhip_iter_result* res);
-/* Device pointer and layout of the reduce buffer: doubles [0,nSum) are sums, [nSum,nSum+nMax) maxima. */
-int lwhip_reduce_buffer(lwhip_context* ctx, void** devPtr, size_t* nSum, size_t* nMax);
+/* Device pointer and layout of the reduce buffer: [0,nSum) partial sums, [nSum,nSum+nGather) the
+ * per-rank (dJMax, idx) slots. */
+int lwhip_reduce_buffer(lwhip_context* ctx, void** devPtr, size_t* nSum, size_t* nGather);
 
 /* formal_sol: chi/S/solve/I only, optionally up-going rays only (FsMode::FsOnly|UpOnly). */
 int lwhip_formal_sol(lwhip_context* ctx, int upOnly);

@@ -83,6 +83,7 @@ class lwhip_problem(C.Structure):
 class lwhip_options(C.Structure):
     _fields_ = [
         ('device', C.c_int32), ('laStart', C.c_int32), ('laEnd', C.c_int32), ('flags', C.c_int32),
+        ('worldSize', C.c_int32), ('worldRank', C.c_int32),
         ('stream', C.c_void_p),
     ]
 

@@ -71,7 +71,8 @@ class Context:
     """Device-resident context for one `Problem` (optionally one wavelength shard of it)."""
 
     def __init__(self, prob: Problem, device: int = 0, laStart: int = 0, laEnd: int = 0,
-                 stream: Optional[int] = None, lib_path: Optional[str] = None):
+                 stream: Optional[int] = None, lib_path: Optional[str] = None,
+                 worldSize: int = 1, worldRank: int = 0):
         self.lib = load_library(lib_path)
         self.prob = prob
         self._desc = prob.descriptor()
@@ -79,6 +80,7 @@ class Context:
         opts.device = device
         opts.laStart, opts.laEnd = laStart, laEnd
         opts.stream = stream
+        opts.worldSize, opts.worldRank = worldSize, worldRank
         h = C.c_void_p()
         st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
         _check(self.lib, st, 'lwhip_create')
@@ -176,13 +178,14 @@ class Context:
         _check(self.lib, self.lib.lwhip_gamma_prefill_from_C(self._h, crsw), 'lwhip_gamma_prefill_from_C')
 
     def reduce_buffer(self):
-        """(device pointer, number of doubles to sum-reduce) of the Gamma/R partial sums."""
+        """(device pointer, total doubles to all-reduce) of the Gamma/R partial sums followed by
+        the per-rank (dJMax, idx) slots."""
         ptr = C.c_void_p()
         nsum = C.c_size_t()
-        nmax = C.c_size_t()
+        ngather = C.c_size_t()
         _check(self.lib, self.lib.lwhip_reduce_buffer(self._h, C.byref(ptr), C.byref(nsum),
-                                                      C.byref(nmax)), 'lwhip_reduce_buffer')
-        return ptr.value, nsum.value
+                                                      C.byref(ngather)), 'lwhip_reduce_buffer')
+        return ptr.value, nsum.value + ngather.value
 
     # -- measurement -----------------------------------------------------------------------------------------
     def profile_enable(self, enable=True):

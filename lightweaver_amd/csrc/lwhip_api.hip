@@ -89,6 +89,7 @@ struct lwhip_context
     std::vector<int> levelOff, atomTrOff;
     std::vector<int64_t> gammaOff;
     int device = 0;
+    int worldSize = 1, worldRank = 0;
     int laStart = 0, laEnd = 0, Nla = 0;
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
     int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, G = 1, P = 8;
@@ -104,7 +105,8 @@ struct lwhip_context
     DevBuf<DevLaEntry> laEnt;
     DevBuf<int32_t> chunkLa, trOff, trRow, atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
     DevBuf<int64_t> atomGammaOff;
-    DevBuf<double> partial, red, dJ, out2;
+    DevBuf<double> partial, red, dJ;
+    std::vector<double> gatherHost;
     DevBuf<int32_t> status;
 
     bool profiling = false;
@@ -571,10 +573,11 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(c->Rij.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     HIP_TRY(c->Rji.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     HIP_TRY(c->partial.alloc((size_t)c->nChunks * c->maxCT * 4 * Ns));
-    HIP_TRY(c->red.alloc((size_t)std::max(c->Ntrans, 1) * 4 * Ns));
+    // reduce buffer: [Ntrans,4,Ns] partial sums followed by one (dJMax, idx) slot per shard
+    HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize));
     HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
+    c->gatherHost.assign(2 * (size_t)c->worldSize, 0.0);
     HIP_TRY(c->dJ.alloc(Nla));
-    HIP_TRY(c->out2.alloc(2));
     HIP_TRY(c->status.alloc(1));
     if (c->prob.zLowerBc.type == LWHIP_BC_CALLABLE)
     {
@@ -717,6 +720,16 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
         {
             delete c;
             return fail(LWHIP_ERR_INVALID, "lwhip_create: bad wavelength shard");
+        }
+    }
+    if (opts && opts->worldSize > 1)
+    {
+        c->worldSize = opts->worldSize;
+        c->worldRank = opts->worldRank;
+        if (c->worldRank < 0 || c->worldRank >= c->worldSize)
+        {
+            delete c;
+            return fail(LWHIP_ERR_INVALID, "lwhip_create: bad worldRank");
         }
     }
     c->Nla = c->laEnd - c->laStart;
@@ -935,6 +948,10 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         r.red = c->red.p;
         HIP_TRY(launch_reduce(r, c->stream));
     }
+    // this shard's (dJMax, global idx) into its own slot of the gather tail, zeros elsewhere
+    double* tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
+    HIP_TRY(hipMemsetAsync(tail, 0, 2 * (size_t)c->worldSize * sizeof(double), c->stream));
+    HIP_TRY(launch_djmax(c->dJ.p, 0, c->Nla, c->laStart, tail + 2 * c->worldRank, c->stream));
     c->partialPending = true;
     return LWHIP_OK;
 }
@@ -964,16 +981,29 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
         a.Rji = c->Rji.p;
         HIP_TRY(launch_apply(a, c->stream));
     }
-    HIP_TRY(launch_djmax(c->dJ.p, 0, c->Nla, c->out2.p, c->stream));
     c->partialPending = false;
     if (res)
     {
-        double h2[2] = { 0.0, 0.0 };
-        HIP_TRY(hipMemcpyAsync(h2, c->out2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        const double* tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
+        HIP_TRY(hipMemcpyAsync(c->gatherHost.data(), tail, c->gatherHost.size() * sizeof(double),
+                               hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        // max over shards, first (lowest) wavelength index on ties: max_idx, Constants.hpp:114-125
+        double best = -1.0;
+        int bestIdx = 0;
+        for (int r = 0; r < c->worldSize; ++r)
+        {
+            const double v = c->gatherHost[2 * r];
+            const int idx = (int)c->gatherHost[2 * r + 1];
+            if (v > best || (v == best && idx < bestIdx))
+            {
+                best = v;
+                bestIdx = idx;
+            }
+        }
         res->updatedJ = 1;
-        res->dJMax = h2[0];
-        res->dJMaxIdx = (int)h2[1] + c->laStart;
+        res->dJMax = best < 0.0 ? 0.0 : best;
+        res->dJMaxIdx = bestIdx;
     }
     return LWHIP_OK;
 }
@@ -986,13 +1016,13 @@ int lwhip_formal_sol_gamma_matrices(lwhip_context* c, int lambdaIterate, lwhip_i
     return lwhip_fs_finalise(c, res);
 }
 
-int lwhip_reduce_buffer(lwhip_context* c, void** devPtr, size_t* nSum, size_t* nMax)
+int lwhip_reduce_buffer(lwhip_context* c, void** devPtr, size_t* nSum, size_t* nGather)
 {
-    if (!c || !devPtr || !nSum || !nMax)
+    if (!c || !devPtr || !nSum || !nGather)
         return fail(LWHIP_ERR_INVALID, "null argument");
     *devPtr = c->red.p;
     *nSum = (size_t)c->Ntrans * 4 * c->Ns;
-    *nMax = 0;
+    *nGather = 2 * (size_t)c->worldSize;
     return LWHIP_OK;
 }
 

@@ -134,7 +134,8 @@ hipError_t launch_sweep(const SweepArgs& a, int solver, int maxL, bool rates, in
                         hipStream_t stream);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream);
-hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, double* out2, hipStream_t stream);
+hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2,
+                        hipStream_t stream);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
 hipError_t launch_stat_eq(int Nlevel, int Ns, double* n, const double* nTotal, const double* Gamma,
                           int* status, hipStream_t stream);

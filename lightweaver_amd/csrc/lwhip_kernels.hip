@@ -877,7 +877,7 @@ hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream)
 }
 
 // ---- dJMax and the index of its first occurrence (max_idx, Constants.hpp:114-125) ---------------------------
-__global__ void djmax_kernel(const double* dJ, int laStart, int laEnd, double* out2)
+__global__ void djmax_kernel(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2)
 {
     __shared__ double sV[1024];
     __shared__ int sI[1024];
@@ -912,13 +912,14 @@ __global__ void djmax_kernel(const double* dJ, int laStart, int laEnd, double* o
     if (threadIdx.x == 0)
     {
         out2[0] = sV[0] < 0.0 ? 0.0 : sV[0];
-        out2[1] = (double)sI[0];
+        out2[1] = (double)(sI[0] + idxOffset);
     }
 }
 
-hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, double* out2, hipStream_t stream)
+hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2,
+                        hipStream_t stream)
 {
-    hipLaunchKernelGGL(djmax_kernel, dim3(1), dim3(1024), 0, stream, dJ, laStart, laEnd, out2);
+    hipLaunchKernelGGL(djmax_kernel, dim3(1), dim3(1024), 0, stream, dJ, laStart, laEnd, idxOffset, out2);
     return hipGetLastError();
 }
 

@@ -130,10 +130,11 @@ def test_wavelength_shards_sum_to_whole(gpu):
     prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
     q = prob.copy()
     with Context(q) as whole:
-        whole.formal_sol_gamma_matrices()
+        upWhole = whole.formal_sol_gamma_matrices()
     m = prob.Nlambda // 2 + 3
     pa, pb = prob.copy(), prob.copy()
-    with Context(pa, laStart=0, laEnd=m) as A, Context(pb, laStart=m, laEnd=prob.Nlambda) as B:
+    with Context(pa, laStart=0, laEnd=m, worldSize=2, worldRank=0) as A, \
+            Context(pb, laStart=m, laEnd=prob.Nlambda, worldSize=2, worldRank=1) as B:
         for c in (A, B):
             c.prob.gamma_prefill()
             c.upload(abi.GAMMA)
@@ -153,6 +154,7 @@ def test_wavelength_shards_sum_to_whole(gpu):
             C.cdll.LoadLibrary('libamdhip64.so').hipMemcpy(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p),
                                                            C.c_size_t(n * 8), 1)
             up = c.fs_finalise()
+            assert (up.dJMax, up.dJMaxIdx) == (upWhole.dJMax, upWhole.dJMaxIdx)
             c.download(abi.ALL_OUTPUTS)
     for ia in range(2):
         assert rel_err(pa.atoms[ia].Gamma, q.atoms[ia].Gamma) <= 1e-12
