@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -92,7 +93,7 @@ struct lwhip_context
     int worldSize = 1, worldRank = 0;
     int laStart = 0, laEnd = 0, Nla = 0;
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
-    int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, G = 1, P = 8;
+    int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, G = 1;
     int64_t gammaTot = 0, phiTot = 0, rhoTot = 0, parTot = 0;
     hipStream_t ownStream = nullptr, stream = nullptr;
 
@@ -102,12 +103,18 @@ struct lwhip_context
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<DevTrans> dtrans;
     DevBuf<DevLaHeader> laHdr;
-    DevBuf<DevLaEntry> laEnt;
+    DevBuf<DevSlot> slots;
+    DevBuf<DevProgram> progs;
+    DevBuf<DevProgRow> progRows;
+    DevBuf<DevProgEnt> progEnts;
+    DevBuf<SweepArgs> dargs;
+    SweepArgs hargs{};
     DevBuf<int32_t> chunkLa, trOff, trRow, atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
     DevBuf<int64_t> atomGammaOff;
-    DevBuf<double> partial, red, dJ;
+    DevBuf<double> partial, red, red8, dJ;
     std::vector<double> gatherHost;
     DevBuf<int32_t> status;
+    DevBuf<long long> stamps;
 
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -362,30 +369,158 @@ int build_tables(lwhip_context* c)
         }
     }
 
-    // ---- per-wavelength activity (lines first, then continua; reference order inside each) -------
+    // ---- per-wavelength activity: [lines][mixed continua][pure continua], row programs --------------
     std::vector<DevLaHeader> hdr(c->Nla);
-    std::vector<DevLaEntry> ent;
+    std::vector<DevSlot> slots;
+    std::vector<int> slotTr; // global transition of each slot record
+    std::vector<DevProgram> progs;
+    std::vector<DevProgRow> progRows;
+    std::vector<DevProgEnt> progEnts;
+    std::map<std::vector<int>, int> progIds;
     c->maxL = c->maxC = 0;
+    const int rowEtaA = 2, rowLevChi = 2 + c->Natom, rowLevU = 2 + c->Natom + c->NlevTot;
     for (int la = 0; la < c->Nla; ++la)
     {
-        hdr[la].off = (int32_t)ent.size();
-        int nl = 0, nc = 0;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int tr = 0; tr < c->Ntrans; ++tr)
+        std::vector<int> lines, conts;
+        for (int tr = 0; tr < c->Ntrans; ++tr)
+        {
+            const HostTrans& h = c->trans[tr];
+            if (la < h.NblueLoc || la >= h.NredLoc)
+                continue;
+            (h.t.type == LWHIP_LINE ? lines : conts).push_back(tr);
+        }
+        auto isOp = [&](int tr) { return !c->atoms[c->trans[tr].atom].detailed; };
+        // moment slots: the first two active atoms that have an active line here
+        std::vector<int> momentAtoms;
+        for (int tr : lines)
+            if (isOp(tr) && std::find(momentAtoms.begin(), momentAtoms.end(), c->trans[tr].atom) == momentAtoms.end())
+                momentAtoms.push_back(c->trans[tr].atom);
+        auto msOf = [&](int atom) {
+            for (int m = 0; m < (int)momentAtoms.size() && m < 2; ++m)
+                if (momentAtoms[m] == atom)
+                    return m;
+            return -1;
+        };
+        auto atomHasLines = [&](int atom) {
+            return std::find(momentAtoms.begin(), momentAtoms.end(), atom) != momentAtoms.end();
+        };
+        std::vector<int> mixed, pure;
+        for (int tr : conts)
+        {
+            const HostTrans& h = c->trans[tr];
+            bool isMixed = false;
+            if (isOp(tr))
             {
-                const HostTrans& h = c->trans[tr];
-                if (la < h.NblueLoc || la >= h.NredLoc)
-                    continue;
-                const bool isLine = h.t.type == LWHIP_LINE;
-                if ((pass == 0) != isLine)
-                    continue;
-                ent.push_back(DevLaEntry{ tr, 0 });
-                (isLine ? nl : nc)++;
+                for (int lt : lines)
+                {
+                    const HostTrans& l = c->trans[lt];
+                    if (l.atom != h.atom || !isOp(lt))
+                        continue;
+                    if (l.t.i == h.t.i || l.t.i == h.t.j || l.t.j == h.t.i || l.t.j == h.t.j)
+                        isMixed = true;
+                }
+                if (atomHasLines(h.atom) && msOf(h.atom) < 0)
+                    isMixed = true;
             }
-        hdr[la].nLine = (int16_t)nl;
-        hdr[la].nCont = (int16_t)nc;
-        c->maxL = std::max(c->maxL, nl);
-        c->maxC = std::max(c->maxC, nc);
+            (isMixed ? mixed : pure).push_back(tr);
+        }
+        std::vector<int> order = lines;
+        order.insert(order.end(), mixed.begin(), mixed.end());
+        order.insert(order.end(), pure.begin(), pure.end());
+        hdr[la].off = (int32_t)slots.size();
+        hdr[la].nLine = (int16_t)lines.size();
+        hdr[la].nMixed = (int16_t)mixed.size();
+        hdr[la].nPure = (int16_t)pure.size();
+        hdr[la]._pad = 0;
+        for (int tr : order)
+        {
+            const HostTrans& h = c->trans[tr];
+            const int l = la - h.NblueLoc;
+            DevSlot sl{};
+            sl.cs = 0;
+            sl.gi = c->levelOff[h.atom] + h.t.i;
+            sl.gj = c->levelOff[h.atom] + h.t.j;
+            sl.atom = h.atom;
+            sl.flags = (isOp(tr) ? 1 : 0) | ((h.t.type == LWHIP_LINE && h.t.prd) ? 2 : 0);
+            sl.row = h.row;
+            sl.ms = isOp(tr) ? msOf(h.atom) : -1;
+            for (int q = 0; q < 4; ++q)
+                sl.p[q] = par[(size_t)h.parOff + 4 * l + q];
+            sl.phiOff = (h.t.type == LWHIP_LINE) ? h.phiOff + (int64_t)l * c->Nrays * 2 * Ns : -1;
+            sl.rhoOff = (h.rhoOff >= 0) ? h.rhoOff + (int64_t)l * Ns : -1;
+            slots.push_back(sl);
+            slotTr.push_back(tr);
+        }
+        c->maxL = std::max(c->maxL, (int)lines.size());
+        c->maxC = std::max(c->maxC, (int)conts.size());
+
+        // row program of this wavelength's continuum set (deduplicated by signature)
+        std::vector<int> contOrder = mixed;
+        contOrder.insert(contOrder.end(), pure.begin(), pure.end());
+        std::vector<int> rowsNeeded = { 0, 1 };
+        for (int tr : order)
+        {
+            if (!isOp(tr))
+                continue;
+            const HostTrans& h = c->trans[tr];
+            const int gi = c->levelOff[h.atom] + h.t.i, gj = c->levelOff[h.atom] + h.t.j;
+            for (int r : { rowEtaA + h.atom, rowLevChi + gi, rowLevChi + gj, rowLevU + gi, rowLevU + gj })
+                if (std::find(rowsNeeded.begin(), rowsNeeded.end(), r) == rowsNeeded.end())
+                    rowsNeeded.push_back(r);
+        }
+        std::sort(rowsNeeded.begin(), rowsNeeded.end());
+        std::vector<int> key = contOrder;
+        key.push_back(-1);
+        key.insert(key.end(), rowsNeeded.begin(), rowsNeeded.end());
+        auto it = progIds.find(key);
+        if (it == progIds.end())
+        {
+            DevProgram pg{};
+            pg.rowOff = (int32_t)progRows.size();
+            pg.entOff = (int32_t)progEnts.size();
+            // continua contribute in reference (transition index) order
+            std::vector<int> byTr(contOrder.size());
+            for (size_t q = 0; q < byTr.size(); ++q)
+                byTr[q] = (int)q;
+            std::sort(byTr.begin(), byTr.end(), [&](int x, int y) { return contOrder[x] < contOrder[y]; });
+            for (int r : rowsNeeded)
+            {
+                DevProgRow pr{};
+                pr.row = (int16_t)r;
+                pr.entOff = (int32_t)(progEnts.size() - pg.entOff);
+                for (int cq : byTr)
+                {
+                    const int tr = contOrder[cq];
+                    const HostTrans& h = c->trans[tr];
+                    const int gi = c->levelOff[h.atom] + h.t.i, gj = c->levelOff[h.atom] + h.t.j;
+                    const bool op = isOp(tr);
+                    if (r == 0)
+                        progEnts.push_back(DevProgEnt{ (int16_t)cq, 0 });
+                    else if (r == 1)
+                        progEnts.push_back(DevProgEnt{ (int16_t)cq, 3 });
+                    else if (op && r == rowEtaA + h.atom)
+                        progEnts.push_back(DevProgEnt{ (int16_t)cq, 3 });
+                    else if (op && r >= rowLevChi && r < rowLevU)
+                    {
+                        if (r == rowLevChi + gi)
+                            progEnts.push_back(DevProgEnt{ (int16_t)cq, 0 });
+                        if (r == rowLevChi + gj)
+                            progEnts.push_back(DevProgEnt{ (int16_t)cq, 1 });
+                    }
+                    else if (op && r == rowLevU + gj)
+                        progEnts.push_back(DevProgEnt{ (int16_t)cq, 2 });
+                }
+                pr.nEnt = (int16_t)(progEnts.size() - pg.entOff - pr.entOff);
+                progRows.push_back(pr);
+            }
+            pg.nRows = (int32_t)(progRows.size() - pg.rowOff);
+            pg.nEnt = (int32_t)(progEnts.size() - pg.entOff);
+            if (pg.nRows > LWHIP_MAX_PROG_ROWS || pg.nEnt > LWHIP_MAX_PROG_ENTS || progs.size() >= 32767)
+                return fail(LWHIP_ERR_UNSUPPORTED, "continuum row program exceeds the kernel's LDS tables");
+            it = progIds.emplace(key, (int)progs.size()).first;
+            progs.push_back(pg);
+        }
+        hdr[la].prog = (int16_t)it->second;
     }
     if (c->maxL > 8)
         return fail(LWHIP_ERR_UNSUPPORTED, "more than 8 lines overlap at one wavelength");
@@ -403,7 +538,7 @@ int build_tables(lwhip_context* c)
     double total = 0.0;
     for (int la = 0; la < c->Nla; ++la)
     {
-        cost[la] = 1.0 + 0.35 * hdr[la].nLine + 0.12 * hdr[la].nCont;
+        cost[la] = 1.0 + 0.35 * hdr[la].nLine + 0.25 * hdr[la].nMixed + 0.03 * hdr[la].nPure;
         total += cost[la];
     }
     std::vector<int32_t> chunkLa;
@@ -435,16 +570,16 @@ int build_tables(lwhip_context* c)
         std::vector<int> slotOf(c->Ntrans, -1);
         for (int la = chunkLa[ch]; la < chunkLa[ch + 1]; ++la)
         {
-            const int n = hdr[la].nLine + hdr[la].nCont;
+            const int n = hdr[la].nLine + hdr[la].nMixed + hdr[la].nPure;
             for (int e = 0; e < n; ++e)
             {
-                DevLaEntry& en = ent[hdr[la].off + e];
-                if (slotOf[en.tr] < 0)
+                const int tr = slotTr[hdr[la].off + e];
+                if (slotOf[tr] < 0)
                 {
-                    slotOf[en.tr] = (int)chunkTrans[ch].size();
-                    chunkTrans[ch].push_back(en.tr);
+                    slotOf[tr] = (int)chunkTrans[ch].size();
+                    chunkTrans[ch].push_back(tr);
                 }
-                en.cs = slotOf[en.tr];
+                slots[hdr[la].off + e].cs = slotOf[tr];
             }
         }
         c->maxCT = std::max(c->maxCT, (int)chunkTrans[ch].size());
@@ -462,26 +597,30 @@ int build_tables(lwhip_context* c)
 
     // ---- rays per pass / scan lanes ------------------------------------------------------------------
     const int NR2 = 2 * c->Nrays;
-    int G = std::min(NR2, 1024 / Ns);
-    G = std::max(G, 1);
-    const int Genv = env_int("LWHIP_G", 0);
-    if (Genv > 0)
-        G = std::max(1, std::min(Genv, G));
-    c->P = std::max(1, env_int("LWHIP_P", 8));
     size_t ldsMax = 160 * 1024;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor > 0)
         ldsMax = prop.maxSharedMemoryPerMultiProcessor;
     auto ldsFor = [&](int g) {
         SweepArgs s{};
         s.Ns = Ns;
-        s.G = g;
-        s.P = c->P;
         s.Natom = c->Natom;
         s.NlevTot = c->NlevTot;
         s.maxC = c->maxC;
         s.maxCT = c->maxCT;
-        return sweep_lds_bytes(s);
+        return sweep_lds_bytes(s, g);
     };
+    // Rays per pass.  Two co-resident workgroups per CU hide each other's barrier and latency
+    // stalls (measured: 0.51 ms vs 0.66 ms per sweep on the north-star grid), so prefer half of
+    // the rays per pass when two such workgroups fit the 160 KB LDS; otherwise all rays at once;
+    // otherwise as many as fit one workgroup (1024 threads, LDS).
+    const int Gmax = std::max(1, std::min(NR2, 1024 / Ns));
+    int G = Gmax;
+    const int half = (NR2 + 1) / 2;
+    if (half <= Gmax && half * Ns >= 256 && 2 * ldsFor(half) <= ldsMax)
+        G = half;
+    const int Genv = env_int("LWHIP_G", 0);
+    if (Genv > 0)
+        G = std::max(1, std::min(Genv, Gmax));
     while (G > 1 && ldsFor(G) > ldsMax)
         --G;
     if (ldsFor(G) > ldsMax)
@@ -527,7 +666,10 @@ int build_tables(lwhip_context* c)
     HIP_TRY(c->par.upload(par));
     HIP_TRY(c->dtrans.upload(dt));
     HIP_TRY(c->laHdr.upload(hdr));
-    HIP_TRY(c->laEnt.upload(ent));
+    HIP_TRY(c->slots.upload(slots));
+    HIP_TRY(c->progs.upload(progs));
+    HIP_TRY(c->progRows.upload(progRows));
+    HIP_TRY(c->progEnts.upload(progEnts));
     HIP_TRY(c->chunkLa.upload(chunkLa));
     HIP_TRY(c->trOff.upload(trOff));
     HIP_TRY(c->trRow.upload(trRow));
@@ -576,9 +718,12 @@ int alloc_state(lwhip_context* c)
     // reduce buffer: [Ntrans,4,Ns] partial sums followed by one (dJMax, idx) slot per shard
     HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize));
     HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
+    HIP_TRY(c->red8.alloc((size_t)std::max(c->Ntrans, 1) * LWHIP_REDUCE_SPLIT * 4 * Ns));
     c->gatherHost.assign(2 * (size_t)c->worldSize, 0.0);
     HIP_TRY(c->dJ.alloc(Nla));
     HIP_TRY(c->status.alloc(1));
+    HIP_TRY(c->stamps.alloc((size_t)c->nChunks * 12));
+    HIP_TRY(hipMemset(c->stamps.p, 0, c->stamps.n * sizeof(long long)));
     if (c->prob.zLowerBc.type == LWHIP_BC_CALLABLE)
     {
         HIP_TRY(c->lowerBcData.alloc(Nla * c->prob.zLowerBc.Nmu));
@@ -597,7 +742,7 @@ int alloc_state(lwhip_context* c)
 #define D2H(dst, src, count)                                                                           \
     HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyDeviceToHost, c->stream))
 
-SweepArgs make_sweep_args(lwhip_context* c, bool upOnly, int lambdaIterate)
+int build_sweep_args(lwhip_context* c)
 {
     SweepArgs a{};
     a.Ns = c->Ns;
@@ -606,24 +751,18 @@ SweepArgs make_sweep_args(lwhip_context* c, bool upOnly, int lambdaIterate)
     a.Natom = c->Natom;
     a.NlevTot = c->NlevTot;
     a.Ntrans = c->Ntrans;
-    a.nRaysActive = upOnly ? c->Nrays : 2 * c->Nrays;
-    a.G = std::min(c->G, a.nRaysActive);
-    a.P = c->P;
     a.maxC = c->maxC;
     a.maxCT = c->maxCT;
-    a.lambdaIterate = lambdaIterate;
     a.lowerBc = c->prob.zLowerBc.type;
     a.upperBc = c->prob.zUpperBc.type;
     a.lowerNmu = c->prob.zLowerBc.Nmu;
     a.upperNmu = c->prob.zUpperBc.Nmu;
-    a.laShardStart = c->laStart;
     a.storeDepth = c->prob.storeDepthData ? 1 : 0;
     a.height = c->height.p;
     a.temperature = c->temperature.p;
     a.muz = c->muz.p;
     a.wmu = c->wmu.p;
     a.wavelength = c->wavelength.p;
-    a.rayList = upOnly ? c->rayUp.p : c->rayAll.p;
     a.lowerIdx = c->lowerIdx.p;
     a.upperIdx = c->upperIdx.p;
     a.lowerBcData = c->lowerBcData.p;
@@ -641,14 +780,29 @@ SweepArgs make_sweep_args(lwhip_context* c, bool upOnly, int lambdaIterate)
     a.wphi = c->wphi.p;
     a.phi = c->phi.p;
     a.rho = c->rho.p;
-    a.par = c->par.p;
-    a.trans = c->dtrans.p;
     a.laHdr = c->laHdr.p;
-    a.laEnt = c->laEnt.p;
+    a.slots = c->slots.p;
+    a.progs = c->progs.p;
+    a.progRows = c->progRows.p;
+    a.progEnts = c->progEnts.p;
     a.chunkLa = c->chunkLa.p;
     a.partial = c->partial.p;
     a.dJ = c->dJ.p;
-    return a;
+    a.stamps = c->stamps.p;
+    c->hargs = a;
+    std::vector<SweepArgs> v(1, a);
+    HIP_TRY(c->dargs.upload(v));
+    return LWHIP_OK;
+}
+
+SweepDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
+{
+    SweepDyn d{};
+    d.nRaysActive = upOnly ? c->Nrays : 2 * c->Nrays;
+    d.G = std::min(c->G, d.nRaysActive);
+    d.lambdaIterate = lambdaIterate;
+    d.rayList = upOnly ? c->rayUp.p : c->rayAll.p;
+    return d;
 }
 
 int collect_profile(lwhip_context* c)
@@ -757,6 +911,9 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     st = alloc_state(c);
     if (st != LWHIP_OK)
         return bail(st);
+    st = build_sweep_args(c);
+    if (st != LWHIP_OK)
+        return bail(st);
     st = lwhip_upload(c, LWHIP_ALL_INPUTS);
     if (st != LWHIP_OK)
         return bail(st);
@@ -770,6 +927,19 @@ int lwhip_destroy(lwhip_context* c)
         return LWHIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (std::getenv("LWHIP_DUMP_STAMPS") && c->stamps.n)
+    {
+        std::vector<long long> h(c->stamps.n);
+        (void)hipMemcpy(h.data(), c->stamps.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        double sum[12] = { 0 };
+        for (size_t i = 0; i < h.size(); ++i)
+            sum[i % 12] += (double)h[i];
+        std::fprintf(stderr, "lwhip stamps (mean cycles per chunk, last launch; nChunks=%d G=%d maxCT=%d maxC=%d lds=%zu):",
+                     c->nChunks, c->G, c->maxCT, c->maxC, sweep_lds_bytes(c->hargs, c->G));
+        for (int i = 0; i < 12; ++i)
+            std::fprintf(stderr, " [%d]=%.0f", i, sum[i] / c->nChunks);
+        std::fprintf(stderr, "\n");
+    }
     delete c;
     return LWHIP_OK;
 }
@@ -922,7 +1092,7 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->dJ.p, 0, c->dJ.n * sizeof(double), c->stream));
-    SweepArgs a = make_sweep_args(c, false, lambdaIterate);
+    const SweepDyn dyn = make_dyn(c, false, lambdaIterate);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling)
     {
@@ -930,7 +1100,7 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    HIP_TRY(launch_sweep(a, c->prob.formalSolver, c->maxL, true, c->nChunks, c->stream));
+    HIP_TRY(launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, true, c->nChunks, c->stream));
     if (c->profiling)
     {
         HIP_TRY(hipEventRecord(e1, c->stream));
@@ -945,6 +1115,7 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         r.trOff = c->trOff.p;
         r.trRow = c->trRow.p;
         r.partial = c->partial.p;
+        r.red8 = c->red8.p;
         r.red = c->red.p;
         HIP_TRY(launch_reduce(r, c->stream));
     }
@@ -1031,8 +1202,8 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    SweepArgs a = make_sweep_args(c, upOnly != 0, 0);
-    HIP_TRY(launch_sweep(a, c->prob.formalSolver, c->maxL, false, c->nChunks, c->stream));
+    const SweepDyn dyn = make_dyn(c, upOnly != 0, 0);
+    HIP_TRY(launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, false, c->nChunks, c->stream));
     return LWHIP_OK;
 }
 

@@ -39,45 +39,73 @@ struct DevTrans
 //   line:      { hnu_4pi*Bij, wlambda, Bji/Bij, Aji/Bji }      LwTransition.hpp:107-113,128-131; LwAtom.hpp:97-105
 //   continuum: { alpha(lt),   wlambda/lambda*pi4_h, twoHc/lambda^3, 0 }   LwTransition.hpp:132-142; LwAtom.hpp:107-115
 
-// Per-wavelength activity header + entries.  Entries of one wavelength are stored lines first
-// (reference order) then continua (reference order).
+// Per-wavelength activity: header + slot records.  Slots of one wavelength are stored as
+//   [lines (reference order)] [mixed continua] [pure continua]
+// where a continuum of an active atom is "mixed" when an active line of the same atom shares one
+// of its levels at this wavelength (its Gamma terms then depend on the ray through the line
+// opacity and it is integrated ray by ray like a line); every other continuum is "pure": all of
+// its ray dependence is in I and Psi*, so its Gamma / rate integrals follow from the angle moments
+// J, M1 = sum w Psi*, Meta = sum w Psi* eta_line.
 struct DevLaHeader
 {
-    int32_t off;        // first entry
+    int32_t off;        // first slot record
     int16_t nLine;
-    int16_t nCont;
+    int16_t nMixed;
+    int16_t nPure;
+    int16_t prog;       // row program of the continuum sums
+    int32_t _pad;
 };
-struct DevLaEntry
+struct DevSlot          // 96 bytes, read with scalar loads
 {
-    int32_t tr;         // global transition index
     int32_t cs;         // chunk-local accumulator slot
+    int32_t gi, gj;     // global level rows
+    int32_t atom;
+    int32_t flags;      // bit 0: atom is active (op); bit 1: rhoPrd multiplies gij
+    int32_t row;        // lines: row in the wphi pool; continua: row in the nStar-ratio pool
+    int32_t ms;         // moment slot (0/1) of the atom's active lines at this wavelength, or -1
+    int32_t _pad;
+    double p[4];        // per-(transition, lt) params (see above)
+    int64_t phiOff;     // lines: offset of this wavelength's [Nrays,2,Ns] block in the phi pool
+    int64_t rhoOff;     // PRD lines: offset of this wavelength's [Ns] row in the rho pool
+    int64_t _pad2[2];
 };
+// Row program: which continua feed which ray-independent per-depth row.  Rows are laid out
+// contiguously in LDS as [chiC][etaC][etaA x Natom][levChi x NlevTot][levU x NlevTot].
+struct DevProgRow
+{
+    int16_t row;        // row id in the layout above
+    int16_t nEnt;
+    int32_t entOff;     // first entry (relative to the program's entry base)
+};
+struct DevProgEnt
+{
+    int16_t c;          // continuum ordinal at this wavelength (0 .. nMixed+nPure-1)
+    int16_t kind;       // 0: +chi_c  1: -chi_c  2: +Uji_c  3: +eta_c
+};
+struct DevProgram
+{
+    int32_t rowOff, nRows, entOff, nEnt;
+};
+enum { LWHIP_MAX_PROG_ROWS = 80, LWHIP_MAX_PROG_ENTS = 320 };
 
+// Static part of the sweep arguments; lives in device memory (keeps SGPR pressure low).
 struct SweepArgs
 {
-    // sizes
     int32_t Ns, Nrays, Nla, Natom, NlevTot, Ntrans;
-    int32_t nRaysActive;   // 2*Nrays, or Nrays when upOnly
-    int32_t G;             // rays per pass
-    int32_t P;             // scan lanes per ray
     int32_t maxC;          // max continua active at one wavelength
     int32_t maxCT;         // accumulator slots per chunk
-    int32_t lambdaIterate;
     int32_t lowerBc, upperBc, lowerNmu, upperNmu;
-    int32_t laShardStart;  // first wavelength of this context's shard
     int32_t storeDepth;
-    // atmosphere
+    int32_t _pad;
     const double* height;
     const double* temperature;
     const double* muz;
     const double* wmu;
     const double* wavelength;
-    const int32_t* rayList;        // [nRaysActive] -> r = 2*mu + toObs
     const int32_t* lowerIdx;       // [Nrays,2] CALLABLE
     const int32_t* upperIdx;
     const double* lowerBcData;     // [Nla, lowerNmu]
     const double* upperBcData;
-    // spectrum / background
     const double* bgChi;
     const double* bgEta;
     const double* bgSca;
@@ -86,29 +114,40 @@ struct SweepArgs
     double* depthChi;
     double* depthEta;
     double* depthI;
-    // atoms
     const double* n;               // [NlevTot, Ns] pool
     const double* ratio;           // [Ncont, Ns]  nStar_i / nStar_j
     const double* wphi;            // [Nline, Ns]
     const double* phi;             // pool
     const double* rho;             // pool
-    const double* par;             // pool, 4 doubles per (transition, lt)
-    const DevTrans* trans;
-    // activity
     const DevLaHeader* laHdr;      // [Nla]
-    const DevLaEntry* laEnt;
+    const DevSlot* slots;
+    const DevProgram* progs;
+    const DevProgRow* progRows;
+    const DevProgEnt* progEnts;
     const int32_t* chunkLa;        // [nChunks+1] wavelength boundaries
-    // outputs
     double* partial;               // [nChunks*maxCT, 4, Ns]
     double* dJ;                    // [Nla]
+    long long* stamps;             // [nChunks, 12] diagnostic build only (-DLWHIP_STAMPS)
 };
 
+// Per-launch part, passed by value.
+struct SweepDyn
+{
+    int32_t nRaysActive;   // 2*Nrays, or Nrays when upOnly
+    int32_t G;             // rays per pass
+    int32_t lambdaIterate;
+    int32_t _pad;
+    const int32_t* rayList;        // [nRaysActive] -> r = 2*mu + toObs
+};
+
+enum { LWHIP_REDUCE_SPLIT = 8 };
 struct ReduceArgs
 {
     int32_t Ns, Ntrans, maxCT;
     const int32_t* trOff;          // [Ntrans+1]
     const int32_t* trRow;          // slab rows (chunk*maxCT + cs) in chunk order
     const double* partial;
+    double* red8;                  // [Ntrans, SPLIT, 4, Ns] stage-1 sums
     double* red;                   // [Ntrans, 4, Ns]
 };
 
@@ -129,9 +168,9 @@ struct ApplyArgs
 };
 
 // launch helpers implemented in lwhip_kernels.hip
-size_t sweep_lds_bytes(const SweepArgs& a);
-hipError_t launch_sweep(const SweepArgs& a, int solver, int maxL, bool rates, int nChunks,
-                        hipStream_t stream);
+size_t sweep_lds_bytes(const SweepArgs& a, int G);
+hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn,
+                        int solver, int maxL, bool rates, int nChunks, hipStream_t stream);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream);
 hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2,

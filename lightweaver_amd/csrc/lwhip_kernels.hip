@@ -152,161 +152,398 @@ DEVINL void lds_add(double* addr, double v)
     unsafeAtomicAdd(addr, v);
 }
 
-// ---- LDS layout ------------------------------------------------------------------------------------
-// [GNs] x5 : sChi(->b->I)  sS  sA(dchi->e->wI)  sDtau  sDS
-// [Ns]  x7 : height temperature Jdag chiC etaC sca J
-// zeroed   : etaA[Natom][Ns] levChi[NlevTot][Ns] levU[NlevTot][Ns]
-// [maxC][Ns] Vji of the active continua
-// [maxCT][4][Ns] Gamma/rate accumulators of the chunk
-// [G*P*2] scan carries
-__host__ __device__ inline size_t lds_doubles(int Ns, int G, int P, int Natom, int NlevTot, int maxC,
-                                              int maxCT)
+// Workgroup barrier that orders LDS traffic only: outstanding global loads (the software prefetch
+// of the next wavelength) and stores (J, I, depth data) stay in flight across it, which a
+// __syncthreads() -- s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier -- would drain.
+DEVINL void lds_barrier()
 {
-    return (size_t)5 * G * Ns + (size_t)7 * Ns + (size_t)(Natom + 2 * NlevTot) * Ns
-           + (size_t)maxC * Ns + (size_t)maxCT * 4 * Ns + (size_t)G * P * 2 + 16;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-size_t sweep_lds_bytes(const SweepArgs& a)
+// Address-space-qualified views of the pointers that live in the (device-memory) argument block:
+// without them the loads compile to flat_load, which counts on lgkmcnt and so stalls every LDS
+// barrier behind the HBM latency of the prefetches; tables read uniformly become scalar loads.
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define CONST_AS __attribute__((address_space(4)))
+#define GCD(p) ((const GLOBAL_AS double*)(p))
+#define GD(p) ((GLOBAL_AS double*)(p))
+#define CTAB(T, p) ((const CONST_AS T*)(p))
+DEVINL const CONST_AS SweepArgs* launder_args(const SweepArgs* p)
 {
-    return sizeof(double) * lds_doubles(a.Ns, a.G, a.P, a.Natom, a.NlevTot, a.maxC, a.maxCT);
+    const CONST_AS SweepArgs* q = (const CONST_AS SweepArgs*)p;
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
+template <typename T> DEVINL T ld_c(const CONST_AS T* p)
+{
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (5 VALU ops instead of the ~15 of an IEEE divide).
+// Used where the reference divides by a quantity that is shared by several expressions; the
+// results differ from a correctly rounded divide by at most a couple of ulp (tolerance 1e-9).
+DEVINL double d_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// cent_deriv (Bezier.hpp:58-65) with the three reciprocals supplied
+DEVINL double d_cent_deriv_r(double dsuw, double dsdw, double ruw, double rdw, double rsum,
+                             double yuw, double y0, double ydw)
+{
+    const double S0 = (ydw - y0) * rdw;
+    const double Suw = (y0 - yuw) * ruw;
+    const double P0 = fabs((Suw * dsdw + S0 * dsuw) * rsum);
+    return (copysign(1.0, S0) + copysign(1.0, Suw)) * fmin(fabs(Suw), fmin(fabs(S0), 0.5 * P0));
+}
+
+// Bezier3_coeffs (Bezier.hpp:81-127); the dt > 30 branch is the exact branch with edt = 0
+DEVINL void d_bezier3_coeffs_r(double dt, double& alpha, double& beta, double& gamma, double& delta,
+                               double& edt)
+{
+    const double dt2 = dt * dt;
+    const double dt3 = dt2 * dt;
+    if (dt < 5e-2)
+    {
+        edt = 1.0 - dt + 0.5 * dt2 - dt3 * (1.0 / 6.0);
+        alpha = 0.25 * dt - 0.2 * dt2 + dt3 * (1.0 / 12.0);
+        beta = 0.25 * dt - 0.05 * dt2 + dt3 * (1.0 / 120.0);
+        gamma = 0.25 * dt - 0.15 * dt2 + 0.05 * dt3;
+        delta = 0.25 * dt - 0.1 * dt2 + 0.025 * dt3;
+    }
+    else
+    {
+        edt = (dt > 30.0) ? 0.0 : exp(-dt);
+        const double r3 = d_rcp(dt3);
+        alpha = (6.0 - edt * (6.0 + 6.0 * dt + 3 * dt2 + dt3)) * r3;
+        beta = (6.0 * edt - 6.0 + 6.0 * dt - 3.0 * dt2 + dt3) * r3;
+        gamma = 3.0 * (2.0 * dt - 6.0 + edt * (6.0 + 4.0 * dt + dt2)) * r3;
+        delta = 3.0 * (6.0 - 4.0 * dt + dt2 - 2.0 * edt * (3.0 + dt)) * r3;
+    }
+}
+
+// ---- LDS layout (doubles) ------------------------------------------------------------------------
+// [G*Ns] x4 : sChi(->e ->w I)  sS(->w Psi)  sDS(->w Psi eta_0)  sB(->I ->w Psi eta_1)
+// [Ns]      : dh rdh rsumh temp J M1 Meta0 Meta1 | Jdag sca bgChi bgEta (inputs, prefetched)
+// rows      : chiC etaC etaA[Natom] levChi[NlevTot] levU[NlevTot]      (row-program targets)
+// [maxC][Ns] Vji   [maxC][Ns] chi_c   [maxCT][4][Ns] accumulators   (populations n: global, L1)
+// program   : rows + entries of the current row program
+__host__ __device__ inline size_t lds_doubles(int Ns, int G, int Natom, int NlevTot, int maxC, int maxCT)
+{
+    return (size_t)4 * G * Ns + (size_t)12 * Ns + (size_t)(2 + Natom + 2 * NlevTot) * Ns
+           + (size_t)2 * maxC * Ns + (size_t)maxCT * 4 * Ns
+           + (LWHIP_MAX_PROG_ROWS * sizeof(DevProgRow) + LWHIP_MAX_PROG_ENTS * sizeof(DevProgEnt)) / 8 + 8
+           + 64 + 64 + 32 + 2 * maxC;
+}
+
+size_t sweep_lds_bytes(const SweepArgs& a, int G)
+{
+    return sizeof(double) * lds_doubles(a.Ns, G, a.Natom, a.NlevTot, a.maxC, a.maxCT);
 }
 
 // ---- the sweep ---------------------------------------------------------------------------------------
 // intensity_core_opt (SimdFullIterationTemplates.hpp:238-487) for every wavelength of the chunk,
 // with UpdateRates = ComputeOperator = RATES, PrdRatesOnly = false.
+#ifdef LWHIP_STAMPS
+#define STAMP(i)                                                                                       \
+    do                                                                                                 \
+    {                                                                                                  \
+        if (t == 0)                                                                                    \
+        {                                                                                              \
+            const long long now__ = clock64();                                                         \
+            stampAcc[i] += now__ - stampLast;                                                          \
+            stampLast = now__;                                                                         \
+        }                                                                                              \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 template <int SOLVER, int MAXL, bool RATES>
-__global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
+__global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict__ ap, const SweepDyn dyn)
 {
     extern __shared__ double lds[];
+#ifdef LWHIP_STAMPS
+    long long stampAcc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long stampLast = clock64();
+#endif
+    const SweepArgs& a = *ap;
     const int Ns = a.Ns;
-    const int GNs = a.G * Ns;
+    const int G = dyn.G;
+    const int GNs = G * Ns;
     const int T = blockDim.x;
     const int t = threadIdx.x;
     const int Nrays = a.Nrays;
+    const int Natom = a.Natom;
+    const int NlevTot = a.NlevTot;
+    const int maxC = a.maxC;
+    const int maxCT = a.maxCT;
+    // Pointers are re-read from the (laundered) argument block at each use site instead of being
+    // kept in SGPRs for the whole kernel: the block is tiny and scalar-cache resident, whereas
+    // ~30 long-lived pointers forced hundreds of SGPR spill moves per wavelength.
+#define ARGS (*launder_args(ap))
+#define gPhi GCD(ARGS.phi)
+#define gRho GCD(ARGS.rho)
+#define gRatio GCD(ARGS.ratio)
+#define gWphi GCD(ARGS.wphi)
+#define gBgChi GCD(ARGS.bgChi)
+#define gBgEta GCD(ARGS.bgEta)
+#define gBgSca GCD(ARGS.bgSca)
+#define gN GCD(ARGS.n)
+#define gHeight GCD(ARGS.height)
+#define gTemperature GCD(ARGS.temperature)
+#define gJ GD(ARGS.J)
+#define gI GD(ARGS.I)
+#define gDepthChi GD(ARGS.depthChi)
+#define gDepthEta GD(ARGS.depthEta)
+#define gDepthI GD(ARGS.depthI)
+#define gPartial GD(ARGS.partial)
+#define cMuz CTAB(double, ARGS.muz)
+#define cWmu CTAB(double, ARGS.wmu)
+#define cWavelength CTAB(double, ARGS.wavelength)
+#define cRayList CTAB(int32_t, dyn.rayList)
+#define cChunkLa CTAB(int32_t, ARGS.chunkLa)
+#define cLaHdr CTAB(DevLaHeader, ARGS.laHdr)
+#define cSlots CTAB(DevSlot, ARGS.slots)
+#define cProgs CTAB(DevProgram, ARGS.progs)
 
     double* sChi = lds;
     double* sS = sChi + GNs;
-    double* sA = sS + GNs;
-    double* sDtau = sA + GNs;
-    double* sDS = sDtau + GNs;
-    double* sK = sDS + GNs;
-    double* sHgt = sK;
-    double* sTemp = sK + Ns;
-    double* sJdag = sK + 2 * Ns;
-    double* sChiC = sK + 3 * Ns;
-    double* sEtaC = sK + 4 * Ns;
-    double* sSca = sK + 5 * Ns;
-    double* sJ = sK + 6 * Ns;
-    double* sEtaA = sK + 7 * Ns;
-    double* sLevChi = sEtaA + a.Natom * Ns;
-    double* sLevU = sLevChi + a.NlevTot * Ns;
-    double* sVji = sLevU + a.NlevTot * Ns;
-    double* sAcc = sVji + a.maxC * Ns;
-    double* sScan = sAcc + a.maxCT * 4 * Ns;
-    double* sB = sChi; // alias: chi column is dead once the optical depths exist
-    double* sE = sA;   // alias: dchi is dead once the optical depths exist
+    double* sDS = sS + GNs;
+    double* sB = sDS + GNs;
+    double* sE = sChi; // alias: the chi column is dead once the optical depths exist
+    double* sK = sB + GNs;
+    double* sDh = sK;
+    double* sRdh = sK + Ns;
+    double* sRsum = sK + 2 * Ns;
+    double* sTemp = sK + 3 * Ns;
+    double* sJ = sK + 4 * Ns;   // sJ, sM1, sMeta0, sMeta1 are contiguous: moment m at sJ + m*Ns
+    double* sIn = sK + 8 * Ns;  // Jdag, sca, bgChi, bgEta are contiguous: input m at sIn + m*Ns
+    double* sJdag = sIn;
+    double* sSca = sIn + Ns;
+    double* sBgChi = sIn + 2 * Ns;
+    double* sBgEta = sIn + 3 * Ns;
+    double* sRows = sK + 12 * Ns;
+    double* sChiC = sRows;
+    double* sEtaC = sRows + Ns;
+    double* sEtaA = sRows + 2 * Ns;
+    double* sLevChi = sEtaA + Natom * Ns;
+    double* sLevU = sLevChi + NlevTot * Ns;
+    double* sVji = sLevU + NlevTot * Ns;
+    double* sChiCo = sVji + maxC * Ns;
+    double* sAcc = sChiCo + maxC * Ns;
+    DevProgRow* sProgRows = (DevProgRow*)(sAcc + maxCT * 4 * Ns);
+    DevProgEnt* sProgEnts = (DevProgEnt*)(sProgRows + LWHIP_MAX_PROG_ENTS * 0 + LWHIP_MAX_PROG_ROWS);
+    double* sRayMuz = (double*)(sProgEnts + LWHIP_MAX_PROG_ENTS); // [64] muz of each active ray
+    double* sRayW = sRayMuz + 64;                                  // [64] 0.5 * wmu
+    int* sRayId = (int*)(sRayW + 64);                               // [64] r = 2 mu + toObs
+    double* sCp2 = (double*)(sRayId + 64);                          // [maxC] 2hc/lambda^3 of continuum c
+    int* sCgj = (int*)(sCp2 + maxC);                                // [maxC] upper level row of continuum c
 
+    // idx / Ns for idx * Ns < 2^32 as one mul_hi (magic = ceil(2^32 / Ns))
+    const unsigned divMagic = (unsigned)((0x100000000ull + (unsigned)Ns - 1) / (unsigned)Ns);
+    auto divNs = [&](int idx) { return (int)__umulhi((unsigned)idx, divMagic); };
     const bool isPoint = t < GNs;
     const int rl = t / Ns;
     const int k = t - rl * Ns;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int nWaves = T >> 6;
 
     const int chunk = blockIdx.x;
-    const int la0 = a.chunkLa[chunk];
-    const int la1 = a.chunkLa[chunk + 1];
+    const int la0 = cChunkLa[chunk];
+    const int la1 = cChunkLa[chunk + 1];
 
+    // ---- once per chunk: geometry, temperature, populations, accumulators ---------------------------
     if (t < Ns)
     {
-        sHgt[t] = a.height[t];
-        sTemp[t] = a.temperature[t];
+        sTemp[t] = gTemperature[t];
+        double dh = 0.0, rdh = 0.0, rsum = 0.0;
+        if (t < Ns - 1)
+        {
+            dh = fabs(gHeight[t] - gHeight[t + 1]);
+            rdh = 1.0 / dh;
+        }
+        if (t >= 1 && t < Ns - 1)
+            rsum = 1.0 / (fabs(gHeight[t - 1] - gHeight[t]) + dh);
+        sDh[t] = dh;       // |h[k] - h[k+1]|: interval between k and k+1
+        sRdh[t] = rdh;
+        sRsum[t] = rsum;   // 1 / (dh[k-1] + dh[k])
     }
     if (RATES)
     {
-        for (int idx = t; idx < a.maxCT * 4 * Ns; idx += T)
+        for (int idx = t; idx < maxCT * 4 * Ns; idx += T)
             sAcc[idx] = 0.0;
     }
+    if (t < dyn.nRaysActive && t < 64)
+    {
+        const int r = cRayList[t];
+        sRayId[t] = r;
+        sRayMuz[t] = cMuz[r >> 1];
+        sRayW[t] = 0.5 * cWmu[r >> 1];
+    }
+    // total quadrature weight of the active rays, in ray order
+    double Wsum = 0.0;
+    for (int r = 0; r < dyn.nRaysActive; ++r)
+        Wsum += 0.5 * cWmu[cRayList[r] >> 1];
+    int curProg = -1;
+    int progRows = 0;
+    // per-depth inputs of a wavelength: input m (Jdag, sca, bgChi, bgEta) row kk is owned by thread
+    // m*Ns + kk, which loads it one wavelength ahead
+    const int inM = t / Ns;
+    const int inK = t - inM * Ns;
+    const bool inOwner = t < 4 * Ns;
+    auto load_input = [&](int la_) -> double {
+        const size_t o = (size_t)la_ * Ns + inK;
+        return (inM == 0) ? gJ[o] : (inM == 1) ? gBgSca[o] : (inM == 2) ? gBgChi[o] : gBgEta[o];
+    };
+    for (int task = t; task < 4 * Ns; task += T) // prologue (also when T < 4 Ns)
+    {
+        const int m = divNs(task), kk = task - m * Ns;
+        const size_t o = (size_t)la0 * Ns + kk;
+        sIn[task] = (m == 0) ? gJ[o] : (m == 1) ? gBgSca[o] : (m == 2) ? gBgChi[o] : gBgEta[o];
+    }
+    const bool pfInputs = (T >= 4 * Ns); // otherwise every wavelength reloads synchronously
+    double pfK = 0.0, pfRatio = 0.0;
+    bool havePfRatio = false;
+    double pfPhi[MAXL], pfWphi[MAXL];
+    bool havePfPhi = false;
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l)
+    {
+        pfPhi[l] = 0.0;
+        pfWphi[l] = 0.0;
+    }
     __syncthreads();
+    STAMP(0);
 
+    DevLaHeader hNext = ld_c(cLaHdr + la0);
     for (int la = la0; la < la1; ++la)
     {
-        const DevLaHeader h = a.laHdr[la];
-        const DevLaEntry* __restrict__ ent = a.laEnt + h.off;
+        const DevLaHeader h = hNext;
+        const bool lastLa = (la + 1 >= la1);
+        if (!lastLa)
+            hNext = ld_c(cLaHdr + la + 1);
+        const CONST_AS DevSlot* slots = cSlots + h.off;
+        const CONST_AS DevSlot* slotsNext = cSlots + hNext.off;
         const int nLine = h.nLine;
-        const int nCont = h.nCont;
-        const double wav = a.wavelength[la];
+        const int nPerRayC = h.nMixed;
+        const int nCont = h.nMixed + h.nPure;
+        const double wav = cWavelength[la];
         const double hc_kl = HC_K / wav;
 
-        // ---- per-wavelength, ray-independent part -----------------------------------------------
-        if (RATES)
+        // ---- ray-independent part ---------------------------------------------------------------------
+        if (h.prog != curProg) // uniform: the active continuum set changed -> stage its row program
         {
-            const int zeroCount = (a.Natom + 2 * a.NlevTot) * Ns;
-            for (int idx = t; idx < zeroCount; idx += T)
-                sEtaA[idx] = 0.0;
+            const DevProgram pg = ld_c(cProgs + h.prog);
+            for (int idx = t; idx < pg.nRows; idx += T)
+                sProgRows[idx] = a.progRows[pg.rowOff + idx];
+            for (int idx = t; idx < pg.nEnt; idx += T)
+                sProgEnts[idx] = a.progEnts[pg.entOff + idx];
+            curProg = h.prog;
+            progRows = pg.nRows;
         }
-        if (t < Ns)
+        if (!pfInputs && la != la0)
         {
-            const size_t o = (size_t)la * Ns + t;
-            sJdag[t] = a.J[o];
-            sChiC[t] = a.bgChi[o];
-            sEtaC[t] = a.bgEta[o];
-            sSca[t] = a.bgSca[o];
+            for (int task = t; task < 4 * Ns; task += T)
+            {
+                const int m = divNs(task), kk = task - m * Ns;
+                const size_t o = (size_t)la * Ns + kk;
+                sIn[task] = (m == 0) ? gJ[o] : (m == 1) ? gBgSca[o] : (m == 2) ? gBgChi[o] : gBgEta[o];
+            }
         }
-        // continuum Vji = gij * alpha,  gij = nStar_i/nStar_j * exp(-hc/(k lambda T))
+        // software prefetch of the next wavelength's per-depth inputs (consumed after this one)
+        if (pfInputs && inOwner && !lastLa)
+            pfK = load_input(la + 1);
+        // continua: Vji = gij alpha with gij = nStar_i/nStar_j exp(-hc/(k lambda T))
         // (Atom::setup_wavelength LwAtom.hpp:107-115, Transition::uv LwTransition.hpp:132-142)
+        // and chi_c = n_i Vij - n_j Vji (chi_eta_aux_accum :70)
+        if (t < nCont)
+        {
+            sCp2[t] = slots[nLine + t].p[2];
+            sCgj[t] = slots[nLine + t].gj;
+        }
         for (int idx = t; idx < nCont * Ns; idx += T)
         {
-            const int c = idx / Ns;
+            const int c = divNs(idx);
             const int kk = idx - c * Ns;
-            const DevTrans& tr = a.trans[ent[nLine + c].tr];
-            const double* par = a.par + tr.parOff + 4 * (la - tr.Nblue);
-            const double gij = a.ratio[(size_t)tr.row * Ns + kk] * exp(-hc_kl / sTemp[kk]);
-            sVji[c * Ns + kk] = gij * par[0];
+            const CONST_AS DevSlot& sl = slots[nLine + c];
+            const double ratio = (havePfRatio && idx == t) ? pfRatio : gRatio[(size_t)sl.row * Ns + kk];
+            const double gij = ratio * exp(-hc_kl / sTemp[kk]);
+            const double vji = gij * sl.p[0];
+            sVji[c * Ns + kk] = vji;
+            sChiCo[c * Ns + kk] = gN[sl.gi * Ns + kk] * sl.p[0] - gN[sl.gj * Ns + kk] * vji;
         }
-        __syncthreads();
-        // chi_eta_aux_accum for the continua (SimdFullIterationTemplates.hpp:59-109): totals and
-        // per-level / per-atom sums, once per depth point
-        if (t < Ns)
+        havePfRatio = false;
+        if (!lastLa)
         {
-            double chi = sChiC[t], eta = sEtaC[t];
-            for (int c = 0; c < nCont; ++c)
+            const int nContN = hNext.nMixed + hNext.nPure;
+            if (t < nContN * Ns)
             {
-                const DevTrans& tr = a.trans[ent[nLine + c].tr];
-                const double* par = a.par + tr.parOff + 4 * (la - tr.Nblue);
-                const double Vij = par[0];
-                const double Vji = sVji[c * Ns + t];
-                const double Uji = par[2] * Vji;
-                const double ni = a.n[(size_t)tr.gi * Ns + t];
-                const double nj = a.n[(size_t)tr.gj * Ns + t];
-                const double x = ni * Vij - nj * Vji;
-                const double em = nj * Uji;
-                if (RATES && tr.op)
-                {
-                    sLevChi[tr.gi * Ns + t] += x;
-                    sLevChi[tr.gj * Ns + t] -= x;
-                    sLevU[tr.gj * Ns + t] += Uji;
-                    sEtaA[tr.atom * Ns + t] += em;
-                }
-                chi += x;
-                eta += em;
+                const int c = t / Ns;
+                pfRatio = gRatio[(size_t)slotsNext[hNext.nLine + c].row * Ns + (t - c * Ns)];
             }
-            sChiC[t] = chi;
-            sEtaC[t] = eta;
+            havePfRatio = true;
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(1);
+        // row program: totals, per-atom emissivity and per-level sums over the continua, one
+        // (row, depth) task per thread, continua added in reference order
+        for (int task = t; task < progRows * Ns; task += T)
+        {
+            const int ri = divNs(task);
+            const int kk = task - ri * Ns;
+            const DevProgRow pr = sProgRows[ri];
+            double v = 0.0;
+            if (pr.row == 0)
+                v = sBgChi[kk];
+            else if (pr.row == 1)
+                v = sBgEta[kk];
+            for (int e = 0; e < pr.nEnt; ++e)
+            {
+                const DevProgEnt en = sProgEnts[pr.entOff + e];
+                const double x = sChiCo[en.c * Ns + kk];
+                const double uji = sCp2[en.c] * sVji[en.c * Ns + kk];
+                if (en.kind == 0)
+                    v += x;
+                else if (en.kind == 1)
+                    v -= x;
+                else if (en.kind == 2)
+                    v += uji;
+                else
+                    v += gN[sCgj[en.c] * Ns + kk] * uji;
+            }
+            sRows[pr.row * Ns + kk] = v;
+        }
+        lds_barrier();
+        STAMP(2);
 
         // ---- passes over groups of G rays -----------------------------------------------------------
-        for (int g0 = 0; g0 < a.nRaysActive; g0 += a.G)
+        for (int g0 = 0; g0 < dyn.nRaysActive; g0 += G)
         {
-            const int nr = min(a.G, a.nRaysActive - g0);
+            const int nr = min(G, dyn.nRaysActive - g0);
             const bool active = isPoint && rl < nr;
             int mu = 0, toObs = 0;
             if (active)
             {
-                const int r = a.rayList[g0 + rl];
+                const int r = sRayId[g0 + rl];
                 mu = r >> 1;
                 toObs = r & 1;
             }
-            double chi = 1.0, S = 0.0, eta = 0.0;
-            double Vij[MAXL], Vji[MAXL], xl[MAXL], el[MAXL];
+            const double muz = active ? sRayMuz[g0 + rl] : 1.0;
+            const double halfwmu = active ? sRayW[g0 + rl] : 0.0;
+            double chi = 1.0, S = 0.0, eta = 0.0, rchi = 1.0;
+            double Vij[MAXL], Vji[MAXL], xl[MAXL], el[MAXL], wph[MAXL];
 #pragma unroll
             for (int l = 0; l < MAXL; ++l)
             {
@@ -314,6 +551,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                 Vji[l] = 0.0;
                 xl[l] = 0.0;
                 el[l] = 0.0;
+                wph[l] = 0.0;
             }
             // gather: Transition::uv + chi_eta_aux_accum for the (ray-dependent) lines
             if (active)
@@ -325,20 +563,18 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                 {
                     if (l < nLine)
                     {
-                        const DevTrans& tr = a.trans[ent[l].tr];
-                        const int lt = la - tr.Nblue;
-                        const double* par = a.par + tr.parOff + 4 * lt;
-                        const double ph = a.phi[tr.phiOff + ((size_t)(lt * Nrays + mu) * 2 + toObs) * Ns + k];
-                        const double vij = par[0] * ph;
-                        double g = par[2];
-                        if (tr.prd)
-                            g *= a.rho[tr.rhoOff + (size_t)lt * Ns + k];
+                        const CONST_AS DevSlot& sl = slots[l];
+                        const double ph = havePfPhi ? pfPhi[l]
+                                                    : gPhi[sl.phiOff + (size_t)(mu * 2 + toObs) * Ns + k];
+                        wph[l] = havePfPhi ? pfWphi[l] : gWphi[(size_t)sl.row * Ns + k];
+                        const double vij = sl.p[0] * ph;
+                        double g = sl.p[2];
+                        if (sl.flags & 2)
+                            g *= gRho[sl.rhoOff + k];
                         const double vji = g * vij;
-                        const double uji = par[3] * vji;
-                        const double ni = a.n[(size_t)tr.gi * Ns + k];
-                        const double nj = a.n[(size_t)tr.gj * Ns + k];
-                        const double x = ni * vij - nj * vji;
-                        const double em = nj * uji;
+                        const double uji = sl.p[3] * vji;
+                        const double x = gN[sl.gi * Ns + k] * vij - gN[sl.gj * Ns + k] * vji;
+                        const double em = gN[sl.gj * Ns + k] * uji;
                         Vij[l] = vij;
                         Vji[l] = vji;
                         xl[l] = x;
@@ -348,17 +584,43 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                     }
                 }
                 // compute_source_fn :169-179
-                S = (eta + sSca[k] * sJdag[k]) / chi;
+                rchi = d_rcp(chi);
+                S = (eta + sSca[k] * sJdag[k]) * rchi;
                 sChi[t] = chi;
                 sS[t] = S;
                 if (RATES && a.storeDepth)
                 {
                     const size_t o = ((size_t)(la * Nrays + mu) * 2 + toObs) * Ns + k;
-                    a.depthChi[o] = chi;
-                    a.depthEta[o] = eta;
+                    gDepthChi[o] = chi;
+                    gDepthEta[o] = eta;
                 }
             }
-            __syncthreads();
+            // software prefetch of phi for the next pass / next wavelength
+            {
+                const bool nextSameLa = (g0 + G < dyn.nRaysActive);
+                havePfPhi = false;
+                if (nextSameLa || !lastLa)
+                {
+                    const int g0n = nextSameLa ? g0 + G : 0;
+                    const CONST_AS DevSlot* sn = nextSameLa ? slots : slotsNext;
+                    const int nLineN = nextSameLa ? nLine : hNext.nLine;
+                    const int nrn = min(G, dyn.nRaysActive - g0n);
+                    if (isPoint && rl < nrn)
+                    {
+                        const int rn = sRayId[g0n + rl];
+#pragma unroll
+                        for (int l = 0; l < MAXL; ++l)
+                            if (l < nLineN)
+                            {
+                                pfPhi[l] = gPhi[sn[l].phiOff + (size_t)rn * Ns + k];
+                                pfWphi[l] = gWphi[(size_t)sn[l].row * Ns + k];
+                            }
+                    }
+                    havePfPhi = true;
+                }
+            }
+            lds_barrier();
+            STAMP(3);
 
             // ---- formal solver: per-point coefficients e, b, Psi of I_k = e I_upwind + b ------------
             const int dk = toObs ? -1 : 1;
@@ -367,16 +629,16 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
             const int cb = rl * Ns; // column base
             double e = 0.0, b = 0.0, Psi = 0.0;
 
-            // boundary intensity (wrappers FormalScalar.cpp:471-666); needs chi before it is aliased
+            // boundary intensity (wrappers FormalScalar.cpp:471-666)
             double Istart = 0.0;
             if (active && k == kS)
             {
-                const double zb = (SOLVER == LWHIP_FS_LINEAR_1D ? 0.5 : 1.0) / a.muz[mu];
+                const double zb = (SOLVER == LWHIP_FS_LINEAR_1D ? 0.5 : 1.0) / muz;
                 double dtau_b;
                 if (SOLVER == LWHIP_FS_LINEAR_1D)
-                    dtau_b = zb * (sChi[cb + kS] + sChi[cb + kS + dk]) * fabs(sHgt[kS] - sHgt[kS + dk]);
+                    dtau_b = zb * (sChi[cb + kS] + sChi[cb + kS + dk]) * sDh[min(kS, kS + dk)];
                 else
-                    dtau_b = 0.5 * zb * (sChi[cb + kS] + sChi[cb + kS + dk]) * fabs(sHgt[kS] - sHgt[kS + dk]);
+                    dtau_b = 0.5 * zb * (sChi[cb + kS] + sChi[cb + kS + dk]) * sDh[min(kS, kS + dk)];
                 if (toObs)
                 {
                     if (a.lowerBc == LWHIP_BC_THERMALISED)
@@ -411,58 +673,53 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
 
             if (SOLVER == LWHIP_FS_BEZIER3_1D)
             {
-                // piecewise_bezier3_1d_impl FormalScalar.cpp:209-325, restated per point:
-                // every carried quantity except I_upw is a local stencil.
-                const double zmu = active ? 1.0 / a.muz[mu] : 1.0;
-                // A: derivative of chi along the ray at each point
+                // piecewise_bezier3_1d_impl FormalScalar.cpp:209-325, restated per point: every
+                // carried quantity except I_upw is a local stencil.  Each thread evaluates the
+                // chi-derivative at its own point and both neighbours (division-free), which
+                // gives it the optical depth of both adjacent intervals without an exchange.
+                const double zmu = 1.0 / muz;
+                const double* col = sChi + cb;
+                auto ds_of = [&](int ka, int kb) { return sDh[min(ka, kb)] * zmu; };   // |dh| * zmu
+                auto rds_of = [&](int ka, int kb) { return sRdh[min(ka, kb)] * muz; }; // 1 / ds
+                auto dchi_at = [&](int p) {
+                    if (p == kS)
+                        return (col[p + dk] - col[p]) * rds_of(p, p + dk); // dx_uw :239
+                    if (p == kE)
+                        return (col[p] - col[p - dk]) * rds_of(p - dk, p); // dx_dw :288
+                    return d_cent_deriv_r(ds_of(p - dk, p), ds_of(p, p + dk), rds_of(p - dk, p),
+                                          rds_of(p, p + dk), sRsum[p] * muz, col[p - dk], col[p],
+                                          col[p + dk]); // :240,251
+                };
+                // optical depth of the interval (pa -> pb), pb = pa + dk  :242-246, 261-263, 289-292
+                auto dtau_of = [&](int pa, int pb, double dchi_a, double dchi_b) {
+                    const double ds = ds_of(pa, pb);
+                    const double ds3 = ds * (1.0 / 3.0);
+                    const double cuw = col[pa] + ds3 * dchi_a;
+                    const double c0 = col[pb] - ds3 * dchi_b;
+                    return ds * (col[pa] + col[pb] + cuw + c0) * 0.25;
+                };
+                double dtau = 0.0, dtauLin = 0.0, dS = 0.0;
                 if (active)
                 {
-                    double d;
+                    const double d0 = dchi_at(k);
+                    double dtauDw = 0.0;
+                    if (k != kS)
+                        dtau = dtau_of(k - dk, k, dchi_at(k - dk), d0);
+                    if (k != kE)
+                        dtauDw = dtau_of(k, k + dk, d0, dchi_at(k + dk));
+                    // derivative of S with respect to tau  :247, 254-255, 268
                     if (k == kS)
-                    {
-                        const double ds = fabs(sHgt[k + dk] - sHgt[k]) * zmu;
-                        d = (sChi[cb + k + dk] - sChi[cb + k]) / ds; // dx_uw :239
-                    }
-                    else if (k == kE)
-                    {
-                        const double ds = fabs(sHgt[k] - sHgt[k - dk]) * zmu;
-                        d = (sChi[cb + k] - sChi[cb + k - dk]) / ds; // dx_dw :288
-                    }
-                    else
-                    {
-                        const double dsuw = fabs(sHgt[k] - sHgt[k - dk]) * zmu;
-                        const double dsdw = fabs(sHgt[k + dk] - sHgt[k]) * zmu;
-                        d = d_cent_deriv(dsuw, dsdw, sChi[cb + k - dk], chi, sChi[cb + k + dk]); // :240,251
-                    }
-                    sA[t] = d;
-                }
-                __syncthreads();
-                // B: optical depth of the upwind interval (k-dk -> k)  :242-246, 261-263, 289-292
-                double dtau = 0.0, dtauLin = 0.0;
-                if (active && k != kS)
-                {
-                    const double ds = fabs(sHgt[k] - sHgt[k - dk]) * zmu;
-                    const double cuw = sChi[cb + k - dk] + (ds / 3.0) * sA[cb + k - dk];
-                    const double c0 = chi - (ds / 3.0) * sA[t];
-                    dtau = ds * (sChi[cb + k - dk] + chi + cuw + c0) * 0.25;
-                    if (k == kE) // piecewise linear on end :309
-                        dtauLin = 0.5 * zmu * (chi + sChi[cb + k - dk]) * fabs(sHgt[k] - sHgt[k - dk]);
-                }
-                if (active)
-                    sDtau[t] = dtau;
-                __syncthreads();
-                // C: derivative of S with respect to tau at each point  :247, 254-255, 268
-                if (active)
-                {
-                    double dS = 0.0;
-                    if (k == kS)
-                        dS = (sS[cb + k + dk] - S) / sDtau[cb + k + dk];
+                        dS = (sS[cb + k + dk] - S) * d_rcp(dtauDw);
                     else if (k != kE)
-                        dS = d_cent_deriv(dtau, sDtau[cb + k + dk], sS[cb + k - dk], S, sS[cb + k + dk]);
+                        dS = d_cent_deriv_r(dtau, dtauDw, d_rcp(dtau), d_rcp(dtauDw), d_rcp(dtau + dtauDw),
+                                            sS[cb + k - dk], S, sS[cb + k + dk]);
+                    else // piecewise linear on end :309
+                        dtauLin = 0.5 * zmu * (chi + col[k - dk]) * sDh[min(k, k - dk)];
                     sDS[t] = dS;
                 }
-                __syncthreads();
-                // D: coefficients  :265-275, 294-304, 314-321
+                lds_barrier();
+                STAMP(4);
+                // coefficients  :265-275, 294-304, 314-321
                 if (active)
                 {
                     if (k == kS)
@@ -473,20 +730,22 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                     }
                     else if (k == kE)
                     {
-                        const double dSuw = (S - sS[cb + k - dk]) / dtauLin;
+                        const double rl_ = d_rcp(dtauLin);
+                        const double dSuw = (S - sS[cb + k - dk]) * rl_;
                         double w0, w1;
                         d_w2(dtauLin, w0, w1);
                         e = 1.0 - w0;
                         b = w0 * S - w1 * dSuw;
-                        Psi = w0 - w1 / dtauLin;
+                        Psi = w0 - w1 * rl_;
                     }
                     else
                     {
                         double al, be, ga, de, edt;
-                        d_bezier3_coeffs(dtau, al, be, ga, de, edt);
+                        d_bezier3_coeffs_r(dtau, al, be, ga, de, edt);
                         const double Suw = sS[cb + k - dk];
-                        const double cuw = Suw + (dtau / 3.0) * sDS[cb + k - dk];
-                        const double c0 = S - (dtau / 3.0) * sDS[t];
+                        const double dt3 = dtau * (1.0 / 3.0);
+                        const double cuw = Suw + dt3 * sDS[cb + k - dk];
+                        const double c0 = S - dt3 * dS;
                         e = edt;
                         b = al * Suw + be * S + ga * cuw + de * c0;
                         Psi = be + de;
@@ -505,9 +764,9 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                     }
                     else
                     {
-                        const double zmu = 0.5 / a.muz[mu];
-                        const double dtau = zmu * (sChi[cb + k - dk] + chi) * fabs(sHgt[k - dk] - sHgt[k]);
-                        const double rcp = 1.0 / dtau;
+                        const double zmu = 0.5 / muz;
+                        const double dtau = zmu * (sChi[cb + k - dk] + chi) * sDh[min(k, k - dk)];
+                        const double rcp = d_rcp(dtau);
                         const double dSuw = (sS[cb + k - dk] - S) * rcp;
                         double w0, w1;
                         d_w2(dtau, w0, w1);
@@ -522,7 +781,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                 // piecewise_besser_1d_impl FormalScalar.cpp:395-467
                 if (active)
                 {
-                    const double zmu = 1.0 / a.muz[mu];
+                    const double zmu = 1.0 / muz;
                     if (k == kS)
                     {
                         e = 0.0;
@@ -530,18 +789,19 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                     }
                     else if (k == kE)
                     {
-                        const double dtau = 0.5 * zmu * (chi + sChi[cb + k - dk]) * fabs(sHgt[k] - sHgt[k - dk]);
-                        const double dSuw = (S - sS[cb + k - dk]) / dtau;
+                        const double dtau = 0.5 * zmu * (chi + sChi[cb + k - dk]) * sDh[min(k, k - dk)];
+                        const double rcp = d_rcp(dtau);
+                        const double dSuw = (S - sS[cb + k - dk]) * rcp;
                         double w0, w1;
                         d_w2(dtau, w0, w1);
                         e = 1.0 - w0;
                         b = w0 * S - w1 * dSuw;
-                        Psi = w0 - w1 / dtau;
+                        Psi = w0 - w1 * rcp;
                     }
                     else
                     {
-                        const double ds_uw = fabs(sHgt[k] - sHgt[k - dk]) * zmu;
-                        const double ds_dw = fabs(sHgt[k + dk] - sHgt[k]) * zmu;
+                        const double ds_uw = sDh[min(k, k - dk)] * zmu;
+                        const double ds_dw = sDh[min(k, k + dk)] * zmu;
                         const double chi_uw = sChi[cb + k - dk], chi_dw = sChi[cb + k + dk];
                         const double chiC = d_besser_control_point(ds_uw, ds_dw, chi_uw, chi, chi_dw);
                         const double dtauUw = (1.0 / 3.0) * (chi_uw + chiC + chi) * ds_uw;
@@ -556,47 +816,45 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                     }
                 }
             }
-            if (SOLVER != LWHIP_FS_BEZIER3_1D)
-                __syncthreads(); // all stencil reads of sChi done before it is overwritten by b
             if (active)
             {
                 sE[t] = e;
                 sB[t] = b;
             }
-            __syncthreads();
+            lds_barrier();
+            STAMP(5);
 
-            // ---- the recurrence: chunked scan, P lanes per ray ----------------------------------------
+            // ---- the recurrence I_k = e_k I_{k-1} + b_k: one wavefront per ray, each lane composes
+            // its contiguous run of points, a shuffle scan composes the lanes  :273,302,317 ----------
             {
-                const int P = a.P;
-                const bool scanLane = t < nr * P;
-                const int rr = t / P;
-                const int c = t - rr * P;
-                const int Lc = (Ns + P - 1) / P;
-                const int q0 = c * Lc;
-                const int q1 = min(q0 + Lc, Ns);
-                int up = 0;
-                if (scanLane)
-                    up = a.rayList[g0 + rr] & 1;
-                if (scanLane)
+                const int Lc = (Ns + 63) >> 6;
+                for (int rr = wave; rr < nr; rr += nWaves)
                 {
+                    const int up = sRayId[g0 + rr] & 1;
+                    const int q0 = lane * Lc;
+                    const int q1 = min(q0 + Lc, Ns);
                     double E = 1.0, B = 0.0;
                     for (int q = q0; q < q1; ++q)
                     {
                         const int kk = up ? Ns - 1 - q : q;
                         const double ee = sE[rr * Ns + kk];
-                        const double bb = sB[rr * Ns + kk];
-                        B = ee * B + bb;
+                        B = ee * B + sB[rr * Ns + kk];
                         E = ee * E;
                     }
-                    sScan[(rr * P + c) * 2] = E;
-                    sScan[(rr * P + c) * 2 + 1] = B;
-                }
-                __syncthreads();
-                if (scanLane)
-                {
-                    double Iin = 0.0;
-                    for (int cc = 0; cc < c; ++cc)
-                        Iin = sScan[(rr * P + cc) * 2] * Iin + sScan[(rr * P + cc) * 2 + 1];
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1)
+                    {
+                        const double Ep = __shfl_up(E, off);
+                        const double Bp = __shfl_up(B, off);
+                        if (lane >= off)
+                        {
+                            B = E * Bp + B;
+                            E = E * Ep;
+                        }
+                    }
+                    double Iin = __shfl_up(B, 1);
+                    if (lane == 0)
+                        Iin = 0.0;
                     for (int q = q0; q < q1; ++q)
                     {
                         const int kk = up ? Ns - 1 - q : q;
@@ -604,37 +862,28 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                         sB[rr * Ns + kk] = Iin;
                     }
                 }
-                __syncthreads();
             }
+            lds_barrier();
+            STAMP(6);
 
             double I = 0.0;
             if (active)
             {
                 I = sB[t];
-                Psi = Psi / chi; // PsiStar :322-323
-                sA[t] = (0.5 * a.wmu[mu]) * I;
+                Psi = Psi * rchi; // PsiStar :322-323
                 if (toObs && k == 0)
-                    a.I[(size_t)la * Nrays + mu] = I; // spect.I(la, mu, 0) :349
+                    gI[(size_t)la * Nrays + mu] = I; // spect.I(la, mu, 0) :349
                 if (RATES && a.storeDepth)
-                    a.depthI[((size_t)(la * Nrays + mu) * 2 + toObs) * Ns + k] = I;
-            }
-            __syncthreads();
-            // accumulate_J :181-190, rays in reference order
-            if (RATES && t < Ns)
-            {
-                double j = (g0 == 0) ? 0.0 : sJ[t];
-                for (int r2 = 0; r2 < nr; ++r2)
-                    j += sA[r2 * Ns + t];
-                sJ[t] = j;
+                    gDepthI[((size_t)(la * Nrays + mu) * 2 + toObs) * Ns + k] = I;
             }
 
-            // ---- compute_full_Ieff + compute_full_operator_rates :192-234 ------------------------------
+            // ---- per-ray rates: lines and mixed continua  :192-234; angle moments for the rest -------
             if (RATES && active)
             {
-                const double halfwmu = 0.5 * a.wmu[mu];
-                const double PsiS = a.lambdaIterate ? 0.0 : Psi;
+                const double PsiS = dyn.lambdaIterate ? 0.0 : Psi;
                 int lgi[MAXL], lgj[MAXL], lat[MAXL], lop[MAXL];
                 double luji[MAXL];
+                double etaM0 = 0.0, etaM1 = 0.0;
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                 {
@@ -645,14 +894,23 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                     luji[l] = 0.0;
                     if (l < nLine)
                     {
-                        const DevTrans& tr = a.trans[ent[l].tr];
-                        lgi[l] = tr.gi;
-                        lgj[l] = tr.gj;
-                        lat[l] = tr.atom;
-                        lop[l] = tr.op;
-                        luji[l] = a.par[tr.parOff + 4 * (la - tr.Nblue) + 3] * Vji[l];
+                        const CONST_AS DevSlot& sl = slots[l];
+                        lgi[l] = sl.gi;
+                        lgj[l] = sl.gj;
+                        lat[l] = sl.atom;
+                        lop[l] = sl.flags & 1;
+                        luji[l] = sl.p[3] * Vji[l];
+                        if (lop[l])
+                        {
+                            etaM0 += (sl.ms == 0) ? el[l] : 0.0;
+                            etaM1 += (sl.ms == 1) ? el[l] : 0.0;
+                        }
                     }
                 }
+                sChi[t] = halfwmu * I;              // -> J
+                sS[t] = halfwmu * PsiS;             // -> M1
+                sDS[t] = halfwmu * PsiS * etaM0;    // -> Meta0
+                sB[t] = halfwmu * PsiS * etaM1;     // -> Meta1 (own element: I was read above)
                 auto levChi = [&](int g) {
                     double v = sLevChi[g * Ns + k];
 #pragma unroll
@@ -686,23 +944,20 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                     }
                     return v;
                 };
-                // lines
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                 {
                     if (l < nLine)
                     {
-                        const DevLaEntry en = ent[l];
-                        const DevTrans& tr = a.trans[en.tr];
-                        const double* par = a.par + tr.parOff + 4 * (la - tr.Nblue);
-                        const double wla = (par[1] * a.wphi[(size_t)tr.row * Ns + k]) * PI4_HC;
+                        const CONST_AS DevSlot& sl = slots[l];
+                        const double wla = (sl.p[1] * wph[l]) * PI4_HC;
                         const double wlamu = wla * halfwmu;
-                        double* acc = sAcc + (size_t)en.cs * 4 * Ns + k;
-                        if (tr.op)
+                        double* acc = sAcc + (size_t)sl.cs * 4 * Ns + k;
+                        if (sl.flags & 1)
                         {
-                            const double Ieff = I - PsiS * atomEta(tr.atom);
-                            const double g0v = ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(tr.gi) * levU(tr.gj))) * wlamu;
-                            const double g1v = ((Vij[l] * Ieff) - (PsiS * levChi(tr.gj) * levU(tr.gi))) * wlamu;
+                            const double Ieff = I - PsiS * atomEta(sl.atom);
+                            const double g0v = ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(sl.gi) * levU(sl.gj))) * wlamu;
+                            const double g1v = ((Vij[l] * Ieff) - (PsiS * levChi(sl.gj) * levU(sl.gi))) * wlamu;
                             lds_add(acc, g0v);
                             lds_add(acc + Ns, g1v);
                         }
@@ -710,63 +965,126 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs a)
                         lds_add(acc + 3 * Ns, (luji[l] + I * Vji[l]) * wlamu);
                     }
                 }
-                // continua
-                for (int c = 0; c < nCont; ++c)
+                for (int c = 0; c < nPerRayC; ++c) // mixed continua (always of active atoms)
                 {
-                    const DevLaEntry en = ent[nLine + c];
-                    const DevTrans& tr = a.trans[en.tr];
-                    const double* par = a.par + tr.parOff + 4 * (la - tr.Nblue);
-                    const double vij = par[0];
+                    const CONST_AS DevSlot& sl = slots[nLine + c];
+                    const double vij = sl.p[0];
                     const double vji = sVji[c * Ns + k];
-                    const double uji = par[2] * vji;
-                    const double wlamu = par[1] * halfwmu;
-                    double* acc = sAcc + (size_t)en.cs * 4 * Ns + k;
-                    if (tr.op)
-                    {
-                        const double Ieff = I - PsiS * atomEta(tr.atom);
-                        const double g0v = ((uji + vji * Ieff) - (PsiS * levChi(tr.gi) * levU(tr.gj))) * wlamu;
-                        const double g1v = ((vij * Ieff) - (PsiS * levChi(tr.gj) * levU(tr.gi))) * wlamu;
-                        lds_add(acc, g0v);
-                        lds_add(acc + Ns, g1v);
-                    }
+                    const double uji = sl.p[2] * vji;
+                    const double wlamu = sl.p[1] * halfwmu;
+                    double* acc = sAcc + (size_t)sl.cs * 4 * Ns + k;
+                    const double Ieff = I - PsiS * atomEta(sl.atom);
+                    const double g0v = ((uji + vji * Ieff) - (PsiS * levChi(sl.gi) * levU(sl.gj))) * wlamu;
+                    const double g1v = ((vij * Ieff) - (PsiS * levChi(sl.gj) * levU(sl.gi))) * wlamu;
+                    lds_add(acc, g0v);
+                    lds_add(acc + Ns, g1v);
                     lds_add(acc + 2 * Ns, I * vij * wlamu);
                     lds_add(acc + 3 * Ns, (uji + I * vji) * wlamu);
                 }
             }
-            __syncthreads();
+            lds_barrier();
+            STAMP(7);
+            // accumulate_J :181-190 and the Psi* moments, rays in reference order
+            if (RATES)
+            {
+                for (int task = t; task < 4 * Ns; task += T)
+                {
+                    const int m = divNs(task);
+                    const int kk = task - m * Ns;
+                    const double* src = (m == 0) ? sChi : (m == 1) ? sS : (m == 2) ? sDS : sB;
+                    double acc = (g0 == 0) ? 0.0 : sJ[m * Ns + kk];
+                    for (int r0 = 0; r0 < nr; r0 += 8) // loads issued together, adds in ray order
+                    {
+                        double v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            v[q] = (r0 + q < nr) ? src[(r0 + q) * Ns + kk] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (r0 + q < nr)
+                                acc += v[q];
+                    }
+                    sJ[m * Ns + kk] = acc;
+                }
+            }
+            lds_barrier();
+            STAMP(8);
         } // ray groups
 
-        // ---- J out, dJ = max_k |1 - Jdag/J|  :477-486 ---------------------------------------------------
-        if (RATES && (t & ~63) < Ns) // whole wavefronts, so the shuffles see every lane
+        if (RATES)
         {
-            double dj = 0.0;
-            if (t < Ns)
+            // ---- pure continua from the angle moments -----------------------------------------------------
+            // sum_r w_r [Uji + Vji (I_r - Psi_r eta_r) - Psi_r chi_i U_j] with chi, U, Uji, Vji ray-
+            // independent and eta_r = etaC + etaLine_r  ->  Uji W + Vji (J - M1 etaC - Meta) - M1 chi_i U_j
+            for (int idx = t; idx < h.nPure * Ns; idx += T)
             {
-                const double Jn = sJ[t];
-                a.J[(size_t)la * Ns + t] = Jn;
-                dj = fabs(1.0 - sJdag[t] / Jn);
+                const int cq = divNs(idx);
+                const int c = h.nMixed + cq;
+                const int kk = idx - cq * Ns;
+                const CONST_AS DevSlot& sl = slots[nLine + c];
+                const double vij = sl.p[0];
+                const double vji = sVji[c * Ns + kk];
+                const double uji = sl.p[2] * vji;
+                const double wla = sl.p[1];
+                const double Jk = sJ[kk];
+                double* acc = sAcc + (size_t)sl.cs * 4 * Ns + kk;
+                if (sl.flags & 1)
+                {
+                    const double M1 = sJ[Ns + kk];
+                    const double Meta = (sl.ms >= 0) ? sJ[(2 + sl.ms) * Ns + kk] : 0.0;
+                    const double Jeff = Jk - M1 * sEtaA[sl.atom * Ns + kk] - Meta;
+                    acc[0] += ((uji * Wsum + vji * Jeff) - (M1 * sLevChi[sl.gi * Ns + kk] * sLevU[sl.gj * Ns + kk])) * wla;
+                    acc[Ns] += ((vij * Jeff) - (M1 * sLevChi[sl.gj * Ns + kk] * sLevU[sl.gi * Ns + kk])) * wla;
+                }
+                acc[2 * Ns] += Jk * vij * wla;
+                acc[3 * Ns] += (uji * Wsum + Jk * vji) * wla;
             }
+            // ---- J out, dJ = max_k |1 - Jdag/J|  :477-486 ---------------------------------------------------
+            if ((t & ~63) < Ns) // whole wavefronts, so the shuffles see every lane
+            {
+                double dj = 0.0;
+                if (t < Ns)
+                {
+                    const double Jn = sJ[t];
+                    gJ[(size_t)la * Ns + t] = Jn;
+                    dj = fabs(1.0 - sJdag[t] / Jn);
+                }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                dj = fmax(dj, __shfl_xor(dj, off));
-            if ((t & 63) == 0)
-                atomicMax((unsigned long long*)(a.dJ + la), (unsigned long long)__double_as_longlong(dj));
+                for (int off = 32; off > 0; off >>= 1)
+                    dj = fmax(dj, __shfl_xor(dj, off));
+                if ((t & 63) == 0)
+                    atomicMax((unsigned long long*)(a.dJ + la), (unsigned long long)__double_as_longlong(dj));
+            }
         }
-        __syncthreads();
+        lds_barrier();
+        // hand the prefetched inputs of the next wavelength over to LDS (made visible by the next
+        // wavelength's first barrier; nothing reads these rows before it)
+        if (pfInputs && inOwner && !lastLa)
+            sIn[t] = pfK;
+        STAMP(9);
     } // wavelengths
 
     if (RATES)
     {
-        double* out = a.partial + (size_t)chunk * a.maxCT * 4 * Ns;
-        for (int idx = t; idx < a.maxCT * 4 * Ns; idx += T)
+        GLOBAL_AS double* out = gPartial + (size_t)chunk * maxCT * 4 * Ns;
+        for (int idx = t; idx < maxCT * 4 * Ns; idx += T)
             out[idx] = sAcc[idx];
     }
+#ifdef LWHIP_STAMPS
+    STAMP(10);
+    if (t == 0 && a.stamps)
+        for (int i = 0; i < 12; ++i)
+            a.stamps[(size_t)chunk * 12 + i] = stampAcc[i];
+#endif
 }
 
+#undef ARGS
+
 template <int SOLVER, int MAXL, bool RATES>
-static hipError_t launch_sweep_t(const SweepArgs& a, int nChunks, hipStream_t stream)
+static hipError_t launch_sweep_t(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn,
+                                 int nChunks, hipStream_t stream)
 {
-    const size_t lds = sweep_lds_bytes(a);
+    const size_t lds = sweep_lds_bytes(a, dyn.G);
     static size_t configured = 0;
     if (lds > configured)
     {
@@ -776,61 +1094,81 @@ static hipError_t launch_sweep_t(const SweepArgs& a, int nChunks, hipStream_t st
             return err;
         configured = lds;
     }
-    int T = ((std::max(a.G * a.Ns, a.G * a.P) + 63) / 64) * 64;
-    if (T < 64)
-        T = 64;
+    // at least one wavefront per ray of a pass (the scan) and one thread per point
+    int T = ((std::max(dyn.G * a.Ns, 64) + 63) / 64) * 64;
     if (T > 1024)
         return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((sweep_kernel<SOLVER, MAXL, RATES>), dim3(nChunks), dim3(T), lds, stream, a);
+    hipLaunchKernelGGL((sweep_kernel<SOLVER, MAXL, RATES>), dim3(nChunks), dim3(T), lds, stream, devArgs, dyn);
     return hipGetLastError();
 }
 
 template <int SOLVER, bool RATES>
-static hipError_t launch_sweep_l(const SweepArgs& a, int maxL, int nChunks, hipStream_t stream)
+static hipError_t launch_sweep_l(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn,
+                                 int maxL, int nChunks, hipStream_t stream)
 {
     if (maxL <= 2)
-        return launch_sweep_t<SOLVER, 2, RATES>(a, nChunks, stream);
+        return launch_sweep_t<SOLVER, 2, RATES>(devArgs, a, dyn, nChunks, stream);
     if (maxL <= 4)
-        return launch_sweep_t<SOLVER, 4, RATES>(a, nChunks, stream);
-    return launch_sweep_t<SOLVER, 8, RATES>(a, nChunks, stream);
+        return launch_sweep_t<SOLVER, 4, RATES>(devArgs, a, dyn, nChunks, stream);
+    return launch_sweep_t<SOLVER, 8, RATES>(devArgs, a, dyn, nChunks, stream);
 }
 
-hipError_t launch_sweep(const SweepArgs& a, int solver, int maxL, bool rates, int nChunks,
-                        hipStream_t stream)
+hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn, int solver,
+                        int maxL, bool rates, int nChunks, hipStream_t stream)
 {
     switch (solver)
     {
         case LWHIP_FS_LINEAR_1D:
-            return rates ? launch_sweep_l<LWHIP_FS_LINEAR_1D, true>(a, maxL, nChunks, stream)
-                         : launch_sweep_l<LWHIP_FS_LINEAR_1D, false>(a, maxL, nChunks, stream);
+            return rates ? launch_sweep_l<LWHIP_FS_LINEAR_1D, true>(devArgs, a, dyn, maxL, nChunks, stream)
+                         : launch_sweep_l<LWHIP_FS_LINEAR_1D, false>(devArgs, a, dyn, maxL, nChunks, stream);
         case LWHIP_FS_BESSER_1D:
-            return rates ? launch_sweep_l<LWHIP_FS_BESSER_1D, true>(a, maxL, nChunks, stream)
-                         : launch_sweep_l<LWHIP_FS_BESSER_1D, false>(a, maxL, nChunks, stream);
+            return rates ? launch_sweep_l<LWHIP_FS_BESSER_1D, true>(devArgs, a, dyn, maxL, nChunks, stream)
+                         : launch_sweep_l<LWHIP_FS_BESSER_1D, false>(devArgs, a, dyn, maxL, nChunks, stream);
         default:
-            return rates ? launch_sweep_l<LWHIP_FS_BEZIER3_1D, true>(a, maxL, nChunks, stream)
-                         : launch_sweep_l<LWHIP_FS_BEZIER3_1D, false>(a, maxL, nChunks, stream);
+            return rates ? launch_sweep_l<LWHIP_FS_BEZIER3_1D, true>(devArgs, a, dyn, maxL, nChunks, stream)
+                         : launch_sweep_l<LWHIP_FS_BEZIER3_1D, false>(devArgs, a, dyn, maxL, nChunks, stream);
     }
 }
 
 // ---- slab reduction: fixed-order sum of the per-chunk partials of each transition ----------------------
 // replaces AtomStorageFactory::accumulate_Gamma / TransitionStorageFactory::accumulate_rates
 // (ThreadStorage.cpp:73-88,150-166)
-__global__ void reduce_kernel(const ReduceArgs a)
+__global__ void reduce_stage1_kernel(const ReduceArgs a)
+{
+    const int tr = blockIdx.x;
+    const int part = blockIdx.y;
+    const int n4 = 4 * a.Ns;
+    const int e0 = a.trOff[tr], e1 = a.trOff[tr + 1];
+    const int per = (e1 - e0 + LWHIP_REDUCE_SPLIT - 1) / LWHIP_REDUCE_SPLIT;
+    const int b0 = e0 + part * per;
+    const int b1 = min(b0 + per, e1);
+    for (int idx = threadIdx.x; idx < n4; idx += blockDim.x)
+    {
+        double s = 0.0;
+        for (int e = b0; e < b1; ++e)
+            s += a.partial[(size_t)a.trRow[e] * n4 + idx];
+        a.red8[((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + idx] = s;
+    }
+}
+
+__global__ void reduce_stage2_kernel(const ReduceArgs a)
 {
     const int tr = blockIdx.x;
     const int n4 = 4 * a.Ns;
     for (int idx = threadIdx.x; idx < n4; idx += blockDim.x)
     {
         double s = 0.0;
-        for (int e = a.trOff[tr]; e < a.trOff[tr + 1]; ++e)
-            s += a.partial[(size_t)a.trRow[e] * n4 + idx];
+#pragma unroll
+        for (int part = 0; part < LWHIP_REDUCE_SPLIT; ++part)
+            s += a.red8[((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + idx];
         a.red[(size_t)tr * n4 + idx] = s;
     }
 }
 
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reduce_kernel, dim3(a.Ntrans), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(reduce_stage1_kernel, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT), dim3(384), 0, stream, a);
+    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(a.Ntrans), dim3(384), 0, stream, a);
     return hipGetLastError();
 }
 
