@@ -40,6 +40,23 @@ def parse():
     return ap.parse_args()
 
 
+def profiled_traffic():
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_summary.json, produced by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate
+    --pmc runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Counters cannot be
+    collected from inside this process, so the latest committed value is reported, or null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json')))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d.get('sweep_traffic_bytes_per_launch'), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(prob, budget_s):
     """The reference core (oracle/_ref, kind 'reference') -- or, where it is absent, the C oracle
     (kind 'port') -- timed on the host cores on a bounded number of iterations of the SAME
@@ -135,6 +152,7 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        traffic, traffic_src = profiled_traffic() if (world == 1 and args.nlambda == 10240) else (None, None)
         out = {
             'metric': 'formal_sol_gamma_matrices iters/sec',
             'value': value,
@@ -165,7 +183,8 @@ def main():
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': traffic,
+                'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'kernel_ms': sweep_ms,
                 'launches_timed': nlaunch,

@@ -54,13 +54,14 @@ def build_plugin(force=False, verbose=False):
     if not os.path.exists(src) or not os.path.exists(os.path.join(REF_SRC, 'Lightweaver.hpp')):
         return PLUGIN if os.path.exists(PLUGIN) else None
     deps = [src, os.path.join(ROOT, 'include', 'lwhip.h')]
+    build_hip()
     if not force and not _stale(PLUGIN, deps):
         return PLUGIN
     cmd = ['g++', '-std=c++17', '-O2', '-fPIC', '-shared', '-Wno-sign-compare',
            '-DENKITS_BUILD_DLL', f'-I{REF_SRC}', f'-I{os.path.join(ROOT, "include")}',
            '-o', PLUGIN, src, os.path.join(REF_SRC, 'LightweaverAmalgamated.cpp'),
            os.path.join(REF_SRC, 'TaskScheduler.cpp'),
-           '-ldl', '-lpthread', '-Wl,-Bsymbolic', '-Wl,-rpath,$ORIGIN']
+           f'-L{PKG}', '-llwhip', '-ldl', '-lpthread', '-Wl,-Bsymbolic', '-Wl,-rpath,$ORIGIN']
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

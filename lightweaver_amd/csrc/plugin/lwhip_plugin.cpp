@@ -1,0 +1,407 @@
+// lwhip_plugin.cpp -- Lightweaver iteration-scheme plugin backed by the MI355X HIP library.
+//
+// This is the reference-side binding of the C ABI in include/lwhip.h: a shared object exporting
+//
+//     extern "C" FsIterationFns fs_iteration_fns_provider();      (Source/LwFormalInterface.hpp:110-136)
+//
+// that Lightweaver loads with FsIterationSchemes.load_fns_from_path(path) and selects with
+// Context(..., fsIterScheme="mali_full_precond_hip_gfx950") (Source/LwMiddleLayer.pyx:4172-4184,
+// 3077-3087).  It is compiled against the Lightweaver headers exactly like the reference's own
+// SIMD plugins (setup.py:255-271: plugin source + LightweaverAmalgamated.cpp), so struct layouts
+// agree by construction.  Nothing numerical happens here: fs_iter / simple_fs / stat_eq flatten
+// the borrowed numpy-backed views of `Context` into an `lwhip_problem`, move the arrays that may
+// have changed to HBM, call the C ABI and copy the results back into the same host arrays, which
+// stay the source of truth (pickling, Ng acceleration, the Python layer all keep working).
+// Members this build does not accelerate forward to the core's own implementations, as the
+// reference plugins do for theirs (Source/SimdImpl_AVX2FMA.cpp:643-658).
+#include "Lightweaver.hpp"
+#include "lwhip.h"
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace
+{
+struct Fingerprint
+{
+    uint64_t h = 0;
+    // cheap change detector for big, rarely changing inputs: pointer, length and a strided sample
+    static uint64_t of(const double* p, size_t n)
+    {
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)(uintptr_t)p ^ (n * 0x9E3779B97F4A7C15ull);
+        if (!p || !n)
+            return h;
+        const size_t step = n / 257 + 1;
+        for (size_t i = 0; i < n; i += step)
+        {
+            uint64_t bits;
+            std::memcpy(&bits, &p[i], 8);
+            h = (h ^ bits) * 1099511628211ull;
+        }
+        uint64_t bits;
+        std::memcpy(&bits, &p[n - 1], 8);
+        return (h ^ bits) * 1099511628211ull;
+    }
+};
+
+struct PluginState
+{
+    lwhip_context* hip = nullptr;
+    lwhip_problem prob{};
+    std::vector<lwhip_atom> atoms;
+    std::vector<std::vector<lwhip_transition>> trans;
+    std::vector<uint64_t> shape;       // structural signature: recreate the device context if it changes
+    uint64_t fpProfiles = 0, fpBackground = 0, fpAtmos = 0, fpNstar = 0, fpCollisions = 0;
+};
+
+std::mutex g_mutex;
+std::map<const Atom*, std::pair<Context*, int>> g_atomOwner; // stat_eq receives only the Atom*
+
+[[noreturn]] void fail(const std::string& what)
+{
+    throw std::runtime_error("lwhip plugin: " + what + ": " + lwhip_last_error());
+}
+
+int solver_id(const Context& ctx)
+{
+    const char* n = ctx.formalSolver.name;
+    if (n && !std::strcmp(n, "piecewise_linear_1d"))
+        return LWHIP_FS_LINEAR_1D;
+    if (n && !std::strcmp(n, "piecewise_besser_1d"))
+        return LWHIP_FS_BESSER_1D;
+    if (n && !std::strcmp(n, "piecewise_bezier3_1d"))
+        return LWHIP_FS_BEZIER3_1D;
+    throw std::runtime_error(std::string("lwhip plugin: formal solver '") + (n ? n : "?")
+                             + "' is not available on the device (1D linear/besser/bezier3 only)");
+}
+
+void flatten_boundary(lwhip_boundary* b, AtmosphericBoundaryCondition& bc)
+{
+    b->type = (int32_t)bc.type;
+    b->Nmu = 0;
+    b->idxs = nullptr;
+    b->bcData = nullptr;
+    if (bc.type == CALLABLE)
+    {
+        b->Nmu = (int32_t)bc.bcData.shape(1);
+        b->idxs = bc.idxs.data;
+        b->bcData = bc.bcData.data();
+    }
+}
+
+// Context -> lwhip_problem (flat restatement, include/lwhip.h); returns the structural signature
+void flatten(Context& ctx, PluginState* st)
+{
+    Atmosphere& atmos = *ctx.atmos;
+    Spectrum& spect = *ctx.spect;
+    if (atmos.Ndim != 1)
+        throw std::runtime_error("lwhip plugin: only 1D plane-parallel atmospheres are supported");
+    if (spect.JRest)
+        throw std::runtime_error("lwhip plugin: hybrid PRD (JRest) is not supported on the device");
+    lwhip_problem& p = st->prob;
+    p = lwhip_problem{};
+    p.abiVersion = LWHIP_ABI_VERSION;
+    p.Nspace = atmos.Nspace;
+    p.Nrays = atmos.Nrays;
+    p.Nlambda = (int32_t)spect.wavelength.shape(0);
+    p.formalSolver = solver_id(ctx);
+    p.storeDepthData = (ctx.depthData && ctx.depthData->fill) ? 1 : 0;
+    p.height = atmos.height.data;
+    p.temperature = atmos.temperature.data;
+    p.vlosMu = atmos.vlosMu.data;
+    p.muz = atmos.muz.data;
+    p.wmu = atmos.wmu.data;
+    p.wavelength = spect.wavelength.data;
+    flatten_boundary(&p.zLowerBc, atmos.zLowerBc);
+    flatten_boundary(&p.zUpperBc, atmos.zUpperBc);
+    p.bgChi = ctx.background->chi.data;
+    p.bgEta = ctx.background->eta.data;
+    p.bgSca = ctx.background->sca.data;
+    p.J = spect.J.data;
+    p.I = spect.I.data;
+    if (p.storeDepthData)
+    {
+        p.depthChi = ctx.depthData->chi.data;
+        p.depthEta = ctx.depthData->eta.data;
+        p.depthI = ctx.depthData->I.data;
+    }
+    std::vector<Atom*> all(ctx.activeAtoms);
+    all.insert(all.end(), ctx.detailedAtoms.begin(), ctx.detailedAtoms.end());
+    st->atoms.assign(all.size(), lwhip_atom{});
+    st->trans.assign(all.size(), {});
+    st->shape = { (uint64_t)p.Nspace, (uint64_t)p.Nrays, (uint64_t)p.Nlambda, (uint64_t)p.formalSolver,
+                  (uint64_t)p.storeDepthData, (uint64_t)p.zLowerBc.type, (uint64_t)p.zUpperBc.type,
+                  (uint64_t)all.size() };
+    for (size_t ia = 0; ia < all.size(); ++ia)
+    {
+        Atom& a = *all[ia];
+        lwhip_atom& fa = st->atoms[ia];
+        fa.Nlevel = a.Nlevel;
+        fa.Ntrans = a.Ntrans;
+        fa.detailed = ia >= ctx.activeAtoms.size();
+        fa.n = a.n.data;
+        fa.nStar = a.nStar.data;
+        fa.nTotal = a.nTotal.data;
+        fa.vBroad = a.vBroad.data;
+        fa.Gamma = fa.detailed ? nullptr : a.Gamma.data;
+        fa.C = (fa.detailed || !a.C) ? nullptr : a.C.data;
+        st->trans[ia].assign(a.Ntrans, lwhip_transition{});
+        for (int kr = 0; kr < a.Ntrans; ++kr)
+        {
+            Transition& t = *a.trans[kr];
+            if (t.hPrdCoeffs)
+                throw std::runtime_error("lwhip plugin: hybrid PRD coefficients are not supported on the device");
+            lwhip_transition& ft = st->trans[ia][kr];
+            ft.type = (t.type == LINE) ? LWHIP_LINE : LWHIP_CONTINUUM;
+            ft.i = t.i;
+            ft.j = t.j;
+            ft.Nblue = t.Nblue;
+            ft.Nred = t.Nred;
+            ft.prd = (t.type == LINE && t.rhoPrd) ? 1 : 0;
+            ft.Aji = t.Aji;
+            ft.Bji = t.Bji;
+            ft.Bij = t.Bij;
+            ft.lambda0 = t.lambda0;
+            ft.dopplerWidth = t.dopplerWidth;
+            ft.wavelength = t.wavelength.data;
+            ft.alpha = t.alpha.data;
+            ft.phi = t.phi.data;
+            ft.wphi = t.wphi.data;
+            ft.aDamp = t.aDamp.data;
+            ft.rhoPrd = t.rhoPrd.data;
+            ft.Rij = t.Rij.data;
+            ft.Rji = t.Rji.data;
+            for (uint64_t v : { (uint64_t)ft.type, (uint64_t)ft.i, (uint64_t)ft.j, (uint64_t)ft.Nblue,
+                                (uint64_t)ft.Nred, (uint64_t)ft.prd })
+                st->shape.push_back(v);
+        }
+        fa.trans = st->trans[ia].data();
+        st->shape.push_back((uint64_t)fa.Nlevel);
+        st->shape.push_back((uint64_t)fa.detailed);
+    }
+    p.Natom = (int32_t)all.size();
+    p.atoms = st->atoms.data();
+}
+
+// fingerprints of the slowly changing inputs -> upload mask
+uint32_t dirty_mask(PluginState* st, bool force)
+{
+    const lwhip_problem& p = st->prob;
+    const size_t Ns = p.Nspace, Nla = p.Nlambda, Nr = p.Nrays;
+    uint64_t fProf = 0, fNstar = 0, fColl = 0;
+    for (int ia = 0; ia < p.Natom; ++ia)
+    {
+        const lwhip_atom& a = p.atoms[ia];
+        fNstar ^= Fingerprint::of(a.nStar, (size_t)a.Nlevel * Ns) * 3 ^ Fingerprint::of(a.nTotal, Ns);
+        if (a.C)
+            fColl ^= Fingerprint::of(a.C, (size_t)a.Nlevel * a.Nlevel * Ns) + ia;
+        for (int kr = 0; kr < a.Ntrans; ++kr)
+        {
+            const lwhip_transition& t = a.trans[kr];
+            if (t.type == LWHIP_LINE)
+                fProf ^= Fingerprint::of(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns) + kr
+                         ^ Fingerprint::of(t.wphi, Ns);
+        }
+    }
+    const uint64_t fBg = Fingerprint::of(p.bgChi, Nla * Ns) ^ Fingerprint::of(p.bgEta, Nla * Ns) * 3
+                         ^ Fingerprint::of(p.bgSca, Nla * Ns) * 5;
+    const uint64_t fAt = Fingerprint::of(p.height, Ns) ^ Fingerprint::of(p.temperature, Ns) * 3
+                         ^ Fingerprint::of(p.wavelength, Nla) * 5 ^ Fingerprint::of(p.muz, Nr) * 7
+                         ^ Fingerprint::of(p.wmu, Nr) * 11;
+    uint32_t mask = LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
+    if (force || fProf != st->fpProfiles)
+        mask |= LWHIP_PROFILES;
+    if (force || fBg != st->fpBackground)
+        mask |= LWHIP_BACKGROUND;
+    if (force || fAt != st->fpAtmos)
+        mask |= LWHIP_ATMOS;
+    if (force || fNstar != st->fpNstar)
+        mask |= LWHIP_NSTAR;
+    if (force || fColl != st->fpCollisions)
+        mask |= LWHIP_COLLISIONS;
+    st->fpProfiles = fProf;
+    st->fpBackground = fBg;
+    st->fpAtmos = fAt;
+    st->fpNstar = fNstar;
+    st->fpCollisions = fColl;
+    return mask;
+}
+
+void destroy_state(Context* ctx)
+{
+    auto* st = (PluginState*)ctx->methodScratch;
+    if (!st)
+        return;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        for (auto it = g_atomOwner.begin(); it != g_atomOwner.end();)
+            it = (it->second.first == ctx) ? g_atomOwner.erase(it) : std::next(it);
+    }
+    if (st->hip)
+        lwhip_destroy(st->hip);
+    delete st;
+    ctx->methodScratch = nullptr;
+}
+
+// make sure a device context matching the current Context exists; returns the upload mask
+uint32_t sync_state(Context& ctx, bool force)
+{
+    auto* st = (PluginState*)ctx.methodScratch;
+    if (!st)
+    {
+        st = new PluginState();
+        ctx.methodScratch = st;
+    }
+    PluginState fresh;
+    flatten(ctx, &fresh);
+    const bool rebuild = !st->hip || fresh.shape != st->shape;
+    // adopt the fresh descriptor (pointers may have moved even when the structure has not)
+    const bool moved = !rebuild && std::memcmp(&fresh.prob, &st->prob, offsetof(lwhip_problem, atoms)) != 0;
+    lwhip_context* old = st->hip;
+    st->prob = fresh.prob;
+    st->atoms = std::move(fresh.atoms);
+    st->trans = std::move(fresh.trans);
+    st->shape = std::move(fresh.shape);
+    for (size_t ia = 0; ia < st->atoms.size(); ++ia)
+        st->atoms[ia].trans = st->trans[ia].data();
+    st->prob.atoms = st->atoms.data();
+    if (rebuild || moved)
+    {
+        if (old)
+            lwhip_destroy(old);
+        st->hip = nullptr;
+        if (lwhip_create(&st->prob, nullptr, &st->hip) != LWHIP_OK)
+            fail("lwhip_create");
+        dirty_mask(st, true); // create uploaded everything: just record the fingerprints
+        std::lock_guard<std::mutex> lock(g_mutex);
+        for (size_t ia = 0; ia < ctx.activeAtoms.size(); ++ia)
+            g_atomOwner[ctx.activeAtoms[ia]] = { &ctx, (int)ia };
+        return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
+    }
+    return dirty_mask(st, force);
+}
+
+bool force_upload(ExtraParams& params)
+{
+    return params.contains("lwhip_force_upload");
+}
+
+void reject_unsupported(ExtraParams& params)
+{
+    if (params.contains("ZPlaneDecomposition"))
+        throw std::runtime_error("lwhip plugin: ZPlaneDecomposition outputs are not produced by the device sweep");
+}
+
+// ---- FsIterationFns members ----------------------------------------------------------------------
+
+// fs_iter: replaces formal_sol_iteration_matrices_<simd> (Source/SimdFullIterationTemplates.hpp:588-719)
+IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params)
+{
+    reject_unsupported(params);
+    const uint32_t up = sync_state(ctx, force_upload(params));
+    auto* st = (PluginState*)ctx.methodScratch;
+    if (lwhip_upload(st->hip, up) != LWHIP_OK)
+        fail("lwhip_upload");
+    lwhip_iter_result r{};
+    if (lwhip_formal_sol_gamma_matrices(st->hip, lambdaIterate ? 1 : 0, &r) != LWHIP_OK)
+        fail("lwhip_formal_sol_gamma_matrices");
+    uint32_t down = LWHIP_J | LWHIP_I | LWHIP_GAMMA | LWHIP_RATES;
+    if (st->prob.storeDepthData)
+        down |= LWHIP_DEPTHDATA;
+    if (lwhip_download(st->hip, down) != LWHIP_OK)
+        fail("lwhip_download");
+    IterationResult result{};
+    result.updatedJ = true;
+    result.dJMax = r.dJMax;
+    result.dJMaxIdx = r.dJMaxIdx;
+    return result;
+}
+
+// simple_fs: replaces formal_sol_<simd> (Source/SimdFullIterationTemplates.hpp:721-781)
+IterationResult simple_fs_hip(Context& ctx, bool upOnly, ExtraParams params)
+{
+    reject_unsupported(params);
+    const uint32_t up = sync_state(ctx, force_upload(params));
+    auto* st = (PluginState*)ctx.methodScratch;
+    if (lwhip_upload(st->hip, up & ~(uint32_t)LWHIP_GAMMA) != LWHIP_OK)
+        fail("lwhip_upload");
+    if (lwhip_formal_sol(st->hip, upOnly ? 1 : 0) != LWHIP_OK)
+        fail("lwhip_formal_sol");
+    if (lwhip_download(st->hip, LWHIP_I) != LWHIP_OK)
+        fail("lwhip_download");
+    return IterationResult{};
+}
+
+// stat_eq: replaces stat_eq_impl (Source/UpdatePopulations.cpp:7-47)
+void stat_eq_hip(Atom* atom, ExtraParams params, int spaceStart, int spaceEnd)
+{
+    Context* ctx = nullptr;
+    int idx = -1;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        auto it = g_atomOwner.find(atom);
+        if (it != g_atomOwner.end())
+        {
+            ctx = it->second.first;
+            idx = it->second.second;
+        }
+    }
+    const int Nspace = (int)atom->n.shape(1);
+    const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
+    if (!ctx || !whole)
+        throw std::runtime_error("lwhip plugin: stat_eq needs an atom of a live Context and the full depth range");
+    sync_state(*ctx, false);
+    auto* st = (PluginState*)ctx->methodScratch;
+    if (lwhip_upload(st->hip, LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
+        fail("lwhip_upload");
+    const int rc = lwhip_stat_equil(st->hip, idx);
+    if (rc == LWHIP_ERR_SINGULAR)
+        throw std::runtime_error("Singular Matrix"); // Source/LuSolve.cpp:22-23 -> ExplodingMatrixError
+    if (rc != LWHIP_OK)
+        fail("lwhip_stat_equil");
+    if (lwhip_download(st->hip, LWHIP_POPS) != LWHIP_OK)
+        fail("lwhip_download");
+}
+
+// scratch hooks (Source/LwFormalInterface.hpp:102-108; called from Source/ThreadStorage.cpp:480-493,538-566)
+void alloc_global_scratch_hip(Context* ctx)
+{
+    ctx->methodScratch = nullptr; // the device context is created on first use, when the arrays are final
+}
+
+void free_global_scratch_hip(Context* ctx)
+{
+    destroy_state(ctx);
+}
+}
+
+extern "C"
+{
+FsIterationFns fs_iteration_fns_provider()
+{
+    return FsIterationFns{
+        1,      // Ndim
+        true,   // dimensionSpecific
+        true,   // respectsFormalSolver (the three 1D solvers are selected by name)
+        true,   // defaultPerAtomStorage: kept for the forwarded core routines below
+        true,   // defaultWlaGijStorage
+        "mali_full_precond_hip_gfx950",
+        fs_iter_hip,
+        simple_fs_hip,
+        formal_sol_full_stokes_impl,      // not accelerated: the core's own (final synthesis only)
+        redistribute_prd_lines_scalar,    // not accelerated yet: the core's own
+        stat_eq_hip,
+        time_dependent_update_impl,       // not accelerated yet: the core's own
+        nr_post_update_impl,              // not accelerated yet: the core's own
+        nullptr, nullptr, nullptr, nullptr,
+        alloc_global_scratch_hip,
+        free_global_scratch_hip,
+        nullptr
+    };
+}
+}

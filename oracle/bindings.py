@@ -144,6 +144,8 @@ class OracleContext(_Handle):
             lib.lworacle_formal_sol_gamma_matrices.argtypes = [
                 C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.lwhip_iter_result), abi.f64p]
             lib.lworacle_formal_sol.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            lib.lworacle_fs_partial.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, abi.f64p, abi.f64p]
+            lib.lworacle_fs_finalise.argtypes = [C.c_void_p, abi.f64p]
             lib.lworacle_stat_equil.argtypes = [C.c_void_p, C.c_int]
             lib.lworacle_w2.argtypes = [C.c_double, abi.f64p]
             lib.lworacle_bezier3_coeffs.argtypes = [C.c_double, abi.f64p]
@@ -176,6 +178,14 @@ class OracleContext(_Handle):
 
     def formal_sol(self, upOnly=True, Nthreads=1):
         assert self.lib.lworacle_formal_sol(self.h, int(upOnly), Nthreads) == 0
+
+    def fs_partial_shard(self, laStart, laEnd, red, dJ, lambdaIterate=False):
+        assert self.lib.lworacle_fs_partial(self.h, int(lambdaIterate), laStart, laEnd,
+                                            red.ctypes.data_as(abi.f64p),
+                                            dJ.ctypes.data_as(abi.f64p)) == 0
+
+    def fs_finalise_shard(self, red):
+        assert self.lib.lworacle_fs_finalise(self.h, red.ctypes.data_as(abi.f64p)) == 0
 
     def stat_equil(self, atom=-1):
         return self.lib.lworacle_stat_equil(self.h, atom)

@@ -1,0 +1,124 @@
+"""The Lightweaver plugin (lightweaver_amd/LwHipIterScheme.so): loaded by the REAL core through its
+own FsIterationFnsManager::load_fns_from_path (Source/FormalInterface.cpp:62-81), selected as the
+iteration scheme of a reference `Context`, and driven through the reference entry points
+formal_sol_gamma_matrices / formal_sol / stat_eq -- i.e. the drop-in path a Lightweaver user gets.
+Needs oracle/_ref (built where the reference sources are; the .so files travel to the GPU box)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import TOL_CONVERGED, TOL_ONE_CALL, collect, load_fixture, rel_err, variant_problem
+from lightweaver_amd import _abi as abi
+from lightweaver_amd import build
+from oracle import bindings
+from oracle.bindings import RefContext
+
+PLUGIN = build.PLUGIN
+needs_ref = pytest.mark.skipif(not (bindings.ref_available() and os.path.exists(PLUGIN)),
+                               reason='reference build / plugin not present')
+
+
+@needs_ref
+def test_provider_is_loadable_and_named(hip_lib):
+    base, _ = load_fixture('falc_h_vel')
+    rc = RefContext(base.copy(), scheme=PLUGIN)
+    assert rc.scheme_name == 'mali_full_precond_hip_gfx950'
+
+
+@needs_ref
+def test_plugin_fails_loudly_without_gpu(hip_lib, capfd):
+    if hip_lib.lwhip_device_count() > 0:
+        pytest.skip('a GPU is present')
+    base, _ = load_fixture('falc_h_vel')
+    p = base.copy()
+    rc = RefContext(p, scheme=PLUGIN)
+    J0 = p.J.copy()
+    st = rc.lib.lwref_formal_sol_gamma_matrices(rc.h, 0, None)
+    assert st != 0                      # the C++ exception surfaced through the driver
+    assert 'no HIP device' in capfd.readouterr().err
+    assert np.array_equal(p.J, J0)      # and nothing was computed on the CPU instead
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['falc_h_ca_small', 'falc_h_vel'])
+def test_dropin_matches_scalar_scheme(gpu, name):
+    base, d = load_fixture(name)
+    p, q = variant_problem(base, d, 'iter1'), variant_problem(base, d, 'iter1')
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(3):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        r1 = hipc.formal_sol_gamma_matrices()
+        r2 = ref.formal_sol_gamma_matrices()
+        assert abs(r1[0] / r2[0] - 1.0) <= TOL_ONE_CALL
+        a, b = collect(p, ('J', 'I', 'Gamma', 'R')), collect(q, ('J', 'I', 'Gamma', 'R'))
+        worst = {k: rel_err(a[k], b[k]) for k in a}
+        assert max(worst.values()) <= TOL_ONE_CALL * (it + 1), (it, worst)
+        assert rel_err(p.depthI, q.depthI) <= TOL_ONE_CALL * (it + 1)
+        assert hipc.stat_equil() == ref.stat_equil() == 0
+        for x, y in zip(p.atoms, q.atoms):
+            assert rel_err(x.n, y.n) <= 1e-7
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_formal_sol_and_solvers(gpu):
+    base, d = load_fixture('falc_h_ca_small')
+    for solver in (abi.FS_LINEAR_1D, abi.FS_BESSER_1D, abi.FS_BEZIER3_1D):
+        p, q = base.copy(), base.copy()
+        p.formalSolver = q.formalSolver = solver
+        hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+        for upOnly in (True, False):
+            hipc.formal_sol(upOnly=upOnly)
+            ref.formal_sol(upOnly=upOnly)
+            assert rel_err(p.I, q.I) <= TOL_ONE_CALL
+        p.gamma_prefill()
+        q.gamma_prefill()
+        hipc.formal_sol_gamma_matrices()
+        ref.formal_sol_gamma_matrices()
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_iterates_like_the_reference(gpu):
+    """iterate_ctx_se-style loop (lightweaver/iterate_ctx.py:157-176) with the host arrays
+    authoritative: 25 iterations, populations updated from iteration 3 on."""
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = base.copy(), base.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(25):
+        for prob, c in ((p, hipc), (q, ref)):
+            prob.gamma_prefill()
+            c.formal_sol_gamma_matrices()
+            if it >= 3:
+                assert c.stat_equil() == 0
+    assert rel_err(p.J, q.J) <= TOL_CONVERGED
+    for x, y in zip(p.atoms, q.atoms):
+        assert rel_err(x.n, y.n) <= TOL_CONVERGED
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_sees_host_side_changes(gpu):
+    """The plugin re-uploads what the host changed between calls (populations, J, profiles,
+    background), as the reference shares memory with the Python layer."""
+    base, d = load_fixture('falc_h_vel')
+    p, q = base.copy(), base.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    rng = np.random.default_rng(5)
+    for it in range(3):
+        scale = 1.0 + 0.1 * rng.random(p.bgChi.shape)
+        for prob in (p, q):
+            prob.bgChi *= scale
+            prob.atoms[0].n *= 1.01
+            for t in prob.atoms[0].trans:
+                if t.type == abi.LINE:
+                    t.phi *= 1.0 + 1e-3 * it
+            prob.gamma_prefill()
+        hipc.formal_sol_gamma_matrices()
+        ref.formal_sol_gamma_matrices()
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL
+        assert rel_err(p.atoms[0].Gamma, q.atoms[0].Gamma) <= TOL_ONE_CALL
