@@ -94,6 +94,7 @@ struct lwhip_context
     int laStart = 0, laEnd = 0, Nla = 0;
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
     int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, G = 1;
+    bool big = false;
     int64_t gammaTot = 0, phiTot = 0, rhoTot = 0, parTot = 0;
     hipStream_t ownStream = nullptr, stream = nullptr;
 
@@ -115,6 +116,7 @@ struct lwhip_context
     std::vector<double> gatherHost;
     DevBuf<int32_t> status;
     DevBuf<long long> stamps;
+    DevBuf<double> bigScratch;
 
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -607,8 +609,12 @@ int build_tables(lwhip_context* c)
         s.NlevTot = c->NlevTot;
         s.maxC = c->maxC;
         s.maxCT = c->maxCT;
+        s.big = c->big ? 1 : 0;
         return sweep_lds_bytes(s, g);
     };
+    // deep atmospheres: when even one ray per pass does not fit the LDS, keep the per-depth rows,
+    // continuum tables and accumulators in a global (L2-resident) scratch instead
+    c->big = env_int("LWHIP_BIG", 0) != 0 || ldsFor(1) > ldsMax;
     // Rays per pass.  Two co-resident workgroups per CU hide each other's barrier and latency
     // stalls (measured: 0.51 ms vs 0.66 ms per sweep on the north-star grid), so prefer half of
     // the rays per pass when two such workgroups fit the 160 KB LDS; otherwise all rays at once;
@@ -722,6 +728,15 @@ int alloc_state(lwhip_context* c)
     c->gatherHost.assign(2 * (size_t)c->worldSize, 0.0);
     HIP_TRY(c->dJ.alloc(Nla));
     HIP_TRY(c->status.alloc(1));
+    if (c->big)
+    {
+        SweepArgs sz{};
+        sz.Ns = c->Ns;
+        sz.Natom = c->Natom;
+        sz.NlevTot = c->NlevTot;
+        sz.maxC = c->maxC;
+        HIP_TRY(c->bigScratch.alloc((size_t)c->nChunks * sweep_big_scratch_doubles(sz)));
+    }
     HIP_TRY(c->stamps.alloc((size_t)c->nChunks * 12));
     HIP_TRY(hipMemset(c->stamps.p, 0, c->stamps.n * sizeof(long long)));
     if (c->prob.zLowerBc.type == LWHIP_BC_CALLABLE)
@@ -758,6 +773,7 @@ int build_sweep_args(lwhip_context* c)
     a.lowerNmu = c->prob.zLowerBc.Nmu;
     a.upperNmu = c->prob.zUpperBc.Nmu;
     a.storeDepth = c->prob.storeDepthData ? 1 : 0;
+    a.big = c->big ? 1 : 0;
     a.height = c->height.p;
     a.temperature = c->temperature.p;
     a.muz = c->muz.p;
@@ -789,6 +805,7 @@ int build_sweep_args(lwhip_context* c)
     a.partial = c->partial.p;
     a.dJ = c->dJ.p;
     a.stamps = c->stamps.p;
+    a.bigScratch = c->bigScratch.p;
     c->hargs = a;
     std::vector<SweepArgs> v(1, a);
     HIP_TRY(c->dargs.upload(v));

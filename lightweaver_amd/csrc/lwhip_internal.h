@@ -96,7 +96,7 @@ struct SweepArgs
     int32_t maxCT;         // accumulator slots per chunk
     int32_t lowerBc, upperBc, lowerNmu, upperNmu;
     int32_t storeDepth;
-    int32_t _pad;
+    int32_t big;           // deep-atmosphere mode: rows / continuum tables / accumulators in global scratch
     const double* height;
     const double* temperature;
     const double* muz;
@@ -128,6 +128,7 @@ struct SweepArgs
     double* partial;               // [nChunks*maxCT, 4, Ns]
     double* dJ;                    // [Nla]
     long long* stamps;             // [nChunks, 12] diagnostic build only (-DLWHIP_STAMPS)
+    double* bigScratch;            // [nChunks, sweep_big_scratch_doubles] (big mode only)
 };
 
 // Per-launch part, passed by value.
@@ -169,6 +170,7 @@ struct ApplyArgs
 
 // launch helpers implemented in lwhip_kernels.hip
 size_t sweep_lds_bytes(const SweepArgs& a, int G);
+size_t sweep_big_scratch_doubles(const SweepArgs& a);
 hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn,
                         int solver, int maxL, bool rates, int nChunks, hipStream_t stream);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);

@@ -238,17 +238,32 @@ DEVINL void d_bezier3_coeffs_r(double dt, double& alpha, double& beta, double& g
 // rows      : chiC etaC etaA[Natom] levChi[NlevTot] levU[NlevTot]      (row-program targets)
 // [maxC][Ns] Vji   [maxC][Ns] chi_c   [maxCT][4][Ns] accumulators   (populations n: global, L1)
 // program   : rows + entries of the current row program
-__host__ __device__ inline size_t lds_doubles(int Ns, int G, int Natom, int NlevTot, int maxC, int maxCT)
+// BIG mode (deep atmospheres): the row-program rows, the continuum tables and the accumulators live
+// in an L2-resident global scratch of the chunk instead of LDS.
+__host__ __device__ inline size_t lds_doubles(int Ns, int G, int Natom, int NlevTot, int maxC, int maxCT, bool big)
 {
-    return (size_t)4 * G * Ns + (size_t)12 * Ns + (size_t)(2 + Natom + 2 * NlevTot) * Ns
-           + (size_t)2 * maxC * Ns + (size_t)maxCT * 4 * Ns
+    return (size_t)4 * G * Ns + (size_t)12 * Ns
+           + (big ? 0 : (size_t)(2 + Natom + 2 * NlevTot) * Ns + (size_t)2 * maxC * Ns + (size_t)maxCT * 4 * Ns)
            + (LWHIP_MAX_PROG_ROWS * sizeof(DevProgRow) + LWHIP_MAX_PROG_ENTS * sizeof(DevProgEnt)) / 8 + 8
            + 64 + 64 + 32 + 2 * maxC;
 }
 
 size_t sweep_lds_bytes(const SweepArgs& a, int G)
 {
-    return sizeof(double) * lds_doubles(a.Ns, G, a.Natom, a.NlevTot, a.maxC, a.maxCT);
+    return sizeof(double) * lds_doubles(a.Ns, G, a.Natom, a.NlevTot, a.maxC, a.maxCT, a.big != 0);
+}
+
+size_t sweep_big_scratch_doubles(const SweepArgs& a)
+{
+    return (size_t)(2 + a.Natom + 2 * a.NlevTot + 2 * a.maxC) * a.Ns;
+}
+
+template <bool BIG> DEVINL void wg_barrier()
+{
+    if (BIG)
+        __syncthreads(); // also orders the global scratch traffic inside the workgroup
+    else
+        lds_barrier();
 }
 
 // ---- the sweep ---------------------------------------------------------------------------------------
@@ -269,7 +284,7 @@ size_t sweep_lds_bytes(const SweepArgs& a, int G)
 #define STAMP(i)
 #endif
 
-template <int SOLVER, int MAXL, bool RATES>
+template <int SOLVER, int MAXL, bool RATES, bool BIG>
 __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict__ ap, const SweepDyn dyn)
 {
     extern __shared__ double lds[];
@@ -333,16 +348,34 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     double* sSca = sIn + Ns;
     double* sBgChi = sIn + 2 * Ns;
     double* sBgEta = sIn + 3 * Ns;
-    double* sRows = sK + 12 * Ns;
+    double* carve = sK + 12 * Ns;
+    double* sRows;
+    double* sVji;
+    double* sChiCo;
+    double* sAcc;
+    const int nRowsTot = 2 + Natom + 2 * NlevTot;
+    if (BIG)
+    {
+        double* gs = ARGS.bigScratch + (size_t)blockIdx.x * (size_t)(nRowsTot + 2 * maxC) * Ns;
+        sRows = gs;
+        sVji = gs + (size_t)nRowsTot * Ns;
+        sChiCo = sVji + (size_t)maxC * Ns;
+        sAcc = ARGS.partial + (size_t)blockIdx.x * maxCT * 4 * Ns;
+    }
+    else
+    {
+        sRows = carve;
+        sVji = carve + nRowsTot * Ns;
+        sChiCo = sVji + maxC * Ns;
+        sAcc = sChiCo + maxC * Ns;
+        carve = sAcc + maxCT * 4 * Ns;
+    }
     double* sChiC = sRows;
     double* sEtaC = sRows + Ns;
     double* sEtaA = sRows + 2 * Ns;
     double* sLevChi = sEtaA + Natom * Ns;
     double* sLevU = sLevChi + NlevTot * Ns;
-    double* sVji = sLevU + NlevTot * Ns;
-    double* sChiCo = sVji + maxC * Ns;
-    double* sAcc = sChiCo + maxC * Ns;
-    DevProgRow* sProgRows = (DevProgRow*)(sAcc + maxCT * 4 * Ns);
+    DevProgRow* sProgRows = (DevProgRow*)carve;
     DevProgEnt* sProgEnts = (DevProgEnt*)(sProgRows + LWHIP_MAX_PROG_ENTS * 0 + LWHIP_MAX_PROG_ROWS);
     double* sRayMuz = (double*)(sProgEnts + LWHIP_MAX_PROG_ENTS); // [64] muz of each active ray
     double* sRayW = sRayMuz + 64;                                  // [64] 0.5 * wmu
@@ -495,7 +528,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             }
             havePfRatio = true;
         }
-        lds_barrier();
+        wg_barrier<BIG>();
         STAMP(1);
         // row program: totals, per-atom emissivity and per-level sums over the continua, one
         // (row, depth) task per thread, continua added in reference order
@@ -525,7 +558,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             }
             sRows[pr.row * Ns + kk] = v;
         }
-        lds_barrier();
+        wg_barrier<BIG>();
         STAMP(2);
 
         // ---- passes over groups of G rays -----------------------------------------------------------
@@ -619,7 +652,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     havePfPhi = true;
                 }
             }
-            lds_barrier();
+            wg_barrier<BIG>();
             STAMP(3);
 
             // ---- formal solver: per-point coefficients e, b, Psi of I_k = e I_upwind + b ------------
@@ -717,7 +750,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                         dtauLin = 0.5 * zmu * (chi + col[k - dk]) * sDh[min(k, k - dk)];
                     sDS[t] = dS;
                 }
-                lds_barrier();
+                wg_barrier<BIG>();
                 STAMP(4);
                 // coefficients  :265-275, 294-304, 314-321
                 if (active)
@@ -821,7 +854,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 sE[t] = e;
                 sB[t] = b;
             }
-            lds_barrier();
+            wg_barrier<BIG>();
             STAMP(5);
 
             // ---- the recurrence I_k = e_k I_{k-1} + b_k: one wavefront per ray, each lane composes
@@ -863,7 +896,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     }
                 }
             }
-            lds_barrier();
+            wg_barrier<BIG>();
             STAMP(6);
 
             double I = 0.0;
@@ -982,7 +1015,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     lds_add(acc + 3 * Ns, (uji + I * vji) * wlamu);
                 }
             }
-            lds_barrier();
+            wg_barrier<BIG>();
             STAMP(7);
             // accumulate_J :181-190 and the Psi* moments, rays in reference order
             if (RATES)
@@ -1007,7 +1040,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     sJ[m * Ns + kk] = acc;
                 }
             }
-            lds_barrier();
+            wg_barrier<BIG>();
             STAMP(8);
         } // ray groups
 
@@ -1033,11 +1066,29 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     const double M1 = sJ[Ns + kk];
                     const double Meta = (sl.ms >= 0) ? sJ[(2 + sl.ms) * Ns + kk] : 0.0;
                     const double Jeff = Jk - M1 * sEtaA[sl.atom * Ns + kk] - Meta;
-                    acc[0] += ((uji * Wsum + vji * Jeff) - (M1 * sLevChi[sl.gi * Ns + kk] * sLevU[sl.gj * Ns + kk])) * wla;
-                    acc[Ns] += ((vij * Jeff) - (M1 * sLevChi[sl.gj * Ns + kk] * sLevU[sl.gi * Ns + kk])) * wla;
+                    const double g0v = ((uji * Wsum + vji * Jeff) - (M1 * sLevChi[sl.gi * Ns + kk] * sLevU[sl.gj * Ns + kk])) * wla;
+                    const double g1v = ((vij * Jeff) - (M1 * sLevChi[sl.gj * Ns + kk] * sLevU[sl.gi * Ns + kk])) * wla;
+                    if (BIG) // accumulators in global memory are only ever touched atomically (L2)
+                    {
+                        lds_add(acc, g0v);
+                        lds_add(acc + Ns, g1v);
+                    }
+                    else
+                    {
+                        acc[0] += g0v;
+                        acc[Ns] += g1v;
+                    }
                 }
-                acc[2 * Ns] += Jk * vij * wla;
-                acc[3 * Ns] += (uji * Wsum + Jk * vji) * wla;
+                if (BIG)
+                {
+                    lds_add(acc + 2 * Ns, Jk * vij * wla);
+                    lds_add(acc + 3 * Ns, (uji * Wsum + Jk * vji) * wla);
+                }
+                else
+                {
+                    acc[2 * Ns] += Jk * vij * wla;
+                    acc[3 * Ns] += (uji * Wsum + Jk * vji) * wla;
+                }
             }
             // ---- J out, dJ = max_k |1 - Jdag/J|  :477-486 ---------------------------------------------------
             if ((t & ~63) < Ns) // whole wavefronts, so the shuffles see every lane
@@ -1056,7 +1107,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     atomicMax((unsigned long long*)(a.dJ + la), (unsigned long long)__double_as_longlong(dj));
             }
         }
-        lds_barrier();
+        wg_barrier<BIG>();
         // hand the prefetched inputs of the next wavelength over to LDS (made visible by the next
         // wavelength's first barrier; nothing reads these rows before it)
         if (pfInputs && inOwner && !lastLa)
@@ -1064,7 +1115,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         STAMP(9);
     } // wavelengths
 
-    if (RATES)
+    if (RATES && !BIG)
     {
         GLOBAL_AS double* out = gPartial + (size_t)chunk * maxCT * 4 * Ns;
         for (int idx = t; idx < maxCT * 4 * Ns; idx += T)
@@ -1080,7 +1131,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
 
 #undef ARGS
 
-template <int SOLVER, int MAXL, bool RATES>
+template <int SOLVER, int MAXL, bool RATES, bool BIG>
 static hipError_t launch_sweep_t(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn,
                                  int nChunks, hipStream_t stream)
 {
@@ -1088,7 +1139,7 @@ static hipError_t launch_sweep_t(const SweepArgs* devArgs, const SweepArgs& a, c
     static size_t configured = 0;
     if (lds > configured)
     {
-        hipError_t err = hipFuncSetAttribute((const void*)sweep_kernel<SOLVER, MAXL, RATES>,
+        hipError_t err = hipFuncSetAttribute((const void*)sweep_kernel<SOLVER, MAXL, RATES, BIG>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess)
             return err;
@@ -1098,7 +1149,7 @@ static hipError_t launch_sweep_t(const SweepArgs* devArgs, const SweepArgs& a, c
     int T = ((std::max(dyn.G * a.Ns, 64) + 63) / 64) * 64;
     if (T > 1024)
         return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((sweep_kernel<SOLVER, MAXL, RATES>), dim3(nChunks), dim3(T), lds, stream, devArgs, dyn);
+    hipLaunchKernelGGL((sweep_kernel<SOLVER, MAXL, RATES, BIG>), dim3(nChunks), dim3(T), lds, stream, devArgs, dyn);
     return hipGetLastError();
 }
 
@@ -1106,11 +1157,19 @@ template <int SOLVER, bool RATES>
 static hipError_t launch_sweep_l(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn,
                                  int maxL, int nChunks, hipStream_t stream)
 {
+    if (a.big)
+    {
+        if (maxL <= 2)
+            return launch_sweep_t<SOLVER, 2, RATES, true>(devArgs, a, dyn, nChunks, stream);
+        if (maxL <= 4)
+            return launch_sweep_t<SOLVER, 4, RATES, true>(devArgs, a, dyn, nChunks, stream);
+        return launch_sweep_t<SOLVER, 8, RATES, true>(devArgs, a, dyn, nChunks, stream);
+    }
     if (maxL <= 2)
-        return launch_sweep_t<SOLVER, 2, RATES>(devArgs, a, dyn, nChunks, stream);
+        return launch_sweep_t<SOLVER, 2, RATES, false>(devArgs, a, dyn, nChunks, stream);
     if (maxL <= 4)
-        return launch_sweep_t<SOLVER, 4, RATES>(devArgs, a, dyn, nChunks, stream);
-    return launch_sweep_t<SOLVER, 8, RATES>(devArgs, a, dyn, nChunks, stream);
+        return launch_sweep_t<SOLVER, 4, RATES, false>(devArgs, a, dyn, nChunks, stream);
+    return launch_sweep_t<SOLVER, 8, RATES, false>(devArgs, a, dyn, nChunks, stream);
 }
 
 hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn, int solver,

@@ -123,6 +123,17 @@ def test_ragged_sizes_vs_oracle(gpu, Nspace, Nrays):
     compare_problems(p, q)
 
 
+def test_deep_atmosphere_mode_forced_on_small_problem(gpu, monkeypatch):
+    """The global-scratch ('big') variant of the sweep, normally selected only when the LDS working
+    set does not fit (e.g. 500 depth points), forced on the 82-point H + Ca II problem."""
+    monkeypatch.setenv('LWHIP_BIG', '1')
+    base, d = load_fixture('falc_h_ca_small')
+    p = variant_problem(base, d, 'iter1')
+    with Context(p) as ctx:
+        ctx.formal_sol_gamma_matrices()
+    compare_to_golden(p, d, 'iter1')
+
+
 def test_wavelength_shards_sum_to_whole(gpu):
     """Two contexts owning [0, m) and [m, Nlambda): their reduce buffers add up to the unsharded
     one and J/I rows are owner-exclusive (the multi-GPU split, on one device)."""
