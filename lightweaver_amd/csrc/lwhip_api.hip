@@ -79,6 +79,7 @@ struct HostTrans
     int ltStart;           // first own-grid index inside the shard
     int row;               // wphi row (lines) / ratio row (continua)
     int64_t parOff, phiOff, rhoOff;
+    int64_t waveOff; // lines: offset of the full own grid / wlambda in the lineWave / lineWlam pools
 };
 }
 
@@ -102,6 +103,7 @@ struct lwhip_context
     DevBuf<int32_t> rayAll, rayUp, lowerIdx, upperIdx;
     DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
+    DevBuf<double> vlosMu, vBroad, aDamp, lineWave, lineWlam;
     DevBuf<DevTrans> dtrans;
     DevBuf<DevLaHeader> laHdr;
     DevBuf<DevSlot> slots;
@@ -669,6 +671,30 @@ int build_tables(lwhip_context* c)
     }
     std::vector<int32_t> atomTrOff32(c->atomTrOff.begin(), c->atomTrOff.end());
 
+    // full own grids and trapezoid weights of the lines (device Voigt profiles)
+    {
+        std::vector<double> lw, lq;
+        for (auto& h : c->trans)
+        {
+            h.waveOff = -1;
+            if (h.t.type != LWHIP_LINE)
+                continue;
+            h.waveOff = (int64_t)lw.size();
+            const int len = h.t.Nred - h.t.Nblue;
+            for (int lt = 0; lt < len; ++lt)
+            {
+                lw.push_back(h.t.wavelength[lt]);
+                lq.push_back(trans_wlambda(h.t, lt));
+            }
+        }
+        if (lw.empty())
+        {
+            lw.push_back(0.0);
+            lq.push_back(0.0);
+        }
+        HIP_TRY(c->lineWave.upload(lw));
+        HIP_TRY(c->lineWlam.upload(lq));
+    }
     HIP_TRY(c->par.upload(par));
     HIP_TRY(c->dtrans.upload(dt));
     HIP_TRY(c->laHdr.upload(hdr));
@@ -709,6 +735,10 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(c->depthEta.alloc(Nla * Nr * 2 * Ns));
         HIP_TRY(c->depthI.alloc(Nla * Nr * 2 * Ns));
     }
+    HIP_TRY(c->vlosMu.alloc(Nr * Ns));
+    HIP_TRY(c->vBroad.alloc((size_t)std::max(c->Natom, 1) * Ns));
+    HIP_TRY(c->aDamp.alloc((size_t)std::max(c->Nline, 1) * Ns));
+    HIP_TRY(hipMemset(c->aDamp.p, 0, c->aDamp.n * sizeof(double)));
     HIP_TRY(c->n.alloc((size_t)c->NlevTot * Ns));
     HIP_TRY(c->nTotal.alloc((size_t)c->Natom * Ns));
     HIP_TRY(c->ratio.alloc((size_t)std::max(c->Ncont, 1) * Ns));
@@ -976,6 +1006,8 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         H2D(c->muz.p, p.muz, Nr);
         H2D(c->wmu.p, p.wmu, Nr);
         H2D(c->wavelength.p, p.wavelength + l0, Nla);
+        if (p.vlosMu)
+            H2D(c->vlosMu.p, p.vlosMu, Nr * Ns);
     }
     if (mask & LWHIP_BACKGROUND)
     {
@@ -1009,7 +1041,10 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         if (mask & LWHIP_POPS)
             H2D(c->n.p + (size_t)c->levelOff[ia] * Ns, a.n, (size_t)a.Nlevel * Ns);
         if (mask & LWHIP_NSTAR)
+        {
             H2D(c->nTotal.p + (size_t)ia * Ns, a.nTotal, Ns);
+            H2D(c->vBroad.p + (size_t)ia * Ns, a.vBroad, Ns);
+        }
         if (!a.detailed && (mask & LWHIP_GAMMA))
             H2D(c->Gamma.p + c->gammaOff[ia], a.Gamma, (size_t)a.Nlevel * a.Nlevel * Ns);
         if (!a.detailed && (mask & LWHIP_COLLISIONS) && a.C)
@@ -1027,6 +1062,8 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                         H2D(c->phi.p + h.phiOff, t.phi + (size_t)h.ltStart * Nr * 2 * Ns, nlt * Nr * 2 * Ns);
                     H2D(c->wphi.p + (size_t)h.row * Ns, t.wphi, Ns);
                 }
+                if ((mask & LWHIP_NSTAR) && t.aDamp)
+                    H2D(c->aDamp.p + (size_t)h.row * Ns, t.aDamp, Ns);
                 if ((mask & LWHIP_RHOPRD) && t.prd && nlt)
                     H2D(c->rho.p + h.rhoOff, t.rhoPrd + (size_t)h.ltStart * Ns, nlt * Ns);
             }
@@ -1253,7 +1290,34 @@ int lwhip_compute_profiles(lwhip_context* c)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
-    return fail(LWHIP_ERR_UNSUPPORTED, "lwhip_compute_profiles: device Voigt kernel not built yet");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->prob.vlosMu)
+        return fail(LWHIP_ERR_INVALID, "lwhip_compute_profiles needs vlosMu in the descriptor");
+    for (int tr = 0; tr < c->Ntrans; ++tr)
+    {
+        const HostTrans& h = c->trans[tr];
+        if (h.t.type != LWHIP_LINE)
+            continue;
+        if (!h.t.aDamp)
+            return fail(LWHIP_ERR_INVALID, "lwhip_compute_profiles needs aDamp for every line");
+        VoigtLineArgs a{};
+        a.Ns = c->Ns;
+        a.Nrays = c->Nrays;
+        a.nlt = h.NredLoc - h.NblueLoc;
+        a.ltStart = h.ltStart;
+        a.nltFull = h.t.Nred - h.t.Nblue;
+        a.lambda0 = h.t.lambda0;
+        a.wave = c->lineWave.p + h.waveOff;
+        a.wlam = c->lineWlam.p + h.waveOff;
+        a.vlosMu = c->vlosMu.p;
+        a.wmu = c->wmu.p;
+        a.vBroad = c->vBroad.p + (size_t)h.atom * c->Ns;
+        a.aDamp = c->aDamp.p + (size_t)h.row * c->Ns;
+        a.phi = c->phi.p + (a.nlt > 0 ? h.phiOff : 0);
+        a.wphi = c->wphi.p + (size_t)h.row * c->Ns;
+        HIP_TRY(launch_voigt_line(a, c->stream));
+    }
+    return LWHIP_OK;
 }
 
 int lwhip_synchronize(lwhip_context* c)

@@ -168,6 +168,26 @@ struct ApplyArgs
     double* Rji;                   // [Ntrans, Ns]
 };
 
+// One line's profile evaluation (lwhip_voigt.hip)
+struct VoigtLineArgs
+{
+    int32_t Ns, Nrays;
+    int32_t nlt;        // rows of this context's shard
+    int32_t ltStart;    // first own-grid index of the shard
+    int32_t nltFull;    // full length of the line's grid
+    int32_t _pad;
+    double lambda0;
+    const double* wave;     // [nltFull] the line's own wavelength grid
+    const double* wlam;     // [nltFull] Transition::wlambda
+    const double* vlosMu;   // [Nrays, Ns]
+    const double* wmu;      // [Nrays]
+    const double* vBroad;   // [Ns] of the line's atom
+    const double* aDamp;    // [Ns]
+    double* phi;            // [nlt, Nrays, 2, Ns]
+    double* wphi;           // [Ns]
+};
+hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream);
+
 // launch helpers implemented in lwhip_kernels.hip
 size_t sweep_lds_bytes(const SweepArgs& a, int G);
 size_t sweep_big_scratch_doubles(const SweepArgs& a);

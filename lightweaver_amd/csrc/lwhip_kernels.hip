@@ -245,7 +245,7 @@ __host__ __device__ inline size_t lds_doubles(int Ns, int G, int Natom, int Nlev
     return (size_t)4 * G * Ns + (size_t)12 * Ns
            + (big ? 0 : (size_t)(2 + Natom + 2 * NlevTot) * Ns + (size_t)2 * maxC * Ns + (size_t)maxCT * 4 * Ns)
            + (LWHIP_MAX_PROG_ROWS * sizeof(DevProgRow) + LWHIP_MAX_PROG_ENTS * sizeof(DevProgEnt)) / 8 + 8
-           + 64 + 64 + 32 + 2 * maxC;
+           + 64 + 64 + 32 + 2 * maxC + 8;
 }
 
 size_t sweep_lds_bytes(const SweepArgs& a, int G)
@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     int* sRayId = (int*)(sRayW + 64);                               // [64] r = 2 mu + toObs
     double* sCp2 = (double*)(sRayId + 64);                          // [maxC] 2hc/lambda^3 of continuum c
     int* sCgj = (int*)(sCp2 + maxC);                                // [maxC] upper level row of continuum c
+    double* sPlanck = (double*)(sCgj + maxC + (maxC & 1));          // [4] B_nu at T[Ns-2], T[Ns-1], T[0], T[1]
 
     // idx / Ns for idx * Ns < 2^32 as one mul_hi (magic = ceil(2^32 / Ns))
     const unsigned divMagic = (unsigned)((0x100000000ull + (unsigned)Ns - 1) / (unsigned)Ns);
@@ -505,6 +506,12 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         {
             sCp2[t] = slots[nLine + t].p[2];
             sCgj[t] = slots[nLine + t].gj;
+        }
+        if (t >= T - 4) // boundary Planck functions, once per wavelength (the last wavefront has idle lanes)
+        {
+            const int q = t - (T - 4);
+            const int kq = (q == 0) ? Ns - 2 : (q == 1) ? Ns - 1 : (q == 2) ? 0 : 1;
+            sPlanck[q] = d_planck(sTemp[kq], wav);
         }
         for (int idx = t; idx < nCont * Ns; idx += T)
         {
@@ -676,8 +683,8 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 {
                     if (a.lowerBc == LWHIP_BC_THERMALISED)
                     {
-                        const double B0 = d_planck(sTemp[Ns - 2], wav);
-                        const double B1 = d_planck(sTemp[Ns - 1], wav);
+                        const double B0 = sPlanck[0];
+                        const double B1 = sPlanck[1];
                         Istart = B1 - (B0 - B1) / dtau_b;
                     }
                     else if (a.lowerBc == LWHIP_BC_CALLABLE)
@@ -691,8 +698,8 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 {
                     if (a.upperBc == LWHIP_BC_THERMALISED)
                     {
-                        const double B0 = d_planck(sTemp[0], wav);
-                        const double B1 = d_planck(sTemp[1], wav);
+                        const double B0 = sPlanck[2];
+                        const double B1 = sPlanck[3];
                         Istart = B0 - (B1 - B0) / dtau_b;
                     }
                     else if (a.upperBc == LWHIP_BC_CALLABLE)
@@ -752,21 +759,40 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 }
                 wg_barrier<BIG>();
                 STAMP(4);
-                // coefficients  :265-275, 294-304, 314-321
+                // coefficients  :265-275, 294-304, 314-321.  One exp call site serves the interior
+                // points (Bezier3_coeffs) and the end point (w2), so a wavefront never runs two.
                 if (active)
                 {
+                    const bool isEnd = (k == kE);
+                    const double x = isEnd ? dtauLin : dtau;
+                    const bool needExp = (k != kS) && (isEnd ? (x >= 5.0E-4 && x <= 50.0) : (x >= 5e-2 && x <= 30.0));
+                    const double ex = needExp ? exp(-x) : 0.0;
                     if (k == kS)
                     {
                         e = 0.0;
                         b = Istart;
                         Psi = 0.0;
                     }
-                    else if (k == kE)
+                    else if (isEnd)
                     {
-                        const double rl_ = d_rcp(dtauLin);
+                        const double rl_ = d_rcp(x);
                         const double dSuw = (S - sS[cb + k - dk]) * rl_;
                         double w0, w1;
-                        d_w2(dtauLin, w0, w1);
+                        if (x < 5.0E-4) // w2, LwInternal.hpp:90-110
+                        {
+                            w0 = x * (1.0 - 0.5 * x);
+                            w1 = (x * x) * (0.5 - x * (1.0 / 3.0));
+                        }
+                        else if (x > 50.0)
+                        {
+                            w0 = 1.0;
+                            w1 = 1.0;
+                        }
+                        else
+                        {
+                            w0 = 1.0 - ex;
+                            w1 = w0 - x * ex;
+                        }
                         e = 1.0 - w0;
                         b = w0 * S - w1 * dSuw;
                         Psi = w0 - w1 * rl_;
@@ -774,9 +800,27 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     else
                     {
                         double al, be, ga, de, edt;
-                        d_bezier3_coeffs_r(dtau, al, be, ga, de, edt);
+                        const double dt2 = x * x;
+                        const double dt3c = dt2 * x;
+                        if (x < 5e-2) // Bezier3_coeffs, Bezier.hpp:81-127
+                        {
+                            edt = 1.0 - x + 0.5 * dt2 - dt3c * (1.0 / 6.0);
+                            al = 0.25 * x - 0.2 * dt2 + dt3c * (1.0 / 12.0);
+                            be = 0.25 * x - 0.05 * dt2 + dt3c * (1.0 / 120.0);
+                            ga = 0.25 * x - 0.15 * dt2 + 0.05 * dt3c;
+                            de = 0.25 * x - 0.1 * dt2 + 0.025 * dt3c;
+                        }
+                        else
+                        {
+                            edt = ex; // 0 beyond dt = 30: the asymptotic branch is the exact one with edt = 0
+                            const double r3 = d_rcp(dt3c);
+                            al = (6.0 - edt * (6.0 + 6.0 * x + 3 * dt2 + dt3c)) * r3;
+                            be = (6.0 * edt - 6.0 + 6.0 * x - 3.0 * dt2 + dt3c) * r3;
+                            ga = 3.0 * (2.0 * x - 6.0 + edt * (6.0 + 4.0 * x + dt2)) * r3;
+                            de = 3.0 * (6.0 - 4.0 * x + dt2 - 2.0 * edt * (3.0 + x)) * r3;
+                        }
                         const double Suw = sS[cb + k - dk];
-                        const double dt3 = dtau * (1.0 / 3.0);
+                        const double dt3 = x * (1.0 / 3.0);
                         const double cuw = Suw + dt3 * sDS[cb + k - dk];
                         const double c0 = S - dt3 * dS;
                         e = edt;
@@ -949,11 +993,10 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
 #pragma unroll
                     for (int l = 0; l < MAXL; ++l)
                     {
-                        if (lop[l])
-                        {
-                            v += (lgi[l] == g) ? xl[l] : 0.0;
-                            v -= (lgj[l] == g) ? xl[l] : 0.0;
-                        }
+                        if (lop[l] && lgi[l] == g) // wave-uniform conditions: scalar branches
+                            v += xl[l];
+                        if (lop[l] && lgj[l] == g)
+                            v -= xl[l];
                     }
                     return v;
                 };
@@ -962,8 +1005,8 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
 #pragma unroll
                     for (int l = 0; l < MAXL; ++l)
                     {
-                        if (lop[l])
-                            v += (lgj[l] == g) ? luji[l] : 0.0;
+                        if (lop[l] && lgj[l] == g)
+                            v += luji[l];
                     }
                     return v;
                 };
@@ -972,8 +1015,8 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
 #pragma unroll
                     for (int l = 0; l < MAXL; ++l)
                     {
-                        if (lop[l])
-                            v += (lat[l] == at) ? el[l] : 0.0;
+                        if (lop[l] && lat[l] == at)
+                            v += el[l];
                     }
                     return v;
                 };

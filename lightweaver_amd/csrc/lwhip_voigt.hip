@@ -1,0 +1,274 @@
+// lwhip_voigt.hip -- line profiles on the device: phi = H(a, v) / (sqrt(pi) vBroad) and
+// wphi = 1 / sum phi w_lambda w_mu/2 (Transition::compute_phi_la / compute_wphi,
+// Source/FormalScalar.cpp:28-51,106-134; voigt_H Source/LwMisc.hpp:13-19).
+//
+// H(a, v) = Re w(v + i a) is evaluated with the algorithm of the Faddeeva package the reference
+// vendors (Source/Faddeeva.cc:680-972, S. G. Johnson, MIT): Laplace continued fraction for large
+// |z|, Zaghloul & Ali's Algorithm 916 sums elsewhere.  exp(-a^2 n^2) comes from a table filled on
+// the host; erfcx is the device math library's.
+#include "lwhip_internal.h"
+#include "../../include/lwhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace lwhip
+{
+__constant__ double c_expa2n2[64];
+
+__device__ __forceinline__ double v_sinc(double x, double sinx)
+{
+    return fabs(x) < 1e-4 ? 1 - (0.1666666666666666666667) * x * x : sinx / x;
+}
+
+__device__ __forceinline__ double v_sinh_taylor(double x)
+{
+    return x * (1 + (x * x) * (0.1666666666666666666667 + 0.00833333333333333333333 * (x * x)));
+}
+
+__device__ double d_voigt_H(double av, double v)
+{
+    const double a = 0.518321480430085929872;
+    const double c = 0.329973702884629072537;
+    const double a2 = 0.268657157075235951582;
+    const double relerr = 2.2204460492503131e-16;
+    const double x = fabs(v);
+    const double y = av, ya = fabs(av);
+    if (v == 0.0)
+        return erfcx(y);
+    if (y == 0.0)
+        return exp(-x * x);
+
+    double ret = 0.0;
+    double sum1 = 0, sum2 = 0, sum3 = 0, sum5 = 0;
+    if (ya > 7 || (x > 6 && (ya > 0.1 || (x > 8 && ya > 1e-10) || x > 28)))
+    {
+        const double ispi = 0.56418958354775628694807945156;
+        const double xs = v;
+        if (x + ya > 4000)
+        {
+            if (x + ya > 1e7)
+            {
+                if (x > ya)
+                {
+                    const double yax = ya / xs;
+                    const double denom = ispi / (xs + yax * ya);
+                    return denom * yax;
+                }
+                const double xya = xs / ya;
+                return ispi / (xya * xs + ya);
+            }
+            const double dr = xs * xs - ya * ya - 0.5, di = 2 * xs * ya;
+            const double denom = ispi / (dr * dr + di * di);
+            return denom * (xs * di - ya * dr);
+        }
+        const double c0 = 3.9, c1 = 11.398, c2 = 0.08254, c3 = 0.1421, c4 = 0.2023;
+        double nu = floor(c0 + c1 / (c2 * x + c3 * ya + c4));
+        double wr = xs, wi = ya;
+        for (nu = 0.5 * (nu - 1); nu > 0.4; nu -= 0.5)
+        {
+            const double denom = nu / (wr * wr + wi * wi);
+            wr = xs - wr * denom;
+            wi = ya + wi * denom;
+        }
+        const double denom = ispi / (wr * wr + wi * wi);
+        return denom * wi;
+    }
+    else if (x < 10)
+    {
+        double prod2ax = 1, prodm2ax = 1;
+        double expx2;
+        if (x < 5e-4)
+        {
+            const double x2 = x * x;
+            expx2 = 1 - x2 * (1 - 0.5 * x2);
+            const double ax2 = 1.036642960860171859744 * x;
+            const double exp2ax = 1 + ax2 * (1 + ax2 * (0.5 + 0.166666666666666666667 * ax2));
+            const double expm2ax = 1 - ax2 * (1 - ax2 * (0.5 - 0.166666666666666666667 * ax2));
+            for (int n = 1; n < 60; ++n)
+            {
+                const double coef = c_expa2n2[n - 1] * expx2 / (a2 * (n * n) + y * y);
+                prod2ax *= exp2ax;
+                prodm2ax *= expm2ax;
+                sum1 += coef;
+                sum2 += coef * prodm2ax;
+                sum3 += coef * prod2ax;
+                sum5 += coef * (2 * a) * n * v_sinh_taylor((2 * a) * n * x);
+                if (coef * prod2ax < relerr * sum3)
+                    break;
+            }
+        }
+        else
+        {
+            expx2 = exp(-x * x);
+            const double exp2ax = exp((2 * a) * x), expm2ax = 1 / exp2ax;
+            for (int n = 1; n < 60; ++n)
+            {
+                const double coef = c_expa2n2[n - 1] * expx2 / (a2 * (n * n) + y * y);
+                prod2ax *= exp2ax;
+                prodm2ax *= expm2ax;
+                sum1 += coef;
+                sum2 += coef * prodm2ax;
+                sum3 += coef * prod2ax;
+                sum5 += (coef * prod2ax) * (a * n);
+                if ((coef * prod2ax) * (a * n) < relerr * sum5)
+                    break;
+            }
+        }
+        const double expx2erfcxy = expx2 * erfcx(y);
+        if (y > 5)
+        {
+            const double sinxy = sin(x * y);
+            ret = (expx2erfcxy - c * y * sum1) * cos(2 * x * y) + (c * x * expx2) * sinxy * v_sinc(x * y, sinxy);
+        }
+        else
+        {
+            const double xs = v;
+            const double sinxy = sin(xs * y);
+            const double cos2xy = cos(2 * xs * y);
+            const double coef1 = expx2erfcxy - c * y * sum1;
+            const double coef2 = c * xs * expx2;
+            ret = coef1 * cos2xy + coef2 * sinxy * v_sinc(xs * y, sinxy);
+        }
+    }
+    else
+    {
+        ret = exp(-x * x);
+        const double n0 = floor(x / a + 0.5);
+        const double dx = a * n0 - x;
+        sum3 = exp(-dx * dx) / (a2 * (n0 * n0) + y * y);
+        sum5 = a * n0 * sum3;
+        const double exp1 = exp(4 * a * dx);
+        double exp1dn = 1;
+        int dn;
+        bool done = false;
+        for (dn = 1; n0 - dn > 0; ++dn)
+        {
+            const double np = n0 + dn, nm = n0 - dn;
+            double tp = exp(-(a * dn + dx) * (a * dn + dx));
+            double tm = tp * (exp1dn *= exp1);
+            tp /= (a2 * (np * np) + y * y);
+            tm /= (a2 * (nm * nm) + y * y);
+            sum3 += tp + tm;
+            sum5 += a * (np * tp + nm * tm);
+            if (a * (np * tp + nm * tm) < relerr * sum5)
+            {
+                done = true;
+                break;
+            }
+        }
+        while (!done)
+        {
+            const double np = n0 + dn++;
+            const double tp = exp(-(a * dn + dx) * (a * dn + dx)) / (a2 * (np * np) + y * y);
+            sum3 += tp;
+            sum5 += a * np * tp;
+            if (a * np * tp < relerr * sum5)
+                break;
+        }
+    }
+    return ret + (0.5 * c) * y * (sum2 + sum3);
+}
+
+
+
+// phi[l, mu, dir, k] for the shard's rows of one line
+__global__ void voigt_phi_kernel(VoigtLineArgs a)
+{
+    const double sqrtPi = 1.772453850905516027298167483341145182798;
+    const size_t n = (size_t)a.nlt * a.Nrays * 2 * a.Ns;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n;
+         idx += (size_t)gridDim.x * blockDim.x)
+    {
+        const int k = (int)(idx % a.Ns);
+        size_t r = idx / a.Ns;
+        const int d = (int)(r % 2);
+        r /= 2;
+        const int mu = (int)(r % a.Nrays);
+        const int l = (int)(r / a.Nrays);
+        const double vBase = (a.wave[a.ltStart + l] - a.lambda0) * CLight / a.lambda0;
+        const double s = d ? 1.0 : -1.0;
+        const double vb = a.vBroad[k];
+        const double vk = (vBase + s * a.vlosMu[(size_t)mu * a.Ns + k]) / vb;
+        a.phi[idx] = d_voigt_H(a.aDamp[k], vk) / (sqrtPi * vb);
+    }
+}
+
+// wphi[k] = 1 / sum_{la, mu, dir} phi w_lambda(la) w_mu/2 over the line's FULL grid (independent of
+// the wavelength shard); thread (part, k) sums la = part, part + P, ...; parts combined in order
+__global__ void voigt_wphi_kernel(VoigtLineArgs a)
+{
+    extern __shared__ double sPart[];
+    const double sqrtPi = 1.772453850905516027298167483341145182798;
+    const int P = blockDim.x / a.Ns;
+    const int part = threadIdx.x / a.Ns;
+    const int k = threadIdx.x - part * a.Ns;
+    double acc = 0.0;
+    if (part < P)
+    {
+        const double vb = a.vBroad[k];
+        const double ad = a.aDamp[k];
+        for (int la = part; la < a.nltFull; la += P)
+        {
+            const double vBase = (a.wave[la] - a.lambda0) * CLight / a.lambda0;
+            const double wla = a.wlam[la];
+            for (int mu = 0; mu < a.Nrays; ++mu)
+            {
+                const double wlamu = wla * 0.5 * a.wmu[mu];
+                const double vl = a.vlosMu[(size_t)mu * a.Ns + k];
+                for (int d = 0; d < 2; ++d)
+                {
+                    const double vk = (vBase + (d ? vl : -vl)) / vb;
+                    acc += (d_voigt_H(ad, vk) / (sqrtPi * vb)) * wlamu;
+                }
+            }
+        }
+        sPart[part * a.Ns + k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < a.Ns)
+    {
+        double s = 0.0;
+        for (int q = 0; q < P; ++q)
+            s += sPart[q * a.Ns + threadIdx.x];
+        a.wphi[threadIdx.x] = 1.0 / s;
+    }
+}
+
+hipError_t voigt_init_tables()
+{
+    static bool done = false;
+    if (done)
+        return hipSuccess;
+    double tab[64];
+    const double a2 = 0.268657157075235951582;
+    for (int n = 1; n <= 64; ++n)
+        tab[n - 1] = std::exp(-a2 * (double)(n * n));
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_expa2n2), tab, sizeof(tab));
+    if (e == hipSuccess)
+        done = true;
+    return e;
+}
+
+hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream)
+{
+    hipError_t e = voigt_init_tables();
+    if (e != hipSuccess)
+        return e;
+    const size_t n = (size_t)a.nlt * a.Nrays * 2 * a.Ns;
+    if (n > 0)
+    {
+        const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(voigt_phi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    }
+    int P = 1024 / a.Ns;
+    if (P < 1)
+        P = 1;
+    if (P > a.nltFull)
+        P = a.nltFull;
+    const int T = ((P * a.Ns + 63) / 64) * 64;
+    hipLaunchKernelGGL(voigt_wphi_kernel, dim3(1), dim3(T), (size_t)P * a.Ns * sizeof(double), stream, a);
+    return hipGetLastError();
+}
+}

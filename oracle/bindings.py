@@ -144,6 +144,9 @@ class OracleContext(_Handle):
             lib.lworacle_formal_sol_gamma_matrices.argtypes = [
                 C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.lwhip_iter_result), abi.f64p]
             lib.lworacle_formal_sol.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            lib.lworacle_compute_profiles.argtypes = [C.c_void_p]
+            lib.lworacle_voigt_H.restype = C.c_double
+            lib.lworacle_voigt_H.argtypes = [C.c_double, C.c_double]
             lib.lworacle_fs_partial.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, abi.f64p, abi.f64p]
             lib.lworacle_fs_finalise.argtypes = [C.c_void_p, abi.f64p]
             lib.lworacle_stat_equil.argtypes = [C.c_void_p, C.c_int]
@@ -167,6 +170,9 @@ class OracleContext(_Handle):
                 raise RuntimeError('lworacle_create failed')
             return h
         super().__init__(lib, prob, create, lib.lworacle_destroy)
+
+    def compute_profiles(self):
+        assert self.lib.lworacle_compute_profiles(self.h) == 0
 
     def formal_sol_gamma_matrices(self, lambdaIterate=False, Nthreads=1, dJ=None):
         res = abi.lwhip_iter_result()

@@ -1,0 +1,107 @@
+"""Voigt / Faddeeva: the restated algorithm (oracle) against the reference's vendored package and
+SciPy's wofz (the same S. G. Johnson code), and the device kernel against both."""
+import numpy as np
+import pytest
+from scipy.special import wofz
+
+from helpers import load_fixture, rel_err
+from lightweaver_amd import _abi as abi
+from oracle import bindings
+from oracle.bindings import OracleContext
+
+TOL_VOIGT = 1e-13
+
+# (a, v) points covering every branch of Faddeeva::w for Im z >= 0 (Source/Faddeeva.cc:680-972):
+# x = 0, y = 0, continued fraction (nu = 1, 2, general), Algorithm 916 sums with x < 5e-4, x < 10,
+# y > 5, and the large-x / tiny-y tail.
+BRANCH_POINTS = [(a, v)
+                 for a in [0.0, 1e-12, 1e-10, 1e-6, 1e-3, 0.09, 0.11, 1.0, 4.9, 5.1, 6.9, 7.1, 50.0, 1e3]
+                 for v in [0.0, 1e-5, 4e-4, 6e-4, 0.3, 3.0, 5.9, 6.1, 7.9, 8.1, 9.9, 10.1, 15.0, 27.9,
+                           28.1, 300.0, 3999.0, 4001.0, 1e6, 2e7, -0.7, -12.0]]
+
+
+def _random_points(n=20000, seed=0):
+    rng = np.random.default_rng(seed)
+    return list(zip(10 ** rng.uniform(-6, 1.2, n), 10 ** rng.uniform(-3, 3, n) * rng.choice([-1, 1], n)))
+
+
+def test_oracle_voigt_vs_scipy_wofz():
+    lib = OracleContext.lib_()
+    pts = BRANCH_POINTS + _random_points()
+    a = np.array([p[0] for p in pts])
+    v = np.array([p[1] for p in pts])
+    want = wofz(v + 1j * a).real
+    got = np.array([lib.lworacle_voigt_H(x, y) for x, y in pts])
+    assert rel_err(got, want) <= TOL_VOIGT
+
+
+@pytest.mark.skipif(not bindings.ref_available(), reason='oracle/_ref not built')
+def test_oracle_voigt_vs_reference_faddeeva():
+    ref, ora = bindings.RefContext.lib_(), OracleContext.lib_()
+    pts = BRANCH_POINTS + _random_points(5000, seed=1)
+    got = np.array([ora.lworacle_voigt_H(a, v) for a, v in pts])
+    want = np.array([ref.lwref_voigt_H(a, v) for a, v in pts])
+    assert rel_err(got, want) <= TOL_VOIGT
+
+
+@pytest.mark.parametrize('name', ['falc_h_ca_small', 'falc_h_vel'])
+def test_oracle_profiles_vs_golden(name):
+    """phi / wphi of the fixtures were produced by the reference's own Faddeeva (SciPy wofz is the
+    same code; equality with Transition::compute_phi is asserted in test_oracle_vs_reference)."""
+    base, _ = load_fixture(name)
+    p = base.copy()
+    for a in p.atoms:
+        for t in a.trans:
+            if t.type == abi.LINE:
+                t.phi[...] = 0.0
+                t.wphi[...] = 0.0
+    OracleContext(p).compute_profiles()
+    for a, b in zip(p.atoms, base.atoms):
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                assert rel_err(t.phi, u.phi) <= TOL_VOIGT
+                assert rel_err(t.wphi, u.wphi) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['falc_h_ca_small', 'falc_h_vel'])
+def test_device_profiles_vs_golden(gpu, name):
+    from lightweaver_amd.context import Context
+    base, _ = load_fixture(name)
+    p = base.copy()
+    for a in p.atoms:
+        for t in a.trans:
+            if t.type == abi.LINE:
+                t.phi[...] = 0.0
+                t.wphi[...] = 0.0
+    with Context(p) as ctx:
+        ctx.compute_profiles()
+    for a, b in zip(p.atoms, base.atoms):
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                assert rel_err(t.phi, u.phi) <= 1e-12
+                assert rel_err(t.wphi, u.wphi) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_device_profiles_on_a_wavelength_shard(gpu):
+    """wphi is a sum over the line's whole grid: a shard that owns only part of a line must still
+    get the full normalisation."""
+    from lightweaver_amd.context import Context
+    base, _ = load_fixture('falc_h_ca_small')
+    p = base.copy()
+    m = p.Nlambda // 2
+    for a in p.atoms:
+        for t in a.trans:
+            if t.type == abi.LINE:
+                t.phi[...] = 0.0
+                t.wphi[...] = 0.0
+    with Context(p, laStart=0, laEnd=m, worldSize=2, worldRank=0) as ctx:
+        ctx.compute_profiles()
+    for a, b in zip(p.atoms, base.atoms):
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                assert rel_err(t.wphi, u.wphi) <= 1e-12
+                hi = min(max(m - t.Nblue, 0), t.Nlambda)
+                assert rel_err(t.phi[:hi], u.phi[:hi]) <= 1e-12
+                assert not t.phi[hi:].any()
