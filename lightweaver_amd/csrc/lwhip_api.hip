@@ -3,8 +3,9 @@
 // Owns the HBM-resident copy of the problem, the per-wavelength activity tables the sweep kernel
 // walks, and the launch sequence of one iteration:
 //
-//     memset dJ -> sweep_kernel (per-chunk partial slabs) -> reduce_kernel (fixed-order slab sum)
-//     [-> caller all-reduces the reduce buffer across GPUs] -> apply_kernel -> djmax_kernel
+//     sweep_kernel (per-chunk partial slabs, dJ) -> reduce_stage1/2 (fixed-order slab sum)
+//     (stage 2 also reduces dJ to (dJMax, idx) in the gather tail)
+//     [-> caller all-reduces the reduce buffer across GPUs] -> apply_kernel (Gamma pre-fill fused)
 //
 // There is no CPU fallback: without a HIP device every compute entry point fails with
 // LWHIP_ERR_DEVICE.
@@ -126,6 +127,9 @@ struct lwhip_context
     double sweepMs = 0.0;
     int sweepCount = 0;
     bool partialPending = false;
+    bool prefillPending = false; // lwhip_gamma_prefill_from_C deferred into the next apply_kernel
+    double prefillCrsw = 1.0;
+    double* gatherPinned = nullptr;
 
     ~lwhip_context()
     {
@@ -136,6 +140,8 @@ struct lwhip_context
         }
         if (ownStream)
             (void)hipStreamDestroy(ownStream);
+        if (gatherPinned)
+            (void)hipHostFree(gatherPinned);
     }
 };
 
@@ -542,7 +548,8 @@ int build_tables(lwhip_context* c)
     double total = 0.0;
     for (int la = 0; la < c->Nla; ++la)
     {
-        cost[la] = 1.0 + 0.35 * hdr[la].nLine + 0.25 * hdr[la].nMixed + 0.03 * hdr[la].nPure;
+        // fitted to per-chunk cycle counts of the stamped build (tools/stamps.py, LWHIP_DUMP_CHUNKS)
+        cost[la] = 1.0 + 0.243 * hdr[la].nLine + 0.089 * hdr[la].nMixed + 0.026 * hdr[la].nPure;
         total += cost[la];
     }
     std::vector<int32_t> chunkLa;
@@ -852,6 +859,14 @@ SweepDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
     return d;
 }
 
+int flush_prefill(lwhip_context* c)
+{
+    if (c->prefillPending && c->gammaTot > 0)
+        HIP_TRY(launch_prefill(c->Gamma.p, c->Cmat.p, c->prefillCrsw, (size_t)c->gammaTot, c->stream));
+    c->prefillPending = false;
+    return LWHIP_OK;
+}
+
 int collect_profile(lwhip_context* c)
 {
     for (auto& pr : c->pending)
@@ -986,6 +1001,33 @@ int lwhip_destroy(lwhip_context* c)
         for (int i = 0; i < 12; ++i)
             std::fprintf(stderr, " [%d]=%.0f", i, sum[i] / c->nChunks);
         std::fprintf(stderr, "\n");
+        if (const char* path = std::getenv("LWHIP_DUMP_CHUNKS"))
+        {
+            // per-chunk total cycles next to the cost model's inputs, for calibrating the balance
+            std::vector<int32_t> cla(c->chunkLa.n);
+            std::vector<DevLaHeader> hh(c->laHdr.n);
+            (void)hipMemcpy(cla.data(), c->chunkLa.p, cla.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hh.data(), c->laHdr.p, hh.size() * sizeof(DevLaHeader), hipMemcpyDeviceToHost);
+            if (FILE* f = std::fopen(path, "w"))
+            {
+                std::fprintf(f, "chunk,nla,nLine,nMixed,nPure,cycles\n");
+                for (int ch = 0; ch < c->nChunks; ++ch)
+                {
+                    long nl = 0, nm = 0, np = 0;
+                    for (int la = cla[ch]; la < cla[ch + 1]; ++la)
+                    {
+                        nl += hh[la].nLine;
+                        nm += hh[la].nMixed;
+                        np += hh[la].nPure;
+                    }
+                    double tot = 0;
+                    for (int i = 0; i < 12; ++i)
+                        tot += (double)h[(size_t)ch * 12 + i];
+                    std::fprintf(f, "%d,%d,%ld,%ld,%ld,%.0f\n", ch, cla[ch + 1] - cla[ch], nl, nm, np, tot);
+                }
+                std::fclose(f);
+            }
+        }
     }
     delete c;
     return LWHIP_OK;
@@ -999,6 +1041,8 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     const lwhip_problem& p = c->prob;
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
     const size_t l0 = c->laStart;
+    if (mask & LWHIP_GAMMA)
+        c->prefillPending = false; // the host pre-fill being uploaded supersedes it
     if (mask & LWHIP_ATMOS)
     {
         H2D(c->height.p, p.height, Ns);
@@ -1091,6 +1135,12 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
     const lwhip_problem& p = c->prob;
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
     const size_t l0 = c->laStart;
+    if (mask & LWHIP_GAMMA)
+    {
+        int stp = flush_prefill(c);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
     if (mask & LWHIP_J)
         D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
     if (mask & LWHIP_I)
@@ -1135,8 +1185,8 @@ int lwhip_gamma_prefill_from_C(lwhip_context* c, double crsw)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->gammaTot > 0)
-        HIP_TRY(launch_prefill(c->Gamma.p, c->Cmat.p, crsw, (size_t)c->gammaTot, c->stream));
+    c->prefillPending = true; // performed by the next apply_kernel (or flushed by download / stat_equil)
+    c->prefillCrsw = crsw;
     return LWHIP_OK;
 }
 
@@ -1145,7 +1195,6 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->dJ.p, 0, c->dJ.n * sizeof(double), c->stream));
     const SweepDyn dyn = make_dyn(c, false, lambdaIterate);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling)
@@ -1160,8 +1209,9 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         HIP_TRY(hipEventRecord(e1, c->stream));
         c->pending.emplace_back(e0, e1);
     }
-    if (c->Ntrans > 0)
     {
+        // fixed-order slab sums; the extra block of stage 2 writes this shard's (dJMax, global idx)
+        // into its slot of the gather tail and zeros the other slots
         ReduceArgs r{};
         r.Ns = c->Ns;
         r.Ntrans = c->Ntrans;
@@ -1171,12 +1221,13 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         r.partial = c->partial.p;
         r.red8 = c->red8.p;
         r.red = c->red.p;
+        r.dJ = c->dJ.p;
+        r.Nla = c->Nla;
+        r.idxOffset = c->laStart;
+        r.world = c->worldSize;
+        r.rank = c->worldRank;
         HIP_TRY(launch_reduce(r, c->stream));
     }
-    // this shard's (dJMax, global idx) into its own slot of the gather tail, zeros elsewhere
-    double* tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
-    HIP_TRY(hipMemsetAsync(tail, 0, 2 * (size_t)c->worldSize * sizeof(double), c->stream));
-    HIP_TRY(launch_djmax(c->dJ.p, 0, c->Nla, c->laStart, tail + 2 * c->worldRank, c->stream));
     c->partialPending = true;
     return LWHIP_OK;
 }
@@ -1204,15 +1255,22 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
         a.Gamma = c->Gamma.p;
         a.Rij = c->Rij.p;
         a.Rji = c->Rji.p;
+        a.Cmat = c->Cmat.p;
+        a.crsw = c->prefillCrsw;
+        a.prefill = c->prefillPending ? 1 : 0;
         HIP_TRY(launch_apply(a, c->stream));
+        c->prefillPending = false;
     }
     c->partialPending = false;
     if (res)
     {
         const double* tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
-        HIP_TRY(hipMemcpyAsync(c->gatherHost.data(), tail, c->gatherHost.size() * sizeof(double),
+        if (!c->gatherPinned)
+            HIP_TRY(hipHostMalloc((void**)&c->gatherPinned, c->gatherHost.size() * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(c->gatherPinned, tail, c->gatherHost.size() * sizeof(double),
                                hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        std::memcpy(c->gatherHost.data(), c->gatherPinned, c->gatherHost.size() * sizeof(double));
         // max over shards, first (lowest) wavelength index on ties: max_idx, Constants.hpp:114-125
         double best = -1.0;
         int bestIdx = 0;
@@ -1266,6 +1324,11 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int stp = flush_prefill(c);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
     HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
     for (int ia = 0; ia < c->Natom; ++ia)
     {

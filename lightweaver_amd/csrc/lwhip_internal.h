@@ -149,7 +149,9 @@ struct ReduceArgs
     const int32_t* trRow;          // slab rows (chunk*maxCT + cs) in chunk order
     const double* partial;
     double* red8;                  // [Ntrans, SPLIT, 4, Ns] stage-1 sums
-    double* red;                   // [Ntrans, 4, Ns]
+    double* red;                   // [Ntrans, 4, Ns] + gather tail [2 * world]
+    const double* dJ;              // [Nla] per-wavelength dJ of this shard
+    int32_t Nla, idxOffset, world, rank;
 };
 
 struct ApplyArgs
@@ -166,6 +168,10 @@ struct ApplyArgs
     double* Gamma;                 // pool
     double* Rij;                   // [Ntrans, Ns]
     double* Rji;                   // [Ntrans, Ns]
+    const double* Cmat;            // pool, same layout as Gamma
+    double crsw;
+    int32_t prefill;               // Gamma <- crsw * C before adding the radiative terms
+    int32_t _pad2;
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)

@@ -245,7 +245,7 @@ __host__ __device__ inline size_t lds_doubles(int Ns, int G, int Natom, int Nlev
     return (size_t)4 * G * Ns + (size_t)12 * Ns
            + (big ? 0 : (size_t)(2 + Natom + 2 * NlevTot) * Ns + (size_t)2 * maxC * Ns + (size_t)maxCT * 4 * Ns)
            + (LWHIP_MAX_PROG_ROWS * sizeof(DevProgRow) + LWHIP_MAX_PROG_ENTS * sizeof(DevProgEnt)) / 8 + 8
-           + 64 + 64 + 32 + 2 * maxC + 8;
+           + 64 + 64 + 32 + 2 * maxC + 8 + 16;
 }
 
 size_t sweep_lds_bytes(const SweepArgs& a, int G)
@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     double* sCp2 = (double*)(sRayId + 64);                          // [maxC] 2hc/lambda^3 of continuum c
     int* sCgj = (int*)(sCp2 + maxC);                                // [maxC] upper level row of continuum c
     double* sPlanck = (double*)(sCgj + maxC + (maxC & 1));          // [4] B_nu at T[Ns-2], T[Ns-1], T[0], T[1]
+    double* sDjWave = sPlanck + 4;                                   // [16] per-wavefront max of dJ
 
     // idx / Ns for idx * Ns < 2^32 as one mul_hi (magic = ceil(2^32 / Ns))
     const unsigned divMagic = (unsigned)((0x100000000ull + (unsigned)Ns - 1) / (unsigned)Ns);
@@ -1147,7 +1148,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 for (int off = 32; off > 0; off >>= 1)
                     dj = fmax(dj, __shfl_xor(dj, off));
                 if ((t & 63) == 0)
-                    atomicMax((unsigned long long*)(a.dJ + la), (unsigned long long)__double_as_longlong(dj));
+                    sDjWave[t >> 6] = dj;
             }
         }
         wg_barrier<BIG>();
@@ -1155,6 +1156,13 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         // wavelength's first barrier; nothing reads these rows before it)
         if (pfInputs && inOwner && !lastLa)
             sIn[t] = pfK;
+        if (RATES && t == 0) // this wavelength belongs to this workgroup alone: plain store, no atomics
+        {
+            double dj = 0.0;
+            for (int w = 0; w < (Ns + 63) / 64; ++w)
+                dj = fmax(dj, sDjWave[w]);
+            GD(ARGS.dJ)[la] = dj;
+        }
         STAMP(9);
     } // wavelengths
 
@@ -1253,9 +1261,59 @@ __global__ void reduce_stage1_kernel(const ReduceArgs a)
     }
 }
 
-__global__ void reduce_stage2_kernel(const ReduceArgs a)
+__device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* tail, int world, int rank)
+{
+    // dJMax and the index of its first occurrence (max_idx, Constants.hpp:114-125) into this
+    // shard's slot of the gather tail; every other slot is zeroed (the all-reduce sums them)
+    __shared__ double sV[512];
+    __shared__ int sI[512];
+    double best = -1.0;
+    int bi = 0;
+    for (int la = threadIdx.x; la < laEnd; la += blockDim.x)
+    {
+        const double v = dJ[la];
+        if (v > best)
+        {
+            best = v;
+            bi = la;
+        }
+    }
+    sV[threadIdx.x] = best;
+    sI[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1)
+    {
+        if (threadIdx.x < s)
+        {
+            const double v = sV[threadIdx.x + s];
+            const int i = sI[threadIdx.x + s];
+            if (v > sV[threadIdx.x] || (v == sV[threadIdx.x] && i < sI[threadIdx.x]))
+            {
+                sV[threadIdx.x] = v;
+                sI[threadIdx.x] = i;
+            }
+        }
+        __syncthreads();
+    }
+    for (int q = threadIdx.x; q < 2 * world; q += blockDim.x)
+    {
+        double v = 0.0;
+        if (q == 2 * rank)
+            v = sV[0] < 0.0 ? 0.0 : sV[0];
+        else if (q == 2 * rank + 1)
+            v = (double)(sI[0] + idxOffset);
+        tail[q] = v;
+    }
+}
+
+__global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a)
 {
     const int tr = blockIdx.x;
+    if (tr == a.Ntrans) // the extra block: dJMax
+    {
+        djmax_block(a.dJ, a.Nla, a.idxOffset, a.red + (size_t)a.Ntrans * 4 * a.Ns, a.world, a.rank);
+        return;
+    }
     const int n4 = 4 * a.Ns;
     for (int idx = threadIdx.x; idx < n4; idx += blockDim.x)
     {
@@ -1269,50 +1327,82 @@ __global__ void reduce_stage2_kernel(const ReduceArgs a)
 
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reduce_stage1_kernel, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT), dim3(384), 0, stream, a);
-    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(a.Ntrans), dim3(384), 0, stream, a);
+    if (a.Ntrans > 0)
+        hipLaunchKernelGGL(reduce_stage1_kernel, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT), dim3(384), 0, stream, a);
+    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(a.Ntrans + 1), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
 // ---- apply: Gamma += radiative terms (Gamma keeps its collisional pre-fill), finalise_Gamma
 // (SimdFullIterationTemplates.hpp:491-508), Rij/Rji out ----------------------------------------------------
-__global__ void apply_kernel(const ApplyArgs a)
+// One block per (atom, slab of APPLY_K depth points): thread (e, kk) owns Gamma entry e = to*Nl+from
+// at depth k; the extra block column x == Natom copies Rij/Rji.
+enum { APPLY_K = 16 };
+__global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a)
 {
-    const int at = blockIdx.x;
     const int Ns = a.Ns;
-    const int Nl = a.atomNlevel[at];
-    for (int k = threadIdx.x; k < Ns; k += blockDim.x)
+    const int k0 = blockIdx.y * APPLY_K;
+    if ((int)blockIdx.x == a.Natom) // rates out
     {
-        double* G = a.Gamma + a.atomGammaOff[at];
-        for (int tr = a.atomTrOff[at]; tr < a.atomTrOff[at + 1]; ++tr)
+        const int Ntr = a.atomTrOff[a.Natom];
+        for (int idx = threadIdx.x; idx < Ntr * APPLY_K; idx += blockDim.x)
         {
-            const double* r = a.red + (size_t)tr * 4 * Ns;
-            if (!a.atomDetailed[at])
+            const int tr = idx / APPLY_K;
+            const int k = k0 + (idx - tr * APPLY_K);
+            if (k < Ns)
             {
-                const int i = a.transLi[tr], j = a.transLj[tr];
-                G[((size_t)i * Nl + j) * Ns + k] += r[k];
-                G[((size_t)j * Nl + i) * Ns + k] += r[Ns + k];
-            }
-            a.Rij[(size_t)tr * Ns + k] = r[2 * Ns + k];
-            a.Rji[(size_t)tr * Ns + k] = r[3 * Ns + k];
-        }
-        if (!a.atomDetailed[at])
-        {
-            for (int i = 0; i < Nl; ++i)
-            {
-                G[((size_t)i * Nl + i) * Ns + k] = 0.0;
-                double gd = 0.0;
-                for (int j = 0; j < Nl; ++j)
-                    gd += G[((size_t)j * Nl + i) * Ns + k];
-                G[((size_t)i * Nl + i) * Ns + k] = -gd;
+                const double* r = a.red + (size_t)tr * 4 * Ns;
+                a.Rij[(size_t)tr * Ns + k] = r[2 * Ns + k];
+                a.Rji[(size_t)tr * Ns + k] = r[3 * Ns + k];
             }
         }
+        return;
+    }
+    const int at = blockIdx.x;
+    if (a.atomDetailed[at])
+        return;
+    const int Nl = a.atomNlevel[at];
+    double* G = a.Gamma + a.atomGammaOff[at];
+    const double* Cm = a.Cmat + a.atomGammaOff[at];
+    const int tr0 = a.atomTrOff[at], tr1 = a.atomTrOff[at + 1];
+    // off-diagonal entries: pre-fill (optional) + radiative terms of the transitions that feed them
+    for (int idx = threadIdx.x; idx < Nl * Nl * APPLY_K; idx += blockDim.x)
+    {
+        const int e = idx / APPLY_K;
+        const int k = k0 + (idx - e * APPLY_K);
+        if (k >= Ns)
+            continue;
+        const int to = e / Nl, from = e - to * Nl;
+        double v = a.prefill ? a.crsw * Cm[(size_t)e * Ns + k] : G[(size_t)e * Ns + k];
+        for (int tr = tr0; tr < tr1; ++tr) // transitions in reference order
+        {
+            const int i = a.transLi[tr], j = a.transLj[tr];
+            if (to == i && from == j)
+                v += a.red[((size_t)tr * 4 + 0) * Ns + k];
+            if (to == j && from == i)
+                v += a.red[((size_t)tr * 4 + 1) * Ns + k];
+        }
+        G[(size_t)e * Ns + k] = v;
+    }
+    __syncthreads();
+    // finalise_Gamma (SimdFullIterationTemplates.hpp:491-508): Gamma(i,i) = -sum_{j != i} Gamma(j,i)
+    for (int idx = threadIdx.x; idx < Nl * APPLY_K; idx += blockDim.x)
+    {
+        const int i = idx / APPLY_K;
+        const int k = k0 + (idx - i * APPLY_K);
+        if (k >= Ns)
+            continue;
+        double gd = 0.0;
+        for (int j = 0; j < Nl; ++j)
+            if (j != i)
+                gd += G[((size_t)j * Nl + i) * Ns + k];
+        G[((size_t)i * Nl + i) * Ns + k] = -gd;
     }
 }
 
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(apply_kernel, dim3(a.Natom), dim3(128), 0, stream, a);
+    hipLaunchKernelGGL(apply_kernel, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -23,6 +23,13 @@ def _build_checkers():
 
 @pytest.fixture(scope='session')
 def hip_lib():
+    # torch bundles its own HIP runtime: when both live in one process (the RCCL test, bench.py)
+    # torch has to initialise first, otherwise it reports "No HIP GPUs are available".
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
     from lightweaver_amd import build, context
     build.build_hip()
     return context.load_library()

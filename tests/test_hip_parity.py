@@ -174,6 +174,38 @@ def test_wavelength_shards_sum_to_whole(gpu):
     assert np.array_equal(pa.I[:m], q.I[:m]) and np.array_equal(pb.I[m:], q.I[m:])
 
 
+def test_rccl_allreduce_on_the_library_reduce_buffer(gpu):
+    """The multi-GPU step on one device: a 1-rank RCCL ('nccl') group all-reduces the zero-copy
+    torch view of the library's reduce buffer between fs_partial and fs_finalise, on the stream
+    the kernels run on; results must equal the plain single-call iteration."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from lightweaver_amd.distributed import ShardedIteration
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 300))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
+        q = prob.copy()
+        with Context(q) as plain:
+            up0 = plain.formal_sol_gamma_matrices(deviceResident=True)
+            plain.download(abi.ALL_OUTPUTS)
+        p = prob.copy()
+        stream = torch.cuda.current_stream()
+        with Context(p, stream=stream.cuda_stream, worldSize=1, worldRank=0) as ctx:
+            it = ShardedIteration(ctx, 1, 0, force_collective=True)
+            up1 = it.formal_sol_gamma_matrices(deviceResident=True)
+            ctx.download(abi.ALL_OUTPUTS)
+        assert (up0.dJMax, up0.dJMaxIdx) == (up1.dJMax, up1.dJMaxIdx)
+        assert np.array_equal(p.J, q.J)
+        for ia in range(2):
+            assert rel_err(p.atoms[ia].Gamma, q.atoms[ia].Gamma) <= 1e-12
+    finally:
+        dist.destroy_process_group()
+
+
 def test_stat_equil_singular_raises(gpu):
     base, _ = load_fixture('falc_h_vel')
     p = base.copy()
