@@ -1,0 +1,73 @@
+"""1.5D column batches (BASELINE.json configs[3]): many independent plane-parallel columns, each a
+Context-equivalent problem with its own atmosphere, profiles and populations.  Columns never
+exchange radiation, so they shard across GPUs with NO collective ("replicas"): rank r simply owns
+columns r, r + world, ....  On one GPU the columns' contexts are all resident in HBM (26 MB of phi
+per H + Ca II column at ~3k wavelengths: thousands fit in 288 GB) and their iterations are queued
+back to back on one stream, so the device never idles between columns; profiles are regenerated on
+the device per column (lwhip_compute_profiles), so phi never crosses PCIe.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+from . import _abi as abi
+from .context import Context
+from .model import Problem
+
+
+def columns_of_rank(ncolumns: int, world: int, rank: int) -> List[int]:
+    """Round-robin column ownership; no data-path communication between ranks."""
+    if not (0 <= rank < world):
+        raise ValueError('bad rank')
+    return list(range(rank, ncolumns, world))
+
+
+class ColumnBatch:
+    def __init__(self, problems: Sequence[Problem], device: int = 0, stream: Optional[int] = None,
+                 device_profiles: bool = True):
+        self.problems = list(problems)
+        self.contexts = [Context(p, device=device, stream=stream) for p in self.problems]
+        if device_profiles:
+            for c in self.contexts:
+                c.compute_profiles(deviceResident=True)
+
+    def __len__(self):
+        return len(self.contexts)
+
+    def close(self):
+        for c in self.contexts:
+            c.close()
+        self.contexts = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def formal_sol_gamma_matrices(self, lambdaIterate=False):
+        """One iteration of every column; kernels of all columns are queued before the first
+        result is read back."""
+        for c in self.contexts:
+            c.gamma_prefill_from_C(c.crsw)
+            c.fs_partial(lambdaIterate)
+        return [c.fs_finalise() for c in self.contexts]
+
+    def stat_equil(self):
+        for c in self.contexts:
+            c.stat_equil(deviceResident=True)
+
+    def iterate(self, niter: int, nscatter: int = 3, callback: Optional[Callable] = None):
+        """iterate_ctx_se-style loop (lightweaver/iterate_ctx.py:157-176) over the whole batch."""
+        ups = []
+        for it in range(niter):
+            ups = self.formal_sol_gamma_matrices()
+            if it >= nscatter:
+                self.stat_equil()
+            if callback is not None:
+                callback(it, ups)
+        return ups
+
+    def download(self, mask=abi.ALL_OUTPUTS | abi.POPS):
+        for c in self.contexts:
+            c.download(mask)
