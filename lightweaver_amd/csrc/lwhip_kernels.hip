@@ -148,8 +148,12 @@ DEVINL void d_besser_coeffs(double t, double& M, double& O, double& Cc, double& 
 
 DEVINL void lds_add(double* addr, double v)
 {
+#ifdef LWHIP_EXPERIMENT_NOATOMIC
+    *addr += v; // timing experiment only (racy)
+#else
     // ds_add_f64 on gfx950
     unsafeAtomicAdd(addr, v);
+#endif
 }
 
 // Workgroup barrier that orders LDS traffic only: outstanding global loads (the software prefetch
@@ -197,6 +201,31 @@ DEVINL double d_rcp(double x)
     return r;
 }
 
+// exp(x) for -700 < x <= 0 (optical depths, Boltzmann factors): range reduction x = n ln2 + r,
+// |r| <= ln2/2, degree-13 Taylor polynomial (truncation 4e-18), ldexp.  No overflow / NaN paths,
+// about half the instructions of the library exp; agrees with it to ~1 ulp.
+DEVINL double d_exp_neg(double x)
+{
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // cent_deriv (Bezier.hpp:58-65) with the three reciprocals supplied
 DEVINL double d_cent_deriv_r(double dsuw, double dsdw, double ruw, double rdw, double rsum,
                              double yuw, double y0, double ydw)
@@ -242,7 +271,7 @@ DEVINL void d_bezier3_coeffs_r(double dt, double& alpha, double& beta, double& g
 // in an L2-resident global scratch of the chunk instead of LDS.
 __host__ __device__ inline size_t lds_doubles(int Ns, int G, int Natom, int NlevTot, int maxC, int maxCT, bool big)
 {
-    return (size_t)4 * G * Ns + (size_t)12 * Ns
+    return (size_t)4 * G * Ns + (size_t)13 * Ns
            + (big ? 0 : (size_t)(2 + Natom + 2 * NlevTot) * Ns + (size_t)2 * maxC * Ns + (size_t)maxCT * 4 * Ns)
            + (LWHIP_MAX_PROG_ROWS * sizeof(DevProgRow) + LWHIP_MAX_PROG_ENTS * sizeof(DevProgEnt)) / 8 + 8
            + 64 + 64 + 32 + 2 * maxC + 8 + 16;
@@ -269,6 +298,10 @@ template <bool BIG> DEVINL void wg_barrier()
 // ---- the sweep ---------------------------------------------------------------------------------------
 // intensity_core_opt (SimdFullIterationTemplates.hpp:238-487) for every wavelength of the chunk,
 // with UpdateRates = ComputeOperator = RATES, PrdRatesOnly = false.
+#ifndef LWHIP_ABLATE
+#define LWHIP_ABLATE 0
+#endif
+
 #ifdef LWHIP_STAMPS
 #define STAMP(i)                                                                                       \
     do                                                                                                 \
@@ -348,7 +381,8 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     double* sSca = sIn + Ns;
     double* sBgChi = sIn + 2 * Ns;
     double* sBgEta = sIn + 3 * Ns;
-    double* carve = sK + 12 * Ns;
+    double* sRT = sK + 12 * Ns; // 1 / T
+    double* carve = sK + 13 * Ns;
     double* sRows;
     double* sVji;
     double* sChiCo;
@@ -403,6 +437,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     if (t < Ns)
     {
         sTemp[t] = gTemperature[t];
+        sRT[t] = 1.0 / gTemperature[t];
         double dh = 0.0, rdh = 0.0, rsum = 0.0;
         if (t < Ns - 1)
         {
@@ -514,13 +549,13 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             const int kq = (q == 0) ? Ns - 2 : (q == 1) ? Ns - 1 : (q == 2) ? 0 : 1;
             sPlanck[q] = d_planck(sTemp[kq], wav);
         }
-        for (int idx = t; idx < nCont * Ns; idx += T)
+        for (int idx = t; idx < nCont * Ns && (!(LWHIP_ABLATE & 8) || la == la0); idx += T)
         {
             const int c = divNs(idx);
             const int kk = idx - c * Ns;
             const CONST_AS DevSlot& sl = slots[nLine + c];
             const double ratio = (havePfRatio && idx == t) ? pfRatio : gRatio[(size_t)sl.row * Ns + kk];
-            const double gij = ratio * exp(-hc_kl / sTemp[kk]);
+            const double gij = ratio * d_exp_neg(-hc_kl * sRT[kk]);
             const double vji = gij * sl.p[0];
             sVji[c * Ns + kk] = vji;
             sChiCo[c * Ns + kk] = gN[sl.gi * Ns + kk] * sl.p[0] - gN[sl.gj * Ns + kk] * vji;
@@ -540,7 +575,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         STAMP(1);
         // row program: totals, per-atom emissivity and per-level sums over the continua, one
         // (row, depth) task per thread, continua added in reference order
-        for (int task = t; task < progRows * Ns; task += T)
+        for (int task = t; task < progRows * Ns && (!(LWHIP_ABLATE & 8) || la == la0); task += T)
         {
             const int ri = divNs(task);
             const int kk = task - ri * Ns;
@@ -570,6 +605,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         STAMP(2);
 
         // ---- passes over groups of G rays -----------------------------------------------------------
+        double mJ = 0.0, mM1 = 0.0, mE0 = 0.0, mE1 = 0.0; // this thread's share of J, M1, Meta0, Meta1
         for (int g0 = 0; g0 < dyn.nRaysActive; g0 += G)
         {
             const int nr = min(G, dyn.nRaysActive - g0);
@@ -602,7 +638,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                 {
-                    if (l < nLine)
+                    if (l < nLine && !(LWHIP_ABLATE & 64))
                     {
                         const CONST_AS DevSlot& sl = slots[l];
                         const double ph = havePfPhi ? pfPhi[l]
@@ -640,7 +676,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             {
                 const bool nextSameLa = (g0 + G < dyn.nRaysActive);
                 havePfPhi = false;
-                if (nextSameLa || !lastLa)
+                if ((nextSameLa || !lastLa) && !(LWHIP_ABLATE & 512))
                 {
                     const int g0n = nextSameLa ? g0 + G : 0;
                     const CONST_AS DevSlot* sn = nextSameLa ? slots : slotsNext;
@@ -740,7 +776,13 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     return ds * (col[pa] + col[pb] + cuw + c0) * 0.25;
                 };
                 double dtau = 0.0, dtauLin = 0.0, dS = 0.0;
-                if (active)
+                if (active && (LWHIP_ABLATE & 2))
+                {
+                    dtau = 0.3;
+                    dtauLin = 0.3;
+                    sDS[t] = 0.0;
+                }
+                if (active && !(LWHIP_ABLATE & 2))
                 {
                     const double d0 = dchi_at(k);
                     double dtauDw = 0.0;
@@ -762,12 +804,18 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 STAMP(4);
                 // coefficients  :265-275, 294-304, 314-321.  One exp call site serves the interior
                 // points (Bezier3_coeffs) and the end point (w2), so a wavefront never runs two.
-                if (active)
+                if (active && (LWHIP_ABLATE & 128))
+                {
+                    e = 0.5;
+                    b = S;
+                    Psi = 0.1;
+                }
+                if (active && !(LWHIP_ABLATE & 128))
                 {
                     const bool isEnd = (k == kE);
                     const double x = isEnd ? dtauLin : dtau;
                     const bool needExp = (k != kS) && (isEnd ? (x >= 5.0E-4 && x <= 50.0) : (x >= 5e-2 && x <= 30.0));
-                    const double ex = needExp ? exp(-x) : 0.0;
+                    const double ex = (needExp && !(LWHIP_ABLATE & 32)) ? d_exp_neg(-x) : 0.5;
                     if (k == kS)
                     {
                         e = 0.0;
@@ -906,7 +954,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             // its contiguous run of points, a shuffle scan composes the lanes  :273,302,317 ----------
             {
                 const int Lc = (Ns + 63) >> 6;
-                for (int rr = wave; rr < nr; rr += nWaves)
+                for (int rr = wave; rr < nr && !(LWHIP_ABLATE & 4); rr += nWaves)
                 {
                     const int up = sRayId[g0 + rr] & 1;
                     const int q0 = lane * Lc;
@@ -956,144 +1004,181 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             }
 
             // ---- per-ray rates: lines and mixed continua  :192-234; angle moments for the rest -------
-            if (RATES && active)
+            if (RATES && active && !(LWHIP_ABLATE & 1))
             {
                 const double PsiS = dyn.lambdaIterate ? 0.0 : Psi;
-                int lgi[MAXL], lgj[MAXL], lat[MAXL], lop[MAXL];
-                double luji[MAXL];
-                double etaM0 = 0.0, etaM1 = 0.0;
-#pragma unroll
-                for (int l = 0; l < MAXL; ++l)
+                const double wPsi = halfwmu * PsiS;
+                mJ += halfwmu * I; // accumulate_J :181-190 and the Psi* moments, in registers over the passes
+                mM1 += wPsi;
+                if (nLine == 1 && nPerRayC == 0)
                 {
-                    lgi[l] = -1;
-                    lgj[l] = -1;
-                    lat[l] = -1;
-                    lop[l] = 0;
-                    luji[l] = 0.0;
-                    if (l < nLine)
-                    {
-                        const CONST_AS DevSlot& sl = slots[l];
-                        lgi[l] = sl.gi;
-                        lgj[l] = sl.gj;
-                        lat[l] = sl.atom;
-                        lop[l] = sl.flags & 1;
-                        luji[l] = sl.p[3] * Vji[l];
-                        if (lop[l])
-                        {
-                            etaM0 += (sl.ms == 0) ? el[l] : 0.0;
-                            etaM1 += (sl.ms == 1) ? el[l] : 0.0;
-                        }
-                    }
-                }
-                sChi[t] = halfwmu * I;              // -> J
-                sS[t] = halfwmu * PsiS;             // -> M1
-                sDS[t] = halfwmu * PsiS * etaM0;    // -> Meta0
-                sB[t] = halfwmu * PsiS * etaM1;     // -> Meta1 (own element: I was read above)
-                auto levChi = [&](int g) {
-                    double v = sLevChi[g * Ns + k];
-#pragma unroll
-                    for (int l = 0; l < MAXL; ++l)
-                    {
-                        if (lop[l] && lgi[l] == g) // wave-uniform conditions: scalar branches
-                            v += xl[l];
-                        if (lop[l] && lgj[l] == g)
-                            v -= xl[l];
-                    }
-                    return v;
-                };
-                auto levU = [&](int g) {
-                    double v = sLevU[g * Ns + k];
-#pragma unroll
-                    for (int l = 0; l < MAXL; ++l)
-                    {
-                        if (lop[l] && lgj[l] == g)
-                            v += luji[l];
-                    }
-                    return v;
-                };
-                auto atomEta = [&](int at) {
-                    double v = sEtaA[at * Ns + k];
-#pragma unroll
-                    for (int l = 0; l < MAXL; ++l)
-                    {
-                        if (lop[l] && lat[l] == at)
-                            v += el[l];
-                    }
-                    return v;
-                };
-#pragma unroll
-                for (int l = 0; l < MAXL; ++l)
-                {
-                    if (l < nLine)
-                    {
-                        const CONST_AS DevSlot& sl = slots[l];
-                        const double wla = (sl.p[1] * wph[l]) * PI4_HC;
-                        const double wlamu = wla * halfwmu;
-                        double* acc = sAcc + (size_t)sl.cs * 4 * Ns + k;
-                        if (sl.flags & 1)
-                        {
-                            const double Ieff = I - PsiS * atomEta(sl.atom);
-                            const double g0v = ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(sl.gi) * levU(sl.gj))) * wlamu;
-                            const double g1v = ((Vij[l] * Ieff) - (PsiS * levChi(sl.gj) * levU(sl.gi))) * wlamu;
-                            lds_add(acc, g0v);
-                            lds_add(acc + Ns, g1v);
-                        }
-                        lds_add(acc + 2 * Ns, I * Vij[l] * wlamu);
-                        lds_add(acc + 3 * Ns, (luji[l] + I * Vji[l]) * wlamu);
-                    }
-                }
-                for (int c = 0; c < nPerRayC; ++c) // mixed continua (always of active atoms)
-                {
-                    const CONST_AS DevSlot& sl = slots[nLine + c];
-                    const double vij = sl.p[0];
-                    const double vji = sVji[c * Ns + k];
-                    const double uji = sl.p[2] * vji;
-                    const double wlamu = sl.p[1] * halfwmu;
+                    // the common case, one active line and no mixed continuum: its level sums are
+                    // the continuum rows plus its own chi / Uji, no searching
+                    const CONST_AS DevSlot& sl = slots[0];
+                    const double uji = sl.p[3] * Vji[0];
+                    const double wlamu = ((sl.p[1] * wph[0]) * PI4_HC) * halfwmu;
                     double* acc = sAcc + (size_t)sl.cs * 4 * Ns + k;
-                    const double Ieff = I - PsiS * atomEta(sl.atom);
-                    const double g0v = ((uji + vji * Ieff) - (PsiS * levChi(sl.gi) * levU(sl.gj))) * wlamu;
-                    const double g1v = ((vij * Ieff) - (PsiS * levChi(sl.gj) * levU(sl.gi))) * wlamu;
-                    lds_add(acc, g0v);
-                    lds_add(acc + Ns, g1v);
-                    lds_add(acc + 2 * Ns, I * vij * wlamu);
-                    lds_add(acc + 3 * Ns, (uji + I * vji) * wlamu);
+                    if (sl.flags & 1)
+                    {
+                        if (sl.ms == 0)
+                            mE0 += wPsi * el[0];
+                        else if (sl.ms == 1)
+                            mE1 += wPsi * el[0];
+                        const double Ieff = I - PsiS * (sEtaA[sl.atom * Ns + k] + el[0]);
+                        const double chi_i = sLevChi[sl.gi * Ns + k] + xl[0];
+                        const double chi_j = sLevChi[sl.gj * Ns + k] - xl[0];
+                        const double U_j = sLevU[sl.gj * Ns + k] + uji;
+                        const double U_i = sLevU[sl.gi * Ns + k];
+                        lds_add(acc, ((uji + Vji[0] * Ieff) - (PsiS * chi_i * U_j)) * wlamu);
+                        lds_add(acc + Ns, ((Vij[0] * Ieff) - (PsiS * chi_j * U_i)) * wlamu);
+                    }
+                    lds_add(acc + 2 * Ns, I * Vij[0] * wlamu);
+                    lds_add(acc + 3 * Ns, (uji + I * Vji[0]) * wlamu);
+                }
+                else if (nLine + nPerRayC > 0)
+                {
+                    int lgi[MAXL], lgj[MAXL], lat[MAXL], lop[MAXL];
+                    double luji[MAXL];
+#pragma unroll
+                    for (int l = 0; l < MAXL; ++l)
+                    {
+                        lgi[l] = -1;
+                        lgj[l] = -1;
+                        lat[l] = -1;
+                        lop[l] = 0;
+                        luji[l] = 0.0;
+                        if (l < nLine)
+                        {
+                            const CONST_AS DevSlot& sl = slots[l];
+                            lgi[l] = sl.gi;
+                            lgj[l] = sl.gj;
+                            lat[l] = sl.atom;
+                            lop[l] = sl.flags & 1;
+                            luji[l] = sl.p[3] * Vji[l];
+                            if (lop[l])
+                            {
+                                if (sl.ms == 0)
+                                    mE0 += wPsi * el[l];
+                                else if (sl.ms == 1)
+                                    mE1 += wPsi * el[l];
+                            }
+                        }
+                    }
+                    auto levChi = [&](int g) {
+                        double v = sLevChi[g * Ns + k];
+#pragma unroll
+                        for (int l = 0; l < MAXL; ++l)
+                        {
+                            if (lop[l] && lgi[l] == g)
+                                v += xl[l];
+                            if (lop[l] && lgj[l] == g)
+                                v -= xl[l];
+                        }
+                        return v;
+                    };
+                    auto levU = [&](int g) {
+                        double v = sLevU[g * Ns + k];
+#pragma unroll
+                        for (int l = 0; l < MAXL; ++l)
+                        {
+                            if (lop[l] && lgj[l] == g)
+                                v += luji[l];
+                        }
+                        return v;
+                    };
+                    auto atomEta = [&](int at) {
+                        double v = sEtaA[at * Ns + k];
+#pragma unroll
+                        for (int l = 0; l < MAXL; ++l)
+                        {
+                            if (lop[l] && lat[l] == at)
+                                v += el[l];
+                        }
+                        return v;
+                    };
+#pragma unroll
+                    for (int l = 0; l < MAXL; ++l)
+                    {
+                        if (l < nLine)
+                        {
+                            const CONST_AS DevSlot& sl = slots[l];
+                            const double wla = (sl.p[1] * wph[l]) * PI4_HC;
+                            const double wlamu = wla * halfwmu;
+                            double* acc = sAcc + (size_t)sl.cs * 4 * Ns + k;
+                            if (sl.flags & 1)
+                            {
+                                const double Ieff = I - PsiS * atomEta(sl.atom);
+                                const double g0v = ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(sl.gi) * levU(sl.gj))) * wlamu;
+                                const double g1v = ((Vij[l] * Ieff) - (PsiS * levChi(sl.gj) * levU(sl.gi))) * wlamu;
+                                lds_add(acc, g0v);
+                                lds_add(acc + Ns, g1v);
+                            }
+                            lds_add(acc + 2 * Ns, I * Vij[l] * wlamu);
+                            lds_add(acc + 3 * Ns, (luji[l] + I * Vji[l]) * wlamu);
+                        }
+                    }
+                    for (int c = 0; c < nPerRayC; ++c) // mixed continua (always of active atoms)
+                    {
+                        const CONST_AS DevSlot& sl = slots[nLine + c];
+                        const double vij = sl.p[0];
+                        const double vji = sVji[c * Ns + k];
+                        const double uji = sl.p[2] * vji;
+                        const double wlamu = sl.p[1] * halfwmu;
+                        double* acc = sAcc + (size_t)sl.cs * 4 * Ns + k;
+                        const double Ieff = I - PsiS * atomEta(sl.atom);
+                        const double g0v = ((uji + vji * Ieff) - (PsiS * levChi(sl.gi) * levU(sl.gj))) * wlamu;
+                        const double g1v = ((vij * Ieff) - (PsiS * levChi(sl.gj) * levU(sl.gi))) * wlamu;
+                        lds_add(acc, g0v);
+                        lds_add(acc + Ns, g1v);
+                        lds_add(acc + 2 * Ns, I * vij * wlamu);
+                        lds_add(acc + 3 * Ns, (uji + I * vji) * wlamu);
+                    }
                 }
             }
-            wg_barrier<BIG>();
             STAMP(7);
-            // accumulate_J :181-190 and the Psi* moments, rays in reference order
-            if (RATES)
+        } // ray groups
+
+        // ---- J and the Psi* moments of the wavelength: each thread holds the partial sums of its own
+        // rays over the passes; stage them and add the G partials in a fixed order -----------------------
+        if (RATES)
+        {
+            if (isPoint)
             {
-                for (int task = t; task < 4 * Ns; task += T)
+                sChi[t] = mJ;
+                sS[t] = mM1;
+                sDS[t] = mE0;
+                sB[t] = mE1;
+            }
+            wg_barrier<BIG>();
+            for (int task = t; task < 4 * Ns && !(LWHIP_ABLATE & 256); task += T)
+            {
+                const int m = divNs(task);
+                const int kk = task - m * Ns;
+                const double* src = (m == 0) ? sChi : (m == 1) ? sS : (m == 2) ? sDS : sB;
+                double acc = 0.0;
+                for (int r0 = 0; r0 < G; r0 += 8) // loads issued together, adds in a fixed order
                 {
-                    const int m = divNs(task);
-                    const int kk = task - m * Ns;
-                    const double* src = (m == 0) ? sChi : (m == 1) ? sS : (m == 2) ? sDS : sB;
-                    double acc = (g0 == 0) ? 0.0 : sJ[m * Ns + kk];
-                    for (int r0 = 0; r0 < nr; r0 += 8) // loads issued together, adds in ray order
-                    {
-                        double v[8];
+                    double v[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            v[q] = (r0 + q < nr) ? src[(r0 + q) * Ns + kk] : 0.0;
+                    for (int q = 0; q < 8; ++q)
+                        v[q] = (r0 + q < G) ? src[(r0 + q) * Ns + kk] : 0.0;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (r0 + q < nr)
-                                acc += v[q];
-                    }
-                    sJ[m * Ns + kk] = acc;
+                    for (int q = 0; q < 8; ++q)
+                        if (r0 + q < G)
+                            acc += v[q];
                 }
+                sJ[m * Ns + kk] = acc;
             }
             wg_barrier<BIG>();
             STAMP(8);
-        } // ray groups
+        }
 
         if (RATES)
         {
             // ---- pure continua from the angle moments -----------------------------------------------------
             // sum_r w_r [Uji + Vji (I_r - Psi_r eta_r) - Psi_r chi_i U_j] with chi, U, Uji, Vji ray-
             // independent and eta_r = etaC + etaLine_r  ->  Uji W + Vji (J - M1 etaC - Meta) - M1 chi_i U_j
-            for (int idx = t; idx < h.nPure * Ns; idx += T)
+            for (int idx = t; idx < h.nPure * Ns && !(LWHIP_ABLATE & 16); idx += T)
             {
                 const int cq = divNs(idx);
                 const int c = h.nMixed + cq;
