@@ -486,14 +486,11 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     const bool pfInputs = (T >= 4 * Ns); // otherwise every wavelength reloads synchronously
     double pfK = 0.0, pfRatio = 0.0;
     bool havePfRatio = false;
-    double pfPhi[MAXL], pfWphi[MAXL];
+    double pfPhi[MAXL];
     bool havePfPhi = false;
 #pragma unroll
     for (int l = 0; l < MAXL; ++l)
-    {
         pfPhi[l] = 0.0;
-        pfWphi[l] = 0.0;
-    }
     __syncthreads();
     STAMP(0);
 
@@ -643,7 +640,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                         const CONST_AS DevSlot& sl = slots[l];
                         const double ph = havePfPhi ? pfPhi[l]
                                                     : gPhi[sl.phiOff + (size_t)(mu * 2 + toObs) * Ns + k];
-                        wph[l] = havePfPhi ? pfWphi[l] : gWphi[(size_t)sl.row * Ns + k];
+                        wph[l] = gWphi[(size_t)sl.row * Ns + k]; // issued here, first used in the rates phase
                         const double vij = sl.p[0] * ph;
                         double g = sl.p[2];
                         if (sl.flags & 2)
@@ -688,10 +685,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
 #pragma unroll
                         for (int l = 0; l < MAXL; ++l)
                             if (l < nLineN)
-                            {
                                 pfPhi[l] = gPhi[sn[l].phiOff + (size_t)rn * Ns + k];
-                                pfWphi[l] = gWphi[(size_t)sn[l].row * Ns + k];
-                            }
                     }
                     havePfPhi = true;
                 }
@@ -815,7 +809,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                     const bool isEnd = (k == kE);
                     const double x = isEnd ? dtauLin : dtau;
                     const bool needExp = (k != kS) && (isEnd ? (x >= 5.0E-4 && x <= 50.0) : (x >= 5e-2 && x <= 30.0));
-                    const double ex = (needExp && !(LWHIP_ABLATE & 32)) ? d_exp_neg(-x) : 0.5;
+                    const double ex = needExp ? ((LWHIP_ABLATE & 32) ? 0.5 : d_exp_neg(-x)) : 0.0;
                     if (k == kS)
                     {
                         e = 0.0;
