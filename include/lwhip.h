@@ -19,6 +19,8 @@
  *        (Source/LwFormalInterface.hpp:91,122; Source/UpdatePopulations.cpp:7-47; Source/LuSolve.cpp:8-132)
  *   lwhip_compute_profiles           <- Transition::compute_phi / compute_wphi
  *        (Source/FormalScalar.cpp:28-68,106-134)
+ *   lwhip_redistribute_prd           <- FsIterationFns::redistribute_prd
+ *        (Source/LwFormalInterface.hpp:90,121; Source/PrdTemplates.hpp:175-351; Source/Prd.cpp:9-30,51-124,180-263,468-645)
  *   lwhip_create / lwhip_destroy     <- FsIterationFns::alloc_global_scratch / free_global_scratch
  *        (Source/LwFormalInterface.hpp:106-107,131-132; called from Source/ThreadStorage.cpp:480-493,538-566)
  *   lwhip_upload / lwhip_download    <- (none: the reference shares host memory; these move the
@@ -114,6 +116,7 @@ typedef struct lwhip_transition {
     double* rhoPrd;        /* [Nred-Nblue, Nspace] or NULL                                         */
     double* Rij;           /* [Nspace] out                                                         */
     double* Rji;           /* [Nspace] out                                                         */
+    const double* Qelast;  /* [Nspace] elastic collision rate, PRD lines only (Prd.cpp:18)          */
 } lwhip_transition;
 
 /* One atom; mirrors Atom (Source/LwAtom.hpp:41-80). */
@@ -241,6 +244,24 @@ int lwhip_formal_sol(lwhip_context* ctx, int upOnly);
  * scaling, partial pivoting and one refinement pass; n overwritten on the device.
  * Returns LWHIP_ERR_SINGULAR where the reference throws "Singular Matrix". */
 int lwhip_stat_equil(lwhip_context* ctx, int atom);
+
+/* PRD sub-iterations (redistribute_prd_lines): for every PRD line of an active atom, the
+ * total depopulation + elastic rate, the angle-averaged scattering integral with Gouttebroze's
+ * GII on a 0.15-Doppler-width fine grid (rho <- 1 + gamma (int J gII / int gII - Jbar)), then a
+ * formal solution restricted to the PRD wavelengths that updates J and the PRD lines' Rij/Rji;
+ * at most maxIter times, until max |d rho / rho| < tol.  rhoPrd, J, Rij/Rji stay on the device.
+ * `dRho`/`dRhoMaxIdx` receive one entry per (sub-iteration, PRD line), `dJPrdMax`/`dJPrdMaxIdx`
+ * one per sub-iteration; capacities maxIter * Nprd and maxIter (any may be NULL).
+ * Not available on a wavelength shard (needs J over each PRD line's whole grid). */
+typedef struct lwhip_prd_result {
+    int32_t NprdSubIter;
+    int32_t Nprd;          /* number of PRD lines */
+    double* dRho;
+    int32_t* dRhoMaxIdx;
+    double* dJPrdMax;
+    int32_t* dJPrdMaxIdx;
+} lwhip_prd_result;
+int lwhip_redistribute_prd(lwhip_context* ctx, int maxIter, double tol, lwhip_prd_result* res);
 
 /* Voigt profiles phi and weights wphi of every line, on the device. */
 int lwhip_compute_profiles(lwhip_context* ctx);

@@ -45,7 +45,7 @@ class lwhip_transition(C.Structure):
         ('Aji', C.c_double), ('Bji', C.c_double), ('Bij', C.c_double),
         ('lambda0', C.c_double), ('dopplerWidth', C.c_double),
         ('wavelength', f64p), ('alpha', f64p), ('phi', f64p), ('wphi', f64p),
-        ('aDamp', f64p), ('rhoPrd', f64p), ('Rij', f64p), ('Rji', f64p),
+        ('aDamp', f64p), ('rhoPrd', f64p), ('Rij', f64p), ('Rji', f64p), ('Qelast', f64p),
     ]
 
 
@@ -88,6 +88,11 @@ class lwhip_options(C.Structure):
     ]
 
 
+class lwhip_prd_result(C.Structure):
+    _fields_ = [('NprdSubIter', C.c_int32), ('Nprd', C.c_int32), ('dRho', f64p), ('dRhoMaxIdx', i32p),
+                ('dJPrdMax', f64p), ('dJPrdMaxIdx', i32p)]
+
+
 class lwhip_iter_result(C.Structure):
     _fields_ = [('updatedJ', C.c_int32), ('dJMaxIdx', C.c_int32), ('dJMax', C.c_double)]
 
@@ -111,6 +116,7 @@ SYMBOLS = [
     ('lwhip_formal_sol', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_stat_equil', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_compute_profiles', C.c_int, [ctx_p]),
+    ('lwhip_redistribute_prd', C.c_int, [ctx_p, C.c_int, C.c_double, C.POINTER(lwhip_prd_result)]),
     ('lwhip_synchronize', C.c_int, [ctx_p]),
     ('lwhip_set_stream', C.c_int, [ctx_p, C.c_void_p]),
     ('lwhip_profile_enable', C.c_int, [ctx_p, C.c_int]),

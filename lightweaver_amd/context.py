@@ -4,6 +4,7 @@ Names, argument meaning and error behaviour follow Source/LwMiddleLayer.pyx:
     Context.formal_sol_gamma_matrices  <- LwContext.formal_sol_gamma_matrices  (:3152-3210)
     Context.formal_sol                 <- LwContext.formal_sol                  (:3212-3242)
     Context.stat_equil                 <- LwContext.stat_equil                  (:3461-3531)
+    Context.prd_redistribute           <- LwContext.prd_redistribute            (:3647-3684)
     ExplodingMatrixError               <- lightweaver.utils.ExplodingMatrixError (raised :3509-3514)
 
 The HIP library is mandatory: if it cannot be loaded, or no gfx950 device is visible, construction
@@ -15,6 +16,8 @@ import ctypes as C
 import os
 from dataclasses import dataclass
 from typing import Optional
+
+import numpy as np
 
 from . import _abi as abi
 from .model import Problem
@@ -65,6 +68,12 @@ class IterationUpdate:
     dJMaxIdx: int = 0
     crsw: float = 1.0
     updatedPops: bool = False
+    updatedRho: bool = False
+    NprdSubIter: int = 0
+    dRho: Optional[np.ndarray] = None         # [NprdSubIter, Nprd]
+    dRhoMaxIdx: Optional[np.ndarray] = None
+    dJPrdMax: Optional[np.ndarray] = None     # [NprdSubIter]
+    dJPrdMaxIdx: Optional[np.ndarray] = None
 
 
 class Context:
@@ -159,6 +168,35 @@ class Context:
         if not deviceResident:
             self.download(abi.POPS)
         return IterationUpdate(updatedPops=True)
+
+    def prd_redistribute(self, maxIter=3, tol=1e-2, deviceResident=False) -> IterationUpdate:
+        """PRD sub-iterations, LwContext.prd_redistribute (Source/LwMiddleLayer.pyx:3647-3684) with
+        include_detailed_atoms = False (the core's default, PrdTemplates.hpp:191-195): updates
+        rhoPrd of every PRD line of the active atoms, J over the PRD wavelengths and those lines'
+        Rij/Rji.  The host arrays are uploaded/downloaded around the call unless deviceResident."""
+        if not deviceResident:
+            self.upload(abi.J | abi.POPS | abi.BC | abi.RHOPRD | abi.RATES | abi.COLLISIONS)
+        Nprd = sum(1 for a in self.prob.atoms if not a.detailed for t in a.trans
+                   if t.type == abi.LINE and t.rhoPrd is not None)
+        n = max(maxIter, 1)
+        dRho = np.zeros(n * max(Nprd, 1))
+        dRhoIdx = np.zeros(n * max(Nprd, 1), dtype=np.int32)
+        dJ = np.zeros(n)
+        dJIdx = np.zeros(n, dtype=np.int32)
+        res = abi.lwhip_prd_result(0, 0, dRho.ctypes.data_as(abi.f64p), dRhoIdx.ctypes.data_as(abi.i32p),
+                                   dJ.ctypes.data_as(abi.f64p), dJIdx.ctypes.data_as(abi.i32p))
+        _check(self.lib, self.lib.lwhip_redistribute_prd(self._h, int(maxIter), float(tol), C.byref(res)),
+               'lwhip_redistribute_prd')
+        if not deviceResident:
+            self.download(abi.J | abi.RATES | abi.RHOPRD)
+        it, m = res.NprdSubIter, res.Nprd
+        return IterationUpdate(updatedRho=it > 0, updatedJ=it > 0, NprdSubIter=it,
+                               dRho=dRho[:it * m].reshape(it, m), dRhoMaxIdx=dRhoIdx[:it * m].reshape(it, m),
+                               dJPrdMax=dJ[:it], dJPrdMaxIdx=dJIdx[:it],
+                               dJMax=float(dJ[it - 1]) if it else 0.0,
+                               dJMaxIdx=int(dJIdx[it - 1]) if it else 0)
+
+    redistribute_prd = prd_redistribute
 
     def compute_profiles(self, deviceResident=False):
         _check(self.lib, self.lib.lwhip_compute_profiles(self._h), 'lwhip_compute_profiles')

@@ -104,7 +104,10 @@ struct lwhip_context
     DevBuf<int32_t> rayAll, rayUp, lowerIdx, upperIdx;
     DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
-    DevBuf<double> vlosMu, vBroad, aDamp, lineWave, lineWlam;
+    DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
+    DevBuf<double> prdChange, prdOut;
+    DevBuf<int32_t> prdChangeIdx;
+    double* prdPinned = nullptr;
     DevBuf<DevTrans> dtrans;
     DevBuf<DevLaHeader> laHdr;
     DevBuf<DevSlot> slots;
@@ -142,6 +145,8 @@ struct lwhip_context
             (void)hipStreamDestroy(ownStream);
         if (gatherPinned)
             (void)hipHostFree(gatherPinned);
+        if (prdPinned)
+            (void)hipHostFree(prdPinned);
     }
 };
 
@@ -441,7 +446,10 @@ int build_tables(lwhip_context* c)
         hdr[la].nLine = (int16_t)lines.size();
         hdr[la].nMixed = (int16_t)mixed.size();
         hdr[la].nPure = (int16_t)pure.size();
-        hdr[la]._pad = 0;
+        hdr[la].hasPrd = 0;
+        for (int tr : lines)
+            if (c->trans[tr].t.prd && c->trans[tr].rhoOff >= 0 && isOp(tr))
+                hdr[la].hasPrd = 1;
         for (int tr : order)
         {
             const HostTrans& h = c->trans[tr];
@@ -746,6 +754,8 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(c->vBroad.alloc((size_t)std::max(c->Natom, 1) * Ns));
     HIP_TRY(c->aDamp.alloc((size_t)std::max(c->Nline, 1) * Ns));
     HIP_TRY(hipMemset(c->aDamp.p, 0, c->aDamp.n * sizeof(double)));
+    HIP_TRY(c->Qelast.alloc((size_t)std::max(c->Nline, 1) * Ns));
+    HIP_TRY(hipMemset(c->Qelast.p, 0, c->Qelast.n * sizeof(double)));
     HIP_TRY(c->n.alloc((size_t)c->NlevTot * Ns));
     HIP_TRY(c->nTotal.alloc((size_t)c->Natom * Ns));
     HIP_TRY(c->ratio.alloc((size_t)std::max(c->Ncont, 1) * Ns));
@@ -1098,6 +1108,12 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
             const HostTrans& h = c->trans[c->atomTrOff[ia] + kr];
             const lwhip_transition& t = h.t;
             const size_t nlt = h.NredLoc - h.NblueLoc;
+            if ((mask & LWHIP_RATES) && t.Rij && t.Rji)
+            {
+                const size_t tr = c->atomTrOff[ia] + kr;
+                H2D(c->Rij.p + tr * Ns, t.Rij, Ns);
+                H2D(c->Rji.p + tr * Ns, t.Rji, Ns);
+            }
             if (t.type == LWHIP_LINE)
             {
                 if (mask & LWHIP_PROFILES)
@@ -1108,6 +1124,8 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                 }
                 if ((mask & LWHIP_NSTAR) && t.aDamp)
                     H2D(c->aDamp.p + (size_t)h.row * Ns, t.aDamp, Ns);
+                if ((mask & LWHIP_NSTAR) && t.Qelast)
+                    H2D(c->Qelast.p + (size_t)h.row * Ns, t.Qelast, Ns);
                 if ((mask & LWHIP_RHOPRD) && t.prd && nlt)
                     H2D(c->rho.p + h.rhoOff, t.rhoPrd + (size_t)h.ltStart * Ns, nlt * Ns);
             }
@@ -1167,6 +1185,8 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
                 D2H(h.t.Rij, c->Rij.p + (size_t)tr * Ns, Ns);
                 D2H(h.t.Rji, c->Rji.p + (size_t)tr * Ns, Ns);
             }
+            if ((mask & LWHIP_RHOPRD) && h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && h.NredLoc > h.NblueLoc)
+                D2H(h.t.rhoPrd + (size_t)h.ltStart * Ns, c->rho.p + h.rhoOff, (size_t)(h.NredLoc - h.NblueLoc) * Ns);
             if ((mask & LWHIP_PROFILES) && h.t.type == LWHIP_LINE)
             {
                 const size_t nlt = h.NredLoc - h.NblueLoc;
@@ -1346,6 +1366,147 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (st == LWHIP_ERR_SINGULAR)
         return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+    return LWHIP_OK;
+}
+
+int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_result* res)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->worldSize > 1 || c->laStart != 0 || c->laEnd != c->prob.Nlambda)
+        return fail(LWHIP_ERR_UNSUPPORTED, "redistribute_prd needs the whole wavelength grid (not a shard)");
+    if (c->partialPending)
+        return fail(LWHIP_ERR_INVALID, "lwhip_redistribute_prd between lwhip_fs_partial and lwhip_fs_finalise");
+    HIP_TRY(hipSetDevice(c->device));
+    const int Ns = c->Ns;
+    // PRD lines of the active atoms, reference order (PrdTemplates.hpp:190-205)
+    std::vector<int> prd;
+    for (int tr = 0; tr < c->Ntrans; ++tr)
+    {
+        const HostTrans& h = c->trans[tr];
+        if (h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && !c->atoms[h.atom].detailed)
+        {
+            if (!c->atoms[h.atom].C)
+                return fail(LWHIP_ERR_INVALID, "redistribute_prd needs the collisional rates C of atom "
+                                               + std::to_string(h.atom));
+            prd.push_back(tr);
+        }
+    }
+    const int Nprd = (int)prd.size();
+    if (res)
+    {
+        res->NprdSubIter = 0;
+        res->Nprd = Nprd;
+    }
+    if (Nprd == 0 || maxIter <= 0)
+        return LWHIP_OK;
+    if (c->prdOut.n < (size_t)2 * Nprd)
+    {
+        HIP_TRY(c->prdOut.alloc((size_t)2 * Nprd));
+        HIP_TRY(c->prdChange.alloc((size_t)Nprd * Ns));
+        HIP_TRY(c->prdChangeIdx.alloc((size_t)Nprd * Ns));
+        if (c->prdPinned)
+            (void)hipHostFree(c->prdPinned);
+        HIP_TRY(hipHostMalloc((void**)&c->prdPinned, ((size_t)2 * Nprd + 2) * sizeof(double), hipHostMallocDefault));
+    }
+    const double* tail = c->red.p + (size_t)c->Ntrans * 4 * Ns;
+    int iter = 0;
+    while (iter < maxIter)
+    {
+        ++iter;
+        for (int q = 0; q < Nprd; ++q)
+        {
+            const int tr = prd[q];
+            const HostTrans& h = c->trans[tr];
+            const lwhip_atom& at = c->atoms[h.atom];
+            PrdLineArgs a{};
+            a.Ns = Ns;
+            a.Nl = h.t.Nred - h.t.Nblue;
+            a.Nblue = h.t.Nblue;
+            a.Nlevel = at.Nlevel;
+            a.tr = tr;
+            a.gi = c->levelOff[h.atom] + h.t.i;
+            a.gj = c->levelOff[h.atom] + h.t.j;
+            a.lj = h.t.j;
+            a.trBegin = c->atomTrOff[h.atom];
+            a.trEnd = c->atomTrOff[h.atom + 1];
+            a.lambda0 = h.t.lambda0;
+            a.Bij = h.t.Bij;
+            a.wave = c->lineWave.p + h.waveOff;
+            a.J = c->J.p;
+            a.vBroad = c->vBroad.p + (size_t)h.atom * Ns;
+            a.aDamp = c->aDamp.p + (size_t)h.row * Ns;
+            a.Qelast = c->Qelast.p + (size_t)h.row * Ns;
+            a.Cmat = c->Cmat.p + c->gammaOff[h.atom];
+            a.n = c->n.p;
+            a.Rij = c->Rij.p;
+            a.Rji = c->Rji.p;
+            a.transLi = c->transLi.p;
+            a.transLj = c->transLj.p;
+            a.rho = c->rho.p + h.rhoOff;
+            a.changeVal = c->prdChange.p + (size_t)q * Ns;
+            a.changeIdx = c->prdChangeIdx.p + (size_t)q * Ns;
+            HIP_TRY(launch_prd_scatter(a, c->prdOut.p + 2 * q, c->stream));
+        }
+        // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
+        SweepDyn dyn = make_dyn(c, false, 0);
+        dyn.prdOnly = 1;
+        HIP_TRY(launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, true, c->nChunks, c->stream));
+        ReduceArgs r{};
+        r.Ns = Ns;
+        r.Ntrans = c->Ntrans;
+        r.maxCT = c->maxCT;
+        r.trOff = c->trOff.p;
+        r.trRow = c->trRow.p;
+        r.partial = c->partial.p;
+        r.red8 = c->red8.p;
+        r.red = c->red.p;
+        r.dJ = c->dJ.p;
+        r.Nla = c->Nla;
+        r.idxOffset = 0;
+        r.world = 1;
+        r.rank = 0;
+        HIP_TRY(launch_reduce(r, c->stream));
+        ApplyArgs ap{};
+        ap.Ns = Ns;
+        ap.Natom = c->Natom;
+        ap.atomTrOff = c->atomTrOffD.p;
+        ap.atomNlevel = c->atomNlevel.p;
+        ap.atomDetailed = c->atomDetailed.p;
+        ap.atomGammaOff = c->atomGammaOff.p;
+        ap.trans = c->dtrans.p;
+        ap.transLi = c->transLi.p;
+        ap.transLj = c->transLj.p;
+        ap.red = c->red.p;
+        ap.Gamma = c->Gamma.p;
+        ap.Rij = c->Rij.p;
+        ap.Rji = c->Rji.p;
+        ap.Cmat = c->Cmat.p;
+        ap.prdOnly = 1;
+        HIP_TRY(launch_apply(ap, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->prdPinned, c->prdOut.p, (size_t)2 * Nprd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->prdPinned + 2 * Nprd, tail, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        double dRhoMax = 0.0;
+        for (int q = 0; q < Nprd; ++q)
+        {
+            const double d = c->prdPinned[2 * q];
+            const int Nl = c->trans[prd[q]].t.Nred - c->trans[prd[q]].t.Nblue;
+            dRhoMax = std::max(dRhoMax, d);
+            if (res && res->dRho)
+                res->dRho[(size_t)(iter - 1) * Nprd + q] = d;
+            if (res && res->dRhoMaxIdx) // the flattened [la, k] index modulo Nlambda, as PrdTemplates.hpp:265 reports it
+                res->dRhoMaxIdx[(size_t)(iter - 1) * Nprd + q] = (int)c->prdPinned[2 * q + 1] % Nl;
+        }
+        if (res && res->dJPrdMax)
+            res->dJPrdMax[iter - 1] = c->prdPinned[2 * Nprd];
+        if (res && res->dJPrdMaxIdx)
+            res->dJPrdMaxIdx[iter - 1] = (int)c->prdPinned[2 * Nprd + 1];
+        if (dRhoMax < tol)
+            break;
+    }
+    if (res)
+        res->NprdSubIter = iter;
     return LWHIP_OK;
 }
 

@@ -53,7 +53,7 @@ struct DevLaHeader
     int16_t nMixed;
     int16_t nPure;
     int16_t prog;       // row program of the continuum sums
-    int32_t _pad;
+    int32_t hasPrd;     // a PRD line (rhoPrd) is active at this wavelength
 };
 struct DevSlot          // 96 bytes, read with scalar loads
 {
@@ -137,7 +137,7 @@ struct SweepDyn
     int32_t nRaysActive;   // 2*Nrays, or Nrays when upOnly
     int32_t G;             // rays per pass
     int32_t lambdaIterate;
-    int32_t _pad;
+    int32_t prdOnly;       // PRD rates pass: only wavelengths with a PRD line, J + Rij/Rji of PRD lines
     const int32_t* rayList;        // [nRaysActive] -> r = 2*mu + toObs
 };
 
@@ -171,7 +171,7 @@ struct ApplyArgs
     const double* Cmat;            // pool, same layout as Gamma
     double crsw;
     int32_t prefill;               // Gamma <- crsw * C before adding the radiative terms
-    int32_t _pad2;
+    int32_t prdOnly;               // only Rij/Rji of PRD lines are written, Gamma untouched
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)
@@ -193,6 +193,32 @@ struct VoigtLineArgs
     double* wphi;           // [Ns]
 };
 hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream);
+
+// One PRD line's scattering integral (lwhip_prd.hip)
+struct PrdLineArgs
+{
+    int32_t Ns, Nl, Nblue, Nlevel;
+    int32_t tr;             // global transition index of the line
+    int32_t gi, gj;         // global level rows
+    int32_t lj;             // local upper level
+    int32_t trBegin, trEnd; // global transition range of the line's atom
+    double lambda0, Bij;
+    const double* wave;     // [Nl] the line's own grid
+    const double* J;        // [Nla, Ns]
+    const double* vBroad;   // [Ns]
+    const double* aDamp;    // [Ns]
+    const double* Qelast;   // [Ns]
+    const double* Cmat;     // [Nlevel, Nlevel, Ns] of the atom
+    const double* n;        // pool
+    const double* Rij;      // [Ntrans, Ns]
+    const double* Rji;
+    const int32_t* transLi;
+    const int32_t* transLj;
+    double* rho;            // [Nl, Ns]
+    double* changeVal;      // [Ns] scratch
+    int32_t* changeIdx;     // [Ns] scratch
+};
+hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t stream);
 
 // launch helpers implemented in lwhip_kernels.hip
 size_t sweep_lds_bytes(const SweepArgs& a, int G);

@@ -483,7 +483,8 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         const size_t o = (size_t)la0 * Ns + kk;
         sIn[task] = (m == 0) ? gJ[o] : (m == 1) ? gBgSca[o] : (m == 2) ? gBgChi[o] : gBgEta[o];
     }
-    const bool pfInputs = (T >= 4 * Ns); // otherwise every wavelength reloads synchronously
+    // otherwise (and in the PRD rates pass, which skips wavelengths) every wavelength reloads synchronously
+    const bool pfInputs = (T >= 4 * Ns) && !dyn.prdOnly;
     double pfK = 0.0, pfRatio = 0.0;
     bool havePfRatio = false;
     double pfPhi[MAXL];
@@ -501,6 +502,12 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         const bool lastLa = (la + 1 >= la1);
         if (!lastLa)
             hNext = ld_c(cLaHdr + la + 1);
+        if (dyn.prdOnly && !h.hasPrd) // formal_sol_prd_update_rates visits prdIdxs only (PrdTemplates.hpp:226-239)
+        {
+            if (RATES && t == 0)
+                GD(ARGS.dJ)[la] = 0.0;
+            continue;
+        }
         const CONST_AS DevSlot* slots = cSlots + h.off;
         const CONST_AS DevSlot* slotsNext = cSlots + hNext.off;
         const int nLine = h.nLine;
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             sChiCo[c * Ns + kk] = gN[sl.gi * Ns + kk] * sl.p[0] - gN[sl.gj * Ns + kk] * vji;
         }
         havePfRatio = false;
-        if (!lastLa)
+        if (!lastLa && !dyn.prdOnly)
         {
             const int nContN = hNext.nMixed + hNext.nPure;
             if (t < nContN * Ns)
@@ -662,7 +669,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 S = (eta + sSca[k] * sJdag[k]) * rchi;
                 sChi[t] = chi;
                 sS[t] = S;
-                if (RATES && a.storeDepth)
+                if (RATES && a.storeDepth && !dyn.prdOnly)
                 {
                     const size_t o = ((size_t)(la * Nrays + mu) * 2 + toObs) * Ns + k;
                     gDepthChi[o] = chi;
@@ -673,7 +680,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             {
                 const bool nextSameLa = (g0 + G < dyn.nRaysActive);
                 havePfPhi = false;
-                if ((nextSameLa || !lastLa) && !(LWHIP_ABLATE & 512))
+                if ((nextSameLa || (!lastLa && !dyn.prdOnly)) && !(LWHIP_ABLATE & 512))
                 {
                     const int g0n = nextSameLa ? g0 + G : 0;
                     const CONST_AS DevSlot* sn = nextSameLa ? slots : slotsNext;
@@ -993,7 +1000,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                 Psi = Psi * rchi; // PsiStar :322-323
                 if (toObs && k == 0)
                     gI[(size_t)la * Nrays + mu] = I; // spect.I(la, mu, 0) :349
-                if (RATES && a.storeDepth)
+                if (RATES && a.storeDepth && !dyn.prdOnly)
                     gDepthI[((size_t)(la * Nrays + mu) * 2 + toObs) * Ns + k] = I;
             }
 
@@ -1431,6 +1438,8 @@ __global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a)
             if (k < Ns)
             {
                 const double* r = a.red + (size_t)tr * 4 * Ns;
+                if (a.prdOnly && !(a.trans[tr].prd && a.trans[tr].op && a.trans[tr].rhoOff >= 0))
+                    continue;
                 a.Rij[(size_t)tr * Ns + k] = r[2 * Ns + k];
                 a.Rji[(size_t)tr * Ns + k] = r[3 * Ns + k];
             }
@@ -1438,7 +1447,7 @@ __global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a)
         return;
     }
     const int at = blockIdx.x;
-    if (a.atomDetailed[at])
+    if (a.atomDetailed[at] || a.prdOnly)
         return;
     const int Nl = a.atomNlevel[at];
     double* G = a.Gamma + a.atomGammaOff[at];

@@ -173,6 +173,7 @@ void flatten(Context& ctx, PluginState* st)
             ft.phi = t.phi.data;
             ft.wphi = t.wphi.data;
             ft.aDamp = t.aDamp.data;
+            ft.Qelast = t.Qelast.data;
             ft.rhoPrd = t.rhoPrd.data;
             ft.Rij = t.Rij.data;
             ft.Rji = t.Rji.data;
@@ -197,12 +198,17 @@ uint32_t dirty_mask(PluginState* st, bool force)
     for (int ia = 0; ia < p.Natom; ++ia)
     {
         const lwhip_atom& a = p.atoms[ia];
-        fNstar ^= Fingerprint::of(a.nStar, (size_t)a.Nlevel * Ns) * 3 ^ Fingerprint::of(a.nTotal, Ns);
+        fNstar ^= Fingerprint::of(a.nStar, (size_t)a.Nlevel * Ns) * 3 ^ Fingerprint::of(a.nTotal, Ns)
+                  ^ Fingerprint::of(a.vBroad, Ns) * 7;
         if (a.C)
             fColl ^= Fingerprint::of(a.C, (size_t)a.Nlevel * a.Nlevel * Ns) + ia;
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
             const lwhip_transition& t = a.trans[kr];
+            if (t.type == LWHIP_LINE && t.aDamp)
+                fNstar ^= Fingerprint::of(t.aDamp, Ns) * 13 + kr;
+            if (t.type == LWHIP_LINE && t.Qelast)
+                fNstar ^= Fingerprint::of(t.Qelast, Ns) * 17 + kr;
             if (t.type == LWHIP_LINE)
                 fProf ^= Fingerprint::of(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns) + kr
                          ^ Fingerprint::of(t.wphi, Ns);
@@ -368,6 +374,47 @@ void stat_eq_hip(Atom* atom, ExtraParams params, int spaceStart, int spaceEnd)
         fail("lwhip_download");
 }
 
+// redistribute_prd: replaces redistribute_prd_lines_template<SimdType> (Source/PrdTemplates.hpp:175-290)
+IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraParams params)
+{
+    if (params.contains("include_detailed_atoms") && params.get_as<bool>("include_detailed_atoms"))
+    {
+        for (auto* a : ctx.detailedAtoms)
+            for (auto* t : a->trans)
+                if (t->rhoPrd)
+                    throw std::runtime_error("lwhip plugin: PRD lines of detailed-static atoms are not redistributed "
+                                             "on the device (pass include_detailed_atoms = False)");
+    }
+    const uint32_t up = sync_state(ctx, force_upload(params));
+    auto* st = (PluginState*)ctx.methodScratch;
+    if (lwhip_upload(st->hip, (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES) != LWHIP_OK)
+        fail("lwhip_upload");
+    int Nprd = 0;
+    for (auto* a : ctx.activeAtoms)
+        for (auto* t : a->trans)
+            if (t->rhoPrd)
+                ++Nprd;
+    IterationResult result{};
+    if (Nprd == 0 || maxIter <= 0)
+        return result;
+    std::vector<f64> dRho((size_t)maxIter * Nprd), dJ(maxIter);
+    std::vector<int32_t> dRhoIdx((size_t)maxIter * Nprd), dJIdx(maxIter);
+    lwhip_prd_result r{ 0, 0, dRho.data(), dRhoIdx.data(), dJ.data(), dJIdx.data() };
+    if (lwhip_redistribute_prd(st->hip, maxIter, tol, &r) != LWHIP_OK)
+        fail("lwhip_redistribute_prd");
+    if (lwhip_download(st->hip, LWHIP_J | LWHIP_RATES | LWHIP_RHOPRD) != LWHIP_OK)
+        fail("lwhip_download");
+    const size_t nEnt = (size_t)r.NprdSubIter * r.Nprd;
+    result.updatedRho = true;
+    result.NprdSubIter = r.NprdSubIter;
+    result.dRho.assign(dRho.begin(), dRho.begin() + nEnt);
+    result.dRhoMaxIdx.assign(dRhoIdx.begin(), dRhoIdx.begin() + nEnt);
+    result.updatedJPrd = true;
+    result.dJPrdMax.assign(dJ.begin(), dJ.begin() + r.NprdSubIter);
+    result.dJPrdMaxIdx.assign(dJIdx.begin(), dJIdx.begin() + r.NprdSubIter);
+    return result;
+}
+
 // scratch hooks (Source/LwFormalInterface.hpp:102-108; called from Source/ThreadStorage.cpp:480-493,538-566)
 void alloc_global_scratch_hip(Context* ctx)
 {
@@ -394,7 +441,7 @@ FsIterationFns fs_iteration_fns_provider()
         fs_iter_hip,
         simple_fs_hip,
         formal_sol_full_stokes_impl,      // not accelerated: the core's own (final synthesis only)
-        redistribute_prd_lines_scalar,    // not accelerated yet: the core's own
+        redistribute_prd_hip,
         stat_eq_hip,
         time_dependent_update_impl,       // not accelerated yet: the core's own
         nr_post_update_impl,              // not accelerated yet: the core's own

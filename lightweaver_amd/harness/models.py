@@ -201,15 +201,16 @@ def _collisional_rates(m: AtomModel, nStar, T, ne):
 
 
 def _damping(m: AtomModel, l: LineModel, Aji_all, lambda0, vBroad, atmos: Atmosphere1d):
+    """Returns (aDamp, Qelast): damping parameter and the elastic-collision part of the width [s^-1]."""
     gRad = sum(A for (i, j), A in Aji_all.items() if j in (l.i, l.j))
-    g = gRad + l.vdw * atmos.nH[0] * (atmos.temperature / 1.0e4)**0.3
+    gEl = l.vdw * atmos.nH[0] * (atmos.temperature / 1.0e4)**0.3
     if l.starkLinear and m.nQuantum is not None:
         nl, nu = m.nQuantum[l.i], m.nQuantum[l.j]
         a1 = 0.642 if nl == 1 else 1.0
-        g = g + a1 * 0.6 * (nu * nu - nl * nl) * atmos.ne**(2.0 / 3.0) * ph.CM_TO_M**2
+        gEl = gEl + a1 * 0.6 * (nu * nu - nl * nl) * atmos.ne**(2.0 / 3.0) * ph.CM_TO_M**2
     else:
-        g = g + 1.0e-12 * atmos.ne  # quadratic-Stark-like
-    return g * lambda0 * ph.NM_TO_M / (4.0 * np.pi * vBroad)
+        gEl = gEl + 1.0e-12 * atmos.ne  # quadratic-Stark-like
+    return (gRad + gEl) * lambda0 * ph.NM_TO_M / (4.0 * np.pi * vBroad), gEl
 
 
 def build_problem(atmos: Atmosphere1d, models: List[AtomModel], Nrays=5,
@@ -249,10 +250,10 @@ def build_problem(atmos: Atmosphere1d, models: List[AtomModel], Nrays=5,
             Nblue = int(np.searchsorted(grid, g[0]))
             Nred = int(np.searchsorted(grid, g[-1])) + 1
             w = grid[Nblue:Nred].copy()
+            aDamp, Qelast = _damping(m, l, Aji_all, lam0, vBroad, atmos)
             t = TransitionData(type=abi.LINE, i=l.i, j=l.j, Nblue=Nblue, Nred=Nred, lambda0=lam0,
                                wavelength=w, Aji=Aji, Bji=Bji, Bij=Bij,
-                               dopplerWidth=ph.CLight / lam0,
-                               aDamp=_damping(m, l, Aji_all, lam0, vBroad, atmos))
+                               dopplerWidth=ph.CLight / lam0, aDamp=aDamp, Qelast=Qelast)
             if l.prd:
                 t.rhoPrd = np.ones((Nred - Nblue, Ns))
             trans.append(t)

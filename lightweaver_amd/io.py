@@ -11,7 +11,7 @@ from . import _abi as abi
 from .model import AtomData, Boundary, Problem, TransitionData
 
 _T_SCALARS = ['type', 'i', 'j', 'Nblue', 'Nred', 'lambda0', 'Aji', 'Bji', 'Bij', 'dopplerWidth']
-_T_ARRAYS = ['wavelength', 'alpha', 'phi', 'wphi', 'aDamp', 'rhoPrd']
+_T_ARRAYS = ['wavelength', 'alpha', 'phi', 'wphi', 'aDamp', 'rhoPrd', 'Qelast']
 
 
 def problem_to_dict(prob: Problem, include_phi=True) -> dict:

@@ -49,6 +49,7 @@ class TransitionData:
     wphi: Optional[np.ndarray] = None      # [Nspace] lines
     aDamp: Optional[np.ndarray] = None     # [Nspace] lines
     rhoPrd: Optional[np.ndarray] = None    # [NlaT, Nspace] PRD lines
+    Qelast: Optional[np.ndarray] = None    # [Nspace] elastic collision rate (PRD lines)
     Rij: Optional[np.ndarray] = None       # [Nspace]
     Rji: Optional[np.ndarray] = None       # [Nspace]
 
@@ -157,6 +158,7 @@ class Problem:
                 t.aDamp = _f64(t.aDamp, (Ns,)) if t.aDamp is not None else np.zeros(Ns)
                 if t.rhoPrd is not None:
                     t.rhoPrd = _f64(t.rhoPrd, (t.Nlambda, Ns))
+                t.Qelast = _f64(t.Qelast, (Ns,)) if t.Qelast is not None else np.zeros(Ns)
             else:
                 t.alpha = _f64(t.alpha, (t.Nlambda,))
             t.Rij = np.zeros(Ns)
@@ -216,6 +218,7 @@ class Problem:
                 ct.rhoPrd = _ptr(t.rhoPrd)
                 ct.Rij = _ptr(t.Rij)
                 ct.Rji = _ptr(t.Rji)
+                ct.Qelast = _ptr(t.Qelast)
             ca = atoms[ia]
             ca.Nlevel, ca.Ntrans, ca.detailed = int(a.Nlevel), len(a.trans), int(bool(a.detailed))
             ca.n = _ptr(a.n)

@@ -64,6 +64,29 @@ class _Handle:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _redistribute(fn, h, maxIter, tol, nprd_guess=16):
+    import numpy as np
+    nit = C.c_int32(0)
+    nprd = C.c_int32(0)
+    dRho = np.zeros(maxIter * nprd_guess)
+    dRhoIdx = np.zeros(maxIter * nprd_guess, dtype=np.int32)
+    dJ = np.zeros(maxIter)
+    dJIdx = np.zeros(maxIter, dtype=np.int32)
+    st = fn(h, maxIter, tol, C.byref(nit), C.byref(nprd), dRho.ctypes.data_as(abi.f64p),
+            dRhoIdx.ctypes.data_as(abi.i32p), dJ.ctypes.data_as(abi.f64p), dJIdx.ctypes.data_as(abi.i32p))
+    assert st == 0
+    n, m = nit.value, nprd.value
+    return {'NprdSubIter': n, 'Nprd': m, 'dRho': dRho[:n * m].reshape(n, m) if m else dRho[:0],
+            'dRhoMaxIdx': dRhoIdx[:n * m].reshape(n, m) if m else dRhoIdx[:0],
+            'dJPrdMax': dJ[:n], 'dJPrdMaxIdx': dJIdx[:n]}
+
 
 class RefContext(_Handle):
     """The reference core driving `prob` (scheme: None = mali_full_precond_scalar, or a plugin path)."""
@@ -83,6 +106,10 @@ class RefContext(_Handle):
                                                             C.POINTER(abi.lwhip_iter_result)]
             lib.lwref_formal_sol.argtypes = [C.c_void_p, C.c_int]
             lib.lwref_stat_equil.argtypes = [C.c_void_p, C.c_int]
+            lib.lwref_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
+                                                   abi.f64p, abi.i32p, abi.f64p, abi.i32p]
+            lib.lwref_GII.restype = C.c_double
+            lib.lwref_GII.argtypes = [C.c_double] * 3
             lib.lwref_w2.argtypes = [C.c_double, abi.f64p]
             lib.lwref_bezier3_coeffs.argtypes = [C.c_double, abi.f64p]
             lib.lwref_cent_deriv.restype = C.c_double
@@ -129,6 +156,9 @@ class RefContext(_Handle):
     def stat_equil(self, atom=-1):
         return self.lib.lwref_stat_equil(self.h, atom)
 
+    def redistribute_prd(self, maxIter=3, tol=1e-2):
+        return _redistribute(self.lib.lwref_redistribute_prd, self.h, maxIter, tol)
+
 
 class OracleContext(_Handle):
     """The plain-C restatement driving `prob`."""
@@ -150,6 +180,10 @@ class OracleContext(_Handle):
             lib.lworacle_fs_partial.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, abi.f64p, abi.f64p]
             lib.lworacle_fs_finalise.argtypes = [C.c_void_p, abi.f64p]
             lib.lworacle_stat_equil.argtypes = [C.c_void_p, C.c_int]
+            lib.lworacle_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
+                                                      abi.f64p, abi.i32p, abi.f64p, abi.i32p]
+            lib.lworacle_GII.restype = C.c_double
+            lib.lworacle_GII.argtypes = [C.c_double] * 3
             lib.lworacle_w2.argtypes = [C.c_double, abi.f64p]
             lib.lworacle_bezier3_coeffs.argtypes = [C.c_double, abi.f64p]
             lib.lworacle_cent_deriv.restype = C.c_double
@@ -195,3 +229,6 @@ class OracleContext(_Handle):
 
     def stat_equil(self, atom=-1):
         return self.lib.lworacle_stat_equil(self.h, atom)
+
+    def redistribute_prd(self, maxIter=3, tol=1e-2):
+        return _redistribute(self.lib.lworacle_redistribute_prd, self.h, maxIter, tol)

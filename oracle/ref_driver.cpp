@@ -23,6 +23,8 @@
 #include "Bezier.hpp"
 #include "LuSolve.hpp"
 
+namespace PrdCores { f64 GII(f64 aDamp, f64 qEmit, f64 qAbs); }
+
 #include "../include/lwhip.h"
 
 #include <cstdio>
@@ -227,6 +229,8 @@ void* lwref_create(const lwhip_problem* p, const char* schemeLib, int Nthreads,
                         t->aDamp = F64View(const_cast<f64*>(pt.aDamp), Nspace);
                     if (pt.prd && pt.rhoPrd)
                         t->rhoPrd = F64View2D(pt.rhoPrd, Nl, Nspace);
+                    if (pt.Qelast)
+                        t->Qelast = F64View(const_cast<f64*>(pt.Qelast), Nspace);
                 }
                 else
                 {
@@ -374,7 +378,51 @@ int lwref_stat_equil(void* h, int atomIdx)
     return LWHIP_OK;
 }
 
+// redistribute_prd_lines (Source/Prd.cpp:648-653 -> PrdTemplates.hpp:175-351)
+int lwref_redistribute_prd(void* h, int maxIter, double tol, int* NprdSubIter, int* NprdOut,
+                           double* dRho, int* dRhoMaxIdx, double* dJPrdMax, int* dJPrdMaxIdx)
+{
+    auto* rc = (RefContext*)h;
+    try
+    {
+        refresh_bcs(rc);
+        IterationResult r = redistribute_prd_lines(rc->ctx, maxIter, tol);
+        if (NprdSubIter)
+            *NprdSubIter = r.NprdSubIter;
+        const int Nprd = r.NprdSubIter > 0 ? (int)(r.dRho.size() / r.NprdSubIter) : 0;
+        if (NprdOut)
+            *NprdOut = Nprd;
+        for (size_t i = 0; i < r.dRho.size(); ++i)
+        {
+            if (dRho)
+                dRho[i] = r.dRho[i];
+            if (dRhoMaxIdx)
+                dRhoMaxIdx[i] = r.dRhoMaxIdx[i];
+        }
+        for (size_t i = 0; i < r.dJPrdMax.size(); ++i)
+        {
+            if (dJPrdMax)
+                dJPrdMax[i] = r.dJPrdMax[i];
+            if (dJPrdMaxIdx)
+                dJPrdMaxIdx[i] = r.dJPrdMaxIdx[i];
+        }
+    }
+    catch (const std::exception& e)
+    {
+        std::fprintf(stderr, "lwref: %s\n", e.what());
+        return LWHIP_ERR_INVALID;
+    }
+    return LWHIP_OK;
+}
+
+double lwref_GII(double aDamp, double qEmit, double qAbs);
+
 // ---- leaf known-answer hooks (pin the restatement function by function) ---------------------
+
+double lwref_GII(double aDamp, double qEmit, double qAbs)
+{
+    return PrdCores::GII(aDamp, qEmit, qAbs);
+}
 
 void lwref_w2(double dtau, double* w)
 {

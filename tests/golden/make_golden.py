@@ -20,6 +20,9 @@ Variants (keys `out/<variant>/...`):
   fs_up / fs_all    formal_sol(upOnly = True / False): I
   bc         iter1 with zUpperBc THERMALISED and zLowerBc CALLABLE
   prd_detailed      iter1 with Ca II as a detailed (rates-only) atom and rhoPrd != 1 on H & K
+
+falc_h_ca_prd.npz (make_prd_fixture) holds the PRD problem of tests/test_prd.py and the reference's
+state after three iterations of formal_sol_gamma_matrices / stat_equil / redistribute_prd(3, 1e-2).
 """
 import os
 import sys
@@ -141,6 +144,45 @@ def make_fixture(name, prob):
     return finish(name, prob, out)
 
 
+def make_prd_fixture(name, baseName, prob):
+    """Delta on top of fixture `baseName` (same atmosphere, atoms and profiles): which lines are PRD,
+    their Qelast, and the reference's state after the iterations of tests/test_prd.run_iterations."""
+    from tests.test_prd import apply_prd_delta, prd_lines, run_iterations
+    from tests.helpers import load_fixture
+    d = {}
+    q = 0
+    for ia, a in enumerate(prob.atoms):
+        for kr, t in enumerate(a.trans):
+            if t.type == abi.LINE and t.rhoPrd is not None:
+                d[f'prd/line{q}'] = np.array([ia, kr])
+                d[f'prd/Qelast{q}'] = t.Qelast
+                q += 1
+    d['prd/N'] = np.array(q)
+    base, _ = load_fixture(baseName)
+    start = apply_prd_delta(base, d)
+    # the delta must describe the harness problem (to rounding: the base fixture's inputs are the ones used)
+    for a, b in zip(start.atoms, prob.atoms):
+        for ta, tb in zip(a.trans, b.trans):
+            assert (ta.rhoPrd is None) == (tb.rhoPrd is None)
+            if ta.type == abi.LINE:
+                assert np.allclose(ta.phi, tb.phi, rtol=1e-13) and np.allclose(ta.aDamp, tb.aDamp, rtol=1e-13)
+    p, upd = run_iterations(RefContext, start)
+    d['NprdSubIter'] = np.array([u['NprdSubIter'] for u in upd])
+    d['dRho'] = np.concatenate([u['dRho'].ravel() for u in upd])
+    d['dRhoMaxIdx'] = np.concatenate([u['dRhoMaxIdx'].ravel() for u in upd])
+    d['dJPrdMax'] = np.concatenate([u['dJPrdMax'] for u in upd])
+    d['J'] = p.J
+    for q, t in enumerate(prd_lines(p)):
+        d[f'rho{q}'] = t.rhoPrd
+        d[f'Rij{q}'] = t.Rij
+        d[f'Rji{q}'] = t.Rji
+    for ia, a in enumerate(p.atoms):
+        d[f'n{ia}'] = a.n
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **d)
+    print(f'wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB')
+
+
 def finish(name, prob, out):
     d = problem_to_dict(prob)
     d.update(out)
@@ -156,6 +198,7 @@ def main():
     atmos = models.perturbed(models.falc82(), seed=11)
     make_fixture('falc_h_vel', models.build_problem(atmos, [models.H_6(0.25)], Nrays=2,
                                                     storeDepthData=True))
+    make_prd_fixture('falc_h_ca_prd', 'falc_h_ca_small', models.falc_h_ca(Nrays=3, lineScale=0.3, prd=True))
 
 
 if __name__ == '__main__':

@@ -122,3 +122,25 @@ def test_dropin_sees_host_side_changes(gpu):
         ref.formal_sol_gamma_matrices()
         assert rel_err(p.J, q.J) <= TOL_ONE_CALL
         assert rel_err(p.atoms[0].Gamma, q.atoms[0].Gamma) <= TOL_ONE_CALL
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_prd_redistribute(gpu):
+    """FsIterationFns::redistribute_prd of the plugin, driven by the real core's
+    redistribute_prd_lines dispatch (Source/Prd.cpp), next to the core's own scalar scheme."""
+    from test_prd import assert_same_state, golden_prd_problem
+    prob, _ = golden_prd_problem()
+    p, q = prob.copy(), prob.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(3):
+        for pr, c in ((p, hipc), (q, ref)):
+            pr.gamma_prefill()
+            c.formal_sol_gamma_matrices()
+            if it >= 1:
+                assert c.stat_equil() == 0
+        u1, u2 = hipc.redistribute_prd(3, 1e-2), ref.redistribute_prd(3, 1e-2)
+        assert u1['NprdSubIter'] == u2['NprdSubIter'] and u1['Nprd'] == u2['Nprd'] == 2
+        assert np.allclose(u1['dRho'], u2['dRho'], rtol=1e-5)
+        assert np.allclose(u1['dJPrdMax'], u2['dJPrdMax'], rtol=1e-7)
+    assert_same_state(p, q, 1e-8)
