@@ -14,8 +14,8 @@ LIB = os.path.join(PKG, 'liblwhip.so')
 PLUGIN = os.path.join(PKG, 'LwHipIterScheme.so')
 REF_SRC = os.environ.get('LW_REFERENCE_SOURCE', '/root/reference/Source')
 
-HIP_SOURCES = ['lwhip_api.hip', 'lwhip_kernels.hip', 'lwhip_voigt.hip', 'lwhip_prd.hip']
-HIP_HEADERS = ['lwhip_internal.h', os.path.join('..', '..', 'include', 'lwhip.h')]
+HIP_SOURCES = ['lwhip_api.hip', 'lwhip_kernels.hip', 'lwhip_march.hip', 'lwhip_voigt.hip', 'lwhip_prd.hip']
+HIP_HEADERS = ['lwhip_internal.h', 'lwhip_device.h', os.path.join('..', '..', 'include', 'lwhip.h')]
 
 
 def _hipcc():
@@ -32,18 +32,35 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> lightweaver_amd/liblwhip.so"""
+def build_hip(force=False, verbose=False, defines=(), out=None):
+    """hipcc --offload-arch=gfx950 -> lightweaver_amd/liblwhip.so.  Translation units are compiled
+    concurrently (objects under build/, git-ignored), then linked."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = out or LIB
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HIP_HEADERS]
-    if not force and not _stale(LIB, deps):
-        return LIB
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-o', LIB] + srcs
+    if not force and not _stale(lib, deps):
+        return lib
+    objdir = os.path.join(ROOT, 'build', os.path.basename(lib) + '.obj')
+    os.makedirs(objdir, exist_ok=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + [f'-D{d}' for d in defines]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
+        if force or _stale(obj, [src] + deps[len(srcs):]):
+            cmd = [_hipcc()] + flags + ['-c', '-o', obj, src]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return lib
 
 
 def build_plugin(force=False, verbose=False):

@@ -97,6 +97,11 @@ struct lwhip_context
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
     int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, G = 1;
     bool big = false;
+    bool march = true;            // wavefront-autonomous sweep (lwhip_march.hip); false: the LDS-column sweep
+    int marchD = 7, marchS = 12, marchWaves = 4;
+    int64_t rowsTot = 0;
+    int nContLa = 0;
+    bool accGlobal = false;
     int64_t gammaTot = 0, phiTot = 0, rhoTot = 0, parTot = 0;
     hipStream_t ownStream = nullptr, stream = nullptr;
 
@@ -105,7 +110,8 @@ struct lwhip_context
     DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
-    DevBuf<double> prdChange, prdOut;
+    DevBuf<double> prdChange, prdOut, rowsBuf;
+    DevBuf<int32_t> contLa;
     DevBuf<int32_t> prdChangeIdx;
     double* prdPinned = nullptr;
     DevBuf<DevTrans> dtrans;
@@ -392,6 +398,8 @@ int build_tables(lwhip_context* c)
     std::vector<DevProgRow> progRows;
     std::vector<DevProgEnt> progEnts;
     std::map<std::vector<int>, int> progIds;
+    std::vector<int32_t> contLaHost;
+    c->rowsTot = 0;
     c->maxL = c->maxC = 0;
     const int rowEtaA = 2, rowLevChi = 2 + c->Natom, rowLevU = 2 + c->Natom + c->NlevTot;
     for (int la = 0; la < c->Nla; ++la)
@@ -539,6 +547,37 @@ int build_tables(lwhip_context* c)
             progs.push_back(pg);
         }
         hdr[la].prog = (int16_t)it->second;
+        // block of this wavelength in the continuum-row buffer (march kernel): the program's rows in
+        // rowsNeeded order, then Vji of each continuum
+        const int nContHere = (int)contOrder.size();
+        hdr[la].nRows = (int32_t)rowsNeeded.size();
+        hdr[la].rowBase = -1;
+        if (nContHere > 0)
+        {
+            hdr[la].rowBase = (int32_t)c->rowsTot;
+            c->rowsTot += (int64_t)rowsNeeded.size() + nContHere;
+            contLaHost.push_back(la);
+        }
+        auto dense = [&](int r) -> int16_t {
+            if (nContHere == 0)
+                return -1;
+            auto f = std::find(rowsNeeded.begin(), rowsNeeded.end(), r);
+            return f == rowsNeeded.end() ? (int16_t)-1 : (int16_t)(f - rowsNeeded.begin());
+        };
+        for (size_t e = 0; e < order.size(); ++e)
+        {
+            DevSlot& sl = slots[hdr[la].off + e];
+            const HostTrans& ht = c->trans[order[e]];
+            const int gi = c->levelOff[ht.atom] + ht.t.i, gj = c->levelOff[ht.atom] + ht.t.j;
+            sl.rEtaA = dense(rowEtaA + ht.atom);
+            sl.rChiI = dense(rowLevChi + gi);
+            sl.rChiJ = dense(rowLevChi + gj);
+            sl.rUI = dense(rowLevU + gi);
+            sl.rUJ = dense(rowLevU + gj);
+            sl.rVji = (int16_t)((int)e >= (int)lines.size() ? (int)rowsNeeded.size() + ((int)e - (int)lines.size()) : -1);
+            if (!isOp(order[e]))
+                sl.rEtaA = sl.rChiI = sl.rChiJ = sl.rUI = sl.rUJ = -1;
+        }
     }
     if (c->maxL > 8)
         return fail(LWHIP_ERR_UNSUPPORTED, "more than 8 lines overlap at one wavelength");
@@ -614,11 +653,55 @@ int build_tables(lwhip_context* c)
     }
     trOff[c->Ntrans] = (int32_t)trRow.size();
 
-    // ---- rays per pass / scan lanes ------------------------------------------------------------------
+    // ---- sweep geometry ---------------------------------------------------------------------------------
     const int NR2 = 2 * c->Nrays;
     size_t ldsMax = 160 * 1024;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor > 0)
         ldsMax = prop.maxSharedMemoryPerMultiProcessor;
+    // March kernel: D depth points per lane, S = ceil(Ns / D) lanes per ray, R = 64 / S rays per pass.
+    // Pick the D that needs the fewest lane-steps for all rays (ties: the smaller D, less serial work).
+    c->march = env_int("LWHIP_SWEEP", 2) >= 3;
+    {
+        int bestD = 0;
+        long bestCost = 0;
+        for (int D : { 4, 7, 8 })
+        {
+            const int S = (Ns + D - 1) / D;
+            if (S > 64 || Ns < 3)
+                continue;
+            const int R = std::min(64 / S, NR2);
+            const long passes = (NR2 + R - 1) / R;
+            const long cost = passes * (D + 3); // + the per-pass shuffles / scan
+            if (bestD == 0 || cost < bestCost)
+            {
+                bestD = D;
+                bestCost = cost;
+            }
+        }
+        const int Denv = env_int("LWHIP_D", 0);
+        if (Denv == 2 || Denv == 3 || Denv == 4 || Denv == 7 || Denv == 8)
+            if ((Ns + Denv - 1) / Denv <= 64)
+                bestD = Denv;
+        if (bestD == 0)
+            c->march = false; // deeper than 512 points: the LDS-column sweep in its global-scratch mode
+        else
+        {
+            c->marchD = bestD;
+            c->marchS = (Ns + bestD - 1) / bestD;
+        }
+        c->marchWaves = std::max(1, std::min(8, env_int("LWHIP_MWAVES", 4)));
+        // populations, wphi and the moment rows must fit the LDS (accumulators may go to the slab)
+        SweepArgs sz{};
+        sz.Ns = Ns;
+        sz.maxCT = c->maxCT;
+        sz.NlevTot = c->NlevTot;
+        sz.Nline = c->Nline;
+        sz.accGlobal = 1;
+        if (march_lds_bytes(sz, c->marchWaves) > 64 * 1024)
+            c->march = false;
+    }
+    if (!c->march)
+    {
     auto ldsFor = [&](int g) {
         SweepArgs s{};
         s.Ns = Ns;
@@ -649,6 +732,7 @@ int build_tables(lwhip_context* c)
     if (ldsFor(G) > ldsMax)
         return fail(LWHIP_ERR_UNSUPPORTED, "problem does not fit the 160 KB LDS budget of one workgroup");
     c->G = G;
+    }
 
     // ---- device tables ---------------------------------------------------------------------------------
     std::vector<DevTrans> dt(c->Ntrans);
@@ -718,6 +802,10 @@ int build_tables(lwhip_context* c)
     HIP_TRY(c->progRows.upload(progRows));
     HIP_TRY(c->progEnts.upload(progEnts));
     HIP_TRY(c->chunkLa.upload(chunkLa));
+    if (contLaHost.empty())
+        contLaHost.push_back(0);
+    c->nContLa = (c->rowsTot > 0) ? (int)contLaHost.size() : 0;
+    HIP_TRY(c->contLa.upload(contLaHost));
     HIP_TRY(c->trOff.upload(trOff));
     HIP_TRY(c->trRow.upload(trRow));
     HIP_TRY(c->rayAll.upload(rayAll));
@@ -783,6 +871,19 @@ int alloc_state(lwhip_context* c)
         sz.NlevTot = c->NlevTot;
         sz.maxC = c->maxC;
         HIP_TRY(c->bigScratch.alloc((size_t)c->nChunks * sweep_big_scratch_doubles(sz)));
+    }
+    if (c->march)
+    {
+        HIP_TRY(c->rowsBuf.alloc((size_t)std::max<int64_t>(c->rowsTot, 1) * c->Ns));
+        // accumulators in LDS when they leave room for >= 2 workgroups per CU, else in the chunk's slab
+        SweepArgs sz{};
+        sz.Ns = c->Ns;
+        sz.maxCT = c->maxCT;
+        sz.NlevTot = c->NlevTot;
+        sz.Nline = c->Nline;
+        sz.accGlobal = 0;
+        c->accGlobal = march_lds_bytes(sz, c->marchWaves) > 64 * 1024;
+
     }
     HIP_TRY(c->stamps.alloc((size_t)c->nChunks * 12));
     HIP_TRY(hipMemset(c->stamps.p, 0, c->stamps.n * sizeof(long long)));
@@ -853,6 +954,11 @@ int build_sweep_args(lwhip_context* c)
     a.dJ = c->dJ.p;
     a.stamps = c->stamps.p;
     a.bigScratch = c->bigScratch.p;
+    a.rows = c->rowsBuf.p;
+    a.contLa = c->contLa.p;
+    a.nContLa = c->nContLa;
+    a.accGlobal = c->accGlobal ? 1 : 0;
+    a.Nline = c->Nline;
     c->hargs = a;
     std::vector<SweepArgs> v(1, a);
     HIP_TRY(c->dargs.upload(v));
@@ -866,7 +972,21 @@ SweepDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
     d.G = std::min(c->G, d.nRaysActive);
     d.lambdaIterate = lambdaIterate;
     d.rayList = upOnly ? c->rayUp.p : c->rayAll.p;
+    d.S = c->marchS;
+    d.R = std::max(1, std::min(64 / c->marchS, d.nRaysActive));
     return d;
+}
+
+// one sweep over this context's wavelengths (rates = the full iteration, else formal_sol)
+hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
+{
+    if (!c->march)
+        return launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, rates, c->nChunks, c->stream);
+    hipError_t e = launch_cont(c->dargs.p, c->hargs, c->stream);
+    if (e != hipSuccess)
+        return e;
+    return launch_march(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->marchD, c->maxL, rates, c->nChunks,
+                        c->marchWaves, c->stream);
 }
 
 int flush_prefill(lwhip_context* c)
@@ -1223,7 +1343,7 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    HIP_TRY(launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, true, c->nChunks, c->stream));
+    HIP_TRY(run_sweep(c, dyn, true));
     if (c->profiling)
     {
         HIP_TRY(hipEventRecord(e1, c->stream));
@@ -1335,7 +1455,7 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     const SweepDyn dyn = make_dyn(c, upOnly != 0, 0);
-    HIP_TRY(launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, false, c->nChunks, c->stream));
+    HIP_TRY(run_sweep(c, dyn, false));
     return LWHIP_OK;
 }
 
@@ -1451,7 +1571,7 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
         // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
         SweepDyn dyn = make_dyn(c, false, 0);
         dyn.prdOnly = 1;
-        HIP_TRY(launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, true, c->nChunks, c->stream));
+        HIP_TRY(run_sweep(c, dyn, true));
         ReduceArgs r{};
         r.Ns = Ns;
         r.Ntrans = c->Ntrans;

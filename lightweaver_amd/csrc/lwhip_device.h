@@ -1,0 +1,249 @@
+// lwhip_device.h -- device-side leaf numerics and address-space helpers shared by the gfx950 kernels.
+#pragma once
+#include "lwhip_internal.h"
+
+#include <hip/hip_runtime.h>
+
+namespace lwhip
+{
+#define DEVINL __device__ __forceinline__
+
+// ---- leaf numerics -------------------------------------------------------------------------------
+
+// w2: LwInternal.hpp:90-110
+DEVINL void d_w2(double dtau, double& w0, double& w1)
+{
+    if (dtau < 5.0E-4)
+    {
+        w0 = dtau * (1.0 - 0.5 * dtau);
+        w1 = (dtau * dtau) * (0.5 - dtau * (1.0 / 3.0));
+    }
+    else if (dtau > 50.0)
+    {
+        w0 = 1.0;
+        w1 = 1.0;
+    }
+    else
+    {
+        const double expdt = exp(-dtau);
+        w0 = 1.0 - expdt;
+        w1 = w0 - dtau * expdt;
+    }
+}
+
+// cent_deriv (Steffen 1990): Bezier.hpp:58-65
+DEVINL double d_cent_deriv(double dsuw, double dsdw, double yuw, double y0, double ydw)
+{
+    const double S0 = (ydw - y0) / dsdw;
+    const double Suw = (y0 - yuw) / dsuw;
+    const double P0 = fabs((Suw * dsdw + S0 * dsuw) / (dsdw + dsuw));
+    return (copysign(1.0, S0) + copysign(1.0, Suw)) * fmin(fabs(Suw), fmin(fabs(S0), 0.5 * P0));
+}
+
+// Bezier3_coeffs: Bezier.hpp:81-127
+DEVINL void d_bezier3_coeffs(double dt, double& alpha, double& beta, double& gamma, double& delta,
+                             double& edt)
+{
+    const double dt2 = dt * dt;
+    const double dt3 = dt2 * dt;
+    if (dt < 5e-2)
+    {
+        edt = 1.0 - dt + 0.5 * dt2 - dt3 / 6.0;
+        alpha = 0.25 * dt - 0.2 * dt2 + dt3 / 12.0;
+        beta = 0.25 * dt - 0.05 * dt2 + dt3 / 120.0;
+        gamma = 0.25 * dt - 0.15 * dt2 + 0.05 * dt3;
+        delta = 0.25 * dt - 0.1 * dt2 + 0.025 * dt3;
+    }
+    else if (dt > 30.0)
+    {
+        edt = 0.0;
+        alpha = 6.0 / dt3;
+        beta = (-6.0 + 6.0 * dt - 3.0 * dt2 + dt3) / dt3;
+        gamma = 3.0 * (2.0 * dt - 6.0) / dt3;
+        delta = 3.0 * (6.0 - 4.0 * dt + dt2) / dt3;
+    }
+    else
+    {
+        edt = exp(-dt);
+        alpha = (6.0 - edt * (6.0 + 6.0 * dt + 3 * dt2 + dt3)) / dt3;
+        beta = (6.0 * edt - 6.0 + 6.0 * dt - 3.0 * dt2 + dt3) / dt3;
+        gamma = 3.0 * (2.0 * dt - 6.0 + edt * (6.0 + 4.0 * dt + dt2)) / dt3;
+        delta = 3.0 * (6.0 - 4.0 * dt + dt2 - 2.0 * edt * (3.0 + dt)) / dt3;
+    }
+}
+
+// planck_nu at one temperature: LwMisc.hpp:29-46
+DEVINL double d_planck(double T, double lambda)
+{
+    const double hc_kla = HC_K / lambda;
+    const double twohnu3_c2 = TWO_HC_NM3 / (lambda * lambda * lambda);
+    const double x = hc_kla / T;
+    return (x <= 150.0) ? twohnu3_c2 / (exp(x) - 1.0) : 0.0;
+}
+
+// besser_control_point_1d: FormalScalar.cpp:327-363
+DEVINL double d_besser_control_point(double hM, double hP, double yM, double yO, double yP)
+{
+    const double dM = (yO - yM) / hM;
+    const double dP = (yP - yO) / hP;
+    if (dM * dP <= 0.0)
+        return yO;
+    double yOp = (hM * dP + hP * dM) / (hM + hP);
+    double cM = yO - 0.5 * hM * yOp;
+    double cP = yO + 0.5 * hP * yOp;
+    double minYMO = yM, maxYMO = yO, minYOP = yO, maxYOP = yP;
+    if (dM < 0.0)
+    {
+        minYMO = yO;
+        maxYMO = yM;
+        minYOP = yP;
+        maxYOP = yO;
+    }
+    if (cM < minYMO || cM > maxYMO)
+        return yM;
+    if (cP < minYOP || cP > maxYOP)
+    {
+        cP = yP;
+        yOp = (cP - yO) / (0.5 * hP);
+        cM = yO - 0.5 * hM * yOp;
+    }
+    return cM;
+}
+
+// besser_coeffs_1d: FormalScalar.cpp:373-393
+DEVINL void d_besser_coeffs(double t, double& M, double& O, double& Cc, double& edt)
+{
+    if (t < 0.14)
+    {
+        M = (t * (t * (t * (t * (t * (t * ((140.0 - 18.0 * t) * t - 945.0) + 5400.0) - 25200.0) + 90720.0) - 226800.0) + 302400.0)) / 907200.0;
+        O = (t * (t * (t * (t * (t * (t * ((10.0 - t) * t - 90.0) + 720.0) - 5040.0) + 30240.0) - 151200.0) + 604800.0)) / 1814400.0;
+        Cc = (t * (t * (t * (t * (t * (t * ((35.0 - 4.0 * t) * t - 270.0) + 1800.0) - 10080.0) + 45360.0) - 151200.0) + 302400.0)) / 907200.0;
+        const double t2 = t * t, t3 = t * t * t;
+        edt = 1.0 - t + 0.5 * t2 - t3 / 6.0 + t * t3 / 24.0 - t2 * t3 / 120.0 + t3 * t3 / 720.0 - t3 * t3 * t / 5040.0;
+    }
+    else
+    {
+        const double t2 = t * t;
+        edt = exp(-t);
+        M = (2.0 - edt * (t2 + 2.0 * t + 2.0)) / t2;
+        O = 1.0 - 2.0 * (edt + t - 1.0) / t2;
+        Cc = 2.0 * (t - 2.0 + edt * (t + 2.0)) / t2;
+    }
+}
+
+DEVINL void lds_add(double* addr, double v)
+{
+#ifdef LWHIP_EXPERIMENT_NOATOMIC
+    *addr += v; // timing experiment only (racy)
+#else
+    // ds_add_f64 on gfx950
+    unsafeAtomicAdd(addr, v);
+#endif
+}
+
+// Workgroup barrier that orders LDS traffic only: outstanding global loads (the software prefetch
+// of the next wavelength) and stores (J, I, depth data) stay in flight across it, which a
+// __syncthreads() -- s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier -- would drain.
+DEVINL void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Address-space-qualified views of the pointers that live in the (device-memory) argument block:
+// without them the loads compile to flat_load, which counts on lgkmcnt and so stalls every LDS
+// barrier behind the HBM latency of the prefetches; tables read uniformly become scalar loads.
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define CONST_AS __attribute__((address_space(4)))
+#define GCD(p) ((const GLOBAL_AS double*)(p))
+#define GD(p) ((GLOBAL_AS double*)(p))
+#define CTAB(T, p) ((const CONST_AS T*)(p))
+DEVINL const CONST_AS SweepArgs* launder_args(const SweepArgs* p)
+{
+    const CONST_AS SweepArgs* q = (const CONST_AS SweepArgs*)p;
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
+template <typename T> DEVINL T ld_c(const CONST_AS T* p)
+{
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (5 VALU ops instead of the ~15 of an IEEE divide).
+// Used where the reference divides by a quantity that is shared by several expressions; the
+// results differ from a correctly rounded divide by at most a couple of ulp (tolerance 1e-9).
+DEVINL double d_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// exp(x) for -700 < x <= 0 (optical depths, Boltzmann factors): range reduction x = n ln2 + r,
+// |r| <= ln2/2, degree-13 Taylor polynomial (truncation 4e-18), ldexp.  No overflow / NaN paths,
+// about half the instructions of the library exp; agrees with it to ~1 ulp.
+DEVINL double d_exp_neg(double x)
+{
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// cent_deriv (Bezier.hpp:58-65) with the three reciprocals supplied
+DEVINL double d_cent_deriv_r(double dsuw, double dsdw, double ruw, double rdw, double rsum,
+                             double yuw, double y0, double ydw)
+{
+    const double S0 = (ydw - y0) * rdw;
+    const double Suw = (y0 - yuw) * ruw;
+    const double P0 = fabs((Suw * dsdw + S0 * dsuw) * rsum);
+    return (copysign(1.0, S0) + copysign(1.0, Suw)) * fmin(fabs(Suw), fmin(fabs(S0), 0.5 * P0));
+}
+
+// Bezier3_coeffs (Bezier.hpp:81-127); the dt > 30 branch is the exact branch with edt = 0
+DEVINL void d_bezier3_coeffs_r(double dt, double& alpha, double& beta, double& gamma, double& delta,
+                               double& edt)
+{
+    const double dt2 = dt * dt;
+    const double dt3 = dt2 * dt;
+    if (dt < 5e-2)
+    {
+        edt = 1.0 - dt + 0.5 * dt2 - dt3 * (1.0 / 6.0);
+        alpha = 0.25 * dt - 0.2 * dt2 + dt3 * (1.0 / 12.0);
+        beta = 0.25 * dt - 0.05 * dt2 + dt3 * (1.0 / 120.0);
+        gamma = 0.25 * dt - 0.15 * dt2 + 0.05 * dt3;
+        delta = 0.25 * dt - 0.1 * dt2 + 0.025 * dt3;
+    }
+    else
+    {
+        edt = (dt > 30.0) ? 0.0 : exp(-dt);
+        const double r3 = d_rcp(dt3);
+        alpha = (6.0 - edt * (6.0 + 6.0 * dt + 3 * dt2 + dt3)) * r3;
+        beta = (6.0 * edt - 6.0 + 6.0 * dt - 3.0 * dt2 + dt3) * r3;
+        gamma = 3.0 * (2.0 * dt - 6.0 + edt * (6.0 + 4.0 * dt + dt2)) * r3;
+        delta = 3.0 * (6.0 - 4.0 * dt + dt2 - 2.0 * edt * (3.0 + dt)) * r3;
+    }
+}
+
+}

@@ -54,6 +54,8 @@ struct DevLaHeader
     int16_t nPure;
     int16_t prog;       // row program of the continuum sums
     int32_t hasPrd;     // a PRD line (rhoPrd) is active at this wavelength
+    int32_t rowBase;    // first row of this wavelength's block in the continuum-row buffer, -1: no continua
+    int32_t nRows;      // rows of the program (the block holds nRows + nMixed + nPure rows)
 };
 struct DevSlot          // 96 bytes, read with scalar loads
 {
@@ -67,8 +69,12 @@ struct DevSlot          // 96 bytes, read with scalar loads
     double p[4];        // per-(transition, lt) params (see above)
     int64_t phiOff;     // lines: offset of this wavelength's [Nrays,2,Ns] block in the phi pool
     int64_t rhoOff;     // PRD lines: offset of this wavelength's [Ns] row in the rho pool
-    int64_t _pad2[2];
+    // rows of this wavelength's block in the continuum-row buffer (march kernel), -1: identically zero
+    int16_t rEtaA, rChiI, rChiJ, rUI, rUJ;
+    int16_t rVji;       // continua: row of Vji_c (= nRows + continuum ordinal)
+    int16_t _pad2[2];
 };
+static_assert(sizeof(DevSlot) == 96, "DevSlot is read with fixed-size scalar loads");
 // Row program: which continua feed which ray-independent per-depth row.  Rows are laid out
 // contiguously in LDS as [chiC][etaC][etaA x Natom][levChi x NlevTot][levU x NlevTot].
 struct DevProgRow
@@ -129,6 +135,13 @@ struct SweepArgs
     double* dJ;                    // [Nla]
     long long* stamps;             // [nChunks, 12] diagnostic build only (-DLWHIP_STAMPS)
     double* bigScratch;            // [nChunks, sweep_big_scratch_doubles] (big mode only)
+    // march kernel (lwhip_march.hip)
+    double* rows;                  // continuum rows written by cont_kernel: [rowBase + r][Ns] per wavelength
+    const int32_t* contLa;         // [nContLa] wavelengths that have continua
+    int32_t nContLa;
+    int32_t accGlobal;             // accumulators live in the chunk's slab (global atomics) instead of LDS
+    int32_t Nline;
+    int32_t _padM;
 };
 
 // Per-launch part, passed by value.
@@ -139,6 +152,7 @@ struct SweepDyn
     int32_t lambdaIterate;
     int32_t prdOnly;       // PRD rates pass: only wavelengths with a PRD line, J + Rij/Rji of PRD lines
     const int32_t* rayList;        // [nRaysActive] -> r = 2*mu + toObs
+    int32_t S, R;          // march kernel: depth segments per ray, rays per pass (R * S <= 64)
 };
 
 enum { LWHIP_REDUCE_SPLIT = 8 };
@@ -225,6 +239,11 @@ size_t sweep_lds_bytes(const SweepArgs& a, int G);
 size_t sweep_big_scratch_doubles(const SweepArgs& a);
 hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn,
                         int solver, int maxL, bool rates, int nChunks, hipStream_t stream);
+// march kernel: D depth points per lane; returns hipErrorInvalidValue for an unsupported D
+hipError_t launch_cont(const SweepArgs* devArgs, const SweepArgs& hostArgs, hipStream_t stream);
+hipError_t launch_march(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn, int solver,
+                        int D, int maxL, bool rates, int nChunks, int wavesPerGroup, hipStream_t stream);
+size_t march_lds_bytes(const SweepArgs& a, int wavesPerGroup);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream);
 hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2,
