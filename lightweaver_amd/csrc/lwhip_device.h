@@ -246,4 +246,32 @@ DEVINL void d_bezier3_coeffs_r(double dt, double& alpha, double& beta, double& g
     }
 }
 
+
+// ---- wave-wide inclusive scan of affine maps I -> E I + B with DPP (row shifts + row broadcasts) ----------
+// Lane order = application order: after the scan lane L holds the composition of lanes 0..L.
+// DPP moves are 32-bit; a double travels as two halves.  Lanes without a source keep the identity.
+template <int CTRL, int ROW_MASK> DEVINL double dpp_f64(double identity, double v)
+{
+    const unsigned long long iv = __double_as_longlong(identity);
+    const unsigned long long vv = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)iv, (int)(unsigned)vv, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(iv >> 32), (int)(unsigned)(vv >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int CTRL, int ROW_MASK> DEVINL void affine_scan_step(double& E, double& B)
+{
+    const double Ep = dpp_f64<CTRL, ROW_MASK>(1.0, E);
+    const double Bp = dpp_f64<CTRL, ROW_MASK>(0.0, B);
+    B = fma(E, Bp, B);
+    E = E * Ep;
+}
+DEVINL void affine_scan_wave(double& E, double& B)
+{
+    affine_scan_step<0x111, 0xf>(E, B); // row_shr:1
+    affine_scan_step<0x112, 0xf>(E, B); // row_shr:2
+    affine_scan_step<0x114, 0xf>(E, B); // row_shr:4
+    affine_scan_step<0x118, 0xf>(E, B); // row_shr:8
+    affine_scan_step<0x142, 0xa>(E, B); // row_bcast:15 into rows 1 and 3
+    affine_scan_step<0x143, 0xc>(E, B); // row_bcast:31 into rows 2 and 3
+}
 }

@@ -726,17 +726,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                         B = ee * B + sB[rr * Ns + kk];
                         E = ee * E;
                     }
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1)
-                    {
-                        const double Ep = __shfl_up(E, off);
-                        const double Bp = __shfl_up(B, off);
-                        if (lane >= off)
-                        {
-                            B = E * Bp + B;
-                            E = E * Ep;
-                        }
-                    }
+                    affine_scan_wave(E, B);
                     double Iin = __shfl_up(B, 1);
                     if (lane == 0)
                         Iin = 0.0;
