@@ -263,6 +263,32 @@ typedef struct lwhip_prd_result {
 } lwhip_prd_result;
 int lwhip_redistribute_prd(lwhip_context* ctx, int maxIter, double tol, lwhip_prd_result* res);
 
+/* time_dependent_update (FsIterationFns::time_dep_update, Source/LwFormalInterface.hpp:92,123;
+ * time_dependent_update_impl, Source/UpdatePopulations.cpp:120-151): for atom `atom`, per depth
+ * point solve (1 - dt Gamma_k) n_k = nOld_k with the solver of lwhip_stat_equil; n overwritten on
+ * the device.  nOld: host [Nlevel, Nspace]. */
+int lwhip_time_dep_update(lwhip_context* ctx, int atom, const double* nOld, double dt);
+
+/* nr_post_update (FsIterationFns::nr_post_update, Source/LwFormalInterface.hpp:94,124;
+ * nr_post_update_impl + F / Ftd, Source/UpdatePopulations.cpp:230-394): one Newton-Raphson step
+ * of the coupled statistical-equilibrium (or backward-Euler, when nPrev is given) + charge-
+ * conservation system of the listed atoms, per depth point: (sum Nlevel + 1) unknowns, the last
+ * one the electron density.  n of the listed atoms is updated on the device, `ne` on the host.
+ * Uses the device copies of Gamma and C (collisional rates). */
+typedef struct lwhip_nr_args {
+    int32_t Natoms;
+    int32_t _pad;
+    const int32_t* atoms;          /* [Natoms] indices into prob->atoms (active atoms), in equation order */
+    const double* const* stages;   /* [Natoms] -> [Nlevel]: ionisation stage of each level (Atom::stages) */
+    const double* const* dC;       /* [Natoms] -> [Nlevel, Nlevel, Nspace]: dC/dne, or NULL: no collisional term */
+    const double* const* nPrev;    /* [Natoms] -> [Nlevel, Nspace]: previous time step, or NULL: not time dependent */
+    const double* backgroundNe;    /* [Nspace] */
+    double* ne;                    /* [Nspace] in: atmos.ne; out: ne + delta */
+    double dt;                     /* time step (time-dependent form only) */
+    double crsw;                   /* collisional-radiative switching value the Gamma pre-fill used */
+} lwhip_nr_args;
+int lwhip_nr_post_update(lwhip_context* ctx, const lwhip_nr_args* args);
+
 /* Voigt profiles phi and weights wphi of every line, on the device. */
 int lwhip_compute_profiles(lwhip_context* ctx);
 

@@ -93,6 +93,12 @@ class lwhip_prd_result(C.Structure):
                 ('dJPrdMax', f64p), ('dJPrdMaxIdx', i32p)]
 
 
+class lwhip_nr_args(C.Structure):
+    _fields_ = [('Natoms', C.c_int32), ('_pad', C.c_int32), ('atoms', i32p),
+                ('stages', C.POINTER(f64p)), ('dC', C.POINTER(f64p)), ('nPrev', C.POINTER(f64p)),
+                ('backgroundNe', f64p), ('ne', f64p), ('dt', C.c_double), ('crsw', C.c_double)]
+
+
 class lwhip_iter_result(C.Structure):
     _fields_ = [('updatedJ', C.c_int32), ('dJMaxIdx', C.c_int32), ('dJMax', C.c_double)]
 
@@ -117,6 +123,8 @@ SYMBOLS = [
     ('lwhip_stat_equil', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_compute_profiles', C.c_int, [ctx_p]),
     ('lwhip_redistribute_prd', C.c_int, [ctx_p, C.c_int, C.c_double, C.POINTER(lwhip_prd_result)]),
+    ('lwhip_time_dep_update', C.c_int, [ctx_p, C.c_int, f64p, C.c_double]),
+    ('lwhip_nr_post_update', C.c_int, [ctx_p, C.POINTER(lwhip_nr_args)]),
     ('lwhip_synchronize', C.c_int, [ctx_p]),
     ('lwhip_set_stream', C.c_int, [ctx_p, C.c_void_p]),
     ('lwhip_profile_enable', C.c_int, [ctx_p, C.c_int]),
@@ -132,3 +140,25 @@ def bind(lib):
         fn.restype = restype
         fn.argtypes = argtypes
     return lib
+
+
+def make_nr_args(atomIdxs, stages, backgroundNe, ne, dC=None, nPrev=None, dt=0.0, crsw=1.0):
+    """lwhip_nr_args over numpy arrays; returns (struct, keepalive)."""
+    import numpy as np
+    n = len(atomIdxs)
+    idx = np.ascontiguousarray(atomIdxs, dtype=np.int32)
+
+    def ptr_array(arrs):
+        if arrs is None:
+            return None, None
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+        arr = (f64p * n)(*[k.ctypes.data_as(f64p) for k in keep])
+        return arr, keep
+    st, k1 = ptr_array(stages)
+    dc, k2 = ptr_array(dC)
+    pv, k3 = ptr_array(nPrev)
+    bg = np.ascontiguousarray(backgroundNe, dtype=np.float64)
+    assert ne.dtype == np.float64 and ne.flags.c_contiguous
+    args = lwhip_nr_args(n, 0, idx.ctypes.data_as(i32p), st, dc, pv, bg.ctypes.data_as(f64p),
+                         ne.ctypes.data_as(f64p), float(dt), float(crsw))
+    return args, (idx, st, dc, pv, k1, k2, k3, bg, ne)

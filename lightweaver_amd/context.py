@@ -198,6 +198,40 @@ class Context:
 
     redistribute_prd = prd_redistribute
 
+    def time_dep_update(self, dt, prevTimePops, deviceResident=False, atom=None) -> IterationUpdate:
+        """Backward-Euler population update, LwContext.time_dep_update (Source/LwMiddleLayer.pyx:3348-3420
+        drives Source/UpdatePopulations.cpp:120-151 per atom): solve (1 - dt Gamma) n = nOld per depth.
+        prevTimePops: list of [Nlevel, Nspace] arrays, one per active atom (the reference's
+        `prevTimePops`); Gamma must hold the operator of the current iterate."""
+        active = [ia for ia, a in enumerate(self.prob.atoms) if not a.detailed]
+        if not deviceResident:
+            self.upload(abi.GAMMA | abi.POPS)
+        for q, ia in enumerate(active):
+            if atom is not None and ia != atom:
+                continue
+            nOld = np.ascontiguousarray(prevTimePops[q], dtype=np.float64)
+            _check(self.lib, self.lib.lwhip_time_dep_update(self._h, ia, nOld.ctypes.data_as(abi.f64p), float(dt)),
+                   'lwhip_time_dep_update')
+        if not deviceResident:
+            self.download(abi.POPS)
+        return IterationUpdate(updatedPops=True)
+
+    def nr_post_update(self, stages, backgroundNe, ne, dC=None, nPrev=None, dt=0.0, atoms=None,
+                       deviceResident=False) -> IterationUpdate:
+        """One Newton-Raphson charge-conservation step for the listed active atoms, the device part
+        of LwContext._nr_post_update_impl (Source/LwMiddleLayer.pyx:3533-3603 ->
+        Source/UpdatePopulations.cpp:294-394).  `ne` [Nspace] is updated in place; `stages`, `dC`,
+        `nPrev` are per-atom lists (dC / nPrev optional)."""
+        if atoms is None:
+            atoms = [ia for ia, a in enumerate(self.prob.atoms) if not a.detailed]
+        if not deviceResident:
+            self.upload(abi.GAMMA | abi.POPS | abi.COLLISIONS)
+        args, keep = abi.make_nr_args(atoms, stages, backgroundNe, ne, dC=dC, nPrev=nPrev, dt=dt, crsw=self.crsw)
+        _check(self.lib, self.lib.lwhip_nr_post_update(self._h, C.byref(args)), 'lwhip_nr_post_update')
+        if not deviceResident:
+            self.download(abi.POPS)
+        return IterationUpdate(updatedPops=True)
+
     def compute_profiles(self, deviceResident=False):
         _check(self.lib, self.lib.lwhip_compute_profiles(self._h), 'lwhip_compute_profiles')
         if not deviceResident:

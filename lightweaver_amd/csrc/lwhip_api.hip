@@ -110,7 +110,9 @@ struct lwhip_context
     DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
-    DevBuf<double> prdChange, prdOut, rowsBuf;
+    DevBuf<double> prdChange, prdOut, rowsBuf, popScratch;
+    DevBuf<NrAtom> nrAtoms;
+    DevBuf<int32_t> transType;
     DevBuf<int32_t> contLa;
     DevBuf<int32_t> prdChangeIdx;
     double* prdPinned = nullptr;
@@ -1483,6 +1485,144 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
     }
     int32_t st = 0;
     HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st == LWHIP_ERR_SINGULAR)
+        return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+    return LWHIP_OK;
+}
+
+int lwhip_time_dep_update(lwhip_context* c, int atom, const double* nOld, double dt)
+{
+    if (!c || !nOld)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    if (atom < 0 || atom >= c->Natom || c->atoms[atom].detailed)
+        return fail(LWHIP_ERR_INVALID, "time_dep_update: not an active atom");
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int stp = flush_prefill(c);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
+    const lwhip_atom& a = c->atoms[atom];
+    const size_t cnt = (size_t)a.Nlevel * c->Ns;
+    if (c->popScratch.n < cnt)
+        HIP_TRY(c->popScratch.alloc(cnt));
+    HIP_TRY(hipMemcpyAsync(c->popScratch.p, nOld, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(launch_time_dep(a.Nlevel, c->Ns, c->n.p + (size_t)c->levelOff[atom] * c->Ns, c->popScratch.p,
+                            c->Gamma.p + c->gammaOff[atom], dt, c->status.p, c->stream));
+    int32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st == LWHIP_ERR_SINGULAR)
+        return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+    return LWHIP_OK;
+}
+
+int lwhip_nr_post_update(lwhip_context* c, const lwhip_nr_args* args)
+{
+    if (!c || !args || !args->atoms || !args->stages || !args->backgroundNe || !args->ne || args->Natoms <= 0)
+        return fail(LWHIP_ERR_INVALID, "nr_post_update: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int stp = flush_prefill(c);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
+    const size_t Ns = c->Ns;
+    std::vector<NrAtom> atoms(args->Natoms);
+    int eq = 0;
+    int64_t dcRows = 0;
+    for (int q = 0; q < args->Natoms; ++q)
+    {
+        const int ia = args->atoms[q];
+        if (ia < 0 || ia >= c->Natom || c->atoms[ia].detailed)
+            return fail(LWHIP_ERR_INVALID, "nr_post_update: not an active atom");
+        if (!c->atoms[ia].C)
+            return fail(LWHIP_ERR_INVALID, "nr_post_update needs the collisional rates C of every listed atom");
+        NrAtom& at = atoms[q];
+        at.atom = ia;
+        at.Nlevel = c->atoms[ia].Nlevel;
+        at.levelOff = c->levelOff[ia];
+        at.eqOff = eq;
+        at.trBegin = c->atomTrOff[ia];
+        at.trEnd = c->atomTrOff[ia + 1];
+        at.gammaOff = c->gammaOff[ia];
+        at.dcOff = dcRows;
+        eq += at.Nlevel;
+        dcRows += (int64_t)at.Nlevel * at.Nlevel;
+    }
+    const int Neqn = eq + 1;
+    if (Neqn > 64)
+        return fail(LWHIP_ERR_UNSUPPORTED, "nr_post_update: more than 63 coupled levels");
+    // scratch: [stages eq] [ne Ns] [bgNe Ns] [nPrev eq*Ns] [dC dcRows*Ns]
+    const bool timeDep = args->nPrev != nullptr;
+    const bool fdC = args->dC != nullptr;
+    const size_t need = (size_t)eq + 2 * Ns + (timeDep ? (size_t)eq * Ns : 0) + (fdC ? (size_t)dcRows * Ns : 0);
+    if (c->popScratch.n < need)
+        HIP_TRY(c->popScratch.alloc(need));
+    if (c->nrAtoms.n < atoms.size())
+        HIP_TRY(c->nrAtoms.alloc(atoms.size()));
+    HIP_TRY(hipMemcpyAsync(c->nrAtoms.p, atoms.data(), atoms.size() * sizeof(NrAtom), hipMemcpyHostToDevice, c->stream));
+    double* dStages = c->popScratch.p;
+    double* dNe = dStages + eq;
+    double* dBg = dNe + Ns;
+    double* dPrev = dBg + Ns;
+    double* dDC = dPrev + (timeDep ? (size_t)eq * Ns : 0);
+    for (int q = 0; q < args->Natoms; ++q)
+    {
+        const NrAtom& at = atoms[q];
+        if (!args->stages[q])
+            return fail(LWHIP_ERR_INVALID, "nr_post_update: null stages");
+        H2D(dStages + at.eqOff, args->stages[q], at.Nlevel);
+        if (timeDep)
+        {
+            if (!args->nPrev[q])
+                return fail(LWHIP_ERR_INVALID, "nr_post_update: null nPrev");
+            H2D(dPrev + (size_t)at.eqOff * Ns, args->nPrev[q], (size_t)at.Nlevel * Ns);
+        }
+        if (fdC)
+        {
+            if (!args->dC[q])
+                return fail(LWHIP_ERR_INVALID, "nr_post_update: null dC");
+            H2D(dDC + (size_t)at.dcOff * Ns, args->dC[q], (size_t)at.Nlevel * at.Nlevel * Ns);
+        }
+    }
+    H2D(dNe, args->ne, Ns);
+    H2D(dBg, args->backgroundNe, Ns);
+    if (c->transType.n < (size_t)std::max(c->Ntrans, 1))
+    {
+        std::vector<int32_t> tt((size_t)std::max(c->Ntrans, 1), 0);
+        for (int tr = 0; tr < c->Ntrans; ++tr)
+            tt[tr] = c->trans[tr].t.type;
+        HIP_TRY(c->transType.upload(tt));
+    }
+    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+    NrArgs a{};
+    a.Ns = (int32_t)Ns;
+    a.Natoms = args->Natoms;
+    a.Neqn = Neqn;
+    a.timeDep = timeDep ? 1 : 0;
+    a.atoms = c->nrAtoms.p;
+    a.Gamma = c->Gamma.p;
+    a.Cmat = c->Cmat.p;
+    a.n = c->n.p;
+    a.nTotal = c->nTotal.p;
+    a.stages = dStages;
+    a.nPrev = timeDep ? dPrev : nullptr;
+    a.dC = fdC ? dDC : nullptr;
+    a.backgroundNe = dBg;
+    a.ne = dNe;
+    a.transType = c->transType.p;
+    a.transLi = c->transLi.p;
+    a.transLj = c->transLj.p;
+    a.dt = args->dt;
+    a.crsw = args->crsw;
+    a.status = c->status.p;
+    HIP_TRY(launch_nr_post(a, c->stream));
+    int32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    D2H(args->ne, dNe, Ns);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (st == LWHIP_ERR_SINGULAR)
         return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");

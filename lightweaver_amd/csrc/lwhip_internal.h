@@ -234,6 +234,40 @@ struct PrdLineArgs
 };
 hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t stream);
 
+// nr_post_update (lwhip_pops.hip): one listed atom, and the launch arguments
+struct NrAtom
+{
+    int32_t atom;       // index into the context's atoms
+    int32_t Nlevel;
+    int32_t levelOff;   // first row in the n pool
+    int32_t eqOff;      // first equation (= offset into stages / nPrev rows)
+    int32_t trBegin, trEnd;
+    int64_t gammaOff;   // offset into the Gamma / C pools
+    int64_t dcOff;      // offset (rows of Ns) into the dC scratch
+};
+struct NrArgs
+{
+    int32_t Ns, Natoms, Neqn, timeDep;
+    const NrAtom* atoms;
+    const double* Gamma;
+    const double* Cmat;
+    double* n;
+    const double* nTotal;       // [Natom, Ns]
+    const double* stages;       // [sum Nlevel]
+    const double* nPrev;        // [sum Nlevel, Ns] (time dependent)
+    const double* dC;           // per atom [Nlevel, Nlevel, Ns] back to back, or null
+    const double* backgroundNe; // [Ns]
+    double* ne;                 // [Ns]
+    const int32_t* transType;   // [Ntrans]
+    const int32_t* transLi;
+    const int32_t* transLj;
+    double dt, crsw;
+    int32_t* status;
+};
+hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream);
+hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
+                           int* status, hipStream_t stream);
+
 // launch helpers implemented in lwhip_kernels.hip
 size_t sweep_lds_bytes(const SweepArgs& a, int G);
 size_t sweep_big_scratch_doubles(const SweepArgs& a);

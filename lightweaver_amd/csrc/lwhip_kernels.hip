@@ -1303,151 +1303,4 @@ hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n,
     return hipGetLastError();
 }
 
-// ---- stat_eq: one thread per depth point; Crout LU with implicit scaling + one refinement pass
-// (UpdatePopulations.cpp:7-47, LuSolve.cpp:8-132).  Nlevel <= MAXN, matrix in registers/scratch. -----------
-template <int MAXN>
-__global__ void stat_eq_kernel(int N, int Ns, double* n, const double* nTotal, const double* Gamma,
-                               int* status)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Ns)
-        return;
-    double A[MAXN * MAXN], A0[MAXN * MAXN], bvec[MAXN], b0[MAXN], res[MAXN], vv[MAXN];
-    int index[MAXN];
-    // Gamma_k and the elimination row
-    int iElim = 0;
-    double nMax = 0.0;
-    for (int i = 0; i < N; ++i)
-    {
-        const double ni = n[(size_t)i * Ns + k];
-        if (nMax < ni)
-        {
-            iElim = i;
-            nMax = ni;
-        }
-        for (int j = 0; j < N; ++j)
-            A[i * MAXN + j] = Gamma[((size_t)i * N + j) * Ns + k];
-    }
-    for (int i = 0; i < N; ++i)
-    {
-        A[iElim * MAXN + i] = 1.0;
-        bvec[i] = 0.0;
-    }
-    bvec[iElim] = nTotal[k];
-    for (int i = 0; i < N; ++i)
-    {
-        b0[i] = bvec[i];
-        for (int j = 0; j < N; ++j)
-            A0[i * MAXN + j] = A[i * MAXN + j];
-    }
-    // lu_decompose
-    bool singular = false;
-    for (int i = 0; i < N; ++i)
-    {
-        double big = 0.0;
-        for (int j = 0; j < N; ++j)
-            big = fmax(big, fabs(A[i * MAXN + j]));
-        if (big == 0.0)
-            singular = true;
-        vv[i] = 1.0 / big;
-    }
-    if (singular)
-    {
-        atomicExch(status, LWHIP_ERR_SINGULAR);
-        return;
-    }
-    for (int j = 0; j < N; ++j)
-    {
-        for (int i = 0; i < j; ++i)
-        {
-            double sum = A[i * MAXN + j];
-            for (int q = 0; q < i; ++q)
-                sum -= A[i * MAXN + q] * A[q * MAXN + j];
-            A[i * MAXN + j] = sum;
-        }
-        int iMax = 0;
-        double big = 0.0;
-        for (int i = j; i < N; ++i)
-        {
-            double sum = A[i * MAXN + j];
-            for (int q = 0; q < j; ++q)
-                sum -= A[i * MAXN + q] * A[q * MAXN + j];
-            A[i * MAXN + j] = sum;
-            const double cand = vv[i] * fabs(sum);
-            if (big < cand)
-            {
-                iMax = i;
-                big = cand;
-            }
-        }
-        if (j != iMax)
-        {
-            for (int q = 0; q < N; ++q)
-            {
-                const double tmp = A[iMax * MAXN + q];
-                A[iMax * MAXN + q] = A[j * MAXN + q];
-                A[j * MAXN + q] = tmp;
-            }
-            vv[iMax] = vv[j];
-        }
-        index[j] = iMax;
-        if (A[j * MAXN + j] == 0.0)
-            A[j * MAXN + j] = 1e-20;
-        const double tmp = 1.0 / A[j * MAXN + j];
-        for (int i = j + 1; i < N; ++i)
-            A[i * MAXN + j] *= tmp;
-    }
-    auto backsub = [&](double* b) {
-        int ii = -1;
-        for (int i = 0; i < N; ++i)
-        {
-            const int ip = index[i];
-            double sum = b[ip];
-            b[ip] = b[i];
-            if (ii >= 0)
-            {
-                for (int j = ii; j < i; ++j)
-                    sum -= A[i * MAXN + j] * b[j];
-            }
-            else if (sum != 0.0)
-            {
-                ii = i;
-            }
-            b[i] = sum;
-        }
-        for (int i = N - 1; i >= 0; --i)
-        {
-            double sum = b[i];
-            for (int j = i + 1; j < N; ++j)
-                sum -= A[i * MAXN + j] * b[j];
-            b[i] = sum / A[i * MAXN + i];
-        }
-    };
-    backsub(bvec);
-    for (int i = 0; i < N; ++i)
-    {
-        double r = b0[i];
-        for (int j = 0; j < N; ++j)
-            r -= A0[i * MAXN + j] * bvec[j];
-        res[i] = r;
-    }
-    backsub(res);
-    for (int i = 0; i < N; ++i)
-        n[(size_t)i * Ns + k] = bvec[i] + res[i];
-}
-
-hipError_t launch_stat_eq(int Nlevel, int Ns, double* n, const double* nTotal, const double* Gamma,
-                          int* status, hipStream_t stream)
-{
-    const int blocks = (Ns + 63) / 64;
-    if (Nlevel <= 8)
-        hipLaunchKernelGGL(stat_eq_kernel<8>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nTotal, Gamma, status);
-    else if (Nlevel <= 16)
-        hipLaunchKernelGGL(stat_eq_kernel<16>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nTotal, Gamma, status);
-    else if (Nlevel <= 32)
-        hipLaunchKernelGGL(stat_eq_kernel<32>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nTotal, Gamma, status);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
-}
 }

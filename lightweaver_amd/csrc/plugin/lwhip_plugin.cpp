@@ -18,6 +18,7 @@
 #include "lwhip.h"
 
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -374,6 +375,84 @@ void stat_eq_hip(Atom* atom, ExtraParams params, int spaceStart, int spaceEnd)
         fail("lwhip_download");
 }
 
+// time_dep_update: replaces time_dependent_update_impl (Source/UpdatePopulations.cpp:120-151)
+void time_dep_update_hip(Atom* atom, F64View2D nOld, f64 dt, ExtraParams params, int spaceStart, int spaceEnd)
+{
+    Context* ctx = nullptr;
+    int idx = -1;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        auto it = g_atomOwner.find(atom);
+        if (it != g_atomOwner.end())
+        {
+            ctx = it->second.first;
+            idx = it->second.second;
+        }
+    }
+    const int Nspace = (int)atom->n.shape(1);
+    const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
+    if (!ctx || !whole)
+        throw std::runtime_error("lwhip plugin: time_dep_update needs an atom of a live Context and the full depth range");
+    sync_state(*ctx, false);
+    auto* st = (PluginState*)ctx->methodScratch;
+    if (lwhip_upload(st->hip, LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
+        fail("lwhip_upload");
+    const int rc = lwhip_time_dep_update(st->hip, idx, nOld.data, dt);
+    if (rc == LWHIP_ERR_SINGULAR)
+        throw std::runtime_error("Singular Matrix");
+    if (rc != LWHIP_OK)
+        fail("lwhip_time_dep_update");
+    if (lwhip_download(st->hip, LWHIP_POPS) != LWHIP_OK)
+        fail("lwhip_download");
+}
+
+// nr_post_update: replaces nr_post_update_impl (Source/UpdatePopulations.cpp:294-394)
+void nr_post_update_hip(Context& ctx, std::vector<Atom*>* atoms, const std::vector<F64View3D>& dC,
+                        F64View backgroundNe, const NrTimeDependentData& timeDepData, f64 crswVal,
+                        ExtraParams params, int spaceStart, int spaceEnd)
+{
+    const int Nspace = ctx.atmos->Nspace;
+    const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
+    if (!whole)
+        throw std::runtime_error("lwhip plugin: nr_post_update needs the full depth range");
+    sync_state(ctx, force_upload(params));
+    auto* st = (PluginState*)ctx.methodScratch;
+    if (lwhip_upload(st->hip, LWHIP_GAMMA | LWHIP_POPS | LWHIP_COLLISIONS) != LWHIP_OK)
+        fail("lwhip_upload");
+    const int n = (int)atoms->size();
+    std::vector<int32_t> idx(n);
+    std::vector<const double*> stages(n), dCp(n), prev(n);
+    for (int q = 0; q < n; ++q)
+    {
+        auto pos = std::find(ctx.activeAtoms.begin(), ctx.activeAtoms.end(), (*atoms)[q]);
+        if (pos == ctx.activeAtoms.end())
+            throw std::runtime_error("lwhip plugin: nr_post_update atom is not an active atom of this Context");
+        idx[q] = (int32_t)(pos - ctx.activeAtoms.begin());
+        stages[q] = (*atoms)[q]->stages.data;
+        if (!dC.empty())
+            dCp[q] = dC[q].data;
+        if (!timeDepData.nPrev.empty())
+            prev[q] = timeDepData.nPrev[q].data;
+    }
+    lwhip_nr_args a{};
+    a.Natoms = n;
+    a.atoms = idx.data();
+    a.stages = stages.data();
+    a.dC = dC.empty() ? nullptr : dCp.data();
+    a.nPrev = timeDepData.nPrev.empty() ? nullptr : prev.data();
+    a.backgroundNe = backgroundNe.data;
+    a.ne = ctx.atmos->ne.data;
+    a.dt = timeDepData.dt;
+    a.crsw = crswVal;
+    const int rc = lwhip_nr_post_update(st->hip, &a);
+    if (rc == LWHIP_ERR_SINGULAR)
+        throw std::runtime_error("Singular Matrix");
+    if (rc != LWHIP_OK)
+        fail("lwhip_nr_post_update");
+    if (lwhip_download(st->hip, LWHIP_POPS) != LWHIP_OK)
+        fail("lwhip_download");
+}
+
 // redistribute_prd: replaces redistribute_prd_lines_template<SimdType> (Source/PrdTemplates.hpp:175-290)
 IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraParams params)
 {
@@ -443,8 +522,8 @@ FsIterationFns fs_iteration_fns_provider()
         formal_sol_full_stokes_impl,      // not accelerated: the core's own (final synthesis only)
         redistribute_prd_hip,
         stat_eq_hip,
-        time_dependent_update_impl,       // not accelerated yet: the core's own
-        nr_post_update_impl,              // not accelerated yet: the core's own
+        time_dep_update_hip,
+        nr_post_update_hip,
         nullptr, nullptr, nullptr, nullptr,
         alloc_global_scratch_hip,
         free_global_scratch_hip,

@@ -108,6 +108,8 @@ class RefContext(_Handle):
             lib.lwref_stat_equil.argtypes = [C.c_void_p, C.c_int]
             lib.lwref_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
                                                    abi.f64p, abi.i32p, abi.f64p, abi.i32p]
+            lib.lwref_time_dep_update.argtypes = [C.c_void_p, C.c_int, abi.f64p, C.c_double]
+            lib.lwref_nr_post_update.argtypes = [C.c_void_p, C.POINTER(abi.lwhip_nr_args)]
             lib.lwref_GII.restype = C.c_double
             lib.lwref_GII.argtypes = [C.c_double] * 3
             lib.lwref_w2.argtypes = [C.c_double, abi.f64p]
@@ -159,6 +161,15 @@ class RefContext(_Handle):
     def redistribute_prd(self, maxIter=3, tol=1e-2):
         return _redistribute(self.lib.lwref_redistribute_prd, self.h, maxIter, tol)
 
+    def time_dep_update(self, atom, nOld, dt):
+        import numpy as np
+        nOld = np.ascontiguousarray(nOld, dtype=np.float64)
+        return self.lib.lwref_time_dep_update(self.h, atom, nOld.ctypes.data_as(abi.f64p), dt)
+
+    def nr_post_update(self, atoms, stages, backgroundNe, ne, dC=None, nPrev=None, dt=0.0, crsw=1.0):
+        args, keep = abi.make_nr_args(atoms, stages, backgroundNe, ne, dC=dC, nPrev=nPrev, dt=dt, crsw=crsw)
+        return self.lib.lwref_nr_post_update(self.h, C.byref(args))
+
 
 class OracleContext(_Handle):
     """The plain-C restatement driving `prob`."""
@@ -182,6 +193,8 @@ class OracleContext(_Handle):
             lib.lworacle_stat_equil.argtypes = [C.c_void_p, C.c_int]
             lib.lworacle_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
                                                       abi.f64p, abi.i32p, abi.f64p, abi.i32p]
+            lib.lworacle_time_dep_update.argtypes = [C.c_void_p, C.c_int, abi.f64p, C.c_double]
+            lib.lworacle_nr_post_update.argtypes = [C.c_void_p, C.POINTER(abi.lwhip_nr_args)]
             lib.lworacle_GII.restype = C.c_double
             lib.lworacle_GII.argtypes = [C.c_double] * 3
             lib.lworacle_w2.argtypes = [C.c_double, abi.f64p]
@@ -232,3 +245,12 @@ class OracleContext(_Handle):
 
     def redistribute_prd(self, maxIter=3, tol=1e-2):
         return _redistribute(self.lib.lworacle_redistribute_prd, self.h, maxIter, tol)
+
+    def time_dep_update(self, atom, nOld, dt):
+        import numpy as np
+        nOld = np.ascontiguousarray(nOld, dtype=np.float64)
+        return self.lib.lworacle_time_dep_update(self.h, atom, nOld.ctypes.data_as(abi.f64p), dt)
+
+    def nr_post_update(self, atoms, stages, backgroundNe, ne, dC=None, nPrev=None, dt=0.0, crsw=1.0):
+        args, keep = abi.make_nr_args(atoms, stages, backgroundNe, ne, dC=dC, nPrev=nPrev, dt=dt, crsw=crsw)
+        return self.lib.lworacle_nr_post_update(self.h, C.byref(args))

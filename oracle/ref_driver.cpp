@@ -378,6 +378,55 @@ int lwref_stat_equil(void* h, int atomIdx)
     return LWHIP_OK;
 }
 
+// time_dependent_update (Source/UpdatePopulations.cpp:153-157 -> iterFns.time_dep_update)
+int lwref_time_dep_update(void* h, int atomIdx, const double* nOld, double dt)
+{
+    auto* rc = (RefContext*)h;
+    try
+    {
+        Atom* atom = rc->atoms[atomIdx].get();
+        F64View2D nOldView(const_cast<double*>(nOld), atom->Nlevel, rc->prob->Nspace);
+        time_dependent_update(rc->ctx, atom, nOldView, dt);
+    }
+    catch (const std::runtime_error& e)
+    {
+        return LWHIP_ERR_SINGULAR;
+    }
+    return LWHIP_OK;
+}
+
+// nr_post_update (Source/UpdatePopulations.cpp:473-483 -> iterFns.nr_post_update)
+int lwref_nr_post_update(void* h, const lwhip_nr_args* a)
+{
+    auto* rc = (RefContext*)h;
+    const int Ns = rc->prob->Nspace;
+    try
+    {
+        std::vector<Atom*> atoms;
+        std::vector<F64View3D> dC;
+        NrTimeDependentData td;
+        td.dt = a->dt;
+        for (int q = 0; q < a->Natoms; ++q)
+        {
+            Atom* atom = rc->atoms[a->atoms[q]].get();
+            atom->stages = F64View1D(const_cast<double*>(a->stages[q]), atom->Nlevel);
+            atoms.push_back(atom);
+            if (a->dC)
+                dC.emplace_back(const_cast<double*>(a->dC[q]), atom->Nlevel, atom->Nlevel, Ns);
+            if (a->nPrev)
+                td.nPrev.emplace_back(const_cast<double*>(a->nPrev[q]), atom->Nlevel, Ns);
+        }
+        rc->atmos.ne = F64View(a->ne, Ns);
+        F64View bgNe(const_cast<double*>(a->backgroundNe), Ns);
+        nr_post_update(rc->ctx, &atoms, dC, bgNe, td, a->crsw);
+    }
+    catch (const std::runtime_error& e)
+    {
+        return LWHIP_ERR_SINGULAR;
+    }
+    return LWHIP_OK;
+}
+
 // redistribute_prd_lines (Source/Prd.cpp:648-653 -> PrdTemplates.hpp:175-351)
 int lwref_redistribute_prd(void* h, int maxIter, double tol, int* NprdSubIter, int* NprdOut,
                            double* dRho, int* dRhoMaxIdx, double* dJPrdMax, int* dJPrdMaxIdx)

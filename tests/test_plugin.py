@@ -144,3 +144,33 @@ def test_dropin_prd_redistribute(gpu):
         assert np.allclose(u1['dRho'], u2['dRho'], rtol=1e-5)
         assert np.allclose(u1['dJPrdMax'], u2['dJPrdMax'], rtol=1e-7)
     assert_same_state(p, q, 1e-8)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_time_dep_and_nr_updates(gpu):
+    """FsIterationFns::time_dep_update / nr_post_update of the plugin through the real core's
+    trampolines (Source/UpdatePopulations.cpp:153-157, 473-483), next to the core's own."""
+    from test_pops import active, nr_inputs
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = variant_problem(base, d, 'iter1'), variant_problem(base, d, 'iter1')
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for pr, c in ((p, hipc), (q, ref)):
+        pr.gamma_prefill()
+        c.formal_sol_gamma_matrices()
+    # identical operators for the two solves (the formal solutions agree to 1e-10, the solves
+    # amplify that; the formal solution itself is compared in the tests above)
+    for x, y in zip(p.atoms, q.atoms):
+        x.Gamma[...] = y.Gamma
+    prev = [a.n.copy() for a in q.atoms]
+    for ia in active(p):
+        assert hipc.time_dep_update(ia, prev[ia], 0.1) == 0
+        assert ref.time_dep_update(ia, prev[ia], 0.1) == 0
+        assert rel_err(p.atoms[ia].n, q.atoms[ia].n) <= 1e-9
+    stages, bg, ne, dC = nr_inputs(q)
+    ne2 = ne.copy()
+    assert hipc.nr_post_update(active(p), stages, bg, ne, dC=dC, crsw=1.0) == 0
+    assert ref.nr_post_update(active(q), stages, bg, ne2, dC=dC, crsw=1.0) == 0
+    assert rel_err(ne, ne2) <= 1e-9
+    for x, y in zip(p.atoms, q.atoms):
+        assert rel_err(x.n, y.n) <= 1e-9
