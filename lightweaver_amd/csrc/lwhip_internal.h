@@ -280,8 +280,6 @@ hipError_t launch_march(const SweepArgs* devArgs, const SweepArgs& hostArgs, con
 size_t march_lds_bytes(const SweepArgs& a, int wavesPerGroup);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream);
-hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2,
-                        hipStream_t stream);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
 hipError_t launch_stat_eq(int Nlevel, int Ns, double* n, const double* nTotal, const double* Gamma,
                           int* status, hipStream_t stream);

@@ -1242,53 +1242,6 @@ hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-// ---- dJMax and the index of its first occurrence (max_idx, Constants.hpp:114-125) ---------------------------
-__global__ void djmax_kernel(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2)
-{
-    __shared__ double sV[1024];
-    __shared__ int sI[1024];
-    double best = -1.0;
-    int bi = 0;
-    for (int la = laStart + threadIdx.x; la < laEnd; la += blockDim.x)
-    {
-        const double v = dJ[la];
-        if (v > best)
-        {
-            best = v;
-            bi = la;
-        }
-    }
-    sV[threadIdx.x] = best;
-    sI[threadIdx.x] = bi;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1)
-    {
-        if (threadIdx.x < s)
-        {
-            const double v = sV[threadIdx.x + s];
-            const int i = sI[threadIdx.x + s];
-            if (v > sV[threadIdx.x] || (v == sV[threadIdx.x] && i < sI[threadIdx.x]))
-            {
-                sV[threadIdx.x] = v;
-                sI[threadIdx.x] = i;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-    {
-        out2[0] = sV[0] < 0.0 ? 0.0 : sV[0];
-        out2[1] = (double)(sI[0] + idxOffset);
-    }
-}
-
-hipError_t launch_djmax(const double* dJ, int laStart, int laEnd, int idxOffset, double* out2,
-                        hipStream_t stream)
-{
-    hipLaunchKernelGGL(djmax_kernel, dim3(1), dim3(1024), 0, stream, dJ, laStart, laEnd, idxOffset, out2);
-    return hipGetLastError();
-}
-
 // ---- Gamma <- crsw * C (LwMiddleLayer.pyx:3198-3203) ------------------------------------------------------------
 __global__ void prefill_kernel(double* G, const double* C, double crsw, size_t n)
 {
