@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--nlambda', type=int, default=10240, help='wavelengths per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--aux', action='store_true',
+                    help='also time the PRD sub-iterations on the PRD variant of the workload (not part of the metric)')
     return ap.parse_args()
 
 
@@ -149,6 +151,31 @@ def main():
     ctx.profile_enable(False)
     alg_bytes = ctx.algorithmic_bytes()
 
+    # not part of the metric ("report stat_eq time separately"): the population solve
+    aux = {}
+    if world == 1:
+        ctx.stat_equil(deviceResident=True)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(20):
+            ctx.stat_equil(deviceResident=True)
+        torch.cuda.synchronize()
+        aux['stat_eq_ms'] = 1e3 * (time.perf_counter() - ta) / 20
+        if args.aux:
+            pp = models.throughput_grid(NlambdaTarget=args.nlambda, Nrays=5, prd=True)
+            with Context(pp, device=local_rank, stream=stream.cuda_stream) as pc:
+                for _ in range(3):
+                    pc.formal_sol_gamma_matrices(deviceResident=True)
+                pc.prd_redistribute(3, 0.0, deviceResident=True)
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(5):
+                    upd = pc.prd_redistribute(3, 0.0, deviceResident=True)
+                torch.cuda.synchronize()
+                aux['prd_ms_per_subiter'] = 1e3 * (time.perf_counter() - ta) / (5 * 3)
+                aux['prd_lines'] = int(upd.dRho.shape[1])
+                aux['prd_Nlambda'] = pp.Nlambda
+
     if rank == 0:
         value = world * args.steps / elapsed
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
@@ -190,6 +217,8 @@ def main():
                 'launches_timed': nlaunch,
             },
         }
+        if aux:
+            out['aux'] = aux
         if world == 1 and not args.no_cpu_baseline:
             try:
                 single = prob if prob.Nlambda == args.nlambda else models.throughput_grid(args.nlambda, 5)

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -95,7 +96,7 @@ struct lwhip_context
     int worldSize = 1, worldRank = 0;
     int laStart = 0, laEnd = 0, Nla = 0;
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
-    int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, G = 1;
+    int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, nChunksPrd = 0, G = 1;
     bool big = false;
     bool march = true;            // wavefront-autonomous sweep (lwhip_march.hip); false: the LDS-column sweep
     int marchD = 7, marchS = 12, marchWaves = 4;
@@ -110,7 +111,9 @@ struct lwhip_context
     DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
-    DevBuf<double> prdChange, prdOut, rowsBuf, popScratch;
+    DevBuf<double> prdChange, prdOut, rowsBuf, popScratch, prdJt;
+    std::vector<std::unique_ptr<DevBuf<double>>> gII; // per transition: cached PRD weights (lazily)
+    std::vector<char> gIIValid;
     DevBuf<NrAtom> nrAtoms;
     DevBuf<int32_t> transType;
     DevBuf<int32_t> contLa;
@@ -118,12 +121,13 @@ struct lwhip_context
     double* prdPinned = nullptr;
     DevBuf<DevTrans> dtrans;
     DevBuf<DevLaHeader> laHdr;
-    DevBuf<DevSlot> slots;
+    DevBuf<DevSlot> slots, slotsPrd;
     DevBuf<DevProgram> progs;
     DevBuf<DevProgRow> progRows;
     DevBuf<DevProgEnt> progEnts;
-    DevBuf<SweepArgs> dargs;
-    SweepArgs hargs{};
+    DevBuf<SweepArgs> dargs, dargsPrd;
+    SweepArgs hargs{}, hargsPrd{};
+    DevBuf<int32_t> chunkLaPrd, trOffPrd, trRowPrd, laListPrd;
     DevBuf<int32_t> chunkLa, trOff, trRow, atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
     DevBuf<int64_t> atomGammaOff;
     DevBuf<double> partial, red, red8, dJ;
@@ -594,66 +598,108 @@ int build_tables(lwhip_context* c)
     int target = env_int("LWHIP_CHUNKS", numCU * 2);
     target = std::max(1, std::min(target, c->Nla));
     std::vector<double> cost(c->Nla);
-    double total = 0.0;
+    bool anyPrd = false;
     for (int la = 0; la < c->Nla; ++la)
     {
         // fitted to per-chunk cycle counts of the stamped build (tools/stamps.py, LWHIP_DUMP_CHUNKS)
         cost[la] = 1.0 + 0.243 * hdr[la].nLine + 0.089 * hdr[la].nMixed + 0.026 * hdr[la].nPure;
-        total += cost[la];
+        anyPrd = anyPrd || hdr[la].hasPrd;
     }
-    std::vector<int32_t> chunkLa;
-    chunkLa.push_back(0);
+    // A chunking = wavelength boundaries + the accumulator slot of every slot record inside its chunk.
+    // The full sweep balances all wavelengths; the PRD rates pass visits only wavelengths with a PRD
+    // line, so it gets its own chunking balanced over those (same kernels, second table set).
+    struct Chunking
     {
+        std::vector<int32_t> chunkLa, cs;
+        std::vector<std::vector<int>> chunkTrans;
+        int maxCT = 1;
+    };
+    // `las`: the wavelengths the launch visits, in order; chunk boundaries index into it
+    auto make_chunking = [&](const std::vector<int32_t>& las) {
+        Chunking ck;
+        const int Nl = (int)las.size();
+        const int tgt = std::max(1, std::min(target, Nl));
+        double total = 0.0;
+        for (int la : las)
+            total += cost[la];
+        ck.chunkLa.push_back(0);
         double acc = 0.0;
         int made = 0;
-        for (int la = 0; la < c->Nla; ++la)
+        for (int li = 0; li < Nl; ++li)
         {
-            acc += cost[la];
-            const int remainingLa = c->Nla - (la + 1);
-            const int remainingChunks = target - (made + 1);
-            if ((acc >= total * (made + 1) / target || remainingLa <= remainingChunks) && la + 1 < c->Nla
-                && made + 1 < target)
+            acc += cost[las[li]];
+            const int remainingLa = Nl - (li + 1);
+            const int remainingChunks = tgt - (made + 1);
+            if ((acc >= total * (made + 1) / tgt || remainingLa <= remainingChunks) && li + 1 < Nl && made + 1 < tgt)
             {
-                chunkLa.push_back(la + 1);
+                ck.chunkLa.push_back(li + 1);
                 made++;
             }
         }
-        chunkLa.push_back(c->Nla);
-    }
-    c->nChunks = (int)chunkLa.size() - 1;
-
-    // accumulator slots per chunk
-    std::vector<std::vector<int>> chunkTrans(c->nChunks);
-    c->maxCT = 1;
-    for (int ch = 0; ch < c->nChunks; ++ch)
-    {
-        std::vector<int> slotOf(c->Ntrans, -1);
-        for (int la = chunkLa[ch]; la < chunkLa[ch + 1]; ++la)
+        ck.chunkLa.push_back(Nl);
+        const int nch = (int)ck.chunkLa.size() - 1;
+        ck.chunkTrans.resize(nch);
+        ck.cs.assign(slots.size(), 0);
+        for (int ch = 0; ch < nch; ++ch)
         {
-            const int n = hdr[la].nLine + hdr[la].nMixed + hdr[la].nPure;
-            for (int e = 0; e < n; ++e)
+            std::vector<int> slotOf(c->Ntrans, -1);
+            for (int li = ck.chunkLa[ch]; li < ck.chunkLa[ch + 1]; ++li)
             {
-                const int tr = slotTr[hdr[la].off + e];
-                if (slotOf[tr] < 0)
+                const int la = las[li];
+                const int n = hdr[la].nLine + hdr[la].nMixed + hdr[la].nPure;
+                for (int e = 0; e < n; ++e)
                 {
-                    slotOf[tr] = (int)chunkTrans[ch].size();
-                    chunkTrans[ch].push_back(tr);
+                    const int tr = slotTr[hdr[la].off + e];
+                    if (slotOf[tr] < 0)
+                    {
+                        slotOf[tr] = (int)ck.chunkTrans[ch].size();
+                        ck.chunkTrans[ch].push_back(tr);
+                    }
+                    ck.cs[hdr[la].off + e] = slotOf[tr];
                 }
-                slots[hdr[la].off + e].cs = slotOf[tr];
             }
+            ck.maxCT = std::max(ck.maxCT, (int)ck.chunkTrans[ch].size());
         }
-        c->maxCT = std::max(c->maxCT, (int)chunkTrans[ch].size());
-    }
-    std::vector<int32_t> trOff(c->Ntrans + 1, 0), trRow;
-    for (int tr = 0; tr < c->Ntrans; ++tr)
+        return ck;
+    };
+    auto make_rows = [&](const Chunking& ck, int maxCT, std::vector<int32_t>& trOff, std::vector<int32_t>& trRow) {
+        trOff.assign(c->Ntrans + 1, 0);
+        trRow.clear();
+        for (int tr = 0; tr < c->Ntrans; ++tr)
+        {
+            trOff[tr] = (int32_t)trRow.size();
+            for (int ch = 0; ch < (int)ck.chunkTrans.size(); ++ch)
+                for (int s = 0; s < (int)ck.chunkTrans[ch].size(); ++s)
+                    if (ck.chunkTrans[ch][s] == tr)
+                        trRow.push_back(ch * maxCT + s);
+        }
+        trOff[c->Ntrans] = (int32_t)trRow.size();
+    };
+    std::vector<int32_t> lasAll(c->Nla), lasPrd;
+    for (int la = 0; la < c->Nla; ++la)
     {
-        trOff[tr] = (int32_t)trRow.size();
-        for (int ch = 0; ch < c->nChunks; ++ch)
-            for (int s = 0; s < (int)chunkTrans[ch].size(); ++s)
-                if (chunkTrans[ch][s] == tr)
-                    trRow.push_back(ch * c->maxCT + s);
+        lasAll[la] = la;
+        if (hdr[la].hasPrd)
+            lasPrd.push_back(la);
     }
-    trOff[c->Ntrans] = (int32_t)trRow.size();
+    const Chunking full = make_chunking(lasAll);
+    const Chunking prdCk = anyPrd ? make_chunking(lasPrd) : Chunking{};
+    const std::vector<int32_t>& chunkLa = full.chunkLa;
+    c->nChunks = (int)full.chunkLa.size() - 1;
+    c->nChunksPrd = anyPrd ? (int)prdCk.chunkLa.size() - 1 : 0;
+    c->maxCT = std::max(full.maxCT, prdCk.maxCT);
+    for (size_t e = 0; e < slots.size(); ++e)
+        slots[e].cs = full.cs[e];
+    std::vector<int32_t> trOff, trRow, trOffPrd, trRowPrd;
+    make_rows(full, c->maxCT, trOff, trRow);
+    std::vector<DevSlot> slotsPrd;
+    if (anyPrd)
+    {
+        make_rows(prdCk, c->maxCT, trOffPrd, trRowPrd);
+        slotsPrd = slots;
+        for (size_t e = 0; e < slots.size(); ++e)
+            slotsPrd[e].cs = prdCk.cs[e];
+    }
 
     // ---- sweep geometry ---------------------------------------------------------------------------------
     const int NR2 = 2 * c->Nrays;
@@ -804,6 +850,14 @@ int build_tables(lwhip_context* c)
     HIP_TRY(c->progRows.upload(progRows));
     HIP_TRY(c->progEnts.upload(progEnts));
     HIP_TRY(c->chunkLa.upload(chunkLa));
+    if (anyPrd)
+    {
+        HIP_TRY(c->slotsPrd.upload(slotsPrd));
+        HIP_TRY(c->chunkLaPrd.upload(prdCk.chunkLa));
+        HIP_TRY(c->laListPrd.upload(lasPrd));
+        HIP_TRY(c->trOffPrd.upload(trOffPrd));
+        HIP_TRY(c->trRowPrd.upload(trRowPrd));
+    }
     if (contLaHost.empty())
         contLaHost.push_back(0);
     c->nContLa = (c->rowsTot > 0) ? (int)contLaHost.size() : 0;
@@ -857,7 +911,7 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(hipMemset(c->Cmat.p, 0, c->Cmat.n * sizeof(double)));
     HIP_TRY(c->Rij.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     HIP_TRY(c->Rji.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
-    HIP_TRY(c->partial.alloc((size_t)c->nChunks * c->maxCT * 4 * Ns));
+    HIP_TRY(c->partial.alloc((size_t)std::max(c->nChunks, c->nChunksPrd) * c->maxCT * 4 * Ns));
     // reduce buffer: [Ntrans,4,Ns] partial sums followed by one (dJMax, idx) slot per shard
     HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize));
     HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
@@ -872,7 +926,7 @@ int alloc_state(lwhip_context* c)
         sz.Natom = c->Natom;
         sz.NlevTot = c->NlevTot;
         sz.maxC = c->maxC;
-        HIP_TRY(c->bigScratch.alloc((size_t)c->nChunks * sweep_big_scratch_doubles(sz)));
+        HIP_TRY(c->bigScratch.alloc((size_t)std::max(c->nChunks, c->nChunksPrd) * sweep_big_scratch_doubles(sz)));
     }
     if (c->march)
     {
@@ -964,6 +1018,16 @@ int build_sweep_args(lwhip_context* c)
     c->hargs = a;
     std::vector<SweepArgs> v(1, a);
     HIP_TRY(c->dargs.upload(v));
+    if (c->nChunksPrd > 0)
+    {
+        // the PRD rates pass: same arguments, its own chunking
+        a.slots = c->slotsPrd.p;
+        a.chunkLa = c->chunkLaPrd.p;
+        a.laList = c->laListPrd.p;
+        c->hargsPrd = a;
+        v[0] = a;
+        HIP_TRY(c->dargsPrd.upload(v));
+    }
     return LWHIP_OK;
 }
 
@@ -982,13 +1046,18 @@ SweepDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
 // one sweep over this context's wavelengths (rates = the full iteration, else formal_sol)
 hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
 {
+    // the PRD rates pass runs on its own chunking (balanced over the PRD wavelengths)
+    const bool prd = dyn.prdOnly && c->nChunksPrd > 0;
+    const SweepArgs* dargs = prd ? c->dargsPrd.p : c->dargs.p;
+    const SweepArgs& hargs = prd ? c->hargsPrd : c->hargs;
+    const int nChunks = prd ? c->nChunksPrd : c->nChunks;
     if (!c->march)
-        return launch_sweep(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->maxL, rates, c->nChunks, c->stream);
-    hipError_t e = launch_cont(c->dargs.p, c->hargs, c->stream);
+        return launch_sweep(dargs, hargs, dyn, c->prob.formalSolver, c->maxL, rates, nChunks, c->stream);
+    hipError_t e = launch_cont(dargs, hargs, c->stream);
     if (e != hipSuccess)
         return e;
-    return launch_march(c->dargs.p, c->hargs, dyn, c->prob.formalSolver, c->marchD, c->maxL, rates, c->nChunks,
-                        c->marchWaves, c->stream);
+    return launch_march(dargs, hargs, dyn, c->prob.formalSolver, c->marchD, c->maxL, rates, nChunks, c->marchWaves,
+                        c->stream);
 }
 
 int flush_prefill(lwhip_context* c)
@@ -1208,6 +1277,8 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                                    hipMemcpyHostToDevice, c->stream));
         }
     }
+    if (mask & LWHIP_NSTAR)
+        std::fill(c->gIIValid.begin(), c->gIIValid.end(), 0); // aDamp / vBroad may have changed
     std::vector<double> ratioHost;
     if (mask & LWHIP_NSTAR)
         ratioHost.assign((size_t)std::max(c->Ncont, 1) * Ns, 1.0);
@@ -1629,6 +1700,8 @@ int lwhip_nr_post_update(lwhip_context* c, const lwhip_nr_args* args)
     return LWHIP_OK;
 }
 
+enum { PRD_MAX_SLICES = 32 };
+
 int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_result* res)
 {
     if (!c)
@@ -1663,11 +1736,18 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
     if (c->prdOut.n < (size_t)2 * Nprd)
     {
         HIP_TRY(c->prdOut.alloc((size_t)2 * Nprd));
-        HIP_TRY(c->prdChange.alloc((size_t)Nprd * Ns));
-        HIP_TRY(c->prdChangeIdx.alloc((size_t)Nprd * Ns));
+        HIP_TRY(c->prdChange.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
+        HIP_TRY(c->prdChangeIdx.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
         if (c->prdPinned)
             (void)hipHostFree(c->prdPinned);
         HIP_TRY(hipHostMalloc((void**)&c->prdPinned, ((size_t)2 * Nprd + 2) * sizeof(double), hipHostMallocDefault));
+    }
+    {
+        size_t maxNl = 1;
+        for (int tr : prd)
+            maxNl = std::max(maxNl, (size_t)(c->trans[tr].t.Nred - c->trans[tr].t.Nblue));
+        if (c->prdJt.n < maxNl * Ns)
+            HIP_TRY(c->prdJt.alloc(maxNl * Ns));
     }
     const double* tail = c->red.p + (size_t)c->Ntrans * 4 * Ns;
     int iter = 0;
@@ -1694,6 +1774,7 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
             a.Bij = h.t.Bij;
             a.wave = c->lineWave.p + h.waveOff;
             a.J = c->J.p;
+            a.Jt = c->prdJt.p;
             a.vBroad = c->vBroad.p + (size_t)h.atom * Ns;
             a.aDamp = c->aDamp.p + (size_t)h.row * Ns;
             a.Qelast = c->Qelast.p + (size_t)h.row * Ns;
@@ -1704,20 +1785,58 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
             a.transLi = c->transLi.p;
             a.transLj = c->transLj.p;
             a.rho = c->rho.p + h.rhoOff;
-            a.changeVal = c->prdChange.p + (size_t)q * Ns;
-            a.changeIdx = c->prdChangeIdx.p + (size_t)q * Ns;
+            // enough workgroups to fill the chip: Ns x slices >= ~4 per CU, at least 64 wavelengths each
+            a.slices = std::max(1, std::min({ (int)PRD_MAX_SLICES, (2048 + Ns - 1) / Ns, (a.Nl + 127) / 128 }));
+            // gII weights depend only on aDamp, vBroad and the grid: cached across sub-iterations and
+            // iterations (the reference's t->gII), dropped when lwhip_upload(LWHIP_NSTAR) refreshes those
+            if (c->gII.size() != (size_t)c->Ntrans)
+            {
+                c->gII.resize(c->Ntrans);
+                c->gIIValid.assign(c->Ntrans, 0);
+            }
+            a.gII = nullptr;
+            a.gIIFill = 1;
+            if (env_int("LWHIP_PRD_CACHE", 1))
+            {
+                // gII and the interpolation fractions (doubles) + the bracketing indices (int32) of the line
+                const size_t per = (size_t)Ns * 88 * a.Nl;
+                const size_t need = 2 * per + (per + 1) / 2;
+                if (!c->gII[tr])
+                    c->gII[tr] = std::make_unique<DevBuf<double>>();
+                if (c->gII[tr]->n < need)
+                {
+                    if (c->gII[tr]->alloc(need) != hipSuccess)
+                    {
+                        (void)hipGetLastError(); // out of memory for the cache: recompute every time
+                        c->gII[tr].reset();
+                    }
+                    c->gIIValid[tr] = 0;
+                }
+                if (c->gII[tr])
+                {
+                    a.gII = c->gII[tr]->p;
+                    a.gTT = a.gII + per;
+                    a.gIT = (int32_t*)(a.gTT + per);
+                    a.gIIFill = c->gIIValid[tr] ? 0 : 1;
+                    c->gIIValid[tr] = 1;
+                }
+            }
+            a.changeVal = c->prdChange.p + (size_t)q * Ns * PRD_MAX_SLICES;
+            a.changeIdx = c->prdChangeIdx.p + (size_t)q * Ns * PRD_MAX_SLICES;
             HIP_TRY(launch_prd_scatter(a, c->prdOut.p + 2 * q, c->stream));
         }
         // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
         SweepDyn dyn = make_dyn(c, false, 0);
         dyn.prdOnly = 1;
+        if (c->nChunksPrd > 0) // wavelengths the pass does not visit report dJ = 0
+            HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
         HIP_TRY(run_sweep(c, dyn, true));
         ReduceArgs r{};
         r.Ns = Ns;
         r.Ntrans = c->Ntrans;
         r.maxCT = c->maxCT;
-        r.trOff = c->trOff.p;
-        r.trRow = c->trRow.p;
+        r.trOff = c->nChunksPrd > 0 ? c->trOffPrd.p : c->trOff.p;
+        r.trRow = c->nChunksPrd > 0 ? c->trRowPrd.p : c->trRow.p;
         r.partial = c->partial.p;
         r.red8 = c->red8.p;
         r.red = c->red.p;

@@ -130,7 +130,8 @@ struct SweepArgs
     const DevProgram* progs;
     const DevProgRow* progRows;
     const DevProgEnt* progEnts;
-    const int32_t* chunkLa;        // [nChunks+1] wavelength boundaries
+    const int32_t* chunkLa;        // [nChunks+1] wavelength boundaries (or boundaries in laList)
+    const int32_t* laList;         // null, or the wavelengths this launch visits (PRD rates pass)
     double* partial;               // [nChunks*maxCT, 4, Ns]
     double* dJ;                    // [Nla]
     long long* stamps;             // [nChunks, 12] diagnostic build only (-DLWHIP_STAMPS)
@@ -216,9 +217,11 @@ struct PrdLineArgs
     int32_t gi, gj;         // global level rows
     int32_t lj;             // local upper level
     int32_t trBegin, trEnd; // global transition range of the line's atom
+    int32_t slices, _padS;  // workgroups per depth point (slices of the emission wavelengths)
     double lambda0, Bij;
     const double* wave;     // [Nl] the line's own grid
     const double* J;        // [Nla, Ns]
+    double* Jt;             // [Ns, Nl] scratch: J of the line, wavelength fastest
     const double* vBroad;   // [Ns]
     const double* aDamp;    // [Ns]
     const double* Qelast;   // [Ns]
@@ -229,8 +232,12 @@ struct PrdLineArgs
     const int32_t* transLi;
     const int32_t* transLj;
     double* rho;            // [Nl, Ns]
-    double* changeVal;      // [Ns] scratch
-    int32_t* changeIdx;     // [Ns] scratch
+    double* gII;            // [Ns, 88, Nl] cached gII weights of the line, or null (always recompute)
+    double* gTT;            // [Ns, 88, Nl] cached interpolation fractions
+    int32_t* gIT;           // [Ns, 88, Nl] cached bracketing indices
+    int32_t gIIFill, _padG; // 1: compute (and store) the weights; 0: read them from the cache
+    double* changeVal;      // [Ns * slices] scratch
+    int32_t* changeIdx;     // [Ns * slices] scratch
 };
 hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t stream);
 

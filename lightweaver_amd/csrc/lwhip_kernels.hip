@@ -235,10 +235,13 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         const size_t o = (size_t)la_ * Ns + inK;
         return (inM == 0) ? gJ[o] : (inM == 1) ? gBgSca[o] : (inM == 2) ? gBgChi[o] : gBgEta[o];
     };
+    // the chunk is a range of wavelengths, or (PRD rates pass) a range of an explicit wavelength list
+    const CONST_AS int32_t* cLaList = CTAB(int32_t, ARGS.laList);
+    const int laFirst = cLaList ? cLaList[la0] : la0;
     for (int task = t; task < 4 * Ns; task += T) // prologue (also when T < 4 Ns)
     {
         const int m = divNs(task), kk = task - m * Ns;
-        const size_t o = (size_t)la0 * Ns + kk;
+        const size_t o = (size_t)laFirst * Ns + kk;
         sIn[task] = (m == 0) ? gJ[o] : (m == 1) ? gBgSca[o] : (m == 2) ? gBgChi[o] : gBgEta[o];
     }
     // otherwise (and in the PRD rates pass, which skips wavelengths) every wavelength reloads synchronously
@@ -253,13 +256,14 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     __syncthreads();
     STAMP(0);
 
-    DevLaHeader hNext = ld_c(cLaHdr + la0);
-    for (int la = la0; la < la1; ++la)
+    DevLaHeader hNext = ld_c(cLaHdr + laFirst);
+    for (int li = la0; li < la1; ++li)
     {
+        const int la = cLaList ? cLaList[li] : li;
         const DevLaHeader h = hNext;
-        const bool lastLa = (la + 1 >= la1);
+        const bool lastLa = (li + 1 >= la1);
         if (!lastLa)
-            hNext = ld_c(cLaHdr + la + 1);
+            hNext = ld_c(cLaHdr + (cLaList ? cLaList[li + 1] : li + 1));
         if (dyn.prdOnly && !h.hasPrd) // formal_sol_prd_update_rates visits prdIdxs only (PrdTemplates.hpp:226-239)
         {
             if (RATES && t == 0)
@@ -271,11 +275,14 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         const int nLine = h.nLine;
         const int nPerRayC = h.nMixed;
         const int nCont = h.nMixed + h.nPure;
+        // wavelengths without an active continuum (most of a line-dominated grid) need no row program:
+        // the totals are the background rows themselves and every per-level continuum sum is zero
+        const bool hasCont = nCont > 0;
         const double wav = cWavelength[la];
         const double hc_kl = HC_K / wav;
 
         // ---- ray-independent part ---------------------------------------------------------------------
-        if (h.prog != curProg) // uniform: the active continuum set changed -> stage its row program
+        if (hasCont && h.prog != curProg) // uniform: the active continuum set changed -> stage its row program
         {
             const DevProgram pg = ld_c(cProgs + h.prog);
             for (int idx = t; idx < pg.nRows; idx += T)
@@ -285,7 +292,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             curProg = h.prog;
             progRows = pg.nRows;
         }
-        if (!pfInputs && la != la0)
+        if (!pfInputs && li != la0)
         {
             for (int task = t; task < 4 * Ns; task += T)
             {
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             const int kq = (q == 0) ? Ns - 2 : (q == 1) ? Ns - 1 : (q == 2) ? 0 : 1;
             sPlanck[q] = d_planck(sTemp[kq], wav);
         }
-        for (int idx = t; idx < nCont * Ns && (!(LWHIP_ABLATE & 8) || la == la0); idx += T)
+        for (int idx = t; idx < nCont * Ns && (!(LWHIP_ABLATE & 8) || li == la0); idx += T)
         {
             const int c = divNs(idx);
             const int kk = idx - c * Ns;
@@ -335,35 +342,38 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
         }
         wg_barrier<BIG>();
         STAMP(1);
-        // row program: totals, per-atom emissivity and per-level sums over the continua, one
-        // (row, depth) task per thread, continua added in reference order
-        for (int task = t; task < progRows * Ns && (!(LWHIP_ABLATE & 8) || la == la0); task += T)
+        if (hasCont)
         {
-            const int ri = divNs(task);
-            const int kk = task - ri * Ns;
-            const DevProgRow pr = sProgRows[ri];
-            double v = 0.0;
-            if (pr.row == 0)
-                v = sBgChi[kk];
-            else if (pr.row == 1)
-                v = sBgEta[kk];
-            for (int e = 0; e < pr.nEnt; ++e)
+            // row program: totals, per-atom emissivity and per-level sums over the continua, one
+            // (row, depth) task per thread, continua added in reference order
+            for (int task = t; task < progRows * Ns && (!(LWHIP_ABLATE & 8) || li == la0); task += T)
             {
-                const DevProgEnt en = sProgEnts[pr.entOff + e];
-                const double x = sChiCo[en.c * Ns + kk];
-                const double uji = sCp2[en.c] * sVji[en.c * Ns + kk];
-                if (en.kind == 0)
-                    v += x;
-                else if (en.kind == 1)
-                    v -= x;
-                else if (en.kind == 2)
-                    v += uji;
-                else
-                    v += gN[sCgj[en.c] * Ns + kk] * uji;
+                const int ri = divNs(task);
+                const int kk = task - ri * Ns;
+                const DevProgRow pr = sProgRows[ri];
+                double v = 0.0;
+                if (pr.row == 0)
+                    v = sBgChi[kk];
+                else if (pr.row == 1)
+                    v = sBgEta[kk];
+                for (int e = 0; e < pr.nEnt; ++e)
+                {
+                    const DevProgEnt en = sProgEnts[pr.entOff + e];
+                    const double x = sChiCo[en.c * Ns + kk];
+                    const double uji = sCp2[en.c] * sVji[en.c * Ns + kk];
+                    if (en.kind == 0)
+                        v += x;
+                    else if (en.kind == 1)
+                        v -= x;
+                    else if (en.kind == 2)
+                        v += uji;
+                    else
+                        v += gN[sCgj[en.c] * Ns + kk] * uji;
+                }
+                sRows[pr.row * Ns + kk] = v;
             }
-            sRows[pr.row * Ns + kk] = v;
+            wg_barrier<BIG>();
         }
-        wg_barrier<BIG>();
         STAMP(2);
 
         // ---- passes over groups of G rays -----------------------------------------------------------
@@ -395,8 +405,8 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
             // gather: Transition::uv + chi_eta_aux_accum for the (ray-dependent) lines
             if (active)
             {
-                chi = sChiC[k];
-                eta = sEtaC[k];
+                chi = hasCont ? sChiC[k] : sBgChi[k];
+                eta = hasCont ? sEtaC[k] : sBgEta[k];
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                 {
@@ -773,11 +783,20 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                             mE0 += wPsi * el[0];
                         else if (sl.ms == 1)
                             mE1 += wPsi * el[0];
-                        const double Ieff = I - PsiS * (sEtaA[sl.atom * Ns + k] + el[0]);
-                        const double chi_i = sLevChi[sl.gi * Ns + k] + xl[0];
-                        const double chi_j = sLevChi[sl.gj * Ns + k] - xl[0];
-                        const double U_j = sLevU[sl.gj * Ns + k] + uji;
-                        const double U_i = sLevU[sl.gi * Ns + k];
+                        double etaA = 0.0, lci = 0.0, lcj = 0.0, luj = 0.0, lui = 0.0;
+                        if (hasCont)
+                        {
+                            etaA = sEtaA[sl.atom * Ns + k];
+                            lci = sLevChi[sl.gi * Ns + k];
+                            lcj = sLevChi[sl.gj * Ns + k];
+                            luj = sLevU[sl.gj * Ns + k];
+                            lui = sLevU[sl.gi * Ns + k];
+                        }
+                        const double Ieff = I - PsiS * (etaA + el[0]);
+                        const double chi_i = lci + xl[0];
+                        const double chi_j = lcj - xl[0];
+                        const double U_j = luj + uji;
+                        const double U_i = lui;
                         lds_add(acc, ((uji + Vji[0] * Ieff) - (PsiS * chi_i * U_j)) * wlamu);
                         lds_add(acc + Ns, ((Vij[0] * Ieff) - (PsiS * chi_j * U_i)) * wlamu);
                     }
@@ -814,7 +833,9 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                         }
                     }
                     auto levChi = [&](int g) {
-                        double v = sLevChi[g * Ns + k];
+                        double v = 0.0;
+                        if (hasCont)
+                            v = sLevChi[g * Ns + k];
 #pragma unroll
                         for (int l = 0; l < MAXL; ++l)
                         {
@@ -826,7 +847,9 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                         return v;
                     };
                     auto levU = [&](int g) {
-                        double v = sLevU[g * Ns + k];
+                        double v = 0.0;
+                        if (hasCont)
+                            v = sLevU[g * Ns + k];
 #pragma unroll
                         for (int l = 0; l < MAXL; ++l)
                         {
@@ -836,7 +859,9 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
                         return v;
                     };
                     auto atomEta = [&](int at) {
-                        double v = sEtaA[at * Ns + k];
+                        double v = 0.0;
+                        if (hasCont)
+                            v = sEtaA[at * Ns + k];
 #pragma unroll
                         for (int l = 0; l < MAXL; ++l)
                         {

@@ -257,8 +257,10 @@ march_kernel(const SweepArgs* __restrict__ ap, const SweepDyn dyn)
 #endif
 
     // wavelengths of the chunk are dealt to the wavefronts round-robin (neighbours cost the same)
-    for (int la = la0 + wave; la < la1; la += nWaves)
+    const CONST_AS int32_t* cLaList = CTAB(int32_t, ARGS.laList); // PRD rates pass: explicit wavelength list
+    for (int li = la0 + wave; li < la1; li += nWaves)
     {
+        const int la = cLaList ? cLaList[li] : li;
         const DevLaHeader h = ld_c(cHdr + la);
         if (dyn.prdOnly && !h.hasPrd) // formal_sol_prd_update_rates visits prdIdxs only (PrdTemplates.hpp:226-239)
         {

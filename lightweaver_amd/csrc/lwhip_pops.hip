@@ -15,17 +15,49 @@
 
 namespace lwhip
 {
+// Per-thread workspace in LDS: element e of thread t lives at base[e * stride + t] (stride = block
+// size), so the threads of a wavefront never collide on a bank and the dynamically indexed rows of
+// the pivoting LU cost an LDS access instead of a scratch (HBM-backed) one.
+struct LdsVec
+{
+    double* p;
+    int stride;
+    DEVINL double& operator[](int e) const { return p[(size_t)e * stride]; }
+};
+// doubles of workspace per thread for an N x N system: A, A0 (N^2 each), b, b0, res, vv, index (N each)
+__host__ __device__ inline size_t solve_ws_doubles(int N) { return (size_t)2 * N * N + 5 * N; }
+struct SolveWs
+{
+    LdsVec A, A0, b, b0, res, vv, index;
+    DEVINL SolveWs(double* base, int N, int stride, int tid)
+    {
+        double* q = base + tid;
+        A = { q, stride };
+        q += (size_t)N * N * stride;
+        A0 = { q, stride };
+        q += (size_t)N * N * stride;
+        b = { q, stride };
+        q += (size_t)N * stride;
+        b0 = { q, stride };
+        q += (size_t)N * stride;
+        res = { q, stride };
+        q += (size_t)N * stride;
+        vv = { q, stride };
+        q += (size_t)N * stride;
+        index = { q, stride };
+    }
+};
+
 // solve A x = b in place (x returned in b); A is destroyed.  Returns false for a singular matrix
 // (an all-zero row, where the reference throws "Singular Matrix", LuSolve.cpp:22-23).
-template <int MAXN> DEVINL bool d_solve_lin_eq(int N, double* A, double* b)
+DEVINL bool d_solve_lin_eq(int N, const SolveWs& w)
 {
-    double A0[MAXN * MAXN], b0[MAXN], res[MAXN], vv[MAXN];
-    int index[MAXN];
+    const LdsVec& A = w.A;
     for (int i = 0; i < N; ++i)
     {
-        b0[i] = b[i];
+        w.b0[i] = w.b[i];
         for (int j = 0; j < N; ++j)
-            A0[i * MAXN + j] = A[i * MAXN + j];
+            w.A0[i * N + j] = A[i * N + j];
     }
     // lu_decompose :8-70
     bool singular = false;
@@ -33,10 +65,10 @@ template <int MAXN> DEVINL bool d_solve_lin_eq(int N, double* A, double* b)
     {
         double big = 0.0;
         for (int j = 0; j < N; ++j)
-            big = fmax(big, fabs(A[i * MAXN + j]));
+            big = fmax(big, fabs(A[i * N + j]));
         if (big == 0.0)
             singular = true;
-        vv[i] = 1.0 / big;
+        w.vv[i] = 1.0 / big;
     }
     if (singular)
         return false;
@@ -44,20 +76,20 @@ template <int MAXN> DEVINL bool d_solve_lin_eq(int N, double* A, double* b)
     {
         for (int i = 0; i < j; ++i)
         {
-            double sum = A[i * MAXN + j];
+            double sum = A[i * N + j];
             for (int q = 0; q < i; ++q)
-                sum -= A[i * MAXN + q] * A[q * MAXN + j];
-            A[i * MAXN + j] = sum;
+                sum -= A[i * N + q] * A[q * N + j];
+            A[i * N + j] = sum;
         }
         int iMax = 0;
         double big = 0.0;
         for (int i = j; i < N; ++i)
         {
-            double sum = A[i * MAXN + j];
+            double sum = A[i * N + j];
             for (int q = 0; q < j; ++q)
-                sum -= A[i * MAXN + q] * A[q * MAXN + j];
-            A[i * MAXN + j] = sum;
-            const double cand = vv[i] * fabs(sum);
+                sum -= A[i * N + q] * A[q * N + j];
+            A[i * N + j] = sum;
+            const double cand = w.vv[i] * fabs(sum);
             if (big < cand)
             {
                 iMax = i;
@@ -68,31 +100,31 @@ template <int MAXN> DEVINL bool d_solve_lin_eq(int N, double* A, double* b)
         {
             for (int q = 0; q < N; ++q)
             {
-                const double tmp = A[iMax * MAXN + q];
-                A[iMax * MAXN + q] = A[j * MAXN + q];
-                A[j * MAXN + q] = tmp;
+                const double tmp = A[iMax * N + q];
+                A[iMax * N + q] = A[j * N + q];
+                A[j * N + q] = tmp;
             }
-            vv[iMax] = vv[j];
+            w.vv[iMax] = w.vv[j];
         }
-        index[j] = iMax;
-        if (A[j * MAXN + j] == 0.0)
-            A[j * MAXN + j] = 1e-20;
-        const double tmp = 1.0 / A[j * MAXN + j];
+        w.index[j] = (double)iMax;
+        if (A[j * N + j] == 0.0)
+            A[j * N + j] = 1e-20;
+        const double tmp = 1.0 / A[j * N + j];
         for (int i = j + 1; i < N; ++i)
-            A[i * MAXN + j] *= tmp;
+            A[i * N + j] *= tmp;
     }
     // lu_backsub :72-101
-    auto backsub = [&](double* x) {
+    auto backsub = [&](const LdsVec& x) {
         int ii = -1;
         for (int i = 0; i < N; ++i)
         {
-            const int ip = index[i];
+            const int ip = (int)w.index[i];
             double sum = x[ip];
             x[ip] = x[i];
             if (ii >= 0)
             {
                 for (int j = ii; j < i; ++j)
-                    sum -= A[i * MAXN + j] * x[j];
+                    sum -= A[i * N + j] * x[j];
             }
             else if (sum != 0.0)
             {
@@ -104,33 +136,49 @@ template <int MAXN> DEVINL bool d_solve_lin_eq(int N, double* A, double* b)
         {
             double sum = x[i];
             for (int j = i + 1; j < N; ++j)
-                sum -= A[i * MAXN + j] * x[j];
-            x[i] = sum / A[i * MAXN + i];
+                sum -= A[i * N + j] * x[j];
+            x[i] = sum / A[i * N + i];
         }
     };
-    backsub(b);
+    backsub(w.b);
     // one pass of iterative improvement :114-131
     for (int i = 0; i < N; ++i)
     {
-        double r = b0[i];
+        double r = w.b0[i];
         for (int j = 0; j < N; ++j)
-            r -= A0[i * MAXN + j] * b[j];
-        res[i] = r;
+            r -= w.A0[i * N + j] * w.b[j];
+        w.res[i] = r;
     }
-    backsub(res);
+    backsub(w.res);
     for (int i = 0; i < N; ++i)
-        b[i] += res[i];
+        w.b[i] += w.res[i];
     return true;
 }
 
+// threads per block such that the workspace fits the LDS (a power of two between 1 and 64)
+static int solve_block_threads(int N)
+{
+    const size_t budget = 150 * 1024;
+    int tb = 64;
+    while (tb > 1 && solve_ws_doubles(N) * sizeof(double) * tb > budget)
+        tb >>= 1;
+    return tb;
+}
+static hipError_t solve_set_lds(const void* fn, size_t lds)
+{
+    if (lds > 48 * 1024)
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return hipSuccess;
+}
+
 // ---- stat_eq_impl: Source/UpdatePopulations.cpp:7-47 -------------------------------------------------------
-template <int MAXN>
 __global__ void stat_eq_kernel(int N, int Ns, double* n, const double* nTotal, const double* Gamma, int* status)
 {
+    extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= Ns)
         return;
-    double A[MAXN * MAXN], bvec[MAXN];
+    const SolveWs w(lds, N, blockDim.x, threadIdx.x);
     // Gamma_k and the elimination row: the level with the largest population
     int iElim = 0;
     double nMax = 0.0;
@@ -143,92 +191,95 @@ __global__ void stat_eq_kernel(int N, int Ns, double* n, const double* nTotal, c
             nMax = ni;
         }
         for (int j = 0; j < N; ++j)
-            A[i * MAXN + j] = Gamma[((size_t)i * N + j) * Ns + k];
+            w.A[i * N + j] = Gamma[((size_t)i * N + j) * Ns + k];
     }
     for (int i = 0; i < N; ++i)
     {
-        A[iElim * MAXN + i] = 1.0;
-        bvec[i] = 0.0;
+        w.A[iElim * N + i] = 1.0;
+        w.b[i] = 0.0;
     }
-    bvec[iElim] = nTotal[k];
-    if (!d_solve_lin_eq<MAXN>(N, A, bvec))
+    w.b[iElim] = nTotal[k];
+    if (!d_solve_lin_eq(N, w))
     {
         atomicExch(status, LWHIP_ERR_SINGULAR);
         return;
     }
     for (int i = 0; i < N; ++i)
-        n[(size_t)i * Ns + k] = bvec[i];
+        n[(size_t)i * Ns + k] = w.b[i];
 }
 
 hipError_t launch_stat_eq(int Nlevel, int Ns, double* n, const double* nTotal, const double* Gamma,
                           int* status, hipStream_t stream)
 {
-    const int blocks = (Ns + 63) / 64;
-    if (Nlevel <= 8)
-        hipLaunchKernelGGL(stat_eq_kernel<8>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nTotal, Gamma, status);
-    else if (Nlevel <= 16)
-        hipLaunchKernelGGL(stat_eq_kernel<16>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nTotal, Gamma, status);
-    else if (Nlevel <= 32)
-        hipLaunchKernelGGL(stat_eq_kernel<32>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nTotal, Gamma, status);
-    else
+    if (Nlevel > 64)
         return hipErrorInvalidValue;
+    const int tb = solve_block_threads(Nlevel);
+    const size_t lds = solve_ws_doubles(Nlevel) * sizeof(double) * tb;
+    hipError_t e = solve_set_lds((const void*)stat_eq_kernel, lds);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(stat_eq_kernel, dim3((Ns + tb - 1) / tb), dim3(tb), lds, stream, Nlevel, Ns, n, nTotal, Gamma,
+                       status);
     return hipGetLastError();
 }
 
 // ---- time_dependent_update_impl: Source/UpdatePopulations.cpp:120-151 --------------------------------------
-template <int MAXN>
 __global__ void time_dep_kernel(int N, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
                                 int* status)
 {
+    extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= Ns)
         return;
-    double A[MAXN * MAXN], nk[MAXN];
+    const SolveWs w(lds, N, blockDim.x, threadIdx.x);
     for (int i = 0; i < N; ++i)
     {
-        nk[i] = nOld[(size_t)i * Ns + k];
+        w.b[i] = nOld[(size_t)i * Ns + k];
         for (int j = 0; j < N; ++j)
-            A[i * MAXN + j] = -Gamma[((size_t)i * N + j) * Ns + k] * dt;
-        A[i * MAXN + i] = 1.0 - Gamma[((size_t)i * N + i) * Ns + k] * dt;
+            w.A[i * N + j] = -Gamma[((size_t)i * N + j) * Ns + k] * dt;
+        w.A[i * N + i] = 1.0 - Gamma[((size_t)i * N + i) * Ns + k] * dt;
     }
-    if (!d_solve_lin_eq<MAXN>(N, A, nk))
+    if (!d_solve_lin_eq(N, w))
     {
         atomicExch(status, LWHIP_ERR_SINGULAR);
         return;
     }
     for (int i = 0; i < N; ++i)
-        n[(size_t)i * Ns + k] = nk[i];
+        n[(size_t)i * Ns + k] = w.b[i];
 }
 
 hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
                            int* status, hipStream_t stream)
 {
-    const int blocks = (Ns + 63) / 64;
-    if (Nlevel <= 8)
-        hipLaunchKernelGGL(time_dep_kernel<8>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nOld, Gamma, dt, status);
-    else if (Nlevel <= 16)
-        hipLaunchKernelGGL(time_dep_kernel<16>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nOld, Gamma, dt, status);
-    else if (Nlevel <= 32)
-        hipLaunchKernelGGL(time_dep_kernel<32>, dim3(blocks), dim3(64), 0, stream, Nlevel, Ns, n, nOld, Gamma, dt, status);
-    else
+    if (Nlevel > 64)
         return hipErrorInvalidValue;
+    const int tb = solve_block_threads(Nlevel);
+    const size_t lds = solve_ws_doubles(Nlevel) * sizeof(double) * tb;
+    hipError_t e = solve_set_lds((const void*)time_dep_kernel, lds);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(time_dep_kernel, dim3((Ns + tb - 1) / tb), dim3(tb), lds, stream, Nlevel, Ns, n, nOld, Gamma, dt,
+                       status);
     return hipGetLastError();
 }
 
 // ---- nr_post_update_impl with F / Ftd: Source/UpdatePopulations.cpp:230-394 --------------------------------
-template <int MAXN> __global__ void nr_post_kernel(const NrArgs a)
+__global__ void nr_post_kernel(const NrArgs a)
 {
+    extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
     if (k >= Ns)
         return;
     const int Neqn = a.Neqn;
-    double dF[MAXN * MAXN], Fg[MAXN];
+    const SolveWs w(lds, Neqn, blockDim.x, threadIdx.x);
+    const LdsVec& dF = w.A;
+    const LdsVec& Fg = w.b;
     for (int i = 0; i < Neqn; ++i)
     {
         Fg[i] = 0.0;
         for (int j = 0; j < Neqn; ++j)
-            dF[i * MAXN + j] = 0.0;
+            dF[i * Neqn + j] = 0.0;
     }
     const double theta = 1.0;
     const double ne = a.ne[k];
@@ -269,14 +320,14 @@ template <int MAXN> __global__ void nr_post_kernel(const NrArgs a)
         // Jacobian :322-372
         for (int l = 0; l < Nl; ++l)
             for (int ll = 0; ll < Nl; ++ll)
-                dF[(start + l) * MAXN + start + ll] = -G[((size_t)l * Nl + ll) * Ns + k];
+                dF[(start + l) * Neqn + start + ll] = -G[((size_t)l * Nl + ll) * Ns + k];
         if (a.timeDep)
         {
             for (int l = 0; l < Nl; ++l)
                 for (int ll = 0; ll < Nl; ++ll)
-                    dF[(start + l) * MAXN + start + ll] *= -theta * a.dt;
+                    dF[(start + l) * Neqn + start + ll] *= -theta * a.dt;
             for (int l = 0; l < Nl; ++l)
-                dF[(start + l) * MAXN + start + l] -= 1.0;
+                dF[(start + l) * Neqn + start + l] -= 1.0;
         }
         const double* Cm = a.Cmat + at.gammaOff;
         for (int tr = at.trBegin; tr < at.trEnd; ++tr)
@@ -288,7 +339,7 @@ template <int MAXN> __global__ void nr_post_kernel(const NrArgs a)
             double entry = -(preconRji / ne) * n[(size_t)tj * Ns + k];
             if (a.timeDep)
                 entry *= -theta * a.dt;
-            dF[(start + ti) * MAXN + Neqn - 1] += entry;
+            dF[(start + ti) * Neqn + Neqn - 1] += entry;
         }
         if (a.dC)
         {
@@ -300,23 +351,23 @@ template <int MAXN> __global__ void nr_post_kernel(const NrArgs a)
                     entry -= dC[((size_t)i * Nl + ll) * Ns + k] * n[(size_t)ll * Ns + k];
                 if (a.timeDep)
                     entry *= -theta * a.dt;
-                dF[(start + i) * MAXN + Neqn - 1] += entry;
+                dF[(start + i) * Neqn + Neqn - 1] += entry;
             }
         }
         for (int c = 0; c < Neqn; ++c)
-            dF[(start + Nl - 1) * MAXN + c] = 0.0;
+            dF[(start + Nl - 1) * Neqn + c] = 0.0;
         for (int ll = 0; ll < Nl; ++ll)
         {
-            dF[(start + Nl - 1) * MAXN + start + ll] = 1.0;
-            dF[(Neqn - 1) * MAXN + start + ll] = -a.stages[at.eqOff + ll];
+            dF[(start + Nl - 1) * Neqn + start + ll] = 1.0;
+            dF[(Neqn - 1) * Neqn + start + ll] = -a.stages[at.eqOff + ll];
         }
         start += Nl;
     }
     Fg[Neqn - 1] -= a.backgroundNe[k];
-    dF[(Neqn - 1) * MAXN + Neqn - 1] = 1.0;
+    dF[(Neqn - 1) * Neqn + Neqn - 1] = 1.0;
     for (int i = 0; i < Neqn; ++i)
         Fg[i] *= -1.0;
-    if (!d_solve_lin_eq<MAXN>(Neqn, dF, Fg))
+    if (!d_solve_lin_eq(Neqn, w))
     {
         atomicExch(a.status, LWHIP_ERR_SINGULAR);
         return;
@@ -335,15 +386,14 @@ template <int MAXN> __global__ void nr_post_kernel(const NrArgs a)
 
 hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream)
 {
-    const int blocks = (a.Ns + 63) / 64;
-    if (a.Neqn <= 16)
-        hipLaunchKernelGGL(nr_post_kernel<16>, dim3(blocks), dim3(64), 0, stream, a);
-    else if (a.Neqn <= 32)
-        hipLaunchKernelGGL(nr_post_kernel<32>, dim3(blocks), dim3(64), 0, stream, a);
-    else if (a.Neqn <= 64)
-        hipLaunchKernelGGL(nr_post_kernel<64>, dim3(blocks), dim3(64), 0, stream, a);
-    else
+    if (a.Neqn > 64)
         return hipErrorInvalidValue;
+    const int tb = solve_block_threads(a.Neqn);
+    const size_t lds = solve_ws_doubles(a.Neqn) * sizeof(double) * tb;
+    hipError_t e = solve_set_lds((const void*)nr_post_kernel, lds);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(nr_post_kernel, dim3((a.Ns + tb - 1) / tb), dim3(tb), lds, stream, a);
     return hipGetLastError();
 }
 }

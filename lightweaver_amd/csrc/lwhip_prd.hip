@@ -3,7 +3,7 @@
 // (Source/Prd.cpp:46-124), the total depopulation + elastic rate (Source/Prd.cpp:9-30) and the
 // max relative change of rho that Ng(0,0,0)::max_change reports (Source/Ng.hpp:136-156).
 //
-// One workgroup per (PRD line, depth point): J(:, k) and the line's wavelengths in Doppler units
+// One workgroup per (PRD line, depth point, slice of the line's wavelengths): J(:, k) and the line's wavelengths in Doppler units
 // are staged in LDS, then every thread owns one emission wavelength and walks its <= 87-point
 // fine grid (spacing 0.15 Doppler widths) exactly as the reference does -- same interpolation,
 // same sequentially accumulated q', same end-corrected trapezoid weights -- evaluating GII on the
@@ -22,6 +22,7 @@ constexpr double PrdQWing = 4.0;
 constexpr double PrdQCore = 2.0;
 constexpr double PrdQSpread = 5.0;
 constexpr double PrdDQ = 0.15;
+constexpr int PRD_MAX_FINE = 88; // >= max_fine_grid_size() = 87, Prd.cpp:126-129
 
 __device__ __forceinline__ double p_G_zero(double x)
 {
@@ -70,7 +71,27 @@ __device__ double p_GII(double aDamp, double qEmit, double qAbs)
 }
 }
 
-__global__ void __launch_bounds__(256) prd_scatter_kernel(const PrdLineArgs a)
+// J(Nblue : Nred, :) -> Jt[k][la]: the scattering integral reads J along wavelength at fixed depth
+__global__ void prd_transpose_kernel(const double* J, int Nblue, int Nl, int Ns, double* Jt)
+{
+    __shared__ double tile[32][33];
+    const int la0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y)
+    {
+        const int la = la0 + r, k = k0 + threadIdx.x;
+        if (la < Nl && k < Ns)
+            tile[r][threadIdx.x] = J[(size_t)(la + Nblue) * Ns + k];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y)
+    {
+        const int k = k0 + r, la = la0 + threadIdx.x;
+        if (la < Nl && k < Ns)
+            Jt[(size_t)k * Nl + la] = tile[threadIdx.x][r];
+    }
+}
+
+__global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
 {
     extern __shared__ double sm[];
     const int k = blockIdx.x;
@@ -79,26 +100,54 @@ __global__ void __launch_bounds__(256) prd_scatter_kernel(const PrdLineArgs a)
     double* Jk = sm;
     double* qW = sm + Nl;
     __shared__ double sPjQj;
-    __shared__ double sBest[256];
-    __shared__ int sBestIdx[256];
+    __shared__ double sBest[128];
+    __shared__ int sBestIdx[128];
 
     for (int la = threadIdx.x; la < Nl; la += blockDim.x)
     {
-        Jk[la] = a.J[(size_t)(la + a.Nblue) * Ns + k];
+        Jk[la] = a.Jt[(size_t)k * Nl + la];
         qW[la] = (a.wave[la] - a.lambda0) * CLight / (a.lambda0 * a.vBroad[k]);
     }
+    // total_depop_elastic_scattering_rate: Prd.cpp:9-30.  The terms are fetched by separate lanes
+    // (one memory round trip), then added by one thread in the reference's order.
+    __shared__ double sTerm[128];
+    const int nTr = a.trEnd - a.trBegin;
+    const int nTerm = a.Nlevel + nTr;
+    for (int q = threadIdx.x; q < nTerm && q < 128; q += blockDim.x)
+    {
+        double v = 0.0;
+        if (q < a.Nlevel)
+            v = a.Cmat[((size_t)q * a.Nlevel + a.lj) * Ns + k];
+        else
+        {
+            const int tr = a.trBegin + (q - a.Nlevel);
+            if (a.transLj[tr] == a.lj)
+                v += a.Rji[(size_t)tr * Ns + k];
+            if (a.transLi[tr] == a.lj)
+                v += a.Rij[(size_t)tr * Ns + k];
+        }
+        sTerm[q] = v;
+    }
+    __syncthreads();
     if (threadIdx.x == 0)
     {
-        // total_depop_elastic_scattering_rate: Prd.cpp:9-30
         double pq = a.Qelast[k];
-        for (int i = 0; i < a.Nlevel; ++i)
-            pq += a.Cmat[((size_t)i * a.Nlevel + a.lj) * Ns + k];
-        for (int tr = a.trBegin; tr < a.trEnd; ++tr)
+        if (nTerm <= 128)
         {
-            if (a.transLj[tr] == a.lj)
-                pq += a.Rji[(size_t)tr * Ns + k];
-            if (a.transLi[tr] == a.lj)
-                pq += a.Rij[(size_t)tr * Ns + k];
+            for (int q = 0; q < nTerm; ++q)
+                pq += sTerm[q];
+        }
+        else
+        {
+            for (int i = 0; i < a.Nlevel; ++i)
+                pq += a.Cmat[((size_t)i * a.Nlevel + a.lj) * Ns + k];
+            for (int tr = a.trBegin; tr < a.trEnd; ++tr)
+            {
+                if (a.transLj[tr] == a.lj)
+                    pq += a.Rji[(size_t)tr * Ns + k];
+                if (a.transLi[tr] == a.lj)
+                    pq += a.Rij[(size_t)tr * Ns + k];
+            }
         }
         sPjQj = pq;
     }
@@ -109,7 +158,11 @@ __global__ void __launch_bounds__(256) prd_scatter_kernel(const PrdLineArgs a)
     const double aDamp = a.aDamp[k];
     double best = 0.0;
     int bestIdx = 0x7fffffff;
-    for (int la = threadIdx.x; la < Nl; la += blockDim.x)
+    // this workgroup's share of the emission wavelengths (blockIdx.y of gridDim.y slices)
+    const int laPer = (Nl + gridDim.y - 1) / gridDim.y;
+    const int laBeg = blockIdx.y * laPer;
+    const int laEnd = min(Nl, laBeg + laPer);
+    for (int la = laBeg + threadIdx.x; la < laEnd; la += blockDim.x)
     {
         const double qEmit = qW[la];
         double q0, qN; // scattering_int_range: Prd.cpp:233-263
@@ -156,36 +209,75 @@ __global__ void __launch_bounds__(256) prd_scatter_kernel(const PrdLineArgs a)
             }
             iter = lo;
         }
+        // Everything about the fine grid of this (depth, emission wavelength) that does not depend on J
+        // -- the end-corrected gII weights (the reference caches these too, t->gII, Prd.cpp:499-553), the
+        // bracketing table index and the interpolation fraction -- is cached, laid out
+        // [k][fine point][la] so that a wavefront's reads coalesce.  With the cache the integral is
+        // 3 loads + 2 LDS reads + 4 flops per fine point, in the reference's order of operations.
+        const size_t cOff = ((size_t)k * PRD_MAX_FINE) * Nl + la;
         double gNorm = 0.0, scatInt = 0.0;
-        double qPrime = q0;
-        for (int i = 0; i < Np; ++i)
+        if (!a.gIIFill)
         {
-            const double x = q0 + i * PrdDQ;
-            while (iter < Nl && qW[iter] <= x)
-                ++iter;
-            double Jf;
-            if (iter == Nl)
-                Jf = Jk[Nl - 1];
-            else if (iter == 0)
-                Jf = Jk[0];
-            else
+            const double* gc = a.gII + cOff;
+            const double* tc = a.gTT + cOff;
+            const int32_t* ic = a.gIT + cOff;
+            for (int i = 0; i < Np; ++i)
             {
-                const double xp = qW[iter - 1], xn = qW[iter];
-                const double tt = (x - xp) / (xn - xp);
-                Jf = (1.0 - tt) * Jk[iter - 1] + tt * Jk[iter];
+                const double gii = gc[(size_t)i * Nl];
+                const double tt = tc[(size_t)i * Nl];
+                const int it = ic[(size_t)i * Nl];
+                const double Jf = (1.0 - tt) * Jk[it - 1] + tt * Jk[it];
+                gNorm += gii;
+                scatInt += Jf * gii;
             }
-            // end-corrected trapezoid weights, q' accumulated step by step: Prd.cpp:526-551
-            if (i > 0)
-                qPrime += PrdDQ;
-            double gii;
-            if (i == 0 || i == Np - 1)
-                gii = p_GII(aDamp, qEmit, qPrime) * 5.0 / 12.0 * PrdDQ;
-            else if (i == 1 || i == Np - 2)
-                gii = p_GII(aDamp, qEmit, qPrime) * 13.0 / 12.0 * PrdDQ;
-            else
-                gii = p_GII(aDamp, qEmit, qPrime) * PrdDQ;
-            gNorm += gii;
-            scatInt += Jf * gii;
+        }
+        else
+        {
+            double qPrime = q0;
+            for (int i = 0; i < Np; ++i)
+            {
+                const double x = q0 + i * PrdDQ;
+                while (iter < Nl && qW[iter] <= x)
+                    ++iter;
+                // beyond the table ends the reference takes the end value: the same number comes out
+                // of the interpolation formula with fraction 1 (0) on the last (first) bracket
+                int it = iter;
+                double tt;
+                if (iter == Nl)
+                {
+                    it = Nl - 1;
+                    tt = 1.0;
+                }
+                else if (iter == 0)
+                {
+                    it = 1;
+                    tt = 0.0;
+                }
+                else
+                {
+                    const double xp = qW[iter - 1], xn = qW[iter];
+                    tt = (x - xp) / (xn - xp);
+                }
+                const double Jf = (1.0 - tt) * Jk[it - 1] + tt * Jk[it];
+                // end-corrected trapezoid weights, q' accumulated step by step: Prd.cpp:526-551
+                if (i > 0)
+                    qPrime += PrdDQ;
+                double gii;
+                if (i == 0 || i == Np - 1)
+                    gii = p_GII(aDamp, qEmit, qPrime) * 5.0 / 12.0 * PrdDQ;
+                else if (i == 1 || i == Np - 2)
+                    gii = p_GII(aDamp, qEmit, qPrime) * 13.0 / 12.0 * PrdDQ;
+                else
+                    gii = p_GII(aDamp, qEmit, qPrime) * PrdDQ;
+                if (a.gII)
+                {
+                    a.gII[cOff + (size_t)i * Nl] = gii;
+                    a.gTT[cOff + (size_t)i * Nl] = tt;
+                    a.gIT[cOff + (size_t)i * Nl] = it;
+                }
+                gNorm += gii;
+                scatInt += Jf * gii;
+            }
         }
         const size_t o = (size_t)la * Ns + k;
         const double rhoNew = 1.0 + gammaPrefactor * (scatInt / gNorm - Jbar);
@@ -221,43 +313,45 @@ __global__ void __launch_bounds__(256) prd_scatter_kernel(const PrdLineArgs a)
     }
     if (threadIdx.x == 0)
     {
-        a.changeVal[k] = sBest[0];
-        a.changeIdx[k] = sBestIdx[0];
+        a.changeVal[k * gridDim.y + blockIdx.y] = sBest[0];
+        a.changeIdx[k * gridDim.y + blockIdx.y] = sBestIdx[0];
     }
 }
 
 // per line: max over depth of the per-depth maxima (first flattened index on ties)
-__global__ void prd_change_kernel(const double* changeVal, const int* changeIdx, int Ns, double* out2)
+__global__ void prd_change_kernel(const double* changeVal, const int* changeIdx, int nEntries, double* out2)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0)
-        return;
+    // one wavefront: max value, smallest flattened index on ties (max_idx semantics: strictly greater
+    // updates in index order, so the first occurrence wins; a zero maximum keeps idx 0)
+    const int lane = threadIdx.x;
     double best = 0.0;
-    int idx = 0;
-    bool any = false;
-    for (int k = 0; k < Ns; ++k)
+    int idx = 0x7fffffff;
+    for (int e = lane; e < nEntries; e += 64)
     {
-        const double v = changeVal[k];
-        const int i = changeIdx[k];
-        if (i == 0x7fffffff)
-            continue;
-        if (!any || v > best || (v == best && i < idx))
+        const double v = changeVal[e];
+        const int i = changeIdx[e];
+        if (i != 0x7fffffff && v > 0.0 && (v > best || (v == best && i < idx)))
         {
-            if (v > 0.0 || !any)
-            {
-                best = v;
-                idx = i;
-                any = true;
-            }
+            best = v;
+            idx = i;
         }
     }
-    // max_idx semantics (strictly greater updates, initial dMax = 0, idx = 0): a zero maximum keeps idx 0
-    if (!(best > 0.0))
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
     {
-        best = 0.0;
-        idx = 0;
+        const double v = __shfl_xor(best, off);
+        const int i = __shfl_xor(idx, off);
+        if (v > best || (v == best && i < idx))
+        {
+            best = v;
+            idx = i;
+        }
     }
-    out2[0] = best;
-    out2[1] = (double)idx;
+    if (lane == 0)
+    {
+        out2[0] = best;
+        out2[1] = (best > 0.0) ? (double)idx : 0.0;
+    }
 }
 
 hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t stream)
@@ -272,8 +366,10 @@ hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t st
             return err;
         configured = lds;
     }
-    hipLaunchKernelGGL(prd_scatter_kernel, dim3(a.Ns), dim3(256), lds, stream, a);
-    hipLaunchKernelGGL(prd_change_kernel, dim3(1), dim3(64), 0, stream, a.changeVal, a.changeIdx, a.Ns, out2);
+    hipLaunchKernelGGL(prd_transpose_kernel, dim3((a.Nl + 31) / 32, (a.Ns + 31) / 32), dim3(32, 8), 0, stream, a.J, a.Nblue,
+                       a.Nl, a.Ns, a.Jt);
+    hipLaunchKernelGGL(prd_scatter_kernel, dim3(a.Ns, a.slices), dim3(128), lds, stream, a);
+    hipLaunchKernelGGL(prd_change_kernel, dim3(1), dim3(64), 0, stream, a.changeVal, a.changeIdx, a.Ns * a.slices, out2);
     return hipGetLastError();
 }
 }
