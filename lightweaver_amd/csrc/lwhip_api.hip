@@ -145,6 +145,10 @@ struct lwhip_context
     bool prefillPending = false; // lwhip_gamma_prefill_from_C deferred into the next apply_kernel
     double prefillCrsw = 1.0;
     double* gatherPinned = nullptr;
+    // pinned staging for the many small per-atom / per-transition host arrays: they are packed here and
+    // cross PCIe as a few large copies (a pageable hipMemcpy per 656-byte row costs ~12 us each)
+    double* stage = nullptr;
+    size_t stageDoubles = 0;
 
     ~lwhip_context()
     {
@@ -157,6 +161,8 @@ struct lwhip_context
             (void)hipStreamDestroy(ownStream);
         if (gatherPinned)
             (void)hipHostFree(gatherPinned);
+        if (stage)
+            (void)hipHostFree(stage);
         if (prdPinned)
             (void)hipHostFree(prdPinned);
     }
@@ -1282,20 +1288,37 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     std::vector<double> ratioHost;
     if (mask & LWHIP_NSTAR)
         ratioHost.assign((size_t)std::max(c->Ncont, 1) * Ns, 1.0);
+    // staging layout (doubles): [n pool][Gamma pool][C pool][Rij][Rji]
+    const size_t nPool = (size_t)c->NlevTot * Ns, gPool = (size_t)c->gammaTot, rPool = (size_t)c->Ntrans * Ns;
+    if (!c->stage)
+    {
+        c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 8;
+        HIP_TRY(hipHostMalloc((void**)&c->stage, c->stageDoubles * sizeof(double), hipHostMallocDefault));
+    }
+    double* stN = c->stage;
+    double* stG = stN + nPool;
+    double* stC = stG + gPool;
+    double* stRij = stC + gPool;
+    double* stRji = stRij + rPool;
+    bool anyC = false, anyR = false;
     for (int ia = 0; ia < c->Natom; ++ia)
     {
         const lwhip_atom& a = c->atoms[ia];
         if (mask & LWHIP_POPS)
-            H2D(c->n.p + (size_t)c->levelOff[ia] * Ns, a.n, (size_t)a.Nlevel * Ns);
+            std::memcpy(stN + (size_t)c->levelOff[ia] * Ns, a.n, (size_t)a.Nlevel * Ns * sizeof(double));
         if (mask & LWHIP_NSTAR)
         {
             H2D(c->nTotal.p + (size_t)ia * Ns, a.nTotal, Ns);
             H2D(c->vBroad.p + (size_t)ia * Ns, a.vBroad, Ns);
         }
         if (!a.detailed && (mask & LWHIP_GAMMA))
-            H2D(c->Gamma.p + c->gammaOff[ia], a.Gamma, (size_t)a.Nlevel * a.Nlevel * Ns);
+            std::memcpy(stG + c->gammaOff[ia], a.Gamma, (size_t)a.Nlevel * a.Nlevel * Ns * sizeof(double));
         if (!a.detailed && (mask & LWHIP_COLLISIONS) && a.C)
+        {
+            // atoms without C keep whatever the pool holds: copy atom by atom, not the whole pool
             H2D(c->Cmat.p + c->gammaOff[ia], a.C, (size_t)a.Nlevel * a.Nlevel * Ns);
+            anyC = true;
+        }
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
             const HostTrans& h = c->trans[c->atomTrOff[ia] + kr];
@@ -1304,8 +1327,9 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
             if ((mask & LWHIP_RATES) && t.Rij && t.Rji)
             {
                 const size_t tr = c->atomTrOff[ia] + kr;
-                H2D(c->Rij.p + tr * Ns, t.Rij, Ns);
-                H2D(c->Rji.p + tr * Ns, t.Rji, Ns);
+                std::memcpy(stRij + tr * Ns, t.Rij, Ns * sizeof(double));
+                std::memcpy(stRji + tr * Ns, t.Rji, Ns * sizeof(double));
+                anyR = true;
             }
             if (t.type == LWHIP_LINE)
             {
@@ -1331,6 +1355,17 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                     ratioHost[(size_t)h.row * Ns + k] = ni[k] / nj[k];
             }
         }
+    }
+    (void)anyC;
+    if ((mask & LWHIP_POPS) && nPool)
+        H2D(c->n.p, stN, nPool);
+    if ((mask & LWHIP_GAMMA) && gPool)
+        H2D(c->Gamma.p, stG, gPool);
+    if (anyR)
+    {
+        // only complete sets are uploaded this way (every transition has host Rij/Rji in this ABI)
+        H2D(c->Rij.p, stRij, rPool);
+        H2D(c->Rji.p, stRji, rPool);
     }
     if (mask & LWHIP_NSTAR)
         H2D(c->ratio.p, ratioHost.data(), ratioHost.size());
@@ -1362,22 +1397,31 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
         D2H(p.depthEta + l0 * Nr * 2 * Ns, c->depthEta.p, Nla * Nr * 2 * Ns);
         D2H(p.depthI + l0 * Nr * 2 * Ns, c->depthI.p, Nla * Nr * 2 * Ns);
     }
+    const size_t nPool = (size_t)c->NlevTot * Ns, gPool = (size_t)c->gammaTot, rPool = (size_t)c->Ntrans * Ns;
+    if (!c->stage)
+    {
+        c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 8;
+        HIP_TRY(hipHostMalloc((void**)&c->stage, c->stageDoubles * sizeof(double), hipHostMallocDefault));
+    }
+    double* stN = c->stage;
+    double* stG = stN + nPool;
+    double* stRij = stG + 2 * gPool;
+    double* stRji = stRij + rPool;
+    if ((mask & LWHIP_POPS) && nPool)
+        D2H(stN, c->n.p, nPool);
+    if ((mask & LWHIP_GAMMA) && gPool)
+        D2H(stG, c->Gamma.p, gPool);
+    if ((mask & LWHIP_RATES) && rPool)
+    {
+        D2H(stRij, c->Rij.p, rPool);
+        D2H(stRji, c->Rji.p, rPool);
+    }
     for (int ia = 0; ia < c->Natom; ++ia)
     {
-        const lwhip_atom& a = c->atoms[ia];
-        if (mask & LWHIP_POPS)
-            D2H(a.n, c->n.p + (size_t)c->levelOff[ia] * Ns, (size_t)a.Nlevel * Ns);
-        if (!a.detailed && (mask & LWHIP_GAMMA))
-            D2H(a.Gamma, c->Gamma.p + c->gammaOff[ia], (size_t)a.Nlevel * a.Nlevel * Ns);
-        for (int kr = 0; kr < a.Ntrans; ++kr)
+        for (int kr = 0; kr < c->atoms[ia].Ntrans; ++kr)
         {
             const int tr = c->atomTrOff[ia] + kr;
             const HostTrans& h = c->trans[tr];
-            if (mask & LWHIP_RATES)
-            {
-                D2H(h.t.Rij, c->Rij.p + (size_t)tr * Ns, Ns);
-                D2H(h.t.Rji, c->Rji.p + (size_t)tr * Ns, Ns);
-            }
             if ((mask & LWHIP_RHOPRD) && h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && h.NredLoc > h.NblueLoc)
                 D2H(h.t.rhoPrd + (size_t)h.ltStart * Ns, c->rho.p + h.rhoOff, (size_t)(h.NredLoc - h.NblueLoc) * Ns);
             if ((mask & LWHIP_PROFILES) && h.t.type == LWHIP_LINE)
@@ -1390,6 +1434,25 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // unpack the staged pools into the caller's arrays
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        const lwhip_atom& a = c->atoms[ia];
+        if (mask & LWHIP_POPS)
+            std::memcpy(a.n, stN + (size_t)c->levelOff[ia] * Ns, (size_t)a.Nlevel * Ns * sizeof(double));
+        if (!a.detailed && (mask & LWHIP_GAMMA))
+            std::memcpy(a.Gamma, stG + c->gammaOff[ia], (size_t)a.Nlevel * a.Nlevel * Ns * sizeof(double));
+        if (mask & LWHIP_RATES)
+        {
+            for (int kr = 0; kr < a.Ntrans; ++kr)
+            {
+                const size_t tr = c->atomTrOff[ia] + kr;
+                const HostTrans& h = c->trans[tr];
+                std::memcpy(h.t.Rij, stRij + tr * Ns, Ns * sizeof(double));
+                std::memcpy(h.t.Rji, stRji + tr * Ns, Ns * sizeof(double));
+            }
+        }
+    }
     return LWHIP_OK;
 }
 
