@@ -114,7 +114,10 @@ struct lwhip_context
     DevBuf<double> prdChange, prdOut, rowsBuf, popScratch, prdJt;
     std::vector<std::unique_ptr<DevBuf<double>>> gII; // per transition: cached PRD weights (lazily)
     std::vector<char> gIIValid;
-    DevBuf<NrAtom> nrAtoms;
+    DevBuf<NrAtom> nrAtoms, statEqAtoms;
+    int statEqKey = -2;
+    int32_t* statusHost = nullptr;
+    int32_t* statusDev = nullptr;
     DevBuf<int32_t> transType;
     DevBuf<int32_t> contLa;
     DevBuf<int32_t> prdChangeIdx;
@@ -163,6 +166,8 @@ struct lwhip_context
             (void)hipHostFree(gatherPinned);
         if (stage)
             (void)hipHostFree(stage);
+        if (statusHost)
+            (void)hipHostFree(statusHost);
         if (prdPinned)
             (void)hipHostFree(prdPinned);
     }
@@ -1605,7 +1610,15 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
         if (stp != LWHIP_OK)
             return stp;
     }
-    HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+    // one launch for all requested atoms; the status word lives in host-mapped pinned memory, so the
+    // call needs no memset kernel and no read-back copy, only the stream synchronisation
+    if (!c->statusHost)
+    {
+        HIP_TRY(hipHostMalloc((void**)&c->statusHost, sizeof(int32_t), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&c->statusDev, c->statusHost, 0));
+    }
+    std::vector<NrAtom> atoms;
+    int maxNl = 0;
     for (int ia = 0; ia < c->Natom; ++ia)
     {
         if (atom >= 0 && ia != atom)
@@ -1613,14 +1626,33 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
         const lwhip_atom& a = c->atoms[ia];
         if (a.detailed)
             continue;
-        HIP_TRY(launch_stat_eq(a.Nlevel, c->Ns, c->n.p + (size_t)c->levelOff[ia] * c->Ns,
-                               c->nTotal.p + (size_t)ia * c->Ns, c->Gamma.p + c->gammaOff[ia],
-                               c->status.p, c->stream));
+        NrAtom at{};
+        at.atom = ia;
+        at.Nlevel = a.Nlevel;
+        at.levelOff = c->levelOff[ia];
+        at.gammaOff = c->gammaOff[ia];
+        atoms.push_back(at);
+        maxNl = std::max(maxNl, a.Nlevel);
     }
-    int32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (atoms.empty())
+        return LWHIP_OK;
+    if (c->statEqKey != atom || c->statEqAtoms.n < atoms.size())
+    {
+        HIP_TRY(c->statEqAtoms.upload(atoms));
+        c->statEqKey = atom;
+    }
+    *c->statusHost = 0;
+    StatEqArgs sa{};
+    sa.Ns = c->Ns;
+    sa.Natoms = (int32_t)atoms.size();
+    sa.atoms = c->statEqAtoms.p;
+    sa.n = c->n.p;
+    sa.nTotal = c->nTotal.p;
+    sa.Gamma = c->Gamma.p;
+    sa.status = c->statusDev;
+    HIP_TRY(launch_stat_eq(sa, maxNl, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (st == LWHIP_ERR_SINGULAR)
+    if (*c->statusHost == LWHIP_ERR_SINGULAR)
         return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
     return LWHIP_OK;
 }

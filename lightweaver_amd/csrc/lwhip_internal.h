@@ -271,6 +271,16 @@ struct NrArgs
     double dt, crsw;
     int32_t* status;
 };
+struct StatEqArgs
+{
+    int32_t Ns, Natoms;
+    const NrAtom* atoms;        // the atoms to solve (atom, Nlevel, levelOff, gammaOff used)
+    double* n;                  // pool
+    const double* nTotal;       // [Natom, Ns]
+    const double* Gamma;        // pool
+    int32_t* status;            // host-mapped: LWHIP_ERR_SINGULAR is written straight into pinned memory
+};
+hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream);
 hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream);
 hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
                            int* status, hipStream_t stream);
@@ -288,6 +298,4 @@ size_t march_lds_bytes(const SweepArgs& a, int wavesPerGroup);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
-hipError_t launch_stat_eq(int Nlevel, int Ns, double* n, const double* nTotal, const double* Gamma,
-                          int* status, hipStream_t stream);
 }

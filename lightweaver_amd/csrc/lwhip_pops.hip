@@ -172,12 +172,18 @@ static hipError_t solve_set_lds(const void* fn, size_t lds)
 }
 
 // ---- stat_eq_impl: Source/UpdatePopulations.cpp:7-47 -------------------------------------------------------
-__global__ void stat_eq_kernel(int N, int Ns, double* n, const double* nTotal, const double* Gamma, int* status)
+// blockIdx.y selects the atom, so every active atom is solved by one launch
+__global__ void stat_eq_kernel(const StatEqArgs a)
 {
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ns = a.Ns;
     if (k >= Ns)
         return;
+    const NrAtom at = a.atoms[blockIdx.y];
+    const int N = at.Nlevel;
+    double* n = a.n + (size_t)at.levelOff * Ns;
+    const double* Gamma = a.Gamma + at.gammaOff;
     const SolveWs w(lds, N, blockDim.x, threadIdx.x);
     // Gamma_k and the elimination row: the level with the largest population
     int iElim = 0;
@@ -198,28 +204,26 @@ __global__ void stat_eq_kernel(int N, int Ns, double* n, const double* nTotal, c
         w.A[iElim * N + i] = 1.0;
         w.b[i] = 0.0;
     }
-    w.b[iElim] = nTotal[k];
+    w.b[iElim] = a.nTotal[(size_t)at.atom * Ns + k];
     if (!d_solve_lin_eq(N, w))
     {
-        atomicExch(status, LWHIP_ERR_SINGULAR);
+        atomicExch(a.status, LWHIP_ERR_SINGULAR);
         return;
     }
     for (int i = 0; i < N; ++i)
         n[(size_t)i * Ns + k] = w.b[i];
 }
 
-hipError_t launch_stat_eq(int Nlevel, int Ns, double* n, const double* nTotal, const double* Gamma,
-                          int* status, hipStream_t stream)
+hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream)
 {
-    if (Nlevel > 64)
+    if (maxNlevel > 64 || a.Natoms <= 0)
         return hipErrorInvalidValue;
-    const int tb = solve_block_threads(Nlevel);
-    const size_t lds = solve_ws_doubles(Nlevel) * sizeof(double) * tb;
+    const int tb = solve_block_threads(maxNlevel);
+    const size_t lds = solve_ws_doubles(maxNlevel) * sizeof(double) * tb;
     hipError_t e = solve_set_lds((const void*)stat_eq_kernel, lds);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(stat_eq_kernel, dim3((Ns + tb - 1) / tb), dim3(tb), lds, stream, Nlevel, Ns, n, nTotal, Gamma,
-                       status);
+    hipLaunchKernelGGL(stat_eq_kernel, dim3((a.Ns + tb - 1) / tb, a.Natoms), dim3(tb), lds, stream, a);
     return hipGetLastError();
 }
 
