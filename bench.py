@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-matrix) peak, same guide
 
 
 def parse():
@@ -57,6 +58,19 @@ def profiled_traffic():
         return d.get('sweep_traffic_bytes_per_launch'), os.path.basename(files[-1])
     except Exception:
         return None, None
+
+
+def algorithmic_flops(prob, la0, la1):
+    """fp64 operations one iteration needs on wavelengths [la0, la1), by SURVEY.md section 8(d)'s count:
+    per (wavelength, ray, depth) ~120 for the Bezier3 short characteristic (incl. one exp and ~10
+    divisions) + 12 per active transition in the gather + 22 per active transition in the rates."""
+    import numpy as np
+    active = np.zeros(prob.Nlambda)
+    for a in prob.atoms:
+        for t in a.trans:
+            active[t.Nblue:t.Nred] += 1
+    per_point = 120.0 + 34.0 * active[la0:la1]
+    return float(per_point.sum() * 2 * prob.Nrays * prob.Nspace)
 
 
 def cpu_baseline(prob, budget_s):
@@ -150,6 +164,7 @@ def main():
     sweep_ms, nlaunch = ctx.sweep_time()
     ctx.profile_enable(False)
     alg_bytes = ctx.algorithmic_bytes()
+    alg_flops = algorithmic_flops(prob, la0, la1)
 
     # not part of the metric ("report stat_eq time separately"): the population solve
     aux = {}
@@ -215,6 +230,15 @@ def main():
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'kernel_ms': sweep_ms,
                 'launches_timed': nlaunch,
+                # what actually limits the kernel: fp64 vector issue, not HBM
+                'secondary': {
+                    'bound': 'fp64 vector (no MFMA: stencil + scan, not a contraction)',
+                    'achieved': alg_flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0,
+                    'peak': FP64_VECTOR_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s',
+                    'frac': (alg_flops / (sweep_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if sweep_ms > 0 else 0.0,
+                    'algorithmic_flops_per_launch': alg_flops,
+                },
             },
         }
         if aux:

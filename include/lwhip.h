@@ -244,6 +244,11 @@ int lwhip_formal_sol(lwhip_context* ctx, int upOnly);
  * scaling, partial pivoting and one refinement pass; n overwritten on the device.
  * Returns LWHIP_ERR_SINGULAR where the reference throws "Singular Matrix". */
 int lwhip_stat_equil(lwhip_context* ctx, int atom);
+/* The same without waiting: the solve is queued on the context's stream and a singular matrix is
+ * remembered; lwhip_check_status waits for the stream and returns (and clears) that condition.
+ * For batches of contexts whose solves should overlap instead of serialising on a host wait each. */
+int lwhip_stat_equil_async(lwhip_context* ctx, int atom);
+int lwhip_check_status(lwhip_context* ctx);
 
 /* PRD sub-iterations (redistribute_prd_lines): for every PRD line of an active atom, the
  * total depopulation + elastic rate, the angle-averaged scattering integral with Gouttebroze's

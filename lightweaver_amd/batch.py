@@ -11,7 +11,7 @@ from __future__ import annotations
 from typing import Callable, List, Optional, Sequence
 
 from . import _abi as abi
-from .context import Context
+from .context import Context, _check
 from .model import Problem
 
 
@@ -24,9 +24,15 @@ def columns_of_rank(ncolumns: int, world: int, rank: int) -> List[int]:
 
 class ColumnBatch:
     def __init__(self, problems: Sequence[Problem], device: int = 0, stream: Optional[int] = None,
-                 device_profiles: bool = True):
+                 device_profiles: bool = True, streams: Optional[Sequence[int]] = None):
+        """`streams`: optional HIP streams (handles) the columns are dealt to round-robin, so that the
+        small reduce / apply / solve kernels of one column overlap the sweep of the next."""
         self.problems = list(problems)
-        self.contexts = [Context(p, device=device, stream=stream) for p in self.problems]
+        if streams:
+            self.contexts = [Context(p, device=device, stream=streams[i % len(streams)])
+                             for i, p in enumerate(self.problems)]
+        else:
+            self.contexts = [Context(p, device=device, stream=stream) for p in self.problems]
         if device_profiles:
             for c in self.contexts:
                 c.compute_profiles(deviceResident=True)
@@ -45,23 +51,32 @@ class ColumnBatch:
     def __exit__(self, *exc):
         self.close()
 
-    def formal_sol_gamma_matrices(self, lambdaIterate=False):
+    def formal_sol_gamma_matrices(self, lambdaIterate=False, sync_host=True):
         """One iteration of every column; kernels of all columns are queued before the first
-        result is read back."""
+        result is read back.  sync_host=False reads nothing back (no host wait per column): use it for
+        all but the iterations whose dJMax is wanted."""
         for c in self.contexts:
             c.gamma_prefill_from_C(c.crsw)
             c.fs_partial(lambdaIterate)
+        if not sync_host:
+            for c in self.contexts:
+                _check(c.lib, c.lib.lwhip_fs_finalise(c._h, None), 'lwhip_fs_finalise')
+            return None
         return [c.fs_finalise() for c in self.contexts]
 
     def stat_equil(self):
+        """Queued for every column without a host wait in between; one status check at the end."""
         for c in self.contexts:
-            c.stat_equil(deviceResident=True)
+            c.stat_equil(deviceResident=True, sync_host=False)
+        for c in self.contexts:
+            c.check_status()
 
     def iterate(self, niter: int, nscatter: int = 3, callback: Optional[Callable] = None):
         """iterate_ctx_se-style loop (lightweaver/iterate_ctx.py:157-176) over the whole batch."""
         ups = []
         for it in range(niter):
-            ups = self.formal_sol_gamma_matrices()
+            want = callback is not None or it == niter - 1
+            ups = self.formal_sol_gamma_matrices(sync_host=want)
             if it >= nscatter:
                 self.stat_equil()
             if callback is not None:

@@ -159,11 +159,15 @@ class Context:
         if not deviceResident:
             self.download(abi.I)
 
-    def stat_equil(self, deviceResident=False, atom=-1):
+    def stat_equil(self, deviceResident=False, atom=-1, sync_host=True):
         """Statistical equilibrium for every active atom; raises ExplodingMatrixError on a
-        singular matrix as the reference does."""
+        singular matrix as the reference does.  With deviceResident and sync_host=False the solve is
+        only queued; `check_status()` later waits and raises."""
         if not deviceResident:
             self.upload(abi.GAMMA | abi.POPS)
+        if deviceResident and not sync_host:
+            _check(self.lib, self.lib.lwhip_stat_equil_async(self._h, atom), 'lwhip_stat_equil_async')
+            return IterationUpdate(updatedPops=True)
         _check(self.lib, self.lib.lwhip_stat_equil(self._h, atom), 'lwhip_stat_equil')
         if not deviceResident:
             self.download(abi.POPS)
@@ -231,6 +235,9 @@ class Context:
         if not deviceResident:
             self.download(abi.POPS)
         return IterationUpdate(updatedPops=True)
+
+    def check_status(self):
+        _check(self.lib, self.lib.lwhip_check_status(self._h), 'lwhip_check_status')
 
     def compute_profiles(self, deviceResident=False):
         _check(self.lib, self.lib.lwhip_compute_profiles(self._h), 'lwhip_compute_profiles')

@@ -1600,7 +1600,33 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
     return LWHIP_OK;
 }
 
+static int stat_equil_impl(lwhip_context* c, int atom, bool wait);
+
 int lwhip_stat_equil(lwhip_context* c, int atom)
+{
+    return stat_equil_impl(c, atom, true);
+}
+
+int lwhip_stat_equil_async(lwhip_context* c, int atom)
+{
+    return stat_equil_impl(c, atom, false);
+}
+
+int lwhip_check_status(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->statusHost && *c->statusHost == LWHIP_ERR_SINGULAR)
+    {
+        *c->statusHost = 0;
+        return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+    }
+    return LWHIP_OK;
+}
+
+static int stat_equil_impl(lwhip_context* c, int atom, bool wait)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
@@ -1641,7 +1667,8 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
         HIP_TRY(c->statEqAtoms.upload(atoms));
         c->statEqKey = atom;
     }
-    *c->statusHost = 0;
+    if (wait)
+        *c->statusHost = 0; // (the async form accumulates until lwhip_check_status)
     StatEqArgs sa{};
     sa.Ns = c->Ns;
     sa.Natoms = (int32_t)atoms.size();
@@ -1651,6 +1678,8 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
     sa.Gamma = c->Gamma.p;
     sa.status = c->statusDev;
     HIP_TRY(launch_stat_eq(sa, maxNl, c->stream));
+    if (!wait)
+        return LWHIP_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (*c->statusHost == LWHIP_ERR_SINGULAR)
         return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");

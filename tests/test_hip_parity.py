@@ -244,6 +244,11 @@ def test_stat_equil_singular_raises(gpu):
         ctx.upload(abi.GAMMA)
         with pytest.raises(ExplodingMatrixError):
             ctx.stat_equil(deviceResident=True)
+        # the queued form reports it at the status check, once
+        ctx.stat_equil(deviceResident=True, sync_host=False)
+        with pytest.raises(ExplodingMatrixError):
+            ctx.check_status()
+        ctx.check_status()
 
 
 def test_linearity_of_formal_solution(gpu):
