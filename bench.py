@@ -132,13 +132,18 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     Nla_total = args.nlambda * world
-    prob = models.throughput_grid(NlambdaTarget=Nla_total, Nrays=5)
+    # the line profiles are generated on the device (lwhip_compute_profiles), shard by shard: the host
+    # never computes or ships the [Nlambda_line, Nmu, 2, Nspace] profile arrays
+    prob = models.throughput_grid(NlambdaTarget=Nla_total, Nrays=5, computeProfiles=False)
+    if abs(prob.Nlambda - Nla_total) > 0.01 * Nla_total:
+        sys.exit(f'workload generator produced {prob.Nlambda} wavelengths, wanted {Nla_total}')
     bounds = shard_bounds(prob, world)
     la0, la1 = bounds[rank], bounds[rank + 1]
 
     stream = torch.cuda.current_stream()
     ctx = Context(prob, device=local_rank, laStart=la0, laEnd=la1, stream=stream.cuda_stream,
                   worldSize=world, worldRank=rank)
+    ctx.compute_profiles(deviceResident=True)
     it = ShardedIteration(ctx, world, rank)
 
     def step():
@@ -245,7 +250,8 @@ def main():
             out['aux'] = aux
         if world == 1 and not args.no_cpu_baseline:
             try:
-                single = prob if prob.Nlambda == args.nlambda else models.throughput_grid(args.nlambda, 5)
+                single = prob.copy()
+                models.compute_profiles_host(single)   # the CPU leg needs phi on the host
                 out['cpu_baseline'] = cpu_baseline(single, args.cpu_seconds)
             except Exception as e:  # the baseline must never break the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': 0, 'kind': 'port',

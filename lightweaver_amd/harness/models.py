@@ -213,6 +213,17 @@ def _damping(m: AtomModel, l: LineModel, Aji_all, lambda0, vBroad, atmos: Atmosp
     return (gRad + gEl) * lambda0 * ph.NM_TO_M / (4.0 * np.pi * vBroad), gEl
 
 
+def grid_size(models: List[AtomModel], lambdaReference=500.0) -> int:
+    """Number of points of the global wavelength grid build_problem would make (no arrays built)."""
+    own = []
+    for m in models:
+        for l in m.lines:
+            own.append(ph.line_quadrature(m.lambda0(l.i, l.j), l.qCore, l.qWing, l.Nlambda))
+        for c in m.continua:
+            own.append(np.linspace(c.minLambda, m.lambda0(c.i, c.j), c.Nlambda))
+    return int(np.unique(np.concatenate(own + [np.array([lambdaReference])])).size)
+
+
 def build_problem(atmos: Atmosphere1d, models: List[AtomModel], Nrays=5,
                   formalSolver=abi.FS_BEZIER3_1D, detailed: Tuple[str, ...] = (),
                   storeDepthData=False, lambdaReference=500.0, computeProfiles=True) -> Problem:
@@ -323,17 +334,22 @@ def falc_h(Nrays=5, lineScale=1.0, formalSolver=abi.FS_BEZIER3_1D, **kw) -> Prob
 
 def throughput_grid(NlambdaTarget=10240, Nrays=5, **kw) -> Problem:
     """FAL-C H + Ca II with the line/continuum quadratures scaled so that the global grid has
-    ~NlambdaTarget points (north-star synthetic throughput grid, Ndepth = 82, Nmu = 5)."""
+    ~NlambdaTarget points (north-star synthetic throughput grid, Ndepth = 82, Nmu = 5; N x 10 240
+    for the N-GPU weak-scaling runs)."""
+    prd = kw.get('prd', False)
+    size = lambda ls: grid_size([H_6(ls), CaII_6(ls, prd=prd)])
     lo, hi = 1.0, 40.0
-    best = None
-    for _ in range(24):
+    while size(hi) < NlambdaTarget and hi < 1e5:
+        lo, hi = hi, hi * 4.0
+    best = hi
+    for _ in range(40):
         mid = 0.5 * (lo + hi)
-        p = falc_h_ca(Nrays=Nrays, lineScale=mid, computeProfiles=False, **kw)
+        n = size(mid)
         best = mid
-        if p.Nlambda < NlambdaTarget:
+        if n < NlambdaTarget:
             lo = mid
         else:
             hi = mid
-        if p.Nlambda == NlambdaTarget:
+        if n == NlambdaTarget:
             break
     return falc_h_ca(Nrays=Nrays, lineScale=best, **kw)
