@@ -257,7 +257,8 @@ int lwhip_check_status(lwhip_context* ctx);
  * at most maxIter times, until max |d rho / rho| < tol.  rhoPrd, J, Rij/Rji stay on the device.
  * `dRho`/`dRhoMaxIdx` receive one entry per (sub-iteration, PRD line), `dJPrdMax`/`dJPrdMaxIdx`
  * one per sub-iteration; capacities maxIter * Nprd and maxIter (any may be NULL).
- * Not available on a wavelength shard (needs J over each PRD line's whole grid). */
+ * On a wavelength shard use the split form below (the scattering integral needs J over each PRD
+ * line's whole grid, which one all-reduce provides). */
 typedef struct lwhip_prd_result {
     int32_t NprdSubIter;
     int32_t Nprd;          /* number of PRD lines */
@@ -267,6 +268,19 @@ typedef struct lwhip_prd_result {
     int32_t* dJPrdMaxIdx;
 } lwhip_prd_result;
 int lwhip_redistribute_prd(lwhip_context* ctx, int maxIter, double tol, lwhip_prd_result* res);
+
+/* One PRD sub-iteration across wavelength shards ("all-gather J rows of PRD lambda
+ * before prd_scatter"), split around its two collectives:
+ *   lwhip_prd_pack      this shard's J rows of every PRD line into the gather buffer (zero elsewhere);
+ *                       devPtr/count describe it: all-reduce(SUM) it over the shards;
+ *   lwhip_prd_partial   rho for this shard's emission wavelengths, max |d rho / rho| per line into this
+ *                       shard's slots of the reduce tail, then the PRD rates pass + slab reduce;
+ *                       all-reduce(SUM) the buffer of lwhip_reduce_buffer (nSum + nGather doubles);
+ *   lwhip_prd_finalise  Rij/Rji of the PRD lines out; per-line (dRho, idx) [Nprd] and (dJMax, idx).
+ * lwhip_redistribute_prd is this loop on one device. */
+int lwhip_prd_pack(lwhip_context* ctx, void** devPtr, size_t* count);
+int lwhip_prd_partial(lwhip_context* ctx);
+int lwhip_prd_finalise(lwhip_context* ctx, double* dRho, int32_t* dRhoMaxIdx, double* dJMax, int32_t* dJMaxIdx);
 
 /* time_dependent_update (FsIterationFns::time_dep_update, Source/LwFormalInterface.hpp:92,123;
  * time_dependent_update_impl, Source/UpdatePopulations.cpp:120-151): for atom `atom`, per depth

@@ -125,6 +125,9 @@ SYMBOLS = [
     ('lwhip_check_status', C.c_int, [ctx_p]),
     ('lwhip_compute_profiles', C.c_int, [ctx_p]),
     ('lwhip_redistribute_prd', C.c_int, [ctx_p, C.c_int, C.c_double, C.POINTER(lwhip_prd_result)]),
+    ('lwhip_prd_pack', C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ('lwhip_prd_partial', C.c_int, [ctx_p]),
+    ('lwhip_prd_finalise', C.c_int, [ctx_p, f64p, i32p, f64p, i32p]),
     ('lwhip_time_dep_update', C.c_int, [ctx_p, C.c_int, f64p, C.c_double]),
     ('lwhip_nr_post_update', C.c_int, [ctx_p, C.POINTER(lwhip_nr_args)]),
     ('lwhip_synchronize', C.c_int, [ctx_p]),

@@ -202,6 +202,32 @@ class Context:
 
     redistribute_prd = prd_redistribute
 
+    # -- PRD sub-iteration split around its two collectives (wavelength shards) ------------------------
+    def prd_pack(self):
+        """(device pointer, count) of the PRD J gather buffer, this shard's rows filled."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib, self.lib.lwhip_prd_pack(self._h, C.byref(ptr), C.byref(n)), 'lwhip_prd_pack')
+        return ptr.value, n.value
+
+    def prd_partial(self):
+        _check(self.lib, self.lib.lwhip_prd_partial(self._h), 'lwhip_prd_partial')
+
+    def prd_finalise(self):
+        """-> (dRho [Nprd], dRhoMaxIdx [Nprd], dJMax, dJMaxIdx) of the sub-iteration."""
+        Nprd = self.Nprd
+        dRho = np.zeros(max(Nprd, 1))
+        idx = np.zeros(max(Nprd, 1), dtype=np.int32)
+        dJ, dJIdx = C.c_double(0.0), C.c_int32(0)
+        _check(self.lib, self.lib.lwhip_prd_finalise(self._h, dRho.ctypes.data_as(abi.f64p), idx.ctypes.data_as(abi.i32p),
+                                                     C.cast(C.byref(dJ), abi.f64p), C.cast(C.byref(dJIdx), abi.i32p)),
+               'lwhip_prd_finalise')
+        return dRho[:Nprd], idx[:Nprd], dJ.value, dJIdx.value
+
+    @property
+    def Nprd(self):
+        return sum(1 for a in self.prob.atoms if not a.detailed for t in a.trans
+                   if t.type == abi.LINE and t.rhoPrd is not None)
+
     def time_dep_update(self, dt, prevTimePops, deviceResident=False, atom=None) -> IterationUpdate:
         """Backward-Euler population update, LwContext.time_dep_update (Source/LwMiddleLayer.pyx:3348-3420
         drives Source/UpdatePopulations.cpp:120-151 per atom): solve (1 - dt Gamma) n = nOld per depth.

@@ -73,6 +73,8 @@ template <typename T> struct DevBuf
     ~DevBuf() { release(); }
 };
 
+enum { PRD_MAX_SLICES = 32 }; // workgroups per depth point in the PRD scattering integral
+
 struct HostTrans
 {
     lwhip_transition t;   // borrowed host pointers
@@ -111,7 +113,11 @@ struct lwhip_context
     DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
-    DevBuf<double> prdChange, prdOut, rowsBuf, popScratch, prdJt;
+    DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
+    std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
+    std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
+    int64_t prdRowsTot = 0;
+    bool prdPending = false;          // between lwhip_prd_partial and lwhip_prd_finalise
     std::vector<std::unique_ptr<DevBuf<double>>> gII; // per transition: cached PRD weights (lazily)
     std::vector<char> gIIValid;
     DevBuf<NrAtom> nrAtoms, statEqAtoms;
@@ -889,6 +895,21 @@ int build_tables(lwhip_context* c)
 int alloc_state(lwhip_context* c)
 {
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
+    // PRD lines of the active atoms in reference order (PrdTemplates.hpp:190-205) and the layout of the
+    // J gather buffer: the full grid of every PRD line, line after line (the same on every shard)
+    c->prdLines.clear();
+    c->prdRowOff.clear();
+    c->prdRowsTot = 0;
+    for (int tr = 0; tr < c->Ntrans; ++tr)
+    {
+        const HostTrans& h = c->trans[tr];
+        if (h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && !c->atoms[h.atom].detailed)
+        {
+            c->prdLines.push_back(tr);
+            c->prdRowOff.push_back(c->prdRowsTot);
+            c->prdRowsTot += h.t.Nred - h.t.Nblue;
+        }
+    }
     HIP_TRY(c->height.alloc(Ns));
     HIP_TRY(c->temperature.alloc(Ns));
     HIP_TRY(c->muz.alloc(Nr));
@@ -924,7 +945,7 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(c->Rji.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     HIP_TRY(c->partial.alloc((size_t)std::max(c->nChunks, c->nChunksPrd) * c->maxCT * 4 * Ns));
     // reduce buffer: [Ntrans,4,Ns] partial sums followed by one (dJMax, idx) slot per shard
-    HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize));
+    HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize * (1 + c->prdLines.size())));
     HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
     HIP_TRY(c->red8.alloc((size_t)std::max(c->Ntrans, 1) * LWHIP_REDUCE_SPLIT * 4 * Ns));
     c->gatherHost.assign(2 * (size_t)c->worldSize, 0.0);
@@ -1509,6 +1530,9 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         r.rank = c->worldRank;
         HIP_TRY(launch_reduce(r, c->stream));
     }
+    if (c->worldSize > 1 && !c->prdLines.empty()) // the PRD slots of the tail ride in the same all-reduce: keep them finite
+        HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
+                               2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
     c->partialPending = true;
     return LWHIP_OK;
 }
@@ -1586,7 +1610,7 @@ int lwhip_reduce_buffer(lwhip_context* c, void** devPtr, size_t* nSum, size_t* n
         return fail(LWHIP_ERR_INVALID, "null argument");
     *devPtr = c->red.p;
     *nSum = (size_t)c->Ntrans * 4 * c->Ns;
-    *nGather = 2 * (size_t)c->worldSize;
+    *nGather = 2 * (size_t)c->worldSize * (1 + c->prdLines.size());
     return LWHIP_OK;
 }
 
@@ -1824,32 +1848,264 @@ int lwhip_nr_post_update(lwhip_context* c, const lwhip_nr_args* args)
     return LWHIP_OK;
 }
 
-enum { PRD_MAX_SLICES = 32 };
+// ---- PRD sub-iterations.  One sub-iteration = pack (J of the PRD lines into the gather buffer) ->
+// [all-reduce of that buffer across wavelength shards] -> partial (scattering integral for the shard's
+// emission wavelengths, max change per line into the shard's slots of the reduce tail, the PRD rates
+// pass + slab reduce) -> [all-reduce of the reduce buffer] -> finalise (rates of the PRD lines out,
+// results read back).  lwhip_redistribute_prd runs the loop on one device.
+int lwhip_prd_pack(lwhip_context* c, void** devPtr, size_t* count)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->partialPending || c->prdPending)
+        return fail(LWHIP_ERR_INVALID, "lwhip_prd_pack inside an unfinished iteration / sub-iteration");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t Ns = c->Ns;
+    const size_t n = (size_t)std::max<int64_t>(c->prdRowsTot, 1) * Ns;
+    if (c->prdJ.n < n)
+        HIP_TRY(c->prdJ.alloc(n));
+    if (c->worldSize > 1)
+        HIP_TRY(hipMemsetAsync(c->prdJ.p, 0, n * sizeof(double), c->stream)); // rows of other shards: the all-reduce sums
+    for (size_t q = 0; q < c->prdLines.size(); ++q)
+    {
+        const HostTrans& h = c->trans[c->prdLines[q]];
+        const size_t nlt = h.NredLoc - h.NblueLoc;
+        if (nlt)
+            HIP_TRY(hipMemcpyAsync(c->prdJ.p + ((size_t)c->prdRowOff[q] + h.ltStart) * Ns, c->J.p + (size_t)h.NblueLoc * Ns,
+                                   nlt * Ns * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (devPtr)
+        *devPtr = c->prdJ.p;
+    if (count)
+        *count = (size_t)c->prdRowsTot * Ns;
+    return LWHIP_OK;
+}
+
+int lwhip_prd_partial(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->partialPending || c->prdPending)
+        return fail(LWHIP_ERR_INVALID, "lwhip_prd_partial inside an unfinished iteration / sub-iteration");
+    HIP_TRY(hipSetDevice(c->device));
+    const int Ns = c->Ns;
+    const int Nprd = (int)c->prdLines.size();
+    if (Nprd == 0)
+        return LWHIP_OK;
+    if (c->prdJ.n < (size_t)c->prdRowsTot * Ns)
+        return fail(LWHIP_ERR_INVALID, "lwhip_prd_partial before lwhip_prd_pack");
+    for (int tr : c->prdLines)
+        if (!c->atoms[c->trans[tr].atom].C)
+            return fail(LWHIP_ERR_INVALID, "redistribute_prd needs the collisional rates C of atom "
+                                           + std::to_string(c->trans[tr].atom));
+    if (c->prdChange.n < (size_t)Nprd * Ns * PRD_MAX_SLICES)
+    {
+        HIP_TRY(c->prdChange.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
+        HIP_TRY(c->prdChangeIdx.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
+    }
+    {
+        size_t maxNl = 1;
+        for (int tr : c->prdLines)
+            maxNl = std::max(maxNl, (size_t)(c->trans[tr].t.Nred - c->trans[tr].t.Nblue));
+        if (c->prdJt.n < maxNl * Ns)
+            HIP_TRY(c->prdJt.alloc(maxNl * Ns));
+    }
+    // PRD section of the reduce tail: [world][Nprd] x (max |d rho / rho|, flattened index)
+    double* prdTail = c->red.p + (size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize;
+    for (int q = 0; q < Nprd; ++q)
+    {
+        const int tr = c->prdLines[q];
+        const HostTrans& h = c->trans[tr];
+        const lwhip_atom& at = c->atoms[h.atom];
+        PrdLineArgs a{};
+        a.Ns = Ns;
+        a.Nl = h.t.Nred - h.t.Nblue;
+        a.Nblue = (int32_t)c->prdRowOff[q]; // rows of this line in the gather buffer
+        a.Nlevel = at.Nlevel;
+        a.tr = tr;
+        a.gi = c->levelOff[h.atom] + h.t.i;
+        a.gj = c->levelOff[h.atom] + h.t.j;
+        a.lj = h.t.j;
+        a.trBegin = c->atomTrOff[h.atom];
+        a.trEnd = c->atomTrOff[h.atom + 1];
+        a.lambda0 = h.t.lambda0;
+        a.Bij = h.t.Bij;
+        a.wave = c->lineWave.p + h.waveOff;
+        a.J = c->prdJ.p;
+        a.Jt = c->prdJt.p;
+        a.vBroad = c->vBroad.p + (size_t)h.atom * Ns;
+        a.aDamp = c->aDamp.p + (size_t)h.row * Ns;
+        a.Qelast = c->Qelast.p + (size_t)h.row * Ns;
+        a.Cmat = c->Cmat.p + c->gammaOff[h.atom];
+        a.n = c->n.p;
+        a.Rij = c->Rij.p;
+        a.Rji = c->Rji.p;
+        a.transLi = c->transLi.p;
+        a.transLj = c->transLj.p;
+        // this shard's emission wavelengths of the line: [laLo, laHi) in the line's own grid; its rho rows
+        a.laLo = h.ltStart;
+        a.laHi = h.ltStart + (h.NredLoc - h.NblueLoc);
+        a.rho = c->rho.p + h.rhoOff;
+        // enough workgroups to fill the chip: Ns x slices >= ~8 per CU, at least 128 wavelengths each
+        a.slices = std::max(1, std::min({ (int)PRD_MAX_SLICES, (2048 + Ns - 1) / Ns, (a.laHi - a.laLo + 127) / 128 }));
+        // gII weights depend only on aDamp, vBroad and the grid: cached across sub-iterations and
+        // iterations (the reference's t->gII), dropped when lwhip_upload(LWHIP_NSTAR) refreshes those
+        if (c->gII.size() != (size_t)c->Ntrans)
+        {
+            c->gII.resize(c->Ntrans);
+            c->gIIValid.assign(c->Ntrans, 0);
+        }
+        a.gII = nullptr;
+        a.gIIFill = 1;
+        if (env_int("LWHIP_PRD_CACHE", 1) && a.laHi > a.laLo)
+        {
+            // gII and the interpolation fractions (doubles) + the bracketing indices (int32) of the line
+            const size_t per = (size_t)Ns * 88 * a.Nl;
+            const size_t need = 2 * per + (per + 1) / 2;
+            if (!c->gII[tr])
+                c->gII[tr] = std::make_unique<DevBuf<double>>();
+            if (c->gII[tr]->n < need)
+            {
+                if (c->gII[tr]->alloc(need) != hipSuccess)
+                {
+                    (void)hipGetLastError(); // out of memory for the cache: recompute every time
+                    c->gII[tr].reset();
+                }
+                c->gIIValid[tr] = 0;
+            }
+            if (c->gII[tr])
+            {
+                a.gII = c->gII[tr]->p;
+                a.gTT = a.gII + per;
+                a.gIT = (int32_t*)(a.gTT + per);
+                a.gIIFill = c->gIIValid[tr] ? 0 : 1;
+                c->gIIValid[tr] = 1;
+            }
+        }
+        a.changeVal = c->prdChange.p + (size_t)q * Ns * PRD_MAX_SLICES;
+        a.changeIdx = c->prdChangeIdx.p + (size_t)q * Ns * PRD_MAX_SLICES;
+        a.tail = prdTail;
+        a.world = c->worldSize;
+        a.rank = c->worldRank;
+        a.q = q;
+        a.Nprd = Nprd;
+        HIP_TRY(launch_prd_scatter(a, c->stream));
+    }
+    // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
+    SweepDyn dyn = make_dyn(c, false, 0);
+    dyn.prdOnly = 1;
+    HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream)); // unvisited wavelengths: dJ = 0
+    if (c->nChunksPrd > 0)
+        HIP_TRY(run_sweep(c, dyn, true));
+    else
+        HIP_TRY(hipMemsetAsync(c->partial.p, 0, c->partial.n * sizeof(double), c->stream)); // a shard without PRD wavelengths
+    ReduceArgs r{};
+    r.Ns = Ns;
+    r.Ntrans = c->Ntrans;
+    r.maxCT = c->maxCT;
+    r.trOff = c->nChunksPrd > 0 ? c->trOffPrd.p : c->trOff.p;
+    r.trRow = c->nChunksPrd > 0 ? c->trRowPrd.p : c->trRow.p;
+    r.partial = c->partial.p;
+    r.red8 = c->red8.p;
+    r.red = c->red.p;
+    r.dJ = c->dJ.p;
+    r.Nla = c->Nla;
+    r.idxOffset = c->laStart;
+    r.world = c->worldSize;
+    r.rank = c->worldRank;
+    HIP_TRY(launch_reduce(r, c->stream));
+    c->prdPending = true;
+    return LWHIP_OK;
+}
+
+int lwhip_prd_finalise(lwhip_context* c, double* dRho, int32_t* dRhoMaxIdx, double* dJMax, int32_t* dJMaxIdx)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    const int Nprd = (int)c->prdLines.size();
+    if (Nprd == 0)
+        return LWHIP_OK;
+    if (!c->prdPending)
+        return fail(LWHIP_ERR_INVALID, "lwhip_prd_finalise without lwhip_prd_partial");
+    HIP_TRY(hipSetDevice(c->device));
+    const int Ns = c->Ns;
+    ApplyArgs ap{};
+    ap.Ns = Ns;
+    ap.Natom = c->Natom;
+    ap.atomTrOff = c->atomTrOffD.p;
+    ap.atomNlevel = c->atomNlevel.p;
+    ap.atomDetailed = c->atomDetailed.p;
+    ap.atomGammaOff = c->atomGammaOff.p;
+    ap.trans = c->dtrans.p;
+    ap.transLi = c->transLi.p;
+    ap.transLj = c->transLj.p;
+    ap.red = c->red.p;
+    ap.Gamma = c->Gamma.p;
+    ap.Rij = c->Rij.p;
+    ap.Rji = c->Rji.p;
+    ap.Cmat = c->Cmat.p;
+    ap.prdOnly = 1;
+    HIP_TRY(launch_apply(ap, c->stream));
+    c->prdPending = false;
+    const size_t nTail = 2 * (size_t)c->worldSize * (1 + Nprd);
+    if (!c->prdPinned)
+        HIP_TRY(hipHostMalloc((void**)&c->prdPinned, nTail * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(c->prdPinned, c->red.p + (size_t)c->Ntrans * 4 * Ns, nTail * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // max over shards, first (lowest) index on ties: max_idx, Constants.hpp:114-125
+    auto best_of = [&](const double* slots, size_t stride, double& v, int& idx) {
+        v = 0.0;
+        idx = 0;
+        bool any = false;
+        for (int rk = 0; rk < c->worldSize; ++rk)
+        {
+            const double x = slots[rk * stride];
+            const int i = (int)slots[rk * stride + 1];
+            if (!any || x > v || (x == v && i < idx))
+            {
+                if (x > 0.0 || !any)
+                {
+                    v = x;
+                    idx = i;
+                    any = true;
+                }
+            }
+        }
+        if (!(v > 0.0))
+        {
+            v = 0.0;
+            idx = 0;
+        }
+    };
+    double v;
+    int idx;
+    best_of(c->prdPinned, 2, v, idx);
+    if (dJMax)
+        *dJMax = v;
+    if (dJMaxIdx)
+        *dJMaxIdx = idx;
+    const double* prdTail = c->prdPinned + 2 * (size_t)c->worldSize;
+    for (int q = 0; q < Nprd; ++q)
+    {
+        best_of(prdTail + 2 * q, 2 * (size_t)Nprd, v, idx);
+        const int Nl = c->trans[c->prdLines[q]].t.Nred - c->trans[c->prdLines[q]].t.Nblue;
+        if (dRho)
+            dRho[q] = v;
+        if (dRhoMaxIdx) // the flattened [la, k] index modulo Nlambda, as PrdTemplates.hpp:265 reports it
+            dRhoMaxIdx[q] = idx % Nl;
+    }
+    return LWHIP_OK;
+}
 
 int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_result* res)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     if (c->worldSize > 1 || c->laStart != 0 || c->laEnd != c->prob.Nlambda)
-        return fail(LWHIP_ERR_UNSUPPORTED, "redistribute_prd needs the whole wavelength grid (not a shard)");
-    if (c->partialPending)
-        return fail(LWHIP_ERR_INVALID, "lwhip_redistribute_prd between lwhip_fs_partial and lwhip_fs_finalise");
-    HIP_TRY(hipSetDevice(c->device));
-    const int Ns = c->Ns;
-    // PRD lines of the active atoms, reference order (PrdTemplates.hpp:190-205)
-    std::vector<int> prd;
-    for (int tr = 0; tr < c->Ntrans; ++tr)
-    {
-        const HostTrans& h = c->trans[tr];
-        if (h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && !c->atoms[h.atom].detailed)
-        {
-            if (!c->atoms[h.atom].C)
-                return fail(LWHIP_ERR_INVALID, "redistribute_prd needs the collisional rates C of atom "
-                                               + std::to_string(h.atom));
-            prd.push_back(tr);
-        }
-    }
-    const int Nprd = (int)prd.size();
+        return fail(LWHIP_ERR_UNSUPPORTED, "redistribute_prd on a wavelength shard: use lwhip_prd_pack / _partial / "
+                                           "_finalise around the two all-reduces");
+    const int Nprd = (int)c->prdLines.size();
     if (res)
     {
         res->NprdSubIter = 0;
@@ -1857,154 +2113,34 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
     }
     if (Nprd == 0 || maxIter <= 0)
         return LWHIP_OK;
-    if (c->prdOut.n < (size_t)2 * Nprd)
-    {
-        HIP_TRY(c->prdOut.alloc((size_t)2 * Nprd));
-        HIP_TRY(c->prdChange.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
-        HIP_TRY(c->prdChangeIdx.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
-        if (c->prdPinned)
-            (void)hipHostFree(c->prdPinned);
-        HIP_TRY(hipHostMalloc((void**)&c->prdPinned, ((size_t)2 * Nprd + 2) * sizeof(double), hipHostMallocDefault));
-    }
-    {
-        size_t maxNl = 1;
-        for (int tr : prd)
-            maxNl = std::max(maxNl, (size_t)(c->trans[tr].t.Nred - c->trans[tr].t.Nblue));
-        if (c->prdJt.n < maxNl * Ns)
-            HIP_TRY(c->prdJt.alloc(maxNl * Ns));
-    }
-    const double* tail = c->red.p + (size_t)c->Ntrans * 4 * Ns;
+    std::vector<double> dRho(Nprd);
+    std::vector<int32_t> dRhoIdx(Nprd);
     int iter = 0;
     while (iter < maxIter)
     {
         ++iter;
-        for (int q = 0; q < Nprd; ++q)
-        {
-            const int tr = prd[q];
-            const HostTrans& h = c->trans[tr];
-            const lwhip_atom& at = c->atoms[h.atom];
-            PrdLineArgs a{};
-            a.Ns = Ns;
-            a.Nl = h.t.Nred - h.t.Nblue;
-            a.Nblue = h.t.Nblue;
-            a.Nlevel = at.Nlevel;
-            a.tr = tr;
-            a.gi = c->levelOff[h.atom] + h.t.i;
-            a.gj = c->levelOff[h.atom] + h.t.j;
-            a.lj = h.t.j;
-            a.trBegin = c->atomTrOff[h.atom];
-            a.trEnd = c->atomTrOff[h.atom + 1];
-            a.lambda0 = h.t.lambda0;
-            a.Bij = h.t.Bij;
-            a.wave = c->lineWave.p + h.waveOff;
-            a.J = c->J.p;
-            a.Jt = c->prdJt.p;
-            a.vBroad = c->vBroad.p + (size_t)h.atom * Ns;
-            a.aDamp = c->aDamp.p + (size_t)h.row * Ns;
-            a.Qelast = c->Qelast.p + (size_t)h.row * Ns;
-            a.Cmat = c->Cmat.p + c->gammaOff[h.atom];
-            a.n = c->n.p;
-            a.Rij = c->Rij.p;
-            a.Rji = c->Rji.p;
-            a.transLi = c->transLi.p;
-            a.transLj = c->transLj.p;
-            a.rho = c->rho.p + h.rhoOff;
-            // enough workgroups to fill the chip: Ns x slices >= ~4 per CU, at least 64 wavelengths each
-            a.slices = std::max(1, std::min({ (int)PRD_MAX_SLICES, (2048 + Ns - 1) / Ns, (a.Nl + 127) / 128 }));
-            // gII weights depend only on aDamp, vBroad and the grid: cached across sub-iterations and
-            // iterations (the reference's t->gII), dropped when lwhip_upload(LWHIP_NSTAR) refreshes those
-            if (c->gII.size() != (size_t)c->Ntrans)
-            {
-                c->gII.resize(c->Ntrans);
-                c->gIIValid.assign(c->Ntrans, 0);
-            }
-            a.gII = nullptr;
-            a.gIIFill = 1;
-            if (env_int("LWHIP_PRD_CACHE", 1))
-            {
-                // gII and the interpolation fractions (doubles) + the bracketing indices (int32) of the line
-                const size_t per = (size_t)Ns * 88 * a.Nl;
-                const size_t need = 2 * per + (per + 1) / 2;
-                if (!c->gII[tr])
-                    c->gII[tr] = std::make_unique<DevBuf<double>>();
-                if (c->gII[tr]->n < need)
-                {
-                    if (c->gII[tr]->alloc(need) != hipSuccess)
-                    {
-                        (void)hipGetLastError(); // out of memory for the cache: recompute every time
-                        c->gII[tr].reset();
-                    }
-                    c->gIIValid[tr] = 0;
-                }
-                if (c->gII[tr])
-                {
-                    a.gII = c->gII[tr]->p;
-                    a.gTT = a.gII + per;
-                    a.gIT = (int32_t*)(a.gTT + per);
-                    a.gIIFill = c->gIIValid[tr] ? 0 : 1;
-                    c->gIIValid[tr] = 1;
-                }
-            }
-            a.changeVal = c->prdChange.p + (size_t)q * Ns * PRD_MAX_SLICES;
-            a.changeIdx = c->prdChangeIdx.p + (size_t)q * Ns * PRD_MAX_SLICES;
-            HIP_TRY(launch_prd_scatter(a, c->prdOut.p + 2 * q, c->stream));
-        }
-        // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
-        SweepDyn dyn = make_dyn(c, false, 0);
-        dyn.prdOnly = 1;
-        if (c->nChunksPrd > 0) // wavelengths the pass does not visit report dJ = 0
-            HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
-        HIP_TRY(run_sweep(c, dyn, true));
-        ReduceArgs r{};
-        r.Ns = Ns;
-        r.Ntrans = c->Ntrans;
-        r.maxCT = c->maxCT;
-        r.trOff = c->nChunksPrd > 0 ? c->trOffPrd.p : c->trOff.p;
-        r.trRow = c->nChunksPrd > 0 ? c->trRowPrd.p : c->trRow.p;
-        r.partial = c->partial.p;
-        r.red8 = c->red8.p;
-        r.red = c->red.p;
-        r.dJ = c->dJ.p;
-        r.Nla = c->Nla;
-        r.idxOffset = 0;
-        r.world = 1;
-        r.rank = 0;
-        HIP_TRY(launch_reduce(r, c->stream));
-        ApplyArgs ap{};
-        ap.Ns = Ns;
-        ap.Natom = c->Natom;
-        ap.atomTrOff = c->atomTrOffD.p;
-        ap.atomNlevel = c->atomNlevel.p;
-        ap.atomDetailed = c->atomDetailed.p;
-        ap.atomGammaOff = c->atomGammaOff.p;
-        ap.trans = c->dtrans.p;
-        ap.transLi = c->transLi.p;
-        ap.transLj = c->transLj.p;
-        ap.red = c->red.p;
-        ap.Gamma = c->Gamma.p;
-        ap.Rij = c->Rij.p;
-        ap.Rji = c->Rji.p;
-        ap.Cmat = c->Cmat.p;
-        ap.prdOnly = 1;
-        HIP_TRY(launch_apply(ap, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->prdPinned, c->prdOut.p, (size_t)2 * Nprd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->prdPinned + 2 * Nprd, tail, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        int st = lwhip_prd_pack(c, nullptr, nullptr);
+        if (st == LWHIP_OK)
+            st = lwhip_prd_partial(c);
+        double dJ = 0.0;
+        int32_t dJIdx = 0;
+        if (st == LWHIP_OK)
+            st = lwhip_prd_finalise(c, dRho.data(), dRhoIdx.data(), &dJ, &dJIdx);
+        if (st != LWHIP_OK)
+            return st;
         double dRhoMax = 0.0;
         for (int q = 0; q < Nprd; ++q)
         {
-            const double d = c->prdPinned[2 * q];
-            const int Nl = c->trans[prd[q]].t.Nred - c->trans[prd[q]].t.Nblue;
-            dRhoMax = std::max(dRhoMax, d);
+            dRhoMax = std::max(dRhoMax, dRho[q]);
             if (res && res->dRho)
-                res->dRho[(size_t)(iter - 1) * Nprd + q] = d;
-            if (res && res->dRhoMaxIdx) // the flattened [la, k] index modulo Nlambda, as PrdTemplates.hpp:265 reports it
-                res->dRhoMaxIdx[(size_t)(iter - 1) * Nprd + q] = (int)c->prdPinned[2 * q + 1] % Nl;
+                res->dRho[(size_t)(iter - 1) * Nprd + q] = dRho[q];
+            if (res && res->dRhoMaxIdx)
+                res->dRhoMaxIdx[(size_t)(iter - 1) * Nprd + q] = dRhoIdx[q];
         }
         if (res && res->dJPrdMax)
-            res->dJPrdMax[iter - 1] = c->prdPinned[2 * Nprd];
+            res->dJPrdMax[iter - 1] = dJ;
         if (res && res->dJPrdMaxIdx)
-            res->dJPrdMaxIdx[iter - 1] = (int)c->prdPinned[2 * Nprd + 1];
+            res->dJPrdMaxIdx[iter - 1] = dJIdx;
         if (dRhoMax < tol)
             break;
     }

@@ -218,6 +218,9 @@ struct PrdLineArgs
     int32_t lj;             // local upper level
     int32_t trBegin, trEnd; // global transition range of the line's atom
     int32_t slices, _padS;  // workgroups per depth point (slices of the emission wavelengths)
+    int32_t laLo, laHi;     // emission wavelengths handled here (the shard's part of the line), own-grid indices
+    int32_t world, rank, q, Nprd; // where the line's (max change, index) goes in the reduce tail
+    double* tail;           // [world][Nprd][2]
     double lambda0, Bij;
     const double* wave;     // [Nl] the line's own grid
     const double* J;        // [Nla, Ns]
@@ -231,7 +234,7 @@ struct PrdLineArgs
     const double* Rji;
     const int32_t* transLi;
     const int32_t* transLj;
-    double* rho;            // [Nl, Ns]
+    double* rho;            // [laHi - laLo, Ns]: the shard's rows
     double* gII;            // [Ns, 88, Nl] cached gII weights of the line, or null (always recompute)
     double* gTT;            // [Ns, 88, Nl] cached interpolation fractions
     int32_t* gIT;           // [Ns, 88, Nl] cached bracketing indices
@@ -239,7 +242,7 @@ struct PrdLineArgs
     double* changeVal;      // [Ns * slices] scratch
     int32_t* changeIdx;     // [Ns * slices] scratch
 };
-hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t stream);
+hipError_t launch_prd_scatter(const PrdLineArgs& a, hipStream_t stream);
 
 // nr_post_update (lwhip_pops.hip): one listed atom, and the launch arguments
 struct NrAtom

@@ -159,9 +159,9 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
     double best = 0.0;
     int bestIdx = 0x7fffffff;
     // this workgroup's share of the emission wavelengths (blockIdx.y of gridDim.y slices)
-    const int laPer = (Nl + gridDim.y - 1) / gridDim.y;
-    const int laBeg = blockIdx.y * laPer;
-    const int laEnd = min(Nl, laBeg + laPer);
+    const int laPer = (a.laHi - a.laLo + gridDim.y - 1) / gridDim.y;
+    const int laBeg = a.laLo + blockIdx.y * laPer;
+    const int laEnd = min(a.laHi, laBeg + laPer);
     for (int la = laBeg + threadIdx.x; la < laEnd; la += blockDim.x)
     {
         const double qEmit = qW[la];
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
                 scatInt += Jf * gii;
             }
         }
-        const size_t o = (size_t)la * Ns + k;
+        const size_t o = (size_t)(la - a.laLo) * Ns + k;
         const double rhoNew = 1.0 + gammaPrefactor * (scatInt / gNorm - Jbar);
         const double rhoOld = a.rho[o];
         a.rho[o] = rhoNew;
@@ -319,10 +319,13 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
 }
 
 // per line: max over depth of the per-depth maxima (first flattened index on ties)
-__global__ void prd_change_kernel(const double* changeVal, const int* changeIdx, int nEntries, double* out2)
+__global__ void prd_change_kernel(const double* changeVal, const int* changeIdx, int nEntries, double* tail, int world,
+                                  int rank, int q, int Nprd)
 {
     // one wavefront: max value, smallest flattened index on ties (max_idx semantics: strictly greater
-    // updates in index order, so the first occurrence wins; a zero maximum keeps idx 0)
+    // updates in index order, so the first occurrence wins; a zero maximum keeps idx 0).  The result
+    // goes into this shard's slot of the line in the reduce tail; the other shards' slots are zeroed
+    // (the all-reduce sums them).
     const int lane = threadIdx.x;
     double best = 0.0;
     int idx = 0x7fffffff;
@@ -347,14 +350,15 @@ __global__ void prd_change_kernel(const double* changeVal, const int* changeIdx,
             idx = i;
         }
     }
-    if (lane == 0)
+    for (int rk = lane; rk < world; rk += 64)
     {
-        out2[0] = best;
-        out2[1] = (best > 0.0) ? (double)idx : 0.0;
+        double* slot = tail + ((size_t)rk * Nprd + q) * 2;
+        slot[0] = (rk == rank) ? best : 0.0;
+        slot[1] = (rk == rank && best > 0.0) ? (double)idx : 0.0;
     }
 }
 
-hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t stream)
+hipError_t launch_prd_scatter(const PrdLineArgs& a, hipStream_t stream)
 {
     const size_t lds = (size_t)2 * a.Nl * sizeof(double);
     static size_t configured = 0;
@@ -366,10 +370,15 @@ hipError_t launch_prd_scatter(const PrdLineArgs& a, double* out2, hipStream_t st
             return err;
         configured = lds;
     }
-    hipLaunchKernelGGL(prd_transpose_kernel, dim3((a.Nl + 31) / 32, (a.Ns + 31) / 32), dim3(32, 8), 0, stream, a.J, a.Nblue,
-                       a.Nl, a.Ns, a.Jt);
-    hipLaunchKernelGGL(prd_scatter_kernel, dim3(a.Ns, a.slices), dim3(128), lds, stream, a);
-    hipLaunchKernelGGL(prd_change_kernel, dim3(1), dim3(64), 0, stream, a.changeVal, a.changeIdx, a.Ns * a.slices, out2);
+    const bool any = a.laHi > a.laLo;
+    if (any)
+    {
+        hipLaunchKernelGGL(prd_transpose_kernel, dim3((a.Nl + 31) / 32, (a.Ns + 31) / 32), dim3(32, 8), 0, stream, a.J,
+                           a.Nblue, a.Nl, a.Ns, a.Jt);
+        hipLaunchKernelGGL(prd_scatter_kernel, dim3(a.Ns, a.slices), dim3(128), lds, stream, a);
+    }
+    hipLaunchKernelGGL(prd_change_kernel, dim3(1), dim3(64), 0, stream, a.changeVal, a.changeIdx,
+                       any ? a.Ns * a.slices : 0, a.tail, a.world, a.rank, a.q, a.Nprd);
     return hipGetLastError();
 }
 }

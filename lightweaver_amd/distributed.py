@@ -88,3 +88,42 @@ class ShardedIteration:
         if not deviceResident:
             ctx.download(abi.ALL_OUTPUTS)
         return up
+
+    def _prd_tensor(self):
+        if hasattr(self.ctx, 'prd_tensor'):
+            return self.ctx.prd_tensor()
+        import torch
+        ptr, n = self.ctx.prd_pack()
+        return torch.as_tensor(DeviceReduceBuffer(ptr, n), device='cuda') if n else None
+
+    def prd_redistribute(self, maxIter=3, tol=1e-2):
+        """PRD sub-iterations on wavelength shards: per sub-iteration one all-reduce of
+        the PRD lines' J rows (each rank contributes its own, ~Nlambda_PRD x Nspace doubles) before the
+        scattering integral, and the iteration's usual all-reduce of the rate sums, whose tail also
+        carries every rank's max |d rho / rho| per line.  Mirrors redistribute_prd_lines' loop
+        (Source/PrdTemplates.hpp:250-290)."""
+        import torch.distributed as dist
+        from .context import IterationUpdate
+        ctx = self.ctx
+        collective = self.world > 1 or self.force_collective
+        dRhoAll, idxAll, dJAll, dJIdxAll = [], [], [], []
+        it = 0
+        while it < maxIter:
+            it += 1
+            buf = self._prd_tensor()          # packs this rank's rows
+            if collective and buf is not None:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            ctx.prd_partial()
+            if collective:
+                dist.all_reduce(self._reduce_tensor(), op=dist.ReduceOp.SUM, group=self.group)
+            dRho, idx, dJ, dJIdx = ctx.prd_finalise()
+            dRhoAll.append(np.array(dRho))
+            idxAll.append(np.array(idx))
+            dJAll.append(dJ)
+            dJIdxAll.append(dJIdx)
+            if len(dRho) == 0 or dRho.max() < tol:
+                break
+        return IterationUpdate(updatedRho=it > 0, updatedJ=it > 0, NprdSubIter=it,
+                               dRho=np.array(dRhoAll), dRhoMaxIdx=np.array(idxAll),
+                               dJPrdMax=np.array(dJAll), dJPrdMaxIdx=np.array(dJIdxAll),
+                               dJMax=dJAll[-1] if dJAll else 0.0, dJMaxIdx=dJIdxAll[-1] if dJIdxAll else 0)

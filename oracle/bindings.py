@@ -193,6 +193,9 @@ class OracleContext(_Handle):
             lib.lworacle_stat_equil.argtypes = [C.c_void_p, C.c_int]
             lib.lworacle_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
                                                       abi.f64p, abi.i32p, abi.f64p, abi.i32p]
+            lib.lworacle_prd_scatter_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.f64p, abi.i32p]
+            lib.lworacle_prd_rates_partial.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.f64p, abi.f64p]
+            lib.lworacle_prd_finalise.argtypes = [C.c_void_p, abi.f64p]
             lib.lworacle_time_dep_update.argtypes = [C.c_void_p, C.c_int, abi.f64p, C.c_double]
             lib.lworacle_nr_post_update.argtypes = [C.c_void_p, C.POINTER(abi.lwhip_nr_args)]
             lib.lworacle_GII.restype = C.c_double
@@ -239,6 +242,17 @@ class OracleContext(_Handle):
 
     def fs_finalise_shard(self, red):
         assert self.lib.lworacle_fs_finalise(self.h, red.ctypes.data_as(abi.f64p)) == 0
+
+    def prd_scatter_shard(self, laStart, laEnd, dRho, dRhoFlatIdx):
+        assert self.lib.lworacle_prd_scatter_shard(self.h, laStart, laEnd, dRho.ctypes.data_as(abi.f64p),
+                                                   dRhoFlatIdx.ctypes.data_as(abi.i32p)) == 0
+
+    def prd_rates_partial_shard(self, laStart, laEnd, red, dJ):
+        assert self.lib.lworacle_prd_rates_partial(self.h, laStart, laEnd, red.ctypes.data_as(abi.f64p),
+                                                   dJ.ctypes.data_as(abi.f64p)) == 0
+
+    def prd_finalise_shard(self, red):
+        assert self.lib.lworacle_prd_finalise(self.h, red.ctypes.data_as(abi.f64p)) == 0
 
     def stat_equil(self, atom=-1):
         return self.lib.lworacle_stat_equil(self.h, atom)

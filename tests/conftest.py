@@ -49,3 +49,11 @@ def gpu(hip_lib):
     if hip_lib.lwhip_device_count() < 1:
         pytest.fail('no gfx950 device visible: -m gpu tests need a GPU box')
     return True
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_initialise_torch_first(request):
+    """Every test marked `gpu` goes through the `gpu` fixture, whether or not it names it: torch's HIP
+    runtime has to be initialised before the library is first loaded in the process."""
+    if request.node.get_closest_marker('gpu') is not None:
+        request.getfixturevalue('gpu')

@@ -32,7 +32,13 @@ class OracleShardContext:
         self.laStart, self.laEnd, self.world, self.rank = laStart, laEnd, world, rank
         self.ntr = sum(len(a.trans) for a in prob.atoms)
         self.nsum = self.ntr * 4 * prob.Nspace
-        self.buf = torch.zeros(self.nsum + 2 * world, dtype=torch.float64)
+        # PRD lines of the active atoms and the layout of the J gather buffer (each line's full grid)
+        self.prd = [t for a in prob.atoms if not a.detailed for t in a.trans
+                    if t.type == abi.LINE and t.rhoPrd is not None]
+        self.nprd = len(self.prd)
+        self.prdOff = np.concatenate([[0], np.cumsum([t.Nred - t.Nblue for t in self.prd])]).astype(int)
+        self.prdJ = torch.zeros(int(self.prdOff[-1]) * prob.Nspace, dtype=torch.float64)
+        self.buf = torch.zeros(self.nsum + 2 * world * (1 + self.nprd), dtype=torch.float64)
         self.dJ = np.zeros(prob.Nlambda)
 
     def gamma_prefill_from_C(self, crsw=1.0):
@@ -57,9 +63,54 @@ class OracleShardContext:
         self.buf[self.nsum + 2 * self.rank] = float(shard[i])
         self.buf[self.nsum + 2 * self.rank + 1] = float(self.laStart + i)
 
+    # -- PRD sub-iteration, same split as lwhip_prd_pack / _partial / _finalise -----------------------
+    def prd_tensor(self):
+        Ns = self.prob.Nspace
+        self.prdJ.zero_()
+        view = self.prdJ.numpy().reshape(-1, Ns)
+        for q, t in enumerate(self.prd):
+            lo, hi = max(t.Nblue, self.laStart), min(t.Nred, self.laEnd)
+            if hi > lo:
+                view[self.prdOff[q] + lo - t.Nblue:self.prdOff[q] + hi - t.Nblue] = self.prob.J[lo:hi]
+        return self.prdJ
+
+    def prd_partial(self):
+        Ns = self.prob.Nspace
+        view = self.prdJ.numpy().reshape(-1, Ns)
+        for q, t in enumerate(self.prd):          # the gathered rows: J over every PRD line's whole grid
+            self.prob.J[t.Nblue:t.Nred] = view[self.prdOff[q]:self.prdOff[q + 1]]
+        dRho = np.zeros(max(self.nprd, 1))
+        idx = np.zeros(max(self.nprd, 1), dtype=np.int32)
+        self.oc.prd_scatter_shard(self.laStart, self.laEnd, dRho, idx)
+        red = np.zeros(self.nsum)
+        self.oc.prd_rates_partial_shard(self.laStart, self.laEnd, red, self.dJ)
+        self.buf.zero_()
+        self.buf[:self.nsum] = torch.from_numpy(red)
+        shard = self.dJ[self.laStart:self.laEnd]
+        i = int(np.argmax(shard))
+        self.buf[self.nsum + 2 * self.rank] = float(shard[i])
+        self.buf[self.nsum + 2 * self.rank + 1] = float(self.laStart + i) if shard[i] > 0 else 0.0
+        base = self.nsum + 2 * self.world + 2 * self.rank * self.nprd
+        for q in range(self.nprd):
+            self.buf[base + 2 * q] = float(dRho[q])
+            self.buf[base + 2 * q + 1] = float(idx[q])
+
+    def prd_finalise(self):
+        self.oc.prd_finalise_shard(self.buf[:self.nsum].numpy().copy())
+        tail = self.buf[self.nsum:self.nsum + 2 * self.world].numpy().reshape(self.world, 2)
+        best = max(range(self.world), key=lambda r: (tail[r, 0], -tail[r, 1]))
+        ptail = self.buf[self.nsum + 2 * self.world:].numpy().reshape(self.world, self.nprd, 2)
+        dRho = np.zeros(self.nprd)
+        idx = np.zeros(self.nprd, dtype=np.int32)
+        for q, t in enumerate(self.prd):
+            r = max(range(self.world), key=lambda r: (ptail[r, q, 0], -ptail[r, q, 1]))
+            dRho[q] = ptail[r, q, 0]
+            idx[q] = int(ptail[r, q, 1]) % (t.Nred - t.Nblue)
+        return dRho, idx, float(tail[best, 0]), int(tail[best, 1])
+
     def fs_finalise(self):
         self.oc.fs_finalise_shard(self.buf[:self.nsum].numpy().copy())
-        tail = self.buf[self.nsum:].numpy().reshape(self.world, 2)
+        tail = self.buf[self.nsum:self.nsum + 2 * self.world].numpy().reshape(self.world, 2)
         best = max(range(self.world), key=lambda r: (tail[r, 0], -tail[r, 1]))
         return IterationUpdate(updatedJ=True, dJMax=float(tail[best, 0]), dJMaxIdx=int(tail[best, 1]))
 
@@ -120,3 +171,62 @@ def test_two_rank_gloo_matches_unsharded(tmp_path):
         assert rel_err(z['R'], np.stack([t.Rij for t in prob.atoms[0].trans])) <= 1e-12
         assert [float(x) for x in z['dJ']] == [r[0] for r in res]
         assert [int(x) for x in z['idx']] == [r[1] for r in res]
+
+
+def _prd_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from test_prd import golden_prd_problem, prd_lines
+        prob, _ = golden_prd_problem()
+        lines = prd_lines(prob)
+        # cut inside a PRD line's grid so that both ranks own part of it
+        m = (lines[-1].Nblue + lines[-1].Nred) // 2
+        bounds = [0, m, prob.Nlambda]
+        ctx = OracleShardContext(prob, bounds[rank], bounds[rank + 1], world, rank)
+        it = ShardedIteration(ctx, world, rank)
+        ups = []
+        for _ in range(2):
+            it.formal_sol_gamma_matrices(deviceResident=True)
+            ups.append(it.prd_redistribute(3, 1e-2))
+        la0, la1 = bounds[rank], bounds[rank + 1]
+        rho = [t.rhoPrd[max(la0 - t.Nblue, 0):max(min(la1, t.Nred) - t.Nblue, 0)] for t in lines]
+        np.savez(os.path.join(out, f'prd{rank}.npz'), J=prob.J[la0:la1], la=[la0, la1],
+                 R=np.stack([t.Rij for t in lines]), rho0=rho[0], rho1=rho[1],
+                 n=[u.NprdSubIter for u in ups], dRho=np.concatenate([u.dRho.ravel() for u in ups]),
+                 idx=np.concatenate([u.dRhoMaxIdx.ravel() for u in ups]),
+                 dJ=np.concatenate([u.dJPrdMax for u in ups]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_prd_matches_unsharded(tmp_path):
+    """PRD sub-iterations on two wavelength shards (J rows of the PRD lines all-reduced before the
+    scattering integral, per-line max changes riding in the tail of the rate all-reduce) against the
+    unsharded oracle loop."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_prd_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle.bindings import OracleContext
+    from test_prd import golden_prd_problem, prd_lines
+    prob, _ = golden_prd_problem()
+    oc = OracleContext(prob)
+    ups = []
+    for _ in range(2):
+        prob.gamma_prefill()
+        oc.formal_sol_gamma_matrices()
+        ups.append(oc.redistribute_prd(3, 1e-2))
+    lines = prd_lines(prob)
+    for rank in range(world):
+        z = np.load(tmp_path / f'prd{rank}.npz')
+        la0, la1 = z['la']
+        assert [int(x) for x in z['n']] == [u['NprdSubIter'] for u in ups]
+        assert np.allclose(z['dRho'], np.concatenate([u['dRho'].ravel() for u in ups]), rtol=1e-9)
+        assert np.array_equal(z['idx'], np.concatenate([u['dRhoMaxIdx'].ravel() for u in ups]))
+        assert np.allclose(z['dJ'], np.concatenate([u['dJPrdMax'] for u in ups]), rtol=1e-12)
+        assert rel_err(z['J'], prob.J[la0:la1]) <= 1e-12
+        assert rel_err(z['R'], np.stack([t.Rij for t in lines])) <= 1e-12
+        for q, t in enumerate(lines):
+            want = t.rhoPrd[max(la0 - t.Nblue, 0):max(min(la1, t.Nred) - t.Nblue, 0)]
+            assert rel_err(z[f'rho{q}'], want) <= 1e-10
