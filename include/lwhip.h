@@ -248,6 +248,12 @@ int lwhip_stat_equil(lwhip_context* ctx, int atom);
  * remembered; lwhip_check_status waits for the stream and returns (and clears) that condition.
  * For batches of contexts whose solves should overlap instead of serialising on a host wait each. */
 int lwhip_stat_equil_async(lwhip_context* ctx, int atom);
+/* lwhip_stat_equil that also reports, per active atom (arrays indexed by position among the active
+ * atoms; entries of atoms not solved are left alone), the maximum relative population change
+ * max |(n_new - n_old) / n_new| and the flattened [level, depth] index of its first occurrence: what
+ * LwContext.stat_equil returns as dPops / dPopsMaxIdx (Ng::max_change, Source/Ng.hpp:138-156, with the
+ * default Ng(0,0,0), i.e. no acceleration). */
+int lwhip_stat_equil_report(lwhip_context* ctx, int atom, double* dPops, int32_t* dPopsMaxIdx);
 int lwhip_check_status(lwhip_context* ctx);
 
 /* PRD sub-iterations (redistribute_prd_lines): for every PRD line of an active atom, the

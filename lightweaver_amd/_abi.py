@@ -122,6 +122,7 @@ SYMBOLS = [
     ('lwhip_formal_sol', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_stat_equil', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_stat_equil_async', C.c_int, [ctx_p, C.c_int]),
+    ('lwhip_stat_equil_report', C.c_int, [ctx_p, C.c_int, f64p, i32p]),
     ('lwhip_check_status', C.c_int, [ctx_p]),
     ('lwhip_compute_profiles', C.c_int, [ctx_p]),
     ('lwhip_redistribute_prd', C.c_int, [ctx_p, C.c_int, C.c_double, C.POINTER(lwhip_prd_result)]),

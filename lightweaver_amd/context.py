@@ -68,6 +68,8 @@ class IterationUpdate:
     dJMaxIdx: int = 0
     crsw: float = 1.0
     updatedPops: bool = False
+    dPops: Optional[list] = None          # per active atom: max |dn / n| of the last population update
+    dPopsMaxIdx: Optional[list] = None    # and its flattened [level, depth] index
     updatedRho: bool = False
     NprdSubIter: int = 0
     dRho: Optional[np.ndarray] = None         # [NprdSubIter, Nprd]
@@ -168,10 +170,14 @@ class Context:
         if deviceResident and not sync_host:
             _check(self.lib, self.lib.lwhip_stat_equil_async(self._h, atom), 'lwhip_stat_equil_async')
             return IterationUpdate(updatedPops=True)
-        _check(self.lib, self.lib.lwhip_stat_equil(self._h, atom), 'lwhip_stat_equil')
+        nAct = sum(1 for a in self.prob.atoms if not a.detailed)
+        dPops = np.zeros(max(nAct, 1))
+        dIdx = np.zeros(max(nAct, 1), dtype=np.int32)
+        _check(self.lib, self.lib.lwhip_stat_equil_report(self._h, atom, dPops.ctypes.data_as(abi.f64p),
+                                                          dIdx.ctypes.data_as(abi.i32p)), 'lwhip_stat_equil')
         if not deviceResident:
             self.download(abi.POPS)
-        return IterationUpdate(updatedPops=True)
+        return IterationUpdate(updatedPops=True, dPops=list(dPops[:nAct]), dPopsMaxIdx=list(dIdx[:nAct]))
 
     def prd_redistribute(self, maxIter=3, tol=1e-2, deviceResident=False) -> IterationUpdate:
         """PRD sub-iterations, LwContext.prd_redistribute (Source/LwMiddleLayer.pyx:3647-3684) with

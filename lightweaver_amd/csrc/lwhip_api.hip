@@ -124,6 +124,9 @@ struct lwhip_context
     int statEqKey = -2;
     int32_t* statusHost = nullptr;
     int32_t* statusDev = nullptr;
+    double* changeHost = nullptr; // host-mapped per-block population changes of the last reported solve
+    double* changeDev = nullptr;
+    size_t changeCount = 0;
     DevBuf<int32_t> transType;
     DevBuf<int32_t> contLa;
     DevBuf<int32_t> prdChangeIdx;
@@ -174,6 +177,8 @@ struct lwhip_context
             (void)hipHostFree(stage);
         if (statusHost)
             (void)hipHostFree(statusHost);
+        if (changeHost)
+            (void)hipHostFree(changeHost);
         if (prdPinned)
             (void)hipHostFree(prdPinned);
     }
@@ -1624,7 +1629,7 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
     return LWHIP_OK;
 }
 
-static int stat_equil_impl(lwhip_context* c, int atom, bool wait);
+static int stat_equil_impl(lwhip_context* c, int atom, bool wait, double* dPops = nullptr, int32_t* dPopsMaxIdx = nullptr);
 
 int lwhip_stat_equil(lwhip_context* c, int atom)
 {
@@ -1634,6 +1639,11 @@ int lwhip_stat_equil(lwhip_context* c, int atom)
 int lwhip_stat_equil_async(lwhip_context* c, int atom)
 {
     return stat_equil_impl(c, atom, false);
+}
+
+int lwhip_stat_equil_report(lwhip_context* c, int atom, double* dPops, int32_t* dPopsMaxIdx)
+{
+    return stat_equil_impl(c, atom, true, dPops, dPopsMaxIdx);
 }
 
 int lwhip_check_status(lwhip_context* c)
@@ -1650,7 +1660,7 @@ int lwhip_check_status(lwhip_context* c)
     return LWHIP_OK;
 }
 
-static int stat_equil_impl(lwhip_context* c, int atom, bool wait)
+static int stat_equil_impl(lwhip_context* c, int atom, bool wait, double* dPops, int32_t* dPopsMaxIdx)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
@@ -1701,12 +1711,60 @@ static int stat_equil_impl(lwhip_context* c, int atom, bool wait)
     sa.nTotal = c->nTotal.p;
     sa.Gamma = c->Gamma.p;
     sa.status = c->statusDev;
+    const int nBlocks = stat_eq_blocks(c->Ns, maxNl);
+    const bool report = wait && dPops;
+    if (report)
+    {
+        const size_t need = atoms.size() * nBlocks * 2;
+        if (c->changeCount < need)
+        {
+            if (c->changeHost)
+                (void)hipHostFree(c->changeHost);
+            c->changeHost = nullptr;
+            HIP_TRY(hipHostMalloc((void**)&c->changeHost, need * sizeof(double), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&c->changeDev, c->changeHost, 0));
+            c->changeCount = need;
+        }
+        sa.change = c->changeDev;
+    }
     HIP_TRY(launch_stat_eq(sa, maxNl, c->stream));
     if (!wait)
         return LWHIP_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (*c->statusHost == LWHIP_ERR_SINGULAR)
         return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+    if (report)
+    {
+        // Ng::max_change (Source/Ng.hpp:138-156): the maximum and the flattened [level, depth] index of its
+        // first occurrence, per solved atom; entries are indexed by position among the ACTIVE atoms
+        int activePos = 0;
+        size_t slot = 0;
+        for (int ia = 0; ia < c->Natom; ++ia)
+        {
+            if (c->atoms[ia].detailed)
+                continue;
+            if (atom < 0 || ia == atom)
+            {
+                double v = 0.0;
+                int idx = 0;
+                for (int b = 0; b < nBlocks; ++b)
+                {
+                    const double x = c->changeHost[(slot * nBlocks + b) * 2];
+                    const int i = (int)c->changeHost[(slot * nBlocks + b) * 2 + 1];
+                    if (x > v || (x == v && x > 0.0 && i < idx))
+                    {
+                        v = x;
+                        idx = i;
+                    }
+                }
+                dPops[activePos] = v;
+                if (dPopsMaxIdx)
+                    dPopsMaxIdx[activePos] = idx;
+                ++slot;
+            }
+            ++activePos;
+        }
+    }
     return LWHIP_OK;
 }
 

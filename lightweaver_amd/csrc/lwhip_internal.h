@@ -282,8 +282,10 @@ struct StatEqArgs
     const double* nTotal;       // [Natom, Ns]
     const double* Gamma;        // pool
     int32_t* status;            // host-mapped: LWHIP_ERR_SINGULAR is written straight into pinned memory
+    double* change;             // host-mapped [Natoms][blocks][2]: max |dn/n| and its flattened index per block, or null
 };
 hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream);
+int stat_eq_blocks(int Ns, int maxNlevel);
 hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream);
 hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
                            int* status, hipStream_t stream);

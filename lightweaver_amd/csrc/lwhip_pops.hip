@@ -171,6 +171,33 @@ static hipError_t solve_set_lds(const void* fn, size_t lds)
     return hipSuccess;
 }
 
+// max |(new - old) / new| over the populations a block has just updated, with the flattened [level, depth]
+// index of its first occurrence (Ng::max_change, Source/Ng.hpp:138-156, which LwContext.stat_equil /
+// time_dep_update report as dPops): one (value, index) pair per block, combined on the host.
+DEVINL void report_change(double best, int bestIdx, double* out /* [gridDim.x][2] of this atom, or null */)
+{
+    if (!out)
+        return;
+    __shared__ double sV[64];
+    __shared__ int sI[64];
+    sV[threadIdx.x] = best;
+    sI[threadIdx.x] = bestIdx;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double v = 0.0;
+        int idx = 0x7fffffff;
+        for (int q = 0; q < (int)blockDim.x; ++q)
+            if (sV[q] > v || (sV[q] == v && sV[q] > 0.0 && sI[q] < idx))
+            {
+                v = sV[q];
+                idx = sI[q];
+            }
+        out[2 * blockIdx.x] = v;
+        out[2 * blockIdx.x + 1] = (v > 0.0) ? (double)idx : 0.0;
+    }
+}
+
 // ---- stat_eq_impl: Source/UpdatePopulations.cpp:7-47 -------------------------------------------------------
 // blockIdx.y selects the atom, so every active atom is solved by one launch
 __global__ void stat_eq_kernel(const StatEqArgs a)
@@ -178,40 +205,63 @@ __global__ void stat_eq_kernel(const StatEqArgs a)
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
-    if (k >= Ns)
-        return;
     const NrAtom at = a.atoms[blockIdx.y];
     const int N = at.Nlevel;
-    double* n = a.n + (size_t)at.levelOff * Ns;
-    const double* Gamma = a.Gamma + at.gammaOff;
-    const SolveWs w(lds, N, blockDim.x, threadIdx.x);
-    // Gamma_k and the elimination row: the level with the largest population
-    int iElim = 0;
-    double nMax = 0.0;
-    for (int i = 0; i < N; ++i)
+    double best = 0.0;
+    int bestIdx = 0x7fffffff;
+    if (k < Ns)
     {
-        const double ni = n[(size_t)i * Ns + k];
-        if (nMax < ni)
+        double* n = a.n + (size_t)at.levelOff * Ns;
+        const double* Gamma = a.Gamma + at.gammaOff;
+        const SolveWs w(lds, N, blockDim.x, threadIdx.x);
+        // Gamma_k and the elimination row: the level with the largest population
+        int iElim = 0;
+        double nMax = 0.0;
+        for (int i = 0; i < N; ++i)
         {
-            iElim = i;
-            nMax = ni;
+            const double ni = n[(size_t)i * Ns + k];
+            if (nMax < ni)
+            {
+                iElim = i;
+                nMax = ni;
+            }
+            for (int j = 0; j < N; ++j)
+                w.A[i * N + j] = Gamma[((size_t)i * N + j) * Ns + k];
         }
-        for (int j = 0; j < N; ++j)
-            w.A[i * N + j] = Gamma[((size_t)i * N + j) * Ns + k];
+        for (int i = 0; i < N; ++i)
+        {
+            w.A[iElim * N + i] = 1.0;
+            w.b[i] = 0.0;
+        }
+        w.b[iElim] = a.nTotal[(size_t)at.atom * Ns + k];
+        if (!d_solve_lin_eq(N, w))
+            atomicExch(a.status, LWHIP_ERR_SINGULAR);
+        else
+        {
+            for (int i = 0; i < N; ++i)
+            {
+                const double cur = w.b[i];
+                const double old = n[(size_t)i * Ns + k];
+                n[(size_t)i * Ns + k] = cur;
+                if (cur != 0.0)
+                {
+                    const double change = fabs((cur - old) / cur);
+                    if (change > best)
+                    {
+                        best = change;
+                        bestIdx = i * Ns + k;
+                    }
+                }
+            }
+        }
     }
-    for (int i = 0; i < N; ++i)
-    {
-        w.A[iElim * N + i] = 1.0;
-        w.b[i] = 0.0;
-    }
-    w.b[iElim] = a.nTotal[(size_t)at.atom * Ns + k];
-    if (!d_solve_lin_eq(N, w))
-    {
-        atomicExch(a.status, LWHIP_ERR_SINGULAR);
-        return;
-    }
-    for (int i = 0; i < N; ++i)
-        n[(size_t)i * Ns + k] = w.b[i];
+    report_change(best, bestIdx, a.change ? a.change + (size_t)blockIdx.y * 2 * gridDim.x : nullptr);
+}
+
+int stat_eq_blocks(int Ns, int maxNlevel)
+{
+    const int tb = solve_block_threads(maxNlevel);
+    return (Ns + tb - 1) / tb;
 }
 
 hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream)

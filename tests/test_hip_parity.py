@@ -235,6 +235,29 @@ def test_column_batch_vs_oracle(gpu):
         compare_problems(p, q, tol=1e-7, what=('J', 'Gamma', 'n'))
 
 
+def test_stat_equil_reports_population_changes(gpu):
+    """dPops / dPopsMaxIdx of LwContext.stat_equil (Ng::max_change with the default Ng(0,0,0)): max relative
+    change of each active atom's populations and the flattened [level, depth] index of its first occurrence."""
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = variant_problem(base, d, 'iter1'), variant_problem(base, d, 'iter1')
+    with OracleContext(q) as oc:
+        q.gamma_prefill()
+        oc.formal_sol_gamma_matrices()
+        before = [a.n.copy() for a in q.atoms]
+        assert oc.stat_equil() == 0
+    with Context(p) as ctx:
+        for a, b in zip(p.atoms, q.atoms):     # identical operator for the two solves
+            a.Gamma[...] = b.Gamma
+        ctx.upload(abi.GAMMA)
+        up = ctx.stat_equil(deviceResident=True)
+        ctx.download(abi.POPS)
+    for ia, (a, old) in enumerate(zip(q.atoms, before)):
+        change = np.abs((a.n - old) / a.n).ravel()
+        assert up.dPops[ia] == pytest.approx(change.max(), rel=1e-9)
+        assert up.dPopsMaxIdx[ia] == int(np.argmax(change))
+        assert rel_err(p.atoms[ia].n, a.n) <= 1e-9
+
+
 def test_stat_equil_singular_raises(gpu):
     base, _ = load_fixture('falc_h_vel')
     p = base.copy()
