@@ -288,6 +288,18 @@ int lwhip_prd_pack(lwhip_context* ctx, void** devPtr, size_t* count);
 int lwhip_prd_partial(lwhip_context* ctx);
 int lwhip_prd_finalise(lwhip_context* ctx, double* dRho, int32_t* dRhoMaxIdx, double* dJMax, int32_t* dJMaxIdx);
 
+/* Ng acceleration of the populations on the device (struct Ng, Source/Ng.hpp:16-156; driven by
+ * LwContext.stat_equil -> rel_diff_ng_accelerate, Source/LwMiddleLayer.pyx:3318-3346).
+ * lwhip_ng_configure(Norder, Nperiod, Ndelay): one history per active atom, seeded with the current
+ *   populations (the reference builds its Ng objects when the Context is constructed); Norder = 0 keeps
+ *   only what max_change needs.
+ * lwhip_ng_accelerate: call after each population update: records the new populations, every Nperiod
+ *   calls from the Ndelay-th on replaces them by the Ng extrapolation, and reports per active atom whether
+ *   it accelerated, the max relative change between the last two recorded solutions and its flattened
+ *   [level, depth] index. */
+int lwhip_ng_configure(lwhip_context* ctx, int Norder, int Nperiod, int Ndelay);
+int lwhip_ng_accelerate(lwhip_context* ctx, int32_t* accelerated, double* dPops, int32_t* dPopsMaxIdx);
+
 /* time_dependent_update (FsIterationFns::time_dep_update, Source/LwFormalInterface.hpp:92,123;
  * time_dependent_update_impl, Source/UpdatePopulations.cpp:120-151): for atom `atom`, per depth
  * point solve (1 - dt Gamma_k) n_k = nOld_k with the solver of lwhip_stat_equil; n overwritten on

@@ -129,6 +129,8 @@ SYMBOLS = [
     ('lwhip_prd_pack', C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ('lwhip_prd_partial', C.c_int, [ctx_p]),
     ('lwhip_prd_finalise', C.c_int, [ctx_p, f64p, i32p, f64p, i32p]),
+    ('lwhip_ng_configure', C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int]),
+    ('lwhip_ng_accelerate', C.c_int, [ctx_p, i32p, f64p, i32p]),
     ('lwhip_time_dep_update', C.c_int, [ctx_p, C.c_int, f64p, C.c_double]),
     ('lwhip_nr_post_update', C.c_int, [ctx_p, C.POINTER(lwhip_nr_args)]),
     ('lwhip_synchronize', C.c_int, [ctx_p]),

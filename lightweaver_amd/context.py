@@ -70,6 +70,7 @@ class IterationUpdate:
     updatedPops: bool = False
     dPops: Optional[list] = None          # per active atom: max |dn / n| of the last population update
     dPopsMaxIdx: Optional[list] = None    # and its flattened [level, depth] index
+    ngAccelerated: bool = False
     updatedRho: bool = False
     NprdSubIter: int = 0
     dRho: Optional[np.ndarray] = None         # [NprdSubIter, Nprd]
@@ -99,6 +100,7 @@ class Context:
         self.laStart = laStart
         self.laEnd = laEnd if laEnd else prob.Nlambda
         self.crsw = 1.0
+        self._ng = None
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -173,11 +175,29 @@ class Context:
         nAct = sum(1 for a in self.prob.atoms if not a.detailed)
         dPops = np.zeros(max(nAct, 1))
         dIdx = np.zeros(max(nAct, 1), dtype=np.int32)
-        _check(self.lib, self.lib.lwhip_stat_equil_report(self._h, atom, dPops.ctypes.data_as(abi.f64p),
-                                                          dIdx.ctypes.data_as(abi.i32p)), 'lwhip_stat_equil')
+        accelerated = False
+        if self._ng is not None:
+            # LwContext.stat_equil -> rel_diff_ng_accelerate (Source/LwMiddleLayer.pyx:3318-3346)
+            _check(self.lib, self.lib.lwhip_stat_equil(self._h, atom), 'lwhip_stat_equil')
+            acc = np.zeros(max(nAct, 1), dtype=np.int32)
+            _check(self.lib, self.lib.lwhip_ng_accelerate(self._h, acc.ctypes.data_as(abi.i32p),
+                                                          dPops.ctypes.data_as(abi.f64p), dIdx.ctypes.data_as(abi.i32p)),
+                   'lwhip_ng_accelerate')
+            accelerated = bool(acc[:nAct].any())
+        else:
+            _check(self.lib, self.lib.lwhip_stat_equil_report(self._h, atom, dPops.ctypes.data_as(abi.f64p),
+                                                              dIdx.ctypes.data_as(abi.i32p)), 'lwhip_stat_equil')
         if not deviceResident:
             self.download(abi.POPS)
-        return IterationUpdate(updatedPops=True, dPops=list(dPops[:nAct]), dPopsMaxIdx=list(dIdx[:nAct]))
+        return IterationUpdate(updatedPops=True, dPops=list(dPops[:nAct]), dPopsMaxIdx=list(dIdx[:nAct]),
+                               ngAccelerated=accelerated)
+
+    def configure_ng(self, Norder=0, Nperiod=0, Ndelay=0):
+        """Ng acceleration of the populations (NgOptions of lightweaver.Context, Source/LwMiddleLayer.pyx:2900;
+        struct Ng, Source/Ng.hpp), kept on the device: call once the initial populations are uploaded."""
+        _check(self.lib, self.lib.lwhip_ng_configure(self._h, int(Norder), int(Nperiod), int(Ndelay)),
+               'lwhip_ng_configure')
+        self._ng = (Norder, Nperiod, Ndelay)
 
     def prd_redistribute(self, maxIter=3, tol=1e-2, deviceResident=False) -> IterationUpdate:
         """PRD sub-iterations, LwContext.prd_redistribute (Source/LwMiddleLayer.pyx:3647-3684) with

@@ -121,6 +121,11 @@ struct lwhip_context
     std::vector<std::unique_ptr<DevBuf<double>>> gII; // per transition: cached PRD weights (lazily)
     std::vector<char> gIIValid;
     DevBuf<NrAtom> nrAtoms, statEqAtoms;
+    DevBuf<NgAtom> ngAtoms;
+    DevBuf<double> ngHistory;
+    std::vector<NgAtom> ngAtomsHost;
+    int ngOrder = 0, ngPeriod = 0, ngDelay = 0, ngCount = 0;
+    bool ngConfigured = false;
     int statEqKey = -2;
     int32_t* statusHost = nullptr;
     int32_t* statusDev = nullptr;
@@ -1764,6 +1769,99 @@ static int stat_equil_impl(lwhip_context* c, int atom, bool wait, double* dPops,
             }
             ++activePos;
         }
+    }
+    return LWHIP_OK;
+}
+
+int lwhip_ng_configure(lwhip_context* c, int Norder, int Nperiod, int Ndelay)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (Norder < 0 || Norder > LWHIP_NG_MAX_ORDER || (Norder > 0 && Nperiod < 1))
+        return fail(LWHIP_ERR_INVALID, "Ng: 0 <= Norder <= 6 and Nperiod >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    c->ngOrder = Norder;
+    c->ngPeriod = Nperiod;
+    c->ngDelay = std::max(Ndelay, Nperiod + 2); // Ng.hpp:32
+    c->ngCount = 1;                             // the constructor stores the current solution :34-38
+    std::vector<NgAtom> atoms;
+    int64_t hist = 0;
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        if (c->atoms[ia].detailed)
+            continue;
+        NgAtom at{};
+        at.len = c->atoms[ia].Nlevel * c->Ns;
+        at.nOff = (int64_t)c->levelOff[ia] * c->Ns;
+        at.histOff = hist;
+        hist += (int64_t)(Norder + 2) * at.len;
+        atoms.push_back(at);
+    }
+    c->ngAtomsHost = atoms;
+    if (atoms.empty())
+        return LWHIP_OK;
+    HIP_TRY(c->ngAtoms.upload(atoms));
+    HIP_TRY(c->ngHistory.alloc((size_t)hist));
+    HIP_TRY(hipMemsetAsync(c->ngHistory.p, 0, (size_t)hist * sizeof(double), c->stream));
+    for (const NgAtom& at : atoms)
+        HIP_TRY(hipMemcpyAsync(c->ngHistory.p + at.histOff, c->n.p + at.nOff, (size_t)at.len * sizeof(double),
+                               hipMemcpyDeviceToDevice, c->stream));
+    c->ngConfigured = true;
+    return LWHIP_OK;
+}
+
+int lwhip_ng_accelerate(lwhip_context* c, int32_t* accelerated, double* dPops, int32_t* dPopsMaxIdx)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (!c->ngConfigured)
+        return fail(LWHIP_ERR_INVALID, "lwhip_ng_accelerate before lwhip_ng_configure");
+    const int nAt = (int)c->ngAtomsHost.size();
+    if (nAt == 0)
+        return LWHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->statusHost)
+    {
+        HIP_TRY(hipHostMalloc((void**)&c->statusHost, sizeof(int32_t), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&c->statusDev, c->statusHost, 0));
+    }
+    if (c->changeCount < (size_t)2 * nAt)
+    {
+        if (c->changeHost)
+            (void)hipHostFree(c->changeHost);
+        c->changeHost = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->changeHost, (size_t)2 * nAt * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&c->changeDev, c->changeHost, 0));
+        c->changeCount = (size_t)2 * nAt;
+    }
+    const int No = c->ngOrder, nslots = No + 2;
+    NgArgs a{};
+    a.atoms = c->ngAtoms.p;
+    a.n = c->n.p;
+    a.history = c->ngHistory.p;
+    a.change = c->changeDev;
+    a.status = c->statusDev;
+    a.Norder = No;
+    a.storeSlot = c->ngCount % nslots; // Ng.hpp:62
+    c->ngCount += 1;
+    a.doAccel = (No > 0 && c->ngCount >= c->ngDelay && ((c->ngCount - c->ngDelay) % c->ngPeriod) == 0) ? 1 : 0;
+    for (int i = 0; i < No + 2; ++i)
+        a.slots[i] = ((c->ngCount - 1 - i) % nslots + nslots) % nslots;
+    a.haveTwo = c->ngCount >= 2 ? 1 : 0;
+    a.oldSlot = ((c->ngCount - 2) % nslots + nslots) % nslots;
+    *c->statusHost = 0;
+    HIP_TRY(launch_ng(a, nAt, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*c->statusHost == LWHIP_ERR_SINGULAR)
+        return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+    for (int q = 0; q < nAt; ++q)
+    {
+        if (accelerated)
+            accelerated[q] = a.doAccel;
+        if (dPops)
+            dPops[q] = c->changeHost[2 * q];
+        if (dPopsMaxIdx)
+            dPopsMaxIdx[q] = (int32_t)c->changeHost[2 * q + 1];
     }
     return LWHIP_OK;
 }

@@ -286,6 +286,26 @@ struct StatEqArgs
 };
 hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream);
 int stat_eq_blocks(int Ns, int maxNlevel);
+// Ng acceleration of the populations (lwhip_pops.hip)
+struct NgAtom
+{
+    int32_t len;        // Nlevel * Ns
+    int32_t _pad;
+    int64_t nOff;       // offset of the atom's populations in the n pool
+    int64_t histOff;    // offset of its history [Norder + 2][len]
+};
+enum { LWHIP_NG_MAX_ORDER = 6 };
+struct NgArgs
+{
+    const NgAtom* atoms;
+    double* n;
+    double* history;
+    double* change;         // host-mapped [nAtoms][2]
+    int32_t* status;
+    int32_t Norder, storeSlot, oldSlot, doAccel, haveTwo;
+    int32_t slots[LWHIP_NG_MAX_ORDER + 2]; // slots of count-1, count-2, ... count-Norder-2
+};
+hipError_t launch_ng(const NgArgs& a, int nAtoms, hipStream_t stream);
 hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream);
 hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
                            int* status, hipStream_t stream);

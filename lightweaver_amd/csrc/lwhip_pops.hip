@@ -450,4 +450,119 @@ hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream)
     hipLaunchKernelGGL(nr_post_kernel, dim3((a.Ns + tb - 1) / tb), dim3(tb), lds, stream, a);
     return hipGetLastError();
 }
+
+// ---- Ng acceleration of one atom's populations: Ng::accelerate + Ng::max_change (Source/Ng.hpp:52-156) ------
+// One workgroup per atom (the vectors are Nlevel x Nspace ~ 500 long).  The weighted dot products that form
+// the Norder x Norder system are accumulated by ONE thread in the reference's order: the system can be
+// ill conditioned, and a few microseconds every Nperiod iterations buy bit-identical coefficients.
+__global__ void __launch_bounds__(256) ng_kernel(const NgArgs a)
+{
+    extern __shared__ double lds[];
+    const NgAtom at = a.atoms[blockIdx.x];
+    const int L = at.len, No = a.Norder;
+    double* n = a.n + (size_t)at.nOff;
+    double* prev = a.history + (size_t)at.histOff;
+    auto slot = [&](int s) { return prev + (size_t)s * L; };
+    // store the new solution :62-65
+    for (int k = threadIdx.x; k < L; k += blockDim.x)
+        slot(a.storeSlot)[k] = n[k];
+    __syncthreads();
+    if (a.doAccel)
+    {
+        // slots of count-1-i (ip) and count-2-i (ipp), i = 0 .. Norder, precomputed on the host in a.slots
+        double* bco = lds;                       // [No]
+        double* ws = lds + 64;                   // solver workspace of thread 0
+        if (threadIdx.x == 0)
+        {
+            const SolveWs w(ws, No, 1, 0);
+            auto Delta = [&](int i, int k) { return slot(a.slots[i])[k] - slot(a.slots[i + 1])[k]; };
+            for (int j = 0; j < No; ++j)
+            {
+                double bj = 0.0;
+                for (int k = 0; k < L; ++k)
+                    bj += (1.0 / fabs(n[k])) * Delta(0, k) * (Delta(0, k) - Delta(j + 1, k));
+                w.b[j] = bj;
+                for (int i = 0; i < No; ++i)
+                {
+                    double aij = 0.0;
+                    for (int k = 0; k < L; ++k)
+                        aij += (1.0 / fabs(n[k])) * (Delta(j + 1, k) - Delta(0, k)) * (Delta(i + 1, k) - Delta(0, k));
+                    w.A[i * No + j] = aij;
+                }
+            }
+            const bool ok = d_solve_lin_eq(No, w);
+            for (int i = 0; i < No; ++i)
+                bco[i] = ok ? (double)w.b[i] : 0.0;
+            if (!ok)
+                atomicExch(a.status, LWHIP_ERR_SINGULAR);
+        }
+        __syncthreads();
+        // sol += sum_i b_i (previous(count-i-2) - previous(count-1)), then previous(count-1) = sol  :104-113
+        double* p0 = slot(a.slots[0]);
+        for (int k = threadIdx.x; k < L; k += blockDim.x)
+        {
+            double v = n[k];
+            const double p0k = p0[k];
+            for (int i = 0; i < No; ++i)
+                v += bco[i] * (slot(a.slots[i + 1])[k] - p0k);
+            n[k] = v;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < L; k += blockDim.x)
+            p0[k] = n[k];
+        __syncthreads();
+    }
+    // max_change :138-156 between the last two stored solutions
+    double best = 0.0;
+    int bestIdx = 0x7fffffff;
+    if (a.haveTwo)
+    {
+        const double* old = slot(a.oldSlot);
+        const double* cur = slot(a.storeSlot);
+        for (int k = threadIdx.x; k < L; k += blockDim.x)
+        {
+            const double c = cur[k];
+            if (c != 0.0)
+            {
+                const double change = fabs((c - old[k]) / c);
+                if (change > best)
+                {
+                    best = change;
+                    bestIdx = k;
+                }
+            }
+        }
+    }
+    __shared__ double sV[256];
+    __shared__ int sI[256];
+    sV[threadIdx.x] = best;
+    sI[threadIdx.x] = bestIdx;
+    __syncthreads();
+    for (int s2 = blockDim.x / 2; s2 > 0; s2 >>= 1)
+    {
+        if (threadIdx.x < s2)
+        {
+            const double v = sV[threadIdx.x + s2];
+            const int i = sI[threadIdx.x + s2];
+            if (v > sV[threadIdx.x] || (v == sV[threadIdx.x] && i < sI[threadIdx.x]))
+            {
+                sV[threadIdx.x] = v;
+                sI[threadIdx.x] = i;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        a.change[2 * blockIdx.x] = sV[0];
+        a.change[2 * blockIdx.x + 1] = sV[0] > 0.0 ? (double)sI[0] : 0.0;
+    }
+}
+
+hipError_t launch_ng(const NgArgs& a, int nAtoms, hipStream_t stream)
+{
+    const size_t lds = (64 + solve_ws_doubles(a.Norder > 0 ? a.Norder : 1)) * sizeof(double);
+    hipLaunchKernelGGL(ng_kernel, dim3(nAtoms), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
 }

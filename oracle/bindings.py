@@ -268,3 +268,47 @@ class OracleContext(_Handle):
     def nr_post_update(self, atoms, stages, backgroundNe, ne, dC=None, nPrev=None, dt=0.0, crsw=1.0):
         args, keep = abi.make_nr_args(atoms, stages, backgroundNe, ne, dC=dC, nPrev=nPrev, dt=dt, crsw=crsw)
         return self.lib.lworacle_nr_post_update(self.h, C.byref(args))
+
+
+class NgHandle:
+    """Ng acceleration of one vector: kind='ref' is the reference's own struct Ng (Source/Ng.hpp) behind
+    oracle/ref_driver.cpp, kind='oracle' the C restatement."""
+
+    def __init__(self, kind, Norder=0, Nperiod=0, Ndelay=0, sol=None):
+        import numpy as np
+        self.np = np
+        lib = RefContext.lib_() if kind == 'ref' else OracleContext.lib_()
+        pre = 'lwref_ng_' if kind == 'ref' else 'lworacle_ng_'
+        self._new, self._free = getattr(lib, pre + 'new'), getattr(lib, pre + 'free')
+        self._acc, self._chg = getattr(lib, pre + 'accelerate'), getattr(lib, pre + 'max_change')
+        self._new.restype = C.c_void_p
+        self._new.argtypes = [C.c_int, C.c_int, C.c_int, abi.f64p, C.c_int]
+        self._free.argtypes = [C.c_void_p]
+        self._acc.argtypes = [C.c_void_p, abi.f64p, C.c_int]
+        self._chg.argtypes = [C.c_void_p, abi.f64p, abi.i32p]
+        if sol is not None:
+            sol = np.ascontiguousarray(sol, dtype=np.float64).ravel()
+            self.h = self._new(Norder, Nperiod, Ndelay, sol.ctypes.data_as(abi.f64p), sol.size)
+        else:
+            self.h = self._new(0, 0, 0, None, 0)
+
+    def accelerate(self, sol):
+        """In place on `sol` (a contiguous float64 array); returns whether it accelerated."""
+        flat = sol.reshape(-1)
+        assert flat.flags.c_contiguous and flat.dtype == self.np.float64
+        r = self._acc(self.h, flat.ctypes.data_as(abi.f64p), flat.size)
+        assert r >= 0
+        return bool(r)
+
+    def max_change(self):
+        d, i = C.c_double(0.0), C.c_int32(0)
+        self._chg(self.h, C.cast(C.byref(d), abi.f64p), C.cast(C.byref(i), abi.i32p))
+        return d.value, i.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._free(self.h)
+                self.h = None
+        except Exception:
+            pass

@@ -22,6 +22,7 @@
 #include "Lightweaver.hpp"
 #include "Bezier.hpp"
 #include "LuSolve.hpp"
+#include "Ng.hpp"
 
 namespace PrdCores { f64 GII(f64 aDamp, f64 qEmit, f64 qAbs); }
 
@@ -425,6 +426,35 @@ int lwref_nr_post_update(void* h, const lwhip_nr_args* a)
         return LWHIP_ERR_SINGULAR;
     }
     return LWHIP_OK;
+}
+
+// Ng acceleration: the reference's own struct Ng (Source/Ng.hpp)
+void* lwref_ng_new(int Norder, int Nperiod, int Ndelay, const double* sol, int len)
+{
+    if (sol)
+        return new Ng(Norder, Nperiod, Ndelay, F64View(const_cast<double*>(sol), len));
+    return new Ng();
+}
+
+void lwref_ng_free(void* h) { delete (Ng*)h; }
+
+int lwref_ng_accelerate(void* h, double* sol, int len)
+{
+    try
+    {
+        return ((Ng*)h)->accelerate(F64View(sol, len)) ? 1 : 0;
+    }
+    catch (const std::runtime_error& e)
+    {
+        return -1;
+    }
+}
+
+void lwref_ng_max_change(void* h, double* dMax, int* idx)
+{
+    NgChange c = ((Ng*)h)->max_change();
+    *dMax = c.dMax;
+    *idx = (int)c.dMaxIdx;
 }
 
 // redistribute_prd_lines (Source/Prd.cpp:648-653 -> PrdTemplates.hpp:175-351)

@@ -14,9 +14,12 @@ from oracle import bindings
 class OracleLoopContext:
     """The Context surface iterate_ctx_se uses, computing on the CPU oracle (host arrays authoritative)."""
 
-    def __init__(self, prob):
+    def __init__(self, prob, ng=None):
         self.prob = prob
         self.oc = bindings.OracleContext(prob)
+        self.ng = None
+        if ng is not None:   # Ng objects exist from Context construction on (LwMiddleLayer.pyx:2900)
+            self.ng = [bindings.NgHandle('oracle', *ng, sol=a.n) for a in prob.atoms if not a.detailed]
 
     def formal_sol_gamma_matrices(self, deviceResident=False):
         self.prob.gamma_prefill()
@@ -28,6 +31,11 @@ class OracleLoopContext:
         act = [a for a in self.prob.atoms if not a.detailed]
         before = [a.n.copy() for a in act]
         assert self.oc.stat_equil() == 0
+        if self.ng is not None:   # rel_diff_ng_accelerate (LwMiddleLayer.pyx:3318-3346)
+            acc = [g.accelerate(a.n) for g, a in zip(self.ng, act)]
+            mc = [g.max_change() for g in self.ng]
+            return IterationUpdate(updatedPops=True, dPops=[m[0] for m in mc], dPopsMaxIdx=[m[1] for m in mc],
+                                   ngAccelerated=any(acc))
         ch = [np.abs((a.n - b) / a.n).ravel() for a, b in zip(act, before)]
         return IterationUpdate(updatedPops=True, dPops=[float(c.max()) for c in ch],
                                dPopsMaxIdx=[int(np.argmax(c)) for c in ch])
@@ -80,6 +88,64 @@ def test_iterate_ctx_se_device_resident_matches_oracle_loop(gpu, prd):
     assert nHip == nOracle and 3 < nHip < 59
     assert finH[0].dJMax == pytest.approx(finO[0].dJMax, rel=1e-6)
     assert np.allclose(finH[1].dPops, finO[1].dPops, rtol=1e-5)
+    assert rel_err(p.J, q.J) <= TOL_CONVERGED
+    for a, b in zip(p.atoms, q.atoms):
+        assert rel_err(a.n, b.n) <= TOL_CONVERGED
+
+
+HAVE_REF = __import__('os').path.exists(bindings.REF_LIB)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+@pytest.mark.parametrize('ng', [(0, 0, 0), (2, 3, 5), (3, 4, 2), (1, 1, 0)])
+def test_oracle_ng_matches_the_reference_struct(ng):
+    """A geometrically converging vector sequence pushed through both implementations: identical
+    accelerate() decisions, solutions and max_change at every step."""
+    rng = np.random.default_rng(7)
+    target = 1.0 + rng.random(300)
+    err = rng.standard_normal(300)
+    x0 = target + err
+    a, b = bindings.NgHandle('ref', *ng, sol=x0), bindings.NgHandle('oracle', *ng, sol=x0)
+    xa, xb = x0.copy(), x0.copy()
+    nacc = 0
+    for it in range(30):
+        for x in (xa, xb):           # the iteration being accelerated: a slowly converging linear map
+            x[:] = target + 0.9 * (x - target) + 0.05 * np.roll(x - target, 1)
+        ra, rb = a.accelerate(xa), b.accelerate(xb)
+        assert ra == rb
+        nacc += ra
+        np.testing.assert_array_equal(xa, xb)
+        assert a.max_change() == b.max_change()
+    assert nacc == (0 if ng[0] == 0 else nacc) and (ng[0] == 0 or nacc >= 3)
+
+
+def test_oracle_ng_without_constructor_only_tracks_changes():
+    g = bindings.NgHandle('oracle')
+    x = np.array([1.0, 2.0, 4.0])
+    assert g.max_change() == (0.0, 0)
+    assert not g.accelerate(x.copy())
+    assert g.max_change() == (0.0, 0)
+    assert not g.accelerate(np.array([1.0, 2.5, 4.0]))
+    assert g.max_change() == (pytest.approx(0.2), 1)
+
+
+@pytest.mark.gpu
+def test_iterate_with_ng_acceleration_matches_oracle_loop(gpu):
+    """NgOptions(2, 3, 5) on the device against the same loop on the oracle with the restated Ng: same
+    acceleration steps, same iteration count, same converged state; and fewer iterations than plain MALI."""
+    from lightweaver_amd.context import Context
+    prob, _ = load_fixture('falc_h_ca_small')
+    kw = dict(NmaxIter=80, JTol=5e-2, popsTol=3e-2)
+    ng = (2, 3, 5)
+    q = prob.copy()
+    nOracle = iterate_ctx_se(OracleLoopContext(q, ng=ng), **kw)
+    nPlain = iterate_ctx_se(OracleLoopContext(prob.copy()), **kw)
+    p = prob.copy()
+    with Context(p) as ctx:
+        ctx.configure_ng(*ng)
+        nHip = iterate_ctx_se(ctx, **kw)
+        ctx.download(abi.ALL_OUTPUTS | abi.POPS)
+    assert nHip == nOracle < nPlain
     assert rel_err(p.J, q.J) <= TOL_CONVERGED
     for a, b in zip(p.atoms, q.atoms):
         assert rel_err(a.n, b.n) <= TOL_CONVERGED
