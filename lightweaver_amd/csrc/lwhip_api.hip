@@ -1336,7 +1336,7 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     double* stC = stG + gPool;
     double* stRij = stC + gPool;
     double* stRji = stRij + rPool;
-    bool anyC = false, anyR = false;
+    bool anyR = false;
     for (int ia = 0; ia < c->Natom; ++ia)
     {
         const lwhip_atom& a = c->atoms[ia];
@@ -1353,7 +1353,6 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         {
             // atoms without C keep whatever the pool holds: copy atom by atom, not the whole pool
             H2D(c->Cmat.p + c->gammaOff[ia], a.C, (size_t)a.Nlevel * a.Nlevel * Ns);
-            anyC = true;
         }
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
@@ -1392,7 +1391,6 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
             }
         }
     }
-    (void)anyC;
     if ((mask & LWHIP_POPS) && nPool)
         H2D(c->n.p, stN, nPool);
     if ((mask & LWHIP_GAMMA) && gPool)

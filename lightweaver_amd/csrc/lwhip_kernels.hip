@@ -1,9 +1,9 @@
 // lwhip_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the formal_sol_gamma_matrices iteration.
 //
 // Mapping: one workgroup owns a contiguous chunk of wavelengths and walks
-// it; inside a wavelength the 2*Nmu rays x Nspace depth points are flattened over the threads of
-// the workgroup (10 x 82 = 820 points -> 13 wavefronts, 98.6 % lane use), so every load of
-// phi[lt, mu, dir, k] is one fully coalesced 6.5 KB block.  The ray columns live in LDS for the
+// it; inside a wavelength the rays x Nspace depth points of a pass of G rays are flattened over the
+// threads of the workgroup (G = 5: 5 x 82 = 410 points -> 7 wavefronts, two workgroups per CU), so every
+// load of phi[lt, mu, dir, k] is a fully coalesced block.  The ray columns live in LDS for the
 // short-characteristic stencils; the only true recurrence, I_k = e_k I_{k-1} + b_k, is a chunked
 // scan.  Continua are ray-independent, so their opacities and per-level sums are evaluated once
 // per (lambda, k) and shared by all rays through LDS.  Gamma / rate integrals are summed over
