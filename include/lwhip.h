@@ -326,6 +326,40 @@ typedef struct lwhip_nr_args {
 } lwhip_nr_args;
 int lwhip_nr_post_update(lwhip_context* ctx, const lwhip_nr_args* args);
 
+/* ---- 2D short characteristics (tier 2): the formal solver primitive -------------------
+ * piecewise_besser_2d with interp_linear_2d (Source/FormalScalar2d.cpp:740-1184, 209-255) on an x-periodic
+ * Nz x Nx grid, given the intersection table the core builds (build_intersection_list, :1188-1327;
+ * Atmosphere::intersections, Source/LwAtmosphere.hpp:145-173), flattened as below.  Not yet wired into
+ * lwhip_formal_sol_gamma_matrices: this entry point solves chi, S -> I, Psi* for a batch of (ray,
+ * direction) pairs. */
+typedef struct lwhip_intersection {   /* IntersectionResult, Source/LwAtmosphere.hpp:93-140 */
+    int32_t axis;                     /* InterpolationAxis: 0 none (on a grid point), 1 interpolate along x, 2 along z */
+    int32_t _pad;
+    double fracZ, fracX;              /* fractional indices of the hit */
+    double distance;                  /* path length to it */
+} lwhip_intersection;
+
+typedef struct lwhip_grid2d {
+    int32_t Nx, Nz, Nrays, periodic;  /* periodic must be 1 */
+    int32_t zLowerBc, zUpperBc;       /* LWHIP_BC_ZERO / LWHIP_BC_THERMALISED */
+    int32_t NlongChar, _pad;
+    const double* x;                  /* [Nx] */
+    const double* z;                  /* [Nz] */
+    const double* mux;                /* [Nrays] */
+    const double* muz;                /* [Nrays] */
+    const double* temperature;        /* [Nz, Nx] (thermalised boundaries) */
+    const lwhip_intersection* uw;     /* [Nrays, 2, Nz, Nx] upwind hit of every point */
+    const lwhip_intersection* dw;     /* [Nrays, 2, Nz, Nx] downwind hit */
+    const int32_t* longCharIdx;       /* [Nrays, 2, Nz, Nx] index of the point's long characteristic, or -1 */
+    const int32_t* substepOff;        /* [NlongChar + 1] offsets into substeps */
+    const lwhip_intersection* substeps; /* the sub-steps of every long characteristic, upwind-most first */
+} lwhip_grid2d;
+
+/* nSolve problems: problem p is ray rays[p] (= 2 * mu + toObs), opacity chi + p * Nz * Nx, source S + ...;
+ * writes I and PsiStar (= Psi / chi) of the same shape.  All pointers are host pointers. */
+int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double wavelength, int nSolve, const int32_t* rays,
+                           const double* chi, const double* S, double* I, double* PsiStar);
+
 /* Voigt profiles phi and weights wphi of every line, on the device. */
 int lwhip_compute_profiles(lwhip_context* ctx);
 

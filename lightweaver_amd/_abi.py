@@ -93,6 +93,19 @@ class lwhip_prd_result(C.Structure):
                 ('dJPrdMax', f64p), ('dJPrdMaxIdx', i32p)]
 
 
+class lwhip_intersection(C.Structure):
+    _fields_ = [('axis', C.c_int32), ('_pad', C.c_int32), ('fracZ', C.c_double), ('fracX', C.c_double),
+                ('distance', C.c_double)]
+
+
+class lwhip_grid2d(C.Structure):
+    _fields_ = [('Nx', C.c_int32), ('Nz', C.c_int32), ('Nrays', C.c_int32), ('periodic', C.c_int32),
+                ('zLowerBc', C.c_int32), ('zUpperBc', C.c_int32), ('NlongChar', C.c_int32), ('_pad', C.c_int32),
+                ('x', f64p), ('z', f64p), ('mux', f64p), ('muz', f64p), ('temperature', f64p),
+                ('uw', C.POINTER(lwhip_intersection)), ('dw', C.POINTER(lwhip_intersection)),
+                ('longCharIdx', i32p), ('substepOff', i32p), ('substeps', C.POINTER(lwhip_intersection))]
+
+
 class lwhip_nr_args(C.Structure):
     _fields_ = [('Natoms', C.c_int32), ('_pad', C.c_int32), ('atoms', i32p),
                 ('stages', C.POINTER(f64p)), ('dC', C.POINTER(f64p)), ('nPrev', C.POINTER(f64p)),
@@ -125,6 +138,8 @@ SYMBOLS = [
     ('lwhip_stat_equil_report', C.c_int, [ctx_p, C.c_int, f64p, i32p]),
     ('lwhip_check_status', C.c_int, [ctx_p]),
     ('lwhip_compute_profiles', C.c_int, [ctx_p]),
+    ('lwhip_formal_solver_2d', C.c_int, [C.c_int, C.POINTER(lwhip_grid2d), C.c_double, C.c_int, i32p, f64p, f64p,
+                                          f64p, f64p]),
     ('lwhip_redistribute_prd', C.c_int, [ctx_p, C.c_int, C.c_double, C.POINTER(lwhip_prd_result)]),
     ('lwhip_prd_pack', C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ('lwhip_prd_partial', C.c_int, [ctx_p]),

@@ -2303,6 +2303,37 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
     return LWHIP_OK;
 }
 
+extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, double wavelength, int nSolve,
+                                           const int32_t* rays, const double* chi, const double* S, double* I,
+                                           double* PsiStar, char* err, int errLen);
+
+int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double wavelength, int nSolve, const int32_t* rays,
+                           const double* chi, const double* S, double* I, double* PsiStar)
+{
+    if (!grid || !rays || !chi || !S || !I || !PsiStar || nSolve < 0)
+        return fail(LWHIP_ERR_INVALID, "formal_solver_2d: null argument");
+    if (!grid->periodic)
+        return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: only x-periodic grids");
+    if (grid->Nx < 2 || grid->Nz < 2 || grid->Nx > 1024)
+        return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: need 2 <= Nx <= 1024 and Nz >= 2");
+    if (!grid->x || !grid->z || !grid->mux || !grid->muz || !grid->temperature || !grid->uw || !grid->dw
+        || !grid->longCharIdx || !grid->substepOff || (grid->NlongChar > 0 && !grid->substeps))
+        return fail(LWHIP_ERR_INVALID, "formal_solver_2d: incomplete grid description");
+    for (int p = 0; p < nSolve; ++p)
+        if (rays[p] < 0 || rays[p] >= 2 * grid->Nrays)
+            return fail(LWHIP_ERR_INVALID, "formal_solver_2d: ray index out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(LWHIP_ERR_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (nSolve == 0)
+        return LWHIP_OK;
+    char err[256] = { 0 };
+    const int st = lwhip_formal_solver_2d_impl(device, grid, wavelength, nSolve, rays, chi, S, I, PsiStar, err, sizeof(err));
+    if (st != LWHIP_OK)
+        return fail(st, err);
+    return LWHIP_OK;
+}
+
 int lwhip_compute_profiles(lwhip_context* c)
 {
     if (!c)

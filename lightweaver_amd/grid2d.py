@@ -1,0 +1,105 @@
+"""Flat description of an x-periodic 2D grid and its short-characteristic intersection table, the
+input of lwhip_formal_solver_2d (include/lwhip.h: lwhip_grid2d).  The table is what the reference's
+build_intersection_list produces (Source/FormalScalar2d.cpp:1188-1327); under Lightweaver the plugin reads
+it from Atmosphere::intersections, the tests load it from fixtures generated with the reference."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _abi as abi
+
+INTERSECTION_DTYPE = np.dtype([('axis', np.int32), ('_pad', np.int32), ('fracZ', np.float64),
+                               ('fracX', np.float64), ('distance', np.float64)])
+assert INTERSECTION_DTYPE.itemsize == C.sizeof(abi.lwhip_intersection)
+
+
+@dataclass
+class Grid2d:
+    x: np.ndarray               # [Nx]
+    z: np.ndarray               # [Nz]
+    mux: np.ndarray             # [Nrays]
+    muz: np.ndarray             # [Nrays]
+    temperature: np.ndarray     # [Nz, Nx]
+    uw: np.ndarray              # [Nrays, 2, Nz, Nx] INTERSECTION_DTYPE
+    dw: np.ndarray
+    longCharIdx: np.ndarray     # [Nrays, 2, Nz, Nx] int32
+    substepOff: np.ndarray      # [NlongChar + 1] int32
+    substeps: np.ndarray        # [substepOff[-1]] INTERSECTION_DTYPE
+    zLowerBc: int = abi.BC_THERMALISED
+    zUpperBc: int = abi.BC_ZERO
+
+    @property
+    def Nx(self):
+        return self.x.size
+
+    @property
+    def Nz(self):
+        return self.z.size
+
+    @property
+    def Nrays(self):
+        return self.mux.size
+
+    def descriptor(self) -> abi.lwhip_grid2d:
+        ip = C.POINTER(abi.lwhip_intersection)
+        for name in ('x', 'z', 'mux', 'muz', 'temperature'):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name), dtype=np.float64))
+        for name in ('uw', 'dw', 'substeps'):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name), dtype=INTERSECTION_DTYPE))
+        self.longCharIdx = np.ascontiguousarray(self.longCharIdx, dtype=np.int32)
+        self.substepOff = np.ascontiguousarray(self.substepOff, dtype=np.int32)
+        g = abi.lwhip_grid2d()
+        g.Nx, g.Nz, g.Nrays, g.periodic = self.Nx, self.Nz, self.Nrays, 1
+        g.zLowerBc, g.zUpperBc = self.zLowerBc, self.zUpperBc
+        g.NlongChar = self.substepOff.size - 1
+        g.x, g.z = self.x.ctypes.data_as(abi.f64p), self.z.ctypes.data_as(abi.f64p)
+        g.mux, g.muz = self.mux.ctypes.data_as(abi.f64p), self.muz.ctypes.data_as(abi.f64p)
+        g.temperature = self.temperature.ctypes.data_as(abi.f64p)
+        g.uw, g.dw = self.uw.ctypes.data_as(ip), self.dw.ctypes.data_as(ip)
+        g.longCharIdx = self.longCharIdx.ctypes.data_as(abi.i32p)
+        g.substepOff = self.substepOff.ctypes.data_as(abi.i32p)
+        g.substeps = self.substeps.ctypes.data_as(ip)
+        return g
+
+    def to_dict(self, prefix='grid/'):
+        d = {prefix + k: getattr(self, k) for k in ('x', 'z', 'mux', 'muz', 'temperature', 'longCharIdx', 'substepOff')}
+        for k in ('uw', 'dw', 'substeps'):
+            a = getattr(self, k)
+            d[prefix + k + '/axis'] = a['axis']
+            d[prefix + k + '/vals'] = np.stack([a['fracZ'], a['fracX'], a['distance']], axis=-1)
+        d[prefix + 'bc'] = np.array([self.zLowerBc, self.zUpperBc])
+        return d
+
+    @staticmethod
+    def from_dict(d, prefix='grid/'):
+        def inter(k):
+            ax, v = d[prefix + k + '/axis'], d[prefix + k + '/vals']
+            a = np.zeros(ax.shape, dtype=INTERSECTION_DTYPE)
+            a['axis'], a['fracZ'], a['fracX'], a['distance'] = ax, v[..., 0], v[..., 1], v[..., 2]
+            return a
+        bc = d[prefix + 'bc']
+        return Grid2d(x=d[prefix + 'x'], z=d[prefix + 'z'], mux=d[prefix + 'mux'], muz=d[prefix + 'muz'],
+                      temperature=d[prefix + 'temperature'], uw=inter('uw'), dw=inter('dw'),
+                      longCharIdx=d[prefix + 'longCharIdx'], substepOff=d[prefix + 'substepOff'],
+                      substeps=inter('substeps'), zLowerBc=int(bc[0]), zUpperBc=int(bc[1]))
+
+
+def formal_solver_2d(grid: Grid2d, wavelength: float, rays, chi, S, device: int = 0):
+    """chi, S: [nSolve, Nz, Nx]; rays[p] = 2 * mu + toObs.  Returns (I, PsiStar) of the same shape."""
+    from .context import _check, load_library
+    lib = load_library()
+    rays = np.ascontiguousarray(rays, dtype=np.int32)
+    chi = np.ascontiguousarray(chi, dtype=np.float64)
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    assert chi.shape == S.shape == (rays.size, grid.Nz, grid.Nx)
+    I = np.zeros_like(chi)
+    Psi = np.zeros_like(chi)
+    g = grid.descriptor()
+    _check(lib, lib.lwhip_formal_solver_2d(device, C.byref(g), float(wavelength), rays.size,
+                                           rays.ctypes.data_as(abi.i32p), chi.ctypes.data_as(abi.f64p),
+                                           S.ctypes.data_as(abi.f64p), I.ctypes.data_as(abi.f64p),
+                                           Psi.ctypes.data_as(abi.f64p)), 'lwhip_formal_solver_2d')
+    return I, Psi

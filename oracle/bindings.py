@@ -312,3 +312,76 @@ class NgHandle:
                 self.h = None
         except Exception:
             pass
+
+
+class Ref2d:
+    """The reference's 2D geometry (build_intersection_list) and solver (piecewise_besser_2d, interp_linear_2d)
+    on an x-periodic grid, behind oracle/ref_driver.cpp."""
+
+    def __init__(self, x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUpperBc=abi.BC_ZERO):
+        import numpy as np
+        self.np = np
+        lib = RefContext.lib_()
+        self.lib = lib
+        ip = C.POINTER(abi.lwhip_intersection)
+        lib.lwref_2d_create.restype = C.c_void_p
+        lib.lwref_2d_create.argtypes = [abi.f64p, C.c_int, abi.f64p, C.c_int, abi.f64p, abi.f64p, C.c_int, C.c_int,
+                                        C.c_int, abi.f64p]
+        lib.lwref_2d_destroy.argtypes = [C.c_void_p]
+        lib.lwref_2d_counts.argtypes = [C.c_void_p, abi.i32p, abi.i32p]
+        lib.lwref_2d_stencils.argtypes = [C.c_void_p, ip, ip, abi.i32p, abi.i32p, ip]
+        lib.lwref_2d_besser.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, abi.f64p, abi.f64p, abi.f64p, abi.f64p]
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.x, self.z, self.mux, self.muz, self.T = f(x), f(z), f(mux), f(muz), f(temperature)
+        self.bc = (zLowerBc, zUpperBc)
+        p = lambda a: a.ctypes.data_as(abi.f64p)
+        self.h = lib.lwref_2d_create(p(self.x), self.x.size, p(self.z), self.z.size, p(self.mux), p(self.muz),
+                                     self.mux.size, zLowerBc, zUpperBc, p(self.T))
+
+    def grid(self):
+        from lightweaver_amd.grid2d import INTERSECTION_DTYPE, Grid2d
+        np = self.np
+        nl, ns = C.c_int32(0), C.c_int32(0)
+        self.lib.lwref_2d_counts(self.h, C.cast(C.byref(nl), abi.i32p), C.cast(C.byref(ns), abi.i32p))
+        shape = (self.mux.size, 2, self.z.size, self.x.size)
+        uw = np.zeros(shape, dtype=INTERSECTION_DTYPE)
+        dw = np.zeros(shape, dtype=INTERSECTION_DTYPE)
+        li = np.zeros(shape, dtype=np.int32)
+        off = np.zeros(nl.value + 1, dtype=np.int32)
+        sub = np.zeros(max(ns.value, 1), dtype=INTERSECTION_DTYPE)
+        ip = C.POINTER(abi.lwhip_intersection)
+        self.lib.lwref_2d_stencils(self.h, uw.ctypes.data_as(ip), dw.ctypes.data_as(ip), li.ctypes.data_as(abi.i32p),
+                                   off.ctypes.data_as(abi.i32p), sub.ctypes.data_as(ip))
+        return Grid2d(x=self.x, z=self.z, mux=self.mux, muz=self.muz, temperature=self.T.reshape(self.z.size, -1),
+                      uw=uw, dw=dw, longCharIdx=li, substepOff=off, substeps=sub[:ns.value],
+                      zLowerBc=self.bc[0], zUpperBc=self.bc[1])
+
+    def besser(self, mu, toObs, wav, chi, S):
+        np = self.np
+        chi, S = np.ascontiguousarray(chi, dtype=np.float64), np.ascontiguousarray(S, dtype=np.float64)
+        I, Psi = np.zeros_like(chi), np.zeros_like(chi)
+        p = lambda a: a.ctypes.data_as(abi.f64p)
+        assert self.lib.lwref_2d_besser(self.h, mu, int(toObs), wav, p(chi), p(S), p(I), p(Psi)) == 0
+        return I, Psi
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.lwref_2d_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def oracle_2d_besser(grid, mu, toObs, wav, chi, S):
+    """The C restatement of piecewise_besser_2d (oracle/lw_oracle_2d.inc) on a lightweaver_amd.grid2d.Grid2d."""
+    import numpy as np
+    lib = OracleContext.lib_()
+    lib.lworacle_2d_besser.argtypes = [C.POINTER(abi.lwhip_grid2d), C.c_int, C.c_int, C.c_double, abi.f64p, abi.f64p,
+                                       abi.f64p, abi.f64p]
+    chi, S = np.ascontiguousarray(chi, dtype=np.float64), np.ascontiguousarray(S, dtype=np.float64)
+    I, Psi = np.zeros_like(chi), np.zeros_like(chi)
+    g = grid.descriptor()
+    p = lambda a: a.ctypes.data_as(abi.f64p)
+    assert lib.lworacle_2d_besser(C.byref(g), mu, int(toObs), wav, p(chi), p(S), p(I), p(Psi)) == 0
+    return I, Psi

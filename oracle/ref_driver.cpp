@@ -428,6 +428,107 @@ int lwref_nr_post_update(void* h, const lwhip_nr_args* a)
     return LWHIP_OK;
 }
 
+// ---- 2D: the core's own geometry (build_intersection_list) and solver (piecewise_besser_2d) ------------
+struct Ref2D
+{
+    Atmosphere atmos;
+    std::vector<double> x, z, mux, muz, temperature;
+};
+
+void* lwref_2d_create(const double* x, int Nx, const double* z, int Nz, const double* mux, const double* muz,
+                      int Nrays, int zLowerBc, int zUpperBc, const double* temperature)
+{
+    auto* r = new Ref2D();
+    r->x.assign(x, x + Nx);
+    r->z.assign(z, z + Nz);
+    r->mux.assign(mux, mux + Nrays);
+    r->muz.assign(muz, muz + Nrays);
+    r->temperature.assign(temperature, temperature + (size_t)Nx * Nz);
+    Atmosphere& a = r->atmos;
+    a.Ndim = 2;
+    a.Nx = Nx;
+    a.Ny = 0;
+    a.Nz = Nz;
+    a.Nspace = Nx * Nz;
+    a.Nrays = Nrays;
+    a.x = F64View(r->x.data(), Nx);
+    a.z = F64View(r->z.data(), Nz);
+    a.mux = F64View(r->mux.data(), Nrays);
+    a.muz = F64View(r->muz.data(), Nrays);
+    a.temperature = F64View(r->temperature.data(), Nx * Nz);
+    a.xLowerBc.type = PERIODIC;
+    a.xUpperBc.type = PERIODIC;
+    auto bc = [](int t) { return t == LWHIP_BC_THERMALISED ? THERMALISED : ZERO; };
+    a.zLowerBc.type = bc(zLowerBc);
+    a.zUpperBc.type = bc(zUpperBc);
+    build_intersection_list(&a);
+    return r;
+}
+
+void lwref_2d_destroy(void* h) { delete (Ref2D*)h; }
+
+void lwref_2d_counts(void* h, int* nLong, int* nSub)
+{
+    auto* r = (Ref2D*)h;
+    *nLong = (int)r->atmos.intersections.substeps.size();
+    int n = 0;
+    for (auto& s : r->atmos.intersections.substeps)
+        n += (int)s.steps.size();
+    *nSub = n;
+}
+
+static lwhip_intersection flat(const IntersectionResult& q)
+{
+    lwhip_intersection o{};
+    o.axis = (int)q.axis;
+    o.fracZ = q.fractionalZ;
+    o.fracX = q.fractionalX;
+    o.distance = q.distance;
+    return o;
+}
+
+void lwref_2d_stencils(void* h, lwhip_intersection* uw, lwhip_intersection* dw, int32_t* longIdx, int32_t* subOff,
+                       lwhip_intersection* sub)
+{
+    auto* r = (Ref2D*)h;
+    Atmosphere& a = r->atmos;
+    size_t o = 0;
+    for (int mu = 0; mu < a.Nrays; ++mu)
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < a.Nz; ++k)
+                for (int j = 0; j < a.Nx; ++j, ++o)
+                {
+                    const auto& st = a.intersections.intersections(mu, d, k, j);
+                    uw[o] = flat(st.uwIntersection);
+                    dw[o] = flat(st.dwIntersection);
+                    longIdx[o] = st.longCharIdx;
+                }
+    int n = 0;
+    for (size_t l = 0; l < a.intersections.substeps.size(); ++l)
+    {
+        subOff[l] = n;
+        for (auto& st : a.intersections.substeps[l].steps)
+            sub[n++] = flat(st);
+    }
+    subOff[a.intersections.substeps.size()] = n;
+}
+
+int lwref_2d_besser(void* h, int mu, int toObs, double wav, const double* chi, const double* S, double* I, double* Psi)
+{
+    auto* r = (Ref2D*)h;
+    LwInternal::FormalData fd;
+    fd.atmos = &r->atmos;
+    const int Ns = r->atmos.Nspace;
+    fd.chi = F64View(const_cast<double*>(chi), Ns);
+    fd.S = F64View(const_cast<double*>(S), Ns);
+    fd.I = F64View(I, Ns);
+    fd.Psi = F64View(Psi, Ns);
+    fd.interp = LwInternal::interp_linear_2d;
+    F64View1D wave(&wav, 1);
+    LwInternal::piecewise_besser_2d(&fd, 0, mu, toObs != 0, wave);
+    return LWHIP_OK;
+}
+
 // Ng acceleration: the reference's own struct Ng (Source/Ng.hpp)
 void* lwref_ng_new(int Norder, int Nperiod, int Ndelay, const double* sol, int len)
 {

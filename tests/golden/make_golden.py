@@ -183,6 +183,28 @@ def make_prd_fixture(name, baseName, prob):
     print(f'wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB')
 
 
+def make_fs2d_fixture(name):
+    """2D formal-solver fixture: the reference's intersection table of a small x-periodic grid and its
+    piecewise_besser_2d solutions for every (ray, direction)."""
+    from oracle.bindings import Ref2d
+    from tests.test_fs2d import fields, small_grid_inputs
+    x, z, mux, muz, T = small_grid_inputs()
+    ref = Ref2d(x, z, mux, muz, T)
+    grid = ref.grid()
+    chi, S = fields(grid, 1)
+    d = grid.to_dict()
+    d['chi'], d['S'], d['wav'] = chi, S, np.array(500.0)
+    I = np.zeros((grid.Nrays, 2, grid.Nz, grid.Nx))
+    Psi = np.zeros_like(I)
+    for mu in range(grid.Nrays):
+        for toObs in (0, 1):
+            I[mu, toObs], Psi[mu, toObs] = ref.besser(mu, toObs, 500.0, chi, S)
+    d['I'], d['Psi'] = I, Psi
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **d)
+    print(f'wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB')
+
+
 def finish(name, prob, out):
     d = problem_to_dict(prob)
     d.update(out)
@@ -198,6 +220,7 @@ def main():
     atmos = models.perturbed(models.falc82(), seed=11)
     make_fixture('falc_h_vel', models.build_problem(atmos, [models.H_6(0.25)], Nrays=2,
                                                     storeDepthData=True))
+    make_fs2d_fixture('fs2d_small')
     make_prd_fixture('falc_h_ca_prd', 'falc_h_ca_small', models.falc_h_ca(Nrays=3, lineScale=0.3, prd=True))
 
 

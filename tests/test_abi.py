@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'lwhip.h')
 
 STRUCTS = [abi.lwhip_transition, abi.lwhip_atom, abi.lwhip_boundary, abi.lwhip_problem,
-           abi.lwhip_options, abi.lwhip_iter_result, abi.lwhip_prd_result, abi.lwhip_nr_args]
+           abi.lwhip_options, abi.lwhip_iter_result, abi.lwhip_prd_result, abi.lwhip_nr_args, abi.lwhip_intersection, abi.lwhip_grid2d]
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -57,7 +57,7 @@ def test_header_enums_match_python():
 
 def test_library_exports_every_declared_symbol(hip_lib):
     txt = open(HEADER).read()
-    declared = set(re.findall(r'\b(lwhip_[a-z_A-Z]+)\s*\(', txt))
+    declared = set(re.findall(r'\b(lwhip_[a-z_A-Z0-9]+)\s*\(', txt))
     bound = {name for name, _, _ in abi.SYMBOLS}
     assert declared == bound, declared ^ bound
     for name in declared:

@@ -1,0 +1,117 @@
+"""2D short characteristics (first stage): the formal solver primitive
+piecewise_besser_2d + interp_linear_2d on an x-periodic grid.
+
+CPU: the C restatement (oracle/lw_oracle_2d.inc) against the real core compiled from /root/reference
+(oracle/_ref: build_intersection_list + piecewise_besser_2d) and against the committed fixture.
+GPU: lwhip_formal_solver_2d through the C ABI against the oracle.  Tolerance 1e-9 relative."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, rel_err
+from lightweaver_amd import _abi as abi
+from lightweaver_amd.grid2d import Grid2d
+from oracle import bindings
+
+HAVE_REF = os.path.exists(bindings.REF_LIB)
+FIXTURE = os.path.join(GOLDEN, 'fs2d_small.npz')
+
+
+def small_grid_inputs(Nx=14, Nz=18, seed=0):
+    """A FAL-C-like stratification with horizontal structure; three rays of an il7n3-like set (positive and
+    negative mu_x, shallow and steep), so that both interpolation axes and long characteristics occur."""
+    rng = np.random.default_rng(seed)
+    x = np.linspace(0.0, 1.3e6, Nx)
+    z = np.linspace(2.1e6, -1.0e5, Nz) + 0.0          # height, decreasing with index
+    z[1:-1] += 2.0e4 * rng.standard_normal(Nz - 2)    # non-uniform
+    z = np.sort(z)[::-1].copy()
+    muz = np.array([0.18, 0.55, 0.86])
+    mux = np.sqrt(1.0 - muz**2) * np.array([0.9, -0.75, 0.4])
+    T = 4500.0 + 3000.0 * np.exp(-z / 8e5)[:, None] * (1.0 + 0.1 * rng.random((Nz, Nx)))
+    return x, z, mux, muz, T
+
+
+def fields(grid, seed):
+    rng = np.random.default_rng(seed)
+    Nz, Nx = grid.Nz, grid.Nx
+    chi = 3e-6 * np.exp(-grid.z / 2.5e5)[:, None] * (1.0 + 0.5 * rng.random((Nz, Nx)))
+    S = 2e-8 * (1.0 + 0.8 * np.sin(np.linspace(0, 5, Nz))[:, None] * rng.random((Nz, Nx)) + rng.random((Nz, Nx)))
+    return chi, S
+
+
+def load_golden():
+    with np.load(FIXTURE) as zf:
+        d = {k: zf[k] for k in zf.files}
+    return Grid2d.from_dict(d), d
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+@pytest.mark.parametrize('bc', [(abi.BC_THERMALISED, abi.BC_ZERO), (abi.BC_ZERO, abi.BC_THERMALISED)])
+def test_oracle_2d_besser_matches_reference(bc):
+    x, z, mux, muz, T = small_grid_inputs()
+    ref = bindings.Ref2d(x, z, mux, muz, T, zLowerBc=bc[0], zUpperBc=bc[1])
+    grid = ref.grid()
+    assert grid.substepOff.size > 1 and set(np.unique(grid.uw['axis'])) == {0, 1, 2}
+    for seed in (1, 2):
+        chi, S = fields(grid, seed)
+        for mu in range(grid.Nrays):
+            for toObs in (0, 1):
+                Ir, Pr = ref.besser(mu, toObs, 500.0, chi, S)
+                Io, Po = bindings.oracle_2d_besser(grid, mu, toObs, 500.0, chi, S)
+                np.testing.assert_array_equal(Io, Ir)
+                np.testing.assert_array_equal(Po, Pr)
+
+
+def test_oracle_2d_besser_golden():
+    grid, d = load_golden()
+    n = 0
+    for mu in range(grid.Nrays):
+        for toObs in (0, 1):
+            I, P = bindings.oracle_2d_besser(grid, mu, toObs, float(d['wav']), d['chi'], d['S'])
+            np.testing.assert_array_equal(I, d['I'][mu, toObs])
+            np.testing.assert_array_equal(P, d['Psi'][mu, toObs])
+            n += 1
+    assert n == 6
+
+
+def test_2d_vertical_uniform_limit():
+    """Horizontally uniform chi and S: every column carries the same intensity (periodic grid)."""
+    grid, d = load_golden()
+    chi = np.repeat(d['chi'][:, :1], grid.Nx, axis=1)
+    S = np.repeat(d['S'][:, :1], grid.Nx, axis=1)
+    g2 = Grid2d(**{**grid.__dict__, 'temperature': np.repeat(grid.temperature[:, :1], grid.Nx, axis=1)})
+    I, _ = bindings.oracle_2d_besser(g2, 2, 1, float(d['wav']), chi, S)
+    assert rel_err(I, np.repeat(I[:, :1], grid.Nx, axis=1)) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_hip_2d_besser_matches_oracle(gpu):
+    from lightweaver_amd.grid2d import formal_solver_2d
+    grid, d = load_golden()
+    rays = np.arange(2 * grid.Nrays, dtype=np.int32)
+    chi = np.broadcast_to(d['chi'], (rays.size,) + d['chi'].shape)
+    S = np.broadcast_to(d['S'], (rays.size,) + d['S'].shape)
+    I, P = formal_solver_2d(grid, float(d['wav']), rays, chi, S)
+    for p, ray in enumerate(rays):
+        assert rel_err(I[p], d['I'][ray >> 1, ray & 1]) <= 1e-9
+        assert rel_err(P[p], d['Psi'][ray >> 1, ray & 1]) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Nx,Nz', [(5, 4), (70, 33), (256, 82)])
+def test_hip_2d_besser_sizes(gpu, Nx, Nz):
+    """Other sizes (incl. BASELINE config 5's 256 x 82) on stencil tables from the reference, where it is
+    present; skipped on the GPU box, which has no reference (the committed fixture covers it there)."""
+    if not HAVE_REF:
+        pytest.skip('needs oracle/_ref for the intersection table')
+    from lightweaver_amd.grid2d import formal_solver_2d
+    x, z, mux, muz, T = small_grid_inputs(Nx, Nz, seed=3)
+    ref = bindings.Ref2d(x, z, mux, muz, T)
+    grid = ref.grid()
+    chi, S = fields(grid, 5)
+    rays = np.arange(2 * grid.Nrays, dtype=np.int32)
+    I, P = formal_solver_2d(grid, 500.0, rays, np.broadcast_to(chi, (6,) + chi.shape), np.broadcast_to(S, (6,) + S.shape))
+    for p, ray in enumerate(rays):
+        Io, Po = bindings.oracle_2d_besser(grid, int(ray >> 1), int(ray & 1), 500.0, chi, S)
+        assert rel_err(I[p], Io) <= 1e-9 and rel_err(P[p], Po) <= 1e-9
