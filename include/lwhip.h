@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LWHIP_ABI_VERSION 1
+#define LWHIP_ABI_VERSION 2
 
 /* ---- enums (values mirror the reference where one exists) ---------------- */
 
@@ -142,6 +142,8 @@ typedef struct lwhip_boundary {
     const double* bcData;  /* [Nlambda, Nmu] (third reference extent is 1 in 1D) (CALLABLE only)   */
 } lwhip_boundary;
 
+struct lwhip_grid2d; /* 2D geometry, defined below */
+
 typedef struct lwhip_problem {
     int32_t abiVersion;    /* LWHIP_ABI_VERSION                                                    */
     int32_t Nspace;        /* depth points                                                         */
@@ -168,6 +170,11 @@ typedef struct lwhip_problem {
     double* depthEta;          /* [Nlambda, Nrays, 2, Nspace] or NULL                               */
     double* depthI;            /* [Nlambda, Nrays, 2, Nspace] or NULL                               */
     lwhip_atom* atoms;         /* [Natom]                                                           */
+    /* 2D (tier 2): non-NULL selects the x-periodic 2D geometry.  Then Nspace = Nz * Nx (index k * Nx + j),
+     * the formal solver is piecewise_besser_2d with interp_linear_2d whatever formalSolver says, `height` is
+     * unused, the z boundaries come from the grid, and I is [Nlambda, Nrays, Nx] (the top row of every
+     * column, Spectrum::I with Noutgoing = Nx).  Not supported on the device yet (LWHIP_ERR_UNSUPPORTED). */
+    const struct lwhip_grid2d* grid2d;
 } lwhip_problem;
 
 typedef struct lwhip_options {

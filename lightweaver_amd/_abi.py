@@ -5,7 +5,7 @@ offsets against a C program compiled from the header.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (include/lwhip.h)
 LINE, CONTINUUM = 0, 1
@@ -77,6 +77,7 @@ class lwhip_problem(C.Structure):
         ('J', f64p), ('I', f64p),
         ('depthChi', f64p), ('depthEta', f64p), ('depthI', f64p),
         ('atoms', C.POINTER(lwhip_atom)),
+        ('grid2d', C.c_void_p),
     ]
 
 

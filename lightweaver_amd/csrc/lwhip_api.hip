@@ -227,6 +227,11 @@ int validate(const lwhip_problem* p, std::string& why)
         why = "need Nspace >= 3, Nrays >= 1, Nlambda >= 1";
         return LWHIP_ERR_INVALID;
     }
+    if (p->grid2d)
+    {
+        why = "2D problems: only the formal-solver primitive lwhip_formal_solver_2d exists on the device so far";
+        return LWHIP_ERR_UNSUPPORTED;
+    }
     if (p->Nspace > 1024)
     {
         why = "Nspace > 1024 is not supported by the 1D sweep kernel";

@@ -353,3 +353,65 @@ def throughput_grid(NlambdaTarget=10240, Nrays=5, **kw) -> Problem:
         if n == NlambdaTarget:
             break
     return falc_h_ca(Nrays=Nrays, lineScale=best, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# 2D (x-periodic) problems from columns: BASELINE configs[4] in miniature
+# ------------------------------------------------------------------------------------------------
+def rays_2d(Nmuz=2):
+    """A small angle set for the half space mu_z > 0 with both signs of mu_x (toObs = False flips both, as the
+    reference does, Source/FormalScalar2d.cpp:766-771): Gauss-Legendre in mu_z, two azimuths each, weights
+    summing to 1."""
+    muz, w = ph.gauss_legendre_mu(Nmuz)
+    mux = np.sqrt(1.0 - muz**2) * np.cos(np.pi / 5.0)
+    return (np.concatenate([mux, -mux]), np.concatenate([muz, muz]), np.concatenate([0.5 * w, 0.5 * w]))
+
+
+def build_problem_2d(columns: List[Atmosphere1d], x: np.ndarray, models_: List[AtomModel], grid2d_factory,
+                     Nmuz=2, lambdaReference=500.0) -> Problem:
+    """An x-periodic 2D problem whose columns are 1D atmospheres on a common height grid.  Every per-depth array
+    of the 1D problems is laid out [.., Nz, Nx] (index k * Nx + j).  `grid2d_factory(x, z, mux, muz, T[Nz, Nx])`
+    returns the lightweaver_amd.grid2d.Grid2d (intersection table): the reference's geometry through
+    oracle/_ref where available, or a fixture."""
+    Nx = len(columns)
+    assert x.shape == (Nx,) and all(np.array_equal(c.height, columns[0].height) for c in columns)
+    mux, muz, wmu = rays_2d(Nmuz)
+    Nrays = muz.size
+    cols = [build_problem(c, models_, Nrays=Nrays, lambdaReference=lambdaReference, computeProfiles=False)
+            for c in columns]
+    p0 = cols[0]
+    Nz = p0.Nspace
+
+    def lay(arrs):        # [Nx] arrays of shape [..., Nz] -> [..., Nz * Nx]
+        a = np.stack(arrs, axis=-1)
+        return np.ascontiguousarray(a.reshape(a.shape[:-2] + (Nz * Nx,)))
+    T = lay([c.temperature for c in cols])
+    atoms = []
+    for ia, a0 in enumerate(p0.atoms):
+        trans = []
+        for kr, t0 in enumerate(a0.trans):
+            kw = dict(type=t0.type, i=t0.i, j=t0.j, Nblue=t0.Nblue, Nred=t0.Nred, lambda0=t0.lambda0,
+                      wavelength=t0.wavelength.copy(), Aji=t0.Aji, Bji=t0.Bji, Bij=t0.Bij, dopplerWidth=t0.dopplerWidth)
+            if t0.type == abi.LINE:
+                kw['aDamp'] = lay([c.atoms[ia].trans[kr].aDamp for c in cols])
+                kw['Qelast'] = lay([c.atoms[ia].trans[kr].Qelast for c in cols])
+                if t0.rhoPrd is not None:
+                    kw['rhoPrd'] = np.ones((t0.Nred - t0.Nblue, Nz * Nx))
+            else:
+                kw['alpha'] = t0.alpha.copy()
+            trans.append(TransitionData(**kw))
+        atoms.append(AtomData(name=a0.name, Nlevel=a0.Nlevel, n=lay([c.atoms[ia].n for c in cols]),
+                              nStar=lay([c.atoms[ia].nStar for c in cols]),
+                              nTotal=lay([c.atoms[ia].nTotal for c in cols]),
+                              vBroad=lay([c.atoms[ia].vBroad for c in cols]), trans=trans, detailed=a0.detailed,
+                              C=lay([c.atoms[ia].C for c in cols]) if a0.C is not None else None))
+    vz = lay([c.vlos for c in columns])
+    vlosMu = muz[:, None] * vz[None, :]
+    grid = grid2d_factory(x, columns[0].height, mux, muz, T.reshape(Nz, Nx))
+    prob = Problem(height=np.repeat(columns[0].height, Nx), temperature=T, muz=muz, wmu=wmu,
+                   wavelength=p0.wavelength, bgChi=lay([c.bgChi for c in cols]), bgEta=lay([c.bgEta for c in cols]),
+                   bgSca=lay([c.bgSca for c in cols]), atoms=atoms, vlosMu=vlosMu, J=lay([c.J for c in cols]),
+                   grid2d=grid)
+    compute_profiles_host(prob)
+    prob.gamma_prefill()
+    return prob

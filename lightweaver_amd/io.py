@@ -25,6 +25,8 @@ def problem_to_dict(prob: Problem, include_phi=True) -> dict:
         if bc.type == abi.BC_CALLABLE:
             d[f'{name}/idxs'] = bc.idxs
             d[f'{name}/bcData'] = bc.bcData
+    if getattr(prob, 'grid2d', None) is not None:
+        d.update(prob.grid2d.to_dict('grid2d/'))
     for ia, a in enumerate(prob.atoms):
         p = f'atom{ia}'
         d[f'{p}/meta'] = np.array([a.Nlevel, int(a.detailed), len(a.trans)], dtype=np.int64)
@@ -72,7 +74,11 @@ def problem_from_dict(d) -> Problem:
             b.idxs = np.array(d[f'{name}/idxs'], dtype=np.int32)
             b.bcData = np.array(d[f'{name}/bcData'], dtype=np.float64)
         bcs[name] = b
-    prob = Problem(height=d['height'], temperature=d['temperature'], muz=d['muz'], wmu=d['wmu'],
+    grid = None
+    if 'grid2d/x' in d:
+        from .grid2d import Grid2d
+        grid = Grid2d.from_dict(d, 'grid2d/')
+    prob = Problem(grid2d=grid, height=d['height'], temperature=d['temperature'], muz=d['muz'], wmu=d['wmu'],
                    wavelength=d['wavelength'], bgChi=d['bgChi'], bgEta=d['bgEta'],
                    bgSca=d['bgSca'], atoms=atoms, vlosMu=d['vlosMu'], J=np.array(d['J']),
                    formalSolver=int(meta[0]), zLowerBc=bcs['zLowerBc'], zUpperBc=bcs['zUpperBc'],

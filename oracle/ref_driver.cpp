@@ -126,10 +126,27 @@ void* lwref_create(const lwhip_problem* p, const char* schemeLib, int Nthreads,
         a.wmu = F64View(const_cast<f64*>(p->wmu), Nrays);
         configure_boundary(&a.zLowerBc, p->zLowerBc, Nla, Nrays);
         configure_boundary(&a.zUpperBc, p->zUpperBc, Nla, Nrays);
+        if (p->grid2d) // x-periodic 2D: the core builds its own intersection table from the grid
+        {
+            const lwhip_grid2d& g = *p->grid2d;
+            a.Ndim = 2;
+            a.Nx = g.Nx;
+            a.Nz = g.Nz;
+            a.Noutgoing = g.Nx;
+            a.x = F64View(const_cast<f64*>(g.x), g.Nx);
+            a.z = F64View(const_cast<f64*>(g.z), g.Nz);
+            a.height = a.z;
+            a.mux = F64View(const_cast<f64*>(g.mux), Nrays);
+            a.xLowerBc.type = PERIODIC;
+            a.xUpperBc.type = PERIODIC;
+            a.zLowerBc.type = (g.zLowerBc == LWHIP_BC_THERMALISED) ? THERMALISED : ZERO;
+            a.zUpperBc.type = (g.zUpperBc == LWHIP_BC_THERMALISED) ? THERMALISED : ZERO;
+            build_intersection_list(&a);
+        }
 
         auto& s = rc->spect;
         s.wavelength = F64View(const_cast<f64*>(p->wavelength), Nla);
-        s.I = F64View3D(p->I, Nla, Nrays, 1);
+        s.I = F64View3D(p->I, Nla, Nrays, p->grid2d ? p->grid2d->Nx : 1);
         s.J = F64View2D(p->J, Nla, Nspace);
 
         auto& bg = rc->background;
@@ -170,7 +187,9 @@ void* lwref_create(const lwhip_problem* p, const char* schemeLib, int Nthreads,
             ctx.iterFns = rc->iterManager.fns[0];
         }
 
-        const char* fsName = solver_name(p->formalSolver);
+        const char* fsName = p->grid2d ? "piecewise_besser_2d" : solver_name(p->formalSolver);
+        if (p->grid2d)
+            ctx.interpFn = InterpFn(2, "interp_linear_2d", LwInternal::interp_linear_2d);
         bool foundFs = false;
         for (auto& fs : rc->fsManager.formalSolvers)
         {

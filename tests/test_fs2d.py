@@ -115,3 +115,54 @@ def test_hip_2d_besser_sizes(gpu, Nx, Nz):
     for p, ray in enumerate(rays):
         Io, Po = bindings.oracle_2d_besser(grid, int(ray >> 1), int(ray & 1), 500.0, chi, S)
         assert rel_err(I[p], Io) <= 1e-9 and rel_err(P[p], Po) <= 1e-9
+
+
+# ---- the whole iteration on a 2D problem: CPU side pinned (the device path is the next stage) --------------
+def small_2d_problem():
+    """10 perturbed 24-point FAL-C columns, H active, 4 rays; the intersection table is the reference's."""
+    from lightweaver_amd.harness import models
+    base = models.resample(models.falc82(), 24)
+    Nx = 10
+    cols = [models.perturbed(base, seed=50 + j) for j in range(Nx)]
+    x = np.linspace(0.0, 9.0e5, Nx)
+    return models.build_problem_2d(cols, x, [models.H_6(0.12)],
+                                   lambda x, z, mux, muz, T: bindings.Ref2d(x, z, mux, muz, T).grid())
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+def test_oracle_2d_iteration_matches_reference():
+    """formal_sol_gamma_matrices + stat_eq on a 2D problem: the oracle (intensity core + 2D solver) against the
+    real core (its own build_intersection_list, piecewise_besser_2d, interp_linear_2d), bit for bit."""
+    p = small_2d_problem()
+    q = p.copy()
+    ref, orc = bindings.RefContext(p), bindings.OracleContext(q)
+    for it in range(3):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        assert ref.formal_sol_gamma_matrices() == orc.formal_sol_gamma_matrices()[:2]
+        np.testing.assert_array_equal(q.J, p.J)
+        np.testing.assert_array_equal(q.I, p.I)
+        for a, b in zip(q.atoms, p.atoms):
+            np.testing.assert_array_equal(a.Gamma, b.Gamma)
+            for ta, tb in zip(a.trans, b.trans):
+                np.testing.assert_array_equal(ta.Rij, tb.Rij)
+        assert ref.stat_equil() == orc.stat_equil() == 0
+        for a, b in zip(q.atoms, p.atoms):
+            np.testing.assert_array_equal(a.n, b.n)
+    assert p.I.shape == (p.Nlambda, p.Nrays, 10) and np.ptp(p.I[5, 0]) > 0     # columns differ
+
+
+def test_device_context_rejects_2d_problems_for_now(hip_lib):
+    from lightweaver_amd import io
+    from lightweaver_amd.context import Context, LwHipError
+    grid, d = load_golden()
+    # a structurally valid (if physically empty) 2D problem: no atoms, background only
+    from lightweaver_amd.model import Problem
+    Ns = grid.Nx * grid.Nz
+    prob = Problem(height=np.repeat(grid.z, grid.Nx), temperature=grid.temperature.ravel(), muz=grid.muz,
+                   wmu=np.full(grid.Nrays, 1.0 / grid.Nrays), wavelength=np.array([500.0, 501.0]),
+                   bgChi=np.ones((2, Ns)), bgEta=np.ones((2, Ns)), bgSca=np.zeros((2, Ns)), atoms=[], grid2d=grid)
+    rt = io.problem_from_dict(io.problem_to_dict(prob))
+    assert rt.grid2d is not None and rt.I.shape == (2, grid.Nrays, grid.Nx)
+    with pytest.raises(LwHipError, match='2D|no HIP device'):
+        Context(prob)
