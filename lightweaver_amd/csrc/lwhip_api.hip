@@ -100,6 +100,10 @@ struct lwhip_context
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
     int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, nChunksPrd = 0, G = 1;
     bool big = false;
+    bool is2d = false;            // x-periodic 2D geometry (prob.grid2d): batched pipeline of lwhip_2d.hip
+    int Nx = 1, batch2d = 1;
+    std::vector<DevLaHeader> hdrHost;
+    std::vector<int32_t> contLaHost;
     bool march = true;            // wavefront-autonomous sweep (lwhip_march.hip); false: the LDS-column sweep
     int marchD = 7, marchS = 12, marchWaves = 4;
     int64_t rowsTot = 0;
@@ -114,6 +118,9 @@ struct lwhip_context
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
     DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
+    DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi;
+    DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
+    DevBuf<int32_t> g2long, g2subOff, slotTrD;
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
     std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
     int64_t prdRowsTot = 0;
@@ -229,15 +236,29 @@ int validate(const lwhip_problem* p, std::string& why)
     }
     if (p->grid2d)
     {
-        why = "2D problems: only the formal-solver primitive lwhip_formal_solver_2d exists on the device so far";
-        return LWHIP_ERR_UNSUPPORTED;
+        const lwhip_grid2d& g = *p->grid2d;
+        if (!g.periodic || g.Nx < 2 || g.Nz < 2 || g.Nx > 1024 || g.Nx * g.Nz != p->Nspace || g.Nrays != p->Nrays)
+        {
+            why = "2D grid: x-periodic, 2 <= Nx <= 1024, Nz >= 2, Nx * Nz = Nspace, Nrays matching";
+            return LWHIP_ERR_UNSUPPORTED;
+        }
+        if (!g.mux || !g.uw || !g.dw || !g.longCharIdx || !g.substepOff || (g.NlongChar > 0 && !g.substeps))
+        {
+            why = "2D grid: incomplete intersection table";
+            return LWHIP_ERR_INVALID;
+        }
+        if (p->storeDepthData && (!p->depthChi || !p->depthEta || !p->depthI))
+        {
+            why = "storeDepthData set but depth arrays are null";
+            return LWHIP_ERR_INVALID;
+        }
     }
-    if (p->Nspace > 1024)
+    else if (p->Nspace > 1024)
     {
         why = "Nspace > 1024 is not supported by the 1D sweep kernel";
         return LWHIP_ERR_UNSUPPORTED;
     }
-    if (p->formalSolver < LWHIP_FS_LINEAR_1D || p->formalSolver > LWHIP_FS_BEZIER3_1D)
+    if (!p->grid2d && (p->formalSolver < LWHIP_FS_LINEAR_1D || p->formalSolver > LWHIP_FS_BEZIER3_1D))
     {
         why = "unknown formal solver";
         return LWHIP_ERR_INVALID;
@@ -741,6 +762,7 @@ int build_tables(lwhip_context* c)
     // March kernel: D depth points per lane, S = ceil(Ns / D) lanes per ray, R = 64 / S rays per pass.
     // Pick the D that needs the fewest lane-steps for all rays (ties: the smaller D, less serial work).
     c->march = env_int("LWHIP_SWEEP", 2) >= 3;
+    if (!c->is2d)
     {
         int bestD = 0;
         long bestCost = 0;
@@ -780,7 +802,9 @@ int build_tables(lwhip_context* c)
         if (march_lds_bytes(sz, c->marchWaves) > 64 * 1024)
             c->march = false;
     }
-    if (!c->march)
+    if (c->is2d)
+        c->march = false; // neither 1D sweep applies: the batched 2D pipeline (run_2d) does
+    if (!c->march && !c->is2d)
     {
     auto ldsFor = [&](int g) {
         SweepArgs s{};
@@ -878,6 +902,14 @@ int build_tables(lwhip_context* c)
     HIP_TRY(c->dtrans.upload(dt));
     HIP_TRY(c->laHdr.upload(hdr));
     HIP_TRY(c->slots.upload(slots));
+    {
+        std::vector<int32_t> st32(slotTr.begin(), slotTr.end());
+        if (st32.empty())
+            st32.push_back(0);
+        HIP_TRY(c->slotTrD.upload(st32));
+    }
+    c->hdrHost = hdr;
+    c->contLaHost = contLaHost;
     HIP_TRY(c->progs.upload(progs));
     HIP_TRY(c->progRows.upload(progRows));
     HIP_TRY(c->progEnts.upload(progEnts));
@@ -934,7 +966,7 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(c->bgEta.alloc(Nla * Ns));
     HIP_TRY(c->bgSca.alloc(Nla * Ns));
     HIP_TRY(c->J.alloc(Nla * Ns));
-    HIP_TRY(c->I.alloc(Nla * Nr));
+    HIP_TRY(c->I.alloc(Nla * Nr * (size_t)c->Nx));
     if (c->prob.storeDepthData)
     {
         HIP_TRY(c->depthChi.alloc(Nla * Nr * 2 * Ns));
@@ -958,11 +990,12 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(hipMemset(c->Cmat.p, 0, c->Cmat.n * sizeof(double)));
     HIP_TRY(c->Rij.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     HIP_TRY(c->Rji.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
-    HIP_TRY(c->partial.alloc((size_t)std::max(c->nChunks, c->nChunksPrd) * c->maxCT * 4 * Ns));
+    // (the 2D pipeline sums straight into the reduce buffer: no per-chunk slabs)
+    HIP_TRY(c->partial.alloc(c->is2d ? 8 : (size_t)std::max(c->nChunks, c->nChunksPrd) * c->maxCT * 4 * Ns));
     // reduce buffer: [Ntrans,4,Ns] partial sums followed by one (dJMax, idx) slot per shard
     HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize * (1 + c->prdLines.size())));
     HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
-    HIP_TRY(c->red8.alloc((size_t)std::max(c->Ntrans, 1) * LWHIP_REDUCE_SPLIT * 4 * Ns));
+    HIP_TRY(c->red8.alloc(c->is2d ? 8 : (size_t)std::max(c->Ntrans, 1) * LWHIP_REDUCE_SPLIT * 4 * Ns));
     c->gatherHost.assign(2 * (size_t)c->worldSize, 0.0);
     HIP_TRY(c->dJ.alloc(Nla));
     HIP_TRY(c->status.alloc(1));
@@ -987,6 +1020,43 @@ int alloc_state(lwhip_context* c)
         sz.accGlobal = 0;
         c->accGlobal = march_lds_bytes(sz, c->marchWaves) > 64 * 1024;
 
+    }
+    if (c->is2d)
+    {
+        const lwhip_grid2d& g = *c->prob.grid2d;
+        const size_t nSt = (size_t)g.Nrays * 2 * Ns;
+        auto upv = [](auto& buf, const auto* host, size_t count) -> hipError_t {
+            hipError_t e = buf.alloc(std::max<size_t>(count, 1));
+            if (e != hipSuccess || !count)
+                return e;
+            return hipMemcpy(buf.p, host, count * sizeof(*host), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(upv(c->g2mux, g.mux, (size_t)g.Nrays));
+        HIP_TRY(upv(c->g2uw, g.uw, nSt));
+        HIP_TRY(upv(c->g2dw, g.dw, nSt));
+        HIP_TRY(upv(c->g2long, g.longCharIdx, nSt));
+        HIP_TRY(upv(c->g2subOff, g.substepOff, (size_t)g.NlongChar + 1));
+        HIP_TRY(upv(c->g2sub, g.substeps, (size_t)g.substepOff[g.NlongChar]));
+        // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~256 MB
+        const size_t perLa = (size_t)4 * 2 * Nr * Ns * sizeof(double);
+        c->batch2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)64, ((size_t)256 << 20) / perLa, Nla }));
+        c->batch2d = std::max(1, env_int("LWHIP_BATCH2D", c->batch2d));
+        const size_t nb = (size_t)c->batch2d * 2 * Nr * Ns;
+        HIP_TRY(c->b2chi.alloc(nb));
+        HIP_TRY(c->b2S.alloc(nb));
+        HIP_TRY(c->b2I.alloc(nb));
+        HIP_TRY(c->b2Psi.alloc(nb));
+        // continuum rows of one batch
+        int64_t maxRows = 1;
+        for (size_t la0 = 0; la0 < Nla; la0 += c->batch2d)
+        {
+            int64_t rows = 0;
+            for (size_t la = la0; la < std::min(Nla, la0 + c->batch2d); ++la)
+                if (c->hdrHost[la].rowBase >= 0)
+                    rows += c->hdrHost[la].nRows + c->hdrHost[la].nMixed + c->hdrHost[la].nPure;
+            maxRows = std::max(maxRows, rows);
+        }
+        HIP_TRY(c->rowsBuf.alloc((size_t)maxRows * Ns));
     }
     HIP_TRY(c->stamps.alloc((size_t)c->nChunks * 12));
     HIP_TRY(hipMemset(c->stamps.p, 0, c->stamps.n * sizeof(long long)));
@@ -1196,6 +1266,8 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
             return fail(LWHIP_ERR_INVALID, "lwhip_create: bad worldRank");
         }
     }
+    c->is2d = prob->grid2d != nullptr;
+    c->Nx = c->is2d ? prob->grid2d->Nx : 1;
     c->Nla = c->laEnd - c->laStart;
     c->Ns = prob->Nspace;
     c->Nrays = prob->Nrays;
@@ -1429,7 +1501,7 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
     if (mask & LWHIP_J)
         D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
     if (mask & LWHIP_I)
-        D2H(p.I + l0 * Nr, c->I.p, Nla * Nr);
+        D2H(p.I + l0 * Nr * c->Nx, c->I.p, Nla * Nr * (size_t)c->Nx);
     if ((mask & LWHIP_DEPTHDATA) && p.storeDepthData)
     {
         D2H(p.depthChi + l0 * Nr * 2 * Ns, c->depthChi.p, Nla * Nr * 2 * Ns);
@@ -1505,11 +1577,117 @@ int lwhip_gamma_prefill_from_C(lwhip_context* c, double crsw)
     return LWHIP_OK;
 }
 
+// The 2D iteration of this context's wavelengths: batches of wavelengths through cont -> gather -> 2D formal
+// solver -> rates (lwhip_2d.hip), the running sums in the reduce buffer, dJ in its tail.
+static int run_2d(lwhip_context* c, int lambdaIterate)
+{
+    const lwhip_grid2d& g = *c->prob.grid2d;
+    const size_t Ns = c->Ns;
+    const int nRaysActive = 2 * c->Nrays;
+    HIP_TRY(hipMemsetAsync(c->red.p, 0, (size_t)c->Ntrans * 4 * Ns * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
+    Batch2dArgs a{};
+    a.Ns = (int32_t)Ns;
+    a.Nx = c->Nx;
+    a.Nrays = c->Nrays;
+    a.nRaysActive = nRaysActive;
+    a.lambdaIterate = lambdaIterate;
+    a.storeDepth = c->prob.storeDepthData ? 1 : 0;
+    a.NlevTot = c->NlevTot;
+    a.Natom = c->Natom;
+    a.rayList = c->rayAll.p;
+    a.muz = c->muz.p;
+    a.wmu = c->wmu.p;
+    a.laHdr = c->laHdr.p;
+    a.slots = c->slots.p;
+    a.bgChi = c->bgChi.p;
+    a.bgEta = c->bgEta.p;
+    a.bgSca = c->bgSca.p;
+    a.n = c->n.p;
+    a.phi = c->phi.p;
+    a.rho = c->rho.p;
+    a.wphi = c->wphi.p;
+    a.J = c->J.p;
+    a.Iout = c->I.p;
+    a.depthChi = c->depthChi.p;
+    a.depthEta = c->depthEta.p;
+    a.depthI = c->depthI.p;
+    a.chi = c->b2chi.p;
+    a.S = c->b2S.p;
+    a.I = c->b2I.p;
+    a.PsiStar = c->b2Psi.p;
+    a.red = c->red.p;
+    a.slotTr = c->slotTrD.p;
+    a.dJbits = (unsigned long long*)c->dJ.p;
+    Fs2dArgs f{};
+    f.Nx = g.Nx;
+    f.Nz = g.Nz;
+    f.Nrays = g.Nrays;
+    f.zLowerBc = g.zLowerBc;
+    f.zUpperBc = g.zUpperBc;
+    f.nRayCycle = nRaysActive;
+    f.mux = c->g2mux.p;
+    f.temperature = c->temperature.p;
+    f.uw = c->g2uw.p;
+    f.dw = c->g2dw.p;
+    f.longCharIdx = c->g2long.p;
+    f.substepOff = c->g2subOff.p;
+    f.substeps = c->g2sub.p;
+    f.rays = c->rayAll.p;
+    f.chi = c->b2chi.p;
+    f.S = c->b2S.p;
+    f.I = c->b2I.p;
+    f.PsiStar = c->b2Psi.p;
+    for (int la0 = 0; la0 < c->Nla; la0 += c->batch2d)
+    {
+        const int nLa = std::min(c->batch2d, c->Nla - la0);
+        // continuum rows of the batch: a window of the global row numbering
+        const auto lo = std::lower_bound(c->contLaHost.begin(), c->contLaHost.begin() + c->nContLa, la0);
+        const auto hi = std::lower_bound(c->contLaHost.begin(), c->contLaHost.begin() + c->nContLa, la0 + nLa);
+        const int contOff = (int)(lo - c->contLaHost.begin());
+        const int nCont = (int)(hi - lo);
+        double* rowsBase = c->rowsBuf.p;
+        if (nCont > 0)
+            rowsBase = c->rowsBuf.p - (size_t)c->hdrHost[*lo].rowBase * Ns;
+        HIP_TRY(launch_cont_range(c->dargs.p, c->hargs, contOff, nCont, rowsBase, c->stream));
+        a.la0 = la0;
+        a.nLa = nLa;
+        a.rows = rowsBase;
+        HIP_TRY(launch_gather2d(a, c->stream));
+        f.wavs = c->wavelength.p + la0;
+        HIP_TRY(launch_fs2d(f, nLa * nRaysActive, c->stream));
+        HIP_TRY(launch_rates2d(a, c->maxL, c->stream));
+    }
+    // dJMax and its first index into this shard's slot of the tail (the slab stages have nothing to do)
+    ReduceArgs r{};
+    r.Ns = (int32_t)Ns;
+    r.Ntrans = 0;
+    r.red = c->red.p + (size_t)c->Ntrans * 4 * Ns;
+    r.dJ = c->dJ.p;
+    r.Nla = c->Nla;
+    r.idxOffset = c->laStart;
+    r.world = c->worldSize;
+    r.rank = c->worldRank;
+    HIP_TRY(launch_reduce(r, c->stream));
+    return LWHIP_OK;
+}
+
 int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->is2d)
+    {
+        const int st2 = run_2d(c, lambdaIterate);
+        if (st2 != LWHIP_OK)
+            return st2;
+        if (c->worldSize > 1 && !c->prdLines.empty())
+            HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
+                                   2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
+        c->partialPending = true;
+        return LWHIP_OK;
+    }
     const SweepDyn dyn = make_dyn(c, false, lambdaIterate);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling)
@@ -1631,6 +1809,8 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->is2d)
+        return fail(LWHIP_ERR_UNSUPPORTED, "formal_sol (intensity only) is not available for 2D problems yet");
     HIP_TRY(hipSetDevice(c->device));
     const SweepDyn dyn = make_dyn(c, upOnly != 0, 0);
     HIP_TRY(run_sweep(c, dyn, false));
@@ -2016,6 +2196,8 @@ int lwhip_prd_pack(lwhip_context* c, void** devPtr, size_t* count)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->is2d)
+        return fail(LWHIP_ERR_UNSUPPORTED, "PRD sub-iterations are not available for 2D problems yet");
     if (c->partialPending || c->prdPending)
         return fail(LWHIP_ERR_INVALID, "lwhip_prd_pack inside an unfinished iteration / sub-iteration");
     HIP_TRY(hipSetDevice(c->device));
@@ -2344,6 +2526,8 @@ int lwhip_compute_profiles(lwhip_context* c)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->is2d)
+        return fail(LWHIP_ERR_UNSUPPORTED, "device profiles are not available for 2D problems yet");
     if (!c->prob.vlosMu)
         return fail(LWHIP_ERR_INVALID, "lwhip_compute_profiles needs vlosMu in the descriptor");
     for (int tr = 0; tr < c->Ntrans; ++tr)

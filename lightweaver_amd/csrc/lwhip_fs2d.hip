@@ -21,23 +21,6 @@ namespace lwhip
 {
 namespace
 {
-struct Fs2dArgs
-{
-    int32_t Nx, Nz, Nrays, zLowerBc, zUpperBc;
-    double wav;
-    const double* mux;
-    const double* temperature;
-    const lwhip_intersection* uw;
-    const lwhip_intersection* dw;
-    const int32_t* longCharIdx;
-    const int32_t* substepOff;
-    const lwhip_intersection* substeps;
-    const int32_t* rays;   // [nSolve]
-    const double* chi;     // [nSolve, Nz, Nx]
-    const double* S;
-    double* I;
-    double* PsiStar;
-};
 
 // interp_linear_2d :209-255
 DEVINL double f2_interp(const lwhip_intersection& loc, const double* p, int Nx)
@@ -159,7 +142,10 @@ __global__ void __launch_bounds__(1024) fs2d_kernel(const Fs2dArgs a)
 {
     __shared__ double sE[16], sB[16];
     const int Nx = a.Nx, Nz = a.Nz;
-    const int ray = a.rays[blockIdx.x];
+    // problem p: ray rays[p % nRayCycle]; wavelength wavs[p / nRayCycle] (2D iteration: a batch of wavelengths x
+    // the active rays) or the single a.wav (primitive)
+    const int ray = a.rays[blockIdx.x % a.nRayCycle];
+    const double wavHere = a.wavs ? a.wavs[blockIdx.x / a.nRayCycle] : a.wav;
     const int mu = ray >> 1;
     const bool toObs = (ray & 1) != 0;
     const double mux = toObs ? a.mux[mu] : -a.mux[mu];
@@ -195,12 +181,12 @@ __global__ void __launch_bounds__(1024) fs2d_kernel(const Fs2dArgs a)
             const double Tdw = f2_interp(dw, a.temperature, Nx);
             if (toObs)
             {
-                const double B0 = d_planck(Tdw, a.wav), B1 = d_planck(a.temperature[o], a.wav);
+                const double B0 = d_planck(Tdw, wavHere), B1 = d_planck(a.temperature[o], wavHere);
                 I0 = B1 - (B0 - B1) / dtauDw;
             }
             else
             {
-                const double B0 = d_planck(a.temperature[o], a.wav), B1 = d_planck(Tdw, a.wav);
+                const double B0 = d_planck(a.temperature[o], wavHere), B1 = d_planck(Tdw, wavHere);
                 I0 = B0 - (B1 - B0) / dtauDw;
             }
         }
@@ -326,6 +312,13 @@ __global__ void __launch_bounds__(1024) fs2d_kernel(const Fs2dArgs a)
 }
 }
 
+hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
+{
+    const int threads = ((a.Nx + 63) / 64) * 64;
+    hipLaunchKernelGGL(fs2d_kernel, dim3(nSolve), dim3(threads), 0, stream, a);
+    return hipGetLastError();
+}
+
 extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, double wavelength, int nSolve,
                                            const int32_t* rays, const double* chi, const double* S, double* I,
                                            double* PsiStar, char* err, int errLen);
@@ -369,6 +362,8 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
     a.zLowerBc = g->zLowerBc;
     a.zUpperBc = g->zUpperBc;
     a.wav = wavelength;
+    a.wavs = nullptr;
+    a.nRayCycle = nSolve;
     F2_TRY(up(g->mux, g->Nrays * sizeof(double), (void**)&a.mux));
     F2_TRY(up(g->temperature, Ns * sizeof(double), (void**)&a.temperature));
     F2_TRY(up(g->uw, nSt * sizeof(lwhip_intersection), (void**)&a.uw));
@@ -383,9 +378,7 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
     allocs.push_back(a.I);
     F2_TRY(hipMalloc((void**)&a.PsiStar, (size_t)nSolve * Ns * sizeof(double)));
     allocs.push_back(a.PsiStar);
-    const int threads = ((g->Nx + 63) / 64) * 64;
-    hipLaunchKernelGGL(fs2d_kernel, dim3(nSolve), dim3(threads), 0, nullptr, a);
-    F2_TRY(hipGetLastError());
+    F2_TRY(launch_fs2d(a, nSolve, nullptr));
     F2_TRY(hipDeviceSynchronize());
     F2_TRY(hipMemcpy(I, a.I, (size_t)nSolve * Ns * sizeof(double), hipMemcpyDeviceToHost));
     F2_TRY(hipMemcpy(PsiStar, a.PsiStar, (size_t)nSolve * Ns * sizeof(double), hipMemcpyDeviceToHost));

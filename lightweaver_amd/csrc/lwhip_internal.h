@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/lwhip.h"
+
 namespace lwhip
 {
 // physical constants, bit-identical to the reference (Source/Constants.hpp:6-47)
@@ -286,6 +288,63 @@ struct StatEqArgs
 };
 hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream);
 int stat_eq_blocks(int Ns, int maxNlevel);
+// 2D formal solver (lwhip_fs2d.hip): one workgroup per problem
+struct Fs2dArgs
+{
+    int32_t Nx, Nz, Nrays, zLowerBc, zUpperBc;
+    int32_t nRayCycle;     // problem p solves ray rays[p % nRayCycle] at wavelength wavs[p / nRayCycle]
+    double wav;            // used when wavs is null
+    const double* wavs;
+    const double* mux;
+    const double* temperature;
+    const lwhip_intersection* uw;
+    const lwhip_intersection* dw;
+    const int32_t* longCharIdx;
+    const int32_t* substepOff;
+    const lwhip_intersection* substeps;
+    const int32_t* rays;
+    const double* chi;     // [nSolve, Nz, Nx]
+    const double* S;
+    double* I;
+    double* PsiStar;
+};
+hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream);
+
+// the 2D iteration's pointwise kernels (lwhip_2d.hip)
+struct Batch2dArgs
+{
+    int32_t Ns, Nx, Nrays, nRaysActive, la0, nLa, lambdaIterate, storeDepth, NlevTot, Natom;
+    const int32_t* rayList;        // [nRaysActive] -> 2 * mu + toObs
+    const double* muz;
+    const double* wmu;
+    const DevLaHeader* laHdr;
+    const DevSlot* slots;
+    const double* rows;            // continuum rows of the batch, already offset: rows + rowBase * Ns is valid
+    const double* bgChi;
+    const double* bgEta;
+    const double* bgSca;
+    const double* n;
+    const double* phi;
+    const double* rho;
+    const double* wphi;
+    double* J;
+    double* Iout;                  // [Nla, Nrays, Nx]
+    double* depthChi;
+    double* depthEta;
+    double* depthI;
+    double* chi;                   // [nLa, nRaysActive, Ns] batch buffers
+    double* S;
+    const double* I;
+    const double* PsiStar;
+    double* red;                   // [Ntrans, 4, Ns] running sums of the iteration
+    const int32_t* slotTr;         // global transition of every slot record
+    unsigned long long* dJbits;    // [Nla] max_k |1 - Jdag/J| as the bits of a non-negative double
+};
+hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream);
+hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream);
+hipError_t launch_cont_range(const SweepArgs* devArgs, const SweepArgs& hostArgs, int contOff, int nCont, double* rowsBase,
+                             hipStream_t stream);
+
 // Ng acceleration of the populations (lwhip_pops.hip)
 struct NgAtom
 {

@@ -38,12 +38,12 @@ namespace lwhip
 // chi_eta_aux_accum (SimdFullIterationTemplates.hpp:59-109) for the continua of one wavelength:
 // Vji_c, the totals chiC = bgChi + sum chi_c, etaC = bgEta + sum eta_c, and the per-atom / per-level
 // sums the preconditioned rates need, written once per (wavelength, depth) for all rays to read.
-__global__ void __launch_bounds__(128) cont_kernel(const SweepArgs* __restrict__ ap)
+__global__ void __launch_bounds__(128) cont_kernel(const SweepArgs* __restrict__ ap, int contOff, double* rowsBase)
 {
     extern __shared__ double lds[]; // [2 * maxC][blockDim.x]: thread-private columns
     const int Ns = ARGS.Ns;
     const int T = blockDim.x;
-    const int la = CTAB(int32_t, ARGS.contLa)[blockIdx.x];
+    const int la = CTAB(int32_t, ARGS.contLa)[contOff + blockIdx.x];
     const DevLaHeader h = ld_c(CTAB(DevLaHeader, ARGS.laHdr) + la);
     const CONST_AS DevSlot* slots = CTAB(DevSlot, ARGS.slots) + h.off + h.nLine;
     const int nCont = h.nMixed + h.nPure;
@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(128) cont_kernel(const SweepArgs* __restrict__
     double* colV = lds + threadIdx.x;
     double* colX = lds + (size_t)ARGS.maxC * T + threadIdx.x;
     const GLOBAL_AS double* gN = GCD(ARGS.n);
-    GLOBAL_AS double* out = GD(ARGS.rows) + (size_t)h.rowBase * Ns;
+    // rowsBase: a window of the row numbering (2D iteration: only a batch of wavelengths is resident)
+    GLOBAL_AS double* out = (rowsBase ? (GLOBAL_AS double*)rowsBase : GD(ARGS.rows)) + (size_t)h.rowBase * Ns;
     for (int k = threadIdx.x; k < Ns; k += T)
     {
         const double boltz = d_exp_neg(-hc_kl * (1.0 / GCD(ARGS.temperature)[k]));
@@ -108,7 +109,24 @@ hipError_t launch_cont(const SweepArgs* devArgs, const SweepArgs& a, hipStream_t
             return err;
         configured = lds;
     }
-    hipLaunchKernelGGL(cont_kernel, dim3(a.nContLa), dim3(T), lds, stream, devArgs);
+    hipLaunchKernelGGL(cont_kernel, dim3(a.nContLa), dim3(T), lds, stream, devArgs, 0, (double*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_cont_range(const SweepArgs* devArgs, const SweepArgs& a, int contOff, int nCont, double* rowsBase,
+                             hipStream_t stream)
+{
+    if (nCont <= 0)
+        return hipSuccess;
+    const int T = 128;
+    const size_t lds = (size_t)2 * a.maxC * T * sizeof(double);
+    if (lds > 48 * 1024)
+    {
+        hipError_t err = hipFuncSetAttribute((const void*)cont_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess)
+            return err;
+    }
+    hipLaunchKernelGGL(cont_kernel, dim3(nCont), dim3(T), lds, stream, devArgs, contOff, rowsBase);
     return hipGetLastError();
 }
 

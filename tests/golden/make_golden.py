@@ -205,6 +205,24 @@ def make_fs2d_fixture(name):
     print(f'wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB')
 
 
+def make_2d_fixture(name):
+    """A small 2D problem (inputs incl. the reference's intersection table) and the reference's state after two
+    iterations of formal_sol_gamma_matrices + stat_equil."""
+    from tests.test_fs2d import small_2d_problem
+    prob = small_2d_problem()
+    d = problem_to_dict(prob)
+    p = prob.copy()
+    ref = RefContext(p)
+    for it in range(2):
+        p.gamma_prefill()
+        ref.formal_sol_gamma_matrices()
+        assert ref.stat_equil() == 0
+    d['out/J'], d['out/I'], d['out/n0'] = p.J, p.I, p.atoms[0].n
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **d)
+    print(f'wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB')
+
+
 def finish(name, prob, out):
     d = problem_to_dict(prob)
     d.update(out)
@@ -221,6 +239,7 @@ def main():
     make_fixture('falc_h_vel', models.build_problem(atmos, [models.H_6(0.25)], Nrays=2,
                                                     storeDepthData=True))
     make_fs2d_fixture('fs2d_small')
+    make_2d_fixture('falc2d_small')
     make_prd_fixture('falc_h_ca_prd', 'falc_h_ca_small', models.falc_h_ca(Nrays=3, lineScale=0.3, prd=True))
 
 

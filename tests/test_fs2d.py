@@ -152,17 +152,80 @@ def test_oracle_2d_iteration_matches_reference():
     assert p.I.shape == (p.Nlambda, p.Nrays, 10) and np.ptp(p.I[5, 0]) > 0     # columns differ
 
 
-def test_device_context_rejects_2d_problems_for_now(hip_lib):
+def test_2d_problem_round_trips_through_io():
     from lightweaver_amd import io
-    from lightweaver_amd.context import Context, LwHipError
-    grid, d = load_golden()
-    # a structurally valid (if physically empty) 2D problem: no atoms, background only
     from lightweaver_amd.model import Problem
+    grid, d = load_golden()
     Ns = grid.Nx * grid.Nz
     prob = Problem(height=np.repeat(grid.z, grid.Nx), temperature=grid.temperature.ravel(), muz=grid.muz,
                    wmu=np.full(grid.Nrays, 1.0 / grid.Nrays), wavelength=np.array([500.0, 501.0]),
                    bgChi=np.ones((2, Ns)), bgEta=np.ones((2, Ns)), bgSca=np.zeros((2, Ns)), atoms=[], grid2d=grid)
     rt = io.problem_from_dict(io.problem_to_dict(prob))
     assert rt.grid2d is not None and rt.I.shape == (2, grid.Nrays, grid.Nx)
-    with pytest.raises(LwHipError, match='2D|no HIP device'):
-        Context(prob)
+    assert np.array_equal(rt.grid2d.uw['fracX'], grid.uw['fracX'])
+
+
+def load_2d_problem():
+    """The committed 2D problem (inputs incl. the reference's intersection table) and the reference's outputs
+    after two iterations (tests/golden/make_golden.py: make_2d_fixture)."""
+    from helpers import load_fixture
+    return load_fixture('falc2d_small')
+
+
+def test_oracle_2d_iteration_golden():
+    prob, gold = load_2d_problem()
+    orc = bindings.OracleContext(prob)
+    for it in range(2):
+        prob.gamma_prefill()
+        orc.formal_sol_gamma_matrices()
+        assert orc.stat_equil() == 0
+    np.testing.assert_array_equal(prob.J, gold['out/J'])
+    np.testing.assert_array_equal(prob.I, gold['out/I'])
+    np.testing.assert_array_equal(prob.atoms[0].n, gold['out/n0'])
+
+
+@pytest.mark.gpu
+def test_hip_2d_iteration_matches_golden(gpu):
+    """formal_sol_gamma_matrices + stat_equil on the 2D problem through the device pipeline (cont -> gather2d ->
+    fs2d -> rates2d -> apply), against the reference's committed outputs."""
+    from lightweaver_amd.context import Context
+    prob, gold = load_2d_problem()
+    q = prob.copy()
+    orc = bindings.OracleContext(q)
+    with Context(prob) as ctx:
+        for it in range(2):
+            up = ctx.formal_sol_gamma_matrices()
+            q.gamma_prefill()
+            dJ, idx = orc.formal_sol_gamma_matrices()
+            assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+            assert rel_err(prob.J, q.J) <= 1e-9 * (it + 1)
+            assert rel_err(prob.I, q.I) <= 1e-9 * (it + 1)
+            for a, b in zip(prob.atoms, q.atoms):
+                # Gamma entries are sums over wavelengths and rays of terms of both signs on top of the collisional
+                # pre-fill; the device adds per-wavelength ray sums where the reference adds term by term
+                assert rel_err(a.Gamma, b.Gamma) <= 1e-8
+                for ta, tb in zip(a.trans, b.trans):
+                    assert rel_err(ta.Rij, tb.Rij) <= 1e-9 * (it + 1) and rel_err(ta.Rji, tb.Rji) <= 1e-9 * (it + 1)
+            ctx.stat_equil()
+            assert orc.stat_equil() == 0
+    assert rel_err(prob.J, gold['out/J']) <= 1e-8
+    assert rel_err(prob.atoms[0].n, gold['out/n0']) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_hip_2d_device_resident_and_batches(gpu, monkeypatch):
+    """Same result with one wavelength per batch and with everything resident in HBM."""
+    from lightweaver_amd.context import Context
+    prob, gold = load_2d_problem()
+    ref = prob.copy()
+    with Context(ref) as ctx:
+        for it in range(2):
+            ctx.formal_sol_gamma_matrices()
+            ctx.stat_equil()
+    monkeypatch.setenv('LWHIP_BATCH2D', '1')
+    with Context(prob) as ctx:
+        for it in range(2):
+            ctx.formal_sol_gamma_matrices(deviceResident=True)
+            ctx.stat_equil(deviceResident=True)
+        ctx.download(abi.ALL_OUTPUTS | abi.POPS)
+    assert rel_err(prob.J, ref.J) <= 1e-11 and rel_err(prob.atoms[0].n, ref.atoms[0].n) <= 1e-10
