@@ -14,6 +14,8 @@
 #include "lwhip_device.h"
 #include "../../include/lwhip.h"
 
+#include <algorithm>
+
 namespace lwhip
 {
 namespace
@@ -78,7 +80,9 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
     double Wsum = 0.0;
     for (int r = 0; r < a.nRaysActive; ++r)
         Wsum += 0.5 * a.wmu[a.rayList[r] >> 1];
-    for (int b = 0; b < a.nLa; ++b)
+    // blockIdx.y: a group of the batch's wavelengths with its own copy of the running sums (added up afterwards)
+    double* redG = a.red + (size_t)blockIdx.y * a.redStride;
+    for (int b = blockIdx.y; b < a.nLa; b += gridDim.y)
     {
         const int la = a.la0 + b;
         const DevLaHeader h = a.laHdr[la];
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
         for (int l = 0; l < MAXL; ++l)
             if (l < nLine)
             {
-                double* red = a.red + ((size_t)a.slotTr[h.off + l] * 4) * Ns + k;
+                double* red = redG + ((size_t)a.slotTr[h.off + l] * 4) * Ns + k;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     red[(size_t)q * Ns] += accL[l][q];
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
         for (int c = 0; c < MAXM; ++c)
             if (c < nMixed)
             {
-                double* red = a.red + ((size_t)a.slotTr[h.off + nLine + c] * 4) * Ns + k;
+                double* red = redG + ((size_t)a.slotTr[h.off + nLine + c] * 4) * Ns + k;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     red[(size_t)q * Ns] += accM[c][q];
@@ -242,7 +246,7 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
             const double vji = rowAt(sl.rVji);
             const double uji = sl.p[2] * vji;
             const double wla = sl.p[1];
-            double* red = a.red + ((size_t)a.slotTr[h.off + nLine + nMixed + cq] * 4) * Ns + k;
+            double* red = redG + ((size_t)a.slotTr[h.off + nLine + nMixed + cq] * 4) * Ns + k;
             if (sl.flags & 1)
             {
                 const double Meta = (sl.ms == 0) ? mE0 : ((sl.ms == 1) ? mE1 : 0.0);
@@ -262,6 +266,27 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
 }
 }
 
+// red[0] += red[1] + ... + red[G-1] (fixed order)
+__global__ void sum_groups_kernel(double* red, size_t n, size_t stride, int G)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        double s = red[i];
+        for (int g = 1; g < G; ++g)
+            s += red[i + g * stride];
+        red[i] = s;
+    }
+}
+
+hipError_t launch_sum_groups(double* red, size_t n, size_t stride, int G, hipStream_t stream)
+{
+    if (G <= 1 || n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, red,
+                       n, stride, G);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream)
 {
     hipLaunchKernelGGL(gather2d_kernel, dim3((a.Ns + 255) / 256, a.nRaysActive, a.nLa), dim3(256), 0, stream, a);
@@ -270,7 +295,7 @@ hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream)
 
 hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream)
 {
-    const dim3 grid((a.Ns + 127) / 128);
+    const dim3 grid((a.Ns + 127) / 128, a.nGroups);
     if (maxL <= 2)
         hipLaunchKernelGGL(rates2d_kernel<2>, grid, dim3(128), 0, stream, a);
     else if (maxL <= 4)

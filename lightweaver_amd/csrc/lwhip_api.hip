@@ -118,7 +118,8 @@ struct lwhip_context
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
     DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
-    DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi;
+    DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, red2d;
+    int groups2d = 1;
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
@@ -1038,9 +1039,16 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(upv(c->g2subOff, g.substepOff, (size_t)g.NlongChar + 1));
         HIP_TRY(upv(c->g2sub, g.substeps, (size_t)g.substepOff[g.NlongChar]));
         // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~256 MB
+        // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~2 GB.  Every kernel of a batch is
+        // latency-bound per workgroup (82 sequential planes in fs2d), so the batch should fill the chip.
         const size_t perLa = (size_t)4 * 2 * Nr * Ns * sizeof(double);
-        c->batch2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)64, ((size_t)256 << 20) / perLa, Nla }));
+        const size_t budget = (size_t)env_int("LWHIP_BATCH2D_MB", 2048) << 20;
+        c->batch2d = (int)std::max<size_t>(1, std::min<size_t>(budget / perLa, Nla));
         c->batch2d = std::max(1, env_int("LWHIP_BATCH2D", c->batch2d));
+        // rates2d: one thread per point per wavelength group; enough groups for ~2 wavefronts per SIMD
+        c->groups2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)c->batch2d, (131072 + Ns - 1) / Ns }));
+        c->groups2d = std::max(1, env_int("LWHIP_GROUPS2D", c->groups2d));
+        HIP_TRY(c->red2d.alloc((size_t)c->groups2d * std::max(c->Ntrans, 1) * 4 * Ns));
         const size_t nb = (size_t)c->batch2d * 2 * Nr * Ns;
         HIP_TRY(c->b2chi.alloc(nb));
         HIP_TRY(c->b2S.alloc(nb));
@@ -1584,7 +1592,8 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
     const lwhip_grid2d& g = *c->prob.grid2d;
     const size_t Ns = c->Ns;
     const int nRaysActive = 2 * c->Nrays;
-    HIP_TRY(hipMemsetAsync(c->red.p, 0, (size_t)c->Ntrans * 4 * Ns * sizeof(double), c->stream));
+    const size_t nRed = (size_t)c->Ntrans * 4 * Ns;
+    HIP_TRY(hipMemsetAsync(c->red2d.p, 0, (size_t)c->groups2d * nRed * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
     Batch2dArgs a{};
     a.Ns = (int32_t)Ns;
@@ -1616,7 +1625,9 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
     a.S = c->b2S.p;
     a.I = c->b2I.p;
     a.PsiStar = c->b2Psi.p;
-    a.red = c->red.p;
+    a.red = c->red2d.p;
+    a.redStride = nRed;
+    a.nGroups = c->groups2d;
     a.slotTr = c->slotTrD.p;
     a.dJbits = (unsigned long long*)c->dJ.p;
     Fs2dArgs f{};
@@ -1658,6 +1669,9 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
         HIP_TRY(launch_fs2d(f, nLa * nRaysActive, c->stream));
         HIP_TRY(launch_rates2d(a, c->maxL, c->stream));
     }
+    // the groups' sums, in a fixed order, into the reduce buffer
+    HIP_TRY(launch_sum_groups(c->red2d.p, nRed, nRed, c->groups2d, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->red.p, c->red2d.p, nRed * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     // dJMax and its first index into this shard's slot of the tail (the slab stages have nothing to do)
     ReduceArgs r{};
     r.Ns = (int32_t)Ns;

@@ -336,12 +336,15 @@ struct Batch2dArgs
     double* S;
     const double* I;
     const double* PsiStar;
-    double* red;                   // [Ntrans, 4, Ns] running sums of the iteration
+    double* red;                   // [nGroups][Ntrans, 4, Ns] running sums of the iteration, one copy per group
+    size_t redStride;              // doubles between the copies
+    int32_t nGroups, _padB;        // wavelength groups of a batch that accumulate concurrently
     const int32_t* slotTr;         // global transition of every slot record
     unsigned long long* dJbits;    // [Nla] max_k |1 - Jdag/J| as the bits of a non-negative double
 };
 hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream);
 hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream);
+hipError_t launch_sum_groups(double* red, size_t n, size_t stride, int G, hipStream_t stream);
 hipError_t launch_cont_range(const SweepArgs* devArgs, const SweepArgs& hostArgs, int contOff, int nCont, double* rowsBase,
                              hipStream_t stream);
 

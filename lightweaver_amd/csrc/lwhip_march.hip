@@ -22,6 +22,8 @@
 #include "lwhip_device.h"
 #include "../../include/lwhip.h"
 
+#include <algorithm>
+
 #ifndef LWHIP_MARCH_WPE
 #define LWHIP_MARCH_WPE 2
 #endif
@@ -56,7 +58,8 @@ __global__ void __launch_bounds__(128) cont_kernel(const SweepArgs* __restrict__
     const GLOBAL_AS double* gN = GCD(ARGS.n);
     // rowsBase: a window of the row numbering (2D iteration: only a batch of wavelengths is resident)
     GLOBAL_AS double* out = (rowsBase ? (GLOBAL_AS double*)rowsBase : GD(ARGS.rows)) + (size_t)h.rowBase * Ns;
-    for (int k = threadIdx.x; k < Ns; k += T)
+    // blockIdx.y strides over the points (2D domains: tens of thousands of points per wavelength)
+    for (int k = blockIdx.y * T + threadIdx.x; k < Ns; k += gridDim.y * T)
     {
         const double boltz = d_exp_neg(-hc_kl * (1.0 / GCD(ARGS.temperature)[k]));
         for (int c = 0; c < nCont; ++c)
@@ -126,7 +129,8 @@ hipError_t launch_cont_range(const SweepArgs* devArgs, const SweepArgs& a, int c
         if (err != hipSuccess)
             return err;
     }
-    hipLaunchKernelGGL(cont_kernel, dim3(nCont), dim3(T), lds, stream, devArgs, contOff, rowsBase);
+    const int ky = std::max(1, std::min(64, (a.Ns + T - 1) / T));
+    hipLaunchKernelGGL(cont_kernel, dim3(nCont, ky), dim3(T), lds, stream, devArgs, contOff, rowsBase);
     return hipGetLastError();
 }
 
