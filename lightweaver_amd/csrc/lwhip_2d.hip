@@ -69,10 +69,16 @@ __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
 }
 
 // ---- rates: one thread per point walks the wavelengths of the batch and the rays ----------------------------
+// Per wavelength, everything that does not depend on the ray -- populations, rho, the line weight, the continuum
+// rows the level sums start from -- is fetched once into registers / the thread's LDS column; the ray loop then
+// reads only I, Psi* and one phi per line from memory.
 template <int MAXL>
 __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
 {
     constexpr int MAXM = 4; // mixed continua integrated ray by ray at one wavelength
+    constexpr int NROW = 5; // rEtaA, rChiI, rChiJ, rUI, rUJ
+    __shared__ double sRow[(MAXL + MAXM) * NROW + MAXM][128];
+    const int tid = threadIdx.x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
     const bool on = k < Ns;
@@ -99,6 +105,51 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
         for (int c = 0; c < MAXM; ++c)
             accM[c][0] = accM[c][1] = accM[c][2] = accM[c][3] = 0.0;
         double mJ = 0.0, mM1 = 0.0, mE0 = 0.0, mE1 = 0.0;
+        // ---- ray-independent part of the wavelength ---------------------------------------------------------
+        double lG[MAXL], lNi[MAXL], lNj[MAXL], lW[MAXL];
+        int lgi[MAXL], lgj[MAXL], lat[MAXL], lop[MAXL];
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l)
+        {
+            lG[l] = lNi[l] = lNj[l] = lW[l] = 0.0;
+            lgi[l] = lgj[l] = lat[l] = -1;
+            lop[l] = 0;
+            if (l < nLine)
+            {
+                const DevSlot& sl = slots[l];
+                double g = sl.p[2];
+                if (sl.flags & 2)
+                    g *= a.rho[sl.rhoOff + kk];
+                lG[l] = g;
+                lNi[l] = a.n[(size_t)sl.gi * Ns + kk];
+                lNj[l] = a.n[(size_t)sl.gj * Ns + kk];
+                lW[l] = (sl.p[1] * a.wphi[(size_t)sl.row * Ns + kk]) * PI4_HC;
+                lgi[l] = sl.gi;
+                lgj[l] = sl.gj;
+                lat[l] = sl.atom;
+                lop[l] = sl.flags & 1;
+                if (lop[l])
+                {
+                    sRow[l * NROW + 0][tid] = rowAt(sl.rEtaA);
+                    sRow[l * NROW + 1][tid] = rowAt(sl.rChiI);
+                    sRow[l * NROW + 2][tid] = rowAt(sl.rChiJ);
+                    sRow[l * NROW + 3][tid] = rowAt(sl.rUI);
+                    sRow[l * NROW + 4][tid] = rowAt(sl.rUJ);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXM; ++c)
+            if (c < nMixed)
+            {
+                const DevSlot& sl = slots[nLine + c];
+                sRow[(MAXL + c) * NROW + 0][tid] = rowAt(sl.rEtaA);
+                sRow[(MAXL + c) * NROW + 1][tid] = rowAt(sl.rChiI);
+                sRow[(MAXL + c) * NROW + 2][tid] = rowAt(sl.rChiJ);
+                sRow[(MAXL + c) * NROW + 3][tid] = rowAt(sl.rUI);
+                sRow[(MAXL + c) * NROW + 4][tid] = rowAt(sl.rUJ);
+                sRow[(MAXL + MAXM) * NROW + c][tid] = rowAt(sl.rVji);
+            }
         for (int r = 0; r < a.nRaysActive; ++r)
         {
             const int ray = a.rayList[r];
@@ -117,32 +168,21 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
             if (nLine + nMixed == 0)
                 continue;
             double Vij[MAXL], Vji[MAXL], xl[MAXL], el[MAXL], luji[MAXL];
-            int lgi[MAXL], lgj[MAXL], lat[MAXL], lop[MAXL];
 #pragma unroll
             for (int l = 0; l < MAXL; ++l)
             {
                 Vij[l] = Vji[l] = xl[l] = el[l] = luji[l] = 0.0;
-                lgi[l] = lgj[l] = lat[l] = -1;
-                lop[l] = 0;
                 if (l < nLine)
                 {
                     const DevSlot& sl = slots[l];
                     const double vij = sl.p[0] * a.phi[sl.phiOff + (size_t)ray * Ns + kk];
-                    double g = sl.p[2];
-                    if (sl.flags & 2)
-                        g *= a.rho[sl.rhoOff + kk];
-                    const double vji = g * vij;
+                    const double vji = lG[l] * vij;
                     const double uji = sl.p[3] * vji;
-                    const double nj = a.n[(size_t)sl.gj * Ns + kk];
                     Vij[l] = vij;
                     Vji[l] = vji;
                     luji[l] = uji;
-                    xl[l] = a.n[(size_t)sl.gi * Ns + kk] * vij - nj * vji;
-                    el[l] = nj * uji;
-                    lgi[l] = sl.gi;
-                    lgj[l] = sl.gj;
-                    lat[l] = sl.atom;
-                    lop[l] = sl.flags & 1;
+                    xl[l] = lNi[l] * vij - lNj[l] * vji;
+                    el[l] = lNj[l] * uji;
                     if (lop[l])
                     {
                         if (sl.ms == 0)
@@ -153,8 +193,7 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
                 }
             }
             // level sums: continuum rows + this ray's lines (chi_eta_aux_accum bookkeeping)
-            auto levChi = [&](int g, int ri) {
-                double v = rowAt(ri);
+            auto levChi = [&](int g, double v) {
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                 {
@@ -165,16 +204,14 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
                 }
                 return v;
             };
-            auto levU = [&](int g, int ri) {
-                double v = rowAt(ri);
+            auto levU = [&](int g, double v) {
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                     if (lop[l] && lgj[l] == g)
                         v += luji[l];
                 return v;
             };
-            auto atomEta = [&](int at, int ri) {
-                double v = rowAt(ri);
+            auto atomEta = [&](int at, double v) {
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                     if (lop[l] && lat[l] == at)
@@ -186,14 +223,14 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
             {
                 if (l < nLine)
                 {
-                    const DevSlot& sl = slots[l];
-                    const double wlamu = ((sl.p[1] * a.wphi[(size_t)sl.row * Ns + kk]) * PI4_HC) * halfwmu;
-                    if (sl.flags & 1)
+                    const double wlamu = lW[l] * halfwmu;
+                    if (lop[l])
                     {
                         // compute_full_Ieff :192-204, compute_full_operator_rates :206-234
-                        const double Ieff = I - PsiS * atomEta(sl.atom, sl.rEtaA);
-                        accL[l][0] += ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(sl.gi, sl.rChiI) * levU(sl.gj, sl.rUJ))) * wlamu;
-                        accL[l][1] += ((Vij[l] * Ieff) - (PsiS * levChi(sl.gj, sl.rChiJ) * levU(sl.gi, sl.rUI))) * wlamu;
+                        const double* q = &sRow[l * NROW][tid];
+                        const double Ieff = I - PsiS * atomEta(lat[l], q[0]);
+                        accL[l][0] += ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(lgi[l], q[128]) * levU(lgj[l], q[4 * 128]))) * wlamu;
+                        accL[l][1] += ((Vij[l] * Ieff) - (PsiS * levChi(lgj[l], q[2 * 128]) * levU(lgi[l], q[3 * 128]))) * wlamu;
                     }
                     accL[l][2] += I * Vij[l] * wlamu;
                     accL[l][3] += (luji[l] + I * Vji[l]) * wlamu;
@@ -205,20 +242,21 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
                 if (c < nMixed) // mixed continua (always of active atoms)
                 {
                     const DevSlot& sl = slots[nLine + c];
+                    const double* q = &sRow[(MAXL + c) * NROW][tid];
                     const double vij = sl.p[0];
-                    const double vji = rowAt(sl.rVji);
+                    const double vji = sRow[(MAXL + MAXM) * NROW + c][tid];
                     const double uji = sl.p[2] * vji;
                     const double wlamu = sl.p[1] * halfwmu;
-                    const double Ieff = I - PsiS * atomEta(sl.atom, sl.rEtaA);
-                    accM[c][0] += ((uji + vji * Ieff) - (PsiS * levChi(sl.gi, sl.rChiI) * levU(sl.gj, sl.rUJ))) * wlamu;
-                    accM[c][1] += ((vij * Ieff) - (PsiS * levChi(sl.gj, sl.rChiJ) * levU(sl.gi, sl.rUI))) * wlamu;
+                    const double Ieff = I - PsiS * atomEta(sl.atom, q[0]);
+                    accM[c][0] += ((uji + vji * Ieff) - (PsiS * levChi(sl.gi, q[128]) * levU(sl.gj, q[4 * 128]))) * wlamu;
+                    accM[c][1] += ((vij * Ieff) - (PsiS * levChi(sl.gj, q[2 * 128]) * levU(sl.gi, q[3 * 128]))) * wlamu;
                     accM[c][2] += I * vij * wlamu;
                     accM[c][3] += (uji + I * vji) * wlamu;
                 }
             }
         } // rays
-        if (!on)
-            continue;
+        if (on)
+        {
         // ---- this wavelength's contributions into the point's column of the running sums ------------------
 #pragma unroll
         for (int l = 0; l < MAXL; ++l)
@@ -257,11 +295,20 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
             red[(size_t)2 * Ns] += mJ * vij * wla;
             red[(size_t)3 * Ns] += (uji * Wsum + mJ * vji) * wla;
         }
-        // J out, dJ = max_k |1 - Jdag/J|  :477-486
-        const double Jd = a.J[laNs + k];
-        a.J[laNs + k] = mJ;
-        const double dj = fabs(1.0 - Jd / mJ);
-        atomicMax(a.dJbits + la, (unsigned long long)__double_as_longlong(dj)); // non-negative doubles order like their bits
+        }
+        // J out, dJ = max_k |1 - Jdag/J|  :477-486 -- the wavefront's maximum first: one atomic per wavefront, not
+        // one per point on the same address
+        double dj = 0.0;
+        if (on)
+        {
+            const double Jd = a.J[laNs + k];
+            a.J[laNs + k] = mJ;
+            dj = fabs(1.0 - Jd / mJ);
+        }
+        for (int sh = 32; sh > 0; sh >>= 1)
+            dj = fmax(dj, __shfl_xor(dj, sh));
+        if ((threadIdx.x & 63) == 0)
+            atomicMax(a.dJbits + la, (unsigned long long)__double_as_longlong(dj)); // non-negative doubles order like their bits
     }
 }
 }

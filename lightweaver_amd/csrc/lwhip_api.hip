@@ -118,7 +118,8 @@ struct lwhip_context
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
     DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
-    DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, red2d;
+    DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
+    DevBuf<int32_t> b2idx;
     int groups2d = 1;
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
@@ -247,6 +248,11 @@ int validate(const lwhip_problem* p, std::string& why)
         {
             why = "2D grid: incomplete intersection table";
             return LWHIP_ERR_INVALID;
+        }
+        if (!fs2d_long_chars_ok(&g))
+        {
+            why = "2D grid: a long characteristic that does not end on a z plane";
+            return LWHIP_ERR_UNSUPPORTED;
         }
         if (p->storeDepthData && (!p->depthChi || !p->depthEta || !p->depthI))
         {
@@ -1038,10 +1044,9 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(upv(c->g2long, g.longCharIdx, nSt));
         HIP_TRY(upv(c->g2subOff, g.substepOff, (size_t)g.NlongChar + 1));
         HIP_TRY(upv(c->g2sub, g.substeps, (size_t)g.substepOff[g.NlongChar]));
-        // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~256 MB
         // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~2 GB.  Every kernel of a batch is
         // latency-bound per workgroup (82 sequential planes in fs2d), so the batch should fill the chip.
-        const size_t perLa = (size_t)4 * 2 * Nr * Ns * sizeof(double);
+        const size_t perLa = (size_t)2 * Nr * Ns * (8 * sizeof(double) + sizeof(int32_t)); // + fs2d's point maps
         const size_t budget = (size_t)env_int("LWHIP_BATCH2D_MB", 2048) << 20;
         c->batch2d = (int)std::max<size_t>(1, std::min<size_t>(budget / perLa, Nla));
         c->batch2d = std::max(1, env_int("LWHIP_BATCH2D", c->batch2d));
@@ -1054,6 +1059,8 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(c->b2S.alloc(nb));
         HIP_TRY(c->b2I.alloc(nb));
         HIP_TRY(c->b2Psi.alloc(nb));
+        HIP_TRY(c->b2coef.alloc(4 * nb));
+        HIP_TRY(c->b2idx.alloc(nb));
         // continuum rows of one batch
         int64_t maxRows = 1;
         for (size_t la0 = 0; la0 < Nla; la0 += c->batch2d)
@@ -1649,6 +1656,8 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
     f.S = c->b2S.p;
     f.I = c->b2I.p;
     f.PsiStar = c->b2Psi.p;
+    f.coef = c->b2coef.p;
+    f.cidx = c->b2idx.p;
     for (int la0 = 0; la0 < c->Nla; la0 += c->batch2d)
     {
         const int nLa = std::min(c->batch2d, c->Nla - la0);
@@ -1666,6 +1675,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
         a.rows = rowsBase;
         HIP_TRY(launch_gather2d(a, c->stream));
         f.wavs = c->wavelength.p + la0;
+        f.nSolve = nLa * nRaysActive;
         HIP_TRY(launch_fs2d(f, nLa * nRaysActive, c->stream));
         HIP_TRY(launch_rates2d(a, c->maxL, c->stream));
     }
@@ -2520,6 +2530,8 @@ int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double waveleng
     if (!grid->x || !grid->z || !grid->mux || !grid->muz || !grid->temperature || !grid->uw || !grid->dw
         || !grid->longCharIdx || !grid->substepOff || (grid->NlongChar > 0 && !grid->substeps))
         return fail(LWHIP_ERR_INVALID, "formal_solver_2d: incomplete grid description");
+    if (!fs2d_long_chars_ok(grid))
+        return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: a long characteristic that does not end on a z plane");
     for (int p = 0; p < nSolve; ++p)
         if (rays[p] < 0 || rays[p] >= 2 * grid->Nrays)
             return fail(LWHIP_ERR_INVALID, "formal_solver_2d: ray index out of range");

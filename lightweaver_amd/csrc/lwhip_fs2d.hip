@@ -116,62 +116,100 @@ DEVINL void f2_linear(double dtau, double Suw, double SLocal, double& e, double&
     psi = w0 - w1 / dtau;
 }
 
-// long characteristic up to the point's upwind hit (:1003-1043): intensity there and the last chi control point
-DEVINL double f2_long_char(const Fs2dArgs& a, int lc, const double* chi, const double* S, const double* I,
-                           double chiHere, double SHere, double& chiC)
+// long characteristic up to the point's upwind hit (:1003-1043).  The walk is affine in the intensity at its far
+// end, I(hit) = Ecum * I(st[0]) + acc, so the pass that knows no intensities can finish it; also returns the last
+// chi control point.
+DEVINL void f2_long_char(const Fs2dArgs& a, int lc, const double* chi, const double* S, double chiHere, double SHere,
+                         double& Ecum, double& acc, double& chiC)
 {
     const int Nx = a.Nx;
     const lwhip_intersection* st = a.substeps + a.substepOff[lc];
     const int n = a.substepOff[lc + 1] - a.substepOff[lc];
-    double Iuw = f2_interp(st[0], I, Nx);
+    Ecum = 1.0;
+    acc = 0.0;
     double edt, src, psi;
     for (int s = 1; s < n - 1; ++s)
     {
         f2_besser(st[s - 1].distance, st[s + 1].distance, f2_interp(st[s - 1], chi, Nx), f2_interp(st[s], chi, Nx),
                   f2_interp(st[s + 1], chi, Nx), f2_interp(st[s - 1], S, Nx), f2_interp(st[s], S, Nx),
                   f2_interp(st[s + 1], S, Nx), edt, src, psi, chiC);
-        Iuw = edt * Iuw + src;
+        acc = edt * acc + src;
+        Ecum = edt * Ecum;
     }
     const int s = n - 1;
     f2_besser(st[s - 1].distance, st[s].distance, f2_interp(st[s - 1], chi, Nx), f2_interp(st[s], chi, Nx), chiHere,
               f2_interp(st[s - 1], S, Nx), f2_interp(st[s], S, Nx), SHere, edt, src, psi, chiC);
-    return edt * Iuw + src;
+    acc = edt * acc + src;
+    Ecum = edt * Ecum;
 }
 
-__global__ void __launch_bounds__(1024) fs2d_kernel(const Fs2dArgs a)
+// where the intensity of a hit on a z plane is read: weights of I(idx), I(idx + 1) and the encoded index
+DEVINL void f2_hit_weights(const lwhip_intersection& loc, int Nx, int kPrev, double scale, double& c1, double& c2,
+                           int& idx)
 {
-    __shared__ double sE[16], sB[16];
+    const int z = (int)loc.fracZ;
+    int x;
+    if (loc.axis == 1)
+    {
+        x = (int)loc.fracX;
+        const double frac = loc.fracX - x;
+        c1 = scale * (1.0 - frac);
+        c2 = scale * frac;
+    }
+    else
+    {
+        x = (int)loc.fracX;
+        c1 = scale;
+        c2 = 0.0;
+    }
+    idx = (z == kPrev) ? x : -(z * Nx + x) - 1;
+}
+
+// Pass 1, one thread per (solve, plane, column): everything of the step that does not need an intensity -- the
+// optical depths, control points, BESSER weights, Psi*, the whole long characteristic -- reduced to the affine map
+// of the point.  Fully parallel; this is where the flops and the chi, S stencil reads are.
+__global__ void __launch_bounds__(256) fs2d_coef_kernel(const Fs2dArgs a)
+{
     const int Nx = a.Nx, Nz = a.Nz;
-    // problem p: ray rays[p % nRayCycle]; wavelength wavs[p / nRayCycle] (2D iteration: a batch of wavelengths x
+    const int Ns = Nx * Nz;
+    // workgroup order: wavelength fastest, then ray, then the 256-point tile -- neighbours in launch order share the
+    // tile's intersection records (64 B per point, the largest read), so each XCD's L2 serves them after the first
+    const int nLa = a.nSolve / a.nRayCycle;
+    const int laIdx = blockIdx.x % nLa;
+    const int rest = blockIdx.x / nLa;
+    const int rayIdx = rest % a.nRayCycle;
+    const int solve = laIdx * a.nRayCycle + rayIdx;
+    const int t = (rest / a.nRayCycle) * blockDim.x + threadIdx.x;
+    if (t >= Ns)
+        return;
+    // solve s: ray rays[s % nRayCycle]; wavelength wavs[s / nRayCycle] (2D iteration: a batch of wavelengths x
     // the active rays) or the single a.wav (primitive)
-    const int ray = a.rays[blockIdx.x % a.nRayCycle];
-    const double wavHere = a.wavs ? a.wavs[blockIdx.x / a.nRayCycle] : a.wav;
+    const int ray = a.rays[solve % a.nRayCycle];
+    const double wavHere = a.wavs ? a.wavs[solve / a.nRayCycle] : a.wav;
     const int mu = ray >> 1;
     const bool toObs = (ray & 1) != 0;
     const double mux = toObs ? a.mux[mu] : -a.mux[mu];
     const int dk = toObs ? -1 : 1;
     const int kStart = toObs ? Nz - 1 : 0;
     const int kEnd = toObs ? 0 : Nz - 1;
-    const int dj = (mux < 0) ? -1 : 1;
-    const int jStart = (mux < 0) ? Nx - 1 : 0;
-    const int p = threadIdx.x;               // position in processing order
-    const bool on = p < Nx;
-    const int j = jStart + (on ? p : 0) * dj;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
+    const int k = t / Nx, p = t - k * Nx;       // p: position in the ray's processing order
+    const int j = (mux < 0) ? Nx - 1 - p : p;
     const size_t plane0 = ((size_t)ray * Nz) * Nx;
     const lwhip_intersection* UW = a.uw + plane0;
     const lwhip_intersection* DW = a.dw + plane0;
     const int32_t* LC = a.longCharIdx + plane0;
-    const double* chi = a.chi + (size_t)blockIdx.x * Nz * Nx;
-    const double* S = a.S + (size_t)blockIdx.x * Nz * Nx;
-    double* I = a.I + (size_t)blockIdx.x * Nz * Nx;
-    double* Ps = a.PsiStar + (size_t)blockIdx.x * Nz * Nx;
+    const double* chi = a.chi + (size_t)solve * Ns;
+    const double* S = a.S + (size_t)solve * Ns;
+    double* Ps = a.PsiStar + (size_t)solve * Ns;
+    double* cf = a.coef + (size_t)solve * 4 * Ns + (size_t)k * Nx + p;
+    int32_t* ci = a.cidx + (size_t)solve * Ns + (size_t)k * Nx + p;
+    const size_t o = (size_t)k * Nx + j;
+    double A = 0.0, c1 = 0.0, c2 = 0.0, src = 0.0, psi = 0.0;
+    int idx = 0;
 
-    // boundary plane :876-948
-    if (on)
+    if (k == kStart)
     {
-        const size_t o = (size_t)kStart * Nx + j;
-        double I0 = 0.0;
+        // boundary plane :876-948
         const int bc = toObs ? a.zLowerBc : a.zUpperBc;
         if (bc == LWHIP_BC_THERMALISED)
         {
@@ -182,141 +220,242 @@ __global__ void __launch_bounds__(1024) fs2d_kernel(const Fs2dArgs a)
             if (toObs)
             {
                 const double B0 = d_planck(Tdw, wavHere), B1 = d_planck(a.temperature[o], wavHere);
-                I0 = B1 - (B0 - B1) / dtauDw;
+                src = B1 - (B0 - B1) / dtauDw;
             }
             else
             {
                 const double B0 = d_planck(a.temperature[o], wavHere), B1 = d_planck(Tdw, wavHere);
-                I0 = B0 - (B1 - B0) / dtauDw;
+                src = B0 - (B1 - B0) / dtauDw;
             }
         }
-        I[o] = I0;
+        cf[0] = 0.0;
+        cf[(size_t)Ns] = 0.0;
+        cf[(size_t)2 * Ns] = 0.0;
+        cf[(size_t)3 * Ns] = src;
+        *ci = 0;
         Ps[o] = 0.0;
+        return;
     }
-    __syncthreads();
 
-    for (int k = kStart + dk;; k += dk)
+    const bool last = (k == kEnd);
+    const int kPrev = k - dk;
+    const lwhip_intersection uw = UW[o];
+    const lwhip_intersection dw = DW[o];
+    const int lc = LC[o];
+    const double chiL = chi[o], SL = S[o];
+    double e;
+    if (lc < 0)
     {
-        const bool last = (k == kEnd);
-        // ---- every column's affine map I(k, j) = A * I(k, previous column) + B ----------------------------
-        double A = 0.0, B = 0.0, psi = 0.0;
-        size_t o = 0;
-        if (on)
+        const double chiUw = f2_interp(uw, chi, Nx);
+        const double Suw = f2_interp(uw, S, Nx);
+        if (last || dw.distance == 0.0)
         {
-            o = (size_t)k * Nx + j;
-            const lwhip_intersection uw = UW[o];
-            const lwhip_intersection dw = DW[o];
-            const int lc = LC[o];
-            const double chiL = chi[o], SL = S[o];
-            double e, src;
-            if (lc < 0)
-            {
-                const double chiUw = f2_interp(uw, chi, Nx);
-                const double Suw = f2_interp(uw, S, Nx);
-                if (last || dw.distance == 0.0)
-                {
-                    // linear step: the last plane (:1086-1101) uses the signed distance, the interior's
-                    // zero-downwind branch (:961-975) its absolute value; both are non-negative here
-                    const double dtau = 0.5 * (chiUw + chiL) * (last ? uw.distance : fabs(uw.distance));
-                    f2_linear(dtau, Suw, SL, e, src, psi);
-                }
-                else
-                {
-                    double chiC;
-                    f2_besser(uw.distance, dw.distance, chiUw, chiL, f2_interp(dw, chi, Nx), Suw, SL, f2_interp(dw, S, Nx),
-                              e, src, psi, chiC);
-                }
-                // the upwind intensity: previous plane (known) and, for a hit on the x face, this plane's
-                // previous column (the unknown of the recurrence)
-                if (uw.axis == 2)
-                {
-                    const int zm = (int)uw.fracZ, x = (int)uw.fracX;
-                    const double frac = uw.fracZ - zm;
-                    const double wK = (zm == k) ? (1.0 - frac) : frac;         // weight of plane k
-                    const double wP = (zm == k) ? frac : (1.0 - frac);
-                    const int zOther = (zm == k) ? zm + 1 : zm;
-                    A = e * wK;
-                    B = e * (wP * I[(size_t)zOther * Nx + x]) + src;
-                }
-                else
-                {
-                    A = 0.0;
-                    B = e * f2_interp(uw, I, Nx) + src;
-                }
-            }
-            else
-            {
-                double chiC;
-                const double Iuw = f2_long_char(a, lc, chi, S, I, chiL, SL, chiC);
-                const lwhip_intersection st = a.substeps[a.substepOff[lc + 1] - 1]; // = the upwind hit
-                const double chiUw = f2_interp(st, chi, Nx);
-                const double Suw = f2_interp(st, S, Nx);
-                if (last || dw.distance == 0.0)
-                {
-                    const double dtau = 0.5 * (chiUw + chiL) * (last ? uw.distance : st.distance);
-                    f2_linear(dtau, last ? f2_interp(uw, S, Nx) : Suw, SL, e, src, psi);
-                }
-                else
-                {
-                    // :1060-1075: the chi control point of the last sub-step is re-used, not recomputed
-                    const double chiDw = f2_interp(dw, chi, Nx);
-                    const double dtauUw = (1.0 / 3.0) * (chiUw + chiL + chiC) * st.distance;
-                    const double dtauDw = (0.5) * (chiL + chiDw) * dw.distance;
-                    const double Sdw = f2_interp(dw, S, Nx);
-                    const double SC = f2_control_point(dtauUw, dtauDw, Suw, SL, Sdw);
-                    double M, O, Cc;
-                    f2_coeffs(dtauUw, M, O, Cc, e);
-                    src = M * Suw + O * SL + Cc * SC;
-                    psi = O + Cc;
-                }
-                A = 0.0;
-                B = e * Iuw + src;
-            }
+            // linear step: the last plane (:1086-1101) uses the signed distance, the interior's
+            // zero-downwind branch (:961-975) its absolute value; both are non-negative here
+            const double dtau = 0.5 * (chiUw + chiL) * (last ? uw.distance : fabs(uw.distance));
+            f2_linear(dtau, Suw, SL, e, src, psi);
         }
         else
         {
-            A = 1.0; // identity beyond the row
-            B = 0.0;
+            double chiC;
+            f2_besser(uw.distance, dw.distance, chiUw, chiL, f2_interp(dw, chi, Nx), Suw, SL, f2_interp(dw, S, Nx), e,
+                      src, psi, chiC);
         }
-        // ---- inclusive scan of the maps along the processing order ------------------------------------------
-        double E = A, Bs = B;
-        affine_scan_wave(E, Bs);
-        if (lane == 63)
+        // the upwind intensity: previous plane (known) and, for a hit on the x face, this plane's
+        // previous column (the unknown of the recurrence)
+        if (uw.axis == 2)
         {
-            sE[wave] = E;
-            sB[wave] = Bs;
+            const int zm = (int)uw.fracZ, x = (int)uw.fracX;
+            const double frac = uw.fracZ - zm;
+            const double wK = (zm == k) ? (1.0 - frac) : frac;         // weight of plane k
+            const double wP = (zm == k) ? frac : (1.0 - frac);
+            const int zOther = (zm == k) ? zm + 1 : zm;
+            A = e * wK;
+            c1 = e * wP;
+            idx = (zOther == kPrev) ? x : -(zOther * Nx + x) - 1;
         }
-        __syncthreads();
-        if (wave > 0)
+        else
+            f2_hit_weights(uw, Nx, kPrev, e, c1, c2, idx);
+    }
+    else
+    {
+        double chiC, Ecum, acc;
+        f2_long_char(a, lc, chi, S, chiL, SL, Ecum, acc, chiC);
+        const lwhip_intersection st = a.substeps[a.substepOff[lc + 1] - 1]; // = the upwind hit
+        const double chiUw = f2_interp(st, chi, Nx);
+        const double Suw = f2_interp(st, S, Nx);
+        if (last || dw.distance == 0.0)
         {
-            // compose with the waves before this one (at most 15 small steps; the first map has A = 0)
-            double Ep = 1.0, Bp = 0.0;
-            for (int w = 0; w < wave; ++w)
+            const double dtau = 0.5 * (chiUw + chiL) * (last ? uw.distance : st.distance);
+            f2_linear(dtau, last ? f2_interp(uw, S, Nx) : Suw, SL, e, src, psi);
+        }
+        else
+        {
+            // :1060-1075: the chi control point of the last sub-step is re-used, not recomputed
+            const double chiDw = f2_interp(dw, chi, Nx);
+            const double dtauUw = (1.0 / 3.0) * (chiUw + chiL + chiC) * st.distance;
+            const double dtauDw = (0.5) * (chiL + chiDw) * dw.distance;
+            const double Sdw = f2_interp(dw, S, Nx);
+            const double SC = f2_control_point(dtauUw, dtauDw, Suw, SL, Sdw);
+            double M, O, Cc;
+            f2_coeffs(dtauUw, M, O, Cc, e);
+            src = M * Suw + O * SL + Cc * SC;
+            psi = O + Cc;
+        }
+        // I = e (Ecum I(far end) + acc) + src; the far end lies on a z plane (checked on the host)
+        f2_hit_weights(a.substeps[a.substepOff[lc]], Nx, kPrev, e * Ecum, c1, c2, idx);
+        src = e * acc + src;
+    }
+    cf[0] = A;
+    cf[(size_t)Ns] = c1;
+    cf[(size_t)2 * Ns] = c2;
+    cf[(size_t)3 * Ns] = src;
+    *ci = idx;
+    Ps[o] = psi / chiL;
+}
+
+// Pass 2, one wavefront per solve: the planes in sequence, each lane D consecutive columns of the processing
+// order.  A plane is: previous-plane intensities from LDS, the lane's D maps composed, one DPP scan over the lanes,
+// the D intensities written.  No workgroup barrier (a one-wavefront group's barrier is a wait on its own LDS
+// traffic), coefficients of the next plane prefetched while this one is scanned.
+template <int D>
+__global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
+{
+    extern __shared__ double prevI[]; // [Nx + 1], by x
+    const int Nx = a.Nx, Nz = a.Nz;
+    const size_t Ns = (size_t)Nx * Nz;
+    const int solve = blockIdx.x;
+    const int ray = a.rays[solve % a.nRayCycle];
+    const int mu = ray >> 1;
+    const bool toObs = (ray & 1) != 0;
+    const double mux = toObs ? a.mux[mu] : -a.mux[mu];
+    const int dk = toObs ? -1 : 1;
+    const int kStart = toObs ? Nz - 1 : 0;
+    const bool rev = mux < 0;
+    const int lane = threadIdx.x;
+    const int p0 = lane * D;
+    const double* cf = a.coef + (size_t)solve * 4 * Ns;
+    const int32_t* ci = a.cidx + (size_t)solve * Ns;
+    double* I = a.I + (size_t)solve * Ns;
+
+    double A[D], C1[D], C2[D], Sr[D];
+    int ix[D];
+    auto load = [&](int k, double (&lA)[D], double (&lC1)[D], double (&lC2)[D], double (&lS)[D], int (&lI)[D]) {
+        const size_t row = (size_t)k * Nx;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+        {
+            const int p = p0 + d;
+            const bool on = p < Nx;
+            const size_t q = row + (on ? p : 0);
+            lA[d] = on ? cf[q] : 1.0;             // identity beyond the row
+            lC1[d] = on ? cf[Ns + q] : 0.0;
+            lC2[d] = on ? cf[2 * Ns + q] : 0.0;
+            lS[d] = on ? cf[3 * Ns + q] : 0.0;
+            lI[d] = on ? ci[q] : 0;
+        }
+    };
+    load(kStart, A, C1, C2, Sr, ix);
+    if (lane == 0)
+        prevI[Nx] = 0.0;
+    for (int step = 0; step < Nz; ++step)
+    {
+        const int k = kStart + step * dk;
+        double nA[D], nC1[D], nC2[D], nS[D];
+        int nI[D];
+        if (step + 1 < Nz)
+            load(k + dk, nA, nC1, nC2, nS, nI);
+        // the lane's maps, with the previous plane's intensities folded into the offsets
+        double b[D];
+        double E = 1.0, B = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+        {
+            double v = Sr[d];
+            if (step > 0 && p0 + d < Nx)
             {
-                Bp = sE[w] * Bp + sB[w];
-                Ep = sE[w] * Ep;
+                const int idx = ix[d];
+                if (idx >= 0)
+                {
+                    v = fma(C1[d], prevI[idx], v);
+                    if (C2[d] != 0.0)
+                        v = fma(C2[d], prevI[idx + 1], v);
+                }
+                else
+                {
+                    const size_t f = (size_t)(-(idx + 1));
+                    v = fma(C1[d], I[f], v);
+                    if (C2[d] != 0.0)
+                        v = fma(C2[d], I[f + 1], v);
+                }
             }
-            Bs = E * Bp + Bs;
-            E = E * Ep;
+            b[d] = v;
+            B = fma(A[d], B, v);
+            E = A[d] * E;
         }
-        (void)nWaves;
-        if (on)
+        affine_scan_wave(E, B);
+        // intensity entering the lane = the composed offset of the lane before (the row's first map has A = 0)
+        double Iin = __shfl_up(B, 1);
+        if (lane == 0)
+            Iin = 0.0;
+        __syncthreads(); // every lane has read the previous plane
+        const size_t row = (size_t)k * Nx;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
         {
-            I[o] = Bs; // the first column's map has A = 0, so the composed offset is the intensity
-            Ps[o] = psi / chi[o];
+            const int p = p0 + d;
+            Iin = fma(A[d], Iin, b[d]);
+            if (p < Nx)
+            {
+                const int j = rev ? Nx - 1 - p : p;
+                prevI[j] = Iin;
+                I[row + j] = Iin;
+            }
         }
         __syncthreads();
-        if (last)
-            break;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+        {
+            A[d] = nA[d];
+            C1[d] = nC1[d];
+            C2[d] = nC2[d];
+            Sr[d] = nS[d];
+            ix[d] = nI[d];
+        }
     }
 }
 }
 
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
 {
-    const int threads = ((a.Nx + 63) / 64) * 64;
-    hipLaunchKernelGGL(fs2d_kernel, dim3(nSolve), dim3(threads), 0, stream, a);
+    const int Ns = a.Nx * a.Nz;
+    if (a.nSolve != nSolve || nSolve % a.nRayCycle != 0)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fs2d_coef_kernel, dim3(((Ns + 255) / 256) * nSolve), dim3(256), 0, stream, a);
+    const size_t lds = ((size_t)a.Nx + 1) * sizeof(double);
+    const int D = (a.Nx + 63) / 64;
+    if (D <= 1)
+        hipLaunchKernelGGL(fs2d_scan_kernel<1>, dim3(nSolve), dim3(64), lds, stream, a);
+    else if (D <= 2)
+        hipLaunchKernelGGL(fs2d_scan_kernel<2>, dim3(nSolve), dim3(64), lds, stream, a);
+    else if (D <= 4)
+        hipLaunchKernelGGL(fs2d_scan_kernel<4>, dim3(nSolve), dim3(64), lds, stream, a);
+    else if (D <= 8)
+        hipLaunchKernelGGL(fs2d_scan_kernel<8>, dim3(nSolve), dim3(64), lds, stream, a);
+    else if (D <= 16)
+        hipLaunchKernelGGL(fs2d_scan_kernel<16>, dim3(nSolve), dim3(64), lds, stream, a);
+    else
+        return hipErrorInvalidValue; // Nx <= 1024 is checked at the boundary
     return hipGetLastError();
+}
+
+// the far end of every long characteristic must lie on a z plane (axis X or none): pass 1 relies on it
+bool fs2d_long_chars_ok(const lwhip_grid2d* g)
+{
+    for (int lc = 0; lc < g->NlongChar; ++lc)
+        if (g->substeps[g->substepOff[lc]].axis == 2)
+            return false;
+    return true;
 }
 
 extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, double wavelength, int nSolve,
@@ -364,6 +503,7 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
     a.wav = wavelength;
     a.wavs = nullptr;
     a.nRayCycle = nSolve;
+    a.nSolve = nSolve;
     F2_TRY(up(g->mux, g->Nrays * sizeof(double), (void**)&a.mux));
     F2_TRY(up(g->temperature, Ns * sizeof(double), (void**)&a.temperature));
     F2_TRY(up(g->uw, nSt * sizeof(lwhip_intersection), (void**)&a.uw));
@@ -378,6 +518,10 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
     allocs.push_back(a.I);
     F2_TRY(hipMalloc((void**)&a.PsiStar, (size_t)nSolve * Ns * sizeof(double)));
     allocs.push_back(a.PsiStar);
+    F2_TRY(hipMalloc((void**)&a.coef, (size_t)nSolve * 4 * Ns * sizeof(double)));
+    allocs.push_back(a.coef);
+    F2_TRY(hipMalloc((void**)&a.cidx, (size_t)nSolve * Ns * sizeof(int32_t)));
+    allocs.push_back(a.cidx);
     F2_TRY(launch_fs2d(a, nSolve, nullptr));
     F2_TRY(hipDeviceSynchronize());
     F2_TRY(hipMemcpy(I, a.I, (size_t)nSolve * Ns * sizeof(double), hipMemcpyDeviceToHost));

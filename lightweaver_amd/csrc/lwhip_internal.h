@@ -292,6 +292,7 @@ int stat_eq_blocks(int Ns, int maxNlevel);
 struct Fs2dArgs
 {
     int32_t Nx, Nz, Nrays, zLowerBc, zUpperBc;
+    int32_t nSolve;        // number of solves of the launch, a multiple of nRayCycle
     int32_t nRayCycle;     // problem p solves ray rays[p % nRayCycle] at wavelength wavs[p / nRayCycle]
     double wav;            // used when wavs is null
     const double* wavs;
@@ -307,8 +308,13 @@ struct Fs2dArgs
     const double* S;
     double* I;
     double* PsiStar;
+    // the solve's two passes meet here: per point, in the ray's processing order, the affine map
+    // I(k, p) = A I(k, p - 1) + c1 I(idx) + c2 I(idx + 1) + src of the point
+    double* coef;          // [nSolve, 4 (A, c1, c2, src), Nz, Nx]
+    int32_t* cidx;         // [nSolve, Nz, Nx]: x of the hit on the previous plane, or -(flat index) - 1
 };
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream);
+bool fs2d_long_chars_ok(const lwhip_grid2d* g);
 
 // the 2D iteration's pointwise kernels (lwhip_2d.hip)
 struct Batch2dArgs
