@@ -5,7 +5,7 @@
 // iteration runs batch by batch over the wavelengths with its per-ray intermediates in HBM:
 //   cont_kernel (lwhip_march.hip)   continuum rows of the batch, once per (wavelength, point)
 //   gather2d_kernel                 chi, S per (wavelength, ray, point)         :113-179
-//   fs2d_kernel (lwhip_fs2d.hip)    I, Psi* per (wavelength, ray)
+//   fs2d_coef / fs2d_scan (lwhip_fs2d.hip)   I, Psi* per (wavelength, ray)
 //   rates2d_kernel                  J, Gamma / rate integrals, dJ               :181-234, 477-486
 // rates2d gives every spatial point to one thread, which walks the batch's wavelengths and rays and adds
 // into its own column of the running sums red[Ntrans, 4, Nspace]: no atomics, no slabs; apply_kernel then

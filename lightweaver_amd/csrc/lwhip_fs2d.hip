@@ -1,17 +1,18 @@
 // lwhip_fs2d.hip -- 2D short characteristics: piecewise_besser_2d with interp_linear_2d
 // (Source/FormalScalar2d.cpp:740-1184, 209-255) on an x-periodic grid, as a device primitive.
 //
-// One workgroup per (ray, direction) problem; thread p owns the p-th column of a z plane in the ray's
-// processing order (x ascending for mu_x >= 0, descending otherwise).  Planes are sequential.  Inside a
-// plane the reference walks the columns in order because a shallow ray's upwind hit lies on the x face
-// shared with the column just computed: I(k, j) = edt * [(1 - f) I(zm, j') + f I(zp, j')] + sources, with one
-// of zm / zp the plane being computed.  That is an affine recurrence I_p = a_p I_(p-1) + b_p along the
-// processing order -- the same composition as the 1D sweep's depth recurrence -- so every thread evaluates
-// its (a, b) independently and a workgroup-wide scan (DPP wavefront scans + one LDS hop) replaces the walk.
+// The reference walks the columns of a z plane in the ray's processing order (x ascending for mu_x >= 0,
+// descending otherwise) because a shallow ray's upwind hit lies on the x face shared with the column just
+// computed: I(k, j) = edt * [(1 - f) I(zm, j') + f I(zp, j')] + sources, with one of zm / zp the plane being
+// computed.  That is an affine recurrence I_p = a_p I_(p-1) + b_p along the processing order -- the same
+// composition as the 1D sweep's depth recurrence -- and everything expensive in it (optical depths, control
+// points, exp, Psi*) does not depend on any intensity.  So a solve is two passes:
+//   fs2d_coef_kernel   one thread per (solve, plane, column): the point's map (A, c1, c2, src, where to read I)
+//   fs2d_scan_kernel   one wavefront per solve: planes in sequence, a DPP scan of the maps per plane
 // The first column of a shallow ray is the periodic long characteristic, whose sub-steps reach back to the
 // previous plane and never read the plane in progress, so its a is 0 and the recurrence has a known start.
-// fp64; HBM traffic per solve is chi, S read ~3x (L1/L2-resident stencil neighbours) and I, Psi* written once;
-// the intersection table (64 B per point) is shared by all wavelengths and stays in L2.
+// fp64; HBM traffic per point and solve: chi, S read (neighbours through L1/L2), the 36 B map written and read,
+// I, Psi* written once; the intersection table (64 B per point) is shared by all wavelengths of a tile.
 #include "lwhip_device.h"
 #include "../../include/lwhip.h"
 
