@@ -339,8 +339,11 @@ int lwhip_nr_post_update(lwhip_context* ctx, const lwhip_nr_args* args);
  * Atmosphere::intersections, Source/LwAtmosphere.hpp:145-173), flattened as below.  Not yet wired into
  * lwhip_formal_sol_gamma_matrices: this entry point solves chi, S -> I, Psi* for a batch of (ray,
  * direction) pairs. */
+#define LWHIP_AXIS_NONE 0
+#define LWHIP_AXIS_X 1
+#define LWHIP_AXIS_Z 2
 typedef struct lwhip_intersection {   /* IntersectionResult, Source/LwAtmosphere.hpp:93-140 */
-    int32_t axis;                     /* InterpolationAxis: 0 none (on a grid point), 1 interpolate along x, 2 along z */
+    int32_t axis;                     /* InterpolationAxis (LWHIP_AXIS_*): 0 none (on a grid point), 1 interpolate along x, 2 along z */
     int32_t _pad;
     double fracZ, fracX;              /* fractional indices of the hit */
     double distance;                  /* path length to it */
@@ -366,6 +369,16 @@ typedef struct lwhip_grid2d {
  * writes I and PsiStar (= Psi / chi) of the same shape.  All pointers are host pointers. */
 int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double wavelength, int nSolve, const int32_t* rays,
                            const double* chi, const double* S, double* I, double* PsiStar);
+
+/* The intersection table of an x-periodic grid: build_intersection_list (Source/FormalScalar2d.cpp:1188-1327) with
+ * dw_intersection_2d (:60-105), uw_intersection_2d (:107-152), uw_intersection_2d_frac_x (:166-206).  Host-side
+ * geometry, once per atmosphere; reads Nx, Nz, Nrays, periodic, x, z, mux, muz of `grid`.  Call with uw == NULL to
+ * learn the sizes (*nLongChar, *nSubsteps), then with uw, dw, longCharIdx [Nrays, 2, Nz, Nx], substepOff
+ * [capLongChar + 1] and substeps [capSubsteps].  Bit-identical to the reference's table. */
+int lwhip_build_intersections(const lwhip_grid2d* grid, lwhip_intersection* uw, lwhip_intersection* dw,
+                              int32_t* longCharIdx, int32_t* substepOff, int32_t capLongChar,
+                              lwhip_intersection* substeps, int64_t capSubsteps, int32_t* nLongChar,
+                              int64_t* nSubsteps);
 
 /* Voigt profiles phi and weights wphi of every line, on the device. */
 int lwhip_compute_profiles(lwhip_context* ctx);

@@ -6,6 +6,7 @@ offsets against a C program compiled from the header.
 import ctypes as C
 
 ABI_VERSION = 2
+AXIS_NONE, AXIS_X, AXIS_Z = 0, 1, 2
 
 # enums (include/lwhip.h)
 LINE, CONTINUUM = 0, 1
@@ -141,6 +142,10 @@ SYMBOLS = [
     ('lwhip_compute_profiles', C.c_int, [ctx_p]),
     ('lwhip_formal_solver_2d', C.c_int, [C.c_int, C.POINTER(lwhip_grid2d), C.c_double, C.c_int, i32p, f64p, f64p,
                                           f64p, f64p]),
+    ('lwhip_build_intersections', C.c_int, [C.POINTER(lwhip_grid2d), C.POINTER(lwhip_intersection),
+                                             C.POINTER(lwhip_intersection), i32p, i32p, C.c_int32,
+                                             C.POINTER(lwhip_intersection), C.c_int64, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int64)]),
     ('lwhip_redistribute_prd', C.c_int, [ctx_p, C.c_int, C.c_double, C.POINTER(lwhip_prd_result)]),
     ('lwhip_prd_pack', C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ('lwhip_prd_partial', C.c_int, [ctx_p]),

@@ -2518,6 +2518,35 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
                                            const int32_t* rays, const double* chi, const double* S, double* I,
                                            double* PsiStar, char* err, int errLen);
 
+extern "C" int lwhip_build_intersections_impl(const lwhip_grid2d* grid, lwhip_intersection* uw, lwhip_intersection* dw,
+                                              int32_t* longCharIdx, int32_t* substepOff, int32_t capLongChar,
+                                              lwhip_intersection* substeps, int64_t capSubsteps, int32_t* nLongChar,
+                                              int64_t* nSubsteps);
+
+int lwhip_build_intersections(const lwhip_grid2d* grid, lwhip_intersection* uw, lwhip_intersection* dw,
+                              int32_t* longCharIdx, int32_t* substepOff, int32_t capLongChar,
+                              lwhip_intersection* substeps, int64_t capSubsteps, int32_t* nLongChar, int64_t* nSubsteps)
+{
+    if (!grid || !nLongChar || !nSubsteps || !grid->x || !grid->z || !grid->mux || !grid->muz)
+        return fail(LWHIP_ERR_INVALID, "build_intersections: null argument");
+    if (!grid->periodic)
+        return fail(LWHIP_ERR_UNSUPPORTED, "build_intersections: only x-periodic grids");
+    if (grid->Nx < 2 || grid->Nz < 2 || grid->Nrays < 1)
+        return fail(LWHIP_ERR_INVALID, "build_intersections: need Nx >= 2, Nz >= 2, Nrays >= 1");
+    if (uw && (!dw || !longCharIdx || !substepOff || (capSubsteps > 0 && !substeps)))
+        return fail(LWHIP_ERR_INVALID, "build_intersections: incomplete output buffers");
+    for (int m = 0; m < grid->Nrays; ++m)
+        if (!(grid->muz[m] != 0.0))
+            return fail(LWHIP_ERR_UNSUPPORTED, "build_intersections: a ray along x (muz = 0) never reaches a z plane");
+    const int st = lwhip_build_intersections_impl(grid, uw, dw, longCharIdx, substepOff, capLongChar, substeps,
+                                                  capSubsteps, nLongChar, nSubsteps);
+    if (st == LWHIP_ERR_INVALID)
+        return fail(st, "build_intersections: substepOff / substeps buffers too small");
+    if (st != LWHIP_OK)
+        return fail(st, "build_intersections: a long characteristic does not reach a z plane");
+    return LWHIP_OK;
+}
+
 int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double wavelength, int nSolve, const int32_t* rays,
                            const double* chi, const double* S, double* I, double* PsiStar)
 {

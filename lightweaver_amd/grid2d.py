@@ -1,7 +1,7 @@
 """Flat description of an x-periodic 2D grid and its short-characteristic intersection table, the
 input of lwhip_formal_solver_2d (include/lwhip.h: lwhip_grid2d).  The table is what the reference's
 build_intersection_list produces (Source/FormalScalar2d.cpp:1188-1327); under Lightweaver the plugin reads
-it from Atmosphere::intersections, the tests load it from fixtures generated with the reference."""
+it from Atmosphere::intersections; the mirror builds it with build_grid2d (lwhip_build_intersections, host side)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -85,6 +85,37 @@ class Grid2d:
                       temperature=d[prefix + 'temperature'], uw=inter('uw'), dw=inter('dw'),
                       longCharIdx=d[prefix + 'longCharIdx'], substepOff=d[prefix + 'substepOff'],
                       substeps=inter('substeps'), zLowerBc=int(bc[0]), zUpperBc=int(bc[1]))
+
+
+def build_grid2d(x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUpperBc=abi.BC_ZERO) -> Grid2d:
+    """The counterpart of Atmosphere.make_2d's geometry step for an x-periodic grid: the intersection table of
+    build_intersection_list (Source/FormalScalar2d.cpp:1188-1327) through lwhip_build_intersections.  mux, muz:
+    the quadrature's direction cosines [Nrays] (toObs direction; the table holds both directions)."""
+    from .context import _check, load_library
+    lib = load_library()
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    x, z, mux, muz = f(x), f(z), f(mux), f(muz)
+    temperature = f(temperature).reshape(z.size, x.size)
+    ip = C.POINTER(abi.lwhip_intersection)
+    g = abi.lwhip_grid2d()
+    g.Nx, g.Nz, g.Nrays, g.periodic = x.size, z.size, mux.size, 1
+    g.x, g.z = x.ctypes.data_as(abi.f64p), z.ctypes.data_as(abi.f64p)
+    g.mux, g.muz = mux.ctypes.data_as(abi.f64p), muz.ctypes.data_as(abi.f64p)
+    nl, ns = C.c_int32(0), C.c_int64(0)
+    _check(lib, lib.lwhip_build_intersections(C.byref(g), None, None, None, None, 0, None, 0, C.byref(nl),
+                                              C.byref(ns)), 'lwhip_build_intersections')
+    shape = (mux.size, 2, z.size, x.size)
+    uw = np.zeros(shape, dtype=INTERSECTION_DTYPE)
+    dw = np.zeros(shape, dtype=INTERSECTION_DTYPE)
+    li = np.zeros(shape, dtype=np.int32)
+    off = np.zeros(nl.value + 1, dtype=np.int32)
+    sub = np.zeros(max(ns.value, 1), dtype=INTERSECTION_DTYPE)
+    _check(lib, lib.lwhip_build_intersections(C.byref(g), uw.ctypes.data_as(ip), dw.ctypes.data_as(ip),
+                                              li.ctypes.data_as(abi.i32p), off.ctypes.data_as(abi.i32p), nl.value,
+                                              sub.ctypes.data_as(ip), ns.value, C.byref(nl), C.byref(ns)),
+           'lwhip_build_intersections')
+    return Grid2d(x=x, z=z, mux=mux, muz=muz, temperature=temperature, uw=uw, dw=dw, longCharIdx=li, substepOff=off,
+                  substeps=sub[:ns.value], zLowerBc=zLowerBc, zUpperBc=zUpperBc)
 
 
 def formal_solver_2d(grid: Grid2d, wavelength: float, rays, chi, S, device: int = 0):

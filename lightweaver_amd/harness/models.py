@@ -367,12 +367,12 @@ def rays_2d(Nmuz=2):
     return (np.concatenate([mux, -mux]), np.concatenate([muz, muz]), np.concatenate([0.5 * w, 0.5 * w]))
 
 
-def build_problem_2d(columns: List[Atmosphere1d], x: np.ndarray, models_: List[AtomModel], grid2d_factory,
+def build_problem_2d(columns: List[Atmosphere1d], x: np.ndarray, models_: List[AtomModel], grid2d_factory=None,
                      Nmuz=2, lambdaReference=500.0) -> Problem:
     """An x-periodic 2D problem whose columns are 1D atmospheres on a common height grid.  Every per-depth array
     of the 1D problems is laid out [.., Nz, Nx] (index k * Nx + j).  `grid2d_factory(x, z, mux, muz, T[Nz, Nx])`
-    returns the lightweaver_amd.grid2d.Grid2d (intersection table): the reference's geometry through
-    oracle/_ref where available, or a fixture."""
+    returns the lightweaver_amd.grid2d.Grid2d (intersection table); by default the library's own builder
+    (grid2d.build_grid2d = lwhip_build_intersections), the tests also pass the reference's through oracle/_ref."""
     Nx = len(columns)
     assert x.shape == (Nx,) and all(np.array_equal(c.height, columns[0].height) for c in columns)
     mux, muz, wmu = rays_2d(Nmuz)
@@ -407,6 +407,8 @@ def build_problem_2d(columns: List[Atmosphere1d], x: np.ndarray, models_: List[A
                               C=lay([c.atoms[ia].C for c in cols]) if a0.C is not None else None))
     vz = lay([c.vlos for c in columns])
     vlosMu = muz[:, None] * vz[None, :]
+    if grid2d_factory is None:
+        from ..grid2d import build_grid2d as grid2d_factory
     grid = grid2d_factory(x, columns[0].height, mux, muz, T.reshape(Nz, Nx))
     prob = Problem(height=np.repeat(columns[0].height, Nx), temperature=T, muz=muz, wmu=wmu,
                    wavelength=p0.wavelength, bgChi=lay([c.bgChi for c in cols]), bgEta=lay([c.bgEta for c in cols]),
