@@ -229,3 +229,42 @@ def test_hip_2d_device_resident_and_batches(gpu, monkeypatch):
             ctx.stat_equil(deviceResident=True)
         ctx.download(abi.ALL_OUTPUTS | abi.POPS)
     assert rel_err(prob.J, ref.J) <= 1e-11 and rel_err(prob.atoms[0].n, ref.atoms[0].n) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_hip_2d_wavelength_shards_sum_to_whole(gpu):
+    """BASELINE config 5's multi-GPU split on one device: two 2D contexts owning [0, m) and [m, Nlambda); their
+    reduce buffers (Gamma / rate partial sums, 8 * Ntrans * 4 * Nspace bytes -- MBs in 2D, so this is the one
+    bandwidth-relevant all-reduce) are added through zero-copy torch views, as ShardedIteration does with RCCL."""
+    import torch
+    from lightweaver_amd.context import Context
+    from lightweaver_amd.distributed import DeviceReduceBuffer
+    prob, _ = load_2d_problem()
+    q = prob.copy()
+    with Context(q) as whole:
+        upWhole = whole.formal_sol_gamma_matrices()
+    m = prob.Nlambda // 2 + 1
+    pa, pb = prob.copy(), prob.copy()
+    with Context(pa, laStart=0, laEnd=m, worldSize=2, worldRank=0) as A, \
+            Context(pb, laStart=m, laEnd=prob.Nlambda, worldSize=2, worldRank=1) as B:
+        views = []
+        for c in (A, B):
+            c.prob.gamma_prefill()
+            c.upload(abi.GAMMA)
+            c.fs_partial()
+            c.synchronize()
+            ptr, n = c.reduce_buffer()
+            views.append(torch.as_tensor(DeviceReduceBuffer(ptr, n), device='cuda'))
+        total = views[0] + views[1]
+        for c, v in zip((A, B), views):
+            v.copy_(total)
+            torch.cuda.synchronize()
+            up = c.fs_finalise()
+            assert up.dJMax == pytest.approx(upWhole.dJMax, rel=1e-12) and up.dJMaxIdx == upWhole.dJMaxIdx
+            c.download(abi.ALL_OUTPUTS)
+    for p in (pa, pb):
+        assert rel_err(p.atoms[0].Gamma, q.atoms[0].Gamma) <= 1e-11
+        for ta, tb in zip(p.atoms[0].trans, q.atoms[0].trans):
+            assert rel_err(ta.Rij, tb.Rij) <= 1e-11 and rel_err(ta.Rji, tb.Rji) <= 1e-11
+    assert rel_err(pa.J[:m], q.J[:m]) <= 1e-13 and rel_err(pb.J[m:], q.J[m:]) <= 1e-13
+    assert rel_err(pa.I[:m], q.I[:m]) <= 1e-13 and rel_err(pb.I[m:], q.I[m:]) <= 1e-13
