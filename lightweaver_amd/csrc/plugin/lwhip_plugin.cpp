@@ -57,6 +57,12 @@ struct PluginState
     std::vector<lwhip_atom> atoms;
     std::vector<std::vector<lwhip_transition>> trans;
     std::vector<uint64_t> shape;       // structural signature: recreate the device context if it changes
+    // Ndim = 2: Atmosphere::intersections flattened into the tables of lwhip_grid2d
+    lwhip_grid2d grid{};
+    std::vector<lwhip_intersection> g2uw, g2dw, g2sub;
+    std::vector<int32_t> g2long, g2subOff;
+    std::vector<double> height2d;
+    uint64_t gridSig = 0, gridEpoch = 0; // geometry fingerprint; epoch enters the structural signature
     uint64_t fpProfiles = 0, fpBackground = 0, fpAtmos = 0, fpNstar = 0, fpCollisions = 0;
 };
 
@@ -78,7 +84,94 @@ int solver_id(const Context& ctx)
     if (n && !std::strcmp(n, "piecewise_bezier3_1d"))
         return LWHIP_FS_BEZIER3_1D;
     throw std::runtime_error(std::string("lwhip plugin: formal solver '") + (n ? n : "?")
-                             + "' is not available on the device (1D linear/besser/bezier3 only)");
+                             + "' is not available on the device (1D linear/besser/bezier3, 2D besser only)");
+}
+
+lwhip_intersection flat_hit(const IntersectionResult& q)
+{
+    lwhip_intersection o{};
+    o.axis = (int32_t)q.axis;
+    o.fracZ = q.fractionalZ;
+    o.fracX = q.fractionalX;
+    o.distance = q.distance;
+    return o;
+}
+
+// Ndim = 2: the x-periodic grid and the core's own intersection table (build_intersection_list,
+// Source/FormalScalar2d.cpp:1188-1327; Atmosphere::intersections, Source/LwAtmosphere.hpp:145-173) -> lwhip_grid2d
+void flatten_grid2d(Context& ctx, PluginState* st)
+{
+    Atmosphere& atmos = *ctx.atmos;
+    const char* fs = ctx.formalSolver.name;
+    const char* ip = ctx.interpFn.name;
+    if (!fs || std::strcmp(fs, "piecewise_besser_2d") || !ip || std::strcmp(ip, "interp_linear_2d"))
+        throw std::runtime_error("lwhip plugin: 2D needs piecewise_besser_2d with interp_linear_2d");
+    if (atmos.xLowerBc.type != PERIODIC || atmos.xUpperBc.type != PERIODIC)
+        throw std::runtime_error("lwhip plugin: 2D atmospheres must be periodic in x");
+    if ((atmos.zLowerBc.type != ZERO && atmos.zLowerBc.type != THERMALISED)
+        || (atmos.zUpperBc.type != ZERO && atmos.zUpperBc.type != THERMALISED))
+        throw std::runtime_error("lwhip plugin: 2D z boundaries must be ZERO or THERMALISED");
+    if (!atmos.intersections)
+        throw std::runtime_error("lwhip plugin: the atmosphere has no intersection table (build_intersection_list)");
+    const int Nx = atmos.Nx, Nz = atmos.Nz, Nrays = atmos.Nrays;
+    // the table is flattened once per geometry: it only changes when the grid or the quadrature does
+    uint64_t sig = Fingerprint::of(atmos.x.data, Nx) ^ (Fingerprint::of(atmos.z.data, Nz) * 3)
+                   ^ (Fingerprint::of(atmos.mux.data, Nrays) * 5) ^ (Fingerprint::of(atmos.muz.data, Nrays) * 7)
+                   ^ ((uint64_t)atmos.zLowerBc.type << 8) ^ ((uint64_t)atmos.zUpperBc.type << 16)
+                   ^ ((uint64_t)atmos.intersections.substeps.size() << 24) ^ 1;
+    if (sig == st->gridSig && st->grid.Nx == Nx && st->grid.Nz == Nz && st->grid.Nrays == Nrays
+        && st->grid.temperature == atmos.temperature.data)
+        return;
+    st->gridSig = sig;
+    ++st->gridEpoch;
+    const size_t nSt = (size_t)Nrays * 2 * Nz * Nx;
+    st->g2uw.resize(nSt);
+    st->g2dw.resize(nSt);
+    st->g2long.resize(nSt);
+    size_t o = 0;
+    for (int mu = 0; mu < Nrays; ++mu)
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < Nz; ++k)
+                for (int j = 0; j < Nx; ++j, ++o)
+                {
+                    const InterpolationStencil& q = atmos.intersections.intersections(mu, d, k, j);
+                    st->g2uw[o] = flat_hit(q.uwIntersection);
+                    st->g2dw[o] = flat_hit(q.dwIntersection);
+                    st->g2long[o] = q.longCharIdx;
+                }
+    st->g2sub.clear();
+    st->g2subOff.assign(1, 0);
+    for (const SubstepIntersections& lc : atmos.intersections.substeps)
+    {
+        for (const IntersectionResult& q : lc.steps)
+            st->g2sub.push_back(flat_hit(q));
+        st->g2subOff.push_back((int32_t)st->g2sub.size());
+    }
+    if (st->g2sub.empty())
+        st->g2sub.push_back(lwhip_intersection{});
+    st->height2d.resize((size_t)Nx * Nz);
+    for (int k = 0; k < Nz; ++k)
+        for (int j = 0; j < Nx; ++j)
+            st->height2d[(size_t)k * Nx + j] = atmos.z(k);
+    lwhip_grid2d& g = st->grid;
+    g = lwhip_grid2d{};
+    g.Nx = Nx;
+    g.Nz = Nz;
+    g.Nrays = Nrays;
+    g.periodic = 1;
+    g.zLowerBc = (int32_t)atmos.zLowerBc.type;
+    g.zUpperBc = (int32_t)atmos.zUpperBc.type;
+    g.NlongChar = (int32_t)st->g2subOff.size() - 1;
+    g.x = atmos.x.data;
+    g.z = atmos.z.data;
+    g.mux = atmos.mux.data;
+    g.muz = atmos.muz.data;
+    g.temperature = atmos.temperature.data;
+    g.uw = st->g2uw.data();
+    g.dw = st->g2dw.data();
+    g.longCharIdx = st->g2long.data();
+    g.substepOff = st->g2subOff.data();
+    g.substeps = st->g2sub.data();
 }
 
 void flatten_boundary(lwhip_boundary* b, AtmosphericBoundaryCondition& bc)
@@ -96,12 +189,14 @@ void flatten_boundary(lwhip_boundary* b, AtmosphericBoundaryCondition& bc)
 }
 
 // Context -> lwhip_problem (flat restatement, include/lwhip.h); returns the structural signature
-void flatten(Context& ctx, PluginState* st)
+// 2D tables live in `keep` (the Context's long-lived state), everything else in `st`
+void flatten(Context& ctx, PluginState* st, PluginState* keep)
 {
     Atmosphere& atmos = *ctx.atmos;
     Spectrum& spect = *ctx.spect;
-    if (atmos.Ndim != 1)
-        throw std::runtime_error("lwhip plugin: only 1D plane-parallel atmospheres are supported");
+    if (atmos.Ndim != 1 && atmos.Ndim != 2)
+        throw std::runtime_error("lwhip plugin: only 1D plane-parallel and 2D x-periodic atmospheres are supported");
+    const bool is2d = atmos.Ndim == 2;
     if (spect.JRest)
         throw std::runtime_error("lwhip plugin: hybrid PRD (JRest) is not supported on the device");
     lwhip_problem& p = st->prob;
@@ -110,9 +205,14 @@ void flatten(Context& ctx, PluginState* st)
     p.Nspace = atmos.Nspace;
     p.Nrays = atmos.Nrays;
     p.Nlambda = (int32_t)spect.wavelength.shape(0);
-    p.formalSolver = solver_id(ctx);
+    p.formalSolver = is2d ? LWHIP_FS_BESSER_1D : solver_id(ctx); // 2D: the solver is fixed by grid2d
     p.storeDepthData = (ctx.depthData && ctx.depthData->fill) ? 1 : 0;
-    p.height = atmos.height.data;
+    if (is2d)
+    {
+        flatten_grid2d(ctx, keep);
+        p.grid2d = &keep->grid;
+    }
+    p.height = is2d ? keep->height2d.data() : atmos.height.data;
     p.temperature = atmos.temperature.data;
     p.vlosMu = atmos.vlosMu.data;
     p.muz = atmos.muz.data;
@@ -137,7 +237,7 @@ void flatten(Context& ctx, PluginState* st)
     st->trans.assign(all.size(), {});
     st->shape = { (uint64_t)p.Nspace, (uint64_t)p.Nrays, (uint64_t)p.Nlambda, (uint64_t)p.formalSolver,
                   (uint64_t)p.storeDepthData, (uint64_t)p.zLowerBc.type, (uint64_t)p.zUpperBc.type,
-                  (uint64_t)all.size() };
+                  (uint64_t)all.size(), (uint64_t)(is2d ? atmos.Nx : 0), (uint64_t)(is2d ? keep->gridEpoch : 0) };
     for (size_t ia = 0; ia < all.size(); ++ia)
     {
         Atom& a = *all[ia];
@@ -265,7 +365,7 @@ uint32_t sync_state(Context& ctx, bool force)
         ctx.methodScratch = st;
     }
     PluginState fresh;
-    flatten(ctx, &fresh);
+    flatten(ctx, &fresh, st);
     const bool rebuild = !st->hip || fresh.shape != st->shape;
     // adopt the fresh descriptor (pointers may have moved even when the structure has not)
     const bool moved = !rebuild && std::memcmp(&fresh.prob, &st->prob, offsetof(lwhip_problem, atoms)) != 0;
@@ -511,9 +611,9 @@ extern "C"
 FsIterationFns fs_iteration_fns_provider()
 {
     return FsIterationFns{
-        1,      // Ndim
-        true,   // dimensionSpecific
-        true,   // respectsFormalSolver (the three 1D solvers are selected by name)
+        -1,     // Ndim: like the built-in scheme, 1D plane-parallel and 2D x-periodic behind one entry
+        false,  // dimensionSpecific
+        true,   // respectsFormalSolver (the three 1D solvers by name; 2D: piecewise_besser_2d + interp_linear_2d)
         true,   // defaultPerAtomStorage: kept for the forwarded core routines below
         true,   // defaultWlaGijStorage
         "mali_full_precond_hip_gfx950",

@@ -174,3 +174,29 @@ def test_dropin_time_dep_and_nr_updates(gpu):
     assert rel_err(ne, ne2) <= 1e-9
     for x, y in zip(p.atoms, q.atoms):
         assert rel_err(x.n, y.n) <= 1e-9
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_2d_matches_scalar_scheme(gpu):
+    """Ndim = 2 under the real core: the plugin flattens Atmosphere::intersections (built by the core's own
+    build_intersection_list) into lwhip_grid2d and runs the device 2D pipeline; the built-in scalar scheme with
+    piecewise_besser_2d + interp_linear_2d is the reference.  Second iteration re-uses the flattened table."""
+    base, _ = load_fixture('falc2d_small')
+    p, q = base.copy(), base.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(2):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        r1 = hipc.formal_sol_gamma_matrices()
+        r2 = ref.formal_sol_gamma_matrices()
+        assert abs(r1[0] / r2[0] - 1.0) <= TOL_ONE_CALL
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL * (it + 1) and rel_err(p.I, q.I) <= TOL_ONE_CALL * (it + 1)
+        for x, y in zip(p.atoms, q.atoms):
+            assert rel_err(x.Gamma, y.Gamma) <= 1e-8       # association of the sums, see tests/test_fs2d.py
+            for ta, tb in zip(x.trans, y.trans):
+                assert rel_err(ta.Rij, tb.Rij) <= TOL_ONE_CALL * (it + 1)
+                assert rel_err(ta.Rji, tb.Rji) <= TOL_ONE_CALL * (it + 1)
+        assert hipc.stat_equil() == ref.stat_equil() == 0
+        for x, y in zip(p.atoms, q.atoms):
+            assert rel_err(x.n, y.n) <= 1e-7
