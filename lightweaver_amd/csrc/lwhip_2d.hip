@@ -313,6 +313,33 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
 }
 }
 
+// ---- formal_sol (intensity only, formal_sol_impl :722-784): the emergent intensity of the up-going rays and, when
+// asked for, I at depth; J, Gamma and the rates stay untouched ---------------------------------------------------
+namespace
+{
+__global__ void __launch_bounds__(256) iout2d_kernel(const Batch2dArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.Ns || (!a.storeDepth && k >= a.Nx))
+        return;
+    const int r = blockIdx.y, b = blockIdx.z;
+    const int la = a.la0 + b;
+    const int ray = a.rayList[r];
+    const double I = a.I[((size_t)b * a.nRaysActive + r) * a.Ns + k];
+    if ((ray & 1) && k < a.Nx) // Spectrum::I: the top row, written by the toObs ray (:365-370)
+        a.Iout[((size_t)la * a.Nrays + (ray >> 1)) * a.Nx + k] = I;
+    if (a.storeDepth)
+        a.depthI[((size_t)la * a.Nrays * 2 + ray) * a.Ns + k] = I;
+}
+}
+
+hipError_t launch_iout2d(const Batch2dArgs& a, hipStream_t stream)
+{
+    const int n = a.storeDepth ? a.Ns : a.Nx;
+    hipLaunchKernelGGL(iout2d_kernel, dim3((n + 255) / 256, a.nRaysActive, a.nLa), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 // red[0] += red[1] + ... + red[G-1] (fixed order)
 __global__ void sum_groups_kernel(double* red, size_t n, size_t stride, int G)
 {

@@ -1594,14 +1594,19 @@ int lwhip_gamma_prefill_from_C(lwhip_context* c, double crsw)
 
 // The 2D iteration of this context's wavelengths: batches of wavelengths through cont -> gather -> 2D formal
 // solver -> rates (lwhip_2d.hip), the running sums in the reduce buffer, dJ in its tail.
-static int run_2d(lwhip_context* c, int lambdaIterate)
+// mode 0: the iteration (J, Gamma, rates); 1: formal_sol, all rays; 2: formal_sol, up-going rays only
+static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
 {
     const lwhip_grid2d& g = *c->prob.grid2d;
     const size_t Ns = c->Ns;
-    const int nRaysActive = 2 * c->Nrays;
+    const int nRaysActive = (mode == 2) ? c->Nrays : 2 * c->Nrays;
+    const int32_t* rayList = (mode == 2) ? c->rayUp.p : c->rayAll.p;
     const size_t nRed = (size_t)c->Ntrans * 4 * Ns;
-    HIP_TRY(hipMemsetAsync(c->red2d.p, 0, (size_t)c->groups2d * nRed * sizeof(double), c->stream));
-    HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
+    if (mode == 0)
+    {
+        HIP_TRY(hipMemsetAsync(c->red2d.p, 0, (size_t)c->groups2d * nRed * sizeof(double), c->stream));
+        HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
+    }
     Batch2dArgs a{};
     a.Ns = (int32_t)Ns;
     a.Nx = c->Nx;
@@ -1611,7 +1616,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
     a.storeDepth = c->prob.storeDepthData ? 1 : 0;
     a.NlevTot = c->NlevTot;
     a.Natom = c->Natom;
-    a.rayList = c->rayAll.p;
+    a.rayList = rayList;
     a.muz = c->muz.p;
     a.wmu = c->wmu.p;
     a.laHdr = c->laHdr.p;
@@ -1651,7 +1656,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
     f.longCharIdx = c->g2long.p;
     f.substepOff = c->g2subOff.p;
     f.substeps = c->g2sub.p;
-    f.rays = c->rayAll.p;
+    f.rays = rayList;
     f.chi = c->b2chi.p;
     f.S = c->b2S.p;
     f.I = c->b2I.p;
@@ -1677,8 +1682,13 @@ static int run_2d(lwhip_context* c, int lambdaIterate)
         f.wavs = c->wavelength.p + la0;
         f.nSolve = nLa * nRaysActive;
         HIP_TRY(launch_fs2d(f, nLa * nRaysActive, c->stream));
-        HIP_TRY(launch_rates2d(a, c->maxL, c->stream));
+        if (mode == 0)
+            HIP_TRY(launch_rates2d(a, c->maxL, c->stream));
+        else
+            HIP_TRY(launch_iout2d(a, c->stream));
     }
+    if (mode != 0)
+        return LWHIP_OK;
     // the groups' sums, in a fixed order, into the reduce buffer
     HIP_TRY(launch_sum_groups(c->red2d.p, nRed, nRed, c->groups2d, c->stream));
     HIP_TRY(hipMemcpyAsync(c->red.p, c->red2d.p, nRed * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1833,9 +1843,9 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
-    if (c->is2d)
-        return fail(LWHIP_ERR_UNSUPPORTED, "formal_sol (intensity only) is not available for 2D problems yet");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->is2d)
+        return run_2d(c, 0, upOnly ? 2 : 1);
     const SweepDyn dyn = make_dyn(c, upOnly != 0, 0);
     HIP_TRY(run_sweep(c, dyn, false));
     return LWHIP_OK;

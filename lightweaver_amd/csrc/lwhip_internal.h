@@ -350,6 +350,7 @@ struct Batch2dArgs
 };
 hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream);
 hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream);
+hipError_t launch_iout2d(const Batch2dArgs& a, hipStream_t stream);
 hipError_t launch_sum_groups(double* red, size_t n, size_t stride, int G, hipStream_t stream);
 hipError_t launch_cont_range(const SweepArgs* devArgs, const SweepArgs& hostArgs, int contOff, int nCont, double* rowsBase,
                              hipStream_t stream);

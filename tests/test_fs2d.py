@@ -268,3 +268,33 @@ def test_hip_2d_wavelength_shards_sum_to_whole(gpu):
             assert rel_err(ta.Rij, tb.Rij) <= 1e-11 and rel_err(ta.Rji, tb.Rji) <= 1e-11
     assert rel_err(pa.J[:m], q.J[:m]) <= 1e-13 and rel_err(pb.J[m:], q.J[m:]) <= 1e-13
     assert rel_err(pa.I[:m], q.I[:m]) <= 1e-13 and rel_err(pb.I[m:], q.I[m:]) <= 1e-13
+
+
+# ---- formal_sol (intensity only) on 2D problems ------------------------------------------------------------------
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+@pytest.mark.parametrize('upOnly', [True, False])
+def test_oracle_2d_formal_sol_matches_reference(upOnly):
+    prob, _ = load_2d_problem()
+    prob.I[:] = -1.0
+    q = prob.copy()
+    bindings.OracleContext(prob).formal_sol(upOnly=upOnly)
+    bindings.RefContext(q).formal_sol(upOnly=upOnly)
+    np.testing.assert_array_equal(prob.I, q.I)
+    assert np.all(prob.I >= 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('upOnly', [True, False])
+def test_hip_2d_formal_sol_matches_oracle(gpu, upOnly):
+    """lwhip_formal_sol on a 2D problem: emergent intensity of every up-going ray, J / Gamma / rates untouched."""
+    from lightweaver_amd.context import Context
+    prob, _ = load_2d_problem()
+    q = prob.copy()
+    bindings.OracleContext(q).formal_sol(upOnly=upOnly)
+    J0, G0 = prob.J.copy(), prob.atoms[0].Gamma.copy()
+    prob.I[:] = -1.0
+    with Context(prob) as ctx:
+        ctx.formal_sol(upOnly=upOnly)
+        ctx.download(abi.ALL_OUTPUTS)
+    assert rel_err(prob.I, q.I) <= 1e-9
+    assert np.array_equal(prob.J, J0) and np.array_equal(prob.atoms[0].Gamma, G0)
