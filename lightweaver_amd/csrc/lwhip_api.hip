@@ -2591,8 +2591,6 @@ int lwhip_compute_profiles(lwhip_context* c)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->is2d)
-        return fail(LWHIP_ERR_UNSUPPORTED, "device profiles are not available for 2D problems yet");
     if (!c->prob.vlosMu)
         return fail(LWHIP_ERR_INVALID, "lwhip_compute_profiles needs vlosMu in the descriptor");
     for (int tr = 0; tr < c->Ntrans; ++tr)

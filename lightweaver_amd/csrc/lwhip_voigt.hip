@@ -197,15 +197,17 @@ __global__ void voigt_phi_kernel(VoigtLineArgs a)
 
 // wphi[k] = 1 / sum_{la, mu, dir} phi w_lambda(la) w_mu/2 over the line's FULL grid (independent of
 // the wavelength shard); thread (part, k) sums la = part, part + P, ...; parts combined in order
-__global__ void voigt_wphi_kernel(VoigtLineArgs a)
+__global__ void voigt_wphi_kernel(VoigtLineArgs a, int KT)
 {
+    // a workgroup owns KT consecutive points (all of them in 1D; tiles of a 2D domain) x P partial sums
     extern __shared__ double sPart[];
     const double sqrtPi = 1.772453850905516027298167483341145182798;
-    const int P = blockDim.x / a.Ns;
-    const int part = threadIdx.x / a.Ns;
-    const int k = threadIdx.x - part * a.Ns;
+    const int P = blockDim.x / KT;
+    const int part = threadIdx.x / KT;
+    const int kl = threadIdx.x - part * KT;
+    const int k = blockIdx.x * KT + kl;
     double acc = 0.0;
-    if (part < P)
+    if (part < P && k < a.Ns)
     {
         const double vb = a.vBroad[k];
         const double ad = a.aDamp[k];
@@ -224,15 +226,15 @@ __global__ void voigt_wphi_kernel(VoigtLineArgs a)
                 }
             }
         }
-        sPart[part * a.Ns + k] = acc;
+        sPart[part * KT + kl] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < a.Ns)
+    if (threadIdx.x < KT && k < a.Ns)
     {
         double s = 0.0;
         for (int q = 0; q < P; ++q)
-            s += sPart[q * a.Ns + threadIdx.x];
-        a.wphi[threadIdx.x] = 1.0 / s;
+            s += sPart[q * KT + threadIdx.x];
+        a.wphi[k] = 1.0 / s;
     }
 }
 
@@ -262,13 +264,15 @@ hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream)
         const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
         hipLaunchKernelGGL(voigt_phi_kernel, dim3(blocks), dim3(256), 0, stream, a);
     }
-    int P = 1024 / a.Ns;
+    const int KT = a.Ns <= 1024 ? a.Ns : 64;
+    int P = 1024 / KT;
     if (P < 1)
         P = 1;
     if (P > a.nltFull)
         P = a.nltFull;
-    const int T = ((P * a.Ns + 63) / 64) * 64;
-    hipLaunchKernelGGL(voigt_wphi_kernel, dim3(1), dim3(T), (size_t)P * a.Ns * sizeof(double), stream, a);
+    const int T = ((P * KT + 63) / 64) * 64;
+    hipLaunchKernelGGL(voigt_wphi_kernel, dim3((a.Ns + KT - 1) / KT), dim3(T), (size_t)P * KT * sizeof(double), stream, a,
+                       KT);
     return hipGetLastError();
 }
 }

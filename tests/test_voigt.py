@@ -64,7 +64,7 @@ def test_oracle_profiles_vs_golden(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['falc_h_ca_small', 'falc_h_vel'])
+@pytest.mark.parametrize('name', ['falc_h_ca_small', 'falc_h_vel', 'falc2d_small'])
 def test_device_profiles_vs_golden(gpu, name):
     from lightweaver_amd.context import Context
     base, _ = load_fixture(name)
@@ -105,3 +105,28 @@ def test_device_profiles_on_a_wavelength_shard(gpu):
                 hi = min(max(m - t.Nblue, 0), t.Nlambda)
                 assert rel_err(t.phi[:hi], u.phi[:hi]) <= 1e-12
                 assert not t.phi[hi:].any()
+
+
+@pytest.mark.gpu
+def test_device_profiles_2d_domain_beyond_one_workgroup(gpu):
+    """A 2D domain of 40 x 82 = 3 280 points: phi per (line wavelength, ray, direction, point) and the wphi sums
+    tiled over workgroups, against the harness's host profiles (scipy wofz)."""
+    import numpy as np
+    from lightweaver_amd.context import Context
+    from lightweaver_amd.harness import models
+    basecol = models.falc82()
+    cols = [models.perturbed(basecol, seed=77 + j) for j in range(40)]
+    base = models.build_problem_2d(cols, np.linspace(0.0, 39 * 30e3, 40), [models.H_6(0.3)])
+    p = base.copy()
+    for a in p.atoms:
+        for t in a.trans:
+            if t.type == abi.LINE:
+                t.phi[...] = 0.0
+                t.wphi[...] = 0.0
+    with Context(p) as ctx:
+        ctx.compute_profiles()
+    for a, b in zip(p.atoms, base.atoms):
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                assert rel_err(t.phi, u.phi) <= 1e-12
+                assert rel_err(t.wphi, u.wphi) <= 1e-12
