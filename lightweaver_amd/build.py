@@ -32,7 +32,7 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False, defines=(), out=None):
+def build_hip(force=False, verbose=False, defines=(), out=None, extra_flags=()):
     """hipcc --offload-arch=gfx950 -> lightweaver_amd/liblwhip.so.  Translation units are compiled
     concurrently (objects under build/, git-ignored), then linked."""
     from concurrent.futures import ThreadPoolExecutor
@@ -43,7 +43,7 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
         return lib
     objdir = os.path.join(ROOT, 'build', os.path.basename(lib) + '.obj')
     os.makedirs(objdir, exist_ok=True)
-    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + [f'-D{d}' for d in defines]
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + [f'-D{d}' for d in defines] + list(extra_flags)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')

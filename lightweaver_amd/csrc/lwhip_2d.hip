@@ -76,34 +76,101 @@ template <int MAXL>
 __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
 {
     constexpr int MAXM = 4; // mixed continua integrated ray by ray at one wavelength
-    constexpr int NROW = 5; // rEtaA, rChiI, rChiJ, rUI, rUJ
-    __shared__ double sRow[(MAXL + MAXM) * NROW + MAXM][128];
+    constexpr int MAXP = 8; // pure continua with register accumulators; any beyond go straight to memory
+    extern __shared__ double sRowAll[]; // [maxRowsLa][128]: every continuum row of the wavelength at the thread's point
     const int tid = threadIdx.x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
     const bool on = k < Ns;
     const int kk = on ? k : 0;
+    // the rays of the pass and their half weights, once, behind the row block (uniform LDS reads in the ray loop:
+    // no scalar-memory round trips there)
+    double* sHalfW = sRowAll + (size_t)a.maxRowsLa * 128;
+    int* sRayId = (int*)(sHalfW + 64);
+    constexpr int MAXSLOT = MAXL + MAXM + MAXP;
+    DevSlot* sSlot = (DevSlot*)(sHalfW + 64 + 32);
+    if (tid < a.nRaysActive)
+    {
+        const int ray = a.rayList[tid];
+        sRayId[tid] = ray;
+        sHalfW[tid] = 0.5 * a.wmu[ray >> 1];
+    }
+    __syncthreads();
     double Wsum = 0.0;
     for (int r = 0; r < a.nRaysActive; ++r)
-        Wsum += 0.5 * a.wmu[a.rayList[r] >> 1];
-    // blockIdx.y: a group of the batch's wavelengths with its own copy of the running sums (added up afterwards)
+        Wsum += sHalfW[r];
+    // blockIdx.y: a contiguous group of the batch's wavelengths with its own copy of the running sums (added up
+    // afterwards).  Contiguous, because neighbouring wavelengths belong to the same transitions: the thread keeps a
+    // transition's four sums in registers for as long as it stays in the same slot and touches its column of the
+    // running sums only when the slot changes hands (a line's ~100 wavelengths -> one read-modify-write, not 100).
     double* redG = a.red + (size_t)blockIdx.y * a.redStride;
-    for (int b = blockIdx.y; b < a.nLa; b += gridDim.y)
+    double accL[MAXL][4], accM[MAXM][4], accP[MAXP][4];
+    int trL[MAXL], trM[MAXM], trP[MAXP];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l)
+    {
+        accL[l][0] = accL[l][1] = accL[l][2] = accL[l][3] = 0.0;
+        trL[l] = -1;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXM; ++c)
+    {
+        accM[c][0] = accM[c][1] = accM[c][2] = accM[c][3] = 0.0;
+        trM[c] = -1;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXP; ++c)
+    {
+        accP[c][0] = accP[c][1] = accP[c][2] = accP[c][3] = 0.0;
+        trP[c] = -1;
+    }
+    auto hand_over = [&](double (&acc)[4], int& trCur, int trNew) {
+        if (trNew == trCur)
+            return;
+        if (trCur >= 0 && on)
+        {
+            double* red = redG + ((size_t)trCur * 4) * Ns + k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                red[(size_t)q * Ns] += acc[q];
+        }
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+        trCur = trNew;
+    };
+    const int bLo = (int)(((long long)blockIdx.y * a.nLa) / gridDim.y);
+    const int bHi = (int)(((long long)(blockIdx.y + 1) * a.nLa) / gridDim.y);
+    for (int b = bLo; b < bHi; ++b)
     {
         const int la = a.la0 + b;
         const DevLaHeader h = a.laHdr[la];
-        const DevSlot* slots = a.slots + h.off;
         const int nLine = h.nLine, nMixed = h.nMixed, nPure = h.nPure;
+        // the wavelength's slot records into LDS: LDS reads are not ordered against the global stores of the ray
+        // loop, so the compiler keeps or re-reads them cheaply (from global memory every field access would be a
+        // scalar load re-issued after each store, and waited for)
+        const int nSlot = min(nLine + nMixed + nPure, MAXSLOT);
+        __syncthreads();
+        for (int i = tid; i < nSlot * (int)(sizeof(DevSlot) / 4); i += blockDim.x)
+            ((int*)sSlot)[i] = ((const int*)(a.slots + h.off))[i];
+        __syncthreads();
+        const DevSlot* slots = sSlot;
         const bool hasRows = h.rowBase >= 0;
         const size_t laNs = (size_t)la * Ns;
-        auto rowAt = [&](int ri) -> double { return (hasRows && ri >= 0) ? a.rows[((size_t)h.rowBase + ri) * Ns + kk] : 0.0; };
-        double accL[MAXL][4], accM[MAXM][4];
+        // the wavelength's block of continuum rows (deduplicated on the host: chi_c, eta_c, per-atom eta, per-level
+        // chi / U, one Vji per continuum), once from memory into the thread's LDS column
+        const int nRowsLa = hasRows ? h.nRows + nMixed + nPure : 0;
+        for (int ri = 0; ri < nRowsLa; ++ri)
+            sRowAll[ri * 128 + tid] = a.rows[((size_t)h.rowBase + ri) * Ns + kk];
+        auto rowAt = [&](int ri) -> double { return (hasRows && ri >= 0) ? sRowAll[ri * 128 + tid] : 0.0; };
+        // slots that changed hands since the previous wavelength give up their sums
 #pragma unroll
         for (int l = 0; l < MAXL; ++l)
-            accL[l][0] = accL[l][1] = accL[l][2] = accL[l][3] = 0.0;
+            hand_over(accL[l], trL[l], (l < nLine) ? a.slotTr[h.off + l] : -1);
 #pragma unroll
         for (int c = 0; c < MAXM; ++c)
-            accM[c][0] = accM[c][1] = accM[c][2] = accM[c][3] = 0.0;
+            hand_over(accM[c], trM[c], (c < nMixed) ? a.slotTr[h.off + nLine + c] : -1);
+#pragma unroll
+        for (int c = 0; c < MAXP; ++c)
+            hand_over(accP[c], trP[c], (c < nPure) ? a.slotTr[h.off + nLine + nMixed + c] : -1);
         double mJ = 0.0, mM1 = 0.0, mE0 = 0.0, mE1 = 0.0;
         // ---- ray-independent part of the wavelength ---------------------------------------------------------
         double lG[MAXL], lNi[MAXL], lNj[MAXL], lW[MAXL];
@@ -128,40 +195,21 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
                 lgj[l] = sl.gj;
                 lat[l] = sl.atom;
                 lop[l] = sl.flags & 1;
-                if (lop[l])
-                {
-                    sRow[l * NROW + 0][tid] = rowAt(sl.rEtaA);
-                    sRow[l * NROW + 1][tid] = rowAt(sl.rChiI);
-                    sRow[l * NROW + 2][tid] = rowAt(sl.rChiJ);
-                    sRow[l * NROW + 3][tid] = rowAt(sl.rUI);
-                    sRow[l * NROW + 4][tid] = rowAt(sl.rUJ);
-                }
             }
         }
-#pragma unroll
-        for (int c = 0; c < MAXM; ++c)
-            if (c < nMixed)
-            {
-                const DevSlot& sl = slots[nLine + c];
-                sRow[(MAXL + c) * NROW + 0][tid] = rowAt(sl.rEtaA);
-                sRow[(MAXL + c) * NROW + 1][tid] = rowAt(sl.rChiI);
-                sRow[(MAXL + c) * NROW + 2][tid] = rowAt(sl.rChiJ);
-                sRow[(MAXL + c) * NROW + 3][tid] = rowAt(sl.rUI);
-                sRow[(MAXL + c) * NROW + 4][tid] = rowAt(sl.rUJ);
-                sRow[(MAXL + MAXM) * NROW + c][tid] = rowAt(sl.rVji);
-            }
+        const bool topRow = kk < a.Nx && on;
         for (int r = 0; r < a.nRaysActive; ++r)
         {
-            const int ray = a.rayList[r];
+            const int ray = sRayId[r];
             const int mu = ray >> 1;
-            const double halfwmu = 0.5 * a.wmu[mu];
+            const double halfwmu = sHalfW[r];
             const size_t o = ((size_t)b * a.nRaysActive + r) * Ns + kk;
             const double I = a.I[o];
             const double PsiS = a.lambdaIterate ? 0.0 : a.PsiStar[o];
             const double wPsi = halfwmu * PsiS;
             mJ += halfwmu * I; // accumulate_J :181-190
             mM1 += wPsi;
-            if ((ray & 1) && kk < a.Nx && on) // Spectrum::I: the top row, last written by the toObs ray (:365-370)
+            if ((ray & 1) && topRow) // Spectrum::I: the top row, last written by the toObs ray (:365-370)
                 a.Iout[((size_t)la * a.Nrays + mu) * a.Nx + kk] = I;
             if (a.storeDepth && on)
                 a.depthI[((size_t)la * a.Nrays * 2 + ray) * Ns + kk] = I;
@@ -227,10 +275,10 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
                     if (lop[l])
                     {
                         // compute_full_Ieff :192-204, compute_full_operator_rates :206-234
-                        const double* q = &sRow[l * NROW][tid];
-                        const double Ieff = I - PsiS * atomEta(lat[l], q[0]);
-                        accL[l][0] += ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(lgi[l], q[128]) * levU(lgj[l], q[4 * 128]))) * wlamu;
-                        accL[l][1] += ((Vij[l] * Ieff) - (PsiS * levChi(lgj[l], q[2 * 128]) * levU(lgi[l], q[3 * 128]))) * wlamu;
+                        const DevSlot& sl = slots[l];
+                        const double Ieff = I - PsiS * atomEta(lat[l], rowAt(sl.rEtaA));
+                        accL[l][0] += ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(lgi[l], rowAt(sl.rChiI)) * levU(lgj[l], rowAt(sl.rUJ)))) * wlamu;
+                        accL[l][1] += ((Vij[l] * Ieff) - (PsiS * levChi(lgj[l], rowAt(sl.rChiJ)) * levU(lgi[l], rowAt(sl.rUI)))) * wlamu;
                     }
                     accL[l][2] += I * Vij[l] * wlamu;
                     accL[l][3] += (luji[l] + I * Vji[l]) * wlamu;
@@ -242,59 +290,54 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
                 if (c < nMixed) // mixed continua (always of active atoms)
                 {
                     const DevSlot& sl = slots[nLine + c];
-                    const double* q = &sRow[(MAXL + c) * NROW][tid];
-                    const double vij = sl.p[0];
-                    const double vji = sRow[(MAXL + MAXM) * NROW + c][tid];
+                    const double vij = sl.p[0], vji = rowAt(sl.rVji);
                     const double uji = sl.p[2] * vji;
                     const double wlamu = sl.p[1] * halfwmu;
-                    const double Ieff = I - PsiS * atomEta(sl.atom, q[0]);
-                    accM[c][0] += ((uji + vji * Ieff) - (PsiS * levChi(sl.gi, q[128]) * levU(sl.gj, q[4 * 128]))) * wlamu;
-                    accM[c][1] += ((vij * Ieff) - (PsiS * levChi(sl.gj, q[2 * 128]) * levU(sl.gi, q[3 * 128]))) * wlamu;
+                    const double Ieff = I - PsiS * atomEta(sl.atom, rowAt(sl.rEtaA));
+                    accM[c][0] += ((uji + vji * Ieff) - (PsiS * levChi(sl.gi, rowAt(sl.rChiI)) * levU(sl.gj, rowAt(sl.rUJ)))) * wlamu;
+                    accM[c][1] += ((vij * Ieff) - (PsiS * levChi(sl.gj, rowAt(sl.rChiJ)) * levU(sl.gi, rowAt(sl.rUI)))) * wlamu;
                     accM[c][2] += I * vij * wlamu;
                     accM[c][3] += (uji + I * vji) * wlamu;
                 }
             }
         } // rays
-        if (on)
-        {
-        // ---- this wavelength's contributions into the point's column of the running sums ------------------
-#pragma unroll
-        for (int l = 0; l < MAXL; ++l)
-            if (l < nLine)
-            {
-                double* red = redG + ((size_t)a.slotTr[h.off + l] * 4) * Ns + k;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    red[(size_t)q * Ns] += accL[l][q];
-            }
-#pragma unroll
-        for (int c = 0; c < MAXM; ++c)
-            if (c < nMixed)
-            {
-                double* red = redG + ((size_t)a.slotTr[h.off + nLine + c] * 4) * Ns + k;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    red[(size_t)q * Ns] += accM[c][q];
-            }
         // pure continua from the angle moments
-        for (int cq = 0; cq < nPure; ++cq)
-        {
-            const DevSlot& sl = slots[nLine + nMixed + cq];
+        auto pure = [&](int cq, double (&out)[4]) {
+            const int si = nLine + nMixed + cq;
+            const DevSlot& sl = (si < MAXSLOT) ? slots[si] : a.slots[h.off + si];
             const double vij = sl.p[0];
             const double vji = rowAt(sl.rVji);
             const double uji = sl.p[2] * vji;
             const double wla = sl.p[1];
-            double* red = redG + ((size_t)a.slotTr[h.off + nLine + nMixed + cq] * 4) * Ns + k;
+            out[0] = out[1] = 0.0;
             if (sl.flags & 1)
             {
                 const double Meta = (sl.ms == 0) ? mE0 : ((sl.ms == 1) ? mE1 : 0.0);
                 const double Jeff = mJ - mM1 * rowAt(sl.rEtaA) - Meta;
-                red[0] += ((uji * Wsum + vji * Jeff) - (mM1 * rowAt(sl.rChiI) * rowAt(sl.rUJ))) * wla;
-                red[(size_t)Ns] += ((vij * Jeff) - (mM1 * rowAt(sl.rChiJ) * rowAt(sl.rUI))) * wla;
+                out[0] = ((uji * Wsum + vji * Jeff) - (mM1 * rowAt(sl.rChiI) * rowAt(sl.rUJ))) * wla;
+                out[1] = ((vij * Jeff) - (mM1 * rowAt(sl.rChiJ) * rowAt(sl.rUI))) * wla;
             }
-            red[(size_t)2 * Ns] += mJ * vij * wla;
-            red[(size_t)3 * Ns] += (uji * Wsum + mJ * vji) * wla;
-        }
+            out[2] = mJ * vij * wla;
+            out[3] = (uji * Wsum + mJ * vji) * wla;
+        };
+#pragma unroll
+        for (int cq = 0; cq < MAXP; ++cq)
+            if (cq < nPure)
+            {
+                double v[4];
+                pure(cq, v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    accP[cq][q] += v[q];
+            }
+        for (int cq = MAXP; cq < nPure && on; ++cq)
+        {
+            double v[4];
+            pure(cq, v);
+            double* red = redG + ((size_t)a.slotTr[h.off + nLine + nMixed + cq] * 4) * Ns + k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                red[(size_t)q * Ns] += v[q];
         }
         // J out, dJ = max_k |1 - Jdag/J|  :477-486 -- the wavefront's maximum first: one atomic per wavefront, not
         // one per point on the same address
@@ -310,6 +353,15 @@ __global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
         if ((threadIdx.x & 63) == 0)
             atomicMax(a.dJbits + la, (unsigned long long)__double_as_longlong(dj)); // non-negative doubles order like their bits
     }
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l)
+        hand_over(accL[l], trL[l], -1);
+#pragma unroll
+    for (int c = 0; c < MAXM; ++c)
+        hand_over(accM[c], trM[c], -1);
+#pragma unroll
+    for (int c = 0; c < MAXP; ++c)
+        hand_over(accP[c], trP[c], -1);
 }
 }
 
@@ -370,12 +422,14 @@ hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream)
 hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream)
 {
     const dim3 grid((a.Ns + 127) / 128, a.nGroups);
+    const size_t lds = (size_t)std::max(a.maxRowsLa, 1) * 128 * sizeof(double) + 64 * (sizeof(double) + sizeof(int))
+                       + (size_t)((maxL <= 2 ? 2 : (maxL <= 4 ? 4 : 8)) + 4 + 8) * sizeof(DevSlot);
     if (maxL <= 2)
-        hipLaunchKernelGGL(rates2d_kernel<2>, grid, dim3(128), 0, stream, a);
+        hipLaunchKernelGGL(rates2d_kernel<2>, grid, dim3(128), lds, stream, a);
     else if (maxL <= 4)
-        hipLaunchKernelGGL(rates2d_kernel<4>, grid, dim3(128), 0, stream, a);
+        hipLaunchKernelGGL(rates2d_kernel<4>, grid, dim3(128), lds, stream, a);
     else
-        hipLaunchKernelGGL(rates2d_kernel<8>, grid, dim3(128), 0, stream, a);
+        hipLaunchKernelGGL(rates2d_kernel<8>, grid, dim3(128), lds, stream, a);
     return hipGetLastError();
 }
 }

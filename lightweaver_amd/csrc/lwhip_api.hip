@@ -120,7 +120,7 @@ struct lwhip_context
     DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
     DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
     DevBuf<int32_t> b2idx;
-    int groups2d = 1;
+    int groups2d = 1, maxRowsLa = 1;
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
@@ -1061,6 +1061,11 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(c->b2Psi.alloc(nb));
         HIP_TRY(c->b2coef.alloc(4 * nb));
         HIP_TRY(c->b2idx.alloc(nb));
+        for (size_t la = 0; la < Nla; ++la)
+            if (c->hdrHost[la].rowBase >= 0)
+                c->maxRowsLa = std::max(c->maxRowsLa, c->hdrHost[la].nRows + c->hdrHost[la].nMixed + c->hdrHost[la].nPure);
+        if ((size_t)c->maxRowsLa * 128 * sizeof(double) > 64 * 1024)
+            return fail(LWHIP_ERR_UNSUPPORTED, "2D: more continuum rows at one wavelength than the rate kernel's LDS block holds");
         // continuum rows of one batch
         int64_t maxRows = 1;
         for (size_t la0 = 0; la0 < Nla; la0 += c->batch2d)
@@ -1640,6 +1645,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     a.red = c->red2d.p;
     a.redStride = nRed;
     a.nGroups = c->groups2d;
+    a.maxRowsLa = c->maxRowsLa;
     a.slotTr = c->slotTrD.p;
     a.dJbits = (unsigned long long*)c->dJ.p;
     Fs2dArgs f{};

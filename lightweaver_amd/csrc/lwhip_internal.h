@@ -344,7 +344,8 @@ struct Batch2dArgs
     const double* PsiStar;
     double* red;                   // [nGroups][Ntrans, 4, Ns] running sums of the iteration, one copy per group
     size_t redStride;              // doubles between the copies
-    int32_t nGroups, _padB;        // wavelength groups of a batch that accumulate concurrently
+    int32_t nGroups;               // wavelength groups of a batch that accumulate concurrently
+    int32_t maxRowsLa;             // most continuum rows (program rows + one per continuum) any wavelength has
     const int32_t* slotTr;         // global transition of every slot record
     unsigned long long* dJbits;    // [Nla] max_k |1 - Jdag/J| as the bits of a non-negative double
 };

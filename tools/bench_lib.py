@@ -14,5 +14,8 @@ t0 = time.perf_counter()
 for _ in range(steps):
     ctx.formal_sol_gamma_matrices(deviceResident=True)
 dt = time.perf_counter() - t0
-print(os.path.basename(lib), 'it/s=%.0f' % (steps / dt), 'sweep_ms=%.3f' % ctx.sweep_time()[0])
+from lightweaver_amd import _abi as abi
+ctx.download(abi.ALL_OUTPUTS)
+print(os.path.basename(lib), 'it/s=%.0f' % (steps / dt), 'sweep_ms=%.3f' % ctx.sweep_time()[0],
+      'J.sum=%.15e G.sum=%.15e' % (prob.J.sum(), prob.atoms[0].Gamma.sum()))
 ctx.close()
