@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
 // rows the level sums start from -- is fetched once into registers / the thread's LDS column; the ray loop then
 // reads only I, Psi* and one phi per line from memory.
 template <int MAXL>
-__global__ void __launch_bounds__(128) rates2d_kernel(const Batch2dArgs a)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) rates2d_kernel(const Batch2dArgs a)
 {
     constexpr int MAXM = 4; // mixed continua integrated ray by ray at one wavelength
     constexpr int MAXP = 8; // pure continua with register accumulators; any beyond go straight to memory

@@ -169,7 +169,7 @@ DEVINL void f2_hit_weights(const lwhip_intersection& loc, int Nx, int kPrev, dou
 // Pass 1, one thread per (solve, plane, column): everything of the step that does not need an intensity -- the
 // optical depths, control points, BESSER weights, Psi*, the whole long characteristic -- reduced to the affine map
 // of the point.  Fully parallel; this is where the flops and the chi, S stencil reads are.
-__global__ void __launch_bounds__(256) fs2d_coef_kernel(const Fs2dArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) fs2d_coef_kernel(const Fs2dArgs a)
 {
     const int Nx = a.Nx, Nz = a.Nz;
     const int Ns = Nx * Nz;
