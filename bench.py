@@ -152,6 +152,13 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.profile_enable(True)
+    # The interpreter's cyclic garbage collector is not part of the workload: with torch imported a full
+    # collection takes ~40 ms (80 steps' worth) and, being triggered by allocation counts, lands at the same
+    # spot of every run -- measured inside the timed region of a 100-step run (tools/trace_bench.sh: a 38 ms gap
+    # with no HIP call before the closing synchronize).  Collect now, keep it off while the clock runs.
+    import gc
+    gc.collect()
+    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -162,6 +169,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

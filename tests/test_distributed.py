@@ -115,12 +115,12 @@ class OracleShardContext:
         return IterationUpdate(updatedJ=True, dJMax=float(tail[best, 0]), dJMaxIdx=int(tail[best, 1]))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, fixture='falc_h_ca_small'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        prob, _ = load_fixture('falc_h_ca_small')
+        prob, _ = load_fixture(fixture)
         bounds = shard_bounds(prob, world)
         ctx = OracleShardContext(prob, bounds[rank], bounds[rank + 1], world, rank)
         it = ShardedIteration(ctx, world, rank)
@@ -129,7 +129,7 @@ def _worker(rank, world, port, out):
             ups.append(it.formal_sol_gamma_matrices(deviceResident=True))
         la0, la1 = bounds[rank], bounds[rank + 1]
         np.savez(os.path.join(out, f'rank{rank}.npz'), J=prob.J[la0:la1], I=prob.I[la0:la1], la=[la0, la1],
-                 G0=prob.atoms[0].Gamma, G1=prob.atoms[1].Gamma,
+                 G0=prob.atoms[0].Gamma, G1=prob.atoms[-1].Gamma,
                  R=np.stack([t.Rij for t in prob.atoms[0].trans]),
                  dJ=[u.dJMax for u in ups], idx=[u.dJMaxIdx for u in ups])
     finally:
@@ -168,6 +168,31 @@ def test_two_rank_gloo_matches_unsharded(tmp_path):
         assert np.array_equal(z['J'], prob.J[la0:la1]) and np.array_equal(z['I'], prob.I[la0:la1])
         assert rel_err(z['G0'], prob.atoms[0].Gamma) <= 1e-12
         assert rel_err(z['G1'], prob.atoms[1].Gamma) <= 1e-12
+        assert rel_err(z['R'], np.stack([t.Rij for t in prob.atoms[0].trans])) <= 1e-12
+        assert [float(x) for x in z['dJ']] == [r[0] for r in res]
+        assert [int(x) for x in z['idx']] == [r[1] for r in res]
+
+
+def test_two_rank_gloo_2d_matches_unsharded(tmp_path):
+    """BASELINE config 5's split: the 2D problem (x-periodic, BESSER short characteristics) on two wavelength shards
+    with one all-reduce of the Gamma / rate partial sums per iteration."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), 'falc2d_small'), nprocs=world, join=True)
+    from oracle.bindings import OracleContext
+    prob, _ = load_fixture('falc2d_small')
+    oc = OracleContext(prob)
+    res = []
+    dJ = np.zeros(prob.Nlambda)
+    for _ in range(2):
+        prob.gamma_prefill()
+        oc.formal_sol_gamma_matrices(dJ=dJ)
+        res.append((dJ.max(), int(np.argmax(dJ))))
+    for rank in range(world):
+        z = np.load(tmp_path / f'rank{rank}.npz')
+        la0, la1 = z['la']
+        assert np.array_equal(z['J'], prob.J[la0:la1]) and np.array_equal(z['I'], prob.I[la0:la1])
+        assert rel_err(z['G0'], prob.atoms[0].Gamma) <= 1e-12
         assert rel_err(z['R'], np.stack([t.Rij for t in prob.atoms[0].trans])) <= 1e-12
         assert [float(x) for x in z['dJ']] == [r[0] for r in res]
         assert [int(x) for x in z['idx']] == [r[1] for r in res]
