@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--aux', action='store_true',
-                    help='also time the PRD sub-iterations on the PRD variant of the workload (not part of the metric)')
+                    help='also time the PRD sub-iterations and the 2D iteration (not part of the metric)')
     return ap.parse_args()
 
 
@@ -203,6 +203,20 @@ def main():
                 aux['prd_ms_per_subiter'] = 1e3 * (time.perf_counter() - ta) / (5 * 3)
                 aux['prd_lines'] = int(upd.dRho.shape[1])
                 aux['prd_Nlambda'] = pp.Nlambda
+            # BASELINE config 5 in miniature: 256 x 82 x-periodic atmosphere, H(6), BESSER short characteristics
+            import numpy as np
+            base = models.falc82()
+            cols = [models.perturbed(base, seed=1234 + j) for j in range(256)]
+            p2 = models.build_problem_2d(cols, np.linspace(0.0, 25.0e3 * 255, 256), [models.H_6(0.5)])
+            with Context(p2, device=local_rank, stream=stream.cuda_stream) as c2:
+                c2.formal_sol_gamma_matrices(deviceResident=True)
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(5):
+                    c2.formal_sol_gamma_matrices(deviceResident=True)
+                torch.cuda.synchronize()
+                aux['iter2d_ms'] = 1e3 * (time.perf_counter() - ta) / 5
+                aux['iter2d_config'] = f'{p2.grid2d.Nx}x{p2.grid2d.Nz}, {p2.Nlambda} wavelengths, {p2.Nrays}x2 rays'
 
     if rank == 0:
         value = world * args.steps / elapsed
