@@ -264,7 +264,9 @@ hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream)
         const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
         hipLaunchKernelGGL(voigt_phi_kernel, dim3(blocks), dim3(256), 0, stream, a);
     }
-    const int KT = a.Ns <= 1024 ? a.Ns : 64;
+    // tiles of 8 points (1D columns: ~10 workgroups instead of one, each with up to 128 partial sums over the
+    // line's wavelengths) or 64 (2D domains, which bring enough tiles)
+    const int KT = a.Ns <= 1024 ? 8 : 64;
     int P = 1024 / KT;
     if (P < 1)
         P = 1;
