@@ -181,7 +181,8 @@ typedef struct lwhip_options {
     int32_t device;        /* HIP device ordinal                                                   */
     int32_t laStart;       /* wavelength shard owned by this context: [laStart, laEnd)             */
     int32_t laEnd;         /* 0,0 = whole grid                                                     */
-    int32_t flags;         /* reserved, 0                                                          */
+    int32_t flags;         /* bits 0-15: column-batch hint = number of contexts that will share the device
+                            * through lwhip_batch_* (0: none; sizes the per-context chunking); rest reserved  */
     int32_t worldSize;     /* number of wavelength shards of the job (0 or 1 = unsharded)          */
     int32_t worldRank;     /* this shard's ordinal: selects its (dJMax, idx) slot in the buffer    */
     void* stream;          /* hipStream_t to launch on, NULL = the library's own stream            */
@@ -369,6 +370,18 @@ typedef struct lwhip_grid2d {
  * writes I and PsiStar (= Psi / chi) of the same shape.  All pointers are host pointers. */
 int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double wavelength, int nSolve, const int32_t* rays,
                            const double* chi, const double* S, double* I, double* PsiStar);
+
+/* 1.5D column batches (BASELINE configs[3]): n structurally identical contexts -- same model atoms, wavelength grid,
+ * solver and device; own atmospheres, profiles, populations -- advance together, one grid slice per column, on the
+ * first column's stream (the others are moved onto it),
+ * so a batch of short columns fills the device the way one long wavelength grid does.  Columns never exchange
+ * radiation (the reference runs them as separate Contexts: README.md:9); results[i] receives column i's dJMax. */
+typedef struct lwhip_batch lwhip_batch;
+int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out);
+void lwhip_batch_destroy(lwhip_batch* batch);
+int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* batch, int lambdaIterate, double crsw,
+                                          lwhip_iter_result* results /* [n] or NULL: nothing is read back */);
+int lwhip_batch_stat_equil(lwhip_batch* batch);
 
 /* The intersection table of an x-periodic grid: build_intersection_list (Source/FormalScalar2d.cpp:1188-1327) with
  * dw_intersection_2d (:60-105), uw_intersection_2d (:107-152), uw_intersection_2d_frac_x (:166-206).  Host-side

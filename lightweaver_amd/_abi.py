@@ -142,6 +142,10 @@ SYMBOLS = [
     ('lwhip_compute_profiles', C.c_int, [ctx_p]),
     ('lwhip_formal_solver_2d', C.c_int, [C.c_int, C.POINTER(lwhip_grid2d), C.c_double, C.c_int, i32p, f64p, f64p,
                                           f64p, f64p]),
+    ('lwhip_batch_create', C.c_int, [C.POINTER(ctx_p), C.c_int, C.POINTER(C.c_void_p)]),
+    ('lwhip_batch_destroy', None, [C.c_void_p]),
+    ('lwhip_batch_formal_sol_gamma_matrices', C.c_int, [C.c_void_p, C.c_int, C.c_double, C.POINTER(lwhip_iter_result)]),
+    ('lwhip_batch_stat_equil', C.c_int, [C.c_void_p]),
     ('lwhip_build_intersections', C.c_int, [C.POINTER(lwhip_grid2d), C.POINTER(lwhip_intersection),
                                              C.POINTER(lwhip_intersection), i32p, i32p, C.c_int32,
                                              C.POINTER(lwhip_intersection), C.c_int64, C.POINTER(C.c_int32),

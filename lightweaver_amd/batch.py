@@ -24,23 +24,38 @@ def columns_of_rank(ncolumns: int, world: int, rank: int) -> List[int]:
 
 class ColumnBatch:
     def __init__(self, problems: Sequence[Problem], device: int = 0, stream: Optional[int] = None,
-                 device_profiles: bool = True, streams: Optional[Sequence[int]] = None):
-        """`streams`: optional HIP streams (handles) the columns are dealt to round-robin, so that the
-        small reduce / apply / solve kernels of one column overlap the sweep of the next."""
+                 device_profiles: bool = True, streams: Optional[Sequence[int]] = None, fused: bool = True):
+        """`fused` (default): the columns advance in ONE set of launches per iteration (lwhip_batch_*: one grid
+        slice per column), which is what fills the device when a single column's wavelength grid does not;
+        it needs structurally identical columns on one stream and falls back to per-column launches otherwise.
+        `streams`: optional HIP streams (handles) the columns are dealt to round-robin in the per-column mode, so
+        that the small reduce / apply / solve kernels of one column overlap the sweep of the next."""
         self.problems = list(problems)
+        self._batch = None
         if streams:
             self.contexts = [Context(p, device=device, stream=streams[i % len(streams)])
                              for i, p in enumerate(self.problems)]
         else:
-            self.contexts = [Context(p, device=device, stream=stream) for p in self.problems]
+            self.contexts = [Context(p, device=device, stream=stream, batchHint=len(self.problems) if fused else 0)
+                             for p in self.problems]
         if device_profiles:
             for c in self.contexts:
                 c.compute_profiles(deviceResident=True)
+        if fused and not streams and self.contexts:
+            import ctypes as C
+            lib = self.contexts[0].lib
+            arr = (C.c_void_p * len(self.contexts))(*[c._h for c in self.contexts])
+            h = C.c_void_p()
+            if lib.lwhip_batch_create(arr, len(self.contexts), C.byref(h)) == abi.OK:
+                self._batch = h
 
     def __len__(self):
         return len(self.contexts)
 
     def close(self):
+        if self._batch is not None:
+            self.contexts[0].lib.lwhip_batch_destroy(self._batch)
+            self._batch = None
         for c in self.contexts:
             c.close()
         self.contexts = []
@@ -55,6 +70,19 @@ class ColumnBatch:
         """One iteration of every column; kernels of all columns are queued before the first
         result is read back.  sync_host=False reads nothing back (no host wait per column): use it for
         all but the iterations whose dJMax is wanted."""
+        if self._batch is not None:
+            import ctypes as C
+            from .context import IterationUpdate
+            lib = self.contexts[0].lib
+            crsw = self.contexts[0].crsw
+            if not sync_host:
+                _check(lib, lib.lwhip_batch_formal_sol_gamma_matrices(self._batch, int(lambdaIterate), crsw, None),
+                       'lwhip_batch_formal_sol_gamma_matrices')
+                return None
+            res = (abi.lwhip_iter_result * len(self.contexts))()
+            _check(lib, lib.lwhip_batch_formal_sol_gamma_matrices(self._batch, int(lambdaIterate), crsw, res),
+                   'lwhip_batch_formal_sol_gamma_matrices')
+            return [IterationUpdate(updatedJ=True, dJMax=r.dJMax, dJMaxIdx=r.dJMaxIdx, crsw=crsw) for r in res]
         for c in self.contexts:
             c.gamma_prefill_from_C(c.crsw)
             c.fs_partial(lambdaIterate)
@@ -66,6 +94,10 @@ class ColumnBatch:
 
     def stat_equil(self):
         """Queued for every column without a host wait in between; one status check at the end."""
+        if self._batch is not None:
+            lib = self.contexts[0].lib
+            _check(lib, lib.lwhip_batch_stat_equil(self._batch), 'lwhip_batch_stat_equil')
+            return
         for c in self.contexts:
             c.stat_equil(deviceResident=True, sync_host=False)
         for c in self.contexts:

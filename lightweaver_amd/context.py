@@ -84,7 +84,7 @@ class Context:
 
     def __init__(self, prob: Problem, device: int = 0, laStart: int = 0, laEnd: int = 0,
                  stream: Optional[int] = None, lib_path: Optional[str] = None,
-                 worldSize: int = 1, worldRank: int = 0):
+                 worldSize: int = 1, worldRank: int = 0, batchHint: int = 0):
         self.lib = load_library(lib_path)
         self.prob = prob
         self._desc = prob.descriptor()
@@ -93,6 +93,7 @@ class Context:
         opts.laStart, opts.laEnd = laStart, laEnd
         opts.stream = stream
         opts.worldSize, opts.worldRank = worldSize, worldRank
+        opts.flags = min(max(int(batchHint), 0), 0xffff)
         h = C.c_void_p()
         st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
         _check(self.lib, st, 'lwhip_create')

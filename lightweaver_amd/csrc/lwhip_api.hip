@@ -121,6 +121,7 @@ struct lwhip_context
     DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
     DevBuf<int32_t> b2idx;
     int groups2d = 1, maxRowsLa = 1;
+    int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
@@ -655,7 +656,12 @@ int build_tables(lwhip_context* c)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
         numCU = prop.multiProcessorCount;
-    int target = env_int("LWHIP_CHUNKS", numCU * 2);
+    // two workgroups per CU for a context that has the device to itself; a member of a column batch (batchHint
+    // co-resident contexts, one grid slice each) needs fewer, longer chunks: less per-chunk set-up and slab traffic
+    int target = numCU * 2;
+    if (c->batchHint > 1)
+        target = std::max(64, std::min(numCU * 2, numCU * 16 / c->batchHint));
+    target = env_int("LWHIP_CHUNKS", target);
     target = std::max(1, std::min(target, c->Nla));
     std::vector<double> cost(c->Nla);
     bool anyPrd = false;
@@ -1259,6 +1265,7 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     c->prob = *prob;
     c->atoms.assign(prob->atoms, prob->atoms + prob->Natom);
     c->device = opts ? opts->device : 0;
+    c->batchHint = opts ? (opts->flags & 0xffff) : 0;
     if (c->device < 0 || c->device >= ndev)
     {
         delete c;
@@ -1712,6 +1719,49 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     return LWHIP_OK;
 }
 
+// argument blocks of the reduce / apply kernels of one context (also the per-column blocks of a batch)
+static ReduceArgs make_reduce_args(lwhip_context* c)
+{
+    ReduceArgs r{};
+    r.Ns = c->Ns;
+    r.Ntrans = c->Ntrans;
+    r.maxCT = c->maxCT;
+    r.trOff = c->trOff.p;
+    r.trRow = c->trRow.p;
+    r.partial = c->partial.p;
+    r.red8 = c->red8.p;
+    r.red = c->red.p;
+    r.dJ = c->dJ.p;
+    r.Nla = c->Nla;
+    r.idxOffset = c->laStart;
+    r.world = c->worldSize;
+    r.rank = c->worldRank;
+    r.batchTail = nullptr;
+    return r;
+}
+
+static ApplyArgs make_apply_args(lwhip_context* c)
+{
+    ApplyArgs a{};
+    a.Ns = c->Ns;
+    a.Natom = c->Natom;
+    a.atomTrOff = c->atomTrOffD.p;
+    a.atomNlevel = c->atomNlevel.p;
+    a.atomDetailed = c->atomDetailed.p;
+    a.atomGammaOff = c->atomGammaOff.p;
+    a.trans = c->dtrans.p;
+    a.transLi = c->transLi.p;
+    a.transLj = c->transLj.p;
+    a.red = c->red.p;
+    a.Gamma = c->Gamma.p;
+    a.Rij = c->Rij.p;
+    a.Rji = c->Rji.p;
+    a.Cmat = c->Cmat.p;
+    a.crsw = c->prefillCrsw;
+    a.prefill = c->prefillPending ? 1 : 0;
+    return a;
+}
+
 int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
 {
     if (!c)
@@ -1745,20 +1795,7 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
     {
         // fixed-order slab sums; the extra block of stage 2 writes this shard's (dJMax, global idx)
         // into its slot of the gather tail and zeros the other slots
-        ReduceArgs r{};
-        r.Ns = c->Ns;
-        r.Ntrans = c->Ntrans;
-        r.maxCT = c->maxCT;
-        r.trOff = c->trOff.p;
-        r.trRow = c->trRow.p;
-        r.partial = c->partial.p;
-        r.red8 = c->red8.p;
-        r.red = c->red.p;
-        r.dJ = c->dJ.p;
-        r.Nla = c->Nla;
-        r.idxOffset = c->laStart;
-        r.world = c->worldSize;
-        r.rank = c->worldRank;
+        const ReduceArgs r = make_reduce_args(c);
         HIP_TRY(launch_reduce(r, c->stream));
     }
     if (c->worldSize > 1 && !c->prdLines.empty()) // the PRD slots of the tail ride in the same all-reduce: keep them finite
@@ -1777,23 +1814,7 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
     HIP_TRY(hipSetDevice(c->device));
     if (c->Natom > 0)
     {
-        ApplyArgs a{};
-        a.Ns = c->Ns;
-        a.Natom = c->Natom;
-        a.atomTrOff = c->atomTrOffD.p;
-        a.atomNlevel = c->atomNlevel.p;
-        a.atomDetailed = c->atomDetailed.p;
-        a.atomGammaOff = c->atomGammaOff.p;
-        a.trans = c->dtrans.p;
-        a.transLi = c->transLi.p;
-        a.transLj = c->transLj.p;
-        a.red = c->red.p;
-        a.Gamma = c->Gamma.p;
-        a.Rij = c->Rij.p;
-        a.Rji = c->Rji.p;
-        a.Cmat = c->Cmat.p;
-        a.crsw = c->prefillCrsw;
-        a.prefill = c->prefillPending ? 1 : 0;
+        const ApplyArgs a = make_apply_args(c);
         HIP_TRY(launch_apply(a, c->stream));
         c->prefillPending = false;
     }
@@ -1833,6 +1854,215 @@ int lwhip_formal_sol_gamma_matrices(lwhip_context* c, int lambdaIterate, lwhip_i
     if (st != LWHIP_OK)
         return st;
     return lwhip_fs_finalise(c, res);
+}
+
+// ---- 1.5D column batches: one iteration of n structurally identical contexts in one set of launches ----------
+struct lwhip_batch
+{
+    std::vector<lwhip_context*> ctxs;
+    std::vector<hipStream_t> ownStreams; // what the columns ran on before they joined the batch
+    DevBuf<const SweepArgs*> apList;
+    DevBuf<ReduceArgs> rList;
+    DevBuf<ApplyArgs> aList;
+    DevBuf<double> tail;       // [n][2] (dJMax, idx) of every column
+    double* tailPinned = nullptr;
+    std::vector<ApplyArgs> aHost;
+    double aCrsw = 0.0;        // what the device copy of the apply blocks was built with
+    bool aValid = false;
+    DevBuf<StatEqArgs> seList; // stat_equil of all active atoms of every column
+    StatEqArgs se0{};
+    int seMaxNl = 0;
+};
+
+int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
+{
+    if (!ctxs || n < 1 || !out)
+        return fail(LWHIP_ERR_INVALID, "batch_create: null argument");
+    lwhip_context* c0 = ctxs[0];
+    for (int i = 0; i < n; ++i)
+    {
+        lwhip_context* c = ctxs[i];
+        if (!c)
+            return fail(LWHIP_ERR_INVALID, "batch_create: null context");
+        if (c->is2d || c->march || c->worldSize != 1)
+            return fail(LWHIP_ERR_UNSUPPORTED, "batch_create: columns are 1D, unsharded contexts on the default sweep");
+        if (c->device != c0->device || c->Ns != c0->Ns || c->Nla != c0->Nla
+            || c->Nrays != c0->Nrays || c->Ntrans != c0->Ntrans || c->Natom != c0->Natom || c->nChunks != c0->nChunks
+            || c->maxL != c0->maxL || c->maxC != c0->maxC || c->maxCT != c0->maxCT || c->G != c0->G || c->big != c0->big
+            || c->NlevTot != c0->NlevTot || c->prob.formalSolver != c0->prob.formalSolver)
+            return fail(LWHIP_ERR_INVALID, "batch_create: the columns must share device, model atoms, wavelength grid "
+                                           "and solver");
+    }
+    HIP_TRY(hipSetDevice(c0->device));
+    // the batch's launches go to the first column's stream; the other columns move onto it so that their own
+    // uploads / downloads stay ordered with the batch
+    std::vector<hipStream_t> before(n);
+    for (int i = 0; i < n; ++i)
+    {
+        before[i] = ctxs[i]->stream;
+        if (ctxs[i]->stream != c0->stream)
+        {
+            HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+            ctxs[i]->stream = c0->stream;
+        }
+    }
+    auto b = std::make_unique<lwhip_batch>();
+    b->ctxs.assign(ctxs, ctxs + n);
+    b->ownStreams = before;
+    std::vector<const SweepArgs*> ap(n);
+    std::vector<ReduceArgs> rl(n);
+    HIP_TRY(b->tail.alloc((size_t)2 * n));
+    for (int i = 0; i < n; ++i)
+    {
+        ap[i] = ctxs[i]->dargs.p;
+        rl[i] = make_reduce_args(ctxs[i]);
+        rl[i].batchTail = b->tail.p + 2 * (size_t)i;
+    }
+    HIP_TRY(b->apList.upload(ap));
+    HIP_TRY(b->rList.upload(rl));
+    HIP_TRY(b->aList.alloc((size_t)n));
+    b->aHost.resize(n);
+    {
+        std::vector<StatEqArgs> sl(n);
+        for (int i = 0; i < n; ++i)
+        {
+            lwhip_context* c = ctxs[i];
+            if (!c->statusHost)
+            {
+                HIP_TRY(hipHostMalloc((void**)&c->statusHost, sizeof(int32_t), hipHostMallocMapped));
+                HIP_TRY(hipHostGetDevicePointer((void**)&c->statusDev, c->statusHost, 0));
+                *c->statusHost = 0;
+            }
+            std::vector<NrAtom> atoms;
+            int maxNl = 0;
+            for (int ia = 0; ia < c->Natom; ++ia)
+            {
+                const lwhip_atom& a = c->atoms[ia];
+                if (a.detailed)
+                    continue;
+                NrAtom at{};
+                at.atom = ia;
+                at.Nlevel = a.Nlevel;
+                at.levelOff = c->levelOff[ia];
+                at.gammaOff = c->gammaOff[ia];
+                atoms.push_back(at);
+                maxNl = std::max(maxNl, a.Nlevel);
+            }
+            if (!atoms.empty())
+            {
+                HIP_TRY(c->statEqAtoms.upload(atoms));
+                c->statEqKey = -1;
+            }
+            StatEqArgs sa{};
+            sa.Ns = c->Ns;
+            sa.Natoms = (int32_t)atoms.size();
+            sa.atoms = c->statEqAtoms.p;
+            sa.n = c->n.p;
+            sa.nTotal = c->nTotal.p;
+            sa.Gamma = c->Gamma.p;
+            sa.status = c->statusDev;
+            sa.change = nullptr;
+            sl[i] = sa;
+            if (i == 0)
+            {
+                b->se0 = sa;
+                b->seMaxNl = maxNl;
+            }
+            else if (sa.Natoms != b->se0.Natoms || maxNl != b->seMaxNl)
+                return fail(LWHIP_ERR_INVALID, "batch_create: the columns must share their active atoms");
+        }
+        HIP_TRY(b->seList.upload(sl));
+    }
+    HIP_TRY(hipHostMalloc((void**)&b->tailPinned, (size_t)2 * n * sizeof(double), hipHostMallocDefault));
+    *out = b.release();
+    return LWHIP_OK;
+}
+
+void lwhip_batch_destroy(lwhip_batch* b)
+{
+    if (!b)
+        return;
+    // the columns go back to their own streams (the first column's may be destroyed before the others)
+    if (!b->ctxs.empty())
+    {
+        (void)hipSetDevice(b->ctxs[0]->device);
+        (void)hipStreamSynchronize(b->ctxs[0]->stream);
+        for (size_t i = 0; i < b->ctxs.size() && i < b->ownStreams.size(); ++i)
+            b->ctxs[i]->stream = b->ownStreams[i];
+    }
+    if (b->tailPinned)
+        (void)hipHostFree(b->tailPinned);
+    delete b;
+}
+
+int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, double crsw, lwhip_iter_result* results)
+{
+    if (!b || b->ctxs.empty())
+        return fail(LWHIP_ERR_INVALID, "null batch");
+    const int n = (int)b->ctxs.size();
+    lwhip_context* c0 = b->ctxs[0];
+    HIP_TRY(hipSetDevice(c0->device));
+    // Gamma <- crsw * C of every column is fused into its slice of the apply launch
+    for (int i = 0; i < n; ++i)
+    {
+        lwhip_context* c = b->ctxs[i];
+        if (c->partialPending || c->prdPending)
+            return fail(LWHIP_ERR_INVALID, "batch iteration while a split iteration of a column is pending");
+        c->prefillCrsw = crsw;
+        c->prefillPending = c->gammaTot > 0 && c->Cmat.p != nullptr;
+        b->aHost[i] = make_apply_args(c);
+        c->prefillPending = false;
+    }
+    if (!b->aValid || b->aCrsw != crsw)
+    {
+        HIP_TRY(hipMemcpyAsync(b->aList.p, b->aHost.data(), (size_t)n * sizeof(ApplyArgs), hipMemcpyHostToDevice, c0->stream));
+        b->aValid = true;
+        b->aCrsw = crsw;
+    }
+    const SweepDyn dyn = make_dyn(c0, false, lambdaIterate);
+    HIP_TRY(launch_sweep(c0->dargs.p, c0->hargs, dyn, c0->prob.formalSolver, c0->maxL, true, c0->nChunks, c0->stream,
+                         b->apList.p, n));
+    HIP_TRY(launch_reduce(make_reduce_args(c0), c0->stream, b->rList.p, n));
+    if (c0->Natom > 0)
+        HIP_TRY(launch_apply(b->aHost[0], c0->stream, b->aList.p, n));
+    if (results)
+    {
+        HIP_TRY(hipMemcpyAsync(b->tailPinned, b->tail.p, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+        HIP_TRY(hipStreamSynchronize(c0->stream));
+        for (int i = 0; i < n; ++i)
+        {
+            results[i].updatedJ = 1;
+            results[i].dJMax = b->tailPinned[2 * i];
+            results[i].dJMaxIdx = (int32_t)b->tailPinned[2 * i + 1];
+        }
+    }
+    return LWHIP_OK;
+}
+
+int lwhip_batch_stat_equil(lwhip_batch* b)
+{
+    if (!b || b->ctxs.empty())
+        return fail(LWHIP_ERR_INVALID, "null batch");
+    lwhip_context* c0 = b->ctxs[0];
+    HIP_TRY(hipSetDevice(c0->device));
+    if (b->se0.Natoms <= 0)
+        return LWHIP_OK;
+    for (lwhip_context* c : b->ctxs)
+    {
+        const int stp = flush_prefill(c);
+        if (stp != LWHIP_OK)
+            return stp;
+        *c->statusHost = 0;
+    }
+    HIP_TRY(launch_stat_eq(b->se0, b->seMaxNl, c0->stream, b->seList.p, (int)b->ctxs.size()));
+    HIP_TRY(hipStreamSynchronize(c0->stream));
+    for (lwhip_context* c : b->ctxs)
+        if (*c->statusHost == LWHIP_ERR_SINGULAR)
+        {
+            *c->statusHost = 0;
+            return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
+        }
+    return LWHIP_OK;
 }
 
 int lwhip_reduce_buffer(lwhip_context* c, void** devPtr, size_t* nSum, size_t* nGather)

@@ -169,6 +169,7 @@ struct ReduceArgs
     double* red;                   // [Ntrans, 4, Ns] + gather tail [2 * world]
     const double* dJ;              // [Nla] per-wavelength dJ of this shard
     int32_t Nla, idxOffset, world, rank;
+    double* batchTail;             // column batches: this column's (dJMax, idx) slot of the batch's read-back buffer
 };
 
 struct ApplyArgs
@@ -286,7 +287,8 @@ struct StatEqArgs
     int32_t* status;            // host-mapped: LWHIP_ERR_SINGULAR is written straight into pinned memory
     double* change;             // host-mapped [Natoms][blocks][2]: max |dn/n| and its flattened index per block, or null
 };
-hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream);
+hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream, const StatEqArgs* list = nullptr,
+                          int nBatch = 0);
 int stat_eq_blocks(int Ns, int maxNlevel);
 // 2D formal solver (lwhip_fs2d.hip): one workgroup per problem
 struct Fs2dArgs
@@ -384,13 +386,15 @@ hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, co
 size_t sweep_lds_bytes(const SweepArgs& a, int G);
 size_t sweep_big_scratch_doubles(const SweepArgs& a);
 hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn,
-                        int solver, int maxL, bool rates, int nChunks, hipStream_t stream);
+                        int solver, int maxL, bool rates, int nChunks, hipStream_t stream,
+                        const SweepArgs* const* apList = nullptr, int nBatch = 0);
 // march kernel: D depth points per lane; returns hipErrorInvalidValue for an unsupported D
 hipError_t launch_cont(const SweepArgs* devArgs, const SweepArgs& hostArgs, hipStream_t stream);
 hipError_t launch_march(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn, int solver,
                         int D, int maxL, bool rates, int nChunks, int wavesPerGroup, hipStream_t stream);
 size_t march_lds_bytes(const SweepArgs& a, int wavesPerGroup);
-hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream);
-hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream);
+// list / nBatch: column batches -- a device array of per-column argument blocks, one grid slice per column
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list = nullptr, int nBatch = 0);
+hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
 }

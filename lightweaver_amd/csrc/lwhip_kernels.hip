@@ -75,15 +75,21 @@ template <bool BIG> DEVINL void wg_barrier()
 #define STAMP(i)
 #endif
 
+// The body is a function so that the single-problem kernel and the column-batch kernel share it; `ap` stays a
+// __restrict__ *parameter* in both (the no-alias guarantee is what lets the compiler keep argument-block fields
+// across the kernel's stores: a pointer merely loaded from a table costs 40 % of the sweep, measured).
 template <int SOLVER, int MAXL, bool RATES, bool BIG>
-__global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict__ ap, const SweepDyn dyn)
+DEVINL void sweep_body(const SweepArgs* __restrict__ ap, const SweepDyn& dyn)
 {
     extern __shared__ double lds[];
 #ifdef LWHIP_STAMPS
     long long stampAcc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long stampLast = clock64();
 #endif
-    const SweepArgs& a = *ap;
+    // the argument block is read through the constant address space: always scalar loads, also when `ap` itself
+    // came from the batch's pointer table (a generic pointer the compiler cannot prove unclobbered would be read
+    // with vector loads: 40 % of the sweep)
+    const CONST_AS SweepArgs& a = *(const CONST_AS SweepArgs*)ap;
     const int Ns = a.Ns;
     const int G = dyn.G;
     const int GNs = G * Ns;
@@ -1042,68 +1048,88 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
 #undef ARGS
 
 template <int SOLVER, int MAXL, bool RATES, bool BIG>
+__global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict__ ap, const SweepDyn dyn)
+{
+    sweep_body<SOLVER, MAXL, RATES, BIG>(ap, dyn);
+}
+
+// column batches (1.5D): blockIdx.y picks the column's argument block; every column has the same structure
+template <int SOLVER, int MAXL, bool RATES, bool BIG>
+__global__ void __launch_bounds__(1024) sweep_batch_kernel(const SweepArgs* const* __restrict__ apList, const SweepDyn dyn)
+{
+    sweep_body<SOLVER, MAXL, RATES, BIG>(apList[blockIdx.y], dyn);
+}
+
+template <int SOLVER, int MAXL, bool RATES, bool BIG>
 static hipError_t launch_sweep_t(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn,
-                                 int nChunks, hipStream_t stream)
+                                 int nChunks, hipStream_t stream, const SweepArgs* const* apList, int nBatch)
 {
     const size_t lds = sweep_lds_bytes(a, dyn.G);
-    static size_t configured = 0;
-    if (lds > configured)
+    static size_t configured = 0, configuredBatch = 0;
+    size_t& conf = apList ? configuredBatch : configured;
+    if (lds > conf)
     {
-        hipError_t err = hipFuncSetAttribute((const void*)sweep_kernel<SOLVER, MAXL, RATES, BIG>,
+        hipError_t err = hipFuncSetAttribute(apList ? (const void*)sweep_batch_kernel<SOLVER, MAXL, RATES, BIG>
+                                                    : (const void*)sweep_kernel<SOLVER, MAXL, RATES, BIG>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess)
             return err;
-        configured = lds;
+        conf = lds;
     }
     // at least one wavefront per ray of a pass (the scan) and one thread per point
     int T = ((std::max(dyn.G * a.Ns, 64) + 63) / 64) * 64;
     if (T > 1024)
         return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((sweep_kernel<SOLVER, MAXL, RATES, BIG>), dim3(nChunks), dim3(T), lds, stream, devArgs, dyn);
+    if (apList)
+        hipLaunchKernelGGL((sweep_batch_kernel<SOLVER, MAXL, RATES, BIG>), dim3(nChunks, std::max(nBatch, 1)), dim3(T), lds,
+                           stream, apList, dyn);
+    else
+        hipLaunchKernelGGL((sweep_kernel<SOLVER, MAXL, RATES, BIG>), dim3(nChunks), dim3(T), lds, stream, devArgs, dyn);
     return hipGetLastError();
 }
 
 template <int SOLVER, bool RATES>
 static hipError_t launch_sweep_l(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn,
-                                 int maxL, int nChunks, hipStream_t stream)
+                                 int maxL, int nChunks, hipStream_t stream, const SweepArgs* const* apList, int nBatch)
 {
     if (a.big)
     {
         if (maxL <= 2)
-            return launch_sweep_t<SOLVER, 2, RATES, true>(devArgs, a, dyn, nChunks, stream);
+            return launch_sweep_t<SOLVER, 2, RATES, true>(devArgs, a, dyn, nChunks, stream, apList, nBatch);
         if (maxL <= 4)
-            return launch_sweep_t<SOLVER, 4, RATES, true>(devArgs, a, dyn, nChunks, stream);
-        return launch_sweep_t<SOLVER, 8, RATES, true>(devArgs, a, dyn, nChunks, stream);
+            return launch_sweep_t<SOLVER, 4, RATES, true>(devArgs, a, dyn, nChunks, stream, apList, nBatch);
+        return launch_sweep_t<SOLVER, 8, RATES, true>(devArgs, a, dyn, nChunks, stream, apList, nBatch);
     }
     if (maxL <= 2)
-        return launch_sweep_t<SOLVER, 2, RATES, false>(devArgs, a, dyn, nChunks, stream);
+        return launch_sweep_t<SOLVER, 2, RATES, false>(devArgs, a, dyn, nChunks, stream, apList, nBatch);
     if (maxL <= 4)
-        return launch_sweep_t<SOLVER, 4, RATES, false>(devArgs, a, dyn, nChunks, stream);
-    return launch_sweep_t<SOLVER, 8, RATES, false>(devArgs, a, dyn, nChunks, stream);
+        return launch_sweep_t<SOLVER, 4, RATES, false>(devArgs, a, dyn, nChunks, stream, apList, nBatch);
+    return launch_sweep_t<SOLVER, 8, RATES, false>(devArgs, a, dyn, nChunks, stream, apList, nBatch);
 }
 
 hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& a, const SweepDyn& dyn, int solver,
-                        int maxL, bool rates, int nChunks, hipStream_t stream)
+                        int maxL, bool rates, int nChunks, hipStream_t stream, const SweepArgs* const* apList, int nBatch)
 {
     switch (solver)
     {
         case LWHIP_FS_LINEAR_1D:
-            return rates ? launch_sweep_l<LWHIP_FS_LINEAR_1D, true>(devArgs, a, dyn, maxL, nChunks, stream)
-                         : launch_sweep_l<LWHIP_FS_LINEAR_1D, false>(devArgs, a, dyn, maxL, nChunks, stream);
+            return rates ? launch_sweep_l<LWHIP_FS_LINEAR_1D, true>(devArgs, a, dyn, maxL, nChunks, stream, apList, nBatch)
+                         : launch_sweep_l<LWHIP_FS_LINEAR_1D, false>(devArgs, a, dyn, maxL, nChunks, stream, apList, nBatch);
         case LWHIP_FS_BESSER_1D:
-            return rates ? launch_sweep_l<LWHIP_FS_BESSER_1D, true>(devArgs, a, dyn, maxL, nChunks, stream)
-                         : launch_sweep_l<LWHIP_FS_BESSER_1D, false>(devArgs, a, dyn, maxL, nChunks, stream);
+            return rates ? launch_sweep_l<LWHIP_FS_BESSER_1D, true>(devArgs, a, dyn, maxL, nChunks, stream, apList, nBatch)
+                         : launch_sweep_l<LWHIP_FS_BESSER_1D, false>(devArgs, a, dyn, maxL, nChunks, stream, apList, nBatch);
         default:
-            return rates ? launch_sweep_l<LWHIP_FS_BEZIER3_1D, true>(devArgs, a, dyn, maxL, nChunks, stream)
-                         : launch_sweep_l<LWHIP_FS_BEZIER3_1D, false>(devArgs, a, dyn, maxL, nChunks, stream);
+            return rates ? launch_sweep_l<LWHIP_FS_BEZIER3_1D, true>(devArgs, a, dyn, maxL, nChunks, stream, apList, nBatch)
+                         : launch_sweep_l<LWHIP_FS_BEZIER3_1D, false>(devArgs, a, dyn, maxL, nChunks, stream, apList, nBatch);
     }
 }
 
 // ---- slab reduction: fixed-order sum of the per-chunk partials of each transition ----------------------
 // replaces AtomStorageFactory::accumulate_Gamma / TransitionStorageFactory::accumulate_rates
 // (ThreadStorage.cpp:73-88,150-166)
-__global__ void reduce_stage1_kernel(const ReduceArgs a)
+__global__ void reduce_stage1_kernel(const ReduceArgs a0, const ReduceArgs* __restrict__ list)
 {
+    const ReduceArgs a = list ? list[blockIdx.z] : a0; // column batches: blockIdx.z picks the column
     const int tr = blockIdx.x;
     const int part = blockIdx.y;
     const int n4 = 4 * a.Ns;
@@ -1165,12 +1191,19 @@ __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* 
     }
 }
 
-__global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a)
+__global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a0, const ReduceArgs* __restrict__ list)
 {
+    const ReduceArgs a = list ? list[blockIdx.z] : a0;
     const int tr = blockIdx.x;
     if (tr == a.Ntrans) // the extra block: dJMax
     {
         djmax_block(a.dJ, a.Nla, a.idxOffset, a.red + (size_t)a.Ntrans * 4 * a.Ns, a.world, a.rank);
+        if (a.batchTail) // column batches: every column's (dJMax, idx) in one buffer
+        {
+            __syncthreads();
+            if (threadIdx.x < 2)
+                a.batchTail[threadIdx.x] = a.red[(size_t)a.Ntrans * 4 * a.Ns + 2 * a.rank + threadIdx.x];
+        }
         return;
     }
     const int n4 = 4 * a.Ns;
@@ -1184,11 +1217,12 @@ __global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a)
     }
 }
 
-hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream)
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list, int nBatch)
 {
+    const int nz = std::max(nBatch, 1);
     if (a.Ntrans > 0)
-        hipLaunchKernelGGL(reduce_stage1_kernel, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT), dim3(384), 0, stream, a);
-    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(a.Ntrans + 1), dim3(512), 0, stream, a);
+        hipLaunchKernelGGL(reduce_stage1_kernel, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT, nz), dim3(384), 0, stream, a, list);
+    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(a.Ntrans + 1, 1, nz), dim3(512), 0, stream, a, list);
     return hipGetLastError();
 }
 
@@ -1197,8 +1231,9 @@ hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream)
 // One block per (atom, slab of APPLY_K depth points): thread (e, kk) owns Gamma entry e = to*Nl+from
 // at depth k; the extra block column x == Natom copies Rij/Rji.
 enum { APPLY_K = 16 };
-__global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a)
+__global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a0, const ApplyArgs* __restrict__ list)
 {
+    const ApplyArgs a = list ? list[blockIdx.z] : a0;
     const int Ns = a.Ns;
     const int k0 = blockIdx.y * APPLY_K;
     if ((int)blockIdx.x == a.Natom) // rates out
@@ -1261,9 +1296,9 @@ __global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a)
     }
 }
 
-hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream)
+hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list, int nBatch)
 {
-    hipLaunchKernelGGL(apply_kernel, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(apply_kernel, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(1024), 0, stream, a, list);
     return hipGetLastError();
 }
 

@@ -200,8 +200,9 @@ DEVINL void report_change(double best, int bestIdx, double* out /* [gridDim.x][2
 
 // ---- stat_eq_impl: Source/UpdatePopulations.cpp:7-47 -------------------------------------------------------
 // blockIdx.y selects the atom, so every active atom is solved by one launch
-__global__ void stat_eq_kernel(const StatEqArgs a)
+__global__ void stat_eq_kernel(const StatEqArgs a0, const StatEqArgs* __restrict__ list)
 {
+    const StatEqArgs a = list ? list[blockIdx.z] : a0; // column batches: blockIdx.z picks the column
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
@@ -264,7 +265,7 @@ int stat_eq_blocks(int Ns, int maxNlevel)
     return (Ns + tb - 1) / tb;
 }
 
-hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream)
+hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream, const StatEqArgs* list, int nBatch)
 {
     if (maxNlevel > 64 || a.Natoms <= 0)
         return hipErrorInvalidValue;
@@ -273,7 +274,7 @@ hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream
     hipError_t e = solve_set_lds((const void*)stat_eq_kernel, lds);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(stat_eq_kernel, dim3((a.Ns + tb - 1) / tb, a.Natoms), dim3(tb), lds, stream, a);
+    hipLaunchKernelGGL(stat_eq_kernel, dim3((a.Ns + tb - 1) / tb, a.Natoms, nBatch > 0 ? nBatch : 1), dim3(tb), lds, stream, a, list);
     return hipGetLastError();
 }
 

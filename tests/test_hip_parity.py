@@ -206,33 +206,40 @@ def test_rccl_allreduce_on_the_library_reduce_buffer(gpu):
         dist.destroy_process_group()
 
 
-def test_column_batch_vs_oracle(gpu):
+@pytest.mark.parametrize('fused', [True, False])
+def test_column_batch_vs_oracle(gpu, fused):
     """BASELINE configs[3] in miniature: perturbed FAL-C columns as independent problems, profiles
-    generated on the device, iterated as a batch; every column must match its own CPU run."""
+    generated on the device, iterated as a batch -- fused (lwhip_batch_*: one grid slice per column in one set of
+    launches) or column by column; every column must match its own CPU run, dJMax included."""
     from lightweaver_amd.batch import ColumnBatch, columns_of_rank
     assert columns_of_rank(10, 4, 1) == [1, 5, 9]
     assert sorted(sum((columns_of_rank(10, 4, r) for r in range(4)), [])) == list(range(10))
     probs = [models.build_problem(models.perturbed(models.falc82(), seed=100 + i),
                                   [models.H_6(0.3), models.CaII_6(0.3)], Nrays=3) for i in range(4)]
     refs = [p.copy() for p in probs]
+    dJref = []
     for q in refs:
         oc = OracleContext(q)
         for it in range(5):
             q.gamma_prefill()
-            oc.formal_sol_gamma_matrices()
+            dj = oc.formal_sol_gamma_matrices()
             if it >= 3:
                 assert oc.stat_equil() == 0
+        dJref.append(dj)
     for p in probs:                      # the device has to rebuild the profiles itself
         for a in p.atoms:
             for t in a.trans:
                 if t.type == abi.LINE:
                     t.phi[...] = 0.0
                     t.wphi[...] = 0.0
-    with ColumnBatch(probs) as batch:
-        batch.iterate(5, nscatter=3)
+    with ColumnBatch(probs, fused=fused) as batch:
+        assert (batch._batch is not None) == fused
+        ups = batch.iterate(5, nscatter=3)
         batch.download()
     for p, q in zip(probs, refs):
         compare_problems(p, q, tol=1e-7, what=('J', 'Gamma', 'n'))
+    for up, (dj, _) in zip(ups, dJref):   # (the oracle restates the single-thread index quirk: value only)
+        assert up.dJMax == pytest.approx(dj, rel=1e-6)
 
 
 def test_stat_equil_reports_population_changes(gpu):
