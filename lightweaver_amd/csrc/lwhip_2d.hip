@@ -30,9 +30,11 @@ __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
     const int b = blockIdx.z;
     const int la = a.la0 + b;
     const int Ns = a.Ns;
-    const int ray = a.rayList[r];
-    const DevLaHeader h = a.laHdr[la];
-    const DevSlot* slots = a.slots + h.off;
+    // the activity tables are read through the constant address space: scalar loads (a generic pointer next to the
+    // kernel's stores would be read with vector loads even at uniform addresses)
+    const int ray = CTAB(int32_t, a.rayList)[r];
+    const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + la);
+    const CONST_AS DevSlot* slots = CTAB(DevSlot, a.slots) + h.off;
     const size_t laNs = (size_t)la * Ns;
     double chi, eta;
     if (h.rowBase >= 0)
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
     }
     for (int l = 0; l < h.nLine; ++l)
     {
-        const DevSlot& sl = slots[l];
+        const CONST_AS DevSlot& sl = slots[l];
         const double vij = sl.p[0] * a.phi[sl.phiOff + (size_t)ray * Ns + k];
         double g = sl.p[2];
         if (sl.flags & 2)
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     for (int b = bLo; b < bHi; ++b)
     {
         const int la = a.la0 + b;
-        const DevLaHeader h = a.laHdr[la];
+        const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + la);
         const int nLine = h.nLine, nMixed = h.nMixed, nPure = h.nPure;
         // the wavelength's slot records into LDS: LDS reads are not ordered against the global stores of the ray
         // loop, so the compiler keeps or re-reads them cheaply (from global memory every field access would be a
@@ -164,13 +166,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         // slots that changed hands since the previous wavelength give up their sums
 #pragma unroll
         for (int l = 0; l < MAXL; ++l)
-            hand_over(accL[l], trL[l], (l < nLine) ? a.slotTr[h.off + l] : -1);
+            hand_over(accL[l], trL[l], (l < nLine) ? CTAB(int32_t, a.slotTr)[h.off + l] : -1);
 #pragma unroll
         for (int c = 0; c < MAXM; ++c)
-            hand_over(accM[c], trM[c], (c < nMixed) ? a.slotTr[h.off + nLine + c] : -1);
+            hand_over(accM[c], trM[c], (c < nMixed) ? CTAB(int32_t, a.slotTr)[h.off + nLine + c] : -1);
 #pragma unroll
         for (int c = 0; c < MAXP; ++c)
-            hand_over(accP[c], trP[c], (c < nPure) ? a.slotTr[h.off + nLine + nMixed + c] : -1);
+            hand_over(accP[c], trP[c], (c < nPure) ? CTAB(int32_t, a.slotTr)[h.off + nLine + nMixed + c] : -1);
         double mJ = 0.0, mM1 = 0.0, mE0 = 0.0, mE1 = 0.0;
         // ---- ray-independent part of the wavelength ---------------------------------------------------------
         double lG[MAXL], lNi[MAXL], lNj[MAXL], lW[MAXL];
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         {
             double v[4];
             pure(cq, v);
-            double* red = redG + ((size_t)a.slotTr[h.off + nLine + nMixed + cq] * 4) * Ns + k;
+            double* red = redG + ((size_t)CTAB(int32_t, a.slotTr)[h.off + nLine + nMixed + cq] * 4) * Ns + k;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 red[(size_t)q * Ns] += v[q];
