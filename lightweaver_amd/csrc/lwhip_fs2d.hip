@@ -41,6 +41,27 @@ DEVINL double f2_interp(const lwhip_intersection& loc, const double* p, int Nx)
     return p[(size_t)((int)loc.fracZ) * Nx + (int)loc.fracX];
 }
 
+// the same interpolation as two flat indices and weights, shared by every field read at one hit (chi and S):
+// value = w0 p[i0] + w1 p[i1], bit-identical to f2_interp (for a hit on a grid point w1 = 0 and i1 = i0)
+struct F2Loc
+{
+    int i0, i1;
+    double w0, w1;
+};
+DEVINL F2Loc f2_loc(const lwhip_intersection& loc, int Nx)
+{
+    F2Loc l;
+    const int z = (int)loc.fracZ, x = (int)loc.fracX;
+    l.i0 = z * Nx + x;
+    const double frac = (loc.axis == 1) ? loc.fracX - x : loc.fracZ - z;
+    const bool two = loc.axis != 0;
+    l.i1 = two ? l.i0 + ((loc.axis == 1) ? 1 : Nx) : l.i0;
+    l.w0 = two ? 1.0 - frac : 1.0;
+    l.w1 = two ? frac : 0.0;
+    return l;
+}
+DEVINL double f2_at(const F2Loc& l, const double* p) { return l.w0 * p[l.i0] + l.w1 * p[l.i1]; }
+
 // besser_control_point :257-294
 DEVINL double f2_control_point(double hM, double hP, double yM, double yO, double yP)
 {
@@ -129,17 +150,24 @@ DEVINL void f2_long_char(const Fs2dArgs& a, int lc, const double* chi, const dou
     Ecum = 1.0;
     acc = 0.0;
     double edt, src, psi;
+    // every sub-step is read three times (as the upwind, the local and the downwind point of consecutive steps):
+    // carry its chi and S along instead of interpolating again
+    F2Loc l0 = f2_loc(st[0], Nx), l1 = f2_loc(st[1], Nx);
+    double chiA = f2_at(l0, chi), SA = f2_at(l0, S), chiB = f2_at(l1, chi), SB = f2_at(l1, S);
     for (int s = 1; s < n - 1; ++s)
     {
-        f2_besser(st[s - 1].distance, st[s + 1].distance, f2_interp(st[s - 1], chi, Nx), f2_interp(st[s], chi, Nx),
-                  f2_interp(st[s + 1], chi, Nx), f2_interp(st[s - 1], S, Nx), f2_interp(st[s], S, Nx),
-                  f2_interp(st[s + 1], S, Nx), edt, src, psi, chiC);
+        const F2Loc l2 = f2_loc(st[s + 1], Nx);
+        const double chiC2 = f2_at(l2, chi), SC2 = f2_at(l2, S);
+        f2_besser(st[s - 1].distance, st[s + 1].distance, chiA, chiB, chiC2, SA, SB, SC2, edt, src, psi, chiC);
         acc = edt * acc + src;
         Ecum = edt * Ecum;
+        chiA = chiB;
+        SA = SB;
+        chiB = chiC2;
+        SB = SC2;
     }
     const int s = n - 1;
-    f2_besser(st[s - 1].distance, st[s].distance, f2_interp(st[s - 1], chi, Nx), f2_interp(st[s], chi, Nx), chiHere,
-              f2_interp(st[s - 1], S, Nx), f2_interp(st[s], S, Nx), SHere, edt, src, psi, chiC);
+    f2_besser(st[s - 1].distance, st[s].distance, chiA, chiB, chiHere, SA, SB, SHere, edt, src, psi, chiC);
     acc = edt * acc + src;
     Ecum = edt * Ecum;
 }
@@ -247,8 +275,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     double e;
     if (lc < 0)
     {
-        const double chiUw = f2_interp(uw, chi, Nx);
-        const double Suw = f2_interp(uw, S, Nx);
+        const F2Loc lu = f2_loc(uw, Nx);
+        const double chiUw = f2_at(lu, chi);
+        const double Suw = f2_at(lu, S);
         if (last || dw.distance == 0.0)
         {
             // linear step: the last plane (:1086-1101) uses the signed distance, the interior's
@@ -259,8 +288,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         else
         {
             double chiC;
-            f2_besser(uw.distance, dw.distance, chiUw, chiL, f2_interp(dw, chi, Nx), Suw, SL, f2_interp(dw, S, Nx), e,
-                      src, psi, chiC);
+            const F2Loc ld = f2_loc(dw, Nx);
+            f2_besser(uw.distance, dw.distance, chiUw, chiL, f2_at(ld, chi), Suw, SL, f2_at(ld, S), e, src, psi, chiC);
         }
         // the upwind intensity: previous plane (known) and, for a hit on the x face, this plane's
         // previous column (the unknown of the recurrence)
@@ -283,8 +312,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         double chiC, Ecum, acc;
         f2_long_char(a, lc, chi, S, chiL, SL, Ecum, acc, chiC);
         const lwhip_intersection st = a.substeps[a.substepOff[lc + 1] - 1]; // = the upwind hit
-        const double chiUw = f2_interp(st, chi, Nx);
-        const double Suw = f2_interp(st, S, Nx);
+        const F2Loc ls = f2_loc(st, Nx);
+        const double chiUw = f2_at(ls, chi);
+        const double Suw = f2_at(ls, S);
         if (last || dw.distance == 0.0)
         {
             const double dtau = 0.5 * (chiUw + chiL) * (last ? uw.distance : st.distance);
@@ -293,10 +323,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         else
         {
             // :1060-1075: the chi control point of the last sub-step is re-used, not recomputed
-            const double chiDw = f2_interp(dw, chi, Nx);
+            const F2Loc ld = f2_loc(dw, Nx);
+            const double chiDw = f2_at(ld, chi);
             const double dtauUw = (1.0 / 3.0) * (chiUw + chiL + chiC) * st.distance;
             const double dtauDw = (0.5) * (chiL + chiDw) * dw.distance;
-            const double Sdw = f2_interp(dw, S, Nx);
+            const double Sdw = f2_at(ld, S);
             const double SC = f2_control_point(dtauUw, dtauDw, Suw, SL, Sdw);
             double M, O, Cc;
             f2_coeffs(dtauUw, M, O, Cc, e);

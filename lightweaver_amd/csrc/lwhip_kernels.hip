@@ -1127,9 +1127,10 @@ hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& a, const Swee
 // ---- slab reduction: fixed-order sum of the per-chunk partials of each transition ----------------------
 // replaces AtomStorageFactory::accumulate_Gamma / TransitionStorageFactory::accumulate_rates
 // (ThreadStorage.cpp:73-88,150-166)
-__global__ void reduce_stage1_kernel(const ReduceArgs a0, const ReduceArgs* __restrict__ list)
+// (BATCH: column batches -- blockIdx.z picks the column's argument block from a table read through the constant
+// address space; the single-problem instantiation keeps its kernel-argument block untouched)
+template <class A> DEVINL void reduce_stage1_kernel_body(const A& a)
 {
-    const ReduceArgs a = list ? list[blockIdx.z] : a0; // column batches: blockIdx.z picks the column
     const int tr = blockIdx.x;
     const int part = blockIdx.y;
     const int n4 = 4 * a.Ns;
@@ -1144,6 +1145,15 @@ __global__ void reduce_stage1_kernel(const ReduceArgs a0, const ReduceArgs* __re
             s += a.partial[(size_t)a.trRow[e] * n4 + idx];
         a.red8[((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + idx] = s;
     }
+}
+
+template <bool BATCH>
+__global__ void reduce_stage1_kernel(const ReduceArgs a0, const ReduceArgs* __restrict__ list)
+{
+    if constexpr (BATCH)
+        reduce_stage1_kernel_body(CTAB(ReduceArgs, list)[blockIdx.z]);
+    else
+        reduce_stage1_kernel_body(a0);
 }
 
 __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* tail, int world, int rank)
@@ -1191,9 +1201,8 @@ __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* 
     }
 }
 
-__global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a0, const ReduceArgs* __restrict__ list)
+template <class A> DEVINL void reduce_stage2_kernel_body(const A& a)
 {
-    const ReduceArgs a = list ? list[blockIdx.z] : a0;
     const int tr = blockIdx.x;
     if (tr == a.Ntrans) // the extra block: dJMax
     {
@@ -1217,12 +1226,28 @@ __global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a0,
     }
 }
 
+template <bool BATCH>
+__global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a0, const ReduceArgs* __restrict__ list)
+{
+    if constexpr (BATCH)
+        reduce_stage2_kernel_body(CTAB(ReduceArgs, list)[blockIdx.z]);
+    else
+        reduce_stage2_kernel_body(a0);
+}
+
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list, int nBatch)
 {
     const int nz = std::max(nBatch, 1);
+    if (list)
+    {
+        if (a.Ntrans > 0)
+            hipLaunchKernelGGL(reduce_stage1_kernel<true>, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT, nz), dim3(384), 0, stream, a, list);
+        hipLaunchKernelGGL(reduce_stage2_kernel<true>, dim3(a.Ntrans + 1, 1, nz), dim3(512), 0, stream, a, list);
+        return hipGetLastError();
+    }
     if (a.Ntrans > 0)
-        hipLaunchKernelGGL(reduce_stage1_kernel, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT, nz), dim3(384), 0, stream, a, list);
-    hipLaunchKernelGGL(reduce_stage2_kernel, dim3(a.Ntrans + 1, 1, nz), dim3(512), 0, stream, a, list);
+        hipLaunchKernelGGL(reduce_stage1_kernel<false>, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT), dim3(384), 0, stream, a, list);
+    hipLaunchKernelGGL(reduce_stage2_kernel<false>, dim3(a.Ntrans + 1), dim3(512), 0, stream, a, list);
     return hipGetLastError();
 }
 
@@ -1231,9 +1256,8 @@ hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceAr
 // One block per (atom, slab of APPLY_K depth points): thread (e, kk) owns Gamma entry e = to*Nl+from
 // at depth k; the extra block column x == Natom copies Rij/Rji.
 enum { APPLY_K = 16 };
-__global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a0, const ApplyArgs* __restrict__ list)
+template <class A> DEVINL void apply_kernel_body(const A& a)
 {
-    const ApplyArgs a = list ? list[blockIdx.z] : a0;
     const int Ns = a.Ns;
     const int k0 = blockIdx.y * APPLY_K;
     if ((int)blockIdx.x == a.Natom) // rates out
@@ -1296,9 +1320,22 @@ __global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a0, const A
     }
 }
 
+template <bool BATCH>
+__global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a0, const ApplyArgs* __restrict__ list)
+{
+    if constexpr (BATCH)
+        apply_kernel_body(CTAB(ApplyArgs, list)[blockIdx.z]);
+    else
+        apply_kernel_body(a0);
+}
+
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list, int nBatch)
 {
-    hipLaunchKernelGGL(apply_kernel, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(1024), 0, stream, a, list);
+    if (list)
+        hipLaunchKernelGGL(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(1024), 0,
+                           stream, a, list);
+    else
+        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0, stream, a, list);
     return hipGetLastError();
 }
 

@@ -200,9 +200,8 @@ DEVINL void report_change(double best, int bestIdx, double* out /* [gridDim.x][2
 
 // ---- stat_eq_impl: Source/UpdatePopulations.cpp:7-47 -------------------------------------------------------
 // blockIdx.y selects the atom, so every active atom is solved by one launch
-__global__ void stat_eq_kernel(const StatEqArgs a0, const StatEqArgs* __restrict__ list)
+template <class A> DEVINL void stat_eq_body(const A& a)
 {
-    const StatEqArgs a = list ? list[blockIdx.z] : a0; // column batches: blockIdx.z picks the column
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
@@ -259,6 +258,15 @@ __global__ void stat_eq_kernel(const StatEqArgs a0, const StatEqArgs* __restrict
     report_change(best, bestIdx, a.change ? a.change + (size_t)blockIdx.y * 2 * gridDim.x : nullptr);
 }
 
+// BATCH: column batches -- blockIdx.z picks the column's argument block (read through the constant address space)
+template <bool BATCH> __global__ void stat_eq_kernel(const StatEqArgs a0, const StatEqArgs* __restrict__ list)
+{
+    if constexpr (BATCH)
+        stat_eq_body(CTAB(StatEqArgs, list)[blockIdx.z]);
+    else
+        stat_eq_body(a0);
+}
+
 int stat_eq_blocks(int Ns, int maxNlevel)
 {
     const int tb = solve_block_threads(maxNlevel);
@@ -271,10 +279,14 @@ hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream
         return hipErrorInvalidValue;
     const int tb = solve_block_threads(maxNlevel);
     const size_t lds = solve_ws_doubles(maxNlevel) * sizeof(double) * tb;
-    hipError_t e = solve_set_lds((const void*)stat_eq_kernel, lds);
+    hipError_t e = solve_set_lds(list ? (const void*)stat_eq_kernel<true> : (const void*)stat_eq_kernel<false>, lds);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(stat_eq_kernel, dim3((a.Ns + tb - 1) / tb, a.Natoms, nBatch > 0 ? nBatch : 1), dim3(tb), lds, stream, a, list);
+    if (list)
+        hipLaunchKernelGGL(stat_eq_kernel<true>, dim3((a.Ns + tb - 1) / tb, a.Natoms, nBatch > 0 ? nBatch : 1), dim3(tb), lds, stream, a,
+                           list);
+    else
+        hipLaunchKernelGGL(stat_eq_kernel<false>, dim3((a.Ns + tb - 1) / tb, a.Natoms), dim3(tb), lds, stream, a, list);
     return hipGetLastError();
 }
 
