@@ -213,11 +213,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         return;
     // solve s: ray rays[s % nRayCycle]; wavelength wavs[s / nRayCycle] (2D iteration: a batch of wavelengths x
     // the active rays) or the single a.wav (primitive)
-    const int ray = a.rays[solve % a.nRayCycle];
-    const double wavHere = a.wavs ? a.wavs[solve / a.nRayCycle] : a.wav;
+    // (uniform table reads through the constant address space: scalar loads, not a chain of vector-load latencies
+    // at the start of every short-lived workgroup)
+    const int ray = CTAB(int32_t, a.rays)[solve % a.nRayCycle];
+    const double wavHere = a.wavs ? CTAB(double, a.wavs)[solve / a.nRayCycle] : a.wav;
     const int mu = ray >> 1;
     const bool toObs = (ray & 1) != 0;
-    const double mux = toObs ? a.mux[mu] : -a.mux[mu];
+    const double mux = toObs ? CTAB(double, a.mux)[mu] : -CTAB(double, a.mux)[mu];
     const int dk = toObs ? -1 : 1;
     const int kStart = toObs ? Nz - 1 : 0;
     const int kEnd = toObs ? 0 : Nz - 1;
@@ -357,10 +359,10 @@ __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
     const int Nx = a.Nx, Nz = a.Nz;
     const size_t Ns = (size_t)Nx * Nz;
     const int solve = blockIdx.x;
-    const int ray = a.rays[solve % a.nRayCycle];
+    const int ray = CTAB(int32_t, a.rays)[solve % a.nRayCycle];
     const int mu = ray >> 1;
     const bool toObs = (ray & 1) != 0;
-    const double mux = toObs ? a.mux[mu] : -a.mux[mu];
+    const double mux = toObs ? CTAB(double, a.mux)[mu] : -CTAB(double, a.mux)[mu];
     const int dk = toObs ? -1 : 1;
     const int kStart = toObs ? Nz - 1 : 0;
     const bool rev = mux < 0;
