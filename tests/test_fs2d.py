@@ -298,3 +298,45 @@ def test_hip_2d_formal_sol_matches_oracle(gpu, upOnly):
         ctx.download(abi.ALL_OUTPUTS)
     assert rel_err(prob.I, q.I) <= 1e-9
     assert np.array_equal(prob.J, J0) and np.array_equal(prob.atoms[0].Gamma, G0)
+
+
+def blended_atoms(ncopy, ls=0.25):
+    """H plus `ncopy` Ca II model atoms with slightly scaled level energies: their lines overlap each other (2 copies:
+    up to 4 lines at one wavelength, 3 copies: up to 6), which the stock H + Ca II pair never does (at most 2)."""
+    import copy
+    from lightweaver_amd.harness import models
+    ca = models.CaII_6(ls)
+
+    def shifted(eps, name):
+        m = copy.deepcopy(ca)
+        m.name, m.E_cm, m.abundance = name, [e * (1 + eps) for e in m.E_cm], 0.5 * m.abundance
+        return m
+    return [models.H_6(ls)] + [shifted(2e-4 * (q - ncopy // 2), f'Ca{q}') for q in range(ncopy)]
+
+
+@pytest.mark.gpu
+def test_hip_2d_overlapping_lines(gpu):
+    """Four lines at one wavelength on a small 2D grid (the MAXL = 4 instantiations of gather2d / rates2d), three
+    active atoms, mixed and pure continua of all of them; built with the library's own geometry."""
+    from lightweaver_amd.context import Context
+    from lightweaver_amd.harness import models
+    base = models.falc82()
+    cols = [models.perturbed(base, seed=300 + j) for j in range(6)]
+    prob = models.build_problem_2d(cols, np.linspace(0.0, 5 * 40e3, 6), blended_atoms(2))
+    q = prob.copy()
+    orc = bindings.OracleContext(q)
+    with Context(prob) as ctx:
+        for it in range(2):
+            up = ctx.formal_sol_gamma_matrices()
+            q.gamma_prefill()
+            dJ, _ = orc.formal_sol_gamma_matrices()
+            assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+            assert rel_err(prob.J, q.J) <= 1e-9 * (it + 1) and rel_err(prob.I, q.I) <= 1e-9 * (it + 1)
+            for a, b in zip(prob.atoms, q.atoms):
+                assert rel_err(a.Gamma, b.Gamma) <= 1e-8
+                for ta, tb in zip(a.trans, b.trans):
+                    assert rel_err(ta.Rij, tb.Rij) <= 1e-9 * (it + 1) and rel_err(ta.Rji, tb.Rji) <= 1e-9 * (it + 1)
+            ctx.stat_equil()
+            assert orc.stat_equil() == 0
+    for a, b in zip(prob.atoms, q.atoms):
+        assert rel_err(a.n, b.n) <= 1e-8

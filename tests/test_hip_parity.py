@@ -308,3 +308,36 @@ def test_repeatability(gpu):
         c2.formal_sol_gamma_matrices()
     assert np.array_equal(p1.J, p2.J) and np.array_equal(p1.I, p2.I)
     assert rel_err(p1.atoms[0].Gamma, p2.atoms[0].Gamma) <= 1e-12
+
+
+@pytest.mark.parametrize('ncopy,maxlines', [(2, 4), (3, 6)])
+def test_more_than_two_overlapping_lines(gpu, ncopy, maxlines):
+    """The MAXL = 4 and MAXL = 8 instantiations of the sweep: blended Ca II copies put up to 4 / 6 lines at one
+    wavelength (the stock H + Ca II pair never exceeds 2).  One iteration + stat_equil against the oracle."""
+    from test_fs2d import blended_atoms
+    prob = models.build_problem(models.falc82(), blended_atoms(ncopy, 0.3), Nrays=3)
+    lines = np.zeros(prob.Nlambda, dtype=int)
+    for a in prob.atoms:
+        for t in a.trans:
+            if t.type == abi.LINE:
+                lines[t.Nblue:t.Nred] += 1
+    assert lines.max() == maxlines
+    q = prob.copy()
+    with OracleContext(q) as oc:
+        q.gamma_prefill()
+        dJ, _ = oc.formal_sol_gamma_matrices()
+        assert oc.stat_equil() == 0
+    with Context(prob) as ctx:
+        up = ctx.formal_sol_gamma_matrices()
+        ctx.stat_equil()
+    assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+    compare_problems(prob, q, tol=1e-9, what=('J', 'I', 'Gamma', 'R'))
+    compare_problems(prob, q, tol=1e-7, what=('n',))
+
+
+def test_more_than_eight_overlapping_lines_is_refused(gpu):
+    from lightweaver_amd.context import LwHipError
+    from test_fs2d import blended_atoms
+    prob = models.build_problem(models.falc82(), blended_atoms(5, 0.3), Nrays=3)
+    with pytest.raises(LwHipError, match='overlap'):
+        Context(prob)
