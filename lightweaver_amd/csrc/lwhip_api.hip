@@ -1072,15 +1072,16 @@ int alloc_state(lwhip_context* c)
                 c->maxRowsLa = std::max(c->maxRowsLa, c->hdrHost[la].nRows + c->hdrHost[la].nMixed + c->hdrHost[la].nPure);
         if ((size_t)c->maxRowsLa * 128 * sizeof(double) > 64 * 1024)
             return fail(LWHIP_ERR_UNSUPPORTED, "2D: more continuum rows at one wavelength than the rate kernel's LDS block holds");
-        // continuum rows of one batch
+        // continuum rows of one batch: the most any window of batch2d consecutive wavelengths holds (the PRD
+        // rates pass starts its batches at the PRD lines, not at multiples of batch2d)
         int64_t maxRows = 1;
-        for (size_t la0 = 0; la0 < Nla; la0 += c->batch2d)
         {
-            int64_t rows = 0;
-            for (size_t la = la0; la < std::min(Nla, la0 + c->batch2d); ++la)
-                if (c->hdrHost[la].rowBase >= 0)
-                    rows += c->hdrHost[la].nRows + c->hdrHost[la].nMixed + c->hdrHost[la].nPure;
-            maxRows = std::max(maxRows, rows);
+            std::vector<int64_t> pre(Nla + 1, 0);
+            for (size_t la = 0; la < Nla; ++la)
+                pre[la + 1] = pre[la] + (c->hdrHost[la].rowBase >= 0 ? c->hdrHost[la].nRows + c->hdrHost[la].nMixed + c->hdrHost[la].nPure
+                                                                     : 0);
+            for (size_t la = 0; la < Nla; ++la)
+                maxRows = std::max(maxRows, pre[std::min(Nla, la + (size_t)c->batch2d)] - pre[la]);
         }
         HIP_TRY(c->rowsBuf.alloc((size_t)maxRows * Ns));
     }
@@ -1606,7 +1607,8 @@ int lwhip_gamma_prefill_from_C(lwhip_context* c, double crsw)
 
 // The 2D iteration of this context's wavelengths: batches of wavelengths through cont -> gather -> 2D formal
 // solver -> rates (lwhip_2d.hip), the running sums in the reduce buffer, dJ in its tail.
-// mode 0: the iteration (J, Gamma, rates); 1: formal_sol, all rays; 2: formal_sol, up-going rays only
+// mode 0: the iteration (J, Gamma, rates); 1: formal_sol, all rays; 2: formal_sol, up-going rays only;
+// 3: formal_sol_prd_update_rates (PrdTemplates.hpp:18-75) -- only the wavelengths that hold a PRD line, no depth data
 static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
 {
     const lwhip_grid2d& g = *c->prob.grid2d;
@@ -1614,10 +1616,11 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     const int nRaysActive = (mode == 2) ? c->Nrays : 2 * c->Nrays;
     const int32_t* rayList = (mode == 2) ? c->rayUp.p : c->rayAll.p;
     const size_t nRed = (size_t)c->Ntrans * 4 * Ns;
-    if (mode == 0)
+    const bool rates = (mode == 0 || mode == 3);
+    if (rates)
     {
         HIP_TRY(hipMemsetAsync(c->red2d.p, 0, (size_t)c->groups2d * nRed * sizeof(double), c->stream));
-        HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
+        HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream)); // unvisited wavelengths: dJ = 0
     }
     Batch2dArgs a{};
     a.Ns = (int32_t)Ns;
@@ -1625,7 +1628,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     a.Nrays = c->Nrays;
     a.nRaysActive = nRaysActive;
     a.lambdaIterate = lambdaIterate;
-    a.storeDepth = c->prob.storeDepthData ? 1 : 0;
+    a.storeDepth = (c->prob.storeDepthData && mode != 3) ? 1 : 0;
     a.NlevTot = c->NlevTot;
     a.Natom = c->Natom;
     a.rayList = rayList;
@@ -1676,9 +1679,20 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     f.PsiStar = c->b2Psi.p;
     f.coef = c->b2coef.p;
     f.cidx = c->b2idx.p;
-    for (int la0 = 0; la0 < c->Nla; la0 += c->batch2d)
+    for (int la0 = 0; la0 < c->Nla;)
     {
-        const int nLa = std::min(c->batch2d, c->Nla - la0);
+        int nLa = std::min(c->batch2d, c->Nla - la0);
+        if (mode == 3)
+        {
+            // the next run of wavelengths with a PRD line, at most one batch long
+            while (la0 < c->Nla && !c->hdrHost[la0].hasPrd)
+                ++la0;
+            if (la0 >= c->Nla)
+                break;
+            nLa = 0;
+            while (la0 + nLa < c->Nla && nLa < c->batch2d && c->hdrHost[la0 + nLa].hasPrd)
+                ++nLa;
+        }
         // continuum rows of the batch: a window of the global row numbering
         const auto lo = std::lower_bound(c->contLaHost.begin(), c->contLaHost.begin() + c->nContLa, la0);
         const auto hi = std::lower_bound(c->contLaHost.begin(), c->contLaHost.begin() + c->nContLa, la0 + nLa);
@@ -1695,12 +1709,13 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
         f.wavs = c->wavelength.p + la0;
         f.nSolve = nLa * nRaysActive;
         HIP_TRY(launch_fs2d(f, nLa * nRaysActive, c->stream));
-        if (mode == 0)
+        if (rates)
             HIP_TRY(launch_rates2d(a, c->maxL, c->stream));
         else
             HIP_TRY(launch_iout2d(a, c->stream));
+        la0 += nLa;
     }
-    if (mode != 0)
+    if (!rates)
         return LWHIP_OK;
     // the groups' sums, in a fixed order, into the reduce buffer
     HIP_TRY(launch_sum_groups(c->red2d.p, nRed, nRed, c->groups2d, c->stream));
@@ -2466,8 +2481,6 @@ int lwhip_prd_pack(lwhip_context* c, void** devPtr, size_t* count)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
-    if (c->is2d)
-        return fail(LWHIP_ERR_UNSUPPORTED, "PRD sub-iterations are not available for 2D problems yet");
     if (c->partialPending || c->prdPending)
         return fail(LWHIP_ERR_INVALID, "lwhip_prd_pack inside an unfinished iteration / sub-iteration");
     HIP_TRY(hipSetDevice(c->device));
@@ -2601,6 +2614,15 @@ int lwhip_prd_partial(lwhip_context* c)
         a.q = q;
         a.Nprd = Nprd;
         HIP_TRY(launch_prd_scatter(a, c->stream));
+    }
+    if (c->is2d)
+    {
+        // the same rates pass through the 2D pipeline, restricted to the runs of PRD wavelengths
+        const int st2 = run_2d(c, 0, 3);
+        if (st2 != LWHIP_OK)
+            return st2;
+        c->prdPending = true;
+        return LWHIP_OK;
     }
     // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
     SweepDyn dyn = make_dyn(c, false, 0);

@@ -340,3 +340,63 @@ def test_hip_2d_overlapping_lines(gpu):
             assert orc.stat_equil() == 0
     for a, b in zip(prob.atoms, q.atoms):
         assert rel_err(a.n, b.n) <= 1e-8
+
+
+# ---- PRD sub-iterations on 2D problems ------------------------------------------------------------------------------
+def prd_problem_2d():
+    from lightweaver_amd.harness import models
+    base = models.falc82()
+    cols = [models.perturbed(base, seed=400 + j) for j in range(5)]
+    return models.build_problem_2d(cols, np.linspace(0.0, 4 * 40e3, 5), [models.H_6(0.2), models.CaII_6(0.2, prd=True)])
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+def test_oracle_2d_prd_matches_reference():
+    """redistribute_prd on a 2D problem (scattering integral per point, the PRD rates pass through the 2D formal
+    solver): the oracle against the core, bit for bit, two iterations with three sub-iterations each."""
+    prob = prd_problem_2d()
+    p, q = prob.copy(), prob.copy()
+    oc, rc = bindings.OracleContext(p), bindings.RefContext(q)
+    for it in range(2):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        assert oc.formal_sol_gamma_matrices() == rc.formal_sol_gamma_matrices()
+        assert oc.stat_equil() == rc.stat_equil() == 0
+        ra, rb = oc.redistribute_prd(3, 1e-2), rc.redistribute_prd(3, 1e-2)
+        assert np.array_equal(ra['dRho'], rb['dRho']) and np.array_equal(ra['dRhoMaxIdx'], rb['dRhoMaxIdx'])
+        assert np.array_equal(ra['dJPrdMax'], rb['dJPrdMax'])
+    assert np.array_equal(p.J, q.J)
+    for a, b in zip(p.atoms, q.atoms):
+        assert np.array_equal(a.n, b.n)
+        for t, u in zip(a.trans, b.trans):
+            if t.rhoPrd is not None:
+                assert np.array_equal(t.rhoPrd, u.rhoPrd)
+            assert np.array_equal(t.Rij, u.Rij) and np.array_equal(t.Rji, u.Rji)
+
+
+@pytest.mark.gpu
+def test_hip_2d_prd_matches_oracle(gpu):
+    """lwhip_redistribute_prd on a 2D problem: rho, J, the PRD lines' rates and the reported changes."""
+    from lightweaver_amd.context import Context
+    prob = prd_problem_2d()
+    q = prob.copy()
+    orc = bindings.OracleContext(q)
+    with Context(prob) as ctx:
+        for it in range(2):
+            ctx.formal_sol_gamma_matrices()
+            ctx.stat_equil()
+            q.gamma_prefill()
+            orc.formal_sol_gamma_matrices()
+            assert orc.stat_equil() == 0
+            up = ctx.prd_redistribute(3, 1e-2)
+            ro = orc.redistribute_prd(3, 1e-2)
+            assert up.NprdSubIter == ro['NprdSubIter']
+            assert rel_err(up.dRho, ro['dRho']) <= 1e-5          # see tests/test_prd.py on dRho's conditioning
+            assert rel_err(up.dJPrdMax, ro['dJPrdMax']) <= 1e-7
+            tol = 1e-8 * (it + 1)
+            assert rel_err(prob.J, q.J) <= tol
+            for a, b in zip(prob.atoms, q.atoms):
+                for t, u in zip(a.trans, b.trans):
+                    if t.rhoPrd is not None:
+                        assert rel_err(t.rhoPrd, u.rhoPrd) <= tol
+                    assert rel_err(t.Rij, u.Rij) <= tol and rel_err(t.Rji, u.Rji) <= tol

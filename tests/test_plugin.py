@@ -200,3 +200,29 @@ def test_dropin_2d_matches_scalar_scheme(gpu):
         assert hipc.stat_equil() == ref.stat_equil() == 0
         for x, y in zip(p.atoms, q.atoms):
             assert rel_err(x.n, y.n) <= 1e-7
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_2d_prd_and_formal_sol(gpu):
+    """The remaining plugin members on an Ndim = 2 Context of the real core: redistribute_prd (Ca II H & K as PRD
+    lines) and simple_fs, next to the core's scalar scheme."""
+    from test_fs2d import prd_problem_2d
+    from test_prd import assert_same_state
+    prob = prd_problem_2d()
+    p, q = prob.copy(), prob.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(2):
+        for pr, c in ((p, hipc), (q, ref)):
+            pr.gamma_prefill()
+            c.formal_sol_gamma_matrices()
+            assert c.stat_equil() == 0
+        u1, u2 = hipc.redistribute_prd(3, 1e-2), ref.redistribute_prd(3, 1e-2)
+        assert u1['NprdSubIter'] == u2['NprdSubIter'] and u1['Nprd'] == u2['Nprd'] == 2
+        assert np.allclose(u1['dRho'], u2['dRho'], rtol=1e-5)
+        assert np.allclose(u1['dJPrdMax'], u2['dJPrdMax'], rtol=1e-7)
+    assert_same_state(p, q, 1e-8)
+    for upOnly in (True, False):
+        hipc.formal_sol(upOnly=upOnly)
+        ref.formal_sol(upOnly=upOnly)
+        assert rel_err(p.I, q.I) <= TOL_ONE_CALL * 10
