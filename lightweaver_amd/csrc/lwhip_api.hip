@@ -121,6 +121,7 @@ struct lwhip_context
     DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
     DevBuf<int32_t> b2idx;
     int groups2d = 1, maxRowsLa = 1;
+    bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
     int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
@@ -363,7 +364,6 @@ int validate(const lwhip_problem* p, std::string& why)
 
 int build_tables(lwhip_context* c)
 {
-    const lwhip_problem& p = c->prob;
     const int Ns = c->Ns;
     // ---- global transition list, level rows, pools ------------------------------------------
     c->levelOff.assign(c->Natom + 1, 0);
@@ -1777,7 +1777,7 @@ static ApplyArgs make_apply_args(lwhip_context* c)
     return a;
 }
 
-int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
+static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
@@ -1811,13 +1811,22 @@ int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
         // fixed-order slab sums; the extra block of stage 2 writes this shard's (dJMax, global idx)
         // into its slot of the gather tail and zeros the other slots
         const ReduceArgs r = make_reduce_args(c);
-        HIP_TRY(launch_reduce(r, c->stream));
+        if (partsOnly) // single-device call: stage 2 and the dJMax reduction are folded into the apply launch
+            HIP_TRY(launch_reduce_parts(r, c->stream));
+        else
+            HIP_TRY(launch_reduce(r, c->stream));
     }
+    c->partsOnly = partsOnly;
     if (c->worldSize > 1 && !c->prdLines.empty()) // the PRD slots of the tail ride in the same all-reduce: keep them finite
         HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
                                2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
     c->partialPending = true;
     return LWHIP_OK;
+}
+
+int lwhip_fs_partial(lwhip_context* c, int lambdaIterate)
+{
+    return fs_partial_impl(c, lambdaIterate, false);
 }
 
 int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
@@ -1829,9 +1838,19 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
     HIP_TRY(hipSetDevice(c->device));
     if (c->Natom > 0)
     {
-        const ApplyArgs a = make_apply_args(c);
+        ApplyArgs a = make_apply_args(c);
+        if (c->partsOnly)
+        {
+            a.fromParts = 1;
+            a.red8 = c->red8.p;
+            a.dJ = c->dJ.p;
+            a.NlaDj = c->Nla;
+            a.idxOffset = c->laStart;
+            a.tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
+        }
         HIP_TRY(launch_apply(a, c->stream));
         c->prefillPending = false;
+        c->partsOnly = false;
     }
     c->partialPending = false;
     if (res)
@@ -1865,7 +1884,9 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
 
 int lwhip_formal_sol_gamma_matrices(lwhip_context* c, int lambdaIterate, lwhip_iter_result* res)
 {
-    int st = lwhip_fs_partial(c, lambdaIterate);
+    // the one-call form knows that nobody reads the reduce buffer between its two halves
+    const bool partsOnly = c && !c->is2d && c->worldSize == 1 && c->Natom > 0 && c->Ntrans > 0;
+    int st = fs_partial_impl(c, lambdaIterate, partsOnly);
     if (st != LWHIP_OK)
         return st;
     return lwhip_fs_finalise(c, res);

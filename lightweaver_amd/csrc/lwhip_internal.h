@@ -190,6 +190,12 @@ struct ApplyArgs
     double crsw;
     int32_t prefill;               // Gamma <- crsw * C before adding the radiative terms
     int32_t prdOnly;               // only Rij/Rji of PRD lines are written, Gamma untouched
+    // single-device iteration without the second reduce stage: the sums are taken from the stage-1 parts (added in
+    // the same order) and one extra workgroup does the dJMax reduction
+    const double* red8;            // [Ntrans, SPLIT, 4, Ns] or null
+    const double* dJ;              // [NlaDj] per-wavelength dJ, or null (no dJMax workgroup)
+    double* tail;                  // (dJMax, idx) slot
+    int32_t fromParts, NlaDj, idxOffset, _padA;
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)
@@ -395,6 +401,7 @@ hipError_t launch_march(const SweepArgs* devArgs, const SweepArgs& hostArgs, con
 size_t march_lds_bytes(const SweepArgs& a, int wavesPerGroup);
 // list / nBatch: column batches -- a device array of per-column argument blocks, one grid slice per column
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list = nullptr, int nBatch = 0);
+hipError_t launch_reduce_parts(const ReduceArgs& a, hipStream_t stream); // stage 1 only (see ApplyArgs::fromParts)
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
 }

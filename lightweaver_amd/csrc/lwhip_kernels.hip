@@ -1160,8 +1160,8 @@ __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* 
 {
     // dJMax and the index of its first occurrence (max_idx, Constants.hpp:114-125) into this
     // shard's slot of the gather tail; every other slot is zeroed (the all-reduce sums them)
-    __shared__ double sV[512];
-    __shared__ int sI[512];
+    __shared__ double sV[1024];
+    __shared__ int sI[1024];
     double best = -1.0;
     int bi = 0;
     for (int la = threadIdx.x; la < laEnd; la += blockDim.x)
@@ -1235,6 +1235,13 @@ __global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a0,
         reduce_stage2_kernel_body(a0);
 }
 
+hipError_t launch_reduce_parts(const ReduceArgs& a, hipStream_t stream)
+{
+    if (a.Ntrans > 0)
+        hipLaunchKernelGGL(reduce_stage1_kernel<false>, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT), dim3(384), 0, stream, a, nullptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list, int nBatch)
 {
     const int nz = std::max(nBatch, 1);
@@ -1260,6 +1267,22 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
 {
     const int Ns = a.Ns;
     const int k0 = blockIdx.y * APPLY_K;
+    if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ is set)
+    {
+        if (blockIdx.y == 0)
+            djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0);
+        return;
+    }
+    // the reduced sum of transition tr, component q at depth k: from the reduce buffer, or from the stage-1 parts
+    auto redAt = [&](int tr, int q, int k) -> double {
+        if (!a.fromParts)
+            return a.red[((size_t)tr * 4 + q) * Ns + k];
+        double s = 0.0;
+#pragma unroll
+        for (int part = 0; part < LWHIP_REDUCE_SPLIT; ++part)
+            s += a.red8[(((size_t)tr * LWHIP_REDUCE_SPLIT + part) * 4 + q) * Ns + k];
+        return s;
+    };
     if ((int)blockIdx.x == a.Natom) // rates out
     {
         const int Ntr = a.atomTrOff[a.Natom];
@@ -1269,11 +1292,10 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
             const int k = k0 + (idx - tr * APPLY_K);
             if (k < Ns)
             {
-                const double* r = a.red + (size_t)tr * 4 * Ns;
                 if (a.prdOnly && !(a.trans[tr].prd && a.trans[tr].op && a.trans[tr].rhoOff >= 0))
                     continue;
-                a.Rij[(size_t)tr * Ns + k] = r[2 * Ns + k];
-                a.Rji[(size_t)tr * Ns + k] = r[3 * Ns + k];
+                a.Rij[(size_t)tr * Ns + k] = redAt(tr, 2, k);
+                a.Rji[(size_t)tr * Ns + k] = redAt(tr, 3, k);
             }
         }
         return;
@@ -1298,9 +1320,9 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
         {
             const int i = a.transLi[tr], j = a.transLj[tr];
             if (to == i && from == j)
-                v += a.red[((size_t)tr * 4 + 0) * Ns + k];
+                v += redAt(tr, 0, k);
             if (to == j && from == i)
-                v += a.red[((size_t)tr * 4 + 1) * Ns + k];
+                v += redAt(tr, 1, k);
         }
         G[(size_t)e * Ns + k] = v;
     }
@@ -1335,7 +1357,8 @@ hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs*
         hipLaunchKernelGGL(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(1024), 0,
                            stream, a, list);
     else
-        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0, stream, a, list);
+        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1 + (a.dJ ? 1 : 0), (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0,
+                           stream, a, list);
     return hipGetLastError();
 }
 

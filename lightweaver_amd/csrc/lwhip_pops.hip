@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256) ng_kernel(const NgArgs a)
     sV[threadIdx.x] = best;
     sI[threadIdx.x] = bestIdx;
     __syncthreads();
-    for (int s2 = blockDim.x / 2; s2 > 0; s2 >>= 1)
+    for (unsigned s2 = blockDim.x / 2; s2 > 0; s2 >>= 1)
     {
         if (threadIdx.x < s2)
         {

@@ -75,6 +75,12 @@ class ShardedIteration:
 
     def formal_sol_gamma_matrices(self, lambdaIterate=False, deviceResident=True, crsw=1.0):
         ctx = self.ctx
+        if self.world == 1 and not self.force_collective and hasattr(ctx, 'formal_sol_gamma_matrices') \
+                and hasattr(ctx, 'lib'):
+            # no collective to interleave: the library's one-call form (which also folds the second reduce stage
+            # and the dJMax reduction into the apply launch)
+            ctx.crsw = crsw
+            return ctx.formal_sol_gamma_matrices(lambdaIterate=lambdaIterate, deviceResident=deviceResident)
         if deviceResident:
             ctx.gamma_prefill_from_C(crsw)
         else:
