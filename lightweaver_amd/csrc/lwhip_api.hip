@@ -121,6 +121,8 @@ struct lwhip_context
     DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
     DevBuf<int32_t> b2idx;
     int groups2d = 1, maxRowsLa = 1;
+    double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration
+    double* tailMappedDev = nullptr;
     bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
     int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
@@ -189,6 +191,8 @@ struct lwhip_context
             (void)hipStreamDestroy(ownStream);
         if (gatherPinned)
             (void)hipHostFree(gatherPinned);
+        if (tailMapped)
+            (void)hipHostFree(tailMapped);
         if (stage)
             (void)hipHostFree(stage);
         if (statusHost)
@@ -1836,6 +1840,7 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
     if (!c->partialPending)
         return fail(LWHIP_ERR_INVALID, "lwhip_fs_finalise without lwhip_fs_partial");
     HIP_TRY(hipSetDevice(c->device));
+    bool mapped = false; // (dJMax, idx) arrives through host-mapped memory: no read-back copy
     if (c->Natom > 0)
     {
         ApplyArgs a = make_apply_args(c);
@@ -1847,12 +1852,27 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
             a.NlaDj = c->Nla;
             a.idxOffset = c->laStart;
             a.tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
+            if (!c->tailMapped)
+            {
+                HIP_TRY(hipHostMalloc((void**)&c->tailMapped, 2 * sizeof(double), hipHostMallocMapped));
+                HIP_TRY(hipHostGetDevicePointer((void**)&c->tailMappedDev, c->tailMapped, 0));
+            }
+            a.tailHost = c->tailMappedDev;
+            mapped = res != nullptr;
         }
         HIP_TRY(launch_apply(a, c->stream));
         c->prefillPending = false;
         c->partsOnly = false;
     }
     c->partialPending = false;
+    if (res && mapped)
+    {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        res->updatedJ = 1;
+        res->dJMax = c->tailMapped[0];
+        res->dJMaxIdx = (int32_t)c->tailMapped[1];
+        return LWHIP_OK;
+    }
     if (res)
     {
         const double* tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;

@@ -195,6 +195,7 @@ struct ApplyArgs
     const double* red8;            // [Ntrans, SPLIT, 4, Ns] or null
     const double* dJ;              // [NlaDj] per-wavelength dJ, or null (no dJMax workgroup)
     double* tail;                  // (dJMax, idx) slot
+    double* tailHost;              // host-mapped mirror of that slot (read after the stream synchronisation), or null
     int32_t fromParts, NlaDj, idxOffset, _padA;
 };
 

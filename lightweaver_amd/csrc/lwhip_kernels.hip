@@ -1156,7 +1156,8 @@ __global__ void reduce_stage1_kernel(const ReduceArgs a0, const ReduceArgs* __re
         reduce_stage1_kernel_body(a0);
 }
 
-__device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* tail, int world, int rank)
+__device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* tail, int world, int rank,
+                            double* mirror = nullptr /* host-mapped copy of the tail: no read-back copy needed */)
 {
     // dJMax and the index of its first occurrence (max_idx, Constants.hpp:114-125) into this
     // shard's slot of the gather tail; every other slot is zeroed (the all-reduce sums them)
@@ -1198,6 +1199,8 @@ __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* 
         else if (q == 2 * rank + 1)
             v = (double)(sI[0] + idxOffset);
         tail[q] = v;
+        if (mirror)
+            mirror[q] = v;
     }
 }
 
@@ -1270,7 +1273,7 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
     if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ is set)
     {
         if (blockIdx.y == 0)
-            djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0);
+            djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0, a.tailHost);
         return;
     }
     // the reduced sum of transition tr, component q at depth k: from the reduce buffer, or from the stage-1 parts
