@@ -341,3 +341,26 @@ def test_more_than_eight_overlapping_lines_is_refused(gpu):
     prob = models.build_problem(models.falc82(), blended_atoms(5, 0.3), Nrays=3)
     with pytest.raises(LwHipError, match='overlap'):
         Context(prob)
+
+
+def test_detailed_static_atom_only(gpu):
+    """No active atom at all: the only atom is detailed-static (its lines shape chi / eta, no Gamma, no rates are
+    accumulated for it); J and I against the oracle, one-call and split forms of the iteration."""
+    prob = models.build_problem(models.falc82(), [models.H_6(0.2)], Nrays=2)
+    for a in prob.atoms:
+        a.detailed = True
+    q = prob.copy()
+    q.gamma_prefill()
+    dJ, _ = OracleContext(q).formal_sol_gamma_matrices()
+    p1, p2 = prob.copy(), prob.copy()
+    with Context(p1) as ctx:
+        up = ctx.formal_sol_gamma_matrices()
+    with Context(p2) as ctx:
+        p2.gamma_prefill()
+        ctx.upload(abi.GAMMA | abi.J | abi.POPS)
+        ctx.fs_partial()
+        up2 = ctx.fs_finalise()
+        ctx.download(abi.ALL_OUTPUTS)
+    for p, u in ((p1, up), (p2, up2)):
+        assert u.dJMax == pytest.approx(dJ, rel=1e-9)
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL and rel_err(p.I, q.I) <= TOL_ONE_CALL
