@@ -7,8 +7,9 @@ import csv,glob
 f=glob.glob("$R/gpurun_out/tl/*/*kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# last 12 kernel records
-sel=rows[-14:]
+# the last iterations' kernels (the population solves of the aux section come after them)
+rows=[r for r in rows if any(k in r['Kernel_Name'] for k in ('sweep_kernel','reduce_stage','apply_kernel'))]
+sel=rows[-12:]
 t0=int(sel[0]['Start_Timestamp'])
 prev_end=None
 for r in sel:
