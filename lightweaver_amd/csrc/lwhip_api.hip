@@ -158,6 +158,9 @@ struct lwhip_context
     DevBuf<SweepArgs> dargs, dargsPrd;
     SweepArgs hargs{}, hargsPrd{};
     DevBuf<int32_t> chunkLaPrd, trOffPrd, trRowPrd, laListPrd;
+    DevBuf<int32_t> slotTrRows;   // [nChunks*maxCT] transition of every slab row (atomic output of the one-call iteration)
+    bool atomicParts = false;     // the pending iteration's parts were accumulated by atomics
+    bool red8Clean = false;       // red8 holds zeros (only the atomic path leaves it so)
     DevBuf<int32_t> chunkLa, trOff, trRow, atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
     DevBuf<int64_t> atomGammaOff;
     DevBuf<double> partial, red, red8, dJ;
@@ -945,6 +948,13 @@ int build_tables(lwhip_context* c)
     HIP_TRY(c->contLa.upload(contLaHost));
     HIP_TRY(c->trOff.upload(trOff));
     HIP_TRY(c->trRow.upload(trRow));
+    {
+        std::vector<int32_t> rowTr((size_t)std::max(c->nChunks, 1) * c->maxCT, -1);
+        for (int tr = 0; tr < c->Ntrans; ++tr)
+            for (int e = trOff[tr]; e < trOff[tr + 1]; ++e)
+                rowTr[trRow[e]] = tr;
+        HIP_TRY(c->slotTrRows.upload(rowTr));
+    }
     HIP_TRY(c->rayAll.upload(rayAll));
     HIP_TRY(c->rayUp.upload(rayUp));
     HIP_TRY(c->transLi.upload(li));
@@ -1155,6 +1165,8 @@ int build_sweep_args(lwhip_context* c)
     a.progEnts = c->progEnts.p;
     a.chunkLa = c->chunkLa.p;
     a.partial = c->partial.p;
+    a.red8 = c->red8.p;
+    a.slotTr = c->slotTrRows.p;
     a.dJ = c->dJ.p;
     a.stamps = c->stamps.p;
     a.bigScratch = c->bigScratch.p;
@@ -1797,7 +1809,17 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
         c->partialPending = true;
         return LWHIP_OK;
     }
-    const SweepDyn dyn = make_dyn(c, false, lambdaIterate);
+    SweepDyn dyn = make_dyn(c, false, lambdaIterate);
+    // one-call iteration on the default sweep: the chunks add their accumulators straight into the stage-1 buffer
+    // (atomics), which the apply launch sums and zeroes -- no slab, no reduce launch
+    const bool atomicOut = partsOnly && !c->march && !c->big && env_int("LWHIP_ATOMIC_OUT", 1) != 0;
+    if (atomicOut)
+    {
+        if (!c->red8Clean)
+            HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));
+        c->red8Clean = true;
+        dyn.atomicOut = 1;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling)
     {
@@ -1815,12 +1837,17 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
         // fixed-order slab sums; the extra block of stage 2 writes this shard's (dJMax, global idx)
         // into its slot of the gather tail and zeros the other slots
         const ReduceArgs r = make_reduce_args(c);
-        if (partsOnly) // single-device call: stage 2 and the dJMax reduction are folded into the apply launch
+        if (atomicOut)
+            ; // nothing to reduce
+        else if (partsOnly) // single-device call: stage 2 and the dJMax reduction are folded into the apply launch
             HIP_TRY(launch_reduce_parts(r, c->stream));
         else
             HIP_TRY(launch_reduce(r, c->stream));
+        if (!atomicOut)
+            c->red8Clean = false;
     }
     c->partsOnly = partsOnly;
+    c->atomicParts = atomicOut;
     if (c->worldSize > 1 && !c->prdLines.empty()) // the PRD slots of the tail ride in the same all-reduce: keep them finite
         HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
                                2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
@@ -1847,6 +1874,7 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
         if (c->partsOnly)
         {
             a.fromParts = 1;
+            a.zeroParts = c->atomicParts ? 1 : 0;
             a.red8 = c->red8.p;
             a.dJ = c->dJ.p;
             a.NlaDj = c->Nla;
@@ -2079,6 +2107,8 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
     HIP_TRY(launch_sweep(c0->dargs.p, c0->hargs, dyn, c0->prob.formalSolver, c0->maxL, true, c0->nChunks, c0->stream,
                          b->apList.p, n));
     HIP_TRY(launch_reduce(make_reduce_args(c0), c0->stream, b->rList.p, n));
+    for (lwhip_context* c : b->ctxs)
+        c->red8Clean = false;
     if (c0->Natom > 0)
         HIP_TRY(launch_apply(b->aHost[0], c0->stream, b->aList.p, n));
     if (results)
@@ -2688,6 +2718,7 @@ int lwhip_prd_partial(lwhip_context* c)
     r.world = c->worldSize;
     r.rank = c->worldRank;
     HIP_TRY(launch_reduce(r, c->stream));
+    c->red8Clean = false;
     c->prdPending = true;
     return LWHIP_OK;
 }

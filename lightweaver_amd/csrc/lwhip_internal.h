@@ -135,6 +135,8 @@ struct SweepArgs
     const int32_t* chunkLa;        // [nChunks+1] wavelength boundaries (or boundaries in laList)
     const int32_t* laList;         // null, or the wavelengths this launch visits (PRD rates pass)
     double* partial;               // [nChunks*maxCT, 4, Ns]
+    double* red8;                  // [Ntrans, SPLIT, 4, Ns]: target of the chunks' atomic adds (SweepDyn::atomicOut)
+    const int32_t* slotTr;         // [nChunks*maxCT] transition of every slab row, -1: unused
     double* dJ;                    // [Nla]
     long long* stamps;             // [nChunks, 12] diagnostic build only (-DLWHIP_STAMPS)
     double* bigScratch;            // [nChunks, sweep_big_scratch_doubles] (big mode only)
@@ -156,6 +158,8 @@ struct SweepDyn
     int32_t prdOnly;       // PRD rates pass: only wavelengths with a PRD line, J + Rij/Rji of PRD lines
     const int32_t* rayList;        // [nRaysActive] -> r = 2*mu + toObs
     int32_t S, R;          // march kernel: depth segments per ray, rays per pass (R * S <= 64)
+    int32_t atomicOut;     // the chunk adds its accumulators straight into red8[part = chunk % SPLIT] (no slab, no stage 1)
+    int32_t _padD;
 };
 
 enum { LWHIP_REDUCE_SPLIT = 8 };
@@ -196,7 +200,8 @@ struct ApplyArgs
     const double* dJ;              // [NlaDj] per-wavelength dJ, or null (no dJMax workgroup)
     double* tail;                  // (dJMax, idx) slot
     double* tailHost;              // host-mapped mirror of that slot (read after the stream synchronisation), or null
-    int32_t fromParts, NlaDj, idxOffset, _padA;
+    int32_t fromParts, NlaDj, idxOffset;
+    int32_t zeroParts;             // the parts are accumulated by atomics: whoever reads an element zeroes it
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)

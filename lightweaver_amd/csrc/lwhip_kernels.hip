@@ -78,7 +78,7 @@ template <bool BIG> DEVINL void wg_barrier()
 // The body is a function so that the single-problem kernel and the column-batch kernel share it; `ap` stays a
 // __restrict__ *parameter* in both (the no-alias guarantee is what lets the compiler keep argument-block fields
 // across the kernel's stores: a pointer merely loaded from a table costs 40 % of the sweep, measured).
-template <int SOLVER, int MAXL, bool RATES, bool BIG>
+template <int SOLVER, int MAXL, bool RATES, bool BIG, bool ATOMIC = false>
 DEVINL void sweep_body(const SweepArgs* __restrict__ ap, const SweepDyn& dyn)
 {
     extern __shared__ double lds[];
@@ -1033,9 +1033,27 @@ DEVINL void sweep_body(const SweepArgs* __restrict__ ap, const SweepDyn& dyn)
 
     if (RATES && !BIG)
     {
-        GLOBAL_AS double* out = gPartial + (size_t)chunk * maxCT * 4 * Ns;
-        for (int idx = t; idx < maxCT * 4 * Ns; idx += T)
-            out[idx] = sAcc[idx];
+        if (ATOMIC)
+        {
+            // straight into the stage-1 buffer: part = chunk % SPLIT keeps 1/SPLIT of the chunks on one address
+            const CONST_AS int32_t* slotTr = CTAB(int32_t, a.slotTr) + (size_t)chunk * maxCT;
+            GLOBAL_AS double* r8 = GD(a.red8);
+            const int n4 = 4 * Ns;
+            const int part = chunk % LWHIP_REDUCE_SPLIT;
+            for (int idx = t; idx < maxCT * n4; idx += T)
+            {
+                const int cs = divNs(idx) >> 2;           // idx / (4 Ns)
+                const int tr = slotTr[cs];
+                if (tr >= 0)
+                    unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + (idx - cs * n4)), sAcc[idx]);
+            }
+        }
+        else
+        {
+            GLOBAL_AS double* out = gPartial + (size_t)chunk * maxCT * 4 * Ns;
+            for (int idx = t; idx < maxCT * 4 * Ns; idx += T)
+                out[idx] = sAcc[idx];
+        }
     }
 #ifdef LWHIP_STAMPS
     STAMP(10);
@@ -1053,6 +1071,14 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepArgs* __restrict
     sweep_body<SOLVER, MAXL, RATES, BIG>(ap, dyn);
 }
 
+// the one-call iteration's instantiation: accumulators leave by atomic adds into the stage-1 buffer (a compile-time
+// choice: as a run-time branch it cost every instantiation 3.5 us of register pressure)
+template <int SOLVER, int MAXL>
+__global__ void __launch_bounds__(1024) sweep_atomic_kernel(const SweepArgs* __restrict__ ap, const SweepDyn dyn)
+{
+    sweep_body<SOLVER, MAXL, true, false, true>(ap, dyn);
+}
+
 // column batches (1.5D): blockIdx.y picks the column's argument block; every column has the same structure
 template <int SOLVER, int MAXL, bool RATES, bool BIG>
 __global__ void __launch_bounds__(1024) sweep_batch_kernel(const SweepArgs* const* __restrict__ apList, const SweepDyn dyn)
@@ -1065,13 +1091,22 @@ static hipError_t launch_sweep_t(const SweepArgs* devArgs, const SweepArgs& a, c
                                  int nChunks, hipStream_t stream, const SweepArgs* const* apList, int nBatch)
 {
     const size_t lds = sweep_lds_bytes(a, dyn.G);
-    static size_t configured = 0, configuredBatch = 0;
-    size_t& conf = apList ? configuredBatch : configured;
+    static size_t configured = 0, configuredBatch = 0, configuredAtomic = 0;
+    const void* fn = apList ? (const void*)sweep_batch_kernel<SOLVER, MAXL, RATES, BIG>
+                            : (const void*)sweep_kernel<SOLVER, MAXL, RATES, BIG>;
+    bool atomic = false;
+    if constexpr (RATES && !BIG)
+        if (dyn.atomicOut && !apList)
+        {
+            atomic = true;
+            fn = (const void*)sweep_atomic_kernel<SOLVER, MAXL>;
+        }
+    if (dyn.atomicOut && !atomic)
+        return hipErrorInvalidValue; // the caller asked for an instantiation that does not exist
+    size_t& conf = atomic ? configuredAtomic : (apList ? configuredBatch : configured);
     if (lds > conf)
     {
-        hipError_t err = hipFuncSetAttribute(apList ? (const void*)sweep_batch_kernel<SOLVER, MAXL, RATES, BIG>
-                                                    : (const void*)sweep_kernel<SOLVER, MAXL, RATES, BIG>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess)
             return err;
         conf = lds;
@@ -1080,6 +1115,12 @@ static hipError_t launch_sweep_t(const SweepArgs* devArgs, const SweepArgs& a, c
     int T = ((std::max(dyn.G * a.Ns, 64) + 63) / 64) * 64;
     if (T > 1024)
         return hipErrorInvalidConfiguration;
+    if constexpr (RATES && !BIG)
+        if (atomic)
+        {
+            hipLaunchKernelGGL((sweep_atomic_kernel<SOLVER, MAXL>), dim3(nChunks), dim3(T), lds, stream, devArgs, dyn);
+            return hipGetLastError();
+        }
     if (apList)
         hipLaunchKernelGGL((sweep_batch_kernel<SOLVER, MAXL, RATES, BIG>), dim3(nChunks, std::max(nBatch, 1)), dim3(T), lds,
                            stream, apList, dyn);
@@ -1281,9 +1322,15 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
         if (!a.fromParts)
             return a.red[((size_t)tr * 4 + q) * Ns + k];
         double s = 0.0;
+        double* r8 = const_cast<double*>(a.red8);
 #pragma unroll
         for (int part = 0; part < LWHIP_REDUCE_SPLIT; ++part)
-            s += a.red8[(((size_t)tr * LWHIP_REDUCE_SPLIT + part) * 4 + q) * Ns + k];
+        {
+            const size_t o = (((size_t)tr * LWHIP_REDUCE_SPLIT + part) * 4 + q) * Ns + k;
+            s += r8[o];
+            if (a.zeroParts)
+                r8[o] = 0.0; // every element has exactly one reader: ready for the next iteration's atomic adds
+        }
         return s;
     };
     if ((int)blockIdx.x == a.Natom) // rates out
@@ -1299,6 +1346,11 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
                     continue;
                 a.Rij[(size_t)tr * Ns + k] = redAt(tr, 2, k);
                 a.Rji[(size_t)tr * Ns + k] = redAt(tr, 3, k);
+                if (a.zeroParts && !a.trans[tr].op) // the Gamma terms of a detailed atom have no reader: drop them here
+                {
+                    (void)redAt(tr, 0, k);
+                    (void)redAt(tr, 1, k);
+                }
             }
         }
         return;
