@@ -151,7 +151,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.profile_enable(True)
+    ctx.profile_enable(int(os.environ.get('LWHIP_BENCH_PROF', '4')))   # HIP events around every 4th sweep launch
     # The interpreter's cyclic garbage collector is not part of the workload: with torch imported a full
     # collection takes ~40 ms (80 steps' worth) and, being triggered by allocation counts, lands at the same
     # spot of every run -- measured inside the timed region of a 100-step run (tools/trace_bench.sh: a 38 ms gap

@@ -170,6 +170,7 @@ struct lwhip_context
     DevBuf<double> bigScratch;
 
     bool profiling = false;
+    int profEvery = 1, profCount = 0; // time every profEvery-th sweep launch (lwhip_profile_enable(ctx, n))
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double sweepMs = 0.0;
@@ -1810,9 +1811,9 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
         return LWHIP_OK;
     }
     SweepDyn dyn = make_dyn(c, false, lambdaIterate);
-    // one-call iteration on the default sweep: the chunks add their accumulators straight into the stage-1 buffer
-    // (atomics), which the apply launch sums and zeroes -- no slab, no reduce launch
-    const bool atomicOut = partsOnly && !c->march && !c->big && env_int("LWHIP_ATOMIC_OUT", 1) != 0;
+    // default sweep: the chunks add their accumulators straight into the stage-1 buffer (atomics); the one-call
+    // iteration lets the apply launch sum and zero it (no reduce launch), the split / sharded form runs stage 2 only
+    const bool atomicOut = !c->march && !c->big && c->Ntrans > 0 && env_int("LWHIP_ATOMIC_OUT", 1) != 0;
     if (atomicOut)
     {
         if (!c->red8Clean)
@@ -1821,14 +1822,15 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
         dyn.atomicOut = 1;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profiling)
+    const bool timeIt = c->profiling && (c->profCount++ % c->profEvery == 0);
+    if (timeIt)
     {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
     HIP_TRY(run_sweep(c, dyn, true));
-    if (c->profiling)
+    if (timeIt)
     {
         HIP_TRY(hipEventRecord(e1, c->stream));
         c->pending.emplace_back(e0, e1);
@@ -1836,9 +1838,14 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
     {
         // fixed-order slab sums; the extra block of stage 2 writes this shard's (dJMax, global idx)
         // into its slot of the gather tail and zeros the other slots
-        const ReduceArgs r = make_reduce_args(c);
-        if (atomicOut)
+        ReduceArgs r = make_reduce_args(c);
+        if (atomicOut && partsOnly)
             ; // nothing to reduce
+        else if (atomicOut)
+        {
+            r.zeroParts = 1;
+            HIP_TRY(launch_reduce_sum(r, c->stream));
+        }
         else if (partsOnly) // single-device call: stage 2 and the dJMax reduction are folded into the apply launch
             HIP_TRY(launch_reduce_parts(r, c->stream));
         else
@@ -1847,7 +1854,7 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
             c->red8Clean = false;
     }
     c->partsOnly = partsOnly;
-    c->atomicParts = atomicOut;
+    c->atomicParts = atomicOut && partsOnly;
     if (c->worldSize > 1 && !c->prdLines.empty()) // the PRD slots of the tail ride in the same all-reduce: keep them finite
         HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
                                2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
@@ -2984,6 +2991,8 @@ int lwhip_profile_enable(lwhip_context* c, int enable)
     if (st != LWHIP_OK)
         return st;
     c->profiling = enable != 0;
+    c->profEvery = enable > 1 ? enable : 1; // n > 1: a sample of every n-th launch (two event records cost ~5 us)
+    c->profCount = 0;
     c->sweepMs = 0.0;
     c->sweepCount = 0;
     return LWHIP_OK;

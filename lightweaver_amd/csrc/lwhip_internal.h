@@ -174,6 +174,7 @@ struct ReduceArgs
     const double* dJ;              // [Nla] per-wavelength dJ of this shard
     int32_t Nla, idxOffset, world, rank;
     double* batchTail;             // column batches: this column's (dJMax, idx) slot of the batch's read-back buffer
+    int32_t zeroParts, _padR;      // stage 2 zeroes the parts it has summed (they were accumulated by atomics)
 };
 
 struct ApplyArgs
@@ -408,6 +409,7 @@ size_t march_lds_bytes(const SweepArgs& a, int wavesPerGroup);
 // list / nBatch: column batches -- a device array of per-column argument blocks, one grid slice per column
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_reduce_parts(const ReduceArgs& a, hipStream_t stream); // stage 1 only (see ApplyArgs::fromParts)
+hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream);   // stage 2 only (parts accumulated by atomics)
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
 }

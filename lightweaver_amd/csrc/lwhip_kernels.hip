@@ -1265,7 +1265,12 @@ template <class A> DEVINL void reduce_stage2_kernel_body(const A& a)
         double s = 0.0;
 #pragma unroll
         for (int part = 0; part < LWHIP_REDUCE_SPLIT; ++part)
-            s += a.red8[((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + idx];
+        {
+            const size_t o = ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + idx;
+            s += a.red8[o];
+            if (a.zeroParts)
+                a.red8[o] = 0.0;
+        }
         a.red[(size_t)tr * n4 + idx] = s;
     }
 }
@@ -1283,6 +1288,12 @@ hipError_t launch_reduce_parts(const ReduceArgs& a, hipStream_t stream)
 {
     if (a.Ntrans > 0)
         hipLaunchKernelGGL(reduce_stage1_kernel<false>, dim3(a.Ntrans, LWHIP_REDUCE_SPLIT), dim3(384), 0, stream, a, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reduce_stage2_kernel<false>, dim3(a.Ntrans + 1), dim3(512), 0, stream, a, nullptr);
     return hipGetLastError();
 }
 
