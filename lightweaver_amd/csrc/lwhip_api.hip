@@ -1375,20 +1375,23 @@ int lwhip_destroy(lwhip_context* c)
             (void)hipMemcpy(hh.data(), c->laHdr.p, hh.size() * sizeof(DevLaHeader), hipMemcpyDeviceToHost);
             if (FILE* f = std::fopen(path, "w"))
             {
-                std::fprintf(f, "chunk,nla,nLine,nMixed,nPure,cycles\n");
+                std::fprintf(f, "chunk,nla,nLine,nMixed,nPure,nCont,nTwo,nRows,cycles\n");
                 for (int ch = 0; ch < c->nChunks; ++ch)
                 {
-                    long nl = 0, nm = 0, np = 0;
+                    long nl = 0, nm = 0, np = 0, nc = 0, n2 = 0, nr = 0;
                     for (int la = cla[ch]; la < cla[ch + 1]; ++la)
                     {
                         nl += hh[la].nLine;
                         nm += hh[la].nMixed;
                         np += hh[la].nPure;
+                        nc += (hh[la].nMixed + hh[la].nPure) > 0;
+                        n2 += hh[la].nLine >= 2;
+                        nr += hh[la].nRows;
                     }
                     double tot = 0;
                     for (int i = 0; i < 12; ++i)
                         tot += (double)h[(size_t)ch * 12 + i];
-                    std::fprintf(f, "%d,%d,%ld,%ld,%ld,%.0f\n", ch, cla[ch + 1] - cla[ch], nl, nm, np, tot);
+                    std::fprintf(f, "%d,%d,%ld,%ld,%ld,%ld,%ld,%ld,%.0f\n", ch, cla[ch + 1] - cla[ch], nl, nm, np, nc, n2, nr, tot);
                 }
                 std::fclose(f);
             }
