@@ -1387,7 +1387,7 @@ int lwhip_destroy(lwhip_context* c)
             (void)hipMemcpy(hh.data(), c->laHdr.p, hh.size() * sizeof(DevLaHeader), hipMemcpyDeviceToHost);
             if (FILE* f = std::fopen(path, "w"))
             {
-                std::fprintf(f, "chunk,nla,nLine,nMixed,nPure,nCont,nTwo,nRows,cycles\n");
+                std::fprintf(f, "chunk,nla,nLine,nMixed,nPure,nCont,nTwo,nRows,cycles,start,end\n");
                 for (int ch = 0; ch < c->nChunks; ++ch)
                 {
                     long nl = 0, nm = 0, np = 0, nc = 0, n2 = 0, nr = 0;
@@ -1401,9 +1401,10 @@ int lwhip_destroy(lwhip_context* c)
                         nr += hh[la].nRows;
                     }
                     double tot = 0;
-                    for (int i = 0; i < 12; ++i)
+                    for (int i = 0; i < 10; ++i)
                         tot += (double)h[(size_t)ch * 12 + i];
-                    std::fprintf(f, "%d,%d,%ld,%ld,%ld,%ld,%ld,%ld,%.0f\n", ch, cla[ch + 1] - cla[ch], nl, nm, np, nc, n2, nr, tot);
+                    std::fprintf(f, "%d,%d,%ld,%ld,%ld,%ld,%ld,%ld,%.0f,%lld,%lld\n", ch, cla[ch + 1] - cla[ch], nl, nm, np, nc, n2, nr,
+                                 tot, h[(size_t)ch * 12 + 10], h[(size_t)ch * 12 + 11]);
                 }
                 std::fclose(f);
             }

@@ -85,6 +85,7 @@ DEVINL void sweep_body(const SweepArgs* __restrict__ ap, const SweepDyn& dyn)
 #ifdef LWHIP_STAMPS
     long long stampAcc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long stampLast = clock64();
+    const long long wallStart = wall_clock64(); // device-wide constant-rate clock: when this workgroup started
 #endif
     // the argument block is read through the constant address space: always scalar loads, also when `ap` itself
     // came from the batch's pointer table (a generic pointer the compiler cannot prove unclobbered would be read
@@ -1058,8 +1059,12 @@ DEVINL void sweep_body(const SweepArgs* __restrict__ ap, const SweepDyn& dyn)
 #ifdef LWHIP_STAMPS
     STAMP(10);
     if (t == 0 && a.stamps)
-        for (int i = 0; i < 12; ++i)
+    {
+        for (int i = 0; i < 10; ++i)
             a.stamps[(size_t)chunk * 12 + i] = stampAcc[i];
+        a.stamps[(size_t)chunk * 12 + 10] = wallStart;     // absolute start / end (wall_clock64 ticks)
+        a.stamps[(size_t)chunk * 12 + 11] = wall_clock64();
+    }
 #endif
 }
 
