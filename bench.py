@@ -247,7 +247,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm',
-                'kernel': 'sweep_kernel',
+                'kernel': 'sweep_atomic_kernel (sweep_body)',
                 'achieved': achieved,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
