@@ -105,6 +105,19 @@ struct lwhip_context
     std::vector<DevLaHeader> hdrHost;
     std::vector<int32_t> contLaHost;
     bool march = true;            // wavefront-autonomous sweep (lwhip_march.hip); false: the LDS-column sweep
+    // the ray-column sweep (lwhip_raymarch.hip): tiles of structurally identical wavelengths
+    bool tiled = false;
+    int tileL = 12, nTiles = 0, nTileChunks = 0, nTileChunksPrd = 0, nPostChunks = 0, nPostChunksPrd = 0, nTilesPrd = 0;
+    int tileWaves = 4, maxSlotsTile = 0, maxCTTile = 1, maxCTPost = 1, tileCap = 0, ktStride = 4;
+    int64_t rowsTileTot = 0, momTot = 0, phiTTot = 0;
+    DevBuf<DevTile> tiles;
+    DevBuf<DevTileSlot> tslots, tslotsPrd;
+    DevBuf<DevTileCopy> tcopies;
+    DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
+        postCs;
+    DevBuf<double> geo, kt, rowsTile, momTile, phiT;
+    DevBuf<TileArgs> dtargs, dtargsPrd;
+    TileArgs htargs{}, htargsPrd{};
     int marchD = 7, marchS = 12, marchWaves = 4;
     int64_t rowsTot = 0;
     int nContLa = 0;
@@ -787,6 +800,267 @@ int build_tables(lwhip_context* c)
             slotsPrd[e].cs = prdCk.cs[e];
     }
 
+    // ---- tiles of the ray-column sweep (lwhip_raymarch.hip) -----------------------------------------------------
+    // A tile = up to L consecutive wavelengths with the same slot records (same transitions in the same order, same
+    // row program): one wavefront marches it, lane = (mu, wavelength).
+    c->tiled = !c->is2d && env_int("LWHIP_SWEEP", 4) >= 4 && c->Nrays <= 64 && Ns >= 3;
+    std::vector<DevTile> tiles;
+    std::vector<DevTileSlot> tslots, tslotsPrd;
+    std::vector<DevTileCopy> tcopies;
+    std::vector<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd,
+        postSlotTr, postCs(std::max<size_t>(slots.size(), 1), 0);
+    if (c->tiled)
+    {
+        const int Nmu = c->Nrays;
+        const int L = std::max(1, std::min({ 16, 64 / Nmu, env_int("LWHIP_TILE_L", 16) }));
+        c->tileL = L;
+        auto pad16 = [](int64_t v) { return (v + 15) / 16 * 16; };
+        auto same_structure = [&](int la, int lb) {
+            const DevLaHeader &a = hdr[la], &b = hdr[lb];
+            if (a.nLine != b.nLine || a.nMixed != b.nMixed || a.nPure != b.nPure || a.prog != b.prog || a.hasPrd != b.hasPrd)
+                return false;
+            const int n = a.nLine + a.nMixed + a.nPure;
+            for (int e = 0; e < n; ++e)
+                if (slotTr[a.off + e] != slotTr[b.off + e])
+                    return false;
+            return true;
+        };
+        c->rowsTileTot = c->momTot = c->phiTTot = 0;
+        c->maxSlotsTile = 0;
+        c->tileCap = env_int("LWHIP_TILE_GENERIC", 0); // > 0: every tile through the guarded generic march (test hook)
+        for (int la = 0; la < c->Nla;)
+        {
+            int nl = 1;
+            while (nl < L && la + nl < c->Nla && same_structure(la, la + nl))
+                ++nl;
+            const DevLaHeader& h = hdr[la];
+            DevTile td{};
+            td.la0 = la;
+            td.nl = (int16_t)nl;
+            td.nLine = h.nLine;
+            td.nMixed = h.nMixed;
+            td.hasPrd = (int16_t)h.hasPrd;
+            td.slotOff = (int32_t)tslots.size();
+            td.copyOff = (int32_t)tcopies.size();
+            int nRowsT = 3;
+            // the five continuum rows of an active slot (eta_A, chi_i, chi_j, U_i, U_j) are consecutive tile rows,
+            // zero-filled where the wavelength has no such term: the march loads them unconditionally
+            auto five_rows = [&](const DevSlot& sl) -> int16_t {
+                const int16_t r0 = (int16_t)nRowsT;
+                for (int dense : { (int)sl.rEtaA, (int)sl.rChiI, (int)sl.rChiJ, (int)sl.rUI, (int)sl.rUJ })
+                {
+                    if (dense >= 0)
+                        tcopies.push_back(DevTileCopy{ 0, (int16_t)dense, (int16_t)nRowsT, 0 });
+                    else
+                        tcopies.push_back(DevTileCopy{ 3, 0, (int16_t)nRowsT, 0 });
+                    ++nRowsT;
+                }
+                return r0;
+            };
+            for (int e = 0; e < h.nLine + h.nMixed; ++e)
+            {
+                const DevSlot& sl = slots[h.off + e];
+                DevTileSlot ts{};
+                ts.tr = slotTr[h.off + e];
+                ts.cs = 0;
+                ts.gi = sl.gi;
+                ts.gj = sl.gj;
+                ts.atom = sl.atom;
+                ts.flags = sl.flags;
+                ts.row = sl.row;
+                ts.ms = sl.ms;
+                ts.r0 = (sl.flags & 1) ? five_rows(sl) : (int16_t)0;
+                ts.rAux = -1;
+                ts.e = (int16_t)e;
+                ts.phiOff = -1;
+                if (e < h.nLine)
+                {
+                    ts.phiOff = c->phiTTot;
+                    c->phiTTot += (int64_t)2 * Ns * 64;
+                    if (sl.flags & 2)
+                    {
+                        ts.rAux = (int16_t)nRowsT;
+                        tcopies.push_back(DevTileCopy{ 2, (int16_t)e, (int16_t)nRowsT++, 0 });
+                    }
+                }
+                else
+                {
+                    ts.rAux = (int16_t)nRowsT;
+                    tcopies.push_back(DevTileCopy{ 1, (int16_t)(e - h.nLine), (int16_t)nRowsT++, 0 });
+                }
+                tslots.push_back(ts);
+                const bool fastKind = (h.nLine == 0 && h.nMixed == 0) || (h.nLine == 1 && h.nMixed <= 1) || (h.nLine == 2 && h.nMixed == 0);
+                if (!fastKind)
+                    c->tileCap = std::max(c->tileCap, std::max((int)h.nLine, (int)h.nMixed));
+            }
+            td.nCopy = (int32_t)tcopies.size() - td.copyOff;
+            td.nRowsT = nRowsT;
+            td.rowBase = c->rowsTileTot;
+            c->rowsTileTot += pad16((int64_t)nRowsT * Ns * L);
+            td.momBase = c->momTot;
+            c->momTot += pad16((int64_t)8 * Ns * L); // [direction][J, M1, Meta0, Meta1][Ns][L]
+            c->maxSlotsTile = std::max(c->maxSlotsTile, h.nLine + h.nMixed);
+            tiles.push_back(td);
+            la += nl;
+        }
+        c->nTiles = (int)tiles.size();
+        if (std::getenv("LWHIP_VERBOSE"))
+        {
+            std::map<std::pair<int, int>, std::pair<int, int>> hist;
+            for (auto& td : tiles)
+            {
+                auto& hh = hist[{ td.nLine, td.nMixed }];
+                hh.first++;
+                hh.second += td.nl;
+            }
+            for (auto& kv : hist)
+                std::fprintf(stderr, "  tiles with %d lines + %d mixed continua: %d (%d wavelengths)\n", kv.first.first, kv.first.second,
+                             kv.second.first, kv.second.second);
+        }
+        if (c->maxSlotsTile > 8)
+            c->tiled = false; // more lines + mixed continua at one wavelength than the march holds in registers
+    }
+    if (c->tiled)
+    {
+        // workgroups of the sweep: contiguous, cost-balanced runs of tiles; the waves of a workgroup take its tiles in turn
+        c->tileWaves = std::max(1, std::min(8, env_int("LWHIP_TWAVES", 4)));
+        const int W = c->tileWaves;
+        int wgPerCU = std::max(1, 8 / W);
+        if (c->batchHint > 1)
+            wgPerCU = 1;
+        struct TileChunking
+        {
+            std::vector<int32_t> chunkTile, slotTr;
+            std::vector<int> cs; // per tile slot
+            int maxCT = 1;
+        };
+        auto tile_cost = [&](const DevTile& td) { return 1.0 + 0.35 * (td.nLine + td.nMixed); };
+        auto chunk_tiles = [&](const std::vector<int32_t>& list, int tgt, bool pure) {
+            TileChunking ck;
+            const int n = (int)list.size();
+            tgt = std::max(1, std::min(tgt, n));
+            double total = 0.0;
+            for (int ti : list)
+                total += tile_cost(tiles[ti]);
+            ck.chunkTile.push_back(0);
+            double acc = 0.0;
+            int made = 0;
+            for (int i = 0; i < n; ++i)
+            {
+                acc += tile_cost(tiles[list[i]]);
+                const int remaining = n - (i + 1), remainingChunks = tgt - (made + 1);
+                if ((acc >= total * (made + 1) / tgt || remaining <= remainingChunks) && i + 1 < n && made + 1 < tgt)
+                {
+                    ck.chunkTile.push_back(i + 1);
+                    ++made;
+                }
+            }
+            ck.chunkTile.push_back(n);
+            const int nch = (int)ck.chunkTile.size() - 1;
+            std::vector<std::vector<int>> chunkTrans(nch);
+            ck.cs.assign(pure ? slots.size() : tslots.size(), 0);
+            for (int ch = 0; ch < nch; ++ch)
+            {
+                std::vector<int> slotOf(c->Ntrans, -1);
+                auto slot_for = [&](int tr) {
+                    if (slotOf[tr] < 0)
+                    {
+                        slotOf[tr] = (int)chunkTrans[ch].size();
+                        chunkTrans[ch].push_back(tr);
+                    }
+                    return slotOf[tr];
+                };
+                for (int i = ck.chunkTile[ch]; i < ck.chunkTile[ch + 1]; ++i)
+                {
+                    const DevTile& td = tiles[list[i]];
+                    if (!pure)
+                        for (int e = 0; e < td.nLine + td.nMixed; ++e)
+                            ck.cs[td.slotOff + e] = slot_for(tslots[td.slotOff + e].tr);
+                    else
+                        for (int q = 0; q < td.nl; ++q)
+                        {
+                            const DevLaHeader& h = hdr[td.la0 + q];
+                            for (int e = h.nLine + h.nMixed; e < h.nLine + h.nMixed + h.nPure; ++e)
+                                ck.cs[h.off + e] = slot_for(slotTr[h.off + e]);
+                        }
+                }
+                ck.maxCT = std::max(ck.maxCT, (int)chunkTrans[ch].size());
+            }
+            ck.slotTr.assign((size_t)nch * ck.maxCT, -1);
+            for (int ch = 0; ch < nch; ++ch)
+                for (size_t q = 0; q < chunkTrans[ch].size(); ++q)
+                    ck.slotTr[(size_t)ch * ck.maxCT + q] = chunkTrans[ch][q];
+            return ck;
+        };
+        std::vector<int32_t> all(c->nTiles);
+        for (int i = 0; i < c->nTiles; ++i)
+        {
+            all[i] = i;
+            if (tiles[i].hasPrd)
+                tileListPrd.push_back(i);
+        }
+        int tgtSweep = std::min((2 * c->nTiles + W - 1) / W, numCU * wgPerCU); // two tasks per tile (down, up)
+        if (c->batchHint > 1)
+            tgtSweep = std::max(1, std::min(tgtSweep, numCU * 4 / c->batchHint));
+        tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
+        int tgtPost = std::min(c->nTiles, numCU * 4);
+        if (c->batchHint > 1)
+            tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
+        TileChunking sw = chunk_tiles(all, tgtSweep, false);
+        TileChunking po = chunk_tiles(all, tgtPost, true);
+        TileChunking swPrd, poPrd;
+        if (!tileListPrd.empty())
+        {
+            swPrd = chunk_tiles(tileListPrd, std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU), false);
+            poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * 4), true);
+        }
+        // both chunkings share one accumulator-slot capacity per kind
+        c->maxCTTile = std::max(sw.maxCT, swPrd.maxCT);
+        c->maxCTPost = po.maxCT;
+        auto widen = [&](TileChunking& ck, int maxCT) {
+            if (ck.maxCT == maxCT)
+                return;
+            const int nch = (int)ck.chunkTile.size() - 1;
+            std::vector<int32_t> w((size_t)nch * maxCT, -1);
+            for (int ch = 0; ch < nch; ++ch)
+                for (int q = 0; q < ck.maxCT; ++q)
+                    w[(size_t)ch * maxCT + q] = ck.slotTr[(size_t)ch * ck.maxCT + q];
+            ck.slotTr.swap(w);
+            ck.maxCT = maxCT;
+        };
+        widen(sw, c->maxCTTile);
+        if (!tileListPrd.empty())
+            widen(swPrd, c->maxCTTile);
+        for (size_t e = 0; e < tslots.size(); ++e)
+            tslots[e].cs = sw.cs[e];
+        chunkTile = sw.chunkTile;
+        tileSlotTr = sw.slotTr;
+        c->nTileChunks = (int)chunkTile.size() - 1;
+        postChunkTile = po.chunkTile;
+        postSlotTr = po.slotTr;
+        for (size_t e = 0; e < slots.size(); ++e)
+            postCs[e] = po.cs[e];
+        c->nPostChunks = (int)postChunkTile.size() - 1;
+        c->nTilesPrd = (int)tileListPrd.size();
+        c->nTileChunksPrd = c->nPostChunksPrd = 0;
+        if (!tileListPrd.empty())
+        {
+            tslotsPrd = tslots;
+            for (size_t e = 0; e < tslots.size(); ++e)
+                tslotsPrd[e].cs = swPrd.cs[e];
+            chunkTilePrd = swPrd.chunkTile;
+            tileSlotTrPrd = swPrd.slotTr;
+            postChunkTilePrd = poPrd.chunkTile;
+            c->nTileChunksPrd = (int)chunkTilePrd.size() - 1;
+            c->nPostChunksPrd = (int)postChunkTilePrd.size() - 1;
+        }
+        // LDS: the workgroup's accumulators + a 2 KB exchange row per wave (sweep); accumulators + continuum columns (post)
+        const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + (size_t)W * 4 * 16 * 9);
+        const size_t ldsPost = sizeof(double) * ((size_t)c->maxCTPost * 4 * Ns + 16 + (size_t)2 * c->maxC * 256);
+        if (ldsSweep > 150 * 1024 || ldsPost > 150 * 1024)
+            c->tiled = false;
+    }
+
     // ---- sweep geometry ---------------------------------------------------------------------------------
     const int NR2 = 2 * c->Nrays;
     size_t ldsMax = 160 * 1024;
@@ -970,6 +1244,27 @@ int build_tables(lwhip_context* c)
     }
     HIP_TRY(c->rayAll.upload(rayAll));
     HIP_TRY(c->rayUp.upload(rayUp));
+    if (c->tiled)
+    {
+        auto up = [](auto& buf, auto& v) -> hipError_t {
+            if (v.empty())
+                v.resize(1);
+            return buf.upload(v);
+        };
+        HIP_TRY(up(c->tiles, tiles));
+        HIP_TRY(up(c->tslots, tslots));
+        HIP_TRY(up(c->tslotsPrd, tslotsPrd));
+        HIP_TRY(up(c->tcopies, tcopies));
+        HIP_TRY(up(c->chunkTile, chunkTile));
+        HIP_TRY(up(c->chunkTilePrd, chunkTilePrd));
+        HIP_TRY(up(c->tileListPrd, tileListPrd));
+        HIP_TRY(up(c->tileSlotTr, tileSlotTr));
+        HIP_TRY(up(c->tileSlotTrPrd, tileSlotTrPrd));
+        HIP_TRY(up(c->postChunkTile, postChunkTile));
+        HIP_TRY(up(c->postChunkTilePrd, postChunkTilePrd));
+        HIP_TRY(up(c->postSlotTr, postSlotTr));
+        HIP_TRY(up(c->postCs, postCs));
+    }
     HIP_TRY(c->transLi.upload(li));
     HIP_TRY(c->transLj.upload(lj));
     HIP_TRY(c->atomNlevel.upload(aNl));
@@ -1047,6 +1342,16 @@ int alloc_state(lwhip_context* c)
         sz.NlevTot = c->NlevTot;
         sz.maxC = c->maxC;
         HIP_TRY(c->bigScratch.alloc((size_t)std::max(c->nChunks, c->nChunksPrd) * sweep_big_scratch_doubles(sz)));
+    }
+    if (c->tiled)
+    {
+        HIP_TRY(c->geo.alloc(4 * Ns));
+        c->ktStride = (4 + c->NlevTot + c->Nline + 1) / 2 * 2;
+        HIP_TRY(c->kt.alloc((size_t)c->ktStride * (Ns + 2))); // one padding entry at each end
+        HIP_TRY(c->rowsTile.alloc((size_t)std::max<int64_t>(c->rowsTileTot, 1)));
+        HIP_TRY(c->momTile.alloc((size_t)std::max<int64_t>(c->momTot, 1)));
+        HIP_TRY(c->phiT.alloc((size_t)std::max<int64_t>(c->phiTTot, 1)));
+        HIP_TRY(hipMemset(c->momTile.p, 0, c->momTile.n * sizeof(double)));
     }
     if (c->march)
     {
@@ -1204,6 +1509,106 @@ int build_sweep_args(lwhip_context* c)
     return LWHIP_OK;
 }
 
+int build_tile_args(lwhip_context* c)
+{
+    if (!c->tiled)
+        return LWHIP_OK;
+    TileArgs a{};
+    a.Ns = c->Ns;
+    a.Nmu = c->Nrays;
+    a.L = c->tileL;
+    a.nTiles = c->nTiles;
+    a.Natom = c->Natom;
+    a.NlevTot = c->NlevTot;
+    a.Ntrans = c->Ntrans;
+    a.maxCT = c->maxCTTile;
+    a.maxC = c->maxC;
+    a.lowerBc = c->prob.zLowerBc.type;
+    a.upperBc = c->prob.zUpperBc.type;
+    a.lowerNmu = c->prob.zLowerBc.Nmu;
+    a.upperNmu = c->prob.zUpperBc.Nmu;
+    a.storeDepth = c->prob.storeDepthData ? 1 : 0;
+    a.Nla = c->Nla;
+    a.Nline = c->Nline;
+    a.ktStride = c->ktStride;
+    a.kt = c->kt.p;
+    a.tiles = c->tiles.p;
+    a.tslots = c->tslots.p;
+    a.copies = c->tcopies.p;
+    a.chunkTile = c->chunkTile.p;
+    a.tileList = nullptr;
+    a.slotTr = c->tileSlotTr.p;
+    a.postChunkTile = c->postChunkTile.p;
+    a.postSlotTr = c->postSlotTr.p;
+    a.postCs = c->postCs.p;
+    a.maxCTPost = c->maxCTPost;
+    a.geo = c->geo.p;
+    a.temperature = c->temperature.p;
+    a.muz = c->muz.p;
+    a.wmu = c->wmu.p;
+    a.wavelength = c->wavelength.p;
+    a.lowerIdx = c->lowerIdx.p;
+    a.upperIdx = c->upperIdx.p;
+    a.lowerBcData = c->lowerBcData.p;
+    a.upperBcData = c->upperBcData.p;
+    a.bgChi = c->bgChi.p;
+    a.bgEta = c->bgEta.p;
+    a.bgSca = c->bgSca.p;
+    a.J = c->J.p;
+    a.I = c->I.p;
+    a.depthChi = c->depthChi.p;
+    a.depthEta = c->depthEta.p;
+    a.depthI = c->depthI.p;
+    a.n = c->n.p;
+    a.ratio = c->ratio.p;
+    a.wphi = c->wphi.p;
+    a.phiT = c->phiT.p;
+    a.rho = c->rho.p;
+    a.rows = c->rowsTile.p;
+    a.mom = c->momTile.p;
+    a.laHdr = c->laHdr.p;
+    a.slots = c->slots.p;
+    a.progs = c->progs.p;
+    a.progRows = c->progRows.p;
+    a.progEnts = c->progEnts.p;
+    a.red8 = c->red8.p;
+    a.dJ = c->dJ.p;
+    c->htargs = a;
+    std::vector<TileArgs> v(1, a);
+    HIP_TRY(c->dtargs.upload(v));
+    if (c->nTileChunksPrd > 0)
+    {
+        a.tslots = c->tslotsPrd.p;
+        a.chunkTile = c->chunkTilePrd.p;
+        a.tileList = c->tileListPrd.p;
+        a.slotTr = c->tileSlotTrPrd.p;
+        a.postChunkTile = c->postChunkTilePrd.p;
+        c->htargsPrd = a;
+        v[0] = a;
+        HIP_TRY(c->dtargsPrd.upload(v));
+    }
+    return LWHIP_OK;
+}
+
+// the tile-blocked copy of the line profiles follows every change of phi
+int retile_profiles(lwhip_context* c)
+{
+    if (!c->tiled || c->Nline == 0)
+        return LWHIP_OK;
+    RetileArgs r{};
+    r.Ns = c->Ns;
+    r.Nmu = c->Nrays;
+    r.L = c->tileL;
+    r.nTiles = c->nTiles;
+    r.tiles = c->tiles.p;
+    r.tslots = c->tslots.p;
+    r.trans = c->dtrans.p;
+    r.phi = c->phi.p;
+    r.phiT = c->phiT.p;
+    HIP_TRY(launch_retile(r, c->stream));
+    return LWHIP_OK;
+}
+
 SweepDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
 {
     SweepDyn d{};
@@ -1224,6 +1629,27 @@ hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
     const SweepArgs* dargs = prd ? c->dargsPrd.p : c->dargs.p;
     const SweepArgs& hargs = prd ? c->hargsPrd : c->hargs;
     const int nChunks = prd ? c->nChunksPrd : c->nChunks;
+    if (c->tiled)
+    {
+        TileDyn td{};
+        td.nPass = (dyn.nRaysActive == c->Nrays) ? 1 : 2;
+        td.lambdaIterate = dyn.lambdaIterate;
+        td.prdOnly = dyn.prdOnly;
+        td._pad = env_int("LWHIP_RM_DEBUG_MASK", 0);
+        const bool tprd = dyn.prdOnly != 0;
+        if (tprd && c->nTileChunksPrd == 0)
+            return hipSuccess;
+        const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
+        const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
+        hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
+        if (e != hipSuccess)
+            return e;
+        e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, tprd ? c->nTileChunksPrd : c->nTileChunks,
+                              c->tileWaves, nullptr, 0, c->stream);
+        if (e != hipSuccess || !rates)
+            return e;
+        return launch_tile_post(da, ha, td, tprd ? c->nPostChunksPrd : c->nPostChunks, nullptr, 0, c->stream);
+    }
     if (!c->march)
         return launch_sweep(dargs, hargs, dyn, c->prob.formalSolver, c->maxL, rates, nChunks, c->stream);
     hipError_t e = launch_cont(dargs, hargs, c->stream);
@@ -1353,9 +1779,19 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     st = build_sweep_args(c);
     if (st != LWHIP_OK)
         return bail(st);
+    st = build_tile_args(c);
+    if (st != LWHIP_OK)
+        return bail(st);
     st = lwhip_upload(c, LWHIP_ALL_INPUTS);
     if (st != LWHIP_OK)
         return bail(st);
+    if (std::getenv("LWHIP_VERBOSE"))
+        std::fprintf(stderr,
+                     "lwhip_create: Nla=%d Ns=%d Nmu=%d sweep=%s tiles=%d (L=%d, max slots %d, cap %d) chunks=%d x %d waves post=%d maxCT=%d/%d "
+                     "rows=%.1f MB phiT=%.1f MB\n",
+                     c->Nla, c->Ns, c->Nrays, c->tiled ? "ray-column" : (c->is2d ? "2d" : (c->march ? "march" : "lds-column")),
+                     c->nTiles, c->tileL, c->maxSlotsTile, c->tileCap, c->nTileChunks, c->tileWaves, c->nPostChunks, c->maxCTTile, c->maxCTPost,
+                     c->rowsTileTot * 8e-6, c->phiTTot * 8e-6);
     *out = c;
     return LWHIP_OK;
 }
@@ -1433,6 +1869,25 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         H2D(c->wavelength.p, p.wavelength + l0, Nla);
         if (p.vlosMu)
             H2D(c->vlosMu.p, p.vlosMu, Nr * Ns);
+        if (c->tiled)
+        {
+            // per-depth geometry of the ray-column sweep (scalar loads): |h_k - h_k+1|, its reciprocal,
+            // 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k
+            std::vector<double> geo(4 * Ns, 0.0);
+            for (size_t k = 0; k < Ns; ++k)
+            {
+                if (k + 1 < Ns)
+                {
+                    geo[4 * k] = std::fabs(p.height[k] - p.height[k + 1]);
+                    geo[4 * k + 1] = 1.0 / geo[4 * k];
+                }
+                if (k >= 1 && k + 1 < Ns)
+                    geo[4 * k + 2] = 1.0 / (std::fabs(p.height[k - 1] - p.height[k]) + std::fabs(p.height[k] - p.height[k + 1]));
+                geo[4 * k + 3] = 1.0 / p.temperature[k];
+            }
+            HIP_TRY(hipMemcpyAsync(c->geo.p, geo.data(), geo.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream)); // `geo` is a local
+        }
     }
     if (mask & LWHIP_BACKGROUND)
     {
@@ -1541,6 +1996,12 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     }
     if (mask & LWHIP_NSTAR)
         H2D(c->ratio.p, ratioHost.data(), ratioHost.size());
+    if (mask & LWHIP_PROFILES)
+    {
+        const int str = retile_profiles(c);
+        if (str != LWHIP_OK)
+            return str;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LWHIP_OK;
 }
@@ -1829,7 +2290,7 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
     SweepDyn dyn = make_dyn(c, false, lambdaIterate);
     // default sweep: the chunks add their accumulators straight into the stage-1 buffer (atomics); the one-call
     // iteration lets the apply launch sum and zero it (no reduce launch), the split / sharded form runs stage 2 only
-    const bool atomicOut = !c->march && !c->big && c->Ntrans > 0 && env_int("LWHIP_ATOMIC_OUT", 1) != 0;
+    const bool atomicOut = c->Ntrans > 0 && (c->tiled || (!c->march && !c->big && env_int("LWHIP_ATOMIC_OUT", 1) != 0));
     if (atomicOut)
     {
         if (!c->red8Clean)
@@ -2722,6 +3183,19 @@ int lwhip_prd_partial(lwhip_context* c)
     SweepDyn dyn = make_dyn(c, false, 0);
     dyn.prdOnly = 1;
     HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream)); // unvisited wavelengths: dJ = 0
+    if (c->tiled)
+    {
+        // the ray-column sweep adds its chunk sums into the stage-1 buffer; stage 2 sums and zeroes the parts
+        if (!c->red8Clean)
+            HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));
+        HIP_TRY(run_sweep(c, dyn, true));
+        ReduceArgs r = make_reduce_args(c);
+        r.zeroParts = 1;
+        HIP_TRY(launch_reduce_sum(r, c->stream));
+        c->red8Clean = true;
+        c->prdPending = true;
+        return LWHIP_OK;
+    }
     if (c->nChunksPrd > 0)
         HIP_TRY(run_sweep(c, dyn, true));
     else
@@ -2970,7 +3444,7 @@ int lwhip_compute_profiles(lwhip_context* c)
         a.wphi = c->wphi.p + (size_t)h.row * c->Ns;
         HIP_TRY(launch_voigt_line(a, c->stream));
     }
-    return LWHIP_OK;
+    return retile_profiles(c);
 }
 
 int lwhip_synchronize(lwhip_context* c)

@@ -162,6 +162,132 @@ struct SweepDyn
     int32_t _padD;
 };
 
+// ---- the ray-column sweep (lwhip_raymarch.hip) -------------------------------------------------------------
+// A *tile* is a run of up to L = min(16, 64 / Nmu) consecutive wavelengths with identical structure (same active
+// lines, same "mixed" continua, same continuum row program).  One wavefront marches a tile through depth:
+// lane = mu * L + j owns the ray (wavelength la0 + j, angle mu); every depth-dependent quantity is then uniform
+// across the wavefront (scalar loads), every wavelength-dependent one is a lane constant.  Everything a tile
+// reads per (wavelength, depth) sits in a tile-blocked, depth-major, wavelength-fastest row block written by the
+// pre-pass:
+//   rows[rowBase + (k * nRowsT + r) * L + j]    r = 0: chi_C  1: eta_C  2: sca * Jdag  3..: per-slot rows
+// (one base address per depth, the rows of a depth contiguous), the line profiles in
+//   phiT[phiOff + ((dir * Ns + k) * 64 + lane)]
+// and the depth-only scalars (geometry, populations, w_phi) in the depth table kt[k][...].
+struct DevTile
+{
+    int32_t la0;        // first wavelength (context-local)
+    int16_t nl;         // wavelengths in the tile (<= L)
+    int16_t nLine;      // line slots (first in the per-wavelength slot order)
+    int16_t nMixed;     // mixed-continuum slots (follow the lines)
+    int16_t hasPrd;
+    int32_t slotOff;    // first DevTileSlot
+    int32_t copyOff;    // pre-pass: first DevTileCopy
+    int32_t nCopy;
+    int32_t nRowsT;     // rows of the tile's block
+    int32_t _pad;
+    int64_t rowBase;    // offset (doubles) of the row block in the row pool
+    int64_t momBase;    // offset (doubles) of the [down, up][J, M1, Meta0, Meta1][L][Ns] moment block
+};
+struct DevTileSlot
+{
+    int32_t tr;         // global transition
+    int32_t cs;         // chunk-local accumulator slot
+    int32_t gi, gj;     // global level rows
+    int32_t atom;
+    int32_t flags;      // bit 0: active atom; bit 1: rhoPrd multiplies gij
+    int32_t row;        // lines: row in the wphi pool
+    int32_t ms;         // moment slot of the atom's lines (0 / 1) or -1
+    int16_t r0;         // first of the slot's five tile rows: eta_A, chi_i, chi_j, U_i, U_j (continuum parts; zero-filled
+                        // where the wavelength has none)
+    int16_t rAux;       // PRD lines: row of rho; mixed continua: row of Vji; -1: none
+    int16_t e;          // ordinal among the wavelength's slot records (DevLaHeader::off + e)
+    int16_t _pad;
+    int64_t phiOff;     // lines: offset (doubles) of the tile's [2][Ns][64] block in the phiT pool
+};
+struct DevTileCopy      // what the pre-pass writes into the tile's row block besides rows 0..2
+{
+    int16_t kind;       // 0: program row (dense index src)  1: Vji of continuum ordinal src  2: rho of line slot src  3: zero
+    int16_t src;
+    int16_t dst;        // tile row
+    int16_t _pad;
+};
+struct TileArgs
+{
+    int32_t Ns, Nmu, L, nTiles, Natom, NlevTot, Ntrans, maxCT, maxC;
+    int32_t lowerBc, upperBc, lowerNmu, upperNmu, storeDepth;
+    int32_t Nla, Nline;
+    int32_t ktStride, _padK;       // doubles per depth of the depth table
+    double* kt;                    // [Ns + 2][ktStride] (entry 0 and Ns + 1 are padding): |h_k - h_k+1|, its reciprocal, 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k,
+                                   // n[0 .. NlevTot)[k], wphi[0 .. Nline)[k]  (refreshed by the pre-pass)
+    const DevTile* tiles;
+    const DevTileSlot* tslots;
+    const DevTileCopy* copies;
+    const int32_t* chunkTile;      // [nChunks + 1] tile boundaries of the sweep's workgroups
+    const int32_t* tileList;       // null, or the tiles this launch visits (PRD rates pass); chunkTile indexes it
+    const int32_t* slotTr;         // [nChunks * maxCT] transition of every chunk-local accumulator slot, -1: unused
+    const int32_t* postChunkTile;  // [nPostChunks + 1] tile boundaries of the post-pass workgroups
+    const int32_t* postSlotTr;     // [nPostChunks * maxCTPost]
+    const int32_t* postCs;         // per (wavelength slot record): accumulator slot inside its post chunk
+    int32_t maxCTPost, _padB;
+    const double* geo;             // [Ns][4]: |h_k - h_k+1|, its reciprocal, 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k
+    const double* temperature;
+    const double* muz;
+    const double* wmu;
+    const double* wavelength;
+    const int32_t* lowerIdx;
+    const int32_t* upperIdx;
+    const double* lowerBcData;
+    const double* upperBcData;
+    const double* bgChi;
+    const double* bgEta;
+    const double* bgSca;
+    double* J;                     // [Nla, Ns]
+    double* I;                     // [Nla, Nmu]
+    double* depthChi;
+    double* depthEta;
+    double* depthI;
+    const double* n;               // [NlevTot, Ns]
+    const double* ratio;           // [Ncont, Ns]
+    const double* wphi;            // [Nline, Ns]
+    const double* phiT;            // tile-blocked profiles
+    const double* rho;             // PRD: [lt][Ns] rows per line (standard layout)
+    double* rows;                  // row pool
+    double* mom;                   // moment pool
+    const DevLaHeader* laHdr;
+    const DevSlot* slots;
+    const DevProgram* progs;
+    const DevProgRow* progRows;
+    const DevProgEnt* progEnts;
+    double* red8;                  // [Ntrans, SPLIT, 4, Ns]
+    double* dJ;                    // [Nla]
+};
+struct TileDyn
+{
+    int32_t nPass;          // 2: down then up; 1: up only
+    int32_t lambdaIterate;
+    int32_t prdOnly;
+    int32_t _pad;
+};
+// retile one line's profiles: standard [nlt][Nmu][2][Ns] -> the tiles' [2][Ns][64] blocks
+struct RetileArgs
+{
+    int32_t Ns, Nmu, L, nTiles;
+    const DevTile* tiles;
+    const DevTileSlot* tslots;
+    const DevTrans* trans;
+    const double* phi;
+    double* phiT;
+};
+size_t raymarch_lds_bytes(const TileArgs& a, int waves);
+hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& hostArgs, int nTilesLaunch, const TileArgs* const* apList,
+                           int nBatch, hipStream_t stream);
+hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int solver, int maxL,
+                             bool rates, int nChunks, int waves, const TileArgs* const* apList, int nBatch,
+                             hipStream_t stream);
+hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int nPostChunks,
+                            const TileArgs* const* apList, int nBatch, hipStream_t stream);
+hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
+
 enum { LWHIP_REDUCE_SPLIT = 8 };
 struct ReduceArgs
 {

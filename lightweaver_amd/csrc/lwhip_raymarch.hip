@@ -1,0 +1,1196 @@
+// lwhip_raymarch.hip -- the ray-column sweep of the formal_sol_gamma_matrices iteration on gfx950 (MI355X).
+//
+// Mapping: the wavelength axis goes across the lanes, the depth axis is marched.
+// A wavefront owns a *tile* of L = min(16, 64 / Nmu) structurally identical consecutive wavelengths in one
+// direction; lane mu * L + j is the ray (wavelength la0 + j, angle mu).  It marches that ray through the
+// atmosphere exactly as the reference's 1D solvers do (rolling three-point stencils in registers, the
+// recurrence I_k = e_k I_k-1 + b_k carried in one register).  Consequences:
+//   * everything that depends on depth only -- level populations, |dh|, w_phi, temperature -- is uniform
+//     across the wavefront and comes in through *scalar* loads (one base address per depth: the depth table);
+//   * everything that depends on wavelength only (B_ij h nu / 4 pi, quadrature weights, ...) is a lane
+//     constant for the whole march;
+//   * each stencil is evaluated once, there is no scan, no LDS column, no workgroup barrier in the march;
+//   * the profile phi is stored wavelength-fastest per (direction, depth): one 512-byte row per wavefront
+//     load; the ray-independent continuum terms come from a pre-pass, once per (wavelength, depth), in a
+//     depth-major block so that one scalar base serves all rows of a depth;
+//   * J and the Psi* moments are summed over the mu lanes of a wavelength through a wavefront-private LDS
+//     row and stored per direction (the post-pass adds down + up in a fixed order: J is bit-reproducible);
+//     the preconditioned rate integrals of the lines are summed over the rays of the step by a DPP
+//     transpose-reduce and added to the workgroup's LDS accumulators; "pure" continua are integrated from the
+//     angle moments by the post-pass;
+//   * the loads of iteration t + 1 are issued at the top of iteration t; the steady state of the march is
+//     one straight-line block (compile-time slot counts, branch-free Bezier coefficients).
+// fp64 throughout, no MFMA: a streaming recurrence over fp64 columns, not a contraction.
+//
+// Reference restated (file:line under Lightweaver's Source/): intensity_core_opt
+// SimdFullIterationTemplates.hpp:238-487, chi_eta_aux_accum :59-109, compute_full_operator_rates :192-234,
+// piecewise_{linear,besser,bezier3}_1d FormalScalar.cpp:136-666, Bezier.hpp:58-127.
+#include "lwhip_device.h"
+#include "../../include/lwhip.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace lwhip
+{
+template <typename T> DEVINL const CONST_AS T* launder_c(const T* p)
+{
+    const CONST_AS T* q = (const CONST_AS T*)p;
+    asm volatile("" : "+s"(q));
+    return q;
+}
+#define TA (*launder_c(ap))
+
+// ---- continuum terms of one (wavelength, depth) point ----------------------------------------------------------
+// Atom::setup_wavelength (LwAtom.hpp:107-115) + Transition::uv (LwTransition.hpp:132-142) for the continua: V_ji and
+// chi_c = n_i alpha - n_j V_ji into the thread's LDS columns; the Boltzmann factor is shared by all continua.
+struct ContCols
+{
+    double* colV; // [maxC] stride T
+    double* colX;
+    int T;
+};
+// `us`: the slot records of the tile's first wavelength (uniform structure: level rows, pool rows, flags);
+// `ls`: this thread's wavelength (the per-wavelength parameters p[])
+DEVINL void cont_point(const TileArgs* __restrict__ ap, const ContCols& cc, const CONST_AS DevSlot* us, const GLOBAL_AS DevSlot* ls,
+                       int nCont, int k, double rT, double hc_kl)
+{
+    const int Ns = TA.Ns;
+    const double boltz = d_exp_neg(-hc_kl * rT);
+    for (int c = 0; c < nCont; ++c)
+    {
+        const double p0 = ls[c].p[0];
+        const double gij = GCD(TA.ratio)[(size_t)us[c].row * Ns + k] * boltz;
+        const double vji = gij * p0;
+        cc.colV[(size_t)c * cc.T] = vji;
+        cc.colX[(size_t)c * cc.T] = GCD(TA.n)[us[c].gi * Ns + k] * p0 - GCD(TA.n)[us[c].gj * Ns + k] * vji;
+    }
+}
+// one row of the wavelength's row program (chi_eta_aux_accum :59-109 for the continua, in reference order)
+DEVINL double prog_row(const TileArgs* __restrict__ ap, const ContCols& cc, const CONST_AS DevSlot* us, const GLOBAL_AS DevSlot* ls,
+                       const CONST_AS DevProgRow* prow, const CONST_AS DevProgEnt* pent, int ri, int k, double bgChi,
+                       double bgEta)
+{
+    const int Ns = TA.Ns;
+    const DevProgRow pr = ld_c(prow + ri);
+    double v = 0.0;
+    if (pr.row == 0)
+        v = bgChi;
+    else if (pr.row == 1)
+        v = bgEta;
+    for (int e = 0; e < pr.nEnt; ++e)
+    {
+        const DevProgEnt en = ld_c(pent + pr.entOff + e);
+        const double x = cc.colX[(size_t)en.c * cc.T];
+        const double uji = ls[en.c].p[2] * cc.colV[(size_t)en.c * cc.T];
+        if (en.kind == 0)
+            v += x;
+        else if (en.kind == 1)
+            v -= x;
+        else if (en.kind == 2)
+            v += uji;
+        else
+            v += GCD(TA.n)[us[en.c].gj * Ns + k] * uji;
+    }
+    return v;
+}
+
+// ---- pre-pass: the tiles' row blocks and the depth table ----------------------------------------------------------
+// grid (tile, part[, column]); thread <-> point p = k * L + j of the tile (wavelength fastest)
+enum { RM_PRE_T = 256 };
+template <bool BATCH>
+__global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
+                                                            const int32_t* __restrict__ tileList)
+{
+    extern __shared__ double lds[];
+    const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.z] : ap0;
+    const int Ns = TA.Ns, L = TA.L;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+    {
+        // the depth table: everything the march reads per depth only, contiguous per depth (scalar loads off one base)
+        const int st = TA.ktStride, NlevTot = TA.NlevTot, Nline = TA.Nline;
+        for (int idx = threadIdx.x; idx < (Ns + 2) * st; idx += RM_PRE_T)
+        {
+            const int k = idx / st - 1, q = idx - (k + 1) * st; // entries -1 and Ns are padding (read, never used)
+            double v = 0.0;
+            if (k < 0 || k >= Ns)
+                v = 0.0;
+            else if (q < 4)
+                v = GCD(TA.geo)[4 * k + q];
+            else if (q < 4 + NlevTot)
+                v = GCD(TA.n)[(size_t)(q - 4) * Ns + k];
+            else if (q < 4 + NlevTot + Nline)
+                v = GCD(TA.wphi)[(size_t)(q - 4 - NlevTot) * Ns + k];
+            GD(TA.kt)[idx] = v;
+        }
+    }
+    const int ti = tileList ? CTAB(int32_t, tileList)[blockIdx.x] : (int)blockIdx.x;
+    const DevTile td = ld_c(CTAB(DevTile, TA.tiles) + ti);
+    const int p = blockIdx.y * RM_PRE_T + threadIdx.x;
+    if (p >= Ns * L)
+        return;
+    const int k = p / L;
+    const int j = p - k * L;
+    if (j >= td.nl)
+        return;
+    const int la = td.la0 + j;
+    // structure from the tile's first wavelength (uniform), parameters from this thread's own
+    const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0);
+    const int off = ((const GLOBAL_AS DevLaHeader*)TA.laHdr)[la].off;
+    const int nCont = h.nMixed + h.nPure;
+    const CONST_AS DevSlot* us = CTAB(DevSlot, TA.slots) + h.off + h.nLine;
+    const GLOBAL_AS DevSlot* lsAll = (const GLOBAL_AS DevSlot*)TA.slots + off;
+    const GLOBAL_AS DevSlot* ls = lsAll + h.nLine;
+    ContCols cc{ lds + threadIdx.x, lds + (size_t)TA.maxC * RM_PRE_T + threadIdx.x, RM_PRE_T };
+    const double rT = GCD(TA.geo)[4 * k + 3];
+    const double hc_kl = HC_K / GCD(TA.wavelength)[la];
+    cont_point(ap, cc, us, ls, nCont, k, rT, hc_kl);
+    const DevProgram pg = ld_c(CTAB(DevProgram, TA.progs) + h.prog);
+    const CONST_AS DevProgRow* prow = CTAB(DevProgRow, TA.progRows) + pg.rowOff;
+    const CONST_AS DevProgEnt* pent = CTAB(DevProgEnt, TA.progEnts) + pg.entOff;
+    const size_t o = (size_t)la * Ns + k;
+    const double bgChi = GCD(TA.bgChi)[o], bgEta = GCD(TA.bgEta)[o];
+    GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (size_t)k * td.nRowsT * L + j;
+    out[0] = prog_row(ap, cc, us, ls, prow, pent, 0, k, bgChi, bgEta);
+    out[L] = prog_row(ap, cc, us, ls, prow, pent, 1, k, bgChi, bgEta);
+    out[2 * L] = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
+    const CONST_AS DevTileCopy* cp = CTAB(DevTileCopy, TA.copies) + td.copyOff;
+    for (int q = 0; q < td.nCopy; ++q)
+    {
+        const DevTileCopy c = ld_c(cp + q);
+        double v = 0.0;
+        if (c.kind == 0)
+            v = prog_row(ap, cc, us, ls, prow, pent, c.src, k, bgChi, bgEta);
+        else if (c.kind == 1)
+            v = cc.colV[(size_t)c.src * RM_PRE_T];
+        else if (c.kind == 2)
+            v = GCD(TA.rho)[lsAll[c.src].rhoOff + k];
+        out[(size_t)c.dst * L] = v;
+    }
+}
+
+// ---- cross-lane helpers -------------------------------------------------------------------------------------------
+template <int CTRL> DEVINL double dpp_all64(double v) // every lane has a source (quad_perm, row_ror)
+{
+    const unsigned long long vv = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)vv, (int)(unsigned)vv, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(vv >> 32), (int)(unsigned)(vv >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// Sum four per-lane quantities over the 16 lanes of each DPP row; afterwards lane l holds the row total of
+// quantity l & 3.  A transpose-reduce: every level halves the number of live quantities (27 VALU, 5 of them fp64).
+DEVINL double row_reduce4(double v0, double v1, double v2, double v3, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double a = (b0 ? v1 : v0) + dpp_all64<0xB1>(b0 ? v0 : v1); // quad_perm [1,0,3,2]
+    const double b = (b0 ? v3 : v2) + dpp_all64<0xB1>(b0 ? v2 : v3);
+    double c = (b1 ? b : a) + dpp_all64<0x4E>(b1 ? a : b);           // quad_perm [2,3,0,1]
+    c += dpp_all64<0x124>(c);                                         // row_ror:4
+    c += dpp_all64<0x128>(c);                                         // row_ror:8
+    return c;
+}
+
+// ---- the march ------------------------------------------------------------------------------------------------------
+enum { RM_MAX_WAVES = 8 };
+enum { PH_0 = 0, PH_1 = 1, PH_2 = 2, PH_MAIN = 3, PH_N = 4, PH_L = 5 };
+enum { RM_WIN = 8, RM_WIN_PAD = 9, RM_WIN_DOUBLES = 4 * 16 * RM_WIN_PAD }; // moment window of a wave: [4][16][8 (+1 pad)]
+
+typedef unsigned int rm_u2 __attribute__((ext_vector_type(2)));
+// buffer access: resource in SGPRs + per-lane byte offset + scalar byte offset: no address arithmetic per load
+DEVINL double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+#ifdef RM_NO_SOFFSET
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff + soff), 0, 0));
+#else
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+#endif
+}
+DEVINL void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rm_u2, v), r, (int)voff, (int)soff, 0);
+}
+#ifdef RM_NO_KEEP
+#define RM_KEEP(v)
+#else
+#define RM_KEEP(v) asm volatile("" : "+v"(v)) // the value is computed here, on every lane (keeps selects branch-free)
+#endif
+
+// What one iteration reads from memory; loaded one iteration ahead.
+template <int NL> struct StepIn
+{
+    // gather of point t
+    double chi, eta, sca;
+    double phi[NL > 0 ? NL : 1], rho[NL > 0 ? NL : 1]; // per lane
+    double ni[NL > 0 ? NL : 1], nj[NL > 0 ? NL : 1];   // uniform
+    double dh, rdh, rsum;                              // uniform: interval (t-1 -> t); point t-1
+    // rate integrals of point m = t - 2 (uniform)
+    double nim[NL > 0 ? NL : 1], njm[NL > 0 ? NL : 1], wphim[NL > 0 ? NL : 1];
+};
+
+// One task = one tile in one direction.  NL / NM: lines / mixed continua of the tile at compile time, or (GENERIC)
+// their capacities with the counts taken from the tile.
+template <int SOLVER, int NL, int NM, bool RATES, bool GENERIC>
+DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int toObs, double* sAcc,
+                       double* win, const int lane)
+{
+    constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
+    const int Ns = a.Ns, L = a.L, Nmu = a.Nmu;
+    const int nLine = GENERIC ? (int)td.nLine : NL;
+    const int nMixed = GENERIC ? (int)td.nMixed : NM;
+#ifdef RM_OPAQUE
+    int nLineO = nLine, nMixedO = nMixed; // experiment: counts the optimiser cannot see through
+    asm volatile("" : "+s"(nLineO), "+s"(nMixedO));
+#define RM_HASL(g, s) ((s) < NL && (((RM_OPAQUE >> (g)) & 1) ? (s) < nLineO : (!GENERIC || (s) < nLine)))
+#define RM_HASM(g, c) ((c) < NM && (((RM_OPAQUE >> (g)) & 1) ? (c) < nMixedO : (!GENERIC || (c) < nMixed)))
+#else
+#define RM_HASL(g, s) ((s) < NL && (!GENERIC || (s) < nLine))
+#define RM_HASM(g, c) ((c) < NM && (!GENERIC || (c) < nMixed))
+#endif
+    const int muRaw = lane / L;
+    const int jRaw = lane - muRaw * L;
+    const bool active = (muRaw < Nmu) && (jRaw < td.nl);
+    const int mu = min(muRaw, Nmu - 1);
+    const int j = min(jRaw, td.nl - 1);
+    const int la = td.la0 + j;
+    const unsigned jb = (unsigned)j * 8u;                        // this lane's byte offset in a row of L doubles
+    const unsigned srcB = (unsigned)(mu * L + j) * 8u;           // ... in a profile row of 64 doubles
+    const unsigned L8 = (unsigned)L * 8u;
+    const double muz = GCD(a.muz)[mu];
+    const double zmu = 1.0 / muz;
+    const double hw = active ? 0.5 * GCD(a.wmu)[mu] : 0.0;
+    const double wav = GCD(a.wavelength)[la];
+    const int dk = toObs ? -1 : 1;
+    const int kS = toObs ? Ns - 1 : 0;
+
+    // ---- slot structure (uniform: SGPRs) and per-lane parameters ------------------------------------------------
+    const CONST_AS DevTileSlot* ts = CTAB(DevTileSlot, a.tslots) + td.slotOff;
+    const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
+    unsigned lnI[NLc], lnJ[NLc], lwO[NLc], lrow[NLc], lacc[NLc], laux[NLc], lphi[NLc];
+    int lgi[NLc], lgj[NLc], lat[NLc], lfl[NLc];
+    double lop[NLc], lm0[NLc], lm1[NLc];             // uniform factors: active atom, moment slot 0 / 1
+    double la0[NLc], la2[NLc], la3[NLc], lcw[NLc];   // per lane
+    long long phi0 = 0;
+#pragma unroll
+    for (int s = 0; s < NLc; ++s)
+    {
+        lnI[s] = lnJ[s] = lwO[s] = lrow[s] = lacc[s] = laux[s] = lphi[s] = 0;
+        lgi[s] = lgj[s] = lat[s] = -1 - s;
+        lfl[s] = 0;
+        lop[s] = lm0[s] = lm1[s] = 0.0;
+        la0[s] = la2[s] = la3[s] = lcw[s] = 0.0;
+        if (RM_HASL(1, s))
+        {
+            const DevTileSlot u = ld_c(ts + s);
+            if (s == 0)
+                phi0 = u.phiOff;
+            lnI[s] = (unsigned)(4 + u.gi) * 8u;
+            lnJ[s] = (unsigned)(4 + u.gj) * 8u;
+            lwO[s] = (unsigned)(4 + a.NlevTot + u.row) * 8u;
+            lrow[s] = (unsigned)u.r0 * L8;
+            laux[s] = (unsigned)max((int)u.rAux, 0) * L8;
+            lacc[s] = (unsigned)(u.cs * 4 * Ns);
+            lphi[s] = (unsigned)((u.phiOff - phi0) * 8) + (unsigned)(toObs * Ns) * 512u;
+            lgi[s] = u.gi;
+            lgj[s] = u.gj;
+            lat[s] = u.atom;
+            lfl[s] = u.flags;
+            lop[s] = (u.flags & 1) ? 1.0 : 0.0;
+            lm0[s] = ((u.flags & 1) && u.ms == 0) ? 1.0 : 0.0;
+            lm1[s] = ((u.flags & 1) && u.ms == 1) ? 1.0 : 0.0;
+            const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
+            la0[s] = sl->p[0];
+            la2[s] = sl->p[2];
+            la3[s] = sl->p[3];
+            lcw[s] = (sl->p[1] * PI4_HC) * hw;
+        }
+    }
+    unsigned mrow[NMc], maux[NMc], macc[NMc];
+    int mgi[NMc], mgj[NMc], mat[NMc];
+    double mb0[NMc], mb2[NMc], mcw[NMc];
+#pragma unroll
+    for (int c = 0; c < NMc; ++c)
+    {
+        mrow[c] = maux[c] = macc[c] = 0;
+        mgi[c] = mgj[c] = mat[c] = -100 - c;
+        mb0[c] = mb2[c] = mcw[c] = 0.0;
+        if (RM_HASM(1, c))
+        {
+            const DevTileSlot u = ld_c(ts + nLine + c);
+            mrow[c] = (unsigned)u.r0 * L8;
+            maux[c] = (unsigned)max((int)u.rAux, 0) * L8;
+            macc[c] = (unsigned)(u.cs * 4 * Ns);
+            mgi[c] = u.gi;
+            mgj[c] = u.gj;
+            mat[c] = u.atom;
+            const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
+            mb0[c] = sl->p[0];
+            mb2[c] = sl->p[2];
+            mcw[c] = sl->p[1] * hw;
+        }
+    }
+    // Which active lines feed which slot's level sums: one 5-bit code per (slot, line), evaluated once per tile.
+    // bit 0: same atom (eta_A += eta_line)   bit 1: line.i == slot.i (chi_i += x)   bit 2: line.j == slot.i (chi_i -= x, U_i += u)
+    // bit 3: line.i == slot.j (chi_j += x)   bit 4: line.j == slot.j (chi_j -= x, U_j += u)
+    auto couple_code = [&](int l, int at, int gi, int gj) -> int {
+        if (!(lfl[l] & 1))
+            return 0;
+        return (lat[l] == at ? 1 : 0) | (lgi[l] == gi ? 2 : 0) | (lgj[l] == gi ? 4 : 0) | (lgi[l] == gj ? 8 : 0)
+               | (lgj[l] == gj ? 16 : 0);
+    };
+    int ccL[NLc][NLc], ccM[NMc][NLc];
+#pragma unroll
+    for (int s = 0; s < NLc; ++s)
+#pragma unroll
+        for (int l = 0; l < NLc; ++l)
+        {
+            ccL[s][l] = __builtin_amdgcn_readfirstlane((l != s && RM_HASL(1, s) && RM_HASL(1, l)) ? couple_code(l, lat[s], lgi[s], lgj[s]) : 0);
+        }
+#pragma unroll
+    for (int c = 0; c < NMc; ++c)
+#pragma unroll
+        for (int l = 0; l < NLc; ++l)
+        {
+            ccM[c][l] = __builtin_amdgcn_readfirstlane((RM_HASM(1, c) && RM_HASL(1, l)) ? couple_code(l, mat[c], mgi[c], mgj[c]) : 0);
+        }
+    // boundary intensity of the ray (wrappers FormalScalar.cpp:471-666)
+    double B0 = 0.0, B1 = 0.0;
+    const int bcType = toObs ? a.lowerBc : a.upperBc;
+    if (bcType == LWHIP_BC_THERMALISED)
+    {
+        const CONST_AS double* T = CTAB(double, a.temperature);
+        B0 = d_planck(toObs ? T[Ns - 2] : T[0], wav);
+        B1 = d_planck(toObs ? T[Ns - 1] : T[1], wav);
+    }
+    auto boundary_I = [&](double dtau_b) -> double {
+        double Ib = 0.0;
+        if (bcType == LWHIP_BC_THERMALISED)
+            Ib = toObs ? B1 - (B0 - B1) / dtau_b : B0 - (B1 - B0) / dtau_b;
+        else if (bcType == LWHIP_BC_CALLABLE)
+        {
+            const int mi = toObs ? CTAB(int32_t, a.lowerIdx)[mu * 2 + 1] : CTAB(int32_t, a.upperIdx)[mu * 2 + 0];
+            if (mi >= 0)
+                Ib = toObs ? GCD(a.lowerBcData)[(size_t)la * a.lowerNmu + mi] : GCD(a.upperBcData)[(size_t)la * a.upperNmu + mi];
+        }
+        return Ib;
+    };
+
+    // buffer resources: the tile's row block (depth-major), its profile blocks, the moment block of this direction
+    const unsigned strideK = (unsigned)td.nRowsT * L8;
+    const __amdgpu_buffer_rsrc_t rRows
+        = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + td.rowBase), 0, (int)(strideK * (unsigned)Ns), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPhi
+        = __builtin_amdgcn_make_buffer_rsrc((void*)(a.phiT + phi0), 0, (int)((unsigned)max(nLine, 1) * 2u * (unsigned)Ns * 512u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rMom = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.mom + td.momBase + (size_t)toObs * 4 * L * Ns), 0, (int)(4u * L8 * (unsigned)Ns), 0x00020000);
+    const CONST_AS char* ktB = (const CONST_AS char*)(a.kt + a.ktStride); // entry -1 and Ns exist (padding)
+    const unsigned ktS = (unsigned)a.ktStride * 8u;
+    const bool storeDepth = RATES && a.storeDepth && !dyn.prdOnly;
+    const double lamf = dyn.lambdaIterate ? 0.0 : 1.0;
+    auto kOf = [&](int t) { return kS + dk * t; };
+    auto lds_ = [](const CONST_AS char* base, unsigned off) { return *(const CONST_AS double*)(base + off); };
+    auto dhAt = [&](int ka, int kb) { return lds_(ktB + (size_t)(long long)(min(ka, kb) * (int)ktS), 0); };
+
+    // ---- loads of iteration t: gather of point t, rate scalars of point t - 2 --------------------------------------------
+    auto load_step = [&](int t, StepIn<NL>& g) {
+        const int k = kOf(t);
+        const unsigned so = (unsigned)k * strideK;
+        const CONST_AS char* kt = ktB + (long long)(k * (int)ktS);
+        g.chi = buf_ld(rRows, jb, so);
+        g.eta = buf_ld(rRows, jb, so + L8);
+        g.sca = buf_ld(rRows, jb, so + 2 * L8);
+        const int km = k - 2 * dk;
+        const CONST_AS char* ktm = ktB + (long long)(km * (int)ktS);
+#pragma unroll
+        for (int s = 0; s < NLc; ++s)
+        {
+            g.phi[s] = 0.0;
+            g.rho[s] = 1.0;
+            g.ni[s] = g.nj[s] = g.nim[s] = g.njm[s] = g.wphim[s] = 0.0;
+            if (RM_HASL(2, s))
+            {
+                g.phi[s] = buf_ld(rPhi, srcB, lphi[s] + (unsigned)k * 512u);
+                if (lfl[s] & 2)
+                    g.rho[s] = buf_ld(rRows, jb, so + laux[s]);
+                g.ni[s] = lds_(kt, lnI[s]);
+                g.nj[s] = lds_(kt, lnJ[s]);
+                if (RATES)
+                {
+                    g.nim[s] = lds_(ktm, lnI[s]);
+                    g.njm[s] = lds_(ktm, lnJ[s]);
+                    g.wphim[s] = lds_(ktm, lwO[s]);
+                }
+            }
+        }
+        const CONST_AS char* kd = ktB + (long long)(min(k, k - dk) * (int)ktS);
+        g.dh = lds_(kd, 0);
+        g.rdh = lds_(kd, 8);
+        g.rsum = lds_(ktB + (long long)((k - dk) * (int)ktS), 16);
+    };
+
+    // ---- march state ----
+    double c0 = 1.0, c1 = 1.0, c2 = 1.0, c3 = 1.0;  // chi(t), chi(t-1), chi(t-2), chi(t-3)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // S(t) .. S(t-3)
+    double r0 = 1.0, r1 = 1.0, r2 = 1.0;            // 1 / chi
+    double ds0 = 1.0, ds1 = 1.0;                    // path length of interval t, t-1
+    double sl0 = 0.0, sl1 = 0.0;                    // chi slope of interval t, t-1
+    double dx1 = 0.0, dx2 = 0.0;                    // d chi / d s at point t-1, t-2
+    double dt1 = 1.0, dt2 = 1.0, rdt1 = 1.0, rdt2 = 1.0; // optical depth of interval t-1, t-2
+    double sS1 = 0.0, sS2 = 0.0;                    // S slope of interval t-1, t-2 (per unit tau)
+    double dS2 = 0.0, dS3 = 0.0;                    // dS/dtau at point t-2, t-3
+    double dtL = 1.0, dSL = 0.0;                    // linear end point
+    double I = 0.0;
+    double vijQ[3][NLc], vjiQ[3][NLc];
+#pragma unroll
+    for (int s = 0; s < NLc; ++s)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            vijQ[q][s] = vjiQ[q][s] = 0.0;
+
+    // ---- J and the Psi* moments (accumulate_J :181-190) -----------------------------------------------------------------
+    // Every ray adds w I, w Psi*, w Psi* eta_line into the wave's LDS window [quantity][wavelength j][step mod 8] (the mu
+    // lanes of a wavelength meet at one address); every 8 steps lane (q, j) moves its 8 sums to the moment block
+    // [q][j][Ns] of this direction.  The post-pass adds the two directions in a fixed order.
+    double* winLane = win + (jRaw * RM_WIN_PAD);
+    const int qF = lane / L, jF = lane - qF * L;
+    const bool flushLane = RATES && qF < 4 && jF < td.nl;
+    double* winF = win + ((qF & 3) * 16 + jF) * RM_WIN_PAD;
+    const unsigned momV = (unsigned)((qF & 3) * L + jF) * (unsigned)Ns * 8u;
+    if (RATES)
+    {
+        for (int idx = lane; idx < RM_WIN_DOUBLES; idx += 64)
+            win[idx] = 0.0;
+    }
+    auto flush_window = [&](int m) { // points m - (m & 7) .. m
+        if (flushLane)
+        {
+            const int m0 = m & ~(RM_WIN - 1);
+            double v[RM_WIN];
+#pragma unroll
+            for (int w = 0; w < RM_WIN; ++w)
+            {
+                v[w] = winF[w];
+                winF[w] = 0.0;
+            }
+#pragma unroll
+            for (int w = 0; w < RM_WIN; ++w)
+                if (m0 + w <= m)
+                    buf_st(rMom, momV, (unsigned)kOf(m0 + w) * 8u, v[w]);
+        }
+    };
+
+    // ---- one iteration: gather point t (inputs `in`), finish point m = t - 2; the next iteration's loads go to `nx` ----
+    auto step = [&](auto phTag, const int t, const StepIn<NL>& in, StepIn<NL>& nx) {
+        constexpr int PH = decltype(phTag)::value;
+        constexpr bool GATHER = PH <= PH_MAIN;
+        constexpr bool DO_RATES = PH >= PH_2;
+        const int km = kOf(t - 2);
+        // loads of the rate integrals of point m: issued first (used at the end of this iteration) ...
+        double lr[NLc][5], mr[NMc][5], mvji[NMc];
+        if (RATES && DO_RATES)
+        {
+            const unsigned so = (unsigned)km * strideK;
+#pragma unroll
+            for (int s = 0; s < NLc; ++s)
+            {
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    lr[s][q] = 0.0;
+                if (RM_HASL(3, s))
+                {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        lr[s][q] = buf_ld(rRows, jb, so + lrow[s] + (unsigned)q * L8);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NMc; ++c)
+            {
+                mvji[c] = 0.0;
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    mr[c][q] = 0.0;
+                if (RM_HASM(3, c))
+                {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        mr[c][q] = buf_ld(rRows, jb, so + mrow[c] + (unsigned)q * L8);
+                    mvji[c] = buf_ld(rRows, jb, so + maux[c]);
+                }
+            }
+        }
+        // ... then everything the next iteration reads (out-of-range depths read zeros / the table's padding)
+        if (PH < PH_L)
+            load_step(t + 1, nx);
+
+        // ---- A. gather point t: Transition::uv + chi_eta_aux_accum + compute_source_fn ----
+        if (GATHER)
+        {
+            double chi = in.chi, eta = in.eta;
+#pragma unroll
+            for (int s = 0; s < NLc; ++s)
+            {
+                vijQ[0][s] = 0.0;
+                vjiQ[0][s] = 0.0;
+                if (RM_HASL(2, s))
+                {
+                    const double vij = la0[s] * in.phi[s];
+                    const double vji = (la2[s] * in.rho[s]) * vij;
+                    const double uji = la3[s] * vji;
+                    chi += in.ni[s] * vij - in.nj[s] * vji;
+                    eta += in.nj[s] * uji;
+                    vijQ[0][s] = vij;
+                    vjiQ[0][s] = vji;
+                }
+            }
+            c0 = chi;
+            r0 = d_rcp(chi);
+            s0 = (eta + in.sca) * r0;
+            if (storeDepth && active)
+            {
+                const size_t o = ((size_t)(la * Nmu + mu) * 2 + toObs) * Ns + kOf(t);
+                GD(a.depthChi)[o] = chi;
+                GD(a.depthEta)[o] = eta;
+            }
+        }
+        double Psi = 0.0;
+        if (SOLVER == LWHIP_FS_BEZIER3_1D)
+        {
+            // piecewise_bezier3_1d_impl FormalScalar.cpp:209-325 with the loop-carried quantities in registers:
+            // interval t is (point t-1 -> point t).  This iteration: slope(t), dx(t-1), dtau(t-1), dS(t-2), I(t-2).
+            if (PH >= PH_1 && GATHER)
+            {
+                ds0 = in.dh * zmu;
+                sl0 = (c0 - c1) * (in.rdh * muz);
+            }
+            if (PH == PH_1)
+                dx1 = sl0; // dx_uw :239
+            else if (PH == PH_2 || PH == PH_MAIN)
+            {
+                // cent_deriv (Steffen 1990, Bezier.hpp:58-65) at point t-1: Suw = slope(t-1), S0 = slope(t)
+                const double P0 = fabs((sl1 * ds0 + sl0 * ds1) * (in.rsum * muz));
+                dx1 = (copysign(1.0, sl0) + copysign(1.0, sl1)) * fmin(fabs(sl1), fmin(fabs(sl0), 0.5 * P0));
+            }
+            else if (PH == PH_N)
+                dx1 = sl1; // dx_dw of the last interval :288
+            if (PH >= PH_2 && PH <= PH_N)
+            {
+                // optical depth of interval t-1 (:242-246, 261-263, 289-292)
+                const double ds3 = ds1 * (1.0 / 3.0);
+                const double Cuw = c2 + ds3 * dx2;
+                const double C0 = c1 - ds3 * dx1;
+                dt1 = ds1 * (c2 + c1 + Cuw + C0) * 0.25;
+                rdt1 = d_rcp(dt1);
+                sS1 = (s1 - s2) * rdt1;
+                if (PH == PH_2)
+                    dS2 = sS1; // dS_uw :247
+                else
+                {
+                    // dS_central at point t-2 (:254-255): cent_deriv(dtau(t-2), dtau(t-1), S(t-3), S(t-2), S(t-1))
+                    const double P0 = fabs((sS2 * dt1 + sS1 * dt2) * d_rcp(dt1 + dt2));
+                    dS2 = (copysign(1.0, sS1) + copysign(1.0, sS2)) * fmin(fabs(sS2), fmin(fabs(sS1), 0.5 * P0));
+                }
+            }
+            if (PH == PH_2)
+                I = boundary_I(0.5 * zmu * (c2 + c1) * dhAt(kOf(0), kOf(1)));
+            else if (PH == PH_MAIN || PH == PH_N)
+            {
+                // Bezier3_coeffs of dtau(t-2) (Bezier.hpp:81-127) and the update :265-275.  Both branches are evaluated on
+                // every lane and selected (no divergent control flow in the steady state); beyond dtau = 30 the
+                // asymptotic branch is the exact one with edt = 0.
+                const double x = dt2;
+                const double x2 = x * x, x3 = x2 * x;
+                double ex = d_exp_neg(-fmin(x, 64.0));
+                RM_KEEP(ex);
+                ex = (x > 30.0) ? 0.0 : ex;
+                const double r3 = d_rcp(x3);
+                double e1 = 1.0 - x + 0.5 * x2 - x3 * (1.0 / 6.0);
+                double a1 = 0.25 * x - 0.2 * x2 + x3 * (1.0 / 12.0), a2 = (6.0 - ex * (6.0 + 6.0 * x + 3.0 * x2 + x3)) * r3;
+                double b1 = 0.25 * x - 0.05 * x2 + x3 * (1.0 / 120.0), b2 = (6.0 * ex - 6.0 + 6.0 * x - 3.0 * x2 + x3) * r3;
+                double g1 = 0.25 * x - 0.15 * x2 + 0.05 * x3, g2 = 3.0 * (2.0 * x - 6.0 + ex * (6.0 + 4.0 * x + x2)) * r3;
+                double d1 = 0.25 * x - 0.1 * x2 + 0.025 * x3, d2 = 3.0 * (6.0 - 4.0 * x + x2 - 2.0 * ex * (3.0 + x)) * r3;
+                RM_KEEP(e1);
+                RM_KEEP(a1);
+                RM_KEEP(a2);
+                RM_KEEP(b1);
+                RM_KEEP(b2);
+                RM_KEEP(g1);
+                RM_KEEP(g2);
+                RM_KEEP(d1);
+                RM_KEEP(d2);
+                const bool small = x < 5e-2;
+                const double edt = small ? e1 : ex, al = small ? a1 : a2, be = small ? b1 : b2, ga = small ? g1 : g2,
+                             de = small ? d1 : d2;
+                const double x_3 = x * (1.0 / 3.0);
+                const double Cuw = s3 + x_3 * dS3;
+                const double C0 = s2 - x_3 * dS2;
+                I = I * edt + al * s3 + be * s2 + ga * Cuw + de * C0;
+                Psi = be + de;
+            }
+            if (PH == PH_N)
+            {
+                // the last point is piecewise linear (:306-321); its inputs are at hand now
+                dtL = 0.5 * zmu * (c1 + c2) * dhAt(kOf(Ns - 1), kOf(Ns - 2));
+                dSL = (s1 - s2) * d_rcp(dtL);
+            }
+            if (PH == PH_L)
+            {
+                double w0, w1;
+                d_w2(dtL, w0, w1);
+                I = (1.0 - w0) * I + w0 * s2 - w1 * dSL;
+                Psi = w0 - w1 * d_rcp(dtL);
+            }
+        }
+        else if (SOLVER == LWHIP_FS_LINEAR_1D)
+        {
+            // piecewise_linear_1d_impl FormalScalar.cpp:136-207.  Point m = t - 2 uses the interval (m-1 -> m), formed
+            // one iteration earlier from c2 = chi(m-1), c1 = chi(m) and carried as dt2, rdt2, sS2
+            if (PH >= PH_2 && PH <= PH_N)
+            {
+                dt1 = (0.5 * zmu) * (c2 + c1) * dhAt(kOf(t - 1), kOf(t - 2));
+                rdt1 = d_rcp(dt1);
+                sS1 = (s2 - s1) * rdt1; // dS_uw = (S(m-1) - S(m)) / dtau
+            }
+            if (PH == PH_2)
+                I = boundary_I(dt1);
+            else if (PH >= PH_MAIN)
+            {
+                double w0, w1;
+                d_w2(dt2, w0, w1);
+                I = (1.0 - w0) * I + w0 * s2 + w1 * sS2;
+                Psi = w0 - w1 * rdt2;
+            }
+        }
+        else
+        {
+            // piecewise_besser_1d_impl FormalScalar.cpp:395-467: point m = t - 2 needs chi, S of m-1, m, m+1
+            // = (c3, c2, c1) and (s3, s2, s1)
+            if (PH == PH_2)
+                I = boundary_I(0.5 * zmu * (c2 + c1) * dhAt(kOf(0), kOf(1)));
+            else if (PH == PH_MAIN || PH == PH_N)
+            {
+                const double ds_uw = dhAt(km, kOf(t - 3)) * zmu;
+                const double ds_dw = dhAt(km, kOf(t - 1)) * zmu;
+                const double chiC = d_besser_control_point(ds_uw, ds_dw, c3, c2, c1);
+                const double dtauUw = (1.0 / 3.0) * (c3 + chiC + c2) * ds_uw;
+                const double dtauDw = 0.5 * (c2 + c1) * ds_dw;
+                const double SC = d_besser_control_point(dtauUw, dtauDw, s3, s2, s1);
+                double cM, cO, cC, edt;
+                d_besser_coeffs(dtauUw, cM, cO, cC, edt);
+                I = I * edt + cM * s3 + cO * s2 + cC * SC;
+                Psi = cO + cC;
+            }
+            else if (PH == PH_L)
+            {
+                // last point: linear (:449-466)
+                const double dtau = 0.5 * zmu * (c2 + c3) * dhAt(kOf(Ns - 1), kOf(Ns - 2));
+                const double rcp = d_rcp(dtau);
+                const double dSuw = (s2 - s3) * rcp;
+                double w0, w1;
+                d_w2(dtau, w0, w1);
+                I = (1.0 - w0) * I + w0 * s2 - w1 * dSuw;
+                Psi = w0 - w1 * rcp;
+            }
+        }
+
+        // ---- F. outputs and rate integrals of point m = t - 2 -----------------------------------------
+        if (DO_RATES)
+        {
+            const double PsiStar = Psi * r2; // PsiStar :322-323
+            if (active)
+            {
+                if (toObs && PH == PH_L)
+                    GD(a.I)[(size_t)la * Nmu + mu] = I; // spect.I(la, mu, 0) :349
+                if (storeDepth)
+                    GD(a.depthI)[((size_t)(la * Nmu + mu) * 2 + toObs) * Ns + km] = I;
+            }
+            if (RATES)
+            {
+                const double PsiS = PsiStar * lamf;
+                const double wPsi = hw * PsiS;
+                double mE0 = 0.0, mE1 = 0.0;
+                // the lines' opacities at point m from the queued V_ij, V_ji and the populations of depth km
+                double xl[NLc], el[NLc], uj[NLc];
+#pragma unroll
+                for (int s = 0; s < NLc; ++s)
+                {
+                    xl[s] = el[s] = uj[s] = 0.0;
+                    if (RM_HASL(5, s))
+                    {
+                        uj[s] = la3[s] * vjiQ[2][s];
+                        xl[s] = in.nim[s] * vijQ[2][s] - in.njm[s] * vjiQ[2][s];
+                        el[s] = in.njm[s] * uj[s];
+                        const double we = wPsi * el[s];
+                        mE0 += we * lm0[s];
+                        mE1 += we * lm1[s];
+                    }
+                }
+                // level sums of a slot: continuum rows + the active lines of this wavelength, selected by the tile's
+                // coupling codes (a line's coupling with itself is known at compile time)
+                auto couple = [&](const int (&cc)[NLc], double& etaA, double& chi_i, double& chi_j, double& U_i, double& U_j) {
+#pragma unroll
+                    for (int l = 0; l < NLc; ++l)
+                    {
+                        if (l < NL)
+                        {
+                            const int c5 = cc[l];
+                            etaA += (c5 & 1) ? el[l] : 0.0;
+                            chi_i += (c5 & 2) ? xl[l] : 0.0;
+                            chi_i -= (c5 & 4) ? xl[l] : 0.0;
+                            chi_j += (c5 & 8) ? xl[l] : 0.0;
+                            chi_j -= (c5 & 16) ? xl[l] : 0.0;
+                            U_j += (c5 & 16) ? uj[l] : 0.0;
+                            U_i += (c5 & 4) ? uj[l] : 0.0;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int s = 0; s < NLc; ++s)
+                {
+                    if (RM_HASL(7, s))
+                    {
+                        const double vij = vijQ[2][s], vji = vjiQ[2][s], uji = uj[s];
+                        const double wlamu = lcw[s] * in.wphim[s];
+                        double etaA = lr[s][0] + el[s], chi_i = lr[s][1] + xl[s], chi_j = lr[s][2] - xl[s];
+                        double U_i = lr[s][3], U_j = lr[s][4] + uj[s];
+                        if (NL > 1)
+                            couple(ccL[s], etaA, chi_i, chi_j, U_i, U_j);
+                        const double Ieff = I - PsiS * etaA; // compute_full_Ieff
+                        const double wop = wlamu * lop[s];   // detailed atoms: rates only
+                        const double g0v = ((uji + vji * Ieff) - (PsiS * chi_i * U_j)) * wop;
+                        const double g1v = ((vij * Ieff) - (PsiS * chi_j * U_i)) * wop;
+                        const double r2v = I * vij * wlamu;
+                        const double r3v = (uji + I * vji) * wlamu;
+                        const double tot = row_reduce4(g0v, g1v, r2v, r3v, lane);
+                        if ((lane & 12) == 0)
+                            lds_add(sAcc + lacc[s] + (unsigned)((lane & 3) * Ns + km), tot);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NMc; ++c)
+                {
+                    if (RM_HASM(8, c)) // mixed continua (always of active atoms)
+                    {
+                        const double vij = mb0[c], vji = mvji[c], uji = mb2[c] * vji;
+                        const double wlamu = mcw[c];
+                        double etaA = mr[c][0], chi_i = mr[c][1], chi_j = mr[c][2], U_i = mr[c][3], U_j = mr[c][4];
+                        if (NL > 0)
+                            couple(ccM[c], etaA, chi_i, chi_j, U_i, U_j);
+                        const double Ieff = I - PsiS * etaA;
+                        const double g0v = ((uji + vji * Ieff) - (PsiS * chi_i * U_j)) * wlamu;
+                        const double g1v = ((vij * Ieff) - (PsiS * chi_j * U_i)) * wlamu;
+                        const double r2v = I * vij * wlamu;
+                        const double r3v = (uji + I * vji) * wlamu;
+                        const double tot = row_reduce4(g0v, g1v, r2v, r3v, lane);
+                        if ((lane & 12) == 0)
+                            lds_add(sAcc + macc[c] + (unsigned)((lane & 3) * Ns + km), tot);
+                    }
+                }
+                // moments of the step into the window; a full window (or the last point) leaves for the moment block
+                const int m = t - 2;
+                if (active)
+                {
+                    double* wp = winLane + (m & (RM_WIN - 1));
+                    lds_add(wp, hw * I);
+                    lds_add(wp + 16 * RM_WIN_PAD, wPsi);
+                    if (NL > 0)
+                    {
+                        lds_add(wp + 2 * 16 * RM_WIN_PAD, mE0);
+                        lds_add(wp + 3 * 16 * RM_WIN_PAD, mE1);
+                    }
+                }
+                if ((m & (RM_WIN - 1)) == RM_WIN - 1 || PH == PH_L)
+                    flush_window(m);
+            }
+        }
+
+        // ---- shift the windows ----
+        c3 = c2;
+        c2 = c1;
+        c1 = c0;
+        s3 = s2;
+        s2 = s1;
+        s1 = s0;
+        r2 = r1;
+        r1 = r0;
+        if (SOLVER == LWHIP_FS_BEZIER3_1D)
+        {
+            ds1 = ds0;
+            sl1 = sl0;
+            dx2 = dx1;
+            dt2 = dt1;
+            rdt2 = rdt1;
+            sS2 = sS1;
+            dS3 = dS2;
+        }
+        else if (SOLVER == LWHIP_FS_LINEAR_1D)
+        {
+            dt2 = dt1;
+            rdt2 = rdt1;
+            sS2 = sS1;
+        }
+#pragma unroll
+        for (int s = 0; s < NLc; ++s)
+        {
+            vijQ[2][s] = vijQ[1][s];
+            vijQ[1][s] = vijQ[0][s];
+            vjiQ[2][s] = vjiQ[1][s];
+            vjiQ[1][s] = vjiQ[0][s];
+        }
+    };
+
+    StepIn<NL> gA, gB;
+    load_step(0, gA);
+    gB = gA;
+    step(std::integral_constant<int, PH_0>{}, 0, gA, gB);
+    step(std::integral_constant<int, PH_1>{}, 1, gB, gA);
+    step(std::integral_constant<int, PH_2>{}, 2, gA, gB);
+    int t = 3;
+    for (; t + 1 < Ns; t += 2) // ping-pong input buffers: no copies in the steady state
+    {
+        step(std::integral_constant<int, PH_MAIN>{}, t, gB, gA);
+        step(std::integral_constant<int, PH_MAIN>{}, t + 1, gA, gB);
+    }
+    if (t < Ns)
+    {
+        step(std::integral_constant<int, PH_MAIN>{}, t, gB, gA);
+        gB = gA;
+    }
+    step(std::integral_constant<int, PH_N>{}, Ns, gB, gA);
+    step(std::integral_constant<int, PH_L>{}, Ns + 1, gA, gB);
+}
+
+// CAP == 0: the tiles of the launch are all of the kinds (0,0), (1,0), (1,1), (2,0) lines + mixed continua, each with
+// its own straight-line march; otherwise every tile goes through the guarded generic march of capacity CAP lines + CAP
+// mixed continua.
+template <int SOLVER, int CAP, bool RATES, bool BATCH>
+__global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileArgs* __restrict__ ap0,
+                                                                      const TileArgs* const* __restrict__ apList, const TileDyn dyn)
+{
+    extern __shared__ double lds[];
+    const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
+    const CONST_AS TileArgs& a = *(const CONST_AS TileArgs*)ap;
+    const int Ns = a.Ns;
+    const int maxCT = a.maxCT;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // uniform: everything derived from the tile stays scalar
+    const int nWaves = blockDim.x >> 6;
+    double* sAcc = lds;
+    double* win = lds + (size_t)maxCT * 4 * Ns + (size_t)wave * RM_WIN_DOUBLES; // the wave's moment window
+    const int chunk = blockIdx.x;
+    const int t0 = CTAB(int32_t, a.chunkTile)[chunk], t1 = CTAB(int32_t, a.chunkTile)[chunk + 1];
+    if (RATES)
+    {
+        for (int idx = t; idx < maxCT * 4 * Ns; idx += blockDim.x)
+            sAcc[idx] = 0.0;
+        __syncthreads();
+    }
+    const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
+    // tasks of the chunk: (tile, direction); both directions unless the launch is up-only
+    const int nDir = dyn.nPass;
+    for (int task = t0 * nDir + wave; task < t1 * nDir; task += nWaves)
+    {
+        const int li = (nDir == 2) ? (task >> 1) : task;
+        const int toObs = (nDir == 2) ? (task & 1) : 1;
+        const int ti = tileList ? tileList[li] : li;
+        const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
+#ifdef RM_DEBUG_MASK
+        // debug build: dyn._pad selects tile kinds that go through the generic march instead of their own variant
+        const int kind = td.nLine == 0 ? 1 : (td.nLine == 1 && td.nMixed == 0) ? 2 : (td.nLine == 1) ? 4 : 8;
+        if (CAP == 0 && (dyn._pad & kind))
+        {
+            if (dyn._pad & 16)
+            {
+                if (kind == 4)
+                    march_tile<SOLVER, 1, 1, RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
+                else
+                    march_tile<SOLVER, 2, 1, RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
+            }
+            else
+                march_tile<SOLVER, 2, 2, RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
+            continue;
+        }
+#endif
+        if (CAP == 0)
+        {
+            if (td.nLine == 0)
+                march_tile<SOLVER, 0, 0, RATES, false>(a, dyn, td, toObs, sAcc, win, lane);
+            else if (td.nLine == 1 && td.nMixed == 0)
+                march_tile<SOLVER, 1, 0, RATES, false>(a, dyn, td, toObs, sAcc, win, lane);
+            else if (td.nLine == 1)
+                march_tile<SOLVER, 1, 1, RATES, false>(a, dyn, td, toObs, sAcc, win, lane);
+            else
+                march_tile<SOLVER, 2, 0, RATES, false>(a, dyn, td, toObs, sAcc, win, lane);
+        }
+        else
+            march_tile<SOLVER, (CAP > 0 ? CAP : 1), (CAP > 0 ? CAP : 1), RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
+    }
+    if (RATES)
+    {
+        __syncthreads();
+        // the chunk's accumulators go straight into the stage-1 buffer: part = chunk % SPLIT keeps 1/SPLIT of the
+        // chunks on one address
+        const CONST_AS int32_t* slotTr = CTAB(int32_t, a.slotTr) + (size_t)chunk * maxCT;
+        GLOBAL_AS double* r8 = GD(a.red8);
+        const int n4 = 4 * Ns;
+        const int part = chunk % LWHIP_REDUCE_SPLIT;
+        for (int idx = t; idx < maxCT * n4; idx += blockDim.x)
+        {
+            const int cs = idx / n4;
+            const int tr = slotTr[cs];
+            if (tr >= 0)
+                unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + (idx - cs * n4)), sAcc[idx]);
+        }
+    }
+}
+
+// ---- post-pass: pure continua from the angle moments, J out, dJ ------------------------------------------------------
+// sum_r w_r [Uji + Vji (I_r - Psi_r eta_r) - Psi_r chi_i U_j] with chi, U, Uji, Vji ray-independent and
+// eta_r = etaC + etaLine_r  ->  Uji W + Vji (J - M1 etaC - Meta) - M1 chi_i U_j: an exact regrouping of
+// compute_full_operator_rates :206-234 for continua whose level sums do not depend on the ray.
+enum { RM_POST_T = 256 };
+template <bool BATCH>
+__global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
+                                                              const TileDyn dyn, const int32_t* __restrict__ chunkTile,
+                                                              const int32_t* __restrict__ tileList)
+{
+    extern __shared__ double lds[];
+    const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
+    const int Ns = TA.Ns, L = TA.L, Nmu = TA.Nmu;
+    const int maxCT = TA.maxCTPost;
+    const int t = threadIdx.x;
+    double* sAcc = lds;                                         // [maxCT][4][Ns]
+    unsigned long long* sDj = (unsigned long long*)(sAcc + (size_t)maxCT * 4 * Ns); // [16]
+    double* cols = (double*)(sDj + 16);                         // [2 maxC][T]
+    ContCols cc{ cols + t, cols + (size_t)TA.maxC * RM_POST_T + t, RM_POST_T };
+    const int chunk = blockIdx.x;
+    const int t0 = CTAB(int32_t, chunkTile)[chunk], t1 = CTAB(int32_t, chunkTile)[chunk + 1];
+    const bool doCont = !dyn.prdOnly; // the PRD rates pass needs J and dJ only
+    for (int idx = t; idx < maxCT * 4 * Ns; idx += RM_POST_T)
+        sAcc[idx] = 0.0;
+    double Wsum = 0.0; // total quadrature weight of the rays of the iteration, in ray order
+    for (int m = 0; m < Nmu; ++m)
+        for (int d = 0; d < 2; ++d)
+            Wsum += 0.5 * CTAB(double, TA.wmu)[m];
+    for (int li = t0; li < t1; ++li)
+    {
+        const int ti = tileList ? CTAB(int32_t, tileList)[li] : li;
+        const DevTile td = ld_c(CTAB(DevTile, TA.tiles) + ti);
+        if (t < 16)
+            sDj[t] = 0ull;
+        __syncthreads();
+        const int P = td.nl * Ns;
+        const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0); // the tile's (uniform) structure
+        const int nCont = h.nMixed + h.nPure;
+        const CONST_AS DevSlot* us = CTAB(DevSlot, TA.slots) + h.off + h.nLine;
+        const DevProgram pg = ld_c(CTAB(DevProgram, TA.progs) + h.prog);
+        const CONST_AS DevProgRow* prow = CTAB(DevProgRow, TA.progRows) + pg.rowOff;
+        const CONST_AS DevProgEnt* pent = CTAB(DevProgEnt, TA.progEnts) + pg.entOff;
+        for (int p = t; p < P; p += RM_POST_T)
+        {
+            const int j = p / Ns;
+            const int k = p - j * Ns;
+            const int la = td.la0 + j;
+            const int off = ((const GLOBAL_AS DevLaHeader*)TA.laHdr)[la].off;
+            const GLOBAL_AS DevSlot* ls = (const GLOBAL_AS DevSlot*)TA.slots + off + h.nLine;
+            // moment block [down, up][J, M1, Meta0, Meta1][L][Ns]: the two directions (two wave tasks of the sweep) are added
+            // in that order
+            const GLOBAL_AS double* mp = GCD(TA.mom) + td.momBase + (size_t)j * Ns + k;
+            const size_t ds = (size_t)Ns * 4 * L, qs = (size_t)L * Ns;
+            const double Jk = mp[0] + mp[ds];
+            if (doCont && h.nPure > 0)
+            {
+                const double M1 = mp[qs] + mp[ds + qs], Me0 = mp[2 * qs] + mp[ds + 2 * qs], Me1 = mp[3 * qs] + mp[ds + 3 * qs];
+                const double rT = GCD(TA.geo)[4 * k + 3];
+                const double hc_kl = HC_K / GCD(TA.wavelength)[la];
+                cont_point(ap, cc, us, ls, nCont, k, rT, hc_kl);
+                auto rowAt = [&](int ri) -> double { return ri >= 0 ? prog_row(ap, cc, us, ls, prow, pent, ri, k, 0.0, 0.0) : 0.0; };
+                for (int c = h.nMixed; c < nCont; ++c)
+                {
+                    const CONST_AS DevSlot& sl = us[c];
+                    const double vij = ls[c].p[0];
+                    const double vji = cc.colV[(size_t)c * RM_POST_T];
+                    const double uji = ls[c].p[2] * vji;
+                    const double wla = ls[c].p[1];
+                    const int cs = CTAB(int32_t, TA.postCs)[h.off + h.nLine + c];
+                    double* acc = sAcc + (size_t)cs * 4 * Ns + k;
+                    if (sl.flags & 1)
+                    {
+                        const double Meta = (sl.ms == 0) ? Me0 : (sl.ms == 1) ? Me1 : 0.0;
+                        const double Jeff = Jk - M1 * rowAt(sl.rEtaA) - Meta;
+                        const double g0v = ((uji * Wsum + vji * Jeff) - (M1 * rowAt(sl.rChiI) * rowAt(sl.rUJ))) * wla;
+                        const double g1v = ((vij * Jeff) - (M1 * rowAt(sl.rChiJ) * rowAt(sl.rUI))) * wla;
+                        lds_add(acc, g0v);
+                        lds_add(acc + Ns, g1v);
+                    }
+                    lds_add(acc + 2 * Ns, Jk * vij * wla);
+                    lds_add(acc + 3 * Ns, (uji * Wsum + Jk * vji) * wla);
+                }
+            }
+            // J out, dJ = max_k |1 - Jdag / J|  :477-486
+            GLOBAL_AS double* Jp = GD(TA.J) + (size_t)la * Ns + k;
+            const double Jdag = *Jp;
+            *Jp = Jk;
+            const double dj = fabs(1.0 - Jdag / Jk);
+            atomicMax(sDj + j, (unsigned long long)__double_as_longlong(dj)); // non-negative doubles order as integers
+        }
+        __syncthreads();
+        if (t < td.nl)
+            GD(TA.dJ)[td.la0 + t] = __longlong_as_double((long long)sDj[t]);
+        __syncthreads();
+    }
+    if (!doCont)
+        return;
+    const CONST_AS int32_t* slotTr = CTAB(int32_t, TA.postSlotTr) + (size_t)chunk * maxCT;
+    GLOBAL_AS double* r8 = GD(TA.red8);
+    const int n4 = 4 * Ns;
+    const int part = chunk % LWHIP_REDUCE_SPLIT;
+    for (int idx = t; idx < maxCT * n4; idx += RM_POST_T)
+    {
+        const int cs = idx / n4;
+        const int tr = slotTr[cs];
+        if (tr >= 0)
+            unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + (idx - cs * n4)), sAcc[idx]);
+    }
+}
+
+// ---- profiles into the tile layout ------------------------------------------------------------------------------------
+// grid (tile, line slot); phiT[phiOff + (dir * Ns + k) * 64 + mu * L + j] = phi[lt0 + j][mu][dir][k]
+__global__ void __launch_bounds__(256) retile_kernel(const RetileArgs a)
+{
+    const DevTile td = a.tiles[blockIdx.x];
+    if ((int)blockIdx.y >= td.nLine)
+        return;
+    const DevTileSlot sl = a.tslots[td.slotOff + blockIdx.y];
+    const DevTrans tr = a.trans[sl.tr];
+    const int lt0 = td.la0 - tr.Nblue;
+    const int Ns = a.Ns, Nmu = a.Nmu, L = a.L;
+    const double* src = a.phi + tr.phiOff;
+    double* dst = a.phiT + sl.phiOff;
+    for (int idx = threadIdx.x; idx < 2 * Ns * 64; idx += blockDim.x)
+    {
+        const int lane = idx & 63;
+        const int dk = idx >> 6;
+        const int dir = dk / Ns, k = dk - dir * Ns;
+        const int mu = lane / L, j = lane - mu * L;
+        double v = 0.0;
+        if (mu < Nmu && j < td.nl)
+            v = src[(((size_t)(lt0 + j) * Nmu + mu) * 2 + dir) * Ns + k];
+        dst[idx] = v;
+    }
+}
+
+hipError_t launch_retile(const RetileArgs& a, hipStream_t stream)
+{
+    if (a.nTiles <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(retile_kernel, dim3(a.nTiles, 8), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+size_t raymarch_lds_bytes(const TileArgs& a, int waves)
+{
+    return sizeof(double) * ((size_t)a.maxCT * 4 * a.Ns + (size_t)waves * RM_WIN_DOUBLES);
+}
+
+hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& a, int nTilesLaunch, const TileArgs* const* apList, int nBatch,
+                           hipStream_t stream)
+{
+    if (nTilesLaunch <= 0)
+        return hipSuccess;
+    const size_t lds = (size_t)2 * a.maxC * RM_PRE_T * sizeof(double);
+    const int parts = (a.Ns * a.L + RM_PRE_T - 1) / RM_PRE_T;
+    if (lds > 48 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute(apList ? (const void*)tile_pre_kernel<true> : (const void*)tile_pre_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (apList)
+        hipLaunchKernelGGL(tile_pre_kernel<true>, dim3(nTilesLaunch, parts, std::max(nBatch, 1)), dim3(RM_PRE_T), lds, stream, devArgs,
+                           apList, a.tileList);
+    else
+        hipLaunchKernelGGL(tile_pre_kernel<false>, dim3(nTilesLaunch, parts), dim3(RM_PRE_T), lds, stream, devArgs, apList, a.tileList);
+    return hipGetLastError();
+}
+
+template <int SOLVER, int CAP, bool RATES>
+static hipError_t launch_rm_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int nChunks, int waves,
+                              const TileArgs* const* apList, int nBatch, hipStream_t stream)
+{
+    const size_t lds = raymarch_lds_bytes(a, waves);
+    if (lds > 48 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute(apList ? (const void*)raymarch_kernel<SOLVER, CAP, RATES, true>
+                                                  : (const void*)raymarch_kernel<SOLVER, CAP, RATES, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (apList)
+        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, true>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds,
+                           stream, devArgs, apList, dyn);
+    else
+        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, false>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList,
+                           dyn);
+    return hipGetLastError();
+}
+
+// cap: 0 = every tile is one of the fast kinds; otherwise the generic march's capacity (lines, and mixed continua)
+template <int SOLVER, bool RATES>
+static hipError_t launch_rm_s(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int cap, int nChunks, int waves,
+                              const TileArgs* const* apList, int nBatch, hipStream_t stream)
+{
+    if (cap == 0)
+        return launch_rm_t<SOLVER, 0, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+    if (cap <= 2)
+        return launch_rm_t<SOLVER, 2, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+    if (cap <= 4)
+        return launch_rm_t<SOLVER, 4, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+    return launch_rm_t<SOLVER, 8, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+}
+
+hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int solver, int cap, bool rates,
+                             int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream)
+{
+    if (nChunks <= 0)
+        return hipSuccess;
+    if (cap > 8 || waves < 1 || waves > RM_MAX_WAVES)
+        return hipErrorInvalidValue;
+    switch (solver)
+    {
+        case LWHIP_FS_LINEAR_1D:
+            return rates ? launch_rm_s<LWHIP_FS_LINEAR_1D, true>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream)
+                         : launch_rm_s<LWHIP_FS_LINEAR_1D, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+        case LWHIP_FS_BESSER_1D:
+            return rates ? launch_rm_s<LWHIP_FS_BESSER_1D, true>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream)
+                         : launch_rm_s<LWHIP_FS_BESSER_1D, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+        default:
+            return rates ? launch_rm_s<LWHIP_FS_BEZIER3_1D, true>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream)
+                         : launch_rm_s<LWHIP_FS_BEZIER3_1D, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+    }
+}
+
+hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int nPostChunks,
+                            const TileArgs* const* apList, int nBatch, hipStream_t stream)
+{
+    if (nPostChunks <= 0)
+        return hipSuccess;
+    const size_t lds = sizeof(double) * ((size_t)a.maxCTPost * 4 * a.Ns + 16 + (size_t)2 * a.maxC * RM_POST_T);
+    if (lds > 48 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute(apList ? (const void*)tile_post_kernel<true> : (const void*)tile_post_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (apList)
+        hipLaunchKernelGGL(tile_post_kernel<true>, dim3(nPostChunks, std::max(nBatch, 1)), dim3(RM_POST_T), lds, stream, devArgs, apList,
+                           dyn, a.postChunkTile, a.tileList);
+    else
+        hipLaunchKernelGGL(tile_post_kernel<false>, dim3(nPostChunks), dim3(RM_POST_T), lds, stream, devArgs, apList, dyn,
+                           a.postChunkTile, a.tileList);
+    return hipGetLastError();
+}
+}
