@@ -565,6 +565,18 @@ int build_tables(lwhip_context* c)
             slots.push_back(sl);
             slotTr.push_back(tr);
         }
+        {
+            // position q of the reference's transition order among this wavelength's continua -> ordinal in the
+            // [mixed][pure] slot order (kept in the q-th continuum record's _pad)
+            std::vector<int> contOrd = mixed;
+            contOrd.insert(contOrd.end(), pure.begin(), pure.end());
+            std::vector<int> byTrQ(contOrd.size());
+            for (size_t q = 0; q < byTrQ.size(); ++q)
+                byTrQ[q] = (int)q;
+            std::sort(byTrQ.begin(), byTrQ.end(), [&](int x, int y) { return contOrd[x] < contOrd[y]; });
+            for (size_t q = 0; q < byTrQ.size(); ++q)
+                slots[hdr[la].off + lines.size() + q]._pad = byTrQ[q];
+        }
         c->maxL = std::max(c->maxL, (int)lines.size());
         c->maxC = std::max(c->maxC, (int)conts.size());
 
@@ -847,10 +859,11 @@ int build_tables(lwhip_context* c)
             // zero-filled where the wavelength has no such term: the march loads them unconditionally
             auto five_rows = [&](const DevSlot& sl) -> int16_t {
                 const int16_t r0 = (int16_t)nRowsT;
-                for (int dense : { (int)sl.rEtaA, (int)sl.rChiI, (int)sl.rChiJ, (int)sl.rUI, (int)sl.rUJ })
+                // row ids as the row programs number them (the pre-pass forms the level sums directly)
+                for (int id : { rowEtaA + sl.atom, rowLevChi + sl.gi, rowLevChi + sl.gj, rowLevU + sl.gi, rowLevU + sl.gj })
                 {
-                    if (dense >= 0)
-                        tcopies.push_back(DevTileCopy{ 0, (int16_t)dense, (int16_t)nRowsT, 0 });
+                    if (h.nMixed + h.nPure > 0)
+                        tcopies.push_back(DevTileCopy{ 0, (int16_t)id, (int16_t)nRowsT, 0 });
                     else
                         tcopies.push_back(DevTileCopy{ 3, 0, (int16_t)nRowsT, 0 });
                     ++nRowsT;
@@ -923,7 +936,7 @@ int build_tables(lwhip_context* c)
     if (c->tiled)
     {
         // workgroups of the sweep: contiguous, cost-balanced runs of tiles; the waves of a workgroup take its tiles in turn
-        c->tileWaves = std::max(1, std::min(8, env_int("LWHIP_TWAVES", 4)));
+        c->tileWaves = std::max(1, std::min(8, env_int("LWHIP_TWAVES", 2)));
         const int W = c->tileWaves;
         int wgPerCU = std::max(1, 8 / W);
         if (c->batchHint > 1)
@@ -1003,7 +1016,7 @@ int build_tables(lwhip_context* c)
         if (c->batchHint > 1)
             tgtSweep = std::max(1, std::min(tgtSweep, numCU * 4 / c->batchHint));
         tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
-        int tgtPost = std::min(c->nTiles, numCU * 4);
+        int tgtPost = std::min(c->nTiles, numCU * 2);
         if (c->batchHint > 1)
             tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
         TileChunking sw = chunk_tiles(all, tgtSweep, false);
@@ -1012,7 +1025,7 @@ int build_tables(lwhip_context* c)
         if (!tileListPrd.empty())
         {
             swPrd = chunk_tiles(tileListPrd, std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU), false);
-            poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * 4), true);
+            poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * 2), true);
         }
         // both chunkings share one accumulator-slot capacity per kind
         c->maxCTTile = std::max(sw.maxCT, swPrd.maxCT);
@@ -1056,7 +1069,7 @@ int build_tables(lwhip_context* c)
         }
         // LDS: the workgroup's accumulators + a 2 KB exchange row per wave (sweep); accumulators + continuum columns (post)
         const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + (size_t)W * 4 * 16 * 9);
-        const size_t ldsPost = sizeof(double) * ((size_t)c->maxCTPost * 4 * Ns + 16 + (size_t)2 * c->maxC * 256);
+        const size_t ldsPost = sizeof(double) * ((size_t)c->maxCTPost * 4 * Ns + 16 + (size_t)(c->Natom + 2 * c->NlevTot) * 256);
         if (ldsSweep > 150 * 1024 || ldsPost > 150 * 1024)
             c->tiled = false;
     }
@@ -1635,7 +1648,7 @@ hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
         td.nPass = (dyn.nRaysActive == c->Nrays) ? 1 : 2;
         td.lambdaIterate = dyn.lambdaIterate;
         td.prdOnly = dyn.prdOnly;
-        td._pad = env_int("LWHIP_RM_DEBUG_MASK", 0);
+        td._pad = env_int("LWHIP_RM_DEBUG_MASK", 0) | (env_int("LWHIP_RM_SKIP", 0) << 8);
         const bool tprd = dyn.prdOnly != 0;
         if (tprd && c->nTileChunksPrd == 0)
             return hipSuccess;

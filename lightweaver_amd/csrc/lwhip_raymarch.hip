@@ -42,61 +42,55 @@ template <typename T> DEVINL const CONST_AS T* launder_c(const T* p)
 #define TA (*launder_c(ap))
 
 // ---- continuum terms of one (wavelength, depth) point ----------------------------------------------------------
-// Atom::setup_wavelength (LwAtom.hpp:107-115) + Transition::uv (LwTransition.hpp:132-142) for the continua: V_ji and
-// chi_c = n_i alpha - n_j V_ji into the thread's LDS columns; the Boltzmann factor is shared by all continua.
-struct ContCols
+// Atom::setup_wavelength (LwAtom.hpp:107-115) + Transition::uv (LwTransition.hpp:132-142) + chi_eta_aux_accum
+// (SimdFullIterationTemplates.hpp:59-109) for the continua of one wavelength, visited in the reference's transition
+// order: the totals chi_C, eta_C and, for the active atoms, the per-atom emissivity and the per-level sums
+//   eta_A[atom] += n_j U_ji    chi[i] += chi_c    chi[j] -= chi_c    U[j] += U_ji
+// accumulated in the thread's LDS column lev[slot * T] (slots: [eta_A x Natom][chi x NlevTot][U x NlevTot]).
+// `us`: the continuum slot records of the tile's first wavelength (uniform structure: level rows, pool rows, flags,
+// and in _pad the continuum's ordinal for position q of the transition order); `ls`: this thread's wavelength (p[]).
+struct LevCols
 {
-    double* colV; // [maxC] stride T
-    double* colX;
-    int T;
+    double* lev;
+    int T, Natom, NlevTot;
+    DEVINL double& etaA(int at) const { return lev[(size_t)at * T]; }
+    DEVINL double& chi(int g) const { return lev[(size_t)(Natom + g) * T]; }
+    DEVINL double& U(int g) const { return lev[(size_t)(Natom + NlevTot + g) * T]; }
+    // row id as the row programs number them: 0 chi_C, 1 eta_C, 2 + atom, 2 + Natom + level, 2 + Natom + NlevTot + level
+    DEVINL double row(int id) const { return lev[(size_t)(id - 2) * T]; }
 };
-// `us`: the slot records of the tile's first wavelength (uniform structure: level rows, pool rows, flags);
-// `ls`: this thread's wavelength (the per-wavelength parameters p[])
-DEVINL void cont_point(const TileArgs* __restrict__ ap, const ContCols& cc, const CONST_AS DevSlot* us, const GLOBAL_AS DevSlot* ls,
-                       int nCont, int k, double rT, double hc_kl)
+DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, const CONST_AS DevSlot* us, const GLOBAL_AS DevSlot* ls,
+                        int nCont, int k, double rT, double hc_kl, double& chiC, double& etaC)
 {
     const int Ns = TA.Ns;
+    const int nLev = lc.Natom + 2 * lc.NlevTot;
+    for (int q = 0; q < nLev; ++q)
+        lc.lev[(size_t)q * lc.T] = 0.0;
     const double boltz = d_exp_neg(-hc_kl * rT);
-    for (int c = 0; c < nCont; ++c)
+    for (int q = 0; q < nCont; ++q)
     {
+        const int c = us[q]._pad;
+        const CONST_AS DevSlot& u = us[c];
         const double p0 = ls[c].p[0];
-        const double gij = GCD(TA.ratio)[(size_t)us[c].row * Ns + k] * boltz;
-        const double vji = gij * p0;
-        cc.colV[(size_t)c * cc.T] = vji;
-        cc.colX[(size_t)c * cc.T] = GCD(TA.n)[us[c].gi * Ns + k] * p0 - GCD(TA.n)[us[c].gj * Ns + k] * vji;
+        const double nj = GCD(TA.n)[u.gj * Ns + k];
+        const double vji = (GCD(TA.ratio)[(size_t)u.row * Ns + k] * boltz) * p0;
+        const double chi_c = GCD(TA.n)[u.gi * Ns + k] * p0 - nj * vji;
+        const double uji = ls[c].p[2] * vji;
+        const double eta_c = nj * uji;
+        chiC += chi_c;
+        etaC += eta_c;
+        if (u.flags & 1)
+        {
+            lc.etaA(u.atom) += eta_c;
+            lc.chi(u.gi) += chi_c;
+            lc.chi(u.gj) -= chi_c;
+            lc.U(u.gj) += uji;
+        }
     }
-}
-// one row of the wavelength's row program (chi_eta_aux_accum :59-109 for the continua, in reference order)
-DEVINL double prog_row(const TileArgs* __restrict__ ap, const ContCols& cc, const CONST_AS DevSlot* us, const GLOBAL_AS DevSlot* ls,
-                       const CONST_AS DevProgRow* prow, const CONST_AS DevProgEnt* pent, int ri, int k, double bgChi,
-                       double bgEta)
-{
-    const int Ns = TA.Ns;
-    const DevProgRow pr = ld_c(prow + ri);
-    double v = 0.0;
-    if (pr.row == 0)
-        v = bgChi;
-    else if (pr.row == 1)
-        v = bgEta;
-    for (int e = 0; e < pr.nEnt; ++e)
-    {
-        const DevProgEnt en = ld_c(pent + pr.entOff + e);
-        const double x = cc.colX[(size_t)en.c * cc.T];
-        const double uji = ls[en.c].p[2] * cc.colV[(size_t)en.c * cc.T];
-        if (en.kind == 0)
-            v += x;
-        else if (en.kind == 1)
-            v -= x;
-        else if (en.kind == 2)
-            v += uji;
-        else
-            v += GCD(TA.n)[us[en.c].gj * Ns + k] * uji;
-    }
-    return v;
 }
 
 // ---- pre-pass: the tiles' row blocks and the depth table ----------------------------------------------------------
-// grid (tile, part[, column]); thread <-> point p = k * L + j of the tile (wavelength fastest)
+// grid (tile, part[, column]); thread <-> point p = k * L + j of the tile (wavelength fastest: coalesced row writes)
 enum { RM_PRE_T = 256 };
 template <bool BATCH>
 __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
@@ -141,18 +135,15 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
     const CONST_AS DevSlot* us = CTAB(DevSlot, TA.slots) + h.off + h.nLine;
     const GLOBAL_AS DevSlot* lsAll = (const GLOBAL_AS DevSlot*)TA.slots + off;
     const GLOBAL_AS DevSlot* ls = lsAll + h.nLine;
-    ContCols cc{ lds + threadIdx.x, lds + (size_t)TA.maxC * RM_PRE_T + threadIdx.x, RM_PRE_T };
+    const LevCols lc{ lds + threadIdx.x, RM_PRE_T, TA.Natom, TA.NlevTot };
     const double rT = GCD(TA.geo)[4 * k + 3];
     const double hc_kl = HC_K / GCD(TA.wavelength)[la];
-    cont_point(ap, cc, us, ls, nCont, k, rT, hc_kl);
-    const DevProgram pg = ld_c(CTAB(DevProgram, TA.progs) + h.prog);
-    const CONST_AS DevProgRow* prow = CTAB(DevProgRow, TA.progRows) + pg.rowOff;
-    const CONST_AS DevProgEnt* pent = CTAB(DevProgEnt, TA.progEnts) + pg.entOff;
     const size_t o = (size_t)la * Ns + k;
-    const double bgChi = GCD(TA.bgChi)[o], bgEta = GCD(TA.bgEta)[o];
+    double chiC = GCD(TA.bgChi)[o], etaC = GCD(TA.bgEta)[o];
+    cont_levels(ap, lc, us, ls, nCont, k, rT, hc_kl, chiC, etaC);
     GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (size_t)k * td.nRowsT * L + j;
-    out[0] = prog_row(ap, cc, us, ls, prow, pent, 0, k, bgChi, bgEta);
-    out[L] = prog_row(ap, cc, us, ls, prow, pent, 1, k, bgChi, bgEta);
+    out[0] = chiC;
+    out[L] = etaC;
     out[2 * L] = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
     const CONST_AS DevTileCopy* cp = CTAB(DevTileCopy, TA.copies) + td.copyOff;
     for (int q = 0; q < td.nCopy; ++q)
@@ -160,9 +151,9 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
         const DevTileCopy c = ld_c(cp + q);
         double v = 0.0;
         if (c.kind == 0)
-            v = prog_row(ap, cc, us, ls, prow, pent, c.src, k, bgChi, bgEta);
-        else if (c.kind == 1)
-            v = cc.colV[(size_t)c.src * RM_PRE_T];
+            v = lc.row(c.src);
+        else if (c.kind == 1) // V_ji of a mixed continuum
+            v = (GCD(TA.ratio)[(size_t)us[c.src].row * Ns + k] * d_exp_neg(-hc_kl * rT)) * ls[c.src].p[0];
         else if (c.kind == 2)
             v = GCD(TA.rho)[lsAll[c.src].rhoOff + k];
         out[(size_t)c.dst * L] = v;
@@ -894,6 +885,12 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
         const int toObs = (nDir == 2) ? (task & 1) : 1;
         const int ti = tileList ? tileList[li] : li;
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
+        if (dyn._pad & 0xf00) // timing experiment (LWHIP_RM_SKIP): leave out the tiles of some kinds (results are then wrong)
+        {
+            const int kd = td.nLine == 0 ? 1 : (td.nLine == 1 && td.nMixed == 0) ? 2 : (td.nLine == 1) ? 4 : 8;
+            if ((dyn._pad >> 8) & kd)
+                continue;
+        }
 #ifdef RM_DEBUG_MASK
         // debug build: dyn._pad selects tile kinds that go through the generic march instead of their own variant
         const int kind = td.nLine == 0 ? 1 : (td.nLine == 1 && td.nMixed == 0) ? 2 : (td.nLine == 1) ? 4 : 8;
@@ -961,8 +958,8 @@ __global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __
     const int t = threadIdx.x;
     double* sAcc = lds;                                         // [maxCT][4][Ns]
     unsigned long long* sDj = (unsigned long long*)(sAcc + (size_t)maxCT * 4 * Ns); // [16]
-    double* cols = (double*)(sDj + 16);                         // [2 maxC][T]
-    ContCols cc{ cols + t, cols + (size_t)TA.maxC * RM_POST_T + t, RM_POST_T };
+    double* cols = (double*)(sDj + 16);                         // [Natom + 2 NlevTot][T]
+    const LevCols lc{ cols + t, RM_POST_T, TA.Natom, TA.NlevTot };
     const int chunk = blockIdx.x;
     const int t0 = CTAB(int32_t, chunkTile)[chunk], t1 = CTAB(int32_t, chunkTile)[chunk + 1];
     const bool doCont = !dyn.prdOnly; // the PRD rates pass needs J and dJ only
@@ -983,9 +980,6 @@ __global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __
         const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0); // the tile's (uniform) structure
         const int nCont = h.nMixed + h.nPure;
         const CONST_AS DevSlot* us = CTAB(DevSlot, TA.slots) + h.off + h.nLine;
-        const DevProgram pg = ld_c(CTAB(DevProgram, TA.progs) + h.prog);
-        const CONST_AS DevProgRow* prow = CTAB(DevProgRow, TA.progRows) + pg.rowOff;
-        const CONST_AS DevProgEnt* pent = CTAB(DevProgEnt, TA.progEnts) + pg.entOff;
         for (int p = t; p < P; p += RM_POST_T)
         {
             const int j = p / Ns;
@@ -1003,13 +997,14 @@ __global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __
                 const double M1 = mp[qs] + mp[ds + qs], Me0 = mp[2 * qs] + mp[ds + 2 * qs], Me1 = mp[3 * qs] + mp[ds + 3 * qs];
                 const double rT = GCD(TA.geo)[4 * k + 3];
                 const double hc_kl = HC_K / GCD(TA.wavelength)[la];
-                cont_point(ap, cc, us, ls, nCont, k, rT, hc_kl);
-                auto rowAt = [&](int ri) -> double { return ri >= 0 ? prog_row(ap, cc, us, ls, prow, pent, ri, k, 0.0, 0.0) : 0.0; };
+                double chiC = 0.0, etaC = 0.0;
+                cont_levels(ap, lc, us, ls, nCont, k, rT, hc_kl, chiC, etaC);
+                const double boltz = d_exp_neg(-hc_kl * rT);
                 for (int c = h.nMixed; c < nCont; ++c)
                 {
                     const CONST_AS DevSlot& sl = us[c];
                     const double vij = ls[c].p[0];
-                    const double vji = cc.colV[(size_t)c * RM_POST_T];
+                    const double vji = (GCD(TA.ratio)[(size_t)sl.row * Ns + k] * boltz) * vij;
                     const double uji = ls[c].p[2] * vji;
                     const double wla = ls[c].p[1];
                     const int cs = CTAB(int32_t, TA.postCs)[h.off + h.nLine + c];
@@ -1017,9 +1012,9 @@ __global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __
                     if (sl.flags & 1)
                     {
                         const double Meta = (sl.ms == 0) ? Me0 : (sl.ms == 1) ? Me1 : 0.0;
-                        const double Jeff = Jk - M1 * rowAt(sl.rEtaA) - Meta;
-                        const double g0v = ((uji * Wsum + vji * Jeff) - (M1 * rowAt(sl.rChiI) * rowAt(sl.rUJ))) * wla;
-                        const double g1v = ((vij * Jeff) - (M1 * rowAt(sl.rChiJ) * rowAt(sl.rUI))) * wla;
+                        const double Jeff = Jk - M1 * lc.etaA(sl.atom) - Meta;
+                        const double g0v = ((uji * Wsum + vji * Jeff) - (M1 * lc.chi(sl.gi) * lc.U(sl.gj))) * wla;
+                        const double g1v = ((vij * Jeff) - (M1 * lc.chi(sl.gj) * lc.U(sl.gi))) * wla;
                         lds_add(acc, g0v);
                         lds_add(acc + Ns, g1v);
                     }
@@ -1098,7 +1093,7 @@ hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& a, int nTile
 {
     if (nTilesLaunch <= 0)
         return hipSuccess;
-    const size_t lds = (size_t)2 * a.maxC * RM_PRE_T * sizeof(double);
+    const size_t lds = (size_t)(a.Natom + 2 * a.NlevTot) * RM_PRE_T * sizeof(double);
     const int parts = (a.Ns * a.L + RM_PRE_T - 1) / RM_PRE_T;
     if (lds > 48 * 1024)
     {
@@ -1177,7 +1172,7 @@ hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& a, const Ti
 {
     if (nPostChunks <= 0)
         return hipSuccess;
-    const size_t lds = sizeof(double) * ((size_t)a.maxCTPost * 4 * a.Ns + 16 + (size_t)2 * a.maxC * RM_POST_T);
+    const size_t lds = sizeof(double) * ((size_t)a.maxCTPost * 4 * a.Ns + 16 + (size_t)(a.Natom + 2 * a.NlevTot) * RM_POST_T);
     if (lds > 48 * 1024)
     {
         hipError_t e = hipFuncSetAttribute(apList ? (const void*)tile_post_kernel<true> : (const void*)tile_post_kernel<false>,
