@@ -909,7 +909,7 @@ int build_tables(lwhip_context* c)
             td.nCopy = (int32_t)tcopies.size() - td.copyOff;
             td.nRowsT = nRowsT;
             td.rowBase = c->rowsTileTot;
-            c->rowsTileTot += pad16((int64_t)nRowsT * Ns * L);
+            c->rowsTileTot += (int64_t)nRowsT * Ns * 16; // rows of 16 doubles whatever L (RM_ROW)
             td.momBase = c->momTot;
             c->momTot += pad16((int64_t)8 * Ns * L); // [direction][J, M1, Meta0, Meta1][Ns][L]
             c->maxSlotsTile = std::max(c->maxSlotsTile, h.nLine + h.nMixed);
@@ -1068,7 +1068,7 @@ int build_tables(lwhip_context* c)
             c->nPostChunksPrd = (int)postChunkTilePrd.size() - 1;
         }
         // LDS: the workgroup's accumulators + a 2 KB exchange row per wave (sweep); accumulators + continuum columns (post)
-        const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + (size_t)W * 4 * 16 * 9);
+        const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + (size_t)W * 5 * 16 * 9);
         const size_t ldsPost = sizeof(double) * ((size_t)c->maxCTPost * 4 * Ns + 16 + (size_t)(c->Natom + 2 * c->NlevTot) * 256);
         if (ldsSweep > 150 * 1024 || ldsPost > 150 * 1024)
             c->tiled = false;

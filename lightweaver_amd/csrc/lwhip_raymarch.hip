@@ -92,6 +92,7 @@ DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, cons
 // ---- pre-pass: the tiles' row blocks and the depth table ----------------------------------------------------------
 // grid (tile, part[, column]); thread <-> point p = k * L + j of the tile (wavelength fastest: coalesced row writes)
 enum { RM_PRE_T = 256 };
+enum { RM_ROW = 16 }; // doubles per row of a tile's row block (L <= 16 used): row offsets are instruction immediates
 template <bool BATCH>
 __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
                                                             const int32_t* __restrict__ tileList)
@@ -141,10 +142,10 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
     const size_t o = (size_t)la * Ns + k;
     double chiC = GCD(TA.bgChi)[o], etaC = GCD(TA.bgEta)[o];
     cont_levels(ap, lc, us, ls, nCont, k, rT, hc_kl, chiC, etaC);
-    GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (size_t)k * td.nRowsT * L + j;
+    GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (size_t)k * td.nRowsT * RM_ROW + j;
     out[0] = chiC;
-    out[L] = etaC;
-    out[2 * L] = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
+    out[RM_ROW] = etaC;
+    out[2 * RM_ROW] = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
     const CONST_AS DevTileCopy* cp = CTAB(DevTileCopy, TA.copies) + td.copyOff;
     for (int q = 0; q < td.nCopy; ++q)
     {
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
             v = (GCD(TA.ratio)[(size_t)us[c.src].row * Ns + k] * d_exp_neg(-hc_kl * rT)) * ls[c.src].p[0];
         else if (c.kind == 2)
             v = GCD(TA.rho)[lsAll[c.src].rhoOff + k];
-        out[(size_t)c.dst * L] = v;
+        out[(size_t)c.dst * RM_ROW] = v;
     }
 }
 
@@ -184,7 +185,7 @@ DEVINL double row_reduce4(double v0, double v1, double v2, double v3, int lane)
 // ---- the march ------------------------------------------------------------------------------------------------------
 enum { RM_MAX_WAVES = 8 };
 enum { PH_0 = 0, PH_1 = 1, PH_2 = 2, PH_MAIN = 3, PH_N = 4, PH_L = 5 };
-enum { RM_WIN = 8, RM_WIN_PAD = 9, RM_WIN_DOUBLES = 4 * 16 * RM_WIN_PAD }; // moment window of a wave: [4][16][8 (+1 pad)]
+enum { RM_WIN = 8, RM_WIN_PAD = 9, RM_WIN_Q = 16 * RM_WIN_PAD, RM_WIN_DOUBLES = 5 * RM_WIN_Q }; // moment window of a wave: [J, M1, Meta0, Meta1, unused][16][8 (+1 pad)]
 
 typedef unsigned int rm_u2 __attribute__((ext_vector_type(2)));
 // buffer access: resource in SGPRs + per-lane byte offset + scalar byte offset: no address arithmetic per load
@@ -200,6 +201,36 @@ DEVINL void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, doubl
 {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rm_u2, v), r, (int)voff, (int)soff, 0);
 }
+// 1 / x from v_rcp_f64 and one Newton step (relative error ~1e-14 at worst: the seed is good to ~2^-26)
+DEVINL double rm_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+// exp(x) for -700 < x <= 0 as d_exp_neg, the degree-13 polynomial split into its even and odd part (two independent
+// Horner chains in r^2: half the dependent latency)
+DEVINL double rm_exp_neg(double x)
+{
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    const double r2 = r * r;
+    double pe = 1.0 / 479001600.0, po = 1.0 / 6227020800.0;
+    pe = fma(pe, r2, 1.0 / 3628800.0);
+    po = fma(po, r2, 1.0 / 39916800.0);
+    pe = fma(pe, r2, 1.0 / 40320.0);
+    po = fma(po, r2, 1.0 / 362880.0);
+    pe = fma(pe, r2, 1.0 / 720.0);
+    po = fma(po, r2, 1.0 / 5040.0);
+    pe = fma(pe, r2, 1.0 / 24.0);
+    po = fma(po, r2, 1.0 / 120.0);
+    pe = fma(pe, r2, 0.5);
+    po = fma(po, r2, 1.0 / 6.0);
+    pe = fma(pe, r2, 1.0);
+    po = fma(po, r2, 1.0);
+    return ldexp(fma(po, r, pe), (int)n);
+}
 #ifdef RM_NO_KEEP
 #define RM_KEEP(v)
 #else
@@ -214,8 +245,6 @@ template <int NL> struct StepIn
     double phi[NL > 0 ? NL : 1], rho[NL > 0 ? NL : 1]; // per lane
     double ni[NL > 0 ? NL : 1], nj[NL > 0 ? NL : 1];   // uniform
     double dh, rdh, rsum;                              // uniform: interval (t-1 -> t); point t-1
-    // rate integrals of point m = t - 2 (uniform)
-    double nim[NL > 0 ? NL : 1], njm[NL > 0 ? NL : 1], wphim[NL > 0 ? NL : 1];
 };
 
 // One task = one tile in one direction.  NL / NM: lines / mixed continua of the tile at compile time, or (GENERIC)
@@ -258,8 +287,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
     unsigned lnI[NLc], lnJ[NLc], lwO[NLc], lrow[NLc], lacc[NLc], laux[NLc], lphi[NLc];
     int lgi[NLc], lgj[NLc], lat[NLc], lfl[NLc];
-    double lop[NLc], lm0[NLc], lm1[NLc];             // uniform factors: active atom, moment slot 0 / 1
-    double la0[NLc], la2[NLc], la3[NLc], lcw[NLc];   // per lane
+    unsigned lmq[NLc];                                // window quantity of the line's Psi* eta moment (Meta0 / Meta1 / unused)
+    double la0[NLc], la2[NLc], la3[NLc], lcw[NLc], lcwOp[NLc]; // per lane
     long long phi0 = 0;
 #pragma unroll
     for (int s = 0; s < NLc; ++s)
@@ -267,8 +296,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         lnI[s] = lnJ[s] = lwO[s] = lrow[s] = lacc[s] = laux[s] = lphi[s] = 0;
         lgi[s] = lgj[s] = lat[s] = -1 - s;
         lfl[s] = 0;
-        lop[s] = lm0[s] = lm1[s] = 0.0;
-        la0[s] = la2[s] = la3[s] = lcw[s] = 0.0;
+        lmq[s] = 4 * RM_WIN_Q;
+        la0[s] = la2[s] = la3[s] = lcw[s] = lcwOp[s] = 0.0;
         if (RM_HASL(1, s))
         {
             const DevTileSlot u = ld_c(ts + s);
@@ -277,22 +306,21 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
             lnI[s] = (unsigned)(4 + u.gi) * 8u;
             lnJ[s] = (unsigned)(4 + u.gj) * 8u;
             lwO[s] = (unsigned)(4 + a.NlevTot + u.row) * 8u;
-            lrow[s] = (unsigned)u.r0 * L8;
-            laux[s] = (unsigned)max((int)u.rAux, 0) * L8;
+            lrow[s] = (unsigned)u.r0 * (RM_ROW * 8u);
+            laux[s] = (unsigned)max((int)u.rAux, 0) * (RM_ROW * 8u);
             lacc[s] = (unsigned)(u.cs * 4 * Ns);
             lphi[s] = (unsigned)((u.phiOff - phi0) * 8) + (unsigned)(toObs * Ns) * 512u;
             lgi[s] = u.gi;
             lgj[s] = u.gj;
             lat[s] = u.atom;
             lfl[s] = u.flags;
-            lop[s] = (u.flags & 1) ? 1.0 : 0.0;
-            lm0[s] = ((u.flags & 1) && u.ms == 0) ? 1.0 : 0.0;
-            lm1[s] = ((u.flags & 1) && u.ms == 1) ? 1.0 : 0.0;
+            lmq[s] = (unsigned)(((u.flags & 1) && (u.ms == 0 || u.ms == 1)) ? 2 + u.ms : 4) * RM_WIN_Q;
             const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
             la0[s] = sl->p[0];
             la2[s] = sl->p[2];
             la3[s] = sl->p[3];
             lcw[s] = (sl->p[1] * PI4_HC) * hw;
+            lcwOp[s] = (u.flags & 1) ? lcw[s] : 0.0; // detailed atoms: rates only
         }
     }
     unsigned mrow[NMc], maux[NMc], macc[NMc];
@@ -307,8 +335,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         if (RM_HASM(1, c))
         {
             const DevTileSlot u = ld_c(ts + nLine + c);
-            mrow[c] = (unsigned)u.r0 * L8;
-            maux[c] = (unsigned)max((int)u.rAux, 0) * L8;
+            mrow[c] = (unsigned)u.r0 * (RM_ROW * 8u);
+            maux[c] = (unsigned)max((int)u.rAux, 0) * (RM_ROW * 8u);
             macc[c] = (unsigned)(u.cs * 4 * Ns);
             mgi[c] = u.gi;
             mgj[c] = u.gj;
@@ -366,7 +394,7 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     };
 
     // buffer resources: the tile's row block (depth-major), its profile blocks, the moment block of this direction
-    const unsigned strideK = (unsigned)td.nRowsT * L8;
+    const unsigned strideK = (unsigned)td.nRowsT * (RM_ROW * 8u);
     const __amdgpu_buffer_rsrc_t rRows
         = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + td.rowBase), 0, (int)(strideK * (unsigned)Ns), 0x00020000);
     const __amdgpu_buffer_rsrc_t rPhi
@@ -387,16 +415,14 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         const unsigned so = (unsigned)k * strideK;
         const CONST_AS char* kt = ktB + (long long)(k * (int)ktS);
         g.chi = buf_ld(rRows, jb, so);
-        g.eta = buf_ld(rRows, jb, so + L8);
-        g.sca = buf_ld(rRows, jb, so + 2 * L8);
-        const int km = k - 2 * dk;
-        const CONST_AS char* ktm = ktB + (long long)(km * (int)ktS);
+        g.eta = buf_ld(rRows, jb + RM_ROW * 8u, so);
+        g.sca = buf_ld(rRows, jb + 2 * RM_ROW * 8u, so);
 #pragma unroll
         for (int s = 0; s < NLc; ++s)
         {
             g.phi[s] = 0.0;
             g.rho[s] = 1.0;
-            g.ni[s] = g.nj[s] = g.nim[s] = g.njm[s] = g.wphim[s] = 0.0;
+            g.ni[s] = g.nj[s] = 0.0;
             if (RM_HASL(2, s))
             {
                 g.phi[s] = buf_ld(rPhi, srcB, lphi[s] + (unsigned)k * 512u);
@@ -404,12 +430,6 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                     g.rho[s] = buf_ld(rRows, jb, so + laux[s]);
                 g.ni[s] = lds_(kt, lnI[s]);
                 g.nj[s] = lds_(kt, lnJ[s]);
-                if (RATES)
-                {
-                    g.nim[s] = lds_(ktm, lnI[s]);
-                    g.njm[s] = lds_(ktm, lnJ[s]);
-                    g.wphim[s] = lds_(ktm, lwO[s]);
-                }
             }
         }
         const CONST_AS char* kd = ktB + (long long)(min(k, k - dk) * (int)ktS);
@@ -444,7 +464,7 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     double* winLane = win + (jRaw * RM_WIN_PAD);
     const int qF = lane / L, jF = lane - qF * L;
     const bool flushLane = RATES && qF < 4 && jF < td.nl;
-    double* winF = win + ((qF & 3) * 16 + jF) * RM_WIN_PAD;
+    double* winF = win + (qF & 3) * RM_WIN_Q + jF * RM_WIN_PAD;
     const unsigned momV = (unsigned)((qF & 3) * L + jF) * (unsigned)Ns * 8u;
     if (RATES)
     {
@@ -477,20 +497,26 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         const int km = kOf(t - 2);
         // loads of the rate integrals of point m: issued first (used at the end of this iteration) ...
         double lr[NLc][5], mr[NMc][5], mvji[NMc];
+        double nim[NLc], njm[NLc], wphim[NLc];
         if (RATES && DO_RATES)
         {
             const unsigned so = (unsigned)km * strideK;
+            const CONST_AS char* ktm = ktB + (long long)(km * (int)ktS);
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
             {
 #pragma unroll
                 for (int q = 0; q < 5; ++q)
                     lr[s][q] = 0.0;
+                nim[s] = njm[s] = wphim[s] = 0.0;
                 if (RM_HASL(3, s))
                 {
 #pragma unroll
                     for (int q = 0; q < 5; ++q)
-                        lr[s][q] = buf_ld(rRows, jb, so + lrow[s] + (unsigned)q * L8);
+                        lr[s][q] = buf_ld(rRows, jb + (unsigned)q * (RM_ROW * 8u), so + lrow[s]);
+                    nim[s] = lds_(ktm, lnI[s]);
+                    njm[s] = lds_(ktm, lnJ[s]);
+                    wphim[s] = lds_(ktm, lwO[s]);
                 }
             }
 #pragma unroll
@@ -504,7 +530,7 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 {
 #pragma unroll
                     for (int q = 0; q < 5; ++q)
-                        mr[c][q] = buf_ld(rRows, jb, so + mrow[c] + (unsigned)q * L8);
+                        mr[c][q] = buf_ld(rRows, jb + (unsigned)q * (RM_ROW * 8u), so + mrow[c]);
                     mvji[c] = buf_ld(rRows, jb, so + maux[c]);
                 }
             }
@@ -534,7 +560,7 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 }
             }
             c0 = chi;
-            r0 = d_rcp(chi);
+            r0 = rm_rcp(chi);
             s0 = (eta + in.sca) * r0;
             if (storeDepth && active)
             {
@@ -570,14 +596,14 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 const double Cuw = c2 + ds3 * dx2;
                 const double C0 = c1 - ds3 * dx1;
                 dt1 = ds1 * (c2 + c1 + Cuw + C0) * 0.25;
-                rdt1 = d_rcp(dt1);
+                rdt1 = rm_rcp(dt1);
                 sS1 = (s1 - s2) * rdt1;
                 if (PH == PH_2)
                     dS2 = sS1; // dS_uw :247
                 else
                 {
                     // dS_central at point t-2 (:254-255): cent_deriv(dtau(t-2), dtau(t-1), S(t-3), S(t-2), S(t-1))
-                    const double P0 = fabs((sS2 * dt1 + sS1 * dt2) * d_rcp(dt1 + dt2));
+                    const double P0 = fabs((sS2 * dt1 + sS1 * dt2) * rm_rcp(dt1 + dt2));
                     dS2 = (copysign(1.0, sS1) + copysign(1.0, sS2)) * fmin(fabs(sS2), fmin(fabs(sS1), 0.5 * P0));
                 }
             }
@@ -590,27 +616,41 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 // asymptotic branch is the exact one with edt = 0.
                 const double x = dt2;
                 const double x2 = x * x, x3 = x2 * x;
-                double ex = d_exp_neg(-fmin(x, 64.0));
-                RM_KEEP(ex);
-                ex = (x > 30.0) ? 0.0 : ex;
-                const double r3 = d_rcp(x3);
-                double e1 = 1.0 - x + 0.5 * x2 - x3 * (1.0 / 6.0);
-                double a1 = 0.25 * x - 0.2 * x2 + x3 * (1.0 / 12.0), a2 = (6.0 - ex * (6.0 + 6.0 * x + 3.0 * x2 + x3)) * r3;
-                double b1 = 0.25 * x - 0.05 * x2 + x3 * (1.0 / 120.0), b2 = (6.0 * ex - 6.0 + 6.0 * x - 3.0 * x2 + x3) * r3;
-                double g1 = 0.25 * x - 0.15 * x2 + 0.05 * x3, g2 = 3.0 * (2.0 * x - 6.0 + ex * (6.0 + 4.0 * x + x2)) * r3;
-                double d1 = 0.25 * x - 0.1 * x2 + 0.025 * x3, d2 = 3.0 * (6.0 - 4.0 * x + x2 - 2.0 * ex * (3.0 + x)) * r3;
-                RM_KEEP(e1);
-                RM_KEEP(a1);
-                RM_KEEP(a2);
-                RM_KEEP(b1);
-                RM_KEEP(b2);
-                RM_KEEP(g1);
-                RM_KEEP(g2);
-                RM_KEEP(d1);
-                RM_KEEP(d2);
                 const bool small = x < 5e-2;
-                const double edt = small ? e1 : ex, al = small ? a1 : a2, be = small ? b1 : b2, ga = small ? g1 : g2,
-                             de = small ? d1 : d2;
+                double edt = 0.0, al = 0.0, be = 0.0, ga = 0.0, de = 0.0;
+                if (__builtin_amdgcn_ballot_w64(!small) != 0) // some ray of the wave is beyond the Taylor range
+                {
+                    const double ex = (x > 30.0) ? 0.0 : rm_exp_neg(-fmin(x, 64.0));
+                    const double r3 = (rdt2 * rdt2) * rdt2; // 1 / dtau^3 from the interval's 1 / dtau
+                    edt = ex;
+                    al = (6.0 - ex * (6.0 + 6.0 * x + 3.0 * x2 + x3)) * r3;
+                    be = (6.0 * ex - 6.0 + 6.0 * x - 3.0 * x2 + x3) * r3;
+                    ga = 3.0 * (2.0 * x - 6.0 + ex * (6.0 + 4.0 * x + x2)) * r3;
+                    de = 3.0 * (6.0 - 4.0 * x + x2 - 2.0 * ex * (3.0 + x)) * r3;
+                    RM_KEEP(edt);
+                    RM_KEEP(al);
+                    RM_KEEP(be);
+                    RM_KEEP(ga);
+                    RM_KEEP(de);
+                }
+                if (__builtin_amdgcn_ballot_w64(small) != 0) // some ray is within it
+                {
+                    double e1 = 1.0 - x + 0.5 * x2 - x3 * (1.0 / 6.0);
+                    double a1 = 0.25 * x - 0.2 * x2 + x3 * (1.0 / 12.0);
+                    double b1 = 0.25 * x - 0.05 * x2 + x3 * (1.0 / 120.0);
+                    double g1 = 0.25 * x - 0.15 * x2 + 0.05 * x3;
+                    double d1 = 0.25 * x - 0.1 * x2 + 0.025 * x3;
+                    RM_KEEP(e1);
+                    RM_KEEP(a1);
+                    RM_KEEP(b1);
+                    RM_KEEP(g1);
+                    RM_KEEP(d1);
+                    edt = small ? e1 : edt;
+                    al = small ? a1 : al;
+                    be = small ? b1 : be;
+                    ga = small ? g1 : ga;
+                    de = small ? d1 : de;
+                }
                 const double x_3 = x * (1.0 / 3.0);
                 const double Cuw = s3 + x_3 * dS3;
                 const double C0 = s2 - x_3 * dS2;
@@ -621,7 +661,7 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
             {
                 // the last point is piecewise linear (:306-321); its inputs are at hand now
                 dtL = 0.5 * zmu * (c1 + c2) * dhAt(kOf(Ns - 1), kOf(Ns - 2));
-                dSL = (s1 - s2) * d_rcp(dtL);
+                dSL = (s1 - s2) * rm_rcp(dtL);
             }
             if (PH == PH_L)
             {
@@ -698,7 +738,6 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
             {
                 const double PsiS = PsiStar * lamf;
                 const double wPsi = hw * PsiS;
-                double mE0 = 0.0, mE1 = 0.0;
                 // the lines' opacities at point m from the queued V_ij, V_ji and the populations of depth km
                 double xl[NLc], el[NLc], uj[NLc];
 #pragma unroll
@@ -708,11 +747,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                     if (RM_HASL(5, s))
                     {
                         uj[s] = la3[s] * vjiQ[2][s];
-                        xl[s] = in.nim[s] * vijQ[2][s] - in.njm[s] * vjiQ[2][s];
-                        el[s] = in.njm[s] * uj[s];
-                        const double we = wPsi * el[s];
-                        mE0 += we * lm0[s];
-                        mE1 += we * lm1[s];
+                        xl[s] = nim[s] * vijQ[2][s] - njm[s] * vjiQ[2][s];
+                        el[s] = njm[s] * uj[s];
                     }
                 }
                 // level sums of a slot: continuum rows + the active lines of this wavelength, selected by the tile's
@@ -740,13 +776,13 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                     if (RM_HASL(7, s))
                     {
                         const double vij = vijQ[2][s], vji = vjiQ[2][s], uji = uj[s];
-                        const double wlamu = lcw[s] * in.wphim[s];
+                        const double wlamu = lcw[s] * wphim[s];
                         double etaA = lr[s][0] + el[s], chi_i = lr[s][1] + xl[s], chi_j = lr[s][2] - xl[s];
                         double U_i = lr[s][3], U_j = lr[s][4] + uj[s];
                         if (NL > 1)
                             couple(ccL[s], etaA, chi_i, chi_j, U_i, U_j);
                         const double Ieff = I - PsiS * etaA; // compute_full_Ieff
-                        const double wop = wlamu * lop[s];   // detailed atoms: rates only
+                        const double wop = lcwOp[s] * wphim[s];
                         const double g0v = ((uji + vji * Ieff) - (PsiS * chi_i * U_j)) * wop;
                         const double g1v = ((vij * Ieff) - (PsiS * chi_j * U_i)) * wop;
                         const double r2v = I * vij * wlamu;
@@ -782,12 +818,11 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 {
                     double* wp = winLane + (m & (RM_WIN - 1));
                     lds_add(wp, hw * I);
-                    lds_add(wp + 16 * RM_WIN_PAD, wPsi);
-                    if (NL > 0)
-                    {
-                        lds_add(wp + 2 * 16 * RM_WIN_PAD, mE0);
-                        lds_add(wp + 3 * 16 * RM_WIN_PAD, mE1);
-                    }
+                    lds_add(wp + RM_WIN_Q, wPsi);
+#pragma unroll
+                    for (int s = 0; s < NLc; ++s)
+                        if (RM_HASL(7, s))
+                            lds_add(wp + lmq[s], wPsi * el[s]); // Meta of the line's atom (or the unused row)
                 }
                 if ((m & (RM_WIN - 1)) == RM_WIN - 1 || PH == PH_L)
                     flush_window(m);
