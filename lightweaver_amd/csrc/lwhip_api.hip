@@ -108,11 +108,13 @@ struct lwhip_context
     // the ray-column sweep (lwhip_raymarch.hip): tiles of structurally identical wavelengths
     bool tiled = false;
     int tileL = 12, nTiles = 0, nTileChunks = 0, nTileChunksPrd = 0, nPostChunks = 0, nPostChunksPrd = 0, nTilesPrd = 0;
+    bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
     int tileWaves = 4, maxSlotsTile = 0, maxCTTile = 1, maxCTPost = 1, tileCap = 0, ktStride = 4;
     int64_t rowsTileTot = 0, momTot = 0, phiTTot = 0;
     DevBuf<DevTile> tiles;
     DevBuf<DevTileSlot> tslots, tslotsPrd;
     DevBuf<DevTileCopy> tcopies;
+    DevBuf<DevContRec> contRec;
     DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
         postCs;
     DevBuf<double> geo, kt, rowsTile, momTile, phiT;
@@ -962,7 +964,7 @@ int build_tables(lwhip_context* c)
             {
                 acc += tile_cost(tiles[list[i]]);
                 const int remaining = n - (i + 1), remainingChunks = tgt - (made + 1);
-                if ((acc >= total * (made + 1) / tgt || remaining <= remainingChunks) && i + 1 < n && made + 1 < tgt)
+                if ((tgt >= n || acc >= total * (made + 1) / tgt || remaining <= remainingChunks) && i + 1 < n && made + 1 < tgt)
                 {
                     ck.chunkTile.push_back(i + 1);
                     ++made;
@@ -1013,10 +1015,18 @@ int build_tables(lwhip_context* c)
                 tileListPrd.push_back(i);
         }
         int tgtSweep = std::min((2 * c->nTiles + W - 1) / W, numCU * wgPerCU); // two tasks per tile (down, up)
+        // fused post-pass: the workgroup is the two wavefronts of one tile (and every tile is a workgroup)
+        c->tileFuse = W == 2 && c->batchHint <= 1 && env_int("LWHIP_TILE_FUSE", 1) != 0;
+        if (c->tileFuse)
+            tgtSweep = c->nTiles;
         if (c->batchHint > 1)
             tgtSweep = std::max(1, std::min(tgtSweep, numCU * 4 / c->batchHint));
-        tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
-        int tgtPost = std::min(c->nTiles, numCU * 2);
+        if (!c->tileFuse)
+            tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
+        // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
+        const size_t ldsPostEst = sizeof(double) * ((size_t)7 * 4 * Ns + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
+        const int postPerCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / ldsPostEst));
+        int tgtPost = std::min(c->nTiles, numCU * env_int("LWHIP_POST_PER_CU", postPerCU));
         if (c->batchHint > 1)
             tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
         TileChunking sw = chunk_tiles(all, tgtSweep, false);
@@ -1025,7 +1035,7 @@ int build_tables(lwhip_context* c)
         if (!tileListPrd.empty())
         {
             swPrd = chunk_tiles(tileListPrd, std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU), false);
-            poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * 2), true);
+            poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * postPerCU), true);
         }
         // both chunkings share one accumulator-slot capacity per kind
         c->maxCTTile = std::max(sw.maxCT, swPrd.maxCT);
@@ -1068,8 +1078,8 @@ int build_tables(lwhip_context* c)
             c->nPostChunksPrd = (int)postChunkTilePrd.size() - 1;
         }
         // LDS: the workgroup's accumulators + a 2 KB exchange row per wave (sweep); accumulators + continuum columns (post)
-        const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + (size_t)W * 5 * 16 * 9);
-        const size_t ldsPost = sizeof(double) * ((size_t)c->maxCTPost * 4 * Ns + 16 + (size_t)(c->Natom + 2 * c->NlevTot) * 256);
+        const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + std::max((size_t)W * 5 * 16 * 9, (size_t)16 + (size_t)(c->Natom + 2 * c->NlevTot) * 128));
+        const size_t ldsPost = sizeof(double) * (16 + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
         if (ldsSweep > 150 * 1024 || ldsPost > 150 * 1024)
             c->tiled = false;
     }
@@ -1264,6 +1274,35 @@ int build_tables(lwhip_context* c)
                 v.resize(1);
             return buf.upload(v);
         };
+        {
+            // the continua of every wavelength in transition order, ready-to-use offsets and level-column slots
+            std::vector<DevContRec> cr(std::max<size_t>(slots.size(), 1), DevContRec{});
+            for (int la = 0; la < c->Nla; ++la)
+            {
+                const DevLaHeader& h = hdr[la];
+                const int base = h.off + h.nLine;
+                for (int q = 0; q < h.nMixed + h.nPure; ++q)
+                {
+                    const int ord = slots[base + q]._pad;
+                    const DevSlot& sl = slots[base + ord];
+                    DevContRec r{};
+                    r.nI = (uint32_t)((size_t)sl.gi * Ns * sizeof(double));
+                    r.nJ = (uint32_t)((size_t)sl.gj * Ns * sizeof(double));
+                    r.rat = (uint32_t)((size_t)sl.row * Ns * sizeof(double));
+                    r.pOff = (uint32_t)((size_t)(h.nLine + ord) * sizeof(DevSlot) + offsetof(DevSlot, p));
+                    r.sEta = (uint16_t)sl.atom;
+                    r.sChiI = (uint16_t)(c->Natom + sl.gi);
+                    r.sChiJ = (uint16_t)(c->Natom + sl.gj);
+                    r.sUi = (uint16_t)(c->Natom + c->NlevTot + sl.gi);
+                    r.sUj = (uint16_t)(c->Natom + c->NlevTot + sl.gj);
+                    r.flags = (uint8_t)((sl.flags & 1) | (ord >= h.nMixed ? 2 : 0));
+                    r.ms = (int8_t)sl.ms;
+                    r.tr = (int16_t)slotTr[base + ord];
+                    cr[base + q] = r;
+                }
+            }
+            HIP_TRY(c->contRec.upload(cr));
+        }
         HIP_TRY(up(c->tiles, tiles));
         HIP_TRY(up(c->tslots, tslots));
         HIP_TRY(up(c->tslotsPrd, tslotsPrd));
@@ -1554,6 +1593,7 @@ int build_tile_args(lwhip_context* c)
     a.postChunkTile = c->postChunkTile.p;
     a.postSlotTr = c->postSlotTr.p;
     a.postCs = c->postCs.p;
+    a.contRec = c->contRec.p;
     a.maxCTPost = c->maxCTPost;
     a.geo = c->geo.p;
     a.temperature = c->temperature.p;
@@ -1648,7 +1688,7 @@ hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
         td.nPass = (dyn.nRaysActive == c->Nrays) ? 1 : 2;
         td.lambdaIterate = dyn.lambdaIterate;
         td.prdOnly = dyn.prdOnly;
-        td._pad = env_int("LWHIP_RM_DEBUG_MASK", 0) | (env_int("LWHIP_RM_SKIP", 0) << 8);
+        td._pad = env_int("LWHIP_RM_DEBUG_MASK", 0) | (env_int("LWHIP_RM_SKIP", 0) << 8) | (env_int("LWHIP_POST_SKIP", 0) << 12);
         const bool tprd = dyn.prdOnly != 0;
         if (tprd && c->nTileChunksPrd == 0)
             return hipSuccess;
@@ -1657,9 +1697,10 @@ hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
         hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
         if (e != hipSuccess)
             return e;
-        e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, tprd ? c->nTileChunksPrd : c->nTileChunks,
+        const bool fuse = c->tileFuse && rates && !tprd;
+        e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, fuse, tprd ? c->nTileChunksPrd : c->nTileChunks,
                               c->tileWaves, nullptr, 0, c->stream);
-        if (e != hipSuccess || !rates)
+        if (e != hipSuccess || !rates || fuse)
             return e;
         return launch_tile_post(da, ha, td, tprd ? c->nPostChunksPrd : c->nPostChunks, nullptr, 0, c->stream);
     }

@@ -204,6 +204,21 @@ struct DevTileSlot
     int16_t _pad;
     int64_t phiOff;     // lines: offset (doubles) of the tile's [2][Ns][64] block in the phiT pool
 };
+// One continuum of a wavelength for the pre / post passes: everything uniform about it ready to use (byte offsets, level
+// column slots), 32 bytes = one scalar load.  Stored per wavelength in the reference's transition order (the order in
+// which chi_eta_aux_accum adds the continua), at DevLaHeader::off + nLine.
+struct DevContRec
+{
+    uint32_t nI, nJ;            // byte offsets of n[gi][0], n[gj][0] in the population pool
+    uint32_t rat;               // byte offset of ratio[row][0] in the nStar-ratio pool
+    uint32_t pOff;              // byte offset of this continuum's p[0] relative to the wavelength's first slot record
+    uint16_t sEta, sChiI, sChiJ, sUi, sUj; // level-column slots: eta_A(atom), chi(i), chi(j), U(i), U(j)
+    uint8_t flags;              // bit 0: active atom   bit 1: "pure" (integrated by the post-pass from the angle moments)
+    int8_t ms;                  // moment slot of the atom's lines (0 / 1) or -1
+    int16_t tr;                 // global transition
+    int16_t _pad;
+};
+static_assert(sizeof(DevContRec) == 32, "DevContRec is fetched with one scalar load");
 struct DevTileCopy      // what the pre-pass writes into the tile's row block besides rows 0..2
 {
     int16_t kind;       // 0: program row (dense index src)  1: Vji of continuum ordinal src  2: rho of line slot src  3: zero
@@ -228,6 +243,7 @@ struct TileArgs
     const int32_t* postChunkTile;  // [nPostChunks + 1] tile boundaries of the post-pass workgroups
     const int32_t* postSlotTr;     // [nPostChunks * maxCTPost]
     const int32_t* postCs;         // per (wavelength slot record): accumulator slot inside its post chunk
+    const DevContRec* contRec;     // per wavelength: at DevLaHeader::off + nLine, its continua in transition order
     int32_t maxCTPost, _padB;
     const double* geo;             // [Ns][4]: |h_k - h_k+1|, its reciprocal, 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k
     const double* temperature;
@@ -278,11 +294,11 @@ struct RetileArgs
     const double* phi;
     double* phiT;
 };
-size_t raymarch_lds_bytes(const TileArgs& a, int waves);
+size_t raymarch_lds_bytes(const TileArgs& a, int waves, bool fuse);
 hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& hostArgs, int nTilesLaunch, const TileArgs* const* apList,
                            int nBatch, hipStream_t stream);
-hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int solver, int maxL,
-                             bool rates, int nChunks, int waves, const TileArgs* const* apList, int nBatch,
+hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int solver, int cap,
+                             bool rates, bool fuse, int nChunks, int waves, const TileArgs* const* apList, int nBatch,
                              hipStream_t stream);
 hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int nPostChunks,
                             const TileArgs* const* apList, int nBatch, hipStream_t stream);

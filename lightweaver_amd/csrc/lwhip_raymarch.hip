@@ -59,32 +59,50 @@ struct LevCols
     // row id as the row programs number them: 0 chi_C, 1 eta_C, 2 + atom, 2 + Natom + level, 2 + Natom + NlevTot + level
     DEVINL double row(int id) const { return lev[(size_t)(id - 2) * T]; }
 };
-DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, const CONST_AS DevSlot* us, const GLOBAL_AS DevSlot* ls,
-                        int nCont, int k, double rT, double hc_kl, double& chiC, double& etaC)
+enum { RM_CB = 8 }; // continua of a wavelength the post-pass integrates from registers (more: a slower general walk)
+// chi_C += sum chi_c, eta_C += sum eta_c and the level sums of the active atoms, continua in transition order.
+// `cr`: the wavelength's continuum records (uniform); `lsB`: this thread's wavelength, byte address of its first slot record
+// (the per-wavelength parameters p[]); kB = 8 k.  The next continuum's record and loads are requested before the
+// current one is used.
+DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, const CONST_AS DevContRec* cr, const GLOBAL_AS char* lsB,
+                        int nCont, unsigned kB, double boltz, double& chiC, double& etaC)
 {
-    const int Ns = TA.Ns;
     const int nLev = lc.Natom + 2 * lc.NlevTot;
     for (int q = 0; q < nLev; ++q)
         lc.lev[(size_t)q * lc.T] = 0.0;
-    const double boltz = d_exp_neg(-hc_kl * rT);
+    if (nCont <= 0)
+        return;
+    const GLOBAL_AS char* nB = (const GLOBAL_AS char*)TA.n;
+    const GLOBAL_AS char* rB = (const GLOBAL_AS char*)TA.ratio;
+    auto ldd = [](const GLOBAL_AS char* b, unsigned o) { return *(const GLOBAL_AS double*)(b + o); };
+    DevContRec r = ld_c(cr);
+    double ratio = ldd(rB + r.rat, kB), ni = ldd(nB + r.nI, kB), nj = ldd(nB + r.nJ, kB), p0 = ldd(lsB, r.pOff), p2 = ldd(lsB, r.pOff + 16);
     for (int q = 0; q < nCont; ++q)
     {
-        const int c = us[q]._pad;
-        const CONST_AS DevSlot& u = us[c];
-        const double p0 = ls[c].p[0];
-        const double nj = GCD(TA.n)[u.gj * Ns + k];
-        const double vji = (GCD(TA.ratio)[(size_t)u.row * Ns + k] * boltz) * p0;
-        const double chi_c = GCD(TA.n)[u.gi * Ns + k] * p0 - nj * vji;
-        const double uji = ls[c].p[2] * vji;
-        const double eta_c = nj * uji;
+        const DevContRec rc = r;
+        const double ratioC = ratio, niC = ni, njC = nj, p0C = p0, p2C = p2;
+        if (q + 1 < nCont)
+        {
+            r = ld_c(cr + q + 1);
+            ratio = ldd(rB + r.rat, kB);
+            ni = ldd(nB + r.nI, kB);
+            nj = ldd(nB + r.nJ, kB);
+            p0 = ldd(lsB, r.pOff);
+            p2 = ldd(lsB, r.pOff + 16);
+        }
+        const double vji = (ratioC * boltz) * p0C;
+        const double chi_c = niC * p0C - njC * vji;
+        const double uji = p2C * vji;
+        const double eta_c = njC * uji;
         chiC += chi_c;
         etaC += eta_c;
-        if (u.flags & 1)
+        if (rc.flags & 1)
         {
-            lc.etaA(u.atom) += eta_c;
-            lc.chi(u.gi) += chi_c;
-            lc.chi(u.gj) -= chi_c;
-            lc.U(u.gj) += uji;
+            // LDS adds without a return value: no read-modify-write round trip, executed in program order
+            lds_add(lc.lev + (size_t)rc.sEta * lc.T, eta_c);
+            lds_add(lc.lev + (size_t)rc.sChiI * lc.T, chi_c);
+            lds_add(lc.lev + (size_t)rc.sChiJ * lc.T, -chi_c);
+            lds_add(lc.lev + (size_t)rc.sUj * lc.T, uji);
         }
     }
 }
@@ -134,6 +152,7 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
     const int off = ((const GLOBAL_AS DevLaHeader*)TA.laHdr)[la].off;
     const int nCont = h.nMixed + h.nPure;
     const CONST_AS DevSlot* us = CTAB(DevSlot, TA.slots) + h.off + h.nLine;
+    const CONST_AS DevContRec* cr = CTAB(DevContRec, TA.contRec) + h.off + h.nLine;
     const GLOBAL_AS DevSlot* lsAll = (const GLOBAL_AS DevSlot*)TA.slots + off;
     const GLOBAL_AS DevSlot* ls = lsAll + h.nLine;
     const LevCols lc{ lds + threadIdx.x, RM_PRE_T, TA.Natom, TA.NlevTot };
@@ -141,11 +160,13 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
     const double hc_kl = HC_K / GCD(TA.wavelength)[la];
     const size_t o = (size_t)la * Ns + k;
     double chiC = GCD(TA.bgChi)[o], etaC = GCD(TA.bgEta)[o];
-    cont_levels(ap, lc, us, ls, nCont, k, rT, hc_kl, chiC, etaC);
+    const double scaJ = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
+    const double boltz = d_exp_neg(-hc_kl * rT);
+    cont_levels(ap, lc, cr, (const GLOBAL_AS char*)lsAll, nCont, (unsigned)k * 8u, boltz, chiC, etaC);
     GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (size_t)k * td.nRowsT * RM_ROW + j;
     out[0] = chiC;
     out[RM_ROW] = etaC;
-    out[2 * RM_ROW] = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
+    out[2 * RM_ROW] = scaJ;
     const CONST_AS DevTileCopy* cp = CTAB(DevTileCopy, TA.copies) + td.copyOff;
     for (int q = 0; q < td.nCopy; ++q)
     {
@@ -154,7 +175,7 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
         if (c.kind == 0)
             v = lc.row(c.src);
         else if (c.kind == 1) // V_ji of a mixed continuum
-            v = (GCD(TA.ratio)[(size_t)us[c.src].row * Ns + k] * d_exp_neg(-hc_kl * rT)) * ls[c.src].p[0];
+            v = (GCD(TA.ratio)[(size_t)us[c.src].row * Ns + k] * boltz) * ls[c.src].p[0];
         else if (c.kind == 2)
             v = GCD(TA.rho)[lsAll[c.src].rhoOff + k];
         out[(size_t)c.dst * RM_ROW] = v;
@@ -885,10 +906,241 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     step(std::integral_constant<int, PH_L>{}, Ns + 1, gA, gB);
 }
 
+// ---- post-pass: pure continua from the angle moments, J out, dJ ------------------------------------------------------
+// sum_r w_r [Uji + Vji (I_r - Psi_r eta_r) - Psi_r chi_i U_j] with chi, U, Uji, Vji ray-independent and
+// eta_r = etaC + etaLine_r  ->  Uji W + Vji (J - M1 etaC - Meta) - M1 chi_i U_j: an exact regrouping of
+// compute_full_operator_rates :206-234 for continua whose level sums do not depend on the ray.
+//
+// post_tile: lane <-> depth (T threads cover depths k0 .. k0 + T - 1), the tile is walked wavelength by wavelength.
+// What depends on depth only (nStar ratios, populations, 1 / T) is fetched once per tile and stays in registers for
+// its wavelengths; what depends on the wavelength only is the same for every lane (broadcast loads, requested one
+// wavelength ahead); the integrals of the tile's pure continua accumulate in registers (a lane owns its depth) and
+// leave with one atomic add per (continuum, component, depth) into the stage-1 buffer.  Called by the sweep's
+// workgroup right after its two wavefronts have marched the tile in both directions (the moments are still in L2),
+// or by the stand-alone kernel below.
+struct PostLa // this lane's moments of one wavelength (both directions), its J of the last iteration
+{
+    double Jd, Ju, M1d, M1u, E0d, E0u, E1d, E1u, Jdag;
+};
+struct PostP { double p0, p1, p2, p3; }; // per-(continuum, wavelength) parameters: one scalar load
+template <int T>
+DEVINL void post_tile(const TileArgs* __restrict__ ap, const DevTile& td, const bool doCont, const int part, double* levCols,
+                      unsigned long long* sDj, const int t)
+{
+    const int Ns = TA.Ns, L = TA.L, Nmu = TA.Nmu;
+    const LevCols lc{ levCols + t, T, TA.Natom, TA.NlevTot };
+    const int nLev = lc.Natom + 2 * lc.NlevTot;
+    double Wsum = 0.0; // total quadrature weight of the rays of the iteration, in ray order
+    for (int m = 0; m < Nmu; ++m)
+        for (int d = 0; d < 2; ++d)
+            Wsum += 0.5 * CTAB(double, TA.wmu)[m];
+    const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0); // the tile's (uniform) structure
+    const int nCont = (doCont && h.nPure > 0) ? h.nMixed + h.nPure : 0;
+    const CONST_AS DevContRec* cr = CTAB(DevContRec, TA.contRec) + h.off + h.nLine;
+    const GLOBAL_AS double* momT = GCD(TA.mom) + td.momBase;
+    const size_t ds = (size_t)Ns * 4 * L, qs = (size_t)L * Ns;
+    GLOBAL_AS double* r8 = GD(TA.red8);
+    const GLOBAL_AS char* nB = (const GLOBAL_AS char*)TA.n;
+    const GLOBAL_AS char* rB = (const GLOBAL_AS char*)TA.ratio;
+    const CONST_AS char* slB = (const CONST_AS char*)TA.slots;
+    const int n4 = 4 * Ns;
+    auto ldd = [](const GLOBAL_AS char* b, unsigned o) { return *(const GLOBAL_AS double*)(b + o); };
+    if (t < 16)
+        sDj[t] = 0ull;
+    __syncthreads();
+    for (int k0 = 0; k0 < Ns; k0 += T) // deep atmospheres: the depth axis in slices of the workgroup
+    {
+        const int k = k0 + t;
+        const bool kOk = k < Ns;
+        const int kc = min(k, Ns - 1);
+        const unsigned kB = (unsigned)kc * 8u;
+        const double rT = GCD(TA.geo)[4 * kc + 3];
+        const bool single = nCont <= RM_CB;
+        double acc[RM_CB][4]; // the tile's integrals of its pure continua at this depth
+#pragma unroll
+        for (int i = 0; i < RM_CB; ++i)
+            acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
+        auto load_la = [&](int j, PostLa& w) {
+            const GLOBAL_AS double* mp = momT + (size_t)j * Ns + kc;
+            w.Jd = mp[0];
+            w.Ju = mp[ds];
+            w.M1d = mp[qs];
+            w.M1u = mp[ds + qs];
+            w.E0d = mp[2 * qs];
+            w.E0u = mp[ds + 2 * qs];
+            w.E1d = mp[3 * qs];
+            w.E1u = mp[ds + 3 * qs];
+            w.Jdag = GCD(TA.J)[(size_t)(td.la0 + j) * Ns + kc];
+        };
+        PostLa wA, wB;
+        load_la(0, wA);
+        wB = wA;
+        auto one_la = [&](int j, const PostLa& w, PostLa& nx) {
+            if (j + 1 < td.nl)
+                load_la(j + 1, nx);
+            const int la = td.la0 + j;
+            // the two directions' sums (two wave tasks of the sweep), added in that order
+            const double Jk = w.Jd + w.Ju;
+            if (nCont > 0)
+            {
+                const double M1 = w.M1d + w.M1u, Me0 = w.E0d + w.E0u, Me1 = w.E1d + w.E1u;
+                const double boltz = d_exp_neg(-(HC_K / CTAB(double, TA.wavelength)[la]) * rT);
+                // this wavelength's slot records: the per-(continuum, wavelength) parameters are uniform -> scalar loads
+                const CONST_AS char* lsB = slB + (size_t)CTAB(DevLaHeader, TA.laHdr)[la].off * sizeof(DevSlot);
+                for (int q = 0; q < nLev; ++q)
+                    lc.lev[(size_t)q * T] = 0.0;
+                // level sums of the active atoms, continua in transition order (LDS adds without a return value: no
+                // read-modify-write round trip, executed in program order)
+                for (int q = 0; q < nCont; ++q)
+                {
+                    const DevContRec rc = ld_c(cr + q);
+                    const PostP pp = ld_c((const CONST_AS PostP*)(lsB + rc.pOff));
+                    const double njq = ldd(nB + rc.nJ, kB);
+                    const double vji = (ldd(rB + rc.rat, kB) * boltz) * pp.p0;
+                    const double chi_c = ldd(nB + rc.nI, kB) * pp.p0 - njq * vji;
+                    const double uji = pp.p2 * vji;
+                    if (rc.flags & 1)
+                    {
+                        lds_add(lc.lev + (size_t)rc.sEta * T, njq * uji);
+                        lds_add(lc.lev + (size_t)rc.sChiI * T, chi_c);
+                        lds_add(lc.lev + (size_t)rc.sChiJ * T, -chi_c);
+                        lds_add(lc.lev + (size_t)rc.sUj * T, uji);
+                    }
+                }
+                // the pure continua of the wavelength (every level sum is complete)
+                if (single)
+                {
+#pragma unroll
+                    for (int i = 0; i < RM_CB; ++i)
+                    {
+                        if (i < nCont)
+                        {
+                            const DevContRec rc = ld_c(cr + i);
+                            if (rc.flags & 2)
+                            {
+                                const PostP pp = ld_c((const CONST_AS PostP*)(lsB + rc.pOff));
+                                const double vij = pp.p0, wla = pp.p1;
+                                const double vji = (ldd(rB + rc.rat, kB) * boltz) * vij;
+                                const double uji = pp.p2 * vji;
+                                if (rc.flags & 1)
+                                {
+                                    const double Meta = (rc.ms == 0) ? Me0 : (rc.ms == 1) ? Me1 : 0.0;
+                                    const double Jeff = Jk - M1 * lc.lev[(size_t)rc.sEta * T] - Meta;
+                                    acc[i][0] += ((uji * Wsum + vji * Jeff) - (M1 * lc.lev[(size_t)rc.sChiI * T] * lc.lev[(size_t)rc.sUj * T])) * wla;
+                                    acc[i][1] += ((vij * Jeff) - (M1 * lc.lev[(size_t)rc.sChiJ * T] * lc.lev[(size_t)rc.sUi * T])) * wla;
+                                }
+                                acc[i][2] += Jk * vij * wla;
+                                acc[i][3] += (uji * Wsum + Jk * vji) * wla;
+                            }
+                        }
+                    }
+                }
+                else if (kOk)
+                {
+                    // more than 8 continua at one wavelength (rare): straight into the stage-1 buffer
+                    for (int q = 0; q < nCont; ++q)
+                    {
+                        const DevContRec rc = ld_c(cr + q);
+                        if (!(rc.flags & 2))
+                            continue;
+                        const PostP pp = ld_c((const CONST_AS PostP*)(lsB + rc.pOff));
+                        const double vij = pp.p0, wla = pp.p1;
+                        const double vji = (ldd(rB + rc.rat, kB) * boltz) * vij;
+                        const double uji = pp.p2 * vji;
+                        GLOBAL_AS double* dst = r8 + ((size_t)rc.tr * LWHIP_REDUCE_SPLIT + part) * n4 + k;
+                        if (rc.flags & 1)
+                        {
+                            const double Meta = (rc.ms == 0) ? Me0 : (rc.ms == 1) ? Me1 : 0.0;
+                            const double Jeff = Jk - M1 * lc.lev[(size_t)rc.sEta * T] - Meta;
+                            unsafeAtomicAdd((double*)dst, ((uji * Wsum + vji * Jeff) - (M1 * lc.lev[(size_t)rc.sChiI * T] * lc.lev[(size_t)rc.sUj * T])) * wla);
+                            unsafeAtomicAdd((double*)(dst + Ns), ((vij * Jeff) - (M1 * lc.lev[(size_t)rc.sChiJ * T] * lc.lev[(size_t)rc.sUi * T])) * wla);
+                        }
+                        unsafeAtomicAdd((double*)(dst + 2 * Ns), Jk * vij * wla);
+                        unsafeAtomicAdd((double*)(dst + 3 * Ns), (uji * Wsum + Jk * vji) * wla);
+                    }
+                }
+            }
+            // J out, dJ = max_k |1 - Jdag / J|  :477-486
+            double dj = 0.0;
+            if (kOk)
+            {
+                GD(TA.J)[(size_t)la * Ns + k] = Jk;
+                dj = fabs(1.0 - w.Jdag / Jk);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                dj = fmax(dj, __shfl_xor(dj, o));
+            if ((t & 63) == 0) // non-negative doubles order as integers; no barrier here: it would drain the prefetch
+                atomicMax(sDj + j, (unsigned long long)__double_as_longlong(dj));
+        };
+        for (int j = 0; j < td.nl; j += 2)
+        {
+            one_la(j, wA, wB);
+            if (j + 1 < td.nl)
+                one_la(j + 1, wB, wA);
+        }
+        if (single && kOk)
+        {
+            // the tile's integrals of this depth leave for the stage-1 buffer (part = tile % SPLIT spreads the adders)
+#pragma unroll
+            for (int i = 0; i < RM_CB; ++i)
+                if (i < nCont)
+                {
+                    const DevContRec rc = ld_c(cr + i);
+                    if (rc.flags & 2)
+                    {
+                        GLOBAL_AS double* dst = r8 + ((size_t)rc.tr * LWHIP_REDUCE_SPLIT + part) * n4 + k;
+                        if (rc.flags & 1)
+                        {
+                            unsafeAtomicAdd((double*)dst, acc[i][0]);
+                            unsafeAtomicAdd((double*)(dst + Ns), acc[i][1]);
+                        }
+                        unsafeAtomicAdd((double*)(dst + 2 * Ns), acc[i][2]);
+                        unsafeAtomicAdd((double*)(dst + 3 * Ns), acc[i][3]);
+                    }
+                }
+        }
+        // the wavelengths' dJ: both waves' maxima are in
+        __syncthreads();
+        if (t < td.nl)
+        {
+            const double all = __longlong_as_double((long long)sDj[t]);
+            GLOBAL_AS double* dJp = GD(TA.dJ) + td.la0 + t;
+            *dJp = (k0 == 0) ? all : fmax(*dJp, all);
+            sDj[t] = 0ull;
+        }
+        __syncthreads();
+    }
+}
+
+// stand-alone post-pass (column batches, PRD rates pass, workgroups of the sweep that hold more than one tile)
+enum { RM_POST_T = 128 };
+template <bool BATCH>
+__global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
+                                                              const TileDyn dyn, const int32_t* __restrict__ chunkTile,
+                                                              const int32_t* __restrict__ tileList)
+{
+    extern __shared__ double lds[];
+    const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
+    unsigned long long* sDj = (unsigned long long*)lds; // [16]
+    double* cols = lds + 16;                            // [Natom + 2 NlevTot][T]
+    const int chunk = blockIdx.x;
+    const int t0 = CTAB(int32_t, chunkTile)[chunk], t1 = CTAB(int32_t, chunkTile)[chunk + 1];
+    const bool doCont = !dyn.prdOnly && !(dyn._pad & 0x2000); // the PRD rates pass needs J and dJ only (0x2000: timing experiment)
+    for (int li = t0; li < t1; ++li)
+    {
+        const int ti = tileList ? CTAB(int32_t, tileList)[li] : li;
+        const DevTile td = ld_c(CTAB(DevTile, TA.tiles) + ti);
+        post_tile<RM_POST_T>(ap, td, doCont, ti % LWHIP_REDUCE_SPLIT, cols, sDj, (int)threadIdx.x);
+    }
+}
+
 // CAP == 0: the tiles of the launch are all of the kinds (0,0), (1,0), (1,1), (2,0) lines + mixed continua, each with
 // its own straight-line march; otherwise every tile goes through the guarded generic march of capacity CAP lines + CAP
 // mixed continua.
-template <int SOLVER, int CAP, bool RATES, bool BATCH>
+// FUSE: the workgroup is the two wavefronts (down, up) of ONE tile and finishes it with the post-pass (post_tile) while
+// the tile's moments are still in L2: no separate post launch, its accumulators in the march's free registers.
+template <int SOLVER, int CAP, bool RATES, bool BATCH, bool FUSE>
 __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileArgs* __restrict__ ap0,
                                                                       const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
@@ -957,6 +1209,15 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
         else
             march_tile<SOLVER, (CAP > 0 ? CAP : 1), (CAP > 0 ? CAP : 1), RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
     }
+    if (RATES && FUSE)
+    {
+        __syncthreads(); // both directions of the tile are marched, their moment stores have left the wavefronts
+        const int li = t0;
+        const int ti = tileList ? tileList[li] : li;
+        const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
+        unsigned long long* sDj = (unsigned long long*)(lds + (size_t)maxCT * 4 * Ns);
+        post_tile<128>(ap, td, !dyn.prdOnly, ti % LWHIP_REDUCE_SPLIT, (double*)(sDj + 16), sDj, t);
+    }
     if (RATES)
     {
         __syncthreads();
@@ -973,114 +1234,6 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
             if (tr >= 0)
                 unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + (idx - cs * n4)), sAcc[idx]);
         }
-    }
-}
-
-// ---- post-pass: pure continua from the angle moments, J out, dJ ------------------------------------------------------
-// sum_r w_r [Uji + Vji (I_r - Psi_r eta_r) - Psi_r chi_i U_j] with chi, U, Uji, Vji ray-independent and
-// eta_r = etaC + etaLine_r  ->  Uji W + Vji (J - M1 etaC - Meta) - M1 chi_i U_j: an exact regrouping of
-// compute_full_operator_rates :206-234 for continua whose level sums do not depend on the ray.
-enum { RM_POST_T = 256 };
-template <bool BATCH>
-__global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
-                                                              const TileDyn dyn, const int32_t* __restrict__ chunkTile,
-                                                              const int32_t* __restrict__ tileList)
-{
-    extern __shared__ double lds[];
-    const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
-    const int Ns = TA.Ns, L = TA.L, Nmu = TA.Nmu;
-    const int maxCT = TA.maxCTPost;
-    const int t = threadIdx.x;
-    double* sAcc = lds;                                         // [maxCT][4][Ns]
-    unsigned long long* sDj = (unsigned long long*)(sAcc + (size_t)maxCT * 4 * Ns); // [16]
-    double* cols = (double*)(sDj + 16);                         // [Natom + 2 NlevTot][T]
-    const LevCols lc{ cols + t, RM_POST_T, TA.Natom, TA.NlevTot };
-    const int chunk = blockIdx.x;
-    const int t0 = CTAB(int32_t, chunkTile)[chunk], t1 = CTAB(int32_t, chunkTile)[chunk + 1];
-    const bool doCont = !dyn.prdOnly; // the PRD rates pass needs J and dJ only
-    for (int idx = t; idx < maxCT * 4 * Ns; idx += RM_POST_T)
-        sAcc[idx] = 0.0;
-    double Wsum = 0.0; // total quadrature weight of the rays of the iteration, in ray order
-    for (int m = 0; m < Nmu; ++m)
-        for (int d = 0; d < 2; ++d)
-            Wsum += 0.5 * CTAB(double, TA.wmu)[m];
-    for (int li = t0; li < t1; ++li)
-    {
-        const int ti = tileList ? CTAB(int32_t, tileList)[li] : li;
-        const DevTile td = ld_c(CTAB(DevTile, TA.tiles) + ti);
-        if (t < 16)
-            sDj[t] = 0ull;
-        __syncthreads();
-        const int P = td.nl * Ns;
-        const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0); // the tile's (uniform) structure
-        const int nCont = h.nMixed + h.nPure;
-        const CONST_AS DevSlot* us = CTAB(DevSlot, TA.slots) + h.off + h.nLine;
-        for (int p = t; p < P; p += RM_POST_T)
-        {
-            const int j = p / Ns;
-            const int k = p - j * Ns;
-            const int la = td.la0 + j;
-            const int off = ((const GLOBAL_AS DevLaHeader*)TA.laHdr)[la].off;
-            const GLOBAL_AS DevSlot* ls = (const GLOBAL_AS DevSlot*)TA.slots + off + h.nLine;
-            // moment block [down, up][J, M1, Meta0, Meta1][L][Ns]: the two directions (two wave tasks of the sweep) are added
-            // in that order
-            const GLOBAL_AS double* mp = GCD(TA.mom) + td.momBase + (size_t)j * Ns + k;
-            const size_t ds = (size_t)Ns * 4 * L, qs = (size_t)L * Ns;
-            const double Jk = mp[0] + mp[ds];
-            if (doCont && h.nPure > 0)
-            {
-                const double M1 = mp[qs] + mp[ds + qs], Me0 = mp[2 * qs] + mp[ds + 2 * qs], Me1 = mp[3 * qs] + mp[ds + 3 * qs];
-                const double rT = GCD(TA.geo)[4 * k + 3];
-                const double hc_kl = HC_K / GCD(TA.wavelength)[la];
-                double chiC = 0.0, etaC = 0.0;
-                cont_levels(ap, lc, us, ls, nCont, k, rT, hc_kl, chiC, etaC);
-                const double boltz = d_exp_neg(-hc_kl * rT);
-                for (int c = h.nMixed; c < nCont; ++c)
-                {
-                    const CONST_AS DevSlot& sl = us[c];
-                    const double vij = ls[c].p[0];
-                    const double vji = (GCD(TA.ratio)[(size_t)sl.row * Ns + k] * boltz) * vij;
-                    const double uji = ls[c].p[2] * vji;
-                    const double wla = ls[c].p[1];
-                    const int cs = CTAB(int32_t, TA.postCs)[h.off + h.nLine + c];
-                    double* acc = sAcc + (size_t)cs * 4 * Ns + k;
-                    if (sl.flags & 1)
-                    {
-                        const double Meta = (sl.ms == 0) ? Me0 : (sl.ms == 1) ? Me1 : 0.0;
-                        const double Jeff = Jk - M1 * lc.etaA(sl.atom) - Meta;
-                        const double g0v = ((uji * Wsum + vji * Jeff) - (M1 * lc.chi(sl.gi) * lc.U(sl.gj))) * wla;
-                        const double g1v = ((vij * Jeff) - (M1 * lc.chi(sl.gj) * lc.U(sl.gi))) * wla;
-                        lds_add(acc, g0v);
-                        lds_add(acc + Ns, g1v);
-                    }
-                    lds_add(acc + 2 * Ns, Jk * vij * wla);
-                    lds_add(acc + 3 * Ns, (uji * Wsum + Jk * vji) * wla);
-                }
-            }
-            // J out, dJ = max_k |1 - Jdag / J|  :477-486
-            GLOBAL_AS double* Jp = GD(TA.J) + (size_t)la * Ns + k;
-            const double Jdag = *Jp;
-            *Jp = Jk;
-            const double dj = fabs(1.0 - Jdag / Jk);
-            atomicMax(sDj + j, (unsigned long long)__double_as_longlong(dj)); // non-negative doubles order as integers
-        }
-        __syncthreads();
-        if (t < td.nl)
-            GD(TA.dJ)[td.la0 + t] = __longlong_as_double((long long)sDj[t]);
-        __syncthreads();
-    }
-    if (!doCont)
-        return;
-    const CONST_AS int32_t* slotTr = CTAB(int32_t, TA.postSlotTr) + (size_t)chunk * maxCT;
-    GLOBAL_AS double* r8 = GD(TA.red8);
-    const int n4 = 4 * Ns;
-    const int part = chunk % LWHIP_REDUCE_SPLIT;
-    for (int idx = t; idx < maxCT * n4; idx += RM_POST_T)
-    {
-        const int cs = idx / n4;
-        const int tr = slotTr[cs];
-        if (tr >= 0)
-            unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + (idx - cs * n4)), sAcc[idx]);
     }
 }
 
@@ -1118,9 +1271,13 @@ hipError_t launch_retile(const RetileArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-size_t raymarch_lds_bytes(const TileArgs& a, int waves)
+size_t raymarch_lds_bytes(const TileArgs& a, int waves, bool fuse)
 {
-    return sizeof(double) * ((size_t)a.maxCT * 4 * a.Ns + (size_t)waves * RM_WIN_DOUBLES);
+    // accumulators + the waves' moment windows; the fused post-pass reuses the windows' space for the dJ row and the
+    // threads' level columns
+    const size_t win = (size_t)waves * RM_WIN_DOUBLES;
+    const size_t post = fuse ? 16 + (size_t)(a.Natom + 2 * a.NlevTot) * 128 : 0;
+    return sizeof(double) * ((size_t)a.maxCT * 4 * a.Ns + std::max(win, post));
 }
 
 hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& a, int nTilesLaunch, const TileArgs* const* apList, int nBatch,
@@ -1145,60 +1302,69 @@ hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& a, int nTile
     return hipGetLastError();
 }
 
-template <int SOLVER, int CAP, bool RATES>
+template <int SOLVER, int CAP, bool RATES, bool FUSE>
 static hipError_t launch_rm_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int nChunks, int waves,
                               const TileArgs* const* apList, int nBatch, hipStream_t stream)
 {
-    const size_t lds = raymarch_lds_bytes(a, waves);
+    const size_t lds = raymarch_lds_bytes(a, waves, FUSE);
     if (lds > 48 * 1024)
     {
-        hipError_t e = hipFuncSetAttribute(apList ? (const void*)raymarch_kernel<SOLVER, CAP, RATES, true>
-                                                  : (const void*)raymarch_kernel<SOLVER, CAP, RATES, false>,
+        hipError_t e = hipFuncSetAttribute(apList ? (const void*)raymarch_kernel<SOLVER, CAP, RATES, true, FUSE>
+                                                  : (const void*)raymarch_kernel<SOLVER, CAP, RATES, false, FUSE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
     if (apList)
-        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, true>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds,
+        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, true, FUSE>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds,
                            stream, devArgs, apList, dyn);
     else
-        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, false>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList,
+        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, false, FUSE>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList,
                            dyn);
     return hipGetLastError();
 }
 
 // cap: 0 = every tile is one of the fast kinds; otherwise the generic march's capacity (lines, and mixed continua)
-template <int SOLVER, bool RATES>
+template <int SOLVER, bool RATES, bool FUSE>
 static hipError_t launch_rm_s(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int cap, int nChunks, int waves,
                               const TileArgs* const* apList, int nBatch, hipStream_t stream)
 {
     if (cap == 0)
-        return launch_rm_t<SOLVER, 0, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+        return launch_rm_t<SOLVER, 0, RATES, FUSE>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
     if (cap <= 2)
-        return launch_rm_t<SOLVER, 2, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+        return launch_rm_t<SOLVER, 2, RATES, FUSE>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
     if (cap <= 4)
-        return launch_rm_t<SOLVER, 4, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
-    return launch_rm_t<SOLVER, 8, RATES>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+        return launch_rm_t<SOLVER, 4, RATES, FUSE>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+    return launch_rm_t<SOLVER, 8, RATES, FUSE>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
 }
 
+template <int SOLVER>
+static hipError_t launch_rm_r(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int cap, bool rates, bool fuse,
+                              int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream)
+{
+    if (!rates)
+        return launch_rm_s<SOLVER, false, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+    if (fuse)
+        return launch_rm_s<SOLVER, true, true>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+    return launch_rm_s<SOLVER, true, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+}
+
+// fuse: every workgroup is the two wavefronts of one tile (waves == 2, one tile per chunk) and runs the post-pass itself
 hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int solver, int cap, bool rates,
-                             int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream)
+                             bool fuse, int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream)
 {
     if (nChunks <= 0)
         return hipSuccess;
-    if (cap > 8 || waves < 1 || waves > RM_MAX_WAVES)
+    if (cap > 8 || waves < 1 || waves > RM_MAX_WAVES || (fuse && (waves != 2 || !rates || dyn.nPass != 2)))
         return hipErrorInvalidValue;
     switch (solver)
     {
         case LWHIP_FS_LINEAR_1D:
-            return rates ? launch_rm_s<LWHIP_FS_LINEAR_1D, true>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream)
-                         : launch_rm_s<LWHIP_FS_LINEAR_1D, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+            return launch_rm_r<LWHIP_FS_LINEAR_1D>(devArgs, a, dyn, cap, rates, fuse, nChunks, waves, apList, nBatch, stream);
         case LWHIP_FS_BESSER_1D:
-            return rates ? launch_rm_s<LWHIP_FS_BESSER_1D, true>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream)
-                         : launch_rm_s<LWHIP_FS_BESSER_1D, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+            return launch_rm_r<LWHIP_FS_BESSER_1D>(devArgs, a, dyn, cap, rates, fuse, nChunks, waves, apList, nBatch, stream);
         default:
-            return rates ? launch_rm_s<LWHIP_FS_BEZIER3_1D, true>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream)
-                         : launch_rm_s<LWHIP_FS_BEZIER3_1D, false>(devArgs, a, dyn, cap, nChunks, waves, apList, nBatch, stream);
+            return launch_rm_r<LWHIP_FS_BEZIER3_1D>(devArgs, a, dyn, cap, rates, fuse, nChunks, waves, apList, nBatch, stream);
     }
 }
 
@@ -1207,7 +1373,7 @@ hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& a, const Ti
 {
     if (nPostChunks <= 0)
         return hipSuccess;
-    const size_t lds = sizeof(double) * ((size_t)a.maxCTPost * 4 * a.Ns + 16 + (size_t)(a.Natom + 2 * a.NlevTot) * RM_POST_T);
+    const size_t lds = sizeof(double) * (16 + (size_t)(a.Natom + 2 * a.NlevTot) * RM_POST_T);
     if (lds > 48 * 1024)
     {
         hipError_t e = hipFuncSetAttribute(apList ? (const void*)tile_post_kernel<true> : (const void*)tile_post_kernel<false>,
