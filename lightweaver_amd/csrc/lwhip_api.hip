@@ -1694,10 +1694,14 @@ hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
             return hipSuccess;
         const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
         const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
-        hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
+        const bool fuse = c->tileFuse && rates && !tprd;
+        const bool fusePre = fuse && env_int("LWHIP_TILE_FUSE", 1) == 3; // the sweep's workgroups also write their own row blocks
+        if (fusePre)
+            td._pad |= 0x4000;
+        hipError_t e = fusePre ? launch_depth_table(da, nullptr, 0, c->stream)
+                               : launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
         if (e != hipSuccess)
             return e;
-        const bool fuse = c->tileFuse && rates && !tprd;
         e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, fuse, tprd ? c->nTileChunksPrd : c->nTileChunks,
                               c->tileWaves, nullptr, 0, c->stream);
         if (e != hipSuccess || !rates || fuse)

@@ -303,6 +303,7 @@ hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, 
 hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int nPostChunks,
                             const TileArgs* const* apList, int nBatch, hipStream_t stream);
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
+hipError_t launch_depth_table(const TileArgs* devArgs, const TileArgs* const* apList, int nBatch, hipStream_t stream);
 
 enum { LWHIP_REDUCE_SPLIT = 8 };
 struct ReduceArgs

@@ -108,54 +108,49 @@ DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, cons
 }
 
 // ---- pre-pass: the tiles' row blocks and the depth table ----------------------------------------------------------
-// grid (tile, part[, column]); thread <-> point p = k * L + j of the tile (wavelength fastest: coalesced row writes)
 enum { RM_PRE_T = 256 };
 enum { RM_ROW = 16 }; // doubles per row of a tile's row block (L <= 16 used): row offsets are instruction immediates
-template <bool BATCH>
-__global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
-                                                            const int32_t* __restrict__ tileList)
+// the depth table: everything the march reads per depth only, contiguous per depth (scalar loads off one base)
+DEVINL void depth_table(const TileArgs* __restrict__ ap, int t, int T)
 {
-    extern __shared__ double lds[];
-    const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.z] : ap0;
-    const int Ns = TA.Ns, L = TA.L;
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    const int Ns = TA.Ns, st = TA.ktStride, NlevTot = TA.NlevTot, Nline = TA.Nline;
+    for (int idx = t; idx < (Ns + 2) * st; idx += T)
     {
-        // the depth table: everything the march reads per depth only, contiguous per depth (scalar loads off one base)
-        const int st = TA.ktStride, NlevTot = TA.NlevTot, Nline = TA.Nline;
-        for (int idx = threadIdx.x; idx < (Ns + 2) * st; idx += RM_PRE_T)
-        {
-            const int k = idx / st - 1, q = idx - (k + 1) * st; // entries -1 and Ns are padding (read, never used)
-            double v = 0.0;
-            if (k < 0 || k >= Ns)
-                v = 0.0;
-            else if (q < 4)
-                v = GCD(TA.geo)[4 * k + q];
-            else if (q < 4 + NlevTot)
-                v = GCD(TA.n)[(size_t)(q - 4) * Ns + k];
-            else if (q < 4 + NlevTot + Nline)
-                v = GCD(TA.wphi)[(size_t)(q - 4 - NlevTot) * Ns + k];
-            GD(TA.kt)[idx] = v;
-        }
+        const int k = idx / st - 1, q = idx - (k + 1) * st; // entries -1 and Ns are padding (read, never used)
+        double v = 0.0;
+        if (k < 0 || k >= Ns)
+            v = 0.0;
+        else if (q < 4)
+            v = GCD(TA.geo)[4 * k + q];
+        else if (q < 4 + NlevTot)
+            v = GCD(TA.n)[(size_t)(q - 4) * Ns + k];
+        else if (q < 4 + NlevTot + Nline)
+            v = GCD(TA.wphi)[(size_t)(q - 4 - NlevTot) * Ns + k];
+        GD(TA.kt)[idx] = v;
     }
-    const int ti = tileList ? CTAB(int32_t, tileList)[blockIdx.x] : (int)blockIdx.x;
-    const DevTile td = ld_c(CTAB(DevTile, TA.tiles) + ti);
-    const int p = blockIdx.y * RM_PRE_T + threadIdx.x;
-    if (p >= Ns * L)
-        return;
+}
+__global__ void __launch_bounds__(256) depth_table_kernel(const TileArgs* __restrict__ ap, const TileArgs* const* __restrict__ apList)
+{
+    if (apList)
+        ap = apList[blockIdx.x];
+    depth_table(ap, threadIdx.x, 256);
+}
+// one point p = k * L + j of a tile (wavelength fastest: coalesced row writes): its rows of the tile's row block
+DEVINL void pre_point(const TileArgs* __restrict__ ap, const DevTile& td, const DevLaHeader& h, const LevCols& lc, int p)
+{
+    const int Ns = TA.Ns, L = TA.L;
     const int k = p / L;
     const int j = p - k * L;
     if (j >= td.nl)
         return;
     const int la = td.la0 + j;
     // structure from the tile's first wavelength (uniform), parameters from this thread's own
-    const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0);
     const int off = ((const GLOBAL_AS DevLaHeader*)TA.laHdr)[la].off;
     const int nCont = h.nMixed + h.nPure;
     const CONST_AS DevSlot* us = CTAB(DevSlot, TA.slots) + h.off + h.nLine;
     const CONST_AS DevContRec* cr = CTAB(DevContRec, TA.contRec) + h.off + h.nLine;
     const GLOBAL_AS DevSlot* lsAll = (const GLOBAL_AS DevSlot*)TA.slots + off;
     const GLOBAL_AS DevSlot* ls = lsAll + h.nLine;
-    const LevCols lc{ lds + threadIdx.x, RM_PRE_T, TA.Natom, TA.NlevTot };
     const double rT = GCD(TA.geo)[4 * k + 3];
     const double hc_kl = HC_K / GCD(TA.wavelength)[la];
     const size_t o = (size_t)la * Ns + k;
@@ -180,6 +175,24 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
             v = GCD(TA.rho)[lsAll[c.src].rhoOff + k];
         out[(size_t)c.dst * RM_ROW] = v;
     }
+}
+// stand-alone pre-pass: grid (tile, part[, column]); block (0, 0) also refreshes the depth table
+template <bool BATCH>
+__global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
+                                                            const int32_t* __restrict__ tileList)
+{
+    extern __shared__ double lds[];
+    const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.z] : ap0;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        depth_table(ap, threadIdx.x, RM_PRE_T);
+    const int ti = tileList ? CTAB(int32_t, tileList)[blockIdx.x] : (int)blockIdx.x;
+    const DevTile td = ld_c(CTAB(DevTile, TA.tiles) + ti);
+    const int p = blockIdx.y * RM_PRE_T + threadIdx.x;
+    if (p >= TA.Ns * TA.L)
+        return;
+    const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0);
+    const LevCols lc{ lds + threadIdx.x, RM_PRE_T, TA.Natom, TA.NlevTot };
+    pre_point(ap, td, h, lc, p);
 }
 
 // ---- cross-lane helpers -------------------------------------------------------------------------------------------
@@ -1164,6 +1177,19 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
         __syncthreads();
     }
     const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
+    if (RATES && FUSE && (dyn._pad & 0x4000))
+    {
+        // (option, measured slower than the stand-alone pre-pass: LWHIP_TILE_FUSE=3)
+        // the tile's row block first (the depth table comes from depth_table_kernel, launched before): the workgroup's 128
+        // threads walk the tile's points; the rows are read back by the march through L2
+        const int ti = tileList ? tileList[t0] : t0;
+        const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
+        const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + td.la0);
+        const LevCols lc{ lds + (size_t)maxCT * 4 * Ns + 16 + t, 128, a.Natom, a.NlevTot };
+        for (int p = t; p < Ns * a.L; p += 128)
+            pre_point(ap, td, h, lc, p);
+        __syncthreads(); // (drains the row stores: s_waitcnt vmcnt(0) precedes the barrier)
+    }
     // tasks of the chunk: (tile, direction); both directions unless the launch is up-only
     const int nDir = dyn.nPass;
     for (int task = t0 * nDir + wave; task < t1 * nDir; task += nWaves)
@@ -1268,6 +1294,12 @@ hipError_t launch_retile(const RetileArgs& a, hipStream_t stream)
     if (a.nTiles <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(retile_kernel, dim3(a.nTiles, 8), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_depth_table(const TileArgs* devArgs, const TileArgs* const* apList, int nBatch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(depth_table_kernel, dim3(std::max(nBatch, 1)), dim3(256), 0, stream, devArgs, apList);
     return hipGetLastError();
 }
 
