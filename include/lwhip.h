@@ -402,10 +402,11 @@ int lwhip_synchronize(lwhip_context* ctx);
 /* Use `stream` (hipStream_t) for all subsequent launches; NULL = the library's own. */
 int lwhip_set_stream(lwhip_context* ctx, void* stream);
 
-/* Measurement support (bench.py): when enabled, sweep launches are bracketed by HIP events on the
- * launch stream -- every launch for enable = 1, every n-th for enable = n > 1 (two event records cost
- * ~5 us of a 460 us step) -- and lwhip_sweep_time returns the mean duration (ms) and the number of
- * launches timed since the last reset. */
+/* Measurement support (bench.py): when enabled, launches of the sweep kernel (raymarch_kernel, the
+ * dominant kernel of the iteration; not the pre-pass or the apply launch) are bracketed by HIP events on
+ * the launch stream -- every launch for enable = 1, every n-th for enable = n > 1 (two event records
+ * cost ~5 us of a 250 us step) -- and lwhip_sweep_time returns the mean duration (ms) and the number
+ * of launches timed since the last reset. */
 int lwhip_profile_enable(lwhip_context* ctx, int enable);
 int lwhip_sweep_time(lwhip_context* ctx, double* meanMs, int* nLaunches);
 

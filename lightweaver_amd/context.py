@@ -155,6 +155,9 @@ class Context:
         _check(lib, st, 'lwhip_formal_sol_gamma_matrices')
         if not deviceResident:
             self.download(abi.ALL_OUTPUTS | (abi.DEPTHDATA if self.prob.storeDepthData else 0))
+        if not sync_host:
+            # nothing was read back: a convergence test must not mistake "not known yet" for dJMax = 0
+            return IterationUpdate(updatedJ=True, dJMax=float('nan'), dJMaxIdx=-1, crsw=self.crsw)
         return IterationUpdate(updatedJ=True, dJMax=res.dJMax, dJMaxIdx=res.dJMaxIdx, crsw=self.crsw)
 
     def formal_sol(self, upOnly=True, deviceResident=False):
@@ -261,7 +264,9 @@ class Context:
         prevTimePops: list of [Nlevel, Nspace] arrays, one per active atom (the reference's
         `prevTimePops`); Gamma must hold the operator of the current iterate."""
         active = [ia for ia, a in enumerate(self.prob.atoms) if not a.detailed]
+        before = None
         if not deviceResident:
+            before = [np.array(self.prob.atoms[ia].n, dtype=np.float64, copy=True) for ia in active]
             self.upload(abi.GAMMA | abi.POPS)
         for q, ia in enumerate(active):
             if atom is not None and ia != atom:
@@ -271,7 +276,24 @@ class Context:
                    'lwhip_time_dep_update')
         if not deviceResident:
             self.download(abi.POPS)
+            return self._rel_diff_pops(active, before)
         return IterationUpdate(updatedPops=True)
+
+    def _rel_diff_pops(self, active, before) -> IterationUpdate:
+        """LwContext.rel_diff_pops (Source/LwMiddleLayer.pyx:3294-3316 -> Ng::relative_change_from_prev,
+        Source/Ng.hpp:116-136): per active atom max |(n - nPrev) / n| over the entries with n != 0 and the
+        flattened [level, depth] index of the first maximum; nPrev = the populations before this update."""
+        dPops, dIdx = [], []
+        for ia, prev in zip(active, before):
+            n = np.asarray(self.prob.atoms[ia].n, dtype=np.float64).reshape(-1)
+            p = prev.reshape(-1)
+            ch = np.zeros_like(n)
+            nz = n != 0.0
+            ch[nz] = np.abs((n[nz] - p[nz]) / n[nz])
+            i = int(np.argmax(ch)) if ch.size else 0
+            dPops.append(float(ch[i]) if ch.size else 0.0)
+            dIdx.append(i)
+        return IterationUpdate(updatedPops=True, dPops=dPops, dPopsMaxIdx=dIdx)
 
     def nr_post_update(self, stages, backgroundNe, ne, dC=None, nPrev=None, dt=0.0, atoms=None,
                        deviceResident=False) -> IterationUpdate:
@@ -281,12 +303,15 @@ class Context:
         `nPrev` are per-atom lists (dC / nPrev optional)."""
         if atoms is None:
             atoms = [ia for ia, a in enumerate(self.prob.atoms) if not a.detailed]
+        before = None
         if not deviceResident:
+            before = [np.array(self.prob.atoms[ia].n, dtype=np.float64, copy=True) for ia in atoms]
             self.upload(abi.GAMMA | abi.POPS | abi.COLLISIONS)
         args, keep = abi.make_nr_args(atoms, stages, backgroundNe, ne, dC=dC, nPrev=nPrev, dt=dt, crsw=self.crsw)
         _check(self.lib, self.lib.lwhip_nr_post_update(self._h, C.byref(args)), 'lwhip_nr_post_update')
         if not deviceResident:
             self.download(abi.POPS)
+            return self._rel_diff_pops(atoms, before)
         return IterationUpdate(updatedPops=True)
 
     def check_status(self):

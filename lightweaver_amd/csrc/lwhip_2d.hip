@@ -3,7 +3,7 @@
 //
 // A 2D domain (Nz x Nx = 20 992 points per ray at BASELINE config 5) does not fit the fused 1D sweep, so the
 // iteration runs batch by batch over the wavelengths with its per-ray intermediates in HBM:
-//   cont_kernel (lwhip_march.hip)   continuum rows of the batch, once per (wavelength, point)
+//   cont_kernel                     continuum rows of the batch, once per (wavelength, point)
 //   gather2d_kernel                 chi, S per (wavelength, ray, point)         :113-179
 //   fs2d_coef / fs2d_scan (lwhip_fs2d.hip)   I, Psi* per (wavelength, ray)
 //   rates2d_kernel                  J, Gamma / rate integrals, dJ               :181-234, 477-486
@@ -18,6 +18,90 @@
 
 namespace lwhip
 {
+#define ARGS (*launder_args(ap))
+
+// ---- continuum rows: everything about the continua that does not depend on the ray ------------------
+// Atom::setup_wavelength (LwAtom.hpp:107-115) + Transition::uv (LwTransition.hpp:132-142) +
+// chi_eta_aux_accum (SimdFullIterationTemplates.hpp:59-109) for the continua of one wavelength:
+// Vji_c, the totals chiC = bgChi + sum chi_c, etaC = bgEta + sum eta_c, and the per-atom / per-level
+// sums the preconditioned rates need, written once per (wavelength, depth) for all rays to read.
+__global__ void __launch_bounds__(128) cont_kernel(const ContArgs* __restrict__ ap, int contOff, double* rowsBase)
+{
+    extern __shared__ double lds[]; // [2 * maxC][blockDim.x]: thread-private columns
+    const int Ns = ARGS.Ns;
+    const int T = blockDim.x;
+    const int la = CTAB(int32_t, ARGS.contLa)[contOff + blockIdx.x];
+    const DevLaHeader h = ld_c(CTAB(DevLaHeader, ARGS.laHdr) + la);
+    const CONST_AS DevSlot* slots = CTAB(DevSlot, ARGS.slots) + h.off + h.nLine;
+    const int nCont = h.nMixed + h.nPure;
+    const DevProgram pg = ld_c(CTAB(DevProgram, ARGS.progs) + h.prog);
+    const CONST_AS DevProgRow* prow = CTAB(DevProgRow, ARGS.progRows) + pg.rowOff;
+    const CONST_AS DevProgEnt* pent = CTAB(DevProgEnt, ARGS.progEnts) + pg.entOff;
+    const double hc_kl = HC_K / CTAB(double, ARGS.wavelength)[la];
+    double* colV = lds + threadIdx.x;
+    double* colX = lds + (size_t)ARGS.maxC * T + threadIdx.x;
+    const GLOBAL_AS double* gN = GCD(ARGS.n);
+    // rowsBase: a window of the row numbering (2D iteration: only a batch of wavelengths is resident)
+    GLOBAL_AS double* out = (rowsBase ? (GLOBAL_AS double*)rowsBase : GD(ARGS.rows)) + (size_t)h.rowBase * Ns;
+    // blockIdx.y strides over the points (2D domains: tens of thousands of points per wavelength)
+    for (int k = blockIdx.y * T + threadIdx.x; k < Ns; k += gridDim.y * T)
+    {
+        const double boltz = d_exp_neg(-hc_kl * (1.0 / GCD(ARGS.temperature)[k]));
+        for (int c = 0; c < nCont; ++c)
+        {
+            const CONST_AS DevSlot& sl = slots[c];
+            const double gij = GCD(ARGS.ratio)[(size_t)sl.row * Ns + k] * boltz;
+            const double vji = gij * sl.p[0];
+            colV[(size_t)c * T] = vji;
+            colX[(size_t)c * T] = gN[sl.gi * Ns + k] * sl.p[0] - gN[sl.gj * Ns + k] * vji;
+            out[(size_t)(h.nRows + c) * Ns + k] = vji;
+        }
+        for (int ri = 0; ri < pg.nRows; ++ri)
+        {
+            const DevProgRow pr = ld_c(prow + ri);
+            double v = 0.0;
+            if (pr.row == 0)
+                v = GCD(ARGS.bgChi)[(size_t)la * Ns + k];
+            else if (pr.row == 1)
+                v = GCD(ARGS.bgEta)[(size_t)la * Ns + k];
+            for (int e = 0; e < pr.nEnt; ++e) // continua in reference order
+            {
+                const DevProgEnt en = ld_c(pent + pr.entOff + e);
+                const double x = colX[(size_t)en.c * T];
+                const double uji = slots[en.c].p[2] * colV[(size_t)en.c * T];
+                if (en.kind == 0)
+                    v += x;
+                else if (en.kind == 1)
+                    v -= x;
+                else if (en.kind == 2)
+                    v += uji;
+                else
+                    v += gN[slots[en.c].gj * Ns + k] * uji;
+            }
+            out[(size_t)ri * Ns + k] = v;
+        }
+    }
+}
+
+hipError_t launch_cont_range(const ContArgs* devArgs, const ContArgs& a, int contOff, int nCont, double* rowsBase,
+                             hipStream_t stream)
+{
+    if (nCont <= 0)
+        return hipSuccess;
+    const int T = 128;
+    const size_t lds = (size_t)2 * a.maxC * T * sizeof(double);
+    if (lds > 48 * 1024)
+    {
+        hipError_t err = hipFuncSetAttribute((const void*)cont_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess)
+            return err;
+    }
+    const int ky = std::max(1, std::min(64, (a.Ns + T - 1) / T));
+    hipLaunchKernelGGL(cont_kernel, dim3(nCont, ky), dim3(T), lds, stream, devArgs, contOff, rowsBase);
+    return hipGetLastError();
+}
+#undef ARGS
+
 namespace
 {
 // ---- gather: Transition::uv + chi_eta_aux_accum + compute_source_fn for one (wavelength, ray, point) ----------

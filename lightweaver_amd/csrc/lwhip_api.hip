@@ -98,13 +98,11 @@ struct lwhip_context
     int worldSize = 1, worldRank = 0;
     int laStart = 0, laEnd = 0, Nla = 0;
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
-    int maxL = 0, maxC = 0, maxCT = 1, nChunks = 0, nChunksPrd = 0, G = 1;
-    bool big = false;
+    int maxL = 0, maxC = 0;
     bool is2d = false;            // x-periodic 2D geometry (prob.grid2d): batched pipeline of lwhip_2d.hip
     int Nx = 1, batch2d = 1;
     std::vector<DevLaHeader> hdrHost;
     std::vector<int32_t> contLaHost;
-    bool march = true;            // wavefront-autonomous sweep (lwhip_march.hip); false: the LDS-column sweep
     // the ray-column sweep (lwhip_raymarch.hip): tiles of structurally identical wavelengths
     bool tiled = false;
     int tileL = 12, nTiles = 0, nTileChunks = 0, nTileChunksPrd = 0, nPostChunks = 0, nPostChunksPrd = 0, nTilesPrd = 0;
@@ -120,10 +118,8 @@ struct lwhip_context
     DevBuf<double> geo, kt, rowsTile, momTile, phiT;
     DevBuf<TileArgs> dtargs, dtargsPrd;
     TileArgs htargs{}, htargsPrd{};
-    int marchD = 7, marchS = 12, marchWaves = 4;
     int64_t rowsTot = 0;
     int nContLa = 0;
-    bool accGlobal = false;
     int64_t gammaTot = 0, phiTot = 0, rhoTot = 0, parTot = 0;
     hipStream_t ownStream = nullptr, stream = nullptr;
 
@@ -166,23 +162,19 @@ struct lwhip_context
     double* prdPinned = nullptr;
     DevBuf<DevTrans> dtrans;
     DevBuf<DevLaHeader> laHdr;
-    DevBuf<DevSlot> slots, slotsPrd;
+    DevBuf<DevSlot> slots;
     DevBuf<DevProgram> progs;
     DevBuf<DevProgRow> progRows;
     DevBuf<DevProgEnt> progEnts;
-    DevBuf<SweepArgs> dargs, dargsPrd;
-    SweepArgs hargs{}, hargsPrd{};
-    DevBuf<int32_t> chunkLaPrd, trOffPrd, trRowPrd, laListPrd;
-    DevBuf<int32_t> slotTrRows;   // [nChunks*maxCT] transition of every slab row (atomic output of the one-call iteration)
+    DevBuf<ContArgs> dargs;      // 2D: argument block of the continuum-row kernel
+    ContArgs hargs{};
     bool atomicParts = false;     // the pending iteration's parts were accumulated by atomics
     bool red8Clean = false;       // red8 holds zeros (only the atomic path leaves it so)
-    DevBuf<int32_t> chunkLa, trOff, trRow, atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
+    DevBuf<int32_t> atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
     DevBuf<int64_t> atomGammaOff;
-    DevBuf<double> partial, red, red8, dJ;
+    DevBuf<double> red, red8, dJ;
     std::vector<double> gatherHost;
     DevBuf<int32_t> status;
-    DevBuf<long long> stamps;
-    DevBuf<double> bigScratch;
 
     bool profiling = false;
     int profEvery = 1, profCount = 0; // time every profEvery-th sweep launch (lwhip_profile_enable(ctx, n))
@@ -686,138 +678,17 @@ int build_tables(lwhip_context* c)
     if (c->maxC < 1)
         c->maxC = 1;
 
-    // ---- chunks of wavelengths (one workgroup each), balanced by a simple cost model --------------
     int numCU = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
         numCU = prop.multiProcessorCount;
-    // two workgroups per CU for a context that has the device to itself; a member of a column batch (batchHint
-    // co-resident contexts, one grid slice each) needs fewer, longer chunks: less per-chunk set-up and slab traffic
-    int target = numCU * 2;
-    if (c->batchHint > 1)
-        target = std::max(64, std::min(numCU * 2, numCU * 16 / c->batchHint));
-    target = env_int("LWHIP_CHUNKS", target);
-    target = std::max(1, std::min(target, c->Nla));
-    std::vector<double> cost(c->Nla);
-    bool anyPrd = false;
-    for (int la = 0; la < c->Nla; ++la)
-    {
-        // fitted to per-chunk cycle counts of the stamped build (tools/stamps.py, LWHIP_DUMP_CHUNKS)
-        // (refitted with a term for the workgroup's dispatch half, see the skew below: without it the fit blamed the
-        // continua for what was the partner's priority; residual 2.3 % of a chunk's cycles)
-        cost[la] = 1.0 + 0.255 * hdr[la].nLine + 0.148 * hdr[la].nMixed + 0.078 * hdr[la].nPure;
-        anyPrd = anyPrd || hdr[la].hasPrd;
-    }
-    // A chunking = wavelength boundaries + the accumulator slot of every slot record inside its chunk.
-    // The full sweep balances all wavelengths; the PRD rates pass visits only wavelengths with a PRD
-    // line, so it gets its own chunking balanced over those (same kernels, second table set).
-    struct Chunking
-    {
-        std::vector<int32_t> chunkLa, cs;
-        std::vector<std::vector<int>> chunkTrans;
-        int maxCT = 1;
-    };
-    // `las`: the wavelengths the launch visits, in order; chunk boundaries index into it
-    auto make_chunking = [&](const std::vector<int32_t>& las) {
-        Chunking ck;
-        const int Nl = (int)las.size();
-        const int tgt = std::max(1, std::min(target, Nl));
-        double total = 0.0;
-        for (int la : las)
-            total += cost[la];
-        ck.chunkLa.push_back(0);
-        double acc = 0.0;
-        int made = 0;
-        // The two workgroups of a CU are not equals: the one dispatched first (chunk < tgt / 2: the dispatcher fills
-        // every CU once before it doubles up) holds the older wavefronts, which the CU's arbiters favour, and runs
-        // ~8 % faster than its partner (measured on equal-cost chunks).  Give it that much more work, so that both
-        // finish together instead of the second one finishing alone.
-        const double skew = (tgt == target && tgt >= 2 && tgt % 2 == 0) ? 1e-3 * env_int("LWHIP_SKEW", 110) : 0.0;
-        auto cum_share = [&](int nDone) { // share of the total cost the first nDone chunks should hold
-            const int half = tgt / 2;
-            const double first = std::min(nDone, half) * (1.0 + skew), second = std::max(nDone - half, 0) * (1.0 - skew);
-            return (first + second) / tgt;
-        };
-        for (int li = 0; li < Nl; ++li)
-        {
-            acc += cost[las[li]];
-            const int remainingLa = Nl - (li + 1);
-            const int remainingChunks = tgt - (made + 1);
-            if ((acc >= total * cum_share(made + 1) || remainingLa <= remainingChunks) && li + 1 < Nl && made + 1 < tgt)
-            {
-                ck.chunkLa.push_back(li + 1);
-                made++;
-            }
-        }
-        ck.chunkLa.push_back(Nl);
-        const int nch = (int)ck.chunkLa.size() - 1;
-        ck.chunkTrans.resize(nch);
-        ck.cs.assign(slots.size(), 0);
-        for (int ch = 0; ch < nch; ++ch)
-        {
-            std::vector<int> slotOf(c->Ntrans, -1);
-            for (int li = ck.chunkLa[ch]; li < ck.chunkLa[ch + 1]; ++li)
-            {
-                const int la = las[li];
-                const int n = hdr[la].nLine + hdr[la].nMixed + hdr[la].nPure;
-                for (int e = 0; e < n; ++e)
-                {
-                    const int tr = slotTr[hdr[la].off + e];
-                    if (slotOf[tr] < 0)
-                    {
-                        slotOf[tr] = (int)ck.chunkTrans[ch].size();
-                        ck.chunkTrans[ch].push_back(tr);
-                    }
-                    ck.cs[hdr[la].off + e] = slotOf[tr];
-                }
-            }
-            ck.maxCT = std::max(ck.maxCT, (int)ck.chunkTrans[ch].size());
-        }
-        return ck;
-    };
-    auto make_rows = [&](const Chunking& ck, int maxCT, std::vector<int32_t>& trOff, std::vector<int32_t>& trRow) {
-        trOff.assign(c->Ntrans + 1, 0);
-        trRow.clear();
-        for (int tr = 0; tr < c->Ntrans; ++tr)
-        {
-            trOff[tr] = (int32_t)trRow.size();
-            for (int ch = 0; ch < (int)ck.chunkTrans.size(); ++ch)
-                for (int s = 0; s < (int)ck.chunkTrans[ch].size(); ++s)
-                    if (ck.chunkTrans[ch][s] == tr)
-                        trRow.push_back(ch * maxCT + s);
-        }
-        trOff[c->Ntrans] = (int32_t)trRow.size();
-    };
-    std::vector<int32_t> lasAll(c->Nla), lasPrd;
-    for (int la = 0; la < c->Nla; ++la)
-    {
-        lasAll[la] = la;
-        if (hdr[la].hasPrd)
-            lasPrd.push_back(la);
-    }
-    const Chunking full = make_chunking(lasAll);
-    const Chunking prdCk = anyPrd ? make_chunking(lasPrd) : Chunking{};
-    const std::vector<int32_t>& chunkLa = full.chunkLa;
-    c->nChunks = (int)full.chunkLa.size() - 1;
-    c->nChunksPrd = anyPrd ? (int)prdCk.chunkLa.size() - 1 : 0;
-    c->maxCT = std::max(full.maxCT, prdCk.maxCT);
-    for (size_t e = 0; e < slots.size(); ++e)
-        slots[e].cs = full.cs[e];
-    std::vector<int32_t> trOff, trRow, trOffPrd, trRowPrd;
-    make_rows(full, c->maxCT, trOff, trRow);
-    std::vector<DevSlot> slotsPrd;
-    if (anyPrd)
-    {
-        make_rows(prdCk, c->maxCT, trOffPrd, trRowPrd);
-        slotsPrd = slots;
-        for (size_t e = 0; e < slots.size(); ++e)
-            slotsPrd[e].cs = prdCk.cs[e];
-    }
 
     // ---- tiles of the ray-column sweep (lwhip_raymarch.hip) -----------------------------------------------------
     // A tile = up to L consecutive wavelengths with the same slot records (same transitions in the same order, same
     // row program): one wavefront marches it, lane = (mu, wavelength).
-    c->tiled = !c->is2d && env_int("LWHIP_SWEEP", 4) >= 4 && c->Nrays <= 64 && Ns >= 3;
+    c->tiled = !c->is2d;
+    if (c->tiled && (c->Nrays > 64 || Ns < 3))
+        return fail(LWHIP_ERR_UNSUPPORTED, "the sweep needs Nrays <= 64 and Nspace >= 3");
     std::vector<DevTile> tiles;
     std::vector<DevTileSlot> tslots, tslotsPrd;
     std::vector<DevTileCopy> tcopies;
@@ -932,8 +803,9 @@ int build_tables(lwhip_context* c)
                 std::fprintf(stderr, "  tiles with %d lines + %d mixed continua: %d (%d wavelengths)\n", kv.first.first, kv.first.second,
                              kv.second.first, kv.second.second);
         }
-        if (c->maxSlotsTile > 8)
-            c->tiled = false; // more lines + mixed continua at one wavelength than the march holds in registers
+        for (auto& td : tiles)
+            if (td.nLine > 8 || td.nMixed > 8)
+                return fail(LWHIP_ERR_UNSUPPORTED, "more than 8 lines (or 8 continua coupled to them) overlap at one wavelength");
     }
     if (c->tiled)
     {
@@ -1081,93 +953,10 @@ int build_tables(lwhip_context* c)
         const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + std::max((size_t)W * 5 * 16 * 9, (size_t)16 + (size_t)(c->Natom + 2 * c->NlevTot) * 128));
         const size_t ldsPost = sizeof(double) * (16 + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
         if (ldsSweep > 150 * 1024 || ldsPost > 150 * 1024)
-            c->tiled = false;
+            return fail(LWHIP_ERR_UNSUPPORTED, "problem does not fit the 160 KB LDS budget of one workgroup");
     }
 
-    // ---- sweep geometry ---------------------------------------------------------------------------------
     const int NR2 = 2 * c->Nrays;
-    size_t ldsMax = 160 * 1024;
-    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor > 0)
-        ldsMax = prop.maxSharedMemoryPerMultiProcessor;
-    // March kernel: D depth points per lane, S = ceil(Ns / D) lanes per ray, R = 64 / S rays per pass.
-    // Pick the D that needs the fewest lane-steps for all rays (ties: the smaller D, less serial work).
-    c->march = env_int("LWHIP_SWEEP", 2) >= 3;
-    if (!c->is2d)
-    {
-        int bestD = 0;
-        long bestCost = 0;
-        for (int D : { 4, 7, 8 })
-        {
-            const int S = (Ns + D - 1) / D;
-            if (S > 64 || Ns < 3)
-                continue;
-            const int R = std::min(64 / S, NR2);
-            const long passes = (NR2 + R - 1) / R;
-            const long cost = passes * (D + 3); // + the per-pass shuffles / scan
-            if (bestD == 0 || cost < bestCost)
-            {
-                bestD = D;
-                bestCost = cost;
-            }
-        }
-        const int Denv = env_int("LWHIP_D", 0);
-        if (Denv == 2 || Denv == 3 || Denv == 4 || Denv == 7 || Denv == 8)
-            if ((Ns + Denv - 1) / Denv <= 64)
-                bestD = Denv;
-        if (bestD == 0)
-            c->march = false; // deeper than 512 points: the LDS-column sweep in its global-scratch mode
-        else
-        {
-            c->marchD = bestD;
-            c->marchS = (Ns + bestD - 1) / bestD;
-        }
-        c->marchWaves = std::max(1, std::min(8, env_int("LWHIP_MWAVES", 4)));
-        // populations, wphi and the moment rows must fit the LDS (accumulators may go to the slab)
-        SweepArgs sz{};
-        sz.Ns = Ns;
-        sz.maxCT = c->maxCT;
-        sz.NlevTot = c->NlevTot;
-        sz.Nline = c->Nline;
-        sz.accGlobal = 1;
-        if (march_lds_bytes(sz, c->marchWaves) > 64 * 1024)
-            c->march = false;
-    }
-    if (c->is2d)
-        c->march = false; // neither 1D sweep applies: the batched 2D pipeline (run_2d) does
-    if (!c->march && !c->is2d)
-    {
-    auto ldsFor = [&](int g) {
-        SweepArgs s{};
-        s.Ns = Ns;
-        s.Natom = c->Natom;
-        s.NlevTot = c->NlevTot;
-        s.maxC = c->maxC;
-        s.maxCT = c->maxCT;
-        s.big = c->big ? 1 : 0;
-        return sweep_lds_bytes(s, g);
-    };
-    // deep atmospheres: when even one ray per pass does not fit the LDS, keep the per-depth rows,
-    // continuum tables and accumulators in a global (L2-resident) scratch instead
-    c->big = env_int("LWHIP_BIG", 0) != 0 || ldsFor(1) > ldsMax;
-    // Rays per pass.  Two co-resident workgroups per CU hide each other's barrier and latency
-    // stalls (measured: 0.51 ms vs 0.66 ms per sweep on the north-star grid), so prefer half of
-    // the rays per pass when two such workgroups fit the 160 KB LDS; otherwise all rays at once;
-    // otherwise as many as fit one workgroup (1024 threads, LDS).
-    const int Gmax = std::max(1, std::min(NR2, 1024 / Ns));
-    int G = Gmax;
-    const int half = (NR2 + 1) / 2;
-    if (half <= Gmax && half * Ns >= 256 && 2 * ldsFor(half) <= ldsMax)
-        G = half;
-    const int Genv = env_int("LWHIP_G", 0);
-    if (Genv > 0)
-        G = std::max(1, std::min(Genv, Gmax));
-    while (G > 1 && ldsFor(G) > ldsMax)
-        --G;
-    if (ldsFor(G) > ldsMax)
-        return fail(LWHIP_ERR_UNSUPPORTED, "problem does not fit the 160 KB LDS budget of one workgroup");
-    c->G = G;
-    }
-
     // ---- device tables ---------------------------------------------------------------------------------
     std::vector<DevTrans> dt(c->Ntrans);
     std::vector<int32_t> li(c->Ntrans), lj(c->Ntrans);
@@ -1243,28 +1032,10 @@ int build_tables(lwhip_context* c)
     HIP_TRY(c->progs.upload(progs));
     HIP_TRY(c->progRows.upload(progRows));
     HIP_TRY(c->progEnts.upload(progEnts));
-    HIP_TRY(c->chunkLa.upload(chunkLa));
-    if (anyPrd)
-    {
-        HIP_TRY(c->slotsPrd.upload(slotsPrd));
-        HIP_TRY(c->chunkLaPrd.upload(prdCk.chunkLa));
-        HIP_TRY(c->laListPrd.upload(lasPrd));
-        HIP_TRY(c->trOffPrd.upload(trOffPrd));
-        HIP_TRY(c->trRowPrd.upload(trRowPrd));
-    }
     if (contLaHost.empty())
         contLaHost.push_back(0);
     c->nContLa = (c->rowsTot > 0) ? (int)contLaHost.size() : 0;
     HIP_TRY(c->contLa.upload(contLaHost));
-    HIP_TRY(c->trOff.upload(trOff));
-    HIP_TRY(c->trRow.upload(trRow));
-    {
-        std::vector<int32_t> rowTr((size_t)std::max(c->nChunks, 1) * c->maxCT, -1);
-        for (int tr = 0; tr < c->Ntrans; ++tr)
-            for (int e = trOff[tr]; e < trOff[tr + 1]; ++e)
-                rowTr[trRow[e]] = tr;
-        HIP_TRY(c->slotTrRows.upload(rowTr));
-    }
     HIP_TRY(c->rayAll.upload(rayAll));
     HIP_TRY(c->rayUp.upload(rayUp));
     if (c->tiled)
@@ -1377,8 +1148,6 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(hipMemset(c->Cmat.p, 0, c->Cmat.n * sizeof(double)));
     HIP_TRY(c->Rij.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     HIP_TRY(c->Rji.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
-    // (the 2D pipeline sums straight into the reduce buffer: no per-chunk slabs)
-    HIP_TRY(c->partial.alloc(c->is2d ? 8 : (size_t)std::max(c->nChunks, c->nChunksPrd) * c->maxCT * 4 * Ns));
     // reduce buffer: [Ntrans,4,Ns] partial sums followed by one (dJMax, idx) slot per shard
     HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize * (1 + c->prdLines.size())));
     HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
@@ -1386,15 +1155,6 @@ int alloc_state(lwhip_context* c)
     c->gatherHost.assign(2 * (size_t)c->worldSize, 0.0);
     HIP_TRY(c->dJ.alloc(Nla));
     HIP_TRY(c->status.alloc(1));
-    if (c->big)
-    {
-        SweepArgs sz{};
-        sz.Ns = c->Ns;
-        sz.Natom = c->Natom;
-        sz.NlevTot = c->NlevTot;
-        sz.maxC = c->maxC;
-        HIP_TRY(c->bigScratch.alloc((size_t)std::max(c->nChunks, c->nChunksPrd) * sweep_big_scratch_doubles(sz)));
-    }
     if (c->tiled)
     {
         HIP_TRY(c->geo.alloc(4 * Ns));
@@ -1404,19 +1164,6 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(c->momTile.alloc((size_t)std::max<int64_t>(c->momTot, 1)));
         HIP_TRY(c->phiT.alloc((size_t)std::max<int64_t>(c->phiTTot, 1)));
         HIP_TRY(hipMemset(c->momTile.p, 0, c->momTile.n * sizeof(double)));
-    }
-    if (c->march)
-    {
-        HIP_TRY(c->rowsBuf.alloc((size_t)std::max<int64_t>(c->rowsTot, 1) * c->Ns));
-        // accumulators in LDS when they leave room for >= 2 workgroups per CU, else in the chunk's slab
-        SweepArgs sz{};
-        sz.Ns = c->Ns;
-        sz.maxCT = c->maxCT;
-        sz.NlevTot = c->NlevTot;
-        sz.Nline = c->Nline;
-        sz.accGlobal = 0;
-        c->accGlobal = march_lds_bytes(sz, c->marchWaves) > 64 * 1024;
-
     }
     if (c->is2d)
     {
@@ -1469,8 +1216,6 @@ int alloc_state(lwhip_context* c)
         }
         HIP_TRY(c->rowsBuf.alloc((size_t)maxRows * Ns));
     }
-    HIP_TRY(c->stamps.alloc((size_t)c->nChunks * 12));
-    HIP_TRY(hipMemset(c->stamps.p, 0, c->stamps.n * sizeof(long long)));
     if (c->prob.zLowerBc.type == LWHIP_BC_CALLABLE)
     {
         HIP_TRY(c->lowerBcData.alloc(Nla * c->prob.zLowerBc.Nmu));
@@ -1489,75 +1234,31 @@ int alloc_state(lwhip_context* c)
 #define D2H(dst, src, count)                                                                           \
     HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyDeviceToHost, c->stream))
 
+// argument block of the 2D pipeline's continuum-row kernel (lwhip_2d.hip)
 int build_sweep_args(lwhip_context* c)
 {
-    SweepArgs a{};
+    if (!c->is2d)
+        return LWHIP_OK;
+    ContArgs a{};
     a.Ns = c->Ns;
-    a.Nrays = c->Nrays;
-    a.Nla = c->Nla;
-    a.Natom = c->Natom;
-    a.NlevTot = c->NlevTot;
-    a.Ntrans = c->Ntrans;
     a.maxC = c->maxC;
-    a.maxCT = c->maxCT;
-    a.lowerBc = c->prob.zLowerBc.type;
-    a.upperBc = c->prob.zUpperBc.type;
-    a.lowerNmu = c->prob.zLowerBc.Nmu;
-    a.upperNmu = c->prob.zUpperBc.Nmu;
-    a.storeDepth = c->prob.storeDepthData ? 1 : 0;
-    a.big = c->big ? 1 : 0;
-    a.height = c->height.p;
     a.temperature = c->temperature.p;
-    a.muz = c->muz.p;
-    a.wmu = c->wmu.p;
     a.wavelength = c->wavelength.p;
-    a.lowerIdx = c->lowerIdx.p;
-    a.upperIdx = c->upperIdx.p;
-    a.lowerBcData = c->lowerBcData.p;
-    a.upperBcData = c->upperBcData.p;
     a.bgChi = c->bgChi.p;
     a.bgEta = c->bgEta.p;
-    a.bgSca = c->bgSca.p;
-    a.J = c->J.p;
-    a.I = c->I.p;
-    a.depthChi = c->depthChi.p;
-    a.depthEta = c->depthEta.p;
-    a.depthI = c->depthI.p;
     a.n = c->n.p;
     a.ratio = c->ratio.p;
-    a.wphi = c->wphi.p;
-    a.phi = c->phi.p;
-    a.rho = c->rho.p;
     a.laHdr = c->laHdr.p;
     a.slots = c->slots.p;
     a.progs = c->progs.p;
     a.progRows = c->progRows.p;
     a.progEnts = c->progEnts.p;
-    a.chunkLa = c->chunkLa.p;
-    a.partial = c->partial.p;
-    a.red8 = c->red8.p;
-    a.slotTr = c->slotTrRows.p;
-    a.dJ = c->dJ.p;
-    a.stamps = c->stamps.p;
-    a.bigScratch = c->bigScratch.p;
     a.rows = c->rowsBuf.p;
     a.contLa = c->contLa.p;
     a.nContLa = c->nContLa;
-    a.accGlobal = c->accGlobal ? 1 : 0;
-    a.Nline = c->Nline;
     c->hargs = a;
-    std::vector<SweepArgs> v(1, a);
+    std::vector<ContArgs> v(1, a);
     HIP_TRY(c->dargs.upload(v));
-    if (c->nChunksPrd > 0)
-    {
-        // the PRD rates pass: same arguments, its own chunking
-        a.slots = c->slotsPrd.p;
-        a.chunkLa = c->chunkLaPrd.p;
-        a.laList = c->laListPrd.p;
-        c->hargsPrd = a;
-        v[0] = a;
-        HIP_TRY(c->dargsPrd.upload(v));
-    }
     return LWHIP_OK;
 }
 
@@ -1662,59 +1363,43 @@ int retile_profiles(lwhip_context* c)
     return LWHIP_OK;
 }
 
-SweepDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
+TileDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
 {
-    SweepDyn d{};
-    d.nRaysActive = upOnly ? c->Nrays : 2 * c->Nrays;
-    d.G = std::min(c->G, d.nRaysActive);
+    (void)c;
+    TileDyn d{};
+    d.nPass = upOnly ? 1 : 2;
     d.lambdaIterate = lambdaIterate;
-    d.rayList = upOnly ? c->rayUp.p : c->rayAll.p;
-    d.S = c->marchS;
-    d.R = std::max(1, std::min(64 / c->marchS, d.nRaysActive));
+    d._pad = (env_int("LWHIP_RM_SKIP", 0) << 8) | (env_int("LWHIP_POST_SKIP", 0) << 12); // timing experiments
     return d;
 }
 
-// one sweep over this context's wavelengths (rates = the full iteration, else formal_sol)
-hipError_t run_sweep(lwhip_context* c, const SweepDyn& dyn, bool rates)
+// one sweep over this context's wavelengths (rates = the full iteration, else formal_sol): pre-pass (the tiles' row
+// blocks, the depth table), the march, and -- unless the sweep's workgroups finish their tiles themselves -- the post-pass
+hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
-    // the PRD rates pass runs on its own chunking (balanced over the PRD wavelengths)
-    const bool prd = dyn.prdOnly && c->nChunksPrd > 0;
-    const SweepArgs* dargs = prd ? c->dargsPrd.p : c->dargs.p;
-    const SweepArgs& hargs = prd ? c->hargsPrd : c->hargs;
-    const int nChunks = prd ? c->nChunksPrd : c->nChunks;
-    if (c->tiled)
-    {
-        TileDyn td{};
-        td.nPass = (dyn.nRaysActive == c->Nrays) ? 1 : 2;
-        td.lambdaIterate = dyn.lambdaIterate;
-        td.prdOnly = dyn.prdOnly;
-        td._pad = env_int("LWHIP_RM_DEBUG_MASK", 0) | (env_int("LWHIP_RM_SKIP", 0) << 8) | (env_int("LWHIP_POST_SKIP", 0) << 12);
-        const bool tprd = dyn.prdOnly != 0;
-        if (tprd && c->nTileChunksPrd == 0)
-            return hipSuccess;
-        const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
-        const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
-        const bool fuse = c->tileFuse && rates && !tprd;
-        const bool fusePre = fuse && env_int("LWHIP_TILE_FUSE", 1) == 3; // the sweep's workgroups also write their own row blocks
-        if (fusePre)
-            td._pad |= 0x4000;
-        hipError_t e = fusePre ? launch_depth_table(da, nullptr, 0, c->stream)
-                               : launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
-        if (e != hipSuccess)
-            return e;
-        e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, fuse, tprd ? c->nTileChunksPrd : c->nTileChunks,
-                              c->tileWaves, nullptr, 0, c->stream);
-        if (e != hipSuccess || !rates || fuse)
-            return e;
-        return launch_tile_post(da, ha, td, tprd ? c->nPostChunksPrd : c->nPostChunks, nullptr, 0, c->stream);
-    }
-    if (!c->march)
-        return launch_sweep(dargs, hargs, dyn, c->prob.formalSolver, c->maxL, rates, nChunks, c->stream);
-    hipError_t e = launch_cont(dargs, hargs, c->stream);
+    TileDyn td = dyn;
+    const bool tprd = dyn.prdOnly != 0; // the PRD rates pass: its own tile list and chunking
+    if (tprd && c->nTileChunksPrd == 0)
+        return hipSuccess;
+    const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
+    const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
+    const bool fuse = c->tileFuse && rates && !tprd;
+    const bool fusePre = fuse && env_int("LWHIP_TILE_FUSE", 1) == 3; // the sweep's workgroups also write their own row blocks
+    if (fusePre)
+        td._pad |= 0x4000;
+    hipError_t e = fusePre ? launch_depth_table(da, nullptr, 0, c->stream)
+                           : launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
     if (e != hipSuccess)
         return e;
-    return launch_march(dargs, hargs, dyn, c->prob.formalSolver, c->marchD, c->maxL, rates, nChunks, c->marchWaves,
-                        c->stream);
+    if (e0) // lwhip_profile_enable: HIP events around the sweep kernel alone
+        (void)hipEventRecord(e0, c->stream);
+    e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, fuse, tprd ? c->nTileChunksPrd : c->nTileChunks,
+                          c->tileWaves, nullptr, 0, c->stream);
+    if (e1)
+        (void)hipEventRecord(e1, c->stream);
+    if (e != hipSuccess || !rates || fuse)
+        return e;
+    return launch_tile_post(da, ha, td, tprd ? c->nPostChunksPrd : c->nPostChunks, nullptr, 0, c->stream);
 }
 
 int flush_prefill(lwhip_context* c)
@@ -1847,7 +1532,7 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
         std::fprintf(stderr,
                      "lwhip_create: Nla=%d Ns=%d Nmu=%d sweep=%s tiles=%d (L=%d, max slots %d, cap %d) chunks=%d x %d waves post=%d maxCT=%d/%d "
                      "rows=%.1f MB phiT=%.1f MB\n",
-                     c->Nla, c->Ns, c->Nrays, c->tiled ? "ray-column" : (c->is2d ? "2d" : (c->march ? "march" : "lds-column")),
+                     c->Nla, c->Ns, c->Nrays, c->is2d ? "2d" : "ray-column",
                      c->nTiles, c->tileL, c->maxSlotsTile, c->tileCap, c->nTileChunks, c->tileWaves, c->nPostChunks, c->maxCTTile, c->maxCTPost,
                      c->rowsTileTot * 8e-6, c->phiTTot * 8e-6);
     *out = c;
@@ -1860,50 +1545,6 @@ int lwhip_destroy(lwhip_context* c)
         return LWHIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (std::getenv("LWHIP_DUMP_STAMPS") && c->stamps.n)
-    {
-        std::vector<long long> h(c->stamps.n);
-        (void)hipMemcpy(h.data(), c->stamps.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        double sum[12] = { 0 };
-        for (size_t i = 0; i < h.size(); ++i)
-            sum[i % 12] += (double)h[i];
-        std::fprintf(stderr, "lwhip stamps (mean cycles per chunk, last launch; nChunks=%d G=%d maxCT=%d maxC=%d lds=%zu):",
-                     c->nChunks, c->G, c->maxCT, c->maxC, sweep_lds_bytes(c->hargs, c->G));
-        for (int i = 0; i < 12; ++i)
-            std::fprintf(stderr, " [%d]=%.0f", i, sum[i] / c->nChunks);
-        std::fprintf(stderr, "\n");
-        if (const char* path = std::getenv("LWHIP_DUMP_CHUNKS"))
-        {
-            // per-chunk total cycles next to the cost model's inputs, for calibrating the balance
-            std::vector<int32_t> cla(c->chunkLa.n);
-            std::vector<DevLaHeader> hh(c->laHdr.n);
-            (void)hipMemcpy(cla.data(), c->chunkLa.p, cla.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hh.data(), c->laHdr.p, hh.size() * sizeof(DevLaHeader), hipMemcpyDeviceToHost);
-            if (FILE* f = std::fopen(path, "w"))
-            {
-                std::fprintf(f, "chunk,nla,nLine,nMixed,nPure,nCont,nTwo,nRows,cycles,start,end\n");
-                for (int ch = 0; ch < c->nChunks; ++ch)
-                {
-                    long nl = 0, nm = 0, np = 0, nc = 0, n2 = 0, nr = 0;
-                    for (int la = cla[ch]; la < cla[ch + 1]; ++la)
-                    {
-                        nl += hh[la].nLine;
-                        nm += hh[la].nMixed;
-                        np += hh[la].nPure;
-                        nc += (hh[la].nMixed + hh[la].nPure) > 0;
-                        n2 += hh[la].nLine >= 2;
-                        nr += hh[la].nRows;
-                    }
-                    double tot = 0;
-                    for (int i = 0; i < 10; ++i)
-                        tot += (double)h[(size_t)ch * 12 + i];
-                    std::fprintf(f, "%d,%d,%ld,%ld,%ld,%ld,%ld,%ld,%.0f,%lld,%lld\n", ch, cla[ch + 1] - cla[ch], nl, nm, np, nc, n2, nr,
-                                 tot, h[(size_t)ch * 12 + 10], h[(size_t)ch * 12 + 11]);
-                }
-                std::fclose(f);
-            }
-        }
-    }
     delete c;
     return LWHIP_OK;
 }
@@ -2282,7 +1923,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     r.idxOffset = c->laStart;
     r.world = c->worldSize;
     r.rank = c->worldRank;
-    HIP_TRY(launch_reduce(r, c->stream));
+    HIP_TRY(launch_reduce_sum(r, c->stream));
     return LWHIP_OK;
 }
 
@@ -2292,10 +1933,6 @@ static ReduceArgs make_reduce_args(lwhip_context* c)
     ReduceArgs r{};
     r.Ns = c->Ns;
     r.Ntrans = c->Ntrans;
-    r.maxCT = c->maxCT;
-    r.trOff = c->trOff.p;
-    r.trRow = c->trRow.p;
-    r.partial = c->partial.p;
     r.red8 = c->red8.p;
     r.red = c->red.p;
     r.dJ = c->dJ.p;
@@ -2345,51 +1982,32 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
         c->partialPending = true;
         return LWHIP_OK;
     }
-    SweepDyn dyn = make_dyn(c, false, lambdaIterate);
-    // default sweep: the chunks add their accumulators straight into the stage-1 buffer (atomics); the one-call
-    // iteration lets the apply launch sum and zero it (no reduce launch), the split / sharded form runs stage 2 only
-    const bool atomicOut = c->Ntrans > 0 && (c->tiled || (!c->march && !c->big && env_int("LWHIP_ATOMIC_OUT", 1) != 0));
-    if (atomicOut)
-    {
-        if (!c->red8Clean)
-            HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));
-        c->red8Clean = true;
-        dyn.atomicOut = 1;
-    }
+    const TileDyn dyn = make_dyn(c, false, lambdaIterate);
+    // the sweep's workgroups add their sums straight into the stage-1 buffer (atomics): the one-call iteration lets the
+    // apply launch sum and zero it (no reduce launch), the split / sharded form runs stage 2
+    if (!c->red8Clean)
+        HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));
+    c->red8Clean = true;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timeIt = c->profiling && (c->profCount++ % c->profEvery == 0);
     if (timeIt)
     {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, c->stream));
     }
-    HIP_TRY(run_sweep(c, dyn, true));
+    HIP_TRY(run_sweep(c, dyn, true, e0, e1));
     if (timeIt)
-    {
-        HIP_TRY(hipEventRecord(e1, c->stream));
         c->pending.emplace_back(e0, e1);
-    }
+    if (!partsOnly)
     {
-        // fixed-order slab sums; the extra block of stage 2 writes this shard's (dJMax, global idx)
-        // into its slot of the gather tail and zeros the other slots
+        // fixed-order sum of the parts; the extra block writes this shard's (dJMax, global idx) into its slot of the
+        // gather tail and zeros the other slots
         ReduceArgs r = make_reduce_args(c);
-        if (atomicOut && partsOnly)
-            ; // nothing to reduce
-        else if (atomicOut)
-        {
-            r.zeroParts = 1;
-            HIP_TRY(launch_reduce_sum(r, c->stream));
-        }
-        else if (partsOnly) // single-device call: stage 2 and the dJMax reduction are folded into the apply launch
-            HIP_TRY(launch_reduce_parts(r, c->stream));
-        else
-            HIP_TRY(launch_reduce(r, c->stream));
-        if (!atomicOut)
-            c->red8Clean = false;
+        r.zeroParts = 1;
+        HIP_TRY(launch_reduce_sum(r, c->stream));
     }
     c->partsOnly = partsOnly;
-    c->atomicParts = atomicOut && partsOnly;
+    c->atomicParts = partsOnly;
     if (c->worldSize > 1 && !c->prdLines.empty()) // the PRD slots of the tail ride in the same all-reduce: keep them finite
         HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
                                2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
@@ -2487,7 +2105,7 @@ struct lwhip_batch
 {
     std::vector<lwhip_context*> ctxs;
     std::vector<hipStream_t> ownStreams; // what the columns ran on before they joined the batch
-    DevBuf<const SweepArgs*> apList;
+    DevBuf<const TileArgs*> apList;
     DevBuf<ReduceArgs> rList;
     DevBuf<ApplyArgs> aList;
     DevBuf<double> tail;       // [n][2] (dJMax, idx) of every column
@@ -2510,11 +2128,13 @@ int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
         lwhip_context* c = ctxs[i];
         if (!c)
             return fail(LWHIP_ERR_INVALID, "batch_create: null context");
-        if (c->is2d || c->march || c->worldSize != 1)
-            return fail(LWHIP_ERR_UNSUPPORTED, "batch_create: columns are 1D, unsharded contexts on the default sweep");
+        if (c->is2d || c->worldSize != 1)
+            return fail(LWHIP_ERR_UNSUPPORTED, "batch_create: columns are 1D, unsharded contexts");
         if (c->device != c0->device || c->Ns != c0->Ns || c->Nla != c0->Nla
-            || c->Nrays != c0->Nrays || c->Ntrans != c0->Ntrans || c->Natom != c0->Natom || c->nChunks != c0->nChunks
-            || c->maxL != c0->maxL || c->maxC != c0->maxC || c->maxCT != c0->maxCT || c->G != c0->G || c->big != c0->big
+            || c->Nrays != c0->Nrays || c->Ntrans != c0->Ntrans || c->Natom != c0->Natom || c->nTiles != c0->nTiles
+            || c->nTileChunks != c0->nTileChunks || c->nPostChunks != c0->nPostChunks || c->tileCap != c0->tileCap
+            || c->tileFuse != c0->tileFuse || c->tileWaves != c0->tileWaves || c->maxCTTile != c0->maxCTTile
+            || c->maxL != c0->maxL || c->maxC != c0->maxC
             || c->NlevTot != c0->NlevTot || c->prob.formalSolver != c0->prob.formalSolver)
             return fail(LWHIP_ERR_INVALID, "batch_create: the columns must share device, model atoms, wavelength grid "
                                            "and solver");
@@ -2535,14 +2155,19 @@ int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
     auto b = std::make_unique<lwhip_batch>();
     b->ctxs.assign(ctxs, ctxs + n);
     b->ownStreams = before;
-    std::vector<const SweepArgs*> ap(n);
+    std::vector<const TileArgs*> ap(n);
     std::vector<ReduceArgs> rl(n);
     HIP_TRY(b->tail.alloc((size_t)2 * n));
     for (int i = 0; i < n; ++i)
     {
-        ap[i] = ctxs[i]->dargs.p;
+        ap[i] = ctxs[i]->dtargs.p;
         rl[i] = make_reduce_args(ctxs[i]);
         rl[i].batchTail = b->tail.p + 2 * (size_t)i;
+        rl[i].zeroParts = 1;
+        // the columns' stage-1 buffers start clean (the sweep adds into them, stage 2 zeroes what it has summed)
+        if (!ctxs[i]->red8Clean)
+            HIP_TRY(hipMemsetAsync(ctxs[i]->red8.p, 0, ctxs[i]->red8.n * sizeof(double), c0->stream));
+        ctxs[i]->red8Clean = true;
     }
     HIP_TRY(b->apList.upload(ap));
     HIP_TRY(b->rList.upload(rl));
@@ -2645,12 +2270,19 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
         b->aValid = true;
         b->aCrsw = crsw;
     }
-    const SweepDyn dyn = make_dyn(c0, false, lambdaIterate);
-    HIP_TRY(launch_sweep(c0->dargs.p, c0->hargs, dyn, c0->prob.formalSolver, c0->maxL, true, c0->nChunks, c0->stream,
-                         b->apList.p, n));
-    HIP_TRY(launch_reduce(make_reduce_args(c0), c0->stream, b->rList.p, n));
-    for (lwhip_context* c : b->ctxs)
-        c->red8Clean = false;
+    // one set of launches for all columns: pre-pass, sweep (each workgroup finishes its tile when fused), stage 2
+    const TileDyn dyn = make_dyn(c0, false, lambdaIterate);
+    const bool fuse = c0->tileFuse;
+    HIP_TRY(launch_tile_pre(c0->dtargs.p, c0->htargs, c0->nTiles, b->apList.p, n, c0->stream));
+    HIP_TRY(launch_tile_sweep(c0->dtargs.p, c0->htargs, dyn, c0->prob.formalSolver, c0->tileCap, true, fuse, c0->nTileChunks,
+                              c0->tileWaves, b->apList.p, n, c0->stream));
+    if (!fuse)
+        HIP_TRY(launch_tile_post(c0->dtargs.p, c0->htargs, dyn, c0->nPostChunks, b->apList.p, n, c0->stream));
+    {
+        ReduceArgs r0 = make_reduce_args(c0);
+        r0.zeroParts = 1;
+        HIP_TRY(launch_reduce_sum(r0, c0->stream, b->rList.p, n));
+    }
     if (c0->Natom > 0)
         HIP_TRY(launch_apply(b->aHost[0], c0->stream, b->aList.p, n));
     if (results)
@@ -2710,7 +2342,7 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
     HIP_TRY(hipSetDevice(c->device));
     if (c->is2d)
         return run_2d(c, 0, upOnly ? 2 : 1);
-    const SweepDyn dyn = make_dyn(c, upOnly != 0, 0);
+    const TileDyn dyn = make_dyn(c, upOnly != 0, 0);
     HIP_TRY(run_sweep(c, dyn, false));
     return LWHIP_OK;
 }
@@ -3238,42 +2870,17 @@ int lwhip_prd_partial(lwhip_context* c)
         return LWHIP_OK;
     }
     // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
-    SweepDyn dyn = make_dyn(c, false, 0);
+    TileDyn dyn = make_dyn(c, false, 0);
     dyn.prdOnly = 1;
     HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream)); // unvisited wavelengths: dJ = 0
-    if (c->tiled)
-    {
-        // the ray-column sweep adds its chunk sums into the stage-1 buffer; stage 2 sums and zeroes the parts
-        if (!c->red8Clean)
-            HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));
-        HIP_TRY(run_sweep(c, dyn, true));
-        ReduceArgs r = make_reduce_args(c);
-        r.zeroParts = 1;
-        HIP_TRY(launch_reduce_sum(r, c->stream));
-        c->red8Clean = true;
-        c->prdPending = true;
-        return LWHIP_OK;
-    }
-    if (c->nChunksPrd > 0)
-        HIP_TRY(run_sweep(c, dyn, true));
-    else
-        HIP_TRY(hipMemsetAsync(c->partial.p, 0, c->partial.n * sizeof(double), c->stream)); // a shard without PRD wavelengths
-    ReduceArgs r{};
-    r.Ns = Ns;
-    r.Ntrans = c->Ntrans;
-    r.maxCT = c->maxCT;
-    r.trOff = c->nChunksPrd > 0 ? c->trOffPrd.p : c->trOff.p;
-    r.trRow = c->nChunksPrd > 0 ? c->trRowPrd.p : c->trRow.p;
-    r.partial = c->partial.p;
-    r.red8 = c->red8.p;
-    r.red = c->red.p;
-    r.dJ = c->dJ.p;
-    r.Nla = c->Nla;
-    r.idxOffset = c->laStart;
-    r.world = c->worldSize;
-    r.rank = c->worldRank;
-    HIP_TRY(launch_reduce(r, c->stream));
-    c->red8Clean = false;
+    // the sweep adds its workgroup sums into the stage-1 buffer; stage 2 sums and zeroes the parts
+    if (!c->red8Clean)
+        HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));
+    HIP_TRY(run_sweep(c, dyn, true));
+    ReduceArgs r = make_reduce_args(c);
+    r.zeroParts = 1;
+    HIP_TRY(launch_reduce_sum(r, c->stream));
+    c->red8Clean = true;
     c->prdPending = true;
     return LWHIP_OK;
 }

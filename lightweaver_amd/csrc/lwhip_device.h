@@ -159,9 +159,9 @@ DEVINL void lds_barrier()
 #define GCD(p) ((const GLOBAL_AS double*)(p))
 #define GD(p) ((GLOBAL_AS double*)(p))
 #define CTAB(T, p) ((const CONST_AS T*)(p))
-DEVINL const CONST_AS SweepArgs* launder_args(const SweepArgs* p)
+DEVINL const CONST_AS ContArgs* launder_args(const ContArgs* p)
 {
-    const CONST_AS SweepArgs* q = (const CONST_AS SweepArgs*)p;
+    const CONST_AS ContArgs* q = (const CONST_AS ContArgs*)p;
     asm volatile("" : "+s"(q));
     return q;
 }

@@ -96,70 +96,24 @@ struct DevProgram
 };
 enum { LWHIP_MAX_PROG_ROWS = 80, LWHIP_MAX_PROG_ENTS = 320 };
 
-// Static part of the sweep arguments; lives in device memory (keeps SGPR pressure low).
-struct SweepArgs
+// Arguments of the continuum-row kernel of the 2D path (lwhip_2d.hip); lives in device memory.
+struct ContArgs
 {
-    int32_t Ns, Nrays, Nla, Natom, NlevTot, Ntrans;
-    int32_t maxC;          // max continua active at one wavelength
-    int32_t maxCT;         // accumulator slots per chunk
-    int32_t lowerBc, upperBc, lowerNmu, upperNmu;
-    int32_t storeDepth;
-    int32_t big;           // deep-atmosphere mode: rows / continuum tables / accumulators in global scratch
-    const double* height;
+    int32_t Ns, maxC;      // maxC: max continua active at one wavelength
+    int32_t nContLa, _pad;
     const double* temperature;
-    const double* muz;
-    const double* wmu;
     const double* wavelength;
-    const int32_t* lowerIdx;       // [Nrays,2] CALLABLE
-    const int32_t* upperIdx;
-    const double* lowerBcData;     // [Nla, lowerNmu]
-    const double* upperBcData;
     const double* bgChi;
     const double* bgEta;
-    const double* bgSca;
-    double* J;
-    double* I;
-    double* depthChi;
-    double* depthEta;
-    double* depthI;
     const double* n;               // [NlevTot, Ns] pool
     const double* ratio;           // [Ncont, Ns]  nStar_i / nStar_j
-    const double* wphi;            // [Nline, Ns]
-    const double* phi;             // pool
-    const double* rho;             // pool
     const DevLaHeader* laHdr;      // [Nla]
     const DevSlot* slots;
     const DevProgram* progs;
     const DevProgRow* progRows;
     const DevProgEnt* progEnts;
-    const int32_t* chunkLa;        // [nChunks+1] wavelength boundaries (or boundaries in laList)
-    const int32_t* laList;         // null, or the wavelengths this launch visits (PRD rates pass)
-    double* partial;               // [nChunks*maxCT, 4, Ns]
-    double* red8;                  // [Ntrans, SPLIT, 4, Ns]: target of the chunks' atomic adds (SweepDyn::atomicOut)
-    const int32_t* slotTr;         // [nChunks*maxCT] transition of every slab row, -1: unused
-    double* dJ;                    // [Nla]
-    long long* stamps;             // [nChunks, 12] diagnostic build only (-DLWHIP_STAMPS)
-    double* bigScratch;            // [nChunks, sweep_big_scratch_doubles] (big mode only)
-    // march kernel (lwhip_march.hip)
     double* rows;                  // continuum rows written by cont_kernel: [rowBase + r][Ns] per wavelength
     const int32_t* contLa;         // [nContLa] wavelengths that have continua
-    int32_t nContLa;
-    int32_t accGlobal;             // accumulators live in the chunk's slab (global atomics) instead of LDS
-    int32_t Nline;
-    int32_t _padM;
-};
-
-// Per-launch part, passed by value.
-struct SweepDyn
-{
-    int32_t nRaysActive;   // 2*Nrays, or Nrays when upOnly
-    int32_t G;             // rays per pass
-    int32_t lambdaIterate;
-    int32_t prdOnly;       // PRD rates pass: only wavelengths with a PRD line, J + Rij/Rji of PRD lines
-    const int32_t* rayList;        // [nRaysActive] -> r = 2*mu + toObs
-    int32_t S, R;          // march kernel: depth segments per ray, rays per pass (R * S <= 64)
-    int32_t atomicOut;     // the chunk adds its accumulators straight into red8[part = chunk % SPLIT] (no slab, no stage 1)
-    int32_t _padD;
 };
 
 // ---- the ray-column sweep (lwhip_raymarch.hip) -------------------------------------------------------------
@@ -308,11 +262,8 @@ hipError_t launch_depth_table(const TileArgs* devArgs, const TileArgs* const* ap
 enum { LWHIP_REDUCE_SPLIT = 8 };
 struct ReduceArgs
 {
-    int32_t Ns, Ntrans, maxCT;
-    const int32_t* trOff;          // [Ntrans+1]
-    const int32_t* trRow;          // slab rows (chunk*maxCT + cs) in chunk order
-    const double* partial;
-    double* red8;                  // [Ntrans, SPLIT, 4, Ns] stage-1 sums
+    int32_t Ns, Ntrans;
+    double* red8;                  // [Ntrans, SPLIT, 4, Ns] stage-1 sums (the sweep's workgroups add into them)
     double* red;                   // [Ntrans, 4, Ns] + gather tail [2 * world]
     const double* dJ;              // [Nla] per-wavelength dJ of this shard
     int32_t Nla, idxOffset, world, rank;
@@ -511,7 +462,7 @@ hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream);
 hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream);
 hipError_t launch_iout2d(const Batch2dArgs& a, hipStream_t stream);
 hipError_t launch_sum_groups(double* red, size_t n, size_t stride, int G, hipStream_t stream);
-hipError_t launch_cont_range(const SweepArgs* devArgs, const SweepArgs& hostArgs, int contOff, int nCont, double* rowsBase,
+hipError_t launch_cont_range(const ContArgs* devArgs, const ContArgs& hostArgs, int contOff, int nCont, double* rowsBase,
                              hipStream_t stream);
 
 // Ng acceleration of the populations (lwhip_pops.hip)
@@ -539,20 +490,8 @@ hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, co
                            int* status, hipStream_t stream);
 
 // launch helpers implemented in lwhip_kernels.hip
-size_t sweep_lds_bytes(const SweepArgs& a, int G);
-size_t sweep_big_scratch_doubles(const SweepArgs& a);
-hipError_t launch_sweep(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn,
-                        int solver, int maxL, bool rates, int nChunks, hipStream_t stream,
-                        const SweepArgs* const* apList = nullptr, int nBatch = 0);
-// march kernel: D depth points per lane; returns hipErrorInvalidValue for an unsupported D
-hipError_t launch_cont(const SweepArgs* devArgs, const SweepArgs& hostArgs, hipStream_t stream);
-hipError_t launch_march(const SweepArgs* devArgs, const SweepArgs& hostArgs, const SweepDyn& dyn, int solver,
-                        int D, int maxL, bool rates, int nChunks, int wavesPerGroup, hipStream_t stream);
-size_t march_lds_bytes(const SweepArgs& a, int wavesPerGroup);
 // list / nBatch: column batches -- a device array of per-column argument blocks, one grid slice per column
-hipError_t launch_reduce(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list = nullptr, int nBatch = 0);
-hipError_t launch_reduce_parts(const ReduceArgs& a, hipStream_t stream); // stage 1 only (see ApplyArgs::fromParts)
-hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream);   // stage 2 only (parts accumulated by atomics)
+hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
 }

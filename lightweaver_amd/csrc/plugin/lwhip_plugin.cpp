@@ -30,23 +30,37 @@ namespace
 {
 struct Fingerprint
 {
-    uint64_t h = 0;
-    // cheap change detector for big, rarely changing inputs: pointer, length and a strided sample
+    // Exact change detector for the slowly changing inputs: pointer, length and a hash of EVERY element (four
+    // independent multiply-xor lanes, so the loop runs at memory speed: ~0.1 ms per MB).  A sampled fingerprint
+    // would miss an in-place edit of an unsampled depth point -- what update_deps() does after a local atmosphere
+    // change -- and the iteration would run on stale device inputs without any sign of it.
+    static uint64_t mix(uint64_t h, uint64_t bits)
+    {
+        h = (h ^ bits) * 0x9E3779B97F4A7C15ull;
+        return h ^ (h >> 29);
+    }
     static uint64_t of(const double* p, size_t n)
     {
-        uint64_t h = 1469598103934665603ull ^ (uint64_t)(uintptr_t)p ^ (n * 0x9E3779B97F4A7C15ull);
+        uint64_t h0 = 1469598103934665603ull ^ (uint64_t)(uintptr_t)p, h1 = n * 0x9E3779B97F4A7C15ull,
+                 h2 = 0x2545F4914F6CDD1Dull, h3 = 0xD6E8FEB86659FD93ull;
         if (!p || !n)
-            return h;
-        const size_t step = n / 257 + 1;
-        for (size_t i = 0; i < n; i += step)
+            return h0 ^ h1;
+        size_t i = 0;
+        uint64_t w[4];
+        for (; i + 4 <= n; i += 4)
         {
-            uint64_t bits;
-            std::memcpy(&bits, &p[i], 8);
-            h = (h ^ bits) * 1099511628211ull;
+            std::memcpy(w, p + i, 32);
+            h0 = mix(h0, w[0]);
+            h1 = mix(h1, w[1]);
+            h2 = mix(h2, w[2]);
+            h3 = mix(h3, w[3]);
         }
-        uint64_t bits;
-        std::memcpy(&bits, &p[n - 1], 8);
-        return (h ^ bits) * 1099511628211ull;
+        for (; i < n; ++i)
+        {
+            std::memcpy(w, p + i, 8);
+            h0 = mix(h0, w[0] + i);
+        }
+        return mix(mix(mix(h0, h1), h2), h3);
     }
 };
 
@@ -68,6 +82,15 @@ struct PluginState
 
 std::mutex g_mutex;
 std::map<const Atom*, std::pair<Context*, int>> g_atomOwner; // stat_eq receives only the Atom*
+
+void register_atoms(Context* ctx)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto it = g_atomOwner.begin(); it != g_atomOwner.end();)
+        it = (it->second.first == ctx) ? g_atomOwner.erase(it) : std::next(it);
+    for (size_t ia = 0; ia < ctx->activeAtoms.size(); ++ia)
+        g_atomOwner[ctx->activeAtoms[ia]] = { ctx, (int)ia };
+}
 
 [[noreturn]] void fail(const std::string& what)
 {
@@ -385,13 +408,14 @@ uint32_t sync_state(Context& ctx, bool force)
         if (lwhip_create(&st->prob, nullptr, &st->hip) != LWHIP_OK)
             fail("lwhip_create");
         dirty_mask(st, true); // create uploaded everything: just record the fingerprints
-        std::lock_guard<std::mutex> lock(g_mutex);
-        for (size_t ia = 0; ia < ctx.activeAtoms.size(); ++ia)
-            g_atomOwner[ctx.activeAtoms[ia]] = { &ctx, (int)ia };
+        register_atoms(&ctx);
         return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
     }
     return dirty_mask(st, force);
 }
+
+// the input groups dirty_mask tracks by fingerprint (the others go up on every call)
+constexpr uint32_t kSlowGroups = LWHIP_PROFILES | LWHIP_BACKGROUND | LWHIP_ATMOS | LWHIP_NSTAR | LWHIP_COLLISIONS;
 
 bool force_upload(ExtraParams& params)
 {
@@ -462,9 +486,10 @@ void stat_eq_hip(Atom* atom, ExtraParams params, int spaceStart, int spaceEnd)
     const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
     if (!ctx || !whole)
         throw std::runtime_error("lwhip plugin: stat_eq needs an atom of a live Context and the full depth range");
-    sync_state(*ctx, false);
+    // whatever else changed since the last call goes up too: sync_state has just recorded its fingerprint as clean
+    const uint32_t up = sync_state(*ctx, force_upload(params)) & kSlowGroups;
     auto* st = (PluginState*)ctx->methodScratch;
-    if (lwhip_upload(st->hip, LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
+    if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
         fail("lwhip_upload");
     const int rc = lwhip_stat_equil(st->hip, idx);
     if (rc == LWHIP_ERR_SINGULAR)
@@ -493,9 +518,9 @@ void time_dep_update_hip(Atom* atom, F64View2D nOld, f64 dt, ExtraParams params,
     const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
     if (!ctx || !whole)
         throw std::runtime_error("lwhip plugin: time_dep_update needs an atom of a live Context and the full depth range");
-    sync_state(*ctx, false);
+    const uint32_t up = sync_state(*ctx, force_upload(params)) & kSlowGroups;
     auto* st = (PluginState*)ctx->methodScratch;
-    if (lwhip_upload(st->hip, LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
+    if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
         fail("lwhip_upload");
     const int rc = lwhip_time_dep_update(st->hip, idx, nOld.data, dt);
     if (rc == LWHIP_ERR_SINGULAR)
@@ -515,9 +540,9 @@ void nr_post_update_hip(Context& ctx, std::vector<Atom*>* atoms, const std::vect
     const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
     if (!whole)
         throw std::runtime_error("lwhip plugin: nr_post_update needs the full depth range");
-    sync_state(ctx, force_upload(params));
+    const uint32_t up = sync_state(ctx, force_upload(params)) & kSlowGroups;
     auto* st = (PluginState*)ctx.methodScratch;
-    if (lwhip_upload(st->hip, LWHIP_GAMMA | LWHIP_POPS | LWHIP_COLLISIONS) != LWHIP_OK)
+    if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS | LWHIP_COLLISIONS) != LWHIP_OK)
         fail("lwhip_upload");
     const int n = (int)atoms->size();
     std::vector<int32_t> idx(n);
@@ -598,6 +623,9 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
 void alloc_global_scratch_hip(Context* ctx)
 {
     ctx->methodScratch = nullptr; // the device context is created on first use, when the arrays are final
+    // stat_eq / time_dep_update receive only an Atom*: the core has filled activeAtoms by now (Source/LwMiddleLayer.pyx:
+    // 2951-2954 before setup_threads at 3055 -> ThreadStorage.cpp:484-486), so either may be the first call of a run
+    register_atoms(ctx);
 }
 
 void free_global_scratch_hip(Context* ctx)

@@ -126,6 +126,59 @@ def test_dropin_sees_host_side_changes(gpu):
 
 @needs_ref
 @pytest.mark.gpu
+def test_dropin_detects_single_element_edits(gpu):
+    """Exact change detection: an in-place edit of ONE depth point of a slowly changing input (what update_deps()
+    does after a local atmosphere change) must reach the device, also when the call that first sees it is stat_eq --
+    which records the new fingerprints -- and the formal solution only comes afterwards."""
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = base.copy(), base.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for pr, c in ((p, hipc), (q, ref)):
+        pr.gamma_prefill()
+        c.formal_sol_gamma_matrices()
+    Ns = p.Nspace
+    # elements a strided sample of the arrays would not look at
+    edits = [('bgChi', (p.Nlambda // 2 + 1, Ns // 2 + 1), 1.7), ('bgEta', (3, 5), 0.4), ('bgSca', (7, Ns - 2), 2.5)]
+    line = next(t for t in p.atoms[0].trans if t.type == abi.LINE)
+    kr = p.atoms[0].trans.index(line)
+    for pr in (p, q):
+        for name, idx, f in edits:
+            getattr(pr, name)[idx] *= f
+        t = pr.atoms[0].trans[kr]
+        t.phi[t.phi.shape[0] // 2, 1, 1, Ns // 3] *= 1.3
+        pr.atoms[0].nStar[1, Ns // 2 + 3] *= 1.2
+        pr.atoms[0].C[0, 1, Ns // 2 + 3] *= 1.5
+        pr.temperature[Ns // 2 + 1] *= 1.01
+    assert hipc.stat_equil() == ref.stat_equil() == 0      # sees the edits first
+    for it in range(2):
+        for pr, c in ((p, hipc), (q, ref)):
+            pr.gamma_prefill()
+            c.formal_sol_gamma_matrices()
+        a, b = collect(p, ('J', 'I', 'Gamma', 'R')), collect(q, ('J', 'I', 'Gamma', 'R'))
+        worst = {k: rel_err(a[k], b[k]) for k in a}
+        assert max(worst.values()) <= TOL_ONE_CALL * (it + 2), (it, worst)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_stat_eq_as_first_call(gpu):
+    """stat_eq may be the first member the core calls on a fresh Context (e.g. after loading a pickled state with
+    its Gamma): the plugin finds the owning Context from the atoms registered by alloc_global_scratch."""
+    base, d = load_fixture('falc_h_ca_small')
+    src = variant_problem(base, d, 'iter1')
+    warm = RefContext(src)
+    src.gamma_prefill()
+    warm.formal_sol_gamma_matrices()
+    p, q = src.copy(), src.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    assert hipc.stat_equil() == 0
+    assert ref.stat_equil() == 0
+    for x, y in zip(p.atoms, q.atoms):
+        assert rel_err(x.n, y.n) <= 1e-9
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_dropin_prd_redistribute(gpu):
     """FsIterationFns::redistribute_prd of the plugin, driven by the real core's
     redistribute_prd_lines dispatch (Source/Prd.cpp), next to the core's own scalar scheme."""
