@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- formal_sol_gamma_matrices iterations/second on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nlambda 10240]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nlambda 10240] [--scaling weak|strong]
 
 Workload (BASELINE.json north star): FAL-C, 82 depths, H(6) + Ca II(6) active, 5 mu-angles, fp64,
 Bezier3 short characteristics, wavelength grid densified to ~10 240 points per GPU.  One step =
@@ -9,10 +9,18 @@ one full iteration (Gamma pre-fill from C on the device, sweep over all waveleng
 J / I / Gamma / rates updated, Gamma finalised, dJMax returned to the host), inputs resident in
 HBM when the timed region starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the global grid has N x 10 240
-wavelengths, sharded contiguously; each iteration does ONE all-reduce (RCCL) of the concatenated
-Gamma / Rij / Rji partial sums and one tiny all-gather of (dJMax, idx).  Per-GPU work is fixed as N
-grows ("weak"); `value` counts 10 240-wavelength shard-iterations per second over all ranks.
+N > 1 (launched by torch.distributed.run, one rank per GPU): wavelengths are sharded contiguously; each
+iteration does ONE all-reduce (RCCL) of the concatenated Gamma / Rij / Rji partial sums with every
+rank's (dJMax, idx) riding in its tail.
+  --scaling weak   (default) the global grid has N x 10 240 wavelengths: per-GPU work is fixed as N grows;
+                   `value` counts 10 240-wavelength shard-iterations per second over all ranks.
+  --scaling strong the 10 240-wavelength grid is split over the N ranks; `value` = whole-problem iterations/s.
+`allreduce_us` is the mean host time per step spent issuing the collective (N > 1).
+
+Beside the headline line's fields: `parity_checked` / `max_rel_err` compare a first iteration of the GPU path with
+the first iteration of the `cpu_baseline` leg on identical inputs; `aux` carries the other BASELINE configs, each
+with its own roofline block (not part of the metric): C3 the PRD sub-iteration, C4 a 512-column fused 1.5D batch,
+C5 the 256 x 82 2D iteration.  `--no-aux` skips them, `--aux-only NAME` runs just one (profiling).
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,6 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-matrix) peak, same guide
+PARITY_TOL = 1e-9       # relative, element-wise, one call on identical inputs
 
 
 def parse():
@@ -35,11 +44,15 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--nlambda', type=int, default=10240, help='wavelengths per GPU')
+    ap.add_argument('--nlambda', type=int, default=10240, help='wavelengths per GPU (weak) / in total (strong)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    ap.add_argument('--aux', action='store_true',
-                    help='also time the PRD sub-iterations and the 2D iteration (not part of the metric)')
+    ap.add_argument('--no-aux', action='store_true', help='skip the C3 / C4 / C5 side measurements')
+    ap.add_argument('--aux', action='store_true', help='(accepted for compatibility: aux entries are on by default)')
+    ap.add_argument('--aux-only', choices=('prd', 'columns', '2d'), default=None,
+                    help='run only this side measurement and print its entry (for rocprofv3)')
+    ap.add_argument('--columns', type=int, default=512, help='columns of the C4 batch')
     return ap.parse_args()
 
 
@@ -73,27 +86,73 @@ def algorithmic_flops(prob, la0, la1):
     return float(per_point.sum() * 2 * prob.Nrays * prob.Nspace)
 
 
+def snapshot(prob):
+    """Copies of everything one iteration writes."""
+    out = {'J': prob.J.copy(), 'I': prob.I.copy()}
+    for ia, a in enumerate(prob.atoms):
+        if not a.detailed:
+            out[f'Gamma{ia}'] = a.Gamma.copy()
+        for kr, t in enumerate(a.trans):
+            out[f'Rij{ia}_{kr}'] = t.Rij.copy()
+            out[f'Rji{ia}_{kr}'] = t.Rji.copy()
+    return out
+
+
+def rel_err(a, b):
+    """max element-wise |a-b|/|b| (where the reference is exactly 0: |a|), as tests/helpers.py."""
+    import numpy as np
+    nz = b != 0.0
+    err = float(np.max(np.abs(a[nz] - b[nz]) / np.abs(b[nz]))) if nz.any() else 0.0
+    if (~nz).any():
+        err = max(err, float(np.max(np.abs(a[~nz]))))
+    return err
+
+
+def first_iteration(p, ctx, step):
+    """Outputs of one iteration from the problem's initial state, and the populations one stat_equil then gives
+    (populations restored afterwards)."""
+    p.gamma_prefill()
+    step()
+    first = snapshot(p)
+    n0 = [a.n.copy() for a in p.atoms]
+    ctx.stat_equil()
+    first.update({f'n{ia}': a.n.copy() for ia, a in enumerate(p.atoms) if not a.detailed})
+    for a, n in zip(p.atoms, n0):
+        a.n[...] = n
+    return first
+
+
 def cpu_baseline(prob, budget_s):
-    """The reference core (oracle/_ref, kind 'reference') -- or, where it is absent, the C oracle
-    (kind 'port') -- timed on the host cores on a bounded number of iterations of the SAME
-    workload.  Reported beside the GPU number; not the optimisation target."""
+    """The reference core (oracle/_ref, kind 'reference') with its widest SIMD scheme -- or, where it is absent, the
+    C oracle (kind 'port') -- timed on the host cores on a bounded number of iterations of the SAME workload.
+    Reported beside the GPU number; not the optimisation target.
+
+    Also returns the parity references: the first iteration (+ stat_equil) of the reference's SCALAR scheme
+    (`mali_full_precond_scalar`, what SURVEY.md 8c names as the oracle; the C port where the reference is absent),
+    and of the timed SIMD scheme -- the reference's own SIMD schemes differ from its scalar scheme by ~1e-6 in J
+    near the lower boundary, which is reported, not hidden."""
     from oracle import bindings
     ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 64)
     p = prob.copy()
+    simd_first = None
     if bindings.ref_available():
         isa = next((i for i in ('AVX512', 'AVX2FMA', 'SSE2') if bindings.simd_plugin(i)), None)
-        threads = min(ncpu, 64)
         ctx = bindings.RefContext(p, scheme=bindings.simd_plugin(isa) if isa else None,
                                   Nthreads=threads)
         kind, name = 'reference', ctx.scheme_name
         step = lambda: ctx.formal_sol_gamma_matrices()
+        q = prob.copy()
+        sc = bindings.RefContext(q, Nthreads=threads)
+        scalar_first = first_iteration(q, sc, lambda: sc.formal_sol_gamma_matrices())
+        scalar_name = sc.scheme_name
+        simd_first = first_iteration(p, ctx, step)
     else:
-        threads = min(ncpu, 64)
         ctx = bindings.OracleContext(p)
         kind, name = 'port', 'lw_oracle.c (OpenMP)'
         step = lambda: ctx.formal_sol_gamma_matrices(Nthreads=threads)
-    p.gamma_prefill()
-    step()  # warm-up
+        scalar_first = first_iteration(p, ctx, step)
+        scalar_name = name
     n, t0 = 0, time.perf_counter()
     while True:
         p.gamma_prefill()
@@ -102,9 +161,107 @@ def cpu_baseline(prob, budget_s):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 50:
             break
-    return {'value': n / dt, 'unit': 'iters/s', 'cores': threads, 'kind': kind,
-            'sample': f'{n} iterations of the same {prob.Nlambda}-wavelength workload, scheme {name}, '
-                      f'Nthreads={threads} of {ncpu} host cpus'}
+    return ({'value': n / dt, 'unit': 'iters/s', 'cores': threads, 'kind': kind,
+             'sample': f'{n} iterations of the same {prob.Nlambda}-wavelength workload, scheme {name}, '
+                       f'Nthreads={threads} of {ncpu} host cpus'},
+            {'name': scalar_name, 'first': scalar_first, 'simd_name': name, 'simd_first': simd_first})
+
+
+def gpu_first_iteration(prob, device, stream):
+    """First iteration + stat_equil of the HIP path on the inputs the CPU leg starts from (host profiles uploaded)."""
+    from lightweaver_amd.context import Context
+    g = prob.copy()
+    with Context(g, device=device, stream=stream) as c:
+        c.formal_sol_gamma_matrices()
+        out = snapshot(g)
+        c.stat_equil()
+        out.update({f'n{ia}': a.n.copy() for ia, a in enumerate(g.atoms) if not a.detailed})
+    return out
+
+
+def roofline_block(kernel, alg_bytes, ms, basis):
+    achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': alg_bytes,
+            'kernel_ms': ms, 'time_basis': basis}
+
+
+def timed(fn, n, torch):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+def aux_prd(args, device, stream, torch, models):
+    """C3: FAL-C with Ca II H & K as PRD lines on the bench grid: one PRD sub-iteration = scattering integral of
+    every PRD line + the rates pass over the PRD wavelengths (redistribute_prd_lines, Source/PrdTemplates.hpp:175-290)."""
+    from lightweaver_amd.context import Context
+    pp = models.throughput_grid(NlambdaTarget=args.nlambda, Nrays=5, prd=True)
+    with Context(pp, device=device, stream=stream) as pc:
+        for _ in range(3):
+            pc.formal_sol_gamma_matrices(deviceResident=True)
+        nsub = 3
+        ms = timed(lambda: pc.prd_redistribute(nsub, 0.0, deviceResident=True), 5, torch) / nsub
+        upd = pc.prd_redistribute(nsub, 0.0, deviceResident=True)
+        lines = [t for a in pp.atoms if not a.detailed for t in a.trans if t.rhoPrd is not None]
+        nla = sum(t.Nred - t.Nblue for t in lines)
+        nprdLa = len({la for t in lines for la in range(t.Nblue, t.Nred)})
+    Ns, Nmu = pp.Nspace, pp.Nrays
+    # inputs/outputs only: the cached fine-grid weights (20 B per fine point, <= 87 points per (lambda, depth)), J in and
+    # rho out per line; then the rates pass over the PRD wavelengths: phi once, background, J in/out
+    alg = 20.0 * 87 * nla * Ns + 8.0 * 2 * nla * Ns + 8.0 * Ns * (2.0 * Nmu * nla + 5.0 * nprdLa)
+    return {'config': 'C3: FALC H(6)+CaII(6), Ca II H & K PRD, same wavelength grid',
+            'ms_per_subiter': ms, 'subiters_per_s': 1e3 / ms, 'prd_lines': int(upd.dRho.shape[1]),
+            'Nlambda': pp.Nlambda, 'Nlambda_prd': nprdLa,
+            'roofline': roofline_block('prd_scatter_kernel + raymarch_kernel (PRD rates pass)', alg, ms,
+                                       'whole sub-iteration (host clock)')}
+
+
+def aux_columns(args, device, stream, torch, models):
+    """C4: a fused 1.5D batch of seeded-perturbed FAL-C columns, H + Ca II at ~3 000 wavelengths each, every column
+    resident in HBM, line profiles generated on the device; columns shard over GPUs with no collective."""
+    from lightweaver_amd.batch import ColumnBatch
+    ncol = args.columns
+    base = models.falc82()
+    t0 = time.perf_counter()
+    probs = [models.falc_h_ca(Nrays=5, lineScale=3.1, atmos=models.perturbed(base, seed=1234 + c), computeProfiles=False)
+             for c in range(ncol)]
+    t1 = time.perf_counter()
+    with ColumnBatch(probs, device=device, stream=stream) as batch:
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        batch.formal_sol_gamma_matrices(sync_host=False)
+        ms = timed(lambda: batch.formal_sol_gamma_matrices(sync_host=False), 5, torch)
+        alg = float(sum(c.algorithmic_bytes() for c in batch.contexts))
+        fused = batch._batch is not None
+    return {'config': f'C4: {ncol} perturbed FALC columns, H(6)+CaII(6), {probs[0].Nlambda} wavelengths each, fused batch',
+            'columns': ncol, 'fused': fused, 'ms_per_batch_iteration': ms, 'column_iters_per_s': ncol * 1e3 / ms,
+            'host_build_s': t1 - t0, 'contexts_and_profiles_s': t2 - t1,
+            'roofline': roofline_block('raymarch_kernel<BATCH> (+ tile_pre / tile_post / reduce / apply)', alg, ms,
+                                       'whole batch iteration (host clock)')}
+
+
+def aux_2d(args, device, stream, torch, models):
+    """C5: 256 x 82 x-periodic atmosphere of perturbed FAL-C columns, H(6), BESSER short characteristics."""
+    import numpy as np
+    from lightweaver_amd.context import Context
+    base = models.falc82()
+    cols = [models.perturbed(base, seed=1234 + j) for j in range(256)]
+    p2 = models.build_problem_2d(cols, np.linspace(0.0, 25.0e3 * 255, 256), [models.H_6(0.5)])
+    with Context(p2, device=device, stream=stream) as c2:
+        ms = timed(lambda: c2.formal_sol_gamma_matrices(deviceResident=True), 5, torch)
+        alg = c2.algorithmic_bytes()
+    return {'config': f'C5: {p2.grid2d.Nx}x{p2.grid2d.Nz}, H(6), {p2.Nlambda} wavelengths, {p2.Nrays}x2 rays, periodic x',
+            'ms_per_iteration': ms, 'iters_per_s': 1e3 / ms,
+            'roofline': roofline_block('fs2d_coef_kernel + rates2d_kernel + fs2d_scan_kernel + gather2d_kernel', alg, ms,
+                                       'whole iteration (host clock)')}
+
+
+AUX = {'prd': ('C3_prd', aux_prd), 'columns': ('C4_columns', aux_columns), '2d': ('C5_2d', aux_2d)}
 
 
 def main():
@@ -128,10 +285,15 @@ def main():
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
+    stream = torch.cuda.current_stream()
+    if args.aux_only:
+        name, fn = AUX[args.aux_only]
+        print(json.dumps({name: fn(args, local_rank, stream.cuda_stream, torch, models)}))
+        return
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    Nla_total = args.nlambda * world
+    Nla_total = args.nlambda * (world if args.scaling == 'weak' else 1)
     # the line profiles are generated on the device (lwhip_compute_profiles), shard by shard: the host
     # never computes or ships the [Nlambda_line, Nmu, 2, Nspace] profile arrays
     prob = models.throughput_grid(NlambdaTarget=Nla_total, Nrays=5, computeProfiles=False)
@@ -140,7 +302,6 @@ def main():
     bounds = shard_bounds(prob, world)
     la0, la1 = bounds[rank], bounds[rank + 1]
 
-    stream = torch.cuda.current_stream()
     ctx = Context(prob, device=local_rank, laStart=la0, laEnd=la1, stream=stream.cuda_stream,
                   worldSize=world, worldRank=rank)
     ctx.compute_profiles(deviceResident=True)
@@ -152,6 +313,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.profile_enable(int(os.environ.get('LWHIP_BENCH_PROF', '4')))   # HIP events around every 4th sweep launch
+    it.allreduce_s = 0.0
     # The interpreter's cyclic garbage collector is not part of the workload: with torch imported a full
     # collection takes ~40 ms (80 steps' worth) and, being triggered by allocation counts, lands at the same
     # spot of every run -- measured inside the timed region of a 100-step run (tools/trace_bench.sh: a 38 ms gap
@@ -170,6 +332,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    allreduce_us = 1e6 * it.allreduce_s / max(args.steps, 1)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -179,47 +342,22 @@ def main():
     alg_bytes = ctx.algorithmic_bytes()
     alg_flops = algorithmic_flops(prob, la0, la1)
 
-    # not part of the metric ("report stat_eq time separately"): the population solve
+    # not part of the metric ("report stat_eq time separately"): the population solve, and the other
+    # BASELINE configs
     aux = {}
     if world == 1:
-        ctx.stat_equil(deviceResident=True)
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for _ in range(20):
-            ctx.stat_equil(deviceResident=True)
-        torch.cuda.synchronize()
-        aux['stat_eq_ms'] = 1e3 * (time.perf_counter() - ta) / 20
-        if args.aux:
-            pp = models.throughput_grid(NlambdaTarget=args.nlambda, Nrays=5, prd=True)
-            with Context(pp, device=local_rank, stream=stream.cuda_stream) as pc:
-                for _ in range(3):
-                    pc.formal_sol_gamma_matrices(deviceResident=True)
-                pc.prd_redistribute(3, 0.0, deviceResident=True)
-                torch.cuda.synchronize()
-                ta = time.perf_counter()
-                for _ in range(5):
-                    upd = pc.prd_redistribute(3, 0.0, deviceResident=True)
-                torch.cuda.synchronize()
-                aux['prd_ms_per_subiter'] = 1e3 * (time.perf_counter() - ta) / (5 * 3)
-                aux['prd_lines'] = int(upd.dRho.shape[1])
-                aux['prd_Nlambda'] = pp.Nlambda
-            # BASELINE config 5 in miniature: 256 x 82 x-periodic atmosphere, H(6), BESSER short characteristics
-            import numpy as np
-            base = models.falc82()
-            cols = [models.perturbed(base, seed=1234 + j) for j in range(256)]
-            p2 = models.build_problem_2d(cols, np.linspace(0.0, 25.0e3 * 255, 256), [models.H_6(0.5)])
-            with Context(p2, device=local_rank, stream=stream.cuda_stream) as c2:
-                c2.formal_sol_gamma_matrices(deviceResident=True)
-                torch.cuda.synchronize()
-                ta = time.perf_counter()
-                for _ in range(5):
-                    c2.formal_sol_gamma_matrices(deviceResident=True)
-                torch.cuda.synchronize()
-                aux['iter2d_ms'] = 1e3 * (time.perf_counter() - ta) / 5
-                aux['iter2d_config'] = f'{p2.grid2d.Nx}x{p2.grid2d.Nz}, {p2.Nlambda} wavelengths, {p2.Nrays}x2 rays'
+        aux['stat_eq_ms'] = timed(lambda: ctx.stat_equil(deviceResident=True), 20, torch)
+    ctx.close()
+    if world == 1 and not args.no_aux:
+        for key, (name, fn) in AUX.items():
+            try:
+                aux[name] = fn(args, local_rank, stream.cuda_stream, torch, models)
+            except Exception as e:   # a side measurement must never break the bench line
+                aux[name] = {'failed': repr(e)}
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        per_step = world if args.scaling == 'weak' else 1
+        value = per_step * args.steps / elapsed
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic() if (world == 1 and args.nlambda == 10240) else (None, None)
         out = {
@@ -231,7 +369,7 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic (FAL-C model atmosphere, own H/CaII model atoms, seeded, generated in-process)',
@@ -247,7 +385,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm',
-                'kernel': 'sweep_atomic_kernel (sweep_body)',
+                'kernel': 'raymarch_kernel (ray-column sweep with the fused post-pass)',
                 'achieved': achieved,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
@@ -259,7 +397,7 @@ def main():
                 'launches_timed': nlaunch,
                 # what actually limits the kernel: fp64 vector issue, not HBM
                 'secondary': {
-                    'bound': 'fp64 vector (no MFMA: stencil + scan, not a contraction)',
+                    'bound': 'fp64 vector (no MFMA: stencil + recurrence, not a contraction)',
                     'achieved': alg_flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0,
                     'peak': FP64_VECTOR_PEAK_TFLOPS,
                     'unit': 'TFLOP/s',
@@ -268,18 +406,40 @@ def main():
                 },
             },
         }
+        if world > 1:
+            out['allreduce_us'] = allreduce_us
         if aux:
             out['aux'] = aux
         if world == 1 and not args.no_cpu_baseline:
             try:
                 single = prob.copy()
                 models.compute_profiles_host(single)   # the CPU leg needs phi on the host
-                out['cpu_baseline'] = cpu_baseline(single, args.cpu_seconds)
+                out['cpu_baseline'], par = cpu_baseline(single, args.cpu_seconds)
+                # parity at the timed size: the HIP path's first iteration (+ stat_equil) on the same inputs
+                gpu_first = gpu_first_iteration(single, local_rank, stream.cuda_stream)
+
+                def group_errs(x, ref):
+                    errs = {}
+                    for k, r in ref.items():
+                        grp = ''.join(ch for ch in k.split('_')[0] if not ch.isdigit())
+                        errs[grp] = max(errs.get(grp, 0.0), rel_err(x[k], r))
+                    return errs
+                errs = group_errs(gpu_first, par['first'])
+                tol = {k: (1e-8 if k == 'n' else PARITY_TOL) for k in errs}
+                out['max_rel_err'] = max(errs.values())
+                out['parity_checked'] = bool(all(errs[k] <= tol[k] for k in errs))
+                out['parity'] = {'against': par['name'], 'rel_err': errs,
+                                 'tolerance': {'one_iteration': PARITY_TOL, 'n_after_stat_equil': 1e-8},
+                                 'what': 'first formal_sol_gamma_matrices + stat_equil from identical inputs, '
+                                         f'{prob.Nlambda} wavelengths'}
+                if par['simd_first'] is not None:
+                    out['parity']['reference_simd_vs_scalar'] = {
+                        'scheme': par['simd_name'], 'rel_err': group_errs(par['simd_first'], par['first'])}
             except Exception as e:  # the baseline must never break the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': 0, 'kind': 'port',
                                        'sample': f'failed: {e!r}'}
+                out['parity_checked'] = False
         print(json.dumps(out))
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -3186,7 +3186,7 @@ int lwhip_algorithmic_bytes(lwhip_context* c, double* bytes)
             gam += 2.0 * a.Nlevel * a.Nlevel;
     }
     double b = 8.0 * Ns * (2.0 * Nmu * sumLineLa + 3.0 * Nla + 2.0 * Nla);
-    b += 8.0 * Nla * Nmu;
+    b += 8.0 * Nla * Nmu * c->Nx; // emergent I
     b += 8.0 * Ns * (gam + lev);
     b += 8.0 * Ns * 2.0 * c->Ntrans;
     b += 8.0 * Ns * (lev + 3.0 + Nmu);

@@ -19,6 +19,8 @@
 
 #include <cstdint>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -28,23 +30,43 @@
 
 namespace
 {
-struct Fingerprint
+// Exact change detection for the slowly changing inputs: a 64-bit hash of EVERY element of every tracked array
+// (plus pointer and length).  A sampled fingerprint would miss an in-place edit of an unsampled depth point -- what
+// update_deps() does after a local atmosphere change -- and the iteration would run on stale device inputs without
+// any sign of it.  Arrays are cut into 256 KB blocks hashed by a few host threads (four independent multiply-xor
+// lanes per block: memory speed), block hashes folded in order: ~0.2 ms for the 16 MB of line profiles of a
+// 3 000-wavelength H + Ca II problem.
+struct HashSet
 {
-    // Exact change detector for the slowly changing inputs: pointer, length and a hash of EVERY element (four
-    // independent multiply-xor lanes, so the loop runs at memory speed: ~0.1 ms per MB).  A sampled fingerprint
-    // would miss an in-place edit of an unsampled depth point -- what update_deps() does after a local atmosphere
-    // change -- and the iteration would run on stale device inputs without any sign of it.
+    enum { BLOCK = 32768 };
+    struct Job
+    {
+        const double* p;
+        size_t n;
+        uint64_t h;
+    };
+    struct Block
+    {
+        int job;
+        size_t off, len;
+        uint64_t h;
+    };
+    std::vector<Job> jobs;
+
+    int add(const double* p, size_t n)
+    {
+        jobs.push_back({ p, p ? n : 0, 0 });
+        return (int)jobs.size() - 1;
+    }
     static uint64_t mix(uint64_t h, uint64_t bits)
     {
         h = (h ^ bits) * 0x9E3779B97F4A7C15ull;
         return h ^ (h >> 29);
     }
-    static uint64_t of(const double* p, size_t n)
+    static uint64_t block_hash(const double* p, size_t n, uint64_t seed)
     {
-        uint64_t h0 = 1469598103934665603ull ^ (uint64_t)(uintptr_t)p, h1 = n * 0x9E3779B97F4A7C15ull,
-                 h2 = 0x2545F4914F6CDD1Dull, h3 = 0xD6E8FEB86659FD93ull;
-        if (!p || !n)
-            return h0 ^ h1;
+        uint64_t h0 = 1469598103934665603ull ^ seed, h1 = n * 0x9E3779B97F4A7C15ull, h2 = 0x2545F4914F6CDD1Dull,
+                 h3 = 0xD6E8FEB86659FD93ull;
         size_t i = 0;
         uint64_t w[4];
         for (; i + 4 <= n; i += 4)
@@ -62,6 +84,34 @@ struct Fingerprint
         }
         return mix(mix(mix(h0, h1), h2), h3);
     }
+    void run()
+    {
+        std::vector<Block> blocks;
+        size_t total = 0;
+        for (size_t j = 0; j < jobs.size(); ++j)
+            for (size_t off = 0; off < jobs[j].n; off += BLOCK)
+            {
+                blocks.push_back({ (int)j, off, std::min<size_t>(BLOCK, jobs[j].n - off), 0 });
+                total += blocks.back().len;
+            }
+        std::atomic<size_t> next{ 0 };
+        auto work = [&]() {
+            for (size_t b = next.fetch_add(1); b < blocks.size(); b = next.fetch_add(1))
+                blocks[b].h = block_hash(jobs[blocks[b].job].p + blocks[b].off, blocks[b].len, blocks[b].off);
+        };
+        unsigned nThreads = total * sizeof(double) > (1u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nThreads; ++t)
+            pool.emplace_back(work);
+        work();
+        for (auto& t : pool)
+            t.join();
+        for (auto& j : jobs)
+            j.h = mix((uint64_t)(uintptr_t)j.p, j.n);
+        for (auto& b : blocks)
+            jobs[b.job].h = mix(jobs[b.job].h, b.h);
+    }
+    uint64_t operator[](int j) const { return jobs[j].h; }
 };
 
 struct PluginState
@@ -138,8 +188,9 @@ void flatten_grid2d(Context& ctx, PluginState* st)
         throw std::runtime_error("lwhip plugin: the atmosphere has no intersection table (build_intersection_list)");
     const int Nx = atmos.Nx, Nz = atmos.Nz, Nrays = atmos.Nrays;
     // the table is flattened once per geometry: it only changes when the grid or the quadrature does
-    uint64_t sig = Fingerprint::of(atmos.x.data, Nx) ^ (Fingerprint::of(atmos.z.data, Nz) * 3)
-                   ^ (Fingerprint::of(atmos.mux.data, Nrays) * 5) ^ (Fingerprint::of(atmos.muz.data, Nrays) * 7)
+    auto hashOf = [](const double* p, size_t n) { return HashSet::mix((uint64_t)(uintptr_t)p, HashSet::block_hash(p, n, n)); };
+    uint64_t sig = hashOf(atmos.x.data, Nx) ^ (hashOf(atmos.z.data, Nz) * 3)
+                   ^ (hashOf(atmos.mux.data, Nrays) * 5) ^ (hashOf(atmos.muz.data, Nrays) * 7)
                    ^ ((uint64_t)atmos.zLowerBc.type << 8) ^ ((uint64_t)atmos.zUpperBc.type << 16)
                    ^ ((uint64_t)atmos.intersections.substeps.size() << 24) ^ 1;
     if (sig == st->gridSig && st->grid.Nx == Nx && st->grid.Nz == Nz && st->grid.Nrays == Nrays
@@ -318,31 +369,37 @@ uint32_t dirty_mask(PluginState* st, bool force)
 {
     const lwhip_problem& p = st->prob;
     const size_t Ns = p.Nspace, Nla = p.Nlambda, Nr = p.Nrays;
-    uint64_t fProf = 0, fNstar = 0, fColl = 0;
+    HashSet hs;
+    std::vector<int> jProf, jNstar, jColl, jBg, jAt;
     for (int ia = 0; ia < p.Natom; ++ia)
     {
         const lwhip_atom& a = p.atoms[ia];
-        fNstar ^= Fingerprint::of(a.nStar, (size_t)a.Nlevel * Ns) * 3 ^ Fingerprint::of(a.nTotal, Ns)
-                  ^ Fingerprint::of(a.vBroad, Ns) * 7;
-        if (a.C)
-            fColl ^= Fingerprint::of(a.C, (size_t)a.Nlevel * a.Nlevel * Ns) + ia;
+        jNstar.push_back(hs.add(a.nStar, (size_t)a.Nlevel * Ns));
+        jNstar.push_back(hs.add(a.nTotal, Ns));
+        jNstar.push_back(hs.add(a.vBroad, Ns));
+        jColl.push_back(hs.add(a.C, (size_t)a.Nlevel * a.Nlevel * Ns));
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
             const lwhip_transition& t = a.trans[kr];
-            if (t.type == LWHIP_LINE && t.aDamp)
-                fNstar ^= Fingerprint::of(t.aDamp, Ns) * 13 + kr;
-            if (t.type == LWHIP_LINE && t.Qelast)
-                fNstar ^= Fingerprint::of(t.Qelast, Ns) * 17 + kr;
-            if (t.type == LWHIP_LINE)
-                fProf ^= Fingerprint::of(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns) + kr
-                         ^ Fingerprint::of(t.wphi, Ns);
+            if (t.type != LWHIP_LINE)
+                continue;
+            jNstar.push_back(hs.add(t.aDamp, Ns));
+            jNstar.push_back(hs.add(t.Qelast, Ns));
+            jProf.push_back(hs.add(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns));
+            jProf.push_back(hs.add(t.wphi, Ns));
         }
     }
-    const uint64_t fBg = Fingerprint::of(p.bgChi, Nla * Ns) ^ Fingerprint::of(p.bgEta, Nla * Ns) * 3
-                         ^ Fingerprint::of(p.bgSca, Nla * Ns) * 5;
-    const uint64_t fAt = Fingerprint::of(p.height, Ns) ^ Fingerprint::of(p.temperature, Ns) * 3
-                         ^ Fingerprint::of(p.wavelength, Nla) * 5 ^ Fingerprint::of(p.muz, Nr) * 7
-                         ^ Fingerprint::of(p.wmu, Nr) * 11;
+    jBg = { hs.add(p.bgChi, Nla * Ns), hs.add(p.bgEta, Nla * Ns), hs.add(p.bgSca, Nla * Ns) };
+    jAt = { hs.add(p.height, Ns), hs.add(p.temperature, Ns), hs.add(p.wavelength, Nla), hs.add(p.muz, Nr), hs.add(p.wmu, Nr),
+            hs.add(p.vlosMu, p.vlosMu ? Nr * Ns : 0) };
+    hs.run();
+    auto fold = [&](const std::vector<int>& js) {
+        uint64_t h = js.size();
+        for (int j : js)
+            h = HashSet::mix(h, hs[j]);
+        return h;
+    };
+    const uint64_t fProf = fold(jProf), fNstar = fold(jNstar), fColl = fold(jColl), fBg = fold(jBg), fAt = fold(jAt);
     uint32_t mask = LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
     if (force || fProf != st->fpProfiles)
         mask |= LWHIP_PROFILES;

@@ -55,6 +55,16 @@ class DeviceReduceBuffer:
 
 
 class ShardedIteration:
+    """One iteration on a wavelength shard: partial sums, ONE all-reduce, finalise.
+
+    Stream contract.  `torch.distributed` orders a collective against torch's CURRENT stream only, while the
+    library queues its kernels on the context's stream.  For a HIP context the two are therefore made the same
+    stream before every collective phase (`ctx.set_stream(torch.cuda.current_stream())`): the sweep and reduce
+    kernels, the all-reduce and the apply kernel are then ordered by stream order alone, with no host
+    synchronisation in between.  A Context created with its own (library-owned) stream is re-bound here, and
+    calling under `with torch.cuda.stream(s):` moves the context to `s` for that call.
+    """
+
     def __init__(self, ctx, world: int = 1, rank: int = 0, group=None, force_collective=False):
         self.ctx = ctx
         self.world = world
@@ -62,6 +72,28 @@ class ShardedIteration:
         self.group = group
         self.force_collective = force_collective  # run the all-reduce even for world == 1 (tests)
         self._buf = None
+        self._bound = None      # the stream handle the context was last bound to
+        self._side = None       # side stream of the host-authoritative mode (all-reduce overlapped with the J download)
+        self.allreduce_s = 0.0  # host time spent issuing collectives (bench.py: allreduce_us)
+        self._bind_stream()
+
+    @property
+    def _collective(self):
+        return self.world > 1 or self.force_collective
+
+    def _is_hip(self):
+        return hasattr(self.ctx, 'lib') and hasattr(self.ctx, 'set_stream')
+
+    def _bind_stream(self):
+        """Make the context's stream torch's current stream (see the class docstring)."""
+        if not (self._collective and self._is_hip()):
+            return None
+        import torch
+        cur = torch.cuda.current_stream()
+        if self._bound != cur.cuda_stream:
+            self.ctx.set_stream(cur.cuda_stream)
+            self._bound = cur.cuda_stream
+        return cur
 
     def _reduce_tensor(self):
         if self._buf is None:
@@ -73,23 +105,43 @@ class ShardedIteration:
                 self._buf = torch.as_tensor(DeviceReduceBuffer(ptr, n), device='cuda')
         return self._buf
 
+    def _all_reduce(self, t):
+        import time
+        import torch.distributed as dist
+        t0 = time.perf_counter()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.allreduce_s += time.perf_counter() - t0
+
     def formal_sol_gamma_matrices(self, lambdaIterate=False, deviceResident=True, crsw=1.0):
         ctx = self.ctx
-        if self.world == 1 and not self.force_collective and hasattr(ctx, 'formal_sol_gamma_matrices') \
-                and hasattr(ctx, 'lib'):
+        if not self._collective and hasattr(ctx, 'formal_sol_gamma_matrices') and hasattr(ctx, 'lib'):
             # no collective to interleave: the library's one-call form (which also folds the second reduce stage
             # and the dJMax reduction into the apply launch)
             ctx.crsw = crsw
             return ctx.formal_sol_gamma_matrices(lambdaIterate=lambdaIterate, deviceResident=deviceResident)
+        cur = self._bind_stream()
         if deviceResident:
             ctx.gamma_prefill_from_C(crsw)
         else:
             ctx.prob.gamma_prefill(crsw)
             ctx.upload(abi.GAMMA | abi.J | abi.POPS | abi.BC | abi.RHOPRD)
         ctx.fs_partial(lambdaIterate)
-        if self.world > 1 or self.force_collective:
-            import torch.distributed as dist
-            dist.all_reduce(self._reduce_tensor(), op=dist.ReduceOp.SUM, group=self.group)
+        if self._collective and not deviceResident and cur is not None:
+            # host-authoritative mode: J and I are final once the sweep has run (they do not depend on the sums), so
+            # the all-reduce runs on a side stream while this stream copies them to the host
+            import torch
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=cur.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self._all_reduce(self._reduce_tensor())
+            ctx.download(abi.J | abi.I)
+            cur.wait_stream(self._side)
+            up = ctx.fs_finalise()
+            ctx.download(abi.ALL_OUTPUTS & ~(abi.J | abi.I))
+            return up
+        if self._collective:
+            self._all_reduce(self._reduce_tensor())
         up = ctx.fs_finalise()
         if not deviceResident:
             ctx.download(abi.ALL_OUTPUTS)
@@ -108,20 +160,20 @@ class ShardedIteration:
         scattering integral, and the iteration's usual all-reduce of the rate sums, whose tail also
         carries every rank's max |d rho / rho| per line.  Mirrors redistribute_prd_lines' loop
         (Source/PrdTemplates.hpp:250-290)."""
-        import torch.distributed as dist
         from .context import IterationUpdate
         ctx = self.ctx
-        collective = self.world > 1 or self.force_collective
+        collective = self._collective
+        self._bind_stream()
         dRhoAll, idxAll, dJAll, dJIdxAll = [], [], [], []
         it = 0
         while it < maxIter:
             it += 1
             buf = self._prd_tensor()          # packs this rank's rows
             if collective and buf is not None:
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(buf)
             ctx.prd_partial()
             if collective:
-                dist.all_reduce(self._reduce_tensor(), op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(self._reduce_tensor())
             dRho, idx, dJ, dJIdx = ctx.prd_finalise()
             dRhoAll.append(np.array(dRho))
             idxAll.append(np.array(idx))

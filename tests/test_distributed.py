@@ -255,3 +255,65 @@ def test_two_rank_gloo_prd_matches_unsharded(tmp_path):
         for q, t in enumerate(lines):
             want = t.rhoPrd[max(la0 - t.Nblue, 0):max(min(la1, t.Nred) - t.Nblue, 0)]
             assert rel_err(z[f'rho{q}'], want) <= 1e-10
+
+
+# ---- the same split on the real device path: two processes share ONE GPU ------------------------------------------
+def _gpu_worker(rank, world, port, out, resident):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lightweaver_amd.context import Context
+        prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
+        bounds = shard_bounds(prob, world)
+        la0, la1 = bounds[rank], bounds[rank + 1]
+        # stream=None: the context starts on a library-owned stream; ShardedIteration must move it to torch's
+        with Context(prob, device=0, laStart=la0, laEnd=la1, worldSize=world, worldRank=rank) as ctx:
+            it = ShardedIteration(ctx, world, rank)
+            ups = []
+            side = torch.cuda.Stream()
+            for i in range(3):
+                if i == 2:       # a different current stream: the context follows it
+                    with torch.cuda.stream(side):
+                        ups.append(it.formal_sol_gamma_matrices(deviceResident=resident))
+                    side.synchronize()
+                else:
+                    ups.append(it.formal_sol_gamma_matrices(deviceResident=resident))
+            if resident:
+                ctx.download(abi.ALL_OUTPUTS)
+        np.savez(os.path.join(out, f'gpu{rank}.npz'), J=prob.J[la0:la1], I=prob.I[la0:la1], la=[la0, la1],
+                 G0=prob.atoms[0].Gamma, G1=prob.atoms[-1].Gamma,
+                 R=np.stack([t.Rij for t in prob.atoms[0].trans]),
+                 dJ=[u.dJMax for u in ups], idx=[u.dJMaxIdx for u in ups])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('resident', [True, False])
+def test_two_process_gloo_on_one_gpu_matches_unsharded(gpu, tmp_path, resident):
+    """The N > 1 data path with the real kernels: two processes, each with a wavelength-shard Context on the SAME
+    GPU, all-reduce the zero-copy view of the library's device reduce buffer (gloo stages device tensors through the
+    host; RCCL refuses two ranks on one device) between fs_partial and fs_finalise.  Contexts start on their own
+    stream, so this also covers the stream contract of ShardedIteration; resident=False covers the all-reduce
+    overlapped with the J / I download."""
+    from lightweaver_amd.context import Context
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path), resident), nprocs=world, join=True)
+    prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
+    ups = []
+    with Context(prob) as ctx:
+        for _ in range(3):
+            ups.append(ctx.formal_sol_gamma_matrices(deviceResident=True))
+        ctx.download(abi.ALL_OUTPUTS)
+    for rank in range(world):
+        z = np.load(tmp_path / f'gpu{rank}.npz')
+        la0, la1 = z['la']
+        assert np.array_equal(z['J'], prob.J[la0:la1]) and np.array_equal(z['I'], prob.I[la0:la1])
+        assert rel_err(z['G0'], prob.atoms[0].Gamma) <= 1e-12
+        assert rel_err(z['G1'], prob.atoms[1].Gamma) <= 1e-12
+        assert rel_err(z['R'], np.stack([t.Rij for t in prob.atoms[0].trans])) <= 1e-12
+        assert [float(x) for x in z['dJ']] == [u.dJMax for u in ups]
+        assert [int(x) for x in z['idx']] == [u.dJMaxIdx for u in ups]

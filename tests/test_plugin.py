@@ -161,6 +161,35 @@ def test_dropin_detects_single_element_edits(gpu):
 
 @needs_ref
 @pytest.mark.gpu
+def test_dropin_detects_collision_edit_before_prd_call(gpu):
+    """One odd-depth element of C changes before a redistribute_prd call (the call that first sees, and records, the
+    new fingerprint); the next formal_sol_gamma_matrices must use the new C through its device-side pre-fill."""
+    from test_prd import golden_prd_problem
+    prob, _ = golden_prd_problem()
+    p, q = prob.copy(), prob.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for pr, c in ((p, hipc), (q, ref)):
+        pr.gamma_prefill()
+        c.formal_sol_gamma_matrices()
+    k = p.Nspace // 2 | 1
+    for pr in (p, q):
+        pr.atoms[-1].C[1, 0, k] *= 3.0
+        pr.atoms[-1].C[0, 0, k] = -pr.atoms[-1].C[1:, 0, k].sum()
+    u1, u2 = hipc.redistribute_prd(2, 1e-2), ref.redistribute_prd(2, 1e-2)
+    assert np.allclose(u1['dRho'], u2['dRho'], rtol=1e-5)
+    for pr, c in ((p, hipc), (q, ref)):
+        pr.gamma_prefill()
+        c.formal_sol_gamma_matrices()
+        assert c.stat_equil() == 0
+    a, b = collect(p, ('J', 'Gamma', 'R')), collect(q, ('J', 'Gamma', 'R'))
+    worst = {kk: rel_err(a[kk], b[kk]) for kk in a}
+    assert max(worst.values()) <= 1e-8, worst
+    for x, y in zip(p.atoms, q.atoms):
+        assert rel_err(x.n, y.n) <= 1e-7
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_dropin_stat_eq_as_first_call(gpu):
     """stat_eq may be the first member the core calls on a fresh Context (e.g. after loading a pickled state with
     its Gamma): the plugin finds the owning Context from the atoms registered by alloc_global_scratch."""

@@ -1,0 +1,101 @@
+"""Parity at the sizes bench.py times (the oracle is the reference's scalar scheme, restated in
+oracle/lw_oracle.c and pinned to it by tests/test_oracle_vs_reference.py): the 10 240-wavelength throughput grid, the
+512-column fused batch, the 256 x 82 2D iteration.  The CPU side runs the C oracle with OpenMP (seconds each)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+from lightweaver_amd import _abi as abi
+from lightweaver_amd.harness import models
+from oracle.bindings import OracleContext
+
+pytestmark = pytest.mark.gpu
+THREADS = min(os.cpu_count() or 1, 64)
+
+
+def assert_iteration_matches(p, q, tolGamma=1e-9, tol=1e-9):
+    worst = {'J': rel_err(p.J, q.J), 'I': rel_err(p.I, q.I)}
+    for ia, (a, b) in enumerate(zip(p.atoms, q.atoms)):
+        if not a.detailed:
+            worst[f'Gamma{ia}'] = rel_err(a.Gamma, b.Gamma)
+        worst[f'R{ia}'] = max(max(rel_err(ta.Rij, tb.Rij), rel_err(ta.Rji, tb.Rji)) for ta, tb in zip(a.trans, b.trans))
+    assert all(v <= (tolGamma if k.startswith('Gamma') else tol) for k, v in worst.items()), worst
+    return worst
+
+
+def test_throughput_grid_iteration_and_stat_equil_vs_oracle(gpu):
+    """BASELINE configs[1] as bench.py times it: models.throughput_grid(10240), Bezier3, 5 mu, default tiling; one
+    iteration (1e-9) and the populations one stat_equil then gives (1e-8), then a second iteration from those."""
+    from lightweaver_amd.context import Context
+    prob = models.throughput_grid(NlambdaTarget=10240, Nrays=5)
+    assert abs(prob.Nlambda - 10240) <= 102
+    q = prob.copy()
+    oc = OracleContext(q)
+    with Context(prob) as ctx:
+        for it in range(2):
+            up = ctx.formal_sol_gamma_matrices()
+            q.gamma_prefill()
+            dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+            assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+            assert_iteration_matches(prob, q, tol=1e-9 * (it + 1), tolGamma=1e-9 * (it + 1))
+            ctx.stat_equil()
+            assert oc.stat_equil() == 0
+            for a, b in zip(prob.atoms, q.atoms):
+                assert rel_err(a.n, b.n) <= 1e-8
+
+
+def test_512_column_fused_batch_sample_vs_oracle(gpu):
+    """BASELINE configs[3] at the size bench.py's aux entry times: 512 perturbed FAL-C columns (H + Ca II, ~2 900
+    wavelengths each, profiles generated on the device) advanced as ONE fused batch; 8 sampled columns against their
+    own oracle runs after 2 iterations + stat_equil."""
+    from lightweaver_amd.batch import ColumnBatch
+    ncol, sample = 512, [0, 1, 63, 64, 200, 255, 300, 511]
+    base = models.falc82()
+    probs = [models.falc_h_ca(Nrays=5, lineScale=3.1, atmos=models.perturbed(base, seed=1234 + c), computeProfiles=False)
+             for c in range(ncol)]
+    with ColumnBatch(probs) as batch:
+        assert batch._batch is not None
+        for it in range(2):
+            ups = batch.formal_sol_gamma_matrices()
+        batch.stat_equil()
+        for c in sample:
+            batch.contexts[c].download(abi.ALL_OUTPUTS | abi.POPS | abi.PROFILES)
+    for c in sample:
+        q = models.falc_h_ca(Nrays=5, lineScale=3.1, atmos=models.perturbed(base, seed=1234 + c))   # host profiles
+        for a, b in zip(probs[c].atoms, q.atoms):
+            for ta, tb in zip(a.trans, b.trans):
+                if ta.type == abi.LINE:
+                    assert rel_err(ta.phi, tb.phi) <= 1e-9       # the device's Voigt profiles vs the harness's
+        oc = OracleContext(q)
+        for it in range(2):
+            q.gamma_prefill()
+            dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+        assert ups[c].dJMax == pytest.approx(dJ, rel=1e-7)
+        assert_iteration_matches(probs[c], q, tol=1e-8, tolGamma=1e-8)
+        assert oc.stat_equil() == 0
+        for a, b in zip(probs[c].atoms, q.atoms):
+            assert rel_err(a.n, b.n) <= 1e-7
+
+
+def test_2d_256x82_iteration_vs_oracle(gpu):
+    """BASELINE configs[4] at the size bench.py's aux entry times: 256 x 82 x-periodic atmosphere of perturbed FAL-C
+    columns, H(6), BESSER short characteristics; the whole iteration (not just the solver) + stat_equil."""
+    from lightweaver_amd.context import Context
+    base = models.falc82()
+    cols = [models.perturbed(base, seed=1234 + j) for j in range(256)]
+    prob = models.build_problem_2d(cols, np.linspace(0.0, 25.0e3 * 255, 256), [models.H_6(0.5)])
+    assert (prob.grid2d.Nx, prob.grid2d.Nz) == (256, 82)
+    q = prob.copy()
+    oc = OracleContext(q)
+    with Context(prob) as ctx:
+        up = ctx.formal_sol_gamma_matrices()
+        q.gamma_prefill()
+        dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+        assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+        # Gamma: the device adds per-wavelength ray sums where the reference adds term by term (tests/test_fs2d.py)
+        assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-8)
+        ctx.stat_equil()
+        assert oc.stat_equil() == 0
+        assert rel_err(prob.atoms[0].n, q.atoms[0].n) <= 1e-8
