@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +135,7 @@ struct lwhip_context
     int groups2d = 1, maxRowsLa = 1;
     double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration
     double* tailMappedDev = nullptr;
+    double tailTicket = 0.0;      // ticket of the last launch that reports through tailMapped
     bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
     int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
@@ -2042,10 +2044,13 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
             a.tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
             if (!c->tailMapped)
             {
-                HIP_TRY(hipHostMalloc((void**)&c->tailMapped, 2 * sizeof(double), hipHostMallocMapped));
+                HIP_TRY(hipHostMalloc((void**)&c->tailMapped, 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
                 HIP_TRY(hipHostGetDevicePointer((void**)&c->tailMappedDev, c->tailMapped, 0));
+                c->tailMapped[2] = 0.0;
             }
             a.tailHost = c->tailMappedDev;
+            c->tailTicket += 1.0;
+            a.tailTicket = c->tailTicket;
             mapped = res != nullptr;
         }
         HIP_TRY(launch_apply(a, c->stream));
@@ -2055,7 +2060,21 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
     c->partialPending = false;
     if (res && mapped)
     {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // The dJMax block of the apply launch publishes (dJMax, idx) and then this launch's ticket in host-mapped memory:
+        // poll for the ticket rather than for the end of the stream, so the caller can queue the next iteration while
+        // the rest of the launch drains (everything downstream is stream-ordered).  The stream is queried now and then
+        // so that a failed launch cannot hang the host.
+        volatile double* tm = c->tailMapped;
+        bool seen = false;
+        for (long spin = 0; !(seen = (tm[2] == c->tailTicket)); ++spin)
+        {
+            __builtin_ia32_pause();
+            if ((spin & 0x3fff) == 0x3fff && hipStreamQuery(c->stream) != hipErrorNotReady)
+                break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!seen)
+            HIP_TRY(hipStreamSynchronize(c->stream));
         res->updatedJ = 1;
         res->dJMax = c->tailMapped[0];
         res->dJMaxIdx = (int32_t)c->tailMapped[1];

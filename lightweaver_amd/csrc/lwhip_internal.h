@@ -294,7 +294,8 @@ struct ApplyArgs
     const double* red8;            // [Ntrans, SPLIT, 4, Ns] or null
     const double* dJ;              // [NlaDj] per-wavelength dJ, or null (no dJMax workgroup)
     double* tail;                  // (dJMax, idx) slot
-    double* tailHost;              // host-mapped mirror of that slot (read after the stream synchronisation), or null
+    double* tailHost;              // host-mapped mirror of that slot [dJMax, idx, ticket], or null
+    double tailTicket;             // written last (system-scope release): the host polls for it instead of waiting for the stream
     int32_t fromParts, NlaDj, idxOffset;
     int32_t zeroParts;             // the parts are accumulated by atomics: whoever reads an element zeroes it
 };

@@ -18,7 +18,8 @@ namespace lwhip
 // (BATCH: column batches -- blockIdx.z picks the column's argument block from a table read through the constant
 // address space; the single-problem instantiation keeps its kernel-argument block untouched)
 __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* tail, int world, int rank,
-                            double* mirror = nullptr /* host-mapped copy of the tail: no read-back copy needed */)
+                            double* mirror = nullptr /* host-mapped copy of the tail: no read-back copy needed */,
+                            double ticket = 0.0 /* stored behind the mirror once it is complete */)
 {
     // dJMax and the index of its first occurrence (max_idx, Constants.hpp:114-125) into this
     // shard's slot of the gather tail; every other slot is zeroed (the all-reduce sums them)
@@ -60,8 +61,14 @@ __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* 
         else if (q == 2 * rank + 1)
             v = (double)(sI[0] + idxOffset);
         tail[q] = v;
-        if (mirror)
-            mirror[q] = v;
+    }
+    if (mirror && threadIdx.x == 0)
+    {
+        // the host polls mirror[2] for this launch's ticket (lwhip_fs_finalise): value and index first, then the ticket
+        // with system-scope release, so the result can be picked up while the other blocks of the launch still run
+        __hip_atomic_store(&mirror[0], sV[0] < 0.0 ? 0.0 : sV[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mirror[1], (double)(sI[0] + idxOffset), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mirror[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -125,7 +132,7 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
     if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ is set)
     {
         if (blockIdx.y == 0)
-            djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0, a.tailHost);
+            djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0, a.tailHost, a.tailTicket);
         return;
     }
     // the reduced sum of transition tr, component q at depth k: from the reduce buffer, or from the stage-1 parts
