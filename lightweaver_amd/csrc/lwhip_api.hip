@@ -136,6 +136,11 @@ struct lwhip_context
     double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration
     double* tailMappedDev = nullptr;
     double tailTicket = 0.0;      // ticket of the last launch that reports through tailMapped
+    // line profiles generated on the device (lwhip_compute_profiles): re-derived before the next sweep whenever the
+    // inputs they depend on (vlosMu: LWHIP_ATMOS; vBroad, aDamp: LWHIP_NSTAR) are uploaded again
+    bool deviceProfiles = false, profilesStale = false;
+    DevBuf<double> wphiScratch;   // [16, Ns] wavelength-slice sums of the profile normalisation
+    DevBuf<int> wphiTicket;       // arrival counters of its point tiles
     bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
     int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
@@ -1702,7 +1707,10 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         const int str = retile_profiles(c);
         if (str != LWHIP_OK)
             return str;
+        c->deviceProfiles = c->profilesStale = false; // the host's profiles are authoritative again
     }
+    else if ((mask & (LWHIP_ATMOS | LWHIP_NSTAR)) && c->deviceProfiles)
+        c->profilesStale = true; // phi / wphi follow the new velocities and widths before the next sweep
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LWHIP_OK;
 }
@@ -1968,11 +1976,18 @@ static ApplyArgs make_apply_args(lwhip_context* c)
     return a;
 }
 
+static int ensure_profiles(lwhip_context* c);
+
 static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int stp = ensure_profiles(c);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
     if (c->is2d)
     {
         const int st2 = run_2d(c, lambdaIterate);
@@ -2278,6 +2293,12 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
         lwhip_context* c = b->ctxs[i];
         if (c->partialPending || c->prdPending)
             return fail(LWHIP_ERR_INVALID, "batch iteration while a split iteration of a column is pending");
+        if (c->profilesStale) // a column whose atmosphere was updated: its phi / wphi first, on the batch's stream
+        {
+            const int stp = ensure_profiles(c);
+            if (stp != LWHIP_OK)
+                return stp;
+        }
         c->prefillCrsw = crsw;
         c->prefillPending = c->gammaTot > 0 && c->Cmat.p != nullptr;
         b->aHost[i] = make_apply_args(c);
@@ -2359,6 +2380,11 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int stp = ensure_profiles(c);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
     if (c->is2d)
         return run_2d(c, 0, upOnly ? 2 : 1);
     const TileDyn dyn = make_dyn(c, upOnly != 0, 0);
@@ -2776,6 +2802,11 @@ int lwhip_prd_partial(lwhip_context* c)
     if (c->partialPending || c->prdPending)
         return fail(LWHIP_ERR_INVALID, "lwhip_prd_partial inside an unfinished iteration / sub-iteration");
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int stp = ensure_profiles(c);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
     const int Ns = c->Ns;
     const int Nprd = (int)c->prdLines.size();
     if (Nprd == 0)
@@ -3097,13 +3128,19 @@ int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double waveleng
     return LWHIP_OK;
 }
 
-int lwhip_compute_profiles(lwhip_context* c)
+// phi and wphi of every line from (aDamp, vBroad, vlosMu) on the device: compute_profile's Voigt loop
+// (Source/LwMiddleLayer.pyx:3244-3288 -> LwTransition.hpp:155-190), one launch pair per line
+static int compute_profiles_impl(lwhip_context* c)
 {
-    if (!c)
-        return fail(LWHIP_ERR_INVALID, "null context");
-    HIP_TRY(hipSetDevice(c->device));
     if (!c->prob.vlosMu)
         return fail(LWHIP_ERR_INVALID, "lwhip_compute_profiles needs vlosMu in the descriptor");
+    const int slices = 16;
+    if (!c->is2d && c->wphiScratch.n == 0)
+    {
+        HIP_TRY(c->wphiScratch.alloc((size_t)slices * c->Ns));
+        HIP_TRY(c->wphiTicket.alloc((size_t)(c->Ns + 7) / 8 + 1));
+        HIP_TRY(hipMemsetAsync(c->wphiTicket.p, 0, c->wphiTicket.n * sizeof(int), c->stream));
+    }
     for (int tr = 0; tr < c->Ntrans; ++tr)
     {
         const HostTrans& h = c->trans[tr];
@@ -3126,9 +3163,28 @@ int lwhip_compute_profiles(lwhip_context* c)
         a.aDamp = c->aDamp.p + (size_t)h.row * c->Ns;
         a.phi = c->phi.p + (a.nlt > 0 ? h.phiOff : 0);
         a.wphi = c->wphi.p + (size_t)h.row * c->Ns;
+        a.wphiScratch = c->wphiScratch.p;
+        a.wphiTicket = c->wphiTicket.p;
+        a.wphiSlices = slices;
         HIP_TRY(launch_voigt_line(a, c->stream));
     }
+    c->deviceProfiles = true;
+    c->profilesStale = false;
     return retile_profiles(c);
+}
+
+// before a sweep: device-generated profiles whose inputs were uploaded again are brought up to date
+static int ensure_profiles(lwhip_context* c)
+{
+    return c->profilesStale ? compute_profiles_impl(c) : LWHIP_OK;
+}
+
+int lwhip_compute_profiles(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return compute_profiles_impl(c);
 }
 
 int lwhip_synchronize(lwhip_context* c)

@@ -317,6 +317,9 @@ struct VoigtLineArgs
     const double* aDamp;    // [Ns]
     double* phi;            // [nlt, Nrays, 2, Ns]
     double* wphi;           // [Ns]
+    double* wphiScratch;    // [wphiSlices, Ns] partial sums of the wavelength slices (null: one slice)
+    int* wphiTicket;        // [point tiles] arrival counters, zero between launches
+    int32_t wphiSlices, _pad2;
 };
 hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream);
 

@@ -196,22 +196,25 @@ __global__ void voigt_phi_kernel(VoigtLineArgs a)
 }
 
 // wphi[k] = 1 / sum_{la, mu, dir} phi w_lambda(la) w_mu/2 over the line's FULL grid (independent of
-// the wavelength shard); thread (part, k) sums la = part, part + P, ...; parts combined in order
+// the wavelength shard).  Workgroup (x, y) owns KT consecutive points (all of them in 1D; tiles of a 2D domain) and the
+// wavelengths of slice y: thread (part, k) sums la = y*P + part, + P*gridDim.y, ...; the workgroup's parts are combined
+// in order into scratch[y][k], and the last workgroup of a point tile to arrive (ticket) adds the slices in order.
 __global__ void voigt_wphi_kernel(VoigtLineArgs a, int KT)
 {
-    // a workgroup owns KT consecutive points (all of them in 1D; tiles of a 2D domain) x P partial sums
     extern __shared__ double sPart[];
+    __shared__ int sLast;
     const double sqrtPi = 1.772453850905516027298167483341145182798;
     const int P = blockDim.x / KT;
     const int part = threadIdx.x / KT;
     const int kl = threadIdx.x - part * KT;
     const int k = blockIdx.x * KT + kl;
+    const int PB = gridDim.y;
     double acc = 0.0;
     if (part < P && k < a.Ns)
     {
         const double vb = a.vBroad[k];
         const double ad = a.aDamp[k];
-        for (int la = part; la < a.nltFull; la += P)
+        for (int la = blockIdx.y * P + part; la < a.nltFull; la += P * PB)
         {
             const double vBase = (a.wave[la] - a.lambda0) * CLight / a.lambda0;
             const double wla = a.wlam[la];
@@ -234,6 +237,31 @@ __global__ void voigt_wphi_kernel(VoigtLineArgs a, int KT)
         double s = 0.0;
         for (int q = 0; q < P; ++q)
             s += sPart[q * KT + threadIdx.x];
+        if (PB == 1)
+            a.wphi[k] = 1.0 / s;
+        else
+            a.wphiScratch[(size_t)blockIdx.y * a.Ns + k] = s;
+    }
+    if (PB == 1)
+        return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int old = atomicAdd(a.wphiTicket + blockIdx.x, 1);
+        sLast = old == PB - 1;
+        if (sLast)
+            a.wphiTicket[blockIdx.x] = 0; // ready for the next launch on this stream
+    }
+    __syncthreads();
+    if (!sLast)
+        return;
+    __threadfence();
+    if (threadIdx.x < KT && k < a.Ns)
+    {
+        double s = 0.0;
+        for (int y = 0; y < PB; ++y)
+            s += __builtin_nontemporal_load(a.wphiScratch + (size_t)y * a.Ns + k);
         a.wphi[k] = 1.0 / s;
     }
 }
@@ -264,16 +292,19 @@ hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream)
         const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
         hipLaunchKernelGGL(voigt_phi_kernel, dim3(blocks), dim3(256), 0, stream, a);
     }
-    // tiles of 8 points (1D columns: ~10 workgroups instead of one, each with up to 128 partial sums over the
-    // line's wavelengths) or 64 (2D domains, which bring enough tiles)
+    // tiles of 8 points (1D columns: ~10 point tiles, each with up to 128 partial sums over a slice of the line's
+    // wavelengths) or 64 (2D domains, which bring enough tiles); wavelength slices so that a thread sums ~2 wavelengths
     const int KT = a.Ns <= 1024 ? 8 : 64;
     int P = 1024 / KT;
     if (P < 1)
         P = 1;
     if (P > a.nltFull)
         P = a.nltFull;
+    int PB = 1;
+    if (a.wphiScratch && a.wphiTicket && a.Ns <= 1024)
+        PB = std::max(1, std::min(a.wphiSlices, (a.nltFull + 2 * P - 1) / (2 * P)));
     const int T = ((P * KT + 63) / 64) * 64;
-    hipLaunchKernelGGL(voigt_wphi_kernel, dim3((a.Ns + KT - 1) / KT), dim3(T), (size_t)P * KT * sizeof(double), stream, a,
+    hipLaunchKernelGGL(voigt_wphi_kernel, dim3((a.Ns + KT - 1) / KT, PB), dim3(T), (size_t)P * KT * sizeof(double), stream, a,
                        KT);
     return hipGetLastError();
 }

@@ -130,3 +130,93 @@ def test_device_profiles_2d_domain_beyond_one_workgroup(gpu):
             if t.type == abi.LINE:
                 assert rel_err(t.phi, u.phi) <= 1e-12
                 assert rel_err(t.wphi, u.wphi) <= 1e-12
+
+
+# ---- atmosphere updates with device-generated profiles (f1) ---------------------------------------------------------
+def _adopt_atmosphere(p, fresh):
+    """Overwrite, in place, every input of `p` that depends on the atmosphere with `fresh`'s (same model atoms, same
+    grids): what the Python layer's update_deps() does after a temperature / velocity change."""
+    for name in ('temperature', 'vlosMu', 'bgChi', 'bgEta', 'bgSca', 'J'):
+        getattr(p, name)[...] = getattr(fresh, name)
+    for a, b in zip(p.atoms, fresh.atoms):
+        for name in ('n', 'nStar', 'nTotal', 'vBroad', 'C'):
+            getattr(a, name)[...] = getattr(b, name)
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                t.aDamp[...] = u.aDamp
+                if t.Qelast is not None:
+                    t.Qelast[...] = u.Qelast
+
+
+def _oracle_run(q, niter):
+    oc = OracleContext(q)
+    for _ in range(niter):
+        q.gamma_prefill()
+        dJ, _ = oc.formal_sol_gamma_matrices()
+    assert oc.stat_equil() == 0
+    return dJ
+
+
+def _assert_column_matches(p, q, tol=1e-9):
+    assert rel_err(p.J, q.J) <= tol and rel_err(p.I, q.I) <= tol
+    for a, b in zip(p.atoms, q.atoms):
+        assert rel_err(a.Gamma, b.Gamma) <= 10 * tol
+        assert rel_err(a.n, b.n) <= 1e-7
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                assert rel_err(t.phi, u.phi) <= tol and rel_err(t.wphi, u.wphi) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batched', [False, True])
+def test_profiles_follow_atmosphere_updates(gpu, batched):
+    """A column whose temperature and line-of-sight velocity change re-derives phi / wphi on the device: uploading
+    LWHIP_ATMOS | LWHIP_NSTAR marks device-generated profiles stale and the next sweep -- of the context, or of the
+    fused batch the column belongs to -- regenerates them first (compute_profile, Source/LwMiddleLayer.pyx:3244-3288;
+    Transition::compute_phi, Source/LwTransition.hpp:155-190).  Against the oracle run of the perturbed column."""
+    from lightweaver_amd.batch import ColumnBatch
+    from lightweaver_amd.context import Context
+    from lightweaver_amd.harness import models
+    base = models.falc82()
+    mk = lambda atmos, prof: models.falc_h_ca(Nrays=3, lineScale=0.3, atmos=atmos, computeProfiles=prof)
+    ncol, j = (4, 2) if batched else (1, 0)
+    probs = [mk(models.perturbed(base, seed=40 + c), False) for c in range(ncol)]
+    newAtmos = models.perturbed(base, seed=977, dT=0.08, dv=3.5e3)
+    up = abi.ATMOS | abi.NSTAR | abi.BACKGROUND | abi.COLLISIONS | abi.POPS | abi.J
+    down = abi.ALL_OUTPUTS | abi.POPS | abi.PROFILES
+    if batched:
+        with ColumnBatch(probs) as batch:
+            assert batch._batch is not None
+            for _ in range(2):
+                batch.formal_sol_gamma_matrices()
+            _adopt_atmosphere(probs[j], mk(newAtmos, False))
+            batch.contexts[j].upload(up)
+            for _ in range(2):
+                ups = batch.formal_sol_gamma_matrices()
+            batch.stat_equil()
+            for c in (j, 0):
+                batch.contexts[c].download(down)
+        dJ = ups[j].dJMax
+        # an untouched column is unaffected by its neighbour's update
+        q0 = mk(models.perturbed(base, seed=40), True)
+        oc = OracleContext(q0)
+        for _ in range(4):
+            q0.gamma_prefill()
+            oc.formal_sol_gamma_matrices()
+        assert rel_err(probs[0].J, q0.J) <= 1e-8
+    else:
+        with Context(probs[0]) as ctx:
+            ctx.compute_profiles(deviceResident=True)
+            for _ in range(2):
+                ctx.formal_sol_gamma_matrices(deviceResident=True)
+            _adopt_atmosphere(probs[0], mk(newAtmos, False))
+            ctx.upload(up)
+            for _ in range(2):
+                u = ctx.formal_sol_gamma_matrices(deviceResident=True)
+            ctx.stat_equil(deviceResident=True)
+            ctx.download(down)
+        dJ = u.dJMax
+    q = mk(newAtmos, True)
+    dJref = _oracle_run(q, 2)
+    assert dJ == pytest.approx(dJref, rel=1e-7)
+    _assert_column_matches(probs[j], q)
