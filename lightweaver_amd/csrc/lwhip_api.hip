@@ -895,11 +895,12 @@ int build_tables(lwhip_context* c)
         }
         int tgtSweep = std::min((2 * c->nTiles + W - 1) / W, numCU * wgPerCU); // two tasks per tile (down, up)
         // fused post-pass: the workgroup is the two wavefronts of one tile (and every tile is a workgroup)
-        c->tileFuse = W == 2 && c->batchHint <= 1 && env_int("LWHIP_TILE_FUSE", 1) != 0;
+        // (column batches too: 12.3k -> 16.0k column-iterations/s at 128 columns against a separate post launch)
+        c->tileFuse = W == 2 && env_int("LWHIP_TILE_FUSE", 1) != 0;
+        if (c->batchHint > 1 && !c->tileFuse)
+            tgtSweep = std::max(1, std::min(tgtSweep, numCU * 4 / c->batchHint));
         if (c->tileFuse)
             tgtSweep = c->nTiles;
-        if (c->batchHint > 1)
-            tgtSweep = std::max(1, std::min(tgtSweep, numCU * 4 / c->batchHint));
         if (!c->tileFuse)
             tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
         // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
