@@ -244,23 +244,50 @@ DEVINL double rm_rcp(double x)
 }
 // exp(x) for -700 < x <= 0 as d_exp_neg, the degree-13 polynomial split into its even and odd part (two independent
 // Horner chains in r^2: half the dependent latency)
-DEVINL double rm_exp_neg(double x)
+// (RM_EXPK: the non-inline constants live in VGPRs for the whole march instead of being re-materialised by two scalar
+// moves each on every step)
+struct ExpK
 {
-    const double n = rint(x * 1.4426950408889634074);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
+    double l2e, ln2h, ln2l, c12, c13, c10, c11, c8, c9, c6, c7, c4, c5, c3;
+    DEVINL void init()
+    {
+        l2e = 1.4426950408889634074;
+        ln2h = -6.93147180369123816490e-01;
+        ln2l = -1.90821492927058770002e-10;
+        c12 = 1.0 / 479001600.0;
+        c13 = 1.0 / 6227020800.0;
+        c10 = 1.0 / 3628800.0;
+        c11 = 1.0 / 39916800.0;
+        c8 = 1.0 / 40320.0;
+        c9 = 1.0 / 362880.0;
+        c6 = 1.0 / 720.0;
+        c7 = 1.0 / 5040.0;
+        c4 = 1.0 / 24.0;
+        c5 = 1.0 / 120.0;
+        c3 = 1.0 / 6.0;
+#ifdef RM_EXPK
+        asm volatile("" : "+v"(l2e), "+v"(ln2h), "+v"(ln2l), "+v"(c12), "+v"(c13), "+v"(c10), "+v"(c11));
+        asm volatile("" : "+v"(c8), "+v"(c9), "+v"(c6), "+v"(c7), "+v"(c4), "+v"(c5), "+v"(c3));
+#endif
+    }
+};
+DEVINL double rm_exp_neg(double x, const ExpK& K)
+{
+    const double n = rint(x * K.l2e);
+    double r = fma(n, K.ln2h, x);
+    r = fma(n, K.ln2l, r);
     const double r2 = r * r;
-    double pe = 1.0 / 479001600.0, po = 1.0 / 6227020800.0;
-    pe = fma(pe, r2, 1.0 / 3628800.0);
-    po = fma(po, r2, 1.0 / 39916800.0);
-    pe = fma(pe, r2, 1.0 / 40320.0);
-    po = fma(po, r2, 1.0 / 362880.0);
-    pe = fma(pe, r2, 1.0 / 720.0);
-    po = fma(po, r2, 1.0 / 5040.0);
-    pe = fma(pe, r2, 1.0 / 24.0);
-    po = fma(po, r2, 1.0 / 120.0);
+    double pe = K.c12, po = K.c13;
+    pe = fma(pe, r2, K.c10);
+    po = fma(po, r2, K.c11);
+    pe = fma(pe, r2, K.c8);
+    po = fma(po, r2, K.c9);
+    pe = fma(pe, r2, K.c6);
+    po = fma(po, r2, K.c7);
+    pe = fma(pe, r2, K.c4);
+    po = fma(po, r2, K.c5);
     pe = fma(pe, r2, 0.5);
-    po = fma(po, r2, 1.0 / 6.0);
+    po = fma(po, r2, K.c3);
     pe = fma(pe, r2, 1.0);
     po = fma(po, r2, 1.0);
     return ldexp(fma(po, r, pe), (int)n);
@@ -438,6 +465,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     const CONST_AS char* ktB = (const CONST_AS char*)(a.kt + a.ktStride); // entry -1 and Ns exist (padding)
     const unsigned ktS = (unsigned)a.ktStride * 8u;
     const bool storeDepth = RATES && a.storeDepth && !dyn.prdOnly;
+    ExpK expK;
+    expK.init();
     const double lamf = dyn.lambdaIterate ? 0.0 : 1.0;
     auto kOf = [&](int t) { return kS + dk * t; };
     auto lds_ = [](const CONST_AS char* base, unsigned off) { return *(const CONST_AS double*)(base + off); };
@@ -654,7 +683,7 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 double edt = 0.0, al = 0.0, be = 0.0, ga = 0.0, de = 0.0;
                 if (__builtin_amdgcn_ballot_w64(!small) != 0) // some ray of the wave is beyond the Taylor range
                 {
-                    const double ex = (x > 30.0) ? 0.0 : rm_exp_neg(-fmin(x, 64.0));
+                    const double ex = (x > 30.0) ? 0.0 : rm_exp_neg(-fmin(x, 64.0), expK);
                     const double r3 = (rdt2 * rdt2) * rdt2; // 1 / dtau^3 from the interval's 1 / dtau
                     edt = ex;
                     al = (6.0 - ex * (6.0 + 6.0 * x + 3.0 * x2 + x3)) * r3;
