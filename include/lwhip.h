@@ -177,12 +177,18 @@ typedef struct lwhip_problem {
     const struct lwhip_grid2d* grid2d;
 } lwhip_problem;
 
+#define LWHIP_OPT_PRD_DETAILED (1 << 16)
+
 typedef struct lwhip_options {
     int32_t device;        /* HIP device ordinal                                                   */
     int32_t laStart;       /* wavelength shard owned by this context: [laStart, laEnd)             */
     int32_t laEnd;         /* 0,0 = whole grid                                                     */
     int32_t flags;         /* bits 0-15: column-batch hint = number of contexts that will share the device
-                            * through lwhip_batch_* (0: none; sizes the per-context chunking); rest reserved  */
+                            * through lwhip_batch_* (0: none; sizes the per-context chunking);
+                            * bit 16 (LWHIP_OPT_PRD_DETAILED): the PRD calls include the PRD lines of
+                            * detailed-static atoms -- ExtraParams "include_detailed_atoms" of
+                            * redistribute_prd_lines (Source/PrdTemplates.hpp:25-29, 190-215), the default of
+                            * LwContext.prd_redistribute (Source/LwMiddleLayer.pyx:3678-3680); rest reserved */
     int32_t worldSize;     /* number of wavelength shards of the job (0 or 1 = unsharded)          */
     int32_t worldRank;     /* this shard's ordinal: selects its (dJMax, idx) slot in the buffer    */
     void* stream;          /* hipStream_t to launch on, NULL = the library's own stream            */

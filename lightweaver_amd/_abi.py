@@ -82,6 +82,9 @@ class lwhip_problem(C.Structure):
     ]
 
 
+OPT_PRD_DETAILED = 1 << 16   # lwhip_options.flags: the PRD calls include the detailed atoms' PRD lines
+
+
 class lwhip_options(C.Structure):
     _fields_ = [
         ('device', C.c_int32), ('laStart', C.c_int32), ('laEnd', C.c_int32), ('flags', C.c_int32),

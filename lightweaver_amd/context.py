@@ -84,7 +84,7 @@ class Context:
 
     def __init__(self, prob: Problem, device: int = 0, laStart: int = 0, laEnd: int = 0,
                  stream: Optional[int] = None, lib_path: Optional[str] = None,
-                 worldSize: int = 1, worldRank: int = 0, batchHint: int = 0):
+                 worldSize: int = 1, worldRank: int = 0, batchHint: int = 0, prdDetailed: bool = False):
         self.lib = load_library(lib_path)
         self.prob = prob
         self._desc = prob.descriptor()
@@ -93,7 +93,9 @@ class Context:
         opts.laStart, opts.laEnd = laStart, laEnd
         opts.stream = stream
         opts.worldSize, opts.worldRank = worldSize, worldRank
-        opts.flags = min(max(int(batchHint), 0), 0xffff)
+        # prdDetailed: ExtraParams 'include_detailed_atoms' of the reference's PRD calls (LwMiddleLayer.pyx:3678-3680)
+        opts.flags = min(max(int(batchHint), 0), 0xffff) | (abi.OPT_PRD_DETAILED if prdDetailed else 0)
+        self.prdDetailed = bool(prdDetailed)
         h = C.c_void_p()
         st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
         _check(self.lib, st, 'lwhip_create')
@@ -203,15 +205,18 @@ class Context:
                'lwhip_ng_configure')
         self._ng = (Norder, Nperiod, Ndelay)
 
-    def prd_redistribute(self, maxIter=3, tol=1e-2, deviceResident=False) -> IterationUpdate:
-        """PRD sub-iterations, LwContext.prd_redistribute (Source/LwMiddleLayer.pyx:3647-3684) with
-        include_detailed_atoms = False (the core's default, PrdTemplates.hpp:191-195): updates
-        rhoPrd of every PRD line of the active atoms, J over the PRD wavelengths and those lines'
-        Rij/Rji.  The host arrays are uploaded/downloaded around the call unless deviceResident."""
+    def prd_redistribute(self, maxIter=3, tol=1e-2, deviceResident=False, include_detailed_atoms=None) -> IterationUpdate:
+        """PRD sub-iterations, LwContext.prd_redistribute (Source/LwMiddleLayer.pyx:3647-3684): updates rhoPrd of
+        every PRD line of the active atoms -- and, on a Context created with prdDetailed=True (ExtraParams
+        include_detailed_atoms, PrdTemplates.hpp:25-29, 190-215), of the detailed atoms --, J over the PRD wavelengths
+        and those lines' Rij/Rji.  The host arrays are uploaded/downloaded around the call unless deviceResident.
+        (`include_detailed_atoms` is accepted for signature parity with the test doubles and must match the Context.)"""
+        if include_detailed_atoms is not None and bool(include_detailed_atoms) != self.prdDetailed:
+            raise LwHipError('include_detailed_atoms is a property of the device context: create it with '
+                             f'prdDetailed={bool(include_detailed_atoms)}')
         if not deviceResident:
             self.upload(abi.J | abi.POPS | abi.BC | abi.RHOPRD | abi.RATES | abi.COLLISIONS)
-        Nprd = sum(1 for a in self.prob.atoms if not a.detailed for t in a.trans
-                   if t.type == abi.LINE and t.rhoPrd is not None)
+        Nprd = self.Nprd
         n = max(maxIter, 1)
         dRho = np.zeros(n * max(Nprd, 1))
         dRhoIdx = np.zeros(n * max(Nprd, 1), dtype=np.int32)
@@ -255,7 +260,7 @@ class Context:
 
     @property
     def Nprd(self):
-        return sum(1 for a in self.prob.atoms if not a.detailed for t in a.trans
+        return sum(1 for a in self.prob.atoms if (self.prdDetailed or not a.detailed) for t in a.trans
                    if t.type == abi.LINE and t.rhoPrd is not None)
 
     def time_dep_update(self, dt, prevTimePops, deviceResident=False, atom=None) -> IterationUpdate:

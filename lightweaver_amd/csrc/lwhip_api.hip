@@ -143,6 +143,7 @@ struct lwhip_context
     DevBuf<int> wphiTicket;       // arrival counters of its point tiles
     bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
     int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
+    bool prdDetailed = false;     // LWHIP_OPT_PRD_DETAILED: the PRD calls include the detailed atoms' PRD lines
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
@@ -545,8 +546,8 @@ int build_tables(lwhip_context* c)
         hdr[la].nPure = (int16_t)pure.size();
         hdr[la].hasPrd = 0;
         for (int tr : lines)
-            if (c->trans[tr].t.prd && c->trans[tr].rhoOff >= 0 && isOp(tr))
-                hdr[la].hasPrd = 1;
+            if (c->trans[tr].t.prd && c->trans[tr].rhoOff >= 0 && (isOp(tr) || c->prdDetailed))
+                hdr[la].hasPrd = 1; // a wavelength the PRD rates pass visits (PrdTemplates.hpp:226-239)
         for (int tr : order)
         {
             const HostTrans& h = c->trans[tr];
@@ -1113,16 +1114,17 @@ int alloc_state(lwhip_context* c)
     c->prdLines.clear();
     c->prdRowOff.clear();
     c->prdRowsTot = 0;
-    for (int tr = 0; tr < c->Ntrans; ++tr)
-    {
-        const HostTrans& h = c->trans[tr];
-        if (h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && !c->atoms[h.atom].detailed)
+    for (int pass = 0; pass < (c->prdDetailed ? 2 : 1); ++pass) // the active atoms' lines, then the detailed atoms'
+        for (int tr = 0; tr < c->Ntrans; ++tr)
         {
-            c->prdLines.push_back(tr);
-            c->prdRowOff.push_back(c->prdRowsTot);
-            c->prdRowsTot += h.t.Nred - h.t.Nblue;
+            const HostTrans& h = c->trans[tr];
+            if (h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && (c->atoms[h.atom].detailed != 0) == (pass == 1))
+            {
+                c->prdLines.push_back(tr);
+                c->prdRowOff.push_back(c->prdRowsTot);
+                c->prdRowsTot += h.t.Nred - h.t.Nblue;
+            }
         }
-    }
     HIP_TRY(c->height.alloc(Ns));
     HIP_TRY(c->temperature.alloc(Ns));
     HIP_TRY(c->muz.alloc(Nr));
@@ -1473,6 +1475,7 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     c->atoms.assign(prob->atoms, prob->atoms + prob->Natom);
     c->device = opts ? opts->device : 0;
     c->batchHint = opts ? (opts->flags & 0xffff) : 0;
+    c->prdDetailed = opts && (opts->flags & LWHIP_OPT_PRD_DETAILED);
     if (c->device < 0 || c->device >= ndev)
     {
         delete c;
@@ -2815,7 +2818,7 @@ int lwhip_prd_partial(lwhip_context* c)
     if (c->prdJ.n < (size_t)c->prdRowsTot * Ns)
         return fail(LWHIP_ERR_INVALID, "lwhip_prd_partial before lwhip_prd_pack");
     for (int tr : c->prdLines)
-        if (!c->atoms[c->trans[tr].atom].C)
+        if (!c->atoms[c->trans[tr].atom].C && !c->atoms[c->trans[tr].atom].detailed)
             return fail(LWHIP_ERR_INVALID, "redistribute_prd needs the collisional rates C of atom "
                                            + std::to_string(c->trans[tr].atom));
     if (c->prdChange.n < (size_t)Nprd * Ns * PRD_MAX_SLICES)
@@ -2856,7 +2859,7 @@ int lwhip_prd_partial(lwhip_context* c)
         a.vBroad = c->vBroad.p + (size_t)h.atom * Ns;
         a.aDamp = c->aDamp.p + (size_t)h.row * Ns;
         a.Qelast = c->Qelast.p + (size_t)h.row * Ns;
-        a.Cmat = c->Cmat.p + c->gammaOff[h.atom];
+        a.Cmat = at.detailed ? nullptr : c->Cmat.p + c->gammaOff[h.atom];
         a.n = c->n.p;
         a.Rij = c->Rij.p;
         a.Rji = c->Rji.p;
@@ -2963,6 +2966,7 @@ int lwhip_prd_finalise(lwhip_context* c, double* dRho, int32_t* dRhoMaxIdx, doub
     ap.Rji = c->Rji.p;
     ap.Cmat = c->Cmat.p;
     ap.prdOnly = 1;
+    ap.prdDetailed = c->prdDetailed ? 1 : 0;
     HIP_TRY(launch_apply(ap, c->stream));
     c->prdPending = false;
     const size_t nTail = 2 * (size_t)c->worldSize * (1 + Nprd);

@@ -289,6 +289,9 @@ struct ApplyArgs
     double crsw;
     int32_t prefill;               // Gamma <- crsw * C before adding the radiative terms
     int32_t prdOnly;               // only Rij/Rji of PRD lines are written, Gamma untouched
+    int32_t prdDetailed;           // ... including the PRD lines of detailed atoms (include_detailed_atoms); otherwise
+                                   // those lines' sums are ADDED to their rates, as the reference does (PrdTemplates.hpp:30-52
+                                   // zeroes only the included lines, SimdFullIterationTemplates.hpp:455-466 integrates all)
     // single-device iteration without the second reduce stage: the sums are taken from the stage-1 parts (added in
     // the same order) and one extra workgroup does the dJMax reduction
     const double* red8;            // [Ntrans, SPLIT, 4, Ns] or null

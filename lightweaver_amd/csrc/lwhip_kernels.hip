@@ -160,8 +160,16 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
             const int k = k0 + (idx - tr * APPLY_K);
             if (k < Ns)
             {
-                if (a.prdOnly && !(a.trans[tr].prd && a.trans[tr].op && a.trans[tr].rhoOff >= 0))
+                if (a.prdOnly && !(a.trans[tr].prd && a.trans[tr].rhoOff >= 0))
                     continue;
+                if (a.prdOnly && !a.trans[tr].op && !a.prdDetailed)
+                {
+                    // a detailed atom's PRD line that is not part of the PRD calls: integrated over the visited
+                    // wavelengths on top of what it holds (see ApplyArgs::prdDetailed)
+                    a.Rij[(size_t)tr * Ns + k] += redAt(tr, 2, k);
+                    a.Rji[(size_t)tr * Ns + k] += redAt(tr, 3, k);
+                    continue;
+                }
                 a.Rij[(size_t)tr * Ns + k] = redAt(tr, 2, k);
                 a.Rji[(size_t)tr * Ns + k] = redAt(tr, 3, k);
                 if (a.zeroParts && !a.trans[tr].op) // the Gamma terms of a detailed atom have no reader: drop them here

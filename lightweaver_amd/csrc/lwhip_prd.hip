@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
     {
         double v = 0.0;
         if (q < a.Nlevel)
-            v = a.Cmat[((size_t)q * a.Nlevel + a.lj) * Ns + k];
+            v = a.Cmat ? a.Cmat[((size_t)q * a.Nlevel + a.lj) * Ns + k] : 0.0; // a detailed atom carries no C
         else
         {
             const int tr = a.trBegin + (q - a.Nlevel);
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
         }
         else
         {
-            for (int i = 0; i < a.Nlevel; ++i)
+            for (int i = 0; i < a.Nlevel && a.Cmat; ++i)
                 pq += a.Cmat[((size_t)i * a.Nlevel + a.lj) * Ns + k];
             for (int tr = a.trBegin; tr < a.trEnd; ++tr)
             {

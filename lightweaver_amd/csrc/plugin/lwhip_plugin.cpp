@@ -128,6 +128,7 @@ struct PluginState
     std::vector<double> height2d;
     uint64_t gridSig = 0, gridEpoch = 0; // geometry fingerprint; epoch enters the structural signature
     uint64_t fpProfiles = 0, fpBackground = 0, fpAtmos = 0, fpNstar = 0, fpCollisions = 0;
+    bool prdDetailed = false;          // the device context was asked to include the detailed atoms' PRD lines
 };
 
 std::mutex g_mutex;
@@ -311,7 +312,8 @@ void flatten(Context& ctx, PluginState* st, PluginState* keep)
     st->trans.assign(all.size(), {});
     st->shape = { (uint64_t)p.Nspace, (uint64_t)p.Nrays, (uint64_t)p.Nlambda, (uint64_t)p.formalSolver,
                   (uint64_t)p.storeDepthData, (uint64_t)p.zLowerBc.type, (uint64_t)p.zUpperBc.type,
-                  (uint64_t)all.size(), (uint64_t)(is2d ? atmos.Nx : 0), (uint64_t)(is2d ? keep->gridEpoch : 0) };
+                  (uint64_t)all.size(), (uint64_t)(is2d ? atmos.Nx : 0), (uint64_t)(is2d ? keep->gridEpoch : 0),
+                  (uint64_t)keep->prdDetailed };
     for (size_t ia = 0; ia < all.size(); ++ia)
     {
         Atom& a = *all[ia];
@@ -462,7 +464,9 @@ uint32_t sync_state(Context& ctx, bool force)
         if (old)
             lwhip_destroy(old);
         st->hip = nullptr;
-        if (lwhip_create(&st->prob, nullptr, &st->hip) != LWHIP_OK)
+        lwhip_options opts{};
+        opts.flags = st->prdDetailed ? LWHIP_OPT_PRD_DETAILED : 0;
+        if (lwhip_create(&st->prob, &opts, &st->hip) != LWHIP_OK)
             fail("lwhip_create");
         dirty_mask(st, true); // create uploaded everything: just record the fingerprints
         register_atoms(&ctx);
@@ -638,14 +642,21 @@ void nr_post_update_hip(Context& ctx, std::vector<Atom*>* atoms, const std::vect
 // redistribute_prd: replaces redistribute_prd_lines_template<SimdType> (Source/PrdTemplates.hpp:175-290)
 IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraParams params)
 {
-    if (params.contains("include_detailed_atoms") && params.get_as<bool>("include_detailed_atoms"))
+    // include_detailed_atoms (the default of LwContext.prd_redistribute, Source/LwMiddleLayer.pyx:3678-3680): a property
+    // of the device context -- its PRD line list and the wavelengths of its PRD rates pass -- so a change of the
+    // effective value rebuilds the context (it is part of the structural signature)
+    bool includeDetailed = params.contains("include_detailed_atoms") && params.get_as<bool>("include_detailed_atoms");
+    if (includeDetailed)
     {
+        includeDetailed = false;
         for (auto* a : ctx.detailedAtoms)
             for (auto* t : a->trans)
                 if (t->rhoPrd)
-                    throw std::runtime_error("lwhip plugin: PRD lines of detailed-static atoms are not redistributed "
-                                             "on the device (pass include_detailed_atoms = False)");
+                    includeDetailed = true;
     }
+    if (!ctx.methodScratch)
+        ctx.methodScratch = new PluginState();
+    ((PluginState*)ctx.methodScratch)->prdDetailed = includeDetailed;
     const uint32_t up = sync_state(ctx, force_upload(params));
     auto* st = (PluginState*)ctx.methodScratch;
     if (lwhip_upload(st->hip, (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES) != LWHIP_OK)
@@ -655,6 +666,11 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
         for (auto* t : a->trans)
             if (t->rhoPrd)
                 ++Nprd;
+    if (includeDetailed)
+        for (auto* a : ctx.detailedAtoms)
+            for (auto* t : a->trans)
+                if (t->rhoPrd)
+                    ++Nprd;
     IterationResult result{};
     if (Nprd == 0 || maxIter <= 0)
         return result;

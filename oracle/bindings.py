@@ -108,6 +108,8 @@ class RefContext(_Handle):
             lib.lwref_stat_equil.argtypes = [C.c_void_p, C.c_int]
             lib.lwref_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
                                                    abi.f64p, abi.i32p, abi.f64p, abi.i32p]
+            lib.lwref_set_include_detailed.argtypes = [C.c_void_p, C.c_int]
+            lib.lwref_set_include_detailed.restype = None
             lib.lwref_time_dep_update.argtypes = [C.c_void_p, C.c_int, abi.f64p, C.c_double]
             lib.lwref_nr_post_update.argtypes = [C.c_void_p, C.POINTER(abi.lwhip_nr_args)]
             lib.lwref_GII.restype = C.c_double
@@ -158,7 +160,8 @@ class RefContext(_Handle):
     def stat_equil(self, atom=-1):
         return self.lib.lwref_stat_equil(self.h, atom)
 
-    def redistribute_prd(self, maxIter=3, tol=1e-2):
+    def redistribute_prd(self, maxIter=3, tol=1e-2, include_detailed_atoms=False):
+        self.lib.lwref_set_include_detailed(self.h, int(include_detailed_atoms))
         return _redistribute(self.lib.lwref_redistribute_prd, self.h, maxIter, tol)
 
     def time_dep_update(self, atom, nOld, dt):
@@ -191,6 +194,8 @@ class OracleContext(_Handle):
             lib.lworacle_fs_partial.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, abi.f64p, abi.f64p]
             lib.lworacle_fs_finalise.argtypes = [C.c_void_p, abi.f64p]
             lib.lworacle_stat_equil.argtypes = [C.c_void_p, C.c_int]
+            lib.lworacle_set_include_detailed.argtypes = [C.c_void_p, C.c_int]
+            lib.lworacle_set_include_detailed.restype = None
             lib.lworacle_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
                                                       abi.f64p, abi.i32p, abi.f64p, abi.i32p]
             lib.lworacle_prd_scatter_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.f64p, abi.i32p]
@@ -257,7 +262,8 @@ class OracleContext(_Handle):
     def stat_equil(self, atom=-1):
         return self.lib.lworacle_stat_equil(self.h, atom)
 
-    def redistribute_prd(self, maxIter=3, tol=1e-2):
+    def redistribute_prd(self, maxIter=3, tol=1e-2, include_detailed_atoms=False):
+        self.lib.lworacle_set_include_detailed(self.h, int(include_detailed_atoms))
         return _redistribute(self.lib.lworacle_redistribute_prd, self.h, maxIter, tol)
 
     def time_dep_update(self, atom, nOld, dt):

@@ -50,6 +50,7 @@ struct RefContext
     const lwhip_problem* prob;
     Context ctx;
     bool threadsInitialised = false;
+    bool includeDetailed = false; // ExtraParams "include_detailed_atoms" of the PRD calls
 
     ~RefContext()
     {
@@ -577,6 +578,12 @@ void lwref_ng_max_change(void* h, double* dMax, int* idx)
     *idx = (int)c.dMaxIdx;
 }
 
+// what LwContext.prd_redistribute passes as extraParams (Source/LwMiddleLayer.pyx:3678-3680)
+void lwref_set_include_detailed(void* h, int on)
+{
+    ((RefContext*)h)->includeDetailed = on != 0;
+}
+
 // redistribute_prd_lines (Source/Prd.cpp:648-653 -> PrdTemplates.hpp:175-351)
 int lwref_redistribute_prd(void* h, int maxIter, double tol, int* NprdSubIter, int* NprdOut,
                            double* dRho, int* dRhoMaxIdx, double* dJPrdMax, int* dJPrdMaxIdx)
@@ -585,7 +592,10 @@ int lwref_redistribute_prd(void* h, int maxIter, double tol, int* NprdSubIter, i
     try
     {
         refresh_bcs(rc);
-        IterationResult r = redistribute_prd_lines(rc->ctx, maxIter, tol);
+        ExtraParams params;
+        if (rc->includeDetailed)
+            params.insert("include_detailed_atoms", true);
+        IterationResult r = redistribute_prd_lines(rc->ctx, maxIter, tol, params);
         if (NprdSubIter)
             *NprdSubIter = r.NprdSubIter;
         const int Nprd = r.NprdSubIter > 0 ? (int)(r.dRho.size() / r.NprdSubIter) : 0;

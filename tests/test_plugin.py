@@ -190,6 +190,31 @@ def test_dropin_detects_collision_edit_before_prd_call(gpu):
 
 @needs_ref
 @pytest.mark.gpu
+@pytest.mark.parametrize('include', [True, False])
+def test_dropin_prd_include_detailed_atoms(gpu, include):
+    """redistribute_prd of the plugin with ExtraParams include_detailed_atoms (what LwContext.prd_redistribute passes,
+    True by default): the device context is rebuilt with the detailed atoms' PRD lines in its list.  (One value per
+    Context, as the Python layer does: the core caches the PRD wavelength list of its first call in spect.hPrdIdxs --
+    PrdTemplates.hpp:222-240 assigns through a reference -- so toggling the flag on a live Context is not meaningful.)"""
+    from test_prd import assert_same_state, detailed_prd_problem
+    prob = detailed_prd_problem()
+    p, q = prob.copy(), prob.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(2):
+        for pr, c in ((p, hipc), (q, ref)):
+            pr.gamma_prefill()
+            c.formal_sol_gamma_matrices()
+            assert c.stat_equil() == 0
+        u1 = hipc.redistribute_prd(3, 1e-3, include_detailed_atoms=include)
+        u2 = ref.redistribute_prd(3, 1e-3, include_detailed_atoms=include)
+        assert u1['NprdSubIter'] == u2['NprdSubIter'] and u1['Nprd'] == u2['Nprd'] == (3 if include else 1)
+        assert np.allclose(u1['dRho'], u2['dRho'], rtol=1e-5)
+        assert np.allclose(u1['dJPrdMax'], u2['dJPrdMax'], rtol=1e-7)
+    assert_same_state(p, q, 1e-8)
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_dropin_stat_eq_as_first_call(gpu):
     """stat_eq may be the first member the core calls on a fresh Context (e.g. after loading a pickled state with
     its Gamma): the plugin finds the owning Context from the atoms registered by alloc_global_scratch."""

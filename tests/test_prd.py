@@ -116,6 +116,48 @@ def test_oracle_prd_matches_reference(solver):
     assert np.isfinite(rho).all() and np.abs(rho - 1.0).max() > 1e-3  # PRD actually did something
 
 
+def detailed_prd_problem():
+    """An active atom with a PRD line (H Lyman-alpha made PRD) next to a DETAILED atom with PRD lines (Ca II H & K):
+    what `include_detailed_atoms` (the default of LwContext.prd_redistribute, LwMiddleLayer.pyx:3678-3680) is about."""
+    p, _ = golden_prd_problem()
+    h, ca = p.atoms
+    t = next(t for t in h.trans if t.type == abi.LINE)
+    t.rhoPrd = np.ones((t.Nred - t.Nblue, p.Nspace))
+    ca.detailed = True
+    return rebuild(p)
+
+
+def run_detailed(ctxFactory, prob, include, nIter=2):
+    p = prob.copy()
+    out = []
+    with ctxFactory(p) as ctx:
+        for it in range(nIter):
+            p.gamma_prefill()
+            ctx.formal_sol_gamma_matrices()
+            ctx.stat_equil()
+            out.append(ctx.redistribute_prd(3, 1e-3, include_detailed_atoms=include))
+    return p, out
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+@pytest.mark.parametrize('include', [True, False])
+def test_oracle_prd_detailed_atoms_matches_reference(include):
+    """redistribute_prd_lines with and without include_detailed_atoms (PrdTemplates.hpp:25-29, 190-215): the
+    detailed atom's PRD lines join the list after the active atoms' (their Pj + Qj has no collisional term: a
+    detailed atom carries no C), their rates are zeroed and re-integrated by the PRD rates pass.  Bit for bit."""
+    prob = detailed_prd_problem()
+    pr, ur = run_detailed(bindings.RefContext, prob, include)
+    po, uo = run_detailed(bindings.OracleContext, prob, include)
+    for a, b in zip(ur, uo):
+        assert a['NprdSubIter'] == b['NprdSubIter'] and a['Nprd'] == b['Nprd'] == (3 if include else 1)
+        for k in ('dRho', 'dRhoMaxIdx', 'dJPrdMax', 'dJPrdMaxIdx'):
+            np.testing.assert_array_equal(a[k], b[k])
+    assert_same_state(pr, po, 0.0)
+    ca = po.atoms[1]
+    moved = max(np.abs(t.rhoPrd - 1.0).max() for t in ca.trans if t.rhoPrd is not None)
+    assert (moved > 1e-3) == include       # the detailed lines are redistributed only when asked for
+
+
 def test_oracle_prd_golden():
     """The oracle against the reference's committed outputs (generated by tests/golden/make_golden.py
     from the real core): bit-for-bit."""
@@ -169,6 +211,23 @@ def test_hip_prd_matches_oracle(solver):
         assert np.allclose(a['dRho'], b.dRho, rtol=1e-5, atol=1e-12)
         assert np.allclose(a['dJPrdMax'], b.dJPrdMax, rtol=1e-7, atol=1e-12)
     assert_same_state(po, ph, 1e-8)  # three full iterations deep: the one-call bound compounded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('include', [True, False])
+def test_hip_prd_detailed_atoms_matches_oracle(include):
+    """include_detailed_atoms on the device: a Context created with prdDetailed redistributes the detailed atom's PRD
+    lines too (no collisional term in their Pj + Qj), visits their wavelengths in the PRD rates pass and rewrites their
+    rates; without it their sums are added on top, as the reference does."""
+    from lightweaver_amd.context import Context
+    prob = detailed_prd_problem()
+    po, uo = run_detailed(bindings.OracleContext, prob, include)
+    ph, uh = run_detailed(lambda p: Context(p, prdDetailed=include), prob, include)
+    for a, b in zip(uo, uh):
+        assert a['NprdSubIter'] == b.NprdSubIter and b.dRho.shape[1] == (3 if include else 1)
+        assert np.allclose(a['dRho'], b.dRho, rtol=1e-5, atol=1e-12)
+        assert np.allclose(a['dJPrdMax'], b.dJPrdMax, rtol=1e-7, atol=1e-12)
+    assert_same_state(po, ph, 1e-8)
 
 
 @pytest.mark.gpu
