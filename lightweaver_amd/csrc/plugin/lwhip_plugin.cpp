@@ -18,6 +18,8 @@
 #include "lwhip.h"
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -141,6 +143,14 @@ void register_atoms(Context* ctx)
         it = (it->second.first == ctx) ? g_atomOwner.erase(it) : std::next(it);
     for (size_t ia = 0; ia < ctx->activeAtoms.size(); ++ia)
         g_atomOwner[ctx->activeAtoms[ia]] = { ctx, (int)ia };
+}
+
+// LWHIP_PLUGIN_TRACE=1: one line per hook on stderr (tools/oracle/hook_lifecycle.sh checks that they pair up)
+void trace(const char* what, const void* ctx)
+{
+    static const bool on = std::getenv("LWHIP_PLUGIN_TRACE") != nullptr;
+    if (on)
+        std::fprintf(stderr, "lwhip-plugin-trace %s ctx=%p\n", what, ctx);
 }
 
 [[noreturn]] void fail(const std::string& what)
@@ -495,6 +505,7 @@ void reject_unsupported(ExtraParams& params)
 IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params)
 {
     reject_unsupported(params);
+    trace("fs_iter", &ctx);
     const uint32_t up = sync_state(ctx, force_upload(params));
     auto* st = (PluginState*)ctx.methodScratch;
     if (lwhip_upload(st->hip, up) != LWHIP_OK)
@@ -695,6 +706,7 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
 // scratch hooks (Source/LwFormalInterface.hpp:102-108; called from Source/ThreadStorage.cpp:480-493,538-566)
 void alloc_global_scratch_hip(Context* ctx)
 {
+    trace("alloc_global_scratch", ctx);
     ctx->methodScratch = nullptr; // the device context is created on first use, when the arrays are final
     // stat_eq / time_dep_update receive only an Atom*: the core has filled activeAtoms by now (Source/LwMiddleLayer.pyx:
     // 2951-2954 before setup_threads at 3055 -> ThreadStorage.cpp:484-486), so either may be the first call of a run
@@ -703,6 +715,7 @@ void alloc_global_scratch_hip(Context* ctx)
 
 void free_global_scratch_hip(Context* ctx)
 {
+    trace("free_global_scratch", ctx);
     destroy_state(ctx);
 }
 }
