@@ -110,6 +110,7 @@ struct lwhip_context
     bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
     int tileWaves = 4, maxSlotsTile = 0, maxCTTile = 1, maxCTPost = 1, tileCap = 0, ktStride = 4;
     int64_t rowsTileTot = 0, momTot = 0, phiTTot = 0;
+    int preCols = 0;              // most level-sum columns a tile's rows need (LDS columns of the pre-pass)
     DevBuf<DevTile> tiles;
     DevBuf<DevTileSlot> tslots, tslotsPrd;
     DevBuf<DevTileCopy> tcopies;
@@ -719,6 +720,7 @@ int build_tables(lwhip_context* c)
             return true;
         };
         c->rowsTileTot = c->momTot = c->phiTTot = 0;
+        c->preCols = 0;
         c->maxSlotsTile = 0;
         c->tileCap = env_int("LWHIP_TILE_GENERIC", 0); // > 0: every tile through the guarded generic march (test hook)
         for (int la = 0; la < c->Nla;)
@@ -788,6 +790,14 @@ int build_tables(lwhip_context* c)
                     c->tileCap = std::max(c->tileCap, std::max((int)h.nLine, (int)h.nMixed));
             }
             td.nCopy = (int32_t)tcopies.size() - td.copyOff;
+            {
+                // distinct level-sum columns this tile's rows are copied from (the pre-pass sizes its LDS columns by the max)
+                std::vector<int16_t> srcs;
+                for (int q = td.copyOff; q < (int)tcopies.size(); ++q)
+                    if (tcopies[q].kind == 0 && std::find(srcs.begin(), srcs.end(), tcopies[q].src) == srcs.end())
+                        srcs.push_back(tcopies[q].src);
+                c->preCols = std::max(c->preCols, (int)srcs.size());
+            }
             td.nRowsT = nRowsT;
             td.rowBase = c->rowsTileTot;
             c->rowsTileTot += (int64_t)nRowsT * Ns * 16; // rows of 16 doubles whatever L (RM_ROW)
@@ -1306,6 +1316,7 @@ int build_tile_args(lwhip_context* c)
     a.postCs = c->postCs.p;
     a.contRec = c->contRec.p;
     a.maxCTPost = c->maxCTPost;
+    a.preCols = c->preCols;
     a.geo = c->geo.p;
     a.temperature = c->temperature.p;
     a.muz = c->muz.p;
@@ -1394,11 +1405,7 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
     const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
     const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
     const bool fuse = c->tileFuse && rates && !tprd;
-    const bool fusePre = fuse && env_int("LWHIP_TILE_FUSE", 1) == 3; // the sweep's workgroups also write their own row blocks
-    if (fusePre)
-        td._pad |= 0x4000;
-    hipError_t e = fusePre ? launch_depth_table(da, nullptr, 0, c->stream)
-                           : launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
+    hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
     if (e != hipSuccess)
         return e;
     if (e0) // lwhip_profile_enable: HIP events around the sweep kernel alone

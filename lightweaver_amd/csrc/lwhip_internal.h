@@ -198,7 +198,8 @@ struct TileArgs
     const int32_t* postSlotTr;     // [nPostChunks * maxCTPost]
     const int32_t* postCs;         // per (wavelength slot record): accumulator slot inside its post chunk
     const DevContRec* contRec;     // per wavelength: at DevLaHeader::off + nLine, its continua in transition order
-    int32_t maxCTPost, _padB;
+    int32_t maxCTPost;
+    int32_t preCols;               // most level-sum columns a tile's rows are copied from (pre-pass LDS columns)
     const double* geo;             // [Ns][4]: |h_k - h_k+1|, its reciprocal, 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k
     const double* temperature;
     const double* muz;
@@ -257,7 +258,6 @@ hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, 
 hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int nPostChunks,
                             const TileArgs* const* apList, int nBatch, hipStream_t stream);
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
-hipError_t launch_depth_table(const TileArgs* devArgs, const TileArgs* const* apList, int nBatch, hipStream_t stream);
 
 enum { LWHIP_REDUCE_SPLIT = 8 };
 struct ReduceArgs

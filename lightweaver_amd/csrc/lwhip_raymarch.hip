@@ -53,22 +53,20 @@ struct LevCols
 {
     double* lev;
     int T, Natom, NlevTot;
-    DEVINL double& etaA(int at) const { return lev[(size_t)at * T]; }
-    DEVINL double& chi(int g) const { return lev[(size_t)(Natom + g) * T]; }
-    DEVINL double& U(int g) const { return lev[(size_t)(Natom + NlevTot + g) * T]; }
+    const int* remap; // pre-pass: dense slot -> column of this tile's compact set (unused slots share one trash column)
+    DEVINL double* col(int slot) const { return lev + (size_t)remap[slot] * T; }
     // row id as the row programs number them: 0 chi_C, 1 eta_C, 2 + atom, 2 + Natom + level, 2 + Natom + NlevTot + level
-    DEVINL double row(int id) const { return lev[(size_t)(id - 2) * T]; }
+    DEVINL double row(int id) const { return *col(id - 2); }
 };
 enum { RM_CB = 8 }; // continua of a wavelength the post-pass integrates from registers (more: a slower general walk)
 // chi_C += sum chi_c, eta_C += sum eta_c and the level sums of the active atoms, continua in transition order.
 // `cr`: the wavelength's continuum records (uniform); `lsB`: this thread's wavelength, byte address of its first slot record
 // (the per-wavelength parameters p[]); kB = 8 k.  The next continuum's record and loads are requested before the
 // current one is used.
-DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, const CONST_AS DevContRec* cr, const GLOBAL_AS char* lsB,
+DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, int nCols, const CONST_AS DevContRec* cr, const GLOBAL_AS char* lsB,
                         int nCont, unsigned kB, double boltz, double& chiC, double& etaC)
 {
-    const int nLev = lc.Natom + 2 * lc.NlevTot;
-    for (int q = 0; q < nLev; ++q)
+    for (int q = 0; q <= nCols; ++q) // the tile's compact columns and the trash column
         lc.lev[(size_t)q * lc.T] = 0.0;
     if (nCont <= 0)
         return;
@@ -99,10 +97,10 @@ DEVINL void cont_levels(const TileArgs* __restrict__ ap, const LevCols& lc, cons
         if (rc.flags & 1)
         {
             // LDS adds without a return value: no read-modify-write round trip, executed in program order
-            lds_add(lc.lev + (size_t)rc.sEta * lc.T, eta_c);
-            lds_add(lc.lev + (size_t)rc.sChiI * lc.T, chi_c);
-            lds_add(lc.lev + (size_t)rc.sChiJ * lc.T, -chi_c);
-            lds_add(lc.lev + (size_t)rc.sUj * lc.T, uji);
+            lds_add(lc.col(rc.sEta), eta_c);
+            lds_add(lc.col(rc.sChiI), chi_c);
+            lds_add(lc.col(rc.sChiJ), -chi_c);
+            lds_add(lc.col(rc.sUj), uji);
         }
     }
 }
@@ -129,14 +127,8 @@ DEVINL void depth_table(const TileArgs* __restrict__ ap, int t, int T)
         GD(TA.kt)[idx] = v;
     }
 }
-__global__ void __launch_bounds__(256) depth_table_kernel(const TileArgs* __restrict__ ap, const TileArgs* const* __restrict__ apList)
-{
-    if (apList)
-        ap = apList[blockIdx.x];
-    depth_table(ap, threadIdx.x, 256);
-}
 // one point p = k * L + j of a tile (wavelength fastest: coalesced row writes): its rows of the tile's row block
-DEVINL void pre_point(const TileArgs* __restrict__ ap, const DevTile& td, const DevLaHeader& h, const LevCols& lc, int p)
+DEVINL void pre_point(const TileArgs* __restrict__ ap, const DevTile& td, const DevLaHeader& h, const LevCols& lc, int nCols, int p)
 {
     const int Ns = TA.Ns, L = TA.L;
     const int k = p / L;
@@ -157,7 +149,7 @@ DEVINL void pre_point(const TileArgs* __restrict__ ap, const DevTile& td, const 
     double chiC = GCD(TA.bgChi)[o], etaC = GCD(TA.bgEta)[o];
     const double scaJ = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
     const double boltz = d_exp_neg(-hc_kl * rT);
-    cont_levels(ap, lc, cr, (const GLOBAL_AS char*)lsAll, nCont, (unsigned)k * 8u, boltz, chiC, etaC);
+    cont_levels(ap, lc, nCols, cr, (const GLOBAL_AS char*)lsAll, nCont, (unsigned)k * 8u, boltz, chiC, etaC);
     GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (size_t)k * td.nRowsT * RM_ROW + j;
     out[0] = chiC;
     out[RM_ROW] = etaC;
@@ -187,12 +179,39 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
         depth_table(ap, threadIdx.x, RM_PRE_T);
     const int ti = tileList ? CTAB(int32_t, tileList)[blockIdx.x] : (int)blockIdx.x;
     const DevTile td = ld_c(CTAB(DevTile, TA.tiles) + ti);
+    // Only the level sums the tile's rows are copied from need a column: the dense slots [eta_A x Natom][chi x NlevTot]
+    // [U x NlevTot] map to the tile's compact set (at most preCols columns, sized on the host), everything else to one
+    // trash column.  LDS per thread drops from 26 to <= 11 doubles for H + Ca II: 3 -> 7 workgroups per CU.
+    int* remap = (int*)(lds + (size_t)(TA.preCols + 1) * RM_PRE_T);
+    __shared__ int sCols;
+    const int nLev = TA.Natom + 2 * TA.NlevTot;
+    for (int q = threadIdx.x; q < nLev; q += RM_PRE_T)
+        remap[q] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const CONST_AS DevTileCopy* cp = CTAB(DevTileCopy, TA.copies) + td.copyOff;
+        int n = 0;
+        for (int q = 0; q < td.nCopy; ++q)
+        {
+            const DevTileCopy c = ld_c(cp + q);
+            if (c.kind == 0 && remap[c.src - 2] < 0)
+                remap[c.src - 2] = n++;
+        }
+        sCols = n;
+    }
+    __syncthreads();
+    const int nCols = sCols;
+    for (int q = threadIdx.x; q < nLev; q += RM_PRE_T)
+        if (remap[q] < 0)
+            remap[q] = nCols;
+    __syncthreads();
     const int p = blockIdx.y * RM_PRE_T + threadIdx.x;
     if (p >= TA.Ns * TA.L)
         return;
     const DevLaHeader h = ld_c(CTAB(DevLaHeader, TA.laHdr) + td.la0);
-    const LevCols lc{ lds + threadIdx.x, RM_PRE_T, TA.Natom, TA.NlevTot };
-    pre_point(ap, td, h, lc, p);
+    const LevCols lc{ lds + threadIdx.x, RM_PRE_T, TA.Natom, TA.NlevTot, remap };
+    pre_point(ap, td, h, lc, nCols, p);
 }
 
 // ---- cross-lane helpers -------------------------------------------------------------------------------------------
@@ -1206,19 +1225,6 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
         __syncthreads();
     }
     const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
-    if (RATES && FUSE && (dyn._pad & 0x4000))
-    {
-        // (option, measured slower than the stand-alone pre-pass: LWHIP_TILE_FUSE=3)
-        // the tile's row block first (the depth table comes from depth_table_kernel, launched before): the workgroup's 128
-        // threads walk the tile's points; the rows are read back by the march through L2
-        const int ti = tileList ? tileList[t0] : t0;
-        const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
-        const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + td.la0);
-        const LevCols lc{ lds + (size_t)maxCT * 4 * Ns + 16 + t, 128, a.Natom, a.NlevTot };
-        for (int p = t; p < Ns * a.L; p += 128)
-            pre_point(ap, td, h, lc, p);
-        __syncthreads(); // (drains the row stores: s_waitcnt vmcnt(0) precedes the barrier)
-    }
     // tasks of the chunk: (tile, direction); both directions unless the launch is up-only
     const int nDir = dyn.nPass;
     for (int task = t0 * nDir + wave; task < t1 * nDir; task += nWaves)
@@ -1326,12 +1332,6 @@ hipError_t launch_retile(const RetileArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_depth_table(const TileArgs* devArgs, const TileArgs* const* apList, int nBatch, hipStream_t stream)
-{
-    hipLaunchKernelGGL(depth_table_kernel, dim3(std::max(nBatch, 1)), dim3(256), 0, stream, devArgs, apList);
-    return hipGetLastError();
-}
-
 size_t raymarch_lds_bytes(const TileArgs& a, int waves, bool fuse)
 {
     // accumulators + the waves' moment windows; the fused post-pass reuses the windows' space for the dJ row and the
@@ -1346,7 +1346,7 @@ hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& a, int nTile
 {
     if (nTilesLaunch <= 0)
         return hipSuccess;
-    const size_t lds = (size_t)(a.Natom + 2 * a.NlevTot) * RM_PRE_T * sizeof(double);
+    const size_t lds = (size_t)(a.preCols + 1) * RM_PRE_T * sizeof(double) + (size_t)(a.Natom + 2 * a.NlevTot + 2) * sizeof(int);
     const int parts = (a.Ns * a.L + RM_PRE_T - 1) / RM_PRE_T;
     if (lds > 48 * 1024)
     {

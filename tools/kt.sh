@@ -1,17 +1,9 @@
 #!/bin/bash
-# kernel durations of a short bench run under given env: bash tools/kt.sh "ENV=1 ENV2=2"
+# kernel times of a short bench run under rocprofv3 + the bench's own numbers: bash tools/kt.sh ["ENV=.. ENV2=.."]
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for e in "$@"; do
-  rm -rf /tmp/kt_out
-  env $e rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_out -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > /tmp/kt.json 2> /tmp/kt.err
-  echo "== $e: $(python3 -c "import json;d=json.load(open('/tmp/kt.json'));print('%.0f it/s %.3f ms/step'%(d['value'],d['ms_per_step']))" 2>/dev/null)"
-  python3 - <<PY
-import csv,glob
-f=glob.glob('/tmp/kt_out/*/*kernel_stats.csv')[0]
-for r in csv.DictReader(open(f)):
-    n=r['Name'].split('(')[0].replace('void lwhip::','')
-    if any(k in n for k in ('raymarch','tile_p','apply','sweep_')):
-        print('   %-45s %8.1f us x %s'%(n[:45], float(r['AverageNs'])/1e3, r['Calls']))
-PY
-done
+rm -rf /tmp/kt_st
+env $1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_st -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-aux > /tmp/kt_b.json 2>/dev/null
+head -6 /tmp/kt_st/*/*kernel_stats.csv | cut -c1-160
+cd $R
+for i in 1 2 3; do env $1 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-aux 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step %.4f sweep %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"; done
