@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 K=$1; E=$2; shift 2
 for grp in "$@"; do
   rm -rf /tmp/pmc1
-  env $E rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc1 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> /tmp/pmc1.err
+  env $E rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc1 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux > /dev/null 2> /tmp/pmc1.err
   python3 - << PY
 import csv,glob,collections
 f=glob.glob("/tmp/pmc1/*/*counter_collection.csv")[0]
