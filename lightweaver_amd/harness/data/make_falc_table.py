@@ -1,4 +1,4 @@
-"""Generate tests/golden/falc82.npz -- the FAL-C 82-point model atmosphere table.
+"""Generate lightweaver_amd/harness/data/falc82.npz -- the FAL-C 82-point model atmosphere table.
 
 Runs ONLY in the build container (needs /root/reference).  The table (Fontenla, Avrett &
 Loeser 1993, model C) is read as DATA out of the reference's lightweaver/fal.py by evaluating
@@ -6,7 +6,7 @@ the numeric array literals `cmass, temp, ne, vel, vturb, nh` found there (fal.py
 reference code is imported, executed beyond those literals, or copied.  The committed .npz is an
 input fixture: column mass [g cm^-2], T [K], ne [cm^-3], vel [km/s], vturb [km/s], nh[6,82] [cm^-3].
 
-    python tests/golden/make_falc_fixture.py
+    python lightweaver_amd/harness/data/make_falc_table.py
 """
 import ast
 import os

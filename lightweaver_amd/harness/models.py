@@ -19,7 +19,7 @@ from ..model import AtomData, Problem, TransitionData
 from . import physics as ph
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-FALC_FIXTURE = os.path.normpath(os.path.join(_HERE, '..', '..', 'tests', 'golden', 'falc82.npz'))
+FALC_FIXTURE = os.path.join(_HERE, 'data', 'falc82.npz')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -44,7 +44,7 @@ MASS_PER_H = 1.4271  # amu per hydrogen nucleus for a solar mixture
 
 
 def falc82() -> Atmosphere1d:
-    """FAL-C on its native 82 points (lightweaver/fal.py:8-431 via tests/golden/falc82.npz)."""
+    """FAL-C on its native 82 points (lightweaver/fal.py:8-431 via harness/data/falc82.npz, written by harness/data/make_falc_table.py)."""
     d = np.load(FALC_FIXTURE)
     cmass = d['cmass'] * 1e-3 / ph.CM_TO_M**2          # kg m^-2
     nH = d['nh'] / ph.CM_TO_M**3
