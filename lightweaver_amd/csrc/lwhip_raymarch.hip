@@ -481,21 +481,21 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         = __builtin_amdgcn_make_buffer_rsrc((void*)(a.phiT + phi0), 0, (int)((unsigned)max(nLine, 1) * 2u * (unsigned)Ns * 512u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rMom = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.mom + td.momBase + (size_t)toObs * 4 * L * Ns), 0, (int)(4u * L8 * (unsigned)Ns), 0x00020000);
-    const CONST_AS char* ktB = (const CONST_AS char*)(a.kt + a.ktStride); // entry -1 and Ns exist (padding)
+    const CONST_AS char* kt0 = (const CONST_AS char*)a.kt; // entry -1 (padding) first: every offset below is unsigned
     const unsigned ktS = (unsigned)a.ktStride * 8u;
     const bool storeDepth = RATES && a.storeDepth && !dyn.prdOnly;
     ExpK expK;
     expK.init();
     const double lamf = dyn.lambdaIterate ? 0.0 : 1.0;
     auto kOf = [&](int t) { return kS + dk * t; };
-    auto lds_ = [](const CONST_AS char* base, unsigned off) { return *(const CONST_AS double*)(base + off); };
-    auto dhAt = [&](int ka, int kb) { return lds_(ktB + (size_t)(long long)(min(ka, kb) * (int)ktS), 0); };
+    // one 64-bit base + one zero-extended 32-bit offset per scalar load (no 64-bit address arithmetic per depth)
+    auto ktAt = [&](int k, unsigned off) { return *(const CONST_AS double*)(kt0 + (size_t)((unsigned)(k + 1) * ktS + off)); };
+    auto dhAt = [&](int ka, int kb) { return ktAt(min(ka, kb), 0); };
 
     // ---- loads of iteration t: gather of point t, rate scalars of point t - 2 --------------------------------------------
     auto load_step = [&](int t, StepIn<NL>& g) {
         const int k = kOf(t);
         const unsigned so = (unsigned)k * strideK;
-        const CONST_AS char* kt = ktB + (long long)(k * (int)ktS);
         g.chi = buf_ld(rRows, jb, so);
         g.eta = buf_ld(rRows, jb + RM_ROW * 8u, so);
         g.sca = buf_ld(rRows, jb + 2 * RM_ROW * 8u, so);
@@ -510,14 +510,14 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 g.phi[s] = buf_ld(rPhi, srcB, lphi[s] + (unsigned)k * 512u);
                 if (lfl[s] & 2)
                     g.rho[s] = buf_ld(rRows, jb, so + laux[s]);
-                g.ni[s] = lds_(kt, lnI[s]);
-                g.nj[s] = lds_(kt, lnJ[s]);
+                g.ni[s] = ktAt(k, lnI[s]);
+                g.nj[s] = ktAt(k, lnJ[s]);
             }
         }
-        const CONST_AS char* kd = ktB + (long long)(min(k, k - dk) * (int)ktS);
-        g.dh = lds_(kd, 0);
-        g.rdh = lds_(kd, 8);
-        g.rsum = lds_(ktB + (long long)((k - dk) * (int)ktS), 16);
+        const int kd = min(k, k - dk);
+        g.dh = ktAt(kd, 0);
+        g.rdh = ktAt(kd, 8);
+        g.rsum = ktAt(k - dk, 16);
     };
 
     // ---- march state ----
@@ -583,7 +583,6 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         if (RATES && DO_RATES)
         {
             const unsigned so = (unsigned)km * strideK;
-            const CONST_AS char* ktm = ktB + (long long)(km * (int)ktS);
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
             {
@@ -596,9 +595,9 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
 #pragma unroll
                     for (int q = 0; q < 5; ++q)
                         lr[s][q] = buf_ld(rRows, jb + (unsigned)q * (RM_ROW * 8u), so + lrow[s]);
-                    nim[s] = lds_(ktm, lnI[s]);
-                    njm[s] = lds_(ktm, lnJ[s]);
-                    wphim[s] = lds_(ktm, lwO[s]);
+                    nim[s] = ktAt(km, lnI[s]);
+                    njm[s] = ktAt(km, lnJ[s]);
+                    wphim[s] = ktAt(km, lwO[s]);
                 }
             }
 #pragma unroll
