@@ -53,6 +53,10 @@ def parse():
     ap.add_argument('--aux-only', choices=('prd', 'columns', '2d'), default=None,
                     help='run only this side measurement and print its entry (for rocprofv3)')
     ap.add_argument('--columns', type=int, default=512, help='columns of the C4 batch')
+    ap.add_argument('--backend', default='nccl',
+                    help="torch.distributed backend for N > 1 ('nccl' = RCCL, one rank per GPU; 'gloo' with --share-gpu "
+                         'exercises the sharded path with several ranks on ONE GPU)')
+    ap.add_argument('--share-gpu', action='store_true', help='every rank uses device 0 (functional check only)')
     return ap.parse_args()
 
 
@@ -284,6 +288,8 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     stream = torch.cuda.current_stream()
     if args.aux_only:
@@ -291,7 +297,10 @@ def main():
         print(json.dumps({name: fn(args, local_rank, stream.cuda_stream, torch, models)}))
         return
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     Nla_total = args.nlambda * (world if args.scaling == 'weak' else 1)
     # the line profiles are generated on the device (lwhip_compute_profiles), shard by shard: the host
