@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LWHIP_ABI_VERSION 2
+#define LWHIP_ABI_VERSION 3
 
 /* ---- enums (values mirror the reference where one exists) ---------------- */
 
@@ -139,7 +139,8 @@ typedef struct lwhip_boundary {
     int32_t type;          /* LWHIP_BC_*                                                           */
     int32_t Nmu;           /* second extent of bcData                                              */
     const int32_t* idxs;   /* [Nrays, 2] -> row of bcData, or -1 (CALLABLE only)                   */
-    const double* bcData;  /* [Nlambda, Nmu] (third reference extent is 1 in 1D) (CALLABLE only)   */
+    const double* bcData;  /* [Nlambda, Nmu] (third reference extent is 1 in 1D; [Nlambda, Nmu, Nz] for the x
+                            * boundaries of a 2D grid) (CALLABLE only)                              */
 } lwhip_boundary;
 
 struct lwhip_grid2d; /* 2D geometry, defined below */
@@ -357,7 +358,7 @@ typedef struct lwhip_intersection {   /* IntersectionResult, Source/LwAtmosphere
 } lwhip_intersection;
 
 typedef struct lwhip_grid2d {
-    int32_t Nx, Nz, Nrays, periodic;  /* periodic must be 1 */
+    int32_t Nx, Nz, Nrays, periodic;  /* 1: PERIODIC x boundaries; 0: CALLABLE ones (xLowerBc / xUpperBc below)    */
     int32_t zLowerBc, zUpperBc;       /* LWHIP_BC_ZERO / LWHIP_BC_THERMALISED */
     int32_t NlongChar, _pad;
     const double* x;                  /* [Nx] */
@@ -370,6 +371,11 @@ typedef struct lwhip_grid2d {
     const int32_t* longCharIdx;       /* [Nrays, 2, Nz, Nx] index of the point's long characteristic, or -1 */
     const int32_t* substepOff;        /* [NlongChar + 1] offsets into substeps */
     const lwhip_intersection* substeps; /* the sub-steps of every long characteristic, upwind-most first */
+    /* periodic == 0 (Source/FormalScalar2d.cpp:806-852): the column a ray enters through is prescribed,
+     * I(k, 0) = xLowerBc.bcData(la, idxs(mu, toObs), k) for mux > 0, I(k, Nx-1) from xUpperBc for mux < 0.
+     * Both CALLABLE, idxs [Nrays, 2], bcData [Nlambda, Nmu, Nz]; no long characteristics.  NULL when periodic. */
+    const struct lwhip_boundary* xLowerBc;
+    const struct lwhip_boundary* xUpperBc;
 } lwhip_grid2d;
 
 /* nSolve problems: problem p is ray rays[p] (= 2 * mu + toObs), opacity chi + p * Nz * Nx, source S + ...;

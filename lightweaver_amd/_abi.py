@@ -5,7 +5,7 @@ offsets against a C program compiled from the header.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 AXIS_NONE, AXIS_X, AXIS_Z = 0, 1, 2
 
 # enums (include/lwhip.h)
@@ -108,7 +108,8 @@ class lwhip_grid2d(C.Structure):
                 ('zLowerBc', C.c_int32), ('zUpperBc', C.c_int32), ('NlongChar', C.c_int32), ('_pad', C.c_int32),
                 ('x', f64p), ('z', f64p), ('mux', f64p), ('muz', f64p), ('temperature', f64p),
                 ('uw', C.POINTER(lwhip_intersection)), ('dw', C.POINTER(lwhip_intersection)),
-                ('longCharIdx', i32p), ('substepOff', i32p), ('substeps', C.POINTER(lwhip_intersection))]
+                ('longCharIdx', i32p), ('substepOff', i32p), ('substeps', C.POINTER(lwhip_intersection)),
+                ('xLowerBc', C.POINTER(lwhip_boundary)), ('xUpperBc', C.POINTER(lwhip_boundary))]
 
 
 class lwhip_nr_args(C.Structure):

@@ -3093,8 +3093,6 @@ int lwhip_build_intersections(const lwhip_grid2d* grid, lwhip_intersection* uw, 
 {
     if (!grid || !nLongChar || !nSubsteps || !grid->x || !grid->z || !grid->mux || !grid->muz)
         return fail(LWHIP_ERR_INVALID, "build_intersections: null argument");
-    if (!grid->periodic)
-        return fail(LWHIP_ERR_UNSUPPORTED, "build_intersections: only x-periodic grids");
     if (grid->Nx < 2 || grid->Nz < 2 || grid->Nrays < 1)
         return fail(LWHIP_ERR_INVALID, "build_intersections: need Nx >= 2, Nz >= 2, Nrays >= 1");
     if (uw && (!dw || !longCharIdx || !substepOff || (capSubsteps > 0 && !substeps)))

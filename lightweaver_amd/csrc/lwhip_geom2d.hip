@@ -19,6 +19,7 @@ struct Grid
     const double* z;
     double mux, muz;
     int xStep, xStart, xEnd, zStep;
+    bool periodic;
 };
 
 // approx_equal (Source/LwAtmosphere.hpp:52-74)
@@ -67,12 +68,22 @@ lwhip_intersection hit(int axis, double fracZ, double fracX, double distance)
 // parametrised hit with a plane of constant x / z: t = -(origin - offset) / mu (IEEE inf / nan semantics relied on)
 inline double plane_t(double origin, double offset, double mu) { return -(origin - offset) / mu; }
 
-// dw_intersection_2d :60-105 (periodic: the last column wraps onto the first)
+// dw_intersection_2d :60-105 (periodic: the last column wraps onto the first; fixed boundaries: an inclined ray has no
+// downwind point there -- distance 0, caught by the solver -- and a vertical one never meets an x face: the reference
+// evaluates its x-face hit one column beyond the grid, where the result is infinite whatever it reads)
 lwhip_intersection dw_hit(const Grid& g, int zp, int xp)
 {
+    bool beyond = false;
     if (xp == g.xEnd)
-        xp = g.xStart;
-    const double tx = plane_t(g.x[xp], g.x[xp + g.xStep], g.mux);
+    {
+        if (g.periodic)
+            xp = g.xStart;
+        else if (std::fabs(g.muz) != 1.0)
+            return hit(LWHIP_AXIS_NONE, zp, xp, 0.0);
+        else
+            beyond = true;
+    }
+    const double tx = beyond ? std::numeric_limits<double>::infinity() : plane_t(g.x[xp], g.x[xp + g.xStep], g.mux);
     const double tz = plane_t(g.z[zp], g.z[zp + g.zStep], g.muz);
     if (std::fabs(tx) < std::fabs(tz))
         return hit(LWHIP_AXIS_Z, zp + g.zStep * (tx / tz), xp + g.xStep, tx);
@@ -84,9 +95,17 @@ lwhip_intersection dw_hit(const Grid& g, int zp, int xp)
 // uw_intersection_2d :107-152
 lwhip_intersection uw_hit(const Grid& g, int zp, int xp)
 {
+    bool beyond = false;
     if (xp == g.xStart)
-        xp = g.xEnd;
-    const double tx = plane_t(g.x[xp], g.x[xp - g.xStep], g.mux);
+    {
+        if (g.periodic)
+            xp = g.xEnd;
+        else if (std::fabs(g.muz) != 1.0)
+            return hit(LWHIP_AXIS_NONE, zp, xp, 0.0);
+        else
+            beyond = true;
+    }
+    const double tx = beyond ? std::numeric_limits<double>::infinity() : plane_t(g.x[xp], g.x[xp - g.xStep], g.mux);
     const double tz = plane_t(g.z[zp], g.z[zp - g.zStep], g.muz);
     if (std::fabs(tx) < std::fabs(tz))
         return hit(LWHIP_AXIS_Z, zp - g.zStep * (tx / tz), xp - g.xStep, tx);
@@ -155,6 +174,8 @@ extern "C" int lwhip_build_intersections_impl(const lwhip_grid2d* grid, lwhip_in
             g.xStep = (g.mux < 0) ? -1 : 1;
             g.xStart = (g.mux < 0) ? Nx - 1 : 0;
             g.xEnd = (g.mux < 0) ? 0 : Nx - 1;
+            g.periodic = grid->periodic != 0;
+            const bool edge = !g.periodic && g.mux != 0.0; // fixed boundaries: no downwind point in the last column
             const size_t base = ((size_t)mu * 2 + toObsI) * Ns;
             int k = kStart;
             // the starting plane :1252-1264
@@ -162,6 +183,8 @@ extern "C" int lwhip_build_intersections_impl(const lwhip_grid2d* grid, lwhip_in
             {
                 lwhip_intersection dw = dw_hit(g, k, j);
                 dw.distance = std::fabs(dw.distance);
+                if (edge && j == g.xEnd)
+                    dw = hit(LWHIP_AXIS_NONE, k, j, 0.0);
                 if (fill)
                 {
                     const size_t o = base + (size_t)k * Nx + j;
@@ -177,7 +200,7 @@ extern "C" int lwhip_build_intersections_impl(const lwhip_grid2d* grid, lwhip_in
                     lwhip_intersection uw = uw_hit(g, k, j);
                     uw.distance = std::fabs(uw.distance);
                     int lc = -1;
-                    if (j == g.xStart && uw.axis == LWHIP_AXIS_Z)
+                    if (g.periodic && j == g.xStart && uw.axis == LWHIP_AXIS_Z)
                     {
                         // periodic long characteristic :1277-1304: walk upwind until a z plane is hit, then store
                         // the steps upwind-most first with the point's own upwind hit last
@@ -200,7 +223,7 @@ extern "C" int lwhip_build_intersections_impl(const lwhip_grid2d* grid, lwhip_in
                         off.push_back((int32_t)steps.size());
                     }
                     lwhip_intersection dw = hit(LWHIP_AXIS_NONE, k, j, 0.0);
-                    if (k != kEnd)
+                    if (k != kEnd && !(edge && j == g.xEnd))
                     {
                         dw = dw_hit(g, k, j);
                         dw.distance = std::fabs(dw.distance);

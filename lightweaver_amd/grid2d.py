@@ -30,6 +30,27 @@ class Grid2d:
     substeps: np.ndarray        # [substepOff[-1]] INTERSECTION_DTYPE
     zLowerBc: int = abi.BC_THERMALISED
     zUpperBc: int = abi.BC_ZERO
+    # x boundaries: None = PERIODIC; else both CALLABLE -- model.Boundary(type=BC_CALLABLE, idxs[Nrays, 2],
+    # bcData[Nlambda, Nmu, Nz]): the column a ray enters through is prescribed (FormalScalar2d.cpp:806-852)
+    xLowerBc: object = None
+    xUpperBc: object = None
+
+    @property
+    def periodic(self):
+        return self.xLowerBc is None and self.xUpperBc is None
+
+    def _xbc(self, b, keep):
+        out = abi.lwhip_boundary()
+        out.type = abi.BC_CALLABLE
+        b.idxs = np.ascontiguousarray(b.idxs, dtype=np.int32)
+        b.bcData = np.ascontiguousarray(b.bcData, dtype=np.float64)
+        if b.idxs.shape != (self.Nrays, 2) or b.bcData.ndim != 3 or b.bcData.shape[2] != self.Nz:
+            raise ValueError('x boundary needs idxs[Nrays, 2] and bcData[Nlambda, Nmu, Nz]')
+        out.Nmu = b.bcData.shape[1]
+        out.idxs = b.idxs.ctypes.data_as(abi.i32p)
+        out.bcData = b.bcData.ctypes.data_as(abi.f64p)
+        keep.append(out)
+        return C.pointer(out)
 
     @property
     def Nx(self):
@@ -52,7 +73,13 @@ class Grid2d:
         self.longCharIdx = np.ascontiguousarray(self.longCharIdx, dtype=np.int32)
         self.substepOff = np.ascontiguousarray(self.substepOff, dtype=np.int32)
         g = abi.lwhip_grid2d()
-        g.Nx, g.Nz, g.Nrays, g.periodic = self.Nx, self.Nz, self.Nrays, 1
+        g.Nx, g.Nz, g.Nrays, g.periodic = self.Nx, self.Nz, self.Nrays, int(self.periodic)
+        if not self.periodic:
+            if self.xLowerBc is None or self.xUpperBc is None:
+                raise ValueError('mixed boundary types are not supported on the x axis')
+            self._keep = []
+            g.xLowerBc = self._xbc(self.xLowerBc, self._keep)
+            g.xUpperBc = self._xbc(self.xUpperBc, self._keep)
         g.zLowerBc, g.zUpperBc = self.zLowerBc, self.zUpperBc
         g.NlongChar = self.substepOff.size - 1
         g.x, g.z = self.x.ctypes.data_as(abi.f64p), self.z.ctypes.data_as(abi.f64p)
@@ -71,6 +98,10 @@ class Grid2d:
             d[prefix + k + '/axis'] = a['axis']
             d[prefix + k + '/vals'] = np.stack([a['fracZ'], a['fracX'], a['distance']], axis=-1)
         d[prefix + 'bc'] = np.array([self.zLowerBc, self.zUpperBc])
+        if not self.periodic:
+            for name, b in (('xLower', self.xLowerBc), ('xUpper', self.xUpperBc)):
+                d[prefix + name + '/idxs'] = np.asarray(b.idxs)
+                d[prefix + name + '/bcData'] = np.asarray(b.bcData)
         return d
 
     @staticmethod
@@ -81,13 +112,19 @@ class Grid2d:
             a['axis'], a['fracZ'], a['fracX'], a['distance'] = ax, v[..., 0], v[..., 1], v[..., 2]
             return a
         bc = d[prefix + 'bc']
-        return Grid2d(x=d[prefix + 'x'], z=d[prefix + 'z'], mux=d[prefix + 'mux'], muz=d[prefix + 'muz'],
+        xb = {}
+        if prefix + 'xLower/idxs' in d:
+            from .model import Boundary
+            for name in ('xLower', 'xUpper'):
+                xb[name + 'Bc'] = Boundary(abi.BC_CALLABLE, idxs=d[prefix + name + '/idxs'], bcData=d[prefix + name + '/bcData'])
+        return Grid2d(**xb, x=d[prefix + 'x'], z=d[prefix + 'z'], mux=d[prefix + 'mux'], muz=d[prefix + 'muz'],
                       temperature=d[prefix + 'temperature'], uw=inter('uw'), dw=inter('dw'),
                       longCharIdx=d[prefix + 'longCharIdx'], substepOff=d[prefix + 'substepOff'],
                       substeps=inter('substeps'), zLowerBc=int(bc[0]), zUpperBc=int(bc[1]))
 
 
-def build_grid2d(x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUpperBc=abi.BC_ZERO) -> Grid2d:
+def build_grid2d(x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUpperBc=abi.BC_ZERO, xLowerBc=None,
+                 xUpperBc=None) -> Grid2d:
     """The counterpart of Atmosphere.make_2d's geometry step for an x-periodic grid: the intersection table of
     build_intersection_list (Source/FormalScalar2d.cpp:1188-1327) through lwhip_build_intersections.  mux, muz:
     the quadrature's direction cosines [Nrays] (toObs direction; the table holds both directions)."""
@@ -98,7 +135,8 @@ def build_grid2d(x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUppe
     temperature = f(temperature).reshape(z.size, x.size)
     ip = C.POINTER(abi.lwhip_intersection)
     g = abi.lwhip_grid2d()
-    g.Nx, g.Nz, g.Nrays, g.periodic = x.size, z.size, mux.size, 1
+    periodic = xLowerBc is None and xUpperBc is None
+    g.Nx, g.Nz, g.Nrays, g.periodic = x.size, z.size, mux.size, int(periodic)
     g.x, g.z = x.ctypes.data_as(abi.f64p), z.ctypes.data_as(abi.f64p)
     g.mux, g.muz = mux.ctypes.data_as(abi.f64p), muz.ctypes.data_as(abi.f64p)
     nl, ns = C.c_int32(0), C.c_int64(0)
@@ -115,7 +153,7 @@ def build_grid2d(x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUppe
                                               sub.ctypes.data_as(ip), ns.value, C.byref(nl), C.byref(ns)),
            'lwhip_build_intersections')
     return Grid2d(x=x, z=z, mux=mux, muz=muz, temperature=temperature, uw=uw, dw=dw, longCharIdx=li, substepOff=off,
-                  substeps=sub[:ns.value], zLowerBc=zLowerBc, zUpperBc=zUpperBc)
+                  substeps=sub[:ns.value], zLowerBc=zLowerBc, zUpperBc=zUpperBc, xLowerBc=xLowerBc, xUpperBc=xUpperBc)
 
 
 def formal_solver_2d(grid: Grid2d, wavelength: float, rays, chi, S, device: int = 0):

@@ -324,7 +324,10 @@ class Ref2d:
     """The reference's 2D geometry (build_intersection_list) and solver (piecewise_besser_2d, interp_linear_2d)
     on an x-periodic grid, behind oracle/ref_driver.cpp."""
 
-    def __init__(self, x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUpperBc=abi.BC_ZERO):
+    def __init__(self, x, z, mux, muz, temperature, zLowerBc=abi.BC_THERMALISED, zUpperBc=abi.BC_ZERO, xLowerBc=None,
+                 xUpperBc=None):
+        """xLowerBc / xUpperBc: None (periodic) or model.Boundary with bcData [1, Nmu, Nz] (the primitive has one
+        wavelength)."""
         import numpy as np
         self.np = np
         lib = RefContext.lib_()
@@ -341,8 +344,28 @@ class Ref2d:
         self.x, self.z, self.mux, self.muz, self.T = f(x), f(z), f(mux), f(muz), f(temperature)
         self.bc = (zLowerBc, zUpperBc)
         p = lambda a: a.ctypes.data_as(abi.f64p)
-        self.h = lib.lwref_2d_create(p(self.x), self.x.size, p(self.z), self.z.size, p(self.mux), p(self.muz),
-                                     self.mux.size, zLowerBc, zUpperBc, p(self.T))
+        self.xbc = (xLowerBc, xUpperBc)
+        if xLowerBc is None:
+            self.h = lib.lwref_2d_create(p(self.x), self.x.size, p(self.z), self.z.size, p(self.mux), p(self.muz),
+                                         self.mux.size, zLowerBc, zUpperBc, p(self.T))
+        else:
+            bp = C.POINTER(abi.lwhip_boundary)
+            lib.lwref_2d_create_ex.restype = C.c_void_p
+            lib.lwref_2d_create_ex.argtypes = lib.lwref_2d_create.argtypes + [bp, bp]
+            self._keep = []
+
+            def flat(b):
+                out = abi.lwhip_boundary()
+                out.type = abi.BC_CALLABLE
+                b.idxs = np.ascontiguousarray(b.idxs, dtype=np.int32)
+                b.bcData = np.ascontiguousarray(b.bcData, dtype=np.float64)
+                out.Nmu = b.bcData.shape[1]
+                out.idxs = b.idxs.ctypes.data_as(abi.i32p)
+                out.bcData = b.bcData.ctypes.data_as(abi.f64p)
+                self._keep.append(out)
+                return C.byref(out)
+            self.h = lib.lwref_2d_create_ex(p(self.x), self.x.size, p(self.z), self.z.size, p(self.mux), p(self.muz),
+                                            self.mux.size, zLowerBc, zUpperBc, p(self.T), flat(xLowerBc), flat(xUpperBc))
 
     def grid(self):
         from lightweaver_amd.grid2d import INTERSECTION_DTYPE, Grid2d
@@ -360,7 +383,7 @@ class Ref2d:
                                    off.ctypes.data_as(abi.i32p), sub.ctypes.data_as(ip))
         return Grid2d(x=self.x, z=self.z, mux=self.mux, muz=self.muz, temperature=self.T.reshape(self.z.size, -1),
                       uw=uw, dw=dw, longCharIdx=li, substepOff=off, substeps=sub[:ns.value],
-                      zLowerBc=self.bc[0], zUpperBc=self.bc[1])
+                      zLowerBc=self.bc[0], zUpperBc=self.bc[1], xLowerBc=self.xbc[0], xUpperBc=self.xbc[1])
 
     def besser(self, mu, toObs, wav, chi, S):
         np = self.np

@@ -138,8 +138,23 @@ void* lwref_create(const lwhip_problem* p, const char* schemeLib, int Nthreads,
             a.z = F64View(const_cast<f64*>(g.z), g.Nz);
             a.height = a.z;
             a.mux = F64View(const_cast<f64*>(g.mux), Nrays);
-            a.xLowerBc.type = PERIODIC;
-            a.xUpperBc.type = PERIODIC;
+            if (g.periodic)
+            {
+                a.xLowerBc.type = PERIODIC;
+                a.xUpperBc.type = PERIODIC;
+            }
+            else
+            {
+                // fixed x boundaries: CALLABLE, bcData [Nlambda, Nmu, Nz] (Source/FormalScalar2d.cpp:806-852)
+                auto xbc = [&](AtmosphericBoundaryCondition* bc, const lwhip_boundary* b) {
+                    if (!b || b->type != LWHIP_BC_CALLABLE || !b->idxs || !b->bcData)
+                        throw std::runtime_error("2D grid without periodic x needs CALLABLE xLowerBc / xUpperBc");
+                    *bc = AtmosphericBoundaryCondition(CALLABLE, Nla, b->Nmu, g.Nz, BcIdxs(const_cast<i32*>(b->idxs), Nrays, 2));
+                    bc->set_bc_data(F64View3D(const_cast<f64*>(b->bcData), Nla, b->Nmu, g.Nz));
+                };
+                xbc(&a.xLowerBc, g.xLowerBc);
+                xbc(&a.xUpperBc, g.xUpperBc);
+            }
             a.zLowerBc.type = (g.zLowerBc == LWHIP_BC_THERMALISED) ? THERMALISED : ZERO;
             a.zUpperBc.type = (g.zUpperBc == LWHIP_BC_THERMALISED) ? THERMALISED : ZERO;
             build_intersection_list(&a);
@@ -455,8 +470,20 @@ struct Ref2D
     std::vector<double> x, z, mux, muz, temperature;
 };
 
+void* lwref_2d_create_ex(const double* x, int Nx, const double* z, int Nz, const double* mux, const double* muz,
+                         int Nrays, int zLowerBc, int zUpperBc, const double* temperature, const lwhip_boundary* xLower,
+                         const lwhip_boundary* xUpper);
+
 void* lwref_2d_create(const double* x, int Nx, const double* z, int Nz, const double* mux, const double* muz,
                       int Nrays, int zLowerBc, int zUpperBc, const double* temperature)
+{
+    return lwref_2d_create_ex(x, Nx, z, Nz, mux, muz, Nrays, zLowerBc, zUpperBc, temperature, nullptr, nullptr);
+}
+
+// xLower / xUpper: null = periodic; else CALLABLE boundaries with bcData [1, Nmu, Nz] (the primitive has one wavelength)
+void* lwref_2d_create_ex(const double* x, int Nx, const double* z, int Nz, const double* mux, const double* muz,
+                         int Nrays, int zLowerBc, int zUpperBc, const double* temperature, const lwhip_boundary* xLower,
+                         const lwhip_boundary* xUpper)
 {
     auto* r = new Ref2D();
     r->x.assign(x, x + Nx);
@@ -476,8 +503,20 @@ void* lwref_2d_create(const double* x, int Nx, const double* z, int Nz, const do
     a.mux = F64View(r->mux.data(), Nrays);
     a.muz = F64View(r->muz.data(), Nrays);
     a.temperature = F64View(r->temperature.data(), Nx * Nz);
-    a.xLowerBc.type = PERIODIC;
-    a.xUpperBc.type = PERIODIC;
+    if (xLower && xUpper)
+    {
+        auto xbc = [&](AtmosphericBoundaryCondition* bc, const lwhip_boundary* b) {
+            *bc = AtmosphericBoundaryCondition(CALLABLE, 1, b->Nmu, Nz, BcIdxs(const_cast<i32*>(b->idxs), Nrays, 2));
+            bc->set_bc_data(F64View3D(const_cast<f64*>(b->bcData), 1, b->Nmu, Nz));
+        };
+        xbc(&a.xLowerBc, xLower);
+        xbc(&a.xUpperBc, xUpper);
+    }
+    else
+    {
+        a.xLowerBc.type = PERIODIC;
+        a.xUpperBc.type = PERIODIC;
+    }
     auto bc = [](int t) { return t == LWHIP_BC_THERMALISED ? THERMALISED : ZERO; };
     a.zLowerBc.type = bc(zLowerBc);
     a.zUpperBc.type = bc(zUpperBc);

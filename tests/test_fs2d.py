@@ -400,3 +400,68 @@ def test_hip_2d_prd_matches_oracle(gpu):
                     if t.rhoPrd is not None:
                         assert rel_err(t.rhoPrd, u.rhoPrd) <= tol
                     assert rel_err(t.Rij, u.Rij) <= tol and rel_err(t.Rji, u.Rji) <= tol
+
+
+# ---- fixed (CALLABLE) x boundaries (Source/FormalScalar2d.cpp:806-852, 884-898) ------------------------------------
+def x_boundaries(Nrays, Nz, Nla=1, seed=0):
+    from lightweaver_amd.model import Boundary
+    rng = np.random.default_rng(seed)
+    idxs = np.arange(2 * Nrays, dtype=np.int32).reshape(Nrays, 2)
+    mk = lambda: Boundary(abi.BC_CALLABLE, idxs=idxs.copy(), bcData=rng.uniform(0.5, 2.0, (Nla, 2 * Nrays, Nz)) * 2e-8)
+    return mk(), mk()
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+@pytest.mark.parametrize('bc', [(abi.BC_THERMALISED, abi.BC_ZERO), (abi.BC_ZERO, abi.BC_THERMALISED)])
+def test_oracle_2d_besser_fixed_x_matches_reference(bc):
+    """The column a ray enters through is prescribed, the march starts one column in, the last column has no downwind
+    point (linear step; thermalised z boundary: the preceding column's gradient), no long characteristics."""
+    x, z, mux, muz, T = small_grid_inputs()
+    muz = np.append(muz, 1.0)            # and a vertical ray, which still traces every column
+    mux = np.append(mux, 0.0)
+    lo, hi = x_boundaries(muz.size, z.size)
+    ref = bindings.Ref2d(x, z, mux, muz, T, zLowerBc=bc[0], zUpperBc=bc[1], xLowerBc=lo, xUpperBc=hi)
+    grid = ref.grid()
+    assert grid.substepOff.size == 1 and not grid.periodic
+    for seed in (1, 2):
+        chi, S = fields(grid, seed)
+        for mu in range(grid.Nrays):
+            for toObs in (0, 1):
+                Ir, Pr = ref.besser(mu, toObs, 500.0, chi, S)
+                Io, Po = bindings.oracle_2d_besser(grid, mu, toObs, 500.0, chi, S)
+                np.testing.assert_array_equal(Io, Ir)
+                np.testing.assert_array_equal(Po, Pr)
+                if mux[mu] != 0.0:       # the prescribed column really is the boundary data
+                    sgn = mux[mu] if toObs else -mux[mu]
+                    b, jb = (lo, 0) if sgn > 0 else (hi, grid.Nx - 1)
+                    np.testing.assert_array_equal(Io[:, jb], b.bcData[0, b.idxs[mu, toObs]])
+
+
+def fixed_x_problem(seed=3):
+    """small_2d_problem with both x boundaries CALLABLE (seeded irradiation of the order of the interior J)."""
+    from lightweaver_amd.grid2d import build_grid2d
+    p = small_2d_problem()
+    g = p.grid2d
+    lo, hi = x_boundaries(g.Nrays, g.Nz, p.Nlambda, seed)
+    p.grid2d = build_grid2d(g.x, g.z, g.mux, g.muz, g.temperature, g.zLowerBc, g.zUpperBc, xLowerBc=lo, xUpperBc=hi)
+    return p
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+def test_oracle_2d_iteration_fixed_x_matches_reference():
+    p = fixed_x_problem()
+    q = p.copy()
+    ref, orc = bindings.RefContext(p), bindings.OracleContext(q)
+    for it in range(2):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        assert ref.formal_sol_gamma_matrices() == orc.formal_sol_gamma_matrices()[:2]
+        np.testing.assert_array_equal(q.J, p.J)
+        np.testing.assert_array_equal(q.I, p.I)
+        for a, b in zip(q.atoms, p.atoms):
+            np.testing.assert_array_equal(a.Gamma, b.Gamma)
+            for ta, tb in zip(a.trans, b.trans):
+                np.testing.assert_array_equal(ta.Rij, tb.Rij)
+        assert ref.stat_equil() == orc.stat_equil() == 0
+        for a, b in zip(q.atoms, p.atoms):
+            np.testing.assert_array_equal(a.n, b.n)

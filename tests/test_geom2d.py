@@ -65,3 +65,30 @@ def test_builder_rejects(hip_lib):
     z = np.arange(5)[::-1] * 10.0
     with pytest.raises(LwHipError):
         build_grid2d(x, z, [1.0], [0.0], np.ones((5, 6)))      # a ray along x
+
+
+# ---- fixed (CALLABLE) x boundaries: no wrap-around, no long characteristics ---------------------------------------
+def x_boundaries(Nrays, Nz, Nla=1, seed=0):
+    """Both x boundaries CALLABLE as the reference requires (FormalScalar2d.cpp:750-759): idxs[mu, toObs] -> row of
+    bcData [Nlambda, Nmu, Nz] (rows for every (mu, toObs) pair; the solver reads the side the ray enters through)."""
+    from lightweaver_amd.model import Boundary
+    rng = np.random.default_rng(seed)
+    idxs = np.arange(2 * Nrays, dtype=np.int32).reshape(Nrays, 2)
+    mk = lambda: Boundary(abi.BC_CALLABLE, idxs=idxs.copy(), bcData=rng.uniform(0.5, 2.0, (Nla, 2 * Nrays, Nz)) * 1e-8)
+    return mk(), mk()
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+@pytest.mark.parametrize('Nx,Nz,seed', [(5, 4, 0), (33, 17, 1), (64, 82, 2)])
+def test_builder_matches_reference_fixed_x_boundaries(hip_lib, Nx, Nz, seed):
+    rng = np.random.default_rng(seed)
+    x = np.cumsum(rng.uniform(0.5, 1.5, Nx)) * 30e3
+    z = np.cumsum(rng.uniform(0.2, 2.0, Nz))[::-1] * 20e3
+    muz = np.array([0.1, 0.3, 0.6, 0.9, 1.0, 0.5])
+    mux = np.array([1, -1, 1, -1, 0, 1]) * np.sqrt(1.0 - muz**2) * np.array([1, 1, 0.7, 1, 1, -0.3])
+    T = rng.uniform(4e3, 1e4, (Nz, Nx))
+    lo, hi = x_boundaries(muz.size, Nz)
+    ref = bindings.Ref2d(x, z, mux, muz, T, xLowerBc=lo, xUpperBc=hi).grid()
+    mine = build_grid2d(x, z, mux, muz, T, xLowerBc=lo, xUpperBc=hi)
+    same_table(mine, ref)
+    assert mine.substepOff.size - 1 == 0 and not mine.periodic
