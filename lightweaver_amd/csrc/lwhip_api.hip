@@ -146,6 +146,8 @@ struct lwhip_context
     int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
     bool prdDetailed = false;     // LWHIP_OPT_PRD_DETAILED: the PRD calls include the detailed atoms' PRD lines
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
+    DevBuf<double> xbcLow, xbcUp;      // 2D, fixed x boundaries: [Nla, Nmu, Nz] of the shard
+    DevBuf<int32_t> xIdxLow, xIdxUp;   // [Nrays, 2]
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
     std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
@@ -265,10 +267,29 @@ int validate(const lwhip_problem* p, std::string& why)
     if (p->grid2d)
     {
         const lwhip_grid2d& g = *p->grid2d;
-        if (!g.periodic || g.Nx < 2 || g.Nz < 2 || g.Nx > 1024 || g.Nx * g.Nz != p->Nspace || g.Nrays != p->Nrays)
+        if (g.Nx < 2 || g.Nz < 2 || g.Nx > 1024 || g.Nx * g.Nz != p->Nspace || g.Nrays != p->Nrays)
         {
-            why = "2D grid: x-periodic, 2 <= Nx <= 1024, Nz >= 2, Nx * Nz = Nspace, Nrays matching";
+            why = "2D grid: 2 <= Nx <= 1024, Nz >= 2, Nx * Nz = Nspace, Nrays matching";
             return LWHIP_ERR_UNSUPPORTED;
+        }
+        if (!g.periodic)
+        {
+            // "Mixed boundary types not supported on x-axis!" (Source/FormalScalar2d.cpp:750-759)
+            auto ok = [&](const lwhip_boundary* b) {
+                return b && b->type == LWHIP_BC_CALLABLE && b->idxs && b->bcData && b->Nmu > 0;
+            };
+            if (!ok(g.xLowerBc) || !ok(g.xUpperBc) || g.NlongChar != 0)
+            {
+                why = "2D grid without periodic x: both x boundaries CALLABLE (idxs, bcData [Nlambda, Nmu, Nz]), no long characteristics";
+                return LWHIP_ERR_UNSUPPORTED;
+            }
+            for (int q = 0; q < 2 * g.Nrays; ++q)
+                if (g.xLowerBc->idxs[q] < 0 || g.xLowerBc->idxs[q] >= g.xLowerBc->Nmu || g.xUpperBc->idxs[q] < 0
+                    || g.xUpperBc->idxs[q] >= g.xUpperBc->Nmu)
+                {
+                    why = "2D grid: x boundary idxs out of range (\"Error in boundary condition indexing\")";
+                    return LWHIP_ERR_INVALID;
+                }
         }
         if (!g.mux || !g.uw || !g.dw || !g.longCharIdx || !g.substepOff || (g.NlongChar > 0 && !g.substeps))
         {
@@ -1628,6 +1649,22 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
             HIP_TRY(hipMemcpyAsync(c->upperIdx.p, p.zUpperBc.idxs, Nr * 2 * sizeof(int32_t),
                                    hipMemcpyHostToDevice, c->stream));
         }
+        if (c->is2d && !p.grid2d->periodic)
+        {
+            const lwhip_grid2d& g = *p.grid2d;
+            const size_t nLow = (size_t)g.xLowerBc->Nmu * g.Nz, nUp = (size_t)g.xUpperBc->Nmu * g.Nz;
+            if (c->xbcLow.n < Nla * nLow)
+            {
+                HIP_TRY(c->xbcLow.alloc(Nla * nLow));
+                HIP_TRY(c->xbcUp.alloc(Nla * nUp));
+                HIP_TRY(c->xIdxLow.alloc(Nr * 2));
+                HIP_TRY(c->xIdxUp.alloc(Nr * 2));
+            }
+            H2D(c->xbcLow.p, g.xLowerBc->bcData + l0 * nLow, Nla * nLow);
+            H2D(c->xbcUp.p, g.xUpperBc->bcData + l0 * nUp, Nla * nUp);
+            HIP_TRY(hipMemcpyAsync(c->xIdxLow.p, g.xLowerBc->idxs, Nr * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->xIdxUp.p, g.xUpperBc->idxs, Nr * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        }
     }
     if (mask & LWHIP_NSTAR)
         std::fill(c->gIIValid.begin(), c->gIIValid.end(), 0); // aDamp / vBroad may have changed
@@ -1880,6 +1917,16 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     f.zUpperBc = g.zUpperBc;
     f.nRayCycle = nRaysActive;
     f.mux = c->g2mux.p;
+    f.periodic = g.periodic ? 1 : 0;
+    if (!g.periodic)
+    {
+        f.xNmuLow = g.xLowerBc->Nmu;
+        f.xNmuUp = g.xUpperBc->Nmu;
+        f.xbcLow = c->xbcLow.p;
+        f.xbcUp = c->xbcUp.p;
+        f.xIdxLow = c->xIdxLow.p;
+        f.xIdxUp = c->xIdxUp.p;
+    }
     f.temperature = c->temperature.p;
     f.uw = c->g2uw.p;
     f.dw = c->g2dw.p;
@@ -1921,6 +1968,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
         a.rows = rowsBase;
         HIP_TRY(launch_gather2d(a, c->stream));
         f.wavs = c->wavelength.p + la0;
+        f.la0 = la0;
         f.nSolve = nLa * nRaysActive;
         HIP_TRY(launch_fs2d(f, nLa * nRaysActive, c->stream));
         if (rates)
@@ -3114,8 +3162,10 @@ int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double waveleng
 {
     if (!grid || !rays || !chi || !S || !I || !PsiStar || nSolve < 0)
         return fail(LWHIP_ERR_INVALID, "formal_solver_2d: null argument");
-    if (!grid->periodic)
-        return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: only x-periodic grids");
+    if (!grid->periodic
+        && (!grid->xLowerBc || !grid->xUpperBc || grid->xLowerBc->type != LWHIP_BC_CALLABLE || grid->xUpperBc->type != LWHIP_BC_CALLABLE
+            || !grid->xLowerBc->idxs || !grid->xUpperBc->idxs || !grid->xLowerBc->bcData || !grid->xUpperBc->bcData))
+        return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: a grid without periodic x needs both x boundaries CALLABLE");
     if (grid->Nx < 2 || grid->Nz < 2 || grid->Nx > 1024)
         return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: need 2 <= Nx <= 1024 and Nz >= 2");
     if (!grid->x || !grid->z || !grid->mux || !grid->muz || !grid->temperature || !grid->uw || !grid->dw

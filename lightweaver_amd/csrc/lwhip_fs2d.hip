@@ -237,6 +237,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     const size_t o = (size_t)k * Nx + j;
     double A = 0.0, c1 = 0.0, c2 = 0.0, src = 0.0, psi = 0.0;
     int idx = 0;
+    const bool edge = !a.periodic && mux != 0.0; // fixed x boundaries and an inclined ray
+
+    if (edge && p == 0)
+    {
+        // the column the ray enters through is prescribed on every plane (:806-852): a constant map
+        const int la = a.la0 + solve / a.nRayCycle;
+        const bool low = mux > 0.0;
+        const int muIdx = (low ? a.xIdxLow : a.xIdxUp)[ray];
+        const int Nmu = low ? a.xNmuLow : a.xNmuUp;
+        src = (low ? a.xbcLow : a.xbcUp)[((size_t)la * Nmu + muIdx) * Nz + k];
+        cf[0] = 0.0;
+        cf[(size_t)Ns] = 0.0;
+        cf[(size_t)2 * Ns] = 0.0;
+        cf[(size_t)3 * Ns] = src;
+        *ci = 0;
+        Ps[o] = 0.0;
+        return;
+    }
 
     if (k == kStart)
     {
@@ -244,7 +262,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         const int bc = toObs ? a.zLowerBc : a.zUpperBc;
         if (bc == LWHIP_BC_THERMALISED)
         {
-            const lwhip_intersection dw = DW[o];
+            // (:884-898) the last column of a fixed-boundary grid has no downwind point: the preceding column's
+            const lwhip_intersection dw = (edge && p == Nx - 1) ? DW[o - (mux < 0 ? -1 : 1)] : DW[o];
             const double chiDw = f2_interp(dw, chi, Nx);
             const double dtauDw = 0.5 * fabs(dw.distance) * (chi[o] + chiDw);
             const double Tdw = f2_interp(dw, a.temperature, Nx);
@@ -545,6 +564,17 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
     F2_TRY(up(g->longCharIdx, nSt * sizeof(int32_t), (void**)&a.longCharIdx));
     F2_TRY(up(g->substepOff, ((size_t)g->NlongChar + 1) * sizeof(int32_t), (void**)&a.substepOff));
     F2_TRY(up(g->substeps, nSub * sizeof(lwhip_intersection), (void**)&a.substeps));
+    a.periodic = g->periodic ? 1 : 0;
+    a.la0 = 0; // the primitive has one wavelength: row 0 of the boundary data
+    if (!g->periodic)
+    {
+        a.xNmuLow = g->xLowerBc->Nmu;
+        a.xNmuUp = g->xUpperBc->Nmu;
+        F2_TRY(up(g->xLowerBc->bcData, (size_t)a.xNmuLow * g->Nz * sizeof(double), (void**)&a.xbcLow));
+        F2_TRY(up(g->xUpperBc->bcData, (size_t)a.xNmuUp * g->Nz * sizeof(double), (void**)&a.xbcUp));
+        F2_TRY(up(g->xLowerBc->idxs, (size_t)g->Nrays * 2 * sizeof(int32_t), (void**)&a.xIdxLow));
+        F2_TRY(up(g->xUpperBc->idxs, (size_t)g->Nrays * 2 * sizeof(int32_t), (void**)&a.xIdxUp));
+    }
     F2_TRY(up(rays, (size_t)nSolve * sizeof(int32_t), (void**)&a.rays));
     F2_TRY(up(chi, (size_t)nSolve * Ns * sizeof(double), (void**)&a.chi));
     F2_TRY(up(S, (size_t)nSolve * Ns * sizeof(double), (void**)&a.S));

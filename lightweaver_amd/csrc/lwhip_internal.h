@@ -428,6 +428,14 @@ struct Fs2dArgs
     // I(k, p) = A I(k, p - 1) + c1 I(idx) + c2 I(idx + 1) + src of the point
     double* coef;          // [nSolve, 4 (A, c1, c2, src), Nz, Nx]
     int32_t* cidx;         // [nSolve, Nz, Nx]: x of the hit on the previous plane, or -(flat index) - 1
+    // fixed (CALLABLE) x boundaries (FormalScalar2d.cpp:806-852): the column a ray enters through is prescribed
+    int32_t periodic;      // 1: x-periodic grid (the fields below are unused)
+    int32_t la0;           // wavelength (row of the boundary data) of solve 0; solve s: la0 + s / nRayCycle
+    int32_t xNmuLow, xNmuUp;
+    const double* xbcLow;  // [Nla, xNmuLow, Nz] (mux > 0: column 0)
+    const double* xbcUp;   // [Nla, xNmuUp, Nz]  (mux < 0: column Nx - 1)
+    const int32_t* xIdxLow; // [Nrays, 2] -> row of the boundary data
+    const int32_t* xIdxUp;
 };
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream);
 bool fs2d_long_chars_ok(const lwhip_grid2d* g);

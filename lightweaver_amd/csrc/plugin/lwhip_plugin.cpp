@@ -125,6 +125,7 @@ struct PluginState
     std::vector<uint64_t> shape;       // structural signature: recreate the device context if it changes
     // Ndim = 2: Atmosphere::intersections flattened into the tables of lwhip_grid2d
     lwhip_grid2d grid{};
+    lwhip_boundary xLow{}, xUp{};      // fixed (CALLABLE) x boundaries of a 2D atmosphere
     std::vector<lwhip_intersection> g2uw, g2dw, g2sub;
     std::vector<int32_t> g2long, g2subOff;
     std::vector<double> height2d;
@@ -190,8 +191,9 @@ void flatten_grid2d(Context& ctx, PluginState* st)
     const char* ip = ctx.interpFn.name;
     if (!fs || std::strcmp(fs, "piecewise_besser_2d") || !ip || std::strcmp(ip, "interp_linear_2d"))
         throw std::runtime_error("lwhip plugin: 2D needs piecewise_besser_2d with interp_linear_2d");
-    if (atmos.xLowerBc.type != PERIODIC || atmos.xUpperBc.type != PERIODIC)
-        throw std::runtime_error("lwhip plugin: 2D atmospheres must be periodic in x");
+    const bool periodic = atmos.xLowerBc.type == PERIODIC && atmos.xUpperBc.type == PERIODIC;
+    if (!periodic && !(atmos.xLowerBc.type == CALLABLE && atmos.xUpperBc.type == CALLABLE))
+        throw std::runtime_error("lwhip plugin: mixed boundary types are not supported on the x axis"); // FormalScalar2d.cpp:755-759
     if ((atmos.zLowerBc.type != ZERO && atmos.zLowerBc.type != THERMALISED)
         || (atmos.zUpperBc.type != ZERO && atmos.zUpperBc.type != THERMALISED))
         throw std::runtime_error("lwhip plugin: 2D z boundaries must be ZERO or THERMALISED");
@@ -203,7 +205,22 @@ void flatten_grid2d(Context& ctx, PluginState* st)
     uint64_t sig = hashOf(atmos.x.data, Nx) ^ (hashOf(atmos.z.data, Nz) * 3)
                    ^ (hashOf(atmos.mux.data, Nrays) * 5) ^ (hashOf(atmos.muz.data, Nrays) * 7)
                    ^ ((uint64_t)atmos.zLowerBc.type << 8) ^ ((uint64_t)atmos.zUpperBc.type << 16)
-                   ^ ((uint64_t)atmos.intersections.substeps.size() << 24) ^ 1;
+                   ^ ((uint64_t)atmos.intersections.substeps.size() << 24) ^ (periodic ? 1 : 2);
+    // the x boundary data is borrowed like every other array: refreshed on every call, outside the cached table
+    auto xbc = [](lwhip_boundary* b, AtmosphericBoundaryCondition& bc) {
+        b->type = LWHIP_BC_CALLABLE;
+        b->Nmu = (int32_t)bc.bcData.shape(1);
+        b->idxs = bc.idxs.data;
+        b->bcData = bc.bcData.data();
+    };
+    st->grid.xLowerBc = st->grid.xUpperBc = nullptr;
+    if (!periodic)
+    {
+        xbc(&st->xLow, atmos.xLowerBc);
+        xbc(&st->xUp, atmos.xUpperBc);
+        st->grid.xLowerBc = &st->xLow;
+        st->grid.xUpperBc = &st->xUp;
+    }
     if (sig == st->gridSig && st->grid.Nx == Nx && st->grid.Nz == Nz && st->grid.Nrays == Nrays
         && st->grid.temperature == atmos.temperature.data)
         return;
@@ -243,7 +260,7 @@ void flatten_grid2d(Context& ctx, PluginState* st)
     g.Nx = Nx;
     g.Nz = Nz;
     g.Nrays = Nrays;
-    g.periodic = 1;
+    g.periodic = periodic ? 1 : 0;
     g.zLowerBc = (int32_t)atmos.zLowerBc.type;
     g.zUpperBc = (int32_t)atmos.zUpperBc.type;
     g.NlongChar = (int32_t)st->g2subOff.size() - 1;
@@ -257,6 +274,8 @@ void flatten_grid2d(Context& ctx, PluginState* st)
     g.longCharIdx = st->g2long.data();
     g.substepOff = st->g2subOff.data();
     g.substeps = st->g2sub.data();
+    g.xLowerBc = periodic ? nullptr : &st->xLow;
+    g.xUpperBc = periodic ? nullptr : &st->xUp;
 }
 
 void flatten_boundary(lwhip_boundary* b, AtmosphericBoundaryCondition& bc)

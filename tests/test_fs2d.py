@@ -438,12 +438,24 @@ def test_oracle_2d_besser_fixed_x_matches_reference(bc):
 
 
 def fixed_x_problem(seed=3):
-    """small_2d_problem with both x boundaries CALLABLE (seeded irradiation of the order of the interior J)."""
+    """small_2d_problem with both x boundaries CALLABLE: the incoming radiation is the Planck function of the
+    boundary column's own temperature, modulated per ray (a physically sane irradiation, so that the statistical
+    equilibrium stays well conditioned)."""
     from lightweaver_amd.grid2d import build_grid2d
+    from lightweaver_amd.harness import physics as ph
+    from lightweaver_amd.model import Boundary
     p = small_2d_problem()
     g = p.grid2d
-    lo, hi = x_boundaries(g.Nrays, g.Nz, p.Nlambda, seed)
-    p.grid2d = build_grid2d(g.x, g.z, g.mux, g.muz, g.temperature, g.zLowerBc, g.zUpperBc, xLowerBc=lo, xUpperBc=hi)
+    rng = np.random.default_rng(seed)
+    idxs = np.arange(2 * g.Nrays, dtype=np.int32).reshape(g.Nrays, 2)
+
+    def side(col):
+        T = g.temperature[:, col]
+        B = np.stack([ph.planck_nu(T, lam) for lam in p.wavelength])          # [Nlambda, Nz]
+        return Boundary(abi.BC_CALLABLE, idxs=idxs.copy(),
+                        bcData=B[:, None, :] * rng.uniform(0.6, 1.0, (1, 2 * g.Nrays, 1)))
+    p.grid2d = build_grid2d(g.x, g.z, g.mux, g.muz, g.temperature, g.zLowerBc, g.zUpperBc, xLowerBc=side(0),
+                            xUpperBc=side(g.Nx - 1))
     return p
 
 
@@ -465,3 +477,45 @@ def test_oracle_2d_iteration_fixed_x_matches_reference():
         assert ref.stat_equil() == orc.stat_equil() == 0
         for a, b in zip(q.atoms, p.atoms):
             np.testing.assert_array_equal(a.n, b.n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bc', [(abi.BC_THERMALISED, abi.BC_ZERO), (abi.BC_ZERO, abi.BC_THERMALISED)])
+def test_hip_2d_besser_fixed_x_matches_oracle(gpu, bc):
+    from lightweaver_amd.grid2d import build_grid2d, formal_solver_2d
+    x, z, mux, muz, T = small_grid_inputs(Nx=37, Nz=29)
+    muz, mux = np.append(muz, 1.0), np.append(mux, 0.0)
+    lo, hi = x_boundaries(muz.size, z.size)
+    grid = build_grid2d(x, z, mux, muz, T, bc[0], bc[1], xLowerBc=lo, xUpperBc=hi)
+    chi, S = fields(grid, 4)
+    rays = np.arange(2 * grid.Nrays)
+    I, Psi = formal_solver_2d(grid, 500.0, rays, np.broadcast_to(chi, (rays.size,) + chi.shape),
+                              np.broadcast_to(S, (rays.size,) + S.shape))
+    for r in rays:
+        Io, Po = bindings.oracle_2d_besser(grid, r // 2, r % 2, 500.0, chi, S)
+        assert rel_err(I[r], Io) <= 1e-9 and rel_err(Psi[r], Po) <= 1e-9, r
+
+
+@pytest.mark.gpu
+def test_hip_2d_iteration_fixed_x_matches_oracle(gpu):
+    """The device 2D pipeline on a grid with CALLABLE x boundaries: iteration + stat_equil against the oracle (which is
+    bit-identical to the core, test_oracle_2d_iteration_fixed_x_matches_reference)."""
+    from lightweaver_amd.context import Context
+    prob = fixed_x_problem()
+    q = prob.copy()
+    orc = bindings.OracleContext(q)
+    with Context(prob) as ctx:
+        for it in range(2):
+            up = ctx.formal_sol_gamma_matrices()
+            q.gamma_prefill()
+            dJ, idx = orc.formal_sol_gamma_matrices()
+            assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+            assert rel_err(prob.J, q.J) <= 1e-9 * (it + 1)
+            assert rel_err(prob.I, q.I) <= 1e-9 * (it + 1)
+            for a, b in zip(prob.atoms, q.atoms):
+                assert rel_err(a.Gamma, b.Gamma) <= 1e-8
+                for ta, tb in zip(a.trans, b.trans):
+                    assert rel_err(ta.Rij, tb.Rij) <= 1e-9 * (it + 1) and rel_err(ta.Rji, tb.Rji) <= 1e-9 * (it + 1)
+            ctx.stat_equil()
+            assert orc.stat_equil() == 0
+            assert rel_err(prob.atoms[0].n, q.atoms[0].n) <= 1e-8

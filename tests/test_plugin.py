@@ -333,3 +333,34 @@ def test_dropin_2d_prd_and_formal_sol(gpu):
         hipc.formal_sol(upOnly=upOnly)
         ref.formal_sol(upOnly=upOnly)
         assert rel_err(p.I, q.I) <= TOL_ONE_CALL * 10
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_2d_fixed_x_boundaries(gpu):
+    """Ndim = 2 with CALLABLE x boundaries under the real core: the plugin flattens the core's own intersection table
+    (no long characteristics) and the boundaries' bcData [Nlambda, Nmu, Nz]; the built-in scalar scheme is the
+    reference."""
+    from test_fs2d import fixed_x_problem
+    base = fixed_x_problem()
+    p, q = base.copy(), base.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(2):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        r1 = hipc.formal_sol_gamma_matrices()
+        r2 = ref.formal_sol_gamma_matrices()
+        assert abs(r1[0] / r2[0] - 1.0) <= TOL_ONE_CALL
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL * (it + 1) and rel_err(p.I, q.I) <= TOL_ONE_CALL * (it + 1)
+        for x, y in zip(p.atoms, q.atoms):
+            assert rel_err(x.Gamma, y.Gamma) <= 1e-8
+        assert hipc.stat_equil() == ref.stat_equil() == 0
+        for x, y in zip(p.atoms, q.atoms):
+            assert rel_err(x.n, y.n) <= 1e-7
+    # the boundary data is borrowed: an in-place change reaches the device on the next call
+    for pr in (p, q):
+        pr.grid2d.xLowerBc.bcData *= 1.5
+        pr.gamma_prefill()
+    hipc.formal_sol_gamma_matrices()
+    ref.formal_sol_gamma_matrices()
+    assert rel_err(p.J, q.J) <= 3 * TOL_ONE_CALL
