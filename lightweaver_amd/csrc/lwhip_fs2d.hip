@@ -62,15 +62,16 @@ DEVINL F2Loc f2_loc(const lwhip_intersection& loc, int Nx)
 }
 DEVINL double f2_at(const F2Loc& l, const double* p) { return l.w0 * p[l.i0] + l.w1 * p[l.i1]; }
 
-// besser_control_point :257-294
-DEVINL double f2_control_point(double hM, double hP, double yM, double yO, double yP)
+// besser_control_point :257-294.  Division-free: the caller supplies 1 / hM, 1 / hP and 1 / (hM + hP) (d_rcp:
+// v_rcp_f64 + two Newton steps, ~1 ulp; an IEEE divide is ~25 instructions and the step has ten of them)
+DEVINL double f2_control_point(double hM, double hP, double rhM, double rhP, double rSum, double yM, double yO, double yP)
 {
     const double deltaMO = yO - yM;
-    const double dM = (yO - yM) / hM;
-    const double dP = (yP - yO) / hP;
+    const double dM = (yO - yM) * rhM;
+    const double dP = (yP - yO) * rhP;
     if (dM * dP <= 0.0)
         return yO;
-    double yOp = (hM * dP + hP * dM) / (hM + hP);
+    double yOp = (hM * dP + hP * dM) * rSum;
     double cM = yO - 0.5 * hM * yOp;
     double cP = yO + 0.5 * hP * yOp;
     double minYMO = yM, maxYMO = yO, minYOP = yO, maxYOP = yP;
@@ -86,7 +87,7 @@ DEVINL double f2_control_point(double hM, double hP, double yM, double yO, doubl
     if (cP < minYOP || cP > maxYOP)
     {
         cP = yP;
-        yOp = (cP - yO) / (0.5 * hP);
+        yOp = (cP - yO) * (2.0 * rhP);
         cM = yO - 0.5 * hM * yOp;
     }
     return cM;
@@ -97,18 +98,19 @@ DEVINL void f2_coeffs(double t, double& M, double& O, double& Cc, double& edt)
 {
     if (t < 0.14)
     {
-        M = (t * (t * (t * (t * (t * (t * ((140.0 - 18.0 * t) * t - 945.0) + 5400.0) - 25200.0) + 90720.0) - 226800.0) + 302400.0)) / 907200.0;
-        O = (t * (t * (t * (t * (t * (t * ((10.0 - t) * t - 90.0) + 720.0) - 5040.0) + 30240.0) - 151200.0) + 604800.0)) / 1814400.0;
-        Cc = (t * (t * (t * (t * (t * (t * ((35.0 - 4.0 * t) * t - 270.0) + 1800.0) - 10080.0) + 45360.0) - 151200.0) + 302400.0)) / 907200.0;
-        edt = (t * (t * (t * (t * (t * (t * ((t / 40320.0 - 1.0 / 5040.0) * t + 1.0 / 720) - 1.0 / 120.0) + 1.0 / 24.0) - 1.0 / 6.0) + 1.0 / 2.0) - 1.0)) + 1.0;
+        M = (t * (t * (t * (t * (t * (t * ((140.0 - 18.0 * t) * t - 945.0) + 5400.0) - 25200.0) + 90720.0) - 226800.0) + 302400.0)) * (1.0 / 907200.0);
+        O = (t * (t * (t * (t * (t * (t * ((10.0 - t) * t - 90.0) + 720.0) - 5040.0) + 30240.0) - 151200.0) + 604800.0)) * (1.0 / 1814400.0);
+        Cc = (t * (t * (t * (t * (t * (t * ((35.0 - 4.0 * t) * t - 270.0) + 1800.0) - 10080.0) + 45360.0) - 151200.0) + 302400.0)) * (1.0 / 907200.0);
+        edt = (t * (t * (t * (t * (t * (t * ((t * (1.0 / 40320.0) - 1.0 / 5040.0) * t + 1.0 / 720) - 1.0 / 120.0) + 1.0 / 24.0) - 1.0 / 6.0) + 1.0 / 2.0) - 1.0)) + 1.0;
     }
     else
     {
         const double t2 = t * t;
-        const double e = exp(-t);
-        M = (2.0 - e * (t2 + 2.0 * t + 2.0)) / t2;
-        O = 1.0 - 2.0 * (e + t - 1.0) / t2;
-        Cc = 2.0 * (t - 2.0 + e * (t + 2.0)) / t2;
+        const double rt2 = d_rcp(t2);
+        const double e = (t > 700.0) ? 0.0 : d_exp_neg(-t);
+        M = (2.0 - e * (t2 + 2.0 * t + 2.0)) * rt2;
+        O = 1.0 - 2.0 * (e + t - 1.0) * rt2;
+        Cc = 2.0 * (t - 2.0 + e * (t + 2.0)) * rt2;
         edt = e;
     }
 }
@@ -117,10 +119,10 @@ DEVINL void f2_coeffs(double t, double& M, double& O, double& Cc, double& edt)
 DEVINL void f2_besser(double dsUw, double dsDw, double chiUw, double chiLocal, double chiDw, double Suw, double SLocal,
                       double Sdw, double& edt, double& src, double& psi, double& chiC)
 {
-    chiC = f2_control_point(dsUw, dsDw, chiUw, chiLocal, chiDw);
+    chiC = f2_control_point(dsUw, dsDw, d_rcp(dsUw), d_rcp(dsDw), d_rcp(dsUw + dsDw), chiUw, chiLocal, chiDw);
     const double dtauUw = (1.0 / 3.0) * (chiUw + chiLocal + chiC) * dsUw;
     const double dtauDw = (0.5) * (chiLocal + chiDw) * dsDw;
-    const double SC = f2_control_point(dtauUw, dtauDw, Suw, SLocal, Sdw);
+    const double SC = f2_control_point(dtauUw, dtauDw, d_rcp(dtauUw), d_rcp(dtauDw), d_rcp(dtauUw + dtauDw), Suw, SLocal, Sdw);
     double M, O, Cc;
     f2_coeffs(dtauUw, M, O, Cc, edt);
     src = M * Suw + O * SLocal + Cc * SC;
@@ -132,10 +134,11 @@ DEVINL void f2_linear(double dtau, double Suw, double SLocal, double& e, double&
 {
     double w0, w1;
     d_w2(dtau, w0, w1);
-    const double c1 = (Suw - SLocal) / dtau;
+    const double rdt = d_rcp(dtau);
+    const double c1 = (Suw - SLocal) * rdt;
     e = 1.0 - w0;
     src = w0 * SLocal + w1 * c1;
-    psi = w0 - w1 / dtau;
+    psi = w0 - w1 * rdt;
 }
 
 // long characteristic up to the point's upwind hit (:1003-1043).  The walk is affine in the intensity at its far
@@ -349,7 +352,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
             const double dtauUw = (1.0 / 3.0) * (chiUw + chiL + chiC) * st.distance;
             const double dtauDw = (0.5) * (chiL + chiDw) * dw.distance;
             const double Sdw = f2_at(ld, S);
-            const double SC = f2_control_point(dtauUw, dtauDw, Suw, SL, Sdw);
+            const double SC = f2_control_point(dtauUw, dtauDw, d_rcp(dtauUw), d_rcp(dtauDw), d_rcp(dtauUw + dtauDw), Suw, SL, Sdw);
             double M, O, Cc;
             f2_coeffs(dtauUw, M, O, Cc, e);
             src = M * Suw + O * SL + Cc * SC;
@@ -364,7 +367,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     cf[(size_t)2 * Ns] = c2;
     cf[(size_t)3 * Ns] = src;
     *ci = idx;
-    Ps[o] = psi / chiL;
+    Ps[o] = psi * d_rcp(chiL);
 }
 
 // Pass 2, one wavefront per solve: the planes in sequence, each lane D consecutive columns of the processing
