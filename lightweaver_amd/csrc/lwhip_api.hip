@@ -2127,6 +2127,23 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
             a.tailTicket = c->tailTicket;
             mapped = res != nullptr;
         }
+        else if (res)
+        {
+            // split / sharded iteration: the (all-reduced) tail holds every shard's (dJMax, idx); the apply launch takes
+            // their maximum and publishes it the same way -- no read-back copy, no wait for the end of the stream
+            a.tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
+            a.gatherWorld = c->worldSize;
+            if (!c->tailMapped)
+            {
+                HIP_TRY(hipHostMalloc((void**)&c->tailMapped, 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(hipHostGetDevicePointer((void**)&c->tailMappedDev, c->tailMapped, 0));
+                c->tailMapped[2] = 0.0;
+            }
+            a.tailHost = c->tailMappedDev;
+            c->tailTicket += 1.0;
+            a.tailTicket = c->tailTicket;
+            mapped = true;
+        }
         HIP_TRY(launch_apply(a, c->stream));
         c->prefillPending = false;
         c->partsOnly = false;

@@ -129,10 +129,28 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
 {
     const int Ns = a.Ns;
     const int k0 = blockIdx.y * APPLY_K;
-    if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ is set)
+    if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ or a.gatherWorld is set)
     {
-        if (blockIdx.y == 0)
+        if (blockIdx.y == 0 && a.dJ)
             djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0, a.tailHost, a.tailTicket);
+        else if (blockIdx.y == 0 && threadIdx.x == 0)
+        {
+            // sharded iteration: max over the shards' slots, first (lowest) wavelength index on ties (max_idx,
+            // Constants.hpp:114-125), published like the single-device result
+            double best = -1.0, bestIdx = 0.0;
+            for (int r = 0; r < a.gatherWorld; ++r)
+            {
+                const double v = a.tail[2 * r], i = a.tail[2 * r + 1];
+                if (v > best || (v == best && i < bestIdx))
+                {
+                    best = v;
+                    bestIdx = i;
+                }
+            }
+            __hip_atomic_store(&a.tailHost[0], best < 0.0 ? 0.0 : best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&a.tailHost[1], bestIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&a.tailHost[2], a.tailTicket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     // the reduced sum of transition tr, component q at depth k: from the reduce buffer, or from the stage-1 parts
@@ -238,7 +256,7 @@ hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs*
         hipLaunchKernelGGL(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(1024), 0,
                            stream, a, list);
     else
-        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1 + (a.dJ ? 1 : 0), (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0,
+        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0), (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0,
                            stream, a, list);
     return hipGetLastError();
 }
