@@ -411,6 +411,12 @@ int lwhip_compute_profiles(lwhip_context* ctx);
 /* Block until all work queued on the context's stream has finished. */
 int lwhip_synchronize(lwhip_context* ctx);
 
+/* ZPlaneDecomposition (ExtraParams "ZPlaneDecomposition" with "ZPlaneDown" / "ZPlaneUp",
+ * Source/SimdFullIterationTemplates.hpp:253-281, 351-384): from now on every formal solution also records the
+ * intensity of the down rays in plane Nz - 2 (zPlaneDown) and of the up rays in plane 1 (zPlaneUp), host arrays
+ * [Nlambda, Nrays] (1D) or [Nlambda, Nrays, Nx] (2D) filled by lwhip_download(LWHIP_I); NULL turns one off. */
+int lwhip_set_zplane_outputs(lwhip_context* ctx, double* zPlaneDown, double* zPlaneUp);
+
 /* Use `stream` (hipStream_t) for all subsequent launches; NULL = the library's own. */
 int lwhip_set_stream(lwhip_context* ctx, void* stream);
 

@@ -164,6 +164,7 @@ SYMBOLS = [
     ('lwhip_nr_post_update', C.c_int, [ctx_p, C.POINTER(lwhip_nr_args)]),
     ('lwhip_synchronize', C.c_int, [ctx_p]),
     ('lwhip_set_stream', C.c_int, [ctx_p, C.c_void_p]),
+    ('lwhip_set_zplane_outputs', C.c_int, [ctx_p, f64p, f64p]),
     ('lwhip_profile_enable', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_sweep_time', C.c_int, [ctx_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ('lwhip_algorithmic_bytes', C.c_int, [ctx_p, C.POINTER(C.c_double)]),

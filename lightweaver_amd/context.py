@@ -130,6 +130,14 @@ class Context:
     def download(self, mask=abi.ALL_OUTPUTS):
         _check(self.lib, self.lib.lwhip_download(self._h, mask), 'lwhip_download')
 
+    def set_zplane(self, down=None, up=None):
+        """ExtraParams ZPlaneDecomposition (Source/SimdFullIterationTemplates.hpp:253-281, 351-384): every formal solution
+        from now on also records I of the down rays in plane Nz - 2 (`down`) and of the up rays in plane 1 (`up`),
+        float64 arrays [Nlambda, Nrays] (1D) / [Nlambda, Nrays, Nx] (2D) filled by download(I); None turns one off."""
+        self._zplane = (down, up)
+        ptr = lambda a: a.ctypes.data_as(abi.f64p) if a is not None else None
+        _check(self.lib, self.lib.lwhip_set_zplane_outputs(self._h, ptr(down), ptr(up)), 'lwhip_set_zplane_outputs')
+
     def synchronize(self):
         _check(self.lib, self.lib.lwhip_synchronize(self._h), 'lwhip_synchronize')
 

@@ -299,6 +299,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
                 a.Iout[((size_t)la * a.Nrays + mu) * a.Nx + kk] = I;
             if (a.storeDepth && on)
                 a.depthI[((size_t)la * a.Nrays * 2 + ray) * Ns + kk] = I;
+            if (on) // ZPlaneDecomposition :372-384: plane 1 of the up rays, plane Nz - 2 of the down rays
+            {
+                if ((ray & 1) && a.zUp && kk >= a.Nx && kk < 2 * a.Nx)
+                    a.zUp[((size_t)la * a.Nrays + mu) * a.Nx + (kk - a.Nx)] = I;
+                else if (!(ray & 1) && a.zDown && kk >= Ns - 2 * a.Nx && kk < Ns - a.Nx)
+                    a.zDown[((size_t)la * a.Nrays + mu) * a.Nx + (kk - (Ns - 2 * a.Nx))] = I;
+            }
             if (nLine + nMixed == 0)
                 continue;
             double Vij[MAXL], Vji[MAXL], xl[MAXL], el[MAXL], luji[MAXL];
@@ -458,12 +465,17 @@ namespace
 __global__ void __launch_bounds__(256) iout2d_kernel(const Batch2dArgs a)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.Ns || (!a.storeDepth && k >= a.Nx))
+    const bool planes = a.zUp || a.zDown;
+    if (k >= a.Ns || (!a.storeDepth && !planes && k >= a.Nx))
         return;
     const int r = blockIdx.y, b = blockIdx.z;
     const int la = a.la0 + b;
     const int ray = a.rayList[r];
     const double I = a.I[((size_t)b * a.nRaysActive + r) * a.Ns + k];
+    if ((ray & 1) && a.zUp && k >= a.Nx && k < 2 * a.Nx) // ZPlaneDecomposition :372-384
+        a.zUp[((size_t)la * a.Nrays + (ray >> 1)) * a.Nx + (k - a.Nx)] = I;
+    else if (!(ray & 1) && a.zDown && k >= a.Ns - 2 * a.Nx && k < a.Ns - a.Nx)
+        a.zDown[((size_t)la * a.Nrays + (ray >> 1)) * a.Nx + (k - (a.Ns - 2 * a.Nx))] = I;
     if ((ray & 1) && k < a.Nx) // Spectrum::I: the top row, written by the toObs ray (:365-370)
         a.Iout[((size_t)la * a.Nrays + (ray >> 1)) * a.Nx + k] = I;
     if (a.storeDepth)
@@ -473,7 +485,7 @@ __global__ void __launch_bounds__(256) iout2d_kernel(const Batch2dArgs a)
 
 hipError_t launch_iout2d(const Batch2dArgs& a, hipStream_t stream)
 {
-    const int n = a.storeDepth ? a.Ns : a.Nx;
+    const int n = (a.storeDepth || a.zUp || a.zDown) ? a.Ns : a.Nx;
     hipLaunchKernelGGL(iout2d_kernel, dim3((n + 255) / 256, a.nRaysActive, a.nLa), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -147,6 +147,9 @@ struct lwhip_context
     bool prdDetailed = false;     // LWHIP_OPT_PRD_DETAILED: the PRD calls include the detailed atoms' PRD lines
     DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
     DevBuf<double> xbcLow, xbcUp;      // 2D, fixed x boundaries: [Nla, Nmu, Nz] of the shard
+    DevBuf<double> zDown, zUp;         // ZPlaneDecomposition outputs [Nla, Nrays, Nx] (lwhip_set_zplane_outputs)
+    double* zDownHost = nullptr;       // their host arrays [Nlambda, Nrays, Nx]
+    double* zUpHost = nullptr;
     DevBuf<int32_t> xIdxLow, xIdxUp;   // [Nrays, 2]
     DevBuf<int32_t> g2long, g2subOff, slotTrD;
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
@@ -1355,6 +1358,8 @@ int build_tile_args(lwhip_context* c)
     a.depthChi = c->depthChi.p;
     a.depthEta = c->depthEta.p;
     a.depthI = c->depthI.p;
+    a.zDown = c->zDown.p;
+    a.zUp = c->zUp.p;
     a.n = c->n.p;
     a.ratio = c->ratio.p;
     a.wphi = c->wphi.p;
@@ -1780,7 +1785,13 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
     if (mask & LWHIP_J)
         D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
     if (mask & LWHIP_I)
+    {
         D2H(p.I + l0 * Nr * c->Nx, c->I.p, Nla * Nr * (size_t)c->Nx);
+        if (c->zDownHost)
+            D2H(c->zDownHost + l0 * Nr * c->Nx, c->zDown.p, Nla * Nr * (size_t)c->Nx);
+        if (c->zUpHost)
+            D2H(c->zUpHost + l0 * Nr * c->Nx, c->zUp.p, Nla * Nr * (size_t)c->Nx);
+    }
     if ((mask & LWHIP_DEPTHDATA) && p.storeDepthData)
     {
         D2H(p.depthChi + l0 * Nr * 2 * Ns, c->depthChi.p, Nla * Nr * 2 * Ns);
@@ -1899,6 +1910,8 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     a.depthChi = c->depthChi.p;
     a.depthEta = c->depthEta.p;
     a.depthI = c->depthI.p;
+    a.zDown = c->zDown.p;
+    a.zUp = c->zUp.p;
     a.chi = c->b2chi.p;
     a.S = c->b2S.p;
     a.I = c->b2I.p;
@@ -3262,6 +3275,30 @@ int lwhip_compute_profiles(lwhip_context* c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     return compute_profiles_impl(c);
+}
+
+int lwhip_set_zplane_outputs(lwhip_context* c, double* zPlaneDown, double* zPlaneUp)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->Nla * c->Nrays * c->Nx;
+    c->zDownHost = zPlaneDown;
+    c->zUpHost = zPlaneUp;
+    if (zPlaneDown && c->zDown.n < n)
+        HIP_TRY(c->zDown.alloc(n));
+    if (zPlaneUp && c->zUp.n < n)
+        HIP_TRY(c->zUp.alloc(n));
+    if (!zPlaneDown)
+        c->zDown.release();
+    if (!zPlaneUp)
+        c->zUp.release();
+    if (zPlaneDown)
+        HIP_TRY(hipMemsetAsync(c->zDown.p, 0, n * sizeof(double), c->stream));
+    if (zPlaneUp)
+        HIP_TRY(hipMemsetAsync(c->zUp.p, 0, n * sizeof(double), c->stream));
+    return build_tile_args(c); // the sweep's argument block carries the pointers
 }
 
 int lwhip_synchronize(lwhip_context* c)

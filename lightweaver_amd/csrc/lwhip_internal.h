@@ -217,6 +217,8 @@ struct TileArgs
     double* depthChi;
     double* depthEta;
     double* depthI;
+    double* zDown;                 // ZPlaneDecomposition outputs [Nla, Nmu] (or null): I at depth Nz - 2 of the down rays,
+    double* zUp;                   // at depth 1 of the up rays (SimdFullIterationTemplates.hpp:351-361)
     const double* n;               // [NlevTot, Ns]
     const double* ratio;           // [Ncont, Ns]
     const double* wphi;            // [Nline, Ns]
@@ -464,6 +466,8 @@ struct Batch2dArgs
     double* depthChi;
     double* depthEta;
     double* depthI;
+    double* zDown;                 // ZPlaneDecomposition outputs [Nla, Nrays, Nx] (or null), :372-384
+    double* zUp;
     double* chi;                   // [nLa, nRaysActive, Ns] batch buffers
     double* S;
     const double* I;

@@ -814,6 +814,14 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                     GD(a.I)[(size_t)la * Nmu + mu] = I; // spect.I(la, mu, 0) :349
                 if (storeDepth)
                     GD(a.depthI)[((size_t)(la * Nmu + mu) * 2 + toObs) * Ns + km] = I;
+                if (PH == PH_N)
+                {
+                    // ZPlaneDecomposition :351-361: the second-to-last point of the march is depth 1 of an up ray,
+                    // depth Nz - 2 of a down ray
+                    double* zp = toObs ? a.zUp : a.zDown;
+                    if (zp)
+                        GD(zp)[(size_t)la * Nmu + mu] = I;
+                }
             }
             if (RATES)
             {

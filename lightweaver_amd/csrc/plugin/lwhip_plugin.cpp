@@ -132,6 +132,8 @@ struct PluginState
     uint64_t gridSig = 0, gridEpoch = 0; // geometry fingerprint; epoch enters the structural signature
     uint64_t fpProfiles = 0, fpBackground = 0, fpAtmos = 0, fpNstar = 0, fpCollisions = 0;
     bool prdDetailed = false;          // the device context was asked to include the detailed atoms' PRD lines
+    double* zDown = nullptr;           // ZPlaneDecomposition outputs the device context currently writes
+    double* zUp = nullptr;
 };
 
 std::mutex g_mutex;
@@ -493,6 +495,7 @@ uint32_t sync_state(Context& ctx, bool force)
         if (old)
             lwhip_destroy(old);
         st->hip = nullptr;
+        st->zDown = st->zUp = nullptr; // a fresh device context writes no z-plane outputs yet
         lwhip_options opts{};
         opts.flags = st->prdDetailed ? LWHIP_OPT_PRD_DETAILED : 0;
         if (lwhip_create(&st->prob, &opts, &st->hip) != LWHIP_OK)
@@ -512,10 +515,27 @@ bool force_upload(ExtraParams& params)
     return params.contains("lwhip_force_upload");
 }
 
-void reject_unsupported(ExtraParams& params)
+// ExtraParams "ZPlaneDecomposition" with "ZPlaneDown" / "ZPlaneUp" (Source/SimdFullIterationTemplates.hpp:253-281): the
+// caller's arrays become the library's z-plane outputs for this call (filled by the download of I)
+void apply_zplane(Context& ctx, PluginState* st, ExtraParams& params)
 {
+    double* down = nullptr;
+    double* up = nullptr;
     if (params.contains("ZPlaneDecomposition"))
-        throw std::runtime_error("lwhip plugin: ZPlaneDecomposition outputs are not produced by the device sweep");
+    {
+        const bool is2d = ctx.atmos->Ndim == 2;
+        if (params.contains("ZPlaneDown"))
+            down = is2d ? params.get_as<F64View3D>("ZPlaneDown").data : params.get_as<F64View2D>("ZPlaneDown").data;
+        if (params.contains("ZPlaneUp"))
+            up = is2d ? params.get_as<F64View3D>("ZPlaneUp").data : params.get_as<F64View2D>("ZPlaneUp").data;
+    }
+    if (down != st->zDown || up != st->zUp)
+    {
+        if (lwhip_set_zplane_outputs(st->hip, down, up) != LWHIP_OK)
+            fail("lwhip_set_zplane_outputs");
+        st->zDown = down;
+        st->zUp = up;
+    }
 }
 
 // ---- FsIterationFns members ----------------------------------------------------------------------
@@ -523,10 +543,10 @@ void reject_unsupported(ExtraParams& params)
 // fs_iter: replaces formal_sol_iteration_matrices_<simd> (Source/SimdFullIterationTemplates.hpp:588-719)
 IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params)
 {
-    reject_unsupported(params);
     trace("fs_iter", &ctx);
     const uint32_t up = sync_state(ctx, force_upload(params));
     auto* st = (PluginState*)ctx.methodScratch;
+    apply_zplane(ctx, st, params);
     if (lwhip_upload(st->hip, up) != LWHIP_OK)
         fail("lwhip_upload");
     lwhip_iter_result r{};
@@ -547,9 +567,9 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
 // simple_fs: replaces formal_sol_<simd> (Source/SimdFullIterationTemplates.hpp:721-781)
 IterationResult simple_fs_hip(Context& ctx, bool upOnly, ExtraParams params)
 {
-    reject_unsupported(params);
     const uint32_t up = sync_state(ctx, force_upload(params));
     auto* st = (PluginState*)ctx.methodScratch;
+    apply_zplane(ctx, st, params);
     if (lwhip_upload(st->hip, up & ~(uint32_t)LWHIP_GAMMA) != LWHIP_OK)
         fail("lwhip_upload");
     if (lwhip_formal_sol(st->hip, upOnly ? 1 : 0) != LWHIP_OK)

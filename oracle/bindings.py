@@ -160,6 +160,15 @@ class RefContext(_Handle):
     def stat_equil(self, atom=-1):
         return self.lib.lwref_stat_equil(self.h, atom)
 
+    def set_zplane(self, down=None, up=None):
+        """ExtraParams ZPlaneDecomposition / ZPlaneDown / ZPlaneUp of the formal solutions: float64 arrays
+        [Nlambda, Nrays(, Nx)] filled in place."""
+        self._zplane = (down, up)
+        ptr = lambda a: a.ctypes.data_as(abi.f64p) if a is not None else None
+        self.lib.lwref_set_zplane.argtypes = [C.c_void_p, abi.f64p, abi.f64p]
+        self.lib.lwref_set_zplane.restype = None
+        self.lib.lwref_set_zplane(self.h, ptr(down), ptr(up))
+
     def redistribute_prd(self, maxIter=3, tol=1e-2, include_detailed_atoms=False):
         self.lib.lwref_set_include_detailed(self.h, int(include_detailed_atoms))
         return _redistribute(self.lib.lwref_redistribute_prd, self.h, maxIter, tol)
@@ -261,6 +270,12 @@ class OracleContext(_Handle):
 
     def stat_equil(self, atom=-1):
         return self.lib.lworacle_stat_equil(self.h, atom)
+
+    def set_zplane(self, down=None, up=None):
+        self._zplane = (down, up)
+        ptr = lambda a: a.ctypes.data_as(abi.f64p) if a is not None else None
+        self.lib.lworacle_set_zplane.argtypes = [C.c_void_p, abi.f64p, abi.f64p]
+        assert self.lib.lworacle_set_zplane(self.h, ptr(down), ptr(up)) == 0
 
     def redistribute_prd(self, maxIter=3, tol=1e-2, include_detailed_atoms=False):
         self.lib.lworacle_set_include_detailed(self.h, int(include_detailed_atoms))

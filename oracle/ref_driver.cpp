@@ -51,6 +51,8 @@ struct RefContext
     Context ctx;
     bool threadsInitialised = false;
     bool includeDetailed = false; // ExtraParams "include_detailed_atoms" of the PRD calls
+    double* zDown = nullptr;      // ExtraParams "ZPlaneDecomposition" + "ZPlaneDown" / "ZPlaneUp"
+    double* zUp = nullptr;
 
     ~RefContext()
     {
@@ -317,6 +319,32 @@ int lwref_scheme_name(void* h, char* buf, int n)
 
 // refresh CALLABLE boundary data from the descriptor (LwAtmosphere.compute_bcs,
 // Source/LwMiddleLayer.pyx:762-829, copies into the core-owned bcData each iteration)
+// ExtraParams of the formal solutions: the ZPlaneDecomposition outputs (SimdFullIterationTemplates.hpp:253-281)
+static ExtraParams fs_params(RefContext* rc)
+{
+    ExtraParams params;
+    if (rc->zDown || rc->zUp)
+    {
+        const lwhip_problem* p = rc->prob;
+        params.insert("ZPlaneDecomposition", true);
+        if (p->grid2d)
+        {
+            if (rc->zDown)
+                params.insert("ZPlaneDown", F64View3D(rc->zDown, p->Nlambda, p->Nrays, p->grid2d->Nx));
+            if (rc->zUp)
+                params.insert("ZPlaneUp", F64View3D(rc->zUp, p->Nlambda, p->Nrays, p->grid2d->Nx));
+        }
+        else
+        {
+            if (rc->zDown)
+                params.insert("ZPlaneDown", F64View2D(rc->zDown, p->Nlambda, p->Nrays));
+            if (rc->zUp)
+                params.insert("ZPlaneUp", F64View2D(rc->zUp, p->Nlambda, p->Nrays));
+        }
+    }
+    return params;
+}
+
 static void refresh_bcs(RefContext* rc)
 {
     const lwhip_problem* p = rc->prob;
@@ -329,6 +357,12 @@ static void refresh_bcs(RefContext* rc)
     {
         F64View3D data(const_cast<f64*>(p->zUpperBc.bcData), p->Nlambda, p->zUpperBc.Nmu, 1);
         rc->atmos.zUpperBc.set_bc_data(data);
+    }
+    if (p->grid2d && !p->grid2d->periodic) // the x boundaries' irradiation is borrowed like the z boundaries'
+    {
+        const lwhip_grid2d& g = *p->grid2d;
+        rc->atmos.xLowerBc.set_bc_data(F64View3D(const_cast<f64*>(g.xLowerBc->bcData), p->Nlambda, g.xLowerBc->Nmu, g.Nz));
+        rc->atmos.xUpperBc.set_bc_data(F64View3D(const_cast<f64*>(g.xUpperBc->bcData), p->Nlambda, g.xUpperBc->Nmu, g.Nz));
     }
 }
 
@@ -361,7 +395,7 @@ int lwref_formal_sol_gamma_matrices(void* h, int lambdaIterate, lwhip_iter_resul
     try
     {
         refresh_bcs(rc);
-        IterationResult r = formal_sol_gamma_matrices(rc->ctx, (bool)lambdaIterate);
+        IterationResult r = formal_sol_gamma_matrices(rc->ctx, (bool)lambdaIterate, fs_params(rc));
         if (res)
         {
             res->updatedJ = r.updatedJ;
@@ -383,7 +417,7 @@ int lwref_formal_sol(void* h, int upOnly)
     try
     {
         refresh_bcs(rc);
-        formal_sol(rc->ctx, (bool)upOnly);
+        formal_sol(rc->ctx, (bool)upOnly, fs_params(rc));
     }
     catch (const std::exception& e)
     {
@@ -615,6 +649,12 @@ void lwref_ng_max_change(void* h, double* dMax, int* idx)
     NgChange c = ((Ng*)h)->max_change();
     *dMax = c.dMax;
     *idx = (int)c.dMaxIdx;
+}
+
+void lwref_set_zplane(void* h, double* down, double* up)
+{
+    ((RefContext*)h)->zDown = down;
+    ((RefContext*)h)->zUp = up;
 }
 
 // what LwContext.prd_redistribute passes as extraParams (Source/LwMiddleLayer.pyx:3678-3680)

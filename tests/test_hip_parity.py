@@ -364,3 +364,28 @@ def test_detailed_static_atom_only(gpu):
     for p, u in ((p1, up), (p2, up2)):
         assert u.dJMax == pytest.approx(dJ, rel=1e-9)
         assert rel_err(p.J, q.J) <= TOL_ONE_CALL and rel_err(p.I, q.I) <= TOL_ONE_CALL
+
+
+def test_zplane_decomposition_outputs(gpu):
+    """ExtraParams ZPlaneDecomposition (Source/SimdFullIterationTemplates.hpp:253-281, 351-361): I of the down rays at
+    depth Nz - 2 and of the up rays at depth 1, next to the emergent intensity; iteration and formal_sol."""
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = variant_problem(base, d, 'iter1'), variant_problem(base, d, 'iter1')
+    zr = [np.full((p.Nlambda, p.Nrays), -1.0) for _ in range(2)]
+    zh = [np.full((p.Nlambda, p.Nrays), -1.0) for _ in range(2)]
+    with OracleContext(q) as oc, Context(p) as ctx:
+        oc.set_zplane(zr[0], zr[1])
+        ctx.set_zplane(zh[0], zh[1])
+        q.gamma_prefill()
+        oc.formal_sol_gamma_matrices()
+        ctx.formal_sol_gamma_matrices()
+        assert zr[0].min() > 0.0 and zr[1].min() > 0.0
+        assert rel_err(zh[0], zr[0]) <= TOL_ONE_CALL and rel_err(zh[1], zr[1]) <= TOL_ONE_CALL
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL
+        for z in zr + zh:
+            z[...] = -1.0
+        oc.formal_sol(upOnly=True)          # only the up rays are traced: ZPlaneDown stays untouched
+        ctx.formal_sol(upOnly=True)
+        assert np.all(zr[0] == -1.0) and rel_err(zh[1], zr[1]) <= TOL_ONE_CALL
+        ctx.set_zplane(None, None)
+        ctx.formal_sol_gamma_matrices()

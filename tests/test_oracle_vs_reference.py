@@ -173,3 +173,30 @@ def test_reference_threads_vs_single():
     RefContext(p, Nthreads=4).formal_sol_gamma_matrices()
     assert rel_err(p.J, d['out/iter1/J']) == 0.0
     assert rel_err(p.atoms[0].Gamma, d['out/iter1/Gamma0']) < 1e-10
+
+
+@pytest.mark.parametrize('two_d', [False, True])
+def test_zplane_decomposition_matches_reference(two_d):
+    """ExtraParams ZPlaneDecomposition / ZPlaneDown / ZPlaneUp (SimdFullIterationTemplates.hpp:253-281, 351-384): the
+    intensity of the down rays in plane Nz - 2 and of the up rays in plane 1, 1D and 2D, bit for bit."""
+    if two_d:
+        from test_fs2d import small_2d_problem
+        base = small_2d_problem()
+        shape = (base.Nlambda, base.Nrays, base.grid2d.Nx)
+    else:
+        base, _ = load_fixture('falc_h_ca_small')
+        shape = (base.Nlambda, base.Nrays)
+    p, q = base.copy(), base.copy()
+    zr = [np.full(shape, -1.0) for _ in range(2)]
+    zo = [np.full(shape, -1.0) for _ in range(2)]
+    ref, orc = bindings.RefContext(p), bindings.OracleContext(q)
+    ref.set_zplane(zr[0], zr[1])
+    orc.set_zplane(zo[0], zo[1])
+    p.gamma_prefill()
+    q.gamma_prefill()
+    ref.formal_sol_gamma_matrices()
+    orc.formal_sol_gamma_matrices()
+    assert zr[0].min() >= 0.0 and zr[1].min() > 0.0
+    np.testing.assert_array_equal(zo[0], zr[0])
+    np.testing.assert_array_equal(zo[1], zr[1])
+    np.testing.assert_array_equal(q.J, p.J)

@@ -364,3 +364,33 @@ def test_dropin_2d_fixed_x_boundaries(gpu):
     hipc.formal_sol_gamma_matrices()
     ref.formal_sol_gamma_matrices()
     assert rel_err(p.J, q.J) <= 3 * TOL_ONE_CALL
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize('two_d', [False, True])
+def test_dropin_zplane_decomposition(gpu, two_d):
+    """ExtraParams ZPlaneDecomposition / ZPlaneDown / ZPlaneUp through the plugin: the caller's arrays are filled with
+    the z-plane intensities of the device sweep (1D march, 2D pipeline), next to the built-in scalar scheme."""
+    if two_d:
+        base, _ = load_fixture('falc2d_small')
+        shape = (base.Nlambda, base.Nrays, base.grid2d.Nx)
+    else:
+        base, _ = load_fixture('falc_h_ca_small')
+        shape = (base.Nlambda, base.Nrays)
+    p, q = base.copy(), base.copy()
+    zh = [np.full(shape, -1.0) for _ in range(2)]
+    zr = [np.full(shape, -1.0) for _ in range(2)]
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    hipc.set_zplane(zh[0], zh[1])
+    ref.set_zplane(zr[0], zr[1])
+    for it in range(2):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        hipc.formal_sol_gamma_matrices()
+        ref.formal_sol_gamma_matrices()
+        assert rel_err(zh[0], zr[0]) <= TOL_ONE_CALL * (it + 1) and rel_err(zh[1], zr[1]) <= TOL_ONE_CALL * (it + 1)
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL * (it + 1)
+    hipc.set_zplane(None, None)          # and off again
+    p.gamma_prefill()
+    hipc.formal_sol_gamma_matrices()
