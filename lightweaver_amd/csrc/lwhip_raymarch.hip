@@ -244,11 +244,7 @@ typedef unsigned int rm_u2 __attribute__((ext_vector_type(2)));
 // buffer access: resource in SGPRs + per-lane byte offset + scalar byte offset: no address arithmetic per load
 DEVINL double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-#ifdef RM_NO_SOFFSET
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff + soff), 0, 0));
-#else
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
-#endif
 }
 DEVINL void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
 {
@@ -263,8 +259,8 @@ DEVINL double rm_rcp(double x)
 }
 // exp(x) for -700 < x <= 0 as d_exp_neg, the degree-13 polynomial split into its even and odd part (two independent
 // Horner chains in r^2: half the dependent latency)
-// (RM_EXPK: the non-inline constants live in VGPRs for the whole march instead of being re-materialised by two scalar
-// moves each on every step)
+// (the constants are gathered in one struct; pinning them in VGPRs for the whole march was measured: 4 % fewer
+// instructions, but 256 VGPRs and a spill)
 struct ExpK
 {
     double l2e, ln2h, ln2l, c12, c13, c10, c11, c8, c9, c6, c7, c4, c5, c3;
@@ -284,10 +280,6 @@ struct ExpK
         c4 = 1.0 / 24.0;
         c5 = 1.0 / 120.0;
         c3 = 1.0 / 6.0;
-#ifdef RM_EXPK
-        asm volatile("" : "+v"(l2e), "+v"(ln2h), "+v"(ln2l), "+v"(c12), "+v"(c13), "+v"(c10), "+v"(c11));
-        asm volatile("" : "+v"(c8), "+v"(c9), "+v"(c6), "+v"(c7), "+v"(c4), "+v"(c5), "+v"(c3));
-#endif
     }
 };
 DEVINL double rm_exp_neg(double x, const ExpK& K)
@@ -311,11 +303,7 @@ DEVINL double rm_exp_neg(double x, const ExpK& K)
     po = fma(po, r2, 1.0);
     return ldexp(fma(po, r, pe), (int)n);
 }
-#ifdef RM_NO_KEEP
-#define RM_KEEP(v)
-#else
 #define RM_KEEP(v) asm volatile("" : "+v"(v)) // the value is computed here, on every lane (keeps selects branch-free)
-#endif
 
 // What one iteration reads from memory; loaded one iteration ahead.
 template <int NL> struct StepIn
@@ -337,15 +325,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     const int Ns = a.Ns, L = a.L, Nmu = a.Nmu;
     const int nLine = GENERIC ? (int)td.nLine : NL;
     const int nMixed = GENERIC ? (int)td.nMixed : NM;
-#ifdef RM_OPAQUE
-    int nLineO = nLine, nMixedO = nMixed; // experiment: counts the optimiser cannot see through
-    asm volatile("" : "+s"(nLineO), "+s"(nMixedO));
-#define RM_HASL(g, s) ((s) < NL && (((RM_OPAQUE >> (g)) & 1) ? (s) < nLineO : (!GENERIC || (s) < nLine)))
-#define RM_HASM(g, c) ((c) < NM && (((RM_OPAQUE >> (g)) & 1) ? (c) < nMixedO : (!GENERIC || (c) < nMixed)))
-#else
 #define RM_HASL(g, s) ((s) < NL && (!GENERIC || (s) < nLine))
 #define RM_HASM(g, c) ((c) < NM && (!GENERIC || (c) < nMixed))
-#endif
     const int muRaw = lane / L;
     const int jRaw = lane - muRaw * L;
     const bool active = (muRaw < Nmu) && (jRaw < td.nl);
@@ -1246,23 +1227,6 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
             if ((dyn._pad >> 8) & kd)
                 continue;
         }
-#ifdef RM_DEBUG_MASK
-        // debug build: dyn._pad selects tile kinds that go through the generic march instead of their own variant
-        const int kind = td.nLine == 0 ? 1 : (td.nLine == 1 && td.nMixed == 0) ? 2 : (td.nLine == 1) ? 4 : 8;
-        if (CAP == 0 && (dyn._pad & kind))
-        {
-            if (dyn._pad & 16)
-            {
-                if (kind == 4)
-                    march_tile<SOLVER, 1, 1, RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
-                else
-                    march_tile<SOLVER, 2, 1, RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
-            }
-            else
-                march_tile<SOLVER, 2, 2, RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
-            continue;
-        }
-#endif
         if (CAP == 0)
         {
             if (td.nLine == 0)
