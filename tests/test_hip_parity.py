@@ -123,10 +123,14 @@ def test_ragged_sizes_vs_oracle(gpu, Nspace, Nrays):
     compare_problems(p, q)
 
 
-def test_deep_atmosphere_mode_forced_on_small_problem(gpu, monkeypatch):
-    """The global-scratch ('big') variant of the sweep, normally selected only when the LDS working
-    set does not fit (e.g. 500 depth points), forced on the 82-point H + Ca II problem."""
-    monkeypatch.setenv('LWHIP_BIG', '1')
+@pytest.mark.parametrize('env', [{'LWHIP_TILE_GENERIC': '2'}, {'LWHIP_TILE_GENERIC': '8'}, {'LWHIP_TILE_FUSE': '0'},
+                                 {'LWHIP_TWAVES': '4'}])
+def test_sweep_variants_forced_on_small_problem(gpu, monkeypatch, env):
+    """The other instantiations of the one sweep on the 82-point H + Ca II problem: every tile through the guarded
+    generic march (capacity 2 / 8: what tiles with more overlapping lines than the compile-time kinds use), the
+    stand-alone post-pass launch instead of the fused one, four wavefronts (two tiles) per workgroup."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     base, d = load_fixture('falc_h_ca_small')
     p = variant_problem(base, d, 'iter1')
     with Context(p) as ctx:
