@@ -62,7 +62,11 @@ class ShardedIteration:
     stream before every collective phase (`ctx.set_stream(torch.cuda.current_stream())`): the sweep and reduce
     kernels, the all-reduce and the apply kernel are then ordered by stream order alone, with no host
     synchronisation in between.  A Context created with its own (library-owned) stream is re-bound here, and
-    calling under `with torch.cuda.stream(s):` moves the context to `s` for that call.
+    calling under `with torch.cuda.stream(s):` moves the context to `s` for that call.  One case needs no re-binding:
+    torch's default stream is the legacy null stream (handle 0, which the C ABI reads as "the library's own stream");
+    the library's own stream is a blocking stream, and the null stream synchronises implicitly with every blocking
+    stream, in both directions -- so a collective on torch's default stream is ordered against the library's kernels
+    by HIP's legacy default-stream semantics.
     """
 
     def __init__(self, ctx, world: int = 1, rank: int = 0, group=None, force_collective=False):
