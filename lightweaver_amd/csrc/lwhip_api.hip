@@ -131,6 +131,8 @@ struct lwhip_context
     DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
     DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
     DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
+    DevBuf<PrdLineArgs> prdArgsDev;   // argument blocks of the PRD lines of a sub-iteration (one launch for all lines)
+    std::vector<PrdLineArgs> prdArgsHost; // what the device copy holds
     DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
     DevBuf<int32_t> b2idx;
     int groups2d = 1, maxRowsLa = 1;
@@ -2911,13 +2913,13 @@ int lwhip_prd_partial(lwhip_context* c)
         HIP_TRY(c->prdChange.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
         HIP_TRY(c->prdChangeIdx.alloc((size_t)Nprd * Ns * PRD_MAX_SLICES));
     }
-    {
-        size_t maxNl = 1;
-        for (int tr : c->prdLines)
-            maxNl = std::max(maxNl, (size_t)(c->trans[tr].t.Nred - c->trans[tr].t.Nblue));
-        if (c->prdJt.n < maxNl * Ns)
-            HIP_TRY(c->prdJt.alloc(maxNl * Ns));
-    }
+    // transposed J of every line side by side (the lines' scattering integrals run in one launch)
+    std::vector<size_t> jtOff(Nprd + 1, 0);
+    for (int q = 0; q < Nprd; ++q)
+        jtOff[q + 1] = jtOff[q] + (size_t)(c->trans[c->prdLines[q]].t.Nred - c->trans[c->prdLines[q]].t.Nblue) * Ns;
+    if (c->prdJt.n < jtOff[Nprd])
+        HIP_TRY(c->prdJt.alloc(jtOff[Nprd]));
+    std::vector<PrdLineArgs> lineArgs(Nprd);
     // PRD section of the reduce tail: [world][Nprd] x (max |d rho / rho|, flattened index)
     double* prdTail = c->red.p + (size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize;
     for (int q = 0; q < Nprd; ++q)
@@ -2940,7 +2942,7 @@ int lwhip_prd_partial(lwhip_context* c)
         a.Bij = h.t.Bij;
         a.wave = c->lineWave.p + h.waveOff;
         a.J = c->prdJ.p;
-        a.Jt = c->prdJt.p;
+        a.Jt = c->prdJt.p + jtOff[q];
         a.vBroad = c->vBroad.p + (size_t)h.atom * Ns;
         a.aDamp = c->aDamp.p + (size_t)h.row * Ns;
         a.Qelast = c->Qelast.p + (size_t)h.row * Ns;
@@ -2997,8 +2999,21 @@ int lwhip_prd_partial(lwhip_context* c)
         a.rank = c->worldRank;
         a.q = q;
         a.Nprd = Nprd;
-        HIP_TRY(launch_prd_scatter(a, c->stream));
+        lineArgs[q] = a;
     }
+    // the blocks change only when a buffer moves or a cache is filled: upload on change (stream-ordered copy from a
+    // host copy that lives until the next change)
+    if (c->prdArgsHost.size() != (size_t)Nprd
+        || std::memcmp(c->prdArgsHost.data(), lineArgs.data(), (size_t)Nprd * sizeof(PrdLineArgs)) != 0)
+    {
+        HIP_TRY(hipStreamSynchronize(c->stream)); // the previous copy may still be read
+        c->prdArgsHost = lineArgs;
+        if (c->prdArgsDev.n < (size_t)Nprd)
+            HIP_TRY(c->prdArgsDev.alloc(Nprd));
+        HIP_TRY(hipMemcpyAsync(c->prdArgsDev.p, c->prdArgsHost.data(), (size_t)Nprd * sizeof(PrdLineArgs), hipMemcpyHostToDevice,
+                               c->stream));
+    }
+    HIP_TRY(launch_prd_scatter(c->prdArgsDev.p, lineArgs.data(), Nprd, c->stream));
     if (c->is2d)
     {
         // the same rates pass through the 2D pipeline, restricted to the runs of PRD wavelengths

@@ -363,7 +363,8 @@ struct PrdLineArgs
     double* changeVal;      // [Ns * slices] scratch
     int32_t* changeIdx;     // [Ns * slices] scratch
 };
-hipError_t launch_prd_scatter(const PrdLineArgs& a, hipStream_t stream);
+// every PRD line of the sub-iteration in one set of launches: devList = the device copy of hostList [nLines]
+hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream);
 
 // nr_post_update (lwhip_pops.hip): one listed atom, and the launch arguments
 struct NrAtom

@@ -9,7 +9,7 @@
 // same sequentially accumulated q', same end-corrected trapezoid weights -- evaluating GII on the
 // fly instead of caching it per (depth, wavelength) as the reference does (the cached values
 // depend only on aDamp, vBroad and the grid, so the numbers are the same).
-#include "lwhip_internal.h"
+#include "lwhip_device.h"
 #include "../../include/lwhip.h"
 
 #include <hip/hip_runtime.h>
@@ -71,9 +71,19 @@ __device__ double p_GII(double aDamp, double qEmit, double qAbs)
 }
 }
 
+// All PRD lines of a sub-iteration go through ONE launch of each kernel: blockIdx.z picks the line's argument block from
+// a device table read through the constant address space (scalar loads).  One line alone leaves the chip half empty
+// (Ns x slices workgroups of two wavefronts); two lines side by side take barely longer than one.
+
 // J(Nblue : Nred, :) -> Jt[k][la]: the scattering integral reads J along wavelength at fixed depth
-__global__ void prd_transpose_kernel(const double* J, int Nblue, int Nl, int Ns, double* Jt)
+__global__ void prd_transpose_kernel(const PrdLineArgs* __restrict__ list)
 {
+    const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.z);
+    const double* J = a.J;
+    double* Jt = a.Jt;
+    const int Nblue = a.Nblue, Nl = a.Nl, Ns = a.Ns;
+    if (a.laHi <= a.laLo || (int)blockIdx.x * 32 >= Nl)
+        return;
     __shared__ double tile[32][33];
     const int la0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y)
@@ -91,9 +101,12 @@ __global__ void prd_transpose_kernel(const double* J, int Nblue, int Nl, int Ns,
     }
 }
 
-__global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
+__global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __restrict__ list)
 {
     extern __shared__ double sm[];
+    const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.z);
+    if (a.laHi <= a.laLo || (int)blockIdx.y >= a.slices)
+        return;
     const int k = blockIdx.x;
     const int Ns = a.Ns;
     const int Nl = a.Nl;
@@ -319,9 +332,14 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs a)
 }
 
 // per line: max over depth of the per-depth maxima (first flattened index on ties)
-__global__ void prd_change_kernel(const double* changeVal, const int* changeIdx, int nEntries, double* tail, int world,
-                                  int rank, int q, int Nprd)
+__global__ void prd_change_kernel(const PrdLineArgs* __restrict__ list)
 {
+    const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.x);
+    const double* changeVal = a.changeVal;
+    const int* changeIdx = a.changeIdx;
+    const int nEntries = (a.laHi > a.laLo) ? a.Ns * a.slices : 0;
+    double* tail = a.tail;
+    const int world = a.world, rank = a.rank, q = a.q, Nprd = a.Nprd;
     // one wavefront: max value, smallest flattened index on ties (max_idx semantics: strictly greater
     // updates in index order, so the first occurrence wins; a zero maximum keeps idx 0).  The result
     // goes into this shard's slot of the line in the reduce tail; the other shards' slots are zeroed
@@ -358,27 +376,32 @@ __global__ void prd_change_kernel(const double* changeVal, const int* changeIdx,
     }
 }
 
-hipError_t launch_prd_scatter(const PrdLineArgs& a, hipStream_t stream)
+hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream)
 {
-    const size_t lds = (size_t)2 * a.Nl * sizeof(double);
-    static size_t configured = 0;
-    if (lds > configured && lds > 48 * 1024)
+    if (nLines <= 0)
+        return hipSuccess;
+    int maxNl = 1, maxSlices = 1, Ns = hostList[0].Ns;
+    bool any = false;
+    for (int q = 0; q < nLines; ++q)
+    {
+        maxNl = std::max(maxNl, hostList[q].Nl);
+        maxSlices = std::max(maxSlices, hostList[q].slices);
+        any = any || hostList[q].laHi > hostList[q].laLo;
+    }
+    const size_t lds = (size_t)2 * maxNl * sizeof(double);
+    if (lds > 48 * 1024)
     {
         hipError_t err = hipFuncSetAttribute((const void*)prd_scatter_kernel,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess)
             return err;
-        configured = lds;
     }
-    const bool any = a.laHi > a.laLo;
     if (any)
     {
-        hipLaunchKernelGGL(prd_transpose_kernel, dim3((a.Nl + 31) / 32, (a.Ns + 31) / 32), dim3(32, 8), 0, stream, a.J,
-                           a.Nblue, a.Nl, a.Ns, a.Jt);
-        hipLaunchKernelGGL(prd_scatter_kernel, dim3(a.Ns, a.slices), dim3(128), lds, stream, a);
+        hipLaunchKernelGGL(prd_transpose_kernel, dim3((maxNl + 31) / 32, (Ns + 31) / 32, nLines), dim3(32, 8), 0, stream, devList);
+        hipLaunchKernelGGL(prd_scatter_kernel, dim3(Ns, maxSlices, nLines), dim3(128), lds, stream, devList);
     }
-    hipLaunchKernelGGL(prd_change_kernel, dim3(1), dim3(64), 0, stream, a.changeVal, a.changeIdx,
-                       any ? a.Ns * a.slices : 0, a.tail, a.world, a.rank, a.q, a.Nprd);
+    hipLaunchKernelGGL(prd_change_kernel, dim3(nLines), dim3(64), 0, stream, devList);
     return hipGetLastError();
 }
 }
