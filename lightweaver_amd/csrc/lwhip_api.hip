@@ -951,7 +951,8 @@ int build_tables(lwhip_context* c)
         TileChunking swPrd, poPrd;
         if (!tileListPrd.empty())
         {
-            swPrd = chunk_tiles(tileListPrd, std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU), false);
+            // (fused post-pass: one tile per workgroup here too)
+            swPrd = chunk_tiles(tileListPrd, c->tileFuse ? (int)tileListPrd.size() : std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU), false);
             poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * postPerCU), true);
         }
         // both chunkings share one accumulator-slot capacity per kind
@@ -1432,7 +1433,7 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
         return hipSuccess;
     const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
     const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
-    const bool fuse = c->tileFuse && rates && !tprd;
+    const bool fuse = c->tileFuse && rates;
     hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
     if (e != hipSuccess)
         return e;
