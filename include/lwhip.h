@@ -359,7 +359,8 @@ typedef struct lwhip_intersection {   /* IntersectionResult, Source/LwAtmosphere
 
 typedef struct lwhip_grid2d {
     int32_t Nx, Nz, Nrays, periodic;  /* 1: PERIODIC x boundaries; 0: CALLABLE ones (xLowerBc / xUpperBc below)    */
-    int32_t zLowerBc, zUpperBc;       /* LWHIP_BC_ZERO / LWHIP_BC_THERMALISED */
+    int32_t zLowerBc, zUpperBc;       /* LWHIP_BC_ZERO / LWHIP_BC_THERMALISED / LWHIP_BC_CALLABLE (then lwhip_problem's
+                                       * zLowerBc / zUpperBc carry idxs and bcData [Nlambda, Nmu, Nx])            */
     int32_t NlongChar, _pad;
     const double* x;                  /* [Nx] */
     const double* z;                  /* [Nz] */

@@ -277,6 +277,18 @@ int validate(const lwhip_problem* p, std::string& why)
             why = "2D grid: 2 <= Nx <= 1024, Nz >= 2, Nx * Nz = Nspace, Nrays matching";
             return LWHIP_ERR_UNSUPPORTED;
         }
+        if ((g.zLowerBc == LWHIP_BC_CALLABLE) != (p->zLowerBc.type == LWHIP_BC_CALLABLE)
+            || (g.zUpperBc == LWHIP_BC_CALLABLE) != (p->zUpperBc.type == LWHIP_BC_CALLABLE))
+        {
+            why = "2D grid: a CALLABLE z boundary needs lwhip_problem.zLowerBc / zUpperBc of type CALLABLE (bcData [Nlambda, Nmu, Nx])";
+            return LWHIP_ERR_INVALID;
+        }
+        for (int bt : { g.zLowerBc, g.zUpperBc })
+            if (bt != LWHIP_BC_ZERO && bt != LWHIP_BC_THERMALISED && bt != LWHIP_BC_CALLABLE)
+            {
+                why = "2D grid: z boundaries are ZERO, THERMALISED or CALLABLE";
+                return LWHIP_ERR_UNSUPPORTED;
+            }
         if (!g.periodic)
         {
             // "Mixed boundary types not supported on x-axis!" (Source/FormalScalar2d.cpp:750-759)
@@ -1265,12 +1277,12 @@ int alloc_state(lwhip_context* c)
     }
     if (c->prob.zLowerBc.type == LWHIP_BC_CALLABLE)
     {
-        HIP_TRY(c->lowerBcData.alloc(Nla * c->prob.zLowerBc.Nmu));
+        HIP_TRY(c->lowerBcData.alloc(Nla * c->prob.zLowerBc.Nmu * (size_t)c->Nx));
         HIP_TRY(c->lowerIdx.alloc(Nr * 2));
     }
     if (c->prob.zUpperBc.type == LWHIP_BC_CALLABLE)
     {
-        HIP_TRY(c->upperBcData.alloc(Nla * c->prob.zUpperBc.Nmu));
+        HIP_TRY(c->upperBcData.alloc(Nla * c->prob.zUpperBc.Nmu * (size_t)c->Nx));
         HIP_TRY(c->upperIdx.alloc(Nr * 2));
     }
     return LWHIP_OK;
@@ -1647,13 +1659,13 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     {
         if (p.zLowerBc.type == LWHIP_BC_CALLABLE)
         {
-            H2D(c->lowerBcData.p, p.zLowerBc.bcData + l0 * p.zLowerBc.Nmu, Nla * p.zLowerBc.Nmu);
+            H2D(c->lowerBcData.p, p.zLowerBc.bcData + l0 * p.zLowerBc.Nmu * c->Nx, Nla * p.zLowerBc.Nmu * (size_t)c->Nx);
             HIP_TRY(hipMemcpyAsync(c->lowerIdx.p, p.zLowerBc.idxs, Nr * 2 * sizeof(int32_t),
                                    hipMemcpyHostToDevice, c->stream));
         }
         if (p.zUpperBc.type == LWHIP_BC_CALLABLE)
         {
-            H2D(c->upperBcData.p, p.zUpperBc.bcData + l0 * p.zUpperBc.Nmu, Nla * p.zUpperBc.Nmu);
+            H2D(c->upperBcData.p, p.zUpperBc.bcData + l0 * p.zUpperBc.Nmu * c->Nx, Nla * p.zUpperBc.Nmu * (size_t)c->Nx);
             HIP_TRY(hipMemcpyAsync(c->upperIdx.p, p.zUpperBc.idxs, Nr * 2 * sizeof(int32_t),
                                    hipMemcpyHostToDevice, c->stream));
         }
@@ -1934,6 +1946,12 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     f.nRayCycle = nRaysActive;
     f.mux = c->g2mux.p;
     f.periodic = g.periodic ? 1 : 0;
+    f.zNmuLow = c->prob.zLowerBc.Nmu;
+    f.zNmuUp = c->prob.zUpperBc.Nmu;
+    f.zbcLow = c->lowerBcData.p;
+    f.zbcUp = c->upperBcData.p;
+    f.zIdxLow = c->lowerIdx.p;
+    f.zIdxUp = c->upperIdx.p;
     if (!g.periodic)
     {
         f.xNmuLow = g.xLowerBc->Nmu;
@@ -3217,6 +3235,8 @@ int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double waveleng
     if (!grid->x || !grid->z || !grid->mux || !grid->muz || !grid->temperature || !grid->uw || !grid->dw
         || !grid->longCharIdx || !grid->substepOff || (grid->NlongChar > 0 && !grid->substeps))
         return fail(LWHIP_ERR_INVALID, "formal_solver_2d: incomplete grid description");
+    if (grid->zLowerBc == LWHIP_BC_CALLABLE || grid->zUpperBc == LWHIP_BC_CALLABLE)
+        return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: CALLABLE z boundaries need a context (lwhip_problem carries their data)");
     if (!fs2d_long_chars_ok(grid))
         return fail(LWHIP_ERR_UNSUPPORTED, "formal_solver_2d: a long characteristic that does not end on a z plane");
     for (int p = 0; p < nSolve; ++p)

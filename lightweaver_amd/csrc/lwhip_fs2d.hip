@@ -281,6 +281,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
                 src = B0 - (B1 - B0) / dtauDw;
             }
         }
+        else if (bc == LWHIP_BC_CALLABLE)
+        {
+            // :930-938: the prescribed intensity of the plane the ray starts from
+            const int la = a.la0 + solve / a.nRayCycle;
+            const int muIdx = (toObs ? a.zIdxLow : a.zIdxUp)[ray];
+            const int Nmu = toObs ? a.zNmuLow : a.zNmuUp;
+            src = (toObs ? a.zbcLow : a.zbcUp)[((size_t)la * Nmu + muIdx) * Nx + j];
+        }
         cf[0] = 0.0;
         cf[(size_t)Ns] = 0.0;
         cf[(size_t)2 * Ns] = 0.0;

@@ -441,6 +441,12 @@ struct Fs2dArgs
     const double* xbcUp;   // [Nla, xNmuUp, Nz]  (mux < 0: column Nx - 1)
     const int32_t* xIdxLow; // [Nrays, 2] -> row of the boundary data
     const int32_t* xIdxUp;
+    // CALLABLE z boundaries (:930-938): I(kStart, j) = bcData(la, idxs(mu, toObs), j), data [Nla, Nmu, Nx]
+    int32_t zNmuLow, zNmuUp;
+    const double* zbcLow;
+    const double* zbcUp;
+    const int32_t* zIdxLow;
+    const int32_t* zIdxUp;
 };
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream);
 bool fs2d_long_chars_ok(const lwhip_grid2d* g);

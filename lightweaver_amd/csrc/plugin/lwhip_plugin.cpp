@@ -196,9 +196,9 @@ void flatten_grid2d(Context& ctx, PluginState* st)
     const bool periodic = atmos.xLowerBc.type == PERIODIC && atmos.xUpperBc.type == PERIODIC;
     if (!periodic && !(atmos.xLowerBc.type == CALLABLE && atmos.xUpperBc.type == CALLABLE))
         throw std::runtime_error("lwhip plugin: mixed boundary types are not supported on the x axis"); // FormalScalar2d.cpp:755-759
-    if ((atmos.zLowerBc.type != ZERO && atmos.zLowerBc.type != THERMALISED)
-        || (atmos.zUpperBc.type != ZERO && atmos.zUpperBc.type != THERMALISED))
-        throw std::runtime_error("lwhip plugin: 2D z boundaries must be ZERO or THERMALISED");
+    for (RadiationBc t : { atmos.zLowerBc.type, atmos.zUpperBc.type })
+        if (t != ZERO && t != THERMALISED && t != CALLABLE)
+            throw std::runtime_error("lwhip plugin: 2D z boundaries must be ZERO, THERMALISED or CALLABLE");
     if (!atmos.intersections)
         throw std::runtime_error("lwhip plugin: the atmosphere has no intersection table (build_intersection_list)");
     const int Nx = atmos.Nx, Nz = atmos.Nz, Nrays = atmos.Nrays;

@@ -191,8 +191,10 @@ class Problem:
         if b.type == abi.BC_CALLABLE:
             idxs = np.ascontiguousarray(b.idxs, dtype=np.int32)
             data = _f64(b.bcData)
-            if idxs.shape != (self.Nrays, 2) or data.ndim != 2 or data.shape[0] != self.Nlambda:
-                raise ValueError('CALLABLE boundary needs idxs[Nrays,2] and bcData[Nlambda,Nmu]')
+            nd = 3 if self.grid2d is not None else 2      # 2D: [Nlambda, Nmu, Nx] (FormalScalar2d.cpp:930-938)
+            if idxs.shape != (self.Nrays, 2) or data.ndim != nd or data.shape[0] != self.Nlambda \
+                    or (nd == 3 and data.shape[2] != self.grid2d.Nx):
+                raise ValueError('CALLABLE boundary needs idxs[Nrays,2] and bcData[Nlambda,Nmu] (2D: [Nlambda,Nmu,Nx])')
             b.idxs, b.bcData = idxs, data
             keep += [idxs, data]
             out.Nmu = data.shape[1]

@@ -157,8 +157,18 @@ void* lwref_create(const lwhip_problem* p, const char* schemeLib, int Nthreads,
                 xbc(&a.xLowerBc, g.xLowerBc);
                 xbc(&a.xUpperBc, g.xUpperBc);
             }
-            a.zLowerBc.type = (g.zLowerBc == LWHIP_BC_THERMALISED) ? THERMALISED : ZERO;
-            a.zUpperBc.type = (g.zUpperBc == LWHIP_BC_THERMALISED) ? THERMALISED : ZERO;
+            // z boundaries of a 2D grid: ZERO / THERMALISED by type, CALLABLE with bcData [Nlambda, Nmu, Nx] (:930-938)
+            auto zbc = [&](AtmosphericBoundaryCondition* bc, int type, const lwhip_boundary& b) {
+                if (type == LWHIP_BC_CALLABLE)
+                {
+                    *bc = AtmosphericBoundaryCondition(CALLABLE, Nla, b.Nmu, g.Nx, BcIdxs(const_cast<i32*>(b.idxs), Nrays, 2));
+                    bc->set_bc_data(F64View3D(const_cast<f64*>(b.bcData), Nla, b.Nmu, g.Nx));
+                }
+                else
+                    bc->type = (type == LWHIP_BC_THERMALISED) ? THERMALISED : ZERO;
+            };
+            zbc(&a.zLowerBc, g.zLowerBc, p->zLowerBc);
+            zbc(&a.zUpperBc, g.zUpperBc, p->zUpperBc);
             build_intersection_list(&a);
         }
 
@@ -348,14 +358,15 @@ static ExtraParams fs_params(RefContext* rc)
 static void refresh_bcs(RefContext* rc)
 {
     const lwhip_problem* p = rc->prob;
-    if (p->zLowerBc.type == LWHIP_BC_CALLABLE && p->zLowerBc.bcData)
+    const int nOut = p->grid2d ? p->grid2d->Nx : 1; // third extent of a z boundary's data
+    if (p->zLowerBc.type == LWHIP_BC_CALLABLE && p->zLowerBc.bcData && rc->atmos.zLowerBc.type == CALLABLE)
     {
-        F64View3D data(const_cast<f64*>(p->zLowerBc.bcData), p->Nlambda, p->zLowerBc.Nmu, 1);
+        F64View3D data(const_cast<f64*>(p->zLowerBc.bcData), p->Nlambda, p->zLowerBc.Nmu, nOut);
         rc->atmos.zLowerBc.set_bc_data(data);
     }
-    if (p->zUpperBc.type == LWHIP_BC_CALLABLE && p->zUpperBc.bcData)
+    if (p->zUpperBc.type == LWHIP_BC_CALLABLE && p->zUpperBc.bcData && rc->atmos.zUpperBc.type == CALLABLE)
     {
-        F64View3D data(const_cast<f64*>(p->zUpperBc.bcData), p->Nlambda, p->zUpperBc.Nmu, 1);
+        F64View3D data(const_cast<f64*>(p->zUpperBc.bcData), p->Nlambda, p->zUpperBc.Nmu, nOut);
         rc->atmos.zUpperBc.set_bc_data(data);
     }
     if (p->grid2d && !p->grid2d->periodic) // the x boundaries' irradiation is borrowed like the z boundaries'

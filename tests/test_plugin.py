@@ -394,3 +394,19 @@ def test_dropin_zplane_decomposition(gpu, two_d):
     hipc.set_zplane(None, None)          # and off again
     p.gamma_prefill()
     hipc.formal_sol_gamma_matrices()
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dropin_2d_callable_z_boundary(gpu):
+    """A 2D Context irradiated from above (zUpperBc CALLABLE, bcData [Nlambda, Nmu, Nx]) under the real core."""
+    from test_fs2d import callable_z_problem
+    base = callable_z_problem()
+    p, q = base.copy(), base.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for it in range(2):
+        p.gamma_prefill()
+        q.gamma_prefill()
+        hipc.formal_sol_gamma_matrices()
+        ref.formal_sol_gamma_matrices()
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL * (it + 1) and rel_err(p.I, q.I) <= TOL_ONE_CALL * (it + 1)
