@@ -2,7 +2,7 @@
 2D BESSER short characteristics.  Times formal_sol_gamma_matrices (device resident) and, with --ref, the reference
 core (oracle/_ref) on the same problem."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 torch.cuda.init()

@@ -1,7 +1,7 @@
 """Where do the HIP path, the C oracle and the reference core (scalar / SIMD scheme) differ on the bench grid?
 usage (GPU box): python tools/parity_big.py [Nlambda]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 torch.cuda.init()

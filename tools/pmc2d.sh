@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: tools/pmc2d.sh "<counters>" tag   -- one rocprofv3 --pmc pass over the 2D iteration (tools/bench2d.py)
+# usage: tools/pmc2d.sh "<counters>" tag   -- one rocprofv3 --pmc pass over the 2D iteration (tests/diag/bench2d.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $R/gpurun_out/pmc2d_$2 -- python3 $R/tools/bench2d.py 256 0.5 > $R/gpurun_out/pmc2d_$2.log 2>&1
+rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $R/gpurun_out/pmc2d_$2 -- python3 $R/tests/diag/bench2d.py 256 0.5 > $R/gpurun_out/pmc2d_$2.log 2>&1
 python3 - << PY
 import csv,glob,collections
 f=glob.glob("$R/gpurun_out/pmc2d_$2/*/*counter_collection.csv")[0]
