@@ -10,6 +10,7 @@
 #include "../../include/lwhip.h"
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cmath>
 
@@ -268,16 +269,20 @@ __global__ void voigt_wphi_kernel(VoigtLineArgs a, int KT)
 
 hipError_t voigt_init_tables()
 {
-    static bool done = false;
-    if (done)
+    // the table is a __constant__ symbol: one copy per device, so the "already filled" flag is per device too
+    static std::atomic<bool> done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        dev = -1;
+    if (dev >= 0 && done[dev].load())
         return hipSuccess;
     double tab[64];
     const double a2 = 0.268657157075235951582;
     for (int n = 1; n <= 64; ++n)
         tab[n - 1] = std::exp(-a2 * (double)(n * n));
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_expa2n2), tab, sizeof(tab));
-    if (e == hipSuccess)
-        done = true;
+    if (e == hipSuccess && dev >= 0)
+        done[dev].store(true);
     return e;
 }
 
