@@ -99,3 +99,27 @@ def test_2d_256x82_iteration_vs_oracle(gpu):
         ctx.stat_equil()
         assert oc.stat_equil() == 0
         assert rel_err(prob.atoms[0].n, q.atoms[0].n) <= 1e-8
+
+
+def test_converged_solution_at_config1_size_vs_oracle(gpu):
+    """BASELINE configs[1] (FAL-C, H(6) + Ca II(6), ~3k wavelengths, 5 mu, Bezier3): the iterate_ctx_se loop -- 25
+    iterations, populations updated from the fourth on, everything resident in HBM -- against the same loop on the
+    oracle.  North star: converged J within 1e-6 relative of the reference."""
+    from lightweaver_amd.context import Context
+    prob = models.falc_h_ca(Nrays=5, lineScale=3.1)
+    assert 2800 <= prob.Nlambda <= 3100
+    q = prob.copy()
+    oc = OracleContext(q)
+    with Context(prob) as ctx:
+        for it in range(25):
+            up = ctx.formal_sol_gamma_matrices(deviceResident=True)
+            q.gamma_prefill()
+            dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+            if it >= 3:
+                ctx.stat_equil(deviceResident=True)
+                assert oc.stat_equil() == 0
+        ctx.download(abi.ALL_OUTPUTS | abi.POPS)
+    assert up.dJMax == pytest.approx(dJ, rel=1e-4)
+    assert rel_err(prob.J, q.J) <= 1e-6
+    for a, b in zip(prob.atoms, q.atoms):
+        assert rel_err(a.n, b.n) <= 1e-6
