@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
 // order.  A plane is: previous-plane intensities from LDS, the lane's D maps composed, one DPP scan over the lanes,
 // the D intensities written.  No workgroup barrier (a one-wavefront group's barrier is a wait on its own LDS
 // traffic), coefficients of the next plane prefetched while this one is scanned.
-template <int D>
+template <int D, bool FULL>
 __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
 {
     extern __shared__ double prevI[]; // [Nx + 1], by x
@@ -402,60 +402,67 @@ __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
     const int32_t* ci = a.cidx + (size_t)solve * Ns;
     double* I = a.I + (size_t)solve * Ns;
 
-    double A[D], C1[D], C2[D], Sr[D];
-    int ix[D];
-    auto load = [&](int k, double (&lA)[D], double (&lC1)[D], double (&lC2)[D], double (&lS)[D], int (&lI)[D]) {
+    // a plane's maps of the lane.  FULL (Nx = 64 D): no guards, the lane's D values of each array are contiguous and
+    // leave as wide loads
+    struct Maps
+    {
+        double A[D], C1[D], C2[D], S[D];
+        int ix[D];
+    };
+    auto load = [&](int k, Maps& m) {
         const size_t row = (size_t)k * Nx;
 #pragma unroll
         for (int d = 0; d < D; ++d)
         {
             const int p = p0 + d;
-            const bool on = p < Nx;
+            const bool on = FULL || p < Nx;
             const size_t q = row + (on ? p : 0);
-            lA[d] = on ? cf[q] : 1.0;             // identity beyond the row
-            lC1[d] = on ? cf[Ns + q] : 0.0;
-            lC2[d] = on ? cf[2 * Ns + q] : 0.0;
-            lS[d] = on ? cf[3 * Ns + q] : 0.0;
-            lI[d] = on ? ci[q] : 0;
+            m.A[d] = on ? cf[q] : 1.0;             // identity beyond the row
+            m.C1[d] = on ? cf[Ns + q] : 0.0;
+            m.C2[d] = on ? cf[2 * Ns + q] : 0.0;
+            m.S[d] = on ? cf[3 * Ns + q] : 0.0;
+            m.ix[d] = on ? ci[q] : 0;
         }
     };
-    load(kStart, A, C1, C2, Sr, ix);
+    // two planes ahead: a wavefront is alone on its SIMD, the loads of a plane take longer than its arithmetic
+    Maps cur, nx1, nx2;
+    load(kStart, cur);
+    if (Nz > 1)
+        load(kStart + dk, nx1);
     if (lane == 0)
         prevI[Nx] = 0.0;
     for (int step = 0; step < Nz; ++step)
     {
         const int k = kStart + step * dk;
-        double nA[D], nC1[D], nC2[D], nS[D];
-        int nI[D];
-        if (step + 1 < Nz)
-            load(k + dk, nA, nC1, nC2, nS, nI);
+        if (step + 2 < Nz)
+            load(k + 2 * dk, nx2);
         // the lane's maps, with the previous plane's intensities folded into the offsets
         double b[D];
         double E = 1.0, B = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d)
         {
-            double v = Sr[d];
-            if (step > 0 && p0 + d < Nx)
+            double v = cur.S[d];
+            if (step > 0 && (FULL || p0 + d < Nx))
             {
-                const int idx = ix[d];
+                const int idx = cur.ix[d];
                 if (idx >= 0)
                 {
-                    v = fma(C1[d], prevI[idx], v);
-                    if (C2[d] != 0.0)
-                        v = fma(C2[d], prevI[idx + 1], v);
+                    v = fma(cur.C1[d], prevI[idx], v);
+                    if (cur.C2[d] != 0.0)
+                        v = fma(cur.C2[d], prevI[idx + 1], v);
                 }
                 else
                 {
                     const size_t f = (size_t)(-(idx + 1));
-                    v = fma(C1[d], I[f], v);
-                    if (C2[d] != 0.0)
-                        v = fma(C2[d], I[f + 1], v);
+                    v = fma(cur.C1[d], I[f], v);
+                    if (cur.C2[d] != 0.0)
+                        v = fma(cur.C2[d], I[f + 1], v);
                 }
             }
             b[d] = v;
-            B = fma(A[d], B, v);
-            E = A[d] * E;
+            B = fma(cur.A[d], B, v);
+            E = cur.A[d] * E;
         }
         affine_scan_wave(E, B);
         // intensity entering the lane = the composed offset of the lane before (the row's first map has A = 0)
@@ -468,8 +475,8 @@ __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
         for (int d = 0; d < D; ++d)
         {
             const int p = p0 + d;
-            Iin = fma(A[d], Iin, b[d]);
-            if (p < Nx)
+            Iin = fma(cur.A[d], Iin, b[d]);
+            if (FULL || p < Nx)
             {
                 const int j = rev ? Nx - 1 - p : p;
                 prevI[j] = Iin;
@@ -477,17 +484,18 @@ __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-        {
-            A[d] = nA[d];
-            C1[d] = nC1[d];
-            C2[d] = nC2[d];
-            Sr[d] = nS[d];
-            ix[d] = nI[d];
-        }
+        cur = nx1;
+        nx1 = nx2;
     }
 }
+}
+
+template <int D> static void launch_scan(const Fs2dArgs& a, int nSolve, size_t lds, hipStream_t stream)
+{
+    if (a.Nx == 64 * D)
+        hipLaunchKernelGGL((fs2d_scan_kernel<D, true>), dim3(nSolve), dim3(64), lds, stream, a);
+    else
+        hipLaunchKernelGGL((fs2d_scan_kernel<D, false>), dim3(nSolve), dim3(64), lds, stream, a);
 }
 
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
@@ -499,15 +507,15 @@ hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
     const size_t lds = ((size_t)a.Nx + 1) * sizeof(double);
     const int D = (a.Nx + 63) / 64;
     if (D <= 1)
-        hipLaunchKernelGGL(fs2d_scan_kernel<1>, dim3(nSolve), dim3(64), lds, stream, a);
+        launch_scan<1>(a, nSolve, lds, stream);
     else if (D <= 2)
-        hipLaunchKernelGGL(fs2d_scan_kernel<2>, dim3(nSolve), dim3(64), lds, stream, a);
+        launch_scan<2>(a, nSolve, lds, stream);
     else if (D <= 4)
-        hipLaunchKernelGGL(fs2d_scan_kernel<4>, dim3(nSolve), dim3(64), lds, stream, a);
+        launch_scan<4>(a, nSolve, lds, stream);
     else if (D <= 8)
-        hipLaunchKernelGGL(fs2d_scan_kernel<8>, dim3(nSolve), dim3(64), lds, stream, a);
+        launch_scan<8>(a, nSolve, lds, stream);
     else if (D <= 16)
-        hipLaunchKernelGGL(fs2d_scan_kernel<16>, dim3(nSolve), dim3(64), lds, stream, a);
+        launch_scan<16>(a, nSolve, lds, stream);
     else
         return hipErrorInvalidValue; // Nx <= 1024 is checked at the boundary
     return hipGetLastError();
