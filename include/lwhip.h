@@ -341,6 +341,14 @@ typedef struct lwhip_nr_args {
 } lwhip_nr_args;
 int lwhip_nr_post_update(lwhip_context* ctx, const lwhip_nr_args* args);
 
+/* spaceStart / spaceEnd of FsIterationFns::stat_eq, time_dep_update and nr_post_update
+ * (Source/LwFormalInterface.hpp:90-100; the loops `for k in [spaceStart, spaceEnd)` of
+ * Source/UpdatePopulations.cpp:22, :135, :316): the depth range the following lwhip_stat_equil* /
+ * lwhip_time_dep_update / lwhip_nr_post_update calls of this context solve; points outside keep their
+ * populations (and ne).  (-1, -1) = the whole atmosphere, the state of a new context.  Column batches
+ * (lwhip_batch_stat_equil) always solve every point. */
+int lwhip_set_depth_range(lwhip_context* ctx, int spaceStart, int spaceEnd);
+
 /* ---- 2D short characteristics (tier 2): the formal solver primitive -------------------
  * piecewise_besser_2d with interp_linear_2d (Source/FormalScalar2d.cpp:740-1184, 209-255) on an x-periodic
  * Nz x Nx grid, given the intersection table the core builds (build_intersection_list, :1188-1327;

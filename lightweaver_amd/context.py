@@ -138,6 +138,12 @@ class Context:
         ptr = lambda a: a.ctypes.data_as(abi.f64p) if a is not None else None
         _check(self.lib, self.lib.lwhip_set_zplane_outputs(self._h, ptr(down), ptr(up)), 'lwhip_set_zplane_outputs')
 
+    def set_depth_range(self, spaceStart=-1, spaceEnd=-1):
+        """spaceStart / spaceEnd of the reference's stat_eq / time_dep_update / nr_post_update
+        (Source/UpdatePopulations.cpp:7-47, 120-151, 294-394): the depth points [spaceStart, spaceEnd) the following
+        population updates solve; the others keep their values.  (-1, -1): the whole atmosphere."""
+        _check(self.lib, self.lib.lwhip_set_depth_range(self._h, int(spaceStart), int(spaceEnd)), 'lwhip_set_depth_range')
+
     def synchronize(self):
         _check(self.lib, self.lib.lwhip_synchronize(self._h), 'lwhip_synchronize')
 

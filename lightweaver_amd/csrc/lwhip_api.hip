@@ -136,6 +136,7 @@ struct lwhip_context
     DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
     DevBuf<int32_t> b2idx;
     int groups2d = 1, maxRowsLa = 1;
+    int kLo = 0, kHi = -1; // depth range of the population updates (lwhip_set_depth_range); kHi < 0: to the end
     double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration
     double* tailMappedDev = nullptr;
     double tailTicket = 0.0;      // ticket of the last launch that reports through tailMapped
@@ -2350,6 +2351,8 @@ int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
             }
             StatEqArgs sa{};
             sa.Ns = c->Ns;
+            sa.k0 = 0;
+            sa.k1 = c->Ns;
             sa.Natoms = (int32_t)atoms.size();
             sa.atoms = c->statEqAtoms.p;
             sa.n = c->n.p;
@@ -2578,6 +2581,8 @@ static int stat_equil_impl(lwhip_context* c, int atom, bool wait, double* dPops,
         *c->statusHost = 0; // (the async form accumulates until lwhip_check_status)
     StatEqArgs sa{};
     sa.Ns = c->Ns;
+    sa.k0 = c->kLo;
+    sa.k1 = c->kHi < 0 ? c->Ns : c->kHi;
     sa.Natoms = (int32_t)atoms.size();
     sa.atoms = c->statEqAtoms.p;
     sa.n = c->n.p;
@@ -2734,6 +2739,23 @@ int lwhip_ng_accelerate(lwhip_context* c, int32_t* accelerated, double* dPops, i
     return LWHIP_OK;
 }
 
+int lwhip_set_depth_range(lwhip_context* c, int spaceStart, int spaceEnd)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (spaceStart < 0 && spaceEnd < 0) // the reference's "whole atmosphere" (UpdatePopulations.cpp:12-16)
+    {
+        c->kLo = 0;
+        c->kHi = -1;
+        return LWHIP_OK;
+    }
+    if (spaceStart < 0 || spaceEnd > c->Ns || spaceStart > spaceEnd)
+        return fail(LWHIP_ERR_INVALID, "set_depth_range: need 0 <= spaceStart <= spaceEnd <= Nspace (or -1, -1)");
+    c->kLo = spaceStart;
+    c->kHi = spaceEnd;
+    return LWHIP_OK;
+}
+
 int lwhip_time_dep_update(lwhip_context* c, int atom, const double* nOld, double dt)
 {
     if (!c || !nOld)
@@ -2752,7 +2774,7 @@ int lwhip_time_dep_update(lwhip_context* c, int atom, const double* nOld, double
         HIP_TRY(c->popScratch.alloc(cnt));
     HIP_TRY(hipMemcpyAsync(c->popScratch.p, nOld, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
-    HIP_TRY(launch_time_dep(a.Nlevel, c->Ns, c->n.p + (size_t)c->levelOff[atom] * c->Ns, c->popScratch.p,
+    HIP_TRY(launch_time_dep(a.Nlevel, c->Ns, c->kLo, c->kHi < 0 ? c->Ns : c->kHi, c->n.p + (size_t)c->levelOff[atom] * c->Ns, c->popScratch.p,
                             c->Gamma.p + c->gammaOff[atom], dt, c->status.p, c->stream));
     int32_t st = 0;
     HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -2862,6 +2884,8 @@ int lwhip_nr_post_update(lwhip_context* c, const lwhip_nr_args* args)
     a.dt = args->dt;
     a.crsw = args->crsw;
     a.status = c->status.p;
+    a.k0 = c->kLo;
+    a.k1 = c->kHi < 0 ? (int32_t)Ns : c->kHi;
     HIP_TRY(launch_nr_post(a, c->stream));
     int32_t st = 0;
     HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -395,10 +395,12 @@ struct NrArgs
     const int32_t* transLj;
     double dt, crsw;
     int32_t* status;
+    int32_t k0, k1;             // depth range solved [k0, k1) (spaceStart / spaceEnd of the reference)
 };
 struct StatEqArgs
 {
     int32_t Ns, Natoms;
+    int32_t k0, k1;             // depth range solved [k0, k1)
     const NrAtom* atoms;        // the atoms to solve (atom, Nlevel, levelOff, gammaOff used)
     double* n;                  // pool
     const double* nTotal;       // [Natom, Ns]
@@ -514,7 +516,7 @@ struct NgArgs
 };
 hipError_t launch_ng(const NgArgs& a, int nAtoms, hipStream_t stream);
 hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream);
-hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
+hipError_t launch_time_dep(int Nlevel, int Ns, int k0, int k1, double* n, const double* nOld, const double* Gamma, double dt,
                            int* status, hipStream_t stream);
 
 // launch helpers implemented in lwhip_kernels.hip

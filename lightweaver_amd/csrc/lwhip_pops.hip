@@ -209,7 +209,7 @@ template <class A> DEVINL void stat_eq_body(const A& a)
     const int N = at.Nlevel;
     double best = 0.0;
     int bestIdx = 0x7fffffff;
-    if (k < Ns)
+    if (k >= a.k0 && k < a.k1)
     {
         double* n = a.n + (size_t)at.levelOff * Ns;
         const double* Gamma = a.Gamma + at.gammaOff;
@@ -291,12 +291,12 @@ hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream
 }
 
 // ---- time_dependent_update_impl: Source/UpdatePopulations.cpp:120-151 --------------------------------------
-__global__ void time_dep_kernel(int N, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
-                                int* status)
+__global__ void time_dep_kernel(int N, int Ns, int k0, int k1, double* n, const double* nOld, const double* Gamma,
+                                double dt, int* status)
 {
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Ns)
+    if (k < k0 || k >= k1)
         return;
     const SolveWs w(lds, N, blockDim.x, threadIdx.x);
     for (int i = 0; i < N; ++i)
@@ -315,8 +315,8 @@ __global__ void time_dep_kernel(int N, int Ns, double* n, const double* nOld, co
         n[(size_t)i * Ns + k] = w.b[i];
 }
 
-hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, const double* Gamma, double dt,
-                           int* status, hipStream_t stream)
+hipError_t launch_time_dep(int Nlevel, int Ns, int k0, int k1, double* n, const double* nOld, const double* Gamma,
+                           double dt, int* status, hipStream_t stream)
 {
     if (Nlevel > 64)
         return hipErrorInvalidValue;
@@ -325,8 +325,8 @@ hipError_t launch_time_dep(int Nlevel, int Ns, double* n, const double* nOld, co
     hipError_t e = solve_set_lds((const void*)time_dep_kernel, lds);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(time_dep_kernel, dim3((Ns + tb - 1) / tb), dim3(tb), lds, stream, Nlevel, Ns, n, nOld, Gamma, dt,
-                       status);
+    hipLaunchKernelGGL(time_dep_kernel, dim3((Ns + tb - 1) / tb), dim3(tb), lds, stream, Nlevel, Ns, k0, k1, n, nOld, Gamma,
+                       dt, status);
     return hipGetLastError();
 }
 
@@ -336,7 +336,7 @@ __global__ void nr_post_kernel(const NrArgs a)
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
-    if (k >= Ns)
+    if (k < a.k0 || k >= a.k1)
         return;
     const int Neqn = a.Neqn;
     const SolveWs w(lds, Neqn, blockDim.x, threadIdx.x);

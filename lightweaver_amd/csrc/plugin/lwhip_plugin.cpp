@@ -579,6 +579,21 @@ IterationResult simple_fs_hip(Context& ctx, bool upOnly, ExtraParams params)
     return IterationResult{};
 }
 
+// spaceStart / spaceEnd of the three population updates: set on the device context for the call, back to the whole
+// atmosphere when it returns or throws
+struct DepthRange
+{
+    lwhip_context* h;
+    DepthRange(lwhip_context* hip, int spaceStart, int spaceEnd) : h(hip)
+    {
+        if (lwhip_set_depth_range(h, spaceStart, spaceEnd) != LWHIP_OK)
+            fail("lwhip_set_depth_range");
+    }
+    ~DepthRange() { (void)lwhip_set_depth_range(h, -1, -1); }
+    DepthRange(const DepthRange&) = delete;
+    DepthRange& operator=(const DepthRange&) = delete;
+};
+
 // stat_eq: replaces stat_eq_impl (Source/UpdatePopulations.cpp:7-47)
 void stat_eq_hip(Atom* atom, ExtraParams params, int spaceStart, int spaceEnd)
 {
@@ -593,15 +608,14 @@ void stat_eq_hip(Atom* atom, ExtraParams params, int spaceStart, int spaceEnd)
             idx = it->second.second;
         }
     }
-    const int Nspace = (int)atom->n.shape(1);
-    const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
-    if (!ctx || !whole)
-        throw std::runtime_error("lwhip plugin: stat_eq needs an atom of a live Context and the full depth range");
+    if (!ctx)
+        throw std::runtime_error("lwhip plugin: stat_eq needs an atom of a live Context");
     // whatever else changed since the last call goes up too: sync_state has just recorded its fingerprint as clean
     const uint32_t up = sync_state(*ctx, force_upload(params)) & kSlowGroups;
     auto* st = (PluginState*)ctx->methodScratch;
     if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
         fail("lwhip_upload");
+    const DepthRange range(st->hip, spaceStart, spaceEnd); // [spaceStart, spaceEnd) only (:22)
     const int rc = lwhip_stat_equil(st->hip, idx);
     if (rc == LWHIP_ERR_SINGULAR)
         throw std::runtime_error("Singular Matrix"); // Source/LuSolve.cpp:22-23 -> ExplodingMatrixError
@@ -625,14 +639,13 @@ void time_dep_update_hip(Atom* atom, F64View2D nOld, f64 dt, ExtraParams params,
             idx = it->second.second;
         }
     }
-    const int Nspace = (int)atom->n.shape(1);
-    const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
-    if (!ctx || !whole)
-        throw std::runtime_error("lwhip plugin: time_dep_update needs an atom of a live Context and the full depth range");
+    if (!ctx)
+        throw std::runtime_error("lwhip plugin: time_dep_update needs an atom of a live Context");
     const uint32_t up = sync_state(*ctx, force_upload(params)) & kSlowGroups;
     auto* st = (PluginState*)ctx->methodScratch;
     if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
         fail("lwhip_upload");
+    const DepthRange range(st->hip, spaceStart, spaceEnd); // (:135)
     const int rc = lwhip_time_dep_update(st->hip, idx, nOld.data, dt);
     if (rc == LWHIP_ERR_SINGULAR)
         throw std::runtime_error("Singular Matrix");
@@ -647,12 +660,9 @@ void nr_post_update_hip(Context& ctx, std::vector<Atom*>* atoms, const std::vect
                         F64View backgroundNe, const NrTimeDependentData& timeDepData, f64 crswVal,
                         ExtraParams params, int spaceStart, int spaceEnd)
 {
-    const int Nspace = ctx.atmos->Nspace;
-    const bool whole = (spaceStart < 0 && spaceEnd < 0) || (spaceStart == 0 && spaceEnd == Nspace);
-    if (!whole)
-        throw std::runtime_error("lwhip plugin: nr_post_update needs the full depth range");
     const uint32_t up = sync_state(ctx, force_upload(params)) & kSlowGroups;
     auto* st = (PluginState*)ctx.methodScratch;
+    const DepthRange range(st->hip, spaceStart, spaceEnd); // (:316)
     if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS | LWHIP_COLLISIONS) != LWHIP_OK)
         fail("lwhip_upload");
     const int n = (int)atoms->size();

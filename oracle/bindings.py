@@ -106,6 +106,7 @@ class RefContext(_Handle):
                                                             C.POINTER(abi.lwhip_iter_result)]
             lib.lwref_formal_sol.argtypes = [C.c_void_p, C.c_int]
             lib.lwref_stat_equil.argtypes = [C.c_void_p, C.c_int]
+            lib.lwref_set_depth_range.argtypes = [C.c_void_p, C.c_int, C.c_int]
             lib.lwref_redistribute_prd.argtypes = [C.c_void_p, C.c_int, C.c_double, abi.i32p, abi.i32p,
                                                    abi.f64p, abi.i32p, abi.f64p, abi.i32p]
             lib.lwref_set_include_detailed.argtypes = [C.c_void_p, C.c_int]
@@ -156,6 +157,10 @@ class RefContext(_Handle):
 
     def formal_sol(self, upOnly=True):
         assert self.lib.lwref_formal_sol(self.h, int(upOnly)) == 0
+
+    def set_depth_range(self, spaceStart=-1, spaceEnd=-1):
+        """spaceStart / spaceEnd of the following stat_equil / time_dep_update / nr_post_update calls."""
+        return self.lib.lwref_set_depth_range(self.h, int(spaceStart), int(spaceEnd))
 
     def stat_equil(self, atom=-1):
         return self.lib.lwref_stat_equil(self.h, atom)

@@ -48,6 +48,7 @@ struct RefContext
     FormalSolverManager fsManager;
     FsIterationFnsManager iterManager;
     const lwhip_problem* prob;
+    int spaceStart = -1, spaceEnd = -1; // lwref_set_depth_range
     Context ctx;
     bool threadsInitialised = false;
     bool includeDetailed = false; // ExtraParams "include_detailed_atoms" of the PRD calls
@@ -438,6 +439,15 @@ int lwref_formal_sol(void* h, int upOnly)
     return LWHIP_OK;
 }
 
+// spaceStart / spaceEnd handed to the three population updates below (-1, -1: the whole atmosphere)
+int lwref_set_depth_range(void* h, int spaceStart, int spaceEnd)
+{
+    auto* rc = (RefContext*)h;
+    rc->spaceStart = spaceStart;
+    rc->spaceEnd = spaceEnd;
+    return LWHIP_OK;
+}
+
 int lwref_stat_equil(void* h, int atomIdx)
 {
     auto* rc = (RefContext*)h;
@@ -449,7 +459,7 @@ int lwref_stat_equil(void* h, int atomIdx)
                 continue;
             if (rc->prob->atoms[ia].detailed)
                 continue;
-            stat_eq(rc->ctx, rc->atoms[ia].get());
+            stat_eq(rc->ctx, rc->atoms[ia].get(), ExtraParams{}, rc->spaceStart, rc->spaceEnd);
         }
     }
     catch (const std::runtime_error& e)
@@ -467,7 +477,7 @@ int lwref_time_dep_update(void* h, int atomIdx, const double* nOld, double dt)
     {
         Atom* atom = rc->atoms[atomIdx].get();
         F64View2D nOldView(const_cast<double*>(nOld), atom->Nlevel, rc->prob->Nspace);
-        time_dependent_update(rc->ctx, atom, nOldView, dt);
+        time_dependent_update(rc->ctx, atom, nOldView, dt, ExtraParams{}, rc->spaceStart, rc->spaceEnd);
     }
     catch (const std::runtime_error& e)
     {
@@ -499,7 +509,7 @@ int lwref_nr_post_update(void* h, const lwhip_nr_args* a)
         }
         rc->atmos.ne = F64View(a->ne, Ns);
         F64View bgNe(const_cast<double*>(a->backgroundNe), Ns);
-        nr_post_update(rc->ctx, &atoms, dC, bgNe, td, a->crsw);
+        nr_post_update(rc->ctx, &atoms, dC, bgNe, td, a->crsw, ExtraParams{}, rc->spaceStart, rc->spaceEnd);
     }
     catch (const std::runtime_error& e)
     {

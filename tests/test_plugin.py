@@ -285,6 +285,54 @@ def test_dropin_time_dep_and_nr_updates(gpu):
 
 @needs_ref
 @pytest.mark.gpu
+def test_dropin_partial_depth_ranges(gpu):
+    """spaceStart / spaceEnd of FsIterationFns::stat_eq / time_dep_update / nr_post_update (the per-chunk form of
+    Source/UpdatePopulations.cpp:22, :135, :316): the plugin solves the same range as the core and leaves the same
+    points alone."""
+    from test_pops import active, nr_inputs
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = variant_problem(base, d, 'iter1'), variant_problem(base, d, 'iter1')
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    for pr, c in ((p, hipc), (q, ref)):
+        pr.gamma_prefill()
+        c.formal_sol_gamma_matrices()
+    for x, y in zip(p.atoms, q.atoms):
+        x.Gamma[...] = y.Gamma
+    start = [a.n.copy() for a in q.atoms]
+    for c in (hipc, ref):
+        c.set_depth_range(11, 60)
+    assert hipc.stat_equil() == ref.stat_equil() == 0
+    for x, y, n0 in zip(p.atoms, q.atoms, start):
+        assert rel_err(x.n, y.n) <= 1e-9
+        np.testing.assert_array_equal(x.n[:, :11], n0[:, :11])
+        np.testing.assert_array_equal(x.n[:, 60:], n0[:, 60:])
+        assert x.detailed or not np.array_equal(x.n[:, 11:60], n0[:, 11:60])
+    for c in (hipc, ref):
+        c.set_depth_range(30, 82)
+    for ia in active(p):
+        assert hipc.time_dep_update(ia, start[ia], 0.1) == 0
+        assert ref.time_dep_update(ia, start[ia], 0.1) == 0
+        assert rel_err(p.atoms[ia].n, q.atoms[ia].n) <= 1e-9
+    for c in (hipc, ref):
+        c.set_depth_range(0, 40)
+    stages, bg, ne, dC = nr_inputs(q)
+    ne0, ne2 = ne.copy(), ne.copy()
+    assert hipc.nr_post_update(active(p), stages, bg, ne, dC=dC, crsw=1.0) == 0
+    assert ref.nr_post_update(active(q), stages, bg, ne2, dC=dC, crsw=1.0) == 0
+    assert rel_err(ne, ne2) <= 1e-9
+    np.testing.assert_array_equal(ne[40:], ne0[40:])
+    for x, y in zip(p.atoms, q.atoms):
+        assert rel_err(x.n, y.n) <= 1e-9
+    # back to the whole atmosphere: the next call is a full one again
+    for c in (hipc, ref):
+        c.set_depth_range(-1, -1)
+    assert hipc.stat_equil() == ref.stat_equil() == 0
+    for x, y in zip(p.atoms, q.atoms):
+        assert rel_err(x.n, y.n) <= 1e-9
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_dropin_2d_matches_scalar_scheme(gpu):
     """Ndim = 2 under the real core: the plugin flattens Atmosphere::intersections (built by the core's own
     build_intersection_list) into lwhip_grid2d and runs the device 2D pipeline; the built-in scalar scheme with

@@ -95,6 +95,51 @@ def test_oracle_nr_post_update_matches_reference(timeDep, fdC):
         assert np.allclose(a.n.sum(axis=0), a.nTotal, rtol=1e-10)
 
 
+RANGE = (17, 49)   # spaceStart, spaceEnd: not aligned with any workgroup size
+
+
+def run_ranged(ctxFactory, what, rng):
+    """One population update restricted to the depth points [rng[0], rng[1]) (None: everywhere); returns the problem,
+    the populations before it and ne."""
+    p, ctx = problem_after_one_iteration(ctxFactory)
+    before = [a.n.copy() for a in p.atoms]
+    stages, bg, ne, dC = nr_inputs(p)
+    ne0 = ne.copy()
+    if rng is not None:
+        ctx.set_depth_range(*rng)
+    if what == 'stat_eq':
+        assert ctx.stat_equil() == 0
+    elif what == 'time_dep':
+        for ia in active(p):
+            assert ctx.time_dep_update(ia, before[ia], 0.1) == 0
+    else:
+        assert ctx.nr_post_update(active(p), stages, bg, ne, dC=dC, crsw=1.0) == 0
+    if rng is not None:
+        ctx.set_depth_range(-1, -1)
+    return p, before, ne0, ne
+
+
+def composed(full, before, rng):
+    out = before.copy()
+    out[..., rng[0]:rng[1]] = full[..., rng[0]:rng[1]]
+    return out
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built (needs /root/reference)')
+@pytest.mark.parametrize('what', ['stat_eq', 'time_dep', 'nr_post'])
+def test_reference_depth_range_is_the_full_update_on_that_range(what):
+    """spaceStart / spaceEnd of the core (Source/UpdatePopulations.cpp:22, :135, :316): the depth points are
+    independent, so a ranged call equals the full call inside the range and leaves the rest alone -- the property the
+    GPU test below checks the HIP path against (the oracle has no ranged form of its own)."""
+    pf, before, ne0, neF = run_ranged(bindings.RefContext, what, None)
+    pr, _, _, neR = run_ranged(bindings.RefContext, what, RANGE)
+    for a, b, b0 in zip(pr.atoms, pf.atoms, before):
+        np.testing.assert_array_equal(a.n, composed(b.n, b0, RANGE))
+        assert not np.array_equal(a.n, b.n) or a.detailed
+    if what == 'nr_post':
+        np.testing.assert_array_equal(neR, composed(neF, ne0, RANGE))
+
+
 def test_time_dep_large_dt_tends_to_statistical_equilibrium():
     """(1 - dt Gamma) n = nOld with dt -> infinity has the kernel of Gamma as its solution: the
     stat_equil populations (up to normalisation)."""
@@ -120,6 +165,13 @@ class _HipAdapter:
         # amplified by the conditioning of (1 - dt Gamma) at large dt)
         with bindings.OracleContext(self.p) as oc:
             return oc.formal_sol_gamma_matrices()
+
+    def set_depth_range(self, s, e):
+        self.ctx.set_depth_range(s, e)
+
+    def stat_equil(self):
+        self.ctx.stat_equil()
+        return 0
 
     def time_dep_update(self, atom, nOld, dt):
         prev = {ia: None for ia in active(self.p)}
@@ -151,6 +203,42 @@ def test_hip_nr_post_update_matches_oracle(gpu, timeDep, fdC):
     assert rel_err(neh, neo) <= TOL
     for a, b in zip(ph.atoms, po.atoms):
         assert rel_err(a.n, b.n) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('what', ['stat_eq', 'time_dep', 'nr_post'])
+@pytest.mark.parametrize('rng', [RANGE, (0, 1), (81, 82), (5, 5)])
+def test_hip_depth_range_matches_oracle(gpu, what, rng):
+    """lwhip_set_depth_range: the three updates on [spaceStart, spaceEnd) only -- equal to the oracle's full update
+    inside the range (1e-9), bit-identical to the input outside it."""
+    po, before, ne0, neO = run_ranged(bindings.OracleContext, what, None)
+    ph, _, _, neH = run_ranged(_HipAdapter, what, rng)
+    sl = slice(rng[0], rng[1])
+    for a, b, b0 in zip(ph.atoms, po.atoms, before):
+        if a.detailed:
+            continue
+        outside = np.ones(a.n.shape[1], bool)
+        outside[sl] = False
+        np.testing.assert_array_equal(a.n[:, outside], b0[:, outside])
+        if rng[1] > rng[0]:
+            assert rel_err(a.n[:, sl], b.n[:, sl]) <= TOL
+    if what == 'nr_post':
+        outside = np.ones(neH.size, bool)
+        outside[sl] = False
+        np.testing.assert_array_equal(neH[outside], ne0[outside])
+        if rng[1] > rng[0]:
+            assert rel_err(neH[sl], neO[sl]) <= TOL
+
+
+@pytest.mark.gpu
+def test_hip_depth_range_rejects_bad_ranges(gpu):
+    from lightweaver_amd.context import Context, LwHipError
+    base, d = load_fixture('falc_h_ca_small')
+    with Context(variant_problem(base, d, 'iter1')) as ctx:
+        for s, e in ((-1, 10), (10, 5), (0, 10 ** 6)):
+            with pytest.raises(LwHipError):
+                ctx.set_depth_range(s, e)
+        ctx.set_depth_range(-1, -1)
 
 
 @pytest.mark.gpu
