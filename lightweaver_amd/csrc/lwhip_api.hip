@@ -1940,6 +1940,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     a.dJbits = (unsigned long long*)c->dJ.p;
     Fs2dArgs f{};
     f.Nx = g.Nx;
+    f.rNx = 1.0f / (float)g.Nx;
     f.Nz = g.Nz;
     f.Nrays = g.Nrays;
     f.zLowerBc = g.zLowerBc;

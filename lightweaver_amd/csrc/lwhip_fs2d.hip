@@ -204,29 +204,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
 {
     const int Nx = a.Nx, Nz = a.Nz;
     const int Ns = Nx * Nz;
-    // workgroup order: wavelength fastest, then ray, then the 256-point tile -- neighbours in launch order share the
-    // tile's intersection records (64 B per point, the largest read), so each XCD's L2 serves them after the first
-    const int nLa = a.nSolve / a.nRayCycle;
-    const int laIdx = blockIdx.x % nLa;
-    const int rest = blockIdx.x / nLa;
-    const int rayIdx = rest % a.nRayCycle;
+    // workgroup order (blockIdx.x fastest): wavelength, then ray, then the 256-point tile -- neighbours in launch order
+    // share the tile's intersection records (64 B per point, the largest read), so each XCD's L2 serves them after
+    // the first.  A 3D grid, so that no index is recovered by an integer division (~40 scalar instructions each).
+    const int laIdx = blockIdx.x;
+    const int rayIdx = blockIdx.y;
     const int solve = laIdx * a.nRayCycle + rayIdx;
-    const int t = (rest / a.nRayCycle) * blockDim.x + threadIdx.x;
+    const int t = blockIdx.z * blockDim.x + threadIdx.x;
     if (t >= Ns)
         return;
     // solve s: ray rays[s % nRayCycle]; wavelength wavs[s / nRayCycle] (2D iteration: a batch of wavelengths x
     // the active rays) or the single a.wav (primitive)
     // (uniform table reads through the constant address space: scalar loads, not a chain of vector-load latencies
     // at the start of every short-lived workgroup)
-    const int ray = CTAB(int32_t, a.rays)[solve % a.nRayCycle];
-    const double wavHere = a.wavs ? CTAB(double, a.wavs)[solve / a.nRayCycle] : a.wav;
+    const int ray = CTAB(int32_t, a.rays)[rayIdx];
+    const double wavHere = a.wavs ? CTAB(double, a.wavs)[laIdx] : a.wav;
     const int mu = ray >> 1;
     const bool toObs = (ray & 1) != 0;
     const double mux = toObs ? CTAB(double, a.mux)[mu] : -CTAB(double, a.mux)[mu];
     const int dk = toObs ? -1 : 1;
     const int kStart = toObs ? Nz - 1 : 0;
     const int kEnd = toObs ? 0 : Nz - 1;
-    const int k = t / Nx, p = t - k * Nx;       // p: position in the ray's processing order
+    // k = t / Nx through a float reciprocal and one correction (t < 2^23: Nspace is far below)
+    int k = (int)(((float)t + 0.5f) * a.rNx);
+    k -= (k * Nx > t) ? 1 : 0;
+    k += ((k + 1) * Nx <= t) ? 1 : 0;
+    const int p = t - k * Nx;                   // p: position in the ray's processing order
     const int j = (mux < 0) ? Nx - 1 - p : p;
     const size_t plane0 = ((size_t)ray * Nz) * Nx;
     const lwhip_intersection* UW = a.uw + plane0;
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     if (edge && p == 0)
     {
         // the column the ray enters through is prescribed on every plane (:806-852): a constant map
-        const int la = a.la0 + solve / a.nRayCycle;
+        const int la = a.la0 + laIdx;
         const bool low = mux > 0.0;
         const int muIdx = (low ? a.xIdxLow : a.xIdxUp)[ray];
         const int Nmu = low ? a.xNmuLow : a.xNmuUp;
@@ -284,7 +287,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         else if (bc == LWHIP_BC_CALLABLE)
         {
             // :930-938: the prescribed intensity of the plane the ray starts from
-            const int la = a.la0 + solve / a.nRayCycle;
+            const int la = a.la0 + laIdx;
             const int muIdx = (toObs ? a.zIdxLow : a.zIdxUp)[ray];
             const int Nmu = toObs ? a.zNmuLow : a.zNmuUp;
             src = (toObs ? a.zbcLow : a.zbcUp)[((size_t)la * Nmu + muIdx) * Nx + j];
@@ -503,7 +506,9 @@ hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
     const int Ns = a.Nx * a.Nz;
     if (a.nSolve != nSolve || nSolve % a.nRayCycle != 0)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fs2d_coef_kernel, dim3(((Ns + 255) / 256) * nSolve), dim3(256), 0, stream, a);
+    if (a.rNx != 1.0f / (float)a.Nx || Ns >= (1 << 23))
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fs2d_coef_kernel, dim3(nSolve / a.nRayCycle, a.nRayCycle, (Ns + 255) / 256), dim3(256), 0, stream, a);
     const size_t lds = ((size_t)a.Nx + 1) * sizeof(double);
     const int D = (a.Nx + 63) / 64;
     if (D <= 1)
@@ -568,6 +573,7 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
     };
     Fs2dArgs a{};
     a.Nx = g->Nx;
+    a.rNx = 1.0f / (float)g->Nx;
     a.Nz = g->Nz;
     a.Nrays = g->Nrays;
     a.zLowerBc = g->zLowerBc;

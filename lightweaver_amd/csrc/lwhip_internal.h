@@ -417,6 +417,7 @@ struct Fs2dArgs
     int32_t Nx, Nz, Nrays, zLowerBc, zUpperBc;
     int32_t nSolve;        // number of solves of the launch, a multiple of nRayCycle
     int32_t nRayCycle;     // problem p solves ray rays[p % nRayCycle] at wavelength wavs[p / nRayCycle]
+    float rNx;             // 1.0f / Nx (the point -> plane division of pass 1)
     double wav;            // used when wavs is null
     const double* wavs;
     const double* mux;
