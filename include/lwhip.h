@@ -403,6 +403,10 @@ void lwhip_batch_destroy(lwhip_batch* batch);
 int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* batch, int lambdaIterate, double crsw,
                                           lwhip_iter_result* results /* [n] or NULL: nothing is read back */);
 int lwhip_batch_stat_equil(lwhip_batch* batch);
+/* lwhip_compute_profiles of every column, all their lines in one launch pair on the batch's stream (a launch pair per
+ * line and column leaves the device empty: 7 680 pairs for 512 columns of 15 lines).  Columns whose atmosphere is
+ * uploaded later (LWHIP_ATMOS) are brought up to date the same way by the next lwhip_batch_formal_sol_gamma_matrices. */
+int lwhip_batch_compute_profiles(lwhip_batch* batch);
 
 /* The intersection table of an x-periodic grid: build_intersection_list (Source/FormalScalar2d.cpp:1188-1327) with
  * dw_intersection_2d (:60-105), uw_intersection_2d (:107-152), uw_intersection_2d_frac_x (:166-206).  Host-side

@@ -150,6 +150,7 @@ SYMBOLS = [
     ('lwhip_batch_destroy', None, [C.c_void_p]),
     ('lwhip_batch_formal_sol_gamma_matrices', C.c_int, [C.c_void_p, C.c_int, C.c_double, C.POINTER(lwhip_iter_result)]),
     ('lwhip_batch_stat_equil', C.c_int, [C.c_void_p]),
+    ('lwhip_batch_compute_profiles', C.c_int, [C.c_void_p]),
     ('lwhip_build_intersections', C.c_int, [C.POINTER(lwhip_grid2d), C.POINTER(lwhip_intersection),
                                              C.POINTER(lwhip_intersection), i32p, i32p, C.c_int32,
                                              C.POINTER(lwhip_intersection), C.c_int64, C.POINTER(C.c_int32),

@@ -38,9 +38,6 @@ class ColumnBatch:
         else:
             self.contexts = [Context(p, device=device, stream=stream, batchHint=len(self.problems) if fused else 0)
                              for p in self.problems]
-        if device_profiles:
-            for c in self.contexts:
-                c.compute_profiles(deviceResident=True)
         if fused and not streams and self.contexts:
             import ctypes as C
             lib = self.contexts[0].lib
@@ -48,9 +45,22 @@ class ColumnBatch:
             h = C.c_void_p()
             if lib.lwhip_batch_create(arr, len(self.contexts), C.byref(h)) == abi.OK:
                 self._batch = h
+        if device_profiles:
+            self.compute_profiles()
 
     def __len__(self):
         return len(self.contexts)
+
+    def compute_profiles(self):
+        """phi / wphi of every line of every column on the device (lwhip_batch_compute_profiles: one launch pair for
+        the whole batch; per column where the batch is not fused).  After an atmosphere upload the next iteration
+        does this by itself for the columns concerned."""
+        if self._batch is not None:
+            lib = self.contexts[0].lib
+            _check(lib, lib.lwhip_batch_compute_profiles(self._batch), 'lwhip_batch_compute_profiles')
+            return
+        for c in self.contexts:
+            c.compute_profiles(deviceResident=True)
 
     def close(self):
         if self._batch is not None:

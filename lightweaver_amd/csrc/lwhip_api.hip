@@ -143,6 +143,7 @@ struct lwhip_context
     // line profiles generated on the device (lwhip_compute_profiles): re-derived before the next sweep whenever the
     // inputs they depend on (vlosMu: LWHIP_ATMOS; vBroad, aDamp: LWHIP_NSTAR) are uploaded again
     bool deviceProfiles = false, profilesStale = false;
+    DevBuf<VoigtLineArgs> voigtList; // the lines' argument blocks of lwhip_compute_profiles
     DevBuf<double> wphiScratch;   // [16, Ns] wavelength-slice sums of the profile normalisation
     DevBuf<int> wphiTicket;       // arrival counters of its point tiles
     bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
@@ -1408,11 +1409,11 @@ int build_tile_args(lwhip_context* c)
 }
 
 // the tile-blocked copy of the line profiles follows every change of phi
-int retile_profiles(lwhip_context* c)
+static bool retile_args(lwhip_context* c, RetileArgs& r)
 {
     if (!c->tiled || c->Nline == 0)
-        return LWHIP_OK;
-    RetileArgs r{};
+        return false;
+    r = RetileArgs{};
     r.Ns = c->Ns;
     r.Nmu = c->Nrays;
     r.L = c->tileL;
@@ -1422,7 +1423,14 @@ int retile_profiles(lwhip_context* c)
     r.trans = c->dtrans.p;
     r.phi = c->phi.p;
     r.phiT = c->phiT.p;
-    HIP_TRY(launch_retile(r, c->stream));
+    return true;
+}
+
+int retile_profiles(lwhip_context* c)
+{
+    RetileArgs r;
+    if (retile_args(c, r))
+        HIP_TRY(launch_retile(r, c->stream));
     return LWHIP_OK;
 }
 
@@ -2262,7 +2270,70 @@ struct lwhip_batch
     DevBuf<StatEqArgs> seList; // stat_equil of all active atoms of every column
     StatEqArgs se0{};
     int seMaxNl = 0;
+    DevBuf<VoigtLineArgs> voigtList; // lines of the columns whose profiles are being recomputed
+    DevBuf<RetileArgs> retileList;   // ... and their retile arguments
 };
+
+static int voigt_line_list(lwhip_context* c, std::vector<VoigtLineArgs>& out);
+
+// device profiles of the batch's columns: every line of every column that needs them (all = the explicit
+// lwhip_batch_compute_profiles, else those whose atmosphere was uploaded since) in ONE launch pair on the batch's stream
+static int batch_compute_profiles(lwhip_batch* b, bool all)
+{
+    std::vector<VoigtLineArgs> list;
+    std::vector<lwhip_context*> todo;
+    for (lwhip_context* c : b->ctxs)
+    {
+        if (!(all || c->profilesStale))
+            continue;
+        const int st = voigt_line_list(c, list);
+        if (st != LWHIP_OK)
+            return st;
+        todo.push_back(c);
+    }
+    if (todo.empty())
+        return LWHIP_OK;
+    lwhip_context* c0 = b->ctxs[0];
+    if (!list.empty())
+    {
+        if (b->voigtList.n < list.size())
+        {
+            HIP_TRY(hipStreamSynchronize(c0->stream)); // nothing may still read the buffer about to be replaced
+            HIP_TRY(b->voigtList.alloc(list.size()));
+        }
+        HIP_TRY(hipMemcpyAsync(b->voigtList.p, list.data(), list.size() * sizeof(VoigtLineArgs), hipMemcpyHostToDevice, c0->stream));
+        // the launch geometry allows 65 535 entries per grid dimension
+        for (size_t off = 0; off < list.size(); off += 32768)
+        {
+            const int cnt = (int)std::min<size_t>(32768, list.size() - off);
+            HIP_TRY(launch_voigt_lines(b->voigtList.p + off, list.data() + off, cnt, c0->stream));
+        }
+    }
+    // ... and their tile-blocked copies, one grid slice per column
+    std::vector<RetileArgs> rl;
+    for (lwhip_context* c : todo)
+    {
+        c->deviceProfiles = true;
+        c->profilesStale = false;
+        RetileArgs r;
+        if (retile_args(c, r))
+            rl.push_back(r);
+    }
+    if (!rl.empty())
+    {
+        if (b->retileList.n < rl.size())
+        {
+            HIP_TRY(hipStreamSynchronize(c0->stream));
+            HIP_TRY(b->retileList.alloc(rl.size()));
+        }
+        HIP_TRY(hipMemcpyAsync(b->retileList.p, rl.data(), rl.size() * sizeof(RetileArgs), hipMemcpyHostToDevice, c0->stream));
+        for (size_t off = 0; off < rl.size(); off += 32768)
+            HIP_TRY(launch_retile_list(b->retileList.p + off, rl.data() + off, (int)std::min<size_t>(32768, rl.size() - off),
+                                       c0->stream));
+    }
+    return LWHIP_OK;
+}
+static int batch_ensure_profiles(lwhip_batch* b) { return batch_compute_profiles(b, false); }
 
 int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
 {
@@ -2401,18 +2472,18 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
     const int n = (int)b->ctxs.size();
     lwhip_context* c0 = b->ctxs[0];
     HIP_TRY(hipSetDevice(c0->device));
+    {
+        // columns whose atmosphere was updated: their phi / wphi first, all their lines in one launch pair
+        const int stp = batch_ensure_profiles(b);
+        if (stp != LWHIP_OK)
+            return stp;
+    }
     // Gamma <- crsw * C of every column is fused into its slice of the apply launch
     for (int i = 0; i < n; ++i)
     {
         lwhip_context* c = b->ctxs[i];
         if (c->partialPending || c->prdPending)
             return fail(LWHIP_ERR_INVALID, "batch iteration while a split iteration of a column is pending");
-        if (c->profilesStale) // a column whose atmosphere was updated: its phi / wphi first, on the batch's stream
-        {
-            const int stp = ensure_profiles(c);
-            if (stp != LWHIP_OK)
-                return stp;
-        }
         c->prefillCrsw = crsw;
         c->prefillPending = c->gammaTot > 0 && c->Cmat.p != nullptr;
         b->aHost[i] = make_apply_args(c);
@@ -2451,6 +2522,14 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
         }
     }
     return LWHIP_OK;
+}
+
+int lwhip_batch_compute_profiles(lwhip_batch* b)
+{
+    if (!b || b->ctxs.empty())
+        return fail(LWHIP_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->ctxs[0]->device));
+    return batch_compute_profiles(b, true);
 }
 
 int lwhip_batch_stat_equil(lwhip_batch* b)
@@ -3279,19 +3358,21 @@ int lwhip_formal_solver_2d(int device, const lwhip_grid2d* grid, double waveleng
     return LWHIP_OK;
 }
 
-// phi and wphi of every line from (aDamp, vBroad, vlosMu) on the device: compute_profile's Voigt loop
-// (Source/LwMiddleLayer.pyx:3244-3288 -> LwTransition.hpp:155-190), one launch pair per line
-static int compute_profiles_impl(lwhip_context* c)
+// the argument blocks of the context's lines (wavelength slices and tickets of their own: the lines run side by side)
+static int voigt_line_list(lwhip_context* c, std::vector<VoigtLineArgs>& out)
 {
     if (!c->prob.vlosMu)
         return fail(LWHIP_ERR_INVALID, "lwhip_compute_profiles needs vlosMu in the descriptor");
     const int slices = 16;
-    if (!c->is2d && c->wphiScratch.n == 0)
+    const size_t tiles = (size_t)(c->Ns + 7) / 8 + 1;
+    const size_t nLine = (size_t)std::max(c->Nline, 1);
+    if (!c->is2d && c->wphiScratch.n < nLine * slices * c->Ns)
     {
-        HIP_TRY(c->wphiScratch.alloc((size_t)slices * c->Ns));
-        HIP_TRY(c->wphiTicket.alloc((size_t)(c->Ns + 7) / 8 + 1));
+        HIP_TRY(c->wphiScratch.alloc(nLine * slices * c->Ns));
+        HIP_TRY(c->wphiTicket.alloc(nLine * tiles));
         HIP_TRY(hipMemsetAsync(c->wphiTicket.p, 0, c->wphiTicket.n * sizeof(int), c->stream));
     }
+    size_t q = 0;
     for (int tr = 0; tr < c->Ntrans; ++tr)
     {
         const HostTrans& h = c->trans[tr];
@@ -3314,10 +3395,32 @@ static int compute_profiles_impl(lwhip_context* c)
         a.aDamp = c->aDamp.p + (size_t)h.row * c->Ns;
         a.phi = c->phi.p + (a.nlt > 0 ? h.phiOff : 0);
         a.wphi = c->wphi.p + (size_t)h.row * c->Ns;
-        a.wphiScratch = c->wphiScratch.p;
-        a.wphiTicket = c->wphiTicket.p;
+        a.wphiScratch = c->is2d ? nullptr : c->wphiScratch.p + q * slices * c->Ns;
+        a.wphiTicket = c->is2d ? nullptr : c->wphiTicket.p + q * tiles;
         a.wphiSlices = slices;
-        HIP_TRY(launch_voigt_line(a, c->stream));
+        out.push_back(a);
+        ++q;
+    }
+    return LWHIP_OK;
+}
+
+// phi and wphi of every line from (aDamp, vBroad, vlosMu) on the device: compute_profile's Voigt loop
+// (Source/LwMiddleLayer.pyx:3244-3288 -> LwTransition.hpp:155-190), one launch pair for the context's lines
+static int compute_profiles_impl(lwhip_context* c)
+{
+    std::vector<VoigtLineArgs> list;
+    const int st = voigt_line_list(c, list);
+    if (st != LWHIP_OK)
+        return st;
+    if (list.size() == 1)
+        HIP_TRY(launch_voigt_line(list[0], c->stream));
+    else if (!list.empty())
+    {
+        // (the copy is queued behind the previous launch pair that read the buffer: same stream)
+        if (c->voigtList.n < list.size())
+            HIP_TRY(c->voigtList.alloc(list.size()));
+        HIP_TRY(hipMemcpyAsync(c->voigtList.p, list.data(), list.size() * sizeof(VoigtLineArgs), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_voigt_lines(c->voigtList.p, list.data(), (int)list.size(), c->stream));
     }
     c->deviceProfiles = true;
     c->profilesStale = false;

@@ -260,6 +260,7 @@ hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, 
 hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int nPostChunks,
                             const TileArgs* const* apList, int nBatch, hipStream_t stream);
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
+hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostList, int n, hipStream_t stream);
 
 enum { LWHIP_REDUCE_SPLIT = 8 };
 struct ReduceArgs
@@ -329,6 +330,8 @@ struct VoigtLineArgs
     int32_t wphiSlices, _pad2;
 };
 hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream);
+// every line of the list in one launch pair (same Ns and slice count; hostList = what devList holds)
+hipError_t launch_voigt_lines(const VoigtLineArgs* devList, const VoigtLineArgs* hostList, int nLines, hipStream_t stream);
 
 // One PRD line's scattering integral (lwhip_prd.hip)
 struct PrdLineArgs

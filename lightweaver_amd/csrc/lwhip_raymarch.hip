@@ -1271,8 +1271,12 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
 
 // ---- profiles into the tile layout ------------------------------------------------------------------------------------
 // grid (tile, line slot); phiT[phiOff + (dir * Ns + k) * 64 + mu * L + j] = phi[lt0 + j][mu][dir][k]
-__global__ void __launch_bounds__(256) retile_kernel(const RetileArgs a)
+// (blockIdx.z: the column of a batch, its arguments read from the list)
+__global__ void __launch_bounds__(256) retile_kernel(const RetileArgs a0, const RetileArgs* __restrict__ list)
 {
+    const RetileArgs a = list ? ld_c(CTAB(RetileArgs, list) + blockIdx.z) : a0;
+    if ((int)blockIdx.x >= a.nTiles)
+        return;
     const DevTile td = a.tiles[blockIdx.x];
     if ((int)blockIdx.y >= td.nLine)
         return;
@@ -1299,7 +1303,18 @@ hipError_t launch_retile(const RetileArgs& a, hipStream_t stream)
 {
     if (a.nTiles <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(retile_kernel, dim3(a.nTiles, 8), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(retile_kernel, dim3(a.nTiles, 8), dim3(256), 0, stream, a, (const RetileArgs*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostList, int n, hipStream_t stream)
+{
+    int maxTiles = 0;
+    for (int i = 0; i < n; ++i)
+        maxTiles = std::max(maxTiles, hostList[i].nTiles);
+    if (n <= 0 || maxTiles <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(retile_kernel, dim3(maxTiles, 8, n), dim3(256), 0, stream, hostList[0], devList);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 // |z|, Zaghloul & Ali's Algorithm 916 sums elsewhere.  exp(-a^2 n^2) comes from a table filled on
 // the host; erfcx is the device math library's.
 #include "lwhip_internal.h"
+#include "lwhip_device.h"
 #include "../../include/lwhip.h"
 
 #include <hip/hip_runtime.h>
@@ -174,9 +175,15 @@ __device__ double d_voigt_H(double av, double v)
 
 
 
+// Both kernels take either one line's arguments by value or a device list of lines (every line of a context, or of all
+// the columns of a batch whose atmosphere changed) indexed by the outermost grid dimension: a launch pair per line left
+// the chip empty (11 workgroups) and cost a 512-column batch 7 680 launch pairs per atmosphere update.
+#define LINE_ARGS(dimIdx) (list ? ld_c(CTAB(VoigtLineArgs, list) + (dimIdx)) : a0)
+
 // phi[l, mu, dir, k] for the shard's rows of one line
-__global__ void voigt_phi_kernel(VoigtLineArgs a)
+__global__ void voigt_phi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* __restrict__ list)
 {
+    const VoigtLineArgs a = LINE_ARGS(blockIdx.y);
     const double sqrtPi = 1.772453850905516027298167483341145182798;
     const size_t n = (size_t)a.nlt * a.Nrays * 2 * a.Ns;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n;
@@ -200,16 +207,20 @@ __global__ void voigt_phi_kernel(VoigtLineArgs a)
 // the wavelength shard).  Workgroup (x, y) owns KT consecutive points (all of them in 1D; tiles of a 2D domain) and the
 // wavelengths of slice y: thread (part, k) sums la = y*P + part, + P*gridDim.y, ...; the workgroup's parts are combined
 // in order into scratch[y][k], and the last workgroup of a point tile to arrive (ticket) adds the slices in order.
-__global__ void voigt_wphi_kernel(VoigtLineArgs a, int KT)
+// Where the context holds the whole line (no wavelength shard) the profile just written by voigt_phi_kernel is read
+// back instead of being evaluated a second time (the same bits: same function, same arguments).
+__global__ void voigt_wphi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* __restrict__ list, int KT)
 {
     extern __shared__ double sPart[];
     __shared__ int sLast;
+    const VoigtLineArgs a = LINE_ARGS(blockIdx.z);
     const double sqrtPi = 1.772453850905516027298167483341145182798;
     const int P = blockDim.x / KT;
     const int part = threadIdx.x / KT;
     const int kl = threadIdx.x - part * KT;
     const int k = blockIdx.x * KT + kl;
     const int PB = gridDim.y;
+    const bool havePhi = a.nlt == a.nltFull && a.ltStart == 0;
     double acc = 0.0;
     if (part < P && k < a.Ns)
     {
@@ -225,8 +236,15 @@ __global__ void voigt_wphi_kernel(VoigtLineArgs a, int KT)
                 const double vl = a.vlosMu[(size_t)mu * a.Ns + k];
                 for (int d = 0; d < 2; ++d)
                 {
-                    const double vk = (vBase + (d ? vl : -vl)) / vb;
-                    acc += (d_voigt_H(ad, vk) / (sqrtPi * vb)) * wlamu;
+                    double ph;
+                    if (havePhi)
+                        ph = a.phi[(((size_t)la * a.Nrays + mu) * 2 + d) * a.Ns + k];
+                    else
+                    {
+                        const double vk = (vBase + (d ? vl : -vl)) / vb;
+                        ph = d_voigt_H(ad, vk) / (sqrtPi * vb);
+                    }
+                    acc += ph * wlamu;
                 }
             }
         }
@@ -266,6 +284,7 @@ __global__ void voigt_wphi_kernel(VoigtLineArgs a, int KT)
         a.wphi[k] = 1.0 / s;
     }
 }
+#undef LINE_ARGS
 
 hipError_t voigt_init_tables()
 {
@@ -286,31 +305,58 @@ hipError_t voigt_init_tables()
     return e;
 }
 
-hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream)
+// The launch shape is common to the lines of a launch: point tiles of KT, P = 1024 / KT wavelength parts per workgroup
+// (parts beyond a short line's grid add nothing), PB wavelength slices from the longest line.
+static hipError_t launch_voigt(const VoigtLineArgs& a0, const VoigtLineArgs* list, int nLines, int Ns, size_t maxPhi,
+                               int maxNltFull, bool sliced, int slices, hipStream_t stream)
 {
     hipError_t e = voigt_init_tables();
     if (e != hipSuccess)
         return e;
-    const size_t n = (size_t)a.nlt * a.Nrays * 2 * a.Ns;
-    if (n > 0)
+    if (nLines <= 0)
+        return hipSuccess;
+    if (maxPhi > 0)
     {
-        const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(voigt_phi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        const int blocks = (int)std::min<size_t>((maxPhi + 255) / 256, 4096);
+        hipLaunchKernelGGL(voigt_phi_kernel, dim3(blocks, nLines), dim3(256), 0, stream, a0, list);
     }
     // tiles of 8 points (1D columns: ~10 point tiles, each with up to 128 partial sums over a slice of the line's
     // wavelengths) or 64 (2D domains, which bring enough tiles); wavelength slices so that a thread sums ~2 wavelengths
-    const int KT = a.Ns <= 1024 ? 8 : 64;
-    int P = 1024 / KT;
-    if (P < 1)
-        P = 1;
-    if (P > a.nltFull)
-        P = a.nltFull;
+    const int KT = Ns <= 1024 ? 8 : 64;
+    const int P = std::max(1, std::min(1024 / KT, maxNltFull));
+    // (slices only while the launch is small: the ticket costs every workgroup two device-scope fences, which with
+    // the 170 000 workgroups of a 512-column batch was all of the kernel's 150 ms)
     int PB = 1;
-    if (a.wphiScratch && a.wphiTicket && a.Ns <= 1024)
-        PB = std::max(1, std::min(a.wphiSlices, (a.nltFull + 2 * P - 1) / (2 * P)));
+    if (sliced && Ns <= 1024 && (size_t)nLines * ((Ns + KT - 1) / KT) <= 1024)
+        PB = std::max(1, std::min(slices, (maxNltFull + 2 * P - 1) / (2 * P)));
     const int T = ((P * KT + 63) / 64) * 64;
-    hipLaunchKernelGGL(voigt_wphi_kernel, dim3((a.Ns + KT - 1) / KT, PB), dim3(T), (size_t)P * KT * sizeof(double), stream, a,
-                       KT);
+    hipLaunchKernelGGL(voigt_wphi_kernel, dim3((Ns + KT - 1) / KT, PB, nLines), dim3(T), (size_t)P * KT * sizeof(double), stream,
+                       a0, list, KT);
     return hipGetLastError();
+}
+
+hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream)
+{
+    return launch_voigt(a, nullptr, 1, a.Ns, (size_t)a.nlt * a.Nrays * 2 * a.Ns, a.nltFull, a.wphiScratch && a.wphiTicket,
+                        a.wphiSlices, stream);
+}
+
+hipError_t launch_voigt_lines(const VoigtLineArgs* devList, const VoigtLineArgs* hostList, int nLines, hipStream_t stream)
+{
+    if (nLines <= 0)
+        return hipSuccess;
+    size_t maxPhi = 0;
+    int maxFull = 1;
+    bool sliced = true;
+    for (int i = 0; i < nLines; ++i)
+    {
+        const VoigtLineArgs& a = hostList[i];
+        if (a.Ns != hostList[0].Ns || a.wphiSlices != hostList[0].wphiSlices)
+            return hipErrorInvalidValue;
+        maxPhi = std::max(maxPhi, (size_t)a.nlt * a.Nrays * 2 * a.Ns);
+        maxFull = std::max(maxFull, a.nltFull);
+        sliced = sliced && a.wphiScratch && a.wphiTicket;
+    }
+    return launch_voigt(hostList[0], devList, nLines, hostList[0].Ns, maxPhi, maxFull, sliced, hostList[0].wphiSlices, stream);
 }
 }
