@@ -96,7 +96,7 @@ hipError_t launch_cont_range(const ContArgs* devArgs, const ContArgs& a, int con
         if (err != hipSuccess)
             return err;
     }
-    const int ky = std::max(1, std::min(64, (a.Ns + T - 1) / T));
+    const int ky = std::max(1, std::min(256, (a.Ns + T - 1) / T));
     hipLaunchKernelGGL(cont_kernel, dim3(nCont, ky), dim3(T), lds, stream, devArgs, contOff, rowsBase);
     return hipGetLastError();
 }
@@ -104,53 +104,96 @@ hipError_t launch_cont_range(const ContArgs* devArgs, const ContArgs& a, int con
 
 namespace
 {
-// ---- gather: Transition::uv + chi_eta_aux_accum + compute_source_fn for one (wavelength, ray, point) ----------
+// ---- gather: Transition::uv + chi_eta_aux_accum + compute_source_fn for one (wavelength, point), ray by ray --------
+// Everything but the line profile is the same for all rays of the wavelength -- the continuum rows, the populations,
+// rho, the scattering term -- and is fetched once; the rays go four at a time so that their profile loads are in
+// flight together (the stores of a ray keep the compiler from hoisting the next ray's loads).
+template <int MAXL>
 __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.Ns)
         return;
-    const int r = blockIdx.y;
-    const int b = blockIdx.z;
+    const int b = blockIdx.y;
     const int la = a.la0 + b;
     const int Ns = a.Ns;
     // the activity tables are read through the constant address space: scalar loads (a generic pointer next to the
     // kernel's stores would be read with vector loads even at uniform addresses)
-    const int ray = CTAB(int32_t, a.rayList)[r];
     const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + la);
     const CONST_AS DevSlot* slots = CTAB(DevSlot, a.slots) + h.off;
     const size_t laNs = (size_t)la * Ns;
-    double chi, eta;
+    double chi0, eta0;
     if (h.rowBase >= 0)
     {
-        chi = a.rows[(size_t)h.rowBase * Ns + k];
-        eta = a.rows[((size_t)h.rowBase + 1) * Ns + k];
+        chi0 = a.rows[(size_t)h.rowBase * Ns + k];
+        eta0 = a.rows[((size_t)h.rowBase + 1) * Ns + k];
     }
     else
     {
-        chi = a.bgChi[laNs + k];
-        eta = a.bgEta[laNs + k];
+        chi0 = a.bgChi[laNs + k];
+        eta0 = a.bgEta[laNs + k];
     }
-    for (int l = 0; l < h.nLine; ++l)
+    const double sca = a.bgSca[laNs + k] * a.J[laNs + k];
+    double lV[MAXL], lG[MAXL], lNi[MAXL], lNj[MAXL], lU[MAXL];
+    size_t lOff[MAXL];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l)
     {
-        const CONST_AS DevSlot& sl = slots[l];
-        const double vij = sl.p[0] * a.phi[sl.phiOff + (size_t)ray * Ns + k];
-        double g = sl.p[2];
-        if (sl.flags & 2)
-            g *= a.rho[sl.rhoOff + k];
-        const double vji = g * vij;
-        const double nj = a.n[(size_t)sl.gj * Ns + k];
-        chi += a.n[(size_t)sl.gi * Ns + k] * vij - nj * vji;
-        eta += nj * (sl.p[3] * vji);
+        lV[l] = lG[l] = lNi[l] = lNj[l] = lU[l] = 0.0;
+        lOff[l] = 0;
+        if (l < h.nLine)
+        {
+            const CONST_AS DevSlot& sl = slots[l];
+            double g = sl.p[2];
+            if (sl.flags & 2)
+                g *= a.rho[sl.rhoOff + k];
+            lV[l] = sl.p[0];
+            lG[l] = g;
+            lU[l] = sl.p[3];
+            lNi[l] = a.n[(size_t)sl.gi * Ns + k];
+            lNj[l] = a.n[(size_t)sl.gj * Ns + k];
+            lOff[l] = sl.phiOff + k;
+        }
     }
-    const size_t o = ((size_t)b * a.nRaysActive + r) * Ns + k;
-    a.chi[o] = chi;
-    a.S[o] = (eta + a.bgSca[laNs + k] * a.J[laNs + k]) / chi;
-    if (a.storeDepth)
+    constexpr int RB = 4;
+    const int nR = a.nRaysActive;
+    for (int r0 = 0; r0 < nR; r0 += RB)
     {
-        const size_t d = ((size_t)la * a.Nrays * 2 + ray) * Ns + k;
-        a.depthChi[d] = chi;
-        a.depthEta[d] = eta;
+        double ph[RB][MAXL];
+        int rayOf[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+        {
+            rayOf[q] = CTAB(int32_t, a.rayList)[min(r0 + q, nR - 1)];
+#pragma unroll
+            for (int l = 0; l < MAXL; ++l)
+                ph[q][l] = (l < h.nLine) ? a.phi[lOff[l] + (size_t)rayOf[q] * Ns] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+        {
+            if (r0 + q >= nR)
+                break;
+            double chi = chi0, eta = eta0;
+#pragma unroll
+            for (int l = 0; l < MAXL; ++l)
+                if (l < h.nLine)
+                {
+                    const double vij = lV[l] * ph[q][l];
+                    const double vji = lG[l] * vij;
+                    chi += lNi[l] * vij - lNj[l] * vji;
+                    eta += lNj[l] * (lU[l] * vji);
+                }
+            const size_t o = ((size_t)b * nR + (r0 + q)) * Ns + k;
+            a.chi[o] = chi;
+            a.S[o] = (eta + sca) / chi;
+            if (a.storeDepth)
+            {
+                const size_t d = ((size_t)la * a.Nrays * 2 + rayOf[q]) * Ns + k;
+                a.depthChi[d] = chi;
+                a.depthEta[d] = eta;
+            }
+        }
     }
 }
 
@@ -511,9 +554,15 @@ hipError_t launch_sum_groups(double* red, size_t n, size_t stride, int G, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_gather2d(const Batch2dArgs& a, hipStream_t stream)
+hipError_t launch_gather2d(const Batch2dArgs& a, int maxL, hipStream_t stream)
 {
-    hipLaunchKernelGGL(gather2d_kernel, dim3((a.Ns + 255) / 256, a.nRaysActive, a.nLa), dim3(256), 0, stream, a);
+    const dim3 grid((a.Ns + 255) / 256, a.nLa);
+    if (maxL <= 2)
+        hipLaunchKernelGGL(gather2d_kernel<2>, grid, dim3(256), 0, stream, a);
+    else if (maxL <= 4)
+        hipLaunchKernelGGL(gather2d_kernel<4>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(gather2d_kernel<8>, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -2010,7 +2010,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
         a.la0 = la0;
         a.nLa = nLa;
         a.rows = rowsBase;
-        HIP_TRY(launch_gather2d(a, c->stream));
+        HIP_TRY(launch_gather2d(a, c->maxL, c->stream));
         f.wavs = c->wavelength.p + la0;
         f.la0 = la0;
         f.nSolve = nLa * nRaysActive;
