@@ -1242,10 +1242,11 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(upv(c->g2long, g.longCharIdx, nSt));
         HIP_TRY(upv(c->g2subOff, g.substepOff, (size_t)g.NlongChar + 1));
         HIP_TRY(upv(c->g2sub, g.substeps, (size_t)g.substepOff[g.NlongChar]));
-        // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~2 GB.  Every kernel of a batch is
-        // latency-bound per workgroup (82 sequential planes in fs2d), so the batch should fill the chip.
-        const size_t perLa = (size_t)2 * Nr * Ns * (8 * sizeof(double) + sizeof(int32_t)); // + fs2d's point maps
-        const size_t budget = (size_t)env_int("LWHIP_BATCH2D_MB", 2048) << 20;
+        // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~8 GB of the 288.  Every kernel of a batch is
+        // latency-bound per workgroup (82 sequential planes in fs2d), so the batch should fill the chip, and fewer,
+        // larger batches mean fewer kernel tails (256 x 82 x 268 wavelengths: one batch of 3 GB, 0.1 ms less than two).
+        const size_t perLa = (size_t)2 * Nr * Ns * (7 * sizeof(double) + sizeof(int32_t)); // + fs2d's point maps
+        const size_t budget = (size_t)env_int("LWHIP_BATCH2D_MB", 8192) << 20;
         c->batch2d = (int)std::max<size_t>(1, std::min<size_t>(budget / perLa, Nla));
         c->batch2d = std::max(1, env_int("LWHIP_BATCH2D", c->batch2d));
         // rates2d: one thread per point per wavelength group; enough groups for ~2 wavefronts per SIMD
@@ -1257,7 +1258,7 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(c->b2S.alloc(nb));
         HIP_TRY(c->b2I.alloc(nb));
         HIP_TRY(c->b2Psi.alloc(nb));
-        HIP_TRY(c->b2coef.alloc(4 * nb));
+        HIP_TRY(c->b2coef.alloc(3 * nb));
         HIP_TRY(c->b2idx.alloc(nb));
         for (size_t la = 0; la < Nla; ++la)
             if (c->hdrHost[la].rowBase >= 0)

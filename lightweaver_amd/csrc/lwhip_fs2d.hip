@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     const double* chi = a.chi + (size_t)solve * Ns;
     const double* S = a.S + (size_t)solve * Ns;
     double* Ps = a.PsiStar + (size_t)solve * Ns;
-    double* cf = a.coef + (size_t)solve * 4 * Ns + (size_t)k * Nx + p;
+    double* cf = a.coef + (size_t)solve * 3 * Ns + (size_t)k * Nx + p;
     int32_t* ci = a.cidx + (size_t)solve * Ns + (size_t)k * Nx + p;
     const size_t o = (size_t)k * Nx + j;
     double A = 0.0, c1 = 0.0, c2 = 0.0, src = 0.0, psi = 0.0;
@@ -255,8 +255,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         src = (low ? a.xbcLow : a.xbcUp)[((size_t)la * Nmu + muIdx) * Nz + k];
         cf[0] = 0.0;
         cf[(size_t)Ns] = 0.0;
-        cf[(size_t)2 * Ns] = 0.0;
-        cf[(size_t)3 * Ns] = src;
+        cf[(size_t)2 * Ns] = src;
         *ci = 0;
         Ps[o] = 0.0;
         return;
@@ -294,8 +293,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         }
         cf[0] = 0.0;
         cf[(size_t)Ns] = 0.0;
-        cf[(size_t)2 * Ns] = 0.0;
-        cf[(size_t)3 * Ns] = src;
+        cf[(size_t)2 * Ns] = src;
         *ci = 0;
         Ps[o] = 0.0;
         return;
@@ -373,11 +371,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         f2_hit_weights(a.substeps[a.substepOff[lc]], Nx, kPrev, e * Ecum, c1, c2, idx);
         src = e * acc + src;
     }
-    cf[0] = A;
+    // A (weight of this plane's previous column: hits on an x face) and c2 (second point of a hit on a z plane) are
+    // never both non-zero: one plane holds whichever applies, bit 0 of the index word says which
+    const bool faceHit = (lc < 0) && uw.axis == 2;
+    cf[0] = faceHit ? A : c2;
     cf[(size_t)Ns] = c1;
-    cf[(size_t)2 * Ns] = c2;
-    cf[(size_t)3 * Ns] = src;
-    *ci = idx;
+    cf[(size_t)2 * Ns] = src;
+    *ci = idx * 2 + (faceHit ? 1 : 0);
     Ps[o] = psi * d_rcp(chiL);
 }
 
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
     const bool rev = mux < 0;
     const int lane = threadIdx.x;
     const int p0 = lane * D;
-    const double* cf = a.coef + (size_t)solve * 4 * Ns;
+    const double* cf = a.coef + (size_t)solve * 3 * Ns;
     const int32_t* ci = a.cidx + (size_t)solve * Ns;
     double* I = a.I + (size_t)solve * Ns;
 
@@ -420,11 +420,13 @@ __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
             const int p = p0 + d;
             const bool on = FULL || p < Nx;
             const size_t q = row + (on ? p : 0);
-            m.A[d] = on ? cf[q] : 1.0;             // identity beyond the row
+            const double X = on ? cf[q] : 1.0;     // identity beyond the row
+            const int w = on ? ci[q] : 1;
+            m.A[d] = (w & 1) ? X : 0.0;
+            m.C2[d] = (w & 1) ? 0.0 : X;
             m.C1[d] = on ? cf[Ns + q] : 0.0;
-            m.C2[d] = on ? cf[2 * Ns + q] : 0.0;
-            m.S[d] = on ? cf[3 * Ns + q] : 0.0;
-            m.ix[d] = on ? ci[q] : 0;
+            m.S[d] = on ? cf[2 * Ns + q] : 0.0;
+            m.ix[d] = w >> 1;
         }
     };
     // two planes ahead: a wavefront is alone on its SIMD, the loads of a plane take longer than its arithmetic
@@ -607,7 +609,7 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
     allocs.push_back(a.I);
     F2_TRY(hipMalloc((void**)&a.PsiStar, (size_t)nSolve * Ns * sizeof(double)));
     allocs.push_back(a.PsiStar);
-    F2_TRY(hipMalloc((void**)&a.coef, (size_t)nSolve * 4 * Ns * sizeof(double)));
+    F2_TRY(hipMalloc((void**)&a.coef, (size_t)nSolve * 3 * Ns * sizeof(double)));
     allocs.push_back(a.coef);
     F2_TRY(hipMalloc((void**)&a.cidx, (size_t)nSolve * Ns * sizeof(int32_t)));
     allocs.push_back(a.cidx);
