@@ -11,7 +11,7 @@
 //   fs2d_scan_kernel   one wavefront per solve: planes in sequence, a DPP scan of the maps per plane
 // The first column of a shallow ray is the periodic long characteristic, whose sub-steps reach back to the
 // previous plane and never read the plane in progress, so its a is 0 and the recurrence has a known start.
-// fp64; HBM traffic per point and solve: chi, S read (neighbours through L1/L2), the 36 B map written and read,
+// fp64; HBM traffic per point and solve: chi, S read (neighbours through L1/L2), the 28 B map written and read,
 // I, Psi* written once; the intersection table (64 B per point) is shared by all wavelengths of a tile.
 #include "lwhip_device.h"
 #include "../../include/lwhip.h"
