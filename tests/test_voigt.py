@@ -220,3 +220,43 @@ def test_profiles_follow_atmosphere_updates(gpu, batched):
     dJref = _oracle_run(q, 2)
     assert dJ == pytest.approx(dJref, rel=1e-7)
     _assert_column_matches(probs[j], q)
+
+
+@pytest.mark.gpu
+def test_batch_profiles_in_one_launch_match_per_line_launches(gpu):
+    """lwhip_batch_compute_profiles (every line of every column through the device list of the Voigt / wphi / retile
+    kernels) against lwhip_compute_profiles of each column alone and against the oracle: phi bit for bit (the same
+    function of the same arguments), wphi to 1e-13 (its wavelength partial sums are grouped by launch shape)."""
+    from lightweaver_amd.batch import ColumnBatch
+    from lightweaver_amd.context import Context
+    from lightweaver_amd.harness import models
+    base = models.falc82()
+    mk = lambda seed: models.falc_h_ca(Nrays=3, lineScale=0.4, atmos=models.perturbed(base, seed=seed, dv=2.0e3),
+                                       computeProfiles=False)
+    seeds = [11, 12, 13, 14, 15]
+    batchProbs, soloProbs = [mk(s) for s in seeds], [mk(s) for s in seeds]
+    with ColumnBatch(batchProbs) as batch:
+        assert batch._batch is not None
+        batch.compute_profiles()        # a second time: the tickets / lists are reusable
+        ups = batch.formal_sol_gamma_matrices()
+        for c in batch.contexts:
+            c.download(abi.PROFILES | abi.ALL_OUTPUTS)
+    for p, u in zip(soloProbs, ups):
+        with Context(p) as ctx:
+            ctx.compute_profiles(deviceResident=True)
+            v = ctx.formal_sol_gamma_matrices(deviceResident=True)
+            ctx.download(abi.PROFILES | abi.ALL_OUTPUTS)
+        assert u.dJMax == pytest.approx(v.dJMax, rel=1e-11)
+    q = mk(seeds[2])
+    OracleContext(q).compute_profiles()
+    for p, s in zip(batchProbs, soloProbs):
+        for a, b in zip(p.atoms, s.atoms):
+            for t, u in zip(a.trans, b.trans):
+                if t.type == abi.LINE:
+                    np.testing.assert_array_equal(t.phi, u.phi)
+                    assert rel_err(t.wphi, u.wphi) <= 1e-13
+        assert rel_err(p.J, s.J) <= 1e-11
+    for a, b in zip(batchProbs[2].atoms, q.atoms):
+        for t, u in zip(a.trans, b.trans):
+            if t.type == abi.LINE:
+                assert rel_err(t.phi, u.phi) <= 1e-12 and rel_err(t.wphi, u.wphi) <= 1e-12
