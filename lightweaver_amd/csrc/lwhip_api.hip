@@ -155,7 +155,8 @@ struct lwhip_context
     double* zDownHost = nullptr;       // their host arrays [Nlambda, Nrays, Nx]
     double* zUpHost = nullptr;
     DevBuf<int32_t> xIdxLow, xIdxUp;   // [Nrays, 2]
-    DevBuf<int32_t> g2long, g2subOff, slotTrD;
+    DevBuf<int32_t> g2long, g2subOff, slotTrD, g2lcOwner;
+    DevBuf<double> b2lc; // [batch2d][NlongChar][3]
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
     std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
     int64_t prdRowsTot = 0;
@@ -1242,6 +1243,25 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(upv(c->g2long, g.longCharIdx, nSt));
         HIP_TRY(upv(c->g2subOff, g.substepOff, (size_t)g.NlongChar + 1));
         HIP_TRY(upv(c->g2sub, g.substeps, (size_t)g.substepOff[g.NlongChar]));
+        if (g.NlongChar > 0)
+        {
+            // who owns each long characteristic: (ray, point)
+            std::vector<int32_t> owner((size_t)2 * g.NlongChar, -1);
+            for (size_t i = 0; i < nSt; ++i)
+            {
+                const int lc = g.longCharIdx[i];
+                if (lc < 0)
+                    continue;
+                if (lc >= g.NlongChar)
+                    return fail(LWHIP_ERR_INVALID, "grid2d: longCharIdx out of range");
+                owner[2 * (size_t)lc] = (int32_t)(i / Ns);
+                owner[2 * (size_t)lc + 1] = (int32_t)(i % Ns);
+            }
+            for (int lc = 0; lc < g.NlongChar; ++lc)
+                if (owner[2 * (size_t)lc] < 0)
+                    return fail(LWHIP_ERR_INVALID, "grid2d: a long characteristic belongs to no point");
+            HIP_TRY(c->g2lcOwner.upload(owner));
+        }
         // wavelengths per batch: per-ray chi, S, I, Psi* of a batch within ~8 GB of the 288.  Every kernel of a batch is
         // latency-bound per workgroup (82 sequential planes in fs2d), so the batch should fill the chip, and fewer,
         // larger batches mean fewer kernel tails (256 x 82 x 268 wavelengths: one batch of 3 GB, 0.1 ms less than two).
@@ -1260,6 +1280,8 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(c->b2Psi.alloc(nb));
         HIP_TRY(c->b2coef.alloc(3 * nb));
         HIP_TRY(c->b2idx.alloc(nb));
+        if (g.NlongChar > 0)
+            HIP_TRY(c->b2lc.alloc((size_t)c->batch2d * g.NlongChar * 3));
         for (size_t la = 0; la < Nla; ++la)
             if (c->hdrHost[la].rowBase >= 0)
                 c->maxRowsLa = std::max(c->maxRowsLa, c->hdrHost[la].nRows + c->hdrHost[la].nMixed + c->hdrHost[la].nPure);
@@ -1978,6 +2000,10 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     f.longCharIdx = c->g2long.p;
     f.substepOff = c->g2subOff.p;
     f.substeps = c->g2sub.p;
+    f.NlongChar = g.NlongChar;
+    f.lcOwner = c->g2lcOwner.p;
+    f.lcBuf = g.NlongChar > 0 ? c->b2lc.p : nullptr;
+    f.lcUpOnly = (mode == 2) ? 1 : 0;
     f.rays = rayList;
     f.chi = c->b2chi.p;
     f.S = c->b2S.p;

@@ -343,7 +343,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     else
     {
         double chiC, Ecum, acc;
-        f2_long_char(a, lc, chi, S, chiL, SL, Ecum, acc, chiC);
+        if (a.lcBuf)
+        {
+            const double* r = a.lcBuf + ((size_t)laIdx * a.NlongChar + lc) * 3;
+            Ecum = r[0];
+            acc = r[1];
+            chiC = r[2];
+        }
+        else
+            f2_long_char(a, lc, chi, S, chiL, SL, Ecum, acc, chiC);
         const lwhip_intersection st = a.substeps[a.substepOff[lc + 1] - 1]; // = the upwind hit
         const F2Loc ls = f2_loc(st, Nx);
         const double chiUw = f2_at(ls, chi);
@@ -379,6 +387,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     cf[(size_t)2 * Ns] = src;
     *ci = idx * 2 + (faceHit ? 1 : 0);
     Ps[o] = psi * d_rcp(chiL);
+}
+
+// Pass 0: the long characteristics, one thread per (wavelength, characteristic).  Inside pass 1 each of them sits alone
+// in a wavefront of short steps (one lane walking 2 ... 16 BESSER sub-steps while 63 wait: 12 % of the wavefronts of
+// the 256 x 82 grid took ~5 times as long as the rest); here they are packed 64 to a wavefront.
+__global__ void __launch_bounds__(64) fs2d_longchar_kernel(const Fs2dArgs a)
+{
+    const int lc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= a.NlongChar)
+        return;
+    const int laIdx = blockIdx.y;
+    const int ray = a.lcOwner[2 * lc], o = a.lcOwner[2 * lc + 1];
+    const int rayIdx = a.lcUpOnly ? ((ray & 1) ? (ray >> 1) : -1) : ray;
+    if (rayIdx < 0 || rayIdx >= a.nRayCycle)
+        return;
+    const size_t Ns = (size_t)a.Nx * a.Nz;
+    const int solve = laIdx * a.nRayCycle + rayIdx;
+    const double* chi = a.chi + (size_t)solve * Ns;
+    const double* S = a.S + (size_t)solve * Ns;
+    double Ecum, acc, chiC;
+    f2_long_char(a, lc, chi, S, chi[o], S[o], Ecum, acc, chiC);
+    double* r = a.lcBuf + ((size_t)laIdx * a.NlongChar + lc) * 3;
+    r[0] = Ecum;
+    r[1] = acc;
+    r[2] = chiC;
 }
 
 // Pass 2, one wavefront per solve: the planes in sequence, each lane D consecutive columns of the processing
@@ -510,6 +543,8 @@ hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
         return hipErrorInvalidValue;
     if (a.rNx != 1.0f / (float)a.Nx || Ns >= (1 << 23))
         return hipErrorInvalidValue;
+    if (a.lcBuf && a.NlongChar > 0)
+        hipLaunchKernelGGL(fs2d_longchar_kernel, dim3((a.NlongChar + 63) / 64, nSolve / a.nRayCycle), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(fs2d_coef_kernel, dim3(nSolve / a.nRayCycle, a.nRayCycle, (Ns + 255) / 256), dim3(256), 0, stream, a);
     const size_t lds = ((size_t)a.Nx + 1) * sizeof(double);
     const int D = (a.Nx + 63) / 64;

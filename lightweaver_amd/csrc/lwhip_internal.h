@@ -429,6 +429,12 @@ struct Fs2dArgs
     const lwhip_intersection* dw;
     const int32_t* longCharIdx;
     const int32_t* substepOff;
+    // long characteristics walked by their own launch (null lcBuf: inline in pass 1): owner (ray, point) of every
+    // characteristic, results [wavelength of the batch][NlongChar][Ecum, acc, chiC]
+    const int32_t* lcOwner; // [NlongChar][2]
+    double* lcBuf;
+    int32_t NlongChar;
+    int32_t lcUpOnly;       // the launch's ray list is the up-going rays (index ray >> 1) instead of every ray
     const lwhip_intersection* substeps;
     const int32_t* rays;
     const double* chi;     // [nSolve, Nz, Nx]
