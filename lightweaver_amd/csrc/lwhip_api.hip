@@ -1269,8 +1269,17 @@ int alloc_state(lwhip_context* c)
         const size_t budget = (size_t)env_int("LWHIP_BATCH2D_MB", 8192) << 20;
         c->batch2d = (int)std::max<size_t>(1, std::min<size_t>(budget / perLa, Nla));
         c->batch2d = std::max(1, env_int("LWHIP_BATCH2D", c->batch2d));
-        // rates2d: one thread per point per wavelength group; enough groups for ~2 wavefronts per SIMD
-        c->groups2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)c->batch2d, (131072 + Ns - 1) / Ns }));
+        // rates2d: one thread per point per wavelength group; as many groups as keep every wavefront resident at the
+        // kernel's 3 wavefronts per SIMD (256 x 82: 9 groups = 2 952 wavefronts on 3 072 slots; 7 were 2.2 per SIMD,
+        // 10 spill into a second round)
+        {
+            int numCU = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+                numCU = prop.multiProcessorCount;
+            const size_t wavesPerGroup = 2 * ((Ns + 127) / 128);
+            c->groups2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)c->batch2d, (size_t)numCU * 12 / wavesPerGroup }));
+        }
         c->groups2d = std::max(1, env_int("LWHIP_GROUPS2D", c->groups2d));
         HIP_TRY(c->red2d.alloc((size_t)c->groups2d * std::max(c->Ntrans, 1) * 4 * Ns));
         const size_t nb = (size_t)c->batch2d * 2 * Nr * Ns;
