@@ -200,7 +200,11 @@ DEVINL void f2_hit_weights(const lwhip_intersection& loc, int Nx, int kPrev, dou
 // Pass 1, one thread per (solve, plane, column): everything of the step that does not need an intensity -- the
 // optical depths, control points, BESSER weights, Psi*, the whole long characteristic -- reduced to the affine map
 // of the point.  Fully parallel; this is where the flops and the chi, S stencil reads are.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) fs2d_coef_kernel(const Fs2dArgs a)
+// LC_INLINE: the long characteristics are walked here (the stand-alone solver primitive); otherwise their results come
+// from fs2d_longchar_kernel's buffer, and without the walk the kernel needs 62 VGPRs: 8 wavefronts per SIMD, no spills.
+template <bool LC_INLINE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LC_INLINE ? 6 : 8, LC_INLINE ? 6 : 8)))
+fs2d_coef_kernel(const Fs2dArgs a)
 {
     const int Nx = a.Nx, Nz = a.Nz;
     const int Ns = Nx * Nz;
@@ -343,15 +347,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     else
     {
         double chiC, Ecum, acc;
-        if (a.lcBuf)
+        if constexpr (LC_INLINE)
+            f2_long_char(a, lc, chi, S, chiL, SL, Ecum, acc, chiC);
+        else
         {
             const double* r = a.lcBuf + ((size_t)laIdx * a.NlongChar + lc) * 3;
             Ecum = r[0];
             acc = r[1];
             chiC = r[2];
         }
-        else
-            f2_long_char(a, lc, chi, S, chiL, SL, Ecum, acc, chiC);
         const lwhip_intersection st = a.substeps[a.substepOff[lc + 1] - 1]; // = the upwind hit
         const F2Loc ls = f2_loc(st, Nx);
         const double chiUw = f2_at(ls, chi);
@@ -543,9 +547,14 @@ hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
         return hipErrorInvalidValue;
     if (a.rNx != 1.0f / (float)a.Nx || Ns >= (1 << 23))
         return hipErrorInvalidValue;
+    const dim3 grid1(nSolve / a.nRayCycle, a.nRayCycle, (Ns + 255) / 256);
     if (a.lcBuf && a.NlongChar > 0)
+    {
         hipLaunchKernelGGL(fs2d_longchar_kernel, dim3((a.NlongChar + 63) / 64, nSolve / a.nRayCycle), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(fs2d_coef_kernel, dim3(nSolve / a.nRayCycle, a.nRayCycle, (Ns + 255) / 256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(fs2d_coef_kernel<false>, grid1, dim3(256), 0, stream, a);
+    }
+    else
+        hipLaunchKernelGGL(fs2d_coef_kernel<true>, grid1, dim3(256), 0, stream, a);
     const size_t lds = ((size_t)a.Nx + 1) * sizeof(double);
     const int D = (a.Nx + 63) / 64;
     if (D <= 1)
