@@ -155,7 +155,8 @@ struct lwhip_context
     double* zDownHost = nullptr;       // their host arrays [Nlambda, Nrays, Nx]
     double* zUpHost = nullptr;
     DevBuf<int32_t> xIdxLow, xIdxUp;   // [Nrays, 2]
-    DevBuf<int32_t> g2long, g2subOff, slotTrD, g2lcOwner;
+    DevBuf<int32_t> g2long, g2subOff, slotTrD, g2lcOwner, g2uwA, g2dwA;
+    DevBuf<double> g2uwS, g2dwS; // the records field by field
     DevBuf<double> b2lc; // [batch2d][NlongChar][3]
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
     std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
@@ -1240,6 +1241,16 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(upv(c->g2mux, g.mux, (size_t)g.Nrays));
         HIP_TRY(upv(c->g2uw, g.uw, nSt));
         HIP_TRY(upv(c->g2dw, g.dw, nSt));
+        {
+            std::vector<double> sv;
+            std::vector<int32_t> av;
+            fs2d_records_planar(g.uw, nSt, sv, av);
+            HIP_TRY(c->g2uwS.upload(sv));
+            HIP_TRY(c->g2uwA.upload(av));
+            fs2d_records_planar(g.dw, nSt, sv, av);
+            HIP_TRY(c->g2dwS.upload(sv));
+            HIP_TRY(c->g2dwA.upload(av));
+        }
         HIP_TRY(upv(c->g2long, g.longCharIdx, nSt));
         HIP_TRY(upv(c->g2subOff, g.substepOff, (size_t)g.NlongChar + 1));
         HIP_TRY(upv(c->g2sub, g.substeps, (size_t)g.substepOff[g.NlongChar]));
@@ -2006,6 +2017,11 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     f.temperature = c->temperature.p;
     f.uw = c->g2uw.p;
     f.dw = c->g2dw.p;
+    f.uwS = c->g2uwS.p;
+    f.dwS = c->g2dwS.p;
+    f.uwA = c->g2uwA.p;
+    f.dwA = c->g2dwA.p;
+    f.nRec = (size_t)2 * g.Nrays * Ns;
     f.longCharIdx = c->g2long.p;
     f.substepOff = c->g2subOff.p;
     f.substeps = c->g2sub.p;

@@ -305,8 +305,24 @@ fs2d_coef_kernel(const Fs2dArgs a)
 
     const bool last = (k == kEnd);
     const int kPrev = k - dk;
-    const lwhip_intersection uw = UW[o];
-    const lwhip_intersection dw = DW[o];
+    lwhip_intersection uw, dw;
+    if (a.uwS)
+    {
+        const size_t r = plane0 + o;
+        uw.axis = a.uwA[r];
+        uw.distance = a.uwS[r];
+        uw.fracX = a.uwS[a.nRec + r];
+        uw.fracZ = a.uwS[2 * a.nRec + r];
+        dw.axis = a.dwA[r];
+        dw.distance = a.dwS[r];
+        dw.fracX = a.dwS[a.nRec + r];
+        dw.fracZ = a.dwS[2 * a.nRec + r];
+    }
+    else
+    {
+        uw = UW[o];
+        dw = DW[o];
+    }
     const int lc = LC[o];
     const double chiL = chi[o], SL = S[o];
     double e;
@@ -538,6 +554,19 @@ template <int D> static void launch_scan(const Fs2dArgs& a, int nSolve, size_t l
         hipLaunchKernelGGL((fs2d_scan_kernel<D, true>), dim3(nSolve), dim3(64), lds, stream, a);
     else
         hipLaunchKernelGGL((fs2d_scan_kernel<D, false>), dim3(nSolve), dim3(64), lds, stream, a);
+}
+
+void fs2d_records_planar(const lwhip_intersection* rec, size_t n, std::vector<double>& s, std::vector<int32_t>& ax)
+{
+    s.resize(3 * n);
+    ax.resize(n);
+    for (size_t i = 0; i < n; ++i)
+    {
+        s[i] = rec[i].distance;
+        s[n + i] = rec[i].fracX;
+        s[2 * n + i] = rec[i].fracZ;
+        ax[i] = rec[i].axis;
+    }
 }
 
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)

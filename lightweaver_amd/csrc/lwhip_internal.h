@@ -1,6 +1,7 @@
 // lwhip_internal.h -- device-side tables shared by the host API (lwhip_api.hip) and the kernels
 // (lwhip_kernels.hip).  Not part of the public ABI (that is include/lwhip.h).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -429,6 +430,13 @@ struct Fs2dArgs
     const lwhip_intersection* dw;
     const int32_t* longCharIdx;
     const int32_t* substepOff;
+    // the same records field by field ([3][nRec]: distance, fracX, fracZ; axis [nRec]) -- pass 1 is bound by the
+    // texture addresser, and a 32-byte record per lane costs it twice the cache lines of four planar loads; null: uw / dw
+    const double* uwS;
+    const double* dwS;
+    const int32_t* uwA;
+    const int32_t* dwA;
+    size_t nRec;
     // long characteristics walked by their own launch (null lcBuf: inline in pass 1): owner (ray, point) of every
     // characteristic, results [wavelength of the batch][NlongChar][Ecum, acc, chiC]
     const int32_t* lcOwner; // [NlongChar][2]
@@ -461,6 +469,8 @@ struct Fs2dArgs
     const int32_t* zIdxUp;
 };
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream);
+// planar copy of n intersection records: s[0..n) distance, s[n..2n) fracX, s[2n..3n) fracZ; ax[0..n) axis
+void fs2d_records_planar(const lwhip_intersection* rec, size_t n, std::vector<double>& s, std::vector<int32_t>& ax);
 bool fs2d_long_chars_ok(const lwhip_grid2d* g);
 
 // the 2D iteration's pointwise kernels (lwhip_2d.hip)
