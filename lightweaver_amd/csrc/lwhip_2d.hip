@@ -327,14 +327,33 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
             }
         }
         const bool topRow = kk < a.Nx && on;
-        for (int r = 0; r < a.nRaysActive; ++r)
+        // the next ray's I, Psi* and profiles are requested before this ray is worked on (one ray of look-ahead costs
+        // 8 VGPRs; a thread has two other wavefronts to hide behind and every ray began with a full load round trip)
+        const int nR = a.nRaysActive;
+        double nxI, nxP, nxPhi[MAXL];
+        auto fetch = [&](int r) {
+            const size_t o = ((size_t)b * nR + r) * Ns + kk;
+            nxI = a.I[o];
+            nxP = a.lambdaIterate ? 0.0 : a.PsiStar[o];
+            const size_t rayOff = (size_t)sRayId[r] * Ns + kk;
+#pragma unroll
+            for (int l = 0; l < MAXL; ++l)
+                nxPhi[l] = (l < nLine) ? a.phi[slots[l].phiOff + rayOff] : 0.0;
+        };
+        fetch(0);
+        for (int r = 0; r < nR; ++r)
         {
             const int ray = sRayId[r];
             const int mu = ray >> 1;
             const double halfwmu = sHalfW[r];
-            const size_t o = ((size_t)b * a.nRaysActive + r) * Ns + kk;
-            const double I = a.I[o];
-            const double PsiS = a.lambdaIterate ? 0.0 : a.PsiStar[o];
+            const double I = nxI;
+            const double PsiS = nxP;
+            double phiR[MAXL];
+#pragma unroll
+            for (int l = 0; l < MAXL; ++l)
+                phiR[l] = nxPhi[l];
+            if (r + 1 < nR)
+                fetch(r + 1);
             const double wPsi = halfwmu * PsiS;
             mJ += halfwmu * I; // accumulate_J :181-190
             mM1 += wPsi;
@@ -359,7 +378,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
                 if (l < nLine)
                 {
                     const DevSlot& sl = slots[l];
-                    const double vij = sl.p[0] * a.phi[sl.phiOff + (size_t)ray * Ns + kk];
+                    const double vij = sl.p[0] * phiR[l];
                     const double vji = lG[l] * vij;
                     const double uji = sl.p[3] * vji;
                     Vij[l] = vij;
