@@ -1242,14 +1242,15 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(upv(c->g2uw, g.uw, nSt));
         HIP_TRY(upv(c->g2dw, g.dw, nSt));
         {
-            std::vector<double> sv;
-            std::vector<int32_t> av;
-            fs2d_records_planar(g.uw, nSt, sv, av);
-            HIP_TRY(c->g2uwS.upload(sv));
-            HIP_TRY(c->g2uwA.upload(av));
-            fs2d_records_planar(g.dw, nSt, sv, av);
-            HIP_TRY(c->g2dwS.upload(sv));
-            HIP_TRY(c->g2dwA.upload(av));
+            std::vector<double> su, sd;
+            std::vector<int32_t> wu, wd;
+            if (fs2d_records_packed(g.uw, nSt, g.Nx, g.Nz, su, wu) && fs2d_records_packed(g.dw, nSt, g.Nx, g.Nz, sd, wd))
+            {
+                HIP_TRY(c->g2uwS.upload(su));
+                HIP_TRY(c->g2uwA.upload(wu));
+                HIP_TRY(c->g2dwS.upload(sd));
+                HIP_TRY(c->g2dwA.upload(wd));
+            }
         }
         HIP_TRY(upv(c->g2long, g.longCharIdx, nSt));
         HIP_TRY(upv(c->g2subOff, g.substepOff, (size_t)g.NlongChar + 1));

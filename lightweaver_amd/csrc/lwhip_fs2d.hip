@@ -308,15 +308,21 @@ fs2d_coef_kernel(const Fs2dArgs a)
     lwhip_intersection uw, dw;
     if (a.uwS)
     {
-        const size_t r = plane0 + o;
-        uw.axis = a.uwA[r];
-        uw.distance = a.uwS[r];
-        uw.fracX = a.uwS[a.nRec + r];
-        uw.fracZ = a.uwS[2 * a.nRec + r];
-        dw.axis = a.dwA[r];
-        dw.distance = a.dwS[r];
-        dw.fracX = a.dwS[a.nRec + r];
-        dw.fracZ = a.dwS[2 * a.nRec + r];
+        // fracZ = z + frac and fracX = x + frac reproduce the record bit for bit (frac was formed by the exact
+        // subtraction of the integer part)
+        auto unpack = [&](const int32_t* W, const double* F, lwhip_intersection& out) {
+            const size_t r = plane0 + o;
+            const int w = W[r];
+            const double frac = F[r];
+            out.distance = F[a.nRec + r];
+            out.axis = (w >> 26) & 3;
+            const int z = k + ((w >> 28) & 3) - 1;
+            const int x = (w & 0x3ffffff) - z * Nx;
+            out.fracZ = (double)z + (out.axis == 2 ? frac : 0.0);
+            out.fracX = (double)x + (out.axis == 1 ? frac : 0.0);
+        };
+        unpack(a.uwA, a.uwS, uw);
+        unpack(a.dwA, a.dwS, dw);
     }
     else
     {
@@ -556,17 +562,43 @@ template <int D> static void launch_scan(const Fs2dArgs& a, int nSolve, size_t l
         hipLaunchKernelGGL((fs2d_scan_kernel<D, false>), dim3(nSolve), dim3(64), lds, stream, a);
 }
 
-void fs2d_records_planar(const lwhip_intersection* rec, size_t n, std::vector<double>& s, std::vector<int32_t>& ax)
+bool fs2d_records_packed(const lwhip_intersection* rec, size_t n, int Nx, int Nz, std::vector<double>& s, std::vector<int32_t>& w)
 {
-    s.resize(3 * n);
-    ax.resize(n);
+    const size_t Ns = (size_t)Nx * Nz;
+    if (Ns >= ((size_t)1 << 26))
+        return false;
+    s.assign(2 * n, 0.0);
+    w.assign(n, 0);
     for (size_t i = 0; i < n; ++i)
     {
-        s[i] = rec[i].distance;
-        s[n + i] = rec[i].fracX;
-        s[2 * n + i] = rec[i].fracZ;
-        ax[i] = rec[i].axis;
+        const lwhip_intersection& r = rec[i];
+        const int k = (int)((i % Ns) / Nx);
+        const int z = (int)r.fracZ, x = (int)r.fracX;
+        double frac = 0.0;
+        if (r.axis == 1)
+            frac = r.fracX - x;
+        else if (r.axis == 2)
+            frac = r.fracZ - z;
+        const int dz = z - k + 1;
+        // everything the packing drops must be recoverable: integral coordinates off the interpolation axis, a hit
+        // within one plane of the point (records never read -- boundary planes -- may hold anything: they only have to
+        // survive the round trip when they do fit)
+        const bool fits = r.axis >= 0 && r.axis <= 2 && dz >= 0 && dz <= 2 && z >= 0 && z < Nz && x >= 0 && x < Nx
+                          && (double)z + (r.axis == 2 ? frac : 0.0) == r.fracZ && (double)x + (r.axis == 1 ? frac : 0.0) == r.fracX;
+        if (!fits)
+        {
+            if (r.distance == 0.0 && r.axis == 0) // the "no hit" record of a boundary point: never interpolated
+            {
+                w[i] = (int32_t)((size_t)k * Nx) | (1 << 28);
+                continue;
+            }
+            return false;
+        }
+        w[i] = (int32_t)((size_t)z * Nx + x) | (r.axis << 26) | (dz << 28);
+        s[i] = frac;
+        s[n + i] = r.distance;
     }
+    return true;
 }
 
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)

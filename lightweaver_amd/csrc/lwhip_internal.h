@@ -430,8 +430,9 @@ struct Fs2dArgs
     const lwhip_intersection* dw;
     const int32_t* longCharIdx;
     const int32_t* substepOff;
-    // the same records field by field ([3][nRec]: distance, fracX, fracZ; axis [nRec]) -- pass 1 is bound by the
-    // texture addresser, and a 32-byte record per lane costs it twice the cache lines of four planar loads; null: uw / dw
+    // the same records packed ([2][nRec] doubles: fractional part, distance; one word: flat index of the hit's lower
+    // grid point | axis << 26 | (plane of the hit - plane of the point + 1) << 28) -- pass 1 is bound by the texture
+    // addresser, and a 32-byte record per lane costs it three times the cache lines of these loads; null: uw / dw
     const double* uwS;
     const double* dwS;
     const int32_t* uwA;
@@ -469,8 +470,9 @@ struct Fs2dArgs
     const int32_t* zIdxUp;
 };
 hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream);
-// planar copy of n intersection records: s[0..n) distance, s[n..2n) fracX, s[2n..3n) fracZ; ax[0..n) axis
-void fs2d_records_planar(const lwhip_intersection* rec, size_t n, std::vector<double>& s, std::vector<int32_t>& ax);
+// packed copy of the n = 2 Nrays Nx Nz intersection records (layout: Fs2dArgs::uwS / uwA); false if a record does not
+// fit the packing (a hit further than one plane from its point), in which case pass 1 reads the records themselves
+bool fs2d_records_packed(const lwhip_intersection* rec, size_t n, int Nx, int Nz, std::vector<double>& s, std::vector<int32_t>& w);
 bool fs2d_long_chars_ok(const lwhip_grid2d* g);
 
 // the 2D iteration's pointwise kernels (lwhip_2d.hip)
