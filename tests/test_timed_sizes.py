@@ -101,6 +101,28 @@ def test_2d_256x82_iteration_vs_oracle(gpu):
         assert rel_err(prob.atoms[0].n, q.atoms[0].n) <= 1e-8
 
 
+@pytest.mark.parametrize('Nx,nz,dx', [(37, 30, 60e3), (100, 24, 15e3), (130, 16, 40e3), (576, 12, 25e3), (1024, 8, 30e3)])
+def test_2d_ragged_widths_iteration_vs_oracle(gpu, Nx, nz, dx):
+    """Widths that are not the timed one: the scan's guarded form (Nx not a multiple of 64) and its 1, 2, 4, 16 columns
+    per lane, rows that straddle pass 1's 256-point workgroups, few planes, cells wider and narrower than they are
+    deep (long characteristics present or absent); the packed intersection records at every shape."""
+    from lightweaver_amd.context import Context
+    base = models.resample(models.falc82(), nz)
+    cols = [models.perturbed(base, seed=500 + j) for j in range(Nx)]
+    prob = models.build_problem_2d(cols, np.linspace(0.0, dx * (Nx - 1), Nx), [models.H_6(0.1)])
+    assert prob.grid2d.Nx == Nx
+    q = prob.copy()
+    oc = OracleContext(q)
+    with Context(prob) as ctx:
+        up = ctx.formal_sol_gamma_matrices()
+        q.gamma_prefill()
+        dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+        assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+        # (Gamma's preconditioned terms cancel to ~1e-6 of their parts on these coarse 8 ... 30-plane atmospheres, and
+        # the device groups the ray sums per wavelength: J, I and the rates agree to 1e-13, Gamma to a few 1e-8)
+        assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-7)
+
+
 def test_converged_solution_at_config1_size_vs_oracle(gpu):
     """BASELINE configs[1] (FAL-C, H(6) + Ca II(6), ~3k wavelengths, 5 mu, Bezier3): the iterate_ctx_se loop -- 25
     iterations, populations updated from the fourth on, everything resident in HBM -- against the same loop on the
