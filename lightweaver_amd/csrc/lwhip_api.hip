@@ -114,6 +114,7 @@ struct lwhip_context
     DevBuf<DevTile> tiles;
     DevBuf<DevTileSlot> tslots, tslotsPrd;
     DevBuf<DevTileCopy> tcopies;
+    DevBuf<int32_t> tileRemap;
     DevBuf<DevContRec> contRec;
     DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
         postCs;
@@ -743,6 +744,7 @@ int build_tables(lwhip_context* c)
     std::vector<DevTile> tiles;
     std::vector<DevTileSlot> tslots, tslotsPrd;
     std::vector<DevTileCopy> tcopies;
+    std::vector<int32_t> tileRemap;
     std::vector<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd,
         postSlotTr, postCs(std::max<size_t>(slots.size(), 1), 0);
     if (c->tiled)
@@ -839,6 +841,14 @@ int build_tables(lwhip_context* c)
                     if (tcopies[q].kind == 0 && std::find(srcs.begin(), srcs.end(), tcopies[q].src) == srcs.end())
                         srcs.push_back(tcopies[q].src);
                 c->preCols = std::max(c->preCols, (int)srcs.size());
+                // ... and where each dense level-sum slot lives among them (what the pre-pass's workgroups used to
+                // work out for themselves, one thread walking the copy list while 127 waited)
+                const int nLev = c->Natom + 2 * c->NlevTot;
+                const size_t base = tileRemap.size();
+                tileRemap.resize(base + nLev + 1, (int32_t)srcs.size());
+                for (size_t q = 0; q < srcs.size(); ++q)
+                    if (srcs[q] >= 2 && srcs[q] - 2 < nLev)
+                        tileRemap[base + (srcs[q] - 2)] = (int32_t)q;
             }
             td.nRowsT = nRowsT;
             td.rowBase = c->rowsTileTot;
@@ -1140,6 +1150,7 @@ int build_tables(lwhip_context* c)
         HIP_TRY(up(c->tslots, tslots));
         HIP_TRY(up(c->tslotsPrd, tslotsPrd));
         HIP_TRY(up(c->tcopies, tcopies));
+        HIP_TRY(up(c->tileRemap, tileRemap));
         HIP_TRY(up(c->chunkTile, chunkTile));
         HIP_TRY(up(c->chunkTilePrd, chunkTilePrd));
         HIP_TRY(up(c->tileListPrd, tileListPrd));
@@ -1393,6 +1404,7 @@ int build_tile_args(lwhip_context* c)
     a.tiles = c->tiles.p;
     a.tslots = c->tslots.p;
     a.copies = c->tcopies.p;
+    a.tileRemap = c->tileRemap.p;
     a.chunkTile = c->chunkTile.p;
     a.tileList = nullptr;
     a.slotTr = c->tileSlotTr.p;

@@ -192,6 +192,8 @@ struct TileArgs
     const DevTile* tiles;
     const DevTileSlot* tslots;
     const DevTileCopy* copies;
+    const int32_t* tileRemap; // [tile][Natom + 2 NlevTot + 1]: level-sum slot -> LDS column of the pre-pass (unused slots: the
+                              // trash column), last entry the tile's column count
     const int32_t* chunkTile;      // [nChunks + 1] tile boundaries of the sweep's workgroups
     const int32_t* tileList;       // null, or the tiles this launch visits (PRD rates pass); chunkTile indexes it
     const int32_t* slotTr;         // [nChunks * maxCT] transition of every chunk-local accumulator slot, -1: unused

@@ -182,29 +182,13 @@ __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __re
     // Only the level sums the tile's rows are copied from need a column: the dense slots [eta_A x Natom][chi x NlevTot]
     // [U x NlevTot] map to the tile's compact set (at most preCols columns, sized on the host), everything else to one
     // trash column.  LDS per thread drops from 26 to <= 11 doubles for H + Ca II: 3 -> 7 workgroups per CU.
+    // (the map is a table of the host's, one row per tile)
     int* remap = (int*)(lds + (size_t)(TA.preCols + 1) * RM_PRE_T);
-    __shared__ int sCols;
     const int nLev = TA.Natom + 2 * TA.NlevTot;
+    const CONST_AS int32_t* rm = CTAB(int32_t, TA.tileRemap) + (size_t)ti * (nLev + 1);
     for (int q = threadIdx.x; q < nLev; q += RM_PRE_T)
-        remap[q] = -1;
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        const CONST_AS DevTileCopy* cp = CTAB(DevTileCopy, TA.copies) + td.copyOff;
-        int n = 0;
-        for (int q = 0; q < td.nCopy; ++q)
-        {
-            const DevTileCopy c = ld_c(cp + q);
-            if (c.kind == 0 && remap[c.src - 2] < 0)
-                remap[c.src - 2] = n++;
-        }
-        sCols = n;
-    }
-    __syncthreads();
-    const int nCols = sCols;
-    for (int q = threadIdx.x; q < nLev; q += RM_PRE_T)
-        if (remap[q] < 0)
-            remap[q] = nCols;
+        remap[q] = ((const GLOBAL_AS int32_t*)TA.tileRemap)[(size_t)ti * (nLev + 1) + q];
+    const int nCols = rm[nLev];
     __syncthreads();
     const int p = blockIdx.y * RM_PRE_T + threadIdx.x;
     if (p >= TA.Ns * TA.L)
