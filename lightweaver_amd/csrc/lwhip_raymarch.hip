@@ -1005,6 +1005,21 @@ DEVINL void post_tile(const TileArgs* __restrict__ ap, const DevTile& td, const 
             w.E1u = mp[ds + 3 * qs];
             w.Jdag = GCD(TA.J)[(size_t)(td.la0 + j) * Ns + kc];
         };
+        // populations and nStar ratios of the tile's continua at this depth: once per tile, not once per wavelength (the
+        // J store of every wavelength keeps the compiler from holding on to anything it loaded through a global pointer)
+        double cNi[RM_CB], cNj[RM_CB], cRat[RM_CB];
+#pragma unroll
+        for (int i = 0; i < RM_CB; ++i)
+        {
+            cNi[i] = cNj[i] = cRat[i] = 0.0;
+            if (i < nCont)
+            {
+                const DevContRec rc = ld_c(cr + i);
+                cNj[i] = ldd(nB + rc.nJ, kB);
+                cNi[i] = ldd(nB + rc.nI, kB);
+                cRat[i] = ldd(rB + rc.rat, kB);
+            }
+        }
         PostLa wA, wB;
         load_la(0, wA);
         wB = wA;
@@ -1024,13 +1039,10 @@ DEVINL void post_tile(const TileArgs* __restrict__ ap, const DevTile& td, const 
                     lc.lev[(size_t)q * T] = 0.0;
                 // level sums of the active atoms, continua in transition order (LDS adds without a return value: no
                 // read-modify-write round trip, executed in program order)
-                for (int q = 0; q < nCont; ++q)
-                {
-                    const DevContRec rc = ld_c(cr + q);
+                auto level_sums = [&](const DevContRec& rc, double njq, double niq, double rat) {
                     const PostP pp = ld_c((const CONST_AS PostP*)(lsB + rc.pOff));
-                    const double njq = ldd(nB + rc.nJ, kB);
-                    const double vji = (ldd(rB + rc.rat, kB) * boltz) * pp.p0;
-                    const double chi_c = ldd(nB + rc.nI, kB) * pp.p0 - njq * vji;
+                    const double vji = (rat * boltz) * pp.p0;
+                    const double chi_c = niq * pp.p0 - njq * vji;
                     const double uji = pp.p2 * vji;
                     if (rc.flags & 1)
                     {
@@ -1039,7 +1051,20 @@ DEVINL void post_tile(const TileArgs* __restrict__ ap, const DevTile& td, const 
                         lds_add(lc.lev + (size_t)rc.sChiJ * T, -chi_c);
                         lds_add(lc.lev + (size_t)rc.sUj * T, uji);
                     }
+                };
+                if (single)
+                {
+#pragma unroll
+                    for (int i = 0; i < RM_CB; ++i)
+                        if (i < nCont)
+                            level_sums(ld_c(cr + i), cNj[i], cNi[i], cRat[i]);
                 }
+                else
+                    for (int q = 0; q < nCont; ++q)
+                    {
+                        const DevContRec rc = ld_c(cr + q);
+                        level_sums(rc, ldd(nB + rc.nJ, kB), ldd(nB + rc.nI, kB), ldd(rB + rc.rat, kB));
+                    }
                 // the pure continua of the wavelength (every level sum is complete)
                 if (single)
                 {
@@ -1053,7 +1078,7 @@ DEVINL void post_tile(const TileArgs* __restrict__ ap, const DevTile& td, const 
                             {
                                 const PostP pp = ld_c((const CONST_AS PostP*)(lsB + rc.pOff));
                                 const double vij = pp.p0, wla = pp.p1;
-                                const double vji = (ldd(rB + rc.rat, kB) * boltz) * vij;
+                                const double vji = (cRat[i] * boltz) * vij;
                                 const double uji = pp.p2 * vji;
                                 if (rc.flags & 1)
                                 {
