@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -108,6 +109,11 @@ struct lwhip_context
     bool tiled = false;
     int tileL = 12, nTiles = 0, nTileChunks = 0, nTileChunksPrd = 0, nPostChunks = 0, nPostChunksPrd = 0, nTilesPrd = 0;
     bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
+    // depth-across-lanes sweep (lwhip_lanesweep.hip): D points per lane, LR lanes per ray, R wavelengths per wavefront
+    bool laneSweep = false;
+    int laneD = 0, laneLR = 0, laneR = 0;
+    DevBuf<DevPostProg> postProg;
+    DevBuf<double> geoT;
     int tileWaves = 4, maxSlotsTile = 0, maxCTTile = 1, maxCTPost = 1, tileCap = 0, ktStride = 4;
     int64_t rowsTileTot = 0, momTot = 0, phiTTot = 0;
     int preCols = 0;              // most level-sum columns a tile's rows need (LDS columns of the pre-pass)
@@ -747,10 +753,103 @@ int build_tables(lwhip_context* c)
     std::vector<int32_t> tileRemap;
     std::vector<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd,
         postSlotTr, postCs(std::max<size_t>(slots.size(), 1), 0);
+    std::function<bool(int, DevPostProg&)> lanePostProgram;
+    std::vector<int> laneCsPure; // lane sweep: accumulator slot of every pure continuum inside its workgroup chunk
     if (c->tiled)
     {
         const int Nmu = c->Nrays;
-        const int L = std::max(1, std::min({ 16, 64 / Nmu, env_int("LWHIP_TILE_L", 16) }));
+        // The depth-across-lanes sweep serves the tiles whose line / mixed-continuum counts have a compiled kind and whose
+        // pure continua fit its register program; anything else (and LWHIP_SWEEP=march) runs the ray-column march.
+        c->laneSweep = false;
+        // The pure continua of a wavelength as the lane sweep integrates them (DevPostProg): which level sums need a
+        // register ("shared": several contributors, or a foreign one), which are the continuum's own term or zero.
+        auto post_program = [&](int la, DevPostProg& pg) -> bool {
+            pg = DevPostProg{};
+            const DevLaHeader& h = hdr[la];
+            const int base = h.off + h.nLine, nC = h.nMixed + h.nPure;
+            if (nC > LWHIP_POST_MAXC)
+                return false;
+            // position q of the reference's transition order -> the continuum's slot record
+            auto ordOf = [&](int q) { return slots[base + q]._pad; };
+            auto rec = [&](int q) -> const DevSlot& { return slots[base + ordOf(q)]; };
+            struct Contrib { int q, kind; };
+            const int colChi = c->Natom, colU = c->Natom + c->NlevTot;
+            auto contributors = [&](int col) {
+                std::vector<Contrib> v;
+                for (int q = 0; q < nC; ++q)
+                {
+                    const DevSlot& sl = rec(q);
+                    if (!(sl.flags & 1))
+                        continue;
+                    if (col == sl.atom)
+                        v.push_back({ q, 4 });
+                    if (col == colChi + sl.gi)
+                        v.push_back({ q, 1 });
+                    if (col == colChi + sl.gj)
+                        v.push_back({ q, 2 });
+                    if (col == colU + sl.gj)
+                        v.push_back({ q, 3 });
+                }
+                return v;
+            };
+            std::map<int, int> sumOf;
+            for (int q = 0; q < nC; ++q)
+            {
+                const DevSlot& sl = rec(q);
+                if (ordOf(q) < h.nMixed || !(sl.flags & 1))
+                    continue; // mixed continua are integrated ray by ray; detailed atoms have rates only
+                const int cols[5] = { sl.atom, colChi + sl.gi, colU + sl.gj, colChi + sl.gj, colU + sl.gi };
+                for (int w = 0; w < 5; ++w)
+                {
+                    const auto v = contributors(cols[w]);
+                    unsigned sel = 0;
+                    if (v.size() == 1 && v[0].q == q)
+                        sel = 8u + (unsigned)v[0].kind;
+                    else if (!v.empty())
+                    {
+                        auto it = sumOf.find(cols[w]);
+                        if (it == sumOf.end())
+                        {
+                            if ((int)sumOf.size() >= LWHIP_POST_SUMS)
+                                return false;
+                            const int m = (int)sumOf.size();
+                            it = sumOf.emplace(cols[w], m).first;
+                            for (const auto& cb : v)
+                                pg.code[cb.q] |= (unsigned)cb.kind << (3 * m);
+                        }
+                        sel = (unsigned)it->second + 1u;
+                    }
+                    pg.ops[q] |= sel << (4 * w);
+                }
+            }
+            return true;
+        };
+        lanePostProgram = post_program;
+        {
+            const char* sw = std::getenv("LWHIP_SWEEP");
+            int D = 0, LR = 0, R = 0;
+            if (!(sw && std::strcmp(sw, "march") == 0) && env_int("LWHIP_TILE_GENERIC", 0) == 0
+                && lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R))
+            {
+                bool ok = true;
+                for (int la = 0; la < c->Nla && ok; ++la)
+                {
+                    const DevLaHeader& h = hdr[la];
+                    const bool fastKind = (h.nLine == 0 && h.nMixed == 0) || (h.nLine == 1 && h.nMixed <= 1) || (h.nLine == 2 && h.nMixed == 0);
+                    DevPostProg pg;
+                    ok = fastKind && post_program(la, pg);
+                }
+                if (ok)
+                {
+                    c->laneSweep = true;
+                    c->laneD = D;
+                    c->laneLR = LR;
+                    c->laneR = R;
+                }
+            }
+        }
+        const int L = c->laneSweep ? c->laneR : std::max(1, std::min({ 16, 64 / Nmu, env_int("LWHIP_TILE_L", 16) }));
+        const int LRD = c->laneLR * c->laneD;
         c->tileL = L;
         auto pad16 = [](int64_t v) { return (v + 15) / 16 * 16; };
         auto same_structure = [&](int la, int lb) {
@@ -784,6 +883,25 @@ int build_tables(lwhip_context* c)
             int nRowsT = 3;
             // the five continuum rows of an active slot (eta_A, chi_i, chi_j, U_i, U_j) are consecutive tile rows,
             // zero-filled where the wavelength has no such term: the march loads them unconditionally
+            // which of a slot's five level sums no continuum of this wavelength feeds (the lane sweep does not read them)
+            auto zero_mask = [&](const DevSlot& sl) -> int16_t {
+                bool fed[5] = { false, false, false, false, false };
+                for (int e = h.nLine; e < h.nLine + h.nMixed + h.nPure; ++e)
+                {
+                    const DevSlot& cs = slots[h.off + e];
+                    if (!(cs.flags & 1))
+                        continue;
+                    fed[0] |= cs.atom == sl.atom;
+                    fed[1] |= cs.gi == sl.gi || cs.gj == sl.gi;
+                    fed[2] |= cs.gi == sl.gj || cs.gj == sl.gj;
+                    fed[3] |= cs.gj == sl.gi;
+                    fed[4] |= cs.gj == sl.gj;
+                }
+                int16_t zm = 0;
+                for (int q = 0; q < 5; ++q)
+                    zm |= fed[q] ? 0 : (int16_t)(1 << q);
+                return zm;
+            };
             auto five_rows = [&](const DevSlot& sl) -> int16_t {
                 const int16_t r0 = (int16_t)nRowsT;
                 // row ids as the row programs number them (the pre-pass forms the level sums directly)
@@ -810,14 +928,21 @@ int build_tables(lwhip_context* c)
                 ts.row = sl.row;
                 ts.ms = sl.ms;
                 ts.r0 = (sl.flags & 1) ? five_rows(sl) : (int16_t)0;
+                ts.zmask = (sl.flags & 1) ? zero_mask(sl) : (int16_t)31;
                 ts.rAux = -1;
                 ts.e = (int16_t)e;
                 ts.phiOff = -1;
-                if (e < h.nLine)
+                ts.rhoOff = sl.rhoOff;
+                if (e < h.nLine && c->laneSweep)
+                    ts.phiOff = sl.phiOff; // the profiles are read where they lie
+                else if (e < h.nLine)
                 {
                     ts.phiOff = c->phiTTot;
                     c->phiTTot += (int64_t)2 * Ns * 64;
-                    if (sl.flags & 2)
+                }
+                if (e < h.nLine)
+                {
+                    if ((sl.flags & 2) && !c->laneSweep) // (the lane sweep reads rho where it lies)
                     {
                         ts.rAux = (int16_t)nRowsT;
                         tcopies.push_back(DevTileCopy{ 2, (int16_t)e, (int16_t)nRowsT++, 0 });
@@ -852,9 +977,14 @@ int build_tables(lwhip_context* c)
             }
             td.nRowsT = nRowsT;
             td.rowBase = c->rowsTileTot;
-            c->rowsTileTot += (int64_t)nRowsT * Ns * 16; // rows of 16 doubles whatever L (RM_ROW)
             td.momBase = c->momTot;
-            c->momTot += pad16((int64_t)8 * Ns * L); // [direction][J, M1, Meta0, Meta1][Ns][L]
+            if (c->laneSweep)
+                c->rowsTileTot += (int64_t)nRowsT * L * LRD; // [row][wavelength][k]
+            else
+            {
+                c->rowsTileTot += (int64_t)nRowsT * Ns * 16; // rows of 16 doubles whatever L (RM_ROW)
+                c->momTot += pad16((int64_t)8 * Ns * L);      // [direction][J, M1, Meta0, Meta1][Ns][L]
+            }
             c->maxSlotsTile = std::max(c->maxSlotsTile, h.nLine + h.nMixed);
             tiles.push_back(td);
             la += nl;
@@ -880,7 +1010,7 @@ int build_tables(lwhip_context* c)
     if (c->tiled)
     {
         // workgroups of the sweep: contiguous, cost-balanced runs of tiles; the waves of a workgroup take its tiles in turn
-        c->tileWaves = std::max(1, std::min(8, env_int("LWHIP_TWAVES", 2)));
+        c->tileWaves = std::max(1, std::min(8, c->laneSweep ? env_int("LWHIP_LWAVES", 4) : env_int("LWHIP_TWAVES", 2)));
         const int W = c->tileWaves;
         int wgPerCU = std::max(1, 8 / W);
         if (c->batchHint > 1)
@@ -888,11 +1018,15 @@ int build_tables(lwhip_context* c)
         struct TileChunking
         {
             std::vector<int32_t> chunkTile, slotTr;
-            std::vector<int> cs; // per tile slot
+            std::vector<int> cs;     // per tile slot (mode 0, 2) or per wavelength slot record (mode 1)
+            std::vector<int> csPure; // mode 2: per wavelength slot record, the pure continua
             int maxCT = 1;
         };
         auto tile_cost = [&](const DevTile& td) { return 1.0 + 0.35 * (td.nLine + td.nMixed); };
-        auto chunk_tiles = [&](const std::vector<int32_t>& list, int tgt, bool pure) {
+        // mode 0: accumulator slots for the tiles' lines and mixed continua; 1: for the pure continua (post-pass chunks);
+        // 2: for both (the lane sweep's workgroups finish their tiles themselves)
+        auto chunk_tiles = [&](const std::vector<int32_t>& list, int tgt, int mode) {
+            const bool pure = mode == 1;
             TileChunking ck;
             const int n = (int)list.size();
             tgt = std::max(1, std::min(tgt, n));
@@ -916,6 +1050,8 @@ int build_tables(lwhip_context* c)
             const int nch = (int)ck.chunkTile.size() - 1;
             std::vector<std::vector<int>> chunkTrans(nch);
             ck.cs.assign(pure ? slots.size() : tslots.size(), 0);
+            if (mode == 2)
+                ck.csPure.assign(slots.size(), 0);
             for (int ch = 0; ch < nch; ++ch)
             {
                 std::vector<int> slotOf(c->Ntrans, -1);
@@ -933,12 +1069,12 @@ int build_tables(lwhip_context* c)
                     if (!pure)
                         for (int e = 0; e < td.nLine + td.nMixed; ++e)
                             ck.cs[td.slotOff + e] = slot_for(tslots[td.slotOff + e].tr);
-                    else
+                    if (mode != 0)
                         for (int q = 0; q < td.nl; ++q)
                         {
                             const DevLaHeader& h = hdr[td.la0 + q];
                             for (int e = h.nLine + h.nMixed; e < h.nLine + h.nMixed + h.nPure; ++e)
-                                ck.cs[h.off + e] = slot_for(slotTr[h.off + e]);
+                                (mode == 2 ? ck.csPure : ck.cs)[h.off + e] = slot_for(slotTr[h.off + e]);
                         }
                 }
                 ck.maxCT = std::max(ck.maxCT, (int)chunkTrans[ch].size());
@@ -959,27 +1095,33 @@ int build_tables(lwhip_context* c)
         int tgtSweep = std::min((2 * c->nTiles + W - 1) / W, numCU * wgPerCU); // two tasks per tile (down, up)
         // fused post-pass: the workgroup is the two wavefronts of one tile (and every tile is a workgroup)
         // (column batches too: 12.3k -> 16.0k column-iterations/s at 128 columns against a separate post launch)
-        c->tileFuse = W == 2 && env_int("LWHIP_TILE_FUSE", 1) != 0;
+        c->tileFuse = W == 2 && env_int("LWHIP_TILE_FUSE", 1) != 0 && !c->laneSweep;
         if (c->batchHint > 1 && !c->tileFuse)
             tgtSweep = std::max(1, std::min(tgtSweep, numCU * 4 / c->batchHint));
         if (c->tileFuse)
             tgtSweep = c->nTiles;
         if (!c->tileFuse)
             tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
+        if (c->laneSweep) // one tile per wavefront
+            tgtSweep = (c->nTiles + W - 1) / W;
         // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
         const size_t ldsPostEst = sizeof(double) * ((size_t)7 * 4 * Ns + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
         const int postPerCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / ldsPostEst));
         int tgtPost = std::min(c->nTiles, numCU * env_int("LWHIP_POST_PER_CU", postPerCU));
         if (c->batchHint > 1)
             tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
-        TileChunking sw = chunk_tiles(all, tgtSweep, false);
-        TileChunking po = chunk_tiles(all, tgtPost, true);
+        TileChunking sw = chunk_tiles(all, tgtSweep, c->laneSweep ? 2 : 0);
+        TileChunking po = chunk_tiles(all, tgtPost, 1);
         TileChunking swPrd, poPrd;
         if (!tileListPrd.empty())
         {
             // (fused post-pass: one tile per workgroup here too)
-            swPrd = chunk_tiles(tileListPrd, c->tileFuse ? (int)tileListPrd.size() : std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU), false);
-            poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * postPerCU), true);
+            swPrd = chunk_tiles(tileListPrd,
+                                c->laneSweep ? ((int)tileListPrd.size() + W - 1) / W
+                                : c->tileFuse ? (int)tileListPrd.size()
+                                              : std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU),
+                                0);
+            poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * postPerCU), 1);
         }
         // both chunkings share one accumulator-slot capacity per kind
         c->maxCTTile = std::max(sw.maxCT, swPrd.maxCT);
@@ -1000,6 +1142,7 @@ int build_tables(lwhip_context* c)
             widen(swPrd, c->maxCTTile);
         for (size_t e = 0; e < tslots.size(); ++e)
             tslots[e].cs = sw.cs[e];
+        laneCsPure = sw.csPure;
         chunkTile = sw.chunkTile;
         tileSlotTr = sw.slotTr;
         c->nTileChunks = (int)chunkTile.size() - 1;
@@ -1024,8 +1167,10 @@ int build_tables(lwhip_context* c)
         // LDS: the workgroup's accumulators + a 2 KB exchange row per wave (sweep); accumulators + continuum columns (post)
         const size_t ldsSweep = sizeof(double) * ((size_t)c->maxCTTile * 4 * Ns + std::max((size_t)W * 5 * 16 * 9, (size_t)16 + (size_t)(c->Natom + 2 * c->NlevTot) * 128));
         const size_t ldsPost = sizeof(double) * (16 + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
-        if (ldsSweep > 150 * 1024 || ldsPost > 150 * 1024)
+        if (!c->laneSweep && (ldsSweep > 150 * 1024 || ldsPost > 150 * 1024))
             return fail(LWHIP_ERR_UNSUPPORTED, "problem does not fit the 160 KB LDS budget of one workgroup");
+        if (c->laneSweep && sizeof(double) * (size_t)c->maxCTTile * 4 * (c->laneLR * c->laneD) > 64 * 1024)
+            return fail(LWHIP_ERR_UNSUPPORTED, "more transitions per workgroup than the lane sweep's LDS accumulators hold");
     }
 
     const int NR2 = 2 * c->Nrays;
@@ -1141,10 +1286,19 @@ int build_tables(lwhip_context* c)
                     r.flags = (uint8_t)((sl.flags & 1) | (ord >= h.nMixed ? 2 : 0));
                     r.ms = (int8_t)sl.ms;
                     r.tr = (int16_t)slotTr[base + ord];
+                    r.cs = (int16_t)((c->laneSweep && ord >= h.nMixed) ? laneCsPure[base + ord] : 0);
                     cr[base + q] = r;
                 }
             }
             HIP_TRY(c->contRec.upload(cr));
+        }
+        if (c->laneSweep)
+        {
+            std::vector<DevPostProg> pp(std::max<size_t>(tiles.size(), 1));
+            for (size_t t = 0; t < tiles.size(); ++t)
+                if (!lanePostProgram(tiles[t].la0, pp[t]))
+                    return fail(LWHIP_ERR_UNSUPPORTED, "lane sweep: post program");
+            HIP_TRY(c->postProg.upload(pp));
         }
         HIP_TRY(up(c->tiles, tiles));
         HIP_TRY(up(c->tslots, tslots));
@@ -1235,6 +1389,12 @@ int alloc_state(lwhip_context* c)
         c->ktStride = (4 + c->NlevTot + c->Nline + 1) / 2 * 2;
         HIP_TRY(c->kt.alloc((size_t)c->ktStride * (Ns + 2))); // one padding entry at each end
         HIP_TRY(c->rowsTile.alloc((size_t)std::max<int64_t>(c->rowsTileTot, 1)));
+        if (c->laneSweep)
+        {
+            // the padding points of the row blocks (k >= Ns) are read: keep them finite
+            HIP_TRY(hipMemset(c->rowsTile.p, 0, c->rowsTile.n * sizeof(double)));
+            HIP_TRY(c->geoT.alloc((size_t)4 * (c->laneLR * c->laneD + 2)));
+        }
         HIP_TRY(c->momTile.alloc((size_t)std::max<int64_t>(c->momTot, 1)));
         HIP_TRY(c->phiT.alloc((size_t)std::max<int64_t>(c->phiTTot, 1)));
         HIP_TRY(hipMemset(c->momTile.p, 0, c->momTile.n * sizeof(double)));
@@ -1447,6 +1607,19 @@ int build_tile_args(lwhip_context* c)
     a.progEnts = c->progEnts.p;
     a.red8 = c->red8.p;
     a.dJ = c->dJ.p;
+    if (c->laneSweep)
+    {
+        a.laneD = c->laneD;
+        a.laneLR = c->laneLR;
+        a.laneR = c->laneR;
+        a.laneLRD = c->laneLR * c->laneD;
+        a.phi = c->phi.p;
+        a.geoT = c->geoT.p;
+        a.postProg = c->postProg.p;
+        a.phiDoubles = c->phi.n;
+        a.rhoDoubles = c->rho.n;
+        a.ratioDoubles = c->ratio.n;
+    }
     c->htargs = a;
     std::vector<TileArgs> v(1, a);
     HIP_TRY(c->dtargs.upload(v));
@@ -1467,7 +1640,7 @@ int build_tile_args(lwhip_context* c)
 // the tile-blocked copy of the line profiles follows every change of phi
 static bool retile_args(lwhip_context* c, RetileArgs& r)
 {
-    if (!c->tiled || c->Nline == 0)
+    if (!c->tiled || c->Nline == 0 || c->laneSweep) // (the lane sweep reads the profiles where they lie)
         return false;
     r = RetileArgs{};
     r.Ns = c->Ns;
@@ -1516,11 +1689,15 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
         return e;
     if (e0) // lwhip_profile_enable: HIP events around the sweep kernel alone
         (void)hipEventRecord(e0, c->stream);
-    e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, fuse, tprd ? c->nTileChunksPrd : c->nTileChunks,
-                          c->tileWaves, nullptr, 0, c->stream);
+    if (c->laneSweep)
+        e = launch_lane_sweep(da, ha, td, c->prob.formalSolver, rates, tprd ? c->nTileChunksPrd : c->nTileChunks, c->tileWaves, nullptr, 0,
+                              c->stream);
+    else
+        e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, fuse, tprd ? c->nTileChunksPrd : c->nTileChunks,
+                              c->tileWaves, nullptr, 0, c->stream);
     if (e1)
         (void)hipEventRecord(e1, c->stream);
-    if (e != hipSuccess || !rates || fuse)
+    if (e != hipSuccess || !rates || fuse || c->laneSweep)
         return e;
     return launch_tile_post(da, ha, td, tprd ? c->nPostChunksPrd : c->nPostChunks, nullptr, 0, c->stream);
 }
@@ -1656,7 +1833,7 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
         std::fprintf(stderr,
                      "lwhip_create: Nla=%d Ns=%d Nmu=%d sweep=%s tiles=%d (L=%d, max slots %d, cap %d) chunks=%d x %d waves post=%d maxCT=%d/%d "
                      "rows=%.1f MB phiT=%.1f MB\n",
-                     c->Nla, c->Ns, c->Nrays, c->is2d ? "2d" : "ray-column",
+                     c->Nla, c->Ns, c->Nrays, c->is2d ? "2d" : c->laneSweep ? "depth-lanes" : "ray-column",
                      c->nTiles, c->tileL, c->maxSlotsTile, c->tileCap, c->nTileChunks, c->tileWaves, c->nPostChunks, c->maxCTTile, c->maxCTPost,
                      c->rowsTileTot * 8e-6, c->phiTTot * 8e-6);
     *out = c;
@@ -1709,6 +1886,17 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                 geo[4 * k + 3] = 1.0 / p.temperature[k];
             }
             HIP_TRY(hipMemcpyAsync(c->geo.p, geo.data(), geo.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            std::vector<double> geoT;
+            if (c->laneSweep)
+            {
+                // the same per quantity, entry k + 1 (zero padding at both ends): what a lane reads for its block of depths
+                const size_t st = (size_t)c->laneLR * c->laneD + 2;
+                geoT.assign(4 * st, 0.0);
+                for (size_t k = 0; k < Ns; ++k)
+                    for (int q = 0; q < 4; ++q)
+                        geoT[q * st + k + 1] = geo[4 * k + q];
+                HIP_TRY(hipMemcpyAsync(c->geoT.p, geoT.data(), geoT.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            }
             HIP_TRY(hipStreamSynchronize(c->stream)); // `geo` is a local
         }
     }
@@ -2416,6 +2604,7 @@ int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
             || c->Nrays != c0->Nrays || c->Ntrans != c0->Ntrans || c->Natom != c0->Natom || c->nTiles != c0->nTiles
             || c->nTileChunks != c0->nTileChunks || c->nPostChunks != c0->nPostChunks || c->tileCap != c0->tileCap
             || c->tileFuse != c0->tileFuse || c->tileWaves != c0->tileWaves || c->maxCTTile != c0->maxCTTile
+            || c->laneSweep != c0->laneSweep
             || c->maxL != c0->maxL || c->maxC != c0->maxC
             || c->NlevTot != c0->NlevTot || c->prob.formalSolver != c0->prob.formalSolver)
             return fail(LWHIP_ERR_INVALID, "batch_create: the columns must share device, model atoms, wavelength grid "
@@ -2564,10 +2753,16 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
     const TileDyn dyn = make_dyn(c0, false, lambdaIterate);
     const bool fuse = c0->tileFuse;
     HIP_TRY(launch_tile_pre(c0->dtargs.p, c0->htargs, c0->nTiles, b->apList.p, n, c0->stream));
-    HIP_TRY(launch_tile_sweep(c0->dtargs.p, c0->htargs, dyn, c0->prob.formalSolver, c0->tileCap, true, fuse, c0->nTileChunks,
-                              c0->tileWaves, b->apList.p, n, c0->stream));
-    if (!fuse)
-        HIP_TRY(launch_tile_post(c0->dtargs.p, c0->htargs, dyn, c0->nPostChunks, b->apList.p, n, c0->stream));
+    if (c0->laneSweep)
+        HIP_TRY(launch_lane_sweep(c0->dtargs.p, c0->htargs, dyn, c0->prob.formalSolver, true, c0->nTileChunks, c0->tileWaves, b->apList.p, n,
+                                  c0->stream));
+    else
+    {
+        HIP_TRY(launch_tile_sweep(c0->dtargs.p, c0->htargs, dyn, c0->prob.formalSolver, c0->tileCap, true, fuse, c0->nTileChunks,
+                                  c0->tileWaves, b->apList.p, n, c0->stream));
+        if (!fuse)
+            HIP_TRY(launch_tile_post(c0->dtargs.p, c0->htargs, dyn, c0->nPostChunks, b->apList.p, n, c0->stream));
+    }
     {
         ReduceArgs r0 = make_reduce_args(c0);
         r0.zeroParts = 1;

@@ -156,8 +156,22 @@ struct DevTileSlot
                         // where the wavelength has none)
     int16_t rAux;       // PRD lines: row of rho; mixed continua: row of Vji; -1: none
     int16_t e;          // ordinal among the wavelength's slot records (DevLaHeader::off + e)
-    int16_t _pad;
-    int64_t phiOff;     // lines: offset (doubles) of the tile's [2][Ns][64] block in the phiT pool
+    int16_t zmask;      // bit q: row r0 + q is identically zero at this tile's wavelengths (no continuum feeds it)
+    int64_t phiOff;     // lines: offset (doubles) of the tile's [2][Ns][64] block in the phiT pool; lane sweep: of the
+                        // first wavelength's [Nmu][2][Ns] block in the phi pool itself
+    int64_t rhoOff;     // PRD lines: offset (doubles) of the first wavelength's [Ns] row in the rho pool, else -1
+};
+// Pure continua of a tile for the lane sweep's in-wave post-pass: the level sums they need that have more than one
+// contributor (or a foreign one) live in up to 8 registers per point ("shared sums"); everything else is the
+// continuum's own term or zero.  Per continuum ordinal q of the wavelength's transition order:
+//   code[q]: 8 x 3 bits, sum m receives from continuum q: 0 nothing, 1 +chi_c, 2 -chi_c, 3 +U_ji, 4 +eta_c
+//   ops[q]:  5 x 4 bits (eta_A, chi_i, U_j, chi_j, U_i of pure continuum q): 0 zero, 1..8 shared sum m = value - 1,
+//            9 +chi_c, 10 -chi_c, 11 U_ji, 12 eta_c of the continuum itself
+enum { LWHIP_POST_MAXC = 16, LWHIP_POST_SUMS = 8 };
+struct DevPostProg
+{
+    uint32_t code[LWHIP_POST_MAXC];
+    uint32_t ops[LWHIP_POST_MAXC];
 };
 // One continuum of a wavelength for the pre / post passes: everything uniform about it ready to use (byte offsets, level
 // column slots), 32 bytes = one scalar load.  Stored per wavelength in the reference's transition order (the order in
@@ -171,7 +185,7 @@ struct DevContRec
     uint8_t flags;              // bit 0: active atom   bit 1: "pure" (integrated by the post-pass from the angle moments)
     int8_t ms;                  // moment slot of the atom's lines (0 / 1) or -1
     int16_t tr;                 // global transition
-    int16_t _pad;
+    int16_t cs;                 // lane sweep: accumulator slot of a pure continuum inside its wavelength's workgroup chunk
 };
 static_assert(sizeof(DevContRec) == 32, "DevContRec is fetched with one scalar load");
 struct DevTileCopy      // what the pre-pass writes into the tile's row block besides rows 0..2
@@ -236,6 +250,14 @@ struct TileArgs
     const DevProgEnt* progEnts;
     double* red8;                  // [Ntrans, SPLIT, 4, Ns]
     double* dJ;                    // [Nla]
+    // ---- depth-across-lanes sweep (lwhip_lanesweep.hip): a lane owns laneD consecutive depth points of one wavelength,
+    // laneLR = ceil(Ns / laneD) lanes make a ray, laneR = L rays (wavelengths) share a wavefront.  Row blocks are
+    // rows[rowBase + (row * L + j) * laneLRD + k] (laneLRD = laneLR * laneD), profiles are read from the phi pool itself.
+    int32_t laneD, laneLR, laneR, laneLRD;
+    const double* phi;             // [line][lt][Nmu][2][Ns] pool (the caller's layout)
+    const double* geoT;            // [4][laneLRD + 2], entry k + 1: |h_k - h_k+1|, its reciprocal, 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k
+    const DevPostProg* postProg;   // [nTiles]
+    uint64_t phiDoubles, rhoDoubles, ratioDoubles; // pool sizes (buffer ranges)
 };
 struct TileDyn
 {
@@ -262,6 +284,11 @@ hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, 
                              hipStream_t stream);
 hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int nPostChunks,
                             const TileArgs* const* apList, int nBatch, hipStream_t stream);
+// the depth-across-lanes sweep (lwhip_lanesweep.hip); D = hostArgs.laneD
+bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R);
+size_t lane_sweep_lds_bytes(const TileArgs& a, int waves);
+hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int solver, bool rates,
+                             int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream);
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
 hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostList, int n, hipStream_t stream);
 

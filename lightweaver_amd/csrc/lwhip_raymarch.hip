@@ -131,8 +131,11 @@ DEVINL void depth_table(const TileArgs* __restrict__ ap, int t, int T)
 DEVINL void pre_point(const TileArgs* __restrict__ ap, const DevTile& td, const DevLaHeader& h, const LevCols& lc, int nCols, int p)
 {
     const int Ns = TA.Ns, L = TA.L;
-    const int k = p / L;
-    const int j = p - k * L;
+    // ray-column march: wavelength fastest (rows of RM_ROW doubles per depth); lane sweep: depth fastest
+    // ([row][wavelength][k] blocks): coalesced row writes either way
+    const bool lanes = TA.laneD > 0;
+    const int k = lanes ? p % Ns : p / L;
+    const int j = lanes ? p / Ns : p - k * L;
     if (j >= td.nl)
         return;
     const int la = td.la0 + j;
@@ -150,10 +153,11 @@ DEVINL void pre_point(const TileArgs* __restrict__ ap, const DevTile& td, const 
     const double scaJ = GCD(TA.bgSca)[o] * GCD(TA.J)[o]; // sca * Jdag of compute_source_fn :169-179
     const double boltz = d_exp_neg(-hc_kl * rT);
     cont_levels(ap, lc, nCols, cr, (const GLOBAL_AS char*)lsAll, nCont, (unsigned)k * 8u, boltz, chiC, etaC);
-    GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (size_t)k * td.nRowsT * RM_ROW + j;
+    const size_t rs = lanes ? (size_t)L * TA.laneLRD : (size_t)RM_ROW; // doubles between two rows of a point
+    GLOBAL_AS double* out = GD(TA.rows) + td.rowBase + (lanes ? (size_t)j * TA.laneLRD + k : (size_t)k * td.nRowsT * RM_ROW + j);
     out[0] = chiC;
-    out[RM_ROW] = etaC;
-    out[2 * RM_ROW] = scaJ;
+    out[rs] = etaC;
+    out[2 * rs] = scaJ;
     const CONST_AS DevTileCopy* cp = CTAB(DevTileCopy, TA.copies) + td.copyOff;
     for (int q = 0; q < td.nCopy; ++q)
     {
@@ -165,7 +169,7 @@ DEVINL void pre_point(const TileArgs* __restrict__ ap, const DevTile& td, const 
             v = (GCD(TA.ratio)[(size_t)us[c.src].row * Ns + k] * boltz) * ls[c.src].p[0];
         else if (c.kind == 2)
             v = GCD(TA.rho)[lsAll[c.src].rhoOff + k];
-        out[(size_t)c.dst * RM_ROW] = v;
+        out[(size_t)c.dst * rs] = v;
     }
 }
 // stand-alone pre-pass: grid (tile, part[, column]); block (0, 0) also refreshes the depth table
