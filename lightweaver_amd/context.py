@@ -23,7 +23,7 @@ from . import _abi as abi
 from .model import Problem
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'liblwhip.so')
+LIB_PATH = os.environ.get('LWHIP_LIB') or os.path.join(_PKG, 'liblwhip.so')  # LWHIP_LIB: an experiment build of the same library
 _lib = None
 
 

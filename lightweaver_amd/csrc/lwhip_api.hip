@@ -50,6 +50,7 @@ template <typename T> struct DevBuf
 {
     T* p = nullptr;
     size_t n = 0;
+    bool owned = true;
     hipError_t alloc(size_t count)
     {
         release();
@@ -57,6 +58,14 @@ template <typename T> struct DevBuf
         if (count == 0)
             return hipSuccess;
         return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    // a window of somebody else's allocation (the depth arena of the lane sweep)
+    void view(T* ptr, size_t count)
+    {
+        release();
+        p = ptr;
+        n = count;
+        owned = false;
     }
     hipError_t upload(const std::vector<T>& v)
     {
@@ -67,10 +76,11 @@ template <typename T> struct DevBuf
     }
     void release()
     {
-        if (p)
+        if (p && owned)
             (void)hipFree(p);
         p = nullptr;
         n = 0;
+        owned = true;
     }
     ~DevBuf() { release(); }
 };
@@ -114,6 +124,8 @@ struct lwhip_context
     int laneD = 0, laneLR = 0, laneR = 0;
     DevBuf<DevPostProg> postProg;
     DevBuf<double> geoT;
+    double* lsDbgHost = nullptr; // LWHIP_LS_TIMING: phase clocks of the last sweep, [nTiles][8]
+    DevBuf<double> depArena; // lane sweep: n | wphi | ratio | geoT in one allocation (one buffer resource in the kernel)
     int tileWaves = 4, maxSlotsTile = 0, maxCTTile = 1, maxCTPost = 1, tileCap = 0, ktStride = 4;
     int64_t rowsTileTot = 0, momTot = 0, phiTTot = 0;
     int preCols = 0;              // most level-sum columns a tile's rows need (LDS columns of the pre-pass)
@@ -826,10 +838,17 @@ int build_tables(lwhip_context* c)
         };
         lanePostProgram = post_program;
         {
+            // Which sweep: measured on MI355X (tools/size_sweep.sh, profiles/r03_size_sweep.md) the lane sweep is the
+            // faster one while its wavefronts (one per R wavelengths) fit the chip in one round of two per SIMD -- shards
+            // of a strong-scaled problem, PRD sub-problems, small grids --, the ray-column march above that (and for
+            // column batches, where the wavefronts of all columns count).  LWHIP_SWEEP=lanes|march forces one.
             const char* sw = std::getenv("LWHIP_SWEEP");
             int D = 0, LR = 0, R = 0;
-            if (!(sw && std::strcmp(sw, "march") == 0) && env_int("LWHIP_TILE_GENERIC", 0) == 0
-                && lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R))
+            const bool supported = lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R);
+            const bool force = sw && std::strcmp(sw, "lanes") == 0;
+            const long waves = supported ? ((long)c->Nla + R - 1) / R * std::max(c->batchHint, 1) : 0;
+            const bool prefer = force || (!sw && waves <= 2L * 4 * numCU);
+            if (!(sw && std::strcmp(sw, "march") == 0) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
                 bool ok = true;
                 for (int la = 0; la < c->Nla && ok; ++la)
@@ -1365,10 +1384,25 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(hipMemset(c->aDamp.p, 0, c->aDamp.n * sizeof(double)));
     HIP_TRY(c->Qelast.alloc((size_t)std::max(c->Nline, 1) * Ns));
     HIP_TRY(hipMemset(c->Qelast.p, 0, c->Qelast.n * sizeof(double)));
-    HIP_TRY(c->n.alloc((size_t)c->NlevTot * Ns));
+    if (c->laneSweep)
+    {
+        // the depth-only pools the lane sweep reads, back to back (+ padding: a ray's last block reads past its row)
+        const size_t nN = (size_t)c->NlevTot * Ns, nW = (size_t)std::max(c->Nline, 1) * Ns, nR = (size_t)std::max(c->Ncont, 1) * Ns;
+        const size_t nG = (size_t)4 * (c->laneLR * c->laneD + 2);
+        HIP_TRY(c->depArena.alloc(nN + nW + nR + nG + 16));
+        HIP_TRY(hipMemset(c->depArena.p, 0, c->depArena.n * sizeof(double)));
+        c->n.view(c->depArena.p, nN);
+        c->wphi.view(c->depArena.p + nN, nW);
+        c->ratio.view(c->depArena.p + nN + nW, nR);
+        c->geoT.view(c->depArena.p + nN + nW + nR, nG);
+    }
+    else
+    {
+        HIP_TRY(c->n.alloc((size_t)c->NlevTot * Ns));
+        HIP_TRY(c->ratio.alloc((size_t)std::max(c->Ncont, 1) * Ns));
+        HIP_TRY(c->wphi.alloc((size_t)std::max(c->Nline, 1) * Ns));
+    }
     HIP_TRY(c->nTotal.alloc((size_t)c->Natom * Ns));
-    HIP_TRY(c->ratio.alloc((size_t)std::max(c->Ncont, 1) * Ns));
-    HIP_TRY(c->wphi.alloc((size_t)std::max(c->Nline, 1) * Ns));
     HIP_TRY(c->phi.alloc((size_t)std::max<int64_t>(c->phiTot, 1)));
     HIP_TRY(c->rho.alloc((size_t)std::max<int64_t>(c->rhoTot, 1)));
     HIP_TRY(c->Gamma.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
@@ -1393,7 +1427,6 @@ int alloc_state(lwhip_context* c)
         {
             // the padding points of the row blocks (k >= Ns) are read: keep them finite
             HIP_TRY(hipMemset(c->rowsTile.p, 0, c->rowsTile.n * sizeof(double)));
-            HIP_TRY(c->geoT.alloc((size_t)4 * (c->laneLR * c->laneD + 2)));
         }
         HIP_TRY(c->momTile.alloc((size_t)std::max<int64_t>(c->momTot, 1)));
         HIP_TRY(c->phiT.alloc((size_t)std::max<int64_t>(c->phiTTot, 1)));
@@ -1618,7 +1651,23 @@ int build_tile_args(lwhip_context* c)
         a.postProg = c->postProg.p;
         a.phiDoubles = c->phi.n;
         a.rhoDoubles = c->rho.n;
-        a.ratioDoubles = c->ratio.n;
+        a.depBase = c->depArena.p;
+        a.depBytes = (uint32_t)(c->depArena.n * sizeof(double));
+        a.depN = (uint32_t)((c->n.p - c->depArena.p) * sizeof(double));
+        a.depW = (uint32_t)((c->wphi.p - c->depArena.p) * sizeof(double));
+        a.depRat = (uint32_t)((c->ratio.p - c->depArena.p) * sizeof(double));
+        a.depG = (uint32_t)((c->geoT.p - c->depArena.p) * sizeof(double));
+        a.lsDbg = nullptr;
+        if (std::getenv("LWHIP_LS_TIMING"))
+        {
+            // phase clocks of a -DLS_TIMING build: host-mapped, dumped by lwhip_destroy
+            if (!c->lsDbgHost)
+            {
+                HIP_TRY(hipHostMalloc((void**)&c->lsDbgHost, (size_t)c->nTiles * 8 * sizeof(double), hipHostMallocMapped));
+                std::memset(c->lsDbgHost, 0, (size_t)c->nTiles * 8 * sizeof(double));
+            }
+            HIP_TRY(hipHostGetDevicePointer((void**)&a.lsDbg, c->lsDbgHost, 0));
+        }
     }
     c->htargs = a;
     std::vector<TileArgs> v(1, a);
@@ -1846,6 +1895,20 @@ int lwhip_destroy(lwhip_context* c)
         return LWHIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->lsDbgHost)
+    {
+        double sum[8] = { 0 }, mx = 0.0;
+        for (int t = 0; t < c->nTiles; ++t)
+        {
+            for (int q = 0; q < 8; ++q)
+                sum[q] += c->lsDbgHost[(size_t)t * 8 + q];
+            mx = std::max(mx, c->lsDbgHost[(size_t)t * 8 + 7]);
+        }
+        std::fprintf(stderr, "lane sweep phase clocks per tile (mean): setup %.0f gather %.0f stencils %.0f coefficients %.0f scan %.0f rates %.0f finish %.0f total %.0f (max %.0f) over %d tiles\n",
+                     sum[0] / c->nTiles, sum[1] / c->nTiles, sum[2] / c->nTiles, sum[3] / c->nTiles, sum[4] / c->nTiles, sum[5] / c->nTiles,
+                     sum[6] / c->nTiles, sum[7] / c->nTiles, mx, c->nTiles);
+        (void)hipHostFree(c->lsDbgHost);
+    }
     delete c;
     return LWHIP_OK;
 }

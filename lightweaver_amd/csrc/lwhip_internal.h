@@ -257,7 +257,12 @@ struct TileArgs
     const double* phi;             // [line][lt][Nmu][2][Ns] pool (the caller's layout)
     const double* geoT;            // [4][laneLRD + 2], entry k + 1: |h_k - h_k+1|, its reciprocal, 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k
     const DevPostProg* postProg;   // [nTiles]
-    uint64_t phiDoubles, rhoDoubles, ratioDoubles; // pool sizes (buffer ranges)
+    uint64_t phiDoubles, rhoDoubles; // pool sizes (buffer ranges)
+    // the depth arena: populations, w_phi, nStar ratios and the transposed geometry in ONE allocation (one buffer
+    // resource, byte offsets)
+    const double* depBase;
+    uint32_t depBytes, depN, depW, depRat, depG, _padD;
+    double* lsDbg;                 // diagnostic builds (-DLS_TIMING): [nTiles][8] phase clocks, host-mapped; else null
 };
 struct TileDyn
 {

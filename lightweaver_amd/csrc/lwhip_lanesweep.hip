@@ -56,6 +56,29 @@ template <int N> DEVINL void ls_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsi
     if (N & 1)
         x[N - 1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff + (unsigned)(N - 1) * 8u), (int)soff, 0));
 }
+// N consecutive doubles of the workgroup's LDS copy of the depth arena: byte offset voff (per lane) + soff (uniform)
+template <int N> DEVINL void ls_lds(const char* base, unsigned voff, unsigned soff, double (&x)[N])
+{
+    const double* p = (const double*)(base + voff + soff);
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        x[q] = p[q];
+}
+#ifdef LS_DBG_NO_ATOMIC
+#define lds_add(p, v) ((void)(p), (void)(v))
+#endif
+// N consecutive doubles at base (uniform) + soff (uniform) + voff (per lane) bytes of a global array: a 64-bit scalar base and
+// a 32-bit lane offset per load, no buffer descriptor (four SGPRs each, and the kernel is short of them).  The pools these
+// loads touch are padded: a ray's last block reads up to 24 bytes past its row.
+template <int N> DEVINL void ls_gld(const double* base, unsigned voff, unsigned soff, double (&x)[N])
+{
+    const GLOBAL_AS char* b = (const GLOBAL_AS char*)base + soff;
+    asm volatile("" : "+s"(b)); // (the uniform part of the address stays a scalar add: folded into the lane offset it costs a VGPR per load)
+    const GLOBAL_AS double* p = (const GLOBAL_AS double*)(b + voff);
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        x[q] = p[q];
+}
 DEVINL double ls_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
@@ -78,19 +101,18 @@ DEVINL double ls_bperm(double v, int srcLane)
     return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 // Inclusive scan of the affine maps I -> E I + B along the march: lane order (down rays) or reverse lane order (up rays).
-// Afterwards a lane holds the composition of every map from the start of the wave up to and including its own.
+// Afterwards a lane holds the composition of every map from the start of the wave up to and including its own.  Each
+// step fetches the partial composite of the lane 1, 2, 4 ... positions upwind (ds_bpermute): the combination tree of a
+// lane depends only on its distance from its ray's first point -- everything upwind of that point is multiplied by an
+// exact 0 --, so the intensities do not depend on which ray slot of the wavefront a wavelength sits in (row-relative DPP
+// shifts would make them: J must not change in the last bit when the wavelength grid is sharded differently).
 template <bool UP> DEVINL void ls_scan(double& E, double& B, const int lane)
 {
-    if (!UP)
-    {
-        affine_scan_wave(E, B); // DPP row shifts + row broadcasts (lwhip_device.h)
-        return;
-    }
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1)
     {
-        const int src = lane + s;
-        const bool ok = src < 64;
+        const int src = UP ? lane + s : lane - s;
+        const bool ok = UP ? src < 64 : src >= 0;
         const double Ep = ls_bperm(E, src), Bp = ls_bperm(B, src);
         const double Bn = fma(E, Bp, B), En = E * Ep; // (Ep, Bp) is applied first
         B = ok ? Bn : B;
@@ -104,56 +126,95 @@ DEVINL double ls_rcp(double x)
     const double e = fma(-x, r, 1.0);
     return fma(r, e, r);
 }
-// exp(x) for -700 < x <= 0: range reduction + the degree-13 polynomial split into its even and odd part
-DEVINL double ls_exp_neg(double x)
+// exp(x) for -700 < x <= 0: x = (32 m + j) ln2 / 32 + r, |r| <= ln2 / 64; 2^(j/32) from a 32-entry LDS table, exp(r) by a
+// degree-6 polynomial (truncation 3e-18), 2^m by ldexp: seven constants and six dependent FMAs instead of fifteen and
+// thirteen
+enum { LS_EXP_TAB = 32 };
+DEVINL void ls_exp_table_init(double* tab, int t)
 {
-    const double n = rint(x * 1.4426950408889634074);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    const double r2 = r * r;
-    double pe = 1.0 / 479001600.0, po = 1.0 / 6227020800.0;
-    pe = fma(pe, r2, 1.0 / 3628800.0);
-    po = fma(po, r2, 1.0 / 39916800.0);
-    pe = fma(pe, r2, 1.0 / 40320.0);
-    po = fma(po, r2, 1.0 / 362880.0);
-    pe = fma(pe, r2, 1.0 / 720.0);
-    po = fma(po, r2, 1.0 / 5040.0);
-    pe = fma(pe, r2, 1.0 / 24.0);
-    po = fma(po, r2, 1.0 / 120.0);
-    pe = fma(pe, r2, 0.5);
-    po = fma(po, r2, 1.0 / 6.0);
-    pe = fma(pe, r2, 1.0);
-    po = fma(po, r2, 1.0);
-    return ldexp(fma(po, r, pe), (int)n);
+    if (t < LS_EXP_TAB)
+        tab[t] = exp2((double)t * (1.0 / LS_EXP_TAB));
+}
+DEVINL double ls_exp_neg(double x, const double* tab)
+{
+#ifdef LS_DBG_FAKE_EXP
+    return 1.0 + x;
+#endif
+    // (the constants are pinned to SGPR pairs where they are used: left alone the compiler parks them in VGPRs for the
+    // whole kernel)
+    double k0 = 46.166241308446828384, k1 = -2.16608493865351192653e-02, k2 = -5.96317165397058656257e-12; // 32 / ln2; ln2 / 32 head, tail
+    double c6 = 1.0 / 720.0, c5 = 1.0 / 120.0, c4 = 1.0 / 24.0, c3 = 1.0 / 6.0;
+    asm volatile("" : "+s"(k0), "+s"(k1), "+s"(k2), "+s"(c6), "+s"(c5), "+s"(c4), "+s"(c3));
+    const double n = rint(x * k0);
+    double r = fma(n, k1, x);
+    r = fma(n, k2, r);
+    const int ni = (int)n;
+    const double T = tab[ni & (LS_EXP_TAB - 1)];
+    double p = fma(r, c6, c5);
+    p = fma(p, r, c4);
+    p = fma(p, r, c3);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(T * p, ni >> 5);
+}
+// planck_nu at one temperature (LwMisc.hpp:29-46) with the exponential above: B = c e / (1 - e), e = exp(-x)
+DEVINL double ls_planck(double T, double lambda, const double* tab)
+{
+    const double hc_kla = HC_K / lambda;
+    const double twohnu3_c2 = TWO_HC_NM3 / (lambda * lambda * lambda);
+    const double x = hc_kla / T;
+    const double e = ls_exp_neg(-fmin(x, 150.0), tab);
+    return (x <= 150.0) ? twohnu3_c2 * e / (1.0 - e) : 0.0;
 }
 
 enum { LS_MAX_WAVES = 8, LS_MAX_R = 16 };
+#ifndef LS_ACC0_REG
+#define LS_ACC0_REG 0
+#endif
 #define LS_KEEP(v) asm volatile("" : "+v"(v)) /* the value is computed here, on every lane (keeps selects branch-free) */
+#define LS_KEEPI(v) asm volatile("" : "+v"(v))
 #define LS_PHASE() __builtin_amdgcn_sched_barrier(0) /* the scheduler does not move code across phase boundaries */
 
+// Phase timers of a diagnostic build (-DLS_TIMING): shader clocks per phase, summed over the rays of a tile, written to
+// TileArgs::lsDbg[tile][8] = setup, gather, stencils, coefficients, scan, rates, finish, total.
+#ifdef LS_TIMING
+#define LS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LS_TACC(acc, a0, a1) acc += (a1) - (a0)
+#else
+#define LS_T(var)
+#define LS_TACC(acc, a0, a1)
+#endif
 // What a lane is in its tile, and the buffers every phase reads.
 struct LaneCtx
 {
-    int Ns, Nmu, LRD, L;
-    int lane, rRaw, blk, r, k0, la, nV, pBot; // nV: valid points of the block; pBot: index of depth Ns - 1 in the block (if in range)
+    int Ns, Nmu, LRD, LR, L;
+    int lane, rRaw, blk, r, k0, la, nV, pBot, ti; // nV: valid points of the block; pBot: index of depth Ns - 1 in the block (if in range)
     bool act;
     double wav;
     unsigned vK, vRow, rowStride, Ns8, gStride;
-    __amdgpu_buffer_rsrc_t rRows, rN, rW, rG;
+    unsigned oN, oW, oRat, oG;                 // byte offsets of the population, w_phi, nStar-ratio pools and the geometry in the depth arena
+    const double* rRows;                       // the tile's row block
+    const char* sDep;                          // the workgroup's LDS copy of the depth arena
+    double* sRow3;                             // the wavefront's LDS copy of its tile's rows chi_C, eta_C, sigma J: [3][64][D]
+    double* sB;                                // the wavefront's LDS row [R][4]: Planck functions of the rays' end points
+    const double* sExp;                        // the workgroup's 2^(j/32) table
 };
 
 // The rays of one tile: NL / NM line / mixed-continuum slots.  Leaves J and the Psi* moments of the lane's points in
-// Jk / M1 / Me and adds the slots' integrals to the workgroup's accumulators.
+// Jk / M1 / Me (Me[0] alone if the tile has fewer than two lines: its moment slot is returned) and adds the slots'
+// integrals to the workgroup's accumulators.
 template <int SOLVER, int D, int NL, int NM, bool RATES>
-DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const LaneCtx& c, double* sAcc,
-                      double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
+DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const LaneCtx& c, double* sAcc,
+                     double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
 {
     constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
-    const int Ns = c.Ns, Nmu = c.Nmu, LRD = c.LRD;
+    const int Ns = c.Ns, Nmu = c.Nmu, LR = c.LR;
     const int la = c.la, k0 = c.k0;
     const bool act = c.act;
-    const unsigned vK = c.vK, vRow = c.vRow, rowStride = c.rowStride, Ns8 = c.Ns8;
-    const __amdgpu_buffer_rsrc_t rRows = c.rRows, rN = c.rN, rW = c.rW, rG = c.rG;
+    const unsigned rowStride = c.rowStride, Ns8 = c.Ns8;
+    const double* rRows = c.rRows;
+    const char* sDep = c.sDep;
 
     // ---- slot structure (uniform) and per-lane parameters -------------------------------------------------------------
     const CONST_AS DevTileSlot* ts = CTAB(DevTileSlot, a.tslots) + td.slotOff;
@@ -161,9 +222,10 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     unsigned lnI[NLc], lnJ[NLc], lwO[NLc], lrow[NLc], lacc[NLc];
     int lgi[NLc], lgj[NLc], lat[NLc], lfl[NLc], lms[NLc], lzm[NLc];
     double la0[NLc], la2[NLc], la3[NLc], lcw1[NLc]; // per lane
-    __amdgpu_buffer_rsrc_t rPhi[NLc], rRho[NLc];
-    const unsigned vPhi = (unsigned)c.r * (unsigned)(Nmu * 2) * Ns8 + vK;
-    const unsigned vRho = (unsigned)c.r * Ns8 + vK;
+    const double* rPhi[NLc];
+    const double* rRho[NLc];
+    const unsigned vPhi0 = (unsigned)c.r * (unsigned)(Nmu * 2) * Ns8 + c.vK;
+    const unsigned vRho0 = (unsigned)c.r * Ns8 + c.vK;
 #pragma unroll
     for (int s = 0; s < NLc; ++s)
     {
@@ -173,25 +235,25 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
         lms[s] = -1;
         lzm[s] = 31;
         la0[s] = la2[s] = la3[s] = lcw1[s] = 0.0;
-        rPhi[s] = ls_rsrc(a.phi, 0);
-        rRho[s] = ls_rsrc(a.rho, 0);
+        rPhi[s] = a.phi;
+        rRho[s] = a.rho;
         if (s < NL)
         {
             const DevTileSlot u = ld_c(ts + s);
-            lnI[s] = (unsigned)u.gi * Ns8;
-            lnJ[s] = (unsigned)u.gj * Ns8;
-            lwO[s] = (unsigned)u.row * Ns8;
+            lnI[s] = c.oN + (unsigned)u.gi * Ns8;
+            lnJ[s] = c.oN + (unsigned)u.gj * Ns8;
+            lwO[s] = c.oW + (unsigned)u.row * Ns8;
             lrow[s] = (unsigned)u.r0 * rowStride;
-            lacc[s] = (unsigned)(u.cs * 4 * LRD);
+            lacc[s] = (unsigned)(u.cs * 4 * c.LRD);
             lgi[s] = u.gi;
             lgj[s] = u.gj;
             lat[s] = u.atom;
             lfl[s] = u.flags;
             lms[s] = (u.flags & 1) ? u.ms : -1;
             lzm[s] = (u.flags & 1) ? u.zmask : 31;
-            rPhi[s] = ls_rsrc(a.phi + u.phiOff, (a.phiDoubles - (unsigned long long)u.phiOff) * 8ull);
+            rPhi[s] = a.phi + u.phiOff;
             if (u.flags & 2)
-                rRho[s] = ls_rsrc(a.rho + u.rhoOff, (a.rhoDoubles - (unsigned long long)u.rhoOff) * 8ull);
+                rRho[s] = a.rho + u.rhoOff;
             const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
             la0[s] = sl->p[0];
             la2[s] = sl->p[2];
@@ -214,7 +276,7 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
             const DevTileSlot u = ld_c(ts + NL + m);
             mrow[m] = (unsigned)u.r0 * rowStride;
             maux[m] = (unsigned)max((int)u.rAux, 0) * rowStride;
-            macc[m] = (unsigned)(u.cs * 4 * LRD);
+            macc[m] = (unsigned)(u.cs * 4 * c.LRD);
             mgi[m] = u.gi;
             mgj[m] = u.gj;
             mat[m] = u.atom;
@@ -248,40 +310,89 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
 
     const bool storeDepth = RATES && a.storeDepth && !dyn.prdOnly;
     const double lamf = dyn.lambdaIterate ? 0.0 : 1.0;
+    // which moment row a line's Psi* eta goes to: with fewer than two lines row 0 stands for the line's moment slot
+    const int meSlot0 = NL == 1 ? lms[0] : 0;
 
-    // boundary intensities of the rays (wrappers FormalScalar.cpp:471-666): Planck functions of the two end points
-    double Bd0 = 0.0, Bd1 = 0.0, Bu0 = 0.0, Bu1 = 0.0;
+    // the ray-independent rows chi_C, eta_C, sigma J of the lane's points: once from memory into the wavefront's LDS block
+    {
+        double t0[D], t1[D], t2[D];
+        ls_gld<D>(rRows, c.vRow, 0u, t0);
+        ls_gld<D>(rRows, c.vRow, rowStride, t1);
+        ls_gld<D>(rRows, c.vRow, 2u * rowStride, t2);
+        double* r3 = c.sRow3 + c.lane * D;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+        {
+            r3[p] = t0[p];
+            r3[64 * D + p] = t1[p];
+            r3[2 * 64 * D + p] = t2[p];
+        }
+    }
+    // boundary intensities of the rays (wrappers FormalScalar.cpp:471-666): Planck functions of the two end points of
+    // this lane's wavelength, parked in the wavefront's LDS row (read by the lane that holds a ray's first point)
+    if (c.blk == 0 && c.rRaw < LS_MAX_R)
     {
         const CONST_AS double* T = CTAB(double, a.temperature);
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
         if (a.upperBc == LWHIP_BC_THERMALISED && dyn.nPass == 2)
         {
-            Bd0 = d_planck(T[0], c.wav);
-            Bd1 = d_planck(T[1], c.wav);
+            b0 = ls_planck(T[0], c.wav, c.sExp);
+            b1 = ls_planck(T[1], c.wav, c.sExp);
         }
         if (a.lowerBc == LWHIP_BC_THERMALISED)
         {
-            Bu0 = d_planck(T[Ns - 2], c.wav);
-            Bu1 = d_planck(T[Ns - 1], c.wav);
+            b2 = ls_planck(T[Ns - 2], c.wav, c.sExp);
+            b3 = ls_planck(T[Ns - 1], c.wav, c.sExp);
+        }
+        c.sB[c.rRaw * 4 + 0] = b0;
+        c.sB[c.rRaw * 4 + 1] = b1;
+        c.sB[c.rRaw * 4 + 2] = b2;
+        c.sB[c.rRaw * 4 + 3] = b3;
+    }
+
+    // The integrals of the slots at this lane's points go to the workgroup's LDS accumulators ray by ray:
+    // [slot][quantity][point of the block][block], so that the lanes of a ray hit consecutive addresses (the R rays of
+    // the wavefront meet at one address: an LDS atomic without return serialises them).
+#ifdef LS_DBG_NOCONFLICT
+    double* accBase = sAcc + c.lane; // timing experiment: the rays of a wavefront do not meet at one address (wrong sums)
+#else
+    double* accBase = sAcc + c.blk;
+#endif
+    // ... except, in an experiment build (-DLS_ACC0_REG=1), the first line's: its sums stay in registers for the whole tile
+    // (an LDS f64 atomic costs ~25 clocks per wavefront instruction) -- measured: the kernel then spills at 256 VGPRs
+    double acc0[4][D];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+            acc0[q][p] = 0.0;
+
+    // the profiles are the one stream that comes from HBM: a ray's block is requested one ray ahead
+    double phiN[NLc][D];
+    {
+        const unsigned sRay0 = (unsigned)(dyn.nPass == 2 ? 0 : 1) * Ns8;
+#pragma unroll
+        for (int s = 0; s < NLc; ++s)
+        {
+            if (s < NL)
+                ls_gld<D>(rPhi[s], vPhi0, sRay0, phiN[s]);
+            else
+            {
+#pragma unroll
+                for (int p = 0; p < D; ++p)
+                    phiN[s][p] = 0.0;
+            }
         }
     }
 
-    // the integrals of the slots at this lane's points, summed over the rays
-    double accL[NLc][4][D], accM[NMc][4][D];
-#pragma unroll
-    for (int p = 0; p < D; ++p)
-    {
-#pragma unroll
-        for (int s = 0; s < NLc; ++s)
-            accL[s][0][p] = accL[s][1][p] = accL[s][2][p] = accL[s][3][p] = 0.0;
-#pragma unroll
-        for (int m = 0; m < NMc; ++m)
-            accM[m][0][p] = accM[m][1][p] = accM[m][2][p] = accM[m][3][p] = 0.0;
-    }
-
+#ifdef LS_TIMING
+    unsigned long long tmA = 0, tmB = 0, tmC = 0, tmS = 0, tmD = 0, tmBprev = 0;
+#endif
     // ---- one ray of every wavelength of the tile ------------------------------------------------------------------------
-    auto pass = [&](auto upTag, const int mu) {
+    auto pass = [&](auto upTag, const int mu, const unsigned sRayNext) {
         constexpr bool UP = decltype(upTag)::value;
         constexpr int dirI = UP ? 1 : 0;
+        LS_T(tp0);
 #define MI(i) (UP ? D - 1 - (i) : (i)) /* march index <-> index in the lane's k-ordered block (an involution) */
 #define IV(i) (UP ? D - (i) : (i))     /* interval i (march point i-1 -> i) -> index in dhK / rdhK */
         const double muz = CTAB(double, a.muz)[mu];
@@ -290,29 +401,44 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
         const unsigned sRay = (unsigned)(mu * 2 + dirI) * Ns8;
         const int bcType = UP ? a.lowerBc : a.upperBc;
         // the ray's first point is depth 0 (down: march index 0 of block 0) or depth Ns - 1 (up), its last the other one
-        auto is_first = [&](int i) { return UP ? MI(i) == c.pBot : (i == 0 && c.blk == 0); };
-        auto is_last = [&](int i) { return UP ? (i == D - 1 && c.blk == 0) : MI(i) == c.pBot; };
-        auto is_ok = [&](int i) { return MI(i) < c.nV; };
+        // (re-derived per ray from the lane's integers: hoisted out of the ray loop they would sit in two dozen SGPRs)
+        int pBot = c.pBot, blk = c.blk, nV = c.nV;
+        LS_KEEPI(pBot);
+        LS_KEEPI(blk);
+        LS_KEEPI(nV);
+        auto is_first = [&](int i) { return UP ? MI(i) == pBot : (i == 0 && blk == 0); };
+        auto is_last = [&](int i) { return UP ? (i == D - 1 && blk == 0) : MI(i) == pBot; };
+        auto is_ok = [&](int i) { return MI(i) < nV; };
 
+        // (the address registers are re-issued per phase: otherwise the compiler keeps what one phase loaded alive for the
+        // next phase, the other direction and the next ray instead of re-reading 32 bytes from the L1)
         // ---- A. gather: Transition::uv + chi_eta_aux_accum + compute_source_fn at the lane's points (march order) ----
         double chi[D], S[D], rch[D];
-        double vij[NLc][D], vji[NLc][D];
+        double dhK[D + 1], rdhK[D + 1], rsumK[D]; // geometry of the block (used by the stencils, requested with the gather's loads)
         {
-            double cC[D], eC[D], sc[D];
-            ls_ld<D>(rRows, vRow, 0u, cC);
-            ls_ld<D>(rRows, vRow, rowStride, eC);
-            ls_ld<D>(rRows, vRow, 2u * rowStride, sc);
+            unsigned vK = c.vK, vRow = c.vRow, vPhi = vPhi0, vRho = vRho0;
+            LS_KEEPI(vK);
+            LS_KEEPI(vRow);
+            LS_KEEPI(vPhi);
+            LS_KEEPI(vRho);
+            double cC[D], eC[D];
+            const double* r3 = c.sRow3 + c.lane * D;
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+            {
+                cC[p] = r3[p];
+                eC[p] = r3[64 * D + p];
+            }
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
             {
                 if (s < NL)
                 {
                     double phi[D], ni[D], nj[D], rho[D];
-                    ls_ld<D>(rPhi[s], vPhi, sRay, phi);
-                    ls_ld<D>(rN, vK, lnI[s], ni);
-                    ls_ld<D>(rN, vK, lnJ[s], nj);
+                    ls_lds<D>(sDep, vK, lnI[s], ni);
+                    ls_lds<D>(sDep, vK, lnJ[s], nj);
                     if (lfl[s] & 2)
-                        ls_ld<D>(rRho[s], vRho, 0u, rho);
+                        ls_gld<D>(rRho[s], vRho, 0u, rho);
                     else
                     {
 #pragma unroll
@@ -321,30 +447,18 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                     }
 #pragma unroll
                     for (int p = 0; p < D; ++p)
+                        phi[p] = phiN[s][p];
+                    ls_gld<D>(rPhi[s], vPhi, sRayNext, phiN[s]); // the next ray's profile
+#pragma unroll
+                    for (int p = 0; p < D; ++p)
                     {
                         const double v1 = la0[s] * phi[p];
                         const double v2 = (la2[s] * rho[p]) * v1;
                         const double uji = la3[s] * v2;
                         cC[p] += ni[p] * v1 - nj[p] * v2;
                         eC[p] += nj[p] * uji;
-                        vij[s][MI(p)] = v1;
-                        vji[s][MI(p)] = v2;
                     }
                 }
-                else
-                {
-#pragma unroll
-                    for (int p = 0; p < D; ++p)
-                        vij[s][p] = vji[s][p] = 0.0;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < D; ++p)
-            {
-                const double rc = ls_rcp(cC[p]);
-                chi[MI(p)] = cC[p];
-                rch[MI(p)] = rc;
-                S[MI(p)] = (eC[p] + sc[p]) * rc;
             }
             if (storeDepth && act)
             {
@@ -357,8 +471,24 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                         GD(a.depthEta)[o + p] = eC[p];
                     }
             }
+            double sc[D];
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+                sc[p] = r3[2 * 64 * D + p];
+            ls_lds<D + 1>(sDep, vK, c.oG, dhK); // entry k + 1 holds |h_k - h_k+1|: dhK[q] = dh[k0 - 1 + q]
+            ls_lds<D + 1>(sDep, vK, c.oG + c.gStride, rdhK);
+            ls_lds<D>(sDep, vK + 8u, c.oG + 2u * c.gStride, rsumK); // rsumK[p] = rsum[k0 + p]
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+            {
+                const double rc = ls_rcp(cC[p]);
+                chi[MI(p)] = cC[p];
+                rch[MI(p)] = rc;
+                S[MI(p)] = (eC[p] + sc[p]) * rc;
+            }
         }
         LS_PHASE();
+        LS_T(tp1);
         // halo: the last point of the upwind lane (P), the first point of the downwind lane (N)
         const double chiP = ls_shift1<!UP>(chi[D - 1]), SP = ls_shift1<!UP>(S[D - 1]);
         const double chiN = ls_shift1<UP>(chi[0]), SN = ls_shift1<UP>(S[0]);
@@ -371,10 +501,6 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
             // piecewise_bezier3_1d_impl FormalScalar.cpp:209-325, every quantity of the march formed per point
             double x[D], dS[D], dSP; // optical depth of the intervals, dS / dtau at the points
             {
-                double dhK[D + 1], rdhK[D + 1], rsumK[D];
-                ls_ld<D + 1>(rG, vK, 0, dhK); // entry k + 1 holds |h_k - h_k+1|: dhK[q] = dh[k0 - 1 + q]
-                ls_ld<D + 1>(rG, vK, c.gStride, rdhK);
-                ls_ld<D>(rG, vK + 8u, 2u * c.gStride, rsumK); // rsumK[p] = rsum[k0 + p]
                 double ds[D + 1], sl[D + 1];
 #pragma unroll
                 for (int i = 0; i <= D; ++i)
@@ -442,7 +568,9 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                         if (bcType == LWHIP_BC_THERMALISED)
                         {
                             const double dtb = ((0.5 * zmu) * (CHI(i) + CHI(i + 1))) * dhK[IV(i + 1)];
-                            Ib = UP ? Bu1 - (Bu0 - Bu1) / dtb : Bd0 - (Bd1 - Bd0) / dtb;
+                            const double* sb = c.sB + min(c.rRaw, LS_MAX_R - 1) * 4 + (UP ? 2 : 0);
+                            const double B0 = sb[0], B1 = sb[1];
+                            Ib = UP ? B1 - (B0 - B1) / dtb : B0 - (B1 - B0) / dtb;
                         }
                         else if (bcType == LWHIP_BC_CALLABLE)
                         {
@@ -455,52 +583,41 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                 }
             }
             LS_PHASE();
+            LS_T(tp2);
+            LS_TACC(tmB, tp1, tp2);
             // Bezier3_coeffs (Bezier.hpp:81-127) and the update :265-275 as a map
-#ifdef LS_DBG_SKIP_C
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-            {
-                ee[i] = x[i] * SRC(i - 1);
-                bb[i] = dS[i] + (i == 0 ? dSP : 0.0) + bb[i];
-                PsiS[i] = rch[i];
-            }
-#else
 #pragma unroll
             for (int i = 0; i < D; ++i)
             {
                 const double Su = SRC(i - 1), S0 = S[i];
                 const double xi = x[i];
                 const double x2 = xi * xi, x3 = x2 * xi;
-                const double exr = ls_exp_neg(-fmin(xi, 64.0));
+                const double exr = ls_exp_neg(-fmin(xi, 64.0), c.sExp);
                 const double ex = (xi > 30.0) ? 0.0 : exr;
                 const double r3 = ls_rcp(x3);
                 const bool small = xi < 5e-2;
-                // both branches are evaluated on every lane and selected: straight-line code
-                double alG = (6.0 - ex * (6.0 + 6.0 * xi + 3.0 * x2 + x3)) * r3;
-                double beG = (6.0 * ex - 6.0 + 6.0 * xi - 3.0 * x2 + x3) * r3;
-                double gaG = 3.0 * (2.0 * xi - 6.0 + ex * (6.0 + 4.0 * xi + x2)) * r3;
-                double deG = 3.0 * (6.0 - 4.0 * xi + x2 - 2.0 * ex * (3.0 + xi)) * r3;
-                double alT = 0.25 * xi - 0.2 * x2 + x3 * (1.0 / 12.0);
-                double beT = 0.25 * xi - 0.05 * x2 + x3 * (1.0 / 120.0);
-                double gaT = 0.25 * xi - 0.15 * x2 + 0.05 * x3;
-                double deT = 0.25 * xi - 0.1 * x2 + 0.025 * x3;
-                double edT = 1.0 - xi + 0.5 * x2 - x3 * (1.0 / 6.0);
-                LS_KEEP(alG);
-                LS_KEEP(beG);
-                LS_KEEP(gaG);
-                LS_KEEP(deG);
-                LS_KEEP(alT);
-                LS_KEEP(beT);
-                LS_KEEP(gaT);
-                LS_KEEP(deT);
-                LS_KEEP(edT);
-                const double al = small ? alT : alG, be = small ? beT : beG, ga = small ? gaT : gaG, de = small ? deT : deG;
-                const double edt = small ? edT : ex;
+                // both branches are evaluated on every lane and selected at once: straight-line code, two values in flight
+                auto pick = [&](double g, double t) {
+                    LS_KEEP(g);
+                    LS_KEEP(t);
+                    double r = small ? t : g;
+                    LS_KEEP(r);
+                    return r;
+                };
+                // (the Taylor branch with two constants: q = x^2 / 20, t = x^3 / 120)
+                const double xq = 0.25 * xi, q = 0.05 * x2, t3 = x3 * (1.0 / 120.0);
+                const double al = pick((6.0 - ex * (6.0 + 6.0 * xi + 3.0 * x2 + x3)) * r3, xq - 4.0 * q + 10.0 * t3);
+                const double be = pick((6.0 * ex - 6.0 + 6.0 * xi - 3.0 * x2 + x3) * r3, xq - q + t3);
+                const double ga = pick(3.0 * (2.0 * xi - 6.0 + ex * (6.0 + 4.0 * xi + x2)) * r3, xq - 3.0 * q + 6.0 * t3);
+                const double de = pick(3.0 * (6.0 - 4.0 * xi + x2 - 2.0 * ex * (3.0 + xi)) * r3, xq - 2.0 * q + 3.0 * t3);
+                const double edt = pick(ex, 1.0 - xi + 0.5 * x2 - 20.0 * t3);
                 const double x_3 = xi * (1.0 / 3.0);
                 const double dSu = i == 0 ? dSP : dS[i > 0 ? i - 1 : 0];
                 const double Cuw = Su + x_3 * dSu;
                 const double C0 = S0 - x_3 * dS[i];
                 double e1 = edt, b1 = al * Su + be * S0 + ga * Cuw + de * C0, ps = be + de;
+                LS_KEEP(b1); // (the point's coefficients are consumed here, before the next point's are formed)
+                LS_KEEP(ps);
                 if (__builtin_amdgcn_ballot_w64(is_last(i)) != 0)
                 {
                     // w2 (LwInternal.hpp:90-110) of the linear closing step, xi = its optical depth
@@ -536,14 +653,11 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                 ee[i] = e1;
                 bb[i] = b1;
                 PsiS[i] = (ps * rch[i]) * lamf;
-#ifdef LS_SERIAL_C
-                if ((i % LS_SERIAL_C) == LS_SERIAL_C - 1)
-                    LS_PHASE();
-#endif
+                LS_PHASE();
             }
-#endif
         }
         LS_PHASE();
+        LS_T(tp3);
 
         // ---- the recurrence: compose the lane's maps, scan the composites along the ray, expand ----
         double Iv[D];
@@ -565,8 +679,11 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
             }
         }
         LS_PHASE();
+        LS_T(tp4);
 
         // ---- outputs and the sums over the rays ----
+        int la = c.la;
+        LS_KEEPI(la); // (output addresses are formed here, not held from the start of the tile)
         if (UP && act && c.blk == 0)
             GD(a.I)[(size_t)la * Nmu + mu] = Iv[D - 1]; // spect.I(la, mu, 0) :349
         if ((UP ? a.zUp : a.zDown) != nullptr && act)
@@ -595,131 +712,186 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                 Jk[MI(i)] += hw * Iv[i]; // accumulate_J :181-190
                 M1[MI(i)] += wPsi[i];
             }
-            // the lines' opacities at the points (populations of the depth, V_ij / V_ji of the gather)
-            double xl[NLc][D], el[NLc][D], uj[NLc][D];
+#ifndef LS_DBG_SKIP_D
+            // The rate integrals, half a block at a time (bounds what is in flight): V_ij / V_ji again from the profile
+            // (an L1 / L2 hit), the populations, the slots' continuum rows.
+            auto rates_half = [&](auto hTag) {
+                constexpr int H = decltype(hTag)::value; // points p = H .. H + HP - 1 of the block (k order)
+                constexpr int HP = D / 2;
+                unsigned vK = c.vK + (unsigned)H * 8u, vRow = c.vRow + (unsigned)H * 8u, vPhi = vPhi0 + (unsigned)H * 8u,
+                         vRho = vRho0 + (unsigned)H * 8u;
+                LS_KEEPI(vK);
+                LS_KEEPI(vRow);
+                LS_KEEPI(vPhi);
+                LS_KEEPI(vRho);
+                double v1[NLc][HP], v2[NLc][HP], xl[NLc][HP], el[NLc][HP], uj[NLc][HP];
 #pragma unroll
-            for (int s = 0; s < NLc; ++s)
-            {
-                if (s < NL)
+                for (int s = 0; s < NLc; ++s)
                 {
-                    double ni[D], nj[D];
-                    ls_ld<D>(rN, vK, lnI[s], ni);
-                    ls_ld<D>(rN, vK, lnJ[s], nj);
-#pragma unroll
-                    for (int i = 0; i < D; ++i)
+                    if (s < NL)
                     {
-                        uj[s][i] = la3[s] * vji[s][i];
-                        xl[s][i] = ni[MI(i)] * vij[s][i] - nj[MI(i)] * vji[s][i];
-                        el[s][i] = nj[MI(i)] * uj[s][i];
+                        double phi[HP], ni[HP], nj[HP], rho[HP];
+                        ls_gld<HP>(rPhi[s], vPhi, sRay, phi);
+                        ls_lds<HP>(sDep, vK, lnI[s], ni);
+                        ls_lds<HP>(sDep, vK, lnJ[s], nj);
+                        if (lfl[s] & 2)
+                            ls_gld<HP>(rRho[s], vRho, 0u, rho);
+                        else
+                        {
+#pragma unroll
+                            for (int p = 0; p < HP; ++p)
+                                rho[p] = 1.0;
+                        }
+#pragma unroll
+                        for (int p = 0; p < HP; ++p)
+                        {
+                            v1[s][p] = la0[s] * phi[p];
+                            v2[s][p] = (la2[s] * rho[p]) * v1[s][p];
+                            uj[s][p] = la3[s] * v2[s][p];
+                            xl[s][p] = ni[p] * v1[s][p] - nj[p] * v2[s][p];
+                            el[s][p] = nj[p] * uj[s][p];
+                        }
                     }
-                }
-                else
-                {
-#pragma unroll
-                    for (int i = 0; i < D; ++i)
-                        xl[s][i] = el[s][i] = uj[s][i] = 0.0;
-                }
-            }
-            // level sums of a slot: continuum rows + the active lines of this wavelength, selected by the tile's
-            // coupling codes (a line's coupling with itself is known at compile time)
-            auto couple = [&](const int (&cc)[NLc], const int i, double& etaA, double& chi_i, double& chi_j, double& U_i, double& U_j) {
-#pragma unroll
-                for (int l = 0; l < NLc; ++l)
-                {
-                    if (l < NL)
-                    {
-                        const int c5 = cc[l];
-                        etaA += (c5 & 1) ? el[l][i] : 0.0;
-                        chi_i += (c5 & 2) ? xl[l][i] : 0.0;
-                        chi_i -= (c5 & 4) ? xl[l][i] : 0.0;
-                        chi_j += (c5 & 8) ? xl[l][i] : 0.0;
-                        chi_j -= (c5 & 16) ? xl[l][i] : 0.0;
-                        U_j += (c5 & 16) ? uj[l][i] : 0.0;
-                        U_i += (c5 & 4) ? uj[l][i] : 0.0;
-                    }
-                }
-            };
-            // the five continuum rows of a slot (rows that no continuum feeds are not read), k order
-            auto load_rows = [&](const unsigned rowOff, const int zm, double (&lr)[5][D]) {
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-                {
-                    if (!(zm & (1 << q)))
-                        ls_ld<D>(rRows, vRow, rowOff + (unsigned)q * rowStride, lr[q]);
                     else
                     {
 #pragma unroll
-                        for (int p = 0; p < D; ++p)
-                            lr[q][p] = 0.0;
+                        for (int p = 0; p < HP; ++p)
+                            v1[s][p] = v2[s][p] = xl[s][p] = el[s][p] = uj[s][p] = 0.0;
+                    }
+                }
+                // level sums of a slot: continuum rows + the active lines of this wavelength, selected by the tile's
+                // coupling codes (a line's coupling with itself is known at compile time)
+                auto couple = [&](const int (&cc)[NLc], const int p, double& etaA, double& chi_i, double& chi_j, double& U_i, double& U_j) {
+#pragma unroll
+                    for (int l = 0; l < NLc; ++l)
+                    {
+                        if (l < NL)
+                        {
+                            const int c5 = cc[l];
+                            etaA += (c5 & 1) ? el[l][p] : 0.0;
+                            chi_i += (c5 & 2) ? xl[l][p] : 0.0;
+                            chi_i -= (c5 & 4) ? xl[l][p] : 0.0;
+                            chi_j += (c5 & 8) ? xl[l][p] : 0.0;
+                            chi_j -= (c5 & 16) ? xl[l][p] : 0.0;
+                            U_j += (c5 & 16) ? uj[l][p] : 0.0;
+                            U_i += (c5 & 4) ? uj[l][p] : 0.0;
+                        }
+                    }
+                };
+                // the five continuum rows of a slot (rows that no continuum feeds are not read)
+                auto load_rows = [&](const unsigned rowOff, const int zm, double (&lr)[5][HP]) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                    {
+                        if (!(zm & (1 << q)))
+                            ls_gld<HP>(rRows, vRow, rowOff + (unsigned)q * rowStride, lr[q]);
+                        else
+                        {
+#pragma unroll
+                            for (int p = 0; p < HP; ++p)
+                                lr[q][p] = 0.0;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int s = 0; s < NLc; ++s)
+                {
+                    if (s < NL)
+                    {
+                        double lr[5][HP], wphi[HP];
+                        load_rows(lrow[s], lzm[s], lr);
+                        ls_lds<HP>(sDep, vK, lwO[s], wphi);
+                        const double lcw = lcw1[s] * hw;
+                        const double lcwOp = (lfl[s] & 1) ? lcw : 0.0; // detailed atoms: rates only
+#pragma unroll
+                        for (int p = 0; p < HP; ++p)
+                        {
+                            constexpr int dummy = 0;
+                            (void)dummy;
+                            const int i = MI(H + p); // march index of the point
+                            const double uji = uj[s][p];
+                            const double wlamu = lcw * wphi[p];
+                            double etaA = lr[0][p] + el[s][p], chi_i = lr[1][p] + xl[s][p], chi_j = lr[2][p] - xl[s][p];
+                            double U_i = lr[3][p], U_j = lr[4][p] + uj[s][p];
+                            if (NL > 1)
+                                couple(ccL[s], p, etaA, chi_i, chi_j, U_i, U_j);
+                            const double Ieff = Iv[i] - PsiS[i] * etaA; // compute_full_Ieff
+                            const double wop = lcwOp * wphi[p];
+                            const double g0 = ((uji + v2[s][p] * Ieff) - (PsiS[i] * chi_i * U_j)) * wop;
+                            const double g1 = ((v1[s][p] * Ieff) - (PsiS[i] * chi_j * U_i)) * wop;
+                            const double g2 = Iv[i] * v1[s][p] * wlamu;
+                            const double g3 = (uji + Iv[i] * v2[s][p]) * wlamu;
+                            if (LS_ACC0_REG && s == 0)
+                            {
+                                acc0[0][H + p] += g0; // (inactive lanes carry hw = 0)
+                                acc0[1][H + p] += g1;
+                                acc0[2][H + p] += g2;
+                                acc0[3][H + p] += g3;
+                            }
+                            else if (act)
+                            {
+                                double* dst = accBase + lacc[s] + (unsigned)((H + p) * LR);
+                                lds_add(dst, g0);
+                                lds_add(dst + D * LR, g1);
+                                lds_add(dst + 2 * D * LR, g2);
+                                lds_add(dst + 3 * D * LR, g3);
+                            }
+                            // Meta of the line's atom
+                            if (lms[s] >= 0)
+                            {
+                                if (NL < 2 || lms[s] == 0)
+                                    Me[0][H + p] += wPsi[i] * el[s][p];
+                                else
+                                    Me[1][H + p] += wPsi[i] * el[s][p];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < NMc; ++m)
+                {
+                    if (m < NM) // mixed continua (always of active atoms)
+                    {
+                        double mr[5][HP], mvji[HP];
+                        load_rows(mrow[m], mzm[m], mr);
+                        ls_gld<HP>(rRows, vRow, maux[m], mvji);
+                        const double wlamu = mcw1[m] * hw;
+#pragma unroll
+                        for (int p = 0; p < HP; ++p)
+                        {
+                            const int i = MI(H + p);
+                            const double w1 = mb0[m], w2 = mvji[p], uji = mb2[m] * w2;
+                            double etaA = mr[0][p], chi_i = mr[1][p], chi_j = mr[2][p], U_i = mr[3][p], U_j = mr[4][p];
+                            if (NL > 0)
+                                couple(ccM[m], p, etaA, chi_i, chi_j, U_i, U_j);
+                            const double Ieff = Iv[i] - PsiS[i] * etaA;
+                            if (act)
+                            {
+                                double* dst = accBase + macc[m] + (unsigned)((H + p) * LR);
+                                lds_add(dst, ((uji + w2 * Ieff) - (PsiS[i] * chi_i * U_j)) * wlamu);
+                                lds_add(dst + D * LR, ((w1 * Ieff) - (PsiS[i] * chi_j * U_i)) * wlamu);
+                                lds_add(dst + 2 * D * LR, Iv[i] * w1 * wlamu);
+                                lds_add(dst + 3 * D * LR, (uji + Iv[i] * w2) * wlamu);
+                            }
+                        }
                     }
                 }
             };
-#pragma unroll
-            for (int s = 0; s < NLc; ++s)
-            {
-                if (s < NL)
-                {
-                    double lr[5][D], wphi[D];
-                    load_rows(lrow[s], lzm[s], lr);
-                    ls_ld<D>(rW, vK, lwO[s], wphi);
-                    const double lcw = lcw1[s] * hw;
-                    const double lcwOp = (lfl[s] & 1) ? lcw : 0.0; // detailed atoms: rates only
-#pragma unroll
-                    for (int i = 0; i < D; ++i)
-                    {
-                        const double v1 = vij[s][i], v2 = vji[s][i], uji = uj[s][i];
-                        const double wlamu = lcw * wphi[MI(i)];
-                        double etaA = lr[0][MI(i)] + el[s][i], chi_i = lr[1][MI(i)] + xl[s][i], chi_j = lr[2][MI(i)] - xl[s][i];
-                        double U_i = lr[3][MI(i)], U_j = lr[4][MI(i)] + uj[s][i];
-                        if (NL > 1)
-                            couple(ccL[s], i, etaA, chi_i, chi_j, U_i, U_j);
-                        const double Ieff = Iv[i] - PsiS[i] * etaA; // compute_full_Ieff
-                        const double wop = lcwOp * wphi[MI(i)];
-                        accL[s][0][MI(i)] += ((uji + v2 * Ieff) - (PsiS[i] * chi_i * U_j)) * wop;
-                        accL[s][1][MI(i)] += ((v1 * Ieff) - (PsiS[i] * chi_j * U_i)) * wop;
-                        accL[s][2][MI(i)] += Iv[i] * v1 * wlamu;
-                        accL[s][3][MI(i)] += (uji + Iv[i] * v2) * wlamu;
-                    }
-                    if (lms[s] == 0)
-                    {
-#pragma unroll
-                        for (int i = 0; i < D; ++i)
-                            Me[0][MI(i)] += wPsi[i] * el[s][i]; // Meta of the line's atom
-                    }
-                    else if (lms[s] == 1)
-                    {
-#pragma unroll
-                        for (int i = 0; i < D; ++i)
-                            Me[1][MI(i)] += wPsi[i] * el[s][i];
-                    }
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < NMc; ++m)
-            {
-                if (m < NM) // mixed continua (always of active atoms)
-                {
-                    double mr[5][D], mvji[D];
-                    load_rows(mrow[m], mzm[m], mr);
-                    ls_ld<D>(rRows, vRow, maux[m], mvji);
-                    const double wlamu = mcw1[m] * hw;
-#pragma unroll
-                    for (int i = 0; i < D; ++i)
-                    {
-                        const double v1 = mb0[m], v2 = mvji[MI(i)], uji = mb2[m] * v2;
-                        double etaA = mr[0][MI(i)], chi_i = mr[1][MI(i)], chi_j = mr[2][MI(i)], U_i = mr[3][MI(i)], U_j = mr[4][MI(i)];
-                        if (NL > 0)
-                            couple(ccM[m], i, etaA, chi_i, chi_j, U_i, U_j);
-                        const double Ieff = Iv[i] - PsiS[i] * etaA;
-                        accM[m][0][MI(i)] += ((uji + v2 * Ieff) - (PsiS[i] * chi_i * U_j)) * wlamu;
-                        accM[m][1][MI(i)] += ((v1 * Ieff) - (PsiS[i] * chi_j * U_i)) * wlamu;
-                        accM[m][2][MI(i)] += Iv[i] * v1 * wlamu;
-                        accM[m][3][MI(i)] += (uji + Iv[i] * v2) * wlamu;
-                    }
-                }
-            }
+            static_assert(D % 2 == 0, "the block's rate integrals are formed in halves");
+            rates_half(std::integral_constant<int, 0>{});
+            LS_PHASE();
+            rates_half(std::integral_constant<int, D / 2>{});
+#endif
         }
         LS_PHASE();
+        LS_T(tp5);
+        LS_TACC(tmA, tp0, tp1);
+        LS_TACC(tmS, tp3, tp4);
+        LS_TACC(tmD, tp4, tp5);
+#ifdef LS_TIMING
+        tmC += tp3 - tp1 - (tmB - tmBprev);
+        tmBprev = tmB;
+#endif
 #undef MI
 #undef IV
 #undef CHI
@@ -729,37 +901,35 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     for (int mu = 0; mu < Nmu; ++mu)
     {
         if (dyn.nPass == 2)
-            pass(std::false_type{}, mu);
-        pass(std::true_type{}, mu);
+        {
+            pass(std::false_type{}, mu, (unsigned)(mu * 2 + 1) * Ns8);
+            pass(std::true_type{}, mu, (unsigned)(mu * 2 + 2) * Ns8);
+        }
+        else
+            pass(std::true_type{}, mu, (unsigned)(mu * 2 + 3) * Ns8);
     }
-    if (!RATES)
-        return;
-    // the slots' integrals of this tile to the workgroup's sums
-    if (act)
+    if (LS_ACC0_REG && RATES && NL > 0 && act)
     {
+        // the first line's sums of this tile to the workgroup's accumulators
 #pragma unroll
-        for (int s = 0; s < NLc; ++s)
-            if (s < NL)
-            {
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int p = 0; p < D; ++p)
-                        if (p < c.nV)
-                            lds_add(sAcc + lacc[s] + (unsigned)(q * LRD + k0 + p), accL[s][q][p]);
-            }
-#pragma unroll
-        for (int m = 0; m < NMc; ++m)
-            if (m < NM)
-            {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int p = 0; p < D; ++p)
-                        if (p < c.nV)
-                            lds_add(sAcc + macc[m] + (unsigned)(q * LRD + k0 + p), accM[m][q][p]);
-            }
+            for (int p = 0; p < D; ++p)
+                if (p < c.nV)
+                    lds_add(accBase + lacc[0] + (unsigned)((q * D + p) * LR), acc0[q][p]);
     }
+#ifdef LS_TIMING
+    if (c.lane == 0 && a.lsDbg)
+    {
+        double* o = a.lsDbg + (size_t)c.ti * 8;
+        o[1] = (double)tmA;
+        o[2] = (double)tmB;
+        o[3] = (double)tmC;
+        o[4] = (double)tmS;
+        o[5] = (double)tmD;
+    }
+#endif
+    return meSlot0;
 }
 
 // The tile's wavelengths are complete: J out, dJ, and the pure continua from the angle moments.
@@ -767,13 +937,149 @@ DEVINL void lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
 // eta_r = etaC + etaLine_r  ->  Uji W + Vji (J - M1 etaC - Meta) - M1 chi_i U_j: an exact regrouping of
 // compute_full_operator_rates :206-234 for continua whose level sums do not depend on the ray.  The level sums
 // (chi_eta_aux_accum :59-109, continua in transition order) live in registers: per tile the host lists which sums have
-// several contributors (DevPostProg).
+// several contributors (DevPostProg).  P0, NP: the points of the lane's block this call handles (the block is
+// finished in pieces to bound the registers).
+template <int D, int P0, int NP>
+DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const DevLaHeader& h, const int ti, const int nCont,
+                             double* sAcc, const int slotOffLa, const int ms0, const int ms1, const double (&Jk)[D],
+                             const double (&M1)[D], const double (&Me)[2][D])
+{
+    const int Nmu = c.Nmu, LR = c.LR;
+    const unsigned vK = c.vK + (unsigned)P0 * 8u;
+    double Wsum = 0.0; // total quadrature weight of the rays of the iteration, in ray order
+    for (int m = 0; m < Nmu; ++m)
+        for (int d = 0; d < 2; ++d)
+            Wsum += 0.5 * CTAB(double, a.wmu)[m];
+    const CONST_AS DevContRec* cr = CTAB(DevContRec, a.contRec) + h.off + h.nLine;
+    const CONST_AS DevPostProg* pg = CTAB(DevPostProg, a.postProg) + ti;
+    const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
+    double boltz[NP];
+    {
+        double rT[NP];
+        ls_lds<NP>(c.sDep, vK + 8u, c.oG + 3u * c.gStride, rT);
+        const double hc_kl = HC_K / c.wav;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            boltz[p] = ls_exp_neg(-hc_kl * rT[p], c.sExp);
+    }
+    double S8[LWHIP_POST_SUMS][NP];
+#pragma unroll
+    for (int m = 0; m < LWHIP_POST_SUMS; ++m)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            S8[m][p] = 0.0;
+    // walk 1: the shared level sums, continua in transition order
+    for (int q = 0; q < nCont; ++q)
+    {
+        const DevContRec rc = ld_c(cr + q);
+        const unsigned code = (rc.flags & 1) ? pg->code[q] : 0u;
+        if (code == 0u)
+            continue;
+        double ni[NP], nj[NP], rat[NP];
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nJ, nj);
+        ls_lds<NP>(c.sDep, vK, c.oRat + rc.rat, rat);
+        const double p0 = *(const GLOBAL_AS double*)(lsB + rc.pOff), p2 = *(const GLOBAL_AS double*)(lsB + rc.pOff + 16);
+        double chi_c[NP], uji[NP], eta_c[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+            const double vji = (rat[p] * boltz[p]) * p0;
+            chi_c[p] = ni[p] * p0 - nj[p] * vji;
+            uji[p] = p2 * vji;
+            eta_c[p] = nj[p] * uji[p];
+        }
+#pragma unroll
+        for (int m = 0; m < LWHIP_POST_SUMS; ++m)
+        {
+            const unsigned kind = (code >> (3 * m)) & 7u;
+            if (kind == 0u)
+                continue;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                S8[m][p] += kind == 1u ? chi_c[p] : kind == 2u ? -chi_c[p] : kind == 3u ? uji[p] : eta_c[p];
+        }
+    }
+    // walk 2: the pure continua
+    for (int q = 0; q < nCont; ++q)
+    {
+        const DevContRec rc = ld_c(cr + q);
+        if (!(rc.flags & 2))
+            continue;
+        double ni[NP], nj[NP], rat[NP];
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nJ, nj);
+        ls_lds<NP>(c.sDep, vK, c.oRat + rc.rat, rat);
+        const double vij = *(const GLOBAL_AS double*)(lsB + rc.pOff), wla = *(const GLOBAL_AS double*)(lsB + rc.pOff + 8),
+                     p2 = *(const GLOBAL_AS double*)(lsB + rc.pOff + 16);
+        double vji[NP], chi_c[NP], uji[NP], eta_c[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+            vji[p] = (rat[p] * boltz[p]) * vij;
+            chi_c[p] = ni[p] * vij - nj[p] * vji[p];
+            uji[p] = p2 * vji[p];
+            eta_c[p] = nj[p] * uji[p];
+        }
+        const unsigned ops = pg->ops[q];
+        double o5[5][NP]; // eta_A, chi_i, U_j, chi_j, U_i
+#pragma unroll
+        for (int w = 0; w < 5; ++w)
+        {
+            const unsigned sel = (ops >> (4 * w)) & 15u;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                o5[w][p] = 0.0;
+            // (real scalar branches: as selects the 40 conditions of a continuum would be held in 80 SGPRs)
+            if (sel >= 9u)
+            {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                {
+                    o5[w][p] = sel == 9u ? chi_c[p] : sel == 10u ? -chi_c[p] : sel == 11u ? uji[p] : eta_c[p];
+                    LS_KEEP(o5[w][p]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < LWHIP_POST_SUMS; ++m)
+                if (sel == (unsigned)(m + 1))
+                {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                    {
+                        o5[w][p] = S8[m][p];
+                        LS_KEEP(o5[w][p]);
+                    }
+                }
+        }
+        double* dst = sAcc + (unsigned)(rc.cs * 4 * c.LRD) + c.blk;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+            if (!(c.act && P0 + p < c.nV))
+                continue;
+            const double Jp = Jk[P0 + p], M1p = M1[P0 + p];
+            if (rc.flags & 1)
+            {
+                const double Meta = (rc.ms < 0) ? 0.0 : (rc.ms == ms0) ? Me[0][P0 + p] : (rc.ms == ms1) ? Me[1][P0 + p] : 0.0;
+                const double Jeff = Jp - M1p * o5[0][p] - Meta;
+                lds_add(dst + (P0 + p) * LR, ((uji[p] * Wsum + vji[p] * Jeff) - (M1p * o5[1][p] * o5[2][p])) * wla);
+                lds_add(dst + (D + P0 + p) * LR, ((vij * Jeff) - (M1p * o5[3][p] * o5[4][p])) * wla);
+            }
+            lds_add(dst + (2 * D + P0 + p) * LR, Jp * vij * wla);
+            lds_add(dst + (3 * D + P0 + p) * LR, (uji[p] * Wsum + Jp * vji[p]) * wla);
+        }
+    }
+}
+
 template <int D>
 DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, const LaneCtx& c,
-                        double* sAcc, unsigned long long* sDj, const double (&Jk)[D], const double (&M1)[D], const double (&Me)[2][D])
+                        double* sAcc, unsigned long long* sDj, const int ms0, const int ms1, const double (&Jk)[D],
+                        const double (&M1)[D], const double (&Me)[2][D])
 {
-    const int Ns = c.Ns, Nmu = c.Nmu, LRD = c.LRD, k0 = c.k0, la = c.la;
-    const unsigned vK = c.vK, Ns8 = c.Ns8;
+    const int Ns = c.Ns, k0 = c.k0;
+    int la = c.la;
+    LS_KEEPI(la); // (nothing of the finish is computed before the rays are done)
     {
         double dj = 0.0;
         if (c.act)
@@ -795,128 +1101,27 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     const int nCont = (!dyn.prdOnly && h.nPure > 0) ? h.nMixed + h.nPure : 0;
     if (nCont <= 0)
         return;
-    double Wsum = 0.0; // total quadrature weight of the rays of the iteration, in ray order
-    for (int m = 0; m < Nmu; ++m)
-        for (int d = 0; d < 2; ++d)
-            Wsum += 0.5 * CTAB(double, a.wmu)[m];
-    const CONST_AS DevContRec* cr = CTAB(DevContRec, a.contRec) + h.off + h.nLine;
-    const CONST_AS DevPostProg* pg = CTAB(DevPostProg, a.postProg) + ti;
-    const __amdgpu_buffer_rsrc_t rRat = ls_rsrc(a.ratio, a.ratioDoubles * 8ull);
     const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
-    const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
-    double boltz[D];
-    {
-        double rT[D];
-        ls_ld<D>(c.rG, vK + 8u, 3u * c.gStride, rT);
-        const double hc_kl = HC_K / c.wav;
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-            boltz[p] = d_exp_neg(-hc_kl * rT[p]);
-    }
-    double S8[LWHIP_POST_SUMS][D];
-#pragma unroll
-    for (int m = 0; m < LWHIP_POST_SUMS; ++m)
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-            S8[m][p] = 0.0;
-    // walk 1: the shared level sums, continua in transition order
-    for (int q = 0; q < nCont; ++q)
-    {
-        const DevContRec rc = ld_c(cr + q);
-        const unsigned code = (rc.flags & 1) ? pg->code[q] : 0u;
-        if (code == 0u)
-            continue;
-        double ni[D], nj[D], rat[D];
-        ls_ld<D>(c.rN, vK, rc.nI, ni);
-        ls_ld<D>(c.rN, vK, rc.nJ, nj);
-        ls_ld<D>(rRat, vK, rc.rat, rat);
-        const double p0 = *(const GLOBAL_AS double*)(lsB + rc.pOff), p2 = *(const GLOBAL_AS double*)(lsB + rc.pOff + 16);
-        double chi_c[D], uji[D], eta_c[D];
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-        {
-            const double vji = (rat[p] * boltz[p]) * p0;
-            chi_c[p] = ni[p] * p0 - nj[p] * vji;
-            uji[p] = p2 * vji;
-            eta_c[p] = nj[p] * uji[p];
-        }
-#pragma unroll
-        for (int m = 0; m < LWHIP_POST_SUMS; ++m)
-        {
-            const unsigned kind = (code >> (3 * m)) & 7u;
-            if (kind == 0u)
-                continue;
-#pragma unroll
-            for (int p = 0; p < D; ++p)
-                S8[m][p] += kind == 1u ? chi_c[p] : kind == 2u ? -chi_c[p] : kind == 3u ? uji[p] : eta_c[p];
-        }
-    }
-    // walk 2: the pure continua
-    for (int q = 0; q < nCont; ++q)
-    {
-        const DevContRec rc = ld_c(cr + q);
-        if (!(rc.flags & 2))
-            continue;
-        double ni[D], nj[D], rat[D];
-        ls_ld<D>(c.rN, vK, rc.nI, ni);
-        ls_ld<D>(c.rN, vK, rc.nJ, nj);
-        ls_ld<D>(rRat, vK, rc.rat, rat);
-        const double vij = *(const GLOBAL_AS double*)(lsB + rc.pOff), wla = *(const GLOBAL_AS double*)(lsB + rc.pOff + 8),
-                     p2 = *(const GLOBAL_AS double*)(lsB + rc.pOff + 16);
-        double vji[D], chi_c[D], uji[D], eta_c[D];
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-        {
-            vji[p] = (rat[p] * boltz[p]) * vij;
-            chi_c[p] = ni[p] * vij - nj[p] * vji[p];
-            uji[p] = p2 * vji[p];
-            eta_c[p] = nj[p] * uji[p];
-        }
-        const unsigned ops = pg->ops[q];
-        double o5[5][D]; // eta_A, chi_i, U_j, chi_j, U_i
-#pragma unroll
-        for (int w = 0; w < 5; ++w)
-        {
-            const unsigned sel = (ops >> (4 * w)) & 15u;
-#pragma unroll
-            for (int p = 0; p < D; ++p)
-                o5[w][p] = sel == 9u ? chi_c[p] : sel == 10u ? -chi_c[p] : sel == 11u ? uji[p] : sel == 12u ? eta_c[p] : 0.0;
-#pragma unroll
-            for (int m = 0; m < LWHIP_POST_SUMS; ++m)
-                if (sel == (unsigned)(m + 1))
-                {
-#pragma unroll
-                    for (int p = 0; p < D; ++p)
-                        o5[w][p] = S8[m][p];
-                }
-        }
-        double* dst = sAcc + (unsigned)(rc.cs * 4 * LRD) + k0;
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-        {
-            if (!(c.act && p < c.nV))
-                continue;
-            if (rc.flags & 1)
-            {
-                const double Meta = (rc.ms == 0) ? Me[0][p] : (rc.ms == 1) ? Me[1][p] : 0.0;
-                const double Jeff = Jk[p] - M1[p] * o5[0][p] - Meta;
-                lds_add(dst + p, ((uji[p] * Wsum + vji[p] * Jeff) - (M1[p] * o5[1][p] * o5[2][p])) * wla);
-                lds_add(dst + LRD + p, ((vij * Jeff) - (M1[p] * o5[3][p] * o5[4][p])) * wla);
-            }
-            lds_add(dst + 2 * LRD + p, Jk[p] * vij * wla);
-            lds_add(dst + 3 * LRD + p, (uji[p] * Wsum + Jk[p] * vji[p]) * wla);
-        }
-    }
+    static_assert(D % 2 == 0, "the block is finished in halves");
+    lane_finish_part<D, 0, D / 2>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    LS_PHASE();
+    lane_finish_part<D, D / 2, D / 2>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
 }
 
 // One task = one tile (up to R wavelengths), every ray of it.
 template <int SOLVER, int D, bool RATES>
 DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, double* sAcc,
-                      unsigned long long* sDj, const int lane)
+                      unsigned long long* sDj, double* sB, const double* sExp, const char* sDep, double* sRow3, const int lane)
 {
+    LS_T(tt0);
     LaneCtx c;
+    c.ti = ti;
+    c.sExp = sExp;
+    c.sDep = sDep;
+    c.sRow3 = sRow3;
     c.Ns = a.Ns;
     c.Nmu = a.Nmu;
+    c.LR = a.laneLR;
     c.LRD = a.laneLRD;
     c.L = a.L;
     c.lane = lane;
@@ -934,33 +1139,68 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     c.rowStride = (unsigned)(c.L * c.LRD) * 8u;
     c.Ns8 = (unsigned)c.Ns * 8u;
     c.gStride = (unsigned)(c.LRD + 2) * 8u;
-    c.rRows = ls_rsrc(a.rows + td.rowBase, (unsigned long long)td.nRowsT * c.rowStride);
-    c.rN = ls_rsrc(a.n, (unsigned long long)a.NlevTot * c.Ns8);
-    c.rW = ls_rsrc(a.wphi, (unsigned long long)max(a.Nline, 1) * c.Ns8);
-    c.rG = ls_rsrc(a.geoT, 4ull * c.gStride);
+    c.oN = a.depN;
+    c.oW = a.depW;
+    c.oRat = a.depRat;
+    c.oG = a.depG;
+    c.rRows = a.rows + td.rowBase;
+    c.sB = sB;
     double Jk[D], M1[D], Me[2][D];
 #pragma unroll
     for (int p = 0; p < D; ++p)
         Jk[p] = M1[p] = Me[0][p] = Me[1][p] = 0.0;
+    int ms0 = 0, ms1 = 1;
 #ifdef LS_ONLY_NL
-    lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+    ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+    if (LS_ONLY_NL < 2)
+        ms1 = -2;
 #else
     if (td.nLine == 0)
+    {
         lane_rays<SOLVER, D, 0, 0, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+        ms0 = ms1 = -2;
+    }
     else if (td.nLine == 1 && td.nMixed == 0)
-        lane_rays<SOLVER, D, 1, 0, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+    {
+        ms0 = lane_rays<SOLVER, D, 1, 0, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+        ms1 = -2;
+    }
     else if (td.nLine == 1)
-        lane_rays<SOLVER, D, 1, 1, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+    {
+        ms0 = lane_rays<SOLVER, D, 1, 1, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+        ms1 = -2;
+    }
     else
         lane_rays<SOLVER, D, 2, 0, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
 #endif
+    LS_T(tt1);
+#ifndef LS_DBG_NO_FINISH
     if (RATES)
-        lane_finish<D>(a, dyn, td, ti, c, sAcc, sDj, Jk, M1, Me);
+        lane_finish<D>(a, dyn, td, ti, c, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+#else
+    if (RATES && c.act)
+        GD(a.J)[(size_t)c.la * c.Ns + c.k0] = Jk[0] + Jk[1] + Jk[2] + Jk[3] + M1[0] + M1[1] + M1[2] + M1[3] + Me[0][0] + Me[0][1] + Me[0][2] + Me[0][3] + Me[1][0] + Me[1][1] + Me[1][2] + Me[1][3];
+#endif
+#ifdef LS_TIMING
+    {
+        LS_T(tt2);
+        if (lane == 0 && a.lsDbg)
+        {
+            double* o = a.lsDbg + (size_t)ti * 8;
+            o[6] = (double)(tt2 - tt1);
+            o[7] = (double)(tt2 - tt0);
+            o[0] = (double)(tt1 - tt0) - o[1] - o[2] - o[3] - o[4] - o[5];
+        }
+    }
+#endif
 }
 
 // Workgroup = W wavefronts, each takes tiles of the workgroup's chunk in turn.
 template <int SOLVER, int D, bool RATES, bool BATCH>
-__global__ void __launch_bounds__(LS_MAX_WAVES * 64) lanesweep_kernel(const TileArgs* __restrict__ ap0,
+#ifndef LS_WAVES_PER_EU
+#define LS_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LS_WAVES_PER_EU))) lanesweep_kernel(const TileArgs* __restrict__ ap0,
                                                                        const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
     extern __shared__ double lds[];
@@ -974,14 +1214,27 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) lanesweep_kernel(const Tile
     const int nWaves = blockDim.x >> 6;
     double* sAcc = lds;                                                             // [maxCT][4][LRD]
     unsigned long long* sDj = (unsigned long long*)(lds + (size_t)maxCT * 4 * LRD) + wave * LS_MAX_R; // per wave [R]
+    double* sB = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R + (size_t)wave * (LS_MAX_R * 4); // per wave [R][4]
+    double* sExp = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R * 5;                              // [LS_EXP_TAB]
+    double* sRow3 = sExp + LS_EXP_TAB + (size_t)wave * (3 * 64 * D);                                            // per wave [3][64][D]
+    double* sDep = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D);                                           // [depBytes / 8]
+    ls_exp_table_init(sExp, t);
+    {
+        // the depth-only pools (populations, w_phi, nStar ratios, geometry) are the same for every tile: one LDS copy per
+        // workgroup serves all rays of all its tiles
+        const GLOBAL_AS double* src = GCD(a.depBase);
+        const int nDep = (int)(a.depBytes >> 3);
+        for (int idx = t; idx < nDep; idx += blockDim.x)
+            sDep[idx] = src[idx];
+    }
     const int chunk = blockIdx.x;
     const int t0 = CTAB(int32_t, a.chunkTile)[chunk], t1 = CTAB(int32_t, a.chunkTile)[chunk + 1];
     if (RATES)
     {
         for (int idx = t; idx < maxCT * 4 * LRD; idx += blockDim.x)
             sAcc[idx] = 0.0;
-        __syncthreads();
     }
+    __syncthreads();
     const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
     for (int li = t0 + wave; li < t1; li += nWaves)
     {
@@ -989,7 +1242,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) lanesweep_kernel(const Tile
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
         if (RATES && lane < LS_MAX_R)
             sDj[lane] = 0ull;
-        lane_task<SOLVER, D, RATES>(a, dyn, td, ti, sAcc, sDj, lane);
+        lane_task<SOLVER, D, RATES>(a, dyn, td, ti, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, lane);
         if (RATES && lane < td.nl)
             GD(a.dJ)[td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
     }
@@ -1003,9 +1256,11 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) lanesweep_kernel(const Tile
         const int part = chunk % LWHIP_REDUCE_SPLIT;
         for (int idx = t; idx < maxCT * 4 * LRD; idx += blockDim.x)
         {
+            // [slot][quantity][point of the block][block] -> depth k = block * D + point
             const int cs = idx / (4 * LRD);
             const int rem = idx - cs * 4 * LRD;
-            const int q = rem / LRD, k = rem - q * LRD;
+            const int q = rem / LRD, pb = rem - q * LRD;
+            const int pp = pb / a.laneLR, k = (pb - pp * a.laneLR) * D + pp;
             const int tr = slotTr[cs];
             if (tr >= 0 && k < Ns)
                 unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + q * Ns + k), sAcc[idx]);
@@ -1053,7 +1308,8 @@ bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R
 
 size_t lane_sweep_lds_bytes(const TileArgs& a, int waves)
 {
-    return sizeof(double) * ((size_t)a.maxCT * 4 * a.laneLRD + (size_t)waves * LS_MAX_R);
+    return sizeof(double) * ((size_t)a.maxCT * 4 * a.laneLRD + (size_t)waves * LS_MAX_R * 5 + LS_EXP_TAB + (size_t)waves * 3 * 64 * a.laneD)
+           + a.depBytes;
 }
 
 hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int solver, bool rates, int nChunks,

@@ -18,6 +18,14 @@ from oracle.bindings import OracleContext
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=['lanes', 'march'])
+def sweep(request, monkeypatch):
+    """Both sweep kernels (the library picks one per context by size: LWHIP_SWEEP forces it): the depth-across-lanes
+    sweep and the ray-column march.  What the lanes sweep does not cover (other solvers, deep columns) runs the march."""
+    monkeypatch.setenv('LWHIP_SWEEP', request.param)
+    return request.param
+
+
 def compare_problems(got, want, tol=TOL_ONE_CALL, what=('J', 'I', 'Gamma', 'R')):
     a, b = collect(got, what), collect(want, what)
     worst = {k: rel_err(a[k], b[k]) for k in a}
@@ -27,7 +35,7 @@ def compare_problems(got, want, tol=TOL_ONE_CALL, what=('J', 'I', 'Gamma', 'R'))
 
 
 @pytest.mark.parametrize('name', FIXTURES)
-def test_iter1_golden(gpu, name):
+def test_iter1_golden(gpu, name, sweep):
     base, d = load_fixture(name)
     p = variant_problem(base, d, 'iter1')
     with Context(p) as ctx:
@@ -47,7 +55,7 @@ def test_iter1_golden(gpu, name):
 
 @pytest.mark.parametrize('name', FIXTURES)
 @pytest.mark.parametrize('variant', ['linear', 'besser', 'bc', 'prd_detailed'])
-def test_variants_golden(gpu, name, variant):
+def test_variants_golden(gpu, name, variant, sweep):
     base, d = load_fixture(name)
     if f'out/{variant}/J' not in d:
         pytest.skip('variant not in this fixture')
@@ -58,7 +66,7 @@ def test_variants_golden(gpu, name, variant):
 
 
 @pytest.mark.parametrize('name', FIXTURES)
-def test_lambda_iterate_golden(gpu, name):
+def test_lambda_iterate_golden(gpu, name, sweep):
     base, d = load_fixture(name)
     p = variant_problem(base, d, 'lambda')
     with Context(p) as ctx:
@@ -68,7 +76,7 @@ def test_lambda_iterate_golden(gpu, name):
 
 @pytest.mark.parametrize('name', FIXTURES)
 @pytest.mark.parametrize('upOnly,key', [(True, 'fs_up'), (False, 'fs_all')])
-def test_formal_sol_golden(gpu, name, upOnly, key):
+def test_formal_sol_golden(gpu, name, upOnly, key, sweep):
     base, d = load_fixture(name)
     p = base.copy()
     J0 = p.J.copy()
@@ -80,7 +88,7 @@ def test_formal_sol_golden(gpu, name, upOnly, key):
 
 
 @pytest.mark.parametrize('name', FIXTURES)
-def test_iter20_golden_device_resident(gpu, name):
+def test_iter20_golden_device_resident(gpu, name, sweep):
     """20 iterations with populations, J and Gamma never leaving HBM; compared with the reference's
     host-driven loop (1e-6 on J per the north star; populations likewise)."""
     base, d = load_fixture(name)
@@ -105,7 +113,7 @@ def _oracle_and_hip(prob, lambdaIterate=False, **ctx_kw):
 
 
 @pytest.mark.parametrize('seed', [1, 2])
-def test_seeded_h_ca_5rays_vs_oracle(gpu, seed):
+def test_seeded_h_ca_5rays_vs_oracle(gpu, seed, sweep):
     """BASELINE configs[1] shape (H + Ca II, 5 mu, 82 depths) on perturbed columns."""
     atmos = models.perturbed(models.falc82(), seed=seed)
     prob = models.build_problem(atmos, [models.H_6(0.5), models.CaII_6(0.5)], Nrays=5)
@@ -114,7 +122,7 @@ def test_seeded_h_ca_5rays_vs_oracle(gpu, seed):
 
 
 @pytest.mark.parametrize('Nspace,Nrays', [(3, 1), (5, 2), (64, 4), (65, 1), (200, 3), (500, 2)])
-def test_ragged_sizes_vs_oracle(gpu, Nspace, Nrays):
+def test_ragged_sizes_vs_oracle(gpu, Nspace, Nrays, sweep):
     """Depth counts around the wavefront width, the minimum the solver admits (3), odd ray
     counts, and the reference benchmark's 500-point atmosphere (several ray passes per lambda)."""
     atmos = models.resample(models.falc82(), Nspace)
@@ -123,12 +131,14 @@ def test_ragged_sizes_vs_oracle(gpu, Nspace, Nrays):
     compare_problems(p, q)
 
 
-@pytest.mark.parametrize('env', [{'LWHIP_TILE_GENERIC': '2'}, {'LWHIP_TILE_GENERIC': '8'}, {'LWHIP_TILE_FUSE': '0'},
-                                 {'LWHIP_TWAVES': '4'}])
+@pytest.mark.parametrize('env', [{'LWHIP_TILE_GENERIC': '2'}, {'LWHIP_TILE_GENERIC': '8'},
+                                 {'LWHIP_SWEEP': 'march', 'LWHIP_TILE_FUSE': '0'}, {'LWHIP_SWEEP': 'march', 'LWHIP_TWAVES': '4'},
+                                 {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '2'}, {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '8'}])
 def test_sweep_variants_forced_on_small_problem(gpu, monkeypatch, env):
     """The other instantiations of the one sweep on the 82-point H + Ca II problem: every tile through the guarded
     generic march (capacity 2 / 8: what tiles with more overlapping lines than the compile-time kinds use), the
-    stand-alone post-pass launch instead of the fused one, four wavefronts (two tiles) per workgroup."""
+    stand-alone post-pass launch instead of the fused one, four wavefronts (two tiles) per workgroup; the lane sweep with
+    two / eight wavefronts (tiles) per workgroup."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     base, d = load_fixture('falc_h_ca_small')
@@ -138,7 +148,7 @@ def test_sweep_variants_forced_on_small_problem(gpu, monkeypatch, env):
     compare_to_golden(p, d, 'iter1')
 
 
-def test_wavelength_shards_sum_to_whole(gpu):
+def test_wavelength_shards_sum_to_whole(gpu, sweep):
     """Two contexts owning [0, m) and [m, Nlambda): their reduce buffers add up to the unsharded
     one and J/I rows are owner-exclusive (the multi-GPU split, on one device)."""
     import ctypes as C
@@ -211,7 +221,7 @@ def test_rccl_allreduce_on_the_library_reduce_buffer(gpu):
 
 
 @pytest.mark.parametrize('fused', [True, False])
-def test_column_batch_vs_oracle(gpu, fused):
+def test_column_batch_vs_oracle(gpu, fused, sweep):
     """BASELINE configs[3] in miniature: perturbed FAL-C columns as independent problems, profiles
     generated on the device, iterated as a batch -- fused (lwhip_batch_*: one grid slice per column in one set of
     launches) or column by column; every column must match its own CPU run, dJMax included."""
@@ -285,7 +295,7 @@ def test_stat_equil_singular_raises(gpu):
         ctx.check_status()
 
 
-def test_linearity_of_formal_solution(gpu):
+def test_linearity_of_formal_solution(gpu, sweep):
     """Size-independent property at the full north-star grid size: with scattering switched off,
     the emergent intensity is linear in the emissivity -- doubling eta (background and, through
     n_j, nothing else here: continuum-free H-less problem) doubles I; and J stays untouched by
@@ -303,7 +313,7 @@ def test_linearity_of_formal_solution(gpu):
     assert rel_err(p2.I, 2.0 * p1.I) <= 1e-12
 
 
-def test_repeatability(gpu):
+def test_repeatability(gpu, sweep):
     """Same inputs twice -> same J and I bit for bit; Gamma to rounding (LDS atomics order)."""
     prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
     p1, p2 = prob.copy(), prob.copy()
@@ -347,7 +357,7 @@ def test_more_than_eight_overlapping_lines_is_refused(gpu):
         Context(prob)
 
 
-def test_detailed_static_atom_only(gpu):
+def test_detailed_static_atom_only(gpu, sweep):
     """No active atom at all: the only atom is detailed-static (its lines shape chi / eta, no Gamma, no rates are
     accumulated for it); J and I against the oracle, one-call and split forms of the iteration."""
     prob = models.build_problem(models.falc82(), [models.H_6(0.2)], Nrays=2)
@@ -370,7 +380,7 @@ def test_detailed_static_atom_only(gpu):
         assert rel_err(p.J, q.J) <= TOL_ONE_CALL and rel_err(p.I, q.I) <= TOL_ONE_CALL
 
 
-def test_zplane_decomposition_outputs(gpu):
+def test_zplane_decomposition_outputs(gpu, sweep):
     """ExtraParams ZPlaneDecomposition (Source/SimdFullIterationTemplates.hpp:253-281, 351-361): I of the down rays at
     depth Nz - 2 and of the up rays at depth 1, next to the emergent intensity; iteration and formal_sol."""
     base, d = load_fixture('falc_h_ca_small')
