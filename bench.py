@@ -45,7 +45,10 @@ def parse():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--nlambda', type=int, default=10240, help='wavelengths per GPU (weak) / in total (strong)')
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong',
+                    help='strong (default): --nlambda wavelengths in total, split over the ranks: value = whole-problem '
+                         'iterations/s, the metric of BASELINE.json; weak: --nlambda per rank, value = shard-iterations/s')
+    ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the secondary weak-scaling measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-aux', action='store_true', help='skip the C3 / C4 / C5 side measurements')
@@ -215,14 +218,50 @@ def aux_prd(args, device, stream, torch, models):
         nla = sum(t.Nred - t.Nblue for t in lines)
         nprdLa = len({la for t in lines for la in range(t.Nblue, t.Nred)})
     Ns, Nmu = pp.Nspace, pp.Nrays
-    # inputs/outputs only: the cached fine-grid weights (20 B per fine point, <= 87 points per (lambda, depth)), J in and
-    # rho out per line; then the rates pass over the PRD wavelengths: phi once, background, J in/out
-    alg = 20.0 * 87 * nla * Ns + 8.0 * 2 * nla * Ns + 8.0 * Ns * (2.0 * Nmu * nla + 5.0 * nprdLa)
-    return {'config': 'C3: FALC H(6)+CaII(6), Ca II H & K PRD, same wavelength grid',
-            'ms_per_subiter': ms, 'subiters_per_s': 1e3 / ms, 'prd_lines': int(upd.dRho.shape[1]),
-            'Nlambda': pp.Nlambda, 'Nlambda_prd': nprdLa,
-            'roofline': roofline_block('prd_scatter_kernel + raymarch_kernel (PRD rates pass)', alg, ms,
-                                       'whole sub-iteration (host clock)')}
+    # inputs and outputs only -- J in and rho out per PRD line, then the rates pass over the PRD wavelengths
+    # (phi once, background, J in / out).  The library's own cache of the fine-grid weights (20 B per fine point, <= 87
+    # points per (lambda, depth)) is an intermediate: reported beside the roofline, not inside it.
+    alg = 8.0 * 2 * nla * Ns + 8.0 * Ns * (2.0 * Nmu * nla + 5.0 * nprdLa)
+    cache = 20.0 * 87 * nla * Ns
+    out = {'config': 'C3: FALC H(6)+CaII(6), Ca II H & K PRD, same wavelength grid',
+           'ms_per_subiter': ms, 'subiters_per_s': 1e3 / ms, 'prd_lines': int(upd.dRho.shape[1]),
+           'Nlambda': pp.Nlambda, 'Nlambda_prd': nprdLa,
+           'roofline': roofline_block('prd_scatter_kernel + the sweep in its PRD-rates mode', alg, ms,
+                                      'whole sub-iteration (host clock)'),
+           'cache_bytes_per_subiter': cache,
+           'cache_stream_GBps': cache / (ms * 1e-3) / 1e9}
+    if not args.no_cpu_baseline:
+        # parity at the timed size: one formal solution + redistribute_prd(3, 0) from identical inputs, oracle vs HIP
+        try:
+            import numpy as np
+            from oracle.bindings import OracleContext
+            q = pp.copy()
+            for t in (t for a in q.atoms for t in a.trans if t.rhoPrd is not None):
+                t.rhoPrd[...] = 1.0
+            p2 = q.copy()
+            oc = OracleContext(q)
+            q.gamma_prefill()
+            oc.formal_sol_gamma_matrices(Nthreads=min(os.cpu_count() or 1, 64))
+            oc.redistribute_prd(3, 0.0)
+            with Context(p2, device=device, stream=stream) as c2:
+                p2.gamma_prefill()
+                c2.formal_sol_gamma_matrices()
+                c2.redistribute_prd(3, 0.0)
+            rel = lambda x, y: float(np.max(np.abs(x - y)) / np.max(np.abs(y)))
+            errs = {'J': rel(p2.J, q.J)}
+            for a, b in zip(p2.atoms, q.atoms):
+                for ta, tb in zip(a.trans, b.trans):
+                    if ta.rhoPrd is not None:
+                        errs['rho'] = max(errs.get('rho', 0.0), rel(ta.rhoPrd, tb.rhoPrd))
+                        errs['R'] = max(errs.get('R', 0.0), rel(ta.Rij, tb.Rij), rel(ta.Rji, tb.Rji))
+            out['parity'] = {'against': 'oracle redistribute_prd (the reference scheme restated, pinned in tests/test_prd.py)',
+                             'rel_err': errs, 'tolerance': 1e-9}
+            out['max_rel_err'] = max(errs.values())
+            out['parity_checked'] = bool(out['max_rel_err'] <= 1e-9)
+        except Exception as e:  # the measurement stands without the check; say why it is missing
+            out['parity_checked'] = False
+            out['parity_error'] = repr(e)
+    return out
 
 
 def aux_columns(args, device, stream, torch, models):
@@ -349,9 +388,37 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     sweep_ms, nlaunch = ctx.sweep_time()
+    sweep_kind = ctx.sweep_kind()
     ctx.profile_enable(False)
     alg_bytes = ctx.algorithmic_bytes()
     alg_flops = algorithmic_flops(prob, la0, la1)
+
+    # N > 1, strong: the weak-scaling figure beside it (every rank keeps --nlambda wavelengths: shard-iterations/s)
+    weak = None
+    if world > 1 and args.scaling == 'strong' and not args.no_weak:
+        ctx.close()
+        probW = models.throughput_grid(NlambdaTarget=args.nlambda * world, Nrays=5, computeProfiles=False)
+        bW = shard_bounds(probW, world)
+        ctx = Context(probW, device=local_rank, laStart=bW[rank], laEnd=bW[rank + 1], stream=stream.cuda_stream,
+                      worldSize=world, worldRank=rank)
+        ctx.compute_profiles(deviceResident=True)
+        itW = ShardedIteration(ctx, world, rank)
+        for _ in range(args.warmup):
+            itW.formal_sol_gamma_matrices(deviceResident=True)
+        gc.collect()
+        gc.disable()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            itW.formal_sol_gamma_matrices(deviceResident=True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        ew = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device='cuda')
+        gc.enable()
+        dist.all_reduce(ew, op=dist.ReduceOp.MAX)
+        weak = {'weak_shard_iters_per_s': world * args.steps / float(ew.item()), 'weak_ms_per_step': 1e3 * float(ew.item()) / args.steps,
+                'weak_Nlambda_total': probW.Nlambda}
 
     # not part of the metric ("report stat_eq time separately"): the population solve, and the other
     # BASELINE configs
@@ -396,7 +463,8 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm',
-                'kernel': 'raymarch_kernel (ray-column sweep with the fused post-pass)',
+                'kernel': ('lanesweep_kernel (depth-across-lanes sweep)' if sweep_kind == 'lanes'
+                           else 'raymarch_kernel (ray-column march with the fused post-pass)'),
                 'achieved': achieved,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
@@ -417,8 +485,11 @@ def main():
                 },
             },
         }
+        out['config']['sweep'] = sweep_kind
         if world > 1:
             out['allreduce_us'] = allreduce_us
+        if weak:
+            out.update(weak)
         if aux:
             out['aux'] = aux
         if world == 1 and not args.no_cpu_baseline:

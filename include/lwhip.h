@@ -443,6 +443,9 @@ int lwhip_sweep_time(lwhip_context* ctx, double* meanMs, int* nLaunches);
 
 /* Algorithmic bytes one iteration of this context moves (SURVEY.md 8d / DESIGN.md). */
 int lwhip_algorithmic_bytes(lwhip_context* ctx, double* bytes);
+/* Which sweep kernel serves this context (chosen at lwhip_create from its size, LWHIP_SWEEP overrides):
+ * 0 the ray-column march (raymarch_kernel), 1 the depth-across-lanes sweep (lanesweep_kernel), 2 the 2D pipeline. */
+int lwhip_sweep_kind(lwhip_context* ctx);
 
 #ifdef __cplusplus
 }

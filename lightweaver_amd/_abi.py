@@ -170,6 +170,7 @@ SYMBOLS = [
     ('lwhip_profile_enable', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_sweep_time', C.c_int, [ctx_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ('lwhip_algorithmic_bytes', C.c_int, [ctx_p, C.POINTER(C.c_double)]),
+    ('lwhip_sweep_kind', C.c_int, [ctx_p]),
 ]
 
 

@@ -373,6 +373,10 @@ class Context:
         _check(self.lib, self.lib.lwhip_sweep_time(self._h, C.byref(ms), C.byref(n)), 'lwhip_sweep_time')
         return ms.value, n.value
 
+    def sweep_kind(self):
+        """'march' (ray-column march), 'lanes' (depth-across-lanes sweep) or '2d': which sweep kernel the library chose."""
+        return {0: 'march', 1: 'lanes', 2: '2d'}.get(self.lib.lwhip_sweep_kind(self._h), '?')
+
     def algorithmic_bytes(self):
         b = C.c_double()
         _check(self.lib, self.lib.lwhip_algorithmic_bytes(self._h, C.byref(b)), 'lwhip_algorithmic_bytes')

@@ -165,6 +165,7 @@ struct lwhip_context
     DevBuf<VoigtLineArgs> voigtList; // the lines' argument blocks of lwhip_compute_profiles
     DevBuf<double> wphiScratch;   // [16, Ns] wavelength-slice sums of the profile normalisation
     DevBuf<int> wphiTicket;       // arrival counters of its point tiles
+    bool lastSweepUpOnly = false; // the last sweep traced the up rays only (lwhip_formal_sol(upOnly))
     bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
     int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
     bool prdDetailed = false;     // LWHIP_OPT_PRD_DETAILED: the PRD calls include the detailed atoms' PRD lines
@@ -1669,9 +1670,19 @@ int build_tile_args(lwhip_context* c)
             HIP_TRY(hipHostGetDevicePointer((void**)&a.lsDbg, c->lsDbgHost, 0));
         }
     }
-    c->htargs = a;
-    std::vector<TileArgs> v(1, a);
-    HIP_TRY(c->dtargs.upload(v));
+    // The device copies of the argument blocks keep their addresses for the life of the context (a fused column batch
+    // holds them): the first call allocates, later ones (lwhip_set_zplane_outputs) overwrite in place on the stream.
+    auto put = [&](DevBuf<TileArgs>& dev, TileArgs& host, const TileArgs& val) -> hipError_t {
+        host = val;
+        if (!dev.p)
+        {
+            hipError_t e = dev.alloc(1);
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipMemcpyAsync(dev.p, &host, sizeof(TileArgs), hipMemcpyHostToDevice, c->stream);
+    };
+    HIP_TRY(put(c->dtargs, c->htargs, a));
     if (c->nTileChunksPrd > 0)
     {
         a.tslots = c->tslotsPrd.p;
@@ -1679,9 +1690,7 @@ int build_tile_args(lwhip_context* c)
         a.tileList = c->tileListPrd.p;
         a.slotTr = c->tileSlotTrPrd.p;
         a.postChunkTile = c->postChunkTilePrd.p;
-        c->htargsPrd = a;
-        v[0] = a;
-        HIP_TRY(c->dtargsPrd.upload(v));
+        HIP_TRY(put(c->dtargsPrd, c->htargsPrd, a));
     }
     return LWHIP_OK;
 }
@@ -1718,7 +1727,7 @@ TileDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
     TileDyn d{};
     d.nPass = upOnly ? 1 : 2;
     d.lambdaIterate = lambdaIterate;
-    d._pad = (env_int("LWHIP_RM_SKIP", 0) << 8) | (env_int("LWHIP_POST_SKIP", 0) << 12); // timing experiments
+    d._pad = 0;
     return d;
 }
 
@@ -1989,10 +1998,20 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         {
             const lwhip_grid2d& g = *p.grid2d;
             const size_t nLow = (size_t)g.xLowerBc->Nmu * g.Nz, nUp = (size_t)g.xUpperBc->Nmu * g.Nz;
+            // the plugin re-borrows these arrays on every call: the index tables are checked again against the (possibly
+            // changed) Nmu of each side, and each side's buffer follows its own size
+            for (int q = 0; q < 2 * g.Nrays; ++q)
+                if (g.xLowerBc->idxs[q] < 0 || g.xLowerBc->idxs[q] >= g.xLowerBc->Nmu || g.xUpperBc->idxs[q] < 0
+                    || g.xUpperBc->idxs[q] >= g.xUpperBc->Nmu)
+                    return fail(LWHIP_ERR_INVALID, "2D grid: x boundary idxs out of range (\"Error in boundary condition indexing\")");
+            if (c->xbcLow.n < Nla * nLow || c->xbcUp.n < Nla * nUp || !c->xIdxLow.p)
+                HIP_TRY(hipStreamSynchronize(c->stream)); // nothing may still read a buffer about to be replaced
             if (c->xbcLow.n < Nla * nLow)
-            {
                 HIP_TRY(c->xbcLow.alloc(Nla * nLow));
+            if (c->xbcUp.n < Nla * nUp)
                 HIP_TRY(c->xbcUp.alloc(Nla * nUp));
+            if (!c->xIdxLow.p)
+            {
                 HIP_TRY(c->xIdxLow.alloc(Nr * 2));
                 HIP_TRY(c->xIdxUp.alloc(Nr * 2));
             }
@@ -2118,7 +2137,9 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
     if (mask & LWHIP_I)
     {
         D2H(p.I + l0 * Nr * c->Nx, c->I.p, Nla * Nr * (size_t)c->Nx);
-        if (c->zDownHost)
+        // (an up-only formal solution does not trace the down rays: ZPlaneDown keeps what the caller has,
+        // SimdFullIterationTemplates.hpp:351-361)
+        if (c->zDownHost && !c->lastSweepUpOnly)
             D2H(c->zDownHost + l0 * Nr * c->Nx, c->zDown.p, Nla * Nr * (size_t)c->Nx);
         if (c->zUpHost)
             D2H(c->zUpHost + l0 * Nr * c->Nx, c->zUp.p, Nla * Nr * (size_t)c->Nx);
@@ -2402,6 +2423,7 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    c->lastSweepUpOnly = false;
     {
         const int stp = ensure_profiles(c);
         if (stp != LWHIP_OK)
@@ -2901,6 +2923,7 @@ int lwhip_formal_sol(lwhip_context* c, int upOnly)
         if (stp != LWHIP_OK)
             return stp;
     }
+    c->lastSweepUpOnly = upOnly != 0;
     if (c->is2d)
         return run_2d(c, 0, upOnly ? 2 : 1);
     const TileDyn dyn = make_dyn(c, upOnly != 0, 0);
@@ -3842,6 +3865,13 @@ int lwhip_sweep_time(lwhip_context* c, double* meanMs, int* nLaunches)
     if (nLaunches)
         *nLaunches = c->sweepCount;
     return LWHIP_OK;
+}
+
+int lwhip_sweep_kind(lwhip_context* c)
+{
+    if (!c)
+        return -1;
+    return c->is2d ? 2 : c->laneSweep ? 1 : 0;
 }
 
 int lwhip_algorithmic_bytes(lwhip_context* c, double* bytes)

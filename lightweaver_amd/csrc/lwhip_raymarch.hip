@@ -1188,7 +1188,7 @@ __global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __
     double* cols = lds + 16;                            // [Natom + 2 NlevTot][T]
     const int chunk = blockIdx.x;
     const int t0 = CTAB(int32_t, chunkTile)[chunk], t1 = CTAB(int32_t, chunkTile)[chunk + 1];
-    const bool doCont = !dyn.prdOnly && !(dyn._pad & 0x2000); // the PRD rates pass needs J and dJ only (0x2000: timing experiment)
+    const bool doCont = !dyn.prdOnly; // the PRD rates pass needs J and dJ only
     for (int li = t0; li < t1; ++li)
     {
         const int ti = tileList ? CTAB(int32_t, tileList)[li] : li;
@@ -1234,12 +1234,6 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileA
         const int toObs = (nDir == 2) ? (task & 1) : 1;
         const int ti = tileList ? tileList[li] : li;
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
-        if (dyn._pad & 0xf00) // timing experiment (LWHIP_RM_SKIP): leave out the tiles of some kinds (results are then wrong)
-        {
-            const int kd = td.nLine == 0 ? 1 : (td.nLine == 1 && td.nMixed == 0) ? 2 : (td.nLine == 1) ? 4 : 8;
-            if ((dyn._pad >> 8) & kd)
-                continue;
-        }
         if (CAP == 0)
         {
             if (td.nLine == 0)

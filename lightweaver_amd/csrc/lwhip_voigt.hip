@@ -6,6 +6,30 @@
 // vendors (Source/Faddeeva.cc:680-972, S. G. Johnson, MIT): Laplace continued fraction for large
 // |z|, Zaghloul & Ali's Algorithm 916 sums elsewhere.  exp(-a^2 n^2) comes from a table filled on
 // the host; erfcx is the device math library's.
+/* The Faddeeva-function algorithm restated in this file is that of the Faddeeva package
+ * (http://ab-initio.mit.edu/Faddeeva), whose licence asks that its notice accompany substantial portions:
+ *
+ * Copyright (c) 2012 Massachusetts Institute of Technology
+ *
+ * Permission is hereby granted, free of charge, to any person obtaining
+ * a copy of this software and associated documentation files (the
+ * "Software"), to deal in the Software without restriction, including
+ * without limitation the rights to use, copy, modify, merge, publish,
+ * distribute, sublicense, and/or sell copies of the Software, and to
+ * permit persons to whom the Software is furnished to do so, subject to
+ * the following conditions:
+ *
+ * The above copyright notice and this permission notice shall be
+ * included in all copies or substantial portions of the Software.
+ *
+ * THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND,
+ * EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF
+ * MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+ * NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE
+ * LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION
+ * OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION
+ * WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+ */
 #include "lwhip_internal.h"
 #include "lwhip_device.h"
 #include "../../include/lwhip.h"

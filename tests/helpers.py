@@ -95,3 +95,32 @@ def compare_to_golden(prob, d, variant, keys=None, tol=TOL_ONE_CALL):
     bad = {k: e for k, e in worst.items() if not e <= tol}
     assert not bad, f'{variant}: beyond tol {tol}: {bad} (all: {worst})'
     return worst
+
+
+def gamma_term_scale(atom):
+    """Cancellation-aware scale of every Gamma element of an active atom, from the REFERENCE side's own outputs: an
+    off-diagonal element is the collisional pre-fill plus, per transition between the two levels, the integrals
+    sum (Uji + Vji I) w = Rji (element (i, j)) / sum Vij I w = Rij (element (j, i)) minus preconditioning terms of at
+    most that size -- a sum of terms of both signs whose magnitude is |C| + R, not |Gamma|.  The diagonal is minus the
+    column sum (finalise_Gamma, SimdFullIterationTemplates.hpp:491-508).  |dGamma| <= tol * scale is the bound a sum
+    formed in a different order can be held to; |dGamma| <= tol * |Gamma| is not where the terms cancel."""
+    Nl = atom.Nlevel
+    S = np.abs(np.asarray(atom.C, dtype=np.float64)) if atom.C is not None else np.zeros_like(atom.Gamma)
+    S = S.copy().reshape(Nl, Nl, -1)
+    for t in atom.trans:
+        S[t.i, t.j] += np.abs(t.Rji)
+        S[t.j, t.i] += np.abs(t.Rij)
+    for i in range(Nl):
+        S[i, i] = 0.0
+    for i in range(Nl):
+        S[i, i] = S[:, i].sum(axis=0)
+    return S.reshape(atom.Gamma.shape)
+
+
+def gamma_err_scaled(got, want_atom):
+    """max |Gamma_got - Gamma_ref| / scale (gamma_term_scale of the reference atom)."""
+    S = gamma_term_scale(want_atom)
+    d = np.abs(np.asarray(got, dtype=np.float64) - want_atom.Gamma)
+    nz = S > 0.0
+    assert np.all(d[~nz] == 0.0)
+    return float(np.max(d[nz] / S[nz])) if nz.any() else 0.0

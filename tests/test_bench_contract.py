@@ -23,11 +23,12 @@ def test_bench_line_contract(gpu):
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity_checked', 'max_rel_err'):
         assert key in d, key
     assert d['n_gpus'] == 1 and d['steps'] == 5 and d['warmup'] == 2 and d['higher_is_better'] is True
-    assert d['dtype'] == 'f64' and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f64' and d['scaling'] == 'strong' and d['vs_baseline'] is None
     assert 'workload' in d['config'] and abs(d['config']['Nlambda_per_gpu'] - 10240) <= 102
+    assert d['config']['sweep'] in ('march', 'lanes')
     assert d['value'] == pytest.approx(1e3 / d['ms_per_step'], rel=1e-9)
     r = d['roofline']
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and 'raymarch_kernel' in r['kernel']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and ('raymarch_kernel' in r['kernel'] or 'lanesweep_kernel' in r['kernel'])
     assert r['launches_timed'] >= 1 and 0.0 < r['kernel_ms'] < d['ms_per_step']
     assert r['achieved'] == pytest.approx(r['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9, rel=1e-9)
     assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], rel=1e-12)

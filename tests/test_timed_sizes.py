@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import rel_err
+from helpers import gamma_err_scaled, rel_err
 from lightweaver_amd import _abi as abi
 from lightweaver_amd.harness import models
 from oracle.bindings import OracleContext
@@ -15,10 +15,16 @@ pytestmark = pytest.mark.gpu
 THREADS = min(os.cpu_count() or 1, 64)
 
 
-def assert_iteration_matches(p, q, tolGamma=1e-9, tol=1e-9):
+def assert_iteration_matches(p, q, tolGamma=1e-9, tol=1e-9, scaledGamma=False):
+    """scaledGamma: Gamma against the cancellation-aware scale of its terms (helpers.gamma_term_scale) at tolGamma, and
+    element-wise relative only as a coarse guard (100 tolGamma): used where the device sums the terms in another order
+    than the reference (2D: per-wavelength ray sums) -- DESIGN.md section 4."""
     worst = {'J': rel_err(p.J, q.J), 'I': rel_err(p.I, q.I)}
     for ia, (a, b) in enumerate(zip(p.atoms, q.atoms)):
-        if not a.detailed:
+        if not a.detailed and scaledGamma:
+            worst[f'Gamma{ia}'] = gamma_err_scaled(a.Gamma, b)
+            assert rel_err(a.Gamma, b.Gamma) <= 100.0 * tolGamma
+        elif not a.detailed:
             worst[f'Gamma{ia}'] = rel_err(a.Gamma, b.Gamma)
         worst[f'R{ia}'] = max(max(rel_err(ta.Rij, tb.Rij), rel_err(ta.Rji, tb.Rji)) for ta, tb in zip(a.trans, b.trans))
     assert all(v <= (tolGamma if k.startswith('Gamma') else tol) for k, v in worst.items()), worst
@@ -44,6 +50,41 @@ def test_throughput_grid_iteration_and_stat_equil_vs_oracle(gpu):
             assert oc.stat_equil() == 0
             for a, b in zip(prob.atoms, q.atoms):
                 assert rel_err(a.n, b.n) <= 1e-8
+
+
+@pytest.mark.parametrize('sweep', ['march', 'lanes'])
+def test_prd_at_timed_size_vs_oracle(gpu, monkeypatch, sweep):
+    """BASELINE configs[2] as bench.py's aux entry C3 times it: the 10 240-wavelength grid with Ca II H & K as PRD lines
+    (2 x ~1 100 wavelengths, 5 mu): one formal solution + one redistribute_prd(3, 0.0) from identical inputs against the
+    oracle (the reference's redistribute_prd_lines restated, pinned to the core by tests/test_prd.py): rho, J, the PRD
+    lines' rates at the one-call bound 1e-9.  This is where the per-line fine-grid cache (185 MB), the emission
+    wavelength slices over workgroups and the all-lines-in-one-launch form of the scattering integral run."""
+    from lightweaver_amd.context import Context
+    monkeypatch.setenv('LWHIP_SWEEP', sweep)
+    prob = models.throughput_grid(NlambdaTarget=10240, Nrays=5, prd=True)
+    q = prob.copy()
+    oc = OracleContext(q)
+    q.gamma_prefill()
+    oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+    uo = oc.redistribute_prd(3, 0.0)
+    p = prob.copy()
+    with Context(p) as ctx:
+        p.gamma_prefill()
+        ctx.formal_sol_gamma_matrices()
+        uh = ctx.redistribute_prd(3, 0.0)
+    assert uo['NprdSubIter'] == uh.NprdSubIter == 3
+    # max |d rho / rho| is attained where rho passes close to 0 in the rough start: the state below is the check
+    assert np.allclose(uo['dRho'], uh.dRho, rtol=1e-5, atol=1e-12)
+    assert np.allclose(uo['dJPrdMax'], uh.dJPrdMax, rtol=1e-7, atol=1e-12)
+    assert rel_err(p.J, q.J) <= 1e-9
+    nprd = 0
+    for a, b in zip(p.atoms, q.atoms):
+        for ta, tb in zip(a.trans, b.trans):
+            if ta.rhoPrd is not None:
+                nprd += 1
+                assert rel_err(ta.rhoPrd, tb.rhoPrd) <= 1e-9
+                assert rel_err(ta.Rij, tb.Rij) <= 1e-9 and rel_err(ta.Rji, tb.Rji) <= 1e-9
+    assert nprd == 2
 
 
 def test_512_column_fused_batch_sample_vs_oracle(gpu):
@@ -94,8 +135,9 @@ def test_2d_256x82_iteration_vs_oracle(gpu):
         q.gamma_prefill()
         dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
         assert up.dJMax == pytest.approx(dJ, rel=1e-9)
-        # Gamma: the device adds per-wavelength ray sums where the reference adds term by term (tests/test_fs2d.py)
-        assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-8)
+        # Gamma: the device adds per-wavelength ray sums where the reference adds term by term: 1e-9 of the magnitude of
+        # the terms summed (helpers.gamma_term_scale), the stated one-call bound
+        assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-9, scaledGamma=True)
         ctx.stat_equil()
         assert oc.stat_equil() == 0
         assert rel_err(prob.atoms[0].n, q.atoms[0].n) <= 1e-8
@@ -120,7 +162,7 @@ def test_2d_ragged_widths_iteration_vs_oracle(gpu, Nx, nz, dx):
         assert up.dJMax == pytest.approx(dJ, rel=1e-9)
         # (Gamma's preconditioned terms cancel to ~1e-6 of their parts on these coarse 8 ... 30-plane atmospheres, and
         # the device groups the ray sums per wavelength: J, I and the rates agree to 1e-13, Gamma to a few 1e-8)
-        assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-7)
+        assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-9, scaledGamma=True)
 
 
 def test_converged_solution_at_config1_size_vs_oracle(gpu):
