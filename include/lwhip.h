@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LWHIP_ABI_VERSION 3
+#define LWHIP_ABI_VERSION 4
 
 /* ---- enums (values mirror the reference where one exists) ---------------- */
 
@@ -178,6 +178,41 @@ typedef struct lwhip_problem {
     const struct lwhip_grid2d* grid2d;
 } lwhip_problem;
 
+/* Hybrid PRD (Leenaarts et al. 2012): what configure_hprd_coeffs (Source/Prd.cpp:697-946) leaves in Spectrum
+ * (prdIdxs, hPrdIdxs, JRest, JCoeffs; Source/LwMisc.hpp:92-104) and in every PRD line (hPrdCoeffs,
+ * Source/LwTransition.hpp:65), flattened.  With it a context
+ *   - multiplies V_ji of a PRD line by rho interpolated to the ray's rest wavelength,
+ *     rho = (1 - frac) rhoPrd(i0, k) + frac rhoPrd(i1, k)   (Transition::uv, Source/LwTransition.hpp:116-127)
+ *     instead of by rhoPrd(lt, k) (Source/LwAtom.hpp:118-123),
+ *   - scatters every ray's intensity into the rest-frame mean intensity,
+ *     JRest(idx, k) += 0.5 wmu frac I(k)   (Source/SimdFullIterationTemplates.hpp:397-408),
+ *   - takes J of the scattering integral from JRest (Source/Prd.cpp:384-389, 484-490),
+ *   - visits hPrdIdxs in the PRD rates pass (Source/PrdTemplates.hpp:234-248).
+ * All arrays are borrowed for the life of the context; JRest is written by lwhip_download(LWHIP_J). */
+typedef struct lwhip_rho_coeff {   /* Prd::RhoInterpCoeffs, Source/LwMisc.hpp:50-57 */
+    int32_t i0, i1;
+    double frac;
+} lwhip_rho_coeff;
+typedef struct lwhip_j_coeff {     /* Prd::JInterpCoeffs, Source/LwMisc.hpp:58-64 */
+    double frac;
+    int32_t idx;                   /* row of JRest */
+    int32_t _pad;
+} lwhip_j_coeff;
+typedef struct lwhip_hprd {
+    int32_t NprdLambda;            /* spect.prdIdxs.size(): wavelengths where a PRD line is active = rows of JRest  */
+    int32_t NhPrd;                 /* spect.hPrdIdxs.size(): wavelengths that scatter into them                     */
+    int32_t Nlines;                /* PRD lines that carry hPrdCoeffs                                                */
+    int32_t _pad;
+    const int32_t* prdIdxs;        /* [NprdLambda] global wavelength indices, increasing                             */
+    const int32_t* hPrdIdxs;       /* [NhPrd]                                                                        */
+    double* JRest;                 /* [NprdLambda, Nspace] out                                                       */
+    const int64_t* jCoeffOff;      /* [NhPrd * Nrays * 2 * Nspace + 1]: where JCoeffs(hPrdLa, mu, toObs, k) starts   */
+    const lwhip_j_coeff* jCoeffs;  /* the entries, back to back                                                      */
+    const int32_t* lineAtom;       /* [Nlines] index into prob->atoms                                                */
+    const int32_t* lineTrans;      /* [Nlines] index into that atom's trans                                          */
+    const lwhip_rho_coeff* const* rhoCoeffs; /* [Nlines] -> [Nred - Nblue, Nrays, 2, Nspace]                         */
+} lwhip_hprd;
+
 #define LWHIP_OPT_PRD_DETAILED (1 << 16)
 
 typedef struct lwhip_options {
@@ -193,6 +228,7 @@ typedef struct lwhip_options {
     int32_t worldSize;     /* number of wavelength shards of the job (0 or 1 = unsharded)          */
     int32_t worldRank;     /* this shard's ordinal: selects its (dJMax, idx) slot in the buffer    */
     void* stream;          /* hipStream_t to launch on, NULL = the library's own stream            */
+    const lwhip_hprd* hprd;/* hybrid PRD tables (configure_hprd_coeffs was called on the Context), or NULL */
 } lwhip_options;
 
 typedef struct lwhip_context lwhip_context; /* opaque */

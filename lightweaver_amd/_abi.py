@@ -5,7 +5,7 @@ offsets against a C program compiled from the header.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 AXIS_NONE, AXIS_X, AXIS_Z = 0, 1, 2
 
 # enums (include/lwhip.h)
@@ -85,11 +85,31 @@ class lwhip_problem(C.Structure):
 OPT_PRD_DETAILED = 1 << 16   # lwhip_options.flags: the PRD calls include the detailed atoms' PRD lines
 
 
+class lwhip_rho_coeff(C.Structure):
+    _fields_ = [('i0', C.c_int32), ('i1', C.c_int32), ('frac', C.c_double)]
+
+
+class lwhip_j_coeff(C.Structure):
+    _fields_ = [('frac', C.c_double), ('idx', C.c_int32), ('_pad', C.c_int32)]
+
+
+class lwhip_hprd(C.Structure):
+    """Hybrid-PRD tables (what configure_hprd_coeffs leaves in Spectrum and the PRD lines), flattened."""
+    _fields_ = [
+        ('NprdLambda', C.c_int32), ('NhPrd', C.c_int32), ('Nlines', C.c_int32), ('_pad', C.c_int32),
+        ('prdIdxs', i32p), ('hPrdIdxs', i32p), ('JRest', f64p),
+        ('jCoeffOff', C.POINTER(C.c_int64)), ('jCoeffs', C.POINTER(lwhip_j_coeff)),
+        ('lineAtom', i32p), ('lineTrans', i32p),
+        ('rhoCoeffs', C.POINTER(C.POINTER(lwhip_rho_coeff))),
+    ]
+
+
 class lwhip_options(C.Structure):
     _fields_ = [
         ('device', C.c_int32), ('laStart', C.c_int32), ('laEnd', C.c_int32), ('flags', C.c_int32),
         ('worldSize', C.c_int32), ('worldRank', C.c_int32),
         ('stream', C.c_void_p),
+        ('hprd', C.POINTER(lwhip_hprd)),
     ]
 
 

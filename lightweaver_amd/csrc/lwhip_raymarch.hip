@@ -1202,8 +1202,15 @@ __global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __
 // mixed continua.
 // FUSE: the workgroup is the two wavefronts (down, up) of ONE tile and finishes it with the post-pass (post_tile) while
 // the tile's moments are still in L2: no separate post launch, its accumulators in the march's free registers.
+// (-DRM_WAVES_PER_EU=n: the occupancy experiment of profiles/r03_occupancy.md -- the register allocator is held to
+// 512 / n VGPRs; the shipped build leaves it at the 2 wavefronts per SIMD its 222 VGPRs give)
+#ifdef RM_WAVES_PER_EU
+#define RM_OCC __attribute__((amdgpu_waves_per_eu(RM_WAVES_PER_EU)))
+#else
+#define RM_OCC
+#endif
 template <int SOLVER, int CAP, bool RATES, bool BATCH, bool FUSE>
-__global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_kernel(const TileArgs* __restrict__ ap0,
+__global__ void __launch_bounds__(RM_MAX_WAVES * 64) RM_OCC raymarch_kernel(const TileArgs* __restrict__ ap0,
                                                                       const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
     extern __shared__ double lds[];

@@ -71,6 +71,42 @@ class _Handle:
         self.close()
 
 
+class HprdTables:
+    """numpy views of an lwhip_hprd (borrowed: valid while the block that owns it lives) and the descriptor itself
+    (`.ptr`: what lwhip_options.hprd / lworacle_set_hprd take)."""
+
+    def __init__(self, ptr, prob, free=None):
+        import numpy as np
+        self.ptr, self._free = ptr, free
+        h = ptr.contents
+        Ns, Nrays = prob.Nspace, prob.Nrays
+        as_np = np.ctypeslib.as_array
+        self.prdIdxs = as_np(h.prdIdxs, (h.NprdLambda,))
+        self.hPrdIdxs = as_np(h.hPrdIdxs, (max(h.NhPrd, 1),))[:h.NhPrd]
+        self.JRest = as_np(h.JRest, (h.NprdLambda, Ns))
+        ncell = h.NhPrd * Nrays * 2 * Ns
+        self.jCoeffOff = as_np(h.jCoeffOff, (ncell + 1,))
+        nj = int(self.jCoeffOff[-1])
+        jdt = np.dtype([('frac', np.float64), ('idx', np.int32), ('_pad', np.int32)])
+        jc = np.frombuffer(as_np(C.cast(h.jCoeffs, C.POINTER(C.c_uint8)), (max(nj, 1) * 16,)), dtype=jdt)[:nj]
+        self.jFrac = jc['frac']
+        self.jIdx = jc['idx']
+        self.lineAtom = as_np(h.lineAtom, (h.Nlines,))
+        self.lineTrans = as_np(h.lineTrans, (h.Nlines,))
+        self.rho = []
+        for q in range(h.Nlines):
+            t = prob.atoms[int(self.lineAtom[q])].trans[int(self.lineTrans[q])]
+            n = (t.Nred - t.Nblue) * Nrays * 2 * Ns
+            rdt = np.dtype([('i0', np.int32), ('i1', np.int32), ('frac', np.float64)])
+            raw = np.frombuffer(as_np(C.cast(h.rhoCoeffs[q], C.POINTER(C.c_uint8)), (n * 16,)), dtype=rdt)
+            self.rho.append((raw['i0'], raw['i1'], raw['frac']))
+
+    def close(self):
+        if self._free and self.ptr:
+            self._free(self.ptr)
+            self.ptr = None
+
+
 def _redistribute(fn, h, maxIter, tol, nprd_guess=16):
     import numpy as np
     nit = C.c_int32(0)
@@ -111,6 +147,10 @@ class RefContext(_Handle):
                                                    abi.f64p, abi.i32p, abi.f64p, abi.i32p]
             lib.lwref_set_include_detailed.argtypes = [C.c_void_p, C.c_int]
             lib.lwref_set_include_detailed.restype = None
+            lib.lwref_hprd_export.restype = C.POINTER(abi.lwhip_hprd)
+            lib.lwref_hprd_export.argtypes = [C.c_void_p, C.c_int]
+            lib.lwref_hprd_free.argtypes = [C.POINTER(abi.lwhip_hprd)]
+            lib.lwref_hprd_free.restype = None
             lib.lwref_time_dep_update.argtypes = [C.c_void_p, C.c_int, abi.f64p, C.c_double]
             lib.lwref_nr_post_update.argtypes = [C.c_void_p, C.POINTER(abi.lwhip_nr_args)]
             lib.lwref_GII.restype = C.c_double
@@ -177,6 +217,12 @@ class RefContext(_Handle):
     def redistribute_prd(self, maxIter=3, tol=1e-2, include_detailed_atoms=False):
         self.lib.lwref_set_include_detailed(self.h, int(include_detailed_atoms))
         return _redistribute(self.lib.lwref_redistribute_prd, self.h, maxIter, tol)
+
+    def configure_hprd(self, include_detailed_atoms=False):
+        """configure_hprd_coeffs on the real Context (hybrid PRD from now on); its tables, flattened."""
+        ptr = self.lib.lwref_hprd_export(self.h, int(include_detailed_atoms))
+        assert ptr, 'configure_hprd_coeffs: no PRD lines'
+        return HprdTables(ptr, self.prob, self.lib.lwref_hprd_free)
 
     def time_dep_update(self, atom, nOld, dt):
         import numpy as np
@@ -285,6 +331,22 @@ class OracleContext(_Handle):
     def redistribute_prd(self, maxIter=3, tol=1e-2, include_detailed_atoms=False):
         self.lib.lworacle_set_include_detailed(self.h, int(include_detailed_atoms))
         return _redistribute(self.lib.lworacle_redistribute_prd, self.h, maxIter, tol)
+
+    def build_hprd(self, include_detailed_atoms=False):
+        """configure_hprd_coeffs restated (lworacle_hprd_build): the tables only, nothing is switched on."""
+        self.lib.lworacle_hprd_build.restype = C.POINTER(abi.lwhip_hprd)
+        self.lib.lworacle_hprd_build.argtypes = [C.c_void_p, C.c_int]
+        self.lib.lworacle_hprd_free.argtypes = [C.POINTER(abi.lwhip_hprd)]
+        self.lib.lworacle_hprd_free.restype = None
+        ptr = self.lib.lworacle_hprd_build(self.h, int(include_detailed_atoms))
+        assert ptr, 'lworacle_hprd_build: no PRD lines (or no vlosMu)'
+        return HprdTables(ptr, self.prob, self.lib.lworacle_hprd_free)
+
+    def set_hprd(self, tables):
+        """Hybrid PRD with these tables from now on (None: plain PRD)."""
+        self.lib.lworacle_set_hprd.argtypes = [C.c_void_p, C.POINTER(abi.lwhip_hprd)]
+        self._hprd = tables
+        assert self.lib.lworacle_set_hprd(self.h, tables.ptr if tables is not None else None) == 0
 
     def time_dep_update(self, atom, nOld, dt):
         import numpy as np

@@ -684,6 +684,103 @@ void lwref_set_include_detailed(void* h, int on)
     ((RefContext*)h)->includeDetailed = on != 0;
 }
 
+// configure_hprd_coeffs (Source/Prd.cpp:697-946) on the real Context, and its tables flattened into the ABI's lwhip_hprd
+// (arrays owned by the returned block; JRest points at the core's own spect.JRest, which the core's iterations fill).
+// The iterations of this context run in hybrid-PRD mode from here on.
+struct HprdExport
+{
+    lwhip_hprd h{};
+    std::vector<int32_t> prdIdxs, hPrdIdxs, lineAtom, lineTrans;
+    std::vector<int64_t> off;
+    std::vector<lwhip_j_coeff> jc;
+    std::vector<std::vector<lwhip_rho_coeff>> rho;
+    std::vector<const lwhip_rho_coeff*> rhoPtr;
+};
+
+lwhip_hprd* lwref_hprd_export(void* hh, int includeDetailed)
+{
+    auto* rc = (RefContext*)hh;
+    try
+    {
+        configure_hprd_coeffs(rc->ctx, includeDetailed != 0);
+        // (the intensity cores take their JRest view and the lines' coefficient views when they are set up: regenerate
+        // them, as LwContext.update_hprd_coeffs does, Source/LwMiddleLayer.pyx:3692-3705)
+        rc->ctx.update_threads();
+    }
+    catch (const std::exception& e)
+    {
+        std::fprintf(stderr, "lwref: %s\n", e.what());
+        return nullptr;
+    }
+    auto& spect = rc->spect;
+    if (!spect.JRest)
+        return nullptr;
+    auto* ex = new HprdExport();
+    const lwhip_problem* p = rc->prob;
+    const int Ns = p->Nspace, Nrays = p->Nrays;
+    ex->prdIdxs.assign(spect.prdIdxs.begin(), spect.prdIdxs.end());
+    ex->hPrdIdxs.assign(spect.hPrdIdxs.begin(), spect.hPrdIdxs.end());
+    const int NhPrd = (int)ex->hPrdIdxs.size();
+    ex->off.reserve((size_t)NhPrd * Nrays * 2 * Ns + 1);
+    for (int hq = 0; hq < NhPrd; ++hq)
+        for (int mu = 0; mu < Nrays; ++mu)
+            for (int toObs = 0; toObs < 2; ++toObs)
+                for (int k = 0; k < Ns; ++k)
+                {
+                    ex->off.push_back((int64_t)ex->jc.size());
+                    for (const auto& c : spect.JCoeffs(hq, mu, toObs, k))
+                        ex->jc.push_back(lwhip_j_coeff{ c.frac, c.idx, 0 });
+                }
+    ex->off.push_back((int64_t)ex->jc.size());
+    // the PRD lines in the order configure_hprd_coeffs walked them: active atoms, then (on request) detailed ones
+    size_t tIdx = 0;
+    std::vector<std::pair<int, int>> where; // (atom, kr) of every transition object, in creation order
+    for (int a = 0; a < p->Natom; ++a)
+        for (int kr = 0; kr < p->atoms[a].Ntrans; ++kr)
+            where.push_back({ a, kr });
+    (void)tIdx;
+    for (int pass = 0; pass < (includeDetailed ? 2 : 1); ++pass)
+        for (size_t q = 0; q < rc->transitions.size(); ++q)
+        {
+            Transition* t = rc->transitions[q].get();
+            const int a = where[q].first;
+            if ((p->atoms[a].detailed != 0) != (pass == 1) || !t->rhoPrd || !t->hPrdCoeffs)
+                continue;
+            ex->lineAtom.push_back(a);
+            ex->lineTrans.push_back(where[q].second);
+            const int nlt = (int)t->wavelength.shape(0);
+            std::vector<lwhip_rho_coeff> v((size_t)nlt * Nrays * 2 * Ns);
+            for (int lt = 0; lt < nlt; ++lt)
+                for (int mu = 0; mu < Nrays; ++mu)
+                    for (int toObs = 0; toObs < 2; ++toObs)
+                        for (int k = 0; k < Ns; ++k)
+                        {
+                            const auto& c = t->hPrdCoeffs(lt, mu, toObs, k);
+                            v[(((size_t)lt * Nrays + mu) * 2 + toObs) * Ns + k] = lwhip_rho_coeff{ c.i0, c.i1, c.frac };
+                        }
+            ex->rho.push_back(std::move(v));
+        }
+    for (auto& v : ex->rho)
+        ex->rhoPtr.push_back(v.data());
+    ex->h.NprdLambda = (int32_t)ex->prdIdxs.size();
+    ex->h.NhPrd = NhPrd;
+    ex->h.Nlines = (int32_t)ex->lineAtom.size();
+    ex->h.prdIdxs = ex->prdIdxs.data();
+    ex->h.hPrdIdxs = ex->hPrdIdxs.data();
+    ex->h.JRest = spect.JRest.data();
+    ex->h.jCoeffOff = ex->off.data();
+    ex->h.jCoeffs = ex->jc.data();
+    ex->h.lineAtom = ex->lineAtom.data();
+    ex->h.lineTrans = ex->lineTrans.data();
+    ex->h.rhoCoeffs = ex->rhoPtr.data();
+    return &ex->h; // (first member: the block is recovered from this pointer)
+}
+
+void lwref_hprd_free(lwhip_hprd* hp)
+{
+    delete (HprdExport*)hp;
+}
+
 // redistribute_prd_lines (Source/Prd.cpp:648-653 -> PrdTemplates.hpp:175-351)
 int lwref_redistribute_prd(void* h, int maxIter, double tol, int* NprdSubIter, int* NprdOut,
                            double* dRho, int* dRhoMaxIdx, double* dJPrdMax, int* dJPrdMaxIdx)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'lwhip.h')
 
 STRUCTS = [abi.lwhip_transition, abi.lwhip_atom, abi.lwhip_boundary, abi.lwhip_problem,
-           abi.lwhip_options, abi.lwhip_iter_result, abi.lwhip_prd_result, abi.lwhip_nr_args, abi.lwhip_intersection, abi.lwhip_grid2d]
+           abi.lwhip_options, abi.lwhip_rho_coeff, abi.lwhip_j_coeff, abi.lwhip_hprd, abi.lwhip_iter_result, abi.lwhip_prd_result, abi.lwhip_nr_args, abi.lwhip_intersection, abi.lwhip_grid2d]
 
 
 def test_struct_layout_matches_header(tmp_path):

@@ -1,0 +1,128 @@
+"""Hybrid PRD (Transition::uv with the per-ray rho interpolation, the JRest scatter of
+intensity_core_opt, the scattering integral on JRest; Source/LwTransition.hpp:116-127,
+Source/SimdFullIterationTemplates.hpp:397-408, Source/Prd.cpp:384-389, 697-946).
+
+CPU: the oracle's restatement of configure_hprd_coeffs against the tables the real core builds (oracle/_ref), bit for
+bit; the oracle's hybrid-PRD iterations against the core's, bit for bit.
+GPU: the HIP path (lwhip_options.hprd) against the oracle at the one-call bound."""
+import os
+
+import numpy as np
+import pytest
+
+from lightweaver_amd import _abi as abi
+from lightweaver_amd.harness import models
+from oracle import bindings
+from tests.helpers import TOL_ONE_CALL, rel_err
+
+HAVE_REF = os.path.exists(bindings.REF_LIB)
+
+
+def hprd_problem(Nrays=3, lineScale=0.3, vamp=8.0e3, seed=7):
+    """FAL-C H + Ca II with Ca II H & K as PRD lines on a column with a few km/s of line-of-sight velocity (what makes
+    the rest-frame and observer-frame grids differ)."""
+    atmos = models.falc82()
+    rng = np.random.default_rng(seed)
+    k = np.arange(atmos.Nspace)
+    atmos.vlos = vamp * np.sin(2.0 * np.pi * k / 37.0) + 0.2 * vamp * rng.standard_normal(atmos.Nspace)
+    return models.falc_h_ca(Nrays=Nrays, lineScale=lineScale, prd=True, atmos=atmos)
+
+
+def assert_tables_equal(a, b):
+    np.testing.assert_array_equal(a.prdIdxs, b.prdIdxs)
+    np.testing.assert_array_equal(a.hPrdIdxs, b.hPrdIdxs)
+    np.testing.assert_array_equal(a.jCoeffOff, b.jCoeffOff)
+    np.testing.assert_array_equal(a.jIdx, b.jIdx)
+    np.testing.assert_array_equal(a.jFrac, b.jFrac)
+    np.testing.assert_array_equal(a.lineAtom, b.lineAtom)
+    np.testing.assert_array_equal(a.lineTrans, b.lineTrans)
+    assert len(a.rho) == len(b.rho)
+    for (i0, i1, f), (j0, j1, g) in zip(a.rho, b.rho):
+        np.testing.assert_array_equal(i0, j0)
+        np.testing.assert_array_equal(i1, j1)
+        np.testing.assert_array_equal(f, g)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built')
+@pytest.mark.parametrize('vamp', [0.0, 8.0e3, 40.0e3])
+def test_oracle_hprd_tables_match_core(vamp):
+    prob = hprd_problem(vamp=vamp)
+    with bindings.RefContext(prob.copy()) as rc, bindings.OracleContext(prob.copy()) as oc:
+        tr = rc.configure_hprd()
+        to = oc.build_hprd()
+        assert tr.prdIdxs.size > 0 and tr.hPrdIdxs.size >= tr.prdIdxs.size
+        assert_tables_equal(to, tr)
+        to.close()
+        tr.close()
+
+
+def run_hprd(ctxFactory, prob, nIter=3, prdIter=3, tol=1e-2, Nthreads=None):
+    """iterate_ctx_se with hybrid PRD (lightweaver/iterate_ctx.py:85-208; LwContext(hprd=True) configures the tables
+    once at construction, Source/LwMiddleLayer.pyx:2822-2826): formal solution, statistical equilibrium, PRD
+    sub-iterations; returns the problem, the per-iteration PRD results and JRest."""
+    p = prob.copy()
+    out = []
+    with ctxFactory(p) as ctx:
+        tables = ctx.configure_hprd() if hasattr(ctx, 'configure_hprd') else None
+        if tables is None:
+            tables = ctx.build_hprd()
+            ctx.set_hprd(tables)
+        for it in range(nIter):
+            p.gamma_prefill()
+            if Nthreads is None:
+                ctx.formal_sol_gamma_matrices()
+            else:
+                ctx.formal_sol_gamma_matrices(Nthreads=Nthreads)
+            if it >= 1:
+                ctx.stat_equil()
+            out.append(ctx.redistribute_prd(prdIter, tol))
+        JRest = tables.JRest.copy()
+        if hasattr(ctx, 'set_hprd'):
+            ctx.set_hprd(None)
+        tables.close()
+    return p, out, JRest
+
+
+def assert_same(pa, pb, tol):
+    assert rel_err(pa.J, pb.J) <= tol
+    for a, b in zip(pa.atoms, pb.atoms):
+        assert rel_err(a.n, b.n) <= tol
+        if not a.detailed:
+            assert rel_err(a.Gamma, b.Gamma) <= tol
+        for ta, tb in zip(a.trans, b.trans):
+            assert rel_err(ta.Rij, tb.Rij) <= tol and rel_err(ta.Rji, tb.Rji) <= tol
+            if ta.rhoPrd is not None:
+                assert rel_err(ta.rhoPrd, tb.rhoPrd) <= tol
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='oracle/_ref not built')
+def test_oracle_hprd_iterations_match_core_bitwise():
+    prob = hprd_problem()
+    pr, ur, Jr = run_hprd(bindings.RefContext, prob)
+    po, uo, Jo = run_hprd(bindings.OracleContext, prob)
+    assert np.abs(Jr).max() > 0.0
+    np.testing.assert_array_equal(Jo, Jr)
+    np.testing.assert_array_equal(po.J, pr.J)
+    for a, b in zip(po.atoms, pr.atoms):
+        np.testing.assert_array_equal(a.n, b.n)
+        for ta, tb in zip(a.trans, b.trans):
+            np.testing.assert_array_equal(ta.Rij, tb.Rij)
+            if ta.rhoPrd is not None:
+                np.testing.assert_array_equal(ta.rhoPrd, tb.rhoPrd)
+    for x, y in zip(uo, ur):
+        assert x['NprdSubIter'] == y['NprdSubIter']
+        np.testing.assert_array_equal(x['dRho'], y['dRho'])
+        np.testing.assert_array_equal(x['dJPrdMax'], y['dJPrdMax'])
+
+
+def test_hybrid_prd_differs_from_plain_prd():
+    """The velocities matter: with them the hybrid scheme's rho differs from angle-averaged PRD's (sanity of the fixture)."""
+    prob = hprd_problem()
+    ph, _, _ = run_hprd(bindings.OracleContext, prob, nIter=1)
+    q = prob.copy()
+    with bindings.OracleContext(q) as oc:
+        q.gamma_prefill()
+        oc.formal_sol_gamma_matrices()
+        oc.redistribute_prd(3, 1e-2)
+    lines = lambda p: [t for a in p.atoms for t in a.trans if t.rhoPrd is not None]
+    assert max(np.abs(a.rhoPrd - b.rhoPrd).max() for a, b in zip(lines(ph), lines(q))) > 1e-3
