@@ -84,7 +84,11 @@ class Context:
 
     def __init__(self, prob: Problem, device: int = 0, laStart: int = 0, laEnd: int = 0,
                  stream: Optional[int] = None, lib_path: Optional[str] = None,
-                 worldSize: int = 1, worldRank: int = 0, batchHint: int = 0, prdDetailed: bool = False):
+                 worldSize: int = 1, worldRank: int = 0, batchHint: int = 0, prdDetailed: bool = False, hprd=None):
+        """hprd: hybrid PRD -- the tables configure_hprd_coeffs leaves in the reference's Context
+        (Source/Prd.cpp:697-946), as a ctypes pointer to lwhip_hprd or any object with such a `.ptr` (what
+        LwContext(hprd=True) sets up, Source/LwMiddleLayer.pyx:2822-2826); borrowed for the life of the context.
+        JRest comes back with download(J)."""
         self.lib = load_library(lib_path)
         self.prob = prob
         self._desc = prob.descriptor()
@@ -96,6 +100,9 @@ class Context:
         # prdDetailed: ExtraParams 'include_detailed_atoms' of the reference's PRD calls (LwMiddleLayer.pyx:3678-3680)
         opts.flags = min(max(int(batchHint), 0), 0xffff) | (abi.OPT_PRD_DETAILED if prdDetailed else 0)
         self.prdDetailed = bool(prdDetailed)
+        self._hprd = hprd   # keep the tables alive
+        if hprd is not None:
+            opts.hprd = getattr(hprd, 'ptr', hprd)
         h = C.c_void_p()
         st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
         _check(self.lib, st, 'lwhip_create')

@@ -124,6 +124,15 @@ struct lwhip_context
     int laneD = 0, laneLR = 0, laneR = 0;
     DevBuf<DevPostProg> postProg;
     DevBuf<double> geoT;
+    // hybrid PRD (lwhip_options.hprd): the tables of configure_hprd_coeffs on the device
+    const lwhip_hprd* hprd = nullptr;
+    std::vector<int> hLa2prdHost, hLa2hHost;     // global wavelength -> row of JRest / ordinal among hPrdIdxs, or -1
+    std::vector<int64_t> hRhoOffHost;             // per transition: offset of its rho-coefficient block, or -1
+    DevBuf<lwhip_rho_coeff> hRho;
+    DevBuf<int32_t> hLa2h;
+    DevBuf<int64_t> hJOff;
+    DevBuf<lwhip_j_coeff> hJCoef;
+    DevBuf<double> JRest;
     double* lsDbgHost = nullptr; // LWHIP_LS_TIMING: phase clocks of the last sweep, [nTiles][8]
     DevBuf<double> depArena; // lane sweep: n | wphi | ratio | geoT in one allocation (one buffer resource in the kernel)
     int tileWaves = 4, maxSlotsTile = 0, maxCTTile = 1, maxCTPost = 1, tileCap = 0, ktStride = 4;
@@ -467,6 +476,72 @@ int build_tables(lwhip_context* c)
     }
     c->NlevTot = c->levelOff[c->Natom];
     c->Ntrans = c->atomTrOff[c->Natom];
+    // ---- hybrid PRD: the tables of configure_hprd_coeffs (lwhip_options.hprd) onto the device ----------------------
+    c->hLa2prdHost.clear();
+    c->hLa2hHost.clear();
+    c->hRhoOffHost.assign(c->Ntrans, -1);
+    if (c->hprd)
+    {
+        const lwhip_hprd& H = *c->hprd;
+        const int Nlam = c->prob.Nlambda, Nr = c->Nrays;
+        if (c->is2d || c->worldSize > 1 || c->laStart != 0 || c->laEnd != Nlam)
+            return fail(LWHIP_ERR_UNSUPPORTED, "hybrid PRD: unsharded 1D contexts only (rho of the neighbouring wavelengths and "
+                                               "JRest live on one device)");
+        if (H.NprdLambda < 1 || H.Nlines < 1 || !H.prdIdxs || !H.JRest || !H.lineAtom || !H.lineTrans || !H.rhoCoeffs
+            || (H.NhPrd > 0 && (!H.hPrdIdxs || !H.jCoeffOff || !H.jCoeffs)))
+            return fail(LWHIP_ERR_INVALID, "hybrid PRD: incomplete lwhip_hprd");
+        c->hLa2prdHost.assign(Nlam, -1);
+        c->hLa2hHost.assign(Nlam, -1);
+        for (int i = 0; i < H.NprdLambda; ++i)
+        {
+            if (H.prdIdxs[i] < 0 || H.prdIdxs[i] >= Nlam)
+                return fail(LWHIP_ERR_INVALID, "hybrid PRD: prdIdxs out of range");
+            c->hLa2prdHost[H.prdIdxs[i]] = i;
+        }
+        for (int i = 0; i < H.NhPrd; ++i)
+        {
+            if (H.hPrdIdxs[i] < 0 || H.hPrdIdxs[i] >= Nlam)
+                return fail(LWHIP_ERR_INVALID, "hybrid PRD: hPrdIdxs out of range");
+            c->hLa2hHost[H.hPrdIdxs[i]] = i;
+        }
+        std::vector<lwhip_rho_coeff> rho;
+        for (int q = 0; q < H.Nlines; ++q)
+        {
+            const int ia = H.lineAtom[q], kr = H.lineTrans[q];
+            if (ia < 0 || ia >= c->Natom || kr < 0 || kr >= c->atoms[ia].Ntrans || !H.rhoCoeffs[q])
+                return fail(LWHIP_ERR_INVALID, "hybrid PRD: bad line list");
+            const lwhip_transition& t = c->atoms[ia].trans[kr];
+            if (t.type != LWHIP_LINE || !t.prd || !t.rhoPrd)
+                return fail(LWHIP_ERR_INVALID, "hybrid PRD: a listed transition is not a PRD line");
+            const int nlt = t.Nred - t.Nblue;
+            const size_t n = (size_t)nlt * Nr * 2 * Ns;
+            for (size_t i = 0; i < n; ++i)
+                if (H.rhoCoeffs[q][i].i0 < 0 || H.rhoCoeffs[q][i].i1 >= nlt || H.rhoCoeffs[q][i].i0 > H.rhoCoeffs[q][i].i1)
+                    return fail(LWHIP_ERR_INVALID, "hybrid PRD: rho interpolation index outside the line's grid");
+            c->hRhoOffHost[c->atomTrOff[ia] + kr] = (int64_t)rho.size();
+            rho.insert(rho.end(), H.rhoCoeffs[q], H.rhoCoeffs[q] + n);
+        }
+        rho.resize(rho.size() + 64, lwhip_rho_coeff{ 0, 0, 0.0 }); // (a ray's last block of depths reads past its row)
+        HIP_TRY(c->hRho.upload(rho));
+        std::vector<int32_t> l2h(c->hLa2hHost.begin(), c->hLa2hHost.end());
+        HIP_TRY(c->hLa2h.upload(l2h));
+        if (H.NhPrd > 0)
+        {
+            const size_t ncell = (size_t)H.NhPrd * Nr * 2 * Ns;
+            std::vector<int64_t> off(H.jCoeffOff, H.jCoeffOff + ncell + 1);
+            off.resize(off.size() + 8, off.back());
+            const int64_t nj = off[ncell];
+            for (int64_t e = 0; e < nj; ++e)
+                if (H.jCoeffs[e].idx < 0 || H.jCoeffs[e].idx >= H.NprdLambda)
+                    return fail(LWHIP_ERR_INVALID, "hybrid PRD: JCoeffs row outside JRest");
+            std::vector<lwhip_j_coeff> jc(H.jCoeffs, H.jCoeffs + nj);
+            jc.resize(jc.size() + 1, lwhip_j_coeff{ 0.0, 0, 0 });
+            HIP_TRY(c->hJOff.upload(off));
+            HIP_TRY(c->hJCoef.upload(jc));
+        }
+        HIP_TRY(c->JRest.alloc((size_t)H.NprdLambda * Ns));
+        HIP_TRY(hipMemset(c->JRest.p, 0, c->JRest.n * sizeof(double)));
+    }
     c->trans.clear();
     c->Nline = c->Ncont = 0;
     c->phiTot = c->rhoTot = c->parTot = 0;
@@ -608,6 +683,9 @@ int build_tables(lwhip_context* c)
         hdr[la].nMixed = (int16_t)mixed.size();
         hdr[la].nPure = (int16_t)pure.size();
         hdr[la].hasPrd = 0;
+        if (c->hprd && c->hprd->NhPrd > 0)
+            hdr[la].hasPrd = c->hLa2hHost[c->laStart + la] >= 0 ? 1 : 0; // hybrid PRD: the wavelengths that scatter into the PRD region (PrdTemplates.hpp:234-248)
+        else
         for (int tr : lines)
             if (c->trans[tr].t.prd && c->trans[tr].rhoOff >= 0 && (isOp(tr) || c->prdDetailed))
                 hdr[la].hasPrd = 1; // a wavelength the PRD rates pass visits (PrdTemplates.hpp:226-239)
@@ -846,10 +924,10 @@ int build_tables(lwhip_context* c)
             const char* sw = std::getenv("LWHIP_SWEEP");
             int D = 0, LR = 0, R = 0;
             const bool supported = lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R);
-            const bool force = sw && std::strcmp(sw, "lanes") == 0;
+            const bool force = (sw && std::strcmp(sw, "lanes") == 0) || c->hprd != nullptr; // (hybrid PRD lives in the lane sweep)
             const long waves = supported ? ((long)c->Nla + R - 1) / R * std::max(c->batchHint, 1) : 0;
             const bool prefer = force || (!sw && waves <= 2L * 4 * numCU);
-            if (!(sw && std::strcmp(sw, "march") == 0) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
+            if ((c->hprd || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
                 bool ok = true;
                 for (int la = 0; la < c->Nla && ok; ++la)
@@ -868,6 +946,9 @@ int build_tables(lwhip_context* c)
                 }
             }
         }
+        if (c->hprd && !c->laneSweep)
+            return fail(LWHIP_ERR_UNSUPPORTED, "hybrid PRD needs the depth-across-lanes sweep (Bezier3, 13 <= Nspace <= 256, at most "
+                                               "two lines or a line and a mixed continuum per wavelength)");
         const int L = c->laneSweep ? c->laneR : std::max(1, std::min({ 16, 64 / Nmu, env_int("LWHIP_TILE_L", 16) }));
         const int LRD = c->laneLR * c->laneD;
         c->tileL = L;
@@ -953,6 +1034,15 @@ int build_tables(lwhip_context* c)
                 ts.e = (int16_t)e;
                 ts.phiOff = -1;
                 ts.rhoOff = sl.rhoOff;
+                ts.hCoefOff = -1;
+                if (c->hprd && e < h.nLine && c->hRhoOffHost[slotTr[h.off + e]] >= 0)
+                {
+                    // hybrid PRD: the coefficient block of the tile's first wavelength, and the line's first rho row
+                    const HostTrans& ht = c->trans[slotTr[h.off + e]];
+                    const int64_t lt0 = la - ht.NblueLoc;
+                    ts.hCoefOff = c->hRhoOffHost[slotTr[h.off + e]] + lt0 * c->Nrays * 2 * Ns;
+                    ts.rhoOff = ht.rhoOff; // row 0 of the line
+                }
                 if (e < h.nLine && c->laneSweep)
                     ts.phiOff = sl.phiOff; // the profiles are read where they lie
                 else if (e < h.nLine)
@@ -1405,7 +1495,7 @@ int alloc_state(lwhip_context* c)
     }
     HIP_TRY(c->nTotal.alloc((size_t)c->Natom * Ns));
     HIP_TRY(c->phi.alloc((size_t)std::max<int64_t>(c->phiTot, 1)));
-    HIP_TRY(c->rho.alloc((size_t)std::max<int64_t>(c->rhoTot, 1)));
+    HIP_TRY(c->rho.alloc((size_t)std::max<int64_t>(c->rhoTot, 1) + 8)); // (+ padding: reads past a row's end by a block of depths)
     HIP_TRY(c->Gamma.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
     HIP_TRY(c->Cmat.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
     HIP_TRY(hipMemset(c->Cmat.p, 0, c->Cmat.n * sizeof(double)));
@@ -1658,6 +1748,11 @@ int build_tile_args(lwhip_context* c)
         a.depW = (uint32_t)((c->wphi.p - c->depArena.p) * sizeof(double));
         a.depRat = (uint32_t)((c->ratio.p - c->depArena.p) * sizeof(double));
         a.depG = (uint32_t)((c->geoT.p - c->depArena.p) * sizeof(double));
+        a.hRho = c->hRho.p;
+        a.hLa2h = c->hLa2h.p;
+        a.hJOff = c->hJOff.p;
+        a.hJCoef = c->hJCoef.p;
+        a.JRest = c->JRest.p;
         a.lsDbg = nullptr;
         if (std::getenv("LWHIP_LS_TIMING"))
         {
@@ -1742,6 +1837,14 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
     const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
     const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
     const bool fuse = c->tileFuse && rates;
+    if (rates && c->hprd && c->JRest.p)
+    {
+        // hybrid PRD: the rest-frame mean intensity is rebuilt by every pass that updates J
+        // (SimdFullIterationTemplates.hpp:602-603, PrdTemplates.hpp:57-58)
+        hipError_t ez = hipMemsetAsync(c->JRest.p, 0, c->JRest.n * sizeof(double), c->stream);
+        if (ez != hipSuccess)
+            return ez;
+    }
     hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
     if (e != hipSuccess)
         return e;
@@ -1824,6 +1927,7 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     c->device = opts ? opts->device : 0;
     c->batchHint = opts ? (opts->flags & 0xffff) : 0;
     c->prdDetailed = opts && (opts->flags & LWHIP_OPT_PRD_DETAILED);
+    c->hprd = opts ? opts->hprd : nullptr;
     if (c->device < 0 || c->device >= ndev)
     {
         delete c;
@@ -2133,7 +2237,11 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
             return stp;
     }
     if (mask & LWHIP_J)
+    {
         D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
+        if (c->hprd && c->JRest.p)
+            D2H(c->hprd->JRest, c->JRest.p, c->JRest.n);
+    }
     if (mask & LWHIP_I)
     {
         D2H(p.I + l0 * Nr * c->Nx, c->I.p, Nla * Nr * (size_t)c->Nx);
@@ -3344,9 +3452,12 @@ int lwhip_prd_pack(lwhip_context* c, void** devPtr, size_t* count)
     {
         const HostTrans& h = c->trans[c->prdLines[q]];
         const size_t nlt = h.NredLoc - h.NblueLoc;
+        // the local mean intensity of the scattering integral: J of the line's wavelengths, or -- hybrid PRD -- the rows
+        // of the rest-frame JRest they map to (consecutive: every wavelength of a PRD line is in prdIdxs; Prd.cpp:384-389)
+        const double* src = c->hprd ? c->JRest.p + (size_t)c->hLa2prdHost[h.t.Nblue + h.ltStart] * Ns : c->J.p + (size_t)h.NblueLoc * Ns;
         if (nlt)
-            HIP_TRY(hipMemcpyAsync(c->prdJ.p + ((size_t)c->prdRowOff[q] + h.ltStart) * Ns, c->J.p + (size_t)h.NblueLoc * Ns,
-                                   nlt * Ns * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->prdJ.p + ((size_t)c->prdRowOff[q] + h.ltStart) * Ns, src, nlt * Ns * sizeof(double),
+                                   hipMemcpyDeviceToDevice, c->stream));
     }
     if (devPtr)
         *devPtr = c->prdJ.p;

@@ -160,6 +160,9 @@ struct DevTileSlot
     int64_t phiOff;     // lines: offset (doubles) of the tile's [2][Ns][64] block in the phiT pool; lane sweep: of the
                         // first wavelength's [Nmu][2][Ns] block in the phi pool itself
     int64_t rhoOff;     // PRD lines: offset (doubles) of the first wavelength's [Ns] row in the rho pool, else -1
+                        // (hybrid PRD: of the LINE's first row -- the interpolation indices count from there)
+    int64_t hCoefOff;   // hybrid PRD lines: offset (entries) of the first wavelength's [Nmu][2][Ns] block of rho
+                        // interpolation coefficients in TileArgs::hRho, else -1
 };
 // Pure continua of a tile for the lane sweep's in-wave post-pass: the level sums they need that have more than one
 // contributor (or a foreign one) live in up to 8 registers per point ("shared sums"); everything else is the
@@ -262,6 +265,14 @@ struct TileArgs
     // resource, byte offsets)
     const double* depBase;
     uint32_t depBytes, depN, depW, depRat, depG, _padD;
+    // hybrid PRD (lwhip_options.hprd), null without: rho interpolation coefficients of the PRD lines, global wavelength ->
+    // ordinal among the wavelengths that scatter into the PRD region (or -1), their (row of JRest, weight) lists
+    // [ordinal][mu][dir][k] in CSR form, the rest-frame mean intensity [NprdLambda][Ns]
+    const lwhip_rho_coeff* hRho;
+    const int32_t* hLa2h;
+    const int64_t* hJOff;
+    const lwhip_j_coeff* hJCoef;
+    double* JRest;
     double* lsDbg;                 // diagnostic builds (-DLS_TIMING): [nTiles][8] phase clocks, host-mapped; else null
 };
 struct TileDyn

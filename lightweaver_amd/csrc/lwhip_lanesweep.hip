@@ -224,6 +224,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
     double la0[NLc], la2[NLc], la3[NLc], lcw1[NLc]; // per lane
     const double* rPhi[NLc];
     const double* rRho[NLc];
+    const lwhip_rho_coeff* rHc[NLc]; // hybrid PRD: the line's rho interpolation coefficients at the tile's first wavelength
     const unsigned vPhi0 = (unsigned)c.r * (unsigned)(Nmu * 2) * Ns8 + c.vK;
     const unsigned vRho0 = (unsigned)c.r * Ns8 + c.vK;
 #pragma unroll
@@ -237,6 +238,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         la0[s] = la2[s] = la3[s] = lcw1[s] = 0.0;
         rPhi[s] = a.phi;
         rRho[s] = a.rho;
+        rHc[s] = nullptr;
         if (s < NL)
         {
             const DevTileSlot u = ld_c(ts + s);
@@ -254,6 +256,8 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
             rPhi[s] = a.phi + u.phiOff;
             if (u.flags & 2)
                 rRho[s] = a.rho + u.rhoOff;
+            if ((u.flags & 2) && u.hCoefOff >= 0 && a.hRho)
+                rHc[s] = a.hRho + u.hCoefOff;
             const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
             la0[s] = sl->p[0];
             la2[s] = sl->p[2];
@@ -412,6 +416,38 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 
         // (the address registers are re-issued per phase: otherwise the compiler keeps what one phase loaded alive for the
         // next phase, the other direction and the next ray instead of re-reading 32 bytes from the L1)
+        // rho of a PRD line at N points of the block starting at point H: its row of this wavelength, or -- hybrid PRD --
+        // interpolated to the ray's rest wavelength between two rows of the line (Transition::uv, LwTransition.hpp:116-127)
+        auto load_rho = [&](const int s, auto nTag, const unsigned H, const unsigned vRho, double* rho) {
+            constexpr int N = decltype(nTag)::value;
+            if (!(lfl[s] & 2))
+            {
+#pragma unroll
+                for (int p = 0; p < N; ++p)
+                    rho[p] = 1.0;
+            }
+            else if (rHc[s])
+            {
+                const GLOBAL_AS lwhip_rho_coeff* cc = (const GLOBAL_AS lwhip_rho_coeff*)rHc[s]
+                                                      + ((size_t)c.r * (Nmu * 2) + (size_t)(mu * 2 + dirI)) * Ns + (k0 + H);
+                const GLOBAL_AS double* rl = (const GLOBAL_AS double*)rRho[s] + (k0 + H);
+#pragma unroll
+                for (int p = 0; p < N; ++p)
+                {
+                    const int i0 = cc[p].i0, i1 = cc[p].i1;
+                    const double fr = cc[p].frac;
+                    rho[p] = (1.0 - fr) * rl[(size_t)i0 * Ns + p] + fr * rl[(size_t)i1 * Ns + p];
+                }
+            }
+            else
+            {
+                double tmp[N];
+                ls_gld<N>(rRho[s], vRho, 0u, tmp);
+#pragma unroll
+                for (int p = 0; p < N; ++p)
+                    rho[p] = tmp[p];
+            }
+        };
         // ---- A. gather: Transition::uv + chi_eta_aux_accum + compute_source_fn at the lane's points (march order) ----
         double chi[D], S[D], rch[D];
         double dhK[D + 1], rdhK[D + 1], rsumK[D]; // geometry of the block (used by the stencils, requested with the gather's loads)
@@ -437,14 +473,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     double phi[D], ni[D], nj[D], rho[D];
                     ls_lds<D>(sDep, vK, lnI[s], ni);
                     ls_lds<D>(sDep, vK, lnJ[s], nj);
-                    if (lfl[s] & 2)
-                        ls_gld<D>(rRho[s], vRho, 0u, rho);
-                    else
-                    {
-#pragma unroll
-                        for (int p = 0; p < D; ++p)
-                            rho[p] = 1.0;
-                    }
+                    load_rho(s, std::integral_constant<int, D>{}, 0u, vRho, rho);
 #pragma unroll
                     for (int p = 0; p < D; ++p)
                         phi[p] = phiN[s][p];
@@ -702,6 +731,29 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 if (is_ok(i))
                     GD(a.depthI)[o + MI(i)] = Iv[i];
         }
+        if (RATES && a.hJOff && td.hasPrd && act)
+        {
+            // hybrid PRD: the ray's intensity into the rest-frame mean intensity, JRest(idx, k) += 0.5 wmu frac I(k)
+            // (SimdFullIterationTemplates.hpp:397-408); fp64 atomics: other wavelengths and rays add to the same rows
+            const int hq = ((const GLOBAL_AS int32_t*)a.hLa2h)[la];
+            if (hq >= 0)
+            {
+                const GLOBAL_AS int64_t* off = (const GLOBAL_AS int64_t*)a.hJOff + ((size_t)(hq * Nmu + mu) * 2 + dirI) * Ns + k0;
+#pragma unroll
+                for (int p = 0; p < D; ++p)
+                {
+                    if (p >= c.nV)
+                        continue;
+                    for (int64_t e = off[p]; e < off[p + 1]; ++e)
+                    {
+                        const GLOBAL_AS lwhip_j_coeff* jc = (const GLOBAL_AS lwhip_j_coeff*)a.hJCoef + e;
+                        const double fr = jc->frac;
+                        const int row = jc->idx;
+                        unsafeAtomicAdd(a.JRest + (size_t)row * Ns + (k0 + p), (hw * fr) * Iv[MI(p)]);
+                    }
+                }
+            }
+        }
         if (RATES)
         {
             double wPsi[D];
@@ -734,14 +786,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                         ls_gld<HP>(rPhi[s], vPhi, sRay, phi);
                         ls_lds<HP>(sDep, vK, lnI[s], ni);
                         ls_lds<HP>(sDep, vK, lnJ[s], nj);
-                        if (lfl[s] & 2)
-                            ls_gld<HP>(rRho[s], vRho, 0u, rho);
-                        else
-                        {
-#pragma unroll
-                            for (int p = 0; p < HP; ++p)
-                                rho[p] = 1.0;
-                        }
+                        load_rho(s, std::integral_constant<int, HP>{}, (unsigned)H, vRho, rho);
 #pragma unroll
                         for (int p = 0; p < HP; ++p)
                         {

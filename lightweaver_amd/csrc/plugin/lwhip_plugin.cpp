@@ -131,6 +131,16 @@ struct PluginState
     std::vector<double> height2d;
     uint64_t gridSig = 0, gridEpoch = 0; // geometry fingerprint; epoch enters the structural signature
     uint64_t fpProfiles = 0, fpBackground = 0, fpAtmos = 0, fpNstar = 0, fpCollisions = 0;
+    // hybrid PRD: the tables configure_hprd_coeffs left in the Context (Source/Prd.cpp:697-946), flattened into lwhip_hprd;
+    // rebuilt (and the device context with them) when the core re-allocates them (update_hprd_coeffs)
+    lwhip_hprd hprd{};
+    bool hprdOn = false;
+    uint64_t hprdSig = 0, hprdEpoch = 0;
+    std::vector<int32_t> hPrdIdxs, hHIdxs, hLineAtom, hLineTrans;
+    std::vector<int64_t> hOff;
+    std::vector<lwhip_j_coeff> hJc;
+    std::vector<std::vector<lwhip_rho_coeff>> hRho;
+    std::vector<const lwhip_rho_coeff*> hRhoPtr;
     bool prdDetailed = false;          // the device context was asked to include the detailed atoms' PRD lines
     double* zDown = nullptr;           // ZPlaneDecomposition outputs the device context currently writes
     double* zUp = nullptr;
@@ -294,6 +304,92 @@ void flatten_boundary(lwhip_boundary* b, AtmosphericBoundaryCondition& bc)
     }
 }
 
+// Hybrid PRD: spect.prdIdxs / hPrdIdxs / JCoeffs / JRest and the PRD lines' hPrdCoeffs -> lwhip_hprd, once per
+// configuration (the tables are large: 16 bytes per (line wavelength, ray, depth) and per JCoeffs entry).
+void flatten_hprd(Context& ctx, PluginState* st)
+{
+    Spectrum& spect = *ctx.spect;
+    st->hprdOn = (bool)spect.JRest;
+    if (!st->hprdOn)
+        return;
+    std::vector<std::pair<int, Transition*>> lines; // (index into the flat atom list, line)
+    const int Nactive = (int)ctx.activeAtoms.size();
+    for (int ia = 0; ia < Nactive + (int)ctx.detailedAtoms.size(); ++ia)
+    {
+        Atom& a = ia < Nactive ? *ctx.activeAtoms[ia] : *ctx.detailedAtoms[ia - Nactive];
+        for (auto* t : a.trans)
+            if (t->rhoPrd && t->hPrdCoeffs)
+                lines.push_back({ ia, t });
+    }
+    if (lines.empty())
+        throw std::runtime_error("lwhip plugin: JRest without hybrid-PRD coefficients on any line");
+    uint64_t sig = HashSet::mix((uint64_t)(uintptr_t)spect.JRest.data(), (uint64_t)spect.hPrdIdxs.size());
+    sig = HashSet::mix(sig, (uint64_t)(uintptr_t)spect.JCoeffs.dataStore.data());
+    for (auto& l : lines)
+        sig = HashSet::mix(sig, (uint64_t)(uintptr_t)l.second->hPrdCoeffs.data);
+    if (sig == st->hprdSig && st->hprd.JRest == spect.JRest.data())
+        return;
+    st->hprdSig = sig;
+    ++st->hprdEpoch;
+    const int Ns = ctx.atmos->Nspace, Nrays = ctx.atmos->Nrays;
+    st->hPrdIdxs.assign(spect.prdIdxs.begin(), spect.prdIdxs.end());
+    st->hHIdxs.assign(spect.hPrdIdxs.begin(), spect.hPrdIdxs.end());
+    const int NhPrd = (int)st->hHIdxs.size();
+    st->hOff.clear();
+    st->hJc.clear();
+    st->hOff.reserve((size_t)NhPrd * Nrays * 2 * Ns + 1);
+    for (int hq = 0; hq < NhPrd; ++hq)
+        for (int mu = 0; mu < Nrays; ++mu)
+            for (int toObs = 0; toObs < 2; ++toObs)
+                for (int k = 0; k < Ns; ++k)
+                {
+                    st->hOff.push_back((int64_t)st->hJc.size());
+                    for (const auto& c : spect.JCoeffs(hq, mu, toObs, k))
+                        st->hJc.push_back(lwhip_j_coeff{ c.frac, c.idx, 0 });
+                }
+    st->hOff.push_back((int64_t)st->hJc.size());
+    st->hLineAtom.clear();
+    st->hLineTrans.clear();
+    st->hRho.clear();
+    for (auto& l : lines)
+    {
+        Atom& a = l.first < Nactive ? *ctx.activeAtoms[l.first] : *ctx.detailedAtoms[l.first - Nactive];
+        int kr = 0;
+        for (; kr < a.Ntrans && a.trans[kr] != l.second; ++kr)
+            ;
+        st->hLineAtom.push_back(l.first);
+        st->hLineTrans.push_back(kr);
+        Transition& t = *l.second;
+        const int nlt = (int)t.wavelength.shape(0);
+        std::vector<lwhip_rho_coeff> v((size_t)nlt * Nrays * 2 * Ns);
+        for (int lt = 0; lt < nlt; ++lt)
+            for (int mu = 0; mu < Nrays; ++mu)
+                for (int toObs = 0; toObs < 2; ++toObs)
+                    for (int k = 0; k < Ns; ++k)
+                    {
+                        const auto& c = t.hPrdCoeffs(lt, mu, toObs, k);
+                        v[(((size_t)lt * Nrays + mu) * 2 + toObs) * Ns + k] = lwhip_rho_coeff{ c.i0, c.i1, c.frac };
+                    }
+        st->hRho.push_back(std::move(v));
+    }
+    st->hRhoPtr.clear();
+    for (auto& v : st->hRho)
+        st->hRhoPtr.push_back(v.data());
+    lwhip_hprd& h = st->hprd;
+    h = lwhip_hprd{};
+    h.NprdLambda = (int32_t)st->hPrdIdxs.size();
+    h.NhPrd = NhPrd;
+    h.Nlines = (int32_t)st->hLineAtom.size();
+    h.prdIdxs = st->hPrdIdxs.data();
+    h.hPrdIdxs = st->hHIdxs.data();
+    h.JRest = spect.JRest.data();
+    h.jCoeffOff = st->hOff.data();
+    h.jCoeffs = st->hJc.data();
+    h.lineAtom = st->hLineAtom.data();
+    h.lineTrans = st->hLineTrans.data();
+    h.rhoCoeffs = st->hRhoPtr.data();
+}
+
 // Context -> lwhip_problem (flat restatement, include/lwhip.h); returns the structural signature
 // 2D tables live in `keep` (the Context's long-lived state), everything else in `st`
 void flatten(Context& ctx, PluginState* st, PluginState* keep)
@@ -303,8 +399,7 @@ void flatten(Context& ctx, PluginState* st, PluginState* keep)
     if (atmos.Ndim != 1 && atmos.Ndim != 2)
         throw std::runtime_error("lwhip plugin: only 1D plane-parallel and 2D x-periodic atmospheres are supported");
     const bool is2d = atmos.Ndim == 2;
-    if (spect.JRest)
-        throw std::runtime_error("lwhip plugin: hybrid PRD (JRest) is not supported on the device");
+    flatten_hprd(ctx, keep); // hybrid PRD tables (cached in the Context's long-lived state)
     lwhip_problem& p = st->prob;
     p = lwhip_problem{};
     p.abiVersion = LWHIP_ABI_VERSION;
@@ -344,7 +439,7 @@ void flatten(Context& ctx, PluginState* st, PluginState* keep)
     st->shape = { (uint64_t)p.Nspace, (uint64_t)p.Nrays, (uint64_t)p.Nlambda, (uint64_t)p.formalSolver,
                   (uint64_t)p.storeDepthData, (uint64_t)p.zLowerBc.type, (uint64_t)p.zUpperBc.type,
                   (uint64_t)all.size(), (uint64_t)(is2d ? atmos.Nx : 0), (uint64_t)(is2d ? keep->gridEpoch : 0),
-                  (uint64_t)keep->prdDetailed };
+                  (uint64_t)keep->prdDetailed, (uint64_t)(keep->hprdOn ? keep->hprdEpoch + 1 : 0) };
     for (size_t ia = 0; ia < all.size(); ++ia)
     {
         Atom& a = *all[ia];
@@ -362,8 +457,6 @@ void flatten(Context& ctx, PluginState* st, PluginState* keep)
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
             Transition& t = *a.trans[kr];
-            if (t.hPrdCoeffs)
-                throw std::runtime_error("lwhip plugin: hybrid PRD coefficients are not supported on the device");
             lwhip_transition& ft = st->trans[ia][kr];
             ft.type = (t.type == LINE) ? LWHIP_LINE : LWHIP_CONTINUUM;
             ft.i = t.i;
@@ -498,6 +591,7 @@ uint32_t sync_state(Context& ctx, bool force)
         st->zDown = st->zUp = nullptr; // a fresh device context writes no z-plane outputs yet
         lwhip_options opts{};
         opts.flags = st->prdDetailed ? LWHIP_OPT_PRD_DETAILED : 0;
+        opts.hprd = st->hprdOn ? &st->hprd : nullptr;
         if (lwhip_create(&st->prob, &opts, &st->hip) != LWHIP_OK)
             fail("lwhip_create");
         dirty_mask(st, true); // create uploaded everything: just record the fingerprints

@@ -126,3 +126,62 @@ def test_hybrid_prd_differs_from_plain_prd():
         oc.redistribute_prd(3, 1e-2)
     lines = lambda p: [t for a in p.atoms for t in a.trans if t.rhoPrd is not None]
     assert max(np.abs(a.rhoPrd - b.rhoPrd).max() for a, b in zip(lines(ph), lines(q))) > 1e-3
+
+
+# ---- the HIP path ------------------------------------------------------------------------------------------------------
+def run_hprd_hip(prob, nIter=3, prdIter=3, tol=1e-2):
+    """The same loop through the C ABI: the tables come from the oracle's builder (pinned to the core above)."""
+    from lightweaver_amd.context import Context
+    p = prob.copy()
+    out = []
+    with bindings.OracleContext(p.copy()) as oc:
+        tables = oc.build_hprd()
+        with Context(p, hprd=tables) as ctx:
+            assert ctx.sweep_kind() == 'lanes'
+            for it in range(nIter):
+                p.gamma_prefill()
+                ctx.formal_sol_gamma_matrices()
+                if it >= 1:
+                    ctx.stat_equil()
+                out.append(ctx.redistribute_prd(prdIter, tol))
+            ctx.download(abi.J)
+        JRest = tables.JRest.copy()
+        tables.close()
+    return p, out, JRest
+
+
+@pytest.mark.gpu
+def test_hip_hprd_single_call_matches_oracle(gpu):
+    """One formal solution + one PRD call from identical inputs: the 1e-9 one-call bound on J, JRest, rho, Gamma, rates."""
+    prob = hprd_problem()
+    po, uo, Jo = run_hprd(bindings.OracleContext, prob, nIter=1, prdIter=2)
+    ph, uh, Jh = run_hprd_hip(prob, nIter=1, prdIter=2)
+    assert uo[0]['NprdSubIter'] == uh[0].NprdSubIter == 2
+    assert np.allclose(uo[0]['dRho'], uh[0].dRho, rtol=1e-6)
+    assert rel_err(Jh, Jo) <= TOL_ONE_CALL
+    assert_same(po, ph, TOL_ONE_CALL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('vamp', [8.0e3, 40.0e3])
+def test_hip_hprd_iterations_match_oracle(gpu, vamp):
+    prob = hprd_problem(vamp=vamp)
+    po, uo, Jo = run_hprd(bindings.OracleContext, prob)
+    ph, uh, Jh = run_hprd_hip(prob)
+    for a, b in zip(uo, uh):
+        assert a['NprdSubIter'] == b.NprdSubIter
+        assert np.allclose(a['dRho'], b.dRho, rtol=1e-5, atol=1e-12)
+        assert np.allclose(a['dJPrdMax'], b.dJPrdMax, rtol=1e-7, atol=1e-12)
+    assert rel_err(Jh, Jo) <= 1e-8
+    assert_same(po, ph, 1e-8)  # three full iterations deep: the one-call bound compounded
+
+
+@pytest.mark.gpu
+def test_hip_hprd_refused_on_a_shard(gpu):
+    from lightweaver_amd.context import Context, LwHipError
+    prob = hprd_problem()
+    with bindings.OracleContext(prob.copy()) as oc:
+        tables = oc.build_hprd()
+        with pytest.raises(LwHipError):
+            Context(prob, laStart=0, laEnd=prob.Nlambda // 2, worldSize=2, worldRank=0, hprd=tables)
+        tables.close()

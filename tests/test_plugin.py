@@ -255,6 +255,36 @@ def test_dropin_prd_redistribute(gpu):
 
 @needs_ref
 @pytest.mark.gpu
+def test_dropin_hybrid_prd(gpu):
+    """Hybrid PRD through the drop-in boundary: configure_hprd_coeffs runs in the real core (it is not part of the
+    iteration scheme), the plugin flattens the tables it finds in the Context (spect.JCoeffs / JRest, the lines'
+    hPrdCoeffs) into lwhip_options.hprd, and the device then interpolates rho per ray, scatters into JRest and runs the
+    scattering integral on it -- next to the core's own scalar scheme on the same Context set-up."""
+    from test_hprd import assert_same, hprd_problem
+    prob = hprd_problem()
+    p, q = prob.copy(), prob.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+    th, tr = hipc.configure_hprd(), ref.configure_hprd()
+    for it in range(3):
+        for pr, c in ((p, hipc), (q, ref)):
+            pr.gamma_prefill()
+            c.formal_sol_gamma_matrices()
+            if it >= 1:
+                assert c.stat_equil() == 0
+        assert rel_err(th.JRest, tr.JRest) <= 1e-8
+        u1, u2 = hipc.redistribute_prd(3, 1e-2), ref.redistribute_prd(3, 1e-2)
+        assert u1['NprdSubIter'] == u2['NprdSubIter'] and u1['Nprd'] == u2['Nprd'] == 2
+        assert np.allclose(u1['dRho'], u2['dRho'], rtol=1e-5)
+        assert np.allclose(u1['dJPrdMax'], u2['dJPrdMax'], rtol=1e-7)
+    assert_same(p, q, 1e-8)
+    th.close()
+    tr.close()
+    hipc.close()
+    ref.close()
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_dropin_time_dep_and_nr_updates(gpu):
     """FsIterationFns::time_dep_update / nr_post_update of the plugin through the real core's
     trampolines (Source/UpdatePopulations.cpp:153-157, 473-483), next to the core's own."""
