@@ -214,6 +214,13 @@ typedef struct lwhip_hprd {
 } lwhip_hprd;
 
 #define LWHIP_OPT_PRD_DETAILED (1 << 16)
+/* Gamma and the rates summed in a fixed order (bit-reproducible run to run, as the reference's single-thread path and
+ * its fixed-order thread reduction are, Source/ThreadStorage.cpp:343-396): per-workgroup partial slabs added in
+ * workgroup order instead of fp64 atomics.  Served by the depth-across-lanes sweep with one wavefront per workgroup
+ * (contexts it does not cover -- other solvers than Bezier3, column batches -- ignore the flag); J and I are
+ * reproducible either way.  Costs a factor 2-4 in the sweep (one wavefront per workgroup): off by
+ * default, also in the plugin (LWHIP_DETERMINISTIC=1 turns it on there and in any context). */
+#define LWHIP_OPT_DETERMINISTIC (1 << 17)
 
 typedef struct lwhip_options {
     int32_t device;        /* HIP device ordinal                                                   */

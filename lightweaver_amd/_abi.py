@@ -83,6 +83,7 @@ class lwhip_problem(C.Structure):
 
 
 OPT_PRD_DETAILED = 1 << 16   # lwhip_options.flags: the PRD calls include the detailed atoms' PRD lines
+OPT_DETERMINISTIC = 1 << 17  # ... Gamma / rates summed in a fixed order (bit-reproducible)
 
 
 class lwhip_rho_coeff(C.Structure):

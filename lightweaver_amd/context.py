@@ -84,7 +84,8 @@ class Context:
 
     def __init__(self, prob: Problem, device: int = 0, laStart: int = 0, laEnd: int = 0,
                  stream: Optional[int] = None, lib_path: Optional[str] = None,
-                 worldSize: int = 1, worldRank: int = 0, batchHint: int = 0, prdDetailed: bool = False, hprd=None):
+                 worldSize: int = 1, worldRank: int = 0, batchHint: int = 0, prdDetailed: bool = False, hprd=None,
+                 deterministic: bool = False):
         """hprd: hybrid PRD -- the tables configure_hprd_coeffs leaves in the reference's Context
         (Source/Prd.cpp:697-946), as a ctypes pointer to lwhip_hprd or any object with such a `.ptr` (what
         LwContext(hprd=True) sets up, Source/LwMiddleLayer.pyx:2822-2826); borrowed for the life of the context.
@@ -98,7 +99,8 @@ class Context:
         opts.stream = stream
         opts.worldSize, opts.worldRank = worldSize, worldRank
         # prdDetailed: ExtraParams 'include_detailed_atoms' of the reference's PRD calls (LwMiddleLayer.pyx:3678-3680)
-        opts.flags = min(max(int(batchHint), 0), 0xffff) | (abi.OPT_PRD_DETAILED if prdDetailed else 0)
+        opts.flags = (min(max(int(batchHint), 0), 0xffff) | (abi.OPT_PRD_DETAILED if prdDetailed else 0)
+                      | (abi.OPT_DETERMINISTIC if deterministic else 0))
         self.prdDetailed = bool(prdDetailed)
         self._hprd = hprd   # keep the tables alive
         if hprd is not None:

@@ -125,6 +125,10 @@ struct lwhip_context
     DevBuf<DevPostProg> postProg;
     DevBuf<double> geoT;
     // hybrid PRD (lwhip_options.hprd): the tables of configure_hprd_coeffs on the device
+    // deterministic mode (LWHIP_OPT_DETERMINISTIC): per-workgroup slabs + the (workgroup, slot) lists of every transition
+    bool deterministic = false;
+    DevBuf<double> detSlab;
+    DevBuf<int32_t> detOff, detEnt, detOffPrd, detEntPrd;
     const lwhip_hprd* hprd = nullptr;
     std::vector<int> hLa2prdHost, hLa2hHost;     // global wavelength -> row of JRest / ordinal among hPrdIdxs, or -1
     std::vector<int64_t> hRhoOffHost;             // per transition: offset of its rho-coefficient block, or -1
@@ -924,10 +928,11 @@ int build_tables(lwhip_context* c)
             const char* sw = std::getenv("LWHIP_SWEEP");
             int D = 0, LR = 0, R = 0;
             const bool supported = lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R);
-            const bool force = (sw && std::strcmp(sw, "lanes") == 0) || c->hprd != nullptr; // (hybrid PRD lives in the lane sweep)
+            const bool force = (sw && std::strcmp(sw, "lanes") == 0) || c->hprd != nullptr // (hybrid PRD lives in the lane sweep)
+                               || c->deterministic;                                    // (and so does the fixed-order reduction)
             const long waves = supported ? ((long)c->Nla + R - 1) / R * std::max(c->batchHint, 1) : 0;
             const bool prefer = force || (!sw && waves <= 2L * 4 * numCU);
-            if ((c->hprd || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
+            if ((c->hprd || c->deterministic || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
                 bool ok = true;
                 for (int la = 0; la < c->Nla && ok; ++la)
@@ -1121,6 +1126,10 @@ int build_tables(lwhip_context* c)
     {
         // workgroups of the sweep: contiguous, cost-balanced runs of tiles; the waves of a workgroup take its tiles in turn
         c->tileWaves = std::max(1, std::min(8, c->laneSweep ? env_int("LWHIP_LWAVES", 4) : env_int("LWHIP_TWAVES", 2)));
+        if (c->laneSweep && c->deterministic)
+            c->tileWaves = 1; // one wavefront per workgroup: its LDS sums are formed in program order
+        else
+            c->deterministic = false; // (not served by the ray-column march: the flag is ignored there)
         const int W = c->tileWaves;
         int wgPerCU = std::max(1, 8 / W);
         if (c->batchHint > 1)
@@ -1256,6 +1265,41 @@ int build_tables(lwhip_context* c)
         chunkTile = sw.chunkTile;
         tileSlotTr = sw.slotTr;
         c->nTileChunks = (int)chunkTile.size() - 1;
+        if (c->deterministic)
+        {
+            // per transition: the (workgroup, slot) pairs that hold its sums, in workgroup order
+            auto lists = [&](const std::vector<int32_t>& slotTrTab, int nch, std::vector<int32_t>& off, std::vector<int32_t>& ent) {
+                std::vector<std::vector<int32_t>> per(c->Ntrans);
+                for (int ch = 0; ch < nch; ++ch)
+                    for (int q = 0; q < c->maxCTTile; ++q)
+                    {
+                        const int tr = slotTrTab[(size_t)ch * c->maxCTTile + q];
+                        if (tr >= 0)
+                            per[tr].push_back(ch * c->maxCTTile + q);
+                    }
+                off.assign(1, 0);
+                ent.clear();
+                for (int tr = 0; tr < c->Ntrans; ++tr)
+                {
+                    ent.insert(ent.end(), per[tr].begin(), per[tr].end());
+                    off.push_back((int32_t)ent.size());
+                }
+                if (ent.empty())
+                    ent.push_back(0);
+            };
+            std::vector<int32_t> o, e;
+            lists(tileSlotTr, c->nTileChunks, o, e);
+            HIP_TRY(c->detOff.upload(o));
+            HIP_TRY(c->detEnt.upload(e));
+            if (!tileListPrd.empty())
+            {
+                lists(swPrd.slotTr, (int)swPrd.chunkTile.size() - 1, o, e);
+                HIP_TRY(c->detOffPrd.upload(o));
+                HIP_TRY(c->detEntPrd.upload(e));
+            }
+            const size_t nch = std::max<size_t>(c->nTileChunks, tileListPrd.empty() ? 0 : swPrd.chunkTile.size() - 1);
+            HIP_TRY(c->detSlab.alloc(nch * c->maxCTTile * 4 * Ns));
+        }
         postChunkTile = po.chunkTile;
         postSlotTr = po.slotTr;
         for (size_t e = 0; e < slots.size(); ++e)
@@ -1753,6 +1797,7 @@ int build_tile_args(lwhip_context* c)
         a.hJOff = c->hJOff.p;
         a.hJCoef = c->hJCoef.p;
         a.JRest = c->JRest.p;
+        a.detSlab = c->deterministic ? c->detSlab.p : nullptr;
         a.lsDbg = nullptr;
         if (std::getenv("LWHIP_LS_TIMING"))
         {
@@ -1858,6 +1903,9 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
                               c->tileWaves, nullptr, 0, c->stream);
     if (e1)
         (void)hipEventRecord(e1, c->stream);
+    if (e == hipSuccess && rates && c->laneSweep && c->deterministic)
+        e = launch_det_reduce(c->detSlab.p, tprd ? c->detOffPrd.p : c->detOff.p, tprd ? c->detEntPrd.p : c->detEnt.p, c->red8.p, c->Ns,
+                              c->Ntrans, c->maxCTTile, c->stream);
     if (e != hipSuccess || !rates || fuse || c->laneSweep)
         return e;
     return launch_tile_post(da, ha, td, tprd ? c->nPostChunksPrd : c->nPostChunks, nullptr, 0, c->stream);
@@ -1928,6 +1976,8 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     c->batchHint = opts ? (opts->flags & 0xffff) : 0;
     c->prdDetailed = opts && (opts->flags & LWHIP_OPT_PRD_DETAILED);
     c->hprd = opts ? opts->hprd : nullptr;
+    c->deterministic = ((opts && (opts->flags & LWHIP_OPT_DETERMINISTIC)) || env_int("LWHIP_DETERMINISTIC", 0) == 1)
+                       && (!opts || (opts->flags & 0xffff) <= 1);
     if (c->device < 0 || c->device >= ndev)
     {
         delete c;

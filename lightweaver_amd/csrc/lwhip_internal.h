@@ -273,6 +273,7 @@ struct TileArgs
     const int64_t* hJOff;
     const lwhip_j_coeff* hJCoef;
     double* JRest;
+    double* detSlab;               // deterministic mode: [workgroup][maxCT][4][Ns] partial sums (no atomics), else null
     double* lsDbg;                 // diagnostic builds (-DLS_TIMING): [nTiles][8] phase clocks, host-mapped; else null
 };
 struct TileDyn
@@ -305,6 +306,8 @@ bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R
 size_t lane_sweep_lds_bytes(const TileArgs& a, int waves);
 hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int solver, bool rates,
                              int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream);
+hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, int Ns, int Ntrans, int maxCT,
+                             hipStream_t stream);
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
 hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostList, int n, hipStream_t stream);
 

@@ -1307,10 +1307,48 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
             const int q = rem / LRD, pb = rem - q * LRD;
             const int pp = pb / a.laneLR, k = (pb - pp * a.laneLR) * D + pp;
             const int tr = slotTr[cs];
-            if (tr >= 0 && k < Ns)
+            if (a.detSlab)
+            {
+                // deterministic mode (LWHIP_OPT_DETERMINISTIC): the workgroup -- one wavefront, so its LDS sums were formed
+                // in program order -- stores its slab; det_reduce_kernel adds the slabs in workgroup order
+                if (k < Ns)
+                    GD(a.detSlab)[((size_t)chunk * maxCT + cs) * n4 + q * Ns + k] = sAcc[idx];
+            }
+            else if (tr >= 0 && k < Ns)
                 unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + q * Ns + k), sAcc[idx]);
         }
     }
+}
+
+// Deterministic mode: red8[tr][part 0][q][k] = sum of the workgroups' slabs that hold transition tr, in workgroup order
+// (the list of (workgroup, slot) pairs per transition is the host's).  Fixed order: bit-reproducible Gamma and rates,
+// as the reference's single-thread path and its fixed-order thread reduction are (ThreadStorage.cpp:343-396).
+__global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restrict__ slab, const int32_t* __restrict__ off,
+                                                         const int32_t* __restrict__ ent, double* __restrict__ red8, int Ns, int maxCT)
+{
+    const int tr = blockIdx.y;
+    const int n4 = 4 * Ns;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4)
+        return;
+    // (eight loads in flight, the additions in list order: the chain is latency-bound otherwise)
+    double sum = 0.0;
+    int e = off[tr];
+    const int e1 = off[tr + 1];
+    for (; e + 8 <= e1; e += 8)
+    {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = slab[(size_t)ent[e + q] * n4 + i]; // ent = workgroup * maxCT + slot
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            sum += v[q];
+    }
+    for (; e < e1; ++e)
+        sum += slab[(size_t)ent[e] * n4 + i];
+    (void)maxCT;
+    red8[(size_t)tr * LWHIP_REDUCE_SPLIT * n4 + i] = sum;
 }
 
 template <int SOLVER, int D, bool RATES>
@@ -1349,6 +1387,15 @@ bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R
     *LR = lr;
     *R = std::min(64 / lr, (int)LS_MAX_R);
     return true;
+}
+
+hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, int Ns, int Ntrans, int maxCT,
+                             hipStream_t stream)
+{
+    if (Ntrans <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((4 * Ns + 255) / 256, Ntrans), dim3(256), 0, stream, slab, off, ent, red8, Ns, maxCT);
+    return hipGetLastError();
 }
 
 size_t lane_sweep_lds_bytes(const TileArgs& a, int waves)

@@ -591,6 +591,13 @@ uint32_t sync_state(Context& ctx, bool force)
         st->zDown = st->zUp = nullptr; // a fresh device context writes no z-plane outputs yet
         lwhip_options opts{};
         opts.flags = st->prdDetailed ? LWHIP_OPT_PRD_DETAILED : 0;
+        // LWHIP_DETERMINISTIC=1: Gamma and the rates summed in a fixed order (bit-reproducible iterations, as the
+        // reference's schemes are) instead of by fp64 atomics; off by default: it costs 2-4x in the sweep
+        {
+            const char* det = std::getenv("LWHIP_DETERMINISTIC");
+            if (det && det[0] == '1')
+                opts.flags |= LWHIP_OPT_DETERMINISTIC;
+        }
         opts.hprd = st->hprdOn ? &st->hprd : nullptr;
         if (lwhip_create(&st->prob, &opts, &st->hip) != LWHIP_OK)
             fail("lwhip_create");

@@ -324,6 +324,37 @@ def test_repeatability(gpu, sweep):
     assert rel_err(p1.atoms[0].Gamma, p2.atoms[0].Gamma) <= 1e-12
 
 
+def test_deterministic_mode_is_bit_reproducible(gpu):
+    """LWHIP_OPT_DETERMINISTIC: Gamma and the rates are sums of per-workgroup slabs added in workgroup order (no fp64
+    atomics across workgroups, one wavefront per workgroup): five runs from the same inputs agree bit for bit -- as the
+    reference's single-thread path and its fixed-order thread reduction do (ThreadStorage.cpp:343-396) -- and with the
+    default (atomic) path to rounding; so does a PRD sub-iteration on top."""
+    prob = models.falc_h_ca(Nrays=3, lineScale=0.3, prd=True)
+    runs = []
+    for rep in range(5):
+        p = prob.copy()
+        with Context(p, deterministic=True) as ctx:
+            assert ctx.sweep_kind() == 'lanes'
+            p.gamma_prefill()
+            ctx.formal_sol_gamma_matrices()
+            ctx.redistribute_prd(2, 0.0)
+        runs.append(p)
+    for p in runs[1:]:
+        assert np.array_equal(p.J, runs[0].J) and np.array_equal(p.I, runs[0].I)
+        for a, b in zip(p.atoms, runs[0].atoms):
+            assert np.array_equal(a.Gamma, b.Gamma)
+            for ta, tb in zip(a.trans, b.trans):
+                assert np.array_equal(ta.Rij, tb.Rij) and np.array_equal(ta.Rji, tb.Rji)
+                if ta.rhoPrd is not None:
+                    assert np.array_equal(ta.rhoPrd, tb.rhoPrd)
+    q = prob.copy()
+    with Context(q) as ctx:
+        q.gamma_prefill()
+        ctx.formal_sol_gamma_matrices()
+        ctx.redistribute_prd(2, 0.0)
+    compare_problems(runs[0], q, tol=1e-10)
+
+
 @pytest.mark.parametrize('ncopy,maxlines', [(2, 4), (3, 6)])
 def test_more_than_two_overlapping_lines(gpu, ncopy, maxlines):
     """The MAXL = 4 and MAXL = 8 instantiations of the sweep: blended Ca II copies put up to 4 / 6 lines at one
