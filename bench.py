@@ -63,21 +63,24 @@ def parse():
     return ap.parse_args()
 
 
-def profiled_traffic():
+def profiled_traffic(sweep_kind='march'):
     """HBM bytes per sweep launch from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_summary.json, produced by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate
     --pmc runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Counters cannot be
     collected from inside this process, so the latest committed value is reported, or null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json')))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        return d.get('sweep_traffic_bytes_per_launch'), os.path.basename(files[-1])
-    except Exception:
-        return None, None
+    want = 'lanesweep_kernel' if sweep_kind == 'lanes' else 'raymarch_kernel'
+    for fn in reversed(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json')))):
+        try:
+            with open(fn) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        base = os.path.basename(fn)
+        # the profile of this command: the same sweep kernel at the default 10 240 wavelengths
+        if want in str(d.get('sweep_kernel', '')) and not any(tag in base for tag in ('_5120', '_2560', '_1280')):
+            return d.get('sweep_traffic_bytes_per_launch'), base
+    return None, None
 
 
 def algorithmic_flops(prob, la0, la1):
@@ -437,7 +440,7 @@ def main():
         per_step = world if args.scaling == 'weak' else 1
         value = per_step * args.steps / elapsed
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        traffic, traffic_src = profiled_traffic() if (world == 1 and args.nlambda == 10240) else (None, None)
+        traffic, traffic_src = profiled_traffic(sweep_kind) if (world == 1 and args.nlambda == 10240) else (None, None)
         out = {
             'metric': 'formal_sol_gamma_matrices iters/sec',
             'value': value,

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -2026,9 +2027,14 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
             return bail(fail(LWHIP_ERR_DEVICE, "hipStreamCreate failed"));
         c->stream = c->ownStream;
     }
+    const bool timing = std::getenv("LWHIP_CREATE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     st = build_tables(c);
     if (st != LWHIP_OK)
         return bail(st);
+    const auto t1 = now();
     st = alloc_state(c);
     if (st != LWHIP_OK)
         return bail(st);
@@ -2038,9 +2044,12 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     st = build_tile_args(c);
     if (st != LWHIP_OK)
         return bail(st);
+    const auto t2 = now();
     st = lwhip_upload(c, LWHIP_ALL_INPUTS);
     if (st != LWHIP_OK)
         return bail(st);
+    if (timing)
+        std::fprintf(stderr, "lwhip_create: tables %.2f ms, allocations %.2f ms, upload %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
     if (std::getenv("LWHIP_VERBOSE"))
         std::fprintf(stderr,
                      "lwhip_create: Nla=%d Ns=%d Nmu=%d sweep=%s tiles=%d (L=%d, max slots %d, cap %d) chunks=%d x %d waves post=%d maxCT=%d/%d "

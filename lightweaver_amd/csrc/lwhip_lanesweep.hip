@@ -199,6 +199,7 @@ struct LaneCtx
     double* sRow3;                             // the wavefront's LDS copy of its tile's rows chi_C, eta_C, sigma J: [3][64][D]
     double* sB;                                // the wavefront's LDS row [R][4]: Planck functions of the rays' end points
     const double* sExp;                        // the workgroup's 2^(j/32) table
+    double* sPP;                               // the wavefront's LDS block [continuum][ray][3]: per-(continuum, wavelength) parameters of the finish
 };
 
 // The rays of one tile: NL / NM line / mixed-continuum slots.  Leaves J and the Psi* moments of the lane's points in
@@ -1024,7 +1025,8 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
         ls_lds<NP>(c.sDep, vK, c.oN + rc.nJ, nj);
         ls_lds<NP>(c.sDep, vK, c.oRat + rc.rat, rat);
-        const double p0 = *(const GLOBAL_AS double*)(lsB + rc.pOff), p2 = *(const GLOBAL_AS double*)(lsB + rc.pOff + 16);
+        const double* ppq = c.sPP + (q * c.L + c.r) * 3;
+        const double p0 = ppq[0], p2 = ppq[2];
         double chi_c[NP], uji[NP], eta_c[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -1055,8 +1057,8 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
         ls_lds<NP>(c.sDep, vK, c.oN + rc.nJ, nj);
         ls_lds<NP>(c.sDep, vK, c.oRat + rc.rat, rat);
-        const double vij = *(const GLOBAL_AS double*)(lsB + rc.pOff), wla = *(const GLOBAL_AS double*)(lsB + rc.pOff + 8),
-                     p2 = *(const GLOBAL_AS double*)(lsB + rc.pOff + 16);
+        const double* ppq = c.sPP + (q * c.L + c.r) * 3;
+        const double vij = ppq[0], wla = ppq[1], p2 = ppq[2];
         double vji[NP], chi_c[NP], uji[NP], eta_c[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -1148,6 +1150,26 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
         return;
     const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
     static_assert(D % 2 == 0, "the block is finished in halves");
+    {
+        // the per-(continuum, wavelength) parameters alpha, w_lambda / lambda 4 pi / h, 2hc / lambda^3 of the tile's
+        // wavelengths into the wavefront's LDS block: lane (ray r, block q) fetches continuum q of its wavelength -- one
+        // memory round trip for all of them instead of one per continuum, walk and half
+        const CONST_AS DevContRec* cr = CTAB(DevContRec, a.contRec) + h.off + h.nLine;
+        const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
+        for (int q0 = 0; q0 < nCont; q0 += c.LR)
+        {
+            const int q = q0 + c.blk;
+            if (q < nCont && c.act)
+            {
+                const unsigned pOff = ((const GLOBAL_AS DevContRec*)(const void*)(a.contRec + h.off + h.nLine))[q].pOff;
+                double* dst = c.sPP + (q * c.L + c.r) * 3;
+                dst[0] = *(const GLOBAL_AS double*)(lsB + pOff);
+                dst[1] = *(const GLOBAL_AS double*)(lsB + pOff + 8);
+                dst[2] = *(const GLOBAL_AS double*)(lsB + pOff + 16);
+            }
+        }
+        (void)cr;
+    }
     lane_finish_part<D, 0, D / 2>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
     LS_PHASE();
     lane_finish_part<D, D / 2, D / 2>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
@@ -1156,10 +1178,11 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
 // One task = one tile (up to R wavelengths), every ray of it.
 template <int SOLVER, int D, bool RATES>
 DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, double* sAcc,
-                      unsigned long long* sDj, double* sB, const double* sExp, const char* sDep, double* sRow3, const int lane)
+                      unsigned long long* sDj, double* sB, const double* sExp, const char* sDep, double* sRow3, double* sPP, const int lane)
 {
     LS_T(tt0);
     LaneCtx c;
+    c.sPP = sPP;
     c.ti = ti;
     c.sExp = sExp;
     c.sDep = sDep;
@@ -1262,7 +1285,8 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     double* sB = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R + (size_t)wave * (LS_MAX_R * 4); // per wave [R][4]
     double* sExp = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R * 5;                              // [LS_EXP_TAB]
     double* sRow3 = sExp + LS_EXP_TAB + (size_t)wave * (3 * 64 * D);                                            // per wave [3][64][D]
-    double* sDep = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D);                                           // [depBytes / 8]
+    double* sPP = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)wave * (LWHIP_POST_MAXC * a.L * 3); // per wave [continuum][ray][3]
+    double* sDep = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)nWaves * (LWHIP_POST_MAXC * a.L * 3); // [depBytes / 8]
     ls_exp_table_init(sExp, t);
     {
         // the depth-only pools (populations, w_phi, nStar ratios, geometry) are the same for every tile: one LDS copy per
@@ -1287,7 +1311,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
         if (RATES && lane < LS_MAX_R)
             sDj[lane] = 0ull;
-        lane_task<SOLVER, D, RATES>(a, dyn, td, ti, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, lane);
+        lane_task<SOLVER, D, RATES>(a, dyn, td, ti, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sPP, lane);
         if (RATES && lane < td.nl)
             GD(a.dJ)[td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
     }
@@ -1400,7 +1424,8 @@ hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32
 
 size_t lane_sweep_lds_bytes(const TileArgs& a, int waves)
 {
-    return sizeof(double) * ((size_t)a.maxCT * 4 * a.laneLRD + (size_t)waves * LS_MAX_R * 5 + LS_EXP_TAB + (size_t)waves * 3 * 64 * a.laneD)
+    return sizeof(double) * ((size_t)a.maxCT * 4 * a.laneLRD + (size_t)waves * LS_MAX_R * 5 + LS_EXP_TAB + (size_t)waves * 3 * 64 * a.laneD
+                             + (size_t)waves * LWHIP_POST_MAXC * a.L * 3)
            + a.depBytes;
 }
 
