@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -122,6 +123,7 @@ struct lwhip_context
     bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
     // depth-across-lanes sweep (lwhip_lanesweep.hip): D points per lane, LR lanes per ray, R wavelengths per wavefront
     bool laneSweep = false;
+    int laneSplit = 1;             // lane sweep: wavefronts a tile's rays are split over (1, 2, 4)
     int laneD = 0, laneLR = 0, laneR = 0;
     DevBuf<DevPostProg> postProg;
     DevBuf<double> geoT;
@@ -923,16 +925,19 @@ int build_tables(lwhip_context* c)
         lanePostProgram = post_program;
         {
             // Which sweep: measured on MI355X (tools/size_sweep.sh, profiles/r03_size_sweep.md) the lane sweep is the
-            // faster one while its wavefronts (one per R wavelengths) fit the chip in one round of two per SIMD -- shards
-            // of a strong-scaled problem, PRD sub-problems, small grids --, the ray-column march above that (and for
-            // column batches, where the wavefronts of all columns count).  LWHIP_SWEEP=lanes|march forces one.
+            // faster one while its wavefronts (one per R wavelengths) are at most ~1.3 rounds of two per SIMD -- shards
+            // of a strong-scaled problem, PRD sub-problems, grids up to ~8 000 wavelengths -- and for column batches
+            // (throughput: many rounds); the ray-column march above that.  LWHIP_SWEEP=lanes|march forces one.
             const char* sw = std::getenv("LWHIP_SWEEP");
             int D = 0, LR = 0, R = 0;
             const bool supported = lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R);
             const bool force = (sw && std::strcmp(sw, "lanes") == 0) || c->hprd != nullptr // (hybrid PRD lives in the lane sweep)
                                || c->deterministic;                                    // (and so does the fixed-order reduction)
-            const long waves = supported ? ((long)c->Nla + R - 1) / R * std::max(c->batchHint, 1) : 0;
-            const bool prefer = force || (!sw && waves <= 2L * 4 * numCU);
+            // (round 3, after the workgroups got exactly one tile per wavefront: the lane sweep wins up to ~8 000 wavelengths
+            // -- 0.079 / 0.146 / 0.214 ms per step at 1 280 / 5 120 / 7 680 against the march's 0.172 / 0.202 / 0.228 --, ties at
+            // 8 192 and loses 4 % at 10 240, where its 3 429 tasks are 1.7 rounds; a 512-column batch runs 17 % faster on it)
+            const long waves = supported ? ((long)c->Nla + R - 1) / R : 0;
+            const bool prefer = force || (!sw && (c->batchHint > 1 || waves * 10 <= 26L * 4 * numCU));
             if ((c->hprd || c->deterministic || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
                 bool ok = true;
@@ -973,12 +978,41 @@ int build_tables(lwhip_context* c)
         c->preCols = 0;
         c->maxSlotsTile = 0;
         c->tileCap = env_int("LWHIP_TILE_GENERIC", 0); // > 0: every tile through the guarded generic march (test hook)
+        // (march, one problem: the launch is one round of workgroups -- one per tile, four per CU -- and lasts as long as its
+        // slowest one, march + post-pass.  The tiles with two slots march longest; capping their wavelengths shortens their
+        // post-pass, as long as the extra tiles still fit the round: measured 0.196 -> 0.184 ms at 10 240 wavelengths with 10
+        // instead of 12, nothing beyond ~0.9 of the slots -- profiles/r03_march_bounds.md)
+        auto count_tiles = [&](int capHeavy) {
+            int n = 0;
+            for (int la = 0; la < c->Nla; ++n)
+            {
+                const DevLaHeader& h = hdr[la];
+                const int Lk = std::min(L, h.nLine + h.nMixed >= 2 ? capHeavy : L);
+                int nl = 1;
+                while (nl < Lk && la + nl < c->Nla && same_structure(la, la + nl))
+                    ++nl;
+                la += nl;
+            }
+            return n;
+        };
+        int autoHeavy = L;
+        if (!c->laneSweep && c->batchHint <= 1 && L >= 6)
+        {
+            const int slots = 4 * numCU; // workgroups of two wavefronts at two wavefronts per SIMD
+            for (int cap = L - 1; cap >= L - L / 6; --cap)
+                if (count_tiles(cap) * 100 <= slots * 91)
+                    autoHeavy = cap;
+        }
+        const int tileLHeavy = std::max(1, env_int("LWHIP_TILE_LH", autoHeavy)), tileLOne = std::max(1, env_int("LWHIP_TILE_L1", L));
         for (int la = 0; la < c->Nla;)
         {
-            int nl = 1;
-            while (nl < L && la + nl < c->Nla && same_structure(la, la + nl))
-                ++nl;
             const DevLaHeader& h = hdr[la];
+            // (march: a workgroup lasts its tile's march + post-pass, and the launch as long as its slowest workgroup: tiles
+            // whose march is long -- two slots -- take fewer wavelengths, so that their post-pass is shorter)
+            const int Lk = c->laneSweep ? L : std::min(L, h.nLine + h.nMixed >= 2 ? tileLHeavy : h.nLine + h.nMixed == 1 ? tileLOne : L);
+            int nl = 1;
+            while (nl < Lk && la + nl < c->Nla && same_structure(la, la + nl))
+                ++nl;
             DevTile td{};
             td.la0 = la;
             td.nl = (int16_t)nl;
@@ -1145,11 +1179,15 @@ int build_tables(lwhip_context* c)
         auto tile_cost = [&](const DevTile& td) { return 1.0 + 0.35 * (td.nLine + td.nMixed); };
         // mode 0: accumulator slots for the tiles' lines and mixed continua; 1: for the pure continua (post-pass chunks);
         // 2: for both (the lane sweep's workgroups finish their tiles themselves)
-        auto chunk_tiles = [&](const std::vector<int32_t>& list, int tgt, int mode) {
+        // fixedCount > 0: every chunk holds that many tiles (lane sweep: one per group of wavefronts -- a workgroup's rounds
+        // are what a launch of one partial round lasts)
+        auto chunk_tiles = [&](const std::vector<int32_t>& list, int tgt, int mode, int fixedCount = 0) {
             const bool pure = mode == 1;
             TileChunking ck;
             const int n = (int)list.size();
             tgt = std::max(1, std::min(tgt, n));
+            if (fixedCount > 0)
+                tgt = (n + fixedCount - 1) / fixedCount;
             double total = 0.0;
             for (int ti : list)
                 total += tile_cost(tiles[ti]);
@@ -1160,7 +1198,8 @@ int build_tables(lwhip_context* c)
             {
                 acc += tile_cost(tiles[list[i]]);
                 const int remaining = n - (i + 1), remainingChunks = tgt - (made + 1);
-                if ((tgt >= n || acc >= total * (made + 1) / tgt || remaining <= remainingChunks) && i + 1 < n && made + 1 < tgt)
+                const bool cut = fixedCount > 0 ? (i + 1) % fixedCount == 0 : (tgt >= n || acc >= total * (made + 1) / tgt || remaining <= remainingChunks);
+                if (cut && i + 1 < n && made + 1 < tgt)
                 {
                     ck.chunkTile.push_back(i + 1);
                     ++made;
@@ -1212,6 +1251,8 @@ int build_tables(lwhip_context* c)
             if (tiles[i].hasPrd)
                 tileListPrd.push_back(i);
         }
+        // (dispatching the lane sweep's long tasks -- tiles with more slots -- first was measured and is WORSE: 0.288 against
+        // 0.204 ms at 10 240 wavelengths; co-resident long tasks slow each other down)
         int tgtSweep = std::min((2 * c->nTiles + W - 1) / W, numCU * wgPerCU); // two tasks per tile (down, up)
         // fused post-pass: the workgroup is the two wavefronts of one tile (and every tile is a workgroup)
         // (column batches too: 12.3k -> 16.0k column-iterations/s at 128 columns against a separate post launch)
@@ -1222,25 +1263,42 @@ int build_tables(lwhip_context* c)
             tgtSweep = c->nTiles;
         if (!c->tileFuse)
             tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
-        if (c->laneSweep) // one tile per wavefront
-            tgtSweep = (c->nTiles + W - 1) / W;
+        c->laneSplit = 1;
+        if (c->laneSweep)
+        {
+            // Small problems: the launch is ONE partial round of tasks and lasts as long as its longest task (a tile with two
+            // slots: ~0.13 ms alone).  While S wavefronts per tile still fit the round, a tile's rays are split over the S
+            // wavefronts of a group (each finishes 1/S of the tile's points): shorter tasks, same round.
+            if (!c->deterministic && c->batchHint <= 1 && W == 4)
+            {
+                const long slots = 2L * 4 * numCU;
+                // (measured, tools/split_exp.sh: S = 2 wins while it fits; S = 4 has the same kernel time at 1 280 wavelengths
+                // and a longer step -- four times the workgroups flushing their sums)
+                c->laneSplit = 2L * c->nTiles <= slots ? 2 : 1;
+                const int forced = env_int("LWHIP_LANE_SPLIT", 0);
+                if (forced == 1 || forced == 2 || forced == 4)
+                    c->laneSplit = forced;
+            }
+            tgtSweep = (c->nTiles * c->laneSplit + W - 1) / W; // one tile per group of wavefronts
+        }
         // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
         const size_t ldsPostEst = sizeof(double) * ((size_t)7 * 4 * Ns + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
         const int postPerCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / ldsPostEst));
         int tgtPost = std::min(c->nTiles, numCU * env_int("LWHIP_POST_PER_CU", postPerCU));
         if (c->batchHint > 1)
             tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
-        TileChunking sw = chunk_tiles(all, tgtSweep, c->laneSweep ? 2 : 0);
+        const int laneFixed = (c->laneSweep && env_int("LWHIP_LANE_UNIFORM", 1) != 0) ? std::max(1, W / c->laneSplit) : 0;
+        TileChunking sw = chunk_tiles(all, tgtSweep, c->laneSweep ? 2 : 0, laneFixed);
         TileChunking po = chunk_tiles(all, tgtPost, 1);
         TileChunking swPrd, poPrd;
         if (!tileListPrd.empty())
         {
             // (fused post-pass: one tile per workgroup here too)
             swPrd = chunk_tiles(tileListPrd,
-                                c->laneSweep ? ((int)tileListPrd.size() + W - 1) / W
+                                c->laneSweep ? ((int)tileListPrd.size() * c->laneSplit + W - 1) / W
                                 : c->tileFuse ? (int)tileListPrd.size()
                                               : std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU),
-                                0);
+                                0, laneFixed);
             poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * postPerCU), 1);
         }
         // both chunkings share one accumulator-slot capacity per kind
@@ -1782,6 +1840,7 @@ int build_tile_args(lwhip_context* c)
         a.laneLR = c->laneLR;
         a.laneR = c->laneR;
         a.laneLRD = c->laneLR * c->laneD;
+        a.laneSplit = c->laneSplit;
         a.phi = c->phi.p;
         a.geoT = c->geoT.p;
         a.postProg = c->postProg.p;
@@ -1799,17 +1858,17 @@ int build_tile_args(lwhip_context* c)
         a.hJCoef = c->hJCoef.p;
         a.JRest = c->JRest.p;
         a.detSlab = c->deterministic ? c->detSlab.p : nullptr;
-        a.lsDbg = nullptr;
-        if (std::getenv("LWHIP_LS_TIMING"))
+    }
+    a.lsDbg = nullptr;
+    if (std::getenv("LWHIP_LS_TIMING"))
+    {
+        // phase clocks of a -DLS_TIMING / -DRM_TIMING build: host-mapped, dumped by lwhip_destroy
+        if (!c->lsDbgHost)
         {
-            // phase clocks of a -DLS_TIMING build: host-mapped, dumped by lwhip_destroy
-            if (!c->lsDbgHost)
-            {
-                HIP_TRY(hipHostMalloc((void**)&c->lsDbgHost, (size_t)c->nTiles * 8 * sizeof(double), hipHostMallocMapped));
-                std::memset(c->lsDbgHost, 0, (size_t)c->nTiles * 8 * sizeof(double));
-            }
-            HIP_TRY(hipHostGetDevicePointer((void**)&a.lsDbg, c->lsDbgHost, 0));
+            HIP_TRY(hipHostMalloc((void**)&c->lsDbgHost, (size_t)c->nTiles * 8 * sizeof(double), hipHostMallocMapped));
+            std::memset(c->lsDbgHost, 0, (size_t)c->nTiles * 8 * sizeof(double));
         }
+        HIP_TRY(hipHostGetDevicePointer((void**)&a.lsDbg, c->lsDbgHost, 0));
     }
     // The device copies of the argument blocks keep their addresses for the life of the context (a fused column batch
     // holds them): the first call allocates, later ones (lwhip_set_zplane_outputs) overwrite in place on the stream.
@@ -2057,6 +2116,12 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
                      c->Nla, c->Ns, c->Nrays, c->is2d ? "2d" : c->laneSweep ? "depth-lanes" : "ray-column",
                      c->nTiles, c->tileL, c->maxSlotsTile, c->tileCap, c->nTileChunks, c->tileWaves, c->nPostChunks, c->maxCTTile, c->maxCTPost,
                      c->rowsTileTot * 8e-6, c->phiTTot * 8e-6);
+    if (std::getenv("LWHIP_VERBOSE") && c->laneSweep)
+        std::fprintf(stderr, "lwhip_create: lane sweep LDS per workgroup: accumulators %zu B + depth arena %zu B + per-wave blocks = %zu B\n",
+                     sizeof(double) * (size_t)c->maxCTTile * 4 * (c->laneLR * c->laneD), (size_t)c->depArena.n * sizeof(double),
+                     sizeof(double) * ((size_t)c->maxCTTile * 4 * (c->laneLR * c->laneD) + (size_t)c->tileWaves * 16 * 5 + 32
+                                       + (size_t)c->tileWaves * 3 * 64 * c->laneD + (size_t)c->tileWaves * LWHIP_POST_MAXC * c->laneR * 3)
+                         + (size_t)c->depArena.n * sizeof(double));
     *out = c;
     return LWHIP_OK;
 }
@@ -2067,6 +2132,26 @@ int lwhip_destroy(lwhip_context* c)
         return LWHIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->lsDbgHost && !c->laneSweep)
+    {
+        // -DRM_TIMING build of the march: per tile kind the count and the mean / max clocks of a direction's march and of the post-pass
+        std::map<int, std::array<double, 6>> kinds; // n, sum march, max march, sum post, max post, -
+        for (int t = 0; t < c->nTiles; ++t)
+        {
+            const double* o = c->lsDbgHost + (size_t)t * 8;
+            auto& k = kinds[(int)o[0]];
+            k[0] += 1.0;
+            k[1] += 0.5 * (o[1] + o[2]);
+            k[2] = std::max({ k[2], o[1], o[2] });
+            k[3] += o[3];
+            k[4] = std::max(k[4], o[3]);
+        }
+        for (const auto& kv : kinds)
+            std::fprintf(stderr, "march clocks, tiles of kind (%d lines, %d mixed): %d tiles, march mean %.0f max %.0f, post-pass mean %.0f max %.0f\n",
+                         kv.first / 10, kv.first % 10, (int)kv.second[0], kv.second[1] / kv.second[0], kv.second[2], kv.second[3] / kv.second[0], kv.second[4]);
+        (void)hipHostFree(c->lsDbgHost);
+        c->lsDbgHost = nullptr;
+    }
     if (c->lsDbgHost)
     {
         double sum[8] = { 0 }, mx = 0.0;
@@ -2075,6 +2160,20 @@ int lwhip_destroy(lwhip_context* c)
             for (int q = 0; q < 8; ++q)
                 sum[q] += c->lsDbgHost[(size_t)t * 8 + q];
             mx = std::max(mx, c->lsDbgHost[(size_t)t * 8 + 7]);
+        }
+        {
+            std::map<int, std::array<double, 3>> kinds;
+            for (int t = 0; t < c->nTiles; ++t)
+            {
+                const double tot = c->lsDbgHost[(size_t)t * 8 + 7];
+                auto& k = kinds[(int)std::lround((tot - std::floor(tot)) * 100.0)];
+                k[0] += 1.0;
+                k[1] += std::floor(tot);
+                k[2] = std::max(k[2], std::floor(tot));
+            }
+            for (const auto& kv : kinds)
+                std::fprintf(stderr, "lane sweep clocks, tiles of kind (%d lines, %d mixed): %d tiles, task mean %.0f max %.0f\n", kv.first / 10,
+                             kv.first % 10, (int)kv.second[0], kv.second[1] / kv.second[0], kv.second[2]);
         }
         std::fprintf(stderr, "lane sweep phase clocks per tile (mean): setup %.0f gather %.0f stencils %.0f coefficients %.0f scan %.0f rates %.0f finish %.0f total %.0f (max %.0f) over %d tiles\n",
                      sum[0] / c->nTiles, sum[1] / c->nTiles, sum[2] / c->nTiles, sum[3] / c->nTiles, sum[4] / c->nTiles, sum[5] / c->nTiles,

@@ -206,8 +206,8 @@ struct LaneCtx
 // Jk / M1 / Me (Me[0] alone if the tile has fewer than two lines: its moment slot is returned) and adds the slots'
 // integrals to the workgroup's accumulators.
 template <int SOLVER, int D, int NL, int NM, bool RATES>
-DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const LaneCtx& c, double* sAcc,
-                     double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
+DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const LaneCtx& c, double* sAcc, const int q0,
+                     const int q1, double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
 {
     constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
     const int Ns = c.Ns, Nmu = c.Nmu, LR = c.LR;
@@ -375,7 +375,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
     // the profiles are the one stream that comes from HBM: a ray's block is requested one ray ahead
     double phiN[NLc][D];
     {
-        const unsigned sRay0 = (unsigned)(dyn.nPass == 2 ? 0 : 1) * Ns8;
+        const unsigned sRay0 = (unsigned)(dyn.nPass == 2 ? q0 : 2 * q0 + 1) * Ns8; // the wavefront's first ray
 #pragma unroll
         for (int s = 0; s < NLc; ++s)
         {
@@ -944,15 +944,16 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 #undef SRC
     };
 
-    for (int mu = 0; mu < Nmu; ++mu)
+    // rays q0 .. q1 - 1 of the iteration's list (mu outer, down then up: SimdFullIterationTemplates.hpp:300-304; up only
+    // for formal_sol's upOnly) -- all of them, or this wavefront's share when the tile's rays are split over S wavefronts
+    for (int q = q0; q < q1; ++q)
     {
-        if (dyn.nPass == 2)
-        {
-            pass(std::false_type{}, mu, (unsigned)(mu * 2 + 1) * Ns8);
-            pass(std::true_type{}, mu, (unsigned)(mu * 2 + 2) * Ns8);
-        }
+        const int mu = dyn.nPass == 2 ? (q >> 1) : q;
+        const unsigned nextOff = (unsigned)(dyn.nPass == 2 ? q + 1 : 2 * q + 3) * Ns8;
+        if (dyn.nPass != 2 || (q & 1))
+            pass(std::true_type{}, mu, nextOff);
         else
-            pass(std::true_type{}, mu, (unsigned)(mu * 2 + 3) * Ns8);
+            pass(std::false_type{}, mu, nextOff);
     }
     if (LS_ACC0_REG && RATES && NL > 0 && act)
     {
@@ -1175,12 +1176,161 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     lane_finish_part<D, D / 2, D / 2>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
 }
 
-// One task = one tile (up to R wavelengths), every ray of it.
+// ---- a tile's rays split over the S wavefronts of a group (small problems: more, shorter tasks) -----------------------------
+// Each wavefront of the group has marched its share of the rays and holds partial sums J, M1, Meta0, Meta1 of its lanes'
+// D points.  Wavefront d finishes the points d * D/S .. of every block: it needs the other wavefronts' partials at those
+// points.  Exchange area X[d][source][quantity][point][lane] (over the group's row blocks, which nobody reads any more);
+// the totals are formed in wavefront order 0 .. S - 1, so J does not depend on timing (it does depend on S: a context
+// pins S, LWHIP_LANE_SPLIT overrides).
+template <int D, int S>
+DEVINL void lane_split_exchange_write(double* sX, const int sub, const int lane, const double (&Jk)[D], const double (&M1)[D],
+                                      const double (&Me)[2][D])
+{
+    constexpr int NP = D / S;
+#pragma unroll
+    for (int d = 0; d < S; ++d)
+    {
+        if (d == sub)
+            continue;
+        double* x = sX + (size_t)((d * (S - 1) + (sub < d ? sub : sub - 1)) * 4 * NP) * 64 + lane;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+        {
+            x[(0 * NP + pp) * 64] = Jk[d * NP + pp];
+            x[(1 * NP + pp) * 64] = M1[d * NP + pp];
+            x[(2 * NP + pp) * 64] = Me[0][d * NP + pp];
+            x[(3 * NP + pp) * 64] = Me[1][d * NP + pp];
+        }
+    }
+}
+template <int D, int S>
+DEVINL void lane_split_exchange_read(const double* sX, const int sub, const int lane, double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
+{
+    constexpr int NP = D / S;
+    double tot[4][NP];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+            tot[q][pp] = 0.0;
+#pragma unroll
+    for (int src = 0; src < S; ++src)
+    {
+        if (src == sub)
+        {
+#pragma unroll
+            for (int dd = 0; dd < S; ++dd)
+                if (dd == sub)
+                {
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp)
+                    {
+                        tot[0][pp] += Jk[dd * NP + pp];
+                        tot[1][pp] += M1[dd * NP + pp];
+                        tot[2][pp] += Me[0][dd * NP + pp];
+                        tot[3][pp] += Me[1][dd * NP + pp];
+                    }
+                }
+        }
+        else
+        {
+            const double* x = sX + (size_t)((sub * (S - 1) + (src < sub ? src : src - 1)) * 4 * NP) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp)
+                    tot[q][pp] += x[(q * NP + pp) * 64];
+        }
+    }
+#pragma unroll
+    for (int dd = 0; dd < S; ++dd)
+        if (dd == sub)
+        {
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+            {
+                Jk[dd * NP + pp] = tot[0][pp];
+                M1[dd * NP + pp] = tot[1][pp];
+                Me[0][dd * NP + pp] = tot[2][pp];
+                Me[1][dd * NP + pp] = tot[3][pp];
+            }
+        }
+}
+// lane_finish for wavefront `sub` of S: its D / S points of every block
+template <int D, int S>
+DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, const LaneCtx& c,
+                              const int sub, double* sAcc, unsigned long long* sDj, const int ms0, const int ms1, const double (&Jk)[D],
+                              const double (&M1)[D], const double (&Me)[2][D])
+{
+    constexpr int NP = D / S;
+    const int Ns = c.Ns, k0 = c.k0;
+    int la = c.la;
+    LS_KEEPI(la);
+    {
+        double dj = 0.0;
+        if (c.act)
+        {
+            const GLOBAL_AS double* Jrow = GCD(a.J) + (size_t)la * Ns + k0;
+#pragma unroll
+            for (int dd = 0; dd < S; ++dd)
+                if (dd == sub)
+                {
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp)
+                    {
+                        const int p = dd * NP + pp;
+                        if (p < c.nV)
+                        {
+                            const double Jdag = Jrow[p];
+                            GD(a.J)[(size_t)la * Ns + k0 + p] = Jk[p];
+                            dj = fmax(dj, fabs(1.0 - Jdag / Jk[p])); // :477-486
+                        }
+                    }
+                }
+            atomicMax(sDj + c.rRaw, (unsigned long long)__double_as_longlong(dj)); // non-negative doubles order as integers
+        }
+    }
+    const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + td.la0); // the tile's (uniform) structure
+    const int nCont = (!dyn.prdOnly && h.nPure > 0) ? h.nMixed + h.nPure : 0;
+    if (nCont <= 0)
+        return;
+    const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
+    {
+        // (the per-(continuum, wavelength) parameters into the wavefront's LDS block: as lane_finish)
+        const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
+        for (int q0 = 0; q0 < nCont; q0 += c.LR)
+        {
+            const int q = q0 + c.blk;
+            if (q < nCont && c.act)
+            {
+                const unsigned pOff = ((const GLOBAL_AS DevContRec*)(const void*)(a.contRec + h.off + h.nLine))[q].pOff;
+                double* dst = c.sPP + (q * c.L + c.r) * 3;
+                dst[0] = *(const GLOBAL_AS double*)(lsB + pOff);
+                dst[1] = *(const GLOBAL_AS double*)(lsB + pOff + 8);
+                dst[2] = *(const GLOBAL_AS double*)(lsB + pOff + 16);
+            }
+        }
+    }
+    if (sub == 0)
+        lane_finish_part<D, 0, NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    else if (sub == 1)
+        lane_finish_part<D, NP, NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    else if (S > 2 && sub == 2)
+        lane_finish_part<D, (S > 2 ? 2 * NP : 0), NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    else if (S > 2)
+        lane_finish_part<D, (S > 2 ? 3 * NP : 0), NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+}
+
+// One task = one tile (up to R wavelengths): every ray of it, or (S > 1) the share of wavefront `sub` of the tile's group.
 template <int SOLVER, int D, bool RATES>
-DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, double* sAcc,
-                      unsigned long long* sDj, double* sB, const double* sExp, const char* sDep, double* sRow3, double* sPP, const int lane)
+DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, const bool have, const int S,
+                      const int sub, double* sAcc, unsigned long long* sDj, double* sB, const double* sExp, const char* sDep,
+                      double* sRow3, double* sX, double* sPP, const int lane)
 {
     LS_T(tt0);
+    // this wavefront's rays of the iteration's list
+    const int nRays = a.Nmu * dyn.nPass;
+    const int q0 = (sub * nRays) / S, q1 = ((sub + 1) * nRays) / S;
     LaneCtx c;
     c.sPP = sPP;
     c.ti = ti;
@@ -1218,33 +1368,65 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     for (int p = 0; p < D; ++p)
         Jk[p] = M1[p] = Me[0][p] = Me[1][p] = 0.0;
     int ms0 = 0, ms1 = 1;
+    if (have)
+    {
 #ifdef LS_ONLY_NL
-    ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
-    if (LS_ONLY_NL < 2)
-        ms1 = -2;
+        ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+        if (LS_ONLY_NL < 2)
+            ms1 = -2;
 #else
-    if (td.nLine == 0)
-    {
-        lane_rays<SOLVER, D, 0, 0, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
-        ms0 = ms1 = -2;
-    }
-    else if (td.nLine == 1 && td.nMixed == 0)
-    {
-        ms0 = lane_rays<SOLVER, D, 1, 0, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
-        ms1 = -2;
-    }
-    else if (td.nLine == 1)
-    {
-        ms0 = lane_rays<SOLVER, D, 1, 1, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
-        ms1 = -2;
-    }
-    else
-        lane_rays<SOLVER, D, 2, 0, RATES>(a, dyn, td, c, sAcc, Jk, M1, Me);
+        if (td.nLine == 0)
+        {
+            lane_rays<SOLVER, D, 0, 0, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            ms0 = ms1 = -2;
+        }
+        else if (td.nLine == 1 && td.nMixed == 0)
+        {
+            ms0 = lane_rays<SOLVER, D, 1, 0, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            ms1 = -2;
+        }
+        else if (td.nLine == 1)
+        {
+            ms0 = lane_rays<SOLVER, D, 1, 1, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            ms1 = -2;
+        }
+        else
+            lane_rays<SOLVER, D, 2, 0, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
 #endif
+    }
     LS_T(tt1);
+    if (RATES && S > 1)
+    {
+        // (barriers of the whole workgroup: every wavefront passes here once per round, with or without a tile)
+        __syncthreads(); // the group's wavefronts are done with their row blocks: the exchange area lies over them
+        if (have)
+        {
+            if (S == 2)
+                lane_split_exchange_write<D, 2>(sX, sub, lane, Jk, M1, Me);
+            else
+                lane_split_exchange_write<D, 4>(sX, sub, lane, Jk, M1, Me);
+        }
+        __syncthreads();
+        if (have)
+        {
+            if (S == 2)
+                lane_split_exchange_read<D, 2>(sX, sub, lane, Jk, M1, Me);
+            else
+                lane_split_exchange_read<D, 4>(sX, sub, lane, Jk, M1, Me);
+        }
+    }
 #ifndef LS_DBG_NO_FINISH
-    if (RATES)
-        lane_finish<D>(a, dyn, td, ti, c, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+    if (RATES && have)
+    {
+        if (S == 1)
+            lane_finish<D>(a, dyn, td, ti, c, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+        else if (S == 2)
+            lane_finish_split<D, 2>(a, dyn, td, ti, c, sub, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+        else
+            lane_finish_split<D, 4>(a, dyn, td, ti, c, sub, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+    }
+    if (RATES && S > 1)
+        __syncthreads(); // the group's dJ maxima are complete; the row blocks may be overwritten by the next round
 #else
     if (RATES && c.act)
         GD(a.J)[(size_t)c.la * c.Ns + c.k0] = Jk[0] + Jk[1] + Jk[2] + Jk[3] + M1[0] + M1[1] + M1[2] + M1[3] + Me[0][0] + Me[0][1] + Me[0][2] + Me[0][3] + Me[1][0] + Me[1][1] + Me[1][2] + Me[1][3];
@@ -1256,7 +1438,7 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
         {
             double* o = a.lsDbg + (size_t)ti * 8;
             o[6] = (double)(tt2 - tt1);
-            o[7] = (double)(tt2 - tt0);
+            o[7] = (double)(tt2 - tt0) + 0.01 * (double)(td.nLine * 10 + td.nMixed); // (the tile's kind rides in the fraction)
             o[0] = (double)(tt1 - tt0) - o[1] - o[2] - o[3] - o[4] - o[5];
         }
     }
@@ -1280,11 +1462,15 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nWaves = blockDim.x >> 6;
+    // S > 1: the rays of a tile are split over the S consecutive wavefronts of a group (sub = 0 .. S - 1)
+    const int S = a.laneSplit > 1 ? a.laneSplit : 1;
+    const int grp = wave / S, sub = wave - grp * S, nGroups = nWaves / S;
     double* sAcc = lds;                                                             // [maxCT][4][LRD]
-    unsigned long long* sDj = (unsigned long long*)(lds + (size_t)maxCT * 4 * LRD) + wave * LS_MAX_R; // per wave [R]
+    unsigned long long* sDj = (unsigned long long*)(lds + (size_t)maxCT * 4 * LRD) + grp * LS_MAX_R; // per group [R]
     double* sB = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R + (size_t)wave * (LS_MAX_R * 4); // per wave [R][4]
     double* sExp = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R * 5;                              // [LS_EXP_TAB]
     double* sRow3 = sExp + LS_EXP_TAB + (size_t)wave * (3 * 64 * D);                                            // per wave [3][64][D]
+    double* sX = sExp + LS_EXP_TAB + (size_t)(grp * S) * (3 * 64 * D); // the group's exchange area: over its row blocks, after the rays
     double* sPP = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)wave * (LWHIP_POST_MAXC * a.L * 3); // per wave [continuum][ray][3]
     double* sDep = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)nWaves * (LWHIP_POST_MAXC * a.L * 3); // [depBytes / 8]
     ls_exp_table_init(sExp, t);
@@ -1305,14 +1491,22 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     }
     __syncthreads();
     const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
-    for (int li = t0 + wave; li < t1; li += nWaves)
+    // rounds of the workgroup: each group takes a tile of the chunk (with S > 1 every wavefront passes the round's barriers,
+    // also a group that has no tile left)
+    const int nRounds = (t1 - t0 + nGroups - 1) / nGroups;
+    for (int rd = 0; rd < nRounds; ++rd)
     {
+        const int li0 = t0 + rd * nGroups + grp;
+        const bool have = li0 < t1;
+        if (S == 1 && !have)
+            break;
+        const int li = have ? li0 : t0;
         const int ti = tileList ? tileList[li] : li;
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
-        if (RATES && lane < LS_MAX_R)
-            sDj[lane] = 0ull;
-        lane_task<SOLVER, D, RATES>(a, dyn, td, ti, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sPP, lane);
-        if (RATES && lane < td.nl)
+        if (RATES && lane < LS_MAX_R && (S == 1 || sub == 0))
+            sDj[lane] = 0ull; // (S > 1: before the task's first barrier, the maxima are added after it)
+        lane_task<SOLVER, D, RATES>(a, dyn, td, ti, have, S, sub, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sX, sPP, lane);
+        if (RATES && have && sub == 0 && lane < td.nl)
             GD(a.dJ)[td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
     }
     if (RATES)

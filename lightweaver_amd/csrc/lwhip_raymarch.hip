@@ -458,12 +458,20 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     const double lamf = dyn.lambdaIterate ? 0.0 : 1.0;
     auto kOf = [&](int t) { return kS + dk * t; };
     // one 64-bit base + one zero-extended 32-bit offset per scalar load (no 64-bit address arithmetic per depth)
+#ifdef RM_DBG_HOTS
+    auto ktAt = [&](int k, unsigned off) { return *(const CONST_AS double*)(kt0 + (size_t)((unsigned)((k & 1) + 1) * ktS + off)); }; // timing experiment
+#else
     auto ktAt = [&](int k, unsigned off) { return *(const CONST_AS double*)(kt0 + (size_t)((unsigned)(k + 1) * ktS + off)); };
+#endif
     auto dhAt = [&](int ka, int kb) { return ktAt(min(ka, kb), 0); };
 
     // ---- loads of iteration t: gather of point t, rate scalars of point t - 2 --------------------------------------------
     auto load_step = [&](int t, StepIn<NL>& g) {
+#ifdef RM_DBG_HOTV
+        const int k = 0; // timing experiment: every step reads depth 0 (cache-hot; wrong results)
+#else
         const int k = kOf(t);
+#endif
         const unsigned so = (unsigned)k * strideK;
         g.chi = buf_ld(rRows, jb, so);
         g.eta = buf_ld(rRows, jb + RM_ROW * 8u, so);
@@ -551,7 +559,11 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         double nim[NLc], njm[NLc], wphim[NLc];
         if (RATES && DO_RATES)
         {
+#ifdef RM_DBG_HOTV
+            const unsigned so = 0u;
+#else
             const unsigned so = (unsigned)km * strideK;
+#endif
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
             {
@@ -846,8 +858,12 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                         const double r2v = I * vij * wlamu;
                         const double r3v = (uji + I * vji) * wlamu;
                         const double tot = row_reduce4(g0v, g1v, r2v, r3v, lane);
+#ifdef RM_DBG_NOACC
+                        asm volatile("" ::"v"(tot)); // timing experiment: no accumulator atomics (wrong results)
+#else
                         if ((lane & 12) == 0)
                             lds_add(sAcc + lacc[s] + (unsigned)((lane & 3) * Ns + km), tot);
+#endif
                     }
                 }
 #pragma unroll
@@ -866,8 +882,12 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                         const double r2v = I * vij * wlamu;
                         const double r3v = (uji + I * vji) * wlamu;
                         const double tot = row_reduce4(g0v, g1v, r2v, r3v, lane);
+#ifdef RM_DBG_NOACC
+                        asm volatile("" ::"v"(tot)); // timing experiment: no accumulator atomics (wrong results)
+#else
                         if ((lane & 12) == 0)
                             lds_add(sAcc + macc[c] + (unsigned)((lane & 3) * Ns + km), tot);
+#endif
                     }
                 }
                 // moments of the step into the window; a full window (or the last point) leaves for the moment block
@@ -875,12 +895,20 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 if (active)
                 {
                     double* wp = winLane + (m & (RM_WIN - 1));
+#ifndef RM_DBG_NOWIN
                     lds_add(wp, hw * I);
                     lds_add(wp + RM_WIN_Q, wPsi);
 #pragma unroll
                     for (int s = 0; s < NLc; ++s)
                         if (RM_HASL(7, s))
                             lds_add(wp + lmq[s], wPsi * el[s]); // Meta of the line's atom (or the unused row)
+#else
+                    double kp = hw * I + wPsi; // timing experiment: no window atomics (wrong results)
+#pragma unroll
+                    for (int s = 0; s < NLc; ++s)
+                        kp += wPsi * el[s];
+                    asm volatile("" ::"v"(kp));
+#endif
                 }
                 if ((m & (RM_WIN - 1)) == RM_WIN - 1 || PH == PH_L)
                     flush_window(m);
@@ -1241,6 +1269,9 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) RM_OCC raymarch_kernel(cons
         const int toObs = (nDir == 2) ? (task & 1) : 1;
         const int ti = tileList ? tileList[li] : li;
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
+#ifdef RM_TIMING
+        const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
         if (CAP == 0)
         {
             if (td.nLine == 0)
@@ -1254,6 +1285,15 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) RM_OCC raymarch_kernel(cons
         }
         else
             march_tile<SOLVER, (CAP > 0 ? CAP : 1), (CAP > 0 ? CAP : 1), RATES, true>(a, dyn, td, toObs, sAcc, win, lane);
+#ifdef RM_TIMING
+        // diagnostic build: shader clocks of this wavefront's march -> lsDbg[tile][kind, down, up, post]
+        if (lane == 0 && a.lsDbg)
+        {
+            double* o = a.lsDbg + (size_t)ti * 8;
+            o[0] = (double)(td.nLine * 10 + td.nMixed);
+            o[1 + toObs] = (double)(__builtin_amdgcn_s_memtime() - tm0);
+        }
+#endif
     }
     if (RATES && FUSE)
     {
@@ -1262,7 +1302,14 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) RM_OCC raymarch_kernel(cons
         const int ti = tileList ? tileList[li] : li;
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
         unsigned long long* sDj = (unsigned long long*)(lds + (size_t)maxCT * 4 * Ns);
+#ifdef RM_TIMING
+        const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
         post_tile<128>(ap, td, !dyn.prdOnly, ti % LWHIP_REDUCE_SPLIT, (double*)(sDj + 16), sDj, t);
+#ifdef RM_TIMING
+        if (t == 0 && a.lsDbg)
+            a.lsDbg[(size_t)ti * 8 + 3] = (double)(__builtin_amdgcn_s_memtime() - tp0);
+#endif
     }
     if (RATES)
     {

@@ -349,10 +349,12 @@ def test_deterministic_mode_is_bit_reproducible(gpu):
                     assert np.array_equal(ta.rhoPrd, tb.rhoPrd)
     q = prob.copy()
     with Context(q) as ctx:
+        same_kernel = ctx.sweep_kind() == 'lanes'
         q.gamma_prefill()
         ctx.formal_sol_gamma_matrices()
         ctx.redistribute_prd(2, 0.0)
-    compare_problems(runs[0], q, tol=1e-10)
+    # against the same kernel's atomic sums: rounding; against the other sweep (LWHIP_SWEEP=march): the one-call bound
+    compare_problems(runs[0], q, tol=1e-10 if same_kernel else TOL_ONE_CALL)
 
 
 @pytest.mark.parametrize('ncopy,maxlines', [(2, 4), (3, 6)])
