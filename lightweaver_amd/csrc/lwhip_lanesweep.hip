@@ -205,10 +205,11 @@ struct LaneCtx
 // The rays of one tile: NL / NM line / mixed-continuum slots.  Leaves J and the Psi* moments of the lane's points in
 // Jk / M1 / Me (Me[0] alone if the tile has fewer than two lines: its moment slot is returned) and adds the slots'
 // integrals to the workgroup's accumulators.
-template <int SOLVER, int D, int NL, int NM, bool RATES>
+template <int SOLVER, int D, int NL, int NM, int MODE>
 DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const LaneCtx& c, double* sAcc, const int q0,
                      const int q1, double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
 {
+    constexpr bool RATES = (MODE & 1) != 0, HPRD = (MODE & 2) != 0; // MODE: bit 0 rates, bit 1 hybrid PRD (compiled in only where used)
     constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
     const int Ns = c.Ns, Nmu = c.Nmu, LR = c.LR;
     const int la = c.la, k0 = c.k0;
@@ -257,7 +258,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
             rPhi[s] = a.phi + u.phiOff;
             if (u.flags & 2)
                 rRho[s] = a.rho + u.rhoOff;
-            if ((u.flags & 2) && u.hCoefOff >= 0 && a.hRho)
+            if (HPRD && (u.flags & 2) && u.hCoefOff >= 0 && a.hRho)
                 rHc[s] = a.hRho + u.hCoefOff;
             const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
             la0[s] = sl->p[0];
@@ -427,7 +428,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 for (int p = 0; p < N; ++p)
                     rho[p] = 1.0;
             }
-            else if (rHc[s])
+            else if (HPRD && rHc[s])
             {
                 const GLOBAL_AS lwhip_rho_coeff* cc = (const GLOBAL_AS lwhip_rho_coeff*)rHc[s]
                                                       + ((size_t)c.r * (Nmu * 2) + (size_t)(mu * 2 + dirI)) * Ns + (k0 + H);
@@ -732,7 +733,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 if (is_ok(i))
                     GD(a.depthI)[o + MI(i)] = Iv[i];
         }
-        if (RATES && a.hJOff && td.hasPrd && act)
+        if (HPRD && RATES && a.hJOff && td.hasPrd && act)
         {
             // hybrid PRD: the ray's intensity into the rest-frame mean intensity, JRest(idx, k) += 0.5 wmu frac I(k)
             // (SimdFullIterationTemplates.hpp:397-408); fp64 atomics: other wavelengths and rays add to the same rows
@@ -946,15 +947,21 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 
     // rays q0 .. q1 - 1 of the iteration's list (mu outer, down then up: SimdFullIterationTemplates.hpp:300-304; up only
     // for formal_sol's upOnly) -- all of them, or this wavefront's share when the tile's rays are split over S wavefronts
-    for (int q = q0; q < q1; ++q)
+    // (written as the loop over mu with its two directions guarded, not as a loop over q with a direction branch: the
+    // latter makes the compiler hoist three dozen registers of addresses and flags in front of the loop, and spill)
+    if (dyn.nPass == 2)
     {
-        const int mu = dyn.nPass == 2 ? (q >> 1) : q;
-        const unsigned nextOff = (unsigned)(dyn.nPass == 2 ? q + 1 : 2 * q + 3) * Ns8;
-        if (dyn.nPass != 2 || (q & 1))
-            pass(std::true_type{}, mu, nextOff);
-        else
-            pass(std::false_type{}, mu, nextOff);
+        for (int mu = q0 >> 1; 2 * mu < q1; ++mu)
+        {
+            if (2 * mu >= q0)
+                pass(std::false_type{}, mu, (unsigned)(mu * 2 + 1) * Ns8);
+            if (2 * mu + 1 < q1)
+                pass(std::true_type{}, mu, (unsigned)(mu * 2 + 2) * Ns8);
+        }
     }
+    else
+        for (int mu = q0; mu < q1; ++mu)
+            pass(std::true_type{}, mu, (unsigned)(mu * 2 + 3) * Ns8);
     if (LS_ACC0_REG && RATES && NL > 0 && act)
     {
         // the first line's sums of this tile to the workgroup's accumulators
@@ -1322,15 +1329,17 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
 }
 
 // One task = one tile (up to R wavelengths): every ray of it, or (S > 1) the share of wavefront `sub` of the tile's group.
-template <int SOLVER, int D, bool RATES>
+template <int SOLVER, int D, int MODE>
 DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, const bool have, const int S,
                       const int sub, double* sAcc, unsigned long long* sDj, double* sB, const double* sExp, const char* sDep,
                       double* sRow3, double* sX, double* sPP, const int lane)
 {
+    constexpr bool RATES = (MODE & 1) != 0;
     LS_T(tt0);
     // this wavefront's rays of the iteration's list
     const int nRays = a.Nmu * dyn.nPass;
-    const int q0 = (sub * nRays) / S, q1 = ((sub + 1) * nRays) / S;
+    const int shS = S == 4 ? 2 : S == 2 ? 1 : 0;
+    const int q0 = (sub * nRays) >> shS, q1 = ((sub + 1) * nRays) >> shS;
     LaneCtx c;
     c.sPP = sPP;
     c.ti = ti;
@@ -1371,27 +1380,27 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     if (have)
     {
 #ifdef LS_ONLY_NL
-        ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+        ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
         if (LS_ONLY_NL < 2)
             ms1 = -2;
 #else
         if (td.nLine == 0)
         {
-            lane_rays<SOLVER, D, 0, 0, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            lane_rays<SOLVER, D, 0, 0, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
             ms0 = ms1 = -2;
         }
         else if (td.nLine == 1 && td.nMixed == 0)
         {
-            ms0 = lane_rays<SOLVER, D, 1, 0, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            ms0 = lane_rays<SOLVER, D, 1, 0, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
             ms1 = -2;
         }
         else if (td.nLine == 1)
         {
-            ms0 = lane_rays<SOLVER, D, 1, 1, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            ms0 = lane_rays<SOLVER, D, 1, 1, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
             ms1 = -2;
         }
         else
-            lane_rays<SOLVER, D, 2, 0, RATES>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            lane_rays<SOLVER, D, 2, 0, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
 #endif
     }
     LS_T(tt1);
@@ -1446,13 +1455,14 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
 }
 
 // Workgroup = W wavefronts, each takes tiles of the workgroup's chunk in turn.
-template <int SOLVER, int D, bool RATES, bool BATCH>
+template <int SOLVER, int D, int MODE, bool BATCH>
 #ifndef LS_WAVES_PER_EU
 #define LS_WAVES_PER_EU 2
 #endif
 __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LS_WAVES_PER_EU))) lanesweep_kernel(const TileArgs* __restrict__ ap0,
                                                                        const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
+    constexpr bool RATES = (MODE & 1) != 0;
     extern __shared__ double lds[];
     const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
     const CONST_AS TileArgs& a = *(const CONST_AS TileArgs*)ap;
@@ -1464,7 +1474,11 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     const int nWaves = blockDim.x >> 6;
     // S > 1: the rays of a tile are split over the S consecutive wavefronts of a group (sub = 0 .. S - 1)
     const int S = a.laneSplit > 1 ? a.laneSplit : 1;
-    const int grp = wave / S, sub = wave - grp * S, nGroups = nWaves / S;
+    // (S is 1, 2 or 4: shifts, and the results pinned in SGPRs -- an integer division is done in the vector unit and would
+    // leave every pointer derived from it in VGPRs)
+    const int sh = S == 4 ? 2 : S == 2 ? 1 : 0;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> sh), sub = __builtin_amdgcn_readfirstlane(wave & (S - 1)),
+              nGroups = __builtin_amdgcn_readfirstlane(nWaves >> sh);
     double* sAcc = lds;                                                             // [maxCT][4][LRD]
     unsigned long long* sDj = (unsigned long long*)(lds + (size_t)maxCT * 4 * LRD) + grp * LS_MAX_R; // per group [R]
     double* sB = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R + (size_t)wave * (LS_MAX_R * 4); // per wave [R][4]
@@ -1493,7 +1507,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
     // rounds of the workgroup: each group takes a tile of the chunk (with S > 1 every wavefront passes the round's barriers,
     // also a group that has no tile left)
-    const int nRounds = (t1 - t0 + nGroups - 1) / nGroups;
+    const int nRounds = __builtin_amdgcn_readfirstlane((t1 - t0 + nGroups - 1) / nGroups);
     for (int rd = 0; rd < nRounds; ++rd)
     {
         const int li0 = t0 + rd * nGroups + grp;
@@ -1505,7 +1519,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
         const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
         if (RATES && lane < LS_MAX_R && (S == 1 || sub == 0))
             sDj[lane] = 0ull; // (S > 1: before the task's first barrier, the maxima are added after it)
-        lane_task<SOLVER, D, RATES>(a, dyn, td, ti, have, S, sub, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sX, sPP, lane);
+        lane_task<SOLVER, D, MODE>(a, dyn, td, ti, have, S, sub, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sX, sPP, lane);
         if (RATES && have && sub == 0 && lane < td.nl)
             GD(a.dJ)[td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
     }
@@ -1569,24 +1583,24 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restric
     red8[(size_t)tr * LWHIP_REDUCE_SPLIT * n4 + i] = sum;
 }
 
-template <int SOLVER, int D, bool RATES>
+template <int SOLVER, int D, int MODE>
 hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int nChunks, int waves,
                        const TileArgs* const* apList, int nBatch, hipStream_t stream)
 {
     const size_t lds = lane_sweep_lds_bytes(a, waves);
     if (lds > 48 * 1024)
     {
-        hipError_t e = hipFuncSetAttribute(apList ? (const void*)lanesweep_kernel<SOLVER, D, RATES, true>
-                                                  : (const void*)lanesweep_kernel<SOLVER, D, RATES, false>,
+        hipError_t e = hipFuncSetAttribute(apList ? (const void*)lanesweep_kernel<SOLVER, D, MODE, true>
+                                                  : (const void*)lanesweep_kernel<SOLVER, D, MODE, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
     if (apList)
-        hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, RATES, true>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds, stream,
+        hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, MODE, true>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds, stream,
                            devArgs, apList, dyn);
     else
-        hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, RATES, false>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList, dyn);
+        hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, MODE, false>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList, dyn);
     return hipGetLastError();
 }
 }
@@ -1630,8 +1644,11 @@ hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& a, const T
         return hipSuccess;
     if (waves < 1 || waves > LS_MAX_WAVES || solver != LWHIP_FS_BEZIER3_1D || a.laneD != 4)
         return hipErrorInvalidValue;
+    const bool hprd = a.hRho != nullptr || a.hJOff != nullptr;
     if (rates)
-        return launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, true>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
-    return launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, false>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+        return hprd ? launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, 3>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream)
+                    : launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, 1>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+    return hprd ? launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, 2>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream)
+                : launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, 0>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
 }
 }
