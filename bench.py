@@ -284,12 +284,15 @@ def aux_columns(args, device, stream, torch, models):
         ms = timed(lambda: batch.formal_sol_gamma_matrices(sync_host=False), 5, torch)
         alg = float(sum(c.algorithmic_bytes() for c in batch.contexts))
         fused = batch._batch is not None
+        kind = batch.contexts[0].sweep_kind()
         # f1: phi / wphi of every line of every column regenerated on the device (what follows an atmosphere update)
         prof_ms = timed(batch.compute_profiles, 3, torch)
     return {'config': f'C4: {ncol} perturbed FALC columns, H(6)+CaII(6), {probs[0].Nlambda} wavelengths each, fused batch',
             'columns': ncol, 'fused': fused, 'ms_per_batch_iteration': ms, 'column_iters_per_s': ncol * 1e3 / ms,
             'host_build_s': t1 - t0, 'contexts_and_profiles_s': t2 - t1, 'device_profiles_ms': prof_ms,
-            'roofline': roofline_block('raymarch_kernel<BATCH> (+ tile_pre / tile_post / reduce / apply)', alg, ms,
+            'sweep': kind,
+            'roofline': roofline_block(('lanesweep_kernel<BATCH> (+ tile_pre / reduce / apply)' if kind == 'lanes'
+                                        else 'raymarch_kernel<BATCH> (+ tile_pre / tile_post / reduce / apply)'), alg, ms,
                                        'whole batch iteration (host clock)')}
 
 

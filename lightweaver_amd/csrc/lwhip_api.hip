@@ -123,6 +123,7 @@ struct lwhip_context
     bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
     // depth-across-lanes sweep (lwhip_lanesweep.hip): D points per lane, LR lanes per ray, R wavelengths per wavefront
     bool laneSweep = false;
+    int laneSplitPrd = 1;          // ... in the PRD rates pass (its tile list is shorter)
     int laneSplit = 1;             // lane sweep: wavefronts a tile's rays are split over (1, 2, 4)
     int laneD = 0, laneLR = 0, laneR = 0;
     DevBuf<DevPostProg> postProg;
@@ -937,7 +938,14 @@ int build_tables(lwhip_context* c)
             // -- 0.079 / 0.146 / 0.214 ms per step at 1 280 / 5 120 / 7 680 against the march's 0.172 / 0.202 / 0.228 --, ties at
             // 8 192 and loses 4 % at 10 240, where its 3 429 tasks are 1.7 rounds; a 512-column batch runs 17 % faster on it)
             const long waves = supported ? ((long)c->Nla + R - 1) / R : 0;
-            const bool prefer = force || (!sw && (c->batchHint > 1 || waves * 10 <= 26L * 4 * numCU));
+            // (problems with PRD lines: every sub-iteration runs the rates pass over the lines' wavelengths only -- a few
+            // hundred tasks, where the lane sweep's short tasks count: 0.215 against 0.268 ms per sub-iteration on the
+            // 10 240-wavelength grid, for 4 % on the formal solution itself -- so they stay with it up to two rounds)
+            long nPrdLa = 0;
+            for (int la = 0; la < c->Nla; ++la)
+                nPrdLa += hdr[la].hasPrd ? 1 : 0;
+            const long limit10 = (nPrdLa > 0 ? 40L : 26L) * 4 * numCU;
+            const bool prefer = force || (!sw && (c->batchHint > 1 || waves * 10 <= limit10));
             if ((c->hprd || c->deterministic || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
                 bool ok = true;
@@ -1280,6 +1288,9 @@ int build_tables(lwhip_context* c)
                     c->laneSplit = forced;
             }
             tgtSweep = (c->nTiles * c->laneSplit + W - 1) / W; // one tile per group of wavefronts
+            c->laneSplitPrd = c->laneSplit;
+            if (!c->deterministic && c->batchHint <= 1 && W == 4 && !tileListPrd.empty() && env_int("LWHIP_LANE_SPLIT", 0) == 0)
+                c->laneSplitPrd = 2L * (long)tileListPrd.size() <= 2L * 4 * numCU ? 2 : 1;
         }
         // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
         const size_t ldsPostEst = sizeof(double) * ((size_t)7 * 4 * Ns + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
@@ -1295,10 +1306,10 @@ int build_tables(lwhip_context* c)
         {
             // (fused post-pass: one tile per workgroup here too)
             swPrd = chunk_tiles(tileListPrd,
-                                c->laneSweep ? ((int)tileListPrd.size() * c->laneSplit + W - 1) / W
+                                c->laneSweep ? ((int)tileListPrd.size() * c->laneSplitPrd + W - 1) / W
                                 : c->tileFuse ? (int)tileListPrd.size()
                                               : std::min((2 * (int)tileListPrd.size() + W - 1) / W, numCU * wgPerCU),
-                                0, laneFixed);
+                                0, c->laneSweep ? std::max(1, W / c->laneSplitPrd) : 0);
             poPrd = chunk_tiles(tileListPrd, std::min((int)tileListPrd.size(), numCU * postPerCU), 1);
         }
         // both chunkings share one accumulator-slot capacity per kind
@@ -1888,6 +1899,7 @@ int build_tile_args(lwhip_context* c)
         a.tslots = c->tslotsPrd.p;
         a.chunkTile = c->chunkTilePrd.p;
         a.tileList = c->tileListPrd.p;
+        a.laneSplit = c->laneSplitPrd;
         a.slotTr = c->tileSlotTrPrd.p;
         a.postChunkTile = c->postChunkTilePrd.p;
         HIP_TRY(put(c->dtargsPrd, c->htargsPrd, a));
