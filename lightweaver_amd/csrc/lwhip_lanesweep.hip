@@ -993,10 +993,55 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 // (chi_eta_aux_accum :59-109, continua in transition order) live in registers: per tile the host lists which sums have
 // several contributors (DevPostProg).  P0, NP: the points of the lane's block this call handles (the block is
 // finished in pieces to bound the registers).
+// The tile's continuum records for the finish: lane q holds record q (and the tile program's words for it), fetched with
+// ONE vector round trip; the walks pick a continuum's words with v_readlane (q is uniform).  As scalar loads inside the
+// walks they were ~40 dependent memory waits per task (every walk of every half re-read them, and a tile's records
+// rarely sit in the scalar cache).
+struct LaneFinRecs
+{
+    unsigned nI, nJ, rat, w6, w7, code, ops; // DevContRec dwords 0, 1, 2, 6 (sUj | flags << 16 | ms << 24), 7 (tr | cs << 16)
+};
+DEVINL LaneFinRecs lane_fin_recs(const CONST_AS TileArgs& a, const DevLaHeader& h, const int ti, const int nCont, const int lane)
+{
+    LaneFinRecs r{};
+    if (lane < nCont)
+    {
+        const GLOBAL_AS unsigned* w = (const GLOBAL_AS unsigned*)(const void*)(a.contRec + h.off + h.nLine + lane);
+        r.nI = w[0];
+        r.nJ = w[1];
+        r.rat = w[2];
+        r.w6 = w[6];
+        r.w7 = w[7];
+        const GLOBAL_AS DevPostProg* pg = (const GLOBAL_AS DevPostProg*)(const void*)(a.postProg + ti);
+        r.code = pg->code[lane];
+        r.ops = pg->ops[lane];
+    }
+    return r;
+}
+struct LaneFinRec1 // one continuum's words, uniform
+{
+    unsigned nI, nJ, rat, flags, code, ops;
+    int ms, cs;
+};
+DEVINL LaneFinRec1 lane_fin_rec(const LaneFinRecs& v, const int q)
+{
+    LaneFinRec1 r;
+    r.nI = (unsigned)__builtin_amdgcn_readlane((int)v.nI, q);
+    r.nJ = (unsigned)__builtin_amdgcn_readlane((int)v.nJ, q);
+    r.rat = (unsigned)__builtin_amdgcn_readlane((int)v.rat, q);
+    const unsigned w6 = (unsigned)__builtin_amdgcn_readlane((int)v.w6, q), w7 = (unsigned)__builtin_amdgcn_readlane((int)v.w7, q);
+    r.flags = (w6 >> 16) & 0xffu;
+    r.ms = (int)(int8_t)(w6 >> 24);
+    r.cs = (int)(int16_t)(w7 >> 16);
+    r.code = (unsigned)__builtin_amdgcn_readlane((int)v.code, q);
+    r.ops = (unsigned)__builtin_amdgcn_readlane((int)v.ops, q);
+    return r;
+}
+
 template <int D, int P0, int NP>
 DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const DevLaHeader& h, const int ti, const int nCont,
-                             double* sAcc, const int slotOffLa, const int ms0, const int ms1, const double (&Jk)[D],
-                             const double (&M1)[D], const double (&Me)[2][D])
+                             const LaneFinRecs& recs, double* sAcc, const int slotOffLa, const int ms0, const int ms1,
+                             const double (&Jk)[D], const double (&M1)[D], const double (&Me)[2][D])
 {
     const int Nmu = c.Nmu, LR = c.LR;
     const unsigned vK = c.vK + (unsigned)P0 * 8u;
@@ -1004,9 +1049,9 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
     for (int m = 0; m < Nmu; ++m)
         for (int d = 0; d < 2; ++d)
             Wsum += 0.5 * CTAB(double, a.wmu)[m];
-    const CONST_AS DevContRec* cr = CTAB(DevContRec, a.contRec) + h.off + h.nLine;
-    const CONST_AS DevPostProg* pg = CTAB(DevPostProg, a.postProg) + ti;
-    const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
+    (void)h;
+    (void)ti;
+    (void)slotOffLa;
     double boltz[NP];
     {
         double rT[NP];
@@ -1025,8 +1070,8 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
     // walk 1: the shared level sums, continua in transition order
     for (int q = 0; q < nCont; ++q)
     {
-        const DevContRec rc = ld_c(cr + q);
-        const unsigned code = (rc.flags & 1) ? pg->code[q] : 0u;
+        const LaneFinRec1 rc = lane_fin_rec(recs, q);
+        const unsigned code = (rc.flags & 1) ? rc.code : 0u;
         if (code == 0u)
             continue;
         double ni[NP], nj[NP], rat[NP];
@@ -1058,7 +1103,7 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
     // walk 2: the pure continua
     for (int q = 0; q < nCont; ++q)
     {
-        const DevContRec rc = ld_c(cr + q);
+        const LaneFinRec1 rc = lane_fin_rec(recs, q);
         if (!(rc.flags & 2))
             continue;
         double ni[NP], nj[NP], rat[NP];
@@ -1076,7 +1121,7 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
             uji[p] = p2 * vji[p];
             eta_c[p] = nj[p] * uji[p];
         }
-        const unsigned ops = pg->ops[q];
+        const unsigned ops = rc.ops;
         double o5[5][NP]; // eta_A, chi_i, U_j, chi_j, U_i
 #pragma unroll
         for (int w = 0; w < 5; ++w)
@@ -1157,6 +1202,7 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     if (nCont <= 0)
         return;
     const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
+    const LaneFinRecs recs = lane_fin_recs(a, h, ti, nCont, c.lane);
     static_assert(D % 2 == 0, "the block is finished in halves");
     {
         // the per-(continuum, wavelength) parameters alpha, w_lambda / lambda 4 pi / h, 2hc / lambda^3 of the tile's
@@ -1178,9 +1224,9 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
         }
         (void)cr;
     }
-    lane_finish_part<D, 0, D / 2>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    lane_finish_part<D, 0, D / 2>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
     LS_PHASE();
-    lane_finish_part<D, D / 2, D / 2>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    lane_finish_part<D, D / 2, D / 2>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
 }
 
 // ---- a tile's rays split over the S wavefronts of a group (small problems: more, shorter tasks) -----------------------------
@@ -1302,6 +1348,7 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
     if (nCont <= 0)
         return;
     const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
+    const LaneFinRecs recs = lane_fin_recs(a, h, ti, nCont, c.lane);
     {
         // (the per-(continuum, wavelength) parameters into the wavefront's LDS block: as lane_finish)
         const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
@@ -1319,13 +1366,13 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
         }
     }
     if (sub == 0)
-        lane_finish_part<D, 0, NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, 0, NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
     else if (sub == 1)
-        lane_finish_part<D, NP, NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, NP, NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
     else if (S > 2 && sub == 2)
-        lane_finish_part<D, (S > 2 ? 2 * NP : 0), NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, (S > 2 ? 2 * NP : 0), NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
     else if (S > 2)
-        lane_finish_part<D, (S > 2 ? 3 * NP : 0), NP>(a, c, h, ti, nCont, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, (S > 2 ? 3 * NP : 0), NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
 }
 
 // One task = one tile (up to R wavelengths): every ray of it, or (S > 1) the share of wavefront `sub` of the tile's group.
