@@ -250,7 +250,7 @@ class Context:
         _check(self.lib, self.lib.lwhip_redistribute_prd(self._h, int(maxIter), float(tol), C.byref(res)),
                'lwhip_redistribute_prd')
         if not deviceResident:
-            self.download(abi.J | abi.RATES | abi.RHOPRD)
+            self.download(abi.J | abi.I | abi.RATES | abi.RHOPRD)  # (the rates pass rewrites spect.I of its wavelengths too)
         it, m = res.NprdSubIter, res.Nprd
         return IterationUpdate(updatedRho=it > 0, updatedJ=it > 0, NprdSubIter=it,
                                dRho=dRho[:it * m].reshape(it, m), dRhoMaxIdx=dRhoIdx[:it * m].reshape(it, m),

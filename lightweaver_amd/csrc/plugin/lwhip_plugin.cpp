@@ -840,7 +840,9 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
     lwhip_prd_result r{ 0, 0, dRho.data(), dRhoIdx.data(), dJ.data(), dJIdx.data() };
     if (lwhip_redistribute_prd(st->hip, maxIter, tol, &r) != LWHIP_OK)
         fail("lwhip_redistribute_prd");
-    if (lwhip_download(st->hip, LWHIP_J | LWHIP_RATES | LWHIP_RHOPRD) != LWHIP_OK)
+    // (the rates pass of every sub-iteration also rewrites spect.I of its wavelengths: intensity_core_opt,
+    // SimdFullIterationTemplates.hpp:349)
+    if (lwhip_download(st->hip, LWHIP_J | LWHIP_I | LWHIP_RATES | LWHIP_RHOPRD) != LWHIP_OK)
         fail("lwhip_download");
     const size_t nEnt = (size_t)r.NprdSubIter * r.Nprd;
     result.updatedRho = true;

@@ -131,9 +131,51 @@ def test_ragged_sizes_vs_oracle(gpu, Nspace, Nrays, sweep):
     compare_problems(p, q)
 
 
+@pytest.mark.parametrize('split', [1, 2, 4])
+@pytest.mark.parametrize('prd', [False, True])
+def test_lane_sweep_ray_split_vs_oracle(gpu, monkeypatch, split, prd):
+    """The lane sweep with a tile's rays split over S = 1 / 2 / 4 wavefronts (TileArgs::laneSplit; small problems get S = 2
+    by themselves): J, I, Gamma, rates against the oracle at the one-call bound, with 5 mu (10 rays: shares of 5 / 5 and
+    2 / 3 / 2 / 3), with and without PRD lines (the PRD rates pass has its own tile list); twice from the same inputs J and I
+    of the formal solution agree bit for bit (the partial sums of the wavefronts are added in wavefront order), and across
+    split factors they agree to rounding."""
+    monkeypatch.setenv('LWHIP_SWEEP', 'lanes')
+    atmos = models.perturbed(models.falc82(), seed=7)
+    prob = (models.falc_h_ca(Nrays=5, lineScale=0.4, prd=True, atmos=atmos) if prd
+            else models.build_problem(atmos, [models.H_6(0.5), models.CaII_6(0.5)], Nrays=5))
+    runs = {}
+    for S in (split, split, 1):
+        monkeypatch.setenv('LWHIP_LANE_SPLIT', str(S))
+        p = prob.copy()
+        with Context(p) as ctx:
+            assert ctx.sweep_kind() == 'lanes'
+            p.gamma_prefill()
+            ctx.formal_sol_gamma_matrices()
+            if prd:
+                ctx.redistribute_prd(2, 0.0)
+        runs.setdefault(S, []).append(p)
+    a, b = runs[split][0], runs[split][1]
+    if prd:
+        # (rho of a PRD sub-iteration is formed from the atomically summed rates, so the J of its rates pass varies in the
+        # last bits from run to run; LWHIP_OPT_DETERMINISTIC removes that)
+        compare_problems(a, b, tol=1e-11, what=('J', 'I'))
+    else:
+        assert np.array_equal(a.J, b.J) and np.array_equal(a.I, b.I)
+    compare_problems(a, runs[1][-1], tol=1e-11 if prd else 1e-12, what=('J', 'I'))
+    q = prob.copy()
+    q.gamma_prefill()
+    oc = OracleContext(q)
+    oc.formal_sol_gamma_matrices()
+    if prd:
+        oc.redistribute_prd(2, 0.0)
+    compare_problems(a, q)
+
+
 @pytest.mark.parametrize('env', [{'LWHIP_TILE_GENERIC': '2'}, {'LWHIP_TILE_GENERIC': '8'},
                                  {'LWHIP_SWEEP': 'march', 'LWHIP_TILE_FUSE': '0'}, {'LWHIP_SWEEP': 'march', 'LWHIP_TWAVES': '4'},
-                                 {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '2'}, {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '8'}])
+                                 {'LWHIP_SWEEP': 'march', 'LWHIP_TILE_LH': '5'},
+                                 {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '2'}, {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '8'},
+                                 {'LWHIP_SWEEP': 'lanes', 'LWHIP_LANE_UNIFORM': '0'}])
 def test_sweep_variants_forced_on_small_problem(gpu, monkeypatch, env):
     """The other instantiations of the one sweep on the 82-point H + Ca II problem: every tile through the guarded
     generic march (capacity 2 / 8: what tiles with more overlapping lines than the compile-time kinds use), the

@@ -85,6 +85,7 @@ def run_hprd(ctxFactory, prob, nIter=3, prdIter=3, tol=1e-2, Nthreads=None):
 
 def assert_same(pa, pb, tol):
     assert rel_err(pa.J, pb.J) <= tol
+    assert rel_err(pa.I, pb.I) <= tol
     for a, b in zip(pa.atoms, pb.atoms):
         assert rel_err(a.n, b.n) <= tol
         if not a.detailed:

@@ -64,6 +64,7 @@ def prd_lines(p):
 
 def assert_same_state(pa, pb, tol):
     assert rel_err(pa.J, pb.J) <= tol
+    assert rel_err(pa.I, pb.I) <= tol  # (the rates pass of a sub-iteration rewrites spect.I of its wavelengths)
     for a, b in zip(pa.atoms, pb.atoms):
         assert rel_err(a.n, b.n) <= tol
         for ta, tb in zip(a.trans, b.trans):

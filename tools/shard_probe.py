@@ -13,7 +13,8 @@ os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 os.environ.setdefault('MASTER_PORT', '29611')
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-prob = models.throughput_grid(10240, 5, computeProfiles=False)
+NLA = int(sys.argv[1]) if len(sys.argv) > 1 else 10240
+prob = models.throughput_grid(NLA, 5, computeProfiles=False)
 stream = torch.cuda.current_stream()
 for force in (False, True):
     ctx = Context(prob.copy(), stream=stream.cuda_stream, worldSize=1, worldRank=0)
@@ -28,7 +29,7 @@ for force in (False, True):
         it.formal_sol_gamma_matrices(deviceResident=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print('sharded path with a 1-rank RCCL all-reduce' if force else 'one-call form', 'ms/step=%.4f' % (1e3 * dt / n),
+    print('Nlambda=%d' % NLA, 'sharded path with a 1-rank RCCL all-reduce' if force else 'one-call form', 'ms/step=%.4f' % (1e3 * dt / n),
           'allreduce host us/step=%.1f' % (1e6 * it.allreduce_s / (n + 20)))
     ctx.close()
 dist.destroy_process_group()
