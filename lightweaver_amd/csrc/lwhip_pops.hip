@@ -155,6 +155,147 @@ DEVINL bool d_solve_lin_eq(int N, const SolveWs& w)
     return true;
 }
 
+
+// The same solver with the system in REGISTERS, for the small level counts (N <= 6: H and Ca II of the benchmark): every
+// loop is unrolled, the dynamically indexed accesses of the pivoting (row iMax, x[index[i]]) become selects over the
+// rows.  Operation for operation the routine above (each element's sums are formed in the same order), so the results
+// are the same bits; what changes is the latency: an LDS round trip per matrix element made the 6 x 6 solve of one
+// depth point ~25 us, here it is a straight-line stream of ~1 500 instructions.
+template <int N> DEVINL bool d_solve_lin_eq_reg(double (&A)[N][N], double (&b)[N])
+{
+    double A0[N][N], b0[N], vv[N], res[N];
+    int index[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        b0[i] = b[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            A0[i][j] = A[i][j];
+    }
+    // lu_decompose :8-70
+    bool singular = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        double big = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            big = fmax(big, fabs(A[i][j]));
+        if (big == 0.0)
+            singular = true;
+        vv[i] = 1.0 / big;
+    }
+    if (singular)
+        return false;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+    {
+#pragma unroll
+        for (int i = 0; i < j; ++i)
+        {
+            double sum = A[i][j];
+#pragma unroll
+            for (int q = 0; q < i; ++q)
+                sum -= A[i][q] * A[q][j];
+            A[i][j] = sum;
+        }
+        int iMax = 0;
+        double big = 0.0;
+#pragma unroll
+        for (int i = j; i < N; ++i)
+        {
+            double sum = A[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q)
+                sum -= A[i][q] * A[q][j];
+            A[i][j] = sum;
+            const double cand = vv[i] * fabs(sum);
+            if (big < cand)
+            {
+                iMax = i;
+                big = cand;
+            }
+        }
+        // rows j and iMax change places (iMax stays 0 when no candidate is positive: the reference then swaps with row 0)
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+        {
+            if (r == j)
+                continue;
+            const bool sw = iMax == r;
+#pragma unroll
+            for (int q = 0; q < N; ++q)
+            {
+                const double ar = A[r][q], aj = A[j][q];
+                A[r][q] = sw ? aj : ar;
+                A[j][q] = sw ? ar : aj;
+            }
+            vv[r] = sw ? vv[j] : vv[r];
+        }
+        index[j] = iMax;
+        if (A[j][j] == 0.0)
+            A[j][j] = 1e-20;
+        const double tmp = 1.0 / A[j][j];
+#pragma unroll
+        for (int i = j + 1; i < N; ++i)
+            A[i][j] *= tmp;
+    }
+    // lu_backsub :72-101
+    auto backsub = [&](double (&x)[N]) {
+        int ii = -1;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+        {
+            const int ip = index[i];
+            double sum = x[i];
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+                sum = (ip == r) ? x[r] : sum;
+            const double xi = x[i];
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+                x[r] = (ip == r) ? xi : x[r];
+            if (ii >= 0)
+            {
+#pragma unroll
+                for (int j = 0; j < i; ++j)
+                    if (j >= ii)
+                        sum -= A[i][j] * x[j];
+            }
+            else if (sum != 0.0)
+                ii = i;
+            x[i] = sum;
+        }
+#pragma unroll
+        for (int i = N - 1; i >= 0; --i)
+        {
+            double sum = x[i];
+#pragma unroll
+            for (int j = i + 1; j < N; ++j)
+                sum -= A[i][j] * x[j];
+            x[i] = sum / A[i][i];
+        }
+    };
+    backsub(b);
+    // one pass of iterative improvement :114-131
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        double r = b0[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            r -= A0[i][j] * b[j];
+        res[i] = r;
+    }
+    backsub(res);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        b[i] += res[i];
+    return true;
+}
+enum { SOLVE_REG_MAXN = 6 };
+
 // threads per block such that the workspace fits the LDS (a power of two between 1 and 64)
 static int solve_block_threads(int N)
 {
@@ -199,6 +340,55 @@ DEVINL void report_change(double best, int bestIdx, double* out /* [gridDim.x][2
 }
 
 // ---- stat_eq_impl: Source/UpdatePopulations.cpp:7-47 -------------------------------------------------------
+// one depth point of an atom with N <= 6 levels, the system in registers
+template <int N>
+DEVINL bool stat_eq_point_reg(double* n, const double* Gamma, const double nTot, const int Ns, const int k, double& best, int& bestIdx)
+{
+    double A[N][N], b[N], old[N];
+    // Gamma_k and the elimination row: the level with the largest population
+    int iElim = 0;
+    double nMax = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        old[i] = n[(size_t)i * Ns + k];
+        if (nMax < old[i])
+        {
+            iElim = i;
+            nMax = old[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+        {
+            const double g = Gamma[((size_t)i * N + j) * Ns + k];
+            A[i][j] = (i == iElim) ? 1.0 : g;
+        }
+        b[i] = (i == iElim) ? nTot : 0.0;
+    }
+    if (!d_solve_lin_eq_reg<N>(A, b))
+        return false;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        const double cur = b[i];
+        n[(size_t)i * Ns + k] = cur;
+        if (cur != 0.0)
+        {
+            const double change = fabs((cur - old[i]) / cur);
+            if (change > best)
+            {
+                best = change;
+                bestIdx = i * Ns + k;
+            }
+        }
+    }
+    return true;
+}
+
 // blockIdx.y selects the atom, so every active atom is solved by one launch
 template <class A> DEVINL void stat_eq_body(const A& a)
 {
@@ -209,7 +399,24 @@ template <class A> DEVINL void stat_eq_body(const A& a)
     const int N = at.Nlevel;
     double best = 0.0;
     int bestIdx = 0x7fffffff;
-    if (k >= a.k0 && k < a.k1)
+    if (k >= a.k0 && k < a.k1 && N >= 2 && N <= SOLVE_REG_MAXN)
+    {
+        double* n = a.n + (size_t)at.levelOff * Ns;
+        const double* Gamma = a.Gamma + at.gammaOff;
+        const double nTot = a.nTotal[(size_t)at.atom * Ns + k];
+        bool ok = true;
+        switch (N)
+        {
+        case 2: ok = stat_eq_point_reg<2>(n, Gamma, nTot, Ns, k, best, bestIdx); break;
+        case 3: ok = stat_eq_point_reg<3>(n, Gamma, nTot, Ns, k, best, bestIdx); break;
+        case 4: ok = stat_eq_point_reg<4>(n, Gamma, nTot, Ns, k, best, bestIdx); break;
+        case 5: ok = stat_eq_point_reg<5>(n, Gamma, nTot, Ns, k, best, bestIdx); break;
+        default: ok = stat_eq_point_reg<6>(n, Gamma, nTot, Ns, k, best, bestIdx); break;
+        }
+        if (!ok)
+            atomicExch(a.status, LWHIP_ERR_SINGULAR);
+    }
+    else if (k >= a.k0 && k < a.k1)
     {
         double* n = a.n + (size_t)at.levelOff * Ns;
         const double* Gamma = a.Gamma + at.gammaOff;
@@ -259,7 +466,8 @@ template <class A> DEVINL void stat_eq_body(const A& a)
 }
 
 // BATCH: column batches -- blockIdx.z picks the column's argument block (read through the constant address space)
-template <bool BATCH> __global__ void stat_eq_kernel(const StatEqArgs a0, const StatEqArgs* __restrict__ list)
+// (blocks of at most 64 threads -- solve_block_threads --: the register form of the 6 x 6 solve may use the whole file)
+template <bool BATCH> __global__ void __launch_bounds__(64) stat_eq_kernel(const StatEqArgs a0, const StatEqArgs* __restrict__ list)
 {
     if constexpr (BATCH)
         stat_eq_body(CTAB(StatEqArgs, list)[blockIdx.z]);
@@ -291,13 +499,51 @@ hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream
 }
 
 // ---- time_dependent_update_impl: Source/UpdatePopulations.cpp:120-151 --------------------------------------
-__global__ void time_dep_kernel(int N, int Ns, int k0, int k1, double* n, const double* nOld, const double* Gamma,
+template <int N>
+DEVINL bool time_dep_point_reg(double* n, const double* nOld, const double* Gamma, const double dt, const int Ns, const int k)
+{
+    double A[N][N], b[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        b[i] = nOld[(size_t)i * Ns + k];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+        {
+            const double g = Gamma[((size_t)i * N + j) * Ns + k];
+            A[i][j] = (i == j) ? 1.0 - g * dt : -g * dt;
+        }
+    }
+    if (!d_solve_lin_eq_reg<N>(A, b))
+        return false;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        n[(size_t)i * Ns + k] = b[i];
+    return true;
+}
+
+__global__ void __launch_bounds__(64) time_dep_kernel(int N, int Ns, int k0, int k1, double* n, const double* nOld, const double* Gamma,
                                 double dt, int* status)
 {
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < k0 || k >= k1)
         return;
+    if (N >= 2 && N <= SOLVE_REG_MAXN)
+    {
+        bool ok = true;
+        switch (N)
+        {
+        case 2: ok = time_dep_point_reg<2>(n, nOld, Gamma, dt, Ns, k); break;
+        case 3: ok = time_dep_point_reg<3>(n, nOld, Gamma, dt, Ns, k); break;
+        case 4: ok = time_dep_point_reg<4>(n, nOld, Gamma, dt, Ns, k); break;
+        case 5: ok = time_dep_point_reg<5>(n, nOld, Gamma, dt, Ns, k); break;
+        default: ok = time_dep_point_reg<6>(n, nOld, Gamma, dt, Ns, k); break;
+        }
+        if (!ok)
+            atomicExch(status, LWHIP_ERR_SINGULAR);
+        return;
+    }
     const SolveWs w(lds, N, blockDim.x, threadIdx.x);
     for (int i = 0; i < N; ++i)
     {
