@@ -185,8 +185,7 @@ __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
                     eta += lNj[l] * (lU[l] * vji);
                 }
             const size_t o = ((size_t)b * nR + (r0 + q)) * Ns + k;
-            a.chi[o] = chi;
-            a.S[o] = (eta + sca) / chi;
+            a.cs[o] = make_double2(chi, (eta + sca) / chi);
             if (a.storeDepth)
             {
                 const size_t d = ((size_t)la * a.Nrays * 2 + rayOf[q]) * Ns + k;

@@ -169,7 +169,7 @@ struct lwhip_context
     DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
     DevBuf<PrdLineArgs> prdArgsDev;   // argument blocks of the PRD lines of a sub-iteration (one launch for all lines)
     std::vector<PrdLineArgs> prdArgsHost; // what the device copy holds
-    DevBuf<double> g2mux, b2chi, b2S, b2I, b2Psi, b2coef, red2d;
+    DevBuf<double> g2mux, b2cs, b2I, b2Psi, b2coef, red2d;
     DevBuf<int32_t> b2idx;
     int groups2d = 1, maxRowsLa = 1;
     int kLo = 0, kHi = -1; // depth range of the population updates (lwhip_set_depth_range); kHi < 0: to the end
@@ -1704,8 +1704,7 @@ int alloc_state(lwhip_context* c)
         c->groups2d = std::max(1, env_int("LWHIP_GROUPS2D", c->groups2d));
         HIP_TRY(c->red2d.alloc((size_t)c->groups2d * std::max(c->Ntrans, 1) * 4 * Ns));
         const size_t nb = (size_t)c->batch2d * 2 * Nr * Ns;
-        HIP_TRY(c->b2chi.alloc(nb));
-        HIP_TRY(c->b2S.alloc(nb));
+        HIP_TRY(c->b2cs.alloc(2 * nb)); // (chi, S) pairs
         HIP_TRY(c->b2I.alloc(nb));
         HIP_TRY(c->b2Psi.alloc(nb));
         HIP_TRY(c->b2coef.alloc(3 * nb));
@@ -2542,8 +2541,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     a.depthI = c->depthI.p;
     a.zDown = c->zDown.p;
     a.zUp = c->zUp.p;
-    a.chi = c->b2chi.p;
-    a.S = c->b2S.p;
+    a.cs = (double2*)c->b2cs.p;
     a.I = c->b2I.p;
     a.PsiStar = c->b2Psi.p;
     a.red = c->red2d.p;
@@ -2593,8 +2591,7 @@ static int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0)
     f.lcBuf = g.NlongChar > 0 ? c->b2lc.p : nullptr;
     f.lcUpOnly = (mode == 2) ? 1 : 0;
     f.rays = rayList;
-    f.chi = c->b2chi.p;
-    f.S = c->b2S.p;
+    f.cs = (const double2*)c->b2cs.p;
     f.I = c->b2I.p;
     f.PsiStar = c->b2Psi.p;
     f.coef = c->b2coef.p;

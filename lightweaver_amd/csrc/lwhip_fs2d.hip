@@ -61,6 +61,14 @@ DEVINL F2Loc f2_loc(const lwhip_intersection& loc, int Nx)
     return l;
 }
 DEVINL double f2_at(const F2Loc& l, const double* p) { return l.w0 * p[l.i0] + l.w1 * p[l.i1]; }
+// chi and S of a hit from the interleaved field: one 16-byte load per stencil point instead of two 8-byte ones (pass 1 is
+// bound by the number of cache lines its loads touch)
+DEVINL void f2_at2(const F2Loc& l, const double2* cs, double& chi, double& S)
+{
+    const double2 v0 = cs[l.i0], v1 = cs[l.i1];
+    chi = l.w0 * v0.x + l.w1 * v1.x;
+    S = l.w0 * v0.y + l.w1 * v1.y;
+}
 
 // besser_control_point :257-294.  Division-free: the caller supplies 1 / hM, 1 / hP and 1 / (hM + hP) (d_rcp:
 // v_rcp_f64 + two Newton steps, ~1 ulp; an IEEE divide is ~25 instructions and the step has ten of them)
@@ -144,7 +152,7 @@ DEVINL void f2_linear(double dtau, double Suw, double SLocal, double& e, double&
 // long characteristic up to the point's upwind hit (:1003-1043).  The walk is affine in the intensity at its far
 // end, I(hit) = Ecum * I(st[0]) + acc, so the pass that knows no intensities can finish it; also returns the last
 // chi control point.
-DEVINL void f2_long_char(const Fs2dArgs& a, int lc, const double* chi, const double* S, double chiHere, double SHere,
+DEVINL void f2_long_char(const Fs2dArgs& a, int lc, const double2* cs, double chiHere, double SHere,
                          double& Ecum, double& acc, double& chiC)
 {
     const int Nx = a.Nx;
@@ -156,11 +164,14 @@ DEVINL void f2_long_char(const Fs2dArgs& a, int lc, const double* chi, const dou
     // every sub-step is read three times (as the upwind, the local and the downwind point of consecutive steps):
     // carry its chi and S along instead of interpolating again
     F2Loc l0 = f2_loc(st[0], Nx), l1 = f2_loc(st[1], Nx);
-    double chiA = f2_at(l0, chi), SA = f2_at(l0, S), chiB = f2_at(l1, chi), SB = f2_at(l1, S);
+    double chiA, SA, chiB, SB;
+    f2_at2(l0, cs, chiA, SA);
+    f2_at2(l1, cs, chiB, SB);
     for (int s = 1; s < n - 1; ++s)
     {
         const F2Loc l2 = f2_loc(st[s + 1], Nx);
-        const double chiC2 = f2_at(l2, chi), SC2 = f2_at(l2, S);
+        double chiC2, SC2;
+        f2_at2(l2, cs, chiC2, SC2);
         f2_besser(st[s - 1].distance, st[s + 1].distance, chiA, chiB, chiC2, SA, SB, SC2, edt, src, psi, chiC);
         acc = edt * acc + src;
         Ecum = edt * Ecum;
@@ -239,8 +250,7 @@ fs2d_coef_kernel(const Fs2dArgs a)
     const lwhip_intersection* UW = a.uw + plane0;
     const lwhip_intersection* DW = a.dw + plane0;
     const int32_t* LC = a.longCharIdx + plane0;
-    const double* chi = a.chi + (size_t)solve * Ns;
-    const double* S = a.S + (size_t)solve * Ns;
+    const double2* cs = a.cs + (size_t)solve * Ns;
     double* Ps = a.PsiStar + (size_t)solve * Ns;
     double* cf = a.coef + (size_t)solve * 3 * Ns + (size_t)k * Nx + p;
     int32_t* ci = a.cidx + (size_t)solve * Ns + (size_t)k * Nx + p;
@@ -273,8 +283,9 @@ fs2d_coef_kernel(const Fs2dArgs a)
         {
             // (:884-898) the last column of a fixed-boundary grid has no downwind point: the preceding column's
             const lwhip_intersection dw = (edge && p == Nx - 1) ? DW[o - (mux < 0 ? -1 : 1)] : DW[o];
-            const double chiDw = f2_interp(dw, chi, Nx);
-            const double dtauDw = 0.5 * fabs(dw.distance) * (chi[o] + chiDw);
+            double chiDw, SDwUnused;
+            f2_at2(f2_loc(dw, Nx), cs, chiDw, SDwUnused);
+            const double dtauDw = 0.5 * fabs(dw.distance) * (cs[o].x + chiDw);
             const double Tdw = f2_interp(dw, a.temperature, Nx);
             if (toObs)
             {
@@ -330,13 +341,14 @@ fs2d_coef_kernel(const Fs2dArgs a)
         dw = DW[o];
     }
     const int lc = LC[o];
-    const double chiL = chi[o], SL = S[o];
+    const double2 csL = cs[o];
+    const double chiL = csL.x, SL = csL.y;
     double e;
     if (lc < 0)
     {
         const F2Loc lu = f2_loc(uw, Nx);
-        const double chiUw = f2_at(lu, chi);
-        const double Suw = f2_at(lu, S);
+        double chiUw, Suw;
+        f2_at2(lu, cs, chiUw, Suw);
         if (last || dw.distance == 0.0)
         {
             // linear step: the last plane (:1086-1101) uses the signed distance, the interior's
@@ -348,7 +360,9 @@ fs2d_coef_kernel(const Fs2dArgs a)
         {
             double chiC;
             const F2Loc ld = f2_loc(dw, Nx);
-            f2_besser(uw.distance, dw.distance, chiUw, chiL, f2_at(ld, chi), Suw, SL, f2_at(ld, S), e, src, psi, chiC);
+            double chiDw, Sdw;
+            f2_at2(ld, cs, chiDw, Sdw);
+            f2_besser(uw.distance, dw.distance, chiUw, chiL, chiDw, Suw, SL, Sdw, e, src, psi, chiC);
         }
         // the upwind intensity: previous plane (known) and, for a hit on the x face, this plane's
         // previous column (the unknown of the recurrence)
@@ -370,7 +384,7 @@ fs2d_coef_kernel(const Fs2dArgs a)
     {
         double chiC, Ecum, acc;
         if constexpr (LC_INLINE)
-            f2_long_char(a, lc, chi, S, chiL, SL, Ecum, acc, chiC);
+            f2_long_char(a, lc, cs, chiL, SL, Ecum, acc, chiC);
         else
         {
             const double* r = a.lcBuf + ((size_t)laIdx * a.NlongChar + lc) * 3;
@@ -380,21 +394,24 @@ fs2d_coef_kernel(const Fs2dArgs a)
         }
         const lwhip_intersection st = a.substeps[a.substepOff[lc + 1] - 1]; // = the upwind hit
         const F2Loc ls = f2_loc(st, Nx);
-        const double chiUw = f2_at(ls, chi);
-        const double Suw = f2_at(ls, S);
+        double chiUw, Suw;
+        f2_at2(ls, cs, chiUw, Suw);
         if (last || dw.distance == 0.0)
         {
             const double dtau = 0.5 * (chiUw + chiL) * (last ? uw.distance : st.distance);
-            f2_linear(dtau, last ? f2_interp(uw, S, Nx) : Suw, SL, e, src, psi);
+            double chiUwEnd, SuwEnd = Suw;
+            if (last)
+                f2_at2(f2_loc(uw, Nx), cs, chiUwEnd, SuwEnd);
+            f2_linear(dtau, SuwEnd, SL, e, src, psi);
         }
         else
         {
             // :1060-1075: the chi control point of the last sub-step is re-used, not recomputed
             const F2Loc ld = f2_loc(dw, Nx);
-            const double chiDw = f2_at(ld, chi);
+            double chiDw, Sdw;
+            f2_at2(ld, cs, chiDw, Sdw);
             const double dtauUw = (1.0 / 3.0) * (chiUw + chiL + chiC) * st.distance;
             const double dtauDw = (0.5) * (chiL + chiDw) * dw.distance;
-            const double Sdw = f2_at(ld, S);
             const double SC = f2_control_point(dtauUw, dtauDw, d_rcp(dtauUw), d_rcp(dtauDw), d_rcp(dtauUw + dtauDw), Suw, SL, Sdw);
             double M, O, Cc;
             f2_coeffs(dtauUw, M, O, Cc, e);
@@ -430,10 +447,10 @@ __global__ void __launch_bounds__(64) fs2d_longchar_kernel(const Fs2dArgs a)
         return;
     const size_t Ns = (size_t)a.Nx * a.Nz;
     const int solve = laIdx * a.nRayCycle + rayIdx;
-    const double* chi = a.chi + (size_t)solve * Ns;
-    const double* S = a.S + (size_t)solve * Ns;
+    const double2* cs = a.cs + (size_t)solve * Ns;
+    const double2 csO = cs[o];
     double Ecum, acc, chiC;
-    f2_long_char(a, lc, chi, S, chi[o], S[o], Ecum, acc, chiC);
+    f2_long_char(a, lc, cs, csO.x, csO.y, Ecum, acc, chiC);
     double* r = a.lcBuf + ((size_t)laIdx * a.NlongChar + lc) * 3;
     r[0] = Ecum;
     r[1] = acc;
@@ -708,8 +725,15 @@ extern "C" int lwhip_formal_solver_2d_impl(int device, const lwhip_grid2d* g, do
         F2_TRY(up(g->xUpperBc->idxs, (size_t)g->Nrays * 2 * sizeof(int32_t), (void**)&a.xIdxUp));
     }
     F2_TRY(up(rays, (size_t)nSolve * sizeof(int32_t), (void**)&a.rays));
-    F2_TRY(up(chi, (size_t)nSolve * Ns * sizeof(double), (void**)&a.chi));
-    F2_TRY(up(S, (size_t)nSolve * Ns * sizeof(double), (void**)&a.S));
+    {
+        std::vector<double> pairs((size_t)nSolve * Ns * 2); // the kernels read (chi, S) pairs
+        for (size_t i = 0; i < (size_t)nSolve * Ns; ++i)
+        {
+            pairs[2 * i] = chi[i];
+            pairs[2 * i + 1] = S[i];
+        }
+        F2_TRY(up(pairs.data(), pairs.size() * sizeof(double), (void**)&a.cs));
+    }
     F2_TRY(hipMalloc((void**)&a.I, (size_t)nSolve * Ns * sizeof(double)));
     allocs.push_back(a.I);
     F2_TRY(hipMalloc((void**)&a.PsiStar, (size_t)nSolve * Ns * sizeof(double)));

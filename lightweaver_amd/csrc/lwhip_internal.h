@@ -495,8 +495,7 @@ struct Fs2dArgs
     int32_t lcUpOnly;       // the launch's ray list is the up-going rays (index ray >> 1) instead of every ray
     const lwhip_intersection* substeps;
     const int32_t* rays;
-    const double* chi;     // [nSolve, Nz, Nx]
-    const double* S;
+    const double2* cs;     // [nSolve, Nz, Nx] (chi, S) pairs: one 16-byte load per stencil point
     double* I;
     double* PsiStar;
     // the solve's two passes meet here: per point, in the ray's processing order, the affine map
@@ -548,8 +547,7 @@ struct Batch2dArgs
     double* depthI;
     double* zDown;                 // ZPlaneDecomposition outputs [Nla, Nrays, Nx] (or null), :372-384
     double* zUp;
-    double* chi;                   // [nLa, nRaysActive, Ns] batch buffers
-    double* S;
+    double2* cs;                   // [nLa, nRaysActive, Ns] batch buffer of (chi, S) pairs
     const double* I;
     const double* PsiStar;
     double* red;                   // [nGroups][Ntrans, 4, Ns] running sums of the iteration, one copy per group
