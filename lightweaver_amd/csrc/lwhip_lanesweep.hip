@@ -1543,7 +1543,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
         for (int idx = t; idx < nDep; idx += blockDim.x)
             sDep[idx] = src[idx];
     }
-    const int chunk = blockIdx.x;
+    const int chunk = a.chunkOrder ? CTAB(int32_t, a.chunkOrder)[blockIdx.x] : (int)blockIdx.x;
     const int t0 = CTAB(int32_t, a.chunkTile)[chunk], t1 = CTAB(int32_t, a.chunkTile)[chunk + 1];
     if (RATES)
     {
