@@ -687,6 +687,100 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 LS_PHASE();
             }
         }
+        else
+        {
+            // The other two solvers (not the benchmark's: written for coverage, not tuned).  The boundary intensity of the
+            // ray's first point, as above:
+            auto boundary_I = [&](const int i) -> double {
+                double Ib = 0.0;
+                if (bcType == LWHIP_BC_THERMALISED)
+                {
+                    const double dtb = ((0.5 * zmu) * (CHI(i) + CHI(i + 1))) * dhK[IV(i + 1)];
+                    const double* sb = c.sB + min(c.rRaw, LS_MAX_R - 1) * 4 + (UP ? 2 : 0);
+                    const double B0 = sb[0], B1 = sb[1];
+                    Ib = UP ? B1 - (B0 - B1) / dtb : B0 - (B1 - B0) / dtb;
+                }
+                else if (bcType == LWHIP_BC_CALLABLE)
+                {
+                    const int mi = UP ? CTAB(int32_t, a.lowerIdx)[mu * 2 + 1] : CTAB(int32_t, a.upperIdx)[mu * 2 + 0];
+                    if (mi >= 0)
+                        Ib = UP ? GCD(a.lowerBcData)[(size_t)la * a.lowerNmu + mi] : GCD(a.upperBcData)[(size_t)la * a.upperNmu + mi];
+                }
+                return Ib;
+            };
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+            {
+                const double cu = CHI(i - 1), c0 = CHI(i), cd = CHI(i + 1);
+                const double Su = SRC(i - 1), S0 = S[i], Sd = SRC(i + 1);
+                double e1, b1, ps;
+                // the linear step over the upwind interval: piecewise_linear_1d_impl FormalScalar.cpp:136-207, and the last
+                // point of piecewise_besser_1d_impl :449-466
+                auto linear_step = [&]() {
+                    double dtau = ((0.5 * zmu) * (cu + c0)) * dhK[IV(i)];
+                    dtau = (is_first(i) || !is_ok(i)) ? 1.0 : dtau;
+                    const double rdt = d_rcp(dtau);
+                    const double dSuw = (Su - S0) * rdt;
+                    double w0, w1;
+                    d_w2(dtau, w0, w1);
+                    e1 = 1.0 - w0;
+                    b1 = w0 * S0 + w1 * dSuw;
+                    ps = w0 - w1 * rdt;
+                };
+                if (SOLVER == LWHIP_FS_LINEAR_1D)
+                    linear_step();
+                else
+                {
+                    // piecewise_besser_1d_impl FormalScalar.cpp:395-467: chi, S of the upwind, local and downwind point
+                    const double ds_uw = dhK[IV(i)] * zmu, ds_dw = dhK[IV(i + 1)] * zmu;
+                    const bool interior = !is_first(i) && !is_last(i) && is_ok(i);
+                    // (points without both neighbours get harmless arguments; their maps are replaced below)
+                    const double hU = interior ? ds_uw : 1.0, hD = interior ? ds_dw : 1.0;
+                    const double chiC = d_besser_control_point(hU, hD, cu, c0, cd);
+                    const double dtauUw = interior ? (1.0 / 3.0) * (cu + chiC + c0) * ds_uw : 1.0;
+                    const double dtauDw = interior ? 0.5 * (c0 + cd) * ds_dw : 1.0;
+                    const double SC = d_besser_control_point(dtauUw, dtauDw, Su, S0, Sd);
+                    double cM, cO, cC, edt;
+                    d_besser_coeffs(dtauUw, cM, cO, cC, edt);
+                    e1 = edt;
+                    b1 = cM * Su + cO * S0 + cC * SC;
+                    ps = cO + cC;
+                    if (__builtin_amdgcn_ballot_w64(is_last(i)) != 0)
+                    {
+                        // last point: linear, w1 with the sign of the reference's dS_uw = (S_0 - S_uw) / dtau (:449-466)
+                        const double dtau = is_last(i) ? ((0.5 * zmu) * (c0 + cu)) * dhK[IV(i)] : 1.0;
+                        const double rcp = d_rcp(dtau);
+                        const double dSuw = (S0 - Su) * rcp;
+                        double w0, w1;
+                        d_w2(dtau, w0, w1);
+                        const bool lst = is_last(i);
+                        e1 = lst ? 1.0 - w0 : e1;
+                        b1 = lst ? w0 * S0 - w1 * dSuw : b1;
+                        ps = lst ? w0 - w1 * rcp : ps;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(is_first(i)) != 0)
+                {
+                    const bool fst = is_first(i);
+                    const double Ib = boundary_I(i);
+                    e1 = fst ? 0.0 : e1;
+                    b1 = fst ? Ib : b1;
+                    ps = fst ? 0.0 : ps;
+                }
+                if (__builtin_amdgcn_ballot_w64(!is_ok(i)) != 0)
+                {
+                    const bool okk = is_ok(i);
+                    e1 = okk ? e1 : 1.0;
+                    b1 = okk ? b1 : 0.0;
+                    ps = okk ? ps : 0.0;
+                }
+                ee[i] = e1;
+                bb[i] = b1;
+                PsiS[i] = (ps * rch[i]) * lamf;
+            }
+            LS_T(tp2);
+            LS_TACC(tmB, tp1, tp2);
+        }
         LS_PHASE();
         LS_T(tp3);
 
@@ -1656,7 +1750,7 @@ hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn
 bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R)
 {
     (void)Nrays;
-    if (solver != LWHIP_FS_BEZIER3_1D)
+    if (solver != LWHIP_FS_BEZIER3_1D && solver != LWHIP_FS_LINEAR_1D && solver != LWHIP_FS_BESSER_1D)
         return false;
     const int d = 4;
     const int lr = (Ns + d - 1) / d;
@@ -1689,7 +1783,16 @@ hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& a, const T
 {
     if (nChunks <= 0)
         return hipSuccess;
-    if (waves < 1 || waves > LS_MAX_WAVES || solver != LWHIP_FS_BEZIER3_1D || a.laneD != 4)
+    if (waves < 1 || waves > LS_MAX_WAVES || a.laneD != 4)
+        return hipErrorInvalidValue;
+    // (the linear and BESSER solvers: one instance each per rates / no rates, with the hybrid-PRD paths compiled in)
+    if (solver == LWHIP_FS_LINEAR_1D)
+        return rates ? launch_ls_t<LWHIP_FS_LINEAR_1D, 4, 3>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream)
+                     : launch_ls_t<LWHIP_FS_LINEAR_1D, 4, 2>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+    if (solver == LWHIP_FS_BESSER_1D)
+        return rates ? launch_ls_t<LWHIP_FS_BESSER_1D, 4, 3>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream)
+                     : launch_ls_t<LWHIP_FS_BESSER_1D, 4, 2>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
+    if (solver != LWHIP_FS_BEZIER3_1D)
         return hipErrorInvalidValue;
     const bool hprd = a.hRho != nullptr || a.hJOff != nullptr;
     if (rates)

@@ -18,14 +18,15 @@ from tests.helpers import TOL_ONE_CALL, rel_err
 HAVE_REF = os.path.exists(bindings.REF_LIB)
 
 
-def hprd_problem(Nrays=3, lineScale=0.3, vamp=8.0e3, seed=7):
+def hprd_problem(Nrays=3, lineScale=0.3, vamp=8.0e3, seed=7, formalSolver=None):
     """FAL-C H + Ca II with Ca II H & K as PRD lines on a column with a few km/s of line-of-sight velocity (what makes
     the rest-frame and observer-frame grids differ)."""
     atmos = models.falc82()
     rng = np.random.default_rng(seed)
     k = np.arange(atmos.Nspace)
     atmos.vlos = vamp * np.sin(2.0 * np.pi * k / 37.0) + 0.2 * vamp * rng.standard_normal(atmos.Nspace)
-    return models.falc_h_ca(Nrays=Nrays, lineScale=lineScale, prd=True, atmos=atmos)
+    kw = {} if formalSolver is None else {'formalSolver': formalSolver}
+    return models.falc_h_ca(Nrays=Nrays, lineScale=lineScale, prd=True, atmos=atmos, **kw)
 
 
 def assert_tables_equal(a, b):
@@ -159,6 +160,20 @@ def test_hip_hprd_single_call_matches_oracle(gpu):
     ph, uh, Jh = run_hprd_hip(prob, nIter=1, prdIter=2)
     assert uo[0]['NprdSubIter'] == uh[0].NprdSubIter == 2
     assert np.allclose(uo[0]['dRho'], uh[0].dRho, rtol=1e-6)
+    assert rel_err(Jh, Jo) <= TOL_ONE_CALL
+    assert_same(po, ph, TOL_ONE_CALL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('solver', ['linear', 'besser'])
+def test_hip_hprd_other_solvers_match_oracle(gpu, solver):
+    """Hybrid PRD under the other two 1D formal solvers (the lane sweep's linear / BESSER coefficients): one formal solution +
+    one PRD call against the oracle at the one-call bound."""
+    from lightweaver_amd import _abi as abi
+    prob = hprd_problem(formalSolver={'linear': abi.FS_LINEAR_1D, 'besser': abi.FS_BESSER_1D}[solver])
+    po, uo, Jo = run_hprd(bindings.OracleContext, prob, nIter=1, prdIter=2)
+    ph, uh, Jh = run_hprd_hip(prob, nIter=1, prdIter=2)
+    assert uo[0]['NprdSubIter'] == uh[0].NprdSubIter == 2
     assert rel_err(Jh, Jo) <= TOL_ONE_CALL
     assert_same(po, ph, TOL_ONE_CALL)
 
