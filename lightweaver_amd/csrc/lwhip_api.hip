@@ -968,7 +968,7 @@ int build_tables(lwhip_context* c)
             }
         }
         if (c->hprd && !c->laneSweep)
-            return fail(LWHIP_ERR_UNSUPPORTED, "hybrid PRD needs the depth-across-lanes sweep (Bezier3, 13 <= Nspace <= 256, at most "
+            return fail(LWHIP_ERR_UNSUPPORTED, "hybrid PRD needs the depth-across-lanes sweep (1D, 13 <= Nspace <= 256, at most "
                                                "two lines or a line and a mixed continuum per wavelength)");
         const int L = c->laneSweep ? c->laneR : std::max(1, std::min({ 16, 64 / Nmu, env_int("LWHIP_TILE_L", 16) }));
         const int LRD = c->laneLR * c->laneD;
