@@ -866,6 +866,8 @@ int build_tables(lwhip_context* c)
         // register ("shared": several contributors, or a foreign one), which are the continuum's own term or zero.
         auto post_program = [&](int la, DevPostProg& pg) -> bool {
             pg = DevPostProg{};
+            for (auto& w : pg.code)
+                w = 0x9999u; // per term (+chi, -chi, U, eta) the entry it is added to: 1 .. 8 a shared sum, 9 none
             const DevLaHeader& h = hdr[la];
             const int base = h.off + h.nLine, nC = h.nMixed + h.nPure;
             if (nC > LWHIP_POST_MAXC)
@@ -915,8 +917,8 @@ int build_tables(lwhip_context* c)
                                 return false;
                             const int m = (int)sumOf.size();
                             it = sumOf.emplace(cols[w], m).first;
-                            for (const auto& cb : v)
-                                pg.code[cb.q] |= (unsigned)cb.kind << (3 * m);
+                            for (const auto& cb : v) // (kind 1 .. 4 -> nibble kind - 1 of the contributor's word: the sum's index)
+                                pg.code[cb.q] = (pg.code[cb.q] & ~(0xFu << (4 * (cb.kind - 1)))) | ((unsigned)(m + 1) << (4 * (cb.kind - 1)));
                         }
                         sel = (unsigned)it->second + 1u;
                     }
@@ -1525,6 +1527,19 @@ int build_tables(lwhip_context* c)
                 if (!lanePostProgram(tiles[t].la0, pp[t]))
                     return fail(LWHIP_ERR_UNSUPPORTED, "lane sweep: post program");
             HIP_TRY(c->postProg.upload(pp));
+            if (std::getenv("LWHIP_VERBOSE"))
+            {
+                // which program words occur (the finish serves the common ones with fixed registers)
+                std::map<std::pair<unsigned, unsigned>, int> hist;
+                for (size_t t = 0; t < tiles.size(); ++t)
+                {
+                    const DevLaHeader& h = hdr[tiles[t].la0];
+                    for (int q = 0; q < h.nMixed + h.nPure; ++q)
+                        hist[{ pp[t].code[q], pp[t].ops[q] }]++;
+                }
+                for (const auto& kv : hist)
+                    std::fprintf(stderr, "  finish program word code %#x ops %#x: %d continua\n", kv.first.first, kv.first.second, kv.second);
+            }
         }
         HIP_TRY(up(c->tiles, tiles));
         HIP_TRY(up(c->tslots, tslots));

@@ -167,7 +167,7 @@ struct DevTileSlot
 // Pure continua of a tile for the lane sweep's in-wave post-pass: the level sums they need that have more than one
 // contributor (or a foreign one) live in up to 8 registers per point ("shared sums"); everything else is the
 // continuum's own term or zero.  Per continuum ordinal q of the wavelength's transition order:
-//   code[q]: 8 x 3 bits, sum m receives from continuum q: 0 nothing, 1 +chi_c, 2 -chi_c, 3 +U_ji, 4 +eta_c
+//   code[q]: 4 x 4 bits, the entry (1 .. 8: a shared sum; 9: none) that continuum q's terms +chi_c, -chi_c, +U_ji, +eta_c are added to
 //   ops[q]:  5 x 4 bits (eta_A, chi_i, U_j, chi_j, U_i of pure continuum q): 0 zero, 1..8 shared sum m = value - 1,
 //            9 +chi_c, 10 -chi_c, 11 U_ji, 12 eta_c of the continuum itself
 enum { LWHIP_POST_MAXC = 16, LWHIP_POST_SUMS = 8 };

@@ -1155,18 +1155,20 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         for (int p = 0; p < NP; ++p)
             boltz[p] = ls_exp_neg(-hc_kl * rT[p], c.sExp);
     }
-    double S8[LWHIP_POST_SUMS][NP];
+    // entry 0: zero (never written); 1 .. 8: the shared sums; 9: the spare entry that takes the terms no shared sum wants.
+    // One register vector per point, so that an entry picked by a (uniform) index is an indexed register access
+    // (v_movrel), not a trip through scratch memory as for an array.
+    typedef double ls_sums_t __attribute__((ext_vector_type(LWHIP_POST_SUMS + 2)));
+    ls_sums_t S8[NP];
 #pragma unroll
-    for (int m = 0; m < LWHIP_POST_SUMS; ++m)
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-            S8[m][p] = 0.0;
+    for (int p = 0; p < NP; ++p)
+        S8[p] = (ls_sums_t)(0.0);
     // walk 1: the shared level sums, continua in transition order
     for (int q = 0; q < nCont; ++q)
     {
         const LaneFinRec1 rc = lane_fin_rec(recs, q);
-        const unsigned code = (rc.flags & 1) ? rc.code : 0u;
-        if (code == 0u)
+        const unsigned code = (rc.flags & 1) ? rc.code : 0x9999u;
+        if (code == 0x9999u)
             continue;
         double ni[NP], nj[NP], rat[NP];
         ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
@@ -1183,16 +1185,54 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
             uji[p] = p2 * vji;
             eta_c[p] = nj[p] * uji[p];
         }
+#ifdef LS_DBG_FASTDECODE
+        // timing experiment (wrong results): no decoding of the tile program
 #pragma unroll
-        for (int m = 0; m < LWHIP_POST_SUMS; ++m)
+        for (int p = 0; p < NP; ++p)
         {
-            const unsigned kind = (code >> (3 * m)) & 7u;
-            if (kind == 0u)
-                continue;
+            S8[p][1] += chi_c[p];
+            S8[p][2] -= chi_c[p];
+            S8[p][3] += uji[p];
+            S8[p][4] += eta_c[p];
+        }
+#else
+        // the program word names, for each of the continuum's four terms, the entry it goes to (1 .. 8 a shared sum, 9: none
+        // -- the spare entry): four indexed register updates instead of a test per (sum, term)
+        // (the two words almost every continuum of a one- or two-atom problem has -- its atom's eta, U(j), chi(j) are the
+        // shared sums 1, 2, 3 or 4, 5, 6, its chi(i) is its own -- are recognised and served with fixed registers; an
+        // indexed register access costs a mode switch each)
+        if (code == 0x1239u)
+        {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
-                S8[m][p] += kind == 1u ? chi_c[p] : kind == 2u ? -chi_c[p] : kind == 3u ? uji[p] : eta_c[p];
+            {
+                S8[p][3] -= chi_c[p];
+                S8[p][2] += uji[p];
+                S8[p][1] += eta_c[p];
+            }
         }
+        else if (code == 0x4569u)
+        {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+            {
+                S8[p][6] -= chi_c[p];
+                S8[p][5] += uji[p];
+                S8[p][4] += eta_c[p];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+            {
+                S8[p][(code >> 0) & 15u] += chi_c[p];
+                S8[p][(code >> 4) & 15u] -= chi_c[p];
+                S8[p][(code >> 8) & 15u] += uji[p];
+                S8[p][(code >> 12) & 15u] += eta_c[p];
+            }
+        }
+#endif
     }
     // walk 2: the pure continua
     for (int q = 0; q < nCont; ++q)
@@ -1217,35 +1257,51 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         }
         const unsigned ops = rc.ops;
         double o5[5][NP]; // eta_A, chi_i, U_j, chi_j, U_i
+#ifdef LS_DBG_FASTDECODE
 #pragma unroll
-        for (int w = 0; w < 5; ++w)
+        for (int p = 0; p < NP; ++p)
         {
-            const unsigned sel = (ops >> (4 * w)) & 15u;
+            o5[0][p] = S8[p][4];
+            o5[1][p] = S8[p][1];
+            o5[2][p] = S8[p][3];
+            o5[3][p] = S8[p][2];
+            o5[4][p] = S8[p][5];
+        }
+        (void)ops;
+#else
+        // operand w of the continuum: sel_w = 0 nothing, 1 .. 8 a shared sum (one indexed register read: the index is
+        // uniform), 9 .. 12 the continuum's own term -- instead of a chain of tests per operand
+        if (ops == 0x03291u || ops == 0x06594u || ops == 0x0AB9Cu)
+        {
+            // the common words: the atom's shared sums 1, 2, 3 / 4, 5, 6, or a continuum alone in its atom at this wavelength
+            const bool a0 = ops == 0x03291u, alone = ops == 0x0AB9Cu;
 #pragma unroll
             for (int p = 0; p < NP; ++p)
-                o5[w][p] = 0.0;
-            // (real scalar branches: as selects the 40 conditions of a continuum would be held in 80 SGPRs)
-            if (sel >= 9u)
             {
+                o5[0][p] = alone ? eta_c[p] : a0 ? S8[p][1] : S8[p][4];
+                o5[1][p] = chi_c[p];
+                o5[2][p] = alone ? uji[p] : a0 ? S8[p][2] : S8[p][5];
+                o5[3][p] = alone ? -chi_c[p] : a0 ? S8[p][3] : S8[p][6];
+                o5[4][p] = 0.0;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int w = 0; w < 5; ++w)
+            {
+                const unsigned sel = (ops >> (4 * w)) & 15u;
+                const unsigned si = sel > 8u ? 0u : sel;
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                 {
-                    o5[w][p] = sel == 9u ? chi_c[p] : sel == 10u ? -chi_c[p] : sel == 11u ? uji[p] : eta_c[p];
-                    LS_KEEP(o5[w][p]);
+                    const double own = sel == 9u ? chi_c[p] : sel == 10u ? -chi_c[p] : sel == 11u ? uji[p] : eta_c[p];
+                    const double shared = S8[p][si];
+                    o5[w][p] = sel > 8u ? own : shared;
                 }
             }
-#pragma unroll
-            for (int m = 0; m < LWHIP_POST_SUMS; ++m)
-                if (sel == (unsigned)(m + 1))
-                {
-#pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                    {
-                        o5[w][p] = S8[m][p];
-                        LS_KEEP(o5[w][p]);
-                    }
-                }
         }
+#endif
         double* dst = sAcc + (unsigned)(rc.cs * 4 * c.LRD) + c.blk;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
