@@ -938,9 +938,10 @@ int build_tables(lwhip_context* c)
             const bool supported = lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R);
             const bool force = (sw && std::strcmp(sw, "lanes") == 0) || c->hprd != nullptr // (hybrid PRD lives in the lane sweep)
                                || c->deterministic;                                    // (and so does the fixed-order reduction)
-            // (round 3, after the workgroups got exactly one tile per wavefront: the lane sweep wins up to ~8 000 wavelengths
-            // -- 0.079 / 0.146 / 0.214 ms per step at 1 280 / 5 120 / 7 680 against the march's 0.172 / 0.202 / 0.228 --, ties at
-            // 8 192 and loses 4 % at 10 240, where its 3 429 tasks are 1.7 rounds; a 512-column batch runs 17 % faster on it)
+            // (round 3, after the workgroups got exactly one tile per wavefront and the finish its fixed-register words: the
+            // lane sweep wins up to ~9 500 wavelengths -- 0.076 / 0.142 / 0.198 / 0.216 ms per step at 1 280 / 5 120 / 7 680 /
+            // 9 216 against the march's 0.172 / 0.202 / 0.228 / 0.234 -- and ties at 10 240 (0.227-0.233 against 0.230-0.243),
+            // where its 3 429 tasks are 1.7 rounds; a 512-column batch runs 20 % faster on it)
             const long waves = supported ? ((long)c->Nla + R - 1) / R : 0;
             // (problems with PRD lines: every sub-iteration runs the rates pass over the lines' wavelengths only -- a few
             // hundred tasks, where the lane sweep's short tasks count: 0.215 against 0.268 ms per sub-iteration on the
@@ -948,7 +949,7 @@ int build_tables(lwhip_context* c)
             long nPrdLa = 0;
             for (int la = 0; la < c->Nla; ++la)
                 nPrdLa += hdr[la].hasPrd ? 1 : 0;
-            const long limit10 = (nPrdLa > 0 ? 40L : 26L) * 4 * numCU;
+            const long limit10 = (nPrdLa > 0 ? 40L : 32L) * 4 * numCU;
             const bool prefer = force || (!sw && (c->batchHint > 1 || waves * 10 <= limit10));
             if ((c->hprd || c->deterministic || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
