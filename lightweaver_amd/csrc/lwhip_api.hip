@@ -123,7 +123,7 @@ struct lwhip_context
     bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
     // depth-across-lanes sweep (lwhip_lanesweep.hip): D points per lane, LR lanes per ray, R wavelengths per wavefront
     bool laneSweep = false;
-    bool chunkOrderOn = false;
+    bool chunkOrderOn = false, chunkSplitOn = false;
     int laneSplitPrd = 1;          // ... in the PRD rates pass (its tile list is shorter)
     int laneSplit = 1;             // lane sweep: wavefronts a tile's rays are split over (1, 2, 4)
     int laneD = 0, laneLR = 0, laneR = 0;
@@ -152,7 +152,8 @@ struct lwhip_context
     DevBuf<DevTileCopy> tcopies;
     DevBuf<int32_t> tileRemap;
     DevBuf<DevContRec> contRec;
-    DevBuf<int32_t> chunkOrder;   // lane sweep: dispatch order of the workgroups' chunks (experiment LWHIP_LANE_ORDER)
+    DevBuf<int32_t> chunkOrder;   // lane sweep: dispatch order of the workgroups' chunks
+    DevBuf<int32_t> chunkSplit;   // lane sweep: per chunk, the wavefronts its tiles' rays are split over (the launch's tail)
     DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
         postCs;
     DevBuf<double> geo, kt, rowsTile, momTile, phiT;
@@ -849,6 +850,7 @@ int build_tables(lwhip_context* c)
     if (c->tiled && (c->Nrays > 64 || Ns < 3))
         return fail(LWHIP_ERR_UNSUPPORTED, "the sweep needs Nrays <= 64 and Nspace >= 3");
     std::vector<DevTile> tiles;
+    std::vector<int32_t> laneChunkSplit, laneChunkOrder; // lane sweep: the tail's shorter chunks (split factor, dispatch order)
     std::vector<DevTileSlot> tslots, tslotsPrd;
     std::vector<DevTileCopy> tcopies;
     std::vector<int32_t> tileRemap;
@@ -929,28 +931,20 @@ int build_tables(lwhip_context* c)
         };
         lanePostProgram = post_program;
         {
-            // Which sweep: measured on MI355X (tools/size_sweep.sh, profiles/r03_size_sweep.md) the lane sweep is the
-            // faster one while its wavefronts (one per R wavelengths) are at most ~1.3 rounds of two per SIMD -- shards
-            // of a strong-scaled problem, PRD sub-problems, grids up to ~8 000 wavelengths -- and for column batches
-            // (throughput: many rounds); the ray-column march above that.  LWHIP_SWEEP=lanes|march forces one.
+            // Which sweep: the lane sweep wherever its compiled kinds cover the problem (measured on MI355X:
+            // tools/size_sweep.sh, tools/cross_exp.sh, profiles/r03_size_sweep.md), the ray-column march otherwise.
+            // LWHIP_SWEEP=lanes|march forces one.
             const char* sw = std::getenv("LWHIP_SWEEP");
             int D = 0, LR = 0, R = 0;
             const bool supported = lane_sweep_supported(Ns, Nmu, c->prob.formalSolver, &D, &LR, &R);
             const bool force = (sw && std::strcmp(sw, "lanes") == 0) || c->hprd != nullptr // (hybrid PRD lives in the lane sweep)
                                || c->deterministic;                                    // (and so does the fixed-order reduction)
-            // (round 3, after the workgroups got exactly one tile per wavefront and the finish its fixed-register words: the
-            // lane sweep wins up to ~9 500 wavelengths -- 0.076 / 0.142 / 0.198 / 0.216 ms per step at 1 280 / 5 120 / 7 680 /
-            // 9 216 against the march's 0.172 / 0.202 / 0.228 / 0.234 -- and ties at 10 240 (0.227-0.233 against 0.230-0.243),
-            // where its 3 429 tasks are 1.7 rounds; a 512-column batch runs 20 % faster on it)
-            const long waves = supported ? ((long)c->Nla + R - 1) / R : 0;
-            // (problems with PRD lines: every sub-iteration runs the rates pass over the lines' wavelengths only -- a few
-            // hundred tasks, where the lane sweep's short tasks count: 0.215 against 0.268 ms per sub-iteration on the
-            // 10 240-wavelength grid, for 4 % on the formal solution itself -- so they stay with it up to two rounds)
-            long nPrdLa = 0;
-            for (int la = 0; la < c->Nla; ++la)
-                nPrdLa += hdr[la].hasPrd ? 1 : 0;
-            const long limit10 = (nPrdLa > 0 ? 40L : 32L) * 4 * numCU;
-            const bool prefer = force || (!sw && (c->batchHint > 1 || waves * 10 <= limit10));
+            // (End of round 3 -- one tile per wavefront, rays split over two wavefronts for small launches and for the tail of
+            // large ones, fixed-register finish: the lane sweep is the faster one at every size measured, 0.076 / 0.142 /
+            // 0.187 / 0.217 / 0.315 / 0.426 ms per step at 1 280 / 5 120 / 8 192 / 10 240 / 15 360 / 20 480 wavelengths against
+            // the march's 0.171 / 0.205 / 0.225 / 0.223-0.234 / 0.396 / 0.457, and 20 % faster on a 512-column batch.  The
+            // march serves what the lane sweep's kinds do not cover, and LWHIP_SWEEP=march.)
+            const bool prefer = force || !sw;
             if ((c->hprd || c->deterministic || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
                 bool ok = true;
@@ -1194,7 +1188,8 @@ int build_tables(lwhip_context* c)
         // 2: for both (the lane sweep's workgroups finish their tiles themselves)
         // fixedCount > 0: every chunk holds that many tiles (lane sweep: one per group of wavefronts -- a workgroup's rounds
         // are what a launch of one partial round lasts)
-        auto chunk_tiles = [&](const std::vector<int32_t>& list, int tgt, int mode, int fixedCount = 0) {
+        auto chunk_tiles = [&](const std::vector<int32_t>& list, int tgt, int mode, int fixedCount = 0,
+                               const std::vector<int32_t>* bounds = nullptr) {
             const bool pure = mode == 1;
             TileChunking ck;
             const int n = (int)list.size();
@@ -1207,7 +1202,9 @@ int build_tables(lwhip_context* c)
             ck.chunkTile.push_back(0);
             double acc = 0.0;
             int made = 0;
-            for (int i = 0; i < n; ++i)
+            if (bounds) // the chunks are given ([0, ..., n])
+                ck.chunkTile.assign(bounds->begin(), bounds->end() - 1);
+            for (int i = 0; i < n && !bounds; ++i)
             {
                 acc += tile_cost(tiles[list[i]]);
                 const int remaining = n - (i + 1), remainingChunks = tgt - (made + 1);
@@ -1305,6 +1302,58 @@ int build_tables(lwhip_context* c)
             tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
         const int laneFixed = (c->laneSweep && env_int("LWHIP_LANE_UNIFORM", 1) != 0) ? std::max(1, W / c->laneSplit) : 0;
         TileChunking sw = chunk_tiles(all, tgtSweep, c->laneSweep ? 2 : 0, laneFixed);
+        // Lane sweep, more workgroups than the chip holds at once (one problem, 2 workgroups of 4 wavefronts per CU): the
+        // launch ends with workgroups that started late and have the chip to themselves -- whole tiles of 0.1 ms.  The
+        // chunks that are dispatched last (the lightest: heaviest go first) are cut into smaller ones whose tiles' rays are
+        // split over 2 or 4 wavefronts: the same work in shorter pieces, so the tail drains evenly.
+        {
+            const int slotsWg = 2 * numCU;
+            const int nch0 = (int)sw.chunkTile.size() - 1;
+            const int tailS = env_int("LWHIP_LANE_TAIL", 2);
+            if (c->laneSweep && c->batchHint <= 1 && !c->deterministic && W == 4 && c->laneSplit == 1 && laneFixed == W && nch0 > slotsWg
+                && (tailS == 2 || tailS == 4))
+            {
+                auto tcost = [&](int i) { return 1.0 + 0.5 * tiles[i].nLine + 0.3 * tiles[i].nMixed + (tiles[i].nLine == 0 ? -0.25 : 0.0); };
+                std::vector<double> cost(nch0, 0.0);
+                for (int ch = 0; ch < nch0; ++ch)
+                    for (int i = sw.chunkTile[ch]; i < sw.chunkTile[ch + 1]; ++i)
+                        cost[ch] += tcost(i);
+                std::vector<int32_t> ord(nch0);
+                for (int ch = 0; ch < nch0; ++ch)
+                    ord[ch] = ch;
+                std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
+                // the first `keep` chunks of the dispatch order stay whole
+                const int keep = std::min(nch0, std::max(0, env_int("LWHIP_LANE_KEEP", slotsWg)));
+                std::vector<char> cut(nch0, 0);
+                for (int q = keep; q < nch0; ++q)
+                    cut[ord[q]] = 1;
+                const int piece = W / tailS; // tiles per piece
+                std::vector<int32_t> bounds, split, firstNew(nch0, 0), nNew(nch0, 0);
+                bounds.push_back(0);
+                for (int ch = 0; ch < nch0; ++ch)
+                {
+                    firstNew[ch] = (int)bounds.size() - 1;
+                    const int b0 = sw.chunkTile[ch], b1 = sw.chunkTile[ch + 1];
+                    if (!cut[ch])
+                    {
+                        bounds.push_back(b1);
+                        split.push_back(1);
+                    }
+                    else
+                        for (int b = b0; b < b1; b += piece)
+                        {
+                            bounds.push_back(std::min(b + piece, b1));
+                            split.push_back(tailS);
+                        }
+                    nNew[ch] = (int)bounds.size() - 1 - firstNew[ch];
+                }
+                sw = chunk_tiles(all, 0, 2, 0, &bounds);
+                laneChunkSplit = split;
+                for (int q = 0; q < nch0; ++q)
+                    for (int e = 0; e < nNew[ord[q]]; ++e)
+                        laneChunkOrder.push_back(firstNew[ord[q]] + e);
+            }
+        }
         TileChunking po = chunk_tiles(all, tgtPost, 1);
         TileChunking swPrd, poPrd;
         if (!tileListPrd.empty())
@@ -1549,11 +1598,18 @@ int build_tables(lwhip_context* c)
         HIP_TRY(up(c->tileRemap, tileRemap));
         HIP_TRY(up(c->chunkTile, chunkTile));
         c->chunkOrderOn = false;
+        c->chunkSplitOn = false;
+        if (!laneChunkOrder.empty())
+        {
+            HIP_TRY(up(c->chunkOrder, laneChunkOrder));
+            HIP_TRY(up(c->chunkSplit, laneChunkSplit));
+            c->chunkOrderOn = c->chunkSplitOn = true;
+        }
         const int nchAll = (int)chunkTile.size() - 1;
         // more workgroups than the chip holds at once (2 per CU): the heavy ones go first, the light ones fill the tail
         // (measured: 8 192 wavelengths 0.188 -> 0.179 ms, 10 240: 0.203 -> 0.200; lightest first: 0.196 / 0.207)
         const int laneOrder = env_int("LWHIP_LANE_ORDER", nchAll > 2 * numCU ? 1 : 0);
-        if (c->laneSweep && c->batchHint <= 1 && laneOrder != 0)
+        if (c->laneSweep && c->batchHint <= 1 && laneOrder != 0 && laneChunkOrder.empty())
         {
             // the chunks stay what they are (neighbouring wavelengths: few accumulator slots); only the order in which the
             // workgroups take them changes: 1 = heaviest first, 2 = lightest first
@@ -1844,6 +1900,7 @@ int build_tile_args(lwhip_context* c)
     a.tileRemap = c->tileRemap.p;
     a.chunkTile = c->chunkTile.p;
     a.chunkOrder = c->chunkOrderOn ? c->chunkOrder.p : nullptr;
+    a.chunkSplit = c->chunkSplitOn ? c->chunkSplit.p : nullptr;
     a.tileList = nullptr;
     a.slotTr = c->tileSlotTr.p;
     a.postChunkTile = c->postChunkTile.p;
@@ -1940,6 +1997,7 @@ int build_tile_args(lwhip_context* c)
         a.chunkTile = c->chunkTilePrd.p;
         a.tileList = c->tileListPrd.p;
         a.chunkOrder = nullptr;
+        a.chunkSplit = nullptr;
         a.laneSplit = c->laneSplitPrd;
         a.slotTr = c->tileSlotTrPrd.p;
         a.postChunkTile = c->postChunkTilePrd.p;

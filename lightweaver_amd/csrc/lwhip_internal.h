@@ -258,6 +258,7 @@ struct TileArgs
     // rows[rowBase + (row * L + j) * laneLRD + k] (laneLRD = laneLR * laneD), profiles are read from the phi pool itself.
     int32_t laneD, laneLR, laneR, laneLRD;
     const int32_t* chunkOrder;     // lane sweep: workgroup -> chunk (dispatch order), or null
+    const int32_t* chunkSplit;     // lane sweep: per chunk the split factor of its tiles' rays (overrides laneSplit), or null
     int32_t laneSplit, _padLS;      // S = 1, 2, 4: a tile's rays are split over S wavefronts of its workgroup (small problems)
     const double* phi;             // [line][lt][Nmu][2][Ns] pool (the caller's layout)
     const double* geoT;            // [4][laneLRD + 2], entry k + 1: |h_k - h_k+1|, its reciprocal, 1 / (|h_k-1 - h_k| + |h_k - h_k+1|), 1 / T_k

@@ -1669,8 +1669,11 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nWaves = blockDim.x >> 6;
-    // S > 1: the rays of a tile are split over the S consecutive wavefronts of a group (sub = 0 .. S - 1)
-    const int S = a.laneSplit > 1 ? a.laneSplit : 1;
+    const int chunk = a.chunkOrder ? CTAB(int32_t, a.chunkOrder)[blockIdx.x] : (int)blockIdx.x;
+    // S > 1: the rays of a tile are split over the S consecutive wavefronts of a group (sub = 0 .. S - 1); the launch's value,
+    // or the chunk's own (the short chunks of a long launch's tail)
+    const int Sraw = a.chunkSplit ? CTAB(int32_t, a.chunkSplit)[chunk] : a.laneSplit;
+    const int S = Sraw > 1 ? Sraw : 1;
     // (S is 1, 2 or 4: shifts, and the results pinned in SGPRs -- an integer division is done in the vector unit and would
     // leave every pointer derived from it in VGPRs)
     const int sh = S == 4 ? 2 : S == 2 ? 1 : 0;
@@ -1693,7 +1696,6 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
         for (int idx = t; idx < nDep; idx += blockDim.x)
             sDep[idx] = src[idx];
     }
-    const int chunk = a.chunkOrder ? CTAB(int32_t, a.chunkOrder)[blockIdx.x] : (int)blockIdx.x;
     const int t0 = CTAB(int32_t, a.chunkTile)[chunk], t1 = CTAB(int32_t, a.chunkTile)[chunk + 1];
     if (RATES)
     {
