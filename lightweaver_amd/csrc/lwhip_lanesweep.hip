@@ -67,6 +67,15 @@ template <int N> DEVINL void ls_lds(const char* base, unsigned voff, unsigned so
 #ifdef LS_DBG_NO_ATOMIC
 #define lds_add(p, v) ((void)(p), (void)(v))
 #endif
+#ifdef LS_DBG_NO_ATOMIC2 /* the sums are formed, only the LDS instruction is left out (wrong results) */
+#define lds_add(p, v)                                                                                                                      \
+    do                                                                                                                                     \
+    {                                                                                                                                      \
+        double lsv_ = (v);                                                                                                                 \
+        const double* lsp_ = (p);                                                                                                          \
+        asm volatile("" ::"v"(lsv_), "v"(lsp_));                                                                                           \
+    } while (0)
+#endif
 // N consecutive doubles at base (uniform) + soff (uniform) + voff (per lane) bytes of a global array: a 64-bit scalar base and
 // a 32-bit lane offset per load, no buffer descriptor (four SGPRs each, and the kernel is short of them).  The pools these
 // loads touch are padded: a ray's last block reads up to 24 bytes past its row.
