@@ -183,6 +183,9 @@ enum { LS_MAX_WAVES = 8, LS_MAX_R = 16 };
 #endif
 #define LS_KEEP(v) asm volatile("" : "+v"(v)) /* the value is computed here, on every lane (keeps selects branch-free) */
 #define LS_KEEPI(v) asm volatile("" : "+v"(v))
+#define LS_KEEPS(v) asm volatile("" : "+s"(v)) /* a uniform value re-issued here, in an SGPR: what is derived from it (flag tests) is formed
+                                                  at its use -- hoisted in front of the ray loop the tests become 64-bit masks, two dozen SGPRs
+                                                  that are spilled to VGPR lanes and read back (v_readlane) in every phase */
 #define LS_PHASE() __builtin_amdgcn_sched_barrier(0) /* the scheduler does not move code across phase boundaries */
 
 // Phase timers of a diagnostic build (-DLS_TIMING): shader clocks per phase, summed over the rays of a tile, written to
@@ -431,7 +434,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         // interpolated to the ray's rest wavelength between two rows of the line (Transition::uv, LwTransition.hpp:116-127)
         auto load_rho = [&](const int s, auto nTag, const unsigned H, const unsigned vRho, double* rho) {
             constexpr int N = decltype(nTag)::value;
-            if (!(lfl[s] & 2))
+            int fl = lfl[s];
+            LS_KEEPS(fl);
+            if (!(fl & 2))
             {
 #pragma unroll
                 for (int p = 0; p < N; ++p)
@@ -881,6 +886,42 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 LS_KEEPI(vRow);
                 LS_KEEPI(vPhi);
                 LS_KEEPI(vRho);
+                int zmL[NLc], flL[NLc], msL[NLc], zmM[NMc];
+#pragma unroll
+                for (int s = 0; s < NLc; ++s)
+                {
+                    zmL[s] = lzm[s];
+                    flL[s] = lfl[s];
+                    msL[s] = lms[s];
+                    LS_KEEPS(zmL[s]);
+                    LS_KEEPS(flL[s]);
+                    LS_KEEPS(msL[s]);
+                }
+#pragma unroll
+                for (int m = 0; m < NMc; ++m)
+                {
+                    zmM[m] = mzm[m];
+                    LS_KEEPS(zmM[m]);
+                }
+                int ccLL[NLc][NLc], ccML[NMc][NLc]; // the coupling codes, likewise
+#pragma unroll
+                for (int l = 0; l < NLc; ++l)
+                {
+#pragma unroll
+                    for (int s = 0; s < NLc; ++s)
+                    {
+                        ccLL[s][l] = ccL[s][l];
+                        if (NL > 1)
+                            LS_KEEPS(ccLL[s][l]);
+                    }
+#pragma unroll
+                    for (int m = 0; m < NMc; ++m)
+                    {
+                        ccML[m][l] = ccM[m][l];
+                        if (NM > 0 && NL > 0)
+                            LS_KEEPS(ccML[m][l]);
+                    }
+                }
                 double v1[NLc][HP], v2[NLc][HP], xl[NLc][HP], el[NLc][HP], uj[NLc][HP];
 #pragma unroll
                 for (int s = 0; s < NLc; ++s)
@@ -949,10 +990,10 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     if (s < NL)
                     {
                         double lr[5][HP], wphi[HP];
-                        load_rows(lrow[s], lzm[s], lr);
+                        load_rows(lrow[s], zmL[s], lr);
                         ls_lds<HP>(sDep, vK, lwO[s], wphi);
                         const double lcw = lcw1[s] * hw;
-                        const double lcwOp = (lfl[s] & 1) ? lcw : 0.0; // detailed atoms: rates only
+                        const double lcwOp = (flL[s] & 1) ? lcw : 0.0; // detailed atoms: rates only
 #pragma unroll
                         for (int p = 0; p < HP; ++p)
                         {
@@ -964,7 +1005,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                             double etaA = lr[0][p] + el[s][p], chi_i = lr[1][p] + xl[s][p], chi_j = lr[2][p] - xl[s][p];
                             double U_i = lr[3][p], U_j = lr[4][p] + uj[s][p];
                             if (NL > 1)
-                                couple(ccL[s], p, etaA, chi_i, chi_j, U_i, U_j);
+                                couple(ccLL[s], p, etaA, chi_i, chi_j, U_i, U_j);
                             const double Ieff = Iv[i] - PsiS[i] * etaA; // compute_full_Ieff
                             const double wop = lcwOp * wphi[p];
                             const double g0 = ((uji + v2[s][p] * Ieff) - (PsiS[i] * chi_i * U_j)) * wop;
@@ -987,9 +1028,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                                 lds_add(dst + 3 * D * LR, g3);
                             }
                             // Meta of the line's atom
-                            if (lms[s] >= 0)
+                            if (msL[s] >= 0)
                             {
-                                if (NL < 2 || lms[s] == 0)
+                                if (NL < 2 || msL[s] == 0)
                                     Me[0][H + p] += wPsi[i] * el[s][p];
                                 else
                                     Me[1][H + p] += wPsi[i] * el[s][p];
@@ -1003,7 +1044,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     if (m < NM) // mixed continua (always of active atoms)
                     {
                         double mr[5][HP], mvji[HP];
-                        load_rows(mrow[m], mzm[m], mr);
+                        load_rows(mrow[m], zmM[m], mr);
                         ls_gld<HP>(rRows, vRow, maux[m], mvji);
                         const double wlamu = mcw1[m] * hw;
 #pragma unroll
@@ -1013,7 +1054,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                             const double w1 = mb0[m], w2 = mvji[p], uji = mb2[m] * w2;
                             double etaA = mr[0][p], chi_i = mr[1][p], chi_j = mr[2][p], U_i = mr[3][p], U_j = mr[4][p];
                             if (NL > 0)
-                                couple(ccM[m], p, etaA, chi_i, chi_j, U_i, U_j);
+                                couple(ccML[m], p, etaA, chi_i, chi_j, U_i, U_j);
                             const double Ieff = Iv[i] - PsiS[i] * etaA;
                             if (act)
                             {
