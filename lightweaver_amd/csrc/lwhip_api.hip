@@ -1310,8 +1310,12 @@ int build_tables(lwhip_context* c)
             const int slotsWg = 2 * numCU;
             const int nch0 = (int)sw.chunkTile.size() - 1;
             const int tailS = env_int("LWHIP_LANE_TAIL", 2);
-            if (c->laneSweep && c->batchHint <= 1 && !c->deterministic && W == 4 && c->laneSplit == 1 && laneFixed == W && nch0 > slotsWg
-                && (tailS == 2 || tailS == 4))
+            // (and in a launch of ONE partial round -- more than half a round of whole tiles, so that not every tile can be
+            // split -- the heaviest chunks are the ones cut, as many as still fit the round: the launch lasts as long as its
+            // longest workgroup)
+            const bool oneRound = nch0 <= slotsWg && env_int("LWHIP_LANE_HEAVY", 1) != 0;
+            if (c->laneSweep && c->batchHint <= 1 && !c->deterministic && W == 4 && c->laneSplit == 1 && laneFixed == W
+                && (nch0 > slotsWg || (oneRound && nch0 > slotsWg / 2)) && (tailS == 2 || tailS == 4))
             {
                 auto tcost = [&](int i) { return 1.0 + 0.5 * tiles[i].nLine + 0.3 * tiles[i].nMixed + (tiles[i].nLine == 0 ? -0.25 : 0.0); };
                 std::vector<double> cost(nch0, 0.0);
@@ -1322,11 +1326,22 @@ int build_tables(lwhip_context* c)
                 for (int ch = 0; ch < nch0; ++ch)
                     ord[ch] = ch;
                 std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
-                // the first `keep` chunks of the dispatch order stay whole
-                const int keep = std::min(nch0, std::max(0, env_int("LWHIP_LANE_KEEP", slotsWg)));
                 std::vector<char> cut(nch0, 0);
-                for (int q = keep; q < nch0; ++q)
-                    cut[ord[q]] = 1;
+                if (nch0 > slotsWg)
+                {
+                    // the first `keep` chunks of the dispatch order stay whole
+                    const int keep = std::min(nch0, std::max(0, env_int("LWHIP_LANE_KEEP", slotsWg)));
+                    for (int q = keep; q < nch0; ++q)
+                        cut[ord[q]] = 1;
+                }
+                else
+                {
+                    // one partial round: a cut chunk becomes tailS / 1 workgroups; the heaviest first, while they fit
+                    const int extra = tailS - 1;
+                    const int k = std::min(nch0, std::max(0, (slotsWg - nch0) / extra));
+                    for (int q = 0; q < k; ++q)
+                        cut[ord[q]] = 1;
+                }
                 const int piece = W / tailS; // tiles per piece
                 std::vector<int32_t> bounds, split, firstNew(nch0, 0), nNew(nch0, 0);
                 bounds.push_back(0);

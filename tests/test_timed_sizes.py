@@ -52,6 +52,25 @@ def test_throughput_grid_iteration_and_stat_equil_vs_oracle(gpu):
                 assert rel_err(a.n, b.n) <= 1e-8
 
 
+@pytest.mark.parametrize('nla,sweep', [(10240, 'march'), (3840, 'lanes'), (5120, 'lanes'), (7680, 'lanes')])
+def test_other_sizes_and_sweeps_vs_oracle(gpu, monkeypatch, nla, sweep):
+    """The work-distribution regimes of the lane sweep the other tests do not reach -- one partial round with the heaviest
+    chunks' rays split (3 840, 5 120 wavelengths), more than one round with a split tail at another size (7 680) -- and the
+    ray-column march at the bench size (the fallback kernel, LWHIP_SWEEP=march): one iteration against the oracle, 1e-9."""
+    from lightweaver_amd.context import Context
+    monkeypatch.setenv('LWHIP_SWEEP', sweep)
+    prob = models.throughput_grid(NlambdaTarget=nla, Nrays=5)
+    q = prob.copy()
+    oc = OracleContext(q)
+    with Context(prob) as ctx:
+        assert ctx.sweep_kind() == sweep
+        up = ctx.formal_sol_gamma_matrices()
+    q.gamma_prefill()
+    dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+    assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+    assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-9)
+
+
 @pytest.mark.parametrize('sweep', ['march', 'lanes'])
 def test_prd_at_timed_size_vs_oracle(gpu, monkeypatch, sweep):
     """BASELINE configs[2] as bench.py's aux entry C3 times it: the 10 240-wavelength grid with Ca II H & K as PRD lines
