@@ -59,7 +59,13 @@ template <typename T> struct DevBuf
         n = count;
         if (count == 0)
             return hipSuccess;
-        return hipMalloc((void**)&p, count * sizeof(T));
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        // diagnosis (LWHIP_POISON=1): fresh allocations hold NaN / -1, so that a read of memory nothing initialised shows up
+        // in the results instead of depending on what the previous owner of the pages left there
+        static const bool poison = std::getenv("LWHIP_POISON") != nullptr;
+        if (e == hipSuccess && poison)
+            e = hipMemset(p, 0xFF, count * sizeof(T));
+        return e;
     }
     // a window of somebody else's allocation (the depth arena of the lane sweep)
     void view(T* ptr, size_t count)
