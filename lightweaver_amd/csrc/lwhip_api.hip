@@ -1059,8 +1059,17 @@ int build_tables(lwhip_context* c)
             auto five_rows = [&](const DevSlot& sl) -> int16_t {
                 const int16_t r0 = (int16_t)nRowsT;
                 // row ids as the row programs number them (the pre-pass forms the level sums directly)
+                // (lane sweep: a row that no continuum of the wavelength feeds is never read -- its zero-mask bit -- and stays
+                // the zero the allocation was cleared to: the pre-pass does not write it)
+                const int16_t zmS = c->laneSweep ? zero_mask(sl) : (int16_t)0;
+                int qi = 0;
                 for (int id : { rowEtaA + sl.atom, rowLevChi + sl.gi, rowLevChi + sl.gj, rowLevU + sl.gi, rowLevU + sl.gj })
                 {
+                    if (zmS & (1 << qi++))
+                    {
+                        ++nRowsT;
+                        continue;
+                    }
                     if (h.nMixed + h.nPure > 0)
                         tcopies.push_back(DevTileCopy{ 0, (int16_t)id, (int16_t)nRowsT, 0 });
                     else
