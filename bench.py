@@ -63,6 +63,9 @@ def parse():
     return ap.parse_args()
 
 
+PREWARM = 60  # untimed steps before the warm-up steps (clock settle; see main)
+
+
 def profiled_traffic(sweep_kind='march'):
     """HBM bytes per sweep launch from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_summary.json, produced by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate
@@ -366,10 +369,6 @@ def main():
     def step():
         return it.formal_sol_gamma_matrices(deviceResident=True)
 
-    for _ in range(args.warmup):
-        step()
-    ctx.profile_enable(int(os.environ.get('LWHIP_BENCH_PROF', '4')))   # HIP events around every 4th sweep launch
-    it.allreduce_s = 0.0
     # The interpreter's cyclic garbage collector is not part of the workload: with torch imported a full
     # collection takes ~40 ms (80 steps' worth) and, being triggered by allocation counts, lands at the same
     # spot of every run -- measured inside the timed region of a 100-step run (tools/trace_bench.sh: a 38 ms gap
@@ -377,6 +376,17 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # (the collection above takes tens of milliseconds: it comes BEFORE the warm-up steps, so that no idle gap -- in which the
+    # device drops its clocks -- separates the warm-up from the timed steps)
+    # Clock settle: a fresh process reaches the device's sustained clocks only after ~10 ms of load -- with W = 5 a 20-step
+    # run measured the sweep kernel 4 % slower than a 100-step one (0.179 against 0.172 ms on the same box).  PREWARM
+    # untimed steps (13 ms) before the W warm-up steps, reported as "prewarm_steps"; the timed region is exactly K steps.
+    for _ in range(PREWARM):
+        step()
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(int(os.environ.get('LWHIP_BENCH_PROF', '4')))   # HIP events around every 4th sweep launch
+    it.allreduce_s = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -409,10 +419,10 @@ def main():
                       worldSize=world, worldRank=rank)
         ctx.compute_profiles(deviceResident=True)
         itW = ShardedIteration(ctx, world, rank)
-        for _ in range(args.warmup):
-            itW.formal_sol_gamma_matrices(deviceResident=True)
         gc.collect()
         gc.disable()
+        for _ in range(PREWARM + args.warmup):
+            itW.formal_sol_gamma_matrices(deviceResident=True)
         dist.barrier()
         torch.cuda.synchronize()
         tw = time.perf_counter()
@@ -451,6 +461,7 @@ def main():
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
+            'prewarm_steps': PREWARM,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True,
             'scaling': args.scaling,
