@@ -27,6 +27,7 @@ namespace lwhip
 // sums the preconditioned rates need, written once per (wavelength, depth) for all rays to read.
 __global__ void __launch_bounds__(128) cont_kernel(const ContArgs* __restrict__ ap, int contOff, double* rowsBase)
 {
+    dbg_poison_lds();
     extern __shared__ double lds[]; // [2 * maxC][blockDim.x]: thread-private columns
     const int Ns = ARGS.Ns;
     const int T = blockDim.x;
@@ -111,6 +112,7 @@ namespace
 template <int MAXL>
 __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
 {
+    dbg_poison_lds();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.Ns)
         return;
@@ -203,6 +205,7 @@ __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
 template <int MAXL>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) rates2d_kernel(const Batch2dArgs a)
 {
+    dbg_poison_lds();
     constexpr int MAXM = 4; // mixed continua integrated ray by ray at one wavelength
     constexpr int MAXP = 8; // pure continua with register accumulators; any beyond go straight to memory
     extern __shared__ double sRowAll[]; // [maxRowsLa][128]: every continuum row of the wavelength at the thread's point
@@ -525,6 +528,7 @@ namespace
 {
 __global__ void __launch_bounds__(256) iout2d_kernel(const Batch2dArgs a)
 {
+    dbg_poison_lds();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool planes = a.zUp || a.zDown;
     if (k >= a.Ns || (!a.storeDepth && !planes && k >= a.Nx))
@@ -554,6 +558,7 @@ hipError_t launch_iout2d(const Batch2dArgs& a, hipStream_t stream)
 // red[0] += red[1] + ... + red[G-1] (fixed order)
 __global__ void sum_groups_kernel(double* red, size_t n, size_t stride, int G)
 {
+    dbg_poison_lds();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     {
         double s = red[i];

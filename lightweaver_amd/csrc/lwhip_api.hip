@@ -62,10 +62,14 @@ template <typename T> struct DevBuf
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         // diagnosis (LWHIP_POISON=1): fresh allocations hold NaN / -1, so that a read of memory nothing initialised shows up
         // in the results instead of depending on what the previous owner of the pages left there
-        static const bool poison = std::getenv("LWHIP_POISON") != nullptr;
-        if (e == hipSuccess && poison)
+        if (e == hipSuccess && poison_on())
             e = hipMemset(p, 0xFF, count * sizeof(T));
         return e;
+    }
+    static bool poison_on()
+    {
+        static const bool poison = std::getenv("LWHIP_POISON") != nullptr;
+        return poison;
     }
     // a window of somebody else's allocation (the depth arena of the lane sweep)
     void view(T* ptr, size_t count)
@@ -85,7 +89,13 @@ template <typename T> struct DevBuf
     void release()
     {
         if (p && owned)
+        {
+            // (LWHIP_POISON=1: and a buffer is poisoned again when it is given back, with another pattern -- a stale device
+            // pointer into it, or memory the allocator hands out behind this wrapper's back, then reads -nan / 0xFEFEFEFE)
+            if (poison_on())
+                (void)hipMemset(p, 0xFE, n * sizeof(T));
             (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
         owned = true;
@@ -236,6 +246,8 @@ struct lwhip_context
     ContArgs hargs{};
     bool atomicParts = false;     // the pending iteration's parts were accumulated by atomics
     bool red8Clean = false;       // red8 holds zeros (only the atomic path leaves it so)
+    int* zeroCheck = nullptr;     // LWHIP_CHECK_ZERO=1 (diagnosis): host-mapped count of non-zero words found in red8 at sweep entry
+    int* zeroCheckDev = nullptr;
     DevBuf<int32_t> atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
     DevBuf<int64_t> atomGammaOff;
     DevBuf<double> red, red8, dJ;
@@ -278,6 +290,8 @@ struct lwhip_context
             (void)hipHostFree(changeHost);
         if (prdPinned)
             (void)hipHostFree(prdPinned);
+        if (zeroCheck)
+            (void)hipHostFree(zeroCheck);
     }
 };
 
@@ -2091,6 +2105,13 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
         if (ez != hipSuccess)
             return ez;
     }
+    if (rates && c->zeroCheckDev)
+    {
+        // diagnosis: the sweep's workgroups ADD into the stage-1 buffer -- it has to hold zeros now
+        hipError_t ec = launch_check_zero(c->red8.p, c->red8.n, c->zeroCheckDev, c->stream);
+        if (ec != hipSuccess)
+            return ec;
+    }
     hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
     if (e != hipSuccess)
         return e;
@@ -2117,6 +2138,19 @@ int flush_prefill(lwhip_context* c)
     if (c->prefillPending && c->gammaTot > 0)
         HIP_TRY(launch_prefill(c->Gamma.p, c->Cmat.p, c->prefillCrsw, (size_t)c->gammaTot, c->stream));
     c->prefillPending = false;
+    return LWHIP_OK;
+}
+
+// diagnosis (LWHIP_CHECK_ZERO=1): called where the host has just waited for the device
+int verify_zero_check(lwhip_context* c)
+{
+    if (c->zeroCheck && *(volatile int*)c->zeroCheck != 0)
+    {
+        const int n = *(volatile int*)c->zeroCheck;
+        *(volatile int*)c->zeroCheck = 0;
+        return fail(LWHIP_ERR_DEVICE, "LWHIP_CHECK_ZERO: the stage-1 reduce buffer held " + std::to_string(n)
+                                          + " non-zero words when a sweep started adding to it");
+    }
     return LWHIP_OK;
 }
 
@@ -2226,6 +2260,13 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
         if (hipStreamCreate(&c->ownStream) != hipSuccess)
             return bail(fail(LWHIP_ERR_DEVICE, "hipStreamCreate failed"));
         c->stream = c->ownStream;
+    }
+    if (env_int("LWHIP_CHECK_ZERO", 0) == 1)
+    {
+        if (hipHostMalloc((void**)&c->zeroCheck, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+            || hipHostGetDevicePointer((void**)&c->zeroCheckDev, c->zeroCheck, 0) != hipSuccess)
+            return bail(fail(LWHIP_ERR_DEVICE, "hipHostMalloc failed"));
+        *c->zeroCheck = 0;
     }
     const bool timing = std::getenv("LWHIP_CREATE_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -2594,6 +2635,11 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int stz = verify_zero_check(c);
+        if (stz != LWHIP_OK)
+            return stz;
+    }
     // unpack the staged pools into the caller's arrays
     for (int ia = 0; ia < c->Natom; ++ia)
     {
@@ -4225,7 +4271,7 @@ int lwhip_synchronize(lwhip_context* c)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return LWHIP_OK;
+    return verify_zero_check(c);
 }
 
 int lwhip_set_stream(lwhip_context* c, void* stream)

@@ -154,6 +154,24 @@ DEVINL void lds_barrier()
 // Address-space-qualified views of the pointers that live in the (device-memory) argument block:
 // without them the loads compile to flat_load, which counts on lgkmcnt and so stalls every LDS
 // barrier behind the HBM latency of the prefetches; tables read uniformly become scalar loads.
+// Diagnostic build (-DLWHIP_DBG_POISON_LDS, tools/build_variant.py): every workgroup starts with its WHOLE LDS allocation --
+// static and dynamic -- holding a NaN pattern, so that a read of an LDS entry nothing wrote shows up in the results instead of
+// returning what the previous workgroup on the CU left there.  The allocation's size comes from the dispatch packet
+// (hsa_kernel_dispatch_packet_t::group_segment_size, byte 28).  The shipped build compiles this to nothing.
+DEVINL void dbg_poison_lds()
+{
+#ifdef LWHIP_DBG_POISON_LDS
+    const unsigned bytes = ((const unsigned*)__builtin_amdgcn_dispatch_ptr())[7];
+    const unsigned nT = blockDim.x * blockDim.y * blockDim.z;
+    const unsigned t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    const unsigned long long pat = 0x7ff8dead0000beefull;
+    for (unsigned o = t * 8u; o + 8u <= bytes; o += nT * 8u)
+        asm volatile("ds_write_b64 %0, %1" ::"v"(o), "v"(pat) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
+}
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define CONST_AS __attribute__((address_space(4)))
 #define GCD(p) ((const GLOBAL_AS double*)(p))

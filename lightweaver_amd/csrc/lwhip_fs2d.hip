@@ -217,6 +217,7 @@ template <bool LC_INLINE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LC_INLINE ? 6 : 8, LC_INLINE ? 6 : 8)))
 fs2d_coef_kernel(const Fs2dArgs a)
 {
+    dbg_poison_lds();
     const int Nx = a.Nx, Nz = a.Nz;
     const int Ns = Nx * Nz;
     // workgroup order (blockIdx.x fastest): wavelength, then ray, then the 256-point tile -- neighbours in launch order
@@ -437,6 +438,7 @@ fs2d_coef_kernel(const Fs2dArgs a)
 // the 256 x 82 grid took ~5 times as long as the rest); here they are packed 64 to a wavefront.
 __global__ void __launch_bounds__(64) fs2d_longchar_kernel(const Fs2dArgs a)
 {
+    dbg_poison_lds();
     const int lc = blockIdx.x * blockDim.x + threadIdx.x;
     if (lc >= a.NlongChar)
         return;
@@ -464,6 +466,7 @@ __global__ void __launch_bounds__(64) fs2d_longchar_kernel(const Fs2dArgs a)
 template <int D, bool FULL>
 __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
 {
+    dbg_poison_lds();
     extern __shared__ double prevI[]; // [Nx + 1], by x
     const int Nx = a.Nx, Nz = a.Nz;
     const size_t Ns = (size_t)Nx * Nz;

@@ -595,4 +595,6 @@ hipError_t launch_time_dep(int Nlevel, int Ns, int k0, int k1, double* n, const 
 hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list = nullptr, int nBatch = 0);
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream);
+// diagnosis (LWHIP_CHECK_ZERO=1): counts the non-zero words of p[0 .. n) into the host-mapped *counter
+hipError_t launch_check_zero(const double* p, size_t n, int* counter, hipStream_t stream);
 }

@@ -105,6 +105,7 @@ template <class A> DEVINL void reduce_stage2_kernel_body(const A& a)
 template <bool BATCH>
 __global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a0, const ReduceArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     if constexpr (BATCH)
         reduce_stage2_kernel_body(CTAB(ReduceArgs, list)[blockIdx.z]);
     else
@@ -244,6 +245,7 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
 template <bool BATCH>
 __global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a0, const ApplyArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     if constexpr (BATCH)
         apply_kernel_body(CTAB(ApplyArgs, list)[blockIdx.z]);
     else
@@ -261,9 +263,32 @@ hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs*
     return hipGetLastError();
 }
 
+// ---- diagnosis (LWHIP_CHECK_ZERO=1): the invariant "the stage-1 buffer holds zeros when a sweep starts adding to it" checked
+// on the device: every non-zero (or NaN) word counts into a host-mapped counter that the library reads at its next
+// synchronising call and reports as LWHIP_ERR_DEVICE ------------------------------------------------------------------
+__global__ void check_zero_kernel(const double* __restrict__ p, size_t n, int* __restrict__ counter)
+{
+    dbg_poison_lds();
+    int bad = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        bad += (__double_as_longlong(p[i]) & 0x7fffffffffffffffLL) != 0 ? 1 : 0;
+    if (bad)
+        atomicAdd_system(counter, bad);
+}
+
+hipError_t launch_check_zero(const double* p, size_t n, int* counter, hipStream_t stream)
+{
+    if (!n)
+        return hipSuccess;
+    const int blocks = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(check_zero_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, p, n, counter);
+    return hipGetLastError();
+}
+
 // ---- Gamma <- crsw * C (LwMiddleLayer.pyx:3198-3203) ------------------------------------------------------------
 __global__ void prefill_kernel(double* G, const double* C, double crsw, size_t n)
 {
+    dbg_poison_lds();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         G[i] = crsw * C[i];
 }

@@ -1709,6 +1709,7 @@ template <int SOLVER, int D, int MODE, bool BATCH>
 __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(LS_WAVES_PER_EU))) lanesweep_kernel(const TileArgs* __restrict__ ap0,
                                                                        const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
+    dbg_poison_lds();
     constexpr bool RATES = (MODE & 1) != 0;
     extern __shared__ double lds[];
     const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
@@ -1737,17 +1738,6 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     double* sX = sExp + LS_EXP_TAB + (size_t)(grp * S) * (3 * 64 * D); // the group's exchange area: over its row blocks, after the rays
     double* sPP = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)wave * (LWHIP_POST_MAXC * a.L * 3); // per wave [continuum][ray][3]
     double* sDep = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)nWaves * (LWHIP_POST_MAXC * a.L * 3); // [depBytes / 8]
-#ifdef LS_DBG_POISON_LDS
-    {
-        // diagnosis: the workgroup's whole LDS allocation starts as NaN (LDS is not cleared between workgroups: a read of an
-        // entry nothing wrote would otherwise see what the previous workgroup on this CU left there)
-        const size_t nAll = (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R * 5 + LS_EXP_TAB + (size_t)nWaves * 3 * 64 * D
-                            + (size_t)nWaves * LWHIP_POST_MAXC * a.L * 3 + (a.depBytes >> 3);
-        for (size_t idx = t; idx < nAll; idx += blockDim.x)
-            lds[idx] = __longlong_as_double(0x7ff8dead0000beefLL);
-        __syncthreads();
-    }
-#endif
     ls_exp_table_init(sExp, t);
     {
         // the depth-only pools (populations, w_phi, nStar ratios, geometry) are the same for every tile: one LDS copy per
@@ -1818,6 +1808,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
 __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restrict__ slab, const int32_t* __restrict__ off,
                                                          const int32_t* __restrict__ ent, double* __restrict__ red8, int Ns, int maxCT)
 {
+    dbg_poison_lds();
     const int tr = blockIdx.y;
     const int n4 = 4 * Ns;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -469,6 +469,7 @@ template <class A> DEVINL void stat_eq_body(const A& a)
 // (blocks of at most 64 threads -- solve_block_threads --: the register form of the 6 x 6 solve may use the whole file)
 template <bool BATCH> __global__ void __launch_bounds__(64) stat_eq_kernel(const StatEqArgs a0, const StatEqArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     if constexpr (BATCH)
         stat_eq_body(CTAB(StatEqArgs, list)[blockIdx.z]);
     else
@@ -525,6 +526,7 @@ DEVINL bool time_dep_point_reg(double* n, const double* nOld, const double* Gamm
 __global__ void __launch_bounds__(64) time_dep_kernel(int N, int Ns, int k0, int k1, double* n, const double* nOld, const double* Gamma,
                                 double dt, int* status)
 {
+    dbg_poison_lds();
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < k0 || k >= k1)
@@ -579,6 +581,7 @@ hipError_t launch_time_dep(int Nlevel, int Ns, int k0, int k1, double* n, const 
 // ---- nr_post_update_impl with F / Ftd: Source/UpdatePopulations.cpp:230-394 --------------------------------
 __global__ void nr_post_kernel(const NrArgs a)
 {
+    dbg_poison_lds();
     extern __shared__ double lds[];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int Ns = a.Ns;
@@ -716,6 +719,7 @@ hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream)
 // ill conditioned, and a few microseconds every Nperiod iterations buy bit-identical coefficients.
 __global__ void __launch_bounds__(256) ng_kernel(const NgArgs a)
 {
+    dbg_poison_lds();
     extern __shared__ double lds[];
     const NgAtom at = a.atoms[blockIdx.x];
     const int L = at.len, No = a.Norder;

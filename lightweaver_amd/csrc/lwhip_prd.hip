@@ -78,6 +78,7 @@ __device__ double p_GII(double aDamp, double qEmit, double qAbs)
 // J(Nblue : Nred, :) -> Jt[k][la]: the scattering integral reads J along wavelength at fixed depth
 __global__ void prd_transpose_kernel(const PrdLineArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.z);
     const double* J = a.J;
     double* Jt = a.Jt;
@@ -103,6 +104,7 @@ __global__ void prd_transpose_kernel(const PrdLineArgs* __restrict__ list)
 
 __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     extern __shared__ double sm[];
     const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.z);
     if (a.laHi <= a.laLo || (int)blockIdx.y >= a.slices)
@@ -334,6 +336,7 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __r
 // per line: max over depth of the per-depth maxima (first flattened index on ties)
 __global__ void prd_change_kernel(const PrdLineArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.x);
     const double* changeVal = a.changeVal;
     const int* changeIdx = a.changeIdx;

@@ -177,6 +177,7 @@ template <bool BATCH>
 __global__ void __launch_bounds__(RM_PRE_T) tile_pre_kernel(const TileArgs* __restrict__ ap0, const TileArgs* const* __restrict__ apList,
                                                             const int32_t* __restrict__ tileList)
 {
+    dbg_poison_lds();
     extern __shared__ double lds[];
     const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.z] : ap0;
     if (blockIdx.x == 0 && blockIdx.y == 0)
@@ -1210,6 +1211,7 @@ __global__ void __launch_bounds__(RM_POST_T) tile_post_kernel(const TileArgs* __
                                                               const TileDyn dyn, const int32_t* __restrict__ chunkTile,
                                                               const int32_t* __restrict__ tileList)
 {
+    dbg_poison_lds();
     extern __shared__ double lds[];
     const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
     unsigned long long* sDj = (unsigned long long*)lds; // [16]
@@ -1241,6 +1243,7 @@ template <int SOLVER, int CAP, bool RATES, bool BATCH, bool FUSE>
 __global__ void __launch_bounds__(RM_MAX_WAVES * 64) RM_OCC raymarch_kernel(const TileArgs* __restrict__ ap0,
                                                                       const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
+    dbg_poison_lds();
     extern __shared__ double lds[];
     const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
     const CONST_AS TileArgs& a = *(const CONST_AS TileArgs*)ap;
@@ -1335,6 +1338,7 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) RM_OCC raymarch_kernel(cons
 // (blockIdx.z: the column of a batch, its arguments read from the list)
 __global__ void __launch_bounds__(256) retile_kernel(const RetileArgs a0, const RetileArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     const RetileArgs a = list ? ld_c(CTAB(RetileArgs, list) + blockIdx.z) : a0;
     if ((int)blockIdx.x >= a.nTiles)
         return;

@@ -207,6 +207,7 @@ __device__ double d_voigt_H(double av, double v)
 // phi[l, mu, dir, k] for the shard's rows of one line
 __global__ void voigt_phi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* __restrict__ list)
 {
+    dbg_poison_lds();
     const VoigtLineArgs a = LINE_ARGS(blockIdx.y);
     const double sqrtPi = 1.772453850905516027298167483341145182798;
     const size_t n = (size_t)a.nlt * a.Nrays * 2 * a.Ns;
@@ -235,6 +236,7 @@ __global__ void voigt_phi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* __
 // back instead of being evaluated a second time (the same bits: same function, same arguments).
 __global__ void voigt_wphi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* __restrict__ list, int KT)
 {
+    dbg_poison_lds();
     extern __shared__ double sPart[];
     __shared__ int sLast;
     const VoigtLineArgs a = LINE_ARGS(blockIdx.z);

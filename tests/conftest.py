@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (gfx950) device')
 
 
+def pytest_addoption(parser):
+    parser.addoption('--lw-shuffle', type=int, default=None, metavar='SEED',
+                     help='run the collected tests in a seeded random order (tools/parity_stress.sh: order-dependent reads of '
+                          'uninitialised device memory show up as failures that follow the seed)')
+
+
+def pytest_collection_modifyitems(config, items):
+    seed = config.getoption('--lw-shuffle')
+    if seed is not None:
+        import random
+        random.Random(seed).shuffle(items)
+
+
 @pytest.fixture(scope='session', autouse=True)
 def _build_checkers():
     """TEST INFRASTRUCTURE: make sure the C oracle (and, where the reference sources exist, the
