@@ -392,6 +392,17 @@ int lwhip_nr_post_update(lwhip_context* ctx, const lwhip_nr_args* args);
  * (lwhip_batch_stat_equil) always solve every point. */
 int lwhip_set_depth_range(lwhip_context* ctx, int spaceStart, int spaceEnd);
 
+/* Which wavelength index lwhip_formal_sol_gamma_matrices reports next to dJMax (lwhip_iter_result::dJMaxIdx):
+ *   0 (default)  the first wavelength that attains dJMax -- what the reference's threaded schemes return
+ *                (the per-thread maxima are merged with max_idx, Source/SimdFullIterationTemplates.hpp:700-715);
+ *   1            the bookkeeping of the reference's single-thread branch, bit for bit: its loop calls
+ *                `dJMax = max_idx(dJ, dJMax, maxIdx, la)` (Source/SimdFullIterationTemplates.hpp:627 with
+ *                Source/Constants.hpp:114-125), which records `la` whenever the wavelength's dJ is BELOW the running
+ *                maximum -- i.e. the last wavelength whose dJ is smaller than the largest one before it (0 if there is
+ *                none).  The plugin selects it when the Context runs with Nthreads == 1, so a drop-in run reports the
+ *                index the scalar scheme reports.  Unsharded 1D contexts; others keep mode 0. */
+int lwhip_set_djmax_index_mode(lwhip_context* ctx, int mode);
+
 /* ---- 2D short characteristics (tier 2): the formal solver primitive -------------------
  * piecewise_besser_2d with interp_linear_2d (Source/FormalScalar2d.cpp:740-1184, 209-255) on an x-periodic
  * Nz x Nx grid, given the intersection table the core builds (build_intersection_list, :1188-1327;

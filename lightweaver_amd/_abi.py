@@ -185,6 +185,7 @@ SYMBOLS = [
     ('lwhip_time_dep_update', C.c_int, [ctx_p, C.c_int, f64p, C.c_double]),
     ('lwhip_nr_post_update', C.c_int, [ctx_p, C.POINTER(lwhip_nr_args)]),
     ('lwhip_set_depth_range', C.c_int, [ctx_p, C.c_int, C.c_int]),
+    ('lwhip_set_djmax_index_mode', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_synchronize', C.c_int, [ctx_p]),
     ('lwhip_set_stream', C.c_int, [ctx_p, C.c_void_p]),
     ('lwhip_set_zplane_outputs', C.c_int, [ctx_p, f64p, f64p]),

@@ -153,6 +153,12 @@ class Context:
         population updates solve; the others keep their values.  (-1, -1): the whole atmosphere."""
         _check(self.lib, self.lib.lwhip_set_depth_range(self._h, int(spaceStart), int(spaceEnd)), 'lwhip_set_depth_range')
 
+    def set_djmax_index_mode(self, mode=0):
+        """0: dJMaxIdx = the first wavelength that attains dJMax (the reference's threaded schemes); 1: the index the
+        reference's single-thread loop records (Source/SimdFullIterationTemplates.hpp:627: the last wavelength whose dJ is
+        below the running maximum)."""
+        _check(self.lib, self.lib.lwhip_set_djmax_index_mode(self._h, int(mode)), 'lwhip_set_djmax_index_mode')
+
     def synchronize(self):
         _check(self.lib, self.lib.lwhip_synchronize(self._h), 'lwhip_synchronize')
 

@@ -192,6 +192,7 @@ struct lwhip_context
     DevBuf<int32_t> b2idx;
     int groups2d = 1, maxRowsLa = 1;
     int kLo = 0, kHi = -1; // depth range of the population updates (lwhip_set_depth_range); kHi < 0: to the end
+    int djIdxMode = 0;     // lwhip_set_djmax_index_mode: 1 = the single-thread scheme's index bookkeeping
     double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration
     double* tailMappedDev = nullptr;
     double tailTicket = 0.0;      // ticket of the last launch that reports through tailMapped
@@ -1709,7 +1710,7 @@ int alloc_state(lwhip_context* c)
         }
     HIP_TRY(c->height.alloc(Ns));
     HIP_TRY(c->temperature.alloc(Ns));
-    HIP_TRY(c->muz.alloc(Nr));
+    HIP_TRY(c->muz.alloc(2 * Nr)); // [muz | 1 / muz]
     HIP_TRY(c->wmu.alloc(Nr));
     HIP_TRY(c->wavelength.alloc(Nla));
     HIP_TRY(c->bgChi.alloc(Nla * Ns));
@@ -2374,6 +2375,7 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     const lwhip_problem& p = c->prob;
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
     const size_t l0 = c->laStart;
+    std::vector<double> rmuzHost; // (lives until the synchronisation at the end)
     if (mask & LWHIP_GAMMA)
         c->prefillPending = false; // the host pre-fill being uploaded supersedes it
     if (mask & LWHIP_ATMOS)
@@ -2381,6 +2383,10 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         H2D(c->height.p, p.height, Ns);
         H2D(c->temperature.p, p.temperature, Ns);
         H2D(c->muz.p, p.muz, Nr);
+        rmuzHost.resize(Nr);
+        for (size_t m = 0; m < Nr; ++m)
+            rmuzHost[m] = 1.0 / p.muz[m]; // zmu of the 1D solvers (FormalScalar.cpp:136-666), once instead of per ray and lane
+        H2D(c->muz.p + Nr, rmuzHost.data(), Nr);
         H2D(c->wmu.p, p.wmu, Nr);
         H2D(c->wavelength.p, p.wavelength + l0, Nla);
         if (p.vlosMu)
@@ -2948,6 +2954,7 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
             a.dJ = c->dJ.p;
             a.NlaDj = c->Nla;
             a.idxOffset = c->laStart;
+            a.scalarIdx = c->djIdxMode;
             a.tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
             if (!c->tailMapped)
             {
@@ -3613,6 +3620,17 @@ int lwhip_ng_accelerate(lwhip_context* c, int32_t* accelerated, double* dPops, i
         if (dPopsMaxIdx)
             dPopsMaxIdx[q] = (int32_t)c->changeHost[2 * q + 1];
     }
+    return LWHIP_OK;
+}
+
+int lwhip_set_djmax_index_mode(lwhip_context* c, int mode)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (mode != 0 && mode != 1)
+        return fail(LWHIP_ERR_INVALID, "lwhip_set_djmax_index_mode: mode is 0 or 1");
+    // (served where the iteration's own apply launch reduces dJ: unsharded 1D contexts; elsewhere the first arg-max stays)
+    c->djIdxMode = (mode == 1 && !c->is2d && c->worldSize == 1) ? 1 : 0;
     return LWHIP_OK;
 }
 

@@ -356,6 +356,7 @@ struct ApplyArgs
     double tailTicket;             // written last (system-scope release): the host polls for it instead of waiting for the stream
     int32_t fromParts, NlaDj, idxOffset;
     int32_t zeroParts;             // the parts are accumulated by atomics: whoever reads an element zeroes it
+    int32_t scalarIdx;             // 1: dJMaxIdx as the reference's single-thread loop records it (lwhip_set_djmax_index_mode)
     int32_t gatherWorld;           // > 0 (sharded iteration, dJ == null): `tail` holds every shard's (dJMax, idx) after the
                                    // all-reduce; the extra workgroup takes their maximum and publishes it through tailHost
 };

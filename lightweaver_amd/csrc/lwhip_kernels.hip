@@ -19,7 +19,7 @@ namespace lwhip
 // address space; the single-problem instantiation keeps its kernel-argument block untouched)
 __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* tail, int world, int rank,
                             double* mirror = nullptr /* host-mapped copy of the tail: no read-back copy needed */,
-                            double ticket = 0.0 /* stored behind the mirror once it is complete */)
+                            double ticket = 0.0 /* stored behind the mirror once it is complete */, int scalarIdx = 0)
 {
     // dJMax and the index of its first occurrence (max_idx, Constants.hpp:114-125) into this
     // shard's slot of the gather tail; every other slot is zeroed (the all-reduce sums them)
@@ -50,6 +50,53 @@ __device__ void djmax_block(const double* dJ, int laEnd, int idxOffset, double* 
                 sV[threadIdx.x] = v;
                 sI[threadIdx.x] = i;
             }
+        }
+        __syncthreads();
+    }
+    if (scalarIdx)
+    {
+        // The index of the reference's single-thread loop (SimdFullIterationTemplates.hpp:620-628): `dJMax = max_idx(dJ,
+        // dJMax, maxIdx, la)` with max_idx(a, b, aIdx, bIdx) = (a < b ? (aIdx = bIdx, b) : a) records la whenever dJ(la) is
+        // BELOW the running maximum: the last wavelength whose dJ is smaller than the largest before it, or 0.  Every thread
+        // walks a contiguous segment behind the exclusive prefix maximum of the segments before it.
+        const double dJMaxAll = sV[0];
+        __syncthreads();
+        const int T = blockDim.x, seg = (laEnd + T - 1) / T;
+        const int a0 = min((int)threadIdx.x * seg, laEnd), a1 = min(a0 + seg, laEnd);
+        double segMax = 0.0; // (the loop starts from dJMax = 0.0)
+        for (int la = a0; la < a1; ++la)
+            segMax = fmax(segMax, dJ[la]);
+        sV[threadIdx.x] = segMax;
+        __syncthreads();
+        for (int s = 1; s < T; s <<= 1) // inclusive prefix maximum over the threads
+        {
+            const double o = (int)threadIdx.x >= s ? sV[threadIdx.x - s] : 0.0;
+            __syncthreads();
+            sV[threadIdx.x] = fmax(sV[threadIdx.x], o);
+            __syncthreads();
+        }
+        double run = threadIdx.x > 0 ? sV[threadIdx.x - 1] : 0.0;
+        int last = -1;
+        for (int la = a0; la < a1; ++la)
+        {
+            const double v = dJ[la];
+            if (v < run)
+                last = la;
+            else
+                run = v;
+        }
+        sI[threadIdx.x] = last;
+        __syncthreads();
+        for (int s = T / 2; s > 0; s >>= 1)
+        {
+            if ((int)threadIdx.x < s)
+                sI[threadIdx.x] = max(sI[threadIdx.x], sI[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+        {
+            sI[0] = max(sI[0], 0);
+            sV[0] = dJMaxAll;
         }
         __syncthreads();
     }
@@ -133,7 +180,7 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
     if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ or a.gatherWorld is set)
     {
         if (blockIdx.y == 0 && a.dJ)
-            djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0, a.tailHost, a.tailTicket);
+            djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0, a.tailHost, a.tailTicket, a.scalarIdx);
         else if (blockIdx.y == 0 && threadIdx.x == 0)
         {
             // sharded iteration: max over the shards' slots, first (lowest) wavelength index on ties (max_idx,

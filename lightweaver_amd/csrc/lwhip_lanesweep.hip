@@ -64,18 +64,6 @@ template <int N> DEVINL void ls_lds(const char* base, unsigned voff, unsigned so
     for (int q = 0; q < N; ++q)
         x[q] = p[q];
 }
-#ifdef LS_DBG_NO_ATOMIC
-#define lds_add(p, v) ((void)(p), (void)(v))
-#endif
-#ifdef LS_DBG_NO_ATOMIC2 /* the sums are formed, only the LDS instruction is left out (wrong results) */
-#define lds_add(p, v)                                                                                                                      \
-    do                                                                                                                                     \
-    {                                                                                                                                      \
-        double lsv_ = (v);                                                                                                                 \
-        const double* lsp_ = (p);                                                                                                          \
-        asm volatile("" ::"v"(lsv_), "v"(lsp_));                                                                                           \
-    } while (0)
-#endif
 // N consecutive doubles at base (uniform) + soff (uniform) + voff (per lane) bytes of a global array: a 64-bit scalar base and
 // a 32-bit lane offset per load, no buffer descriptor (four SGPRs each, and the kernel is short of them).  The pools these
 // loads touch are padded: a ray's last block reads up to 24 bytes past its row.
@@ -98,8 +86,8 @@ template <bool FROM_LOWER> DEVINL double ls_shift1(double v)
 {
     const unsigned long long vv = __double_as_longlong(v);
     constexpr int CTRL = FROM_LOWER ? 0x138 : 0x130;
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)vv, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(vv >> 32), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)vv, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(vv >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 DEVINL double ls_bperm(double v, int srcLane)
@@ -115,17 +103,22 @@ DEVINL double ls_bperm(double v, int srcLane)
 // lane depends only on its distance from its ray's first point -- everything upwind of that point is multiplied by an
 // exact 0 --, so the intensities do not depend on which ray slot of the wavefront a wavelength sits in (row-relative DPP
 // shifts would make them: J must not change in the last bit when the wavelength grid is sharded differently).
-template <bool UP> DEVINL void ls_scan(double& E, double& B, const int lane)
+// (A ray of LR lanes is complete after ceil(log2 LR) steps: a step that reaches beyond the ray's first point multiplies by
+// that point's exact 0 and changes nothing, so the last step is skipped -- uniformly -- where no ray is longer than 32 lanes.)
+template <bool UP> DEVINL void ls_scan(double& E, double& B, const int lane, const int LR)
 {
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1)
     {
+        if (s == 32 && LR <= 32)
+            break;
+        // (a lane closer than s to its ray's first point already holds E = 0 exactly -- its composite contains that point's
+        // constant map --, so whatever the fetch brings from beyond the ray, or wrapped around the wavefront, changes
+        // nothing: no validity select)
         const int src = UP ? lane + s : lane - s;
-        const bool ok = UP ? src < 64 : src >= 0;
         const double Ep = ls_bperm(E, src), Bp = ls_bperm(B, src);
-        const double Bn = fma(E, Bp, B), En = E * Ep; // (Ep, Bp) is applied first
-        B = ok ? Bn : B;
-        E = ok ? En : E;
+        B = fma(E, Bp, B); // (Ep, Bp) is applied first
+        E = E * Ep;
     }
 }
 // 1 / x from v_rcp_f64 and one Newton step
@@ -146,9 +139,6 @@ DEVINL void ls_exp_table_init(double* tab, int t)
 }
 DEVINL double ls_exp_neg(double x, const double* tab)
 {
-#ifdef LS_DBG_FAKE_EXP
-    return 1.0 + x;
-#endif
     // (the constants are pinned to SGPR pairs where they are used: left alone the compiler parks them in VGPRs for the
     // whole kernel)
     double k0 = 46.166241308446828384, k1 = -2.16608493865351192653e-02, k2 = -5.96317165397058656257e-12; // 32 / ln2; ln2 / 32 head, tail
@@ -178,9 +168,6 @@ DEVINL double ls_planck(double T, double lambda, const double* tab)
 }
 
 enum { LS_MAX_WAVES = 8, LS_MAX_R = 16 };
-#ifndef LS_ACC0_REG
-#define LS_ACC0_REG 0
-#endif
 #define LS_KEEP(v) asm volatile("" : "+v"(v)) /* the value is computed here, on every lane (keeps selects branch-free) */
 #define LS_KEEPI(v) asm volatile("" : "+v"(v))
 #define LS_KEEPS(v) asm volatile("" : "+s"(v)) /* a uniform value re-issued here, in an SGPR: what is derived from it (flag tests) is formed
@@ -217,11 +204,23 @@ struct LaneCtx
 // The rays of one tile: NL / NM line / mixed-continuum slots.  Leaves J and the Psi* moments of the lane's points in
 // Jk / M1 / Me (Me[0] alone if the tile has fewer than two lines: its moment slot is returned) and adds the slots'
 // integrals to the workgroup's accumulators.
+//
+// Rates of the slots (compute_full_operator_rates, SimdFullIterationTemplates.hpp:192-234).  Per ray r every integrand of a
+// line or mixed-continuum slot is a polynomial in the rays' profiles phi_l(r) with ray-independent coefficients:
+//   V_ij = c1 phi, V_ji = c2 phi, U_ji = cu phi, chi_line = cx phi, eta_line = ce phi   (c* from n_i, n_j, rho and the line's constants),
+//   eta_A, chi_i, chi_j, U_i, U_j = continuum rows + multiples of the coupled lines' phi_l,
+// so the sums over the rays need only the angle moments
+//   P0_l = sum w phi_l,  P1_l = sum w phi_l I,  Q_l = sum w Psi* phi_l,  Q_ll' = sum w Psi* phi_l phi_l'   (+ J, M1 = sum w Psi*, W = sum w)
+// -- an exact regrouping of the reference's ray sum, as the pure continua's (lane_finish).  The ray loop accumulates the
+// moments in registers (6 flops per point, ray and line; no continuum rows, no populations, no LDS atomics); the slots'
+// integrals are formed ONCE per tile after the last ray (slot_finish_half) and are linear in the moments, so the
+// wavefronts of a split tile each add theirs.  Hybrid PRD (rho follows the ray) keeps the ray-by-ray form.
 template <int SOLVER, int D, int NL, int NM, int MODE>
 DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const LaneCtx& c, double* sAcc, const int q0,
                      const int q1, double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
 {
     constexpr bool RATES = (MODE & 1) != 0, HPRD = (MODE & 2) != 0; // MODE: bit 0 rates, bit 1 hybrid PRD (compiled in only where used)
+    constexpr bool MOM = RATES && !HPRD;                            // the slots' rates from angle moments
     constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
     const int Ns = c.Ns, Nmu = c.Nmu, LR = c.LR;
     const int la = c.la, k0 = c.k0;
@@ -326,6 +325,60 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         for (int l = 0; l < NLc; ++l)
             ccM[m][l] = __builtin_amdgcn_readfirstlane((m < NM && l < NL) ? couple_code(l, mat[m], mgi[m], mgj[m]) : 0);
 
+    // rho of a PRD line at N points of the block starting at point H, ray independent: its row of this wavelength
+    auto load_rho0 = [&](const int s, auto nTag, const unsigned H, double* rho) {
+        constexpr int N = decltype(nTag)::value;
+        if (!(lfl[s] & 2))
+        {
+#pragma unroll
+            for (int p = 0; p < N; ++p)
+                rho[p] = 1.0;
+        }
+        else
+        {
+            double tmp[N];
+            ls_gld<N>(rRho[s], (unsigned)c.r * Ns8 + c.vK + H * 8u, 0u, tmp);
+#pragma unroll
+            for (int p = 0; p < N; ++p)
+                rho[p] = tmp[p];
+        }
+    };
+    // (not hybrid PRD) the lines' opacity and emissivity per unit profile at the lane's points, for the gather of every ray:
+    // chi_line = n_i V_ij - n_j V_ji = cx phi, eta_line = n_j U_ji = ce phi with V_ij = la0 phi, V_ji = la2 rho V_ij,
+    // U_ji = la3 V_ji (Transition::uv LwTransition.hpp:93-144, chi_eta_aux_accum :59-109)
+    double cxr[NLc][D], cer[NLc][D];
+#pragma unroll
+    for (int s = 0; s < NLc; ++s)
+    {
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+            cxr[s][p] = cer[s][p] = 0.0;
+        if (!HPRD && s < NL)
+        {
+            double ni[D], nj[D], rho[D];
+            ls_lds<D>(sDep, c.vK, lnI[s], ni);
+            ls_lds<D>(sDep, c.vK, lnJ[s], nj);
+            load_rho0(s, std::integral_constant<int, D>{}, 0u, rho);
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+            {
+                const double c2 = (la2[s] * rho[p]) * la0[s];
+                cxr[s][p] = ni[p] * la0[s] - nj[p] * c2;
+                cer[s][p] = nj[p] * (la3[s] * c2);
+            }
+        }
+    }
+    // the angle moments of the slots' rates (see above): per line P0, P1, Q, Q_ll; Q_01 of a blend; W
+    double mP0[NLc][D], mP1[NLc][D], mQ1[NLc][D], mQ2[NLc][D], mQ12[D], mW = 0.0;
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+    {
+        mQ12[p] = 0.0;
+#pragma unroll
+        for (int s = 0; s < NLc; ++s)
+            mP0[s][p] = mP1[s][p] = mQ1[s][p] = mQ2[s][p] = 0.0;
+    }
+
     const bool storeDepth = RATES && a.storeDepth && !dyn.prdOnly;
     const double lamf = dyn.lambdaIterate ? 0.0 : 1.0;
     // which moment row a line's Psi* eta goes to: with fewer than two lines row 0 stands for the line's moment slot
@@ -371,19 +424,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
     // The integrals of the slots at this lane's points go to the workgroup's LDS accumulators ray by ray:
     // [slot][quantity][point of the block][block], so that the lanes of a ray hit consecutive addresses (the R rays of
     // the wavefront meet at one address: an LDS atomic without return serialises them).
-#ifdef LS_DBG_NOCONFLICT
-    double* accBase = sAcc + c.lane; // timing experiment: the rays of a wavefront do not meet at one address (wrong sums)
-#else
     double* accBase = sAcc + c.blk;
-#endif
-    // ... except, in an experiment build (-DLS_ACC0_REG=1), the first line's: its sums stay in registers for the whole tile
-    // (an LDS f64 atomic costs ~25 clocks per wavefront instruction) -- measured: the kernel then spills at 256 VGPRs
-    double acc0[4][D];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-            acc0[q][p] = 0.0;
 
     // the profiles are the one stream that comes from HBM: a ray's block is requested one ray ahead
     double phiN[NLc][D];
@@ -414,7 +455,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 #define MI(i) (UP ? D - 1 - (i) : (i)) /* march index <-> index in the lane's k-ordered block (an involution) */
 #define IV(i) (UP ? D - (i) : (i))     /* interval i (march point i-1 -> i) -> index in dhK / rdhK */
         const double muz = CTAB(double, a.muz)[mu];
-        const double zmu = 1.0 / muz;
+        const double zmu = CTAB(double, a.muz)[Nmu + mu]; // 1 / muz (the host's division)
         const double hw = act ? 0.5 * CTAB(double, a.wmu)[mu] : 0.0;
         const unsigned sRay = (unsigned)(mu * 2 + dirI) * Ns8;
         const int bcType = UP ? a.lowerBc : a.upperBc;
@@ -466,6 +507,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         };
         // ---- A. gather: Transition::uv + chi_eta_aux_accum + compute_source_fn at the lane's points (march order) ----
         double chi[D], S[D], rch[D];
+        double phiK[NLc][D]; // the ray's profiles at the lane's points (k order): kept for the moments
         double dhK[D + 1], rdhK[D + 1], rsumK[D]; // geometry of the block (used by the stencils, requested with the gather's loads)
         {
             unsigned vK = c.vK, vRow = c.vRow, vPhi = vPhi0, vRho = vRho0;
@@ -484,7 +526,20 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
             {
-                if (s < NL)
+                if (s < NL && !HPRD)
+                {
+#pragma unroll
+                    for (int p = 0; p < D; ++p)
+                        phiK[s][p] = phiN[s][p];
+                    ls_gld<D>(rPhi[s], vPhi, sRayNext, phiN[s]); // the next ray's profile
+#pragma unroll
+                    for (int p = 0; p < D; ++p)
+                    {
+                        cC[p] = fma(cxr[s][p], phiK[s][p], cC[p]);
+                        eC[p] = fma(cer[s][p], phiK[s][p], eC[p]);
+                    }
+                }
+                else if (s < NL)
                 {
                     double phi[D], ni[D], nj[D], rho[D];
                     ls_lds<D>(sDep, vK, lnI[s], ni);
@@ -503,6 +558,12 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                         cC[p] += ni[p] * v1 - nj[p] * v2;
                         eC[p] += nj[p] * uji;
                     }
+                }
+                else
+                {
+#pragma unroll
+                    for (int p = 0; p < D; ++p)
+                        phiK[s][p] = 0.0;
                 }
             }
             if (storeDepth && act)
@@ -613,9 +674,10 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                         if (bcType == LWHIP_BC_THERMALISED)
                         {
                             const double dtb = ((0.5 * zmu) * (CHI(i) + CHI(i + 1))) * dhK[IV(i + 1)];
+                            const double rdtb = ls_rcp(dtb);
                             const double* sb = c.sB + min(c.rRaw, LS_MAX_R - 1) * 4 + (UP ? 2 : 0);
                             const double B0 = sb[0], B1 = sb[1];
-                            Ib = UP ? B1 - (B0 - B1) / dtb : B0 - (B1 - B0) / dtb;
+                            Ib = UP ? B1 - (B0 - B1) * rdtb : B0 - (B1 - B0) * rdtb;
                         }
                         else if (bcType == LWHIP_BC_CALLABLE)
                         {
@@ -674,7 +736,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     }
                     else if (xi > 50.0)
                         w0 = w1 = 1.0;
-                    const double rL = d_rcp(xi);
+                    const double rL = ls_rcp(xi);
                     const double dSL = (S0 - Su) * rL;
                     const bool lst = is_last(i);
                     e1 = lst ? 1.0 - w0 : e1;
@@ -710,9 +772,10 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 if (bcType == LWHIP_BC_THERMALISED)
                 {
                     const double dtb = ((0.5 * zmu) * (CHI(i) + CHI(i + 1))) * dhK[IV(i + 1)];
+                    const double rdtb = ls_rcp(dtb);
                     const double* sb = c.sB + min(c.rRaw, LS_MAX_R - 1) * 4 + (UP ? 2 : 0);
                     const double B0 = sb[0], B1 = sb[1];
-                    Ib = UP ? B1 - (B0 - B1) / dtb : B0 - (B1 - B0) / dtb;
+                    Ib = UP ? B1 - (B0 - B1) * rdtb : B0 - (B1 - B0) * rdtb;
                 }
                 else if (bcType == LWHIP_BC_CALLABLE)
                 {
@@ -808,7 +871,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 B = fma(ee[i], B, bb[i]);
                 E = ee[i] * E;
             }
-            ls_scan<UP>(E, B, c.lane);
+            ls_scan<UP>(E, B, c.lane, LR);
             double I = ls_shift1<!UP>(B); // the intensity entering the lane (a ray's first point multiplies it by 0)
 #pragma unroll
             for (int i = 0; i < D; ++i)
@@ -874,9 +937,32 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 Jk[MI(i)] += hw * Iv[i]; // accumulate_J :181-190
                 M1[MI(i)] += wPsi[i];
             }
-#ifndef LS_DBG_SKIP_D
-            // The rate integrals, half a block at a time (bounds what is in flight): V_ij / V_ji again from the profile
-            // (an L1 / L2 hit), the populations, the slots' continuum rows.
+            if (MOM)
+            {
+                // the angle moments of the slots' rates
+                mW += hw;
+#pragma unroll
+                for (int s = 0; s < NLc; ++s)
+                {
+                    if (s < NL)
+                    {
+#pragma unroll
+                        for (int p = 0; p < D; ++p)
+                        {
+                            const int i = MI(p);
+                            const double wa = hw * phiK[s][p], wb = wPsi[i] * phiK[s][p];
+                            mP0[s][p] += wa;
+                            mP1[s][p] = fma(wa, Iv[i], mP1[s][p]);
+                            mQ1[s][p] += wb;
+                            mQ2[s][p] = fma(wb, phiK[s][p], mQ2[s][p]);
+                            if (NL > 1 && s == 0)
+                                mQ12[p] = fma(wb, phiK[NLc - 1][p], mQ12[p]);
+                        }
+                    }
+                }
+            }
+            // Hybrid PRD: the rate integrals ray by ray, half a block at a time (bounds what is in flight): V_ij / V_ji again
+            // from the profile (an L1 / L2 hit), the populations, the slots' continuum rows.
             auto rates_half = [&](auto hTag) {
                 constexpr int H = decltype(hTag)::value; // points p = H .. H + HP - 1 of the block (k order)
                 constexpr int HP = D / 2;
@@ -997,8 +1083,6 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 #pragma unroll
                         for (int p = 0; p < HP; ++p)
                         {
-                            constexpr int dummy = 0;
-                            (void)dummy;
                             const int i = MI(H + p); // march index of the point
                             const double uji = uj[s][p];
                             const double wlamu = lcw * wphi[p];
@@ -1012,14 +1096,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                             const double g1 = ((v1[s][p] * Ieff) - (PsiS[i] * chi_j * U_i)) * wop;
                             const double g2 = Iv[i] * v1[s][p] * wlamu;
                             const double g3 = (uji + Iv[i] * v2[s][p]) * wlamu;
-                            if (LS_ACC0_REG && s == 0)
-                            {
-                                acc0[0][H + p] += g0; // (inactive lanes carry hw = 0)
-                                acc0[1][H + p] += g1;
-                                acc0[2][H + p] += g2;
-                                acc0[3][H + p] += g3;
-                            }
-                            else if (act)
+                            if (act)
                             {
                                 double* dst = accBase + lacc[s] + (unsigned)((H + p) * LR);
                                 lds_add(dst, g0);
@@ -1069,10 +1146,12 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 }
             };
             static_assert(D % 2 == 0, "the block's rate integrals are formed in halves");
-            rates_half(std::integral_constant<int, 0>{});
-            LS_PHASE();
-            rates_half(std::integral_constant<int, D / 2>{});
-#endif
+            if (!MOM)
+            {
+                rates_half(std::integral_constant<int, 0>{});
+                LS_PHASE();
+                rates_half(std::integral_constant<int, D / 2>{});
+            }
         }
         LS_PHASE();
         LS_T(tp5);
@@ -1106,15 +1185,203 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
     else
         for (int mu = q0; mu < q1; ++mu)
             pass(std::true_type{}, mu, (unsigned)(mu * 2 + 3) * Ns8);
-    if (LS_ACC0_REG && RATES && NL > 0 && act)
+    if constexpr (MOM)
     {
-        // the first line's sums of this tile to the workgroup's accumulators
+        // ---- the slots' rate integrals from the moments, half a block at a time -------------------------------------------
+        // A level sum of a slot is affine in the profiles: X = X0 + sum_l X_l phi_l (X0: the slot's continuum row; X_l: the
+        // coupled line's cx / ce / cu, selected by the tile's coupling codes).  With
+        //   L(X)    = sum w Psi* X          = X0 M1 + sum_l X_l Q_l
+        //   L_s(X)  = sum w Psi* phi_s X    = X0 Q_s + sum_l X_l Q_sl
+        //   B(X, Y) = sum w Psi* X Y        = X0 Y0 M1 + sum_l (X0 Y_l + X_l Y0) Q_l + sum_ll' X_l Y_l' Q_ll'
+        // the sums of compute_full_operator_rates :206-234 over the rays are
+        //   line s:   Gij += K_op [cu_s P0_s + c2_s P1_s - c2_s L_s(eta_A) - B(chi_i, U_j)]      Rij += K c1_s P1_s
+        //             Gji += K_op [c1_s P1_s - c1_s L_s(eta_A) - B(chi_j, U_i)]                  Rji += K (cu_s P0_s + c2_s P1_s)
+        //   mixed c:  Gij += K_c [U_c W + V_c (J - L(eta_A)) - B(chi_i, U_j)]                    Rij += K_c alpha J
+        //             Gji += K_c [alpha (J - L(eta_A)) - B(chi_j, U_i)]                          Rji += K_c (U_c W + V_c J)
+        // (K = w_lambda 4 pi / hc w_phi; K_op = K for active atoms, 0 for detailed ones; the quadrature weights are in the moments)
+        auto slot_finish_half = [&](auto hTag) {
+            constexpr int H = decltype(hTag)::value, HP = D / 2;
+            const unsigned vK = c.vK + (unsigned)H * 8u, vRow = c.vRow + (unsigned)H * 8u;
+            // the lines' coefficients per unit profile at these points
+            double c2[NLc][HP], cu[NLc][HP], cx[NLc][HP], ce[NLc][HP];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int s = 0; s < NLc; ++s)
+            {
+                if (s < NL)
+                {
+                    double ni[HP], nj[HP], rho[HP];
+                    ls_lds<HP>(sDep, vK, lnI[s], ni);
+                    ls_lds<HP>(sDep, vK, lnJ[s], nj);
+                    load_rho0(s, std::integral_constant<int, HP>{}, (unsigned)H, rho);
 #pragma unroll
-            for (int p = 0; p < D; ++p)
-                if (p < c.nV)
-                    lds_add(accBase + lacc[0] + (unsigned)((q * D + p) * LR), acc0[q][p]);
+                    for (int p = 0; p < HP; ++p)
+                    {
+                        c2[s][p] = (la2[s] * rho[p]) * la0[s];
+                        cu[s][p] = la3[s] * c2[s][p];
+                        cx[s][p] = ni[p] * la0[s] - nj[p] * c2[s][p];
+                        ce[s][p] = nj[p] * cu[s][p];
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int p = 0; p < HP; ++p)
+                        c2[s][p] = cu[s][p] = cx[s][p] = ce[s][p] = 0.0;
+                }
+            }
+            // a slot's level sums: X0 from the continuum rows, X_l from the coupling code of line l with the slot
+            // (own: the slot is line l itself); bits as couple_code
+            struct Aff
+            {
+                double e[NLc], xi[NLc], xj[NLc], ui[NLc], uj[NLc];
+            };
+            auto coupled = [&](const int code, const bool own, const int l, const int p, Aff& f) {
+                const double sE = (own || (code & 1)) ? 1.0 : 0.0;
+                const double sXi = own ? 1.0 : ((code & 2) ? 1.0 : 0.0) - ((code & 4) ? 1.0 : 0.0);
+                const double sXj = own ? -1.0 : ((code & 8) ? 1.0 : 0.0) - ((code & 16) ? 1.0 : 0.0);
+                const double sUi = own ? 0.0 : (code & 4) ? 1.0 : 0.0;
+                const double sUj = (own || (code & 16)) ? 1.0 : 0.0;
+                f.e[l] = sE * ce[l][p];
+                f.xi[l] = sXi * cx[l][p];
+                f.xj[l] = sXj * cx[l][p];
+                f.ui[l] = sUi * cu[l][p];
+                f.uj[l] = sUj * cu[l][p];
+            };
+            auto Q2of = [&](const int l, const int m, const int P) { return l == m ? mQ2[l][P] : mQ12[P]; };
+            auto Lin = [&](const double X0, const double (&X)[NLc], const int P) {
+                double r = X0 * M1[P];
+#pragma unroll
+                for (int l = 0; l < NLc; ++l)
+                    if (l < NL)
+                        r = fma(X[l], mQ1[l][P], r);
+                return r;
+            };
+            auto LinS = [&](const int s, const double X0, const double (&X)[NLc], const int P) {
+                double r = X0 * mQ1[s][P];
+#pragma unroll
+                for (int l = 0; l < NLc; ++l)
+                    if (l < NL)
+                        r = fma(X[l], Q2of(s, l, P), r);
+                return r;
+            };
+            auto Bil = [&](const double X0, const double (&X)[NLc], const double Y0, const double (&Y)[NLc], const int P) {
+                double r = (X0 * Y0) * M1[P];
+#pragma unroll
+                for (int l = 0; l < NLc; ++l)
+                {
+                    if (l < NL)
+                    {
+                        r = fma(fma(X0, Y[l], X[l] * Y0), mQ1[l][P], r);
+#pragma unroll
+                        for (int m = 0; m < NLc; ++m)
+                            if (m < NL)
+                                r = fma(X[l] * Y[m], Q2of(l, m, P), r);
+                    }
+                }
+                return r;
+            };
+            // the five continuum rows of a slot (rows that no continuum feeds are not read)
+            auto load_rows = [&](const unsigned rowOff, const int zm, double (&lr)[5][HP]) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                {
+                    if (!(zm & (1 << q)))
+                        ls_gld<HP>(rRows, vRow, rowOff + (unsigned)q * rowStride, lr[q]);
+                    else
+                    {
+#pragma unroll
+                        for (int p = 0; p < HP; ++p)
+                            lr[q][p] = 0.0;
+                    }
+                }
+            };
+#pragma unroll
+            for (int s = 0; s < NLc; ++s)
+            {
+                if (s < NL)
+                {
+                    double lr[5][HP], wphi[HP];
+                    load_rows(lrow[s], lzm[s], lr);
+                    ls_lds<HP>(sDep, vK, lwO[s], wphi);
+#pragma unroll
+                    for (int p = 0; p < HP; ++p)
+                    {
+                        const int P = H + p;
+                        Aff f;
+#pragma unroll
+                        for (int l = 0; l < NLc; ++l)
+                        {
+                            f.e[l] = f.xi[l] = f.xj[l] = f.ui[l] = f.uj[l] = 0.0;
+                            if (l < NL)
+                                coupled(ccL[s][l], l == s, l, p, f);
+                        }
+                        const double K = lcw1[s] * wphi[p];
+                        const double Kop = (lfl[s] & 1) ? K : 0.0; // detailed atoms: rates only
+                        const double up = fma(cu[s][p], mP0[s][P], c2[s][p] * mP1[s][P]); // sum w (U_ji + V_ji I)
+                        const double LsE = LinS(s, lr[0][p], f.e, P);
+                        const double g0 = ((up - c2[s][p] * LsE) - Bil(lr[1][p], f.xi, lr[4][p], f.uj, P)) * Kop;
+                        const double g1 = ((la0[s] * (mP1[s][P] - LsE)) - Bil(lr[2][p], f.xj, lr[3][p], f.ui, P)) * Kop;
+                        const double g2 = (la0[s] * mP1[s][P]) * K;
+                        const double g3 = up * K;
+                        if (act)
+                        {
+                            double* dst = accBase + lacc[s] + (unsigned)(P * LR);
+                            lds_add(dst, g0);
+                            lds_add(dst + D * LR, g1);
+                            lds_add(dst + 2 * D * LR, g2);
+                            lds_add(dst + 3 * D * LR, g3);
+                        }
+                        // Meta of the line's atom for the pure continua (lane_finish): sum w Psi* eta_line
+                        if (lms[s] >= 0)
+                        {
+                            if (NL < 2 || lms[s] == 0)
+                                Me[0][P] = fma(ce[s][p], mQ1[s][P], Me[0][P]);
+                            else
+                                Me[1][P] = fma(ce[s][p], mQ1[s][P], Me[1][P]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < NMc; ++m)
+            {
+                if (m < NM) // mixed continua (always of active atoms)
+                {
+                    double mr[5][HP], mvji[HP];
+                    load_rows(mrow[m], mzm[m], mr);
+                    ls_gld<HP>(rRows, vRow, maux[m], mvji);
+#pragma unroll
+                    for (int p = 0; p < HP; ++p)
+                    {
+                        const int P = H + p;
+                        Aff f;
+#pragma unroll
+                        for (int l = 0; l < NLc; ++l)
+                        {
+                            f.e[l] = f.xi[l] = f.xj[l] = f.ui[l] = f.uj[l] = 0.0;
+                            if (l < NL)
+                                coupled(ccM[m][l], false, l, p, f);
+                        }
+                        const double w1 = mb0[m], w2 = mvji[p], uji = mb2[m] * w2;
+                        const double Jeff = Jk[P] - Lin(mr[0][p], f.e, P);
+                        const double uw = fma(uji, mW, w2 * Jk[P]); // sum w (U_ji + V_ji I)
+                        if (act)
+                        {
+                            double* dst = accBase + macc[m] + (unsigned)(P * LR);
+                            lds_add(dst, ((uji * mW + w2 * Jeff) - Bil(mr[1][p], f.xi, mr[4][p], f.uj, P)) * mcw1[m]);
+                            lds_add(dst + D * LR, ((w1 * Jeff) - Bil(mr[2][p], f.xj, mr[3][p], f.ui, P)) * mcw1[m]);
+                            lds_add(dst + 2 * D * LR, (w1 * Jk[P]) * mcw1[m]);
+                            lds_add(dst + 3 * D * LR, uw * mcw1[m]);
+                        }
+                    }
+                }
+            }
+        };
+        LS_PHASE();
+        slot_finish_half(std::integral_constant<int, 0>{});
+        LS_PHASE();
+        slot_finish_half(std::integral_constant<int, D / 2>{});
+        LS_PHASE();
     }
 #ifdef LS_TIMING
     if (c.lane == 0 && a.lsDbg)
@@ -1235,17 +1502,6 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
             uji[p] = p2 * vji;
             eta_c[p] = nj[p] * uji[p];
         }
-#ifdef LS_DBG_FASTDECODE
-        // timing experiment (wrong results): no decoding of the tile program
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-        {
-            S8[p][1] += chi_c[p];
-            S8[p][2] -= chi_c[p];
-            S8[p][3] += uji[p];
-            S8[p][4] += eta_c[p];
-        }
-#else
         // the program word names, for each of the continuum's four terms, the entry it goes to (1 .. 8 a shared sum, 9: none
         // -- the spare entry): four indexed register updates instead of a test per (sum, term)
         // (the two words almost every continuum of a one- or two-atom problem has -- its atom's eta, U(j), chi(j) are the
@@ -1282,7 +1538,6 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
                 S8[p][(code >> 12) & 15u] += eta_c[p];
             }
         }
-#endif
     }
     // walk 2: the pure continua
     for (int q = 0; q < nCont; ++q)
@@ -1307,18 +1562,6 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         }
         const unsigned ops = rc.ops;
         double o5[5][NP]; // eta_A, chi_i, U_j, chi_j, U_i
-#ifdef LS_DBG_FASTDECODE
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-        {
-            o5[0][p] = S8[p][4];
-            o5[1][p] = S8[p][1];
-            o5[2][p] = S8[p][3];
-            o5[3][p] = S8[p][2];
-            o5[4][p] = S8[p][5];
-        }
-        (void)ops;
-#else
         // operand w of the continuum: sel_w = 0 nothing, 1 .. 8 a shared sum (one indexed register read: the index is
         // uniform), 9 .. 12 the continuum's own term -- instead of a chain of tests per operand
         if (ops == 0x03291u || ops == 0x06594u || ops == 0x0AB9Cu)
@@ -1351,7 +1594,6 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
                 }
             }
         }
-#endif
         double* dst = sAcc + (unsigned)(rc.cs * 4 * c.LRD) + c.blk;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -1626,7 +1868,7 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     int ms0 = 0, ms1 = 1;
     if (have)
     {
-#ifdef LS_ONLY_NL
+#if defined(LS_ISA_ONLY) && defined(LS_ONLY_NL) /* one tile kind, for register / instruction counts of the listing */
         ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
         if (LS_ONLY_NL < 2)
             ms1 = -2;
@@ -1671,7 +1913,6 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                 lane_split_exchange_read<D, 4>(sX, sub, lane, Jk, M1, Me);
         }
     }
-#ifndef LS_DBG_NO_FINISH
     if (RATES && have)
     {
         if (S == 1)
@@ -1683,10 +1924,6 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     }
     if (RATES && S > 1)
         __syncthreads(); // the group's dJ maxima are complete; the row blocks may be overwritten by the next round
-#else
-    if (RATES && c.act)
-        GD(a.J)[(size_t)c.la * c.Ns + c.k0] = Jk[0] + Jk[1] + Jk[2] + Jk[3] + M1[0] + M1[1] + M1[2] + M1[3] + Me[0][0] + Me[0][1] + Me[0][2] + Me[0][3] + Me[1][0] + Me[1][1] + Me[1][2] + Me[1][3];
-#endif
 #ifdef LS_TIMING
     {
         LS_T(tt2);
@@ -1834,6 +2071,10 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restric
     red8[(size_t)tr * LWHIP_REDUCE_SPLIT * n4 + i] = sum;
 }
 
+#ifdef LS_ISA_ONLY /* one instance, for instruction counts of the listing (tools/isa_loops.py) */
+template __global__ void lanesweep_kernel<LWHIP_FS_BEZIER3_1D, 4, 1, false>(const TileArgs* __restrict__, const TileArgs* const* __restrict__,
+                                                                            const TileDyn);
+#else
 template <int SOLVER, int D, int MODE>
 hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int nChunks, int waves,
                        const TileArgs* const* apList, int nBatch, hipStream_t stream)
@@ -1854,6 +2095,7 @@ hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn
         hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, MODE, false>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList, dyn);
     return hipGetLastError();
 }
+#endif
 }
 
 // D: depth points per lane; LR: lanes per ray; R: rays (wavelengths) per wavefront
@@ -1888,6 +2130,7 @@ size_t lane_sweep_lds_bytes(const TileArgs& a, int waves)
            + a.depBytes;
 }
 
+#ifndef LS_ISA_ONLY
 hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int solver, bool rates, int nChunks,
                              int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream)
 {
@@ -1911,4 +2154,5 @@ hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& a, const T
     return hprd ? launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, 2>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream)
                 : launch_ls_t<LWHIP_FS_BEZIER3_1D, 4, 0>(devArgs, a, dyn, nChunks, waves, apList, nBatch, stream);
 }
+#endif
 }

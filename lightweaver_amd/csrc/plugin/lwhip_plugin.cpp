@@ -650,6 +650,10 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
     apply_zplane(ctx, st, params);
     if (lwhip_upload(st->hip, up) != LWHIP_OK)
         fail("lwhip_upload");
+    // a Context with one thread runs the reference's single-thread loop, whose dJMaxIdx is NOT the arg-max (max_idx's
+    // argument order, SimdFullIterationTemplates.hpp:627): report what that loop reports
+    if (lwhip_set_djmax_index_mode(st->hip, ctx.Nthreads <= 1 ? 1 : 0) != LWHIP_OK)
+        fail("lwhip_set_djmax_index_mode");
     lwhip_iter_result r{};
     if (lwhip_formal_sol_gamma_matrices(st->hip, lambdaIterate ? 1 : 0, &r) != LWHIP_OK)
         fail("lwhip_formal_sol_gamma_matrices");

@@ -54,6 +54,39 @@ def test_iter1_golden(gpu, name, sweep):
 
 
 @pytest.mark.parametrize('name', FIXTURES)
+def test_djmax_index_of_the_single_thread_scheme(gpu, name, sweep):
+    """Index outputs are held bit-exact: with lwhip_set_djmax_index_mode(1) dJMaxIdx is the golden fixture's own value --
+    what the reference's single-thread loop records (`dJMax = max_idx(dJ, dJMax, maxIdx, la)`,
+    SimdFullIterationTemplates.hpp:627: the last wavelength whose dJ is below the running maximum), which is NOT the
+    arg-max; mode 0 keeps the arg-max of the threaded schemes.  Also on a permuted dJ pattern built from the per-wavelength
+    dJ of the fixture (a numpy restatement of the loop as the second checker)."""
+    base, d = load_fixture(name)
+    p = variant_problem(base, d, 'iter1')
+    want = int(d['out/iter1/dJMaxIdx'])
+    dJ = d['out/iter1/dJ']
+
+    def scalar_loop(v):
+        run, idx = 0.0, 0
+        for la, x in enumerate(v):
+            if x < run:
+                idx = la
+            else:
+                run = x
+        return idx
+    assert scalar_loop(dJ) == want  # the restatement reproduces the fixture
+    with Context(p) as ctx:
+        ctx.set_djmax_index_mode(1)
+        up = ctx.formal_sol_gamma_matrices()
+        assert up.dJMaxIdx == want, (up.dJMaxIdx, want, int(np.argmax(dJ)))
+        assert abs(up.dJMax / dJ.max() - 1.0) <= TOL_ONE_CALL
+        ctx.set_djmax_index_mode(0)
+    q = variant_problem(base, d, 'iter1')
+    with Context(q) as ctx:
+        up = ctx.formal_sol_gamma_matrices()
+        assert up.dJMaxIdx == int(np.argmax(dJ))
+
+
+@pytest.mark.parametrize('name', FIXTURES)
 @pytest.mark.parametrize('variant', ['linear', 'besser', 'bc', 'prd_detailed'])
 def test_variants_golden(gpu, name, variant, sweep):
     base, d = load_fixture(name)
