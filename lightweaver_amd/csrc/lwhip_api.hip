@@ -64,6 +64,9 @@ template <typename T> struct DevBuf
         // in the results instead of depending on what the previous owner of the pages left there
         if (e == hipSuccess && poison_on())
             e = hipMemset(p, 0xFF, count * sizeof(T));
+        static const bool trace = std::getenv("LWHIP_TRACE_ALLOC") != nullptr; // diagnosis: which buffer a faulting address follows
+        if (trace)
+            std::fprintf(stderr, "lwhip alloc %p .. %p (%zu x %zu B)\n", (void*)p, (void*)((char*)p + count * sizeof(T)), count, sizeof(T));
         return e;
     }
     static bool poison_on()
@@ -169,6 +172,12 @@ struct lwhip_context
     DevBuf<int32_t> tileRemap;
     DevBuf<DevContRec> contRec;
     DevBuf<int32_t> chunkOrder;   // lane sweep: dispatch order of the workgroups' chunks
+    // lane sweep: the flat per-workgroup / per-tile records of a task's setup and finish (lwhip_internal.h)
+    DevBuf<DevLaneWg> laneWg, laneWgPrd;
+    DevBuf<DevLaneTile> laneTiles, laneTilesPrd;
+    DevBuf<DevLaneRay> laneRays;
+    DevBuf<DevLaneFin> laneFin;
+    DevBuf<double> laneFinPar, bcPlanck;
     DevBuf<int32_t> chunkSplit;   // lane sweep: per chunk, the wavefronts its tiles' rays are split over (the launch's tail)
     DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
         postCs;
@@ -1359,8 +1368,13 @@ int build_tables(lwhip_context* c)
                 std::vector<char> cut(nch0, 0);
                 if (nch0 > slotsWg)
                 {
-                    // the first `keep` chunks of the dispatch order stay whole
-                    const int keep = std::min(nch0, std::max(0, env_int("LWHIP_LANE_KEEP", slotsWg)));
+                    // the first `keep` chunks of the dispatch order stay whole; as many of the rest are cut in two as fill the
+                    // launch's last round of workgroup slots exactly: whole + 2 cut = rounds x slots (measured at 10 240
+                    // wavelengths, 857 chunks on 512 slots: keep 512 / 600 / 700 / 780 / all -> 0.152 / 0.150 / 0.139 / 0.148 /
+                    // 0.155 ms; the rule gives 690)
+                    const int rounds = (nch0 + slotsWg - 1) / slotsWg;
+                    const int keepAuto = std::max(0, std::min(nch0, 2 * nch0 - rounds * slotsWg));
+                    const int keep = std::min(nch0, std::max(0, env_int("LWHIP_LANE_KEEP", tailS == 2 ? keepAuto : slotsWg)));
                     for (int q = keep; q < nch0; ++q)
                         cut[ord[q]] = 1;
                 }
@@ -1585,9 +1599,10 @@ int build_tables(lwhip_context* c)
                 v.resize(1);
             return buf.upload(v);
         };
+        std::vector<DevContRec> cr(std::max<size_t>(slots.size(), 1), DevContRec{});
+        std::vector<DevPostProg> pp;
         {
             // the continua of every wavelength in transition order, ready-to-use offsets and level-column slots
-            std::vector<DevContRec> cr(std::max<size_t>(slots.size(), 1), DevContRec{});
             for (int la = 0; la < c->Nla; ++la)
             {
                 const DevLaHeader& h = hdr[la];
@@ -1617,7 +1632,7 @@ int build_tables(lwhip_context* c)
         }
         if (c->laneSweep)
         {
-            std::vector<DevPostProg> pp(std::max<size_t>(tiles.size(), 1));
+            pp.assign(std::max<size_t>(tiles.size(), 1), DevPostProg{});
             for (size_t t = 0; t < tiles.size(); ++t)
                 if (!lanePostProgram(tiles[t].la0, pp[t]))
                     return fail(LWHIP_ERR_UNSUPPORTED, "lane sweep: post program");
@@ -1670,6 +1685,94 @@ int build_tables(lwhip_context* c)
             std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return heavyFirst ? cost[x] > cost[y] : cost[x] < cost[y]; });
             HIP_TRY(up(c->chunkOrder, order));
             c->chunkOrderOn = true;
+        }
+        if (c->laneSweep)
+        {
+            // the flat records of the lane sweep's tasks (lwhip_internal.h: DevLaneWg, DevLaneTile, DevLaneRay, DevLaneFin)
+            const int L = c->tileL;
+            auto wg_records = [&](const std::vector<int32_t>& chTile, const std::vector<int32_t>* order, const std::vector<int32_t>* split,
+                                  int launchSplit) {
+                const int nch = (int)chTile.size() - 1;
+                std::vector<DevLaneWg> w(std::max(nch, 1));
+                for (int b = 0; b < nch; ++b)
+                {
+                    const int ch = order ? (*order)[b] : b;
+                    const int S = split ? (*split)[ch] : launchSplit;
+                    w[b] = DevLaneWg{ ch, S > 1 ? S : 1, chTile[ch], chTile[ch + 1] };
+                }
+                return w;
+            };
+            std::vector<int32_t> orderHost;
+            if (c->chunkOrderOn)
+            {
+                orderHost.resize(c->chunkOrder.n);
+                HIP_TRY(hipMemcpy(orderHost.data(), c->chunkOrder.p, orderHost.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            }
+            auto wgs = wg_records(chunkTile, c->chunkOrderOn ? &orderHost : nullptr, c->chunkSplitOn ? &laneChunkSplit : nullptr, c->laneSplit);
+            HIP_TRY(c->laneWg.upload(wgs));
+            auto tile_records = [&](const std::vector<DevTileSlot>& ts) {
+                std::vector<DevLaneTile> v(std::max<size_t>(tiles.size(), 1), DevLaneTile{});
+                for (size_t t = 0; t < tiles.size(); ++t)
+                {
+                    const DevLaHeader& h = hdr[tiles[t].la0];
+                    v[t].td = tiles[t];
+                    v[t].nCont = h.nPure > 0 ? h.nMixed + h.nPure : 0;
+                    for (int e = 0; e < std::min(2, tiles[t].nLine + tiles[t].nMixed); ++e)
+                        v[t].slot[e] = ts[tiles[t].slotOff + e];
+                }
+                return v;
+            };
+            {
+                auto v = tile_records(tslots);
+                HIP_TRY(c->laneTiles.upload(v));
+                if (!tslotsPrd.empty() && tslotsPrd.size() == tslots.size() && !tileListPrd.empty())
+                {
+                    v = tile_records(tslotsPrd);
+                    HIP_TRY(c->laneTilesPrd.upload(v));
+                    auto wp = wg_records(chunkTilePrd, nullptr, nullptr, c->laneSplitPrd);
+                    HIP_TRY(c->laneWgPrd.upload(wp));
+                }
+            }
+            std::vector<DevLaneRay> rays(std::max<size_t>(tiles.size() * L, 1), DevLaneRay{});
+            std::vector<DevLaneFin> fin(std::max<size_t>(tiles.size() * LWHIP_POST_MAXC, 1), DevLaneFin{});
+            std::vector<double> finPar(std::max<size_t>(tiles.size() * LWHIP_POST_MAXC * L * 3, 1), 0.0);
+            for (size_t t = 0; t < tiles.size(); ++t)
+            {
+                const DevTile& td = tiles[t];
+                const DevLaHeader& h0 = hdr[td.la0];
+                const int nSl = std::min(2, td.nLine + td.nMixed);
+                for (int r = 0; r < L; ++r)
+                {
+                    const int la = td.la0 + std::min(r, td.nl - 1);
+                    DevLaneRay& lr = rays[t * L + r];
+                    lr.wav = c->prob.wavelength[c->laStart + la];
+                    for (int e = 0; e < nSl; ++e)
+                        for (int q = 0; q < 4; ++q)
+                            lr.p[e][q] = slots[hdr[la].off + tslots[td.slotOff + e].e].p[q];
+                }
+                const int nC = h0.nMixed + h0.nPure;
+                for (int q = 0; q < nC && q < LWHIP_POST_MAXC; ++q)
+                {
+                    const DevContRec& r = cr[h0.off + h0.nLine + q];
+                    uint32_t w[8];
+                    std::memcpy(w, &r, sizeof(w));
+                    fin[t * LWHIP_POST_MAXC + q] = DevLaneFin{ w[0], w[1], w[2], w[6], w[7], pp[t].code[q], pp[t].ops[q], 0u };
+                    for (int rr = 0; rr < L; ++rr)
+                    {
+                        const int la = td.la0 + std::min(rr, td.nl - 1);
+                        const char* lsB = (const char*)&slots[hdr[la].off];
+                        for (int k = 0; k < 3; ++k)
+                        {
+                            double v;
+                            std::memcpy(&v, lsB + r.pOff + 8 * k, sizeof(double));
+                            finPar[((t * LWHIP_POST_MAXC + q) * L + rr) * 3 + k] = v;
+                        }
+                    }
+                }
+            }
+            HIP_TRY(c->laneRays.upload(rays));
+            HIP_TRY(c->laneFin.upload(fin));
+            HIP_TRY(c->laneFinPar.upload(finPar));
         }
         HIP_TRY(up(c->chunkTilePrd, chunkTilePrd));
         HIP_TRY(up(c->tileListPrd, tileListPrd));
@@ -1741,6 +1844,8 @@ int alloc_state(lwhip_context* c)
         c->wphi.view(c->depArena.p + nN, nW);
         c->ratio.view(c->depArena.p + nN + nW, nR);
         c->geoT.view(c->depArena.p + nN + nW + nR, nG);
+        HIP_TRY(c->bcPlanck.alloc(4 * Nla));
+        HIP_TRY(hipMemset(c->bcPlanck.p, 0, c->bcPlanck.n * sizeof(double)));
     }
     else
     {
@@ -1749,7 +1854,9 @@ int alloc_state(lwhip_context* c)
         HIP_TRY(c->wphi.alloc((size_t)std::max(c->Nline, 1) * Ns));
     }
     HIP_TRY(c->nTotal.alloc((size_t)c->Natom * Ns));
-    HIP_TRY(c->phi.alloc((size_t)std::max<int64_t>(c->phiTot, 1)));
+    // (+ one ray's block: the lane sweep requests a ray's profile one ray ahead, after the last ray of the pool's last
+    // wavelength that request reaches up to 2 Ns doubles past the end -- it is never used, but it must be mapped memory)
+    HIP_TRY(c->phi.alloc((size_t)std::max<int64_t>(c->phiTot, 1) + 2 * (size_t)c->Ns + 8));
     HIP_TRY(c->rho.alloc((size_t)std::max<int64_t>(c->rhoTot, 1) + 8)); // (+ padding: reads past a row's end by a block of depths)
     HIP_TRY(c->Gamma.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
     HIP_TRY(c->Cmat.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
@@ -2011,6 +2118,12 @@ int build_tile_args(lwhip_context* c)
         a.hJCoef = c->hJCoef.p;
         a.JRest = c->JRest.p;
         a.detSlab = c->deterministic ? c->detSlab.p : nullptr;
+        a.laneWg = c->laneWg.p;
+        a.laneTiles = c->laneTiles.p;
+        a.laneRays = c->laneRays.p;
+        a.laneFin = c->laneFin.p;
+        a.laneFinPar = c->laneFinPar.p;
+        a.bcPlanck = c->bcPlanck.p;
     }
     a.lsDbg = nullptr;
     if (std::getenv("LWHIP_LS_TIMING"))
@@ -2046,6 +2159,8 @@ int build_tile_args(lwhip_context* c)
         a.laneSplit = c->laneSplitPrd;
         a.slotTr = c->tileSlotTrPrd.p;
         a.postChunkTile = c->postChunkTilePrd.p;
+        a.laneWg = c->laneWgPrd.p;
+        a.laneTiles = c->laneTilesPrd.p;
         HIP_TRY(put(c->dtargsPrd, c->htargsPrd, a));
     }
     return LWHIP_OK;
@@ -2419,7 +2534,27 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                         geoT[q * st + k + 1] = geo[4 * k + q];
                 HIP_TRY(hipMemcpyAsync(c->geoT.p, geoT.data(), geoT.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
             }
-            HIP_TRY(hipStreamSynchronize(c->stream)); // `geo` is a local
+            std::vector<double> bcB;
+            if (c->laneSweep)
+            {
+                // the thermalised boundaries' Planck functions (FormalScalar.cpp:471-666 -> planck_nu, LwMisc.hpp:29-46) of
+                // every wavelength at the two uppermost and the two lowermost points: once per atmosphere, not per task
+                auto planck = [](double T, double lambda) {
+                    const double hc_kla = HC_K / lambda;
+                    const double twohnu3_c2 = TWO_HC_NM3 / (lambda * lambda * lambda);
+                    const double x = hc_kla / T;
+                    return x <= 150.0 ? twohnu3_c2 / (std::exp(x) - 1.0) : 0.0;
+                };
+                bcB.resize(4 * Nla);
+                const size_t kk[4] = { 0, 1, Ns - 2, Ns - 1 };
+                for (size_t la = 0; la < Nla; ++la)
+                    for (int q = 0; q < 4; ++q)
+                        bcB[4 * la + q] = planck(p.temperature[kk[q]], p.wavelength[l0 + la]);
+                if (c->bcPlanck.n < bcB.size())
+                    HIP_TRY(c->bcPlanck.alloc(bcB.size()));
+                HIP_TRY(hipMemcpyAsync(c->bcPlanck.p, bcB.data(), bcB.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream)); // `geo`, `bcB` are locals
         }
     }
     if (mask & LWHIP_BACKGROUND)

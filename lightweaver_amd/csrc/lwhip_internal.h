@@ -198,6 +198,37 @@ struct DevTileCopy      // what the pre-pass writes into the tile's row block be
     int16_t dst;        // tile row
     int16_t _pad;
 };
+// ---- lane sweep: what a task needs about its workgroup and tile behind ONE index each.  The chain kernel argument ->
+// workgroup record -> tile record -> data is three dependent memory round trips; through the general tables
+// (chunkOrder -> chunkSplit / chunkTile -> tiles -> tslots, laHdr -> slots, contRec -> slots) it was eight, ~30 k clocks of a
+// 130 k-clock task (profiles/r04_lanesweep.md).  Built once per context (lwhip_create); atmosphere independent.
+struct DevLaneWg            // per workgroup, in dispatch order
+{
+    int32_t chunk;          // the chunk it works on (slotTr row, reduce part)
+    int32_t split;          // wavefronts a tile's rays are split over (1, 2, 4)
+    int32_t t0, t1;         // the chunk's tiles [t0, t1) (indices into tileList where the launch has one)
+};
+struct DevLaneTile          // per tile: uniform, one burst of scalar loads
+{
+    DevTile td;
+    int32_t nCont;          // continua the finish walks (0: none are pure): the first wavelength's nMixed + nPure
+    int32_t _pad[3];
+    DevTileSlot slot[2];    // the tile's line / mixed-continuum slots (cs: of this launch's chunking)
+};
+static_assert(sizeof(DevLaneTile) % 16 == 0, "DevLaneTile is read with wide scalar loads");
+struct DevLaneRay           // per (tile, ray slot r < L): what depends on the wavelength (r >= nl repeats the last one)
+{
+    double wav;
+    double p[2][4];         // the slots' per-(transition, wavelength) parameters (DevSlot::p)
+    double _pad[3];
+};
+struct DevLaneFin           // per (tile, continuum q of the transition order): the finish's words, one per lane
+{
+    uint32_t nI, nJ, rat;   // DevContRec byte offsets
+    uint32_t w6, w7;        // DevContRec dwords 6, 7: sUj | flags << 16 | ms << 24, tr | cs << 16
+    uint32_t code, ops;     // DevPostProg words
+    uint32_t _pad;
+};
 struct TileArgs
 {
     int32_t Ns, Nmu, L, nTiles, Natom, NlevTot, Ntrans, maxCT, maxC;
@@ -276,6 +307,12 @@ struct TileArgs
     const int64_t* hJOff;
     const lwhip_j_coeff* hJCoef;
     double* JRest;
+    const DevLaneWg* laneWg;       // [workgroups of the launch]
+    const DevLaneTile* laneTiles;  // [nTiles]
+    const DevLaneRay* laneRays;    // [nTiles][L]
+    const DevLaneFin* laneFin;     // [nTiles][LWHIP_POST_MAXC]
+    const double* laneFinPar;      // [nTiles][LWHIP_POST_MAXC][L][3]: alpha, w_lambda / lambda 4 pi / h, 2hc / lambda^3 of (continuum, wavelength)
+    const double* bcPlanck;        // [Nla][4]: Planck function of the wavelength at depths 0, 1, Ns - 2, Ns - 1 (thermalised boundaries)
     double* detSlab;               // deterministic mode: [workgroup][maxCT][4][Ns] partial sums (no atomics), else null
     double* lsDbg;                 // diagnostic builds (-DLS_TIMING): [nTiles][8] phase clocks, host-mapped; else null
 };

@@ -157,24 +157,25 @@ DEVINL double ls_exp_neg(double x, const double* tab)
     p = fma(p, r, 1.0);
     return ldexp(T * p, ni >> 5);
 }
-// planck_nu at one temperature (LwMisc.hpp:29-46) with the exponential above: B = c e / (1 - e), e = exp(-x)
-DEVINL double ls_planck(double T, double lambda, const double* tab)
-{
-    const double hc_kla = HC_K / lambda;
-    const double twohnu3_c2 = TWO_HC_NM3 / (lambda * lambda * lambda);
-    const double x = hc_kla / T;
-    const double e = ls_exp_neg(-fmin(x, 150.0), tab);
-    return (x <= 150.0) ? twohnu3_c2 * e / (1.0 - e) : 0.0;
-}
-
 enum { LS_MAX_WAVES = 8, LS_MAX_R = 16 };
 #define LS_KEEP(v) asm volatile("" : "+v"(v)) /* the value is computed here, on every lane (keeps selects branch-free) */
 #define LS_KEEPI(v) asm volatile("" : "+v"(v))
-#define LS_KEEPS(v) asm volatile("" : "+s"(v)) /* a uniform value re-issued here, in an SGPR: what is derived from it (flag tests) is formed
-                                                  at its use -- hoisted in front of the ray loop the tests become 64-bit masks, two dozen SGPRs
-                                                  that are spilled to VGPR lanes and read back (v_readlane) in every phase */
+#define LS_KEEPS(v)                                                                                                                        \
+    do                                                                                                                                     \
+    {                                                                                                                                      \
+        v = __builtin_amdgcn_readfirstlane(v);                                                                                             \
+        asm volatile("" : "+s"(v));                                                                                                        \
+    } while (0) /* a uniform int re-issued here, in an SGPR: what is derived from it (flag tests) is formed at its use -- hoisted in    \
+                   front of the ray loop the tests become 64-bit masks, two dozen SGPRs that are spilled to VGPR lanes and read back   \
+                   (v_readlane) in every phase */
 #define LS_PHASE() __builtin_amdgcn_sched_barrier(0) /* the scheduler does not move code across phase boundaries */
 
+// Ablation switches of diagnostic builds (tools/build_variant.py; results are WRONG on purpose, used with the instruction
+// counters): -DLS_ABL_NO_RAYS skips the ray loop, -DLS_ABL_NO_SLOTFIN the slots' rates from the moments, -DLS_ABL_NO_FINISH the
+// pure continua.  The shipped build defines none of them.
+#if defined(LS_ABL_NO_RAYS) || defined(LS_ABL_NO_SLOTFIN) || defined(LS_ABL_NO_FINISH)
+#define LS_ABLATION 1
+#endif
 // Phase timers of a diagnostic build (-DLS_TIMING): shader clocks per phase, summed over the rays of a tile, written to
 // TileArgs::lsDbg[tile][8] = setup, gather, stencils, coefficients, scan, rates, finish, total.
 #ifdef LS_TIMING
@@ -216,11 +217,20 @@ struct LaneCtx
 // integrals are formed ONCE per tile after the last ray (slot_finish_half) and are linear in the moments, so the
 // wavefronts of a split tile each add theirs.  Hybrid PRD (rho follows the ray) keeps the ray-by-ray form.
 template <int SOLVER, int D, int NL, int NM, int MODE>
-DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const LaneCtx& c, double* sAcc, const int q0,
+DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLaneTile& tr, const LaneCtx& c, double* sAcc, const int q0,
                      const int q1, double (&Jk)[D], double (&M1)[D], double (&Me)[2][D])
 {
     constexpr bool RATES = (MODE & 1) != 0, HPRD = (MODE & 2) != 0; // MODE: bit 0 rates, bit 1 hybrid PRD (compiled in only where used)
     constexpr bool MOM = RATES && !HPRD;                            // the slots' rates from angle moments
+    // Two lines (a blend): the moments of both would be 72 registers, and this kernel has none to spare and must not spill
+    // (what a value spilled inside divergent control flow did).  Every integral is LINEAR in the moments,
+    // so such a tile walks its rays TWICE -- run 0 accumulates J, M1, W and the moments of line 0 (and Q_01), run 1 those of
+    // line 1 alone -- and the slots' integrals are formed after each run from what that run accumulated; the gather takes the
+    // populations from LDS ray by ray and the moments re-read the profiles (an L1 hit) instead of holding cx / ce / phi.
+    // Blends are rare (28 of 3 429 tiles on the bench grid); they pay twice the ray work, the other kinds nothing.
+    constexpr bool HOLD = !HPRD && NL < 2;
+    constexpr int NRUN = (MOM && NL > 1) ? 2 : 1;
+    int run = 0;
     constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
     const int Ns = c.Ns, Nmu = c.Nmu, LR = c.LR;
     const int la = c.la, k0 = c.k0;
@@ -229,9 +239,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
     const double* rRows = c.rRows;
     const char* sDep = c.sDep;
 
-    // ---- slot structure (uniform) and per-lane parameters -------------------------------------------------------------
-    const CONST_AS DevTileSlot* ts = CTAB(DevTileSlot, a.tslots) + td.slotOff;
-    const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
+    // ---- slot structure (uniform: the tile record) and per-lane parameters (the lane's ray record) ------------------------
+    const DevTile& td = tr.td;
+    const GLOBAL_AS DevLaneRay* lray = (const GLOBAL_AS DevLaneRay*)a.laneRays + (size_t)c.ti * c.L + min(c.rRaw, c.L - 1);
     unsigned lnI[NLc], lnJ[NLc], lwO[NLc], lrow[NLc], lacc[NLc];
     int lgi[NLc], lgj[NLc], lat[NLc], lfl[NLc], lms[NLc], lzm[NLc];
     double la0[NLc], la2[NLc], la3[NLc], lcw1[NLc]; // per lane
@@ -254,7 +264,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         rHc[s] = nullptr;
         if (s < NL)
         {
-            const DevTileSlot u = ld_c(ts + s);
+            const DevTileSlot& u = tr.slot[s];
             lnI[s] = c.oN + (unsigned)u.gi * Ns8;
             lnJ[s] = c.oN + (unsigned)u.gj * Ns8;
             lwO[s] = c.oW + (unsigned)u.row * Ns8;
@@ -271,13 +281,27 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 rRho[s] = a.rho + u.rhoOff;
             if (HPRD && (u.flags & 2) && u.hCoefOff >= 0 && a.hRho)
                 rHc[s] = a.hRho + u.hCoefOff;
-            const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
-            la0[s] = sl->p[0];
-            la2[s] = sl->p[2];
-            la3[s] = sl->p[3];
-            lcw1[s] = sl->p[1] * PI4_HC; // times 0.5 wmu per ray
+            if (HPRD)
+            {
+                la0[s] = lray->p[s][0];
+                la2[s] = lray->p[s][2];
+                la3[s] = lray->p[s][3];
+                lcw1[s] = lray->p[s][1] * PI4_HC; // times 0.5 wmu per ray
+            }
         }
     }
+    // (not hybrid PRD) a line's per-(transition, wavelength) parameters hnu/4pi Bij, Bji/Bij, Aji/Bji, w_lambda 4pi/hc are
+    // re-read from the lane's ray record where they are used (setup, a blend's gather, the slots' integrals): an L1 / L2 hit
+    // instead of 8 registers per line held over the rays
+    struct LinePar
+    {
+        double a0, a2, a3, cw1;
+    };
+    auto line_par = [&](const int s) -> LinePar {
+        const GLOBAL_AS DevLaneRay* q = lray;
+        asm volatile("" : "+v"(q)); // (re-issued here: not kept from an earlier use)
+        return LinePar{ q->p[s][0], q->p[s][2], q->p[s][3], q->p[s][1] * PI4_HC };
+    };
     unsigned mrow[NMc], maux[NMc], macc[NMc];
     int mgi[NMc], mgj[NMc], mat[NMc], mzm[NMc];
     double mb0[NMc], mb2[NMc], mcw1[NMc];
@@ -290,7 +314,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         mb0[m] = mb2[m] = mcw1[m] = 0.0;
         if (m < NM)
         {
-            const DevTileSlot u = ld_c(ts + NL + m);
+            const DevTileSlot& u = tr.slot[NL + m < 2 ? NL + m : 1];
             mrow[m] = (unsigned)u.r0 * rowStride;
             maux[m] = (unsigned)max((int)u.rAux, 0) * rowStride;
             macc[m] = (unsigned)(u.cs * 4 * c.LRD);
@@ -298,10 +322,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
             mgj[m] = u.gj;
             mat[m] = u.atom;
             mzm[m] = u.zmask;
-            const GLOBAL_AS DevSlot* sl = (const GLOBAL_AS DevSlot*)a.slots + slotOffLa + u.e;
-            mb0[m] = sl->p[0];
-            mb2[m] = sl->p[2];
-            mcw1[m] = sl->p[1];
+            mb0[m] = lray->p[NL + m < 2 ? NL + m : 1][0];
+            mb2[m] = lray->p[NL + m < 2 ? NL + m : 1][2];
+            mcw1[m] = lray->p[NL + m < 2 ? NL + m : 1][1];
         }
     }
     // Which active lines feed which slot's level sums: one 5-bit code per (slot, line), evaluated once per tile.
@@ -353,31 +376,28 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 #pragma unroll
         for (int p = 0; p < D; ++p)
             cxr[s][p] = cer[s][p] = 0.0;
-        if (!HPRD && s < NL)
+        if (HOLD && s < NL)
         {
             double ni[D], nj[D], rho[D];
             ls_lds<D>(sDep, c.vK, lnI[s], ni);
             ls_lds<D>(sDep, c.vK, lnJ[s], nj);
             load_rho0(s, std::integral_constant<int, D>{}, 0u, rho);
+            const LinePar lp = line_par(s);
 #pragma unroll
             for (int p = 0; p < D; ++p)
             {
-                const double c2 = (la2[s] * rho[p]) * la0[s];
-                cxr[s][p] = ni[p] * la0[s] - nj[p] * c2;
-                cer[s][p] = nj[p] * (la3[s] * c2);
+                const double c2 = (lp.a2 * rho[p]) * lp.a0;
+                cxr[s][p] = ni[p] * lp.a0 - nj[p] * c2;
+                cer[s][p] = nj[p] * (lp.a3 * c2);
             }
         }
     }
-    // the angle moments of the slots' rates (see above): per line P0, P1, Q, Q_ll; Q_01 of a blend; W
-    double mP0[NLc][D], mP1[NLc][D], mQ1[NLc][D], mQ2[NLc][D], mQ12[D], mW = 0.0;
+    // the angle moments of the slots' rates (see above) of the line the current run accumulates: P0, P1, Q, Q_ll; Q_01 of a
+    // blend (run 0); W
+    double mP0[D], mP1[D], mQ1[D], mQ2[D], mQ12[D], mW = 0.0;
 #pragma unroll
     for (int p = 0; p < D; ++p)
-    {
-        mQ12[p] = 0.0;
-#pragma unroll
-        for (int s = 0; s < NLc; ++s)
-            mP0[s][p] = mP1[s][p] = mQ1[s][p] = mQ2[s][p] = 0.0;
-    }
+        mP0[p] = mP1[p] = mQ1[p] = mQ2[p] = mQ12[p] = 0.0;
 
     const bool storeDepth = RATES && a.storeDepth && !dyn.prdOnly;
     const double lamf = dyn.lambdaIterate ? 0.0 : 1.0;
@@ -401,19 +421,20 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
     }
     // boundary intensities of the rays (wrappers FormalScalar.cpp:471-666): Planck functions of the two end points of
     // this lane's wavelength, parked in the wavefront's LDS row (read by the lane that holds a ray's first point)
+    // (the host's table: once per atmosphere and wavelength, not per task)
     if (c.blk == 0 && c.rRaw < LS_MAX_R)
     {
-        const CONST_AS double* T = CTAB(double, a.temperature);
+        const GLOBAL_AS double* bp = GCD(a.bcPlanck) + (size_t)la * 4;
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
         if (a.upperBc == LWHIP_BC_THERMALISED && dyn.nPass == 2)
         {
-            b0 = ls_planck(T[0], c.wav, c.sExp);
-            b1 = ls_planck(T[1], c.wav, c.sExp);
+            b0 = bp[0];
+            b1 = bp[1];
         }
         if (a.lowerBc == LWHIP_BC_THERMALISED)
         {
-            b2 = ls_planck(T[Ns - 2], c.wav, c.sExp);
-            b3 = ls_planck(T[Ns - 1], c.wav, c.sExp);
+            b2 = bp[2];
+            b3 = bp[3];
         }
         c.sB[c.rRaw * 4 + 0] = b0;
         c.sB[c.rRaw * 4 + 1] = b1;
@@ -428,12 +449,12 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 
     // the profiles are the one stream that comes from HBM: a ray's block is requested one ray ahead
     double phiN[NLc][D];
-    {
+    auto prefetch_first = [&]() {
         const unsigned sRay0 = (unsigned)(dyn.nPass == 2 ? q0 : 2 * q0 + 1) * Ns8; // the wavefront's first ray
 #pragma unroll
         for (int s = 0; s < NLc; ++s)
         {
-            if (s < NL)
+            if (s < NL && (HOLD || HPRD))
                 ls_gld<D>(rPhi[s], vPhi0, sRay0, phiN[s]);
             else
             {
@@ -442,7 +463,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     phiN[s][p] = 0.0;
             }
         }
-    }
+    };
 
 #ifdef LS_TIMING
     unsigned long long tmA = 0, tmB = 0, tmC = 0, tmS = 0, tmD = 0, tmBprev = 0;
@@ -526,7 +547,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
             {
-                if (s < NL && !HPRD)
+                if (s < NL && HOLD)
                 {
 #pragma unroll
                     for (int p = 0; p < D; ++p)
@@ -545,16 +566,24 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     ls_lds<D>(sDep, vK, lnI[s], ni);
                     ls_lds<D>(sDep, vK, lnJ[s], nj);
                     load_rho(s, std::integral_constant<int, D>{}, 0u, vRho, rho);
+                    if (HPRD)
+                    {
 #pragma unroll
-                    for (int p = 0; p < D; ++p)
-                        phi[p] = phiN[s][p];
-                    ls_gld<D>(rPhi[s], vPhi, sRayNext, phiN[s]); // the next ray's profile
+                        for (int p = 0; p < D; ++p)
+                            phi[p] = phiN[s][p];
+                        ls_gld<D>(rPhi[s], vPhi, sRayNext, phiN[s]); // the next ray's profile
+                    }
+                    else
+                        ls_gld<D>(rPhi[s], vPhi, sRay, phi); // (a blend: no register for a profile held one ray ahead)
+                    LinePar lp{ la0[s], la2[s], la3[s], lcw1[s] };
+                    if (!HPRD)
+                        lp = line_par(s);
 #pragma unroll
                     for (int p = 0; p < D; ++p)
                     {
-                        const double v1 = la0[s] * phi[p];
-                        const double v2 = (la2[s] * rho[p]) * v1;
-                        const double uji = la3[s] * v2;
+                        const double v1 = lp.a0 * phi[p];
+                        const double v2 = (lp.a2 * rho[p]) * v1;
+                        const double uji = lp.a3 * v2;
                         cC[p] += ni[p] * v1 - nj[p] * v2;
                         eC[p] += nj[p] * uji;
                     }
@@ -934,30 +963,51 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
             for (int i = 0; i < D; ++i)
             {
                 wPsi[i] = hw * PsiS[i];
-                Jk[MI(i)] += hw * Iv[i]; // accumulate_J :181-190
-                M1[MI(i)] += wPsi[i];
+                if (NRUN == 1 || run == 0)
+                {
+                    Jk[MI(i)] += hw * Iv[i]; // accumulate_J :181-190
+                    M1[MI(i)] += wPsi[i];
+                }
             }
             if (MOM)
             {
-                // the angle moments of the slots' rates
-                mW += hw;
-#pragma unroll
-                for (int s = 0; s < NLc; ++s)
+                // the angle moments of the slots' rates: of line 0, or (a blend) of the line this run accumulates
+                if (NRUN == 1 || run == 0)
+                    mW += hw;
+                if (NL > 0)
                 {
-                    if (s < NL)
+                    double ph[D], phB[D];
+                    if (HOLD)
                     {
 #pragma unroll
                         for (int p = 0; p < D; ++p)
+                            ph[p] = phB[p] = phiK[0][p];
+                    }
+                    else
+                    {
+                        // (the ray's profiles again: an L1 hit)
+                        const double* rp = (NL > 1 && run != 0) ? rPhi[NLc - 1] : rPhi[0];
+                        ls_gld<D>(rp, vPhi0, sRay, ph);
+                        if (NL > 1 && run == 0)
+                            ls_gld<D>(rPhi[NLc - 1], vPhi0, sRay, phB);
+                        else
                         {
-                            const int i = MI(p);
-                            const double wa = hw * phiK[s][p], wb = wPsi[i] * phiK[s][p];
-                            mP0[s][p] += wa;
-                            mP1[s][p] = fma(wa, Iv[i], mP1[s][p]);
-                            mQ1[s][p] += wb;
-                            mQ2[s][p] = fma(wb, phiK[s][p], mQ2[s][p]);
-                            if (NL > 1 && s == 0)
-                                mQ12[p] = fma(wb, phiK[NLc - 1][p], mQ12[p]);
+#pragma unroll
+                            for (int p = 0; p < D; ++p)
+                                phB[p] = 0.0;
                         }
+                    }
+#pragma unroll
+                    for (int p = 0; p < D; ++p)
+                    {
+                        const int i = MI(p);
+                        const double wa = hw * ph[p], wb = wPsi[i] * ph[p];
+                        mP0[p] += wa;
+                        mP1[p] = fma(wa, Iv[i], mP1[p]);
+                        mQ1[p] += wb;
+                        mQ2[p] = fma(wb, ph[p], mQ2[p]);
+                        if (NL > 1)
+                            mQ12[p] = fma(wb, phB[p], mQ12[p]);
                     }
                 }
             }
@@ -1172,7 +1222,14 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
     // for formal_sol's upOnly) -- all of them, or this wavefront's share when the tile's rays are split over S wavefronts
     // (written as the loop over mu with its two directions guarded, not as a loop over q with a direction branch: the
     // latter makes the compiler hoist three dozen registers of addresses and flags in front of the loop, and spill)
+    for (run = 0; run < NRUN; ++run)
+    {
+    prefetch_first();
+#ifdef LS_ABL_NO_RAYS
+    if (dyn.nPass == 77)
+#else
     if (dyn.nPass == 2)
+#endif
     {
         for (int mu = q0 >> 1; 2 * mu < q1; ++mu)
         {
@@ -1183,9 +1240,16 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         }
     }
     else
+#ifdef LS_ABL_NO_RAYS
+        if (dyn.nPass == 78)
+#endif
         for (int mu = q0; mu < q1; ++mu)
             pass(std::true_type{}, mu, (unsigned)(mu * 2 + 3) * Ns8);
+#ifdef LS_ABL_NO_SLOTFIN
+    if (MOM && dyn.nPass == 77)
+#else
     if constexpr (MOM)
+#endif
     {
         // ---- the slots' rate integrals from the moments, half a block at a time -------------------------------------------
         // A level sum of a slot is affine in the profiles: X = X0 + sum_l X_l phi_l (X0: the slot's continuum row; X_l: the
@@ -1199,9 +1263,13 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
         //   mixed c:  Gij += K_c [U_c W + V_c (J - L(eta_A)) - B(chi_i, U_j)]                    Rij += K_c alpha J
         //             Gji += K_c [alpha (J - L(eta_A)) - B(chi_j, U_i)]                          Rji += K_c (U_c W + V_c J)
         // (K = w_lambda 4 pi / hc w_phi; K_op = K for active atoms, 0 for detailed ones; the quadrature weights are in the moments)
-        auto slot_finish_half = [&](auto hTag) {
-            constexpr int H = decltype(hTag)::value, HP = D / 2;
+        auto slot_finish_half = [&](auto hTag, auto npTag) {
+            constexpr int H = decltype(hTag)::value, HP = decltype(npTag)::value; // points H .. H + HP - 1 of the block
             const unsigned vK = c.vK + (unsigned)H * 8u, vRow = c.vRow + (unsigned)H * 8u;
+            // (the accumulator addresses are formed here: hoisted in front of a blend's run loop they are two dozen registers
+            // held -- spilled -- over the rays)
+            double* accB = accBase;
+            asm volatile("" : "+v"(accB));
             // the lines' coefficients per unit profile at these points
             double c2[NLc][HP], cu[NLc][HP], cx[NLc][HP], ce[NLc][HP];
 #pragma unroll
@@ -1213,12 +1281,13 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     ls_lds<HP>(sDep, vK, lnI[s], ni);
                     ls_lds<HP>(sDep, vK, lnJ[s], nj);
                     load_rho0(s, std::integral_constant<int, HP>{}, (unsigned)H, rho);
+                    const LinePar lp = line_par(s);
 #pragma unroll
                     for (int p = 0; p < HP; ++p)
                     {
-                        c2[s][p] = (la2[s] * rho[p]) * la0[s];
-                        cu[s][p] = la3[s] * c2[s][p];
-                        cx[s][p] = ni[p] * la0[s] - nj[p] * c2[s][p];
+                        c2[s][p] = (lp.a2 * rho[p]) * lp.a0;
+                        cu[s][p] = lp.a3 * c2[s][p];
+                        cx[s][p] = ni[p] * lp.a0 - nj[p] * c2[s][p];
                         ce[s][p] = nj[p] * cu[s][p];
                     }
                 }
@@ -1247,17 +1316,25 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 f.ui[l] = sUi * cu[l][p];
                 f.uj[l] = sUj * cu[l][p];
             };
-            auto Q2of = [&](const int l, const int m, const int P) { return l == m ? mQ2[l][P] : mQ12[P]; };
+            // what this run accumulated (a blend's run 0: J, M1, W, line 0 and Q_01; its run 1: line 1 alone)
+            auto cur = [&](const int l) { return NRUN == 1 ? l == 0 : l == run; };
+            auto Q1of = [&](const int l, const int P) { return cur(l) ? mQ1[P] : 0.0; };
+            auto Q2of = [&](const int l, const int m, const int P) { return l == m ? (cur(l) ? mQ2[P] : 0.0) : (run == 0 ? mQ12[P] : 0.0); };
+            auto P0of = [&](const int l, const int P) { return cur(l) ? mP0[P] : 0.0; };
+            auto P1of = [&](const int l, const int P) { return cur(l) ? mP1[P] : 0.0; };
+            auto M1of = [&](const int P) { return (NRUN == 1 || run == 0) ? M1[P] : 0.0; };
+            auto Jof = [&](const int P) { return (NRUN == 1 || run == 0) ? Jk[P] : 0.0; };
+            const double Wof = (NRUN == 1 || run == 0) ? mW : 0.0;
             auto Lin = [&](const double X0, const double (&X)[NLc], const int P) {
-                double r = X0 * M1[P];
+                double r = X0 * M1of(P);
 #pragma unroll
                 for (int l = 0; l < NLc; ++l)
                     if (l < NL)
-                        r = fma(X[l], mQ1[l][P], r);
+                        r = fma(X[l], Q1of(l, P), r);
                 return r;
             };
             auto LinS = [&](const int s, const double X0, const double (&X)[NLc], const int P) {
-                double r = X0 * mQ1[s][P];
+                double r = X0 * Q1of(s, P);
 #pragma unroll
                 for (int l = 0; l < NLc; ++l)
                     if (l < NL)
@@ -1265,13 +1342,13 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                 return r;
             };
             auto Bil = [&](const double X0, const double (&X)[NLc], const double Y0, const double (&Y)[NLc], const int P) {
-                double r = (X0 * Y0) * M1[P];
+                double r = (X0 * Y0) * M1of(P);
 #pragma unroll
                 for (int l = 0; l < NLc; ++l)
                 {
                     if (l < NL)
                     {
-                        r = fma(fma(X0, Y[l], X[l] * Y0), mQ1[l][P], r);
+                        r = fma(fma(X0, Y[l], X[l] * Y0), Q1of(l, P), r);
 #pragma unroll
                         for (int m = 0; m < NLc; ++m)
                             if (m < NL)
@@ -1303,6 +1380,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                     double lr[5][HP], wphi[HP];
                     load_rows(lrow[s], lzm[s], lr);
                     ls_lds<HP>(sDep, vK, lwO[s], wphi);
+                    const LinePar lp = line_par(s);
 #pragma unroll
                     for (int p = 0; p < HP; ++p)
                     {
@@ -1315,17 +1393,17 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                             if (l < NL)
                                 coupled(ccL[s][l], l == s, l, p, f);
                         }
-                        const double K = lcw1[s] * wphi[p];
+                        const double K = lp.cw1 * wphi[p];
                         const double Kop = (lfl[s] & 1) ? K : 0.0; // detailed atoms: rates only
-                        const double up = fma(cu[s][p], mP0[s][P], c2[s][p] * mP1[s][P]); // sum w (U_ji + V_ji I)
+                        const double up = fma(cu[s][p], P0of(s, P), c2[s][p] * P1of(s, P)); // sum w (U_ji + V_ji I)
                         const double LsE = LinS(s, lr[0][p], f.e, P);
                         const double g0 = ((up - c2[s][p] * LsE) - Bil(lr[1][p], f.xi, lr[4][p], f.uj, P)) * Kop;
-                        const double g1 = ((la0[s] * (mP1[s][P] - LsE)) - Bil(lr[2][p], f.xj, lr[3][p], f.ui, P)) * Kop;
-                        const double g2 = (la0[s] * mP1[s][P]) * K;
+                        const double g1 = ((lp.a0 * (P1of(s, P) - LsE)) - Bil(lr[2][p], f.xj, lr[3][p], f.ui, P)) * Kop;
+                        const double g2 = (lp.a0 * P1of(s, P)) * K;
                         const double g3 = up * K;
                         if (act)
                         {
-                            double* dst = accBase + lacc[s] + (unsigned)(P * LR);
+                            double* dst = accB + lacc[s] + (unsigned)(P * LR);
                             lds_add(dst, g0);
                             lds_add(dst + D * LR, g1);
                             lds_add(dst + 2 * D * LR, g2);
@@ -1335,9 +1413,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                         if (lms[s] >= 0)
                         {
                             if (NL < 2 || lms[s] == 0)
-                                Me[0][P] = fma(ce[s][p], mQ1[s][P], Me[0][P]);
+                                Me[0][P] = fma(ce[s][p], Q1of(s, P), Me[0][P]);
                             else
-                                Me[1][P] = fma(ce[s][p], mQ1[s][P], Me[1][P]);
+                                Me[1][P] = fma(ce[s][p], Q1of(s, P), Me[1][P]);
                         }
                     }
                 }
@@ -1363,14 +1441,14 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
                                 coupled(ccM[m][l], false, l, p, f);
                         }
                         const double w1 = mb0[m], w2 = mvji[p], uji = mb2[m] * w2;
-                        const double Jeff = Jk[P] - Lin(mr[0][p], f.e, P);
-                        const double uw = fma(uji, mW, w2 * Jk[P]); // sum w (U_ji + V_ji I)
+                        const double Jeff = Jof(P) - Lin(mr[0][p], f.e, P);
+                        const double uw = fma(uji, Wof, w2 * Jof(P)); // sum w (U_ji + V_ji I)
                         if (act)
                         {
-                            double* dst = accBase + macc[m] + (unsigned)(P * LR);
-                            lds_add(dst, ((uji * mW + w2 * Jeff) - Bil(mr[1][p], f.xi, mr[4][p], f.uj, P)) * mcw1[m]);
+                            double* dst = accB + macc[m] + (unsigned)(P * LR);
+                            lds_add(dst, ((uji * Wof + w2 * Jeff) - Bil(mr[1][p], f.xi, mr[4][p], f.uj, P)) * mcw1[m]);
                             lds_add(dst + D * LR, ((w1 * Jeff) - Bil(mr[2][p], f.xj, mr[3][p], f.ui, P)) * mcw1[m]);
-                            lds_add(dst + 2 * D * LR, (w1 * Jk[P]) * mcw1[m]);
+                            lds_add(dst + 2 * D * LR, (w1 * Jof(P)) * mcw1[m]);
                             lds_add(dst + 3 * D * LR, uw * mcw1[m]);
                         }
                     }
@@ -1378,11 +1456,32 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTi
             }
         };
         LS_PHASE();
-        slot_finish_half(std::integral_constant<int, 0>{});
+        if constexpr (NL > 1)
+        {
+            // (a blend: a point at a time -- two lines' coefficients and level sums are twice the registers)
+            slot_finish_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            LS_PHASE();
+            slot_finish_half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            LS_PHASE();
+            slot_finish_half(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+            LS_PHASE();
+            slot_finish_half(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+        }
+        else
+        {
+            slot_finish_half(std::integral_constant<int, 0>{}, std::integral_constant<int, D / 2>{});
+            LS_PHASE();
+            slot_finish_half(std::integral_constant<int, D / 2>{}, std::integral_constant<int, D / 2>{});
+        }
         LS_PHASE();
-        slot_finish_half(std::integral_constant<int, D / 2>{});
-        LS_PHASE();
+        if (NRUN > 1)
+        {
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+                mP0[p] = mP1[p] = mQ1[p] = mQ2[p] = mQ12[p] = 0.0;
+        }
     }
+    } // run
 #ifdef LS_TIMING
     if (c.lane == 0 && a.lsDbg)
     {
@@ -1412,22 +1511,40 @@ struct LaneFinRecs
 {
     unsigned nI, nJ, rat, w6, w7, code, ops; // DevContRec dwords 0, 1, 2, 6 (sUj | flags << 16 | ms << 24), 7 (tr | cs << 16)
 };
-DEVINL LaneFinRecs lane_fin_recs(const CONST_AS TileArgs& a, const DevLaHeader& h, const int ti, const int nCont, const int lane)
+DEVINL LaneFinRecs lane_fin_recs(const CONST_AS TileArgs& a, const int ti, const int nCont, const int lane)
 {
     LaneFinRecs r{};
     if (lane < nCont)
     {
-        const GLOBAL_AS unsigned* w = (const GLOBAL_AS unsigned*)(const void*)(a.contRec + h.off + h.nLine + lane);
+        // (the tile's flat record of continuum `lane`: one 32-byte load, its address known from the tile index alone)
+        const GLOBAL_AS unsigned* w = (const GLOBAL_AS unsigned*)(const void*)(a.laneFin + (size_t)ti * LWHIP_POST_MAXC + lane);
         r.nI = w[0];
         r.nJ = w[1];
         r.rat = w[2];
-        r.w6 = w[6];
-        r.w7 = w[7];
-        const GLOBAL_AS DevPostProg* pg = (const GLOBAL_AS DevPostProg*)(const void*)(a.postProg + ti);
-        r.code = pg->code[lane];
-        r.ops = pg->ops[lane];
+        r.w6 = w[3];
+        r.w7 = w[4];
+        r.code = w[5];
+        r.ops = w[6];
     }
     return r;
+}
+// the per-(continuum, wavelength) parameters alpha, w_lambda / lambda 4 pi / h, 2hc / lambda^3 of the tile's wavelengths into
+// the wavefront's LDS block: lane (ray r, block q) fetches continuum q of its wavelength -- one memory round trip for all of
+// them, from the tile's flat table
+DEVINL void lane_fin_params(const CONST_AS TileArgs& a, const LaneCtx& c, const int ti, const int nCont)
+{
+    for (int q0 = 0; q0 < nCont; q0 += c.LR)
+    {
+        const int q = q0 + c.blk;
+        if (q < nCont && c.act)
+        {
+            const GLOBAL_AS double* src = GCD(a.laneFinPar) + (((size_t)ti * LWHIP_POST_MAXC + q) * c.L + c.r) * 3;
+            double* dst = c.sPP + (q * c.L + c.r) * 3;
+            dst[0] = src[0];
+            dst[1] = src[1];
+            dst[2] = src[2];
+        }
+    }
 }
 struct LaneFinRec1 // one continuum's words, uniform
 {
@@ -1450,9 +1567,8 @@ DEVINL LaneFinRec1 lane_fin_rec(const LaneFinRecs& v, const int q)
 }
 
 template <int D, int P0, int NP>
-DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const DevLaHeader& h, const int ti, const int nCont,
-                             const LaneFinRecs& recs, double* sAcc, const int slotOffLa, const int ms0, const int ms1,
-                             const double (&Jk)[D], const double (&M1)[D], const double (&Me)[2][D])
+DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const int nCont, const LaneFinRecs& recs, double* sAcc,
+                             const int ms0, const int ms1, const double (&Jk)[D], const double (&M1)[D], const double (&Me)[2][D])
 {
     const int Nmu = c.Nmu, LR = c.LR;
     const unsigned vK = c.vK + (unsigned)P0 * 8u;
@@ -1460,9 +1576,6 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
     for (int m = 0; m < Nmu; ++m)
         for (int d = 0; d < 2; ++d)
             Wsum += 0.5 * CTAB(double, a.wmu)[m];
-    (void)h;
-    (void)ti;
-    (void)slotOffLa;
     double boltz[NP];
     {
         double rT[NP];
@@ -1615,13 +1728,26 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
 }
 
 template <int D>
-DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, const LaneCtx& c,
+DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLaneTile& tr, const int ti, const LaneCtx& c,
                         double* sAcc, unsigned long long* sDj, const int ms0, const int ms1, const double (&Jk)[D],
                         const double (&M1)[D], const double (&Me)[2][D])
 {
     const int Ns = c.Ns, k0 = c.k0;
     int la = c.la;
     LS_KEEPI(la); // (nothing of the finish is computed before the rays are done)
+    // the finish's records and parameters are requested first: they arrive while J goes out
+    const int nCont = dyn.prdOnly ? 0 : tr.nCont;
+#ifdef LS_X2
+    const LaneFinRecs recs{};
+#else
+    const LaneFinRecs recs = lane_fin_recs(a, ti, nCont, c.lane);
+#endif
+#ifndef LS_X1
+    lane_fin_params(a, c, ti, nCont);
+#endif
+#ifdef LS_X3
+    if (dyn.nPass == 77)
+#endif
     {
         double dj = 0.0;
         if (c.act)
@@ -1639,36 +1765,12 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
             atomicMax(sDj + c.rRaw, (unsigned long long)__double_as_longlong(dj));
         }
     }
-    const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + td.la0); // the tile's (uniform) structure
-    const int nCont = (!dyn.prdOnly && h.nPure > 0) ? h.nMixed + h.nPure : 0;
     if (nCont <= 0)
         return;
-    const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
-    const LaneFinRecs recs = lane_fin_recs(a, h, ti, nCont, c.lane);
     static_assert(D % 2 == 0, "the block is finished in halves");
-    {
-        // the per-(continuum, wavelength) parameters alpha, w_lambda / lambda 4 pi / h, 2hc / lambda^3 of the tile's
-        // wavelengths into the wavefront's LDS block: lane (ray r, block q) fetches continuum q of its wavelength -- one
-        // memory round trip for all of them instead of one per continuum, walk and half
-        const CONST_AS DevContRec* cr = CTAB(DevContRec, a.contRec) + h.off + h.nLine;
-        const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
-        for (int q0 = 0; q0 < nCont; q0 += c.LR)
-        {
-            const int q = q0 + c.blk;
-            if (q < nCont && c.act)
-            {
-                const unsigned pOff = ((const GLOBAL_AS DevContRec*)(const void*)(a.contRec + h.off + h.nLine))[q].pOff;
-                double* dst = c.sPP + (q * c.L + c.r) * 3;
-                dst[0] = *(const GLOBAL_AS double*)(lsB + pOff);
-                dst[1] = *(const GLOBAL_AS double*)(lsB + pOff + 8);
-                dst[2] = *(const GLOBAL_AS double*)(lsB + pOff + 16);
-            }
-        }
-        (void)cr;
-    }
-    lane_finish_part<D, 0, D / 2>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    lane_finish_part<D, 0, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
     LS_PHASE();
-    lane_finish_part<D, D / 2, D / 2>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+    lane_finish_part<D, D / 2, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
 }
 
 // ---- a tile's rays split over the S wavefronts of a group (small problems: more, shorter tasks) -----------------------------
@@ -1753,7 +1855,7 @@ DEVINL void lane_split_exchange_read(const double* sX, const int sub, const int 
 }
 // lane_finish for wavefront `sub` of S: its D / S points of every block
 template <int D, int S>
-DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, const LaneCtx& c,
+DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLaneTile& tr, const int ti, const LaneCtx& c,
                               const int sub, double* sAcc, unsigned long long* sDj, const int ms0, const int ms1, const double (&Jk)[D],
                               const double (&M1)[D], const double (&Me)[2][D])
 {
@@ -1761,6 +1863,9 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
     const int Ns = c.Ns, k0 = c.k0;
     int la = c.la;
     LS_KEEPI(la);
+    const int nCont = dyn.prdOnly ? 0 : tr.nCont;
+    const LaneFinRecs recs = lane_fin_recs(a, ti, nCont, c.lane);
+    lane_fin_params(a, c, ti, nCont);
     {
         double dj = 0.0;
         if (c.act)
@@ -1785,82 +1890,70 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
             atomicMax(sDj + c.rRaw, (unsigned long long)__double_as_longlong(dj)); // non-negative doubles order as integers
         }
     }
-    const DevLaHeader h = ld_c(CTAB(DevLaHeader, a.laHdr) + td.la0); // the tile's (uniform) structure
-    const int nCont = (!dyn.prdOnly && h.nPure > 0) ? h.nMixed + h.nPure : 0;
     if (nCont <= 0)
         return;
-    const int slotOffLa = ((const GLOBAL_AS DevLaHeader*)a.laHdr)[la].off;
-    const LaneFinRecs recs = lane_fin_recs(a, h, ti, nCont, c.lane);
-    {
-        // (the per-(continuum, wavelength) parameters into the wavefront's LDS block: as lane_finish)
-        const GLOBAL_AS char* lsB = (const GLOBAL_AS char*)a.slots + (size_t)slotOffLa * sizeof(DevSlot);
-        for (int q0 = 0; q0 < nCont; q0 += c.LR)
-        {
-            const int q = q0 + c.blk;
-            if (q < nCont && c.act)
-            {
-                const unsigned pOff = ((const GLOBAL_AS DevContRec*)(const void*)(a.contRec + h.off + h.nLine))[q].pOff;
-                double* dst = c.sPP + (q * c.L + c.r) * 3;
-                dst[0] = *(const GLOBAL_AS double*)(lsB + pOff);
-                dst[1] = *(const GLOBAL_AS double*)(lsB + pOff + 8);
-                dst[2] = *(const GLOBAL_AS double*)(lsB + pOff + 16);
-            }
-        }
-    }
     if (sub == 0)
-        lane_finish_part<D, 0, NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, 0, NP>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
     else if (sub == 1)
-        lane_finish_part<D, NP, NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, NP, NP>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
     else if (S > 2 && sub == 2)
-        lane_finish_part<D, (S > 2 ? 2 * NP : 0), NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, (S > 2 ? 2 * NP : 0), NP>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
     else if (S > 2)
-        lane_finish_part<D, (S > 2 ? 3 * NP : 0), NP>(a, c, h, ti, nCont, recs, sAcc, slotOffLa, ms0, ms1, Jk, M1, Me);
+        lane_finish_part<D, (S > 2 ? 3 * NP : 0), NP>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
 }
 
 // One task = one tile (up to R wavelengths): every ray of it, or (S > 1) the share of wavefront `sub` of the tile's group.
 template <int SOLVER, int D, int MODE>
-DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int ti, const bool have, const int S,
+DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLaneTile& tr, const int ti, const bool have, const int S,
                       const int sub, double* sAcc, unsigned long long* sDj, double* sB, const double* sExp, const char* sDep,
                       double* sRow3, double* sX, double* sPP, const int lane)
 {
     constexpr bool RATES = (MODE & 1) != 0;
     LS_T(tt0);
+    const DevTile& td = tr.td;
     // this wavefront's rays of the iteration's list
     const int nRays = a.Nmu * dyn.nPass;
     const int shS = S == 4 ? 2 : S == 2 ? 1 : 0;
     const int q0 = (sub * nRays) >> shS, q1 = ((sub + 1) * nRays) >> shS;
-    LaneCtx c;
-    c.sPP = sPP;
-    c.ti = ti;
-    c.sExp = sExp;
-    c.sDep = sDep;
-    c.sRow3 = sRow3;
-    c.Ns = a.Ns;
-    c.Nmu = a.Nmu;
-    c.LR = a.laneLR;
-    c.LRD = a.laneLRD;
-    c.L = a.L;
-    c.lane = lane;
-    c.rRaw = lane / a.laneLR;
-    c.blk = lane - c.rRaw * a.laneLR;
-    c.act = c.rRaw < td.nl;
-    c.r = min(c.rRaw, td.nl - 1);
-    c.k0 = c.blk * D;
-    c.la = td.la0 + c.r;
-    c.nV = min(max(c.Ns - c.k0, 0), D);
-    c.pBot = c.Ns - 1 - c.k0;
-    c.wav = GCD(a.wavelength)[c.la];
-    c.vK = (unsigned)c.k0 * 8u;
-    c.vRow = (unsigned)(c.r * c.LRD + c.k0) * 8u;
-    c.rowStride = (unsigned)(c.L * c.LRD) * 8u;
-    c.Ns8 = (unsigned)c.Ns * 8u;
-    c.gStride = (unsigned)(c.LRD + 2) * 8u;
-    c.oN = a.depN;
-    c.oW = a.depW;
-    c.oRat = a.depRat;
-    c.oG = a.depG;
-    c.rRows = a.rows + td.rowBase;
-    c.sB = sB;
+    // what a lane is in its tile: formed for the rays and formed AGAIN for the finish from the lane number (a dozen integer
+    // operations) -- kept alive over the ray loop it would be a dozen registers that the kernel does not have
+    auto lane_ctx = [&](int ln) {
+        asm volatile("" : "+v"(ln)); // (recomputed from here on)
+        LaneCtx c;
+        c.sPP = sPP;
+        c.ti = ti;
+        c.sExp = sExp;
+        c.sDep = sDep;
+        c.sRow3 = sRow3;
+        c.Ns = a.Ns;
+        c.Nmu = a.Nmu;
+        c.LR = a.laneLR;
+        c.LRD = a.laneLRD;
+        c.L = a.L;
+        c.lane = ln;
+        c.rRaw = ln / a.laneLR;
+        c.blk = ln - c.rRaw * a.laneLR;
+        c.act = c.rRaw < td.nl;
+        c.r = min(c.rRaw, td.nl - 1);
+        c.k0 = c.blk * D;
+        c.la = td.la0 + c.r;
+        c.nV = min(max(c.Ns - c.k0, 0), D);
+        c.pBot = c.Ns - 1 - c.k0;
+        c.vK = (unsigned)c.k0 * 8u;
+        c.vRow = (unsigned)(c.r * c.LRD + c.k0) * 8u;
+        c.rowStride = (unsigned)(c.L * c.LRD) * 8u;
+        c.Ns8 = (unsigned)c.Ns * 8u;
+        c.gStride = (unsigned)(c.LRD + 2) * 8u;
+        c.oN = a.depN;
+        c.oW = a.depW;
+        c.oRat = a.depRat;
+        c.oG = a.depG;
+        c.rRows = a.rows + td.rowBase;
+        c.sB = sB;
+        c.wav = 0.0;
+        return c;
+    };
+    LaneCtx c = lane_ctx(lane);
     double Jk[D], M1[D], Me[2][D];
 #pragma unroll
     for (int p = 0; p < D; ++p)
@@ -1869,27 +1962,31 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
     if (have)
     {
 #if defined(LS_ISA_ONLY) && defined(LS_ONLY_NL) /* one tile kind, for register / instruction counts of the listing */
-        ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+        ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
         if (LS_ONLY_NL < 2)
             ms1 = -2;
 #else
         if (td.nLine == 0)
         {
-            lane_rays<SOLVER, D, 0, 0, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            lane_rays<SOLVER, D, 0, 0, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
             ms0 = ms1 = -2;
         }
         else if (td.nLine == 1 && td.nMixed == 0)
         {
-            ms0 = lane_rays<SOLVER, D, 1, 0, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            ms0 = lane_rays<SOLVER, D, 1, 0, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
             ms1 = -2;
         }
         else if (td.nLine == 1)
         {
-            ms0 = lane_rays<SOLVER, D, 1, 1, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+            ms0 = lane_rays<SOLVER, D, 1, 1, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
             ms1 = -2;
         }
         else
-            lane_rays<SOLVER, D, 2, 0, MODE>(a, dyn, td, c, sAcc, q0, q1, Jk, M1, Me);
+#ifndef LS_X_NO20
+            lane_rays<SOLVER, D, 2, 0, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
+#else
+            ms0 = -2;
+#endif
 #endif
     }
     LS_T(tt1);
@@ -1913,14 +2010,20 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevT
                 lane_split_exchange_read<D, 4>(sX, sub, lane, Jk, M1, Me);
         }
     }
+#ifdef LS_ABL_NO_FINISH
+    if (RATES && have && dyn.nPass == 77)
+#else
     if (RATES && have)
+#endif
     {
+        c = lane_ctx(lane);
+        c.wav = ((const GLOBAL_AS DevLaneRay*)a.laneRays)[(size_t)ti * a.L + min(c.rRaw, a.L - 1)].wav;
         if (S == 1)
-            lane_finish<D>(a, dyn, td, ti, c, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+            lane_finish<D>(a, dyn, tr, ti, c, sAcc, sDj, ms0, ms1, Jk, M1, Me);
         else if (S == 2)
-            lane_finish_split<D, 2>(a, dyn, td, ti, c, sub, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+            lane_finish_split<D, 2>(a, dyn, tr, ti, c, sub, sAcc, sDj, ms0, ms1, Jk, M1, Me);
         else
-            lane_finish_split<D, 4>(a, dyn, td, ti, c, sub, sAcc, sDj, ms0, ms1, Jk, M1, Me);
+            lane_finish_split<D, 4>(a, dyn, tr, ti, c, sub, sAcc, sDj, ms0, ms1, Jk, M1, Me);
     }
     if (RATES && S > 1)
         __syncthreads(); // the group's dJ maxima are complete; the row blocks may be overwritten by the next round
@@ -1957,11 +2060,11 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nWaves = blockDim.x >> 6;
-    const int chunk = a.chunkOrder ? CTAB(int32_t, a.chunkOrder)[blockIdx.x] : (int)blockIdx.x;
-    // S > 1: the rays of a tile are split over the S consecutive wavefronts of a group (sub = 0 .. S - 1); the launch's value,
-    // or the chunk's own (the short chunks of a long launch's tail)
-    const int Sraw = a.chunkSplit ? CTAB(int32_t, a.chunkSplit)[chunk] : a.laneSplit;
-    const int S = Sraw > 1 ? Sraw : 1;
+    // the workgroup's record: its chunk, the chunk's tiles and split factor (S > 1: the rays of a tile are split over the S
+    // consecutive wavefronts of a group, sub = 0 .. S - 1 -- small launches, and the short chunks of a long launch's tail)
+    const DevLaneWg wg = ld_c(CTAB(DevLaneWg, a.laneWg) + blockIdx.x);
+    const int chunk = wg.chunk;
+    const int S = wg.split;
     // (S is 1, 2 or 4: shifts, and the results pinned in SGPRs -- an integer division is done in the vector unit and would
     // leave every pointer derived from it in VGPRs)
     const int sh = S == 4 ? 2 : S == 2 ? 1 : 0;
@@ -1979,12 +2082,23 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     {
         // the depth-only pools (populations, w_phi, nStar ratios, geometry) are the same for every tile: one LDS copy per
         // workgroup serves all rays of all its tiles
+        // (eight loads in flight per thread: one after the other the copy is ~13 dependent memory round trips per workgroup)
         const GLOBAL_AS double* src = GCD(a.depBase);
         const int nDep = (int)(a.depBytes >> 3);
-        for (int idx = t; idx < nDep; idx += blockDim.x)
-            sDep[idx] = src[idx];
+        const int T = blockDim.x;
+        for (int base = t; base < nDep; base += 8 * T)
+        {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = base + q * T < nDep ? src[base + q * T] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (base + q * T < nDep)
+                    sDep[base + q * T] = v[q];
+        }
     }
-    const int t0 = CTAB(int32_t, a.chunkTile)[chunk], t1 = CTAB(int32_t, a.chunkTile)[chunk + 1];
+    const int t0 = wg.t0, t1 = wg.t1;
     if (RATES)
     {
         for (int idx = t; idx < maxCT * 4 * LRD; idx += blockDim.x)
@@ -2003,12 +2117,12 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
             break;
         const int li = have ? li0 : t0;
         const int ti = tileList ? tileList[li] : li;
-        const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
+        const DevLaneTile tr = ld_c(CTAB(DevLaneTile, a.laneTiles) + ti);
         if (RATES && lane < LS_MAX_R && (S == 1 || sub == 0))
             sDj[lane] = 0ull; // (S > 1: before the task's first barrier, the maxima are added after it)
-        lane_task<SOLVER, D, MODE>(a, dyn, td, ti, have, S, sub, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sX, sPP, lane);
-        if (RATES && have && sub == 0 && lane < td.nl)
-            GD(a.dJ)[td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
+        lane_task<SOLVER, D, MODE>(a, dyn, tr, ti, have, S, sub, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sX, sPP, lane);
+        if (RATES && have && sub == 0 && lane < tr.td.nl)
+            GD(a.dJ)[tr.td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
     }
     if (RATES)
     {
@@ -2072,8 +2186,13 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restric
 }
 
 #ifdef LS_ISA_ONLY /* one instance, for instruction counts of the listing (tools/isa_loops.py) */
-template __global__ void lanesweep_kernel<LWHIP_FS_BEZIER3_1D, 4, 1, false>(const TileArgs* __restrict__, const TileArgs* const* __restrict__,
-                                                                            const TileDyn);
+#ifndef LS_ISA_SOLVER
+#define LS_ISA_SOLVER LWHIP_FS_BEZIER3_1D
+#define LS_ISA_MODE 1
+#define LS_ISA_BATCH false
+#endif
+template __global__ void lanesweep_kernel<LS_ISA_SOLVER, 4, LS_ISA_MODE, LS_ISA_BATCH>(const TileArgs* __restrict__, const TileArgs* const* __restrict__,
+                                                                                       const TileDyn);
 #else
 template <int SOLVER, int D, int MODE>
 hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int nChunks, int waves,
