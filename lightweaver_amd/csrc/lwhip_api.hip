@@ -2131,8 +2131,9 @@ int build_tile_args(lwhip_context* c)
         // phase clocks of a -DLS_TIMING / -DRM_TIMING build: host-mapped, dumped by lwhip_destroy
         if (!c->lsDbgHost)
         {
-            HIP_TRY(hipHostMalloc((void**)&c->lsDbgHost, (size_t)c->nTiles * 8 * sizeof(double), hipHostMallocMapped));
-            std::memset(c->lsDbgHost, 0, (size_t)c->nTiles * 8 * sizeof(double));
+            // [nTiles][8] per tile, then [workgroup][4]: prologue, tasks, epilogue clocks (lane sweep)
+            HIP_TRY(hipHostMalloc((void**)&c->lsDbgHost, (size_t)c->nTiles * 24 * sizeof(double), hipHostMallocMapped));
+            std::memset(c->lsDbgHost, 0, (size_t)c->nTiles * 24 * sizeof(double));
         }
         HIP_TRY(hipHostGetDevicePointer((void**)&a.lsDbg, c->lsDbgHost, 0));
     }
@@ -2472,6 +2473,23 @@ int lwhip_destroy(lwhip_context* c)
             for (const auto& kv : kinds)
                 std::fprintf(stderr, "lane sweep clocks, tiles of kind (%d lines, %d mixed): %d tiles, task mean %.0f max %.0f\n", kv.first / 10,
                              kv.first % 10, (int)kv.second[0], kv.second[1] / kv.second[0], kv.second[2]);
+        }
+        {
+            double w[3] = { 0, 0, 0 };
+            int nw = 0;
+            for (int b = 0; b < 4 * c->nTiles; ++b)
+            {
+                const double* o = c->lsDbgHost + (size_t)c->nTiles * 8 + (size_t)b * 4;
+                if (o[1] > 0.0)
+                {
+                    ++nw;
+                    for (int q = 0; q < 3; ++q)
+                        w[q] += o[q];
+                }
+            }
+            if (nw)
+                std::fprintf(stderr, "lane sweep workgroup clocks (mean over %d workgroups): prologue %.0f tasks %.0f epilogue %.0f\n", nw, w[0] / nw,
+                             w[1] / nw, w[2] / nw);
         }
         std::fprintf(stderr, "lane sweep phase clocks per tile (mean): setup %.0f gather %.0f stencils %.0f coefficients %.0f scan %.0f rates %.0f finish %.0f total %.0f (max %.0f) over %d tiles\n",
                      sum[0] / c->nTiles, sum[1] / c->nTiles, sum[2] / c->nTiles, sum[3] / c->nTiles, sum[4] / c->nTiles, sum[5] / c->nTiles,

@@ -635,6 +635,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         {
             // piecewise_bezier3_1d_impl FormalScalar.cpp:209-325, every quantity of the march formed per point
             double x[D], dS[D], dSP; // optical depth of the intervals, dS / dtau at the points
+            double rx[D];            // 1 / x: serves the S slopes here and, cubed, the coefficients' 1 / x^3
             {
                 double ds[D + 1], sl[D + 1];
 #pragma unroll
@@ -667,7 +668,8 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                     double t = ds[i] * (cu + cd + Cuw + C0) * 0.25;
                     t = (is_first(i) || !is_ok(i)) ? 1.0 : t;
                     x[i] = t;
-                    sS[i] = (SRC(i) - SRC(i - 1)) * ls_rcp(t);
+                    rx[i] = ls_rcp(t);
+                    sS[i] = (SRC(i) - SRC(i - 1)) * rx[i];
                 }
                 const double dtN = ls_shift1<UP>(x[0]), sSN = ls_shift1<UP>(sS[0]);
                 // dS / dtau at the points (:247, :254-255)
@@ -730,7 +732,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                 const double x2 = xi * xi, x3 = x2 * xi;
                 const double exr = ls_exp_neg(-fmin(xi, 64.0), c.sExp);
                 const double ex = (xi > 30.0) ? 0.0 : exr;
-                const double r3 = ls_rcp(x3);
+                // (1 / x^3 from the stencils' 1 / x: two multiplications instead of a quarter-rate reciprocal and its Newton step;
+                // at the ray's last point x was replaced by the closing step's optical depth, whose coefficients do not use it)
+                const double r3 = (rx[i] * rx[i]) * rx[i];
                 const bool small = xi < 5e-2;
                 // both branches are evaluated on every lane and selected at once: straight-line code, two values in flight
                 auto pick = [&](double g, double t) {
@@ -1469,9 +1473,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         }
         else
         {
-            slot_finish_half(std::integral_constant<int, 0>{}, std::integral_constant<int, D / 2>{});
-            LS_PHASE();
-            slot_finish_half(std::integral_constant<int, D / 2>{}, std::integral_constant<int, D / 2>{});
+            // (the whole block at once: every load of the slots' rows, populations and parameters is in flight together --
+            // the registers of the ray loop are free here; measured 0.1342 -> 0.1321 ms against two halves)
+            slot_finish_half(std::integral_constant<int, 0>{}, std::integral_constant<int, D>{});
         }
         LS_PHASE();
         if (NRUN > 1)
@@ -1737,17 +1741,8 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     LS_KEEPI(la); // (nothing of the finish is computed before the rays are done)
     // the finish's records and parameters are requested first: they arrive while J goes out
     const int nCont = dyn.prdOnly ? 0 : tr.nCont;
-#ifdef LS_X2
-    const LaneFinRecs recs{};
-#else
     const LaneFinRecs recs = lane_fin_recs(a, ti, nCont, c.lane);
-#endif
-#ifndef LS_X1
     lane_fin_params(a, c, ti, nCont);
-#endif
-#ifdef LS_X3
-    if (dyn.nPass == 77)
-#endif
     {
         double dj = 0.0;
         if (c.act)
@@ -1982,11 +1977,7 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevL
             ms1 = -2;
         }
         else
-#ifndef LS_X_NO20
             lane_rays<SOLVER, D, 2, 0, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
-#else
-            ms0 = -2;
-#endif
 #endif
     }
     LS_T(tt1);
@@ -2050,6 +2041,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
                                                                        const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
     dbg_poison_lds();
+    LS_T(tk0);
     constexpr bool RATES = (MODE & 1) != 0;
     extern __shared__ double lds[];
     const TileArgs* __restrict__ ap = BATCH ? apList[blockIdx.y] : ap0;
@@ -2106,6 +2098,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     }
     __syncthreads();
     const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
+    LS_T(tk1);
     // rounds of the workgroup: each group takes a tile of the chunk (with S > 1 every wavefront passes the round's barriers,
     // also a group that has no tile left)
     const int nRounds = __builtin_amdgcn_readfirstlane((t1 - t0 + nGroups - 1) / nGroups);
@@ -2124,33 +2117,49 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
         if (RATES && have && sub == 0 && lane < tr.td.nl)
             GD(a.dJ)[tr.td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
     }
+    LS_T(tk2);
     if (RATES)
     {
         __syncthreads();
-        // the chunk's sums go straight into the stage-1 buffer: part = chunk % SPLIT keeps 1/SPLIT of the chunks on one address
+        // the chunk's sums go straight into the stage-1 buffer: part = chunk % SPLIT keeps 1/SPLIT of the chunks on one address.
+        // [slot][quantity][point of the block][block] -> depth k = block * D + point: a wavefront takes a quantity, a lane a
+        // depth -- no integer division per element (the flat loop's three per element were 8 k of a workgroup's 130 k clocks)
         const CONST_AS int32_t* slotTr = CTAB(int32_t, a.slotTr) + (size_t)chunk * maxCT;
         GLOBAL_AS double* r8 = GD(a.red8);
         const int n4 = 4 * Ns;
         const int part = chunk % LWHIP_REDUCE_SPLIT;
-        for (int idx = t; idx < maxCT * 4 * LRD; idx += blockDim.x)
+        for (int k = lane; k < Ns; k += 64) // (consecutive lanes, consecutive depths: a wavefront's atomics cover whole lines)
         {
-            // [slot][quantity][point of the block][block] -> depth k = block * D + point
-            const int cs = idx / (4 * LRD);
-            const int rem = idx - cs * 4 * LRD;
-            const int q = rem / LRD, pb = rem - q * LRD;
-            const int pp = pb / a.laneLR, k = (pb - pp * a.laneLR) * D + pp;
-            const int tr = slotTr[cs];
-            if (a.detSlab)
+            const int pb = (k % D) * a.laneLR + k / D;
+            for (int q = wave; q < 4; q += nWaves)
             {
-                // deterministic mode (LWHIP_OPT_DETERMINISTIC): the workgroup -- one wavefront, so its LDS sums were formed
-                // in program order -- stores its slab; det_reduce_kernel adds the slabs in workgroup order
-                if (k < Ns)
-                    GD(a.detSlab)[((size_t)chunk * maxCT + cs) * n4 + q * Ns + k] = sAcc[idx];
+                for (int cs = 0; cs < maxCT; ++cs)
+                {
+                    const int tr = slotTr[cs];
+                    const double v = sAcc[(cs * 4 + q) * LRD + pb];
+                    if (a.detSlab)
+                    {
+                        // deterministic mode (LWHIP_OPT_DETERMINISTIC): the workgroup -- one wavefront, so its LDS sums were
+                        // formed in program order -- stores its slab; det_reduce_kernel adds the slabs in workgroup order
+                        GD(a.detSlab)[((size_t)chunk * maxCT + cs) * n4 + q * Ns + k] = v;
+                    }
+                    else if (tr >= 0)
+                        unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + q * Ns + k), v);
+                }
             }
-            else if (tr >= 0 && k < Ns)
-                unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + q * Ns + k), sAcc[idx]);
         }
     }
+#ifdef LS_TIMING
+    if (t == 0 && a.lsDbg && !BATCH)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LS_T(tk3);
+        double* o = a.lsDbg + (size_t)a.nTiles * 8 + (size_t)blockIdx.x * 4;
+        o[0] = (double)(tk1 - tk0);
+        o[1] = (double)(tk2 - tk1);
+        o[2] = (double)(tk3 - tk2);
+    }
+#endif
 }
 
 // Deterministic mode: red8[tr][part 0][q][k] = sum of the workgroups' slabs that hold transition tr, in workgroup order

@@ -228,12 +228,17 @@ __global__ void voigt_phi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* __
     }
 }
 
-// wphi[k] = 1 / sum_{la, mu, dir} phi w_lambda(la) w_mu/2 over the line's FULL grid (independent of
-// the wavelength shard).  Workgroup (x, y) owns KT consecutive points (all of them in 1D; tiles of a 2D domain) and the
-// wavelengths of slice y: thread (part, k) sums la = y*P + part, + P*gridDim.y, ...; the workgroup's parts are combined
-// in order into scratch[y][k], and the last workgroup of a point tile to arrive (ticket) adds the slices in order.
-// Where the context holds the whole line (no wavelength shard) the profile just written by voigt_phi_kernel is read
-// back instead of being evaluated a second time (the same bits: same function, same arguments).
+// wphi[k] = 1 / sum_{la, mu, dir} phi w_lambda(la) w_mu/2 over the line's FULL grid (independent of the wavelength
+// shard).  The order of the additions is a function of the LINE alone, so that the same line gets the same bits from
+// lwhip_compute_profiles, from a single-line launch and from lwhip_batch_compute_profiles: the grid is cut into
+// C = clamp(ceil(nltFull / 2P), 1, wphiSlices) canonical slices of P = 1024 / KT interleaved parts (part q of slice y sums
+// la = y P + q, + P C, ...), a slice's parts are added in part order and the slices in slice order -- whatever the launch
+// looks like: a workgroup (x, y) owns KT consecutive points (all of them in 1D; tiles of a 2D domain) and the canonical
+// slices y, y + gridDim.y, ...; with one workgroup per point tile (gridDim.y = 1: large launches, where a ticket per
+// workgroup costs more than it saves) the slices never leave the workgroup, otherwise they meet in scratch[slice][k] and
+// the last workgroup of a point tile to arrive (ticket) adds them.  Where the context holds the whole line (no wavelength
+// shard) the profile just written by voigt_phi_kernel is read back instead of being evaluated a second time (the same
+// bits: same function, same arguments).
 __global__ void voigt_wphi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* __restrict__ list, int KT)
 {
     dbg_poison_lds();
@@ -246,49 +251,60 @@ __global__ void voigt_wphi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* _
     const int kl = threadIdx.x - part * KT;
     const int k = blockIdx.x * KT + kl;
     const int PB = gridDim.y;
+    const int C = max(1, min(max(a.wphiSlices, 1), (a.nltFull + 2 * P - 1) / (2 * P))); // the line's canonical slices
     const bool havePhi = a.nlt == a.nltFull && a.ltStart == 0;
-    double acc = 0.0;
-    if (part < P && k < a.Ns)
+    double total = 0.0;
+    for (int y = blockIdx.y; y < C; y += PB)
     {
-        const double vb = a.vBroad[k];
-        const double ad = a.aDamp[k];
-        for (int la = blockIdx.y * P + part; la < a.nltFull; la += P * PB)
+        double acc = 0.0;
+        if (part < P && k < a.Ns)
         {
-            const double vBase = (a.wave[la] - a.lambda0) * CLight / a.lambda0;
-            const double wla = a.wlam[la];
-            for (int mu = 0; mu < a.Nrays; ++mu)
+            const double vb = a.vBroad[k];
+            const double ad = a.aDamp[k];
+            for (int la = y * P + part; la < a.nltFull; la += P * C)
             {
-                const double wlamu = wla * 0.5 * a.wmu[mu];
-                const double vl = a.vlosMu[(size_t)mu * a.Ns + k];
-                for (int d = 0; d < 2; ++d)
+                const double vBase = (a.wave[la] - a.lambda0) * CLight / a.lambda0;
+                const double wla = a.wlam[la];
+                for (int mu = 0; mu < a.Nrays; ++mu)
                 {
-                    double ph;
-                    if (havePhi)
-                        ph = a.phi[(((size_t)la * a.Nrays + mu) * 2 + d) * a.Ns + k];
-                    else
+                    const double wlamu = wla * 0.5 * a.wmu[mu];
+                    const double vl = a.vlosMu[(size_t)mu * a.Ns + k];
+                    for (int d = 0; d < 2; ++d)
                     {
-                        const double vk = (vBase + (d ? vl : -vl)) / vb;
-                        ph = d_voigt_H(ad, vk) / (sqrtPi * vb);
+                        double ph;
+                        if (havePhi)
+                            ph = a.phi[(((size_t)la * a.Nrays + mu) * 2 + d) * a.Ns + k];
+                        else
+                        {
+                            const double vk = (vBase + (d ? vl : -vl)) / vb;
+                            ph = d_voigt_H(ad, vk) / (sqrtPi * vb);
+                        }
+                        acc += ph * wlamu;
                     }
-                    acc += ph * wlamu;
                 }
             }
         }
-        sPart[part * KT + kl] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < KT && k < a.Ns)
-    {
-        double s = 0.0;
-        for (int q = 0; q < P; ++q)
-            s += sPart[q * KT + threadIdx.x];
-        if (PB == 1)
-            a.wphi[k] = 1.0 / s;
-        else
-            a.wphiScratch[(size_t)blockIdx.y * a.Ns + k] = s;
+        __syncthreads(); // (the previous slice's parts have been read)
+        if (part < P)
+            sPart[part * KT + kl] = acc;
+        __syncthreads();
+        if (threadIdx.x < KT && k < a.Ns)
+        {
+            double s = 0.0;
+            for (int q = 0; q < P; ++q)
+                s += sPart[q * KT + threadIdx.x];
+            if (PB == 1)
+                total += s; // slice order
+            else
+                a.wphiScratch[(size_t)y * a.Ns + k] = s;
+        }
     }
     if (PB == 1)
+    {
+        if (threadIdx.x < KT && k < a.Ns)
+            a.wphi[k] = 1.0 / total;
         return;
+    }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0)
@@ -305,7 +321,7 @@ __global__ void voigt_wphi_kernel(const VoigtLineArgs a0, const VoigtLineArgs* _
     if (threadIdx.x < KT && k < a.Ns)
     {
         double s = 0.0;
-        for (int y = 0; y < PB; ++y)
+        for (int y = 0; y < C; ++y)
             s += __builtin_nontemporal_load(a.wphiScratch + (size_t)y * a.Ns + k);
         a.wphi[k] = 1.0 / s;
     }
@@ -332,7 +348,8 @@ hipError_t voigt_init_tables()
 }
 
 // The launch shape is common to the lines of a launch: point tiles of KT, P = 1024 / KT wavelength parts per workgroup
-// (parts beyond a short line's grid add nothing), PB wavelength slices from the longest line.
+// (parts beyond a short line's grid add nothing), PB workgroups per point tile from the longest line; the ORDER of a
+// line's additions does not depend on it (voigt_wphi_kernel).
 static hipError_t launch_voigt(const VoigtLineArgs& a0, const VoigtLineArgs* list, int nLines, int Ns, size_t maxPhi,
                                int maxNltFull, bool sliced, int slices, hipStream_t stream)
 {
@@ -349,7 +366,7 @@ static hipError_t launch_voigt(const VoigtLineArgs& a0, const VoigtLineArgs* lis
     // tiles of 8 points (1D columns: ~10 point tiles, each with up to 128 partial sums over a slice of the line's
     // wavelengths) or 64 (2D domains, which bring enough tiles); wavelength slices so that a thread sums ~2 wavelengths
     const int KT = Ns <= 1024 ? 8 : 64;
-    const int P = std::max(1, std::min(1024 / KT, maxNltFull));
+    const int P = 1024 / KT; // (fixed: a line's summation order must not depend on which other lines share the launch)
     // (slices only while the launch is small: the ticket costs every workgroup two device-scope fences, which with
     // the 170 000 workgroups of a 512-column batch was all of the kernel's 150 ms)
     int PB = 1;
