@@ -1754,7 +1754,7 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
                 {
                     const double Jdag = Jrow[p];
                     GD(a.J)[(size_t)la * Ns + k0 + p] = Jk[p];
-                    dj = fmax(dj, fabs(1.0 - Jdag / Jk[p])); // :477-486
+                    dj = fmax(dj, fabs(1.0 - Jdag * ls_rcp(Jk[p]))); // :477-486 (the quotient by a refined reciprocal: 1e-16 of a convergence measure)
                 }
             // non-negative doubles order as integers
             atomicMax(sDj + c.rRaw, (unsigned long long)__double_as_longlong(dj));
@@ -1763,9 +1763,13 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     if (nCont <= 0)
         return;
     static_assert(D % 2 == 0, "the block is finished in halves");
+#ifdef LS_X_FINFULL
+    lane_finish_part<D, 0, D>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+#else
     lane_finish_part<D, 0, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
     LS_PHASE();
     lane_finish_part<D, D / 2, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+#endif
 }
 
 // ---- a tile's rays split over the S wavefronts of a group (small problems: more, shorter tasks) -----------------------------
@@ -1878,7 +1882,7 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
                         {
                             const double Jdag = Jrow[p];
                             GD(a.J)[(size_t)la * Ns + k0 + p] = Jk[p];
-                            dj = fmax(dj, fabs(1.0 - Jdag / Jk[p])); // :477-486
+                            dj = fmax(dj, fabs(1.0 - Jdag * ls_rcp(Jk[p]))); // :477-486 (the quotient by a refined reciprocal: 1e-16 of a convergence measure)
                         }
                     }
                 }
