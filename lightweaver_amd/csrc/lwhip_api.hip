@@ -1717,6 +1717,21 @@ int build_tables(lwhip_context* c)
                     const DevLaHeader& h = hdr[tiles[t].la0];
                     v[t].td = tiles[t];
                     v[t].nCont = h.nPure > 0 ? h.nMixed + h.nPure : 0;
+                    {
+                        // the finish's named-register form serves the tiles whose continua all carry the common words
+                        bool fast = true;
+                        const int nC = h.nMixed + h.nPure;
+                        for (int q = 0; q < nC && q < LWHIP_POST_MAXC; ++q)
+                        {
+                            const DevContRec& r = cr[h.off + h.nLine + q];
+                            const unsigned code = (r.flags & 1) ? pp[t].code[q] : 0x9999u, ops = pp[t].ops[q];
+                            if (code != 0x9999u && code != 0x1239u && code != 0x4569u)
+                                fast = false;
+                            if ((r.flags & 2) && (r.flags & 1) && ops != 0x03291u && ops != 0x06594u && ops != 0x0AB9Cu)
+                                fast = false;
+                        }
+                        v[t].finFast = (fast && env_int("LWHIP_FIN_FAST", 1) != 0) ? 1 : 0;
+                    }
                     for (int e = 0; e < std::min(2, tiles[t].nLine + tiles[t].nMixed); ++e)
                         v[t].slot[e] = ts[tiles[t].slotOff + e];
                 }

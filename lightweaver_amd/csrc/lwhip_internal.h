@@ -212,7 +212,8 @@ struct DevLaneTile          // per tile: uniform, one burst of scalar loads
 {
     DevTile td;
     int32_t nCont;          // continua the finish walks (0: none are pure): the first wavelength's nMixed + nPure
-    int32_t _pad[3];
+    int32_t finFast;        // every continuum carries one of the common program words: the finish's named-register form
+    int32_t _pad[2];
     DevTileSlot slot[2];    // the tile's line / mixed-continuum slots (cs: of this launch's chunking)
 };
 static_assert(sizeof(DevLaneTile) % 16 == 0, "DevLaneTile is read with wide scalar loads");

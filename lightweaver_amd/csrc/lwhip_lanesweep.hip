@@ -1731,6 +1731,111 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
     }
 }
 
+// lane_finish_part for the tiles whose continua all carry the common program words (the host's DevLaneTile::finFast: every
+// contributing continuum feeds its atom's sums 1, 2, 3 or 4, 5, 6 -- eta_A, U(j), chi(j) --, every pure one reads them, or stands
+// alone in its atom; 97 % of the continua on the bench grid): six NAMED sums per point instead of a ten-entry register vector,
+// so the whole block (NP = D) fits the registers and is finished in ONE pair of walks -- half the record reads, scalar branches
+// and LDS round trips of two half-block passes, and four points of independent arithmetic per instruction stream.
+template <int D, int P0, int NP>
+DEVINL void lane_finish_fast(const CONST_AS TileArgs& a, const LaneCtx& c, const int nCont, const LaneFinRecs& recs, double* sAcc,
+                             const int ms0, const int ms1, const double (&Jk)[D], const double (&M1)[D], const double (&Me)[2][D])
+{
+    const int Nmu = c.Nmu, LR = c.LR;
+    const unsigned vK = c.vK + (unsigned)P0 * 8u;
+    double Wsum = 0.0; // total quadrature weight of the rays of the iteration, in ray order
+    for (int m = 0; m < Nmu; ++m)
+        for (int d = 0; d < 2; ++d)
+            Wsum += 0.5 * CTAB(double, a.wmu)[m];
+    double boltz[NP];
+    {
+        double rT[NP];
+        ls_lds<NP>(c.sDep, vK + 8u, c.oG + 3u * c.gStride, rT);
+        const double hc_kl = HC_K / c.wav;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            boltz[p] = ls_exp_neg(-hc_kl * rT[p], c.sExp);
+    }
+    double e1[NP], u1[NP], x1[NP], e2[NP], u2[NP], x2[NP]; // eta_A, U(j), chi(j) of the two atom slots
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        e1[p] = u1[p] = x1[p] = e2[p] = u2[p] = x2[p] = 0.0;
+    // walk 1: the shared level sums, continua in transition order (chi_eta_aux_accum :59-109)
+    for (int q = 0; q < nCont; ++q)
+    {
+        const LaneFinRec1 rc = lane_fin_rec(recs, q);
+        const unsigned code = (rc.flags & 1) ? rc.code : 0x9999u;
+        if (code == 0x9999u)
+            continue;
+        double ni[NP], nj[NP], rat[NP];
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nJ, nj);
+        ls_lds<NP>(c.sDep, vK, c.oRat + rc.rat, rat);
+        const double* ppq = c.sPP + (q * c.L + c.r) * 3;
+        const double p0 = ppq[0], p2 = ppq[2];
+        const bool first = code == 0x1239u;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+            const double vji = (rat[p] * boltz[p]) * p0;
+            const double chi_c = ni[p] * p0 - nj[p] * vji;
+            const double uji = p2 * vji;
+            const double eta_c = nj[p] * uji;
+            if (first)
+            {
+                x1[p] -= chi_c;
+                u1[p] += uji;
+                e1[p] += eta_c;
+            }
+            else
+            {
+                x2[p] -= chi_c;
+                u2[p] += uji;
+                e2[p] += eta_c;
+            }
+        }
+    }
+    // walk 2: the pure continua (compute_full_operator_rates :206-234 from the angle moments)
+    for (int q = 0; q < nCont; ++q)
+    {
+        const LaneFinRec1 rc = lane_fin_rec(recs, q);
+        if (!(rc.flags & 2))
+            continue;
+        double ni[NP], nj[NP], rat[NP];
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
+        ls_lds<NP>(c.sDep, vK, c.oN + rc.nJ, nj);
+        ls_lds<NP>(c.sDep, vK, c.oRat + rc.rat, rat);
+        const double* ppq = c.sPP + (q * c.L + c.r) * 3;
+        const double vij = ppq[0], wla = ppq[1], p2 = ppq[2];
+        const unsigned ops = rc.ops;
+        const bool a0 = ops == 0x03291u, alone = ops == 0x0AB9Cu;
+        const bool active = (rc.flags & 1) != 0;
+        const int msel = (rc.ms < 0) ? -1 : (rc.ms == ms0) ? 0 : (rc.ms == ms1) ? 1 : -1;
+        double* dst = sAcc + (unsigned)(rc.cs * 4 * c.LRD) + c.blk;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+            const double vji = (rat[p] * boltz[p]) * vij;
+            const double chi_c = ni[p] * vij - nj[p] * vji;
+            const double uji = p2 * vji;
+            const double eta_c = nj[p] * uji;
+            const double oEta = alone ? eta_c : a0 ? e1[p] : e2[p];
+            const double oUj = alone ? uji : a0 ? u1[p] : u2[p];
+            if (!(c.act && P0 + p < c.nV))
+                continue;
+            const double Jp = Jk[P0 + p], M1p = M1[P0 + p];
+            if (active)
+            {
+                const double Meta = msel < 0 ? 0.0 : msel == 0 ? Me[0][P0 + p] : Me[1][P0 + p];
+                const double Jeff = Jp - M1p * oEta - Meta;
+                lds_add(dst + (P0 + p) * LR, ((uji * Wsum + vji * Jeff) - (M1p * chi_c * oUj)) * wla);
+                lds_add(dst + (D + P0 + p) * LR, (vij * Jeff) * wla); // (U_i of a pure continuum's lower level is zero here)
+            }
+            lds_add(dst + (2 * D + P0 + p) * LR, Jp * vij * wla);
+            lds_add(dst + (3 * D + P0 + p) * LR, (uji * Wsum + Jp * vji) * wla);
+        }
+    }
+}
+
 template <int D>
 DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLaneTile& tr, const int ti, const LaneCtx& c,
                         double* sAcc, unsigned long long* sDj, const int ms0, const int ms1, const double (&Jk)[D],
@@ -1763,13 +1868,14 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     if (nCont <= 0)
         return;
     static_assert(D % 2 == 0, "the block is finished in halves");
-#ifdef LS_X_FINFULL
-    lane_finish_part<D, 0, D>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
-#else
-    lane_finish_part<D, 0, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
-    LS_PHASE();
-    lane_finish_part<D, D / 2, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
-#endif
+    if (tr.finFast)
+        lane_finish_fast<D, 0, D>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+    else
+    {
+        lane_finish_part<D, 0, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        LS_PHASE();
+        lane_finish_part<D, D / 2, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+    }
 }
 
 // ---- a tile's rays split over the S wavefronts of a group (small problems: more, shorter tasks) -----------------------------
