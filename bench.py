@@ -225,10 +225,11 @@ def aux_prd(args, device, stream, torch, models):
         nprdLa = len({la for t in lines for la in range(t.Nblue, t.Nred)})
     Ns, Nmu = pp.Nspace, pp.Nrays
     # inputs and outputs only -- J in and rho out per PRD line, then the rates pass over the PRD wavelengths
-    # (phi once, background, J in / out).  The library's own cache of the fine-grid weights (20 B per fine point, <= 87
-    # points per (lambda, depth)) is an intermediate: reported beside the roofline, not inside it.
+    # (phi once, background, J in / out).  The library's own cache of the fine-grid gII weights and grid indices (10 B per fine point, <= 87
+    # points per (lambda, depth); 20 B until round 4, which also cached the interpolation fraction) is an
+    # intermediate: reported beside the roofline, not inside it.
     alg = 8.0 * 2 * nla * Ns + 8.0 * Ns * (2.0 * Nmu * nla + 5.0 * nprdLa)
-    cache = 20.0 * 87 * nla * Ns
+    cache = 10.0 * 87 * nla * Ns
     out = {'config': 'C3: FALC H(6)+CaII(6), Ca II H & K PRD, same wavelength grid',
            'ms_per_subiter': ms, 'subiters_per_s': 1e3 / ms, 'prd_lines': int(upd.dRho.shape[1]),
            'Nlambda': pp.Nlambda, 'Nlambda_prd': nprdLa,

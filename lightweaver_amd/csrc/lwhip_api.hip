@@ -4078,9 +4078,12 @@ int lwhip_prd_partial(lwhip_context* c)
         a.gIIFill = 1;
         if (env_int("LWHIP_PRD_CACHE", 1) && a.laHi > a.laLo)
         {
-            // gII and the interpolation fractions (doubles) + the bracketing indices (int32) of the line
+            // the end-corrected gII weights of the line's fine grids and the bracketing indices as 16 bits (10 bytes per fine
+            // point; the interpolation fraction is re-derived in the kernel)
             const size_t per = (size_t)Ns * 88 * a.Nl;
-            const size_t need = 2 * per + (per + 1) / 2;
+            const size_t need = per + (per + 3) / 4;
+            if (a.Nl > 32767)
+                return fail(LWHIP_ERR_UNSUPPORTED, "a PRD line with more than 32 767 wavelengths");
             if (!c->gII[tr])
                 c->gII[tr] = std::make_unique<DevBuf<double>>();
             if (c->gII[tr]->n < need)
@@ -4095,8 +4098,8 @@ int lwhip_prd_partial(lwhip_context* c)
             if (c->gII[tr])
             {
                 a.gII = c->gII[tr]->p;
-                a.gTT = a.gII + per;
-                a.gIT = (int32_t*)(a.gTT + per);
+                a.gTT = nullptr;
+                a.gIT = (int32_t*)(a.gII + per);
                 a.gIIFill = c->gIIValid[tr] ? 0 : 1;
                 c->gIIValid[tr] = 1;
             }

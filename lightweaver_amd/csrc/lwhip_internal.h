@@ -451,8 +451,8 @@ struct PrdLineArgs
     const int32_t* transLj;
     double* rho;            // [laHi - laLo, Ns]: the shard's rows
     double* gII;            // [Ns, 88, Nl] cached gII weights of the line, or null (always recompute)
-    double* gTT;            // [Ns, 88, Nl] cached interpolation fractions
-    int32_t* gIT;           // [Ns, 88, Nl] cached bracketing indices
+    double* gTT;            // (unused since round 4: the fraction is re-derived from the index)
+    int32_t* gIT;           // [Ns, 88, Nl] cached bracketing indices, 16 bits each
     int32_t gIIFill, _padG; // 1: compute (and store) the weights; 0: read them from the cache
     double* changeVal;      // [Ns * slices] scratch
     int32_t* changeIdx;     // [Ns * slices] scratch

@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __r
     const int Nl = a.Nl;
     double* Jk = sm;
     double* qW = sm + Nl;
+    double* rq = sm + 2 * Nl; // 1 / (q[i] - q[i - 1]): the interpolation fraction of a fine point without a division
     __shared__ double sPjQj;
     __shared__ double sBest[128];
     __shared__ int sBestIdx[128];
@@ -122,6 +123,11 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __r
     {
         Jk[la] = a.Jt[(size_t)k * Nl + la];
         qW[la] = (a.wave[la] - a.lambda0) * CLight / (a.lambda0 * a.vBroad[k]);
+        if (la > 0)
+            rq[la] = 1.0 / ((a.wave[la] - a.lambda0) * CLight / (a.lambda0 * a.vBroad[k])
+                            - (a.wave[la - 1] - a.lambda0) * CLight / (a.lambda0 * a.vBroad[k]));
+        else
+            rq[la] = 0.0;
     }
     // total_depop_elastic_scattering_rate: Prd.cpp:9-30.  The terms are fetched by separate lanes
     // (one memory round trip), then added by one thread in the reference's order.
@@ -224,23 +230,25 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __r
             }
             iter = lo;
         }
-        // Everything about the fine grid of this (depth, emission wavelength) that does not depend on J
-        // -- the end-corrected gII weights (the reference caches these too, t->gII, Prd.cpp:499-553), the
-        // bracketing table index and the interpolation fraction -- is cached, laid out
-        // [k][fine point][la] so that a wavefront's reads coalesce.  With the cache the integral is
-        // 3 loads + 2 LDS reads + 4 flops per fine point, in the reference's order of operations.
+        // What of the fine grid of this (depth, emission wavelength) does not depend on J is cached, laid out [k][fine point][la]
+        // so that a wavefront's reads coalesce: the end-corrected gII weights (the reference caches these too, t->gII,
+        // Prd.cpp:499-553) and the bracketing index of the line's grid as 16 bits -- 10 bytes per fine point.  (Round 3 also
+        // cached the interpolation fraction, 20 bytes per point, and was bound by streaming them; the fraction is re-derived
+        // from the index with a tabulated reciprocal.  Re-deriving the index too -- the reference's walk -- was measured:
+        // 87 dependent LDS round trips per thread, twice the time of streaming it.)
         const size_t cOff = ((size_t)k * PRD_MAX_FINE) * Nl + la;
         double gNorm = 0.0, scatInt = 0.0;
         if (!a.gIIFill)
         {
             const double* gc = a.gII + cOff;
-            const double* tc = a.gTT + cOff;
-            const int32_t* ic = a.gIT + cOff;
+            const int16_t* ic = (const int16_t*)a.gIT + cOff;
             for (int i = 0; i < Np; ++i)
             {
                 const double gii = gc[(size_t)i * Nl];
-                const double tt = tc[(size_t)i * Nl];
                 const int it = ic[(size_t)i * Nl];
+                const double x = q0 + i * PrdDQ;
+                // (beyond the table ends the fraction leaves [0, 1]: clamped, it is the 1 / 0 of the filling pass)
+                const double tt = fmin(fmax((x - qW[it - 1]) * rq[it], 0.0), 1.0);
                 const double Jf = (1.0 - tt) * Jk[it - 1] + tt * Jk[it];
                 gNorm += gii;
                 scatInt += Jf * gii;
@@ -269,10 +277,7 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __r
                     tt = 0.0;
                 }
                 else
-                {
-                    const double xp = qW[iter - 1], xn = qW[iter];
-                    tt = (x - xp) / (xn - xp);
-                }
+                    tt = (x - qW[iter - 1]) * rq[iter]; // (the same expression as the cached pass: one rho from either)
                 const double Jf = (1.0 - tt) * Jk[it - 1] + tt * Jk[it];
                 // end-corrected trapezoid weights, q' accumulated step by step: Prd.cpp:526-551
                 if (i > 0)
@@ -287,8 +292,7 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __r
                 if (a.gII)
                 {
                     a.gII[cOff + (size_t)i * Nl] = gii;
-                    a.gTT[cOff + (size_t)i * Nl] = tt;
-                    a.gIT[cOff + (size_t)i * Nl] = it;
+                    ((int16_t*)a.gIT)[cOff + (size_t)i * Nl] = (int16_t)it;
                 }
                 gNorm += gii;
                 scatInt += Jf * gii;
@@ -391,7 +395,7 @@ hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hos
         maxSlices = std::max(maxSlices, hostList[q].slices);
         any = any || hostList[q].laHi > hostList[q].laLo;
     }
-    const size_t lds = (size_t)2 * maxNl * sizeof(double);
+    const size_t lds = (size_t)3 * maxNl * sizeof(double);
     if (lds > 48 * 1024)
     {
         hipError_t err = hipFuncSetAttribute((const void*)prd_scatter_kernel,
