@@ -1311,7 +1311,7 @@ int build_tables(lwhip_context* c)
         if (c->tileFuse)
             tgtSweep = c->nTiles;
         if (!c->tileFuse)
-            tgtSweep = env_int("LWHIP_TCHUNKS", tgtSweep);
+            tgtSweep = std::max(1, tgtSweep);
         c->laneSplit = 1;
         if (c->laneSweep)
         {
@@ -1336,7 +1336,7 @@ int build_tables(lwhip_context* c)
         // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
         const size_t ldsPostEst = sizeof(double) * ((size_t)7 * 4 * Ns + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
         const int postPerCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / ldsPostEst));
-        int tgtPost = std::min(c->nTiles, numCU * env_int("LWHIP_POST_PER_CU", postPerCU));
+        int tgtPost = std::min(c->nTiles, numCU * postPerCU);
         if (c->batchHint > 1)
             tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
         const int laneFixed = (c->laneSweep && env_int("LWHIP_LANE_UNIFORM", 1) != 0) ? std::max(1, W / c->laneSplit) : 0;
@@ -1352,7 +1352,7 @@ int build_tables(lwhip_context* c)
             // (and in a launch of ONE partial round -- more than half a round of whole tiles, so that not every tile can be
             // split -- the heaviest chunks are the ones cut, as many as still fit the round: the launch lasts as long as its
             // longest workgroup)
-            const bool oneRound = nch0 <= slotsWg && env_int("LWHIP_LANE_HEAVY", 1) != 0;
+            const bool oneRound = nch0 <= slotsWg;
             if (c->laneSweep && c->batchHint <= 1 && !c->deterministic && W == 4 && c->laneSplit == 1 && laneFixed == W
                 && (nch0 > slotsWg || (oneRound && nch0 > slotsWg / 2)) && (tailS == 2 || tailS == 4))
             {
@@ -1668,7 +1668,7 @@ int build_tables(lwhip_context* c)
         const int nchAll = (int)chunkTile.size() - 1;
         // more workgroups than the chip holds at once (2 per CU): the heavy ones go first, the light ones fill the tail
         // (measured: 8 192 wavelengths 0.188 -> 0.179 ms, 10 240: 0.203 -> 0.200; lightest first: 0.196 / 0.207)
-        const int laneOrder = env_int("LWHIP_LANE_ORDER", nchAll > 2 * numCU ? 1 : 0);
+        const int laneOrder = nchAll > 2 * numCU ? 1 : 0; // heaviest first
         if (c->laneSweep && c->batchHint <= 1 && laneOrder != 0 && laneChunkOrder.empty())
         {
             // the chunks stay what they are (neighbouring wavelengths: few accumulator slots); only the order in which the
@@ -1964,7 +1964,7 @@ int alloc_state(lwhip_context* c)
             const size_t wavesPerGroup = 2 * ((Ns + 127) / 128);
             c->groups2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)c->batch2d, (size_t)numCU * 12 / wavesPerGroup }));
         }
-        c->groups2d = std::max(1, env_int("LWHIP_GROUPS2D", c->groups2d));
+        c->groups2d = std::max(1, c->groups2d);
         HIP_TRY(c->red2d.alloc((size_t)c->groups2d * std::max(c->Ntrans, 1) * 4 * Ns));
         const size_t nb = (size_t)c->batch2d * 2 * Nr * Ns;
         HIP_TRY(c->b2cs.alloc(2 * nb)); // (chi, S) pairs
@@ -4076,7 +4076,7 @@ int lwhip_prd_partial(lwhip_context* c)
         }
         a.gII = nullptr;
         a.gIIFill = 1;
-        if (env_int("LWHIP_PRD_CACHE", 1) && a.laHi > a.laLo)
+        if (a.laHi > a.laLo)
         {
             // the end-corrected gII weights of the line's fine grids and the bracketing indices as 16 bits (10 bytes per fine
             // point; the interpolation fraction is re-derived in the kernel)

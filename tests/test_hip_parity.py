@@ -208,12 +208,14 @@ def test_lane_sweep_ray_split_vs_oracle(gpu, monkeypatch, split, prd):
                                  {'LWHIP_SWEEP': 'march', 'LWHIP_TILE_FUSE': '0'}, {'LWHIP_SWEEP': 'march', 'LWHIP_TWAVES': '4'},
                                  {'LWHIP_SWEEP': 'march', 'LWHIP_TILE_LH': '5'},
                                  {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '2'}, {'LWHIP_SWEEP': 'lanes', 'LWHIP_LWAVES': '8'},
-                                 {'LWHIP_SWEEP': 'lanes', 'LWHIP_LANE_UNIFORM': '0'}])
+                                 {'LWHIP_SWEEP': 'lanes', 'LWHIP_LANE_UNIFORM': '0'},
+                                 {'LWHIP_SWEEP': 'lanes', 'LWHIP_FIN_FAST': '0'}])
 def test_sweep_variants_forced_on_small_problem(gpu, monkeypatch, env):
     """The other instantiations of the one sweep on the 82-point H + Ca II problem: every tile through the guarded
     generic march (capacity 2 / 8: what tiles with more overlapping lines than the compile-time kinds use), the
     stand-alone post-pass launch instead of the fused one, four wavefronts (two tiles) per workgroup; the lane sweep with
-    two / eight wavefronts (tiles) per workgroup."""
+    two / eight wavefronts (tiles) per workgroup, and with the finish's general (program-decoding) form instead of the
+    named-register form that the common program words get."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     base, d = load_fixture('falc_h_ca_small')
