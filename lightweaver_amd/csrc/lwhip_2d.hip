@@ -303,6 +303,15 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         for (int c = 0; c < MAXP; ++c)
             hand_over(accP[c], trP[c], (c < nPure) ? CTAB(int32_t, a.slotTr)[h.off + nLine + nMixed + c] : -1);
         double mJ = 0.0, mM1 = 0.0, mE0 = 0.0, mE1 = 0.0;
+        double mP0[MAXL], mP1[MAXL], mQ1[MAXL], mQ2[MAXL][MAXL];
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l)
+        {
+            mP0[l] = mP1[l] = mQ1[l] = 0.0;
+#pragma unroll
+            for (int m = 0; m < MAXL; ++m)
+                mQ2[l][m] = 0.0;
+        }
         // ---- ray-independent part of the wavelength ---------------------------------------------------------
         double lG[MAXL], lNi[MAXL], lNj[MAXL], lW[MAXL];
         int lgi[MAXL], lgj[MAXL], lat[MAXL], lop[MAXL];
@@ -329,33 +338,41 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
             }
         }
         const bool topRow = kk < a.Nx && on;
-        // the next ray's I, Psi* and profiles are requested before this ray is worked on (one ray of look-ahead costs
-        // 8 VGPRs; a thread has two other wavefronts to hide behind and every ray began with a full load round trip)
+        // the rays' I, Psi* and profiles are requested RB at a time and then worked through: with the moments the ray loop
+        // holds no per-line temporaries any more, so four rays of loads in flight fit the registers (one ray of look-ahead
+        // -- 8 VGPRs -- was all the ray-by-ray integrands left room for), and a wavelength costs two load round trips, not eight
         const int nR = a.nRaysActive;
-        double nxI, nxP, nxPhi[MAXL];
-        auto fetch = [&](int r) {
-            const size_t o = ((size_t)b * nR + r) * Ns + kk;
-            nxI = a.I[o];
-            nxP = a.lambdaIterate ? 0.0 : a.PsiStar[o];
-            const size_t rayOff = (size_t)sRayId[r] * Ns + kk;
-#pragma unroll
-            for (int l = 0; l < MAXL; ++l)
-                nxPhi[l] = (l < nLine) ? a.phi[slots[l].phiOff + rayOff] : 0.0;
-        };
-        fetch(0);
-        for (int r = 0; r < nR; ++r)
+        constexpr int RB = 4; // (2 and 8, and 2 wavefronts per SIMD with 4 or 8, were measured: the same within noise)
+        for (int r0 = 0; r0 < nR; r0 += RB)
         {
+            double bI[RB], bP[RB], bPhi[RB][MAXL];
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+            {
+                const int r = min(r0 + q, nR - 1);
+                const size_t o = ((size_t)b * nR + r) * Ns + kk;
+                bI[q] = a.I[o];
+                bP[q] = a.lambdaIterate ? 0.0 : a.PsiStar[o];
+                const size_t rayOff = (size_t)sRayId[r] * Ns + kk;
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l)
+                    bPhi[q][l] = (l < nLine) ? a.phi[slots[l].phiOff + rayOff] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+            {
+            const int r = r0 + q;
+            if (r >= nR)
+                break;
             const int ray = sRayId[r];
             const int mu = ray >> 1;
             const double halfwmu = sHalfW[r];
-            const double I = nxI;
-            const double PsiS = nxP;
+            const double I = bI[q];
+            const double PsiS = bP[q];
             double phiR[MAXL];
 #pragma unroll
             for (int l = 0; l < MAXL; ++l)
-                phiR[l] = nxPhi[l];
-            if (r + 1 < nR)
-                fetch(r + 1);
+                phiR[l] = bPhi[q][l];
             const double wPsi = halfwmu * PsiS;
             mJ += halfwmu * I; // accumulate_J :181-190
             mM1 += wPsi;
@@ -370,75 +387,123 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
                 else if (!(ray & 1) && a.zDown && kk >= Ns - 2 * a.Nx && kk < Ns - a.Nx)
                     a.zDown[((size_t)la * a.Nrays + mu) * a.Nx + (kk - (Ns - 2 * a.Nx))] = I;
             }
-            if (nLine + nMixed == 0)
-                continue;
-            double Vij[MAXL], Vji[MAXL], xl[MAXL], el[MAXL], luji[MAXL];
+            // the angle moments of the line and mixed-continuum rates (lwhip_lanesweep.hip: every integrand is a polynomial in
+            // the rays' profiles with ray-independent coefficients, so the sums over the rays need only P0_l = sum w phi_l,
+            // P1_l = sum w phi_l I, Q_l = sum w Psi* phi_l, Q_ll' = sum w Psi* phi_l phi_l' next to J and M1): six flops per
+            // ray and line here, the integrals once per wavelength below -- no continuum row, no level matching in the ray loop
 #pragma unroll
             for (int l = 0; l < MAXL; ++l)
             {
-                Vij[l] = Vji[l] = xl[l] = el[l] = luji[l] = 0.0;
+                if (l < nLine)
+                {
+                    const double wa = halfwmu * phiR[l], wb = wPsi * phiR[l];
+                    mP0[l] += wa;
+                    mP1[l] = fma(wa, I, mP1[l]);
+                    mQ1[l] += wb;
+#pragma unroll
+                    for (int m = l; m < MAXL; ++m)
+                        if (m < nLine)
+                            mQ2[l][m] = fma(wb, phiR[m], mQ2[l][m]);
+                }
+            }
+            } // rays of the round
+        } // rounds
+        if (nLine + nMixed > 0)
+        {
+            // per unit profile: V_ij = c1 phi, V_ji = c2 phi, U_ji = cu phi, chi_line = cx phi, eta_line = ce phi
+            double c1[MAXL], c2[MAXL], cu[MAXL], cx[MAXL], ce[MAXL];
+#pragma unroll
+            for (int l = 0; l < MAXL; ++l)
+            {
+                c1[l] = c2[l] = cu[l] = cx[l] = ce[l] = 0.0;
                 if (l < nLine)
                 {
                     const DevSlot& sl = slots[l];
-                    const double vij = sl.p[0] * phiR[l];
-                    const double vji = lG[l] * vij;
-                    const double uji = sl.p[3] * vji;
-                    Vij[l] = vij;
-                    Vji[l] = vji;
-                    luji[l] = uji;
-                    xl[l] = lNi[l] * vij - lNj[l] * vji;
-                    el[l] = lNj[l] * uji;
+                    c1[l] = sl.p[0];
+                    c2[l] = lG[l] * sl.p[0];
+                    cu[l] = sl.p[3] * c2[l];
+                    cx[l] = lNi[l] * c1[l] - lNj[l] * c2[l];
+                    ce[l] = lNj[l] * cu[l];
                     if (lop[l])
                     {
                         if (sl.ms == 0)
-                            mE0 += wPsi * el[l];
+                            mE0 = fma(ce[l], mQ1[l], mE0);
                         else if (sl.ms == 1)
-                            mE1 += wPsi * el[l];
+                            mE1 = fma(ce[l], mQ1[l], mE1);
                     }
                 }
             }
-            // level sums: continuum rows + this ray's lines (chi_eta_aux_accum bookkeeping)
-            auto levChi = [&](int g, double v) {
+            auto Q2of = [&](int l, int m) { return l <= m ? mQ2[l][m] : mQ2[m][l]; };
+            // a level sum X = X0 + sum_l X_l phi_l (X0: the continuum row; X_l from the active lines that share the level /
+            // the atom: chi_eta_aux_accum's bookkeeping);  L(X) = sum w Psi* X,  L_s(X) = sum w Psi* phi_s X,
+            // B(X, Y) = sum w Psi* X Y in terms of the moments
+            struct Aff
+            {
+                double x0, x[MAXL];
+            };
+            auto levChi = [&](int g, double row) {
+                Aff f{ row, {} };
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l)
+                    f.x[l] = (lop[l] && lgi[l] == g) ? cx[l] : (lop[l] && lgj[l] == g) ? -cx[l] : 0.0;
+                return f;
+            };
+            auto levU = [&](int g, double row) {
+                Aff f{ row, {} };
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l)
+                    f.x[l] = (lop[l] && lgj[l] == g) ? cu[l] : 0.0;
+                return f;
+            };
+            auto atomEta = [&](int at, double row) {
+                Aff f{ row, {} };
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l)
+                    f.x[l] = (lop[l] && lat[l] == at) ? ce[l] : 0.0;
+                return f;
+            };
+            auto Lin = [&](const Aff& X) {
+                double r = X.x0 * mM1;
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l)
+                    r = fma(X.x[l], mQ1[l], r);
+                return r;
+            };
+            auto LinS = [&](int s, const Aff& X) {
+                double r = X.x0 * mQ1[s];
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l)
+                    r = fma(X.x[l], Q2of(s, l), r);
+                return r;
+            };
+            auto Bil = [&](const Aff& X, const Aff& Y) {
+                double r = (X.x0 * Y.x0) * mM1;
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l)
                 {
-                    if (lop[l] && lgi[l] == g)
-                        v += xl[l];
-                    if (lop[l] && lgj[l] == g)
-                        v -= xl[l];
+                    r = fma(fma(X.x0, Y.x[l], X.x[l] * Y.x0), mQ1[l], r);
+#pragma unroll
+                    for (int m = 0; m < MAXL; ++m)
+                        r = fma(X.x[l] * Y.x[m], Q2of(l, m), r);
                 }
-                return v;
-            };
-            auto levU = [&](int g, double v) {
-#pragma unroll
-                for (int l = 0; l < MAXL; ++l)
-                    if (lop[l] && lgj[l] == g)
-                        v += luji[l];
-                return v;
-            };
-            auto atomEta = [&](int at, double v) {
-#pragma unroll
-                for (int l = 0; l < MAXL; ++l)
-                    if (lop[l] && lat[l] == at)
-                        v += el[l];
-                return v;
+                return r;
             };
 #pragma unroll
             for (int l = 0; l < MAXL; ++l)
             {
                 if (l < nLine)
                 {
-                    const double wlamu = lW[l] * halfwmu;
+                    const DevSlot& sl = slots[l];
+                    const double up = fma(cu[l], mP0[l], c2[l] * mP1[l]); // sum w (U_ji + V_ji I)
                     if (lop[l])
                     {
-                        // compute_full_Ieff :192-204, compute_full_operator_rates :206-234
-                        const DevSlot& sl = slots[l];
-                        const double Ieff = I - PsiS * atomEta(lat[l], rowAt(sl.rEtaA));
-                        accL[l][0] += ((luji[l] + Vji[l] * Ieff) - (PsiS * levChi(lgi[l], rowAt(sl.rChiI)) * levU(lgj[l], rowAt(sl.rUJ)))) * wlamu;
-                        accL[l][1] += ((Vij[l] * Ieff) - (PsiS * levChi(lgj[l], rowAt(sl.rChiJ)) * levU(lgi[l], rowAt(sl.rUI)))) * wlamu;
+                        // compute_full_Ieff :192-204, compute_full_operator_rates :206-234, summed over the rays
+                        const double LsE = LinS(l, atomEta(lat[l], rowAt(sl.rEtaA)));
+                        accL[l][0] += ((up - c2[l] * LsE) - Bil(levChi(lgi[l], rowAt(sl.rChiI)), levU(lgj[l], rowAt(sl.rUJ)))) * lW[l];
+                        accL[l][1] += ((c1[l] * (mP1[l] - LsE)) - Bil(levChi(lgj[l], rowAt(sl.rChiJ)), levU(lgi[l], rowAt(sl.rUI)))) * lW[l];
                     }
-                    accL[l][2] += I * Vij[l] * wlamu;
-                    accL[l][3] += (luji[l] + I * Vji[l]) * wlamu;
+                    accL[l][2] += (c1[l] * mP1[l]) * lW[l];
+                    accL[l][3] += up * lW[l];
                 }
             }
 #pragma unroll
@@ -449,15 +514,14 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
                     const DevSlot& sl = slots[nLine + c];
                     const double vij = sl.p[0], vji = rowAt(sl.rVji);
                     const double uji = sl.p[2] * vji;
-                    const double wlamu = sl.p[1] * halfwmu;
-                    const double Ieff = I - PsiS * atomEta(sl.atom, rowAt(sl.rEtaA));
-                    accM[c][0] += ((uji + vji * Ieff) - (PsiS * levChi(sl.gi, rowAt(sl.rChiI)) * levU(sl.gj, rowAt(sl.rUJ)))) * wlamu;
-                    accM[c][1] += ((vij * Ieff) - (PsiS * levChi(sl.gj, rowAt(sl.rChiJ)) * levU(sl.gi, rowAt(sl.rUI)))) * wlamu;
-                    accM[c][2] += I * vij * wlamu;
-                    accM[c][3] += (uji + I * vji) * wlamu;
+                    const double Jeff = mJ - Lin(atomEta(sl.atom, rowAt(sl.rEtaA)));
+                    accM[c][0] += ((uji * Wsum + vji * Jeff) - Bil(levChi(sl.gi, rowAt(sl.rChiI)), levU(sl.gj, rowAt(sl.rUJ)))) * sl.p[1];
+                    accM[c][1] += ((vij * Jeff) - Bil(levChi(sl.gj, rowAt(sl.rChiJ)), levU(sl.gi, rowAt(sl.rUI)))) * sl.p[1];
+                    accM[c][2] += (mJ * vij) * sl.p[1];
+                    accM[c][3] += (uji * Wsum + mJ * vji) * sl.p[1];
                 }
             }
-        } // rays
+        }
         // pure continua from the angle moments
         auto pure = [&](int cq, double (&out)[4]) {
             const int si = nLine + nMixed + cq;
