@@ -1717,6 +1717,7 @@ int build_tables(lwhip_context* c)
                     const DevLaHeader& h = hdr[tiles[t].la0];
                     v[t].td = tiles[t];
                     v[t].nCont = h.nPure > 0 ? h.nMixed + h.nPure : 0;
+                    v[t].nContAll = std::min(h.nMixed + h.nPure, (int)LWHIP_POST_MAXC);
                     {
                         // the finish's named-register form serves the tiles whose continua all carry the common words
                         bool fast = true;
@@ -1771,7 +1772,31 @@ int build_tables(lwhip_context* c)
                     const DevContRec& r = cr[h0.off + h0.nLine + q];
                     uint32_t w[8];
                     std::memcpy(w, &r, sizeof(w));
-                    fin[t * LWHIP_POST_MAXC + q] = DevLaneFin{ w[0], w[1], w[2], w[6], w[7], pp[t].code[q], pp[t].ops[q], 0u };
+                    // the rows of the tile's slots this continuum feeds (zero_mask's matching, per continuum)
+                    uint32_t feed = 0;
+                    {
+                        const int ord = slots[h0.off + h0.nLine + q]._pad; // transition-order position q -> slot ordinal
+                        const DevSlot& cs = slots[h0.off + h0.nLine + ord];
+                        for (int e = 0; e < nSl; ++e)
+                        {
+                            const DevTileSlot& us = tslots[td.slotOff + e];
+                            uint32_t b = 0;
+                            if ((cs.flags & 1) && (us.flags & 1))
+                            {
+                                b |= cs.atom == us.atom ? 1u : 0u;
+                                b |= cs.gi == us.gi ? 2u : 0u;
+                                b |= cs.gj == us.gi ? 4u : 0u;
+                                b |= cs.gi == us.gj ? 8u : 0u;
+                                b |= cs.gj == us.gj ? 16u : 0u;
+                                b |= cs.gj == us.gi ? 32u : 0u;
+                                b |= cs.gj == us.gj ? 64u : 0u;
+                            }
+                            if (e >= td.nLine && ord == e - td.nLine)
+                                b |= 128u;
+                            feed |= b << (8 * e);
+                        }
+                    }
+                    fin[t * LWHIP_POST_MAXC + q] = DevLaneFin{ w[0], w[1], w[2], w[6], w[7], pp[t].code[q], pp[t].ops[q], feed };
                     for (int rr = 0; rr < L; ++rr)
                     {
                         const int la = td.la0 + std::min(rr, td.nl - 1);
@@ -1831,10 +1856,11 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(c->muz.alloc(2 * Nr)); // [muz | 1 / muz]
     HIP_TRY(c->wmu.alloc(Nr));
     HIP_TRY(c->wavelength.alloc(Nla));
-    HIP_TRY(c->bgChi.alloc(Nla * Ns));
-    HIP_TRY(c->bgEta.alloc(Nla * Ns));
-    HIP_TRY(c->bgSca.alloc(Nla * Ns));
-    HIP_TRY(c->J.alloc(Nla * Ns));
+    // (+ 8: the lane sweep reads a lane's block of depths with one wide load -- up to three doubles past the last row)
+    HIP_TRY(c->bgChi.alloc(Nla * Ns + 8));
+    HIP_TRY(c->bgEta.alloc(Nla * Ns + 8));
+    HIP_TRY(c->bgSca.alloc(Nla * Ns + 8));
+    HIP_TRY(c->J.alloc(Nla * Ns + 8));
     HIP_TRY(c->I.alloc(Nla * Nr * (size_t)c->Nx));
     if (c->prob.storeDepthData)
     {
@@ -2244,7 +2270,8 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
         if (ec != hipSuccess)
             return ec;
     }
-    hipError_t e = launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
+    // (the lane sweep's tasks do their own pre-pass; the ray-column march has it as a launch of its own)
+    hipError_t e = c->laneSweep ? hipSuccess : launch_tile_pre(da, ha, tprd ? c->nTilesPrd : c->nTiles, nullptr, 0, c->stream);
     if (e != hipSuccess)
         return e;
     if (e0) // lwhip_profile_enable: HIP events around the sweep kernel alone
@@ -3463,7 +3490,8 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
     // one set of launches for all columns: pre-pass, sweep (each workgroup finishes its tile when fused), stage 2
     const TileDyn dyn = make_dyn(c0, false, lambdaIterate);
     const bool fuse = c0->tileFuse;
-    HIP_TRY(launch_tile_pre(c0->dtargs.p, c0->htargs, c0->nTiles, b->apList.p, n, c0->stream));
+    if (!c0->laneSweep) // (the lane sweep's tasks do their own pre-pass)
+        HIP_TRY(launch_tile_pre(c0->dtargs.p, c0->htargs, c0->nTiles, b->apList.p, n, c0->stream));
     if (c0->laneSweep)
         HIP_TRY(launch_lane_sweep(c0->dtargs.p, c0->htargs, dyn, c0->prob.formalSolver, true, c0->nTileChunks, c0->tileWaves, b->apList.p, n,
                                   c0->stream));

@@ -213,7 +213,8 @@ struct DevLaneTile          // per tile: uniform, one burst of scalar loads
     DevTile td;
     int32_t nCont;          // continua the finish walks (0: none are pure): the first wavelength's nMixed + nPure
     int32_t finFast;        // every continuum carries one of the common program words: the finish's named-register form
-    int32_t _pad[2];
+    int32_t nContAll;       // continua of the wavelength (the task's own pre-pass walks them all): nMixed + nPure
+    int32_t _pad;
     DevTileSlot slot[2];    // the tile's line / mixed-continuum slots (cs: of this launch's chunking)
 };
 static_assert(sizeof(DevLaneTile) % 16 == 0, "DevLaneTile is read with wide scalar loads");
@@ -228,7 +229,11 @@ struct DevLaneFin           // per (tile, continuum q of the transition order): 
     uint32_t nI, nJ, rat;   // DevContRec byte offsets
     uint32_t w6, w7;        // DevContRec dwords 6, 7: sUj | flags << 16 | ms << 24, tr | cs << 16
     uint32_t code, ops;     // DevPostProg words
-    uint32_t _pad;
+    // which of the tile's slots' continuum rows this continuum feeds (the task's own pre-pass: Atom::setup_wavelength +
+    // chi_eta_aux_accum for the continua, SimdFullIterationTemplates.hpp:59-109): byte e = slot e, bit 0 eta_A += eta_c,
+    // bit 1 / 2 chi_i += / -= chi_c, bit 3 / 4 chi_j += / -= chi_c, bit 5 U_i += U_ji, bit 6 U_j += U_ji, bit 7: the
+    // continuum IS mixed slot e (its V_ji row)
+    uint32_t feed;
 };
 struct TileArgs
 {

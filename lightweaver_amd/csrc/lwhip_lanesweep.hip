@@ -404,21 +404,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     // which moment row a line's Psi* eta goes to: with fewer than two lines row 0 stands for the line's moment slot
     const int meSlot0 = NL == 1 ? lms[0] : 0;
 
-    // the ray-independent rows chi_C, eta_C, sigma J of the lane's points: once from memory into the wavefront's LDS block
-    {
-        double t0[D], t1[D], t2[D];
-        ls_gld<D>(rRows, c.vRow, 0u, t0);
-        ls_gld<D>(rRows, c.vRow, rowStride, t1);
-        ls_gld<D>(rRows, c.vRow, 2u * rowStride, t2);
-        double* r3 = c.sRow3 + c.lane * D;
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-        {
-            r3[p] = t0[p];
-            r3[64 * D + p] = t1[p];
-            r3[2 * 64 * D + p] = t2[p];
-        }
-    }
+    // (the ray-independent rows chi_C, eta_C, sigma J of the lane's points are in the wavefront's LDS block: lane_pre)
     // boundary intensities of the rays (wrappers FormalScalar.cpp:471-666): Planck functions of the two end points of
     // this lane's wavelength, parked in the wavefront's LDS row (read by the lane that holds a ray's first point)
     // (the host's table: once per atmosphere and wavelength, not per task)
@@ -1514,6 +1500,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
 struct LaneFinRecs
 {
     unsigned nI, nJ, rat, w6, w7, code, ops; // DevContRec dwords 0, 1, 2, 6 (sUj | flags << 16 | ms << 24), 7 (tr | cs << 16)
+    unsigned feed;                           // DevLaneFin::feed
 };
 DEVINL LaneFinRecs lane_fin_recs(const CONST_AS TileArgs& a, const int ti, const int nCont, const int lane)
 {
@@ -1529,6 +1516,7 @@ DEVINL LaneFinRecs lane_fin_recs(const CONST_AS TileArgs& a, const int ti, const
         r.w7 = w[4];
         r.code = w[5];
         r.ops = w[6];
+        r.feed = w[7];
     }
     return r;
 }
@@ -1568,6 +1556,160 @@ DEVINL LaneFinRec1 lane_fin_rec(const LaneFinRecs& v, const int q)
     r.code = (unsigned)__builtin_amdgcn_readlane((int)v.code, q);
     r.ops = (unsigned)__builtin_amdgcn_readlane((int)v.ops, q);
     return r;
+}
+
+// The task's own pre-pass (round 4; until then a launch of its own, tile_pre_kernel): the ray-independent continuum terms
+// of the lane's points -- Atom::setup_wavelength (LwAtom.hpp:107-115) + Transition::uv (LwTransition.hpp:132-142) +
+// chi_eta_aux_accum (SimdFullIterationTemplates.hpp:59-109) for the wavelength's continua in the reference's transition order:
+//   chi_C = bgChi + sum chi_c,  eta_C = bgEta + sum eta_c,  sca J  -> the wavefront's LDS block (rows 0 .. 2),
+//   per line / mixed slot the level sums eta_A, chi(i), chi(j), U(i), U(j) of the active continua (DevLaneFin::feed says
+//   which) and V_ji of a mixed continuum -> the tile's row block in global memory (read back ONCE, by the slots' integrals
+//   after the rays: the same lane, tens of microseconds later).
+// One launch, 60 MB of row writes and 60 MB of reads per 10 240 wavelengths less; the walk is ~600 vector instructions of a
+// task's ~11 000.
+template <int D>
+DEVINL void lane_pre(const CONST_AS TileArgs& a, const DevLaneTile& tr, const LaneCtx& c, const int ti, const bool slotRows)
+{
+    const int Ns = c.Ns;
+    const int nC = tr.nContAll;
+    // background, J and the finish's records / parameters are requested first
+    double chiC[D], etaC[D], scaJ[D];
+    {
+        const size_t o = (size_t)c.la * Ns + c.k0;
+        double bs[D], bj[D];
+        const GLOBAL_AS double* pc = GCD(a.bgChi) + o;
+        const GLOBAL_AS double* pe = GCD(a.bgEta) + o;
+        const GLOBAL_AS double* ps = GCD(a.bgSca) + o;
+        const GLOBAL_AS double* pj = GCD(a.J) + o;
+#pragma unroll
+        for (int p = 0; p < D; ++p) // (the pools are padded: the last lane of a ray reads past its row)
+        {
+            chiC[p] = pc[p];
+            etaC[p] = pe[p];
+            bs[p] = ps[p];
+            bj[p] = pj[p];
+        }
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+            scaJ[p] = bs[p] * bj[p]; // sca * Jdag of compute_source_fn :169-179
+    }
+    const LaneFinRecs recs = lane_fin_recs(a, ti, nC, c.lane);
+    lane_fin_params(a, c, ti, nC); // (stays in the wavefront's LDS block for the finish)
+    double boltz[D];
+    {
+        double rT[D];
+        ls_lds<D>(c.sDep, c.vK + 8u, c.oG + 3u * c.gStride, rT);
+        const double hc_kl = HC_K / c.wav;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+            boltz[p] = ls_exp_neg(-hc_kl * rT[p], c.sExp);
+    }
+    // the slots' level sums: [slot][eta_A, chi_i, chi_j, U_i, U_j] and the mixed continuum's V_ji
+    double ls[2][5][D], vj[2][D];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+        {
+            vj[e][p] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                ls[e][q][p] = 0.0;
+        }
+    for (int q = 0; q < nC; ++q)
+    {
+        const LaneFinRec1 rc = lane_fin_rec(recs, q);
+        const unsigned feed = (unsigned)__builtin_amdgcn_readlane((int)recs.feed, q);
+        double ni[D], nj[D], rat[D];
+        ls_lds<D>(c.sDep, c.vK, c.oN + rc.nI, ni);
+        ls_lds<D>(c.sDep, c.vK, c.oN + rc.nJ, nj);
+        ls_lds<D>(c.sDep, c.vK, c.oRat + rc.rat, rat);
+        const double* ppq = c.sPP + (q * c.L + c.r) * 3;
+        const double p0 = ppq[0], p2 = ppq[2];
+        double vji[D], chi_c[D], uji[D], eta_c[D];
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+        {
+            vji[p] = (rat[p] * boltz[p]) * p0;
+            chi_c[p] = ni[p] * p0 - nj[p] * vji[p];
+            uji[p] = p2 * vji[p];
+            eta_c[p] = nj[p] * uji[p];
+            chiC[p] += chi_c[p];
+            etaC[p] += eta_c[p];
+        }
+        if (slotRows && feed != 0u)
+        {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+            {
+                const unsigned f = (feed >> (8 * e)) & 0xffu;
+                if (f == 0u)
+                    continue;
+#pragma unroll
+                for (int p = 0; p < D; ++p)
+                {
+                    if (f & 1u)
+                        ls[e][0][p] += eta_c[p];
+                    if (f & 2u)
+                        ls[e][1][p] += chi_c[p];
+                    if (f & 4u)
+                        ls[e][1][p] -= chi_c[p];
+                    if (f & 8u)
+                        ls[e][2][p] += chi_c[p];
+                    if (f & 16u)
+                        ls[e][2][p] -= chi_c[p];
+                    if (f & 32u)
+                        ls[e][3][p] += uji[p];
+                    if (f & 64u)
+                        ls[e][4][p] += uji[p];
+                    if (f & 128u)
+                        vj[e][p] = vji[p];
+                }
+            }
+        }
+    }
+    {
+        double* r3 = c.sRow3 + c.lane * D;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+        {
+            r3[p] = chiC[p];
+            r3[64 * D + p] = etaC[p];
+            r3[2 * 64 * D + p] = scaJ[p];
+        }
+    }
+    if (slotRows)
+    {
+        // the slots' rows into the tile's row block (rows no continuum feeds are neither written nor read: zmask)
+        const int nSl = tr.td.nLine + tr.td.nMixed;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+        {
+            if (e >= nSl)
+                continue;
+            const DevTileSlot& u = tr.slot[e];
+            if (!(u.flags & 1))
+                continue;
+            GLOBAL_AS double* dst = (GLOBAL_AS double*)c.rRows + (size_t)(c.vRow >> 3);
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+            {
+                if (u.zmask & (1 << q))
+                    continue;
+                GLOBAL_AS double* d = dst + (size_t)(u.r0 + q) * (c.rowStride >> 3);
+#pragma unroll
+                for (int p = 0; p < D; ++p)
+                    d[p] = ls[e][q][p];
+            }
+            if (e >= tr.td.nLine && u.rAux >= 0)
+            {
+                GLOBAL_AS double* d = dst + (size_t)u.rAux * (c.rowStride >> 3);
+#pragma unroll
+                for (int p = 0; p < D; ++p)
+                    d[p] = vj[e][p];
+            }
+        }
+    }
 }
 
 template <int D, int P0, int NP>
@@ -1847,7 +1989,7 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     // the finish's records and parameters are requested first: they arrive while J goes out
     const int nCont = dyn.prdOnly ? 0 : tr.nCont;
     const LaneFinRecs recs = lane_fin_recs(a, ti, nCont, c.lane);
-    lane_fin_params(a, c, ti, nCont);
+    // (the continua's per-wavelength parameters are in the wavefront's LDS block since lane_pre)
     {
         double dj = 0.0;
         if (c.act)
@@ -1970,7 +2112,6 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
     LS_KEEPI(la);
     const int nCont = dyn.prdOnly ? 0 : tr.nCont;
     const LaneFinRecs recs = lane_fin_recs(a, ti, nCont, c.lane);
-    lane_fin_params(a, c, ti, nCont);
     {
         double dj = 0.0;
         if (c.act)
@@ -2066,6 +2207,9 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevL
     int ms0 = 0, ms1 = 1;
     if (have)
     {
+        c.wav = ((const GLOBAL_AS DevLaneRay*)a.laneRays)[(size_t)ti * a.L + min(c.rRaw, a.L - 1)].wav;
+        lane_pre<D>(a, tr, c, ti, RATES);
+        LS_PHASE();
 #if defined(LS_ISA_ONLY) && defined(LS_ONLY_NL) /* one tile kind, for register / instruction counts of the listing */
         ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
         if (LS_ONLY_NL < 2)
