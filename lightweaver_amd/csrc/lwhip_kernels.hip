@@ -254,6 +254,16 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
     double* G = a.Gamma + a.atomGammaOff[at];
     const double* Cm = a.Cmat + a.atomGammaOff[at];
     const int tr0 = a.atomTrOff[at], tr1 = a.atomTrOff[at + 1];
+    // the atom's (i, j) pairs once into LDS: read from global memory inside the loop below they were a chain of ~2 Ntrans
+    // dependent memory round trips per thread (7 of the launch's 11 microseconds)
+    enum { APPLY_TR = 512 };
+    __shared__ short sLi[APPLY_TR], sLj[APPLY_TR];
+    for (int q = threadIdx.x; q < min(tr1 - tr0, (int)APPLY_TR); q += blockDim.x)
+    {
+        sLi[q] = (short)a.transLi[tr0 + q];
+        sLj[q] = (short)a.transLj[tr0 + q];
+    }
+    __syncthreads();
     // off-diagonal entries: pre-fill (optional) + radiative terms of the transitions that feed them
     for (int idx = threadIdx.x; idx < Nl * Nl * APPLY_K; idx += blockDim.x)
     {
@@ -265,7 +275,7 @@ template <class A> DEVINL void apply_kernel_body(const A& a)
         double v = a.prefill ? a.crsw * Cm[(size_t)e * Ns + k] : G[(size_t)e * Ns + k];
         for (int tr = tr0; tr < tr1; ++tr) // transitions in reference order
         {
-            const int i = a.transLi[tr], j = a.transLj[tr];
+            const int i = tr - tr0 < APPLY_TR ? (int)sLi[tr - tr0] : a.transLi[tr], j = tr - tr0 < APPLY_TR ? (int)sLj[tr - tr0] : a.transLj[tr];
             if (to == i && from == j)
                 v += redAt(tr, 0, k);
             if (to == j && from == i)
