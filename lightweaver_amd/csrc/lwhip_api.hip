@@ -1380,9 +1380,15 @@ int build_tables(lwhip_context* c)
                 }
                 else
                 {
-                    // one partial round: a cut chunk becomes tailS / 1 workgroups; the heaviest first, while they fit
+                    // one partial round: a cut chunk becomes tailS / 1 workgroups; the heaviest first, while they fit.
+                    // A round that is (nearly) full does not run as one: the dispatcher does not co-schedule every workgroup
+                    // (6 144 wavelengths = 512 chunks on 512 slots took two task lengths, 0.115 ms) -- then EVERY chunk is cut
+                    // and the launch is two rounds of half-length tasks
                     const int extra = tailS - 1;
-                    const int k = std::min(nch0, std::max(0, (slotsWg - nch0) / extra));
+                    const int fullPct = env_int("LWHIP_LANE_FULL", 85);
+                    int k = std::min(nch0, std::max(0, (slotsWg - nch0) / extra));
+                    if (tailS == 2 && nch0 * 100 > slotsWg * fullPct)
+                        k = nch0;
                     for (int q = 0; q < k; ++q)
                         cut[ord[q]] = 1;
                 }
