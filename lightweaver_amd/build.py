@@ -14,8 +14,9 @@ LIB = os.path.join(PKG, 'liblwhip.so')
 PLUGIN = os.path.join(PKG, 'LwHipIterScheme.so')
 REF_SRC = os.environ.get('LW_REFERENCE_SOURCE', '/root/reference/Source')
 
-HIP_SOURCES = ['lwhip_api.hip', 'lwhip_kernels.hip', 'lwhip_raymarch.hip', 'lwhip_lanesweep.hip', 'lwhip_voigt.hip', 'lwhip_prd.hip', 'lwhip_pops.hip', 'lwhip_fs2d.hip', 'lwhip_2d.hip', 'lwhip_geom2d.hip']
-HIP_HEADERS = ['lwhip_internal.h', 'lwhip_device.h', os.path.join('..', '..', 'include', 'lwhip.h')]
+HIP_SOURCES = ['lwhip_api.hip', 'lwhip_tables.hip', 'lwhip_state.hip', 'lwhip_api2d.hip', 'lwhip_batch.hip', 'lwhip_api_prd.hip',
+               'lwhip_kernels.hip', 'lwhip_raymarch.hip', 'lwhip_lanesweep.hip', 'lwhip_voigt.hip', 'lwhip_prd.hip', 'lwhip_pops.hip', 'lwhip_fs2d.hip', 'lwhip_2d.hip', 'lwhip_geom2d.hip']
+HIP_HEADERS = ['lwhip_internal.h', 'lwhip_device.h', 'lwhip_host.h', os.path.join('..', '..', 'include', 'lwhip.h')]
 
 
 def _hipcc():

@@ -1,0 +1,352 @@
+// lwhip_host.h -- what the host-side translation units of the C ABI (include/lwhip.h) share: the device-buffer wrapper,
+// the context (the HBM-resident copy of a problem, its tables and launch state), the error plumbing and the functions that
+// cross file boundaries.
+//
+//     lwhip_api.hip      create / destroy, one iteration (sweep -> reduce -> [all-reduce by the caller] -> apply), populations
+//     lwhip_tables.hip   validation of the descriptor and the per-wavelength activity tables of the sweeps (build_tables)
+//     lwhip_state.hip    device allocations, kernel argument blocks, the sweep's launch sequence, upload / download
+//     lwhip_api2d.hip    the 2D iteration's launch sequence, the 2D primitives
+//     lwhip_batch.hip    1.5D column batches
+//     lwhip_api_prd.hip  PRD sub-iterations
+//
+// There is no CPU fallback: without a HIP device every compute entry point fails with LWHIP_ERR_DEVICE.
+#pragma once
+#include "lwhip_internal.h"
+#include "../../include/lwhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace lwhip
+{
+// records the message lwhip_last_error() returns (thread-local) and passes the code through
+int fail(int code, const std::string& msg);
+
+#define HIP_TRY(expr)                                                                                  \
+    do                                                                                                 \
+    {                                                                                                  \
+        hipError_t err__ = (expr);                                                                     \
+        if (err__ != hipSuccess)                                                                       \
+            return fail(LWHIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(err__));       \
+    } while (0)
+
+template <typename T> struct DevBuf
+{
+    T* p = nullptr;
+    size_t n = 0;
+    bool owned = true;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0)
+            return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        // diagnosis (LWHIP_POISON=1): fresh allocations hold NaN / -1, so that a read of memory nothing initialised shows up
+        // in the results instead of depending on what the previous owner of the pages left there
+        if (e == hipSuccess && poison_on())
+            e = hipMemset(p, 0xFF, count * sizeof(T));
+        static const bool trace = std::getenv("LWHIP_TRACE_ALLOC") != nullptr; // diagnosis: which buffer a faulting address follows
+        if (trace)
+            std::fprintf(stderr, "lwhip alloc %p .. %p (%zu x %zu B)\n", (void*)p, (void*)((char*)p + count * sizeof(T)), count, sizeof(T));
+        return e;
+    }
+    static bool poison_on()
+    {
+        static const bool poison = std::getenv("LWHIP_POISON") != nullptr;
+        return poison;
+    }
+    // a window of somebody else's allocation (the depth arena of the lane sweep)
+    void view(T* ptr, size_t count)
+    {
+        release();
+        p = ptr;
+        n = count;
+        owned = false;
+    }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty())
+            return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release()
+    {
+        if (p && owned)
+        {
+            // (LWHIP_POISON=1: and a buffer is poisoned again when it is given back, with another pattern -- a stale device
+            // pointer into it, or memory the allocator hands out behind this wrapper's back, then reads -nan / 0xFEFEFEFE)
+            if (poison_on())
+                (void)hipMemset(p, 0xFE, n * sizeof(T));
+            (void)hipFree(p);
+        }
+        p = nullptr;
+        n = 0;
+        owned = true;
+    }
+    ~DevBuf() { release(); }
+};
+
+enum { PRD_MAX_SLICES = 32 }; // workgroups per depth point in the PRD scattering integral
+
+struct HostTrans
+{
+    lwhip_transition t;   // borrowed host pointers
+    int atom;
+    int NblueLoc, NredLoc; // clipped to the shard, shard-local indices
+    int ltStart;           // first own-grid index inside the shard
+    int row;               // wphi row (lines) / ratio row (continua)
+    int64_t parOff, phiOff, rhoOff;
+    int64_t waveOff; // lines: offset of the full own grid / wlambda in the lineWave / lineWlam pools
+};
+}
+using namespace lwhip;
+
+struct lwhip_context
+{
+    lwhip_problem prob;             // copy of the descriptor (host pointers borrowed)
+    std::vector<lwhip_atom> atoms;
+    std::vector<HostTrans> trans;   // global transition list, reference order
+    std::vector<int> levelOff, atomTrOff;
+    std::vector<int64_t> gammaOff;
+    int device = 0;
+    int worldSize = 1, worldRank = 0;
+    int laStart = 0, laEnd = 0, Nla = 0;
+    int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
+    int maxL = 0, maxC = 0;
+    bool is2d = false;            // x-periodic 2D geometry (prob.grid2d): batched pipeline of lwhip_2d.hip
+    int Nx = 1, batch2d = 1;
+    std::vector<DevLaHeader> hdrHost;
+    std::vector<int32_t> contLaHost;
+    // the ray-column sweep (lwhip_raymarch.hip): tiles of structurally identical wavelengths
+    bool tiled = false;
+    int tileL = 12, nTiles = 0, nTileChunks = 0, nTileChunksPrd = 0, nPostChunks = 0, nPostChunksPrd = 0, nTilesPrd = 0;
+    bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
+    // depth-across-lanes sweep (lwhip_lanesweep.hip): D points per lane, LR lanes per ray, R wavelengths per wavefront
+    bool laneSweep = false;
+    bool chunkOrderOn = false, chunkSplitOn = false;
+    int laneSplitPrd = 1;          // ... in the PRD rates pass (its tile list is shorter)
+    int laneSplit = 1;             // lane sweep: wavefronts a tile's rays are split over (1, 2, 4)
+    int laneD = 0, laneLR = 0, laneR = 0;
+    DevBuf<DevPostProg> postProg;
+    DevBuf<double> geoT;
+    // hybrid PRD (lwhip_options.hprd): the tables of configure_hprd_coeffs on the device
+    // deterministic mode (LWHIP_OPT_DETERMINISTIC): per-workgroup slabs + the (workgroup, slot) lists of every transition
+    bool deterministic = false;
+    DevBuf<double> detSlab;
+    DevBuf<int32_t> detOff, detEnt, detOffPrd, detEntPrd;
+    const lwhip_hprd* hprd = nullptr;
+    std::vector<int> hLa2prdHost, hLa2hHost;     // global wavelength -> row of JRest / ordinal among hPrdIdxs, or -1
+    std::vector<int64_t> hRhoOffHost;             // per transition: offset of its rho-coefficient block, or -1
+    DevBuf<lwhip_rho_coeff> hRho;
+    DevBuf<int32_t> hLa2h;
+    DevBuf<int64_t> hJOff;
+    DevBuf<lwhip_j_coeff> hJCoef;
+    DevBuf<double> JRest;
+    double* lsDbgHost = nullptr; // LWHIP_LS_TIMING: phase clocks of the last sweep, [nTiles][8]
+    DevBuf<double> depArena; // lane sweep: n | wphi | ratio | geoT in one allocation (one buffer resource in the kernel)
+    int tileWaves = 4, maxSlotsTile = 0, maxCTTile = 1, maxCTPost = 1, tileCap = 0, ktStride = 4;
+    int64_t rowsTileTot = 0, momTot = 0, phiTTot = 0;
+    int preCols = 0;              // most level-sum columns a tile's rows need (LDS columns of the pre-pass)
+    DevBuf<DevTile> tiles;
+    DevBuf<DevTileSlot> tslots, tslotsPrd;
+    DevBuf<DevTileCopy> tcopies;
+    DevBuf<int32_t> tileRemap;
+    DevBuf<DevContRec> contRec;
+    DevBuf<int32_t> chunkOrder;   // lane sweep: dispatch order of the workgroups' chunks
+    // lane sweep: the flat per-workgroup / per-tile records of a task's setup and finish (lwhip_internal.h)
+    DevBuf<DevLaneWg> laneWg, laneWgPrd;
+    DevBuf<DevLaneTile> laneTiles, laneTilesPrd;
+    DevBuf<DevLaneRay> laneRays;
+    DevBuf<DevLaneFin> laneFin;
+    DevBuf<double> laneFinPar, bcPlanck;
+    DevBuf<int32_t> chunkSplit;   // lane sweep: per chunk, the wavefronts its tiles' rays are split over (the launch's tail)
+    DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
+        postCs;
+    DevBuf<double> geo, kt, rowsTile, momTile, phiT;
+    DevBuf<TileArgs> dtargs, dtargsPrd;
+    TileArgs htargs{}, htargsPrd{};
+    int64_t rowsTot = 0;
+    int nContLa = 0;
+    int64_t gammaTot = 0, phiTot = 0, rhoTot = 0, parTot = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+
+    DevBuf<double> height, temperature, muz, wmu, wavelength, lowerBcData, upperBcData;
+    DevBuf<int32_t> rayAll, rayUp, lowerIdx, upperIdx;
+    DevBuf<double> bgChi, bgEta, bgSca, J, I, depthChi, depthEta, depthI;
+    DevBuf<double> n, nTotal, ratio, wphi, phi, rho, par, Gamma, Cmat, Rij, Rji;
+    DevBuf<double> vlosMu, vBroad, aDamp, Qelast, lineWave, lineWlam;
+    DevBuf<double> prdChange, rowsBuf, popScratch, prdJt, prdJ;
+    DevBuf<PrdLineArgs> prdArgsDev;   // argument blocks of the PRD lines of a sub-iteration (one launch for all lines)
+    std::vector<PrdLineArgs> prdArgsHost; // what the device copy holds
+    DevBuf<double> g2mux, b2cs, b2I, b2Psi, b2coef, red2d;
+    DevBuf<int32_t> b2idx;
+    int groups2d = 1, maxRowsLa = 1;
+    int kLo = 0, kHi = -1; // depth range of the population updates (lwhip_set_depth_range); kHi < 0: to the end
+    int djIdxMode = 0;     // lwhip_set_djmax_index_mode: 1 = the single-thread scheme's index bookkeeping
+    double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration
+    double* tailMappedDev = nullptr;
+    double tailTicket = 0.0;      // ticket of the last launch that reports through tailMapped
+    // line profiles generated on the device (lwhip_compute_profiles): re-derived before the next sweep whenever the
+    // inputs they depend on (vlosMu: LWHIP_ATMOS; vBroad, aDamp: LWHIP_NSTAR) are uploaded again
+    bool deviceProfiles = false, profilesStale = false;
+    DevBuf<VoigtLineArgs> voigtList; // the lines' argument blocks of lwhip_compute_profiles
+    DevBuf<double> wphiScratch;   // [16, Ns] wavelength-slice sums of the profile normalisation
+    DevBuf<int> wphiTicket;       // arrival counters of its point tiles
+    bool lastSweepUpOnly = false; // the last sweep traced the up rays only (lwhip_formal_sol(upOnly))
+    bool partsOnly = false;       // fs_partial ran stage 1 of the slab reduce only (one-call iteration)
+    int batchHint = 0;            // lwhip_options.flags & 0xffff: contexts expected to share the device (column batch)
+    bool prdDetailed = false;     // LWHIP_OPT_PRD_DETAILED: the PRD calls include the detailed atoms' PRD lines
+    DevBuf<lwhip_intersection> g2uw, g2dw, g2sub;
+    DevBuf<double> xbcLow, xbcUp;      // 2D, fixed x boundaries: [Nla, Nmu, Nz] of the shard
+    DevBuf<double> zDown, zUp;         // ZPlaneDecomposition outputs [Nla, Nrays, Nx] (lwhip_set_zplane_outputs)
+    double* zDownHost = nullptr;       // their host arrays [Nlambda, Nrays, Nx]
+    double* zUpHost = nullptr;
+    DevBuf<int32_t> xIdxLow, xIdxUp;   // [Nrays, 2]
+    DevBuf<int32_t> g2long, g2subOff, slotTrD, g2lcOwner, g2uwA, g2dwA;
+    DevBuf<double> g2uwS, g2dwS; // the records field by field
+    DevBuf<double> b2lc; // [batch2d][NlongChar][3]
+    std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
+    std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
+    int64_t prdRowsTot = 0;
+    bool prdPending = false;          // between lwhip_prd_partial and lwhip_prd_finalise
+    std::vector<std::unique_ptr<DevBuf<double>>> gII; // per transition: cached PRD weights (lazily)
+    std::vector<char> gIIValid;
+    DevBuf<NrAtom> nrAtoms, statEqAtoms;
+    DevBuf<NgAtom> ngAtoms;
+    DevBuf<double> ngHistory;
+    std::vector<NgAtom> ngAtomsHost;
+    int ngOrder = 0, ngPeriod = 0, ngDelay = 0, ngCount = 0;
+    bool ngConfigured = false;
+    int statEqKey = -2;
+    int32_t* statusHost = nullptr;
+    int32_t* statusDev = nullptr;
+    double* changeHost = nullptr; // host-mapped per-block population changes of the last reported solve
+    double* changeDev = nullptr;
+    size_t changeCount = 0;
+    DevBuf<int32_t> transType;
+    DevBuf<int32_t> contLa;
+    DevBuf<int32_t> prdChangeIdx;
+    double* prdPinned = nullptr;
+    DevBuf<DevTrans> dtrans;
+    DevBuf<DevLaHeader> laHdr;
+    DevBuf<DevSlot> slots;
+    DevBuf<DevProgram> progs;
+    DevBuf<DevProgRow> progRows;
+    DevBuf<DevProgEnt> progEnts;
+    DevBuf<ContArgs> dargs;      // 2D: argument block of the continuum-row kernel
+    ContArgs hargs{};
+    bool atomicParts = false;     // the pending iteration's parts were accumulated by atomics
+    bool red8Clean = false;       // red8 holds zeros (only the atomic path leaves it so)
+    int* zeroCheck = nullptr;     // LWHIP_CHECK_ZERO=1 (diagnosis): host-mapped count of non-zero words found in red8 at sweep entry
+    int* zeroCheckDev = nullptr;
+    DevBuf<int32_t> atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
+    DevBuf<int64_t> atomGammaOff;
+    DevBuf<double> red, red8, dJ;
+    std::vector<double> gatherHost;
+    DevBuf<int32_t> status;
+
+    bool profiling = false;
+    int profEvery = 1, profCount = 0; // time every profEvery-th sweep launch (lwhip_profile_enable(ctx, n))
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double sweepMs = 0.0;
+    int sweepCount = 0;
+    bool partialPending = false;
+    bool prefillPending = false; // lwhip_gamma_prefill_from_C deferred into the next apply_kernel
+    double prefillCrsw = 1.0;
+    double* gatherPinned = nullptr;
+    // pinned staging for the many small per-atom / per-transition host arrays: they are packed here and
+    // cross PCIe as a few large copies (a pageable hipMemcpy per 656-byte row costs ~12 us each)
+    double* stage = nullptr;
+    size_t stageDoubles = 0;
+
+    ~lwhip_context()
+    {
+        for (auto& pr : pending)
+        {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        if (ownStream)
+            (void)hipStreamDestroy(ownStream);
+        if (gatherPinned)
+            (void)hipHostFree(gatherPinned);
+        if (tailMapped)
+            (void)hipHostFree(tailMapped);
+        if (stage)
+            (void)hipHostFree(stage);
+        if (statusHost)
+            (void)hipHostFree(statusHost);
+        if (changeHost)
+            (void)hipHostFree(changeHost);
+        if (prdPinned)
+            (void)hipHostFree(prdPinned);
+        if (zeroCheck)
+            (void)hipHostFree(zeroCheck);
+    }
+};
+
+#define H2D(dst, src, count)                                                                           \
+    HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyHostToDevice, c->stream))
+#define D2H(dst, src, count)                                                                           \
+    HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyDeviceToHost, c->stream))
+
+namespace lwhip
+{
+inline int env_int(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v)
+        return dflt;
+    return std::atoi(v);
+}
+
+inline double trans_wlambda(const lwhip_transition& t, int lt)
+{
+    // Transition::wlambda, LwTransition.hpp:71-81
+    const int len = t.Nred - t.Nblue;
+    if (lt == 0)
+        return 0.5 * (t.wavelength[1] - t.wavelength[0]) * t.dopplerWidth;
+    if (lt == len - 1)
+        return 0.5 * (t.wavelength[len - 1] - t.wavelength[len - 2]) * t.dopplerWidth;
+    return 0.5 * (t.wavelength[lt + 1] - t.wavelength[lt - 1]) * t.dopplerWidth;
+}
+
+// lwhip_tables.hip
+int validate(const lwhip_problem* p, std::string& why);
+int build_tables(lwhip_context* c);
+// lwhip_state.hip
+int alloc_state(lwhip_context* c);
+int build_sweep_args(lwhip_context* c);
+int build_tile_args(lwhip_context* c);
+int retile_profiles(lwhip_context* c);
+bool retile_args(lwhip_context* c, RetileArgs& r);
+TileDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate);
+hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+int flush_prefill(lwhip_context* c);
+int verify_zero_check(lwhip_context* c);
+int collect_profile(lwhip_context* c);
+// lwhip_api.hip
+ReduceArgs make_reduce_args(lwhip_context* c);
+ApplyArgs make_apply_args(lwhip_context* c);
+int ensure_profiles(lwhip_context* c);
+int voigt_line_list(lwhip_context* c, std::vector<VoigtLineArgs>& out);
+int stat_equil_impl(lwhip_context* c, int atom, bool wait, double* dPops = nullptr, int32_t* dPopsMaxIdx = nullptr);
+// lwhip_api2d.hip
+int run_2d(lwhip_context* c, int lambdaIterate, int mode = 0);
+}

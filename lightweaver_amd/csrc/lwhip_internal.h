@@ -1,4 +1,4 @@
-// lwhip_internal.h -- device-side tables shared by the host API (lwhip_api.hip) and the kernels
+// lwhip_internal.h -- device-side tables shared by the host API (lwhip_host.h and the files it lists) and the kernels
 // (lwhip_kernels.hip).  Not part of the public ABI (that is include/lwhip.h).
 #pragma once
 #include <vector>

@@ -52,10 +52,12 @@ def test_throughput_grid_iteration_and_stat_equil_vs_oracle(gpu):
                 assert rel_err(a.n, b.n) <= 1e-8
 
 
-@pytest.mark.parametrize('nla,sweep', [(10240, 'march'), (3840, 'lanes'), (5120, 'lanes'), (7680, 'lanes')])
+@pytest.mark.parametrize('nla,sweep', [(10240, 'march'), (3840, 'lanes'), (5120, 'lanes'), (5632, 'lanes'), (6144, 'lanes'),
+                                       (7680, 'lanes')])
 def test_other_sizes_and_sweeps_vs_oracle(gpu, monkeypatch, nla, sweep):
     """The work-distribution regimes of the lane sweep the other tests do not reach -- one partial round with the heaviest
-    chunks' rays split (3 840, 5 120 wavelengths), more than one round with a split tail at another size (7 680) -- and the
+    chunks' rays split (3 840, 5 120 wavelengths), a single round so full that every chunk is cut in two (5 632, 6 144:
+    the LWHIP_LANE_FULL rule), more than one round with a split tail at another size (7 680) -- and the
     ray-column march at the bench size (the fallback kernel, LWHIP_SWEEP=march): one iteration against the oracle, 1e-9."""
     from lightweaver_amd.context import Context
     monkeypatch.setenv('LWHIP_SWEEP', sweep)
