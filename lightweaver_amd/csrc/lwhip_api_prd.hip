@@ -24,12 +24,20 @@ int lwhip_prd_pack(lwhip_context* c, void** devPtr, size_t* count)
     for (size_t q = 0; q < c->prdLines.size(); ++q)
     {
         const HostTrans& h = c->trans[c->prdLines[q]];
-        const size_t nlt = h.NredLoc - h.NblueLoc;
         // the local mean intensity of the scattering integral: J of the line's wavelengths, or -- hybrid PRD -- the rows
-        // of the rest-frame JRest they map to (consecutive: every wavelength of a PRD line is in prdIdxs; Prd.cpp:384-389)
-        const double* src = c->hprd ? c->JRest.p + (size_t)c->hLa2prdHost[h.t.Nblue + h.ltStart] * Ns : c->J.p + (size_t)h.NblueLoc * Ns;
+        // of the rest-frame JRest they map to (consecutive: every wavelength of a PRD line is in prdIdxs; Prd.cpp:384-389).
+        // A shard contributes its own wavelengths' J rows; of JRest, which every wavelength of the shard has added to, its
+        // partial sums of ALL rows of the line (the all-reduce of the gather buffer then yields the totals)
+        size_t nlt = h.NredLoc - h.NblueLoc, lt0 = h.ltStart;
+        const double* src = c->J.p + (size_t)h.NblueLoc * Ns;
+        if (c->hprd)
+        {
+            lt0 = 0;
+            nlt = h.t.Nred - h.t.Nblue;
+            src = c->JRest.p + (size_t)c->hLa2prdHost[h.t.Nblue] * Ns;
+        }
         if (nlt)
-            HIP_TRY(hipMemcpyAsync(c->prdJ.p + ((size_t)c->prdRowOff[q] + h.ltStart) * Ns, src, nlt * Ns * sizeof(double),
+            HIP_TRY(hipMemcpyAsync(c->prdJ.p + ((size_t)c->prdRowOff[q] + lt0) * Ns, src, nlt * Ns * sizeof(double),
                                    hipMemcpyDeviceToDevice, c->stream));
     }
     if (devPtr)
@@ -106,8 +114,10 @@ int lwhip_prd_partial(lwhip_context* c)
         a.transLi = c->transLi.p;
         a.transLj = c->transLj.p;
         // this shard's emission wavelengths of the line: [laLo, laHi) in the line's own grid; its rho rows
-        a.laLo = h.ltStart;
-        a.laHi = h.ltStart + (h.NredLoc - h.NblueLoc);
+        // (hybrid PRD: rho of the line's whole grid on every shard -- a ray's rho is interpolated between neighbouring
+        // wavelengths of the line, wherever they are swept)
+        a.laLo = h.rhoLt0;
+        a.laHi = h.rhoLt0 + h.rhoRows;
         a.rho = c->rho.p + h.rhoOff;
         // enough workgroups to fill the chip: Ns x slices >= ~8 per CU, at least 128 wavelengths each
         a.slices = std::max(1, std::min({ (int)PRD_MAX_SLICES, (2048 + Ns - 1) / Ns, (a.laHi - a.laLo + 127) / 128 }));

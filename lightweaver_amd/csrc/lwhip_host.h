@@ -109,6 +109,7 @@ struct HostTrans
     int atom;
     int NblueLoc, NredLoc; // clipped to the shard, shard-local indices
     int ltStart;           // first own-grid index inside the shard
+    int rhoLt0 = 0, rhoRows = 0; // PRD lines: the own-grid rows held in the rho pool (the shard's; hybrid PRD: the whole grid)
     int row;               // wphi row (lines) / ratio row (continua)
     int64_t parOff, phiOff, rhoOff;
     int64_t waveOff; // lines: offset of the full own grid / wlambda in the lineWave / lineWlam pools

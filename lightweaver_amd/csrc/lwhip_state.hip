@@ -682,8 +682,8 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                     H2D(c->aDamp.p + (size_t)h.row * Ns, t.aDamp, Ns);
                 if ((mask & LWHIP_NSTAR) && t.Qelast)
                     H2D(c->Qelast.p + (size_t)h.row * Ns, t.Qelast, Ns);
-                if ((mask & LWHIP_RHOPRD) && t.prd && nlt)
-                    H2D(c->rho.p + h.rhoOff, t.rhoPrd + (size_t)h.ltStart * Ns, nlt * Ns);
+                if ((mask & LWHIP_RHOPRD) && t.prd && h.rhoOff >= 0 && h.rhoRows > 0)
+                    H2D(c->rho.p + h.rhoOff, t.rhoPrd + (size_t)h.rhoLt0 * Ns, (size_t)h.rhoRows * Ns);
             }
             else if (mask & LWHIP_NSTAR)
             {
@@ -781,8 +781,8 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
         {
             const int tr = c->atomTrOff[ia] + kr;
             const HostTrans& h = c->trans[tr];
-            if ((mask & LWHIP_RHOPRD) && h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && h.NredLoc > h.NblueLoc)
-                D2H(h.t.rhoPrd + (size_t)h.ltStart * Ns, c->rho.p + h.rhoOff, (size_t)(h.NredLoc - h.NblueLoc) * Ns);
+            if ((mask & LWHIP_RHOPRD) && h.t.type == LWHIP_LINE && h.t.prd && h.rhoOff >= 0 && h.rhoRows > 0)
+                D2H(h.t.rhoPrd + (size_t)h.rhoLt0 * Ns, c->rho.p + h.rhoOff, (size_t)h.rhoRows * Ns);
             if ((mask & LWHIP_PROFILES) && h.t.type == LWHIP_LINE)
             {
                 const size_t nlt = h.NredLoc - h.NblueLoc;

@@ -203,9 +203,12 @@ int build_tables(lwhip_context* c)
     {
         const lwhip_hprd& H = *c->hprd;
         const int Nlam = c->prob.Nlambda, Nr = c->Nrays;
-        if (c->is2d || c->worldSize > 1 || c->laStart != 0 || c->laEnd != Nlam)
-            return fail(LWHIP_ERR_UNSUPPORTED, "hybrid PRD: unsharded 1D contexts only (rho of the neighbouring wavelengths and "
-                                               "JRest live on one device)");
+        // On a wavelength shard (round 4) every rank keeps rho of the WHOLE grid of each PRD line (a ray's rho is interpolated
+        // between neighbouring wavelengths of the line, which may belong to another shard) and evaluates the scattering
+        // integral for all of them; JRest is additive over the wavelengths (Prd.cpp:384-389), so each rank's partial sums
+        // ride in the all-reduce of the PRD gather buffer (lwhip_prd_pack).
+        if (c->is2d)
+            return fail(LWHIP_ERR_UNSUPPORTED, "hybrid PRD: 1D contexts only");
         if (H.NprdLambda < 1 || H.Nlines < 1 || !H.prdIdxs || !H.JRest || !H.lineAtom || !H.lineTrans || !H.rhoCoeffs
             || (H.NhPrd > 0 && (!H.hPrdIdxs || !H.jCoeffOff || !H.jCoeffs)))
             return fail(LWHIP_ERR_INVALID, "hybrid PRD: incomplete lwhip_hprd");
@@ -242,7 +245,7 @@ int build_tables(lwhip_context* c)
         }
         rho.resize(rho.size() + 64, lwhip_rho_coeff{ 0, 0, 0.0 }); // (a ray's last block of depths reads past its row)
         HIP_TRY(c->hRho.upload(rho));
-        std::vector<int32_t> l2h(c->hLa2hHost.begin(), c->hLa2hHost.end());
+        std::vector<int32_t> l2h(c->hLa2hHost.begin() + c->laStart, c->hLa2hHost.begin() + c->laEnd); // (indexed by the shard's wavelength)
         HIP_TRY(c->hLa2h.upload(l2h));
         if (H.NhPrd > 0)
         {
@@ -294,10 +297,18 @@ int build_tables(lwhip_context* c)
                 h.row = c->Nline++;
                 h.phiOff = c->phiTot;
                 c->phiTot += nlt * c->Nrays * 2 * Ns;
+                h.rhoLt0 = h.ltStart;
+                h.rhoRows = (int)nlt;
                 if (h.t.prd)
                 {
+                    if (c->hprd && c->hRhoOffHost[c->trans.size()] >= 0)
+                    {
+                        // hybrid PRD: rho of the line's whole grid on every shard
+                        h.rhoLt0 = 0;
+                        h.rhoRows = h.t.Nred - h.t.Nblue;
+                    }
                     h.rhoOff = c->rhoTot;
-                    c->rhoTot += nlt * Ns;
+                    c->rhoTot += (int64_t)h.rhoRows * Ns;
                 }
             }
             else
@@ -423,7 +434,7 @@ int build_tables(lwhip_context* c)
             for (int q = 0; q < 4; ++q)
                 sl.p[q] = par[(size_t)h.parOff + 4 * l + q];
             sl.phiOff = (h.t.type == LWHIP_LINE) ? h.phiOff + (int64_t)l * c->Nrays * 2 * Ns : -1;
-            sl.rhoOff = (h.rhoOff >= 0) ? h.rhoOff + (int64_t)l * Ns : -1;
+            sl.rhoOff = (h.rhoOff >= 0) ? h.rhoOff + (int64_t)(h.ltStart - h.rhoLt0 + l) * Ns : -1;
             slots.push_back(sl);
             slotTr.push_back(tr);
         }
@@ -803,7 +814,7 @@ int build_tables(lwhip_context* c)
                 {
                     // hybrid PRD: the coefficient block of the tile's first wavelength, and the line's first rho row
                     const HostTrans& ht = c->trans[slotTr[h.off + e]];
-                    const int64_t lt0 = la - ht.NblueLoc;
+                    const int64_t lt0 = ht.ltStart + la - ht.NblueLoc; // (the coefficient table covers the line's whole grid)
                     ts.hCoefOff = c->hRhoOffHost[slotTr[h.off + e]] + lt0 * c->Nrays * 2 * Ns;
                     ts.rhoOff = ht.rhoOff; // row 0 of the line
                 }

@@ -193,11 +193,64 @@ def test_hip_hprd_iterations_match_oracle(gpu, vamp):
 
 
 @pytest.mark.gpu
-def test_hip_hprd_refused_on_a_shard(gpu):
-    from lightweaver_amd.context import Context, LwHipError
+def test_hip_hprd_on_wavelength_shards(gpu):
+    """Hybrid PRD on two wavelength shards (round 4; the reference's hybrid path has no such restriction,
+    SimdFullIterationTemplates.hpp:397-408, Prd.cpp:384-389): two contexts owning [0, m) and [m, Nlambda) on one device, m
+    inside Ca II K's grid, the two all-reduces of a sub-iteration emulated through the library's own buffers.  Every rank keeps
+    rho of the lines' whole grids (a ray's rho is interpolated across the cut) and its partial JRest rides in the all-reduce of
+    the gather buffer: the sharded iteration + sub-iterations must reproduce the unsharded ones."""
+    import torch
+    from lightweaver_amd.context import Context
+    from lightweaver_amd.distributed import DeviceReduceBuffer
+
+    def allreduce(ctxs, getbuf):
+        views = []
+        for c in ctxs:
+            ptr, n = getbuf(c)
+            c.synchronize()
+            views.append(torch.as_tensor(DeviceReduceBuffer(ptr, n), device='cuda'))
+        total = sum(v.clone() for v in views)
+        for v in views:
+            v.copy_(total)
+        torch.cuda.synchronize()
+
     prob = hprd_problem()
+    lines = lambda p: [t for a in p.atoms for t in a.trans if t.rhoPrd is not None]
+    last = lines(prob)[-1]
+    m = (last.Nblue + last.Nred) // 2
     with bindings.OracleContext(prob.copy()) as oc:
         tables = oc.build_hprd()
-        with pytest.raises(LwHipError):
-            Context(prob, laStart=0, laEnd=prob.Nlambda // 2, worldSize=2, worldRank=0, hprd=tables)
+        whole = prob.copy()
+        with Context(whole, hprd=tables) as ctx:
+            ctx.formal_sol_gamma_matrices(deviceResident=True)
+            uw = ctx.prd_redistribute(3, 1e-30, deviceResident=True)
+            ctx.download(abi.J | abi.RATES | abi.RHOPRD)
+        pa, pb = prob.copy(), prob.copy()
+        with Context(pa, laStart=0, laEnd=m, worldSize=2, worldRank=0, hprd=tables) as A, \
+                Context(pb, laStart=m, laEnd=prob.Nlambda, worldSize=2, worldRank=1, hprd=tables) as B:
+            ctxs = (A, B)
+            for c in ctxs:
+                assert c.sweep_kind() == 'lanes'
+                c.gamma_prefill_from_C(1.0)
+                c.fs_partial()
+            allreduce(ctxs, lambda c: c.reduce_buffer())
+            for c in ctxs:
+                c.fs_finalise()
+            for it in range(3):
+                allreduce(ctxs, lambda c: c.prd_pack())
+                for c in ctxs:
+                    c.prd_partial()
+                allreduce(ctxs, lambda c: c.reduce_buffer())
+                res = [c.prd_finalise() for c in ctxs]
+                for dRho, idx, dJ, dJIdx in res:         # every rank sees the same global maxima
+                    assert np.allclose(dRho, uw.dRho[it], rtol=1e-7)
+                    assert dJ == pytest.approx(uw.dJPrdMax[it], rel=1e-7)
+            for c in ctxs:
+                c.download(abi.J | abi.RATES | abi.RHOPRD)
         tables.close()
+    assert rel_err(pa.J[:m], whole.J[:m]) <= 1e-9 and rel_err(pb.J[m:], whole.J[m:]) <= 1e-9
+    for ta, tb, tw in zip(lines(pa), lines(pb), lines(whole)):
+        # (rho of the whole grid on both ranks)
+        assert rel_err(ta.rhoPrd, tw.rhoPrd) <= 1e-9 and rel_err(tb.rhoPrd, tw.rhoPrd) <= 1e-9
+        for t in (ta, tb):
+            assert rel_err(t.Rij, tw.Rij) <= 1e-9 and rel_err(t.Rji, tw.Rji) <= 1e-9
