@@ -202,12 +202,20 @@ __global__ void __launch_bounds__(256) gather2d_kernel(const Batch2dArgs a)
 // Per wavelength, everything that does not depend on the ray -- populations, rho, the line weight, the continuum
 // rows the level sums start from -- is fetched once into registers / the thread's LDS column; the ray loop then
 // reads only I, Psi* and one phi per line from memory.
-template <int MAXL>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) rates2d_kernel(const Batch2dArgs a)
+// MAXM: mixed continua integrated ray by ray at one wavelength (the host refuses a 2D problem with more than 4); MAXP: pure
+// continua with register accumulators, any beyond go straight to memory.  The accumulators are most of the kernel's registers
+// (4 doubles per slot): the host picks the smallest instance that covers the problem -- <2, 2, 5> (hydrogen-like problems:
+// 36 doubles of sums) instead of <2, 4, 8> (56 doubles, 161 spilled registers at the 168 the occupancy allows).
+#ifndef R2D_WAVES
+#define R2D_WAVES 3 // wavefronts per SIMD the register budget is cut for
+#endif
+#ifndef R2D_RB
+#define R2D_RB 4 // rays whose loads are requested together
+#endif
+template <int MAXL, int MAXM, int MAXP>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(R2D_WAVES, R2D_WAVES))) rates2d_kernel(const Batch2dArgs a)
 {
     dbg_poison_lds();
-    constexpr int MAXM = 4; // mixed continua integrated ray by ray at one wavelength
-    constexpr int MAXP = 8; // pure continua with register accumulators; any beyond go straight to memory
     extern __shared__ double sRowAll[]; // [maxRowsLa][128]: every continuum row of the wavelength at the thread's point
     const int tid = threadIdx.x;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -342,7 +350,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         // holds no per-line temporaries any more, so four rays of loads in flight fit the registers (one ray of look-ahead
         // -- 8 VGPRs -- was all the ray-by-ray integrands left room for), and a wavelength costs two load round trips, not eight
         const int nR = a.nRaysActive;
-        constexpr int RB = 4; // (2 and 8, and 2 wavefronts per SIMD with 4 or 8, were measured: the same within noise)
+        constexpr int RB = R2D_RB; // (measured again with the <2, 2, 5> instance, 2.11 ms per iteration: RB 2 -> 2.14, 4 wavefronts
+                                   // per SIMD with RB 4 / 2 -> 2.19 / 2.17, 2 wavefronts with RB 8 -> 2.15)
         for (int r0 = 0; r0 < nR; r0 += RB)
         {
             double bI[RB], bP[RB], bPhi[RB][MAXL];
@@ -653,17 +662,21 @@ hipError_t launch_gather2d(const Batch2dArgs& a, int maxL, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream)
+hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, int maxM, int maxP, hipStream_t stream)
 {
+    if (maxM > 4)
+        return hipErrorInvalidValue; // (refused at lwhip_create)
     const dim3 grid((a.Ns + 127) / 128, a.nGroups);
     const size_t lds = (size_t)std::max(a.maxRowsLa, 1) * 128 * sizeof(double) + 64 * (sizeof(double) + sizeof(int))
                        + (size_t)((maxL <= 2 ? 2 : (maxL <= 4 ? 4 : 8)) + 4 + 8) * sizeof(DevSlot);
-    if (maxL <= 2)
-        hipLaunchKernelGGL(rates2d_kernel<2>, grid, dim3(128), lds, stream, a);
+    if (maxL <= 2 && maxM <= 2 && maxP <= 5)
+        hipLaunchKernelGGL((rates2d_kernel<2, 2, 5>), grid, dim3(128), lds, stream, a);
+    else if (maxL <= 2)
+        hipLaunchKernelGGL((rates2d_kernel<2, 4, 8>), grid, dim3(128), lds, stream, a);
     else if (maxL <= 4)
-        hipLaunchKernelGGL(rates2d_kernel<4>, grid, dim3(128), lds, stream, a);
+        hipLaunchKernelGGL((rates2d_kernel<4, 4, 8>), grid, dim3(128), lds, stream, a);
     else
-        hipLaunchKernelGGL(rates2d_kernel<8>, grid, dim3(128), lds, stream, a);
+        hipLaunchKernelGGL((rates2d_kernel<8, 4, 8>), grid, dim3(128), lds, stream, a);
     return hipGetLastError();
 }
 }

@@ -136,7 +136,7 @@ int run_2d(lwhip_context* c, int lambdaIterate, int mode)
         f.nSolve = nLa * nRaysActive;
         HIP_TRY(launch_fs2d(f, nLa * nRaysActive, c->stream));
         if (rates)
-            HIP_TRY(launch_rates2d(a, c->maxL, c->stream));
+            HIP_TRY(launch_rates2d(a, c->maxL, c->maxM, c->maxP, c->stream));
         else
             HIP_TRY(launch_iout2d(a, c->stream));
         la0 += nLa;

@@ -129,6 +129,7 @@ struct lwhip_context
     int laStart = 0, laEnd = 0, Nla = 0;
     int Ns = 0, Nrays = 0, Natom = 0, NlevTot = 0, Ntrans = 0, Nline = 0, Ncont = 0;
     int maxL = 0, maxC = 0;
+    int maxM = 0, maxP = 0; // most mixed / pure continua at one wavelength
     bool is2d = false;            // x-periodic 2D geometry (prob.grid2d): batched pipeline of lwhip_2d.hip
     int Nx = 1, batch2d = 1;
     std::vector<DevLaHeader> hdrHost;

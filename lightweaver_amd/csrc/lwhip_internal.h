@@ -604,7 +604,7 @@ struct Batch2dArgs
     unsigned long long* dJbits;    // [Nla] max_k |1 - Jdag/J| as the bits of a non-negative double
 };
 hipError_t launch_gather2d(const Batch2dArgs& a, int maxL, hipStream_t stream);
-hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, hipStream_t stream);
+hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, int maxM, int maxP, hipStream_t stream);
 hipError_t launch_iout2d(const Batch2dArgs& a, hipStream_t stream);
 hipError_t launch_sum_groups(double* red, size_t n, size_t stride, int G, hipStream_t stream);
 hipError_t launch_cont_range(const ContArgs* devArgs, const ContArgs& hostArgs, int contOff, int nCont, double* rowsBase,

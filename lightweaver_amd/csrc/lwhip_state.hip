@@ -151,6 +151,7 @@ int alloc_state(lwhip_context* c)
         const size_t budget = (size_t)env_int("LWHIP_BATCH2D_MB", 8192) << 20;
         c->batch2d = (int)std::max<size_t>(1, std::min<size_t>(budget / perLa, Nla));
         c->batch2d = std::max(1, env_int("LWHIP_BATCH2D", c->batch2d));
+        constexpr int R2D_WAVES_HOST = 3; // (= R2D_WAVES of lwhip_2d.hip)
         // rates2d: one thread per point per wavelength group; as many groups as keep every wavefront resident at the
         // kernel's 3 wavefronts per SIMD (256 x 82: 9 groups = 2 952 wavefronts on 3 072 slots; 7 were 2.2 per SIMD,
         // 10 spill into a second round)
@@ -160,7 +161,7 @@ int alloc_state(lwhip_context* c)
             if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
                 numCU = prop.multiProcessorCount;
             const size_t wavesPerGroup = 2 * ((Ns + 127) / 128);
-            c->groups2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)c->batch2d, (size_t)numCU * 12 / wavesPerGroup }));
+            c->groups2d = (int)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)c->batch2d, (size_t)numCU * 4 * R2D_WAVES_HOST / wavesPerGroup }));
         }
         c->groups2d = std::max(1, c->groups2d);
         HIP_TRY(c->red2d.alloc((size_t)c->groups2d * std::max(c->Ntrans, 1) * 4 * Ns));

@@ -358,7 +358,7 @@ int build_tables(lwhip_context* c)
     std::map<std::vector<int>, int> progIds;
     std::vector<int32_t> contLaHost;
     c->rowsTot = 0;
-    c->maxL = c->maxC = 0;
+    c->maxL = c->maxC = c->maxM = c->maxP = 0;
     const int rowEtaA = 2, rowLevChi = 2 + c->Natom, rowLevU = 2 + c->Natom + c->NlevTot;
     for (int la = 0; la < c->Nla; ++la)
     {
@@ -452,6 +452,8 @@ int build_tables(lwhip_context* c)
         }
         c->maxL = std::max(c->maxL, (int)lines.size());
         c->maxC = std::max(c->maxC, (int)conts.size());
+        c->maxM = std::max(c->maxM, (int)mixed.size());
+        c->maxP = std::max(c->maxP, (int)pure.size());
 
         // row program of this wavelength's continuum set (deduplicated by signature)
         std::vector<int> contOrder = mixed;
@@ -554,6 +556,8 @@ int build_tables(lwhip_context* c)
     }
     if (c->maxL > 8)
         return fail(LWHIP_ERR_UNSUPPORTED, "more than 8 lines overlap at one wavelength");
+    if (c->is2d && c->maxM > 4)
+        return fail(LWHIP_ERR_UNSUPPORTED, "2D: more than 4 continua coupled to the lines of one wavelength (rates2d_kernel's MAXM)");
     if (c->maxC < 1)
         c->maxC = 1;
 
