@@ -36,7 +36,8 @@ int lwhip_prd_pack(lwhip_context* c, void** devPtr, size_t* count)
             nlt = h.t.Nred - h.t.Nblue;
             src = c->JRest.p + (size_t)c->hLa2prdHost[h.t.Nblue] * Ns;
         }
-        if (nlt)
+        // (one device: nothing to exchange -- the scattering integral reads these rows where they lie, lwhip_prd_partial)
+        if (nlt && c->worldSize > 1)
             HIP_TRY(hipMemcpyAsync(c->prdJ.p + ((size_t)c->prdRowOff[q] + lt0) * Ns, src, nlt * Ns * sizeof(double),
                                    hipMemcpyDeviceToDevice, c->stream));
     }
@@ -103,6 +104,13 @@ int lwhip_prd_partial(lwhip_context* c)
         a.Bij = h.t.Bij;
         a.wave = c->lineWave.p + h.waveOff;
         a.J = c->prdJ.p;
+        if (c->worldSize == 1)
+        {
+            // one device: the line's rows of J (hybrid PRD: of JRest) themselves, no copy into the gather buffer (the rates pass
+            // that rewrites them comes after the scattering integral in the stream)
+            a.Nblue = 0;
+            a.J = c->hprd ? c->JRest.p + (size_t)c->hLa2prdHost[h.t.Nblue] * Ns : c->J.p + (size_t)h.NblueLoc * Ns;
+        }
         a.Jt = c->prdJt.p + jtOff[q];
         a.vBroad = c->vBroad.p + (size_t)h.atom * Ns;
         a.aDamp = c->aDamp.p + (size_t)h.row * Ns;
@@ -192,7 +200,10 @@ int lwhip_prd_partial(lwhip_context* c)
     // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
     TileDyn dyn = make_dyn(c, false, 0);
     dyn.prdOnly = 1;
-    HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream)); // unvisited wavelengths: dJ = 0
+    // unvisited wavelengths: dJ = 0 -- after a full sweep; the sub-iterations that follow visit the same wavelengths
+    if (!c->dJPrdClean)
+        HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
+    c->dJPrdClean = true;
     // the sweep adds its workgroup sums into the stage-1 buffer; stage 2 sums and zeroes the parts
     if (!c->red8Clean)
         HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));

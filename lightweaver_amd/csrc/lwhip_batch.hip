@@ -235,6 +235,7 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
         if (c->partialPending || c->prdPending)
             return fail(LWHIP_ERR_INVALID, "batch iteration while a split iteration of a column is pending");
         c->prefillCrsw = crsw;
+        c->dJPrdClean = false; // (the batch sweep writes every wavelength's dJ)
         c->prefillPending = c->gammaTot > 0 && c->Cmat.p != nullptr;
         b->aHost[i] = make_apply_args(c);
         c->prefillPending = false;

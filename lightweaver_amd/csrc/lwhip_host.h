@@ -222,6 +222,7 @@ struct lwhip_context
     DevBuf<int32_t> g2long, g2subOff, slotTrD, g2lcOwner, g2uwA, g2dwA;
     DevBuf<double> g2uwS, g2dwS; // the records field by field
     DevBuf<double> b2lc; // [batch2d][NlongChar][3]
+    bool dJPrdClean = false; // dJ holds zeros outside the wavelengths the PRD rates pass visits (no full sweep since)
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
     std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
     int64_t prdRowsTot = 0;

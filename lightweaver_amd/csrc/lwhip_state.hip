@@ -420,6 +420,8 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
     const bool tprd = dyn.prdOnly != 0; // the PRD rates pass: its own tile list and chunking
     if (tprd && c->nTileChunksPrd == 0)
         return hipSuccess;
+    if (!tprd)
+        c->dJPrdClean = false; // (every wavelength's dJ is written)
     const TileArgs* da = tprd ? c->dtargsPrd.p : c->dtargs.p;
     const TileArgs& ha = tprd ? c->htargsPrd : c->htargs;
     const bool fuse = c->tileFuse && rates;
