@@ -17,6 +17,6 @@ for ((i = 0; i < N; ++i)); do
   seed=$((S0 + i))
   python3 -m pytest $R/tests -q -m gpu -p no:cacheprovider --lw-shuffle $seed -x > $OUT/run_$seed.log 2>&1
   rc=$?
-  echo "seed $seed rc $rc: $(tail -n 1 $OUT/run_$seed.log)" >> $OUT/summary.txt
+  echo "seed $seed rc $rc: $(grep -E "passed|failed|error" $OUT/run_$seed.log | tail -n 1)" >> $OUT/summary.txt
 done
 cat $OUT/summary.txt
