@@ -57,42 +57,29 @@ __global__ void __launch_bounds__(128) cont_kernel(const ContArgs* __restrict__ 
             colX[(size_t)c * T] = gN[sl.gi * Ns + k] * sl.p[0] - gN[sl.gj * Ns + k] * vji;
             out[(size_t)(h.nRows + c) * Ns + k] = vji;
         }
-        // The row program is a chain of scalar loads (row header -> its entries -> the entries' slot records), and the kernel
-        // spent 79 % of its wave time waiting on it: the next row's header and a row's entries four at a time are requested
-        // together (the host pads both tables), so a row costs one wait instead of 1 + nEnt.
-        DevProgRow prNext = ld_c(prow);
+        // (measured: requesting the next row's header and a row's entries four at a time -- one wait per row instead of
+        // 1 + nEnt -- changes nothing, 0.197 ms either way: the kernel is not bound by this chain of scalar loads)
         for (int ri = 0; ri < pg.nRows; ++ri)
         {
-            const DevProgRow pr = prNext;
-            prNext = ld_c(prow + ri + 1); // (padded)
+            const DevProgRow pr = ld_c(prow + ri);
             double v = 0.0;
             if (pr.row == 0)
                 v = GCD(ARGS.bgChi)[(size_t)la * Ns + k];
             else if (pr.row == 1)
                 v = GCD(ARGS.bgEta)[(size_t)la * Ns + k];
-            for (int e0 = 0; e0 < pr.nEnt; e0 += 4) // continua in reference order
+            for (int e = 0; e < pr.nEnt; ++e) // continua in reference order
             {
-                DevProgEnt en[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    en[q] = ld_c(pent + pr.entOff + e0 + q); // (padded)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                {
-                    if (e0 + q < pr.nEnt)
-                    {
-                        const double x = colX[(size_t)en[q].c * T];
-                        const double uji = slots[en[q].c].p[2] * colV[(size_t)en[q].c * T];
-                        if (en[q].kind == 0)
-                            v += x;
-                        else if (en[q].kind == 1)
-                            v -= x;
-                        else if (en[q].kind == 2)
-                            v += uji;
-                        else
-                            v += gN[slots[en[q].c].gj * Ns + k] * uji;
-                    }
-                }
+                const DevProgEnt en = ld_c(pent + pr.entOff + e);
+                const double x = colX[(size_t)en.c * T];
+                const double uji = slots[en.c].p[2] * colV[(size_t)en.c * T];
+                if (en.kind == 0)
+                    v += x;
+                else if (en.kind == 1)
+                    v -= x;
+                else if (en.kind == 2)
+                    v += uji;
+                else
+                    v += gN[slots[en.c].gj * Ns + k] * uji;
             }
             out[(size_t)ri * Ns + k] = v;
         }

@@ -1283,9 +1283,6 @@ int build_tables(lwhip_context* c)
     c->hdrHost = hdr;
     c->contLaHost = contLaHost;
     HIP_TRY(c->progs.upload(progs));
-    // (cont_kernel requests the next row's header and a row's entries four at a time: one row / four entries of padding)
-    progRows.resize(progRows.size() + 1, DevProgRow{ 0, 0, 0 });
-    progEnts.resize(progEnts.size() + 4, DevProgEnt{ 0, 0 });
     HIP_TRY(c->progRows.upload(progRows));
     HIP_TRY(c->progEnts.upload(progEnts));
     if (contLaHost.empty())
