@@ -284,13 +284,13 @@ def build_problem(atmos: Atmosphere1d, models: List[AtomModel], Nrays=5,
             a.C = _collisional_rates(m, nStar, T, ne)
         atoms.append(a)
 
-    chi, eta, sca = ph.h_minus_background(grid, T, ne, atmos.nH[0])
+    chi, eta, sca, planck = ph.h_minus_background(grid, T, ne, atmos.nH[0], with_planck=True)
     vlosMu = muz[:, None] * atmos.vlos[None, :]
     prob = Problem(height=atmos.height, temperature=T, muz=muz, wmu=wmu, wavelength=grid,
                    bgChi=chi, bgEta=eta, bgSca=sca, atoms=atoms, vlosMu=vlosMu,
                    formalSolver=formalSolver, storeDepthData=storeDepthData)
     # initial J = B_nu(T) (LTE start)
-    prob.J[...] = np.stack([ph.planck_nu(T, w) for w in grid])
+    prob.J[...] = planck
     if computeProfiles:
         compute_profiles_host(prob)
     prob.gamma_prefill()
