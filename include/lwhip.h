@@ -263,6 +263,16 @@ int lwhip_device_count(void);
  * LWHIP_ALL_INPUTS.  Replaces alloc_global_scratch.  `opts` may be NULL. */
 int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context** out);
 
+/* The same for a problem of the SAME STRUCTURE as the one `like` was made for -- sizes, solver, wavelength shard and grid, and
+ * of every transition its levels, wavelength range, coefficients, own grid and cross-sections; populations, atmosphere,
+ * profiles, boundary data are free to differ: the columns of a 1.5D batch, lwhip_batch_create.  The new context borrows
+ * `like`'s structure tables (per-wavelength activity tables, tile / workgroup / ray records: a few MB and half of the
+ * creation time per context) instead of building device copies of its own.  The structures are compared by a fingerprint:
+ * LWHIP_ERR_INVALID if they differ.  `like` cannot be destroyed before its borrowers (lwhip_destroy fails with
+ * LWHIP_ERR_INVALID and leaves it intact).  No counterpart in the reference: every Context owns its tables
+ * (update_deps, Source/LwMiddleLayer.pyx:3244-3288). */
+int lwhip_create_like(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context* like, lwhip_context** out);
+
 /* Free everything lwhip_create allocated.  Replaces free_global_scratch. */
 int lwhip_destroy(lwhip_context* ctx);
 

@@ -150,6 +150,7 @@ SYMBOLS = [
     ('lwhip_abi_version', C.c_int, []),
     ('lwhip_device_count', C.c_int, []),
     ('lwhip_create', C.c_int, [C.POINTER(lwhip_problem), C.POINTER(lwhip_options), C.POINTER(ctx_p)]),
+    ('lwhip_create_like', C.c_int, [C.POINTER(lwhip_problem), C.POINTER(lwhip_options), ctx_p, C.POINTER(ctx_p)]),
     ('lwhip_destroy', C.c_int, [ctx_p]),
     ('lwhip_upload', C.c_int, [ctx_p, C.c_uint32]),
     ('lwhip_download', C.c_int, [ctx_p, C.c_uint32]),

@@ -36,8 +36,11 @@ class ColumnBatch:
             self.contexts = [Context(p, device=device, stream=streams[i % len(streams)])
                              for i, p in enumerate(self.problems)]
         else:
-            self.contexts = [Context(p, device=device, stream=stream, batchHint=len(self.problems) if fused else 0)
-                             for p in self.problems]
+            # (the columns of a fused batch share their structure: all but the first borrow the first one's tables)
+            self.contexts = []
+            for p in self.problems:
+                self.contexts.append(Context(p, device=device, stream=stream, batchHint=len(self.problems) if fused else 0,
+                                             like=self.contexts[0] if (fused and self.contexts) else None))
         if fused and not streams and self.contexts:
             import ctypes as C
             lib = self.contexts[0].lib
@@ -66,7 +69,7 @@ class ColumnBatch:
         if self._batch is not None:
             self.contexts[0].lib.lwhip_batch_destroy(self._batch)
             self._batch = None
-        for c in self.contexts:
+        for c in reversed(self.contexts):  # (borrowers of the first column's tables before the first column)
             c.close()
         self.contexts = []
 

@@ -85,8 +85,11 @@ class Context:
     def __init__(self, prob: Problem, device: int = 0, laStart: int = 0, laEnd: int = 0,
                  stream: Optional[int] = None, lib_path: Optional[str] = None,
                  worldSize: int = 1, worldRank: int = 0, batchHint: int = 0, prdDetailed: bool = False, hprd=None,
-                 deterministic: bool = False):
-        """hprd: hybrid PRD -- the tables configure_hprd_coeffs leaves in the reference's Context
+                 deterministic: bool = False, like: Optional['Context'] = None):
+        """like: a Context of a problem of the same structure (model atoms, wavelength grid, rays, solver, shard) whose
+        structure tables this one borrows instead of building its own (lwhip_create_like: the columns of a batch); the
+        library compares the structures and this constructor falls back to tables of its own when they differ.
+        hprd: hybrid PRD -- the tables configure_hprd_coeffs leaves in the reference's Context
         (Source/Prd.cpp:697-946), as a ctypes pointer to lwhip_hprd or any object with such a `.ptr` (what
         LwContext(hprd=True) sets up, Source/LwMiddleLayer.pyx:2822-2826); borrowed for the life of the context.
         JRest comes back with download(J)."""
@@ -106,7 +109,17 @@ class Context:
         if hprd is not None:
             opts.hprd = getattr(hprd, 'ptr', hprd)
         h = C.c_void_p()
-        st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
+        self._like = None      # (kept alive: its tables are in use)
+        self._pending = False  # close() asked for while borrowers were alive
+        st = abi.ERR_INVALID
+        if like is not None and getattr(like, '_h', None):
+            st = self.lib.lwhip_create_like(C.byref(self._desc), C.byref(opts), like._h, C.byref(h))
+            if st == abi.OK:
+                while getattr(like, '_like', None) is not None:   # (a borrower's tables are its owner's)
+                    like = like._like
+                self._like = like
+        if st != abi.OK:
+            st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
         _check(self.lib, st, 'lwhip_create')
         self._h = h
         self.laStart = laStart
@@ -117,8 +130,14 @@ class Context:
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, '_h', None):
-            self.lib.lwhip_destroy(self._h)
+            if self.lib.lwhip_destroy(self._h) != abi.OK:
+                self._pending = True   # contexts made with like=self still use its tables: the last of them closes it
+                return
             self._h = None
+            like, self._like = getattr(self, '_like', None), None
+            if like is not None and like._pending:
+                like._pending = False
+                like.close()
 
     def __del__(self):
         try:

@@ -42,7 +42,21 @@ int lwhip_device_count(void)
     return n;
 }
 
+static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context* like, lwhip_context** out);
+
 int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context** out)
+{
+    return create_impl(prob, opts, nullptr, out);
+}
+
+int lwhip_create_like(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context* like, lwhip_context** out)
+{
+    if (!like)
+        return fail(LWHIP_ERR_INVALID, "lwhip_create_like: null context to share the tables of");
+    return create_impl(prob, opts, like, out);
+}
+
+static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context* like, lwhip_context** out)
 {
     if (!out)
         return fail(LWHIP_ERR_INVALID, "null out pointer");
@@ -99,6 +113,8 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     c->Natom = prob->Natom;
 
     auto bail = [&](int code) {
+        if (c->tablesFrom)
+            c->tablesFrom->borrowers--;
         delete c;
         return code;
     };
@@ -123,9 +139,24 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
+    c->structSig = structure_signature(c);
+    if (like)
+    {
+        // a borrower of a borrower borrows from the owner
+        lwhip_context* owner = like->tablesFrom ? like->tablesFrom : like;
+        if (owner->structSig != c->structSig)
+            return bail(fail(LWHIP_ERR_INVALID, "lwhip_create_like: the problems differ in structure (sizes, solver, shard, wavelength "
+                                                "grid, or a transition's levels / range / coefficients / grid / cross-sections)"));
+        c->tablesFrom = owner;
+    }
     st = build_tables(c);
     if (st != LWHIP_OK)
+    {
+        c->tablesFrom = nullptr; // (not counted yet)
         return bail(st);
+    }
+    if (c->tablesFrom)
+        c->tablesFrom->borrowers++;
     const auto t1 = now();
     st = alloc_state(c);
     if (st != LWHIP_OK)
@@ -163,8 +194,16 @@ int lwhip_destroy(lwhip_context* c)
 {
     if (!c)
         return LWHIP_OK;
+    if (c->borrowers > 0)
+        return fail(LWHIP_ERR_INVALID, "lwhip_destroy: " + std::to_string(c->borrowers)
+                                           + " context(s) made with lwhip_create_like still use this context's tables");
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->tablesFrom)
+    {
+        c->tablesFrom->borrowers--;
+        c->tablesFrom = nullptr;
+    }
     if (c->lsDbgHost && !c->laneSweep)
     {
         // -DRM_TIMING build of the march: per tile kind the count and the mean / max clocks of a direction's march and of the post-pass

@@ -77,6 +77,16 @@ template <typename T> struct DevBuf
         n = count;
         owned = false;
     }
+    // the table of a structurally identical context instead of a copy of one's own (lwhip_create_like): same size, or upload
+    hipError_t upload_or_borrow(const std::vector<T>& v, const DevBuf<T>* from)
+    {
+        if (from && from->p && from->n == v.size() && !v.empty())
+        {
+            view(from->p, from->n);
+            return hipSuccess;
+        }
+        return upload(v);
+    }
     hipError_t upload(const std::vector<T>& v)
     {
         hipError_t e = alloc(v.size());
@@ -222,6 +232,11 @@ struct lwhip_context
     DevBuf<int32_t> g2long, g2subOff, slotTrD, g2lcOwner, g2uwA, g2dwA;
     DevBuf<double> g2uwS, g2dwS; // the records field by field
     DevBuf<double> b2lc; // [batch2d][NlongChar][3]
+    // lwhip_create_like: the structure tables (lwhip_tables.hip) are borrowed from a context of the same structure, which
+    // counts its borrowers and cannot be destroyed before them
+    lwhip_context* tablesFrom = nullptr;
+    int borrowers = 0;
+    uint64_t structSig = 0; // fingerprint of everything the structure tables are built from
     bool dJPrdClean = false; // dJ holds zeros outside the wavelengths the PRD rates pass visits (no full sweep since)
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
     std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
@@ -333,6 +348,7 @@ inline double trans_wlambda(const lwhip_transition& t, int lt)
 // lwhip_tables.hip
 int validate(const lwhip_problem* p, std::string& why);
 int build_tables(lwhip_context* c);
+uint64_t structure_signature(const lwhip_context* c);
 // lwhip_state.hip
 int alloc_state(lwhip_context* c);
 int build_sweep_args(lwhip_context* c);

@@ -176,8 +176,64 @@ int validate(const lwhip_problem* p, std::string& why)
     return LWHIP_OK;
 }
 
+// Everything the structure tables depend on, folded into 64 bits: sizes, solver, shard, the wavelength grid, and of every
+// transition its levels, wavelength range, Einstein coefficients, own grid and cross-sections.  Two contexts with the same
+// fingerprint build the same tables (populations, atmosphere, profiles, boundary data live elsewhere).
+uint64_t structure_signature(const lwhip_context* c)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    auto mix = [&](uint64_t v) {
+        h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xFF51AFD7ED558CCDull;
+        h ^= h >> 33;
+    };
+    auto mixd = [&](double v) {
+        uint64_t u;
+        std::memcpy(&u, &v, 8);
+        mix(u);
+    };
+    auto mixv = [&](const double* p, size_t n) {
+        mix(n);
+        for (size_t i = 0; p && i < n; ++i)
+            mixd(p[i]);
+    };
+    const lwhip_problem& p = c->prob;
+    for (int64_t v : { (int64_t)p.Nlambda, (int64_t)p.Nspace, (int64_t)p.Nrays, (int64_t)p.Natom, (int64_t)p.formalSolver,
+                       (int64_t)c->laStart, (int64_t)c->laEnd, (int64_t)c->worldSize, (int64_t)c->batchHint, (int64_t)c->prdDetailed,
+                       (int64_t)c->deterministic, (int64_t)(c->hprd != nullptr), (int64_t)c->is2d, (int64_t)p.storeDepthData,
+                       (int64_t)c->device })
+        mix((uint64_t)v);
+    mixv(p.wavelength, (size_t)p.Nlambda);
+    for (int ia = 0; ia < p.Natom; ++ia)
+    {
+        const lwhip_atom& a = c->atoms[ia];
+        mix((uint64_t)a.Nlevel);
+        mix((uint64_t)a.Ntrans);
+        mix((uint64_t)(a.detailed != 0));
+        mix((uint64_t)(a.C != nullptr));
+        for (int kr = 0; kr < a.Ntrans; ++kr)
+        {
+            const lwhip_transition& t = a.trans[kr];
+            for (int64_t v : { (int64_t)t.type, (int64_t)t.i, (int64_t)t.j, (int64_t)t.Nblue, (int64_t)t.Nred, (int64_t)(t.prd != 0),
+                               (int64_t)(t.rhoPrd != nullptr) })
+                mix((uint64_t)v);
+            mixd(t.Aji);
+            mixd(t.Bji);
+            mixd(t.Bij);
+            mixd(t.lambda0);
+            mixd(t.dopplerWidth);
+            mixv(t.wavelength, (size_t)std::max(t.Nred - t.Nblue, 0));
+            if (t.type != LWHIP_LINE)
+                mixv(t.alpha, (size_t)std::max(t.Nred - t.Nblue, 0));
+        }
+    }
+    return h;
+}
+
 int build_tables(lwhip_context* c)
 {
+    // (lwhip_create_like: the donor of the structure tables, checked to have this context's fingerprint)
+    const lwhip_context* like = c->tablesFrom;
     const int Ns = c->Ns;
     // ---- global transition list, level rows, pools ------------------------------------------
     c->levelOff.assign(c->Natom + 1, 0);
@@ -1171,13 +1227,13 @@ int build_tables(lwhip_context* c)
             };
             std::vector<int32_t> o, e;
             lists(tileSlotTr, c->nTileChunks, o, e);
-            HIP_TRY(c->detOff.upload(o));
-            HIP_TRY(c->detEnt.upload(e));
+            HIP_TRY(c->detOff.upload_or_borrow(o, like ? &like->detOff : nullptr));
+            HIP_TRY(c->detEnt.upload_or_borrow(e, like ? &like->detEnt : nullptr));
             if (!tileListPrd.empty())
             {
                 lists(swPrd.slotTr, (int)swPrd.chunkTile.size() - 1, o, e);
-                HIP_TRY(c->detOffPrd.upload(o));
-                HIP_TRY(c->detEntPrd.upload(e));
+                HIP_TRY(c->detOffPrd.upload_or_borrow(o, like ? &like->detOffPrd : nullptr));
+                HIP_TRY(c->detEntPrd.upload_or_borrow(e, like ? &like->detEntPrd : nullptr));
             }
             const size_t nch = std::max<size_t>(c->nTileChunks, tileListPrd.empty() ? 0 : swPrd.chunkTile.size() - 1);
             HIP_TRY(c->detSlab.alloc(nch * c->maxCTTile * 4 * Ns));
@@ -1267,36 +1323,36 @@ int build_tables(lwhip_context* c)
             lw.push_back(0.0);
             lq.push_back(0.0);
         }
-        HIP_TRY(c->lineWave.upload(lw));
-        HIP_TRY(c->lineWlam.upload(lq));
+        HIP_TRY(c->lineWave.upload_or_borrow(lw, like ? &like->lineWave : nullptr));
+        HIP_TRY(c->lineWlam.upload_or_borrow(lq, like ? &like->lineWlam : nullptr));
     }
-    HIP_TRY(c->par.upload(par));
-    HIP_TRY(c->dtrans.upload(dt));
-    HIP_TRY(c->laHdr.upload(hdr));
-    HIP_TRY(c->slots.upload(slots));
+    HIP_TRY(c->par.upload_or_borrow(par, like ? &like->par : nullptr));
+    HIP_TRY(c->dtrans.upload_or_borrow(dt, like ? &like->dtrans : nullptr));
+    HIP_TRY(c->laHdr.upload_or_borrow(hdr, like ? &like->laHdr : nullptr));
+    HIP_TRY(c->slots.upload_or_borrow(slots, like ? &like->slots : nullptr));
     {
         std::vector<int32_t> st32(slotTr.begin(), slotTr.end());
         if (st32.empty())
             st32.push_back(0);
-        HIP_TRY(c->slotTrD.upload(st32));
+        HIP_TRY(c->slotTrD.upload_or_borrow(st32, like ? &like->slotTrD : nullptr));
     }
     c->hdrHost = hdr;
     c->contLaHost = contLaHost;
-    HIP_TRY(c->progs.upload(progs));
-    HIP_TRY(c->progRows.upload(progRows));
-    HIP_TRY(c->progEnts.upload(progEnts));
+    HIP_TRY(c->progs.upload_or_borrow(progs, like ? &like->progs : nullptr));
+    HIP_TRY(c->progRows.upload_or_borrow(progRows, like ? &like->progRows : nullptr));
+    HIP_TRY(c->progEnts.upload_or_borrow(progEnts, like ? &like->progEnts : nullptr));
     if (contLaHost.empty())
         contLaHost.push_back(0);
     c->nContLa = (c->rowsTot > 0) ? (int)contLaHost.size() : 0;
-    HIP_TRY(c->contLa.upload(contLaHost));
-    HIP_TRY(c->rayAll.upload(rayAll));
-    HIP_TRY(c->rayUp.upload(rayUp));
+    HIP_TRY(c->contLa.upload_or_borrow(contLaHost, like ? &like->contLa : nullptr));
+    HIP_TRY(c->rayAll.upload_or_borrow(rayAll, like ? &like->rayAll : nullptr));
+    HIP_TRY(c->rayUp.upload_or_borrow(rayUp, like ? &like->rayUp : nullptr));
     if (c->tiled)
     {
-        auto up = [](auto& buf, auto& v) -> hipError_t {
+        auto up = [](auto& buf, auto& v, const auto* from) -> hipError_t {
             if (v.empty())
                 v.resize(1);
-            return buf.upload(v);
+            return buf.upload_or_borrow(v, from);
         };
         std::vector<DevContRec> cr(std::max<size_t>(slots.size(), 1), DevContRec{});
         std::vector<DevPostProg> pp;
@@ -1327,7 +1383,7 @@ int build_tables(lwhip_context* c)
                     cr[base + q] = r;
                 }
             }
-            HIP_TRY(c->contRec.upload(cr));
+            HIP_TRY(c->contRec.upload_or_borrow(cr, like ? &like->contRec : nullptr));
         }
         if (c->laneSweep)
         {
@@ -1335,7 +1391,7 @@ int build_tables(lwhip_context* c)
             for (size_t t = 0; t < tiles.size(); ++t)
                 if (!lanePostProgram(tiles[t].la0, pp[t]))
                     return fail(LWHIP_ERR_UNSUPPORTED, "lane sweep: post program");
-            HIP_TRY(c->postProg.upload(pp));
+            HIP_TRY(c->postProg.upload_or_borrow(pp, like ? &like->postProg : nullptr));
             if (std::getenv("LWHIP_VERBOSE"))
             {
                 // which program words occur (the finish serves the common ones with fixed registers)
@@ -1350,18 +1406,18 @@ int build_tables(lwhip_context* c)
                     std::fprintf(stderr, "  finish program word code %#x ops %#x: %d continua\n", kv.first.first, kv.first.second, kv.second);
             }
         }
-        HIP_TRY(up(c->tiles, tiles));
-        HIP_TRY(up(c->tslots, tslots));
-        HIP_TRY(up(c->tslotsPrd, tslotsPrd));
-        HIP_TRY(up(c->tcopies, tcopies));
-        HIP_TRY(up(c->tileRemap, tileRemap));
-        HIP_TRY(up(c->chunkTile, chunkTile));
+        HIP_TRY(up(c->tiles, tiles, like ? &like->tiles : nullptr));
+        HIP_TRY(up(c->tslots, tslots, like ? &like->tslots : nullptr));
+        HIP_TRY(up(c->tslotsPrd, tslotsPrd, like ? &like->tslotsPrd : nullptr));
+        HIP_TRY(up(c->tcopies, tcopies, like ? &like->tcopies : nullptr));
+        HIP_TRY(up(c->tileRemap, tileRemap, like ? &like->tileRemap : nullptr));
+        HIP_TRY(up(c->chunkTile, chunkTile, like ? &like->chunkTile : nullptr));
         c->chunkOrderOn = false;
         c->chunkSplitOn = false;
         if (!laneChunkOrder.empty())
         {
-            HIP_TRY(up(c->chunkOrder, laneChunkOrder));
-            HIP_TRY(up(c->chunkSplit, laneChunkSplit));
+            HIP_TRY(up(c->chunkOrder, laneChunkOrder, like ? &like->chunkOrder : nullptr));
+            HIP_TRY(up(c->chunkSplit, laneChunkSplit, like ? &like->chunkSplit : nullptr));
             c->chunkOrderOn = c->chunkSplitOn = true;
         }
         const int nchAll = (int)chunkTile.size() - 1;
@@ -1382,7 +1438,7 @@ int build_tables(lwhip_context* c)
                 order[ch] = ch;
             const bool heavyFirst = laneOrder == 1;
             std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return heavyFirst ? cost[x] > cost[y] : cost[x] < cost[y]; });
-            HIP_TRY(up(c->chunkOrder, order));
+            HIP_TRY(up(c->chunkOrder, order, like ? &like->chunkOrder : nullptr));
             c->chunkOrderOn = true;
         }
         if (c->laneSweep)
@@ -1408,7 +1464,7 @@ int build_tables(lwhip_context* c)
                 HIP_TRY(hipMemcpy(orderHost.data(), c->chunkOrder.p, orderHost.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
             }
             auto wgs = wg_records(chunkTile, c->chunkOrderOn ? &orderHost : nullptr, c->chunkSplitOn ? &laneChunkSplit : nullptr, c->laneSplit);
-            HIP_TRY(c->laneWg.upload(wgs));
+            HIP_TRY(c->laneWg.upload_or_borrow(wgs, like ? &like->laneWg : nullptr));
             auto tile_records = [&](const std::vector<DevTileSlot>& ts) {
                 std::vector<DevLaneTile> v(std::max<size_t>(tiles.size(), 1), DevLaneTile{});
                 for (size_t t = 0; t < tiles.size(); ++t)
@@ -1439,13 +1495,13 @@ int build_tables(lwhip_context* c)
             };
             {
                 auto v = tile_records(tslots);
-                HIP_TRY(c->laneTiles.upload(v));
+                HIP_TRY(c->laneTiles.upload_or_borrow(v, like ? &like->laneTiles : nullptr));
                 if (!tslotsPrd.empty() && tslotsPrd.size() == tslots.size() && !tileListPrd.empty())
                 {
                     v = tile_records(tslotsPrd);
-                    HIP_TRY(c->laneTilesPrd.upload(v));
+                    HIP_TRY(c->laneTilesPrd.upload_or_borrow(v, like ? &like->laneTilesPrd : nullptr));
                     auto wp = wg_records(chunkTilePrd, nullptr, nullptr, c->laneSplitPrd);
-                    HIP_TRY(c->laneWgPrd.upload(wp));
+                    HIP_TRY(c->laneWgPrd.upload_or_borrow(wp, like ? &like->laneWgPrd : nullptr));
                 }
             }
             std::vector<DevLaneRay> rays(std::max<size_t>(tiles.size() * L, 1), DevLaneRay{});
@@ -1509,24 +1565,24 @@ int build_tables(lwhip_context* c)
                     }
                 }
             }
-            HIP_TRY(c->laneRays.upload(rays));
-            HIP_TRY(c->laneFin.upload(fin));
-            HIP_TRY(c->laneFinPar.upload(finPar));
+            HIP_TRY(c->laneRays.upload_or_borrow(rays, like ? &like->laneRays : nullptr));
+            HIP_TRY(c->laneFin.upload_or_borrow(fin, like ? &like->laneFin : nullptr));
+            HIP_TRY(c->laneFinPar.upload_or_borrow(finPar, like ? &like->laneFinPar : nullptr));
         }
-        HIP_TRY(up(c->chunkTilePrd, chunkTilePrd));
-        HIP_TRY(up(c->tileListPrd, tileListPrd));
-        HIP_TRY(up(c->tileSlotTr, tileSlotTr));
-        HIP_TRY(up(c->tileSlotTrPrd, tileSlotTrPrd));
-        HIP_TRY(up(c->postChunkTile, postChunkTile));
-        HIP_TRY(up(c->postChunkTilePrd, postChunkTilePrd));
-        HIP_TRY(up(c->postSlotTr, postSlotTr));
-        HIP_TRY(up(c->postCs, postCs));
+        HIP_TRY(up(c->chunkTilePrd, chunkTilePrd, like ? &like->chunkTilePrd : nullptr));
+        HIP_TRY(up(c->tileListPrd, tileListPrd, like ? &like->tileListPrd : nullptr));
+        HIP_TRY(up(c->tileSlotTr, tileSlotTr, like ? &like->tileSlotTr : nullptr));
+        HIP_TRY(up(c->tileSlotTrPrd, tileSlotTrPrd, like ? &like->tileSlotTrPrd : nullptr));
+        HIP_TRY(up(c->postChunkTile, postChunkTile, like ? &like->postChunkTile : nullptr));
+        HIP_TRY(up(c->postChunkTilePrd, postChunkTilePrd, like ? &like->postChunkTilePrd : nullptr));
+        HIP_TRY(up(c->postSlotTr, postSlotTr, like ? &like->postSlotTr : nullptr));
+        HIP_TRY(up(c->postCs, postCs, like ? &like->postCs : nullptr));
     }
-    HIP_TRY(c->transLi.upload(li));
-    HIP_TRY(c->transLj.upload(lj));
-    HIP_TRY(c->atomNlevel.upload(aNl));
-    HIP_TRY(c->atomDetailed.upload(aDet));
-    HIP_TRY(c->atomTrOffD.upload(atomTrOff32));
+    HIP_TRY(c->transLi.upload_or_borrow(li, like ? &like->transLi : nullptr));
+    HIP_TRY(c->transLj.upload_or_borrow(lj, like ? &like->transLj : nullptr));
+    HIP_TRY(c->atomNlevel.upload_or_borrow(aNl, like ? &like->atomNlevel : nullptr));
+    HIP_TRY(c->atomDetailed.upload_or_borrow(aDet, like ? &like->atomDetailed : nullptr));
+    HIP_TRY(c->atomTrOffD.upload_or_borrow(atomTrOff32, like ? &like->atomTrOffD : nullptr));
     HIP_TRY(c->atomGammaOff.upload(c->gammaOff));
     return LWHIP_OK;
 }

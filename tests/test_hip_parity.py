@@ -333,6 +333,43 @@ def test_column_batch_vs_oracle(gpu, fused, sweep):
         assert up.dJMax == pytest.approx(dj, rel=1e-6)
 
 
+def test_create_like_borrows_structure_tables(gpu, sweep):
+    """lwhip_create_like: a context of the same structure borrows the first one's structure tables (the columns of a batch);
+    its results equal those of a context with tables of its own, a problem of another structure gets its own tables, and the
+    donor outlives its borrowers whatever the order of close()."""
+    mods = lambda: [models.H_6(0.3), models.CaII_6(0.3)]
+    p0 = models.build_problem(models.perturbed(models.falc82(), seed=11), mods(), Nrays=3)
+    p1 = models.build_problem(models.perturbed(models.falc82(), seed=12), mods(), Nrays=3)
+    p2 = models.build_problem(models.perturbed(models.falc82(), seed=12), [models.H_6(0.35), models.CaII_6(0.3)], Nrays=3)
+    own = p1.copy()
+    with Context(own) as ctx:
+        ctx.formal_sol_gamma_matrices()
+    c0 = Context(p0)
+    a, b = p1.copy(), p2
+    c1 = Context(a, like=c0)
+    c2 = Context(b, like=c0)
+    c3 = Context(p1.copy(), like=c1)            # a borrower of a borrower borrows from the owner
+    try:
+        assert c1._like is c0 and c3._like is c0
+        assert c2._like is None                 # another wavelength grid: tables of its own
+        assert c0.lib.lwhip_destroy(c0._h) != abi.OK and 'still use' in c0.lib.lwhip_last_error().decode()
+        c0.close()                              # asked for too early: stays alive until the borrowers are gone
+        assert c0._h is not None and c0._pending
+        c1.formal_sol_gamma_matrices()
+        assert np.array_equal(a.J, own.J) and np.array_equal(a.I, own.I)
+        compare_problems(a, own, tol=1e-12, what=('Gamma', 'R'))
+        q = p2.copy()
+        q.gamma_prefill()
+        OracleContext(q).formal_sol_gamma_matrices()
+        c2.formal_sol_gamma_matrices()
+        compare_problems(b, q)
+    finally:
+        c3.close()
+        c1.close()
+        c2.close()
+    assert c0._h is None                        # closed by its last borrower
+
+
 def test_stat_equil_reports_population_changes(gpu):
     """dPops / dPopsMaxIdx of LwContext.stat_equil (Ng::max_change with the default Ng(0,0,0)): max relative
     change of each active atom's populations and the flattened [level, depth] index of its first occurrence."""
