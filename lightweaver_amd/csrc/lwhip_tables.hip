@@ -234,6 +234,16 @@ int build_tables(lwhip_context* c)
 {
     // (lwhip_create_like: the donor of the structure tables, checked to have this context's fingerprint)
     const lwhip_context* like = c->tablesFrom;
+    // LWHIP_CREATE_TIMING=1: where the host time of the tables goes
+    const bool timing = std::getenv("LWHIP_CREATE_TIMING") != nullptr;
+    auto tPrev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!timing)
+            return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  build_tables: %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tPrev).count());
+        tPrev = t;
+    };
     const int Ns = c->Ns;
     // ---- global transition list, level rows, pools ------------------------------------------
     c->levelOff.assign(c->Natom + 1, 0);
@@ -375,6 +385,7 @@ int build_tables(lwhip_context* c)
         }
     }
 
+    tick("transition list, hybrid PRD");
     // ---- per-(transition, lt) params -----------------------------------------------------------
     std::vector<double> par((size_t)c->parTot, 0.0);
     for (auto& h : c->trans)
@@ -404,6 +415,7 @@ int build_tables(lwhip_context* c)
         }
     }
 
+    tick("per-transition parameters");
     // ---- per-wavelength activity: [lines][mixed continua][pure continua], row programs --------------
     std::vector<DevLaHeader> hdr(c->Nla);
     std::vector<DevSlot> slots;
@@ -622,6 +634,7 @@ int build_tables(lwhip_context* c)
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
         numCU = prop.multiProcessorCount;
 
+    tick("wavelength activity, programs");
     // ---- tiles of the ray-column sweep (lwhip_raymarch.hip) -----------------------------------------------------
     // A tile = up to L consecutive wavelengths with the same slot records (same transitions in the same order, same
     // row program): one wavefront marches it, lane = (mu, wavelength).
@@ -1266,6 +1279,7 @@ int build_tables(lwhip_context* c)
     }
 
     const int NR2 = 2 * c->Nrays;
+    tick("tiles, chunks, work distribution");
     // ---- device tables ---------------------------------------------------------------------------------
     std::vector<DevTrans> dt(c->Ntrans);
     std::vector<int32_t> li(c->Ntrans), lj(c->Ntrans);
@@ -1584,6 +1598,7 @@ int build_tables(lwhip_context* c)
     HIP_TRY(c->atomDetailed.upload_or_borrow(aDet, like ? &like->atomDetailed : nullptr));
     HIP_TRY(c->atomTrOffD.upload_or_borrow(atomTrOff32, like ? &like->atomTrOffD : nullptr));
     HIP_TRY(c->atomGammaOff.upload(c->gammaOff));
+    tick("device tables, lane records");
     return LWHIP_OK;
 }
 }
