@@ -220,6 +220,10 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
     };
     if ((int)blockIdx.x == a.Natom) // rates out
     {
+#ifdef AP_ABL_NO_RATES
+        if (a.Ns != 77)
+            return;
+#endif
         const int Ntr = a.atomTrOff[a.Natom];
         for (int idx = threadIdx.x; idx < Ntr * APPLY_K; idx += blockDim.x)
         {
@@ -251,14 +255,31 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
     const int at = blockIdx.x;
     if (a.atomDetailed[at] || a.prdOnly)
         return;
+#ifdef AP_ABL_NO_GAMMA
+    if (a.Ns != 77)
+        return;
+#endif
     const int Nl = a.atomNlevel[at];
     double* G = a.Gamma + a.atomGammaOff[at];
     const double* Cm = a.Cmat + a.atomGammaOff[at];
     const int tr0 = a.atomTrOff[at], tr1 = a.atomTrOff[at + 1];
     // the atom's (i, j) pairs once into LDS: read from global memory inside the loop below they were a chain of ~2 Ntrans
     // dependent memory round trips per thread (7 of the launch's 11 microseconds)
-    enum { APPLY_TR = 512 };
+    enum { APPLY_TR = 512, APPLY_TILE = 4096 };
     __shared__ short sLi[APPLY_TR], sLj[APPLY_TR];
+    // (the workgroup is a chain of memory round trips -- 12.9 us against the 7 us of the dJMax block beside it: the entry's own
+    // start value is requested before the wait for the staged pairs, and the diagonal sums read the entries from an LDS tile
+    // instead of from memory again, where the atom's slab fits it)
+    __shared__ double sG[APPLY_TILE];
+    const bool tileFits = Nl * Nl * APPLY_K <= (int)APPLY_TILE;
+    double v0 = 0.0;
+    if ((int)threadIdx.x < Nl * Nl * APPLY_K)
+    {
+        const int e = threadIdx.x / APPLY_K;
+        const int k = k0 + ((int)threadIdx.x - e * APPLY_K);
+        if (k < Ns)
+            v0 = a.prefill ? a.crsw * Cm[(size_t)e * Ns + k] : G[(size_t)e * Ns + k];
+    }
     for (int q = threadIdx.x; q < min(tr1 - tr0, (int)APPLY_TR); q += blockDim.x)
     {
         sLi[q] = (short)a.transLi[tr0 + q];
@@ -273,7 +294,7 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
         if (k >= Ns)
             continue;
         const int to = e / Nl, from = e - to * Nl;
-        double v = a.prefill ? a.crsw * Cm[(size_t)e * Ns + k] : G[(size_t)e * Ns + k];
+        double v = (idx == (int)threadIdx.x) ? v0 : (a.prefill ? a.crsw * Cm[(size_t)e * Ns + k] : G[(size_t)e * Ns + k]);
         for (int tr = tr0; tr < tr1; ++tr) // transitions in reference order
         {
             const int i = tr - tr0 < APPLY_TR ? (int)sLi[tr - tr0] : a.transLi[tr], j = tr - tr0 < APPLY_TR ? (int)sLj[tr - tr0] : a.transLj[tr];
@@ -283,7 +304,13 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
                 v += redAt(tr, 1, k);
         }
         G[(size_t)e * Ns + k] = v;
+        if (tileFits)
+            sG[idx] = v;
     }
+#ifdef AP_ABL_NO_DIAG
+    if (a.Ns != 77)
+        return;
+#endif
     __syncthreads();
     // finalise_Gamma (SimdFullIterationTemplates.hpp:491-508): Gamma(i,i) = -sum_{j != i} Gamma(j,i)
     for (int idx = threadIdx.x; idx < Nl * APPLY_K; idx += blockDim.x)
@@ -295,7 +322,7 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
         double gd = 0.0;
         for (int j = 0; j < Nl; ++j)
             if (j != i)
-                gd += G[((size_t)j * Nl + i) * Ns + k];
+                gd += tileFits ? sG[(j * Nl + i) * APPLY_K + (k - k0)] : G[((size_t)j * Nl + i) * Ns + k];
         G[((size_t)i * Nl + i) * Ns + k] = -gd;
     }
 }
