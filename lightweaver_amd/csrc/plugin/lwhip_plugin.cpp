@@ -23,7 +23,11 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <condition_variable>
+#include <chrono>
 #include <cstring>
+#include <unistd.h>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -32,12 +36,89 @@
 
 namespace
 {
-// Exact change detection for the slowly changing inputs: a 64-bit hash of EVERY element of every tracked array
+// Exact change detection for the slowly changing inputs: a 64-bit fingerprint of EVERY element of every tracked array
 // (plus pointer and length).  A sampled fingerprint would miss an in-place edit of an unsampled depth point -- what
 // update_deps() does after a local atmosphere change -- and the iteration would run on stale device inputs without
-// any sign of it.  Arrays are cut into 256 KB blocks hashed by a few host threads (four independent multiply-xor
-// lanes per block: memory speed), block hashes folded in order: ~0.2 ms for the 16 MB of line profiles of a
-// 3 000-wavelength H + Ca II problem.
+// any sign of it.  At the bench size that is 90 MB per call (67 MB of line profiles), so it has to run at memory speed:
+// arrays are cut into 256 KB blocks handed to a persistent pool of host threads (round 4: spawning 7 threads per call
+// was a tenth of a millisecond by itself); a block's fingerprint is a Fletcher-style pair of running sums in 8 independent
+// 64-bit lanes -- s1 += w, s2 += s1: additions only, so the loop vectorises and one thread streams ~20 GB/s, against ~8 for
+// the multiply-xor chains of rounds 2-3 -- folded through a multiplicative mix with the block's offset; block fingerprints
+// are folded in order.  Any change of a single element changes s1 of its lane, a swap of two elements changes s2.
+class HashPool
+{
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::function<void()> job;
+    uint64_t generation = 0;
+    int running = 0;
+    bool stop = false;
+
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;)
+        {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                wake.wait(lock, [&] { return stop || generation != seen; });
+                if (stop)
+                    return;
+                seen = generation;
+                f = job;
+            }
+            f();
+            {
+                std::lock_guard<std::mutex> lock(m);
+                if (--running == 0)
+                    done.notify_one();
+            }
+        }
+    }
+
+public:
+    // (never destroyed: the threads are detached and end with the process; a forked child -- the threads do not exist
+    // there -- works through the blocks alone)
+    static HashPool& get()
+    {
+        static HashPool* pool = new HashPool();
+        return *pool;
+    }
+    long owner = 0;
+    HashPool()
+    {
+        owner = (long)getpid();
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned n = std::min(15u, hw > 2 ? hw / 2 - 1 : 0u); // (+ the calling thread)
+        for (unsigned t = 0; t < n; ++t)
+        {
+            threads.emplace_back([this] { loop(); });
+            threads.back().detach();
+        }
+    }
+    // f on every pool thread and on the caller; returns when all are through
+    void run(const std::function<void()>& f)
+    {
+        if (threads.empty() || (long)getpid() != owner)
+        {
+            f();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m);
+            job = f;
+            running = (int)threads.size();
+            ++generation;
+        }
+        wake.notify_all();
+        f();
+        std::unique_lock<std::mutex> lock(m);
+        done.wait(lock, [&] { return running == 0; });
+    }
+};
+
 struct HashSet
 {
     enum { BLOCK = 32768 };
@@ -46,6 +127,7 @@ struct HashSet
         const double* p;
         size_t n;
         uint64_t h;
+        bool sampled;
     };
     struct Block
     {
@@ -57,7 +139,31 @@ struct HashSet
 
     int add(const double* p, size_t n)
     {
-        jobs.push_back({ p, p ? n : 0, 0 });
+        jobs.push_back({ p, p ? n : 0, 0, false });
+        return (int)jobs.size() - 1;
+    }
+    // LWHIP_SAMPLED_FINGERPRINTS=1 (opt-in): every 509th element (and the last) of a large array instead of all of them --
+    // 0.4 ms per call less at the bench size, at the price the comment above names: an in-place edit that touches none of the
+    // sampled elements goes unnoticed (ExtraParams lwhip_force_upload covers a caller that knows it made one)
+    int add_sampled(const double* p, size_t n)
+    {
+        uint64_t h = mix((uint64_t)(uintptr_t)p, n);
+        if (p)
+        {
+            for (size_t i = 0; i < n; i += 509)
+            {
+                uint64_t w;
+                std::memcpy(&w, p + i, 8);
+                h = mix(h, w + i);
+            }
+            if (n)
+            {
+                uint64_t w;
+                std::memcpy(&w, p + n - 1, 8);
+                h = mix(h, w);
+            }
+        }
+        jobs.push_back({ p, 0, h, true });
         return (int)jobs.size() - 1;
     }
     static uint64_t mix(uint64_t h, uint64_t bits)
@@ -67,24 +173,29 @@ struct HashSet
     }
     static uint64_t block_hash(const double* p, size_t n, uint64_t seed)
     {
-        uint64_t h0 = 1469598103934665603ull ^ seed, h1 = n * 0x9E3779B97F4A7C15ull, h2 = 0x2545F4914F6CDD1Dull,
-                 h3 = 0xD6E8FEB86659FD93ull;
+        uint64_t s1[8] = { 1, 2, 3, 4, 5, 6, 7, 8 }, s2[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         size_t i = 0;
-        uint64_t w[4];
-        for (; i + 4 <= n; i += 4)
+        for (; i + 8 <= n; i += 8)
         {
-            std::memcpy(w, p + i, 32);
-            h0 = mix(h0, w[0]);
-            h1 = mix(h1, w[1]);
-            h2 = mix(h2, w[2]);
-            h3 = mix(h3, w[3]);
+            uint64_t w[8];
+            std::memcpy(w, p + i, 64);
+            for (int l = 0; l < 8; ++l)
+            {
+                s1[l] += w[l];
+                s2[l] += s1[l];
+            }
         }
-        for (; i < n; ++i)
+        for (int l = 0; i < n; ++i, ++l)
         {
-            std::memcpy(w, p + i, 8);
-            h0 = mix(h0, w[0] + i);
+            uint64_t w;
+            std::memcpy(&w, p + i, 8);
+            s1[l] += w;
+            s2[l] += s1[l];
         }
-        return mix(mix(mix(h0, h1), h2), h3);
+        uint64_t h = mix(1469598103934665603ull ^ seed, (uint64_t)n);
+        for (int l = 0; l < 8; ++l)
+            h = mix(mix(h, s1[l]), s2[l]);
+        return h;
     }
     void run()
     {
@@ -101,15 +212,13 @@ struct HashSet
             for (size_t b = next.fetch_add(1); b < blocks.size(); b = next.fetch_add(1))
                 blocks[b].h = block_hash(jobs[blocks[b].job].p + blocks[b].off, blocks[b].len, blocks[b].off);
         };
-        unsigned nThreads = total * sizeof(double) > (1u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nThreads; ++t)
-            pool.emplace_back(work);
-        work();
-        for (auto& t : pool)
-            t.join();
+        if (total * sizeof(double) > (1u << 20))
+            HashPool::get().run(work);
+        else
+            work();
         for (auto& j : jobs)
-            j.h = mix((uint64_t)(uintptr_t)j.p, j.n);
+            if (!j.sampled)
+                j.h = mix((uint64_t)(uintptr_t)j.p, j.n);
         for (auto& b : blocks)
             jobs[b.job].h = mix(jobs[b.job].h, b.h);
     }
@@ -144,6 +253,7 @@ struct PluginState
     bool prdDetailed = false;          // the device context was asked to include the detailed atoms' PRD lines
     double* zDown = nullptr;           // ZPlaneDecomposition outputs the device context currently writes
     double* zUp = nullptr;
+    bool jDeviceAhead = false;         // LWHIP_RESIDENT_J: the device holds a newer J (JRest) than spect.J
 };
 
 std::mutex g_mutex;
@@ -496,6 +606,8 @@ uint32_t dirty_mask(PluginState* st, bool force)
     const lwhip_problem& p = st->prob;
     const size_t Ns = p.Nspace, Nla = p.Nlambda, Nr = p.Nrays;
     HashSet hs;
+    const char* smp = std::getenv("LWHIP_SAMPLED_FINGERPRINTS");
+    const bool sampled = smp && smp[0] == '1';
     std::vector<int> jProf, jNstar, jColl, jBg, jAt;
     for (int ia = 0; ia < p.Natom; ++ia)
     {
@@ -511,11 +623,15 @@ uint32_t dirty_mask(PluginState* st, bool force)
                 continue;
             jNstar.push_back(hs.add(t.aDamp, Ns));
             jNstar.push_back(hs.add(t.Qelast, Ns));
-            jProf.push_back(hs.add(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns));
+            jProf.push_back(sampled ? hs.add_sampled(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns)
+                                    : hs.add(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns));
             jProf.push_back(hs.add(t.wphi, Ns));
         }
     }
-    jBg = { hs.add(p.bgChi, Nla * Ns), hs.add(p.bgEta, Nla * Ns), hs.add(p.bgSca, Nla * Ns) };
+    if (sampled)
+        jBg = { hs.add_sampled(p.bgChi, Nla * Ns), hs.add_sampled(p.bgEta, Nla * Ns), hs.add_sampled(p.bgSca, Nla * Ns) };
+    else
+        jBg = { hs.add(p.bgChi, Nla * Ns), hs.add(p.bgEta, Nla * Ns), hs.add(p.bgSca, Nla * Ns) };
     jAt = { hs.add(p.height, Ns), hs.add(p.temperature, Ns), hs.add(p.wavelength, Nla), hs.add(p.muz, Nr), hs.add(p.wmu, Nr),
             hs.add(p.vlosMu, p.vlosMu ? Nr * Ns : 0) };
     hs.run();
@@ -589,6 +705,7 @@ uint32_t sync_state(Context& ctx, bool force)
             lwhip_destroy(old);
         st->hip = nullptr;
         st->zDown = st->zUp = nullptr; // a fresh device context writes no z-plane outputs yet
+        st->jDeviceAhead = false;      // (LWHIP_RESIDENT_J: a rebuilt context starts from spect.J again)
         lwhip_options opts{};
         opts.flags = st->prdDetailed ? LWHIP_OPT_PRD_DETAILED : 0;
         // LWHIP_DETERMINISTIC=1: Gamma and the rates summed in a fixed order (bit-reproducible iterations, as the
@@ -639,17 +756,69 @@ void apply_zplane(Context& ctx, PluginState* st, ExtraParams& params)
     }
 }
 
+// LWHIP_RESIDENT_J=1 (read at every call): J stays in HBM between the calls -- 6.7 MB each way at the bench size, three
+// quarters of what the host-authoritative call adds to the kernels.  While it is set, spect.J (and JRest)
+// is neither uploaded nor written back: the caller promises not to rewrite it; the first call made without it brings the
+// device's J down before anything is uploaded, so the host is authoritative again from there.  Not the reference's contract
+// (every scheme leaves J in spect.J when it returns), hence opt-in.
+bool resident_J()
+{
+    const char* e = std::getenv("LWHIP_RESIDENT_J");
+    return e && e[0] == '1';
+}
+
+// the upload mask of a call under that policy (before lwhip_upload); `fresh`: the device context was just (re)created
+uint32_t j_policy_upload(PluginState* st, uint32_t up)
+{
+    if (st->jDeviceAhead)
+    {
+        if (!resident_J())
+        {
+            if (lwhip_download(st->hip, LWHIP_J) != LWHIP_OK) // spect.J catches up first
+                fail("lwhip_download");
+            st->jDeviceAhead = false;
+        }
+        up &= ~(uint32_t)LWHIP_J; // the device's J is the current one either way
+    }
+    return up;
+}
+
+// ... and the download mask after it
+uint32_t j_policy_download(PluginState* st, uint32_t down)
+{
+    if ((down & LWHIP_J) && resident_J())
+    {
+        down &= ~(uint32_t)LWHIP_J;
+        st->jDeviceAhead = true;
+    }
+    return down;
+}
+
 // ---- FsIterationFns members ----------------------------------------------------------------------
 
 // fs_iter: replaces formal_sol_iteration_matrices_<simd> (Source/SimdFullIterationTemplates.hpp:588-719)
 IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params)
 {
     trace("fs_iter", &ctx);
+    // LWHIP_PLUGIN_TIMING=1: where a call's host time goes (stderr)
+    static const bool timing = std::getenv("LWHIP_PLUGIN_TIMING") != nullptr;
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    auto lap = [&](const char* what, clk::time_point& prev) {
+        if (!timing)
+            return;
+        const auto t = clk::now();
+        std::fprintf(stderr, "  fs_iter: %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - prev).count());
+        prev = t;
+    };
+    auto tPrev = t0;
     const uint32_t up = sync_state(ctx, force_upload(params));
+    lap("flatten + fingerprints", tPrev);
     auto* st = (PluginState*)ctx.methodScratch;
     apply_zplane(ctx, st, params);
-    if (lwhip_upload(st->hip, up) != LWHIP_OK)
+    if (lwhip_upload(st->hip, j_policy_upload(st, up)) != LWHIP_OK)
         fail("lwhip_upload");
+    lap("upload", tPrev);
     // a Context with one thread runs the reference's single-thread loop, whose dJMaxIdx is NOT the arg-max (max_idx's
     // argument order, SimdFullIterationTemplates.hpp:627): report what that loop reports
     if (lwhip_set_djmax_index_mode(st->hip, ctx.Nthreads <= 1 ? 1 : 0) != LWHIP_OK)
@@ -657,11 +826,13 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
     lwhip_iter_result r{};
     if (lwhip_formal_sol_gamma_matrices(st->hip, lambdaIterate ? 1 : 0, &r) != LWHIP_OK)
         fail("lwhip_formal_sol_gamma_matrices");
+    lap("kernels", tPrev);
     uint32_t down = LWHIP_J | LWHIP_I | LWHIP_GAMMA | LWHIP_RATES;
     if (st->prob.storeDepthData)
         down |= LWHIP_DEPTHDATA;
-    if (lwhip_download(st->hip, down) != LWHIP_OK)
+    if (lwhip_download(st->hip, j_policy_download(st, down)) != LWHIP_OK)
         fail("lwhip_download");
+    lap("download", tPrev);
     IterationResult result{};
     result.updatedJ = true;
     result.dJMax = r.dJMax;
@@ -675,7 +846,7 @@ IterationResult simple_fs_hip(Context& ctx, bool upOnly, ExtraParams params)
     const uint32_t up = sync_state(ctx, force_upload(params));
     auto* st = (PluginState*)ctx.methodScratch;
     apply_zplane(ctx, st, params);
-    if (lwhip_upload(st->hip, up & ~(uint32_t)LWHIP_GAMMA) != LWHIP_OK)
+    if (lwhip_upload(st->hip, j_policy_upload(st, up & ~(uint32_t)LWHIP_GAMMA)) != LWHIP_OK)
         fail("lwhip_upload");
     if (lwhip_formal_sol(st->hip, upOnly ? 1 : 0) != LWHIP_OK)
         fail("lwhip_formal_sol");
@@ -824,7 +995,7 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
     ((PluginState*)ctx.methodScratch)->prdDetailed = includeDetailed;
     const uint32_t up = sync_state(ctx, force_upload(params));
     auto* st = (PluginState*)ctx.methodScratch;
-    if (lwhip_upload(st->hip, (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES) != LWHIP_OK)
+    if (lwhip_upload(st->hip, j_policy_upload(st, (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES)) != LWHIP_OK)
         fail("lwhip_upload");
     int Nprd = 0;
     for (auto* a : ctx.activeAtoms)
@@ -846,7 +1017,7 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
         fail("lwhip_redistribute_prd");
     // (the rates pass of every sub-iteration also rewrites spect.I of its wavelengths: intensity_core_opt,
     // SimdFullIterationTemplates.hpp:349)
-    if (lwhip_download(st->hip, LWHIP_J | LWHIP_I | LWHIP_RATES | LWHIP_RHOPRD) != LWHIP_OK)
+    if (lwhip_download(st->hip, j_policy_download(st, LWHIP_J | LWHIP_I | LWHIP_RATES | LWHIP_RHOPRD)) != LWHIP_OK)
         fail("lwhip_download");
     const size_t nEnt = (size_t)r.NprdSubIter * r.Nprd;
     result.updatedRho = true;

@@ -64,6 +64,39 @@ def test_dropin_matches_scalar_scheme(gpu, name):
 
 @needs_ref
 @pytest.mark.gpu
+def test_dropin_resident_J(gpu, monkeypatch):
+    """LWHIP_RESIDENT_J=1 (opt-in): J stays in HBM between the plugin's calls -- spect.J is neither
+    uploaded nor written back while the variable is set, and the first call made without it brings the device's J down before
+    anything goes up.  Four iterations with the variable set for the first three must end where four plain drop-in
+    iterations end (to the run-to-run noise of the atomically summed Gamma), and spect.J must stay untouched in between."""
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = variant_problem(base, d, 'iter1'), variant_problem(base, d, 'iter1')
+    plain, res = RefContext(q, scheme=PLUGIN), RefContext(p, scheme=PLUGIN)
+    for it in range(4):
+        q.gamma_prefill()
+        plain.formal_sol_gamma_matrices()
+        plain.stat_equil()
+    J0 = p.J.copy()
+    monkeypatch.setenv('LWHIP_RESIDENT_J', '1')
+    for it in range(3):
+        p.gamma_prefill()
+        r = res.formal_sol_gamma_matrices()
+        res.stat_equil()
+        assert np.array_equal(p.J, J0)          # not written back ...
+        p.J[...] = -1.0                         # ... and not read either: garbage here must not matter
+        J0 = p.J.copy()
+    monkeypatch.delenv('LWHIP_RESIDENT_J')
+    p.gamma_prefill()
+    res.formal_sol_gamma_matrices()             # the device's J comes down before this call uploads anything
+    res.stat_equil()
+    # (Gamma is summed by atomics, so the populations -- and through them the later iterations' J -- agree to the last bits only)
+    assert rel_err(p.J, q.J) <= 1e-10 and rel_err(p.I, q.I) <= 1e-10
+    for a, b in zip(p.atoms, q.atoms):
+        assert rel_err(a.n, b.n) <= 1e-9        # (the solve amplifies Gamma's last-bit noise: 1.4e-10 seen)
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_dropin_formal_sol_and_solvers(gpu):
     base, d = load_fixture('falc_h_ca_small')
     for solver in (abi.FS_LINEAR_1D, abi.FS_BESSER_1D, abi.FS_BEZIER3_1D):
@@ -102,9 +135,13 @@ def test_dropin_iterates_like_the_reference(gpu):
 
 @needs_ref
 @pytest.mark.gpu
-def test_dropin_sees_host_side_changes(gpu):
+@pytest.mark.parametrize('sampled', [False, True])
+def test_dropin_sees_host_side_changes(gpu, monkeypatch, sampled):
     """The plugin re-uploads what the host changed between calls (populations, J, profiles,
-    background), as the reference shares memory with the Python layer."""
+    background), as the reference shares memory with the Python layer -- with the exact fingerprints of the default and
+    with the sampled ones of LWHIP_SAMPLED_FINGERPRINTS=1 (updates that rewrite a whole array are seen by both)."""
+    if sampled:
+        monkeypatch.setenv('LWHIP_SAMPLED_FINGERPRINTS', '1')
     base, d = load_fixture('falc_h_vel')
     p, q = base.copy(), base.copy()
     hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
