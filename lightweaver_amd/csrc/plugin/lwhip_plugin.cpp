@@ -98,14 +98,12 @@ public:
             threads.back().detach();
         }
     }
-    // f on every pool thread and on the caller; returns when all are through
-    void run(const std::function<void()>& f)
+    bool usable() const { return !threads.empty() && (long)getpid() == owner; }
+    std::mutex busy; // one round of work at a time: a second caller (another Context on another thread) waits in start()
+    // f on every pool thread; returns at once (f must stay valid until wait() returns)
+    void start(const std::function<void()>& f)
     {
-        if (threads.empty() || (long)getpid() != owner)
-        {
-            f();
-            return;
-        }
+        busy.lock();
         {
             std::lock_guard<std::mutex> lock(m);
             job = f;
@@ -113,9 +111,26 @@ public:
             ++generation;
         }
         wake.notify_all();
+    }
+    void wait()
+    {
+        {
+            std::unique_lock<std::mutex> lock(m);
+            done.wait(lock, [&] { return running == 0; });
+        }
+        busy.unlock();
+    }
+    // f on every pool thread and on the caller; returns when all are through
+    void run(const std::function<void()>& f)
+    {
+        if (!usable())
+        {
+            f();
+            return;
+        }
+        start(f);
         f();
-        std::unique_lock<std::mutex> lock(m);
-        done.wait(lock, [&] { return running == 0; });
+        wait();
     }
 };
 
@@ -197,9 +212,14 @@ struct HashSet
             h = mix(mix(h, s1[l]), s2[l]);
         return h;
     }
-    void run()
+    std::vector<Block> blocks;
+    std::atomic<size_t> next{ 0 };
+    std::function<void()> worker;
+    bool inFlight = false;
+    size_t prepare()
     {
-        std::vector<Block> blocks;
+        blocks.clear();
+        next = 0;
         size_t total = 0;
         for (size_t j = 0; j < jobs.size(); ++j)
             for (size_t off = 0; off < jobs[j].n; off += BLOCK)
@@ -207,20 +227,49 @@ struct HashSet
                 blocks.push_back({ (int)j, off, std::min<size_t>(BLOCK, jobs[j].n - off), 0 });
                 total += blocks.back().len;
             }
-        std::atomic<size_t> next{ 0 };
-        auto work = [&]() {
-            for (size_t b = next.fetch_add(1); b < blocks.size(); b = next.fetch_add(1))
-                blocks[b].h = block_hash(jobs[blocks[b].job].p + blocks[b].off, blocks[b].len, blocks[b].off);
-        };
-        if (total * sizeof(double) > (1u << 20))
-            HashPool::get().run(work);
-        else
-            work();
+        return total;
+    }
+    void work()
+    {
+        for (size_t b = next.fetch_add(1); b < blocks.size(); b = next.fetch_add(1))
+            blocks[b].h = block_hash(jobs[blocks[b].job].p + blocks[b].off, blocks[b].len, blocks[b].off);
+    }
+    void fold()
+    {
         for (auto& j : jobs)
             if (!j.sampled)
                 j.h = mix((uint64_t)(uintptr_t)j.p, j.n);
         for (auto& b : blocks)
             jobs[b.job].h = mix(jobs[b.job].h, b.h);
+    }
+    void run()
+    {
+        start();
+        finish();
+    }
+    // the pool threads begin on the blocks; the caller goes on with something else and joins in at finish()
+    void start()
+    {
+        const size_t total = prepare();
+        inFlight = total * sizeof(double) > (1u << 20) && HashPool::get().usable();
+        if (inFlight)
+        {
+            worker = [this] { work(); };
+            HashPool::get().start(worker);
+        }
+    }
+    void finish()
+    {
+        work();
+        if (inFlight)
+            HashPool::get().wait();
+        inFlight = false;
+        fold();
+    }
+    ~HashSet()
+    {
+        if (inFlight)
+            HashPool::get().wait(); // (an exception between start and finish: the threads still read this object)
     }
     uint64_t operator[](int j) const { return jobs[j].h; }
 };
@@ -600,48 +649,63 @@ void flatten(Context& ctx, PluginState* st, PluginState* keep)
     p.atoms = st->atoms.data();
 }
 
-// fingerprints of the slowly changing inputs -> upload mask
-uint32_t dirty_mask(PluginState* st, bool force)
+// fingerprints of the slowly changing inputs -> upload mask.  In two halves, so that fs_iter can let the pool threads work
+// through the 90 MB while it uploads the per-call groups and runs the kernels (the common case: nothing changed).
+struct Prints
+{
+    HashSet hs;
+    std::vector<int> jProf, jNstar, jColl, jBg, jAt;
+    bool active = false;
+};
+
+void prints_begin(PluginState* st, Prints& pr)
 {
     const lwhip_problem& p = st->prob;
     const size_t Ns = p.Nspace, Nla = p.Nlambda, Nr = p.Nrays;
-    HashSet hs;
+    HashSet& hs = pr.hs;
     const char* smp = std::getenv("LWHIP_SAMPLED_FINGERPRINTS");
     const bool sampled = smp && smp[0] == '1';
-    std::vector<int> jProf, jNstar, jColl, jBg, jAt;
     for (int ia = 0; ia < p.Natom; ++ia)
     {
         const lwhip_atom& a = p.atoms[ia];
-        jNstar.push_back(hs.add(a.nStar, (size_t)a.Nlevel * Ns));
-        jNstar.push_back(hs.add(a.nTotal, Ns));
-        jNstar.push_back(hs.add(a.vBroad, Ns));
-        jColl.push_back(hs.add(a.C, (size_t)a.Nlevel * a.Nlevel * Ns));
+        pr.jNstar.push_back(hs.add(a.nStar, (size_t)a.Nlevel * Ns));
+        pr.jNstar.push_back(hs.add(a.nTotal, Ns));
+        pr.jNstar.push_back(hs.add(a.vBroad, Ns));
+        pr.jColl.push_back(hs.add(a.C, (size_t)a.Nlevel * a.Nlevel * Ns));
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
             const lwhip_transition& t = a.trans[kr];
             if (t.type != LWHIP_LINE)
                 continue;
-            jNstar.push_back(hs.add(t.aDamp, Ns));
-            jNstar.push_back(hs.add(t.Qelast, Ns));
-            jProf.push_back(sampled ? hs.add_sampled(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns)
-                                    : hs.add(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns));
-            jProf.push_back(hs.add(t.wphi, Ns));
+            pr.jNstar.push_back(hs.add(t.aDamp, Ns));
+            pr.jNstar.push_back(hs.add(t.Qelast, Ns));
+            pr.jProf.push_back(sampled ? hs.add_sampled(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns)
+                                       : hs.add(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns));
+            pr.jProf.push_back(hs.add(t.wphi, Ns));
         }
     }
     if (sampled)
-        jBg = { hs.add_sampled(p.bgChi, Nla * Ns), hs.add_sampled(p.bgEta, Nla * Ns), hs.add_sampled(p.bgSca, Nla * Ns) };
+        pr.jBg = { hs.add_sampled(p.bgChi, Nla * Ns), hs.add_sampled(p.bgEta, Nla * Ns), hs.add_sampled(p.bgSca, Nla * Ns) };
     else
-        jBg = { hs.add(p.bgChi, Nla * Ns), hs.add(p.bgEta, Nla * Ns), hs.add(p.bgSca, Nla * Ns) };
-    jAt = { hs.add(p.height, Ns), hs.add(p.temperature, Ns), hs.add(p.wavelength, Nla), hs.add(p.muz, Nr), hs.add(p.wmu, Nr),
-            hs.add(p.vlosMu, p.vlosMu ? Nr * Ns : 0) };
-    hs.run();
+        pr.jBg = { hs.add(p.bgChi, Nla * Ns), hs.add(p.bgEta, Nla * Ns), hs.add(p.bgSca, Nla * Ns) };
+    pr.jAt = { hs.add(p.height, Ns), hs.add(p.temperature, Ns), hs.add(p.wavelength, Nla), hs.add(p.muz, Nr), hs.add(p.wmu, Nr),
+               hs.add(p.vlosMu, p.vlosMu ? Nr * Ns : 0) };
+    hs.start();
+    pr.active = true;
+}
+
+uint32_t prints_finish(PluginState* st, Prints& pr, bool force)
+{
+    HashSet& hs = pr.hs;
+    hs.finish();
+    pr.active = false;
     auto fold = [&](const std::vector<int>& js) {
         uint64_t h = js.size();
         for (int j : js)
             h = HashSet::mix(h, hs[j]);
         return h;
     };
-    const uint64_t fProf = fold(jProf), fNstar = fold(jNstar), fColl = fold(jColl), fBg = fold(jBg), fAt = fold(jAt);
+    const uint64_t fProf = fold(pr.jProf), fNstar = fold(pr.jNstar), fColl = fold(pr.jColl), fBg = fold(pr.jBg), fAt = fold(pr.jAt);
     uint32_t mask = LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
     if (force || fProf != st->fpProfiles)
         mask |= LWHIP_PROFILES;
@@ -661,6 +725,13 @@ uint32_t dirty_mask(PluginState* st, bool force)
     return mask;
 }
 
+uint32_t dirty_mask(PluginState* st, bool force)
+{
+    Prints pr;
+    prints_begin(st, pr);
+    return prints_finish(st, pr, force);
+}
+
 void destroy_state(Context* ctx)
 {
     auto* st = (PluginState*)ctx->methodScratch;
@@ -678,7 +749,9 @@ void destroy_state(Context* ctx)
 }
 
 // make sure a device context matching the current Context exists; returns the upload mask
-uint32_t sync_state(Context& ctx, bool force)
+// `later`: the fingerprints of the slow groups are only started (prints_begin); the returned mask holds the per-call groups and
+// the caller asks prints_finish for the rest when it has nothing better to do (later->active tells whether there is a rest)
+uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr)
 {
     auto* st = (PluginState*)ctx.methodScratch;
     if (!st)
@@ -720,6 +793,11 @@ uint32_t sync_state(Context& ctx, bool force)
             fail("lwhip_create");
         dirty_mask(st, true); // create uploaded everything: just record the fingerprints
         register_atoms(&ctx);
+        return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
+    }
+    if (later)
+    {
+        prints_begin(st, *later);
         return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
     }
     return dirty_mask(st, force);
@@ -812,21 +890,40 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
         prev = t;
     };
     auto tPrev = t0;
-    const uint32_t up = sync_state(ctx, force_upload(params));
-    lap("flatten + fingerprints", tPrev);
+    // The slow groups (profiles, background, atmosphere, ...) almost never change between two calls, but finding that out means
+    // reading 90 MB of the caller's arrays (0.4 ms at the bench size).  So the pool threads fingerprint them WHILE this thread
+    // uploads the per-call groups and runs the kernels as if nothing had changed; if something had, the changed groups and the
+    // per-call groups go up (again: J was overwritten) and the kernels run a second time.  Same results either way.  Not with
+    // LWHIP_RESIDENT_J (the J the first run started from is gone) and not with a forced upload.
+    const bool force = force_upload(params);
+    Prints prints;
+    const bool speculate = !force && !resident_J() && ((PluginState*)ctx.methodScratch != nullptr)
+                           && !((PluginState*)ctx.methodScratch)->jDeviceAhead;
+    uint32_t up = sync_state(ctx, force, speculate ? &prints : nullptr);
+    lap(speculate ? "flatten" : "flatten + fingerprints", tPrev);
     auto* st = (PluginState*)ctx.methodScratch;
     apply_zplane(ctx, st, params);
-    if (lwhip_upload(st->hip, j_policy_upload(st, up)) != LWHIP_OK)
-        fail("lwhip_upload");
-    lap("upload", tPrev);
     // a Context with one thread runs the reference's single-thread loop, whose dJMaxIdx is NOT the arg-max (max_idx's
     // argument order, SimdFullIterationTemplates.hpp:627): report what that loop reports
     if (lwhip_set_djmax_index_mode(st->hip, ctx.Nthreads <= 1 ? 1 : 0) != LWHIP_OK)
         fail("lwhip_set_djmax_index_mode");
     lwhip_iter_result r{};
-    if (lwhip_formal_sol_gamma_matrices(st->hip, lambdaIterate ? 1 : 0, &r) != LWHIP_OK)
-        fail("lwhip_formal_sol_gamma_matrices");
-    lap("kernels", tPrev);
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+        if (lwhip_upload(st->hip, j_policy_upload(st, up)) != LWHIP_OK)
+            fail("lwhip_upload");
+        lap("upload", tPrev);
+        if (lwhip_formal_sol_gamma_matrices(st->hip, lambdaIterate ? 1 : 0, &r) != LWHIP_OK)
+            fail("lwhip_formal_sol_gamma_matrices");
+        lap("kernels", tPrev);
+        if (!prints.active)
+            break;
+        const uint32_t all = prints_finish(st, prints, false);
+        lap("fingerprints (rest)", tPrev);
+        if (!(all & kSlowGroups))
+            break;
+        up = all; // something had changed: the changed groups and the per-call groups (again), then the kernels again
+    }
     uint32_t down = LWHIP_J | LWHIP_I | LWHIP_GAMMA | LWHIP_RATES;
     if (st->prob.storeDepthData)
         down |= LWHIP_DEPTHDATA;
