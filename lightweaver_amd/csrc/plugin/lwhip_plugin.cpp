@@ -651,15 +651,21 @@ void flatten(Context& ctx, PluginState* st, PluginState* keep)
 
 // fingerprints of the slowly changing inputs -> upload mask.  In two halves, so that fs_iter can let the pool threads work
 // through the 90 MB while it uploads the per-call groups and runs the kernels (the common case: nothing changed).
+// the input groups tracked by fingerprint (the others go up on every call)
+constexpr uint32_t kSlowGroups = LWHIP_PROFILES | LWHIP_BACKGROUND | LWHIP_ATMOS | LWHIP_NSTAR | LWHIP_COLLISIONS;
+
 struct Prints
 {
     HashSet hs;
     std::vector<int> jProf, jNstar, jColl, jBg, jAt;
+    uint32_t groups = kSlowGroups; // the groups looked at: a population update reads only two small ones and leaves the large
+                                   // ones (profiles, background: 0.4 ms to read) to the next formal solution, unrecorded
     bool active = false;
 };
 
-void prints_begin(PluginState* st, Prints& pr)
+void prints_begin(PluginState* st, Prints& pr, uint32_t groups = kSlowGroups)
 {
+    pr.groups = groups;
     const lwhip_problem& p = st->prob;
     const size_t Ns = p.Nspace, Nla = p.Nlambda, Nr = p.Nrays;
     HashSet& hs = pr.hs;
@@ -668,28 +674,41 @@ void prints_begin(PluginState* st, Prints& pr)
     for (int ia = 0; ia < p.Natom; ++ia)
     {
         const lwhip_atom& a = p.atoms[ia];
-        pr.jNstar.push_back(hs.add(a.nStar, (size_t)a.Nlevel * Ns));
-        pr.jNstar.push_back(hs.add(a.nTotal, Ns));
-        pr.jNstar.push_back(hs.add(a.vBroad, Ns));
-        pr.jColl.push_back(hs.add(a.C, (size_t)a.Nlevel * a.Nlevel * Ns));
+        if (groups & LWHIP_NSTAR)
+        {
+            pr.jNstar.push_back(hs.add(a.nStar, (size_t)a.Nlevel * Ns));
+            pr.jNstar.push_back(hs.add(a.nTotal, Ns));
+            pr.jNstar.push_back(hs.add(a.vBroad, Ns));
+        }
+        if (groups & LWHIP_COLLISIONS)
+            pr.jColl.push_back(hs.add(a.C, (size_t)a.Nlevel * a.Nlevel * Ns));
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
             const lwhip_transition& t = a.trans[kr];
             if (t.type != LWHIP_LINE)
                 continue;
-            pr.jNstar.push_back(hs.add(t.aDamp, Ns));
-            pr.jNstar.push_back(hs.add(t.Qelast, Ns));
-            pr.jProf.push_back(sampled ? hs.add_sampled(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns)
-                                       : hs.add(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns));
-            pr.jProf.push_back(hs.add(t.wphi, Ns));
+            if (groups & LWHIP_NSTAR)
+            {
+                pr.jNstar.push_back(hs.add(t.aDamp, Ns));
+                pr.jNstar.push_back(hs.add(t.Qelast, Ns));
+            }
+            if (groups & LWHIP_PROFILES)
+            {
+                pr.jProf.push_back(sampled ? hs.add_sampled(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns)
+                                           : hs.add(t.phi, (size_t)(t.Nred - t.Nblue) * Nr * 2 * Ns));
+                pr.jProf.push_back(hs.add(t.wphi, Ns));
+            }
         }
     }
-    if (sampled)
+    if (!(groups & LWHIP_BACKGROUND))
+        pr.jBg.clear();
+    else if (sampled)
         pr.jBg = { hs.add_sampled(p.bgChi, Nla * Ns), hs.add_sampled(p.bgEta, Nla * Ns), hs.add_sampled(p.bgSca, Nla * Ns) };
     else
         pr.jBg = { hs.add(p.bgChi, Nla * Ns), hs.add(p.bgEta, Nla * Ns), hs.add(p.bgSca, Nla * Ns) };
-    pr.jAt = { hs.add(p.height, Ns), hs.add(p.temperature, Ns), hs.add(p.wavelength, Nla), hs.add(p.muz, Nr), hs.add(p.wmu, Nr),
-               hs.add(p.vlosMu, p.vlosMu ? Nr * Ns : 0) };
+    if (groups & LWHIP_ATMOS)
+        pr.jAt = { hs.add(p.height, Ns), hs.add(p.temperature, Ns), hs.add(p.wavelength, Nla), hs.add(p.muz, Nr), hs.add(p.wmu, Nr),
+                   hs.add(p.vlosMu, p.vlosMu ? Nr * Ns : 0) };
     hs.start();
     pr.active = true;
 }
@@ -707,28 +726,25 @@ uint32_t prints_finish(PluginState* st, Prints& pr, bool force)
     };
     const uint64_t fProf = fold(pr.jProf), fNstar = fold(pr.jNstar), fColl = fold(pr.jColl), fBg = fold(pr.jBg), fAt = fold(pr.jAt);
     uint32_t mask = LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
-    if (force || fProf != st->fpProfiles)
-        mask |= LWHIP_PROFILES;
-    if (force || fBg != st->fpBackground)
-        mask |= LWHIP_BACKGROUND;
-    if (force || fAt != st->fpAtmos)
-        mask |= LWHIP_ATMOS;
-    if (force || fNstar != st->fpNstar)
-        mask |= LWHIP_NSTAR;
-    if (force || fColl != st->fpCollisions)
-        mask |= LWHIP_COLLISIONS;
-    st->fpProfiles = fProf;
-    st->fpBackground = fBg;
-    st->fpAtmos = fAt;
-    st->fpNstar = fNstar;
-    st->fpCollisions = fColl;
+    auto look = [&](uint32_t group, uint64_t f, uint64_t& recorded) {
+        if (!(pr.groups & group))
+            return; // not looked at: whoever looks next compares against what was recorded before
+        if (force || f != recorded)
+            mask |= group;
+        recorded = f;
+    };
+    look(LWHIP_PROFILES, fProf, st->fpProfiles);
+    look(LWHIP_BACKGROUND, fBg, st->fpBackground);
+    look(LWHIP_ATMOS, fAt, st->fpAtmos);
+    look(LWHIP_NSTAR, fNstar, st->fpNstar);
+    look(LWHIP_COLLISIONS, fColl, st->fpCollisions);
     return mask;
 }
 
-uint32_t dirty_mask(PluginState* st, bool force)
+uint32_t dirty_mask(PluginState* st, bool force, uint32_t groups = kSlowGroups)
 {
     Prints pr;
-    prints_begin(st, pr);
+    prints_begin(st, pr, groups);
     return prints_finish(st, pr, force);
 }
 
@@ -751,7 +767,7 @@ void destroy_state(Context* ctx)
 // make sure a device context matching the current Context exists; returns the upload mask
 // `later`: the fingerprints of the slow groups are only started (prints_begin); the returned mask holds the per-call groups and
 // the caller asks prints_finish for the rest when it has nothing better to do (later->active tells whether there is a rest)
-uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr)
+uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr, uint32_t groups = kSlowGroups)
 {
     auto* st = (PluginState*)ctx.methodScratch;
     if (!st)
@@ -800,11 +816,9 @@ uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr)
         prints_begin(st, *later);
         return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
     }
-    return dirty_mask(st, force);
+    return dirty_mask(st, force, force ? kSlowGroups : groups);
 }
 
-// the input groups dirty_mask tracks by fingerprint (the others go up on every call)
-constexpr uint32_t kSlowGroups = LWHIP_PROFILES | LWHIP_BACKGROUND | LWHIP_ATMOS | LWHIP_NSTAR | LWHIP_COLLISIONS;
 
 bool force_upload(ExtraParams& params)
 {
@@ -984,7 +998,7 @@ void stat_eq_hip(Atom* atom, ExtraParams params, int spaceStart, int spaceEnd)
     if (!ctx)
         throw std::runtime_error("lwhip plugin: stat_eq needs an atom of a live Context");
     // whatever else changed since the last call goes up too: sync_state has just recorded its fingerprint as clean
-    const uint32_t up = sync_state(*ctx, force_upload(params)) & kSlowGroups;
+    const uint32_t up = sync_state(*ctx, force_upload(params), nullptr, LWHIP_NSTAR) & kSlowGroups;
     auto* st = (PluginState*)ctx->methodScratch;
     if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
         fail("lwhip_upload");
@@ -1014,7 +1028,7 @@ void time_dep_update_hip(Atom* atom, F64View2D nOld, f64 dt, ExtraParams params,
     }
     if (!ctx)
         throw std::runtime_error("lwhip plugin: time_dep_update needs an atom of a live Context");
-    const uint32_t up = sync_state(*ctx, force_upload(params)) & kSlowGroups;
+    const uint32_t up = sync_state(*ctx, force_upload(params), nullptr, LWHIP_NSTAR) & kSlowGroups;
     auto* st = (PluginState*)ctx->methodScratch;
     if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS) != LWHIP_OK)
         fail("lwhip_upload");
@@ -1033,7 +1047,7 @@ void nr_post_update_hip(Context& ctx, std::vector<Atom*>* atoms, const std::vect
                         F64View backgroundNe, const NrTimeDependentData& timeDepData, f64 crswVal,
                         ExtraParams params, int spaceStart, int spaceEnd)
 {
-    const uint32_t up = sync_state(ctx, force_upload(params)) & kSlowGroups;
+    const uint32_t up = sync_state(ctx, force_upload(params), nullptr, LWHIP_NSTAR | LWHIP_COLLISIONS) & kSlowGroups;
     auto* st = (PluginState*)ctx.methodScratch;
     const DepthRange range(st->hip, spaceStart, spaceEnd); // (:316)
     if (lwhip_upload(st->hip, up | LWHIP_GAMMA | LWHIP_POPS | LWHIP_COLLISIONS) != LWHIP_OK)

@@ -1,5 +1,6 @@
 """The drop-in call as a Lightweaver user gets it -- the real core (oracle/_ref) driving the plugin -- per iteration, with
-spect.J host-authoritative (the default) and with LWHIP_RESIDENT_J=1: python3 tools/plugin_time.py [Nlambda]"""
+spect.J host-authoritative (the default), with the opt-in switches of INTEGRATION.md section 5, and with the statistical
+equilibrium of all atoms after it: python3 tools/plugin_time.py [Nlambda]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightweaver_amd import build
@@ -11,21 +12,31 @@ prob = models.throughput_grid(nla, 5)
 rc = RefContext(prob, scheme=build.PLUGIN)
 
 
-def timed(n=20):
-    for _ in range(3):
+def timed(n=20, se=False):
+    def step():
         rc.formal_sol_gamma_matrices()
+        if se:
+            rc.stat_equil()
+    for _ in range(3):
+        step()
     t0 = time.perf_counter()
     for _ in range(n):
-        rc.formal_sol_gamma_matrices()
+        step()
     return 1e3 * (time.perf_counter() - t0) / n
 
 
-print(f'Nlambda={prob.Nlambda}: plugin call, host-authoritative J  {timed():.3f} ms')
+def show(what, **kw):
+    print(f'Nlambda={prob.Nlambda}: {what:58s} {timed(**kw):.3f} ms')
+
+
+show('plugin call, host-authoritative J')
+show('formal solution + stat_equil of every atom', se=True)
 os.environ['LWHIP_RESIDENT_J'] = '1'
-print(f'Nlambda={prob.Nlambda}: plugin call, LWHIP_RESIDENT_J=1     {timed():.3f} ms')
+show('LWHIP_RESIDENT_J=1')
 os.environ['LWHIP_SAMPLED_FINGERPRINTS'] = '1'
-print(f'Nlambda={prob.Nlambda}: ... and LWHIP_SAMPLED_FINGERPRINTS=1  {timed():.3f} ms')
+show('LWHIP_RESIDENT_J=1 LWHIP_SAMPLED_FINGERPRINTS=1')
+show('... + stat_equil of every atom', se=True)
 del os.environ['LWHIP_RESIDENT_J']
-print(f'Nlambda={prob.Nlambda}: sampled fingerprints, host J        {timed():.3f} ms')
+show('LWHIP_SAMPLED_FINGERPRINTS=1')
 del os.environ['LWHIP_SAMPLED_FINGERPRINTS']
-print(f'Nlambda={prob.Nlambda}: plugin call, host-authoritative J  {timed():.3f} ms')
+show('plugin call, host-authoritative J')
