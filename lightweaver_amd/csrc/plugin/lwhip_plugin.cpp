@@ -954,13 +954,25 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
 // simple_fs: replaces formal_sol_<simd> (Source/SimdFullIterationTemplates.hpp:721-781)
 IterationResult simple_fs_hip(Context& ctx, bool upOnly, ExtraParams params)
 {
-    const uint32_t up = sync_state(ctx, force_upload(params));
+    // (as fs_iter: the slow groups are fingerprinted while the formal solution runs on what the device holds; it changes none of
+    // its inputs, so the second run, should something have changed, needs no more than the changed groups)
+    const bool force = force_upload(params);
+    Prints prints;
+    uint32_t up = sync_state(ctx, force, (!force && ctx.methodScratch) ? &prints : nullptr);
     auto* st = (PluginState*)ctx.methodScratch;
     apply_zplane(ctx, st, params);
-    if (lwhip_upload(st->hip, j_policy_upload(st, up & ~(uint32_t)LWHIP_GAMMA)) != LWHIP_OK)
-        fail("lwhip_upload");
-    if (lwhip_formal_sol(st->hip, upOnly ? 1 : 0) != LWHIP_OK)
-        fail("lwhip_formal_sol");
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+        if (lwhip_upload(st->hip, j_policy_upload(st, up & ~(uint32_t)LWHIP_GAMMA)) != LWHIP_OK)
+            fail("lwhip_upload");
+        if (lwhip_formal_sol(st->hip, upOnly ? 1 : 0) != LWHIP_OK)
+            fail("lwhip_formal_sol");
+        if (!prints.active)
+            break;
+        up = prints_finish(st, prints, false) & kSlowGroups;
+        if (!up)
+            break;
+    }
     if (lwhip_download(st->hip, LWHIP_I) != LWHIP_OK)
         fail("lwhip_download");
     return IterationResult{};
