@@ -1116,10 +1116,16 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
     if (!ctx.methodScratch)
         ctx.methodScratch = new PluginState();
     ((PluginState*)ctx.methodScratch)->prdDetailed = includeDetailed;
-    const uint32_t up = sync_state(ctx, force_upload(params));
+    // (as fs_iter: the fingerprints of the slow groups run beside the sub-iterations.  Everything the sub-iterations change on
+    // the device -- rho, J and I of the PRD wavelengths, the PRD lines' rates -- goes up from the host at the start of every
+    // call, so a second run after a detected change is a fresh call.  Not for hybrid PRD, whose JRest lives on the device only,
+    // and not with LWHIP_RESIDENT_J.)
+    const bool force = force_upload(params);
+    Prints prints;
+    const bool speculate = !force && !resident_J() && !((PluginState*)ctx.methodScratch)->hprdOn
+                           && !((PluginState*)ctx.methodScratch)->jDeviceAhead;
+    uint32_t up = sync_state(ctx, force, speculate ? &prints : nullptr);
     auto* st = (PluginState*)ctx.methodScratch;
-    if (lwhip_upload(st->hip, j_policy_upload(st, (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES)) != LWHIP_OK)
-        fail("lwhip_upload");
     int Nprd = 0;
     for (auto* a : ctx.activeAtoms)
         for (auto* t : a->trans)
@@ -1136,8 +1142,19 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
     std::vector<f64> dRho((size_t)maxIter * Nprd), dJ(maxIter);
     std::vector<int32_t> dRhoIdx((size_t)maxIter * Nprd), dJIdx(maxIter);
     lwhip_prd_result r{ 0, 0, dRho.data(), dRhoIdx.data(), dJ.data(), dJIdx.data() };
-    if (lwhip_redistribute_prd(st->hip, maxIter, tol, &r) != LWHIP_OK)
-        fail("lwhip_redistribute_prd");
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+        if (lwhip_upload(st->hip, j_policy_upload(st, (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES)) != LWHIP_OK)
+            fail("lwhip_upload");
+        if (lwhip_redistribute_prd(st->hip, maxIter, tol, &r) != LWHIP_OK)
+            fail("lwhip_redistribute_prd");
+        if (!prints.active)
+            break;
+        const uint32_t all = prints_finish(st, prints, false);
+        if (!(all & kSlowGroups))
+            break;
+        up = all;
+    }
     // (the rates pass of every sub-iteration also rewrites spect.I of its wavelengths: intensity_core_opt,
     // SimdFullIterationTemplates.hpp:349)
     if (lwhip_download(st->hip, j_policy_download(st, LWHIP_J | LWHIP_I | LWHIP_RATES | LWHIP_RHOPRD)) != LWHIP_OK)
