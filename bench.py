@@ -63,7 +63,7 @@ def parse():
     return ap.parse_args()
 
 
-PREWARM = 60  # untimed steps before the warm-up steps (clock settle; see main)
+PREWARM = int(os.environ.get('LWHIP_BENCH_PREWARM', '200'))  # untimed steps before the warm-up steps (clock settle; see main)
 
 
 def profiled_traffic(sweep_kind='march'):
@@ -379,9 +379,10 @@ def main():
     gc.disable()
     # (the collection above takes tens of milliseconds: it comes BEFORE the warm-up steps, so that no idle gap -- in which the
     # device drops its clocks -- separates the warm-up from the timed steps)
-    # Clock settle: a fresh process reaches the device's sustained clocks only after ~10 ms of load -- with W = 5 a 20-step
-    # run measured the sweep kernel 4 % slower than a 100-step one (0.179 against 0.172 ms on the same box).  PREWARM
-    # untimed steps (13 ms) before the W warm-up steps, reported as "prewarm_steps"; the timed region is exactly K steps.
+    # Clock settle: a fresh process reaches the device's sustained clocks only after ~30 ms of load.  Round 4, the same box, the
+    # 20-step form (tools/prewarm_exp.sh): sweep kernel 0.137 ms / step 0.153 ms with no settle steps, 0.131 / 0.149 with 60
+    # (8 ms), 0.127 / 0.142 with 200 (28 ms), the same with 500 and 1 000 -- and the same as a 100-step run measures.  PREWARM
+    # untimed steps before the W warm-up steps, reported as "prewarm_steps"; the timed region is exactly K steps.
     for _ in range(PREWARM):
         step()
     for _ in range(args.warmup):
