@@ -159,7 +159,7 @@ struct lwhip_context
     // hybrid PRD (lwhip_options.hprd): the tables of configure_hprd_coeffs on the device
     // deterministic mode (LWHIP_OPT_DETERMINISTIC): per-workgroup slabs + the (workgroup, slot) lists of every transition
     bool deterministic = false;
-    DevBuf<double> detSlab;
+    DevBuf<double> detSlab, detPart; // (detPart: partial sums of the fixed-shape reduction, lwhip_lanesweep.hip)
     DevBuf<int32_t> detOff, detEnt, detOffPrd, detEntPrd;
     const lwhip_hprd* hprd = nullptr;
     std::vector<int> hLa2prdHost, hLa2hHost;     // global wavelength -> row of JRest / ordinal among hPrdIdxs, or -1

@@ -352,8 +352,9 @@ bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R
 size_t lane_sweep_lds_bytes(const TileArgs& a, int waves);
 hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int solver, bool rates,
                              int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream);
-hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, int Ns, int Ntrans, int maxCT,
+hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, double* part, int Ns, int Ntrans,
                              hipStream_t stream);
+size_t det_reduce_scratch_doubles(int Ns, int Ntrans); // `part`: the partial sums of the fixed-shape reduction
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
 hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostList, int n, hipStream_t stream);
 

@@ -2416,22 +2416,28 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
 #endif
 }
 
-// Deterministic mode: red8[tr][part 0][q][k] = sum of the workgroups' slabs that hold transition tr, in workgroup order
-// (the list of (workgroup, slot) pairs per transition is the host's).  Fixed order: bit-reproducible Gamma and rates,
-// as the reference's single-thread path and its fixed-order thread reduction are (ThreadStorage.cpp:343-396).
+// Deterministic mode: red8[tr][part 0][q][k] = sum of the workgroups' slabs that hold transition tr, in a FIXED order
+// (the list of (workgroup, slot) pairs per transition is the host's): bit-reproducible Gamma and rates, as the reference's
+// single-thread path and its fixed-order thread reduction are (ThreadStorage.cpp:343-396).  Round 4: a two-level sum of fixed
+// shape instead of one thread walking a whole list -- a continuum's list has one entry per workgroup, 3 429 at the bench size, and
+// the walk was 0.7 ms of latency.  Segment s of DET_SEG covers list positions [L s / DET_SEG, L (s + 1) / DET_SEG) -- a function
+// of the list's length alone --, is added up in list order (eight loads in flight), and the DET_SEG partial sums are added in
+// segment order.
+enum { DET_SEG = 32 };
 __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restrict__ slab, const int32_t* __restrict__ off,
-                                                         const int32_t* __restrict__ ent, double* __restrict__ red8, int Ns, int maxCT)
+                                                         const int32_t* __restrict__ ent, double* __restrict__ part, int Ns)
 {
     dbg_poison_lds();
-    const int tr = blockIdx.y;
+    const int tr = blockIdx.y, seg = blockIdx.z;
     const int n4 = 4 * Ns;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4)
         return;
-    // (eight loads in flight, the additions in list order: the chain is latency-bound otherwise)
+    const int e0 = off[tr];
+    const long long L = off[tr + 1] - e0;
+    int e = e0 + (int)((L * seg) / DET_SEG);
+    const int e1 = e0 + (int)((L * (seg + 1)) / DET_SEG);
     double sum = 0.0;
-    int e = off[tr];
-    const int e1 = off[tr + 1];
     for (; e + 8 <= e1; e += 8)
     {
         double v[8];
@@ -2444,7 +2450,25 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restric
     }
     for (; e < e1; ++e)
         sum += slab[(size_t)ent[e] * n4 + i];
-    (void)maxCT;
+    part[((size_t)tr * DET_SEG + seg) * n4 + i] = sum;
+}
+
+__global__ void __launch_bounds__(256) det_reduce2_kernel(const double* __restrict__ part, double* __restrict__ red8, int Ns)
+{
+    dbg_poison_lds();
+    const int tr = blockIdx.y;
+    const int n4 = 4 * Ns;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4)
+        return;
+    double v[DET_SEG];
+#pragma unroll
+    for (int s = 0; s < DET_SEG; ++s)
+        v[s] = part[((size_t)tr * DET_SEG + s) * n4 + i];
+    double sum = 0.0;
+#pragma unroll
+    for (int s = 0; s < DET_SEG; ++s)
+        sum += v[s];
     red8[(size_t)tr * LWHIP_REDUCE_SPLIT * n4 + i] = sum;
 }
 
@@ -2496,12 +2520,15 @@ bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R
     return true;
 }
 
-hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, int Ns, int Ntrans, int maxCT,
+size_t det_reduce_scratch_doubles(int Ns, int Ntrans) { return (size_t)std::max(Ntrans, 1) * DET_SEG * 4 * Ns; }
+
+hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, double* part, int Ns, int Ntrans,
                              hipStream_t stream)
 {
     if (Ntrans <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(det_reduce_kernel, dim3((4 * Ns + 255) / 256, Ntrans), dim3(256), 0, stream, slab, off, ent, red8, Ns, maxCT);
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((4 * Ns + 255) / 256, Ntrans, DET_SEG), dim3(256), 0, stream, slab, off, ent, part, Ns);
+    hipLaunchKernelGGL(det_reduce2_kernel, dim3((4 * Ns + 255) / 256, Ntrans), dim3(256), 0, stream, part, red8, Ns);
     return hipGetLastError();
 }
 

@@ -1250,6 +1250,7 @@ int build_tables(lwhip_context* c)
             }
             const size_t nch = std::max<size_t>(c->nTileChunks, tileListPrd.empty() ? 0 : swPrd.chunkTile.size() - 1);
             HIP_TRY(c->detSlab.alloc(nch * c->maxCTTile * 4 * Ns));
+            HIP_TRY(c->detPart.alloc(det_reduce_scratch_doubles((int)Ns, c->Ntrans)));
         }
         postChunkTile = po.chunkTile;
         postSlotTr = po.slotTr;

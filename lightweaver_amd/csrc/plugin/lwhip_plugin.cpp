@@ -798,7 +798,7 @@ uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr, uint32_t 
         lwhip_options opts{};
         opts.flags = st->prdDetailed ? LWHIP_OPT_PRD_DETAILED : 0;
         // LWHIP_DETERMINISTIC=1: Gamma and the rates summed in a fixed order (bit-reproducible iterations, as the
-        // reference's schemes are) instead of by fp64 atomics; off by default: it costs 2-4x in the sweep
+        // reference's schemes are) instead of by fp64 atomics; off by default: it costs 1.7-2.7x per step
         {
             const char* det = std::getenv("LWHIP_DETERMINISTIC");
             if (det && det[0] == '1')
