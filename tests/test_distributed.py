@@ -317,3 +317,77 @@ def test_two_process_gloo_on_one_gpu_matches_unsharded(gpu, tmp_path, resident):
         assert rel_err(z['R'], np.stack([t.Rij for t in prob.atoms[0].trans])) <= 1e-12
         assert [float(x) for x in z['dJ']] == [u.dJMax for u in ups]
         assert [int(x) for x in z['idx']] == [u.dJMaxIdx for u in ups]
+
+
+# ---- PRD and hybrid PRD sub-iterations through the real collectives: two processes on one GPU ---------------------------
+def _gpu_prd_worker(rank, world, port, out, hybrid):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lightweaver_amd.context import Context
+        from oracle import bindings
+        from test_hprd import hprd_problem
+        prob = hprd_problem()
+        bounds = shard_bounds(prob, world)
+        la0, la1 = bounds[rank], bounds[rank + 1]
+        tables = None
+        if hybrid:
+            oc = bindings.OracleContext(prob.copy())
+            tables = oc.build_hprd()
+        with Context(prob, device=0, laStart=la0, laEnd=la1, worldSize=world, worldRank=rank, hprd=tables) as ctx:
+            it = ShardedIteration(ctx, world, rank)
+            ups = []
+            for _ in range(2):
+                it.formal_sol_gamma_matrices(deviceResident=True)
+                ups.append(it.prd_redistribute(2, 1e-30))
+            ctx.download(abi.J | abi.RATES | abi.RHOPRD)
+        lines = [t for a in prob.atoms for t in a.trans if t.rhoPrd is not None]
+        np.savez(os.path.join(out, f'gprd{rank}.npz'), J=prob.J[la0:la1], la=[la0, la1],
+                 R=np.stack([t.Rij for t in lines]), dRho=np.concatenate([u.dRho.ravel() for u in ups]),
+                 **{f'rho{q}': t.rhoPrd for q, t in enumerate(lines)})
+        if tables is not None:
+            tables.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hybrid', [False, True])
+def test_two_process_gloo_prd_on_one_gpu(gpu, tmp_path, hybrid):
+    """ShardedIteration.prd_redistribute with the real kernels and real (gloo) collectives: two processes, each a
+    wavelength shard on the same GPU -- angle-averaged PRD, and hybrid PRD (round 4: rho of the lines' whole grids on every
+    rank, the ranks' partial JRest sums in the all-reduce of the gather buffer) -- against the unsharded device run."""
+    from lightweaver_amd.context import Context
+    from oracle import bindings
+    from test_hprd import hprd_problem
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_gpu_prd_worker, args=(world, port, str(tmp_path), hybrid), nprocs=world, join=True)
+    prob = hprd_problem()
+    tables = None
+    if hybrid:
+        oc = bindings.OracleContext(prob.copy())
+        tables = oc.build_hprd()
+    ups = []
+    with Context(prob, hprd=tables) as ctx:
+        for _ in range(2):
+            ctx.formal_sol_gamma_matrices(deviceResident=True)
+            ups.append(ctx.prd_redistribute(2, 1e-30, deviceResident=True))
+        ctx.download(abi.J | abi.RATES | abi.RHOPRD)
+    if tables is not None:
+        tables.close()
+    lines = [t for a in prob.atoms for t in a.trans if t.rhoPrd is not None]
+    for rank in range(world):
+        z = np.load(tmp_path / f'gprd{rank}.npz')
+        la0, la1 = z['la']
+        assert rel_err(z['J'], prob.J[la0:la1]) <= 1e-9
+        assert rel_err(z['R'], np.stack([t.Rij for t in lines])) <= 1e-9
+        assert np.allclose(z['dRho'], np.concatenate([u.dRho.ravel() for u in ups]), rtol=1e-6)
+        for q, t in enumerate(lines):
+            if hybrid:                   # the whole grid on every rank
+                assert rel_err(z[f'rho{q}'], t.rhoPrd) <= 1e-9
+            else:                        # the shard's rows
+                lo, hi = max(la0 - t.Nblue, 0), max(min(la1, t.Nred) - t.Nblue, 0)
+                assert rel_err(z[f'rho{q}'][lo:hi], t.rhoPrd[lo:hi]) <= 1e-9
