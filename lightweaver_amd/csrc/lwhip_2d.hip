@@ -671,7 +671,9 @@ hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, int maxM, int maxP, hi
     const dim3 grid((a.Ns + 127) / 128, a.nGroups);
     const size_t lds = (size_t)std::max(a.maxRowsLa, 1) * 128 * sizeof(double) + 64 * (sizeof(double) + sizeof(int))
                        + (size_t)((maxL <= 2 ? 2 : (maxL <= 4 ? 4 : 8)) + 4 + 8) * sizeof(DevSlot);
-    if (maxL <= 2 && maxM <= 2 && maxP <= 5)
+    if (maxL <= 2 && maxM <= 1 && maxP <= 5)
+        hipLaunchKernelGGL((rates2d_kernel<2, 1, 5>), grid, dim3(128), lds, stream, a);
+    else if (maxL <= 2 && maxM <= 2 && maxP <= 5)
         hipLaunchKernelGGL((rates2d_kernel<2, 2, 5>), grid, dim3(128), lds, stream, a);
     else if (maxL <= 2)
         hipLaunchKernelGGL((rates2d_kernel<2, 4, 8>), grid, dim3(128), lds, stream, a);
