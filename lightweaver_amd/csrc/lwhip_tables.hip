@@ -1130,12 +1130,19 @@ int build_tables(lwhip_context* c)
                 std::vector<char> cut(nch0, 0);
                 if (nch0 > slotsWg)
                 {
-                    // the first `keep` chunks of the dispatch order stay whole; as many of the rest are cut in two as fill the
-                    // launch's last round of workgroup slots exactly: whole + 2 cut = rounds x slots (measured at 10 240
-                    // wavelengths, 857 chunks on 512 slots: keep 512 / 600 / 700 / 780 / all -> 0.152 / 0.150 / 0.139 / 0.148 /
-                    // 0.155 ms; the rule gives 690)
+                    // the first `keep` chunks of the cost order stay whole, the lightest numCU / 2 are cut in two: one pair of
+                    // half-length workgroups per compute unit to even out the end of the launch.  (Until late in round 4 the rule
+                    // was "as many as fill the last round of slots exactly", whole + 2 cut = rounds x slots; a sweep over sizes
+                    // and counts -- tools/keep_rule_exp.sh, profiles/r04_tail_rule.md -- showed a spiky landscape in which that
+                    // was rarely the minimum: cutting 128 chunks is 3-9 % faster at 6 656 ... 12 288 wavelengths, 3 % at the bench
+                    // size, 3 % slower at 11 264.)
+                    // (... and where the last round has room for fewer pairs than that but for some -- 11 264: 85 -- only as many)
                     const int rounds = (nch0 + slotsWg - 1) / slotsWg;
-                    const int keepAuto = std::max(0, std::min(nch0, 2 * nch0 - rounds * slotsWg));
+                    const int room = rounds * slotsWg - nch0;
+                    int nCut = std::max(1, numCU / 2);
+                    if (room >= numCU / 8 && room < nCut)
+                        nCut = room;
+                    const int keepAuto = std::max(0, nch0 - nCut);
                     const int keep = std::min(nch0, std::max(0, env_int("LWHIP_LANE_KEEP", tailS == 2 ? keepAuto : slotsWg)));
                     for (int q = keep; q < nch0; ++q)
                         cut[ord[q]] = 1;
