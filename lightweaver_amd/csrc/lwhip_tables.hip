@@ -1083,9 +1083,11 @@ int build_tables(lwhip_context* c)
             if (!c->deterministic && c->batchHint <= 1 && W == 4)
             {
                 const long slots = 2L * 4 * numCU;
-                // (measured, tools/split_exp.sh: S = 2 wins while it fits; S = 4 has the same kernel time at 1 280 wavelengths
-                // and a longer step -- four times the workgroups flushing their sums)
-                c->laneSplit = 2L * c->nTiles <= slots ? 2 : 1;
+                // (measured, tools/split_exp.sh: S = 2 wins while it fits.  S = 4 while IT fits: in round 3 it had the same kernel
+                // time at 1 280 wavelengths and a longer step -- four times the workgroups flushing their sums --; with the
+                // round-4 kernel (moments, own pre-pass) it is 0.048 against 0.059 ms there, the step 0.059 against 0.074)
+                // (a launch that S = 4 fills to the brim -- 1 536 wavelengths, 2 048 wavefronts -- is no faster than with S = 2)
+                c->laneSplit = 4L * c->nTiles <= slots * 9 / 10 ? 4 : 2L * c->nTiles <= slots ? 2 : 1;
                 const int forced = env_int("LWHIP_LANE_SPLIT", 0);
                 if (forced == 1 || forced == 2 || forced == 4)
                     c->laneSplit = forced;
@@ -1093,7 +1095,7 @@ int build_tables(lwhip_context* c)
             tgtSweep = (c->nTiles * c->laneSplit + W - 1) / W; // one tile per group of wavefronts
             c->laneSplitPrd = c->laneSplit;
             if (!c->deterministic && c->batchHint <= 1 && W == 4 && !tileListPrd.empty() && env_int("LWHIP_LANE_SPLIT", 0) == 0)
-                c->laneSplitPrd = 2L * (long)tileListPrd.size() <= 2L * 4 * numCU ? 2 : 1;
+                c->laneSplitPrd = 4L * (long)tileListPrd.size() <= 2L * 4 * numCU * 9 / 10 ? 4 : 2L * (long)tileListPrd.size() <= 2L * 4 * numCU ? 2 : 1;
         }
         // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
         const size_t ldsPostEst = sizeof(double) * ((size_t)7 * 4 * Ns + (size_t)(c->Natom + 2 * c->NlevTot) * 128);
