@@ -1160,6 +1160,7 @@ int build_tables(lwhip_context* c)
                     int k = std::min(nch0, std::max(0, (slotsWg - nch0) / extra));
                     if (tailS == 2 && nch0 * 100 > slotsWg * fullPct)
                         k = nch0;
+                    k = std::min(nch0, std::max(0, env_int("LWHIP_LANE_ONE_CUT", k))); // (experiments: the number of chunks cut)
                     for (int q = 0; q < k; ++q)
                         cut[ord[q]] = 1;
                 }
