@@ -172,7 +172,13 @@ hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream, const Redu
 // (SimdFullIterationTemplates.hpp:491-508), Rij/Rji out ----------------------------------------------------
 // One block per (atom, slab of APPLY_K depth points): thread (e, kk) owns Gamma entry e = to*Nl+from
 // at depth k; the extra block column x == Natom copies Rij/Rji.
-enum { APPLY_K = 16, APPLY_K_WIDE = 64 }; // depth points per workgroup: 16 (a 1D column's 82 points spread over 6 workgroups per
+#ifndef APPLY_K_1D
+#define APPLY_K_1D 8 // (at the bench size, tools/apply_abl.sh: 4 -> 15.8 us, 8 -> 11.0, 16 -> 11.8, 32 -> 14.6; 512 / 320 / 256 threads: no better)
+#endif
+#ifndef APPLY_T
+#define APPLY_T 1024
+#endif
+enum { APPLY_K = APPLY_K_1D, APPLY_K_WIDE = 64 }; // depth points per workgroup: 8 (a 1D column's 82 points spread over 11 workgroups per
                                            // atom), 64 for the tens of thousands of points of a 2D domain (whole 512-byte rows per wavefront)
 template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
 {
@@ -328,7 +334,7 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
 }
 
 template <bool BATCH, int K = APPLY_K>
-__global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a0, const ApplyArgs* __restrict__ list)
+__global__ void __launch_bounds__(APPLY_T) apply_kernel(const ApplyArgs a0, const ApplyArgs* __restrict__ list)
 {
     dbg_poison_lds();
     if constexpr (BATCH)
@@ -340,13 +346,13 @@ __global__ void __launch_bounds__(1024) apply_kernel(const ApplyArgs a0, const A
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list, int nBatch)
 {
     if (list)
-        hipLaunchKernelGGL(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(1024), 0,
+        hipLaunchKernelGGL(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(APPLY_T), 0,
                            stream, a, list);
     else if (a.Ns >= 2048)
         hipLaunchKernelGGL((apply_kernel<false, APPLY_K_WIDE>), dim3(a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0), (a.Ns + APPLY_K_WIDE - 1) / APPLY_K_WIDE),
-                           dim3(1024), 0, stream, a, list);
+                           dim3(APPLY_T), 0, stream, a, list);
     else
-        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0), (a.Ns + APPLY_K - 1) / APPLY_K), dim3(1024), 0,
+        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0), (a.Ns + APPLY_K - 1) / APPLY_K), dim3(APPLY_T), 0,
                            stream, a, list);
     return hipGetLastError();
 }

@@ -2,7 +2,7 @@
 # apply_kernel's duration (rocprofv3 average) under the ablation builds AP_ABL_* of lwhip_kernels.hip (wrong results on purpose)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for v in base apng apnd apnr apnone; do
+for v in ${@:-base apng apnd apnr apnone}; do
   if [ "$v" = base ]; then unset LWHIP_LIB; else export LWHIP_LIB=$R/lightweaver_amd/variants/liblwhip_$v.so; fi
   rm -rf /tmp/ap_st
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ap_st -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-aux > /tmp/ap_b.json 2>/dev/null
