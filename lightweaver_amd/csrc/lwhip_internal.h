@@ -358,7 +358,13 @@ size_t det_reduce_scratch_doubles(int Ns, int Ntrans); // `part`: the partial su
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
 hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostList, int n, hipStream_t stream);
 
-enum { LWHIP_REDUCE_SPLIT = 8 };
+// parts of a transition's sums in the stage-1 buffer (a workgroup adds to part chunk % SPLIT): contention of the sweep's atomics
+// against the loads of whoever sums the parts.  Measured at the bench size (round 4): the sweep is the same with 2, 4, 8 and 16 parts
+// (0.122 ms), apply_kernel takes 9.0 / 9.5 / 11.2 / 13.9 us
+#ifndef LWHIP_REDUCE_SPLIT_N
+#define LWHIP_REDUCE_SPLIT_N 4
+#endif
+enum { LWHIP_REDUCE_SPLIT = LWHIP_REDUCE_SPLIT_N };
 struct ReduceArgs
 {
     int32_t Ns, Ntrans;
