@@ -285,6 +285,10 @@ int lwhip_download(lwhip_context* ctx, uint32_t mask);
  * the host before calling the core (Source/LwMiddleLayer.pyx:3198-3203). */
 int lwhip_gamma_prefill_from_C(lwhip_context* ctx, double crsw);
 
+/* lwhip_gamma_prefill_from_C(crsw) followed by lwhip_formal_sol_gamma_matrices in one call: the device-resident iteration of
+ * LwContext.formal_sol_gamma_matrices (Source/LwMiddleLayer.pyx:3152-3210: Gamma <- crsw C, then the scheme's fs_iter). */
+int lwhip_iterate_from_C(lwhip_context* ctx, int lambdaIterate, double crsw, lwhip_iter_result* res);
+
 /* One formal_sol_gamma_matrices iteration over the context's wavelength shard:
  * J, I overwritten, Rij/Rji fresh integrals, Gamma += radiative terms, diagonal finalised.
  * Pre-condition (as in the reference): Gamma holds the collisional pre-fill.

@@ -155,6 +155,7 @@ SYMBOLS = [
     ('lwhip_upload', C.c_int, [ctx_p, C.c_uint32]),
     ('lwhip_download', C.c_int, [ctx_p, C.c_uint32]),
     ('lwhip_gamma_prefill_from_C', C.c_int, [ctx_p, C.c_double]),
+    ('lwhip_iterate_from_C', C.c_int, [ctx_p, C.c_int, C.c_double, C.POINTER(lwhip_iter_result)]),
     ('lwhip_formal_sol_gamma_matrices', C.c_int, [ctx_p, C.c_int, C.POINTER(lwhip_iter_result)]),
     ('lwhip_fs_partial', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_fs_finalise', C.c_int, [ctx_p, C.POINTER(lwhip_iter_result)]),

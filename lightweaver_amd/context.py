@@ -122,6 +122,8 @@ class Context:
             st = self.lib.lwhip_create(C.byref(self._desc), C.byref(opts), C.byref(h))
         _check(self.lib, st, 'lwhip_create')
         self._h = h
+        self._res = abi.lwhip_iter_result()
+        self._res_ref = C.byref(self._res)
         self.laStart = laStart
         self.laEnd = laEnd if laEnd else prob.Nlambda
         self.crsw = 1.0
@@ -194,6 +196,14 @@ class Context:
         `download()` when the host needs them).  Collisional rates are an input here
         (`fixCollisionalRates` is accepted for signature parity; the harness never recomputes C)."""
         lib = self.lib
+        if deviceResident and sync_host:
+            # (one ABI call and a reused result record: every microsecond between the previous result and this launch is a
+            # microsecond the device idles)
+            res = self._res
+            st = lib.lwhip_iterate_from_C(self._h, int(lambdaIterate), self.crsw, self._res_ref)
+            if st != abi.OK:
+                _check(lib, st, 'lwhip_iterate_from_C')
+            return IterationUpdate(updatedJ=True, dJMax=res.dJMax, dJMaxIdx=res.dJMaxIdx, crsw=self.crsw)
         if deviceResident:
             _check(lib, lib.lwhip_gamma_prefill_from_C(self._h, self.crsw), 'lwhip_gamma_prefill_from_C')
         else:

@@ -504,6 +504,17 @@ int lwhip_formal_sol_gamma_matrices(lwhip_context* c, int lambdaIterate, lwhip_i
     return lwhip_fs_finalise(c, res);
 }
 
+// the device-resident iteration in one call: lwhip_gamma_prefill_from_C + lwhip_formal_sol_gamma_matrices (a caller that
+// iterates from Python pays a microsecond or two per ABI call, and the device idles while it does)
+int lwhip_iterate_from_C(lwhip_context* c, int lambdaIterate, double crsw, lwhip_iter_result* res)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    c->prefillPending = true;
+    c->prefillCrsw = crsw;
+    return lwhip_formal_sol_gamma_matrices(c, lambdaIterate, res);
+}
+
 int lwhip_reduce_buffer(lwhip_context* c, void** devPtr, size_t* nSum, size_t* nGather)
 {
     if (!c || !devPtr || !nSum || !nGather)
