@@ -25,6 +25,7 @@
 // SimdFullIterationTemplates.hpp:238-487, chi_eta_aux_accum :59-109, compute_full_operator_rates :192-234,
 // piecewise_bezier3_1d FormalScalar.cpp:209-325, Bezier.hpp:58-127, w2 LwInternal.hpp:90-110.
 #include "lwhip_device.h"
+#include <atomic>
 #include "../../include/lwhip.h"
 
 #include <algorithm>
@@ -2488,11 +2489,21 @@ hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn
     const size_t lds = lane_sweep_lds_bytes(a, waves);
     if (lds > 48 * 1024)
     {
-        hipError_t e = hipFuncSetAttribute(apList ? (const void*)lanesweep_kernel<SOLVER, D, MODE, true>
-                                                  : (const void*)lanesweep_kernel<SOLVER, D, MODE, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
+        // (once per kernel instance, device and size: the call is a driver round trip of a microsecond or two in front of
+        // EVERY launch otherwise, while the device idles between two iterations)
+        static std::atomic<size_t> granted[2][16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t>& g = granted[apList ? 1 : 0][dev & 15];
+        if (g.load(std::memory_order_relaxed) < lds)
+        {
+            hipError_t e = hipFuncSetAttribute(apList ? (const void*)lanesweep_kernel<SOLVER, D, MODE, true>
+                                                      : (const void*)lanesweep_kernel<SOLVER, D, MODE, false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return e;
+            g.store(lds, std::memory_order_relaxed);
+        }
     }
     if (apList)
         hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, MODE, true>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds, stream,
