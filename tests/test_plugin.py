@@ -90,7 +90,7 @@ def test_dropin_resident_J(gpu, monkeypatch):
     res.formal_sol_gamma_matrices()             # the device's J comes down before this call uploads anything
     res.stat_equil()
     # (Gamma is summed by atomics, so the populations -- and through them the later iterations' J -- agree to the last bits only)
-    assert rel_err(p.J, q.J) <= 1e-10 and rel_err(p.I, q.I) <= 1e-10
+    assert rel_err(p.J, q.J) <= 1e-9 and rel_err(p.I, q.I) <= 1e-9  # (4e-11 / 1e-10 seen: the populations' noise, below)
     for a, b in zip(p.atoms, q.atoms):
         assert rel_err(a.n, b.n) <= 1e-9        # (the solve amplifies Gamma's last-bit noise: 1.4e-10 seen)
 
