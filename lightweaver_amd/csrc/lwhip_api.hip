@@ -69,6 +69,7 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(LWHIP_ERR_DEVICE, "lwhip_create: no HIP device visible (this library has no CPU path)");
 
+    DevBuf<double>::alloc_seq() = 0; // (diagnosis: allocations are numbered per context)
     auto c = new lwhip_context();
     c->prob = *prob;
     c->atoms.assign(prob->atoms, prob->atoms + prob->Natom);

@@ -28,6 +28,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace lwhip
@@ -61,6 +62,16 @@ template <typename T> struct DevBuf
         if (count == 0)
             return hipSuccess;
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        // diagnosis: LWHIP_CLEAR_FROM / LWHIP_CLEAR_TO restrict the clearing to the allocations numbered [from, to) of each
+        // context (lwhip_create restarts the count; LWHIP_TRACE_ALLOC prints the numbers) -- how the read was narrowed down
+        static const int clearFrom = std::getenv("LWHIP_CLEAR_FROM") ? std::atoi(std::getenv("LWHIP_CLEAR_FROM")) : 0;
+        static const int clearTo = std::getenv("LWHIP_CLEAR_TO") ? std::atoi(std::getenv("LWHIP_CLEAR_TO")) : 1 << 30;
+        static const bool noClear = std::getenv("LWHIP_NO_CLEAR") != nullptr; // (diagnosis: the behaviour before the fix)
+        if (noClear)
+            clear = false;
+        const int seq = alloc_seq()++;
+        if (clear && std::is_same<T, double>::value && (seq < clearFrom || seq >= clearTo)) // (the fp64 buffers are numbered)
+            clear = false;
         if (e == hipSuccess && clear && !poison_on())
         {
             e = hipMemset(p, 0, count * sizeof(T));
@@ -73,8 +84,14 @@ template <typename T> struct DevBuf
             e = hipMemset(p, 0xFF, count * sizeof(T));
         static const bool trace = std::getenv("LWHIP_TRACE_ALLOC") != nullptr; // diagnosis: which buffer a faulting address follows
         if (trace)
-            std::fprintf(stderr, "lwhip alloc %p .. %p (%zu x %zu B)\n", (void*)p, (void*)((char*)p + count * sizeof(T)), count, sizeof(T));
+            std::fprintf(stderr, "lwhip alloc #%d %p .. %p (%zu x %zu B)%s\n", seq, (void*)p, (void*)((char*)p + count * sizeof(T)), count, sizeof(T),
+                         clear ? " cleared" : "");
         return e;
+    }
+    static int& alloc_seq()
+    {
+        static int seq = 0;
+        return seq;
     }
     static bool poison_on()
     {
