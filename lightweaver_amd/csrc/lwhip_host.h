@@ -70,7 +70,9 @@ template <typename T> struct DevBuf
         if (noClear)
             clear = false;
         const int seq = alloc_seq()++;
-        if (clear && std::is_same<T, double>::value && (seq < clearFrom || seq >= clearTo)) // (the fp64 buffers are numbered)
+        static const int skipFrom = std::getenv("LWHIP_CLEAR_SKIP_FROM") ? std::atoi(std::getenv("LWHIP_CLEAR_SKIP_FROM")) : 0;
+        static const int skipTo = std::getenv("LWHIP_CLEAR_SKIP_TO") ? std::atoi(std::getenv("LWHIP_CLEAR_SKIP_TO")) : 0;
+        if (clear && std::is_same<T, double>::value && (seq < clearFrom || seq >= clearTo || (seq >= skipFrom && seq < skipTo))) // (the fp64 buffers are numbered)
             clear = false;
         if (e == hipSuccess && clear && !poison_on())
         {
