@@ -5,7 +5,8 @@ order (non-PRD problem under split factors 2, 2, 1, then the PRD problem under 2
 holds every PRD run to the one-call bound, run to run and against the oracle.  With `tools/parity_stress.sh` the whole suite,
 this file included, runs in seeded random orders under the poison builds (NaN-filled device allocations on malloc and on free,
 NaN-filled LDS at the start of every workgroup, a device-side check that the stage-1 reduce buffer holds zeros when a sweep
-starts): profiles/r04_parity_stress.md holds the log.
+starts): profiles/r04_parity_stress.md holds the log.  (End of round 4: the deviation was reproduced by plain in-order runs of
+tests/test_hip_parity.py and traced to never-written device memory; allocations are cleared now -- DESIGN section 0.)
 """
 import numpy as np
 import pytest
