@@ -191,10 +191,10 @@ def test_lane_sweep_ray_split_vs_oracle(gpu, monkeypatch, split, prd):
     if prd:
         # (rho of a PRD sub-iteration is formed from the atomically summed rates, so the J of its rates pass varies in the
         # last bits from run to run; LWHIP_OPT_DETERMINISTIC removes that)
-        compare_problems(a, b, tol=1e-11, what=('J', 'I'))
+        compare_problems(a, b, tol=1e-10, what=('J', 'I'))   # (1.8e-11 seen in I, 3 of 80 in-order runs)
     else:
         assert np.array_equal(a.J, b.J) and np.array_equal(a.I, b.I)
-    compare_problems(a, runs[1][-1], tol=1e-11 if prd else 1e-12, what=('J', 'I'))
+    compare_problems(a, runs[1][-1], tol=1e-10 if prd else 1e-12, what=('J', 'I'))
     q = prob.copy()
     q.gamma_prefill()
     oc = OracleContext(q)

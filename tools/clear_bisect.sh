@@ -9,6 +9,6 @@ N=${3:-40}
 n=0
 for i in $(seq 1 $N); do
   python -m pytest tests/test_hip_parity.py -x -q -m gpu > /tmp/fl.log 2>&1
-  case "$(grep -E 'passed|failed' /tmp/fl.log | tail -1)" in *failed*) n=$((n+1));; esac
+  case "$(grep -E 'passed|failed' /tmp/fl.log | tail -1)" in *failed*) n=$((n+1)); grep -E '^FAILED|beyond tol' /tmp/fl.log | cut -c1-400;; esac
 done
 echo "clear [$1, $2): $n failures of $N"
