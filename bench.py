@@ -9,7 +9,8 @@ one full iteration (Gamma pre-fill from C on the device, sweep over all waveleng
 J / I / Gamma / rates updated, Gamma finalised, dJMax returned to the host), inputs resident in
 HBM when the timed region starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): wavelengths are sharded contiguously; each
+N > 1 (one rank per GPU under torch.distributed.run; called WITHOUT a launcher, `python bench.py --gpus N` starts the ranks
+itself as child processes before it touches the GPU): wavelengths are sharded contiguously; each
 iteration does ONE all-reduce (RCCL) of the concatenated Gamma / Rij / Rji partial sums with every
 rank's (dJMax, idx) riding in its tail.
   --scaling weak   (default) the global grid has N x 10 240 wavelengths: per-GPU work is fixed as N grows;
@@ -36,6 +37,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-matrix) peak, same guide
+# What the part actually issues (tools/micro/issue_bench.hip, profiles/r04_lanesweep.md section 1): one fp64 FMA per 8.5 clocks per
+# SIMD with two resident wavefronts (the lane sweep's occupancy: 256 VGPRs), 6.9 with four -- against the data sheet's 4
+FP64_ATTAINABLE_TFLOPS = {'two_waves_per_simd': FP64_VECTOR_PEAK_TFLOPS * 4.0 / 8.5, 'four_waves_per_simd': FP64_VECTOR_PEAK_TFLOPS * 4.0 / 6.9}
 PARITY_TOL = 1e-9       # relative, element-wise, one call on identical inputs
 
 
@@ -319,14 +323,38 @@ def aux_2d(args, device, stream, torch, models):
 AUX = {'prd': ('C3_prd', aux_prd), 'columns': ('C4_columns', aux_columns), '2d': ('C5_2d', aux_2d)}
 
 
+def rank_launch_command(ngpus, argv, port=None):
+    """`python bench.py --gpus N` called without a launcher: the command that starts the N ranks (one per GPU) as fresh
+    child processes under torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ngpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """Spawns the ranks and passes rank 0's JSON line and the job's exit code on.  Nothing in THIS process has touched the GPU
+    (no torch import, no HIP call): the ranks are children, never a re-exec of a process that initialised the device."""
+    import subprocess
+    cmd = rank_launch_command(args.gpus, sys.argv[1:])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # (dmabuf IPC: what RCCL needs on this driver)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // max(args.gpus, 1))))
+    proc = subprocess.run(cmd, env=env, cwd=ROOT)
+    sys.exit(proc.returncode)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        if world == 1 and args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+            self_launch(args)
         args.gpus = world
 
     import numpy as np
@@ -501,6 +529,13 @@ def main():
                     'unit': 'TFLOP/s',
                     'frac': (alg_flops / (sweep_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if sweep_ms > 0 else 0.0,
                     'algorithmic_flops_per_launch': alg_flops,
+                    # the measured issue ceiling of the part at the kernel's occupancy (not the data-sheet peak)
+                    'attainable': FP64_ATTAINABLE_TFLOPS['two_waves_per_simd'],
+                    'attainable_four_waves': FP64_ATTAINABLE_TFLOPS['four_waves_per_simd'],
+                    'frac_of_attainable': (alg_flops / (sweep_ms * 1e-3) / 1e12 / FP64_ATTAINABLE_TFLOPS['two_waves_per_simd'])
+                    if sweep_ms > 0 else 0.0,
+                    'attainable_source': 'tools/micro/issue_bench.hip: one fp64 FMA per 8.5 / 6.9 clocks per SIMD at 2 / 4 '
+                                         'wavefronts per SIMD (profiles/r04_lanesweep.md)',
                 },
             },
         }

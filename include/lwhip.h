@@ -74,7 +74,8 @@ enum {
     LWHIP_ERR_INVALID = 1,      /* bad descriptor / argument                       */
     LWHIP_ERR_UNSUPPORTED = 2,  /* valid in the reference, not built here (stated)   */
     LWHIP_ERR_DEVICE = 3,       /* HIP runtime failure or no gfx950 device          */
-    LWHIP_ERR_SINGULAR = 4      /* "Singular Matrix" of Source/LuSolve.cpp:22-23       */
+    LWHIP_ERR_SINGULAR = 4,     /* "Singular Matrix" of Source/LuSolve.cpp:22-23       */
+    LWHIP_ERR_BUSY = 5          /* lwhip_destroy of a context whose tables are still borrowed (lwhip_create_like) */
 };
 
 /* array groups for lwhip_upload / lwhip_download (bit mask) */
@@ -269,7 +270,7 @@ int lwhip_create(const lwhip_problem* prob, const lwhip_options* opts, lwhip_con
  * `like`'s structure tables (per-wavelength activity tables, tile / workgroup / ray records: a few MB and half of the
  * creation time per context) instead of building device copies of its own.  The structures are compared by a fingerprint:
  * LWHIP_ERR_INVALID if they differ.  `like` cannot be destroyed before its borrowers (lwhip_destroy fails with
- * LWHIP_ERR_INVALID and leaves it intact).  No counterpart in the reference: every Context owns its tables
+ * LWHIP_ERR_BUSY and leaves it intact).  No counterpart in the reference: every Context owns its tables
  * (update_deps, Source/LwMiddleLayer.pyx:3244-3288). */
 int lwhip_create_like(const lwhip_problem* prob, const lwhip_options* opts, lwhip_context* like, lwhip_context** out);
 

@@ -17,7 +17,7 @@ FS_NAMES = {
     'piecewise_besser_1d': FS_BESSER_1D,
     'piecewise_bezier3_1d': FS_BEZIER3_1D,
 }
-OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_SINGULAR = range(5)
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_SINGULAR, ERR_BUSY = range(6)
 
 ATMOS = 1 << 0
 BACKGROUND = 1 << 1

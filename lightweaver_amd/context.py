@@ -132,9 +132,12 @@ class Context:
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, '_h', None):
-            if self.lib.lwhip_destroy(self._h) != abi.OK:
+            st = self.lib.lwhip_destroy(self._h)
+            if st == abi.ERR_BUSY:
                 self._pending = True   # contexts made with like=self still use its tables: the last of them closes it
                 return
+            if st != abi.OK:
+                _check(self.lib, st, 'lwhip_destroy')
             self._h = None
             like, self._like = getattr(self, '_like', None), None
             if like is not None and like._pending:

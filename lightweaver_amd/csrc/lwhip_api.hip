@@ -185,7 +185,7 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
         std::fprintf(stderr, "lwhip_create: lane sweep LDS per workgroup: accumulators %zu B + depth arena %zu B + per-wave blocks = %zu B\n",
                      sizeof(double) * (size_t)c->maxCTTile * 4 * (c->laneLR * c->laneD), (size_t)c->depArena.n * sizeof(double),
                      sizeof(double) * ((size_t)c->maxCTTile * 4 * (c->laneLR * c->laneD) + (size_t)c->tileWaves * 16 * 5 + 32
-                                       + (size_t)c->tileWaves * 3 * 64 * c->laneD + (size_t)c->tileWaves * LWHIP_POST_MAXC * c->laneR * 3)
+                                       + (size_t)c->tileWaves * 3 * 64 * c->laneD + (size_t)c->tileWaves * std::min(c->maxC, (int)LWHIP_POST_MAXC) * c->laneR * 3)
                          + (size_t)c->depArena.n * sizeof(double));
     *out = c;
     return LWHIP_OK;
@@ -195,8 +195,8 @@ int lwhip_destroy(lwhip_context* c)
 {
     if (!c)
         return LWHIP_OK;
-    if (c->borrowers > 0)
-        return fail(LWHIP_ERR_INVALID, "lwhip_destroy: " + std::to_string(c->borrowers)
+    if (c->borrowers.load() > 0)
+        return fail(LWHIP_ERR_BUSY, "lwhip_destroy: " + std::to_string(c->borrowers.load())
                                            + " context(s) made with lwhip_create_like still use this context's tables");
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -249,7 +249,7 @@ int lwhip_destroy(lwhip_context* c)
                              kv.first % 10, (int)kv.second[0], kv.second[1] / kv.second[0], kv.second[2]);
         }
         {
-            double w[3] = { 0, 0, 0 };
+            double w[4] = { 0, 0, 0, 0 }, wmax = 0.0;
             int nw = 0;
             for (int b = 0; b < 4 * c->nTiles; ++b)
             {
@@ -257,13 +257,15 @@ int lwhip_destroy(lwhip_context* c)
                 if (o[1] > 0.0)
                 {
                     ++nw;
-                    for (int q = 0; q < 3; ++q)
+                    for (int q = 0; q < 4; ++q)
                         w[q] += o[q];
+                    wmax = std::max(wmax, o[3]);
                 }
             }
             if (nw)
-                std::fprintf(stderr, "lane sweep workgroup clocks (mean over %d workgroups): prologue %.0f tasks %.0f epilogue %.0f\n", nw, w[0] / nw,
-                             w[1] / nw, w[2] / nw);
+                std::fprintf(stderr, "lane sweep workgroup clocks (mean over %d workgroups): prologue %.0f tasks %.0f epilogue %.0f; fixed-order mode: "
+                                     "clocks between a wavefront's leaving its first turn wait and its handing the turn on (line / mixed slots), summed over the workgroup, mean %.0f max %.0f\n",
+                             nw, w[0] / nw, w[1] / nw, w[2] / nw, w[3] / nw, wmax);
         }
         std::fprintf(stderr, "lane sweep phase clocks per tile (mean): setup %.0f gather %.0f stencils %.0f coefficients %.0f scan %.0f rates %.0f finish %.0f total %.0f (max %.0f) over %d tiles\n",
                      sum[0] / c->nTiles, sum[1] / c->nTiles, sum[2] / c->nTiles, sum[3] / c->nTiles, sum[4] / c->nTiles, sum[5] / c->nTiles,

@@ -187,7 +187,11 @@ int lwhip_prd_partial(lwhip_context* c)
         HIP_TRY(hipMemcpyAsync(c->prdArgsDev.p, c->prdArgsHost.data(), (size_t)Nprd * sizeof(PrdLineArgs), hipMemcpyHostToDevice,
                                c->stream));
     }
-    HIP_TRY(launch_prd_scatter(c->prdArgsDev.p, lineArgs.data(), Nprd, c->stream));
+    // one device, 1D: the per-line maxima of |d rho / rho| are reduced by the apply launch of lwhip_prd_finalise, which also
+    // sums the stage-1 parts itself -- a sub-iteration is scatter -> rates pass -> apply (round 4: six launches)
+    const bool fused = c->worldSize == 1 && !c->is2d && !c->deterministic;
+    HIP_TRY(launch_prd_scatter(c->prdArgsDev.p, lineArgs.data(), Nprd, c->stream, !fused));
+    c->prdFused = fused;
     if (c->is2d)
     {
         // the same rates pass through the 2D pipeline, restricted to the runs of PRD wavelengths
@@ -208,9 +212,12 @@ int lwhip_prd_partial(lwhip_context* c)
     if (!c->red8Clean)
         HIP_TRY(hipMemsetAsync(c->red8.p, 0, c->red8.n * sizeof(double), c->stream));
     HIP_TRY(run_sweep(c, dyn, true));
-    ReduceArgs r = make_reduce_args(c);
-    r.zeroParts = 1;
-    HIP_TRY(launch_reduce_sum(r, c->stream));
+    if (!fused)
+    {
+        ReduceArgs r = make_reduce_args(c);
+        r.zeroParts = 1;
+        HIP_TRY(launch_reduce_sum(r, c->stream));
+    }
     c->red8Clean = true;
     c->prdPending = true;
     return LWHIP_OK;
@@ -244,7 +251,22 @@ int lwhip_prd_finalise(lwhip_context* c, double* dRho, int32_t* dRhoMaxIdx, doub
     ap.Cmat = c->Cmat.p;
     ap.prdOnly = 1;
     ap.prdDetailed = c->prdDetailed ? 1 : 0;
+    if (c->prdFused)
+    {
+        // the sums straight from the stage-1 parts (zeroed as they are read), dJMax of the pass and the lines' changes in
+        // extra workgroups of this launch
+        ap.fromParts = 1;
+        ap.zeroParts = 1;
+        ap.red8 = c->red8.p;
+        ap.dJ = c->dJ.p;
+        ap.NlaDj = c->Nla;
+        ap.idxOffset = c->laStart;
+        ap.tail = c->red.p + (size_t)c->Ntrans * 4 * Ns;
+        ap.prdList = c->prdArgsDev.p;
+        ap.nPrdChange = Nprd;
+    }
     HIP_TRY(launch_apply(ap, c->stream));
+    c->prdFused = false;
     c->prdPending = false;
     const size_t nTail = 2 * (size_t)c->worldSize * (1 + Nprd);
     if (!c->prdPinned)

@@ -292,4 +292,49 @@ DEVINL void affine_scan_wave(double& E, double& B)
     affine_scan_step<0x142, 0xa>(E, B); // row_bcast:15 into rows 1 and 3
     affine_scan_step<0x143, 0xc>(E, B); // row_bcast:31 into rows 2 and 3
 }
+// PRD: per line the max over (depth, slice) of the scattering integral's maxima of |d rho / rho| (lwhip_prd.hip), by ONE
+// wavefront: prd_change_kernel on shards, an extra workgroup of the apply launch on one device (lwhip_kernels.hip)
+DEVINL void prd_change_reduce(const PrdLineArgs& a, const int laneIn)
+{
+    const double* changeVal = a.changeVal;
+    const int* changeIdx = a.changeIdx;
+    const int nEntries = (a.laHi > a.laLo) ? a.Ns * a.slices : 0;
+    double* tail = a.tail;
+    const int world = a.world, rank = a.rank, q = a.q, Nprd = a.Nprd;
+    // one wavefront: max value, smallest flattened index on ties (max_idx semantics: strictly greater
+    // updates in index order, so the first occurrence wins; a zero maximum keeps idx 0).  The result
+    // goes into this shard's slot of the line in the reduce tail; the other shards' slots are zeroed
+    // (the all-reduce sums them).
+    const int lane = laneIn;
+    double best = 0.0;
+    int idx = 0x7fffffff;
+    for (int e = lane; e < nEntries; e += 64)
+    {
+        const double v = changeVal[e];
+        const int i = changeIdx[e];
+        if (i != 0x7fffffff && v > 0.0 && (v > best || (v == best && i < idx)))
+        {
+            best = v;
+            idx = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        const double v = __shfl_xor(best, off);
+        const int i = __shfl_xor(idx, off);
+        if (v > best || (v == best && i < idx))
+        {
+            best = v;
+            idx = i;
+        }
+    }
+    for (int rk = lane; rk < world; rk += 64)
+    {
+        double* slot = tail + ((size_t)rk * Nprd + q) * 2;
+        slot[0] = (rk == rank) ? best : 0.0;
+        slot[1] = (rk == rank && best > 0.0) ? (double)idx : 0.0;
+    }
+}
+
 }

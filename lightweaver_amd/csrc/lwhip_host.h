@@ -49,56 +49,152 @@ template <typename T> struct DevBuf
     T* p = nullptr;
     size_t n = 0;
     bool owned = true;
-    // Device memory is handed out CLEARED (round 4): a few pools are read a block of depths or a ray past what the uploads fill
-    // (padding lanes, one-ahead requests), and hipMalloc returns whatever the previous owner of the pages left -- another
-    // context's data, in a process that has made and destroyed contexts before.  One such read reached the rates: a deviation of
-    // 1.77e-6 in the Ca II rates of one test problem in ~1 of 8 processes that ran the test file in order (never under
-    // LWHIP_POISON: the NaN pattern is swallowed by a max / min on the way, and never with fresh pages, which hold zeros).  With
-    // zeros everywhere the result is the validated one, always.  `clear = false`: the caller overwrites all of it at once (upload).
-    hipError_t alloc(size_t count, bool clear = true)
+    uint64_t sig = 0; // content fingerprint of what upload() put there (see upload_or_borrow)
+    // What a fresh allocation holds.  Round 4 handed out CLEARED memory because some kernel read bytes no upload had written and
+    // hipMalloc returns whatever the pages' previous owner left there.  Round 5 located such reads with a FINITE sentinel
+    // (LWHIP_PAD_SENTINEL, below; NaN is swallowed by the fmin / fmax of the Steffen derivative, a finite 6.7e299 is not) and
+    // fixed them; what is left of the clearing is listed in DESIGN.md section 4.
+    //   alloc(count)         state buffer: every byte a kernel reads is written first by an upload or a kernel (asserted by the
+    //                        sentinel test); cleared all the same as a safety net unless LWHIP_NO_CLEAR is set
+    //   alloc(count, false)  the caller overwrites all of it at once (upload)
+    //   alloc_zero(count)    a buffer that is ACCUMULATED into, or whose zero is a value: always cleared
+    // LWHIP_PAD_SENTINEL=all | N | A-B (diagnosis): the fp64 state allocations numbered so (per context, LWHIP_TRACE_ALLOC prints
+    // the numbers) are filled with the sentinel instead of zeros -- a result that depends on never-written memory is then off by
+    // hundreds of orders of magnitude, deterministically (tests/test_padding.py runs the parity problems this way).
+    hipError_t alloc(size_t count, bool clear = true) { return alloc_impl(count, clear ? 1 : 0); }
+    hipError_t alloc_zero(size_t count) { return alloc_impl(count, 2); }
+    hipError_t alloc_impl(size_t count, int init)
     {
         release();
         n = count;
         if (count == 0)
             return hipSuccess;
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-        // diagnosis: LWHIP_CLEAR_FROM / LWHIP_CLEAR_TO restrict the clearing to the allocations numbered [from, to) of each
-        // context (lwhip_create restarts the count; LWHIP_TRACE_ALLOC prints the numbers) -- how the read was narrowed down
-        static const int clearFrom = std::getenv("LWHIP_CLEAR_FROM") ? std::atoi(std::getenv("LWHIP_CLEAR_FROM")) : 0;
-        static const int clearTo = std::getenv("LWHIP_CLEAR_TO") ? std::atoi(std::getenv("LWHIP_CLEAR_TO")) : 1 << 30;
-        static const bool noClear = std::getenv("LWHIP_NO_CLEAR") != nullptr; // (diagnosis: the behaviour before the fix)
-        if (noClear)
-            clear = false;
         const int seq = alloc_seq()++;
-        static const int skipFrom = std::getenv("LWHIP_CLEAR_SKIP_FROM") ? std::atoi(std::getenv("LWHIP_CLEAR_SKIP_FROM")) : 0;
-        static const int skipTo = std::getenv("LWHIP_CLEAR_SKIP_TO") ? std::atoi(std::getenv("LWHIP_CLEAR_SKIP_TO")) : 0;
-        if (clear && std::is_same<T, double>::value && (seq < clearFrom || seq >= clearTo || (seq >= skipFrom && seq < skipTo))) // (the fp64 buffers are numbered)
-            clear = false;
-        if (e == hipSuccess && clear && !poison_on())
+        static const bool noClear = std::getenv("LWHIP_NO_CLEAR") != nullptr; // (no safety net: what hipMalloc returns)
+        const bool sentinel = init == 1 && std::is_same<T, double>::value && sentinel_for(seq);
+        const char* what = "";
+        if (e == hipSuccess && poison_on())
+        {
+            // diagnosis (LWHIP_POISON=1): fresh allocations hold NaN / -1
+            e = hipMemset(p, 0xFF, count * sizeof(T));
+            what = " poisoned";
+        }
+        else if (e == hipSuccess && sentinel)
+        {
+            // LWHIP_PAD_SENTINEL_VALUE=<x>: another fill value (a huge one is "optically thick" and may be as harmless as zero
+            // where a plausible one is not: tests/test_padding.py tries several)
+            static const char* sv = std::getenv("LWHIP_PAD_SENTINEL_VALUE");
+            if (sv && *sv)
+            {
+                std::vector<double> h(count * sizeof(T) / sizeof(double) + 1, std::atof(sv));
+                if (sv[0] == 'r')
+                {
+                    // "rand" / "randsign": DIFFERENT plausible values everywhere (log-uniform in 1e-8 .. 1e8) -- what stale data
+                    // of a destroyed context looks like.  A uniform fill cannot show a dependence that goes through a
+                    // difference or a ratio of two padding values (a slope, S = eta / chi): those are 0 and 1 for any constant.
+                    // (one table of 2^20 values, made once, laid end to end from an offset that follows the allocation number)
+                    const bool sign = std::strncmp(sv, "randsign", 8) == 0;
+                    static std::vector<double> table;
+                    if (table.empty())
+                    {
+                        table.resize(1u << 20);
+                        uint64_t x = 0x9E3779B97F4A7C15ull;
+                        for (auto& v : table)
+                        {
+                            x ^= x << 13;
+                            x ^= x >> 7;
+                            x ^= x << 17;
+                            const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+                            v = std::pow(10.0, 16.0 * u - 8.0) * ((sign && (x & 1)) ? -1.0 : 1.0);
+                        }
+                    }
+                    size_t off = ((size_t)(seq + 1) * 7919u) & (table.size() - 1);
+                    for (size_t i = 0; i < h.size();)
+                    {
+                        const size_t nCopy = std::min(h.size() - i, table.size() - off);
+                        std::memcpy(h.data() + i, table.data() + off, nCopy * sizeof(double));
+                        i += nCopy;
+                        off = 0;
+                    }
+                }
+                e = hipMemcpy(p, h.data(), count * sizeof(T), hipMemcpyHostToDevice);
+            }
+            else
+                e = hipMemsetD32((hipDeviceptr_t)p, (int)0x7E377E37, count * sizeof(T) / 4); // 0x7E377E377E377E37 = 6.7e299
+            what = " sentinel";
+        }
+        else if (e == hipSuccess && init == 1 && !std::is_same<T, double>::value && sentinel_on() && std::getenv("LWHIP_PAD_SENTINEL_INT"))
+        {
+            // (the other state allocations -- index and argument tables -- hold this 32-bit word: stale but valid-looking
+            // indices are what neither zeros nor the 0xFF of LWHIP_POISON imitate)
+            e = hipMemset(p, 0, count * sizeof(T));
+            if (e == hipSuccess && count * sizeof(T) >= 4)
+                e = hipMemsetD32((hipDeviceptr_t)p, std::atoi(std::getenv("LWHIP_PAD_SENTINEL_INT")), count * sizeof(T) / 4);
+            what = " int-sentinel";
+        }
+        else if (e == hipSuccess && (init == 2 || (init == 1 && !noClear)))
         {
             e = hipMemset(p, 0, count * sizeof(T));
-            if (e == hipSuccess)
-                e = hipStreamSynchronize(nullptr); // (the caller's stream may be a non-blocking one: no implicit order with this)
+            what = " cleared";
         }
-        // diagnosis (LWHIP_POISON=1): fresh allocations hold NaN / -1, so that a read of memory nothing initialised shows up
-        // in the results instead of depending on what the previous owner of the pages left there
-        if (e == hipSuccess && poison_on())
-            e = hipMemset(p, 0xFF, count * sizeof(T));
-        static const bool trace = std::getenv("LWHIP_TRACE_ALLOC") != nullptr; // diagnosis: which buffer a faulting address follows
+        static const bool syncAlloc = std::getenv("LWHIP_SYNC_ALLOC") != nullptr; // (diagnosis: round 4's clearing minus the clearing)
+        if (e == hipSuccess && (*what || syncAlloc))
+            e = hipStreamSynchronize(nullptr); // (the caller's stream may be a non-blocking one: no implicit order with this)
+        static const bool trace = std::getenv("LWHIP_TRACE_ALLOC") != nullptr; // diagnosis: which buffer a number / an address is
         if (trace)
             std::fprintf(stderr, "lwhip alloc #%d %p .. %p (%zu x %zu B)%s\n", seq, (void*)p, (void*)((char*)p + count * sizeof(T)), count, sizeof(T),
-                         clear ? " cleared" : "");
+                         what);
         return e;
     }
-    static int& alloc_seq()
+    static std::atomic<int>& alloc_seq() // (diagnosis only: the numbers of LWHIP_TRACE_ALLOC / LWHIP_PAD_SENTINEL)
     {
-        static int seq = 0;
+        static std::atomic<int> seq{ 0 };
         return seq;
     }
     static bool poison_on()
     {
         static const bool poison = std::getenv("LWHIP_POISON") != nullptr;
         return poison;
+    }
+    // LWHIP_PAD_SENTINEL: "all", one number, or a range A-B (inclusive) of the fp64 allocation numbers of a context
+    static bool sentinel_on()
+    {
+        static const bool on = std::getenv("LWHIP_PAD_SENTINEL") != nullptr && *std::getenv("LWHIP_PAD_SENTINEL");
+        return on;
+    }
+    static bool sentinel_for(int seq)
+    {
+        if (!sentinel_on())
+            return false;
+        static int lo = 0, hi = -1;
+        static bool parsed = false;
+        if (!parsed)
+        {
+            const char* v = std::getenv("LWHIP_PAD_SENTINEL");
+            if (v[0] == 'a')
+            {
+                lo = 0;
+                hi = 1 << 30;
+            }
+            else
+            {
+                lo = hi = std::atoi(v);
+                const char* dash = std::strchr(v, '-');
+                if (dash)
+                    hi = std::atoi(dash + 1);
+            }
+            parsed = true;
+        }
+        return seq >= lo && seq <= hi;
+    }
+    // the clearing of a buffer whose zeros only keep its padding finite (not a value): left out under the sentinel
+    hipError_t clear_padding()
+    {
+        if (!p || sentinel_on())
+            return hipSuccess;
+        hipError_t e = hipMemset(p, 0, n * sizeof(T));
+        return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
     }
     // a window of somebody else's allocation (the depth arena of the lane sweep)
     void view(T* ptr, size_t count)
@@ -109,11 +205,34 @@ template <typename T> struct DevBuf
         owned = false;
     }
     // the table of a structurally identical context instead of a copy of one's own (lwhip_create_like): same size, or upload
+    // ... and only if it holds what this context would upload: the structure fingerprint of lwhip_create_like covers the
+    // problem, not the layout choices build_tables reads from the environment (LWHIP_SWEEP, the tile / split / tail knobs of
+    // tests and tools) -- a borrower made under another environment computes another layout and must not run on the donor's
+    // tables.  The fingerprint samples the bytes (size, both ends, ~4 000 words in between): a different layout differs in
+    // sizes or in the first records.
+    static uint64_t fingerprint(const std::vector<T>& v)
+    {
+        const size_t nw = v.size() * sizeof(T) / 4;
+        const unsigned char* b = (const unsigned char*)v.data();
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)(v.size() * sizeof(T));
+        auto word = [&](size_t w) {
+            uint32_t x;
+            std::memcpy(&x, b + 4 * w, 4);
+            h = (h ^ x) * 1099511628211ull;
+        };
+        const size_t step = nw > 8192 ? nw / 4096 : 1;
+        for (size_t w = 0; w < nw; w += step)
+            word(w);
+        for (size_t w = nw > 16 ? nw - 16 : 0; w < nw; ++w)
+            word(w);
+        return h | 1ull;
+    }
     hipError_t upload_or_borrow(const std::vector<T>& v, const DevBuf<T>* from)
     {
-        if (from && from->p && from->n == v.size() && !v.empty())
+        if (from && from->p && from->n == v.size() && !v.empty() && from->sig == fingerprint(v))
         {
             view(from->p, from->n);
+            sig = from->sig;
             return hipSuccess;
         }
         return upload(v);
@@ -123,6 +242,7 @@ template <typename T> struct DevBuf
         hipError_t e = alloc(v.size(), poison_on());
         if (e != hipSuccess || v.empty())
             return e;
+        sig = fingerprint(v);
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     void release()
@@ -138,6 +258,7 @@ template <typename T> struct DevBuf
         p = nullptr;
         n = 0;
         owned = true;
+        sig = 0;
     }
     ~DevBuf() { release(); }
 };
@@ -217,6 +338,8 @@ struct lwhip_context
     DevBuf<DevLaneRay> laneRays;
     DevBuf<DevLaneFin> laneFin;
     DevBuf<double> laneFinPar, bcPlanck;
+    DevBuf<uint8_t> laneFeedG;    // generic tiles of the lane sweep: continuum -> slot feed bytes
+    int nGenTiles = 0;
     DevBuf<int32_t> chunkSplit;   // lane sweep: per chunk, the wavefronts its tiles' rays are split over (the launch's tail)
     DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
         postCs;
@@ -266,13 +389,14 @@ struct lwhip_context
     // lwhip_create_like: the structure tables (lwhip_tables.hip) are borrowed from a context of the same structure, which
     // counts its borrowers and cannot be destroyed before them
     lwhip_context* tablesFrom = nullptr;
-    int borrowers = 0;
+    std::atomic<int> borrowers{ 0 }; // (contexts are created and destroyed from several host threads: columns, per-GPU workers)
     uint64_t structSig = 0; // fingerprint of everything the structure tables are built from
     bool dJPrdClean = false; // dJ holds zeros outside the wavelengths the PRD rates pass visits (no full sweep since)
     std::vector<int> prdLines;        // PRD lines of the active atoms (global transition indices), reference order
     std::vector<int64_t> prdRowOff;   // first row of each line's grid in the prdJ gather buffer
     int64_t prdRowsTot = 0;
     bool prdPending = false;          // between lwhip_prd_partial and lwhip_prd_finalise
+    bool prdFused = false;            // ... and its apply launch reads the stage-1 parts and reduces the lines' changes itself
     std::vector<std::unique_ptr<DevBuf<double>>> gII; // per transition: cached PRD weights (lazily)
     std::vector<char> gIIValid;
     DevBuf<NrAtom> nrAtoms, statEqAtoms;
@@ -364,6 +488,15 @@ inline int env_int(const char* name, int dflt)
         return dflt;
     return std::atoi(v);
 }
+// The layout / experiment knobs of tests and tools (tile widths, wavefronts per workgroup, split factors, forced kinds: the list
+// is in INTEGRATION.md section 5) are read only when LWHIP_DEBUG is set: a production process cannot change the work
+// distribution -- or the summation order -- through a stray environment variable.
+inline bool debug_knobs_on()
+{
+    static const bool on = std::getenv("LWHIP_DEBUG") != nullptr;
+    return on;
+}
+inline int dbg_env_int(const char* name, int dflt) { return debug_knobs_on() ? env_int(name, dflt) : dflt; }
 
 inline double trans_wlambda(const lwhip_transition& t, int lt)
 {

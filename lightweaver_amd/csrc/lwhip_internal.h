@@ -170,7 +170,8 @@ struct DevTileSlot
 //   code[q]: 4 x 4 bits, the entry (1 .. 8: a shared sum; 9: none) that continuum q's terms +chi_c, -chi_c, +U_ji, +eta_c are added to
 //   ops[q]:  5 x 4 bits (eta_A, chi_i, U_j, chi_j, U_i of pure continuum q): 0 zero, 1..8 shared sum m = value - 1,
 //            9 +chi_c, 10 -chi_c, 11 U_ji, 12 eta_c of the continuum itself
-enum { LWHIP_POST_MAXC = 16, LWHIP_POST_SUMS = 8 };
+enum { LWHIP_POST_MAXC = 24, LWHIP_POST_SUMS = 8, LWHIP_POST_SUMS_WIDE = 14 }; // (wide encoding: 8 / 6 bits per field instead of 4, see lwhip_tables.hip; 14 sums + the zero and the
+                                            // spare entry are a 16-entry register vector: other lengths are legalised through scratch memory)
 struct DevPostProg
 {
     uint32_t code[LWHIP_POST_MAXC];
@@ -212,11 +213,15 @@ struct DevLaneTile          // per tile: uniform, one burst of scalar loads
 {
     DevTile td;
     int32_t nCont;          // continua the finish walks (0: none are pure): the first wavelength's nMixed + nPure
-    int32_t finFast;        // every continuum carries one of the common program words: the finish's named-register form
+    int32_t finFast;        // 1: every continuum carries one of the common program words: the finish's named-register form;
+                            // 2: the program words are in the WIDE encoding (more than 8 shared sums): the general form's wide instance
     int32_t nContAll;       // continua of the wavelength (the task's own pre-pass walks them all): nMixed + nPure
-    int32_t _pad;
-    DevTileSlot slot[2];    // the tile's line / mixed-continuum slots (cs: of this launch's chunking)
+    int32_t gen;            // -1: one of the compiled kinds (slot[] holds its slots); >= 0: the generic kind -- any number of lines
+                            // and mixed continua, slots read from TileArgs::tslots --, index into TileArgs::laneFeedG
+    DevTileSlot slot[2];    // the tile's line / mixed-continuum slots (cs: of this launch's chunking; flags bits 8 ..: the task's
+                            // turn at the slot's accumulator in the fixed-order mode)
 };
+enum { LWHIP_GEN_MAXS = 16 }; // line + mixed-continuum slots of a generic tile (8 + 8)
 static_assert(sizeof(DevLaneTile) % 16 == 0, "DevLaneTile is read with wide scalar loads");
 struct DevLaneRay           // per (tile, ray slot r < L): what depends on the wavelength (r >= nl repeats the last one)
 {
@@ -319,6 +324,7 @@ struct TileArgs
     const DevLaneFin* laneFin;     // [nTiles][LWHIP_POST_MAXC]
     const double* laneFinPar;      // [nTiles][LWHIP_POST_MAXC][L][3]: alpha, w_lambda / lambda 4 pi / h, 2hc / lambda^3 of (continuum, wavelength)
     const double* bcPlanck;        // [Nla][4]: Planck function of the wavelength at depths 0, 1, Ns - 2, Ns - 1 (thermalised boundaries)
+    const uint8_t* laneFeedG;      // generic tiles: [gen][LWHIP_POST_MAXC][LWHIP_GEN_MAXS] which rows of slot e continuum q feeds (DevLaneFin::feed's byte)
     double* detSlab;               // deterministic mode: [workgroup][maxCT][4][Ns] partial sums (no atomics), else null
     double* lsDbg;                 // diagnostic builds (-DLS_TIMING): [nTiles][8] phase clocks, host-mapped; else null
 };
@@ -409,6 +415,10 @@ struct ApplyArgs
     int32_t scalarIdx;             // 1: dJMaxIdx as the reference's single-thread loop records it (lwhip_set_djmax_index_mode)
     int32_t gatherWorld;           // > 0 (sharded iteration, dJ == null): `tail` holds every shard's (dJMax, idx) after the
                                    // all-reduce; the extra workgroup takes their maximum and publishes it through tailHost
+    // PRD sub-iteration on one device (round 5): the apply launch also reduces every PRD line's per-(depth, slice) maxima of
+    // |d rho / rho| (what prd_change_kernel does as a launch of its own on shards): nPrdChange extra workgroups
+    const struct PrdLineArgs* prdList;
+    int32_t nPrdChange, _padA;
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)
@@ -470,7 +480,8 @@ struct PrdLineArgs
     int32_t* changeIdx;     // [Ns * slices] scratch
 };
 // every PRD line of the sub-iteration in one set of launches: devList = the device copy of hostList [nLines]
-hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream);
+// reduceChange = false: the per-line maxima are reduced by the apply launch that follows (ApplyArgs::prdList), no prd_change launch
+hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream, bool reduceChange = true);
 
 // nr_post_update (lwhip_pops.hip): one listed atom, and the launch arguments
 struct NrAtom

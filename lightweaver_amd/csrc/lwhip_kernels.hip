@@ -184,11 +184,17 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
 {
     const int Ns = a.Ns;
     const int k0 = blockIdx.y * APPLY_K;
+    if ((int)blockIdx.x >= a.Natom + 2) // PRD sub-iteration on one device: the lines' max |d rho / rho| (one wavefront each)
+    {
+        if (blockIdx.y == 0 && threadIdx.x < 64 && a.prdList && (int)blockIdx.x - (a.Natom + 2) < a.nPrdChange)
+            prd_change_reduce(ld_c(CTAB(PrdLineArgs, a.prdList) + ((int)blockIdx.x - (a.Natom + 2))), (int)threadIdx.x);
+        return;
+    }
     if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ or a.gatherWorld is set)
     {
         if (blockIdx.y == 0 && a.dJ)
             djmax_block(a.dJ, a.NlaDj, a.idxOffset, a.tail, 1, 0, a.tailHost, a.tailTicket, a.scalarIdx);
-        else if (blockIdx.y == 0 && threadIdx.x == 0)
+        else if (blockIdx.y == 0 && threadIdx.x == 0 && a.gatherWorld > 0)
         {
             // sharded iteration: max over the shards' slots, first (lowest) wavelength index on ties (max_idx,
             // Constants.hpp:114-125), published like the single-device result
@@ -237,6 +243,25 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
             const int k = k0 + (idx - tr * APPLY_K);
             if (k < Ns)
             {
+                if (a.prdOnly && a.fromParts && a.zeroParts)
+                {
+                    // the PRD rates pass on one device, read straight from the stage-1 parts: nobody else reads them, so every
+                    // part of every transition the pass added to is summed -- and zeroed -- here, used or not
+                    const double r2 = redAt(tr, 2, k), r3 = redAt(tr, 3, k);
+                    (void)redAt(tr, 0, k);
+                    (void)redAt(tr, 1, k);
+                    if (!(a.trans[tr].prd && a.trans[tr].rhoOff >= 0))
+                        continue;
+                    if (!a.trans[tr].op && !a.prdDetailed)
+                    {
+                        a.Rij[(size_t)tr * Ns + k] += r2;
+                        a.Rji[(size_t)tr * Ns + k] += r3;
+                        continue;
+                    }
+                    a.Rij[(size_t)tr * Ns + k] = r2;
+                    a.Rji[(size_t)tr * Ns + k] = r3;
+                    continue;
+                }
                 if (a.prdOnly && !(a.trans[tr].prd && a.trans[tr].rhoOff >= 0))
                     continue;
                 if (a.prdOnly && !a.trans[tr].op && !a.prdDetailed)
@@ -348,12 +373,15 @@ hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs*
     if (list)
         hipLaunchKernelGGL(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(APPLY_T), 0,
                            stream, a, list);
-    else if (a.Ns >= 2048)
-        hipLaunchKernelGGL((apply_kernel<false, APPLY_K_WIDE>), dim3(a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0), (a.Ns + APPLY_K_WIDE - 1) / APPLY_K_WIDE),
-                           dim3(APPLY_T), 0, stream, a, list);
     else
-        hipLaunchKernelGGL(apply_kernel<false>, dim3(a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0), (a.Ns + APPLY_K - 1) / APPLY_K), dim3(APPLY_T), 0,
-                           stream, a, list);
+    {
+        // (+ the dJMax workgroup, + one workgroup per PRD line whose change is reduced here)
+        const int nx = a.nPrdChange > 0 ? a.Natom + 2 + a.nPrdChange : a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0);
+        if (a.Ns >= 2048)
+            hipLaunchKernelGGL((apply_kernel<false, APPLY_K_WIDE>), dim3(nx, (a.Ns + APPLY_K_WIDE - 1) / APPLY_K_WIDE), dim3(APPLY_T), 0, stream, a, list);
+        else
+            hipLaunchKernelGGL(apply_kernel<false>, dim3(nx, (a.Ns + APPLY_K - 1) / APPLY_K), dim3(APPLY_T), 0, stream, a, list);
+    }
     return hipGetLastError();
 }
 

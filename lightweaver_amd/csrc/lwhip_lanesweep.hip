@@ -159,6 +159,12 @@ DEVINL double ls_exp_neg(double x, const double* tab)
     return ldexp(T * p, ni >> 5);
 }
 enum { LS_MAX_WAVES = 8, LS_MAX_R = 16 };
+// The workgroup's LDS accumulators through an LDS-address-space pointer: an address that has been through an `asm` (to keep its
+// arithmetic where it is used) is a GENERIC pointer to the compiler otherwise, and the adds become flat_atomic_add_f64 -- correct,
+// but ~750 clocks each once somebody waits for them (the fixed-order mode hands a slot on only when its adds are complete:
+// measured 12 k clocks per hand-over against ~1 k with ds_add_f64).
+typedef __attribute__((address_space(3))) double ls_lds_double;
+DEVINL void ls_lds_add(ls_lds_double* addr, double v) { (void)__hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define LS_KEEP(v) asm volatile("" : "+v"(v)) /* the value is computed here, on every lane (keeps selects branch-free) */
 #define LS_KEEPI(v) asm volatile("" : "+v"(v))
 #define LS_KEEPS(v)                                                                                                                        \
@@ -201,7 +207,65 @@ struct LaneCtx
     double* sB;                                // the wavefront's LDS row [R][4]: Planck functions of the rays' end points
     const double* sExp;                        // the workgroup's 2^(j/32) table
     double* sPP;                               // the wavefront's LDS block [continuum][ray][3]: per-(continuum, wavelength) parameters of the finish
+    int* sTurn;                                // fixed-order mode: the workgroup's turn counters [slot][D], else null
+    double* dbgWait;                           // -DLS_TIMING: clocks the workgroup's wavefronts waited for their turns at line / mixed slots
+    int sub;                                   // which wavefront of the tile's group this is (0 unless the rays are split)
 };
+
+// ---- fixed-order accumulation with several wavefronts per workgroup (LWHIP_OPT_DETERMINISTIC, round 5) --------------------
+// The wavefronts of a workgroup add their tiles' integrals to the SAME LDS accumulators (neighbouring tiles share their
+// continua, a line spans many tiles); left alone, the order of those atomic adds follows the wavefronts' timing and the
+// last bits of Gamma / Rij / Rji change from run to run.  In the fixed-order mode every (accumulator slot, point of the
+// block) has a turn counter in LDS, and the host gives every task, per slot, the value the counter holds when it is this
+// task's turn (lwhip_tables.hip: tasks of a round in order of expected cost, line / mixed-continuum adds of a round before
+// its pure-continuum adds): a wavefront waits for that value before its first add to the slot and counts the slot on after
+// its last one.  Nobody waits for a task that is behind it in the order, so the waits cannot deadlock (also across the
+// barriers of a split tile: the order never puts an add that follows a barrier in front of one that precedes it); the
+// wavefronts walk the shared continua in the same (transition) order, so they follow each other through the slots like a
+// pipeline.  The sums are then formed in ONE order, whatever the timing: bit-reproducible, with four wavefronts per
+// workgroup (round 3's fixed-order mode ran one, at a quarter of the occupancy: 2.7 x the default's time).
+template <int D> DEVINL void ls_turn_wait(int* sTurn, const int cs, const int p0, const int np, const int turn, double* dbgClocks = nullptr)
+{
+    if (!sTurn)
+        return;
+#ifdef LS_TIMING
+    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+    // (LDS only: the wavefront's LDS operations reach the LDS in program order, so the adds that follow are behind the read
+    // that saw the turn -- no fence, which would also wait for the task's global loads and stores)
+    // (bounded: a wait that never ends would take the device down with it; ~2^20 polls are tens of milliseconds, a thousand
+    // times a task -- past that the wavefront goes on, and the sums are merely in timing order)
+    // (an LDS pointer, not a generic one: volatile loads through a generic pointer are flat_load ... sc0 sc1 with a wait for
+    // ALL of the wavefront's global memory traffic behind each -- measured: 21 k clocks per hand-over instead of ~1 k)
+    volatile __attribute__((address_space(3))) int* t = (volatile __attribute__((address_space(3))) int*)(sTurn + cs * D + p0);
+    for (int spin = 0; spin < (1 << 20); ++spin)
+    {
+        int lo = 0x7fffffff;
+        for (int p = 0; p < np; ++p)
+            lo = min(lo, t[p]);
+        if (__builtin_amdgcn_readfirstlane(lo) >= turn)
+            break;
+#ifndef LS_TURN_SLEEP
+#define LS_TURN_SLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(LS_TURN_SLEEP);
+    }
+    asm volatile("" ::: "memory");
+#ifdef LS_TIMING
+    if (dbgClocks && (threadIdx.x & 63) == 0)
+        unsafeAtomicAdd(dbgClocks, (double)(__builtin_amdgcn_s_memtime() - tw0));
+#endif
+}
+template <int D> DEVINL void ls_turn_done(int* sTurn, const int cs, const int p0, const int np, const int lane)
+{
+    if (!sTurn)
+        return;
+    // (the adds are LDS atomics without return: counted by lgkmcnt, complete when it reaches zero; no fence -- it would wait
+    // for the task's outstanding global loads and stores as well, a memory round trip per slot)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < np)
+        __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(sTurn + cs * D + p0 + lane), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // The rays of one tile: NL / NM line / mixed-continuum slots.  Leaves J and the Psi* moments of the lane's points in
 // Jk / M1 / Me (Me[0] alone if the tile has fewer than two lines: its moment slot is returned) and adds the slots'
@@ -229,10 +293,58 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     // line 1 alone -- and the slots' integrals are formed after each run from what that run accumulated; the gather takes the
     // populations from LDS ray by ray and the moments re-read the profiles (an L1 hit) instead of holding cx / ce / phi.
     // Blends are rare (28 of 3 429 tiles on the bench grid); they pay twice the ray work, the other kinds nothing.
-    constexpr bool HOLD = !HPRD && NL < 2;
+    // NL < 0: the GENERIC kind (round 5) -- any number of lines (<= 8) and mixed continua (<= 8), for the tiles no compiled kind
+    // covers.  It generalises the blend: the gather walks all lines of the tile per ray (a uniform loop over the tile's slot
+    // records), the rays are walked once per RUN, and a run accumulates the moments of ONE line a (P0, P1, Q_a, Q_aa; first
+    // run of that line only) and its cross moment Q_ab with ONE partner b.  Every integral is linear in the moments, so
+    // after each run every slot adds what that run's moments contribute (gen_slot_finish).  Runs: one per line with its
+    // cyclic neighbour as partner, then the remaining pairs -- max(nL, nL (nL - 1) / 2) for nL >= 3.  Rare tiles (none on
+    // the benchmark grid) pay several times the ray work; nothing else changes.  Not for hybrid PRD (rates ray by ray).
+    constexpr bool GEN = NL < 0;
+    static_assert(!(GEN && HPRD), "the generic kind forms its rates from the angle moments");
+    constexpr bool HOLD = !HPRD && !GEN && NL < 2;
     constexpr int NRUN = (MOM && NL > 1) ? 2 : 1;
     int run = 0;
     constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
+    // (generic kind: the tile's slot records and, per lane, its wavelength's slot parameters)
+    const int gnL = GEN ? (int)tr.td.nLine : 0, gnM = GEN ? (int)tr.td.nMixed : 0;
+    const CONST_AS DevTileSlot* gSlots = CTAB(DevTileSlot, a.tslots) + tr.td.slotOff;
+    const GLOBAL_AS DevSlot* gPar = nullptr; // the lane's wavelength: slot record e of the tile is gPar[gSlots[e].e]
+    if (GEN)
+        gPar = (const GLOBAL_AS DevSlot*)a.slots + ((const GLOBAL_AS DevLaHeader*)a.laHdr)[c.la].off;
+#ifdef LS_TIMING
+    unsigned long long lsTurnExit = 0; // (when the wavefront left its first turn wait: the critical section's length is reported)
+#endif
+    int gA = -1, gB = -1;     // the run's line and partner (slot ordinals), uniform
+    bool gNewA = false;       // the run accumulates the line's own moments
+    auto gen_runs = [&]() { return gnL <= 2 ? (gnL < 1 ? 1 : gnL) : gnL * (gnL - 1) / 2; };
+    auto gen_set_run = [&](const int r) {
+        gA = gB = -1;
+        gNewA = false;
+        if (gnL <= 0)
+            return;
+        if (r < gnL)
+        {
+            gA = r;
+            gNewA = true;
+            gB = gnL == 1 ? -1 : gnL == 2 ? (r == 0 ? 1 : -1) : (r + 1) % gnL;
+            return;
+        }
+        // the pairs (i < j) that are not cyclic neighbours, in order
+        int q = r - gnL;
+        for (int i = 0; i < gnL; ++i)
+            for (int j = i + 2; j < gnL; ++j)
+            {
+                if (i == 0 && j == gnL - 1)
+                    continue;
+                if (q-- == 0)
+                {
+                    gA = i;
+                    gB = j;
+                    return;
+                }
+            }
+    };
     const int Ns = c.Ns, Nmu = c.Nmu, LR = c.LR;
     const int la = c.la, k0 = c.k0;
     const bool act = c.act;
@@ -530,6 +642,37 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             {
                 cC[p] = r3[p];
                 eC[p] = r3[64 * D + p];
+            }
+            if constexpr (GEN)
+            {
+                // every line of the tile: Transition::uv + chi_eta_aux_accum (LwTransition.hpp:93-144, :59-109)
+                for (int l = 0; l < gnL; ++l)
+                {
+                    const DevTileSlot u = ld_c(gSlots + l);
+                    double phi[D], ni[D], nj[D], rho[D];
+                    ls_lds<D>(sDep, vK, c.oN + (unsigned)u.gi * Ns8, ni);
+                    ls_lds<D>(sDep, vK, c.oN + (unsigned)u.gj * Ns8, nj);
+                    if (u.flags & 2)
+                        ls_gld<D>(a.rho + u.rhoOff, vRho, 0u, rho);
+                    else
+                    {
+#pragma unroll
+                        for (int p = 0; p < D; ++p)
+                            rho[p] = 1.0;
+                    }
+                    ls_gld<D>(a.phi + u.phiOff, vPhi, sRay, phi);
+                    const GLOBAL_AS DevSlot* q = gPar + u.e;
+                    const double a0 = q->p[0], a2 = q->p[2], a3 = q->p[3];
+#pragma unroll
+                    for (int p = 0; p < D; ++p)
+                    {
+                        const double v1 = a0 * phi[p];
+                        const double v2 = (a2 * rho[p]) * v1;
+                        const double uji = a3 * v2;
+                        cC[p] += ni[p] * v1 - nj[p] * v2;
+                        eC[p] += nj[p] * uji;
+                    }
+                }
             }
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
@@ -954,7 +1097,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             for (int i = 0; i < D; ++i)
             {
                 wPsi[i] = hw * PsiS[i];
-                if (NRUN == 1 || run == 0)
+                if ((!GEN && NRUN == 1) || run == 0)
                 {
                     Jk[MI(i)] += hw * Iv[i]; // accumulate_J :181-190
                     M1[MI(i)] += wPsi[i];
@@ -963,9 +1106,38 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             if (MOM)
             {
                 // the angle moments of the slots' rates: of line 0, or (a blend) of the line this run accumulates
-                if (NRUN == 1 || run == 0)
+                if ((!GEN && NRUN == 1) || run == 0)
                     mW += hw;
-                if (NL > 0)
+                if constexpr (GEN)
+                {
+                    if (gA >= 0)
+                    {
+                        // the run's line a and partner b (the ray's profiles again: an L1 hit)
+                        double ph[D], phB[D];
+                        ls_gld<D>(a.phi + ld_c(gSlots + gA).phiOff, vPhi0, sRay, ph);
+                        if (gB >= 0)
+                            ls_gld<D>(a.phi + ld_c(gSlots + gB).phiOff, vPhi0, sRay, phB);
+                        else
+                        {
+#pragma unroll
+                            for (int p = 0; p < D; ++p)
+                                phB[p] = 0.0;
+                        }
+                        const double own = gNewA ? 1.0 : 0.0;
+#pragma unroll
+                        for (int p = 0; p < D; ++p)
+                        {
+                            const int i = MI(p);
+                            const double wa = (own * hw) * ph[p], wb = wPsi[i] * ph[p];
+                            mP0[p] += wa;
+                            mP1[p] = fma(wa, Iv[i], mP1[p]);
+                            mQ1[p] = fma(own, wb, mQ1[p]);
+                            mQ2[p] = fma(own * wb, ph[p], mQ2[p]);
+                            mQ12[p] = fma(wb, phB[p], mQ12[p]);
+                        }
+                    }
+                }
+                else if (NL > 0)
                 {
                     double ph[D], phB[D];
                     if (HOLD)
@@ -1213,8 +1385,11 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     // for formal_sol's upOnly) -- all of them, or this wavefront's share when the tile's rays are split over S wavefronts
     // (written as the loop over mu with its two directions guarded, not as a loop over q with a direction branch: the
     // latter makes the compiler hoist three dozen registers of addresses and flags in front of the loop, and spill)
-    for (run = 0; run < NRUN; ++run)
+    const int nRun = GEN ? gen_runs() : NRUN;
+    for (run = 0; run < nRun; ++run)
     {
+    if constexpr (GEN)
+        gen_set_run(run);
     prefetch_first();
 #ifdef LS_ABL_NO_RAYS
     if (dyn.nPass == 77)
@@ -1259,7 +1434,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             const unsigned vK = c.vK + (unsigned)H * 8u, vRow = c.vRow + (unsigned)H * 8u;
             // (the accumulator addresses are formed here: hoisted in front of a blend's run loop they are two dozen registers
             // held -- spilled -- over the rays)
-            double* accB = accBase;
+            ls_lds_double* accB = (ls_lds_double*)accBase;
             asm volatile("" : "+v"(accB));
             // the lines' coefficients per unit profile at these points
             double c2[NLc][HP], cu[NLc][HP], cx[NLc][HP], ce[NLc][HP];
@@ -1368,7 +1543,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             {
                 if (s < NL)
                 {
-                    double lr[5][HP], wphi[HP];
+                    double lr[5][HP], wphi[HP], gq[4][HP];
                     load_rows(lrow[s], lzm[s], lr);
                     ls_lds<HP>(sDep, vK, lwO[s], wphi);
                     const LinePar lp = line_par(s);
@@ -1392,14 +1567,10 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                         const double g1 = ((lp.a0 * (P1of(s, P) - LsE)) - Bil(lr[2][p], f.xj, lr[3][p], f.ui, P)) * Kop;
                         const double g2 = (lp.a0 * P1of(s, P)) * K;
                         const double g3 = up * K;
-                        if (act)
-                        {
-                            double* dst = accB + lacc[s] + (unsigned)(P * LR);
-                            lds_add(dst, g0);
-                            lds_add(dst + D * LR, g1);
-                            lds_add(dst + 2 * D * LR, g2);
-                            lds_add(dst + 3 * D * LR, g3);
-                        }
+                        gq[0][p] = g0;
+                        gq[1][p] = g1;
+                        gq[2][p] = g2;
+                        gq[3][p] = g3;
                         // Meta of the line's atom for the pure continua (lane_finish): sum w Psi* eta_line
                         if (lms[s] >= 0)
                         {
@@ -1409,6 +1580,28 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                                 Me[1][P] = fma(ce[s][p], Q1of(s, P), Me[1][P]);
                         }
                     }
+                    // (fixed-order mode: the task's turn at the slot's accumulator -- waited for HERE, with the integrals formed:
+                    // only the adds themselves are serialised between the wavefronts of a workgroup)
+                    if (c.sTurn && H == 0)
+                    {
+                        ls_turn_wait<D>(c.sTurn, tr.slot[s].cs, 0, D, (int)(((unsigned)tr.slot[s].flags >> (run == 0 ? 8 : 20)) & 0xfffu) + c.sub, nullptr);
+#ifdef LS_TIMING
+                        if (s == 0)
+                            lsTurnExit = __builtin_amdgcn_s_memtime();
+#endif
+                    }
+                    if (act)
+                    {
+#pragma unroll
+                        for (int p = 0; p < HP; ++p)
+                        {
+                            ls_lds_double* dst = accB + lacc[s] + (unsigned)((H + p) * LR);
+                            ls_lds_add(dst, gq[0][p]);
+                            ls_lds_add(dst + D * LR, gq[1][p]);
+                            ls_lds_add(dst + 2 * D * LR, gq[2][p]);
+                            ls_lds_add(dst + 3 * D * LR, gq[3][p]);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -1416,7 +1609,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             {
                 if (m < NM) // mixed continua (always of active atoms)
                 {
-                    double mr[5][HP], mvji[HP];
+                    double mr[5][HP], mvji[HP], gq[4][HP];
                     load_rows(mrow[m], mzm[m], mr);
                     ls_gld<HP>(rRows, vRow, maux[m], mvji);
 #pragma unroll
@@ -1434,20 +1627,177 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                         const double w1 = mb0[m], w2 = mvji[p], uji = mb2[m] * w2;
                         const double Jeff = Jof(P) - Lin(mr[0][p], f.e, P);
                         const double uw = fma(uji, Wof, w2 * Jof(P)); // sum w (U_ji + V_ji I)
-                        if (act)
+                        gq[0][p] = ((uji * Wof + w2 * Jeff) - Bil(mr[1][p], f.xi, mr[4][p], f.uj, P)) * mcw1[m];
+                        gq[1][p] = ((w1 * Jeff) - Bil(mr[2][p], f.xj, mr[3][p], f.ui, P)) * mcw1[m];
+                        gq[2][p] = (w1 * Jof(P)) * mcw1[m];
+                        gq[3][p] = uw * mcw1[m];
+                    }
+                    if (c.sTurn && H == 0)
+                        ls_turn_wait<D>(c.sTurn, tr.slot[NL + m < 2 ? NL + m : 1].cs, 0, D,
+                                        (int)(((unsigned)tr.slot[NL + m < 2 ? NL + m : 1].flags >> (run == 0 ? 8 : 20)) & 0xfffu) + c.sub, c.dbgWait);
+                    if (act)
+                    {
+#pragma unroll
+                        for (int p = 0; p < HP; ++p)
                         {
-                            double* dst = accB + macc[m] + (unsigned)(P * LR);
-                            lds_add(dst, ((uji * Wof + w2 * Jeff) - Bil(mr[1][p], f.xi, mr[4][p], f.uj, P)) * mcw1[m]);
-                            lds_add(dst + D * LR, ((w1 * Jeff) - Bil(mr[2][p], f.xj, mr[3][p], f.ui, P)) * mcw1[m]);
-                            lds_add(dst + 2 * D * LR, (w1 * Jof(P)) * mcw1[m]);
-                            lds_add(dst + 3 * D * LR, uw * mcw1[m]);
+                            ls_lds_double* dst = accB + macc[m] + (unsigned)((H + p) * LR);
+                            ls_lds_add(dst, gq[0][p]);
+                            ls_lds_add(dst + D * LR, gq[1][p]);
+                            ls_lds_add(dst + 2 * D * LR, gq[2][p]);
+                            ls_lds_add(dst + 3 * D * LR, gq[3][p]);
                         }
                     }
                 }
             }
         };
+        // ---- the generic kind: what this run's moments contribute to every slot of the tile, a point at a time -------------
+        // With the run's line a and partner b (coefficients c2, cu, cx, ce per unit profile as above), a slot's level sums are
+        // X = X0 + X_a phi_a + X_b phi_b + (lines of other runs), and of L, L_s, B above this run holds the terms in
+        //   M1, J, W (run 0)      Q_a, Q_aa, P0_a, P1_a (the run in which a is new; zero otherwise)      Q_ab:
+        //   B_run(X, Y)  = X0 Y0 M1 + (X0 Y_a + X_a Y0) Q_a + X_a Y_a Q_aa + (X_a Y_b + X_b Y_a) Q_ab
+        //   L_run(X)     = X0 M1 + X_a Q_a
+        //   L_s_run(X)   = [s = a] (X0 Q_a + X_a Q_aa + X_b Q_ab) + [s = b] X_a Q_ab
+        // Summed over the runs these are the full sums (every Q_l and Q_ll once, every pair once).
+        auto gen_slot_finish = [&]() {
+            const bool run0 = run == 0;
+            DevTileSlot ua{}, ub{};
+            double pA[4] = { 0, 0, 0, 0 }, pB[4] = { 0, 0, 0, 0 };
+            if (gA >= 0)
+            {
+                ua = ld_c(gSlots + gA);
+                const GLOBAL_AS DevSlot* q = gPar + ua.e;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    pA[k] = q->p[k];
+            }
+            if (gB >= 0)
+            {
+                ub = ld_c(gSlots + gB);
+                const GLOBAL_AS DevSlot* q = gPar + ub.e;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    pB[k] = q->p[k];
+            }
+            ls_lds_double* accB = (ls_lds_double*)accBase;
+            asm volatile("" : "+v"(accB));
+            const GLOBAL_AS char* rowsB = (const GLOBAL_AS char*)rRows + c.vRow;
+            const GLOBAL_AS double* rhoB = (const GLOBAL_AS double*)a.rho + (vRho0 >> 3);
+            auto line_coefs = [&](const DevTileSlot& u, const double (&pp)[4], const int P, double& c2, double& cu, double& cx, double& ce) {
+                const double ni = ((const double*)(sDep + c.vK + c.oN + (unsigned)u.gi * Ns8))[P];
+                const double nj = ((const double*)(sDep + c.vK + c.oN + (unsigned)u.gj * Ns8))[P];
+                const double rho = (u.flags & 2) ? rhoB[u.rhoOff + P] : 1.0;
+                c2 = (pp[2] * rho) * pp[0];
+                cu = pp[3] * c2;
+                cx = ni * pp[0] - nj * c2;
+                ce = nj * cu;
+            };
+            const int nS = gnL + gnM;
+#pragma unroll
+            for (int P = 0; P < D; ++P)
+            {
+                double c2a = 0.0, cua = 0.0, cxa = 0.0, cea = 0.0, c2b = 0.0, cub = 0.0, cxb = 0.0, ceb = 0.0;
+                if (gA >= 0)
+                    line_coefs(ua, pA, P, c2a, cua, cxa, cea);
+                if (gB >= 0)
+                    line_coefs(ub, pB, P, c2b, cub, cxb, ceb);
+                const double M1P = run0 ? M1[P] : 0.0, JP = run0 ? Jk[P] : 0.0, WP = run0 ? mW : 0.0;
+                const double Qa = mQ1[P], Qaa = mQ2[P], Qab = mQ12[P], P0a = mP0[P], P1a = mP1[P];
+                for (int sI = 0; sI < nS; ++sI)
+                {
+                    const DevTileSlot us = ld_c(gSlots + sI);
+                    const bool isLine = sI < gnL, isA = isLine && sI == gA, isB = isLine && sI == gB;
+                    const bool op = (us.flags & 1) != 0;
+                    // how the run's lines enter this slot's level sums (couple_code's bits; the slot's own line as in `coupled`)
+                    struct Cpl
+                    {
+                        double e, xi, xj, ui, uj;
+                    };
+                    auto cpl = [&](const DevTileSlot& ul, const bool have, const bool own, const double cx, const double ce, const double cu) {
+                        Cpl r{ 0.0, 0.0, 0.0, 0.0, 0.0 };
+                        if (!have)
+                            return r;
+                        const int code = (ul.flags & 1) ? ((ul.atom == us.atom ? 1 : 0) | (ul.gi == us.gi ? 2 : 0) | (ul.gj == us.gi ? 4 : 0)
+                                                           | (ul.gi == us.gj ? 8 : 0) | (ul.gj == us.gj ? 16 : 0))
+                                                        : 0;
+                        const double sE = (own || (code & 1)) ? 1.0 : 0.0;
+                        const double sXi = own ? 1.0 : ((code & 2) ? 1.0 : 0.0) - ((code & 4) ? 1.0 : 0.0);
+                        const double sXj = own ? -1.0 : ((code & 8) ? 1.0 : 0.0) - ((code & 16) ? 1.0 : 0.0);
+                        const double sUi = own ? 0.0 : (code & 4) ? 1.0 : 0.0;
+                        const double sUj = (own || (code & 16)) ? 1.0 : 0.0;
+                        r.e = sE * ce;
+                        r.xi = sXi * cx;
+                        r.xj = sXj * cx;
+                        r.ui = sUi * cu;
+                        r.uj = sUj * cu;
+                        return r;
+                    };
+                    const Cpl fa = cpl(ua, gA >= 0, isA, cxa, cea, cua), fb = cpl(ub, gB >= 0, isB, cxb, ceb, cub);
+                    // the slot's continuum rows at this point (rows no continuum feeds are not read)
+                    double lr[5];
+                    const int zm = (isLine && !op) ? 31 : (int)us.zmask;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        lr[q] = (zm & (1 << q)) ? 0.0 : ((const GLOBAL_AS double*)(rowsB + (size_t)(us.r0 + q) * rowStride))[P];
+                    auto Bil = [&](const double X0, const double Xa, const double Xb, const double Y0, const double Ya, const double Yb) {
+                        double r = (X0 * Y0) * M1P;
+                        r = fma(fma(X0, Ya, Xa * Y0), Qa, r);
+                        r = fma(Xa * Ya, Qaa, r);
+                        r = fma(fma(Xa, Yb, Xb * Ya), Qab, r);
+                        return r;
+                    };
+                    const GLOBAL_AS DevSlot* qs = gPar + us.e;
+                    double g0, g1, g2, g3;
+                    if (isLine)
+                    {
+                        const double wphi = ((const double*)(sDep + c.vK + c.oW + (unsigned)us.row * Ns8))[P];
+                        const double K = (qs->p[1] * PI4_HC) * wphi;
+                        const double Kop = op ? K : 0.0; // detailed atoms: rates only
+                        const double c2s = isA ? c2a : isB ? c2b : 0.0, cus = isA ? cua : isB ? cub : 0.0, a0s = isA ? pA[0] : isB ? pB[0] : 0.0;
+                        const double P0s = isA ? P0a : 0.0, P1s = isA ? P1a : 0.0;
+                        const double up = fma(cus, P0s, c2s * P1s);
+                        const double LsE = isA ? fma(fb.e, Qab, fma(fa.e, Qaa, lr[0] * Qa)) : isB ? fa.e * Qab : 0.0;
+                        g0 = ((up - c2s * LsE) - Bil(lr[1], fa.xi, fb.xi, lr[4], fa.uj, fb.uj)) * Kop;
+                        g1 = ((a0s * (P1s - LsE)) - Bil(lr[2], fa.xj, fb.xj, lr[3], fa.ui, fb.ui)) * Kop;
+                        g2 = (a0s * P1s) * K;
+                        g3 = up * K;
+                        if (isA && us.ms >= 0) // Meta of the line's atom for the pure continua (lane_finish): sum w Psi* eta_line
+                        {
+                            if (us.ms == 0)
+                                Me[0][P] = fma(cea, Qa, Me[0][P]);
+                            else
+                                Me[1][P] = fma(cea, Qa, Me[1][P]);
+                        }
+                    }
+                    else
+                    {
+                        const double w1 = qs->p[0], mcw = qs->p[1];
+                        const double w2 = ((const GLOBAL_AS double*)(rowsB + (size_t)max((int)us.rAux, 0) * rowStride))[P];
+                        const double uji = qs->p[2] * w2;
+                        const double Jeff = JP - fma(fa.e, Qa, lr[0] * M1P);
+                        const double uw = fma(uji, WP, w2 * JP);
+                        g0 = ((uji * WP + w2 * Jeff) - Bil(lr[1], fa.xi, fb.xi, lr[4], fa.uj, fb.uj)) * mcw;
+                        g1 = ((w1 * Jeff) - Bil(lr[2], fa.xj, fb.xj, lr[3], fa.ui, fb.ui)) * mcw;
+                        g2 = (w1 * JP) * mcw;
+                        g3 = uw * mcw;
+                    }
+                    if (c.sTurn && run <= 1 && P == 0) // (the first run's turn; one more for the adds of all later runs)
+                        ls_turn_wait<D>(c.sTurn, us.cs, 0, D, (int)(((unsigned)us.flags >> (run == 0 ? 8 : 20)) & 0xfffu) + c.sub);
+                    if (act)
+                    {
+                        ls_lds_double* dst = accB + (unsigned)(us.cs * 4 * c.LRD) + (unsigned)(P * LR);
+                        ls_lds_add(dst, g0);
+                        ls_lds_add(dst + D * LR, g1);
+                        ls_lds_add(dst + 2 * D * LR, g2);
+                        ls_lds_add(dst + 3 * D * LR, g3);
+                    }
+                }
+            }
+        };
         LS_PHASE();
-        if constexpr (NL > 1)
+        // (fixed-order mode: a task waits for its turn at a slot right before its first add to it, inside the functions below)
+        if constexpr (GEN)
+            gen_slot_finish();
+        else if constexpr (NL > 1)
         {
             // (a blend: a point at a time -- two lines' coefficients and level sums are twice the registers)
             slot_finish_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -1465,7 +1815,26 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             slot_finish_half(std::integral_constant<int, 0>{}, std::integral_constant<int, D>{});
         }
         LS_PHASE();
-        if (NRUN > 1)
+        if (c.sTurn && (run == 0 || run == nRun - 1)) // (the first run's turn is handed on at once, the later runs' after the last)
+        {
+            if constexpr (GEN)
+            {
+                for (int e = 0; e < gnL + gnM; ++e)
+                    ls_turn_done<D>(c.sTurn, ld_c(gSlots + e).cs, 0, D, c.lane);
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    if (e < NL + NM)
+                        ls_turn_done<D>(c.sTurn, tr.slot[e].cs, 0, D, c.lane);
+#ifdef LS_TIMING
+                if (NL > 0 && c.dbgWait && c.lane == 0 && lsTurnExit)
+                    unsafeAtomicAdd(c.dbgWait, (double)(__builtin_amdgcn_s_memtime() - lsTurnExit));
+#endif
+            }
+        }
+        if (GEN || NRUN > 1)
         {
 #pragma unroll
             for (int p = 0; p < D; ++p)
@@ -1568,11 +1937,16 @@ DEVINL LaneFinRec1 lane_fin_rec(const LaneFinRecs& v, const int q)
 //   after the rays: the same lane, tens of microseconds later).
 // One launch, 60 MB of row writes and 60 MB of reads per 10 240 wavelengths less; the walk is ~600 vector instructions of a
 // task's ~11 000.
-template <int D>
+template <int D, bool GEN>
 DEVINL void lane_pre(const CONST_AS TileArgs& a, const DevLaneTile& tr, const LaneCtx& c, const int ti, const bool slotRows)
 {
     const int Ns = c.Ns;
     const int nC = tr.nContAll;
+    // (generic kind: any number of slots -- their records from the launch's slot table, the continua's feed bytes from the
+    // host's table for generic tiles; the walk below serves slots 0 and 1, gen_more_rows the rest, two at a time)
+    const CONST_AS DevTileSlot* gSlots = CTAB(DevTileSlot, a.tslots) + tr.td.slotOff;
+    const CONST_AS uint8_t* gFeed = CTAB(uint8_t, a.laneFeedG) + (size_t)(GEN ? tr.gen : 0) * (LWHIP_POST_MAXC * LWHIP_GEN_MAXS);
+    auto slot_rec = [&](const int e) -> DevTileSlot { return GEN ? ld_c(gSlots + e) : tr.slot[e < 2 ? e : 1]; };
     // background, J and the finish's records / parameters are requested first
     double chiC[D], etaC[D], scaJ[D];
     {
@@ -1620,7 +1994,9 @@ DEVINL void lane_pre(const CONST_AS TileArgs& a, const DevLaneTile& tr, const La
     for (int q = 0; q < nC; ++q)
     {
         const LaneFinRec1 rc = lane_fin_rec(recs, q);
-        const unsigned feed = (unsigned)__builtin_amdgcn_readlane((int)recs.feed, q);
+        unsigned feed = (unsigned)__builtin_amdgcn_readlane((int)recs.feed, q) & 0xffffu;
+        if (GEN)
+            feed = (unsigned)gFeed[q * LWHIP_GEN_MAXS + 0] | ((unsigned)gFeed[q * LWHIP_GEN_MAXS + 1] << 8);
         double ni[D], nj[D], rat[D];
         ls_lds<D>(c.sDep, c.vK, c.oN + rc.nI, ni);
         ls_lds<D>(c.sDep, c.vK, c.oN + rc.nJ, nj);
@@ -1679,16 +2055,15 @@ DEVINL void lane_pre(const CONST_AS TileArgs& a, const DevLaneTile& tr, const La
             r3[2 * 64 * D + p] = scaJ[p];
         }
     }
-    if (slotRows)
-    {
-        // the slots' rows into the tile's row block (rows no continuum feeds are neither written nor read: zmask)
-        const int nSl = tr.td.nLine + tr.td.nMixed;
+    // the slots' rows into the tile's row block (rows no continuum feeds are neither written nor read: zmask)
+    const int nSl = tr.td.nLine + tr.td.nMixed;
+    auto write_rows = [&](const int e0) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
         {
-            if (e >= nSl)
+            if (e0 + e >= nSl)
                 continue;
-            const DevTileSlot& u = tr.slot[e];
+            const DevTileSlot u = slot_rec(e0 + e);
             if (!(u.flags & 1))
                 continue;
             GLOBAL_AS double* dst = (GLOBAL_AS double*)c.rRows + (size_t)(c.vRow >> 3);
@@ -1702,7 +2077,7 @@ DEVINL void lane_pre(const CONST_AS TileArgs& a, const DevLaneTile& tr, const La
                 for (int p = 0; p < D; ++p)
                     d[p] = ls[e][q][p];
             }
-            if (e >= tr.td.nLine && u.rAux >= 0)
+            if (e0 + e >= tr.td.nLine && u.rAux >= 0)
             {
                 GLOBAL_AS double* d = dst + (size_t)u.rAux * (c.rowStride >> 3);
 #pragma unroll
@@ -1710,13 +2085,81 @@ DEVINL void lane_pre(const CONST_AS TileArgs& a, const DevLaneTile& tr, const La
                     d[p] = vj[e][p];
             }
         }
+    };
+    if (slotRows)
+        write_rows(0);
+    if constexpr (GEN)
+    {
+        // the rows of slots 2, 3, ...: the continua are walked again for every further pair of slots (a rare kind of tile)
+        for (int e0 = 2; slotRows && e0 < nSl; e0 += 2)
+        {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int p = 0; p < D; ++p)
+                {
+                    vj[e][p] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        ls[e][q][p] = 0.0;
+                }
+            for (int q = 0; q < nC; ++q)
+            {
+                const unsigned feed = (unsigned)gFeed[q * LWHIP_GEN_MAXS + e0] | ((unsigned)gFeed[q * LWHIP_GEN_MAXS + e0 + 1] << 8);
+                if (feed == 0u)
+                    continue;
+                const LaneFinRec1 rc = lane_fin_rec(recs, q);
+                double ni[D], nj[D], rat[D];
+                ls_lds<D>(c.sDep, c.vK, c.oN + rc.nI, ni);
+                ls_lds<D>(c.sDep, c.vK, c.oN + rc.nJ, nj);
+                ls_lds<D>(c.sDep, c.vK, c.oRat + rc.rat, rat);
+                const double* ppq = c.sPP + (q * c.L + c.r) * 3;
+                const double p0 = ppq[0], p2 = ppq[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                {
+                    const unsigned f = (feed >> (8 * e)) & 0xffu;
+                    if (f == 0u)
+                        continue;
+#pragma unroll
+                    for (int p = 0; p < D; ++p)
+                    {
+                        const double vji = (rat[p] * boltz[p]) * p0;
+                        const double chi_c = ni[p] * p0 - nj[p] * vji;
+                        const double uji = p2 * vji;
+                        const double eta_c = nj[p] * uji;
+                        if (f & 1u)
+                            ls[e][0][p] += eta_c;
+                        if (f & 2u)
+                            ls[e][1][p] += chi_c;
+                        if (f & 4u)
+                            ls[e][1][p] -= chi_c;
+                        if (f & 8u)
+                            ls[e][2][p] += chi_c;
+                        if (f & 16u)
+                            ls[e][2][p] -= chi_c;
+                        if (f & 32u)
+                            ls[e][3][p] += uji;
+                        if (f & 64u)
+                            ls[e][4][p] += uji;
+                        if (f & 128u)
+                            vj[e][p] = vji;
+                    }
+                }
+            }
+            write_rows(e0);
+        }
     }
 }
 
-template <int D, int P0, int NP>
+template <int D, int P0, int NP, bool WIDE = false>
 DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const int nCont, const LaneFinRecs& recs, double* sAcc,
                              const int ms0, const int ms1, const double (&Jk)[D], const double (&M1)[D], const double (&Me)[2][D])
 {
+    // WIDE: the tile's program words are in the wide encoding (more than 8 shared sums -- continua of three and more active
+    // atoms at one wavelength): 8 bits per target (0xFF none), 6 bits per operand (60 .. 63 the continuum's own terms)
+    constexpr int NSUMS = WIDE ? (int)LWHIP_POST_SUMS_WIDE : (int)LWHIP_POST_SUMS;
+    constexpr unsigned CODE_NONE = WIDE ? 0xFFFFFFFFu : 0x9999u;
     const int Nmu = c.Nmu, LR = c.LR;
     const unsigned vK = c.vK + (unsigned)P0 * 8u;
     double Wsum = 0.0; // total quadrature weight of the rays of the iteration, in ray order
@@ -1735,7 +2178,7 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
     // entry 0: zero (never written); 1 .. 8: the shared sums; 9: the spare entry that takes the terms no shared sum wants.
     // One register vector per point, so that an entry picked by a (uniform) index is an indexed register access
     // (v_movrel), not a trip through scratch memory as for an array.
-    typedef double ls_sums_t __attribute__((ext_vector_type(LWHIP_POST_SUMS + 2)));
+    typedef double ls_sums_t __attribute__((ext_vector_type(NSUMS + 2)));
     ls_sums_t S8[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -1744,8 +2187,8 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
     for (int q = 0; q < nCont; ++q)
     {
         const LaneFinRec1 rc = lane_fin_rec(recs, q);
-        const unsigned code = (rc.flags & 1) ? rc.code : 0x9999u;
-        if (code == 0x9999u)
+        const unsigned code = (rc.flags & 1) ? rc.code : CODE_NONE;
+        if (code == CODE_NONE)
             continue;
         double ni[NP], nj[NP], rat[NP];
         ls_lds<NP>(c.sDep, vK, c.oN + rc.nI, ni);
@@ -1767,7 +2210,7 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         // (the two words almost every continuum of a one- or two-atom problem has -- its atom's eta, U(j), chi(j) are the
         // shared sums 1, 2, 3 or 4, 5, 6, its chi(i) is its own -- are recognised and served with fixed registers; an
         // indexed register access costs a mode switch each)
-        if (code == 0x1239u)
+        if (!WIDE && code == 0x1239u)
         {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
@@ -1777,7 +2220,7 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
                 S8[p][1] += eta_c[p];
             }
         }
-        else if (code == 0x4569u)
+        else if (!WIDE && code == 0x4569u)
         {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
@@ -1789,13 +2232,21 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         }
         else
         {
+            // (wide: a target of 0xFF -- none -- goes to the spare entry NSUMS + 1)
+            auto tgt = [&](const int f) -> unsigned {
+                if (!WIDE)
+                    return (code >> (4 * f)) & 15u;
+                const unsigned v = (code >> (8 * f)) & 0xffu;
+                return v == 0xffu ? (unsigned)(NSUMS + 1) : v;
+            };
+            const unsigned t0 = tgt(0), t1 = tgt(1), t2 = tgt(2), t3 = tgt(3);
 #pragma unroll
             for (int p = 0; p < NP; ++p)
             {
-                S8[p][(code >> 0) & 15u] += chi_c[p];
-                S8[p][(code >> 4) & 15u] -= chi_c[p];
-                S8[p][(code >> 8) & 15u] += uji[p];
-                S8[p][(code >> 12) & 15u] += eta_c[p];
+                S8[p][t0] += chi_c[p];
+                S8[p][t1] -= chi_c[p];
+                S8[p][t2] += uji[p];
+                S8[p][t3] += eta_c[p];
             }
         }
     }
@@ -1824,7 +2275,7 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
         double o5[5][NP]; // eta_A, chi_i, U_j, chi_j, U_i
         // operand w of the continuum: sel_w = 0 nothing, 1 .. 8 a shared sum (one indexed register read: the index is
         // uniform), 9 .. 12 the continuum's own term -- instead of a chain of tests per operand
-        if (ops == 0x03291u || ops == 0x06594u || ops == 0x0AB9Cu)
+        if (!WIDE && (ops == 0x03291u || ops == 0x06594u || ops == 0x0AB9Cu))
         {
             // the common words: the atom's shared sums 1, 2, 3 / 4, 5, 6, or a continuum alone in its atom at this wavelength
             const bool a0 = ops == 0x03291u, alone = ops == 0x0AB9Cu;
@@ -1843,34 +2294,49 @@ DEVINL void lane_finish_part(const CONST_AS TileArgs& a, const LaneCtx& c, const
 #pragma unroll
             for (int w = 0; w < 5; ++w)
             {
-                const unsigned sel = (ops >> (4 * w)) & 15u;
-                const unsigned si = sel > 8u ? 0u : sel;
+                const unsigned sel = WIDE ? (ops >> (6 * w)) & 63u : (ops >> (4 * w)) & 15u;
+                constexpr unsigned OWN0 = WIDE ? 60u : 9u; // the continuum's own +chi, -chi, U, eta: OWN0 .. OWN0 + 3
+                const unsigned si = sel >= OWN0 ? 0u : sel;
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                 {
-                    const double own = sel == 9u ? chi_c[p] : sel == 10u ? -chi_c[p] : sel == 11u ? uji[p] : eta_c[p];
+                    const double own = sel == OWN0 ? chi_c[p] : sel == OWN0 + 1u ? -chi_c[p] : sel == OWN0 + 2u ? uji[p] : eta_c[p];
                     const double shared = S8[p][si];
-                    o5[w][p] = sel > 8u ? own : shared;
+                    o5[w][p] = sel >= OWN0 ? own : shared;
                 }
             }
         }
         double* dst = sAcc + (unsigned)(rc.cs * 4 * c.LRD) + c.blk;
+        // (the integrals first, then -- fixed-order mode -- the task's turn at the continuum's accumulator, then the adds: only
+        // these are serialised between the wavefronts of a workgroup)
+        double gq[4][NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+            const double Jp = Jk[P0 + p], M1p = M1[P0 + p];
+            const double Meta = (rc.ms < 0) ? 0.0 : (rc.ms == ms0) ? Me[0][P0 + p] : (rc.ms == ms1) ? Me[1][P0 + p] : 0.0;
+            const double Jeff = Jp - M1p * o5[0][p] - Meta;
+            gq[0][p] = ((uji[p] * Wsum + vji[p] * Jeff) - (M1p * o5[1][p] * o5[2][p])) * wla;
+            gq[1][p] = ((vij * Jeff) - (M1p * o5[3][p] * o5[4][p])) * wla;
+            gq[2][p] = Jp * vij * wla;
+            gq[3][p] = (uji[p] * Wsum + Jp * vji[p]) * wla;
+        }
+        if (c.sTurn)
+            ls_turn_wait<D>(c.sTurn, rc.cs, P0, NP, (int)(__builtin_amdgcn_readlane((int)recs.feed, q) >> 16) & 0xffff);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
         {
             if (!(c.act && P0 + p < c.nV))
                 continue;
-            const double Jp = Jk[P0 + p], M1p = M1[P0 + p];
             if (rc.flags & 1)
             {
-                const double Meta = (rc.ms < 0) ? 0.0 : (rc.ms == ms0) ? Me[0][P0 + p] : (rc.ms == ms1) ? Me[1][P0 + p] : 0.0;
-                const double Jeff = Jp - M1p * o5[0][p] - Meta;
-                lds_add(dst + (P0 + p) * LR, ((uji[p] * Wsum + vji[p] * Jeff) - (M1p * o5[1][p] * o5[2][p])) * wla);
-                lds_add(dst + (D + P0 + p) * LR, ((vij * Jeff) - (M1p * o5[3][p] * o5[4][p])) * wla);
+                lds_add(dst + (P0 + p) * LR, gq[0][p]);
+                lds_add(dst + (D + P0 + p) * LR, gq[1][p]);
             }
-            lds_add(dst + (2 * D + P0 + p) * LR, Jp * vij * wla);
-            lds_add(dst + (3 * D + P0 + p) * LR, (uji[p] * Wsum + Jp * vji[p]) * wla);
+            lds_add(dst + (2 * D + P0 + p) * LR, gq[2][p]);
+            lds_add(dst + (3 * D + P0 + p) * LR, gq[3][p]);
         }
+        ls_turn_done<D>(c.sTurn, rc.cs, P0, NP, c.lane);
     }
 }
 
@@ -1954,27 +2420,60 @@ DEVINL void lane_finish_fast(const CONST_AS TileArgs& a, const LaneCtx& c, const
         const bool active = (rc.flags & 1) != 0;
         const int msel = (rc.ms < 0) ? -1 : (rc.ms == ms0) ? 0 : (rc.ms == ms1) ? 1 : -1;
         double* dst = sAcc + (unsigned)(rc.cs * 4 * c.LRD) + c.blk;
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-        {
+        auto integrals = [&](const int p, double& g0, double& g1, double& g2, double& g3) {
             const double vji = (rat[p] * boltz[p]) * vij;
             const double chi_c = ni[p] * vij - nj[p] * vji;
             const double uji = p2 * vji;
             const double eta_c = nj[p] * uji;
             const double oEta = alone ? eta_c : a0 ? e1[p] : e2[p];
             const double oUj = alone ? uji : a0 ? u1[p] : u2[p];
+            const double Jp = Jk[P0 + p], M1p = M1[P0 + p];
+            const double Meta = msel < 0 ? 0.0 : msel == 0 ? Me[0][P0 + p] : Me[1][P0 + p];
+            const double Jeff = Jp - M1p * oEta - Meta;
+            g0 = ((uji * Wsum + vji * Jeff) - (M1p * chi_c * oUj)) * wla;
+            g1 = (vij * Jeff) * wla; // (U_i of a pure continuum's lower level is zero here)
+            g2 = Jp * vij * wla;
+            g3 = (uji * Wsum + Jp * vji) * wla;
+        };
+        if (c.sTurn)
+        {
+            // fixed-order mode: the integrals first, then the task's turn at the continuum's accumulator, then the adds -- only
+            // these are serialised between the wavefronts of a workgroup
+            double gq[4][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                integrals(p, gq[0][p], gq[1][p], gq[2][p], gq[3][p]);
+            ls_turn_wait<D>(c.sTurn, rc.cs, P0, NP, (int)(__builtin_amdgcn_readlane((int)recs.feed, q) >> 16) & 0xffff);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+            {
+                if (!(c.act && P0 + p < c.nV))
+                    continue;
+                if (active)
+                {
+                    lds_add(dst + (P0 + p) * LR, gq[0][p]);
+                    lds_add(dst + (D + P0 + p) * LR, gq[1][p]);
+                }
+                lds_add(dst + (2 * D + P0 + p) * LR, gq[2][p]);
+                lds_add(dst + (3 * D + P0 + p) * LR, gq[3][p]);
+            }
+            ls_turn_done<D>(c.sTurn, rc.cs, P0, NP, c.lane);
+            continue;
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
             if (!(c.act && P0 + p < c.nV))
                 continue;
-            const double Jp = Jk[P0 + p], M1p = M1[P0 + p];
+            double g0, g1, g2, g3;
+            integrals(p, g0, g1, g2, g3);
             if (active)
             {
-                const double Meta = msel < 0 ? 0.0 : msel == 0 ? Me[0][P0 + p] : Me[1][P0 + p];
-                const double Jeff = Jp - M1p * oEta - Meta;
-                lds_add(dst + (P0 + p) * LR, ((uji * Wsum + vji * Jeff) - (M1p * chi_c * oUj)) * wla);
-                lds_add(dst + (D + P0 + p) * LR, (vij * Jeff) * wla); // (U_i of a pure continuum's lower level is zero here)
+                lds_add(dst + (P0 + p) * LR, g0);
+                lds_add(dst + (D + P0 + p) * LR, g1);
             }
-            lds_add(dst + (2 * D + P0 + p) * LR, Jp * vij * wla);
-            lds_add(dst + (3 * D + P0 + p) * LR, (uji * Wsum + Jp * vji) * wla);
+            lds_add(dst + (2 * D + P0 + p) * LR, g2);
+            lds_add(dst + (3 * D + P0 + p) * LR, g3);
         }
     }
 }
@@ -2011,8 +2510,19 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
     if (nCont <= 0)
         return;
     static_assert(D % 2 == 0, "the block is finished in halves");
-    if (tr.finFast)
+    if (tr.finFast == 1)
         lane_finish_fast<D, 0, D>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+    else if (tr.finFast == 2)
+    {
+        // (the wide encoding: 18 sums per point -- a point at a time)
+        lane_finish_part<D, 0, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        LS_PHASE();
+        lane_finish_part<D, 1, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        LS_PHASE();
+        lane_finish_part<D, 2, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        LS_PHASE();
+        lane_finish_part<D, 3, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+    }
     else
     {
         lane_finish_part<D, 0, D / 2>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
@@ -2139,6 +2649,20 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
     }
     if (nCont <= 0)
         return;
+    static_assert(D == 4, "the wide form below finishes the wavefront's points one at a time");
+    if (tr.finFast == 2)
+    {
+        // (the wide encoding: a point at a time; this wavefront's NP points)
+        if (sub * NP == 0)
+            lane_finish_part<D, 0, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        if (sub * NP <= 1 && 1 < (sub + 1) * NP)
+            lane_finish_part<D, 1, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        if (sub * NP <= 2 && 2 < (sub + 1) * NP)
+            lane_finish_part<D, 2, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        if (sub * NP <= 3 && 3 < (sub + 1) * NP)
+            lane_finish_part<D, 3, 1, true>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
+        return;
+    }
     if (sub == 0)
         lane_finish_part<D, 0, NP>(a, c, nCont, recs, sAcc, ms0, ms1, Jk, M1, Me);
     else if (sub == 1)
@@ -2153,7 +2677,7 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
 template <int SOLVER, int D, int MODE>
 DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLaneTile& tr, const int ti, const bool have, const int S,
                       const int sub, double* sAcc, unsigned long long* sDj, double* sB, const double* sExp, const char* sDep,
-                      double* sRow3, double* sX, double* sPP, const int lane)
+                      double* sRow3, double* sX, double* sPP, int* sTurn, const int lane)
 {
     constexpr bool RATES = (MODE & 1) != 0;
     LS_T(tt0);
@@ -2168,6 +2692,9 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevL
         asm volatile("" : "+v"(ln)); // (recomputed from here on)
         LaneCtx c;
         c.sPP = sPP;
+        c.sTurn = sTurn;
+        c.sub = sub;
+        c.dbgWait = a.lsDbg ? a.lsDbg + (size_t)a.nTiles * 8 + (size_t)blockIdx.x * 4 + 3 : nullptr;
         c.ti = ti;
         c.sExp = sExp;
         c.sDep = sDep;
@@ -2209,14 +2736,22 @@ DEVINL void lane_task(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevL
     if (have)
     {
         c.wav = ((const GLOBAL_AS DevLaneRay*)a.laneRays)[(size_t)ti * a.L + min(c.rRaw, a.L - 1)].wav;
-        lane_pre<D>(a, tr, c, ti, RATES);
+        if (tr.gen >= 0)
+            lane_pre<D, true>(a, tr, c, ti, RATES);
+        else
+            lane_pre<D, false>(a, tr, c, ti, RATES);
         LS_PHASE();
 #if defined(LS_ISA_ONLY) && defined(LS_ONLY_NL) /* one tile kind, for register / instruction counts of the listing */
         ms0 = lane_rays<SOLVER, D, LS_ONLY_NL, LS_ONLY_NM, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
         if (LS_ONLY_NL < 2)
             ms1 = -2;
 #else
-        if (td.nLine == 0)
+        if (tr.gen >= 0)
+        {
+            if constexpr ((MODE & 2) == 0)
+                lane_rays<SOLVER, D, -1, -1, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me); // the generic kind (not hybrid PRD)
+        }
+        else if (td.nLine == 0)
         {
             lane_rays<SOLVER, D, 0, 0, MODE>(a, dyn, tr, c, sAcc, q0, q1, Jk, M1, Me);
             ms0 = ms1 = -2;
@@ -2323,8 +2858,21 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     double* sExp = lds + (size_t)maxCT * 4 * LRD + (size_t)nWaves * LS_MAX_R * 5;                              // [LS_EXP_TAB]
     double* sRow3 = sExp + LS_EXP_TAB + (size_t)wave * (3 * 64 * D);                                            // per wave [3][64][D]
     double* sX = sExp + LS_EXP_TAB + (size_t)(grp * S) * (3 * 64 * D); // the group's exchange area: over its row blocks, after the rays
-    double* sPP = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)wave * (LWHIP_POST_MAXC * a.L * 3); // per wave [continuum][ray][3]
-    double* sDep = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)nWaves * (LWHIP_POST_MAXC * a.L * 3); // [depBytes / 8]
+    // (the per-wave parameter blocks hold the most continua any wavelength of THIS context has, not the kernel's capacity)
+    const int nContLds = min(a.maxC, (int)LWHIP_POST_MAXC);
+    double* sPP = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)wave * (nContLds * a.L * 3); // per wave [continuum][ray][3]
+    double* sDep = sExp + LS_EXP_TAB + (size_t)nWaves * (3 * 64 * D) + (size_t)nWaves * (nContLds * a.L * 3); // [depBytes / 8]
+    // fixed-order mode with several wavefronts per workgroup: the accumulators' turn counters [maxCT][D] behind the depth arena
+    // (one wavefront alone adds in program order anyway)
+    constexpr bool HPRD_K = (MODE & 2) != 0;
+    int* sTurn = (RATES && !HPRD_K && a.detSlab && nWaves > 1) ? (int*)((char*)sDep + a.depBytes) : nullptr;
+    if (sTurn)
+        for (int idx = t; idx < maxCT * D; idx += blockDim.x)
+            sTurn[idx] = 0;
+#ifdef LS_TIMING
+    if (t == 0 && a.lsDbg && !BATCH)
+        a.lsDbg[(size_t)a.nTiles * 8 + (size_t)blockIdx.x * 4 + 3] = 0.0;
+#endif
     ls_exp_table_init(sExp, t);
     {
         // the depth-only pools (populations, w_phi, nStar ratios, geometry) are the same for every tile: one LDS copy per
@@ -2368,7 +2916,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
         const DevLaneTile tr = ld_c(CTAB(DevLaneTile, a.laneTiles) + ti);
         if (RATES && lane < LS_MAX_R && (S == 1 || sub == 0))
             sDj[lane] = 0ull; // (S > 1: before the task's first barrier, the maxima are added after it)
-        lane_task<SOLVER, D, MODE>(a, dyn, tr, ti, have, S, sub, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sX, sPP, lane);
+        lane_task<SOLVER, D, MODE>(a, dyn, tr, ti, have, S, sub, sAcc, sDj, sB, sExp, (const char*)sDep, sRow3, sX, sPP, sTurn, lane);
         if (RATES && have && sub == 0 && lane < tr.td.nl)
             GD(a.dJ)[tr.td.la0 + lane] = __longlong_as_double((long long)sDj[lane]);
     }
@@ -2546,8 +3094,8 @@ hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32
 size_t lane_sweep_lds_bytes(const TileArgs& a, int waves)
 {
     return sizeof(double) * ((size_t)a.maxCT * 4 * a.laneLRD + (size_t)waves * LS_MAX_R * 5 + LS_EXP_TAB + (size_t)waves * 3 * 64 * a.laneD
-                             + (size_t)waves * LWHIP_POST_MAXC * a.L * 3)
-           + a.depBytes;
+                             + (size_t)waves * std::min(a.maxC, (int)LWHIP_POST_MAXC) * a.L * 3)
+           + a.depBytes + (a.detSlab ? ((size_t)a.maxCT * a.laneD * sizeof(int) + 7) / 8 * 8 : 0); // (+ the fixed-order mode's turn counters)
 }
 
 #ifndef LS_ISA_ONLY

@@ -242,16 +242,34 @@ __global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __r
         {
             const double* gc = a.gII + cOff;
             const int16_t* ic = (const int16_t*)a.gIT + cOff;
-            for (int i = 0; i < Np; ++i)
+            // (eight fine points' weights and indices requested together: the pass streams its cache, and one dependent pair
+            // of loads per iteration left the memory pipe mostly idle; the sums are formed in the same order)
+            constexpr int PRD_UNROLL = 8;
+            for (int i0 = 0; i0 < Np; i0 += PRD_UNROLL)
             {
-                const double gii = gc[(size_t)i * Nl];
-                const int it = ic[(size_t)i * Nl];
-                const double x = q0 + i * PrdDQ;
-                // (beyond the table ends the fraction leaves [0, 1]: clamped, it is the 1 / 0 of the filling pass)
-                const double tt = fmin(fmax((x - qW[it - 1]) * rq[it], 0.0), 1.0);
-                const double Jf = (1.0 - tt) * Jk[it - 1] + tt * Jk[it];
-                gNorm += gii;
-                scatInt += Jf * gii;
+                double gv[PRD_UNROLL];
+                int iv[PRD_UNROLL];
+#pragma unroll
+                for (int u = 0; u < PRD_UNROLL; ++u)
+                {
+                    const bool in = i0 + u < Np;
+                    gv[u] = in ? gc[(size_t)(i0 + u) * Nl] : 0.0;
+                    iv[u] = in ? (int)ic[(size_t)(i0 + u) * Nl] : 1;
+                }
+#pragma unroll
+                for (int u = 0; u < PRD_UNROLL; ++u)
+                {
+                    if (i0 + u >= Np)
+                        break;
+                    const double gii = gv[u];
+                    const int it = iv[u];
+                    const double x = q0 + (i0 + u) * PrdDQ;
+                    // (beyond the table ends the fraction leaves [0, 1]: clamped, it is the 1 / 0 of the filling pass)
+                    const double tt = fmin(fmax((x - qW[it - 1]) * rq[it], 0.0), 1.0);
+                    const double Jf = (1.0 - tt) * Jk[it - 1] + tt * Jk[it];
+                    gNorm += gii;
+                    scatInt += Jf * gii;
+                }
             }
         }
         else
@@ -342,48 +360,10 @@ __global__ void prd_change_kernel(const PrdLineArgs* __restrict__ list)
 {
     dbg_poison_lds();
     const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.x);
-    const double* changeVal = a.changeVal;
-    const int* changeIdx = a.changeIdx;
-    const int nEntries = (a.laHi > a.laLo) ? a.Ns * a.slices : 0;
-    double* tail = a.tail;
-    const int world = a.world, rank = a.rank, q = a.q, Nprd = a.Nprd;
-    // one wavefront: max value, smallest flattened index on ties (max_idx semantics: strictly greater
-    // updates in index order, so the first occurrence wins; a zero maximum keeps idx 0).  The result
-    // goes into this shard's slot of the line in the reduce tail; the other shards' slots are zeroed
-    // (the all-reduce sums them).
-    const int lane = threadIdx.x;
-    double best = 0.0;
-    int idx = 0x7fffffff;
-    for (int e = lane; e < nEntries; e += 64)
-    {
-        const double v = changeVal[e];
-        const int i = changeIdx[e];
-        if (i != 0x7fffffff && v > 0.0 && (v > best || (v == best && i < idx)))
-        {
-            best = v;
-            idx = i;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-    {
-        const double v = __shfl_xor(best, off);
-        const int i = __shfl_xor(idx, off);
-        if (v > best || (v == best && i < idx))
-        {
-            best = v;
-            idx = i;
-        }
-    }
-    for (int rk = lane; rk < world; rk += 64)
-    {
-        double* slot = tail + ((size_t)rk * Nprd + q) * 2;
-        slot[0] = (rk == rank) ? best : 0.0;
-        slot[1] = (rk == rank && best > 0.0) ? (double)idx : 0.0;
-    }
+    prd_change_reduce(a, (int)threadIdx.x);
 }
 
-hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream)
+hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream, bool reduceChange)
 {
     if (nLines <= 0)
         return hipSuccess;
@@ -408,7 +388,8 @@ hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hos
         hipLaunchKernelGGL(prd_transpose_kernel, dim3((maxNl + 31) / 32, (Ns + 31) / 32, nLines), dim3(32, 8), 0, stream, devList);
         hipLaunchKernelGGL(prd_scatter_kernel, dim3(Ns, maxSlices, nLines), dim3(128), lds, stream, devList);
     }
-    hipLaunchKernelGGL(prd_change_kernel, dim3(nLines), dim3(64), 0, stream, devList);
+    if (reduceChange)
+        hipLaunchKernelGGL(prd_change_kernel, dim3(nLines), dim3(64), 0, stream, devList);
     return hipGetLastError();
 }
 }

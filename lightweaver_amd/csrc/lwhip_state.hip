@@ -42,23 +42,21 @@ int alloc_state(lwhip_context* c)
     }
     HIP_TRY(c->vlosMu.alloc(Nr * Ns));
     HIP_TRY(c->vBroad.alloc((size_t)std::max(c->Natom, 1) * Ns));
-    HIP_TRY(c->aDamp.alloc((size_t)std::max(c->Nline, 1) * Ns));
-    HIP_TRY(hipMemset(c->aDamp.p, 0, c->aDamp.n * sizeof(double)));
-    HIP_TRY(c->Qelast.alloc((size_t)std::max(c->Nline, 1) * Ns));
-    HIP_TRY(hipMemset(c->Qelast.p, 0, c->Qelast.n * sizeof(double)));
+    HIP_TRY(c->aDamp.alloc_zero((size_t)std::max(c->Nline, 1) * Ns)); // (zero = the value of a line without damping data)
+    HIP_TRY(c->Qelast.alloc_zero((size_t)std::max(c->Nline, 1) * Ns));
     if (c->laneSweep)
     {
         // the depth-only pools the lane sweep reads, back to back (+ padding: a ray's last block reads past its row)
         const size_t nN = (size_t)c->NlevTot * Ns, nW = (size_t)std::max(c->Nline, 1) * Ns, nR = (size_t)std::max(c->Ncont, 1) * Ns;
         const size_t nG = (size_t)4 * (c->laneLR * c->laneD + 2);
         HIP_TRY(c->depArena.alloc(nN + nW + nR + nG + 16));
-        HIP_TRY(hipMemset(c->depArena.p, 0, c->depArena.n * sizeof(double)));
+        HIP_TRY(c->depArena.clear_padding());
         c->n.view(c->depArena.p, nN);
         c->wphi.view(c->depArena.p + nN, nW);
         c->ratio.view(c->depArena.p + nN + nW, nR);
         c->geoT.view(c->depArena.p + nN + nW + nR, nG);
         HIP_TRY(c->bcPlanck.alloc(4 * Nla));
-        HIP_TRY(hipMemset(c->bcPlanck.p, 0, c->bcPlanck.n * sizeof(double)));
+        HIP_TRY(c->bcPlanck.clear_padding());
     }
     else
     {
@@ -72,13 +70,11 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(c->phi.alloc((size_t)std::max<int64_t>(c->phiTot, 1) + 2 * (size_t)c->Ns + 8));
     HIP_TRY(c->rho.alloc((size_t)std::max<int64_t>(c->rhoTot, 1) + 8)); // (+ padding: reads past a row's end by a block of depths)
     HIP_TRY(c->Gamma.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
-    HIP_TRY(c->Cmat.alloc((size_t)std::max<int64_t>(c->gammaTot, 1)));
-    HIP_TRY(hipMemset(c->Cmat.p, 0, c->Cmat.n * sizeof(double)));
+    HIP_TRY(c->Cmat.alloc_zero((size_t)std::max<int64_t>(c->gammaTot, 1))); // (zero = no collisional pre-fill given)
     HIP_TRY(c->Rij.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     HIP_TRY(c->Rji.alloc((size_t)std::max(c->Ntrans, 1) * Ns));
     // reduce buffer: [Ntrans,4,Ns] partial sums followed by one (dJMax, idx) slot per shard
-    HIP_TRY(c->red.alloc((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize * (1 + c->prdLines.size())));
-    HIP_TRY(hipMemset(c->red.p, 0, c->red.n * sizeof(double)));
+    HIP_TRY(c->red.alloc_zero((size_t)c->Ntrans * 4 * Ns + 2 * (size_t)c->worldSize * (1 + c->prdLines.size())));
     HIP_TRY(c->red8.alloc(c->is2d ? 8 : (size_t)std::max(c->Ntrans, 1) * LWHIP_REDUCE_SPLIT * 4 * Ns));
     c->gatherHost.assign(2 * (size_t)c->worldSize, 0.0);
     HIP_TRY(c->dJ.alloc(Nla));
@@ -92,11 +88,11 @@ int alloc_state(lwhip_context* c)
         if (c->laneSweep)
         {
             // the padding points of the row blocks (k >= Ns) are read: keep them finite
-            HIP_TRY(hipMemset(c->rowsTile.p, 0, c->rowsTile.n * sizeof(double)));
+            HIP_TRY(c->rowsTile.clear_padding());
         }
         HIP_TRY(c->momTile.alloc((size_t)std::max<int64_t>(c->momTot, 1)));
         HIP_TRY(c->phiT.alloc((size_t)std::max<int64_t>(c->phiTTot, 1)));
-        HIP_TRY(hipMemset(c->momTile.p, 0, c->momTile.n * sizeof(double)));
+        HIP_TRY(c->momTile.clear_padding());
     }
     if (c->is2d)
     {
@@ -333,6 +329,7 @@ int build_tile_args(lwhip_context* c)
         a.laneFin = c->laneFin.p;
         a.laneFinPar = c->laneFinPar.p;
         a.bcPlanck = c->bcPlanck.p;
+        a.laneFeedG = c->laneFeedG.p;
     }
     a.lsDbg = nullptr;
     if (std::getenv("LWHIP_LS_TIMING"))

@@ -327,8 +327,7 @@ int build_tables(lwhip_context* c)
             HIP_TRY(c->hJOff.upload(off));
             HIP_TRY(c->hJCoef.upload(jc));
         }
-        HIP_TRY(c->JRest.alloc((size_t)H.NprdLambda * Ns));
-        HIP_TRY(hipMemset(c->JRest.p, 0, c->JRest.n * sizeof(double)));
+        HIP_TRY(c->JRest.alloc_zero((size_t)H.NprdLambda * Ns)); // (accumulated into by atomics)
     }
     c->trans.clear();
     c->Nline = c->Ncont = 0;
@@ -648,7 +647,7 @@ int build_tables(lwhip_context* c)
     std::vector<int32_t> tileRemap;
     std::vector<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd,
         postSlotTr, postCs(std::max<size_t>(slots.size(), 1), 0);
-    std::function<bool(int, DevPostProg&)> lanePostProgram;
+    std::function<bool(int, DevPostProg&, bool*)> lanePostProgram;
     std::vector<int> laneCsPure; // lane sweep: accumulator slot of every pure continuum inside its workgroup chunk
     if (c->tiled)
     {
@@ -658,10 +657,14 @@ int build_tables(lwhip_context* c)
         c->laneSweep = false;
         // The pure continua of a wavelength as the lane sweep integrates them (DevPostProg): which level sums need a
         // register ("shared": several contributors, or a foreign one), which are the continuum's own term or zero.
-        auto post_program = [&](int la, DevPostProg& pg) -> bool {
+        // Two encodings of the program words: the NARROW one (4 bits per field, up to LWHIP_POST_SUMS = 8 shared sums: one- and
+        // two-atom problems; the finish's fast forms recognise its common words) and the WIDE one (round 5: 8 / 6 bits per field,
+        // up to LWHIP_POST_SUMS_WIDE = 14 shared sums -- continua of up to four active atoms at one wavelength), chosen per
+        // tile (DevLaneTile::finFast = 2).
+        auto post_program = [&](int la, DevPostProg& pg, bool* wideOut) -> bool {
             pg = DevPostProg{};
-            for (auto& w : pg.code)
-                w = 0x9999u; // per term (+chi, -chi, U, eta) the entry it is added to: 1 .. 8 a shared sum, 9 none
+            if (wideOut)
+                *wideOut = false;
             const DevLaHeader& h = hdr[la];
             const int base = h.off + h.nLine, nC = h.nMixed + h.nPure;
             if (nC > LWHIP_POST_MAXC)
@@ -689,6 +692,10 @@ int build_tables(lwhip_context* c)
                 }
                 return v;
             };
+            // per continuum: the entry each of its four terms (+chi, -chi, U, eta) is added to (0: none, 1 .. : a shared sum), and
+            // the five operands of a pure continuum (0: zero, 1 .. : a shared sum, -1 .. -4: its own +chi, -chi, U, eta)
+            int target[LWHIP_POST_MAXC][4] = {};
+            int operand[LWHIP_POST_MAXC][5] = {};
             std::map<int, int> sumOf;
             for (int q = 0; q < nC; ++q)
             {
@@ -699,25 +706,46 @@ int build_tables(lwhip_context* c)
                 for (int w = 0; w < 5; ++w)
                 {
                     const auto v = contributors(cols[w]);
-                    unsigned sel = 0;
+                    int sel = 0;
                     if (v.size() == 1 && v[0].q == q)
-                        sel = 8u + (unsigned)v[0].kind;
+                        sel = -v[0].kind;
                     else if (!v.empty())
                     {
                         auto it = sumOf.find(cols[w]);
                         if (it == sumOf.end())
                         {
-                            if ((int)sumOf.size() >= LWHIP_POST_SUMS)
+                            if ((int)sumOf.size() >= LWHIP_POST_SUMS_WIDE)
                                 return false;
                             const int m = (int)sumOf.size();
                             it = sumOf.emplace(cols[w], m).first;
-                            for (const auto& cb : v) // (kind 1 .. 4 -> nibble kind - 1 of the contributor's word: the sum's index)
-                                pg.code[cb.q] = (pg.code[cb.q] & ~(0xFu << (4 * (cb.kind - 1)))) | ((unsigned)(m + 1) << (4 * (cb.kind - 1)));
+                            for (const auto& cb : v)
+                                target[cb.q][cb.kind - 1] = m + 1;
                         }
-                        sel = (unsigned)it->second + 1u;
+                        sel = it->second + 1;
                     }
-                    pg.ops[q] |= sel << (4 * w);
+                    operand[q][w] = sel;
                 }
+            }
+            const bool wide = (int)sumOf.size() > LWHIP_POST_SUMS;
+            if (wideOut)
+                *wideOut = wide;
+            for (int q = 0; q < LWHIP_POST_MAXC; ++q)
+            {
+                uint32_t code = 0, ops = 0;
+                for (int f = 0; f < 4; ++f)
+                {
+                    const int tg = target[q][f];
+                    code |= wide ? (uint32_t)(tg ? tg : 0xFF) << (8 * f) : (uint32_t)(tg ? tg : 9) << (4 * f);
+                }
+                for (int w = 0; w < 5; ++w)
+                {
+                    const int sel = operand[q][w];
+                    // own terms: narrow 9 .. 12, wide 60 .. 63 (+chi, -chi, U, eta)
+                    const uint32_t field = sel >= 0 ? (uint32_t)sel : (uint32_t)((wide ? 59 : 8) - sel);
+                    ops |= field << ((wide ? 6 : 4) * w);
+                }
+                pg.code[q] = code;
+                pg.ops[q] = ops;
             }
             return true;
         };
@@ -737,15 +765,19 @@ int build_tables(lwhip_context* c)
             // the march's 0.171 / 0.205 / 0.225 / 0.223-0.234 / 0.396 / 0.457, and 20 % faster on a 512-column batch.  The
             // march serves what the lane sweep's kinds do not cover, and LWHIP_SWEEP=march.)
             const bool prefer = force || !sw;
-            if ((c->hprd || c->deterministic || !(sw && std::strcmp(sw, "march") == 0)) && env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
+            if ((c->hprd || c->deterministic || !(sw && std::strcmp(sw, "march") == 0)) && dbg_env_int("LWHIP_TILE_GENERIC", 0) == 0 && supported && prefer)
             {
+                // (round 5: the choice is per TILE -- a wavelength whose lines / mixed continua have no compiled kind runs the lane
+                // sweep's generic kind, lane_rays<-1, -1>: any number of lines up to 8, walked in runs of one line and one partner,
+                // any mixed continua up to 8; only hybrid PRD, whose rates are formed ray by ray, is limited to the compiled kinds)
                 bool ok = true;
                 for (int la = 0; la < c->Nla && ok; ++la)
                 {
                     const DevLaHeader& h = hdr[la];
                     const bool fastKind = (h.nLine == 0 && h.nMixed == 0) || (h.nLine == 1 && h.nMixed <= 1) || (h.nLine == 2 && h.nMixed == 0);
+                    const bool genKind = !c->hprd && h.nLine <= 8 && h.nMixed <= 8 && dbg_env_int("LWHIP_LANE_GENERIC", 1) != 0;
                     DevPostProg pg;
-                    ok = fastKind && post_program(la, pg);
+                    ok = (fastKind || genKind) && post_program(la, pg, nullptr);
                 }
                 if (ok)
                 {
@@ -759,7 +791,7 @@ int build_tables(lwhip_context* c)
         if (c->hprd && !c->laneSweep)
             return fail(LWHIP_ERR_UNSUPPORTED, "hybrid PRD needs the depth-across-lanes sweep (1D, 13 <= Nspace <= 256, at most "
                                                "two lines or a line and a mixed continuum per wavelength)");
-        const int L = c->laneSweep ? c->laneR : std::max(1, std::min({ 16, 64 / Nmu, env_int("LWHIP_TILE_L", 16) }));
+        const int L = c->laneSweep ? c->laneR : std::max(1, std::min({ 16, 64 / Nmu, dbg_env_int("LWHIP_TILE_L", 16) }));
         const int LRD = c->laneLR * c->laneD;
         c->tileL = L;
         auto pad16 = [](int64_t v) { return (v + 15) / 16 * 16; };
@@ -776,7 +808,7 @@ int build_tables(lwhip_context* c)
         c->rowsTileTot = c->momTot = c->phiTTot = 0;
         c->preCols = 0;
         c->maxSlotsTile = 0;
-        c->tileCap = env_int("LWHIP_TILE_GENERIC", 0); // > 0: every tile through the guarded generic march (test hook)
+        c->tileCap = dbg_env_int("LWHIP_TILE_GENERIC", 0); // > 0: every tile through the guarded generic march (test hook)
         // (march, one problem: the launch is one round of workgroups -- one per tile, four per CU -- and lasts as long as its
         // slowest one, march + post-pass.  The tiles with two slots march longest; capping their wavelengths shortens their
         // post-pass, as long as the extra tiles still fit the round: measured 0.196 -> 0.184 ms at 10 240 wavelengths with 10
@@ -802,7 +834,7 @@ int build_tables(lwhip_context* c)
                 if (count_tiles(cap) * 100 <= slots * 91)
                     autoHeavy = cap;
         }
-        const int tileLHeavy = std::max(1, env_int("LWHIP_TILE_LH", autoHeavy)), tileLOne = std::max(1, env_int("LWHIP_TILE_L1", L));
+        const int tileLHeavy = std::max(1, dbg_env_int("LWHIP_TILE_LH", autoHeavy)), tileLOne = std::max(1, dbg_env_int("LWHIP_TILE_L1", L));
         for (int la = 0; la < c->Nla;)
         {
             const DevLaHeader& h = hdr[la];
@@ -968,10 +1000,13 @@ int build_tables(lwhip_context* c)
     if (c->tiled)
     {
         // workgroups of the sweep: contiguous, cost-balanced runs of tiles; the waves of a workgroup take its tiles in turn
-        c->tileWaves = std::max(1, std::min(8, c->laneSweep ? env_int("LWHIP_LWAVES", 4) : env_int("LWHIP_TWAVES", 2)));
-        if (c->laneSweep && c->deterministic)
-            c->tileWaves = 1; // one wavefront per workgroup: its LDS sums are formed in program order
-        else
+        c->tileWaves = std::max(1, std::min(8, c->laneSweep ? dbg_env_int("LWHIP_LWAVES", 4) : dbg_env_int("LWHIP_TWAVES", 2)));
+        // (fixed-order mode: since round 5 with the default's four wavefronts per workgroup -- they add to the workgroup's
+        // accumulators in turn, lwhip_lanesweep.hip ls_turn_wait; hybrid PRD adds ray by ray and keeps round 3's form, one
+        // wavefront per workgroup, whose LDS sums are formed in program order)
+        if (c->laneSweep && c->deterministic && c->hprd)
+            c->tileWaves = 1;
+        if (!c->laneSweep)
             c->deterministic = false; // (not served by the ray-column march: the flag is ignored there)
         const int W = c->tileWaves;
         int wgPerCU = std::max(1, 8 / W);
@@ -1067,7 +1102,7 @@ int build_tables(lwhip_context* c)
         int tgtSweep = std::min((2 * c->nTiles + W - 1) / W, numCU * wgPerCU); // two tasks per tile (down, up)
         // fused post-pass: the workgroup is the two wavefronts of one tile (and every tile is a workgroup)
         // (column batches too: 12.3k -> 16.0k column-iterations/s at 128 columns against a separate post launch)
-        c->tileFuse = W == 2 && env_int("LWHIP_TILE_FUSE", 1) != 0 && !c->laneSweep;
+        c->tileFuse = W == 2 && dbg_env_int("LWHIP_TILE_FUSE", 1) != 0 && !c->laneSweep;
         if (c->batchHint > 1 && !c->tileFuse)
             tgtSweep = std::max(1, std::min(tgtSweep, numCU * 4 / c->batchHint));
         if (c->tileFuse)
@@ -1080,7 +1115,7 @@ int build_tables(lwhip_context* c)
             // Small problems: the launch is ONE partial round of tasks and lasts as long as its longest task (a tile with two
             // slots: ~0.13 ms alone).  While S wavefronts per tile still fit the round, a tile's rays are split over the S
             // wavefronts of a group (each finishes 1/S of the tile's points): shorter tasks, same round.
-            if (!c->deterministic && c->batchHint <= 1 && W == 4)
+            if ((!c->deterministic || !c->hprd) && c->batchHint <= 1 && W == 4)
             {
                 const long slots = 2L * 4 * numCU;
                 // (measured, tools/split_exp.sh: S = 2 wins while it fits.  S = 4 while IT fits: in round 3 it had the same kernel
@@ -1088,13 +1123,13 @@ int build_tables(lwhip_context* c)
                 // round-4 kernel (moments, own pre-pass) it is 0.048 against 0.059 ms there, the step 0.059 against 0.074)
                 // (a launch that S = 4 fills to the brim -- 1 536 wavelengths, 2 048 wavefronts -- is no faster than with S = 2)
                 c->laneSplit = 4L * c->nTiles <= slots * 9 / 10 ? 4 : 2L * c->nTiles <= slots ? 2 : 1;
-                const int forced = env_int("LWHIP_LANE_SPLIT", 0);
+                const int forced = dbg_env_int("LWHIP_LANE_SPLIT", 0);
                 if (forced == 1 || forced == 2 || forced == 4)
                     c->laneSplit = forced;
             }
             tgtSweep = (c->nTiles * c->laneSplit + W - 1) / W; // one tile per group of wavefronts
             c->laneSplitPrd = c->laneSplit;
-            if (!c->deterministic && c->batchHint <= 1 && W == 4 && !tileListPrd.empty() && env_int("LWHIP_LANE_SPLIT", 0) == 0)
+            if ((!c->deterministic || !c->hprd) && c->batchHint <= 1 && W == 4 && !tileListPrd.empty() && dbg_env_int("LWHIP_LANE_SPLIT", 0) == 0)
                 c->laneSplitPrd = 4L * (long)tileListPrd.size() <= 2L * 4 * numCU * 9 / 10 ? 4 : 2L * (long)tileListPrd.size() <= 2L * 4 * numCU ? 2 : 1;
         }
         // post-pass workgroups: one resident set (LDS: accumulators + the threads' level columns; 8 waves per CU by registers)
@@ -1103,7 +1138,7 @@ int build_tables(lwhip_context* c)
         int tgtPost = std::min(c->nTiles, numCU * postPerCU);
         if (c->batchHint > 1)
             tgtPost = std::max(1, std::min(tgtPost, numCU * 8 / c->batchHint));
-        const int laneFixed = (c->laneSweep && env_int("LWHIP_LANE_UNIFORM", 1) != 0) ? std::max(1, W / c->laneSplit) : 0;
+        const int laneFixed = c->laneSweep ? std::max(1, W / c->laneSplit) : 0; // (one tile per group of wavefronts)
         TileChunking sw = chunk_tiles(all, tgtSweep, c->laneSweep ? 2 : 0, laneFixed);
         // Lane sweep, more workgroups than the chip holds at once (one problem, 2 workgroups of 4 wavefronts per CU): the
         // launch ends with workgroups that started late and have the chip to themselves -- whole tiles of 0.1 ms.  The
@@ -1112,12 +1147,12 @@ int build_tables(lwhip_context* c)
         {
             const int slotsWg = 2 * numCU;
             const int nch0 = (int)sw.chunkTile.size() - 1;
-            const int tailS = env_int("LWHIP_LANE_TAIL", 2);
+            const int tailS = 2; // (the cut chunks' tiles have their rays split over two wavefronts; four measured worse, DESIGN 3.1b vi)
             // (and in a launch of ONE partial round -- more than half a round of whole tiles, so that not every tile can be
             // split -- the heaviest chunks are the ones cut, as many as still fit the round: the launch lasts as long as its
             // longest workgroup)
             const bool oneRound = nch0 <= slotsWg;
-            if (c->laneSweep && c->batchHint <= 1 && !c->deterministic && W == 4 && c->laneSplit == 1 && laneFixed == W
+            if (c->laneSweep && c->batchHint <= 1 && W == 4 && c->laneSplit == 1 && laneFixed == W
                 && (nch0 > slotsWg || (oneRound && nch0 > slotsWg / 2)) && (tailS == 2 || tailS == 4))
             {
                 auto tcost = [&](int i) { return 1.0 + 0.5 * tiles[i].nLine + 0.3 * tiles[i].nMixed + (tiles[i].nLine == 0 ? -0.25 : 0.0); };
@@ -1145,7 +1180,7 @@ int build_tables(lwhip_context* c)
                     if (room >= numCU / 8 && room < nCut)
                         nCut = room;
                     const int keepAuto = std::max(0, nch0 - nCut);
-                    const int keep = std::min(nch0, std::max(0, env_int("LWHIP_LANE_KEEP", tailS == 2 ? keepAuto : slotsWg)));
+                    const int keep = std::min(nch0, std::max(0, keepAuto));
                     for (int q = keep; q < nch0; ++q)
                         cut[ord[q]] = 1;
                 }
@@ -1156,11 +1191,10 @@ int build_tables(lwhip_context* c)
                     // (6 144 wavelengths = 512 chunks on 512 slots took two task lengths, 0.115 ms) -- then EVERY chunk is cut
                     // and the launch is two rounds of half-length tasks
                     const int extra = tailS - 1;
-                    const int fullPct = env_int("LWHIP_LANE_FULL", 85);
+                    const int fullPct = 85; // (profiles/r04_tail_rule.md)
                     int k = std::min(nch0, std::max(0, (slotsWg - nch0) / extra));
                     if (tailS == 2 && nch0 * 100 > slotsWg * fullPct)
                         k = nch0;
-                    k = std::min(nch0, std::max(0, env_int("LWHIP_LANE_ONE_CUT", k))); // (experiments: the number of chunks cut)
                     for (int q = 0; q < k; ++q)
                         cut[ord[q]] = 1;
                 }
@@ -1381,6 +1415,7 @@ int build_tables(lwhip_context* c)
         };
         std::vector<DevContRec> cr(std::max<size_t>(slots.size(), 1), DevContRec{});
         std::vector<DevPostProg> pp;
+        std::vector<char> ppWide; // per tile: the finish program's words are in the wide encoding
         {
             // the continua of every wavelength in transition order, ready-to-use offsets and level-column slots
             for (int la = 0; la < c->Nla; ++la)
@@ -1413,9 +1448,14 @@ int build_tables(lwhip_context* c)
         if (c->laneSweep)
         {
             pp.assign(std::max<size_t>(tiles.size(), 1), DevPostProg{});
+            ppWide.assign(std::max<size_t>(tiles.size(), 1), 0);
             for (size_t t = 0; t < tiles.size(); ++t)
-                if (!lanePostProgram(tiles[t].la0, pp[t]))
+            {
+                bool wide = false;
+                if (!lanePostProgram(tiles[t].la0, pp[t], &wide))
                     return fail(LWHIP_ERR_UNSUPPORTED, "lane sweep: post program");
+                ppWide[t] = wide ? 1 : 0;
+            }
             HIP_TRY(c->postProg.upload_or_borrow(pp, like ? &like->postProg : nullptr));
             if (std::getenv("LWHIP_VERBOSE"))
             {
@@ -1430,6 +1470,88 @@ int build_tables(lwhip_context* c)
                 for (const auto& kv : hist)
                     std::fprintf(stderr, "  finish program word code %#x ops %#x: %d continua\n", kv.first.first, kv.first.second, kv.second);
             }
+        }
+        // Fixed-order mode (LWHIP_OPT_DETERMINISTIC): every task's turn at each of its accumulator slots -- the value the slot's
+        // turn counter holds when the task may add (lwhip_lanesweep.hip, ls_turn_wait).  Per workgroup: its rounds in order;
+        // inside a round first the line / mixed-continuum adds of every task (they precede the barriers of a split tile, the
+        // pure continua's follow them: a wait never points across a barrier the other way), then the pure continua's; the
+        // tasks of a round in order of expected cost, so that nobody waits for a wavefront that is still marching.  A line /
+        // mixed slot counts one per wavefront of the tile's group (each adds the integrals of its own rays to every point), a
+        // pure continuum one per task (every point is finished by exactly one wavefront).  The turn rides in bits 8 .. 23 of
+        // the slot's flags (lines, mixed continua) and in bits 16 .. 31 of DevLaneFin::feed (pure continua).
+        std::vector<uint32_t> turnPure(std::max<size_t>(tiles.size() * LWHIP_POST_MAXC, 1), 0u);
+        if (c->laneSweep && c->deterministic)
+        {
+            auto assign_turns = [&](std::vector<DevTileSlot>& ts, const std::vector<int32_t>& chTile, const std::vector<int32_t>* list,
+                                    const std::vector<int32_t>* split, int launchSplit, bool pure) -> bool {
+                const int nch = (int)chTile.size() - 1;
+                std::vector<int> cnt(std::max(c->maxCTTile, 1));
+                // (measurement only: bit 0 -- the line / mixed slots' turns are 0, nobody waits there; bit 1 -- the pure continua's;
+                // bit 2 -- tasks in wavefront order instead of by expected cost.  With a bit of 0 / 1 set the sums' order is the timing's)
+                const int noWaitBits = dbg_env_int("LWHIP_DET_NOWAIT", 0);
+                auto tcost = [&](int t) { return 1.0 + 0.5 * tiles[t].nLine + 0.3 * tiles[t].nMixed + (tiles[t].nLine == 0 ? -0.25 : 0.0); };
+                for (int ch = 0; ch < nch; ++ch)
+                {
+                    std::fill(cnt.begin(), cnt.end(), 0);
+                    const int S = std::max(1, split ? (*split)[ch] : launchSplit);
+                    const int nGroups = std::max(1, c->tileWaves / S);
+                    const int n = chTile[ch + 1] - chTile[ch];
+                    for (int r0 = 0; r0 < n; r0 += nGroups)
+                    {
+                        std::vector<int> tasks;
+                        for (int i = r0; i < std::min(n, r0 + nGroups); ++i)
+                            tasks.push_back(list ? (*list)[chTile[ch] + i] : chTile[ch] + i);
+                        if (!(noWaitBits & 4))
+                            std::stable_sort(tasks.begin(), tasks.end(), [&](int x, int y) { return tcost(x) < tcost(y); });
+                        // (a tile that walks its rays more than once -- a blend, a generic tile -- adds after every run: it takes a
+                        // SECOND turn for the adds of its later runs, behind the first turns of the whole round, so that it does not
+                        // hold a slot while it marches again -- 28 blends of 3 429 tiles doubled the launch's time when they did)
+                        for (int pass = 0; pass < 2; ++pass)
+                            for (int t : tasks)
+                            {
+                                const int nl = tiles[t].nLine;
+                                const int nRun = nl <= 2 ? std::max(nl, 1) : nl * (nl - 1) / 2; // (lane_rays: NRUN / gen_runs)
+                                const bool fastKind = (nl == 0 && tiles[t].nMixed == 0) || (nl == 1 && tiles[t].nMixed <= 1) || (nl == 2 && tiles[t].nMixed == 0);
+                                if (pass == 1 && (fastKind ? nl < 2 : nRun < 2))
+                                    continue;
+                                for (int e = 0; e < tiles[t].nLine + tiles[t].nMixed; ++e)
+                                {
+                                    DevTileSlot& u = ts[tiles[t].slotOff + e];
+                                    if (u.cs < 0 || u.cs >= (int)cnt.size() || cnt[u.cs] + S > 0x7ff)
+                                        return false;
+                                    const int turn = (noWaitBits & 1) ? 0 : cnt[u.cs];
+                                    if (pass == 0)
+                                        u.flags = (u.flags & 0xff) | (turn << 8);
+                                    else
+                                        u.flags |= turn << 20;
+                                    cnt[u.cs] += S;
+                                }
+                            }
+                        for (int t : tasks)
+                        {
+                            const DevLaHeader& h = hdr[tiles[t].la0];
+                            if (!pure || h.nPure == 0)
+                                continue;
+                            for (int q = 0; q < std::min(h.nMixed + h.nPure, (int)LWHIP_POST_MAXC); ++q)
+                            {
+                                const DevContRec& r = cr[h.off + h.nLine + q];
+                                if (!(r.flags & 2))
+                                    continue;
+                                if (r.cs < 0 || r.cs >= (int)cnt.size() || cnt[r.cs] + 1 > 0xffff)
+                                    return false;
+                                turnPure[(size_t)t * LWHIP_POST_MAXC + q] = (noWaitBits & 2) ? 0u : (uint32_t)cnt[r.cs];
+                                cnt[r.cs] += 1;
+                            }
+                        }
+                    }
+                }
+                return true;
+            };
+            bool okT = assign_turns(tslots, chunkTile, nullptr, laneChunkSplit.empty() ? nullptr : &laneChunkSplit, c->laneSplit, true);
+            if (okT && !tslotsPrd.empty() && !tileListPrd.empty())
+                okT = assign_turns(tslotsPrd, chunkTilePrd, &tileListPrd, nullptr, c->laneSplitPrd, false);
+            if (!okT)
+                return fail(LWHIP_ERR_UNSUPPORTED, "fixed-order mode: more adds to one accumulator slot of a workgroup than a turn counter counts");
         }
         HIP_TRY(up(c->tiles, tiles, like ? &like->tiles : nullptr));
         HIP_TRY(up(c->tslots, tslots, like ? &like->tslots : nullptr));
@@ -1490,6 +1612,49 @@ int build_tables(lwhip_context* c)
             }
             auto wgs = wg_records(chunkTile, c->chunkOrderOn ? &orderHost : nullptr, c->chunkSplitOn ? &laneChunkSplit : nullptr, c->laneSplit);
             HIP_TRY(c->laneWg.upload_or_borrow(wgs, like ? &like->laneWg : nullptr));
+            // which tiles run the generic kind (no compiled kind for their line / mixed-continuum counts), and for those the
+            // feed bytes of every (continuum, slot) pair -- DevLaneFin::feed holds two slots' worth
+            std::vector<int32_t> genOf(std::max<size_t>(tiles.size(), 1), -1);
+            std::vector<uint8_t> feedG;
+            c->nGenTiles = 0;
+            auto feed_byte = [&](const DevSlot& cs, const DevTileSlot& us, bool isThisMixed) -> uint8_t {
+                uint32_t b = 0;
+                if ((cs.flags & 1) && (us.flags & 1))
+                {
+                    b |= cs.atom == us.atom ? 1u : 0u;
+                    b |= cs.gi == us.gi ? 2u : 0u;
+                    b |= cs.gj == us.gi ? 4u : 0u;
+                    b |= cs.gi == us.gj ? 8u : 0u;
+                    b |= cs.gj == us.gj ? 16u : 0u;
+                    b |= cs.gj == us.gi ? 32u : 0u;
+                    b |= cs.gj == us.gj ? 64u : 0u;
+                }
+                if (isThisMixed)
+                    b |= 128u;
+                return (uint8_t)b;
+            };
+            for (size_t t = 0; t < tiles.size(); ++t)
+            {
+                const DevTile& td = tiles[t];
+                const bool fastKind = (td.nLine == 0 && td.nMixed == 0) || (td.nLine == 1 && td.nMixed <= 1) || (td.nLine == 2 && td.nMixed == 0);
+                if (fastKind)
+                    continue;
+                genOf[t] = c->nGenTiles++;
+                const DevLaHeader& h0 = hdr[td.la0];
+                const size_t base = feedG.size();
+                feedG.resize(base + (size_t)LWHIP_POST_MAXC * LWHIP_GEN_MAXS, 0);
+                const int nC = std::min(h0.nMixed + h0.nPure, (int)LWHIP_POST_MAXC);
+                for (int q = 0; q < nC; ++q)
+                {
+                    const int ord = slots[h0.off + h0.nLine + q]._pad;
+                    const DevSlot& cs = slots[h0.off + h0.nLine + ord];
+                    for (int e = 0; e < std::min(td.nLine + td.nMixed, (int)LWHIP_GEN_MAXS); ++e)
+                        feedG[base + (size_t)q * LWHIP_GEN_MAXS + e] = feed_byte(cs, tslots[td.slotOff + e], e >= td.nLine && ord == e - td.nLine);
+                }
+            }
+            if (feedG.empty())
+                feedG.push_back(0);
+            HIP_TRY(c->laneFeedG.upload_or_borrow(feedG, like ? &like->laneFeedG : nullptr));
             auto tile_records = [&](const std::vector<DevTileSlot>& ts) {
                 std::vector<DevLaneTile> v(std::max<size_t>(tiles.size(), 1), DevLaneTile{});
                 for (size_t t = 0; t < tiles.size(); ++t)
@@ -1500,7 +1665,7 @@ int build_tables(lwhip_context* c)
                     v[t].nContAll = std::min(h.nMixed + h.nPure, (int)LWHIP_POST_MAXC);
                     {
                         // the finish's named-register form serves the tiles whose continua all carry the common words
-                        bool fast = true;
+                        bool fast = !ppWide[t];
                         const int nC = h.nMixed + h.nPure;
                         for (int q = 0; q < nC && q < LWHIP_POST_MAXC; ++q)
                         {
@@ -1511,10 +1676,11 @@ int build_tables(lwhip_context* c)
                             if ((r.flags & 2) && (r.flags & 1) && ops != 0x03291u && ops != 0x06594u && ops != 0x0AB9Cu)
                                 fast = false;
                         }
-                        v[t].finFast = (fast && env_int("LWHIP_FIN_FAST", 1) != 0) ? 1 : 0;
+                        v[t].finFast = ppWide[t] ? 2 : (fast && dbg_env_int("LWHIP_FIN_FAST", 1) != 0) ? 1 : 0; // (2: the wide encoding, general form)
                     }
                     for (int e = 0; e < std::min(2, tiles[t].nLine + tiles[t].nMixed); ++e)
                         v[t].slot[e] = ts[tiles[t].slotOff + e];
+                    v[t].gen = genOf[t];
                 }
                 return v;
             };
@@ -1576,6 +1742,7 @@ int build_tables(lwhip_context* c)
                             feed |= b << (8 * e);
                         }
                     }
+                    feed |= (turnPure[t * LWHIP_POST_MAXC + q] & 0xffffu) << 16; // (fixed-order mode: the task's turn at this continuum's slot)
                     fin[t * LWHIP_POST_MAXC + q] = DevLaneFin{ w[0], w[1], w[2], w[6], w[7], pp[t].code[q], pp[t].ops[q], feed };
                     for (int rr = 0; rr < L; ++rr)
                     {

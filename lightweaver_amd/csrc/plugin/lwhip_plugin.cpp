@@ -99,11 +99,13 @@ public:
         }
     }
     bool usable() const { return !threads.empty() && (long)getpid() == owner; }
-    std::mutex busy; // one round of work at a time: a second caller (another Context on another thread) waits in start()
-    // f on every pool thread; returns at once (f must stay valid until wait() returns)
-    void start(const std::function<void()>& f)
+    std::mutex busy; // one round of work at a time: a second caller (another Context on another thread) hashes inline
+    // f on every pool thread; returns at once (f must stay valid until wait() returns).  false: the pool is serving
+    // somebody else's round (which spans that caller's uploads and kernels) -- the caller works through its blocks alone
+    bool start(const std::function<void()>& f)
     {
-        busy.lock();
+        if (!busy.try_lock())
+            return false;
         {
             std::lock_guard<std::mutex> lock(m);
             job = f;
@@ -111,6 +113,7 @@ public:
             ++generation;
         }
         wake.notify_all();
+        return true;
     }
     void wait()
     {
@@ -128,9 +131,10 @@ public:
             f();
             return;
         }
-        start(f);
+        const bool pooled = start(f);
         f();
-        wait();
+        if (pooled)
+            wait();
     }
 };
 
@@ -255,7 +259,7 @@ struct HashSet
         if (inFlight)
         {
             worker = [this] { work(); };
-            HashPool::get().start(worker);
+            inFlight = HashPool::get().start(worker); // (false: the pool is busy, finish() does the blocks on this thread)
         }
     }
     void finish()

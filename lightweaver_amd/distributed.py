@@ -79,7 +79,6 @@ class ShardedIteration:
         self._bound = None      # the stream handle the context was last bound to
         self._side = None       # side stream of the host-authoritative mode (all-reduce overlapped with the J download)
         self.allreduce_s = 0.0  # host time spent issuing collectives (bench.py: allreduce_us)
-        self._one_call = None   # no collective to interleave: the library's one-call iteration (decided at the first call)
         self._bind_stream()
 
     @property
@@ -119,9 +118,8 @@ class ShardedIteration:
 
     def formal_sol_gamma_matrices(self, lambdaIterate=False, deviceResident=True, crsw=1.0):
         ctx = self.ctx
-        if self._one_call is None:
-            self._one_call = not self._collective and hasattr(ctx, 'formal_sol_gamma_matrices') and hasattr(ctx, 'lib')
-        if self._one_call:
+        # (decided per call: `force_collective` or `world` may be changed between calls)
+        if not self._collective and hasattr(ctx, 'formal_sol_gamma_matrices') and hasattr(ctx, 'lib'):
             # no collective to interleave: the library's one-call form (which also folds the second reduce stage
             # and the dJMax reduction into the apply launch)
             ctx.crsw = crsw

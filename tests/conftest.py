@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the tests force layouts (LWHIP_LANE_SPLIT, LWHIP_LWAVES, LWHIP_TILE_GENERIC ...): the library reads those experiment knobs only
+# in a process that sets LWHIP_DEBUG
+os.environ.setdefault('LWHIP_DEBUG', '1')
 
 
 def pytest_configure(config):

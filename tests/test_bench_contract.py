@@ -35,3 +35,49 @@ def test_bench_line_contract(gpu):
     c = d['cpu_baseline']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'iters/s'
     assert d['parity_checked'] is True and d['max_rel_err'] <= 1e-8
+
+
+def test_rank_launch_command_shape():
+    """`python bench.py --gpus N` without a launcher starts its ranks itself: the command it spawns."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.rank_launch_command(4, ['--gpus', '4', '--steps', '7'], port=29511)
+    assert cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nproc-per-node=4' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29511'
+    assert cmd[-5].endswith('bench.py') and cmd[-4:] == ['--gpus', '4', '--steps', '7']
+
+
+def test_self_launch_spawns_ranks_without_a_gpu():
+    """No launcher, no GPU: the parent spawns two ranks (it must not touch the GPU itself), each rank refuses to run
+    without a device, and the parent passes the failure on as its own exit code."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU box: covered by test_bench_self_launch_two_ranks_on_one_gpu')
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--share-gpu',
+                          '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count('bench.py needs a GPU') >= 2, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_one_gpu(gpu):
+    """`python3 bench.py --gpus 2` with no launcher and no WORLD_SIZE: the form the driver's SCALE command may take.  Two
+    ranks share the box's one GPU under gloo (functional: the sharded path, one collective per step, rank 0's line)."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--share-gpu',
+                          '--steps', '5', '--warmup', '2', '--no-weak'], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['scaling'] == 'strong'
+    assert d['value'] == pytest.approx(1e3 / d['ms_per_step'], rel=1e-9)
+    assert abs(d['config']['Nlambda_total'] - 10240) <= 102 and d['config']['Nlambda_per_gpu'] < 6000
+    assert 'allreduce_us' in d

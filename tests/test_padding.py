@@ -1,0 +1,61 @@
+"""Results must not depend on device memory that nothing wrote.
+
+A few pools are read past what the uploads fill -- the padding lanes of a ray's last block of depths, the profile request one
+ray ahead -- and `hipMalloc` hands back whatever the pages' previous owner left.  `LWHIP_PAD_SENTINEL=all` fills every fp64
+state allocation of every context with a FINITE sentinel instead of zeros (NaN, the pattern of `LWHIP_POISON`, is swallowed by
+the fmin / fmax of the Steffen derivative; a finite value is not), `LWHIP_PAD_SENTINEL_VALUE` picks the value -- a huge one is
+"optically thick" and can be as harmless as zero; `rand` / `randsign` put DIFFERENT plausible values everywhere (log-uniform
+in 1e-8 .. 1e8), what stale data looks like: a dependence through a difference or a ratio of two padding values (a slope,
+S = eta / chi) vanishes under any constant fill --, and
+`LWHIP_PAD_SENTINEL_INT` puts small valid-looking integers into the index / argument tables.  Under every such fill the parity
+problems (both sweeps, split rays, PRD, hybrid PRD) must still meet the one-call bound against the oracle: a read of padding
+that reaches a result fails here on the first run, deterministically.
+
+The environment is read once per process by the library, so each fill runs the parity tests in a child pytest process.
+`tools/sentinel_hunt.py` is the same loop with one allocation number at a time (which buffer it is, if this ever fails).
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+PARITY = ['tests/test_hip_parity.py::test_lane_sweep_ray_split_vs_oracle', 'tests/test_hip_parity.py::test_iter1_golden',
+          'tests/test_hip_parity.py::test_variants_golden', 'tests/test_hip_parity.py::test_ragged_sizes_vs_oracle',
+          'tests/test_split_order.py', 'tests/test_prd.py', 'tests/test_hprd.py']
+
+
+def _child(env_extra, extra_args=()):
+    env = dict(os.environ)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '--tb=short', '-p', 'no:cacheprovider', '-x']
+                          + PARITY + list(extra_args), cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+
+
+@pytest.mark.parametrize('fill', [{'LWHIP_PAD_SENTINEL_VALUE': 'rand'}, {'LWHIP_PAD_SENTINEL_VALUE': 'randsign', 'LWHIP_PAD_SENTINEL_INT': '2'},
+                                  {}, {'LWHIP_PAD_SENTINEL_VALUE': '1e-3'}],
+                         ids=['random-positive', 'random-signed-and-int-2', '6.7e299', '1e-3'])
+def test_results_do_not_depend_on_padding(gpu, fill):
+    env = {'LWHIP_PAD_SENTINEL': 'all'}
+    env.update(fill)
+    out = _child(env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    m = re.search(r'(\d+) passed', out.stdout)
+    assert m and int(m.group(1)) >= 40, out.stdout[-1000:]
+
+
+def test_the_sentinel_is_applied(gpu):
+    """The mode does what it says: the traced allocations of a parity test carry the sentinel (otherwise the test above
+    would pass vacuously)."""
+    env = dict(os.environ)
+    env.update({'LWHIP_PAD_SENTINEL': 'all', 'LWHIP_PAD_SENTINEL_INT': '1', 'LWHIP_TRACE_ALLOC': '1'})
+    out = subprocess.run([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '-s', '-p', 'no:cacheprovider',
+                          'tests/test_hip_parity.py::test_lane_sweep_ray_split_vs_oracle'], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:]
+    txt = out.stdout + out.stderr
+    assert txt.count(' sentinel') >= 100 and txt.count(' int-sentinel') >= 10, (txt.count(' sentinel'), txt.count(' int-sentinel'))

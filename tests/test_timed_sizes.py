@@ -57,7 +57,7 @@ def test_throughput_grid_iteration_and_stat_equil_vs_oracle(gpu):
 def test_other_sizes_and_sweeps_vs_oracle(gpu, monkeypatch, nla, sweep):
     """The work-distribution regimes of the lane sweep the other tests do not reach -- one partial round with the heaviest
     chunks' rays split (3 840, 5 120 wavelengths), a single round so full that every chunk is cut in two (5 632, 6 144:
-    the LWHIP_LANE_FULL rule), more than one round with a split tail at another size (7 680) -- and the
+    the 85 % rule of lwhip_create), more than one round with a split tail at another size (7 680) -- and the
     ray-column march at the bench size (the fallback kernel, LWHIP_SWEEP=march): one iteration against the oracle, 1e-9."""
     from lightweaver_amd.context import Context
     monkeypatch.setenv('LWHIP_SWEEP', sweep)
