@@ -57,7 +57,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-aux', action='store_true', help='skip the C3 / C4 / C5 side measurements')
     ap.add_argument('--aux', action='store_true', help='(accepted for compatibility: aux entries are on by default)')
-    ap.add_argument('--aux-only', choices=('prd', 'columns', '2d'), default=None,
+    ap.add_argument('--aux-only', choices=('prd', 'columns', '2d', 'fixed', 'realistic'), default=None,
                     help='run only this side measurement and print its entry (for rocprofv3)')
     ap.add_argument('--columns', type=int, default=512, help='columns of the C4 batch')
     ap.add_argument('--backend', default='nccl',
@@ -320,7 +320,51 @@ def aux_2d(args, device, stream, torch, models):
                                        'whole iteration (host clock)')}
 
 
-AUX = {'prd': ('C3_prd', aux_prd), 'columns': ('C4_columns', aux_columns), '2d': ('C5_2d', aux_2d)}
+def aux_fixed_order(args, device, stream, torch, models):
+    """The same workload with Gamma / rates summed in a FIXED order (LWHIP_OPT_DETERMINISTIC: what the Lightweaver plugin
+    selects by default): bit-reproducible iterations, as the reference's schemes are."""
+    from lightweaver_amd.context import Context
+    prob = models.throughput_grid(NlambdaTarget=args.nlambda, Nrays=5, computeProfiles=False)
+    with Context(prob, device=device, stream=stream, deterministic=True) as c:
+        c.compute_profiles(deviceResident=True)
+        for _ in range(100):
+            c.formal_sol_gamma_matrices(deviceResident=True)
+        ms = timed(lambda: c.formal_sol_gamma_matrices(deviceResident=True), 100, torch)
+        kind = c.sweep_kind()
+    return {'config': 'the headline workload in the fixed-order mode (bit-reproducible Gamma / rates)', 'ms_per_step': ms,
+            'iters_per_s': 1e3 / ms, 'sweep': kind}
+
+
+def aux_realistic(args, device, stream, torch, models):
+    """A grid with what real model atoms have and the stock H + Ca II pair lacks: overlapping lines WITH coupled continua --
+    hydrogen and its deuterium-like twin (models.D_6: every Lyman / Balmer line sits inside the other atom's line, so more
+    than half of the wavelengths carry two lines and the bound-free continua coupled to each), three active atoms'
+    continua in the ultraviolet.  Round 4 sent such a context to the march as a whole; the lane sweep now serves it tile
+    by tile (generic kind, wide finish program)."""
+    from lightweaver_amd.context import Context
+    prob = models.throughput_grid(NlambdaTarget=args.nlambda, Nrays=5, realistic=True, computeProfiles=False)
+    import numpy as np
+    lines = np.zeros(prob.Nlambda, dtype=int)
+    for a in prob.atoms:
+        for t in a.trans:
+            if t.alpha is None:
+                lines[t.Nblue:t.Nred] += 1
+    with Context(prob, device=device, stream=stream) as c:
+        c.compute_profiles(deviceResident=True)
+        for _ in range(60):
+            c.formal_sol_gamma_matrices(deviceResident=True)
+        ms = timed(lambda: c.formal_sol_gamma_matrices(deviceResident=True), 60, torch)
+        kind = c.sweep_kind()
+        alg = c.algorithmic_bytes()
+    return {'config': f'FALC 82-depth H(6)+D(6)+CaII(6), 5 mu, {prob.Nlambda} wavelengths: '
+                      f'{int((lines >= 2).sum())} with two overlapping lines, {int((lines == 1).sum())} with one',
+            'ms_per_step': ms, 'iters_per_s': 1e3 / ms, 'sweep': kind,
+            'roofline': roofline_block('lanesweep_kernel (generic tiles: two lines + coupled continua)' if kind == 'lanes'
+                                       else 'raymarch_kernel', alg, ms, 'whole step (host clock)')}
+
+
+AUX = {'prd': ('C3_prd', aux_prd), 'columns': ('C4_columns', aux_columns), '2d': ('C5_2d', aux_2d),
+       'fixed': ('fixed_order', aux_fixed_order), 'realistic': ('realistic_1d', aux_realistic)}
 
 
 def rank_launch_command(ngpus, argv, port=None):
@@ -544,6 +588,9 @@ def main():
             out['allreduce_us'] = allreduce_us
         if weak:
             out.update(weak)
+        for name in ('fixed_order', 'realistic_1d'):
+            if isinstance(aux.get(name), dict) and 'ms_per_step' in aux[name]:
+                aux[name]['ratio_to_headline'] = aux[name]['ms_per_step'] / out['ms_per_step']
         if aux:
             out['aux'] = aux
         if world == 1 and not args.no_cpu_baseline:

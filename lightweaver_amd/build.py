@@ -44,7 +44,10 @@ def build_hip(force=False, verbose=False, defines=(), out=None, extra_flags=()):
         return lib
     objdir = os.path.join(ROOT, 'build', os.path.basename(lib) + '.obj')
     os.makedirs(objdir, exist_ok=True)
-    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + [f'-D{d}' for d in defines] + list(extra_flags)
+    # (-save-temps=obj: the compiler leaves the device listing <unit>-hip-amdgcn-amd-amdhsa-gfx950.s next to the object -- the
+    # listing of exactly the code that ships, for the spill check below)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-save-temps=obj'] + [f'-D{d}' for d in defines] + list(extra_flags)
+    rebuilt = []
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
@@ -53,15 +56,55 @@ def build_hip(force=False, verbose=False, defines=(), out=None, extra_flags=()):
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True, cwd=CSRC)
+            rebuilt.append(src)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, srcs))
+    check_spills(objdir, rebuilt, verbose=verbose)
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
     return lib
+
+
+def check_spills(objdir, sources, verbose=False):
+    """No kernel may reload a spilled register for lanes that were switched off when it was stored (spill_lint.py: what
+    ROCm 7.2's register allocator did to lanesweep_kernel in round 5).  Checked on the listings of the units just compiled;
+    the report of every kernel with spills goes to build/spill_lint.txt.  A reported kernel fails the build: restructure the
+    lane-divergent `if` the report points at (or relieve the register pressure) until it is clean."""
+    from . import spill_lint
+    from concurrent.futures import ProcessPoolExecutor
+    lst = []
+    for src in sources:
+        s = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+        if os.path.exists(s):
+            lst.append(s)
+    if not lst:
+        return
+    with ProcessPoolExecutor(max_workers=min(len(lst), os.cpu_count() or 1)) as ex:
+        res = list(ex.map(_lint_one, lst))
+    lines, nbad = [], 0
+    for path, bad, report in res:
+        nbad += bad
+        for kernel, nsp, nslots in report:
+            lines.append(f'{os.path.basename(path)}: {kernel}: {nsp} spill stores (dwords), {nslots} slot(s) reported')
+    with open(os.path.join(os.path.dirname(objdir), 'spill_lint.txt'), 'a') as f:
+        f.write('\n'.join(lines) + '\n')
+    if verbose:
+        print('\n'.join(l for l in lines if not l.endswith(' 0 slot(s) reported')) or 'spill check: clean')
+    if nbad:
+        raise RuntimeError('spill check: %d slot(s) of spilled registers are stored with lanes switched off and reloaded for more lanes '
+                           '(python -m lightweaver_amd.spill_lint <listing under %s> for the lines):\n%s'
+                           % (nbad, objdir, '\n'.join(l for l in lines if not l.endswith(' 0 slot(s) reported'))))
+
+
+def _lint_one(path):
+    from . import spill_lint
+    report = []
+    bad = spill_lint.lint_file(path, quiet=True, report=report)
+    return path, bad, report
 
 
 def build_plugin(force=False, verbose=False):

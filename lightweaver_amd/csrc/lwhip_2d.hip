@@ -100,7 +100,7 @@ hipError_t launch_cont_range(const ContArgs* devArgs, const ContArgs& a, int con
             return err;
     }
     const int ky = std::max(1, std::min(256, (a.Ns + T - 1) / T));
-    hipLaunchKernelGGL(cont_kernel, dim3(nCont, ky), dim3(T), lds, stream, devArgs, contOff, rowsBase);
+    LWHIP_LAUNCH(cont_kernel, dim3(nCont, ky), dim3(T), lds, stream, devArgs, contOff, rowsBase);
     return hipGetLastError();
 }
 #undef ARGS
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(256) iout2d_kernel(const Batch2dArgs a)
 hipError_t launch_iout2d(const Batch2dArgs& a, hipStream_t stream)
 {
     const int n = (a.storeDepth || a.zUp || a.zDown) ? a.Ns : a.Nx;
-    hipLaunchKernelGGL(iout2d_kernel, dim3((n + 255) / 256, a.nRaysActive, a.nLa), dim3(256), 0, stream, a);
+    LWHIP_LAUNCH(iout2d_kernel, dim3((n + 255) / 256, a.nRaysActive, a.nLa), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -647,7 +647,7 @@ hipError_t launch_sum_groups(double* red, size_t n, size_t stride, int G, hipStr
 {
     if (G <= 1 || n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, red,
+    LWHIP_LAUNCH(sum_groups_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, red,
                        n, stride, G);
     return hipGetLastError();
 }
@@ -656,11 +656,11 @@ hipError_t launch_gather2d(const Batch2dArgs& a, int maxL, hipStream_t stream)
 {
     const dim3 grid((a.Ns + 255) / 256, a.nLa);
     if (maxL <= 2)
-        hipLaunchKernelGGL(gather2d_kernel<2>, grid, dim3(256), 0, stream, a);
+        LWHIP_LAUNCH(gather2d_kernel<2>, grid, dim3(256), 0, stream, a);
     else if (maxL <= 4)
-        hipLaunchKernelGGL(gather2d_kernel<4>, grid, dim3(256), 0, stream, a);
+        LWHIP_LAUNCH(gather2d_kernel<4>, grid, dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(gather2d_kernel<8>, grid, dim3(256), 0, stream, a);
+        LWHIP_LAUNCH(gather2d_kernel<8>, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -672,17 +672,17 @@ hipError_t launch_rates2d(const Batch2dArgs& a, int maxL, int maxM, int maxP, hi
     const size_t lds = (size_t)std::max(a.maxRowsLa, 1) * 128 * sizeof(double) + 64 * (sizeof(double) + sizeof(int))
                        + (size_t)((maxL <= 2 ? 2 : (maxL <= 4 ? 4 : 8)) + 4 + 8) * sizeof(DevSlot);
     if (maxL <= 2 && maxM <= 1 && maxP <= 5)
-        hipLaunchKernelGGL((rates2d_kernel<2, 1, 5>), grid, dim3(128), lds, stream, a);
+        LWHIP_LAUNCH((rates2d_kernel<2, 1, 5>), grid, dim3(128), lds, stream, a);
     else if (maxL <= 2 && maxM <= 2 && maxP <= 5)
-        hipLaunchKernelGGL((rates2d_kernel<2, 2, 5>), grid, dim3(128), lds, stream, a);
+        LWHIP_LAUNCH((rates2d_kernel<2, 2, 5>), grid, dim3(128), lds, stream, a);
     else if (maxL <= 2)
-        hipLaunchKernelGGL((rates2d_kernel<2, 4, 8>), grid, dim3(128), lds, stream, a);
+        LWHIP_LAUNCH((rates2d_kernel<2, 4, 8>), grid, dim3(128), lds, stream, a);
     else if (maxL <= 4 && maxM <= 2 && maxP <= 5)
-        hipLaunchKernelGGL((rates2d_kernel<4, 2, 5>), grid, dim3(128), lds, stream, a);
+        LWHIP_LAUNCH((rates2d_kernel<4, 2, 5>), grid, dim3(128), lds, stream, a);
     else if (maxL <= 4)
-        hipLaunchKernelGGL((rates2d_kernel<4, 4, 8>), grid, dim3(128), lds, stream, a);
+        LWHIP_LAUNCH((rates2d_kernel<4, 4, 8>), grid, dim3(128), lds, stream, a);
     else
-        hipLaunchKernelGGL((rates2d_kernel<8, 4, 8>), grid, dim3(128), lds, stream, a);
+        LWHIP_LAUNCH((rates2d_kernel<8, 4, 8>), grid, dim3(128), lds, stream, a);
     return hipGetLastError();
 }
 }

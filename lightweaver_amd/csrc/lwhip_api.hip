@@ -159,7 +159,17 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
     if (c->tablesFrom)
         c->tablesFrom->borrowers++;
     const auto t1 = now();
-    st = alloc_state(c);
+    {
+        // (the state allocations' clearing fills queue up on the null stream; one wait for all of them)
+        struct Defer
+        {
+            Defer() { ++devbuf_defer_fill_sync(); }
+            ~Defer() { --devbuf_defer_fill_sync(); }
+        } defer;
+        st = alloc_state(c);
+        if (hipStreamSynchronize(nullptr) != hipSuccess && st == LWHIP_OK)
+            st = fail(LWHIP_ERR_DEVICE, "lwhip_create: clearing the state allocations failed");
+    }
     if (st != LWHIP_OK)
         return bail(st);
     st = build_sweep_args(c);
@@ -295,7 +305,10 @@ ReduceArgs make_reduce_args(lwhip_context* c)
     ReduceArgs r{};
     r.Ns = c->Ns;
     r.Ntrans = c->Ntrans;
-    r.red8 = c->red8.p;
+    // (fixed-order mode: the "parts" are the segment sums of the slab reduce, in segment order)
+    const bool detParts = c->laneSweep && c->deterministic && !c->is2d;
+    r.red8 = detParts ? c->detPart.p : c->red8.p;
+    r.nParts = detParts ? (int)LWHIP_DET_SEG : (int)LWHIP_REDUCE_SPLIT;
     r.red = c->red.p;
     r.dJ = c->dJ.p;
     r.Nla = c->Nla;
@@ -407,7 +420,10 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
         {
             a.fromParts = 1;
             a.zeroParts = c->atomicParts ? 1 : 0;
-            a.red8 = c->red8.p;
+            a.red8 = (c->laneSweep && c->deterministic) ? c->detPart.p : c->red8.p;
+            a.nParts = (c->laneSweep && c->deterministic) ? (int)LWHIP_DET_SEG : (int)LWHIP_REDUCE_SPLIT;
+            if (c->laneSweep && c->deterministic)
+                a.zeroParts = 0; // (the segment sums are rewritten by every slab reduce)
             a.dJ = c->dJ.p;
             a.NlaDj = c->Nla;
             a.idxOffset = c->laStart;

@@ -96,6 +96,9 @@ int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
             return fail(LWHIP_ERR_INVALID, "batch_create: null context");
         if (c->is2d || c->worldSize != 1)
             return fail(LWHIP_ERR_UNSUPPORTED, "batch_create: columns are 1D, unsharded contexts");
+        if (c->deterministic)
+            return fail(LWHIP_ERR_UNSUPPORTED, "batch_create: the fused batch sums by atomics (a context made with LWHIP_OPT_DETERMINISTIC "
+                                               "iterates on its own)");
         if (c->device != c0->device || c->Ns != c0->Ns || c->Nla != c0->Nla
             || c->Nrays != c0->Nrays || c->Ntrans != c0->Ntrans || c->Natom != c0->Natom || c->nTiles != c0->nTiles
             || c->nTileChunks != c0->nTileChunks || c->nPostChunks != c0->nPostChunks || c->tileCap != c0->tileCap

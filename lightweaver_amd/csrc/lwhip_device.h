@@ -4,6 +4,14 @@
 
 #include <hip/hip_runtime.h>
 
+// every kernel of the library is launched through this: under LWHIP_SCRATCH_POISON the scratch memory is poisoned first
+#define LWHIP_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                        \
+    do                                                                                                                             \
+    {                                                                                                                              \
+        ::lwhip::dbg_scratch_poison(stream);                                                                                       \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                         \
+    } while (0)
+
 namespace lwhip
 {
 #define DEVINL __device__ __forceinline__
@@ -164,7 +172,11 @@ DEVINL void dbg_poison_lds()
     const unsigned bytes = ((const unsigned*)__builtin_amdgcn_dispatch_ptr())[7];
     const unsigned nT = blockDim.x * blockDim.y * blockDim.z;
     const unsigned t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+#ifdef LWHIP_DBG_POISON_LDS_FINITE /* NaN is swallowed by the fmin / fmax of the Steffen derivative: a finite value is not */
+    const unsigned long long pat = (unsigned long long)__double_as_longlong(1.0e-3 * (double)(1 + (t & 7)));
+#else
     const unsigned long long pat = 0x7ff8dead0000beefull;
+#endif
     for (unsigned o = t * 8u; o + 8u <= bytes; o += nT * 8u)
         asm volatile("ds_write_b64 %0, %1" ::"v"(o), "v"(pat) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -577,9 +577,9 @@ __global__ void __launch_bounds__(64) fs2d_scan_kernel(const Fs2dArgs a)
 template <int D> static void launch_scan(const Fs2dArgs& a, int nSolve, size_t lds, hipStream_t stream)
 {
     if (a.Nx == 64 * D)
-        hipLaunchKernelGGL((fs2d_scan_kernel<D, true>), dim3(nSolve), dim3(64), lds, stream, a);
+        LWHIP_LAUNCH((fs2d_scan_kernel<D, true>), dim3(nSolve), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL((fs2d_scan_kernel<D, false>), dim3(nSolve), dim3(64), lds, stream, a);
+        LWHIP_LAUNCH((fs2d_scan_kernel<D, false>), dim3(nSolve), dim3(64), lds, stream, a);
 }
 
 bool fs2d_records_packed(const lwhip_intersection* rec, size_t n, int Nx, int Nz, std::vector<double>& s, std::vector<int32_t>& w)
@@ -631,11 +631,11 @@ hipError_t launch_fs2d(const Fs2dArgs& a, int nSolve, hipStream_t stream)
     const dim3 grid1(nSolve / a.nRayCycle, a.nRayCycle, (Ns + 255) / 256);
     if (a.lcBuf && a.NlongChar > 0)
     {
-        hipLaunchKernelGGL(fs2d_longchar_kernel, dim3((a.NlongChar + 63) / 64, nSolve / a.nRayCycle), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL(fs2d_coef_kernel<false>, grid1, dim3(256), 0, stream, a);
+        LWHIP_LAUNCH(fs2d_longchar_kernel, dim3((a.NlongChar + 63) / 64, nSolve / a.nRayCycle), dim3(64), 0, stream, a);
+        LWHIP_LAUNCH(fs2d_coef_kernel<false>, grid1, dim3(256), 0, stream, a);
     }
     else
-        hipLaunchKernelGGL(fs2d_coef_kernel<true>, grid1, dim3(256), 0, stream, a);
+        LWHIP_LAUNCH(fs2d_coef_kernel<true>, grid1, dim3(256), 0, stream, a);
     const size_t lds = ((size_t)a.Nx + 1) * sizeof(double);
     const int D = (a.Nx + 63) / 64;
     if (D <= 1)

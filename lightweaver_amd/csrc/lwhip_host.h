@@ -44,6 +44,14 @@ int fail(int code, const std::string& msg);
             return fail(LWHIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(err__));       \
     } while (0)
 
+// > 0: the clearing fills of DevBuf::alloc are queued, not waited for: whoever raised it synchronises the null stream before
+// anything touches the buffers (lwhip_create: 0.7 s less per 512 columns than a wait per allocation)
+inline int& devbuf_defer_fill_sync()
+{
+    static thread_local int depth = 0;
+    return depth;
+}
+
 template <typename T> struct DevBuf
 {
     T* p = nullptr;
@@ -139,8 +147,10 @@ template <typename T> struct DevBuf
             what = " cleared";
         }
         static const bool syncAlloc = std::getenv("LWHIP_SYNC_ALLOC") != nullptr; // (diagnosis: round 4's clearing minus the clearing)
-        if (e == hipSuccess && (*what || syncAlloc))
-            e = hipStreamSynchronize(nullptr); // (the caller's stream may be a non-blocking one: no implicit order with this)
+        // (the caller's stream may be a non-blocking one: no implicit order with the fill -- wait for it, or, inside lwhip_create,
+        // let the ~60 fills of a context queue up and wait once before the first upload: defer_fill_sync)
+        if (e == hipSuccess && ((*what && devbuf_defer_fill_sync() == 0) || syncAlloc))
+            e = hipStreamSynchronize(nullptr);
         static const bool trace = std::getenv("LWHIP_TRACE_ALLOC") != nullptr; // diagnosis: which buffer a number / an address is
         if (trace)
             std::fprintf(stderr, "lwhip alloc #%d %p .. %p (%zu x %zu B)%s\n", seq, (void*)p, (void*)((char*)p + count * sizeof(T)), count, sizeof(T),
@@ -194,7 +204,7 @@ template <typename T> struct DevBuf
         if (!p || sentinel_on())
             return hipSuccess;
         hipError_t e = hipMemset(p, 0, n * sizeof(T));
-        return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
+        return (e == hipSuccess && devbuf_defer_fill_sync() == 0) ? hipStreamSynchronize(nullptr) : e;
     }
     // a window of somebody else's allocation (the depth arena of the lane sweep)
     void view(T* ptr, size_t count)
@@ -340,6 +350,8 @@ struct lwhip_context
     DevBuf<double> laneFinPar, bcPlanck;
     DevBuf<uint8_t> laneFeedG;    // generic tiles of the lane sweep: continuum -> slot feed bytes
     int nGenTiles = 0;
+    DevBuf<double> momScratch;    // ... and the moment scratch of their wavefronts (TileArgs::momS)
+    int momA = 0;
     DevBuf<int32_t> chunkSplit;   // lane sweep: per chunk, the wavefronts its tiles' rays are split over (the launch's tail)
     DevBuf<int32_t> chunkTile, chunkTilePrd, tileListPrd, tileSlotTr, tileSlotTrPrd, postChunkTile, postChunkTilePrd, postSlotTr,
         postCs;

@@ -325,6 +325,8 @@ struct TileArgs
     const double* laneFinPar;      // [nTiles][LWHIP_POST_MAXC][L][3]: alpha, w_lambda / lambda 4 pi / h, 2hc / lambda^3 of (continuum, wavelength)
     const double* bcPlanck;        // [Nla][4]: Planck function of the wavelength at depths 0, 1, Ns - 2, Ns - 1 (thermalised boundaries)
     const uint8_t* laneFeedG;      // generic tiles: [gen][LWHIP_POST_MAXC][LWHIP_GEN_MAXS] which rows of slot e continuum q feeds (DevLaneFin::feed's byte)
+    double* momS;                  // generic tiles: the moment scratch, [workgroup of the launch][wavefront][momA][laneD][64] (null: no generic tile)
+    int32_t momA, _padM;           // arrays per wavefront: the most any generic tile needs (4 (nL - 1) + nL (nL - 1) / 2 moments + 4 nL coefficients)
     double* detSlab;               // deterministic mode: [workgroup][maxCT][4][Ns] partial sums (no atomics), else null
     double* lsDbg;                 // diagnostic builds (-DLS_TIMING): [nTiles][8] phase clocks, host-mapped; else null
 };
@@ -358,8 +360,11 @@ bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R
 size_t lane_sweep_lds_bytes(const TileArgs& a, int waves);
 hipError_t launch_lane_sweep(const TileArgs* devArgs, const TileArgs& hostArgs, const TileDyn& dyn, int solver, bool rates,
                              int nChunks, int waves, const TileArgs* const* apList, int nBatch, hipStream_t stream);
-hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, double* part, int Ns, int Ntrans,
-                             hipStream_t stream);
+// Diagnosis (LWHIP_DEBUG=1 LWHIP_SCRATCH_POISON=1): fills every wavefront slot's private-segment ("scratch") memory with a
+// finite pattern in front of a kernel launch (lwhip_lanesweep.hip: scratch_poison_kernel).  Nothing otherwise.
+void dbg_scratch_poison(hipStream_t stream);
+hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* part, int Ns, int Ntrans,
+                             hipStream_t stream); // -> part[Ntrans][LWHIP_DET_SEG][4][Ns]: read like red8 with nParts = LWHIP_DET_SEG
 size_t det_reduce_scratch_doubles(int Ns, int Ntrans); // `part`: the partial sums of the fixed-shape reduction
 hipError_t launch_retile(const RetileArgs& a, hipStream_t stream);
 hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostList, int n, hipStream_t stream);
@@ -371,6 +376,7 @@ hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostL
 #define LWHIP_REDUCE_SPLIT_N 4
 #endif
 enum { LWHIP_REDUCE_SPLIT = LWHIP_REDUCE_SPLIT_N };
+enum { LWHIP_DET_SEG = 32 }; // fixed-order mode: segments of a transition's slab list that are summed in parallel (lwhip_lanesweep.hip)
 struct ReduceArgs
 {
     int32_t Ns, Ntrans;
@@ -379,7 +385,9 @@ struct ReduceArgs
     const double* dJ;              // [Nla] per-wavelength dJ of this shard
     int32_t Nla, idxOffset, world, rank;
     double* batchTail;             // column batches: this column's (dJMax, idx) slot of the batch's read-back buffer
-    int32_t zeroParts, _padR;      // stage 2 zeroes the parts it has summed (they were accumulated by atomics)
+    int32_t zeroParts;             // stage 2 zeroes the parts it has summed (they were accumulated by atomics)
+    int32_t nParts;                // parts per transition in red8: LWHIP_REDUCE_SPLIT, or -- fixed-order mode -- the LWHIP_DET_SEG
+                                   // segment sums of the slab reduce (red8 then points at them)
 };
 
 struct ApplyArgs
@@ -418,7 +426,8 @@ struct ApplyArgs
     // PRD sub-iteration on one device (round 5): the apply launch also reduces every PRD line's per-(depth, slice) maxima of
     // |d rho / rho| (what prd_change_kernel does as a launch of its own on shards): nPrdChange extra workgroups
     const struct PrdLineArgs* prdList;
-    int32_t nPrdChange, _padA;
+    int32_t nPrdChange;
+    int32_t nParts;                // parts per transition behind red8 (see ReduceArgs::nParts); 0: LWHIP_REDUCE_SPLIT
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)

@@ -137,10 +137,10 @@ template <class A> DEVINL void reduce_stage2_kernel_body(const A& a)
     for (int idx = threadIdx.x; idx < n4; idx += blockDim.x)
     {
         double s = 0.0;
-#pragma unroll
-        for (int part = 0; part < LWHIP_REDUCE_SPLIT; ++part)
+        const int nParts = a.nParts > 0 ? a.nParts : (int)LWHIP_REDUCE_SPLIT;
+        for (int part = 0; part < nParts; ++part)
         {
-            const size_t o = ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + idx;
+            const size_t o = ((size_t)tr * nParts + part) * n4 + idx;
             s += a.red8[o];
             if (a.zeroParts)
                 a.red8[o] = 0.0;
@@ -162,9 +162,9 @@ __global__ void __launch_bounds__(512) reduce_stage2_kernel(const ReduceArgs a0,
 hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream, const ReduceArgs* list, int nBatch)
 {
     if (list)
-        hipLaunchKernelGGL(reduce_stage2_kernel<true>, dim3(a.Ntrans + 1, 1, std::max(nBatch, 1)), dim3(512), 0, stream, a, list);
+        LWHIP_LAUNCH(reduce_stage2_kernel<true>, dim3(a.Ntrans + 1, 1, std::max(nBatch, 1)), dim3(512), 0, stream, a, list);
     else
-        hipLaunchKernelGGL(reduce_stage2_kernel<false>, dim3(a.Ntrans + 1), dim3(512), 0, stream, a, list);
+        LWHIP_LAUNCH(reduce_stage2_kernel<false>, dim3(a.Ntrans + 1), dim3(512), 0, stream, a, list);
     return hipGetLastError();
 }
 
@@ -220,6 +220,21 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
             return a.red[((size_t)tr * 4 + q) * Ns + k];
         double s = 0.0;
         double* r8 = const_cast<double*>(a.red8);
+        if (a.nParts > 0 && a.nParts != (int)LWHIP_REDUCE_SPLIT)
+        {
+            // (fixed-order mode: the segment sums of the slab reduce, in segment order; eight loads in flight)
+            for (int p0 = 0; p0 < a.nParts; p0 += 8)
+            {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = p0 + u < a.nParts ? r8[(((size_t)tr * a.nParts + p0 + u) * 4 + q) * Ns + k] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    s += v[u];
+            }
+            return s;
+        }
 #pragma unroll
         for (int part = 0; part < LWHIP_REDUCE_SPLIT; ++part)
         {
@@ -371,16 +386,16 @@ __global__ void __launch_bounds__(APPLY_T) apply_kernel(const ApplyArgs a0, cons
 hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs* list, int nBatch)
 {
     if (list)
-        hipLaunchKernelGGL(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(APPLY_T), 0,
+        LWHIP_LAUNCH(apply_kernel<true>, dim3(a.Natom + 1, (a.Ns + APPLY_K - 1) / APPLY_K, std::max(nBatch, 1)), dim3(APPLY_T), 0,
                            stream, a, list);
     else
     {
         // (+ the dJMax workgroup, + one workgroup per PRD line whose change is reduced here)
         const int nx = a.nPrdChange > 0 ? a.Natom + 2 + a.nPrdChange : a.Natom + 1 + ((a.dJ || a.gatherWorld) ? 1 : 0);
         if (a.Ns >= 2048)
-            hipLaunchKernelGGL((apply_kernel<false, APPLY_K_WIDE>), dim3(nx, (a.Ns + APPLY_K_WIDE - 1) / APPLY_K_WIDE), dim3(APPLY_T), 0, stream, a, list);
+            LWHIP_LAUNCH((apply_kernel<false, APPLY_K_WIDE>), dim3(nx, (a.Ns + APPLY_K_WIDE - 1) / APPLY_K_WIDE), dim3(APPLY_T), 0, stream, a, list);
         else
-            hipLaunchKernelGGL(apply_kernel<false>, dim3(nx, (a.Ns + APPLY_K - 1) / APPLY_K), dim3(APPLY_T), 0, stream, a, list);
+            LWHIP_LAUNCH(apply_kernel<false>, dim3(nx, (a.Ns + APPLY_K - 1) / APPLY_K), dim3(APPLY_T), 0, stream, a, list);
     }
     return hipGetLastError();
 }
@@ -403,7 +418,7 @@ hipError_t launch_check_zero(const double* p, size_t n, int* counter, hipStream_
     if (!n)
         return hipSuccess;
     const int blocks = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(check_zero_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, p, n, counter);
+    LWHIP_LAUNCH(check_zero_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, p, n, counter);
     return hipGetLastError();
 }
 
@@ -418,7 +433,7 @@ __global__ void prefill_kernel(double* G, const double* C, double crsw, size_t n
 hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n, hipStream_t stream)
 {
     const int blocks = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(prefill_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, Gamma, C, crsw, n);
+    LWHIP_LAUNCH(prefill_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, Gamma, C, crsw, n);
     return hipGetLastError();
 }
 

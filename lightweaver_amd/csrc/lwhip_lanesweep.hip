@@ -26,6 +26,7 @@
 // piecewise_bezier3_1d FormalScalar.cpp:209-325, Bezier.hpp:58-127, w2 LwInternal.hpp:90-110.
 #include "lwhip_device.h"
 #include <atomic>
+#include <cstdlib>
 #include "../../include/lwhip.h"
 
 #include <algorithm>
@@ -163,8 +164,13 @@ enum { LS_MAX_WAVES = 8, LS_MAX_R = 16 };
 // arithmetic where it is used) is a GENERIC pointer to the compiler otherwise, and the adds become flat_atomic_add_f64 -- correct,
 // but ~750 clocks each once somebody waits for them (the fixed-order mode hands a slot on only when its adds are complete:
 // measured 12 k clocks per hand-over against ~1 k with ds_add_f64).
+#ifdef LS_FLAT_ACC /* diagnostic build: rounds 3 and 4's generic pointer -- flat_atomic_add_f64 -- for the slots' adds */
+typedef double ls_lds_double;
+DEVINL void ls_lds_add(ls_lds_double* addr, double v) { unsafeAtomicAdd(addr, v); }
+#else
 typedef __attribute__((address_space(3))) double ls_lds_double;
 DEVINL void ls_lds_add(ls_lds_double* addr, double v) { (void)__hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
 #define LS_KEEP(v) asm volatile("" : "+v"(v)) /* the value is computed here, on every lane (keeps selects branch-free) */
 #define LS_KEEPI(v) asm volatile("" : "+v"(v))
 #define LS_KEEPS(v)                                                                                                                        \
@@ -294,12 +300,10 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     // populations from LDS ray by ray and the moments re-read the profiles (an L1 hit) instead of holding cx / ce / phi.
     // Blends are rare (28 of 3 429 tiles on the bench grid); they pay twice the ray work, the other kinds nothing.
     // NL < 0: the GENERIC kind (round 5) -- any number of lines (<= 8) and mixed continua (<= 8), for the tiles no compiled kind
-    // covers.  It generalises the blend: the gather walks all lines of the tile per ray (a uniform loop over the tile's slot
-    // records), the rays are walked once per RUN, and a run accumulates the moments of ONE line a (P0, P1, Q_a, Q_aa; first
-    // run of that line only) and its cross moment Q_ab with ONE partner b.  Every integral is linear in the moments, so
-    // after each run every slot adds what that run's moments contribute (gen_slot_finish).  Runs: one per line with its
-    // cyclic neighbour as partner, then the remaining pairs -- max(nL, nL (nL - 1) / 2) for nL >= 3.  Rare tiles (none on
-    // the benchmark grid) pay several times the ray work; nothing else changes.  Not for hybrid PRD (rates ray by ray).
+    // covers.  The gather walks all lines of the tile per ray (a uniform loop over the tile's slot records); the rays are
+    // walked ONCE, whatever the number of lines: the moments that do not fit the registers live in a scratch block in global
+    // memory (below); after the last ray every slot's integrals are formed from all of them (gen_slot_finish).  Not for
+    // hybrid PRD (rates ray by ray).
     constexpr bool GEN = NL < 0;
     static_assert(!(GEN && HPRD), "the generic kind forms its rates from the angle moments");
     constexpr bool HOLD = !HPRD && !GEN && NL < 2;
@@ -315,35 +319,20 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
 #ifdef LS_TIMING
     unsigned long long lsTurnExit = 0; // (when the wavefront left its first turn wait: the critical section's length is reported)
 #endif
-    int gA = -1, gB = -1;     // the run's line and partner (slot ordinals), uniform
-    bool gNewA = false;       // the run accumulates the line's own moments
-    auto gen_runs = [&]() { return gnL <= 2 ? (gnL < 1 ? 1 : gnL) : gnL * (gnL - 1) / 2; };
-    auto gen_set_run = [&](const int r) {
-        gA = gB = -1;
-        gNewA = false;
-        if (gnL <= 0)
-            return;
-        if (r < gnL)
-        {
-            gA = r;
-            gNewA = true;
-            gB = gnL == 1 ? -1 : gnL == 2 ? (r == 0 ? 1 : -1) : (r + 1) % gnL;
-            return;
-        }
-        // the pairs (i < j) that are not cyclic neighbours, in order
-        int q = r - gnL;
-        for (int i = 0; i < gnL; ++i)
-            for (int j = i + 2; j < gnL; ++j)
-            {
-                if (i == 0 && j == gnL - 1)
-                    continue;
-                if (q-- == 0)
-                {
-                    gA = i;
-                    gB = j;
-                    return;
-                }
-            }
+    // The moments of a generic tile: line 0's in the registers every kind uses (mP0, mP1, mQ1, mQ2), those of the further lines
+    // and every cross moment in the wavefront's block of the moment scratch in global memory (TileArgs::momS), updated ray by
+    // ray by the lane that owns them (an L1 / L2 resident read-modify-write: 20 doubles per lane and ray for two lines --
+    // against walking the rays once more per further line, which is what round 5's first version did).  Arrays, each [D][64]:
+    //   line l >= 1:  4 (l - 1) + { P0, P1, Q, Q_ll }        pair m < l:  4 (nL - 1) + l (l - 1) / 2 + m  (Q_ml)
+    //   then, filled by the slots' integrals: per line l { c2, cu, cx, ce } of the point being finished
+    GLOBAL_AS double* gMom = nullptr;
+    bool gFirstRay = true; // (the first ray of the tile stores, the others add: the scratch needs no clearing)
+    if (GEN && a.momS)
+        gMom = (GLOBAL_AS double*)a.momS + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * ((size_t)a.momA * D * 64) + c.lane;
+    const int gPairBase = 4 * (gnL - 1), gCoefBase = gPairBase + gnL * (gnL - 1) / 2;
+    auto gm_add = [&](const int arr, const int p, const double v) {
+        GLOBAL_AS double* q = gMom + (size_t)(arr * D + p) * 64;
+        *q = gFirstRay ? v : *q + v;
     };
     const int Ns = c.Ns, Nmu = c.Nmu, LR = c.LR;
     const int la = c.la, k0 = c.k0;
@@ -521,7 +510,10 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     // boundary intensities of the rays (wrappers FormalScalar.cpp:471-666): Planck functions of the two end points of
     // this lane's wavelength, parked in the wavefront's LDS row (read by the lane that holds a ray's first point)
     // (the host's table: once per atmosphere and wavelength, not per task)
-    if (c.blk == 0 && c.rRaw < LS_MAX_R)
+    // (EVERY lane of a ray writes the ray's four values -- the same ones, to the same address: no lane-divergent `if` here.
+    // The register allocator of ROCm 7.2 put spill stores at the top of the block that joined this `if`, in front of the
+    // instruction that switches the other lanes back on: stored for three lanes, reloaded for 64 -- tools/spill_lint.py.)
+    // (c.rRaw < LS_MAX_R for every lane: LR >= 4 lanes per ray, lane_sweep_supported)
     {
         const GLOBAL_AS double* bp = GCD(a.bcPlanck) + (size_t)la * 4;
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
@@ -646,8 +638,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             if constexpr (GEN)
             {
                 // every line of the tile: Transition::uv + chi_eta_aux_accum (LwTransition.hpp:93-144, :59-109)
-                for (int l = 0; l < gnL; ++l)
-                {
+                auto gather_line = [&](const int l) {
                     const DevTileSlot u = ld_c(gSlots + l);
                     double phi[D], ni[D], nj[D], rho[D];
                     ls_lds<D>(sDep, vK, c.oN + (unsigned)u.gi * Ns8, ni);
@@ -672,7 +663,14 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                         cC[p] += ni[p] * v1 - nj[p] * v2;
                         eC[p] += nj[p] * uji;
                     }
-                }
+                };
+                // (the first two lines as straight-line code -- their loads are in flight together --, further ones in a loop)
+                if (gnL > 0)
+                    gather_line(0);
+                if (gnL > 1)
+                    gather_line(1);
+                for (int l = 2; l < gnL; ++l)
+                    gather_line(l);
             }
 #pragma unroll
             for (int s = 0; s < NLc; ++s)
@@ -1110,32 +1108,68 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                     mW += hw;
                 if constexpr (GEN)
                 {
-                    if (gA >= 0)
+                    if (gnL > 0)
                     {
-                        // the run's line a and partner b (the ray's profiles again: an L1 hit)
-                        double ph[D], phB[D];
-                        ls_gld<D>(a.phi + ld_c(gSlots + gA).phiOff, vPhi0, sRay, ph);
-                        if (gB >= 0)
-                            ls_gld<D>(a.phi + ld_c(gSlots + gB).phiOff, vPhi0, sRay, phB);
-                        else
-                        {
-#pragma unroll
-                            for (int p = 0; p < D; ++p)
-                                phB[p] = 0.0;
-                        }
-                        const double own = gNewA ? 1.0 : 0.0;
+                        // (the ray's profiles again: an L1 hit)
+                        double ph0[D];
+                        ls_gld<D>(a.phi + ld_c(gSlots + 0).phiOff, vPhi0, sRay, ph0);
 #pragma unroll
                         for (int p = 0; p < D; ++p)
                         {
                             const int i = MI(p);
-                            const double wa = (own * hw) * ph[p], wb = wPsi[i] * ph[p];
+                            const double wa = hw * ph0[p], wb = wPsi[i] * ph0[p];
                             mP0[p] += wa;
                             mP1[p] = fma(wa, Iv[i], mP1[p]);
-                            mQ1[p] = fma(own, wb, mQ1[p]);
-                            mQ2[p] = fma(own * wb, ph[p], mQ2[p]);
-                            mQ12[p] = fma(wb, phB[p], mQ12[p]);
+                            mQ1[p] += wb;
+                            mQ2[p] = fma(wb, ph0[p], mQ2[p]);
+                        }
+                        if (gnL > 1)
+                        {
+                            // line 1 and its pair with line 0: the five arrays' old values requested together, then stored
+                            double ph1[D], old[5][D];
+                            ls_gld<D>(a.phi + ld_c(gSlots + 1).phiOff, vPhi0, sRay, ph1);
+#pragma unroll
+                            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                                for (int p = 0; p < D; ++p)
+                                    old[k][p] = gFirstRay ? 0.0 : gMom[(size_t)(((k < 4 ? k : gPairBase)) * D + p) * 64];
+#pragma unroll
+                            for (int p = 0; p < D; ++p)
+                            {
+                                const int i = MI(p);
+                                const double wa = hw * ph1[p], wb = wPsi[i] * ph1[p];
+                                gMom[(size_t)(0 * D + p) * 64] = old[0][p] + wa;
+                                gMom[(size_t)(1 * D + p) * 64] = fma(wa, Iv[i], old[1][p]);
+                                gMom[(size_t)(2 * D + p) * 64] = old[2][p] + wb;
+                                gMom[(size_t)(3 * D + p) * 64] = fma(wb, ph1[p], old[3][p]);
+                                gMom[(size_t)(gPairBase * D + p) * 64] = fma(wb, ph0[p], old[4][p]);
+                            }
+                        }
+                        for (int l = 2; l < gnL; ++l)
+                        {
+                            double phl[D];
+                            ls_gld<D>(a.phi + ld_c(gSlots + l).phiOff, vPhi0, sRay, phl);
+#pragma unroll
+                            for (int p = 0; p < D; ++p)
+                            {
+                                const int i = MI(p);
+                                const double wa = hw * phl[p], wb = wPsi[i] * phl[p];
+                                gm_add(4 * (l - 1) + 0, p, wa);
+                                gm_add(4 * (l - 1) + 1, p, wa * Iv[i]);
+                                gm_add(4 * (l - 1) + 2, p, wb);
+                                gm_add(4 * (l - 1) + 3, p, wb * phl[p]);
+                            }
+                            for (int m = 0; m < l; ++m)
+                            {
+                                double phm[D];
+                                ls_gld<D>(a.phi + ld_c(gSlots + m).phiOff, vPhi0, sRay, phm);
+#pragma unroll
+                                for (int p = 0; p < D; ++p)
+                                    gm_add(gPairBase + l * (l - 1) / 2 + m, p, (wPsi[MI(p)] * phl[p]) * phm[p]);
+                            }
                         }
                     }
+                    gFirstRay = false;
                 }
                 else if (NL > 0)
                 {
@@ -1385,11 +1419,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     // for formal_sol's upOnly) -- all of them, or this wavefront's share when the tile's rays are split over S wavefronts
     // (written as the loop over mu with its two directions guarded, not as a loop over q with a direction branch: the
     // latter makes the compiler hoist three dozen registers of addresses and flags in front of the loop, and spill)
-    const int nRun = GEN ? gen_runs() : NRUN;
+    const int nRun = NRUN;
     for (run = 0; run < nRun; ++run)
     {
-    if constexpr (GEN)
-        gen_set_run(run);
     prefetch_first();
 #ifdef LS_ABL_NO_RAYS
     if (dyn.nPass == 77)
@@ -1650,101 +1682,95 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                 }
             }
         };
-        // ---- the generic kind: what this run's moments contribute to every slot of the tile, a point at a time -------------
-        // With the run's line a and partner b (coefficients c2, cu, cx, ce per unit profile as above), a slot's level sums are
-        // X = X0 + X_a phi_a + X_b phi_b + (lines of other runs), and of L, L_s, B above this run holds the terms in
-        //   M1, J, W (run 0)      Q_a, Q_aa, P0_a, P1_a (the run in which a is new; zero otherwise)      Q_ab:
-        //   B_run(X, Y)  = X0 Y0 M1 + (X0 Y_a + X_a Y0) Q_a + X_a Y_a Q_aa + (X_a Y_b + X_b Y_a) Q_ab
-        //   L_run(X)     = X0 M1 + X_a Q_a
-        //   L_s_run(X)   = [s = a] (X0 Q_a + X_a Q_aa + X_b Q_ab) + [s = b] X_a Q_ab
-        // Summed over the runs these are the full sums (every Q_l and Q_ll once, every pair once).
+        // ---- the generic kind: every slot's integrals from the moments of all lines, a point at a time --------------------------
+        // A slot's level sums are X = X0 + sum_l X_l phi_l over the tile's lines (X0: its continuum row; X_l: line l's cx / ce / cu
+        // through the coupling code of (slot, l)), so with the moments Q_l, Q_lm (Q_ll on the diagonal), P0_l, P1_l, M1, J, W
+        //   B(X, Y)  = X0 Y0 M1 + sum_l (X0 Y_l + X_l Y0) Q_l + sum_lm X_l Y_m Q_lm
+        //   L(X)     = X0 M1 + sum_l X_l Q_l                  L_s(X) = X0 Q_s + sum_l X_l Q_sl
+        // and the sums of compute_full_operator_rates :206-234 are those of slot_finish_half above.  Per point the lines'
+        // coefficients go to the scratch block once; the slots' loops read them back (an L1 hit) instead of holding 4 nL values.
         auto gen_slot_finish = [&]() {
-            const bool run0 = run == 0;
-            DevTileSlot ua{}, ub{};
-            double pA[4] = { 0, 0, 0, 0 }, pB[4] = { 0, 0, 0, 0 };
-            if (gA >= 0)
-            {
-                ua = ld_c(gSlots + gA);
-                const GLOBAL_AS DevSlot* q = gPar + ua.e;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    pA[k] = q->p[k];
-            }
-            if (gB >= 0)
-            {
-                ub = ld_c(gSlots + gB);
-                const GLOBAL_AS DevSlot* q = gPar + ub.e;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    pB[k] = q->p[k];
-            }
             ls_lds_double* accB = (ls_lds_double*)accBase;
             asm volatile("" : "+v"(accB));
             const GLOBAL_AS char* rowsB = (const GLOBAL_AS char*)rRows + c.vRow;
             const GLOBAL_AS double* rhoB = (const GLOBAL_AS double*)a.rho + (vRho0 >> 3);
-            auto line_coefs = [&](const DevTileSlot& u, const double (&pp)[4], const int P, double& c2, double& cu, double& cx, double& ce) {
-                const double ni = ((const double*)(sDep + c.vK + c.oN + (unsigned)u.gi * Ns8))[P];
-                const double nj = ((const double*)(sDep + c.vK + c.oN + (unsigned)u.gj * Ns8))[P];
-                const double rho = (u.flags & 2) ? rhoB[u.rhoOff + P] : 1.0;
-                c2 = (pp[2] * rho) * pp[0];
-                cu = pp[3] * c2;
-                cx = ni * pp[0] - nj * c2;
-                ce = nj * cu;
-            };
             const int nS = gnL + gnM;
+            auto momAt = [&](const int arr, const int P) -> double { return gMom[(size_t)(arr * D + P) * 64]; };
 #pragma unroll
             for (int P = 0; P < D; ++P)
             {
-                double c2a = 0.0, cua = 0.0, cxa = 0.0, cea = 0.0, c2b = 0.0, cub = 0.0, cxb = 0.0, ceb = 0.0;
-                if (gA >= 0)
-                    line_coefs(ua, pA, P, c2a, cua, cxa, cea);
-                if (gB >= 0)
-                    line_coefs(ub, pB, P, c2b, cub, cxb, ceb);
-                const double M1P = run0 ? M1[P] : 0.0, JP = run0 ? Jk[P] : 0.0, WP = run0 ? mW : 0.0;
-                const double Qa = mQ1[P], Qaa = mQ2[P], Qab = mQ12[P], P0a = mP0[P], P1a = mP1[P];
+                // the lines' coefficients per unit profile at this point (Transition::uv, chi_eta_aux_accum) -> scratch
+                for (int l = 0; l < gnL; ++l)
+                {
+                    const DevTileSlot u = ld_c(gSlots + l);
+                    const GLOBAL_AS DevSlot* q = gPar + u.e;
+                    const double a0 = q->p[0], a2 = q->p[2], a3 = q->p[3];
+                    const double ni = ((const double*)(sDep + c.vK + c.oN + (unsigned)u.gi * Ns8))[P];
+                    const double nj = ((const double*)(sDep + c.vK + c.oN + (unsigned)u.gj * Ns8))[P];
+                    const double rho = (u.flags & 2) ? rhoB[u.rhoOff + P] : 1.0;
+                    const double c2 = (a2 * rho) * a0, cu = a3 * c2;
+                    GLOBAL_AS double* o = gMom + (size_t)((gCoefBase + 4 * l) * D + P) * 64;
+                    o[0] = c2;
+                    o[(size_t)D * 64] = cu;
+                    o[(size_t)2 * D * 64] = ni * a0 - nj * c2;
+                    o[(size_t)3 * D * 64] = nj * cu;
+                }
+                auto coefAt = [&](const int l, const int k) -> double { return gMom[(size_t)((gCoefBase + 4 * l + k) * D + P) * 64]; };
+                // the moments of line l and of the pair (l, m)
+                auto Q1at = [&](const int l) -> double { return l == 0 ? mQ1[P] : momAt(4 * (l - 1) + 2, P); };
+                auto Q2at = [&](const int l, const int m) -> double {
+                    if (l == m)
+                        return l == 0 ? mQ2[P] : momAt(4 * (l - 1) + 3, P);
+                    const int lo = l < m ? l : m, hi = l < m ? m : l;
+                    return momAt(gPairBase + hi * (hi - 1) / 2 + lo, P);
+                };
+                const double M1P = M1[P], JP = Jk[P], WP = mW;
                 for (int sI = 0; sI < nS; ++sI)
                 {
                     const DevTileSlot us = ld_c(gSlots + sI);
-                    const bool isLine = sI < gnL, isA = isLine && sI == gA, isB = isLine && sI == gB;
+                    const bool isLine = sI < gnL;
                     const bool op = (us.flags & 1) != 0;
-                    // how the run's lines enter this slot's level sums (couple_code's bits; the slot's own line as in `coupled`)
-                    struct Cpl
-                    {
-                        double e, xi, xj, ui, uj;
-                    };
-                    auto cpl = [&](const DevTileSlot& ul, const bool have, const bool own, const double cx, const double ce, const double cu) {
-                        Cpl r{ 0.0, 0.0, 0.0, 0.0, 0.0 };
-                        if (!have)
-                            return r;
+                    // how line l enters this slot's level sums (couple_code's bits; the slot's own line as in `coupled`)
+                    auto cpl = [&](const int l, double& e, double& xi, double& xj, double& ui, double& uj) {
+                        const DevTileSlot ul = ld_c(gSlots + l);
+                        const bool own = isLine && l == sI;
                         const int code = (ul.flags & 1) ? ((ul.atom == us.atom ? 1 : 0) | (ul.gi == us.gi ? 2 : 0) | (ul.gj == us.gi ? 4 : 0)
                                                            | (ul.gi == us.gj ? 8 : 0) | (ul.gj == us.gj ? 16 : 0))
                                                         : 0;
-                        const double sE = (own || (code & 1)) ? 1.0 : 0.0;
-                        const double sXi = own ? 1.0 : ((code & 2) ? 1.0 : 0.0) - ((code & 4) ? 1.0 : 0.0);
-                        const double sXj = own ? -1.0 : ((code & 8) ? 1.0 : 0.0) - ((code & 16) ? 1.0 : 0.0);
-                        const double sUi = own ? 0.0 : (code & 4) ? 1.0 : 0.0;
-                        const double sUj = (own || (code & 16)) ? 1.0 : 0.0;
-                        r.e = sE * ce;
-                        r.xi = sXi * cx;
-                        r.xj = sXj * cx;
-                        r.ui = sUi * cu;
-                        r.uj = sUj * cu;
-                        return r;
+                        const double cx = coefAt(l, 2), ce = coefAt(l, 3), cu = coefAt(l, 1);
+                        e = ((own || (code & 1)) ? 1.0 : 0.0) * ce;
+                        xi = (own ? 1.0 : ((code & 2) ? 1.0 : 0.0) - ((code & 4) ? 1.0 : 0.0)) * cx;
+                        xj = (own ? -1.0 : ((code & 8) ? 1.0 : 0.0) - ((code & 16) ? 1.0 : 0.0)) * cx;
+                        ui = (own ? 0.0 : (code & 4) ? 1.0 : 0.0) * cu;
+                        uj = ((own || (code & 16)) ? 1.0 : 0.0) * cu;
                     };
-                    const Cpl fa = cpl(ua, gA >= 0, isA, cxa, cea, cua), fb = cpl(ub, gB >= 0, isB, cxb, ceb, cub);
-                    // the slot's continuum rows at this point (rows no continuum feeds are not read)
                     double lr[5];
                     const int zm = (isLine && !op) ? 31 : (int)us.zmask;
 #pragma unroll
                     for (int q = 0; q < 5; ++q)
                         lr[q] = (zm & (1 << q)) ? 0.0 : ((const GLOBAL_AS double*)(rowsB + (size_t)(us.r0 + q) * rowStride))[P];
-                    auto Bil = [&](const double X0, const double Xa, const double Xb, const double Y0, const double Ya, const double Yb) {
-                        double r = (X0 * Y0) * M1P;
-                        r = fma(fma(X0, Ya, Xa * Y0), Qa, r);
-                        r = fma(Xa * Ya, Qaa, r);
-                        r = fma(fma(Xa, Yb, Xb * Ya), Qab, r);
-                        return r;
-                    };
+                    // L(eta_A), L_s(eta_A), B(chi_i, U_j), B(chi_j, U_i)
+                    double LinE = lr[0] * M1P, LsE = isLine ? lr[0] * Q1at(sI) : 0.0;
+                    double BilA = (lr[1] * lr[4]) * M1P, BilB = (lr[2] * lr[3]) * M1P;
+                    for (int l = 0; l < gnL; ++l)
+                    {
+                        double el, xil, xjl, uil, ujl;
+                        cpl(l, el, xil, xjl, uil, ujl);
+                        const double Ql = Q1at(l);
+                        LinE = fma(el, Ql, LinE);
+                        if (isLine)
+                            LsE = fma(el, Q2at(sI, l), LsE);
+                        BilA = fma(fma(lr[1], ujl, xil * lr[4]), Ql, BilA);
+                        BilB = fma(fma(lr[2], uil, xjl * lr[3]), Ql, BilB);
+                        for (int m = 0; m < gnL; ++m)
+                        {
+                            double em, xim, xjm, uim, ujm;
+                            cpl(m, em, xim, xjm, uim, ujm);
+                            const double Qlm = Q2at(l, m);
+                            BilA = fma(xil * ujm, Qlm, BilA);
+                            BilB = fma(xjl * uim, Qlm, BilB);
+                        }
+                    }
                     const GLOBAL_AS DevSlot* qs = gPar + us.e;
                     double g0, g1, g2, g3;
                     if (isLine)
@@ -1752,20 +1778,19 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                         const double wphi = ((const double*)(sDep + c.vK + c.oW + (unsigned)us.row * Ns8))[P];
                         const double K = (qs->p[1] * PI4_HC) * wphi;
                         const double Kop = op ? K : 0.0; // detailed atoms: rates only
-                        const double c2s = isA ? c2a : isB ? c2b : 0.0, cus = isA ? cua : isB ? cub : 0.0, a0s = isA ? pA[0] : isB ? pB[0] : 0.0;
-                        const double P0s = isA ? P0a : 0.0, P1s = isA ? P1a : 0.0;
+                        const double c2s = coefAt(sI, 0), cus = coefAt(sI, 1), a0s = qs->p[0];
+                        const double P0s = sI == 0 ? mP0[P] : momAt(4 * (sI - 1) + 0, P), P1s = sI == 0 ? mP1[P] : momAt(4 * (sI - 1) + 1, P);
                         const double up = fma(cus, P0s, c2s * P1s);
-                        const double LsE = isA ? fma(fb.e, Qab, fma(fa.e, Qaa, lr[0] * Qa)) : isB ? fa.e * Qab : 0.0;
-                        g0 = ((up - c2s * LsE) - Bil(lr[1], fa.xi, fb.xi, lr[4], fa.uj, fb.uj)) * Kop;
-                        g1 = ((a0s * (P1s - LsE)) - Bil(lr[2], fa.xj, fb.xj, lr[3], fa.ui, fb.ui)) * Kop;
+                        g0 = ((up - c2s * LsE) - BilA) * Kop;
+                        g1 = ((a0s * (P1s - LsE)) - BilB) * Kop;
                         g2 = (a0s * P1s) * K;
                         g3 = up * K;
-                        if (isA && us.ms >= 0) // Meta of the line's atom for the pure continua (lane_finish): sum w Psi* eta_line
+                        if (us.ms >= 0) // Meta of the line's atom for the pure continua (lane_finish): sum w Psi* eta_line
                         {
                             if (us.ms == 0)
-                                Me[0][P] = fma(cea, Qa, Me[0][P]);
+                                Me[0][P] = fma(coefAt(sI, 3), Q1at(sI), Me[0][P]);
                             else
-                                Me[1][P] = fma(cea, Qa, Me[1][P]);
+                                Me[1][P] = fma(coefAt(sI, 3), Q1at(sI), Me[1][P]);
                         }
                     }
                     else
@@ -1773,15 +1798,144 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                         const double w1 = qs->p[0], mcw = qs->p[1];
                         const double w2 = ((const GLOBAL_AS double*)(rowsB + (size_t)max((int)us.rAux, 0) * rowStride))[P];
                         const double uji = qs->p[2] * w2;
-                        const double Jeff = JP - fma(fa.e, Qa, lr[0] * M1P);
-                        const double uw = fma(uji, WP, w2 * JP);
-                        g0 = ((uji * WP + w2 * Jeff) - Bil(lr[1], fa.xi, fb.xi, lr[4], fa.uj, fb.uj)) * mcw;
-                        g1 = ((w1 * Jeff) - Bil(lr[2], fa.xj, fb.xj, lr[3], fa.ui, fb.ui)) * mcw;
+                        const double Jeff = JP - LinE;
+                        g0 = ((uji * WP + w2 * Jeff) - BilA) * mcw;
+                        g1 = ((w1 * Jeff) - BilB) * mcw;
                         g2 = (w1 * JP) * mcw;
-                        g3 = uw * mcw;
+                        g3 = fma(uji, WP, w2 * JP) * mcw;
                     }
-                    if (c.sTurn && run <= 1 && P == 0) // (the first run's turn; one more for the adds of all later runs)
-                        ls_turn_wait<D>(c.sTurn, us.cs, 0, D, (int)(((unsigned)us.flags >> (run == 0 ? 8 : 20)) & 0xfffu) + c.sub);
+                    if (c.sTurn && P == 0)
+                        ls_turn_wait<D>(c.sTurn, us.cs, 0, D, (int)(((unsigned)us.flags >> 8) & 0xfffu) + c.sub);
+                    if (act)
+                    {
+                        ls_lds_double* dst = accB + (unsigned)(us.cs * 4 * c.LRD) + (unsigned)(P * LR);
+                        ls_lds_add(dst, g0);
+                        ls_lds_add(dst + D * LR, g1);
+                        ls_lds_add(dst + 2 * D * LR, g2);
+                        ls_lds_add(dst + 3 * D * LR, g3);
+                    }
+                }
+            }
+        };
+        // The same for tiles with at most TWO lines (any number of mixed continua: overlapping lines with the continua coupled to
+        // them, the realistic case): the lines' coefficients and every moment of the point in registers -- the general form above
+        // reads them back from the scratch inside its loops, a chain of memory round trips per slot.
+        auto gen_slot_finish2 = [&]() {
+            ls_lds_double* accB = (ls_lds_double*)accBase;
+            asm volatile("" : "+v"(accB));
+            const GLOBAL_AS char* rowsB = (const GLOBAL_AS char*)rRows + c.vRow;
+            const GLOBAL_AS double* rhoB = (const GLOBAL_AS double*)a.rho + (vRho0 >> 3);
+            const int nS = gnL + gnM;
+            const bool hasB = gnL > 1;
+            DevTileSlot ul[2] = { ld_c(gSlots + 0), ld_c(gSlots + (hasB ? 1 : 0)) };
+            double pl[2][4];
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+            {
+                const GLOBAL_AS DevSlot* q = gPar + ul[l].e;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    pl[l][k] = q->p[k];
+            }
+#pragma unroll
+            for (int P = 0; P < D; ++P)
+            {
+                double c2[2], cu[2], cx[2], ce[2];
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+                {
+                    const double ni = ((const double*)(sDep + c.vK + c.oN + (unsigned)ul[l].gi * Ns8))[P];
+                    const double nj = ((const double*)(sDep + c.vK + c.oN + (unsigned)ul[l].gj * Ns8))[P];
+                    const double rho = (ul[l].flags & 2) ? rhoB[ul[l].rhoOff + P] : 1.0;
+                    const double on = (l == 0 || hasB) ? 1.0 : 0.0; // (a tile with one line: line "1" is absent)
+                    c2[l] = on * ((pl[l][2] * rho) * pl[l][0]);
+                    cu[l] = pl[l][3] * c2[l];
+                    cx[l] = on * (ni * pl[l][0]) - nj * c2[l];
+                    ce[l] = nj * cu[l];
+                }
+                // moments: line 0 in registers, line 1 and the pair from the scratch (five loads in flight)
+                const double M1P = M1[P], JP = Jk[P], WP = mW;
+                double Ql[2] = { mQ1[P], 0.0 }, Qll[2] = { mQ2[P], 0.0 }, P0l[2] = { mP0[P], 0.0 }, P1l[2] = { mP1[P], 0.0 }, Q01 = 0.0;
+                if (hasB)
+                {
+                    P0l[1] = gMom[(size_t)(0 * D + P) * 64];
+                    P1l[1] = gMom[(size_t)(1 * D + P) * 64];
+                    Ql[1] = gMom[(size_t)(2 * D + P) * 64];
+                    Qll[1] = gMom[(size_t)(3 * D + P) * 64];
+                    Q01 = gMom[(size_t)(gPairBase * D + P) * 64];
+                }
+                for (int sI = 0; sI < nS; ++sI)
+                {
+                    const DevTileSlot us = ld_c(gSlots + sI);
+                    const bool isLine = sI < gnL;
+                    const bool op = (us.flags & 1) != 0;
+                    double e[2], xi[2], xj[2], ui[2], uj[2];
+#pragma unroll
+                    for (int l = 0; l < 2; ++l)
+                    {
+                        const bool own = isLine && l == sI;
+                        const int code = (ul[l].flags & 1) ? ((ul[l].atom == us.atom ? 1 : 0) | (ul[l].gi == us.gi ? 2 : 0) | (ul[l].gj == us.gi ? 4 : 0)
+                                                              | (ul[l].gi == us.gj ? 8 : 0) | (ul[l].gj == us.gj ? 16 : 0))
+                                                           : 0;
+                        e[l] = ((own || (code & 1)) ? 1.0 : 0.0) * ce[l];
+                        xi[l] = (own ? 1.0 : ((code & 2) ? 1.0 : 0.0) - ((code & 4) ? 1.0 : 0.0)) * cx[l];
+                        xj[l] = (own ? -1.0 : ((code & 8) ? 1.0 : 0.0) - ((code & 16) ? 1.0 : 0.0)) * cx[l];
+                        ui[l] = (own ? 0.0 : (code & 4) ? 1.0 : 0.0) * cu[l];
+                        uj[l] = ((own || (code & 16)) ? 1.0 : 0.0) * cu[l];
+                    }
+                    double lr[5];
+                    const int zm = (isLine && !op) ? 31 : (int)us.zmask;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        lr[q] = (zm & (1 << q)) ? 0.0 : ((const GLOBAL_AS double*)(rowsB + (size_t)(us.r0 + q) * rowStride))[P];
+                    auto Bil = [&](const double X0, const double (&X)[2], const double Y0, const double (&Y)[2]) {
+                        double r = (X0 * Y0) * M1P;
+                        r = fma(fma(X0, Y[0], X[0] * Y0), Ql[0], r);
+                        r = fma(fma(X0, Y[1], X[1] * Y0), Ql[1], r);
+                        r = fma(X[0] * Y[0], Qll[0], r);
+                        r = fma(X[1] * Y[1], Qll[1], r);
+                        r = fma(fma(X[0], Y[1], X[1] * Y[0]), Q01, r);
+                        return r;
+                    };
+                    const double LinE = fma(e[1], Ql[1], fma(e[0], Ql[0], lr[0] * M1P));
+                    const GLOBAL_AS DevSlot* qs = gPar + us.e;
+                    double g0, g1, g2, g3;
+                    if (isLine)
+                    {
+                        const int sl = sI; // 0 or 1
+                        const double wphi = ((const double*)(sDep + c.vK + c.oW + (unsigned)us.row * Ns8))[P];
+                        const double K = (qs->p[1] * PI4_HC) * wphi;
+                        const double Kop = op ? K : 0.0; // detailed atoms: rates only
+                        const double c2s = sl == 0 ? c2[0] : c2[1], cus = sl == 0 ? cu[0] : cu[1], a0s = sl == 0 ? pl[0][0] : pl[1][0];
+                        const double P0s = sl == 0 ? P0l[0] : P0l[1], P1s = sl == 0 ? P1l[0] : P1l[1];
+                        const double up = fma(cus, P0s, c2s * P1s);
+                        const double LsE = sl == 0 ? fma(e[1], Q01, fma(e[0], Qll[0], lr[0] * Ql[0])) : fma(e[0], Q01, fma(e[1], Qll[1], lr[0] * Ql[1]));
+                        g0 = ((up - c2s * LsE) - Bil(lr[1], xi, lr[4], uj)) * Kop;
+                        g1 = ((a0s * (P1s - LsE)) - Bil(lr[2], xj, lr[3], ui)) * Kop;
+                        g2 = (a0s * P1s) * K;
+                        g3 = up * K;
+                        if (us.ms >= 0) // Meta of the line's atom for the pure continua (lane_finish): sum w Psi* eta_line
+                        {
+                            const double me = (sl == 0 ? ce[0] : ce[1]) * (sl == 0 ? Ql[0] : Ql[1]);
+                            if (us.ms == 0)
+                                Me[0][P] += me;
+                            else
+                                Me[1][P] += me;
+                        }
+                    }
+                    else
+                    {
+                        const double w1 = qs->p[0], mcw = qs->p[1];
+                        const double w2 = ((const GLOBAL_AS double*)(rowsB + (size_t)max((int)us.rAux, 0) * rowStride))[P];
+                        const double uji = qs->p[2] * w2;
+                        const double Jeff = JP - LinE;
+                        g0 = ((uji * WP + w2 * Jeff) - Bil(lr[1], xi, lr[4], uj)) * mcw;
+                        g1 = ((w1 * Jeff) - Bil(lr[2], xj, lr[3], ui)) * mcw;
+                        g2 = (w1 * JP) * mcw;
+                        g3 = fma(uji, WP, w2 * JP) * mcw;
+                    }
+                    if (c.sTurn && P == 0)
+                        ls_turn_wait<D>(c.sTurn, us.cs, 0, D, (int)(((unsigned)us.flags >> 8) & 0xfffu) + c.sub);
                     if (act)
                     {
                         ls_lds_double* dst = accB + (unsigned)(us.cs * 4 * c.LRD) + (unsigned)(P * LR);
@@ -1796,7 +1950,12 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         LS_PHASE();
         // (fixed-order mode: a task waits for its turn at a slot right before its first add to it, inside the functions below)
         if constexpr (GEN)
-            gen_slot_finish();
+        {
+            if (gnL <= 2)
+                gen_slot_finish2();
+            else
+                gen_slot_finish();
+        }
         else if constexpr (NL > 1)
         {
             // (a blend: a point at a time -- two lines' coefficients and level sums are twice the registers)
@@ -1834,7 +1993,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
 #endif
             }
         }
-        if (GEN || NRUN > 1)
+        if (NRUN > 1)
         {
 #pragma unroll
             for (int p = 0; p < D; ++p)
@@ -2972,7 +3131,7 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
 // the walk was 0.7 ms of latency.  Segment s of DET_SEG covers list positions [L s / DET_SEG, L (s + 1) / DET_SEG) -- a function
 // of the list's length alone --, is added up in list order (eight loads in flight), and the DET_SEG partial sums are added in
 // segment order.
-enum { DET_SEG = 32 };
+enum { DET_SEG = LWHIP_DET_SEG };
 __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restrict__ slab, const int32_t* __restrict__ off,
                                                          const int32_t* __restrict__ ent, double* __restrict__ part, int Ns)
 {
@@ -3002,25 +3161,6 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(const double* __restric
     part[((size_t)tr * DET_SEG + seg) * n4 + i] = sum;
 }
 
-__global__ void __launch_bounds__(256) det_reduce2_kernel(const double* __restrict__ part, double* __restrict__ red8, int Ns)
-{
-    dbg_poison_lds();
-    const int tr = blockIdx.y;
-    const int n4 = 4 * Ns;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4)
-        return;
-    double v[DET_SEG];
-#pragma unroll
-    for (int s = 0; s < DET_SEG; ++s)
-        v[s] = part[((size_t)tr * DET_SEG + s) * n4 + i];
-    double sum = 0.0;
-#pragma unroll
-    for (int s = 0; s < DET_SEG; ++s)
-        sum += v[s];
-    red8[(size_t)tr * LWHIP_REDUCE_SPLIT * n4 + i] = sum;
-}
-
 #ifdef LS_ISA_ONLY /* one instance, for instruction counts of the listing (tools/isa_loops.py) */
 #ifndef LS_ISA_SOLVER
 #define LS_ISA_SOLVER LWHIP_FS_BEZIER3_1D
@@ -3030,6 +3170,33 @@ __global__ void __launch_bounds__(256) det_reduce2_kernel(const double* __restri
 template __global__ void lanesweep_kernel<LS_ISA_SOLVER, 4, LS_ISA_MODE, LS_ISA_BATCH>(const TileArgs* __restrict__, const TileArgs* const* __restrict__,
                                                                                        const TileDyn);
 #else
+// Diagnosis (LWHIP_DEBUG=1 LWHIP_SCRATCH_POISON=1): every wavefront slot's private-segment ("scratch") memory is filled with a
+// finite pattern in front of EVERY kernel launch of the library (LWHIP_LAUNCH).  A register the compiler spills while some lanes are switched off is
+// stored for the active lanes only; reloaded with all lanes on, the others get what the scratch slot held before -- what an
+// earlier kernel of this or another process left there.  Under this fill such a reload reaches the results on every run.
+__global__ void __launch_bounds__(256) scratch_poison_kernel(double* sink, const double pat, const int n)
+{
+    volatile double buf[320]; // (2560 bytes per lane: more than any kernel's private segment in this library)
+    for (int i = 0; i < 320; ++i)
+        buf[i] = pat * (double)(1 + ((threadIdx.x + i) & 7));
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) // (n = 0: nothing is read back; the stores above stay because the array is volatile)
+        sum += buf[i % 320];
+    if (n > 0)
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
+} // namespace
+
+void dbg_scratch_poison(hipStream_t stream)
+{
+    static const bool poison = std::getenv("LWHIP_DEBUG") && std::getenv("LWHIP_SCRATCH_POISON");
+    if (poison)
+        hipLaunchKernelGGL(scratch_poison_kernel, dim3(8192), dim3(256), 0, stream, (double*)nullptr, 1.0e-3, 0);
+}
+
+namespace
+{
 template <int SOLVER, int D, int MODE>
 hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn& dyn, int nChunks, int waves,
                        const TileArgs* const* apList, int nBatch, hipStream_t stream)
@@ -3054,10 +3221,10 @@ hipError_t launch_ls_t(const TileArgs* devArgs, const TileArgs& a, const TileDyn
         }
     }
     if (apList)
-        hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, MODE, true>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds, stream,
+        LWHIP_LAUNCH((lanesweep_kernel<SOLVER, D, MODE, true>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds, stream,
                            devArgs, apList, dyn);
     else
-        hipLaunchKernelGGL((lanesweep_kernel<SOLVER, D, MODE, false>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList, dyn);
+        LWHIP_LAUNCH((lanesweep_kernel<SOLVER, D, MODE, false>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList, dyn);
     return hipGetLastError();
 }
 #endif
@@ -3081,13 +3248,14 @@ bool lane_sweep_supported(int Ns, int Nrays, int solver, int* D, int* LR, int* R
 
 size_t det_reduce_scratch_doubles(int Ns, int Ntrans) { return (size_t)std::max(Ntrans, 1) * DET_SEG * 4 * Ns; }
 
-hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* red8, double* part, int Ns, int Ntrans,
+// (round 5: the DET_SEG segment sums are what the apply launch -- or stage 2 of a sharded iteration -- reads as the transition's
+// "parts", in segment order: the second-level launch of round 4 is gone)
+hipError_t launch_det_reduce(const double* slab, const int32_t* off, const int32_t* ent, double* part, int Ns, int Ntrans,
                              hipStream_t stream)
 {
     if (Ntrans <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(det_reduce_kernel, dim3((4 * Ns + 255) / 256, Ntrans, DET_SEG), dim3(256), 0, stream, slab, off, ent, part, Ns);
-    hipLaunchKernelGGL(det_reduce2_kernel, dim3((4 * Ns + 255) / 256, Ntrans), dim3(256), 0, stream, part, red8, Ns);
+    LWHIP_LAUNCH(det_reduce_kernel, dim3((4 * Ns + 255) / 256, Ntrans, DET_SEG), dim3(256), 0, stream, slab, off, ent, part, Ns);
     return hipGetLastError();
 }
 

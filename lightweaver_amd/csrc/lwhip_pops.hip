@@ -492,10 +492,10 @@ hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream
     if (e != hipSuccess)
         return e;
     if (list)
-        hipLaunchKernelGGL(stat_eq_kernel<true>, dim3((a.Ns + tb - 1) / tb, a.Natoms, nBatch > 0 ? nBatch : 1), dim3(tb), lds, stream, a,
+        LWHIP_LAUNCH(stat_eq_kernel<true>, dim3((a.Ns + tb - 1) / tb, a.Natoms, nBatch > 0 ? nBatch : 1), dim3(tb), lds, stream, a,
                            list);
     else
-        hipLaunchKernelGGL(stat_eq_kernel<false>, dim3((a.Ns + tb - 1) / tb, a.Natoms), dim3(tb), lds, stream, a, list);
+        LWHIP_LAUNCH(stat_eq_kernel<false>, dim3((a.Ns + tb - 1) / tb, a.Natoms), dim3(tb), lds, stream, a, list);
     return hipGetLastError();
 }
 
@@ -573,7 +573,7 @@ hipError_t launch_time_dep(int Nlevel, int Ns, int k0, int k1, double* n, const 
     hipError_t e = solve_set_lds((const void*)time_dep_kernel, lds);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(time_dep_kernel, dim3((Ns + tb - 1) / tb), dim3(tb), lds, stream, Nlevel, Ns, k0, k1, n, nOld, Gamma,
+    LWHIP_LAUNCH(time_dep_kernel, dim3((Ns + tb - 1) / tb), dim3(tb), lds, stream, Nlevel, Ns, k0, k1, n, nOld, Gamma,
                        dt, status);
     return hipGetLastError();
 }
@@ -709,7 +709,7 @@ hipError_t launch_nr_post(const NrArgs& a, hipStream_t stream)
     hipError_t e = solve_set_lds((const void*)nr_post_kernel, lds);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(nr_post_kernel, dim3((a.Ns + tb - 1) / tb), dim3(tb), lds, stream, a);
+    LWHIP_LAUNCH(nr_post_kernel, dim3((a.Ns + tb - 1) / tb), dim3(tb), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(256) ng_kernel(const NgArgs a)
 hipError_t launch_ng(const NgArgs& a, int nAtoms, hipStream_t stream)
 {
     const size_t lds = (64 + solve_ws_doubles(a.Norder > 0 ? a.Norder : 1)) * sizeof(double);
-    hipLaunchKernelGGL(ng_kernel, dim3(nAtoms), dim3(256), lds, stream, a);
+    LWHIP_LAUNCH(ng_kernel, dim3(nAtoms), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 }

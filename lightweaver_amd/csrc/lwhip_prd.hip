@@ -385,11 +385,11 @@ hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hos
     }
     if (any)
     {
-        hipLaunchKernelGGL(prd_transpose_kernel, dim3((maxNl + 31) / 32, (Ns + 31) / 32, nLines), dim3(32, 8), 0, stream, devList);
-        hipLaunchKernelGGL(prd_scatter_kernel, dim3(Ns, maxSlices, nLines), dim3(128), lds, stream, devList);
+        LWHIP_LAUNCH(prd_transpose_kernel, dim3((maxNl + 31) / 32, (Ns + 31) / 32, nLines), dim3(32, 8), 0, stream, devList);
+        LWHIP_LAUNCH(prd_scatter_kernel, dim3(Ns, maxSlices, nLines), dim3(128), lds, stream, devList);
     }
     if (reduceChange)
-        hipLaunchKernelGGL(prd_change_kernel, dim3(nLines), dim3(64), 0, stream, devList);
+        LWHIP_LAUNCH(prd_change_kernel, dim3(nLines), dim3(64), 0, stream, devList);
     return hipGetLastError();
 }
 }

@@ -1368,7 +1368,7 @@ hipError_t launch_retile(const RetileArgs& a, hipStream_t stream)
 {
     if (a.nTiles <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(retile_kernel, dim3(a.nTiles, 8), dim3(256), 0, stream, a, (const RetileArgs*)nullptr);
+    LWHIP_LAUNCH(retile_kernel, dim3(a.nTiles, 8), dim3(256), 0, stream, a, (const RetileArgs*)nullptr);
     return hipGetLastError();
 }
 
@@ -1379,7 +1379,7 @@ hipError_t launch_retile_list(const RetileArgs* devList, const RetileArgs* hostL
         maxTiles = std::max(maxTiles, hostList[i].nTiles);
     if (n <= 0 || maxTiles <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(retile_kernel, dim3(maxTiles, 8, n), dim3(256), 0, stream, hostList[0], devList);
+    LWHIP_LAUNCH(retile_kernel, dim3(maxTiles, 8, n), dim3(256), 0, stream, hostList[0], devList);
     return hipGetLastError();
 }
 
@@ -1407,10 +1407,10 @@ hipError_t launch_tile_pre(const TileArgs* devArgs, const TileArgs& a, int nTile
             return e;
     }
     if (apList)
-        hipLaunchKernelGGL(tile_pre_kernel<true>, dim3(nTilesLaunch, parts, std::max(nBatch, 1)), dim3(RM_PRE_T), lds, stream, devArgs,
+        LWHIP_LAUNCH(tile_pre_kernel<true>, dim3(nTilesLaunch, parts, std::max(nBatch, 1)), dim3(RM_PRE_T), lds, stream, devArgs,
                            apList, a.tileList);
     else
-        hipLaunchKernelGGL(tile_pre_kernel<false>, dim3(nTilesLaunch, parts), dim3(RM_PRE_T), lds, stream, devArgs, apList, a.tileList);
+        LWHIP_LAUNCH(tile_pre_kernel<false>, dim3(nTilesLaunch, parts), dim3(RM_PRE_T), lds, stream, devArgs, apList, a.tileList);
     return hipGetLastError();
 }
 
@@ -1428,10 +1428,10 @@ static hipError_t launch_rm_t(const TileArgs* devArgs, const TileArgs& a, const 
             return e;
     }
     if (apList)
-        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, true, FUSE>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds,
+        LWHIP_LAUNCH((raymarch_kernel<SOLVER, CAP, RATES, true, FUSE>), dim3(nChunks, std::max(nBatch, 1)), dim3(waves * 64), lds,
                            stream, devArgs, apList, dyn);
     else
-        hipLaunchKernelGGL((raymarch_kernel<SOLVER, CAP, RATES, false, FUSE>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList,
+        LWHIP_LAUNCH((raymarch_kernel<SOLVER, CAP, RATES, false, FUSE>), dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, apList,
                            dyn);
     return hipGetLastError();
 }
@@ -1494,10 +1494,10 @@ hipError_t launch_tile_post(const TileArgs* devArgs, const TileArgs& a, const Ti
             return e;
     }
     if (apList)
-        hipLaunchKernelGGL(tile_post_kernel<true>, dim3(nPostChunks, std::max(nBatch, 1)), dim3(RM_POST_T), lds, stream, devArgs, apList,
+        LWHIP_LAUNCH(tile_post_kernel<true>, dim3(nPostChunks, std::max(nBatch, 1)), dim3(RM_POST_T), lds, stream, devArgs, apList,
                            dyn, a.postChunkTile, a.tileList);
     else
-        hipLaunchKernelGGL(tile_post_kernel<false>, dim3(nPostChunks), dim3(RM_POST_T), lds, stream, devArgs, apList, dyn,
+        LWHIP_LAUNCH(tile_post_kernel<false>, dim3(nPostChunks), dim3(RM_POST_T), lds, stream, devArgs, apList, dyn,
                            a.postChunkTile, a.tileList);
     return hipGetLastError();
 }

@@ -330,6 +330,8 @@ int build_tile_args(lwhip_context* c)
         a.laneFinPar = c->laneFinPar.p;
         a.bcPlanck = c->bcPlanck.p;
         a.laneFeedG = c->laneFeedG.p;
+        a.momS = c->momScratch.p;
+        a.momA = c->momA;
     }
     a.lsDbg = nullptr;
     if (std::getenv("LWHIP_LS_TIMING"))
@@ -452,8 +454,8 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
     if (e1)
         (void)hipEventRecord(e1, c->stream);
     if (e == hipSuccess && rates && c->laneSweep && c->deterministic)
-        e = launch_det_reduce(c->detSlab.p, tprd ? c->detOffPrd.p : c->detOff.p, tprd ? c->detEntPrd.p : c->detEnt.p, c->red8.p,
-                              c->detPart.p, c->Ns, c->Ntrans, c->stream);
+        e = launch_det_reduce(c->detSlab.p, tprd ? c->detOffPrd.p : c->detOff.p, tprd ? c->detEntPrd.p : c->detEnt.p, c->detPart.p, c->Ns,
+                              c->Ntrans, c->stream);
     if (e != hipSuccess || !rates || fuse || c->laneSweep)
         return e;
     return launch_tile_post(da, ha, td, tprd ? c->nPostChunksPrd : c->nPostChunks, nullptr, 0, c->stream);

@@ -1510,9 +1510,8 @@ int build_tables(lwhip_context* c)
                             for (int t : tasks)
                             {
                                 const int nl = tiles[t].nLine;
-                                const int nRun = nl <= 2 ? std::max(nl, 1) : nl * (nl - 1) / 2; // (lane_rays: NRUN / gen_runs)
                                 const bool fastKind = (nl == 0 && tiles[t].nMixed == 0) || (nl == 1 && tiles[t].nMixed <= 1) || (nl == 2 && tiles[t].nMixed == 0);
-                                if (pass == 1 && (fastKind ? nl < 2 : nRun < 2))
+                                if (pass == 1 && !(fastKind && nl == 2)) // (only the compiled blend kind walks its rays twice)
                                     continue;
                                 for (int e = 0; e < tiles[t].nLine + tiles[t].nMixed; ++e)
                                 {
@@ -1651,6 +1650,19 @@ int build_tables(lwhip_context* c)
                     for (int e = 0; e < std::min(td.nLine + td.nMixed, (int)LWHIP_GEN_MAXS); ++e)
                         feedG[base + (size_t)q * LWHIP_GEN_MAXS + e] = feed_byte(cs, tslots[td.slotOff + e], e >= td.nLine && ord == e - td.nLine);
                 }
+            }
+            // the moment scratch of the generic tiles' wavefronts: every workgroup of the largest launch, W wavefronts each
+            c->momA = 0;
+            for (size_t t = 0; t < tiles.size(); ++t)
+                if (genOf[t] >= 0)
+                {
+                    const int nl = tiles[t].nLine;
+                    c->momA = std::max(c->momA, 4 * std::max(nl - 1, 0) + nl * (nl - 1) / 2 + 4 * nl);
+                }
+            if (c->momA > 0)
+            {
+                const size_t nWg = std::max<size_t>(chunkTile.size(), chunkTilePrd.size());
+                HIP_TRY(c->momScratch.alloc(nWg * c->tileWaves * (size_t)c->momA * c->laneD * 64)); // (written before it is read: first ray / per point)
             }
             if (feedG.empty())
                 feedG.push_back(0);

@@ -361,7 +361,7 @@ static hipError_t launch_voigt(const VoigtLineArgs& a0, const VoigtLineArgs* lis
     if (maxPhi > 0)
     {
         const int blocks = (int)std::min<size_t>((maxPhi + 255) / 256, 4096);
-        hipLaunchKernelGGL(voigt_phi_kernel, dim3(blocks, nLines), dim3(256), 0, stream, a0, list);
+        LWHIP_LAUNCH(voigt_phi_kernel, dim3(blocks, nLines), dim3(256), 0, stream, a0, list);
     }
     // tiles of 8 points (1D columns: ~10 point tiles, each with up to 128 partial sums over a slice of the line's
     // wavelengths) or 64 (2D domains, which bring enough tiles); wavelength slices so that a thread sums ~2 wavelengths
@@ -373,7 +373,7 @@ static hipError_t launch_voigt(const VoigtLineArgs& a0, const VoigtLineArgs* lis
     if (sliced && Ns <= 1024 && (size_t)nLines * ((Ns + KT - 1) / KT) <= 1024)
         PB = std::max(1, std::min(slices, (maxNltFull + 2 * P - 1) / (2 * P)));
     const int T = ((P * KT + 63) / 64) * 64;
-    hipLaunchKernelGGL(voigt_wphi_kernel, dim3((Ns + KT - 1) / KT, PB, nLines), dim3(T), (size_t)P * KT * sizeof(double), stream,
+    LWHIP_LAUNCH(voigt_wphi_kernel, dim3((Ns + KT - 1) / KT, PB, nLines), dim3(T), (size_t)P * KT * sizeof(double), stream,
                        a0, list, KT);
     return hipGetLastError();
 }

@@ -801,11 +801,16 @@ uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr, uint32_t 
         st->jDeviceAhead = false;      // (LWHIP_RESIDENT_J: a rebuilt context starts from spect.J again)
         lwhip_options opts{};
         opts.flags = st->prdDetailed ? LWHIP_OPT_PRD_DETAILED : 0;
-        // LWHIP_DETERMINISTIC=1: Gamma and the rates summed in a fixed order (bit-reproducible iterations, as the
-        // reference's schemes are) instead of by fp64 atomics; off by default: it costs 1.7-2.7x per step
+        // Gamma and the rates are summed in a FIXED order by default (round 5): bit-reproducible iterations, as the reference's
+        // schemes are -- the same iteration count from run to run.  The lane sweep's fixed-order mode keeps four wavefronts per
+        // workgroup now (they add to the accumulators in turn) and costs ~1.1 x the atomic path (it was 2.7 x).
+        // LWHIP_DETERMINISTIC=0 selects the atomic sums; LWHIP_DETERMINISTIC=1 asks for the fixed order also where it is
+        // expensive (hybrid PRD: one wavefront per workgroup); a forced march (LWHIP_SWEEP=march) has no such mode.
         {
             const char* det = std::getenv("LWHIP_DETERMINISTIC");
-            if (det && det[0] == '1')
+            const char* sw = std::getenv("LWHIP_SWEEP");
+            const bool marchForced = sw && std::strcmp(sw, "march") == 0;
+            if (det ? det[0] == '1' : (!st->hprdOn && !marchForced))
                 opts.flags |= LWHIP_OPT_DETERMINISTIC;
         }
         opts.hprd = st->hprdOn ? &st->hprd : nullptr;

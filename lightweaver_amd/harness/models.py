@@ -332,12 +332,28 @@ def falc_h(Nrays=5, lineScale=1.0, formalSolver=abi.FS_BEZIER3_1D, **kw) -> Prob
     return build_problem(falc82(), [H_6(lineScale)], Nrays=Nrays, formalSolver=formalSolver, **kw)
 
 
-def throughput_grid(NlambdaTarget=10240, Nrays=5, **kw) -> Problem:
+def D_6(lineScale=1.0) -> AtomModel:
+    """A deuterium-like twin of the hydrogen model: the same levels with the isotope shift of the energies (reduced mass:
+    +2.72e-4) and 2e-5 of the abundance.  Its Lyman / Balmer lines sit 0.03 nm blueward of hydrogen's, inside their cores
+    and wings: with both atoms active a wavelength of those lines carries TWO lines and the bound-free continua coupled to
+    each of them -- the overlap the stock H + Ca II pair never has (throughput_grid(realistic=True), bench.py's
+    aux.realistic_1d)."""
+    import copy
+    m = copy.deepcopy(H_6(lineScale))
+    m.name = 'D'
+    m.E_cm = [e * (1.0 + 2.72e-4) for e in m.E_cm]
+    m.abundance = 2e-5 * m.abundance
+    return m
+
+
+def throughput_grid(NlambdaTarget=10240, Nrays=5, realistic=False, **kw) -> Problem:
     """FAL-C H + Ca II with the line/continuum quadratures scaled so that the global grid has
     ~NlambdaTarget points (north-star synthetic throughput grid, Ndepth = 82, Nmu = 5; N x 10 240
-    for the N-GPU weak-scaling runs)."""
+    for the N-GPU weak-scaling runs).  realistic=True adds the deuterium-like twin of hydrogen (D_6): pairwise
+    overlapping lines with coupled continua of both atoms, three active atoms' continua in the ultraviolet."""
     prd = kw.get('prd', False)
-    size = lambda ls: grid_size([H_6(ls), CaII_6(ls, prd=prd)])
+    atoms = lambda ls: [H_6(ls), CaII_6(ls, prd=prd)] + ([D_6(ls)] if realistic else [])
+    size = lambda ls: grid_size(atoms(ls))
     lo, hi = 1.0, 40.0
     while size(hi) < NlambdaTarget and hi < 1e5:
         lo, hi = hi, hi * 4.0
@@ -352,6 +368,9 @@ def throughput_grid(NlambdaTarget=10240, Nrays=5, **kw) -> Problem:
             hi = mid
         if n == NlambdaTarget:
             break
+    if realistic:
+        kw.pop('prd', None)
+        return build_problem(falc82(), atoms(best), Nrays=Nrays, **kw)
     return falc_h_ca(Nrays=Nrays, lineScale=best, **kw)
 
 

@@ -534,7 +534,10 @@ def test_generic_tiles_in_the_fixed_order_mode_and_split(gpu, monkeypatch):
             assert ctx.sweep_kind() == 'lanes'
             p.gamma_prefill()
             ctx.formal_sol_gamma_matrices()
-        compare_problems(p, q)
+        try:
+            compare_problems(p, q)
+        except AssertionError as e:
+            raise AssertionError(f'split {split} deterministic {det}: {e}') from None
         runs.append(p)
     a, b = runs[-2], runs[-1]
     assert np.array_equal(a.J, b.J)

@@ -64,6 +64,36 @@ def test_dropin_matches_scalar_scheme(gpu, name):
 
 @needs_ref
 @pytest.mark.gpu
+def test_dropin_is_bit_reproducible_by_default(gpu, monkeypatch):
+    """What a Lightweaver user gets (round 5): the plugin creates its contexts in the fixed-order mode, so four iterations with
+    stat_equil from the same inputs end in the SAME bits -- J, Gamma, rates, populations -- run after run, as the reference's
+    own schemes do (SimdFullIterationTemplates.hpp:620-628, ThreadStorage.cpp:343-396); LWHIP_DETERMINISTIC=0 brings the
+    atomic sums back (equal to rounding)."""
+    base, d = load_fixture('falc_h_ca_small')
+    runs = []
+    for rep, det in enumerate((None, None, '0')):
+        if det is None:
+            monkeypatch.delenv('LWHIP_DETERMINISTIC', raising=False)
+        else:
+            monkeypatch.setenv('LWHIP_DETERMINISTIC', det)
+        p = variant_problem(base, d, 'iter1')
+        hipc = RefContext(p, scheme=PLUGIN)
+        for it in range(4):
+            p.gamma_prefill()
+            hipc.formal_sol_gamma_matrices()
+            assert hipc.stat_equil() == 0
+        runs.append(p)
+    a, b, c = runs
+    assert np.array_equal(a.J, b.J) and np.array_equal(a.I, b.I)
+    for x, y, z in zip(a.atoms, b.atoms, c.atoms):
+        assert np.array_equal(x.Gamma, y.Gamma) and np.array_equal(x.n, y.n)
+        for tx, ty in zip(x.trans, y.trans):
+            assert np.array_equal(tx.Rij, ty.Rij) and np.array_equal(tx.Rji, ty.Rji)
+        assert rel_err(x.n, z.n) <= 1e-9
+
+
+@needs_ref
+@pytest.mark.gpu
 def test_dropin_resident_J(gpu, monkeypatch):
     """LWHIP_RESIDENT_J=1 (opt-in): J stays in HBM between the plugin's calls -- spect.J is neither
     uploaded nor written back while the variable is set, and the first call made without it brings the device's J down before

@@ -52,6 +52,25 @@ def test_throughput_grid_iteration_and_stat_equil_vs_oracle(gpu):
                 assert rel_err(a.n, b.n) <= 1e-8
 
 
+@pytest.mark.parametrize('nla,det', [(3000, False), (3000, True), (10240, False)])
+def test_realistic_overlapping_lines_vs_oracle(gpu, nla, det):
+    """The lane sweep's generic kind at scale: hydrogen, its deuterium-like twin and Ca II (models.D_6) -- more than half of the
+    wavelengths carry two overlapping lines AND the bound-free continua coupled to each, three active atoms' continua meet in
+    the ultraviolet (the finish program's wide encoding).  Round 4 sent such a context to the march as a whole.  One iteration
+    against the oracle at the one-call bound, also in the fixed-order mode."""
+    from lightweaver_amd.context import Context
+    prob = models.throughput_grid(NlambdaTarget=nla, Nrays=5, realistic=True)
+    q = prob.copy()
+    oc = OracleContext(q)
+    with Context(prob, deterministic=det) as ctx:
+        assert ctx.sweep_kind() == 'lanes'
+        up = ctx.formal_sol_gamma_matrices()
+    q.gamma_prefill()
+    dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+    assert up.dJMax == pytest.approx(dJ, rel=1e-9)
+    assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-9)
+
+
 @pytest.mark.parametrize('nla,sweep', [(10240, 'march'), (3840, 'lanes'), (5120, 'lanes'), (5632, 'lanes'), (6144, 'lanes'),
                                        (7680, 'lanes')])
 def test_other_sizes_and_sweeps_vs_oracle(gpu, monkeypatch, nla, sweep):
