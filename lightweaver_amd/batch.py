@@ -8,6 +8,7 @@ the device per column (lwhip_compute_profiles), so phi never crosses PCIe.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence
 
 from . import _abi as abi
@@ -37,10 +38,34 @@ class ColumnBatch:
                              for i, p in enumerate(self.problems)]
         else:
             # (the columns of a fused batch share their structure: all but the first borrow the first one's tables)
-            self.contexts = []
-            for p in self.problems:
-                self.contexts.append(Context(p, device=device, stream=stream, batchHint=len(self.problems) if fused else 0,
-                                             like=self.contexts[0] if (fused and self.contexts) else None))
+            # Columns 2 .. n are created concurrently: a borrower's lwhip_create is ~3 ms of host work (its own bookkeeping of
+            # the shared structure) + ~2 ms of allocations and uploads, ctypes releases the interpreter lock for the call, and
+            # the library's create path shares nothing writable between contexts (the donor's borrower count is atomic, the
+            # error text is per thread).  LWHIP_CREATE_THREADS=1 creates them one after the other.
+            hint = len(self.problems) if fused else 0
+            self.contexts = [Context(self.problems[0], device=device, stream=stream, batchHint=hint)] if self.problems else []
+            donor = self.contexts[0] if (fused and self.contexts) else None
+            rest = self.problems[1:]
+            nthr = max(1, min(int(os.environ.get('LWHIP_CREATE_THREADS', '8')), os.cpu_count() or 1, len(rest)))
+            make = lambda p: Context(p, device=device, stream=stream, batchHint=hint, like=donor)  # noqa: E731
+            if nthr > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=nthr) as ex:
+                    futs = [ex.submit(make, p) for p in rest]
+                    made, err = [], None
+                    for f in futs:
+                        try:
+                            made.append(f.result())
+                        except Exception as e:  # (close what was made, then report the first failure)
+                            err = err or e
+                    if err is not None:
+                        for c in reversed(made):
+                            c.close()
+                        self.contexts[0].close()
+                        raise err
+                    self.contexts += made
+            else:
+                self.contexts += [make(p) for p in rest]
         if fused and not streams and self.contexts:
             import ctypes as C
             lib = self.contexts[0].lib
