@@ -1,8 +1,13 @@
 // lwhip_api_prd.hip -- host side of the C ABI (lwhip_host.h): the PRD sub-iterations.
 #include "lwhip_host.h"
 
+namespace
+{
+enum { PRD_PIPE_DEPTH = 4 }; // sub-iterations queued per host round trip (lwhip_redistribute_prd)
+}
 extern "C"
 {
+void prd_read_results(lwhip_context* c, const double* pinned, double* dRho, int32_t* dRhoMaxIdx, double* dJMax, int32_t* dJMaxIdx);
 // ---- PRD sub-iterations.  One sub-iteration = pack (J of the PRD lines into the gather buffer) ->
 // [all-reduce of that buffer across wavelength shards] -> partial (scattering integral for the shard's
 // emission wavelengths, max change per line into the shard's slots of the reduce tail, the PRD rates
@@ -190,7 +195,8 @@ int lwhip_prd_partial(lwhip_context* c)
     // one device, 1D: the per-line maxima of |d rho / rho| are reduced by the apply launch of lwhip_prd_finalise, which also
     // sums the stage-1 parts itself -- a sub-iteration is scatter -> rates pass -> apply (round 4: six launches)
     const bool fused = c->worldSize == 1 && !c->is2d && !c->deterministic;
-    HIP_TRY(launch_prd_scatter(c->prdArgsDev.p, lineArgs.data(), Nprd, c->stream, !fused));
+    const bool piped = fused && c->prdPipeIter > 0;
+    HIP_TRY(launch_prd_scatter(c->prdArgsDev.p, lineArgs.data(), Nprd, c->stream, !fused, piped ? c->prdCtl.p : nullptr, c->prdPipeIter));
     c->prdFused = fused;
     if (c->is2d)
     {
@@ -204,6 +210,11 @@ int lwhip_prd_partial(lwhip_context* c)
     // formal_sol_prd_update_rates (PrdTemplates.hpp:18-75): J and the PRD lines' rates over the PRD wavelengths
     TileDyn dyn = make_dyn(c, false, 0);
     dyn.prdOnly = 1;
+    if (piped)
+    {
+        dyn.stopCtl = c->prdCtl.p;
+        dyn.stopIter = c->prdPipeIter;
+    }
     // unvisited wavelengths: dJ = 0 -- after a full sweep; the sub-iterations that follow visit the same wavelengths
     if (!c->dJPrdClean)
         HIP_TRY(hipMemsetAsync(c->dJ.p, 0, (size_t)c->Nla * sizeof(double), c->stream));
@@ -265,15 +276,37 @@ int lwhip_prd_finalise(lwhip_context* c, double* dRho, int32_t* dRhoMaxIdx, doub
         ap.prdList = c->prdArgsDev.p;
         ap.nPrdChange = Nprd;
     }
+    const bool piped = c->prdFused && c->prdPipeIter > 0;
+    if (piped)
+    {
+        ap.prdCtl = c->prdCtl.p;
+        ap.prdTol = c->prdPipeTol;
+        ap.prdIter = c->prdPipeIter;
+    }
     HIP_TRY(launch_apply(ap, c->stream));
     c->prdFused = false;
     c->prdPending = false;
     const size_t nTail = 2 * (size_t)c->worldSize * (1 + Nprd);
+    if (piped)
+    {
+        // (queued: the slot of this sub-iteration; lwhip_redistribute_prd waits once for the whole group and reads them)
+        HIP_TRY(hipMemcpyAsync(c->prdPinnedPipe + (size_t)((c->prdPipeIter - 1) % PRD_PIPE_DEPTH) * nTail,
+                               c->red.p + (size_t)c->Ntrans * 4 * Ns, nTail * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        return LWHIP_OK;
+    }
     if (!c->prdPinned)
         HIP_TRY(hipHostMalloc((void**)&c->prdPinned, nTail * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(c->prdPinned, c->red.p + (size_t)c->Ntrans * 4 * Ns, nTail * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    prd_read_results(c, c->prdPinned, dRho, dRhoMaxIdx, dJMax, dJMaxIdx);
+    return LWHIP_OK;
+}
+
+// the sub-iteration's results out of the reduce tail's copy: (dJMax, idx) per shard, then per line and shard (max |d rho / rho|, idx)
+void prd_read_results(lwhip_context* c, const double* pinned, double* dRho, int32_t* dRhoMaxIdx, double* dJMax, int32_t* dJMaxIdx)
+{
+    const int Nprd = (int)c->prdLines.size();
     // max over shards, first (lowest) index on ties: max_idx, Constants.hpp:114-125
     auto best_of = [&](const double* slots, size_t stride, double& v, int& idx) {
         v = 0.0;
@@ -301,12 +334,12 @@ int lwhip_prd_finalise(lwhip_context* c, double* dRho, int32_t* dRhoMaxIdx, doub
     };
     double v;
     int idx;
-    best_of(c->prdPinned, 2, v, idx);
+    best_of(pinned, 2, v, idx);
     if (dJMax)
         *dJMax = v;
     if (dJMaxIdx)
         *dJMaxIdx = idx;
-    const double* prdTail = c->prdPinned + 2 * (size_t)c->worldSize;
+    const double* prdTail = pinned + 2 * (size_t)c->worldSize;
     for (int q = 0; q < Nprd; ++q)
     {
         best_of(prdTail + 2 * q, 2 * (size_t)Nprd, v, idx);
@@ -316,7 +349,6 @@ int lwhip_prd_finalise(lwhip_context* c, double* dRho, int32_t* dRhoMaxIdx, doub
         if (dRhoMaxIdx) // the flattened [la, k] index modulo Nlambda, as PrdTemplates.hpp:265 reports it
             dRhoMaxIdx[q] = idx % Nl;
     }
-    return LWHIP_OK;
 }
 
 int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_result* res)
@@ -337,6 +369,86 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
     std::vector<double> dRho(Nprd);
     std::vector<int32_t> dRhoIdx(Nprd);
     int iter = 0;
+    auto record = [&](int it, double dJ, int32_t dJIdx) {
+        double dRhoMax = 0.0;
+        for (int q = 0; q < Nprd; ++q)
+        {
+            dRhoMax = std::max(dRhoMax, dRho[q]);
+            if (res && res->dRho)
+                res->dRho[(size_t)(it - 1) * Nprd + q] = dRho[q];
+            if (res && res->dRhoMaxIdx)
+                res->dRhoMaxIdx[(size_t)(it - 1) * Nprd + q] = dRhoIdx[q];
+        }
+        if (res && res->dJPrdMax)
+            res->dJPrdMax[it - 1] = dJ;
+        if (res && res->dJPrdMaxIdx)
+            res->dJPrdMaxIdx[it - 1] = dJIdx;
+        return dRhoMax;
+    };
+    // One device, 1D, lane sweep, atomic sums: the launches of up to PRD_PIPE_DEPTH sub-iterations are queued back to back --
+    // no host round trip between them (it was 20-25 us of an idle device per sub-iteration, of 155).  The stopping rule of the
+    // loop (PrdTemplates.hpp:250-275: stop after the sub-iteration whose largest |d rho / rho| is below tol) is kept ON THE
+    // DEVICE: the apply launch of a sub-iteration records that it met the tolerance, and every launch of a later
+    // sub-iteration returns at once, so nothing is computed or written that the reference's loop would not have.
+    const bool piped = c->worldSize == 1 && !c->is2d && !c->deterministic && c->laneSweep && !c->hprd && env_int("LWHIP_PRD_PIPELINE", 1) != 0;
+    if (piped)
+    {
+        const size_t nTail = 2 * (size_t)c->worldSize * (1 + Nprd);
+        if (c->prdPinnedPipeN < (size_t)PRD_PIPE_DEPTH * nTail + 4)
+        {
+            if (c->prdPinnedPipe)
+                HIP_TRY(hipHostFree(c->prdPinnedPipe));
+            c->prdPinnedPipe = nullptr;
+            c->prdPinnedPipeN = (size_t)PRD_PIPE_DEPTH * nTail + 4;
+            HIP_TRY(hipHostMalloc((void**)&c->prdPinnedPipe, c->prdPinnedPipeN * sizeof(double), hipHostMallocDefault));
+        }
+        if (c->prdCtl.n < 4)
+            HIP_TRY(c->prdCtl.alloc_zero(4));
+        HIP_TRY(hipMemsetAsync(c->prdCtl.p, 0, 4 * sizeof(int32_t), c->stream));
+        int32_t* ctlHost = (int32_t*)(c->prdPinnedPipe + (size_t)PRD_PIPE_DEPTH * nTail);
+        int st = LWHIP_OK;
+        while (iter < maxIter)
+        {
+            const int nb = std::min((int)PRD_PIPE_DEPTH, maxIter - iter);
+            for (int j = 0; j < nb && st == LWHIP_OK; ++j)
+            {
+                c->prdPipeIter = iter + j + 1;
+                c->prdPipeTol = tol;
+                st = lwhip_prd_pack(c, nullptr, nullptr);
+                if (st == LWHIP_OK)
+                    st = lwhip_prd_partial(c);
+                if (st == LWHIP_OK)
+                    st = lwhip_prd_finalise(c, nullptr, nullptr, nullptr, nullptr);
+            }
+            c->prdPipeIter = 0;
+            if (st != LWHIP_OK)
+                return st;
+            HIP_TRY(hipMemcpyAsync(ctlHost, c->prdCtl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const int stopAt = ctlHost[0]; // the sub-iteration that met the tolerance (0: none so far)
+            bool stopped = false;
+            for (int j = 0; j < nb; ++j)
+            {
+                const int it = iter + j + 1;
+                double dJ = 0.0;
+                int32_t dJIdx = 0;
+                prd_read_results(c, c->prdPinnedPipe + (size_t)((it - 1) % PRD_PIPE_DEPTH) * nTail, dRho.data(), dRhoIdx.data(), &dJ, &dJIdx);
+                record(it, dJ, dJIdx);
+                if (stopAt == it)
+                {
+                    iter = it;
+                    stopped = true;
+                    break;
+                }
+            }
+            if (stopped)
+                break;
+            iter += nb;
+        }
+        if (res)
+            res->NprdSubIter = iter;
+        return LWHIP_OK;
+    }
     while (iter < maxIter)
     {
         ++iter;
@@ -349,20 +461,7 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
             st = lwhip_prd_finalise(c, dRho.data(), dRhoIdx.data(), &dJ, &dJIdx);
         if (st != LWHIP_OK)
             return st;
-        double dRhoMax = 0.0;
-        for (int q = 0; q < Nprd; ++q)
-        {
-            dRhoMax = std::max(dRhoMax, dRho[q]);
-            if (res && res->dRho)
-                res->dRho[(size_t)(iter - 1) * Nprd + q] = dRho[q];
-            if (res && res->dRhoMaxIdx)
-                res->dRhoMaxIdx[(size_t)(iter - 1) * Nprd + q] = dRhoIdx[q];
-        }
-        if (res && res->dJPrdMax)
-            res->dJPrdMax[iter - 1] = dJ;
-        if (res && res->dJPrdMaxIdx)
-            res->dJPrdMaxIdx[iter - 1] = dJIdx;
-        if (dRhoMax < tol)
+        if (record(iter, dJ, dJIdx) < tol)
             break;
     }
     if (res)

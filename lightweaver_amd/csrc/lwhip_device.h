@@ -306,7 +306,7 @@ DEVINL void affine_scan_wave(double& E, double& B)
 }
 // PRD: per line the max over (depth, slice) of the scattering integral's maxima of |d rho / rho| (lwhip_prd.hip), by ONE
 // wavefront: prd_change_kernel on shards, an extra workgroup of the apply launch on one device (lwhip_kernels.hip)
-DEVINL void prd_change_reduce(const PrdLineArgs& a, const int laneIn)
+DEVINL double prd_change_reduce(const PrdLineArgs& a, const int laneIn)
 {
     const double* changeVal = a.changeVal;
     const int* changeIdx = a.changeIdx;
@@ -347,6 +347,7 @@ DEVINL void prd_change_reduce(const PrdLineArgs& a, const int laneIn)
         slot[0] = (rk == rank) ? best : 0.0;
         slot[1] = (rk == rank && best > 0.0) ? (double)idx : 0.0;
     }
+    return best; // (every lane holds it)
 }
 
 }

@@ -427,6 +427,14 @@ struct lwhip_context
     DevBuf<int32_t> contLa;
     DevBuf<int32_t> prdChangeIdx;
     double* prdPinned = nullptr;
+    // pipelined sub-iterations of lwhip_redistribute_prd (one device, 1D, lane sweep): the launches of up to PRD_PIPE_DEPTH
+    // sub-iterations are queued without a host round trip in between; the device keeps the loop's stopping rule (prdCtl, see
+    // ApplyArgs) and every sub-iteration's results land in its own slot of prdPinnedPipe
+    DevBuf<int32_t> prdCtl;
+    double* prdPinnedPipe = nullptr;
+    size_t prdPinnedPipeN = 0;
+    int prdPipeIter = 0;     // > 0: the sub-iteration the calls of lwhip_prd_partial / _finalise belong to
+    double prdPipeTol = 0.0;
     DevBuf<DevTrans> dtrans;
     DevBuf<DevLaHeader> laHdr;
     DevBuf<DevSlot> slots;
@@ -481,6 +489,8 @@ struct lwhip_context
             (void)hipHostFree(changeHost);
         if (prdPinned)
             (void)hipHostFree(prdPinned);
+        if (prdPinnedPipe)
+            (void)hipHostFree(prdPinnedPipe);
         if (zeroCheck)
             (void)hipHostFree(zeroCheck);
     }

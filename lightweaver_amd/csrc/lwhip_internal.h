@@ -335,7 +335,10 @@ struct TileDyn
     int32_t nPass;          // 2: down then up; 1: up only
     int32_t lambdaIterate;
     int32_t prdOnly;
-    int32_t _pad;
+    // pipelined PRD sub-iterations (lwhip_redistribute_prd, round 5): this launch belongs to sub-iteration stopIter and does
+    // nothing if an EARLIER sub-iteration met the tolerance (stopCtl[0] = that sub-iteration's number, 0: none yet)
+    int32_t stopIter;
+    const int32_t* stopCtl;
 };
 // retile one line's profiles: standard [nlt][Nmu][2][Ns] -> the tiles' [2][Ns][64] blocks
 struct RetileArgs
@@ -428,6 +431,12 @@ struct ApplyArgs
     const struct PrdLineArgs* prdList;
     int32_t nPrdChange;
     int32_t nParts;                // parts per transition behind red8 (see ReduceArgs::nParts); 0: LWHIP_REDUCE_SPLIT
+    // pipelined PRD sub-iterations: prdCtl = { number of the first sub-iteration whose max |d rho / rho| was below prdTol (0:
+    // none yet), lines below the tolerance so far, lines reduced so far, sub-iterations run }.  The launch does nothing if
+    // an earlier sub-iteration stopped the loop; its last PRD-line workgroup records whether THIS one does
+    int32_t* prdCtl;
+    double prdTol;
+    int32_t prdIter;
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)
@@ -490,7 +499,8 @@ struct PrdLineArgs
 };
 // every PRD line of the sub-iteration in one set of launches: devList = the device copy of hostList [nLines]
 // reduceChange = false: the per-line maxima are reduced by the apply launch that follows (ApplyArgs::prdList), no prd_change launch
-hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream, bool reduceChange = true);
+hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream, bool reduceChange = true,
+                              const int32_t* stopCtl = nullptr, int stopIter = 0);
 
 // nr_post_update (lwhip_pops.hip): one listed atom, and the launch arguments
 struct NrAtom

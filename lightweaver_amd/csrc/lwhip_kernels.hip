@@ -4,6 +4,7 @@
 //
 // Reference restated (file:line under Lightweaver's Source/): see each kernel.
 #include "lwhip_device.h"
+#include <type_traits>
 #include "../../include/lwhip.h"
 
 #include <algorithm>
@@ -184,10 +185,45 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
 {
     const int Ns = a.Ns;
     const int k0 = blockIdx.y * APPLY_K;
+    if constexpr (std::is_same<A, ApplyArgs>::value)
+    {
+        // pipelined PRD sub-iterations: an earlier one met the tolerance -- this launch does nothing
+        if (a.prdCtl)
+        {
+            const int s = *(const volatile int32_t*)a.prdCtl;
+            if (s != 0 && s < a.prdIter)
+                return;
+        }
+    }
     if ((int)blockIdx.x >= a.Natom + 2) // PRD sub-iteration on one device: the lines' max |d rho / rho| (one wavefront each)
     {
         if (blockIdx.y == 0 && threadIdx.x < 64 && a.prdList && (int)blockIdx.x - (a.Natom + 2) < a.nPrdChange)
-            prd_change_reduce(ld_c(CTAB(PrdLineArgs, a.prdList) + ((int)blockIdx.x - (a.Natom + 2))), (int)threadIdx.x);
+        {
+            const double best = prd_change_reduce(ld_c(CTAB(PrdLineArgs, a.prdList) + ((int)blockIdx.x - (a.Natom + 2))), (int)threadIdx.x);
+            if constexpr (std::is_same<A, ApplyArgs>::value)
+            {
+                if (a.prdCtl && threadIdx.x == 0)
+                {
+                    // the loop of redistribute_prd (PrdTemplates.hpp:250-275) stops after the sub-iteration whose largest change
+                    // over all lines is below the tolerance: the last line's workgroup to arrive records it for the launches
+                    // of the following sub-iterations, which are queued already
+                    if (best < a.prdTol)
+                        atomicAdd(a.prdCtl + 1, 1);
+                    __threadfence();
+                    const int t = atomicAdd(a.prdCtl + 2, 1);
+                    if (t == a.nPrdChange - 1)
+                    {
+                        const int below = atomicAdd(a.prdCtl + 1, 0);
+                        a.prdCtl[1] = 0;
+                        a.prdCtl[2] = 0;
+                        a.prdCtl[3] = a.prdIter;
+                        __threadfence();
+                        if (below == a.nPrdChange)
+                            atomicExch(a.prdCtl, a.prdIter);
+                    }
+                }
+            }
+        }
         return;
     }
     if ((int)blockIdx.x == a.Natom + 1) // dJMax (only launched when a.dJ or a.gatherWorld is set)

@@ -2990,6 +2990,13 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
                                                                        const TileArgs* const* __restrict__ apList, const TileDyn dyn)
 {
     dbg_poison_lds();
+    if (dyn.stopCtl)
+    {
+        // (the PRD rates pass of a pipelined sub-iteration: an earlier sub-iteration met the tolerance -- nothing to do)
+        const int stopAt = __builtin_amdgcn_readfirstlane(*(const volatile int32_t*)dyn.stopCtl);
+        if (stopAt != 0 && stopAt < dyn.stopIter)
+            return;
+    }
     LS_T(tk0);
     constexpr bool RATES = (MODE & 1) != 0;
     extern __shared__ double lds[];

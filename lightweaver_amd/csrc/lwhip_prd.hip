@@ -76,9 +76,21 @@ __device__ double p_GII(double aDamp, double qEmit, double qAbs)
 // (Ns x slices workgroups of two wavefronts); two lines side by side take barely longer than one.
 
 // J(Nblue : Nred, :) -> Jt[k][la]: the scattering integral reads J along wavelength at fixed depth
-__global__ void prd_transpose_kernel(const PrdLineArgs* __restrict__ list)
+// (stopCtl / stopIter: the pipelined sub-iterations of lwhip_redistribute_prd -- a launch of a sub-iteration that comes after
+// the one that met the tolerance does nothing)
+DEVINL bool prd_stopped(const int32_t* stopCtl, const int stopIter)
+{
+    if (!stopCtl)
+        return false;
+    const int s = *(const volatile int32_t*)stopCtl;
+    return s != 0 && s < stopIter;
+}
+
+__global__ void prd_transpose_kernel(const PrdLineArgs* __restrict__ list, const int32_t* stopCtl, const int stopIter)
 {
     dbg_poison_lds();
+    if (prd_stopped(stopCtl, stopIter))
+        return;
     const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.z);
     const double* J = a.J;
     double* Jt = a.Jt;
@@ -102,10 +114,12 @@ __global__ void prd_transpose_kernel(const PrdLineArgs* __restrict__ list)
     }
 }
 
-__global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __restrict__ list)
+__global__ void __launch_bounds__(128) prd_scatter_kernel(const PrdLineArgs* __restrict__ list, const int32_t* stopCtl, const int stopIter)
 {
     dbg_poison_lds();
     extern __shared__ double sm[];
+    if (prd_stopped(stopCtl, stopIter))
+        return;
     const PrdLineArgs a = ld_c(CTAB(PrdLineArgs, list) + blockIdx.z);
     if (a.laHi <= a.laLo || (int)blockIdx.y >= a.slices)
         return;
@@ -363,7 +377,8 @@ __global__ void prd_change_kernel(const PrdLineArgs* __restrict__ list)
     prd_change_reduce(a, (int)threadIdx.x);
 }
 
-hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream, bool reduceChange)
+hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hostList, int nLines, hipStream_t stream, bool reduceChange,
+                              const int32_t* stopCtl, int stopIter)
 {
     if (nLines <= 0)
         return hipSuccess;
@@ -385,8 +400,8 @@ hipError_t launch_prd_scatter(const PrdLineArgs* devList, const PrdLineArgs* hos
     }
     if (any)
     {
-        LWHIP_LAUNCH(prd_transpose_kernel, dim3((maxNl + 31) / 32, (Ns + 31) / 32, nLines), dim3(32, 8), 0, stream, devList);
-        LWHIP_LAUNCH(prd_scatter_kernel, dim3(Ns, maxSlices, nLines), dim3(128), lds, stream, devList);
+        LWHIP_LAUNCH(prd_transpose_kernel, dim3((maxNl + 31) / 32, (Ns + 31) / 32, nLines), dim3(32, 8), 0, stream, devList, stopCtl, stopIter);
+        LWHIP_LAUNCH(prd_scatter_kernel, dim3(Ns, maxSlices, nLines), dim3(128), lds, stream, devList, stopCtl, stopIter);
     }
     if (reduceChange)
         LWHIP_LAUNCH(prd_change_kernel, dim3(nLines), dim3(64), 0, stream, devList);

@@ -407,7 +407,8 @@ TileDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
     TileDyn d{};
     d.nPass = upOnly ? 1 : 2;
     d.lambdaIterate = lambdaIterate;
-    d._pad = 0;
+    d.stopIter = 0;
+    d.stopCtl = nullptr;
     return d;
 }
 

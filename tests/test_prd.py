@@ -215,6 +215,43 @@ def test_hip_prd_matches_oracle(solver):
 
 
 @pytest.mark.gpu
+def test_hip_prd_loop_stops_where_the_reference_loop_stops(monkeypatch):
+    """redistribute_prd(maxIter, tol) stops after the first sub-iteration whose largest |d rho / rho| is below tol
+    (PrdTemplates.hpp:250-275).  The library queues up to four sub-iterations' launches without a host round trip and keeps
+    that rule on the device (the launches of sub-iterations after the stop return at once): same number of sub-iterations as
+    the oracle for a tolerance that stops the loop in the MIDDLE of a queued group, in the next group and never; the state
+    equals the oracle's, and equals what the library does with a host round trip per sub-iteration (LWHIP_PRD_PIPELINE=0)."""
+    from lightweaver_amd.context import Context
+    prob = prd_problem()
+
+    def run(factory, maxIter, tol):
+        p = prob.copy()
+        with factory(p) as ctx:
+            p.gamma_prefill()
+            ctx.formal_sol_gamma_matrices()
+            u = ctx.redistribute_prd(maxIter, tol)
+        return p, u
+
+    _, u0 = run(bindings.OracleContext, 7, 0.0)
+    assert u0['NprdSubIter'] == 7
+    m = np.max(np.asarray(u0['dRho']).reshape(7, -1), axis=1)   # the largest change of each sub-iteration
+    assert np.all(m[1:] < m[:-1]), m   # (it shrinks from one to the next: a tolerance between two values stops at a known place)
+    for stopAfter in (2, 3, 5, 6):     # 1-based sub-iteration that is the first below the tolerance
+        tol = float(np.sqrt(m[stopAfter - 1] * m[stopAfter - 2]))
+        po, uo = run(bindings.OracleContext, 7, tol)
+        assert uo['NprdSubIter'] == stopAfter
+        ph, uh = run(Context, 7, tol)
+        assert uh.NprdSubIter == stopAfter, (stopAfter, uh.NprdSubIter)
+        assert np.allclose(np.asarray(uo['dRho']).reshape(-1)[:uh.dRho.size], np.asarray(uh.dRho).reshape(-1), rtol=1e-5, atol=1e-12)
+        assert_same_state(po, ph, 1e-9)
+        monkeypatch.setenv('LWHIP_PRD_PIPELINE', '0')
+        pn, un = run(Context, 7, tol)
+        monkeypatch.delenv('LWHIP_PRD_PIPELINE')
+        assert un.NprdSubIter == stopAfter
+        assert_same_state(pn, ph, 1e-10)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('include', [True, False])
 def test_hip_prd_detailed_atoms_matches_oracle(include):
     """include_detailed_atoms on the device: a Context created with prdDetailed redistributes the detailed atom's PRD
