@@ -129,7 +129,7 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
             return bail(fail(LWHIP_ERR_DEVICE, "hipStreamCreate failed"));
         c->stream = c->ownStream;
     }
-    if (env_int("LWHIP_CHECK_ZERO", 0) == 1)
+    if (dbg_env_int("LWHIP_CHECK_ZERO", 0) == 1)
     {
         if (hipHostMalloc((void**)&c->zeroCheck, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
             || hipHostGetDevicePointer((void**)&c->zeroCheckDev, c->zeroCheck, 0) != hipSuccess)

@@ -46,6 +46,7 @@ int fail(int code, const std::string& msg);
 
 // > 0: the clearing fills of DevBuf::alloc are queued, not waited for: whoever raised it synchronises the null stream before
 // anything touches the buffers (lwhip_create: 0.7 s less per 512 columns than a wait per allocation)
+inline bool debug_knobs_on(); // (LWHIP_DEBUG=1: the diagnosis knobs below are read only then)
 inline int& devbuf_defer_fill_sync()
 {
     static thread_local int depth = 0;
@@ -79,7 +80,7 @@ template <typename T> struct DevBuf
             return hipSuccess;
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         const int seq = alloc_seq()++;
-        static const bool noClear = std::getenv("LWHIP_NO_CLEAR") != nullptr; // (no safety net: what hipMalloc returns)
+        static const bool noClear = debug_knobs_on() && std::getenv("LWHIP_NO_CLEAR") != nullptr; // (no safety net: what hipMalloc returns)
         const bool sentinel = init == 1 && std::is_same<T, double>::value && sentinel_for(seq);
         const char* what = "";
         if (e == hipSuccess && poison_on())
@@ -146,7 +147,7 @@ template <typename T> struct DevBuf
             e = hipMemset(p, 0, count * sizeof(T));
             what = " cleared";
         }
-        static const bool syncAlloc = std::getenv("LWHIP_SYNC_ALLOC") != nullptr; // (diagnosis: round 4's clearing minus the clearing)
+        static const bool syncAlloc = debug_knobs_on() && std::getenv("LWHIP_SYNC_ALLOC") != nullptr; // (diagnosis: round 4's clearing minus the clearing)
         // (the caller's stream may be a non-blocking one: no implicit order with the fill -- wait for it, or, inside lwhip_create,
         // let the ~60 fills of a context queue up and wait once before the first upload: defer_fill_sync)
         if (e == hipSuccess && ((*what && devbuf_defer_fill_sync() == 0) || syncAlloc))
@@ -164,13 +165,13 @@ template <typename T> struct DevBuf
     }
     static bool poison_on()
     {
-        static const bool poison = std::getenv("LWHIP_POISON") != nullptr;
+        static const bool poison = debug_knobs_on() && std::getenv("LWHIP_POISON") != nullptr;
         return poison;
     }
     // LWHIP_PAD_SENTINEL: "all", one number, or a range A-B (inclusive) of the fp64 allocation numbers of a context
     static bool sentinel_on()
     {
-        static const bool on = std::getenv("LWHIP_PAD_SENTINEL") != nullptr && *std::getenv("LWHIP_PAD_SENTINEL");
+        static const bool on = debug_knobs_on() && std::getenv("LWHIP_PAD_SENTINEL") != nullptr && *std::getenv("LWHIP_PAD_SENTINEL");
         return on;
     }
     static bool sentinel_for(int seq)

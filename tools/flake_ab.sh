@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B on ONE box: in-order runs of tests/test_hip_parity.py with nothing cleared, alternating between the build whose slot adds
 # are flat atomics (rounds 3 / 4) and the shipped one (ds_add_f64)
+export LWHIP_DEBUG=1   # (the diagnosis knobs are read only with it)
 N=${1:-40}
 mkdir -p gpurun_out/flake
 fa=0; fb=0

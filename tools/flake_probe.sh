@@ -3,6 +3,7 @@
 #   tools/flake_probe.sh 50 noclear LWHIP_NO_CLEAR=1
 #   tools/flake_probe.sh 50 noclear_sync LWHIP_NO_CLEAR=1 LWHIP_SYNC_ALLOC=1
 # (round 4 saw the 1.77e-6 deviation of the PRD atom's rates in 5 of 40 such runs before device allocations were cleared)
+export LWHIP_DEBUG=1   # (the diagnosis knobs are read only with it)
 N=${1:-40}; TAG=${2:-default}; shift 2
 mkdir -p gpurun_out/flake
 fails=0

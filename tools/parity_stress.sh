@@ -5,6 +5,7 @@
 #   LWHIP_LIB=.../variants/liblwhip_poison.so  (-DLWHIP_DBG_POISON_LDS: every workgroup of every kernel starts with its
 #                        whole LDS allocation holding a NaN pattern)
 # usage: bash tools/parity_stress.sh [N=20] [first seed=1]  -> gpurun_out/r04_stress/{run_SEED.log,summary.txt}
+export LWHIP_DEBUG=1   # (the diagnosis knobs are read only with it)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 N=${1:-20}
 S0=${2:-1}

@@ -30,6 +30,7 @@ CONFIGS = [('rand', {'LWHIP_PAD_SENTINEL_VALUE': 'rand'}), ('randsign', {'LWHIP_
 
 def run(env_extra, args, log):
     env = dict(os.environ)
+    env['LWHIP_DEBUG'] = '1'   # (the diagnosis knobs are read only with it)
     env.update(env_extra)
     with open(log, 'w') as f:
         p = subprocess.run([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '--tb=line', '-p', 'no:cacheprovider'] + args,
