@@ -556,6 +556,96 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         }
     };
 
+    // ---- continuum-only tiles (no line, no mixed continuum; round 5) ---------------------------------------------------------
+    // chi and S of such a wavelength are the same for every ray, the slopes per unit path scale with mu and the path with 1 / mu:
+    // the control points of chi (ds/3 d chi/ds) and of S (dtau/3 dS/dtau) do not depend on the ray at all, the intervals'
+    // optical depths are T / mu, dS/dtau is mu G.  And the up direction walks the same intervals: T is symmetric, the
+    // derivatives change sign (also at the end points: the one-sided rules of the two directions are each other's mirror).
+    // So gather + stencils -- 31 k of such a task's 77 k clocks -- are formed ONCE per tile at mu = 1, in depth order
+    // (cont_unit), and a ray scales and, going up, mirrors them.
+#ifdef LS_NO_CONT_HOIST
+    constexpr bool CONT = false;
+#else
+    constexpr bool CONT = !GEN && !HPRD && NL == 0 && NM == 0 && SOLVER == LWHIP_FS_BEZIER3_1D;
+#endif
+    double hChi[D], hEta[D], hS[D], hRch[D], hDS[D]; // the lane's points, depth order
+    double hT[D + 1], hRT[D + 1];                    // hT[q]: optical depth at mu = 1 of the interval (k0 + q - 1, k0 + q), and 1 / hT
+    double hChiLo = 0.0, hChiHi = 0.0, hSLo = 0.0, hSHi = 0.0, hDSLo = 0.0, hDSHi = 0.0; // the neighbouring lanes' edge points
+    auto cont_unit = [&]() {
+        const double* r3 = c.sRow3 + c.lane * D;
+        double dh[D + 1], rdh[D + 1], rsum[D];
+        ls_lds<D + 1>(sDep, c.vK, c.oG, dh); // entry k + 1 holds |h_k - h_k+1|: dh[q] = the interval (k0 + q - 1, k0 + q)
+        ls_lds<D + 1>(sDep, c.vK, c.oG + c.gStride, rdh);
+        ls_lds<D>(sDep, c.vK + 8u, c.oG + 2u * c.gStride, rsum);
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+        {
+            const double cC = r3[p], eC = r3[64 * D + p], sc = r3[2 * 64 * D + p];
+            const double rc = ls_rcp(cC);
+            hChi[p] = cC;
+            hEta[p] = eC;
+            hRch[p] = rc;
+            hS[p] = (eC + sc) * rc;
+        }
+        hChiLo = ls_shift1<true>(hChi[D - 1]);
+        hSLo = ls_shift1<true>(hS[D - 1]);
+        hChiHi = ls_shift1<false>(hChi[0]);
+        hSHi = ls_shift1<false>(hS[0]);
+        const int pBot = c.pBot, blk = c.blk, nV = c.nV;
+        auto dFirst = [&](int i) { return i == 0 && blk == 0; };
+        auto dLast = [&](int i) { return i == pBot; };
+        auto dOk = [&](int i) { return i < nV; };
+        auto chiK = [&](int i) { return i < 0 ? hChiLo : i >= D ? hChiHi : hChi[i < 0 ? 0 : i >= D ? D - 1 : i]; };
+        auto srcK = [&](int i) { return i < 0 ? hSLo : i >= D ? hSHi : hS[i < 0 ? 0 : i >= D ? D - 1 : i]; };
+        // (the stencils of the ray loop below for the down direction with zmu = muz = 1: FormalScalar.cpp:209-325)
+        double sl[D + 1];
+#pragma unroll
+        for (int i = 0; i <= D; ++i)
+            sl[i] = (chiK(i) - chiK(i - 1)) * rdh[i];
+        double dx[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+        {
+            const double P0 = fabs((sl[i] * dh[i + 1] + sl[i + 1] * dh[i]) * rsum[i]);
+            const double v = (copysign(1.0, sl[i + 1]) + copysign(1.0, sl[i])) * fmin(fabs(sl[i]), fmin(fabs(sl[i + 1]), 0.5 * P0));
+            dx[i] = dFirst(i) ? sl[i + 1] : dLast(i) ? sl[i] : v;
+        }
+        const double dxP = ls_shift1<true>(dx[D - 1]);
+        double sS[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+        {
+            const double cu = chiK(i - 1), cd = chiK(i);
+            const double dxu = i == 0 ? dxP : dx[i > 0 ? i - 1 : 0];
+            const double ds3 = dh[i] * (1.0 / 3.0);
+            const double Cuw = cu + ds3 * dxu;
+            const double C0 = cd - ds3 * dx[i];
+            double t = dh[i] * (cu + cd + Cuw + C0) * 0.25;
+            t = (dFirst(i) || !dOk(i)) ? 1.0 : t;
+            hT[i] = t;
+            hRT[i] = ls_rcp(t);
+            sS[i] = (srcK(i) - srcK(i - 1)) * hRT[i];
+        }
+        const double dtN = ls_shift1<false>(hT[0]), rtN = ls_shift1<false>(hRT[0]), sSN = ls_shift1<false>(sS[0]);
+        // (the interval to the next lane's first point; past the column's end it is as inert as a padding point's)
+        const bool okN = c.k0 + D < Ns;
+        hT[D] = okN ? dtN : 1.0;
+        hRT[D] = okN ? rtN : 1.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+        {
+            const double dtd = i == D - 1 ? dtN : hT[i < D - 1 ? i + 1 : 0];
+            const double sSd = i == D - 1 ? sSN : sS[i < D - 1 ? i + 1 : 0];
+            const double P0 = fabs((sS[i] * dtd + sSd * hT[i]) * ls_rcp(hT[i] + dtd));
+            const double v = (copysign(1.0, sSd) + copysign(1.0, sS[i])) * fmin(fabs(sS[i]), fmin(fabs(sSd), 0.5 * P0));
+            // the column's first point takes the slope of the interval below it, its last point that of the interval above it
+            // (what the up direction, whose first point it is, takes with the opposite sign: the down direction closes linearly)
+            hDS[i] = dFirst(i) ? sSd : dLast(i) ? sS[i] : v;
+        }
+        hDSLo = ls_shift1<true>(hDS[D - 1]);
+        hDSHi = ls_shift1<false>(hDS[0]);
+    };
+
 #ifdef LS_TIMING
     unsigned long long tmA = 0, tmB = 0, tmC = 0, tmS = 0, tmD = 0, tmBprev = 0;
 #endif
@@ -621,6 +711,30 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         double chi[D], S[D], rch[D];
         double phiK[NLc][D]; // the ray's profiles at the lane's points (k order): kept for the moments
         double dhK[D + 1], rdhK[D + 1], rsumK[D]; // geometry of the block (used by the stencils, requested with the gather's loads)
+        if constexpr (CONT)
+        {
+            // (continuum-only tile: chi, S, 1 / chi from cont_unit, in march order; dh for the boundary steps)
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+            {
+                chi[MI(p)] = hChi[p];
+                rch[MI(p)] = hRch[p];
+                S[MI(p)] = hS[p];
+            }
+            ls_lds<D + 1>(sDep, c.vK, c.oG, dhK);
+            if (storeDepth && act)
+            {
+                const size_t o = ((size_t)(la * Nmu + mu) * 2 + dirI) * Ns + k0;
+#pragma unroll
+                for (int p = 0; p < D; ++p)
+                    if (p < c.nV)
+                    {
+                        GD(a.depthChi)[o + p] = hChi[p];
+                        GD(a.depthEta)[o + p] = hEta[p];
+                    }
+            }
+        }
+        else
         {
             unsigned vK = c.vK, vRow = c.vRow, vPhi = vPhi0, vRho = vRho0;
             LS_KEEPI(vK);
@@ -753,8 +867,8 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         LS_PHASE();
         LS_T(tp1);
         // halo: the last point of the upwind lane (P), the first point of the downwind lane (N)
-        const double chiP = ls_shift1<!UP>(chi[D - 1]), SP = ls_shift1<!UP>(S[D - 1]);
-        const double chiN = ls_shift1<UP>(chi[0]), SN = ls_shift1<UP>(S[0]);
+        const double chiP = CONT ? (UP ? hChiHi : hChiLo) : ls_shift1<!UP>(chi[D - 1]), SP = CONT ? (UP ? hSHi : hSLo) : ls_shift1<!UP>(S[D - 1]);
+        const double chiN = CONT ? (UP ? hChiLo : hChiHi) : ls_shift1<UP>(chi[0]), SN = CONT ? (UP ? hSLo : hSHi) : ls_shift1<UP>(S[0]);
 #define CHI(i) ((i) < 0 ? chiP : (i) >= D ? chiN : chi[(i) < 0 ? 0 : (i) >= D ? D - 1 : (i)])
 #define SRC(i) ((i) < 0 ? SP : (i) >= D ? SN : S[(i) < 0 ? 0 : (i) >= D ? D - 1 : (i)])
 
@@ -764,6 +878,19 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             // piecewise_bezier3_1d_impl FormalScalar.cpp:209-325, every quantity of the march formed per point
             double x[D], dS[D], dSP; // optical depth of the intervals, dS / dtau at the points
             double rx[D];            // 1 / x: serves the S slopes here and, cubed, the coefficients' 1 / x^3
+            if constexpr (CONT)
+            {
+                // (continuum-only tile: the intervals of this direction, scaled; going up the derivatives change sign)
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                {
+                    x[i] = hT[UP ? D - i : i] * zmu;
+                    rx[i] = hRT[UP ? D - i : i] * muz;
+                    dS[i] = UP ? -(hDS[D - 1 - i] * muz) : hDS[i] * muz;
+                }
+                dSP = UP ? -(hDSHi * muz) : hDSLo * muz;
+            }
+            else
             {
                 double ds[D + 1], sl[D + 1];
 #pragma unroll
@@ -811,6 +938,8 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                     dS[i] = is_first(i) ? sSd : v;
                 }
                 dSP = ls_shift1<!UP>(dS[D - 1]);
+            }
+            {
                 // the last point of the ray is piecewise linear (:306-321): its optical depth replaces the interval's
 #pragma unroll
                 for (int i = 0; i < D; ++i)
@@ -1423,6 +1552,8 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     for (run = 0; run < nRun; ++run)
     {
     prefetch_first();
+    if constexpr (CONT)
+        cont_unit();
 #ifdef LS_ABL_NO_RAYS
     if (dyn.nPass == 77)
 #else
