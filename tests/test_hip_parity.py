@@ -383,6 +383,42 @@ def test_create_like_borrows_structure_tables(gpu, sweep):
     assert c0._h is None                        # closed by its last borrower
 
 
+def test_create_like_under_another_layout_uploads_its_own_tables(gpu, monkeypatch):
+    """The structure fingerprint of lwhip_create_like covers the problem, not the layout choices build_tables reads from the
+    environment: a borrower made under another split factor (or sweep) computes another layout and must not run on the donor's
+    tables.  Every table is borrowed only if its content fingerprint equals what the borrower would upload (round 4's advisor
+    finding); results equal the oracle's either way."""
+    mods = lambda: [models.H_6(0.3), models.CaII_6(0.3)]
+    p0 = models.build_problem(models.perturbed(models.falc82(), seed=21), mods(), Nrays=3)
+    p1 = models.build_problem(models.perturbed(models.falc82(), seed=22), mods(), Nrays=3)
+    q = p1.copy()
+    with OracleContext(q) as oc:
+        q.gamma_prefill()
+        oc.formal_sol_gamma_matrices()
+    monkeypatch.setenv('LWHIP_LANE_SPLIT', '1')
+    c0 = Context(p0)
+    try:
+        for env in ({'LWHIP_LANE_SPLIT': '2'}, {'LWHIP_LANE_SPLIT': '4'}, {'LWHIP_SWEEP': 'march'}):
+            for k in ('LWHIP_LANE_SPLIT', 'LWHIP_SWEEP'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            a = p1.copy()
+            with Context(a, like=c0) as c1:
+                a.gamma_prefill()
+                c1.formal_sol_gamma_matrices()
+            compare_problems(a, q)
+        q0 = p0.copy()
+        with OracleContext(q0) as oc:
+            q0.gamma_prefill()
+            oc.formal_sol_gamma_matrices()
+        p0.gamma_prefill()
+        c0.formal_sol_gamma_matrices()             # the donor is unharmed
+        compare_problems(p0, q0)
+    finally:
+        c0.close()
+
+
 def test_stat_equil_reports_population_changes(gpu):
     """dPops / dPopsMaxIdx of LwContext.stat_equil (Ng::max_change with the default Ng(0,0,0)): max relative
     change of each active atom's populations and the flattened [level, depth] index of its first occurrence."""
