@@ -1039,6 +1039,7 @@ static int compute_profiles_impl(lwhip_context* c)
     }
     c->deviceProfiles = true;
     c->profilesStale = false;
+    c->phiSym = c->vlosZero; // (the Voigt arguments of the two directions differ by the sign of the line-of-sight velocity alone)
     return retile_profiles(c);
 }
 

@@ -62,6 +62,7 @@ static int batch_compute_profiles(lwhip_batch* b, bool all)
     {
         c->deviceProfiles = true;
         c->profilesStale = false;
+        c->phiSym = c->vlosZero;
         RetileArgs r;
         if (retile_args(c, r))
             rl.push_back(r);
@@ -250,7 +251,9 @@ int lwhip_batch_formal_sol_gamma_matrices(lwhip_batch* b, int lambdaIterate, dou
         b->aCrsw = crsw;
     }
     // one set of launches for all columns: pre-pass, sweep (each workgroup finishes its tile when fused), stage 2
-    const TileDyn dyn = make_dyn(c0, false, lambdaIterate);
+    TileDyn dyn = make_dyn(c0, false, lambdaIterate);
+    for (int q = 0; q < n && dyn.phiSym; ++q) // (one launch for all columns: pairs only if every column's profiles are symmetric)
+        dyn.phiSym = b->ctxs[q]->phiSym ? 1 : 0;
     const bool fuse = c0->tileFuse;
     if (!c0->laneSweep) // (the lane sweep's tasks do their own pre-pass)
         HIP_TRY(launch_tile_pre(c0->dtargs.p, c0->htargs, c0->nTiles, b->apList.p, n, c0->stream));

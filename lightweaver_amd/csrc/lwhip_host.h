@@ -432,6 +432,9 @@ struct lwhip_context
     // sub-iterations are queued without a host round trip in between; the device keeps the loop's stopping rule (prdCtl, see
     // ApplyArgs) and every sub-iteration's results land in its own slot of prdPinnedPipe
     DevBuf<int32_t> prdCtl;
+    // every line's profile is the same for the two directions of an angle (static atmosphere): found when the profiles are
+    // uploaded (the host's arrays are compared) or generated (all line-of-sight velocities zero); TileDyn::phiSym
+    bool phiSym = false, vlosZero = false;
     double* prdPinnedPipe = nullptr;
     size_t prdPinnedPipeN = 0;
     int prdPipeIter = 0;     // > 0: the sub-iteration the calls of lwhip_prd_partial / _finalise belong to

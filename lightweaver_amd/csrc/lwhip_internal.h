@@ -339,6 +339,9 @@ struct TileDyn
     // nothing if an EARLIER sub-iteration met the tolerance (stopCtl[0] = that sub-iteration's number, 0: none yet)
     int32_t stopIter;
     const int32_t* stopCtl;
+    // 1: every line's profile is the same for the two directions of an angle (a static atmosphere): the lane sweep forms
+    // chi, S and the stencils once per angle for its one-line tiles (lwhip_lanesweep.hip, "pairs")
+    int32_t phiSym, _padS;
 };
 // retile one line's profiles: standard [nlt][Nmu][2][Ns] -> the tiles' [2][Ns][64] blocks
 struct RetileArgs

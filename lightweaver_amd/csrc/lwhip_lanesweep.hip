@@ -568,19 +568,49 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
 #else
     constexpr bool CONT = !GEN && !HPRD && NL == 0 && NM == 0 && SOLVER == LWHIP_FS_BEZIER3_1D;
 #endif
+    // ---- one-line tiles whose profiles do not depend on the direction (a static atmosphere: phi(mu, up) = phi(mu, down)) ----
+    // The two rays of an angle then see the same chi and S, so the same holds for the pair: gather and stencils once per
+    // ANGLE (cont_unit with the line's opacity of that angle), the down and the up ray scale / mirror them.  The host sets
+    // TileDyn::phiSym when every line's profile is direction-symmetric (checked when the profiles are uploaded or generated);
+    // wavefronts that hold only one direction of an angle (split rays) take the general path.
+#ifdef LS_NO_PAIR_HOIST
+    constexpr bool PAIRABLE = false;
+#else
+    constexpr bool PAIRABLE = !GEN && HOLD && NL == 1 && SOLVER == LWHIP_FS_BEZIER3_1D;
+#endif
     double hChi[D], hEta[D], hS[D], hRch[D], hDS[D]; // the lane's points, depth order
+    double hPhi[D];                                  // (pairs: the line's profile of the angle, for the moments)
     double hT[D + 1], hRT[D + 1];                    // hT[q]: optical depth at mu = 1 of the interval (k0 + q - 1, k0 + q), and 1 / hT
     double hChiLo = 0.0, hChiHi = 0.0, hSLo = 0.0, hSHi = 0.0, hDSLo = 0.0, hDSHi = 0.0; // the neighbouring lanes' edge points
-    auto cont_unit = [&]() {
+    auto cont_unit = [&](const int muLine) {
         const double* r3 = c.sRow3 + c.lane * D;
         double dh[D + 1], rdh[D + 1], rsum[D];
         ls_lds<D + 1>(sDep, c.vK, c.oG, dh); // entry k + 1 holds |h_k - h_k+1|: dh[q] = the interval (k0 + q - 1, k0 + q)
         ls_lds<D + 1>(sDep, c.vK, c.oG + c.gStride, rdh);
         ls_lds<D>(sDep, c.vK + 8u, c.oG + 2u * c.gStride, rsum);
+        double lphi[D];
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+            lphi[p] = 0.0;
+        if constexpr (PAIRABLE)
+        {
+            // the line's profile of this angle (its down ray's block; the up ray's is the same) -- requested here, not one ray
+            // ahead (a request one ANGLE ahead was measured: 14 more spilled registers, no gain)
+            ls_gld<D>(rPhi[0], vPhi0, (unsigned)(muLine * 2) * Ns8, lphi);
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+                hPhi[p] = lphi[p];
+        }
 #pragma unroll
         for (int p = 0; p < D; ++p)
         {
-            const double cC = r3[p], eC = r3[64 * D + p], sc = r3[2 * 64 * D + p];
+            double cC = r3[p], eC = r3[64 * D + p];
+            const double sc = r3[2 * 64 * D + p];
+            if constexpr (PAIRABLE)
+            {
+                cC = fma(cxr[0][p], lphi[p], cC);
+                eC = fma(cer[0][p], lphi[p], eC);
+            }
             const double rc = ls_rcp(cC);
             hChi[p] = cC;
             hEta[p] = eC;
@@ -650,8 +680,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     unsigned long long tmA = 0, tmB = 0, tmC = 0, tmS = 0, tmD = 0, tmBprev = 0;
 #endif
     // ---- one ray of every wavelength of the tile ------------------------------------------------------------------------
-    auto pass = [&](auto upTag, const int mu, const unsigned sRayNext) {
+    auto pass = [&](auto upTag, auto reuseTag, const int mu, const unsigned sRayNext) {
         constexpr bool UP = decltype(upTag)::value;
+        constexpr bool REUSE = CONT || decltype(reuseTag)::value; // chi, S and the stencils come from cont_unit
         constexpr int dirI = UP ? 1 : 0;
         LS_T(tp0);
 #define MI(i) (UP ? D - 1 - (i) : (i)) /* march index <-> index in the lane's k-ordered block (an involution) */
@@ -711,15 +742,18 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         double chi[D], S[D], rch[D];
         double phiK[NLc][D]; // the ray's profiles at the lane's points (k order): kept for the moments
         double dhK[D + 1], rdhK[D + 1], rsumK[D]; // geometry of the block (used by the stencils, requested with the gather's loads)
-        if constexpr (CONT)
+        if constexpr (REUSE)
         {
-            // (continuum-only tile: chi, S, 1 / chi from cont_unit, in march order; dh for the boundary steps)
+            // (continuum-only tile, or the pair of a direction-symmetric angle: chi, S, 1 / chi from cont_unit, in march order;
+            // dh for the boundary steps)
 #pragma unroll
             for (int p = 0; p < D; ++p)
             {
                 chi[MI(p)] = hChi[p];
                 rch[MI(p)] = hRch[p];
                 S[MI(p)] = hS[p];
+                if constexpr (NL > 0)
+                    phiK[0][p] = hPhi[p];
             }
             ls_lds<D + 1>(sDep, c.vK, c.oG, dhK);
             if (storeDepth && act)
@@ -867,8 +901,8 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         LS_PHASE();
         LS_T(tp1);
         // halo: the last point of the upwind lane (P), the first point of the downwind lane (N)
-        const double chiP = CONT ? (UP ? hChiHi : hChiLo) : ls_shift1<!UP>(chi[D - 1]), SP = CONT ? (UP ? hSHi : hSLo) : ls_shift1<!UP>(S[D - 1]);
-        const double chiN = CONT ? (UP ? hChiLo : hChiHi) : ls_shift1<UP>(chi[0]), SN = CONT ? (UP ? hSLo : hSHi) : ls_shift1<UP>(S[0]);
+        const double chiP = REUSE ? (UP ? hChiHi : hChiLo) : ls_shift1<!UP>(chi[D - 1]), SP = REUSE ? (UP ? hSHi : hSLo) : ls_shift1<!UP>(S[D - 1]);
+        const double chiN = REUSE ? (UP ? hChiLo : hChiHi) : ls_shift1<UP>(chi[0]), SN = REUSE ? (UP ? hSLo : hSHi) : ls_shift1<UP>(S[0]);
 #define CHI(i) ((i) < 0 ? chiP : (i) >= D ? chiN : chi[(i) < 0 ? 0 : (i) >= D ? D - 1 : (i)])
 #define SRC(i) ((i) < 0 ? SP : (i) >= D ? SN : S[(i) < 0 ? 0 : (i) >= D ? D - 1 : (i)])
 
@@ -878,9 +912,9 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             // piecewise_bezier3_1d_impl FormalScalar.cpp:209-325, every quantity of the march formed per point
             double x[D], dS[D], dSP; // optical depth of the intervals, dS / dtau at the points
             double rx[D];            // 1 / x: serves the S slopes here and, cubed, the coefficients' 1 / x^3
-            if constexpr (CONT)
+            if constexpr (REUSE)
             {
-                // (continuum-only tile: the intervals of this direction, scaled; going up the derivatives change sign)
+                // (the intervals of this direction, scaled; going up the derivatives change sign)
 #pragma unroll
                 for (int i = 0; i < D; ++i)
                 {
@@ -1551,21 +1585,39 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
     const int nRun = NRUN;
     for (run = 0; run < nRun; ++run)
     {
-    prefetch_first();
+    // (pairs: only a wavefront that holds both rays of every angle -- no split -- and only if the host found the profiles symmetric)
+    const bool pairMode = PAIRABLE && dyn.phiSym != 0 && dyn.nPass == 2 && q0 == 0 && q1 == 2 * Nmu;
+    if (!pairMode)
+        prefetch_first();
     if constexpr (CONT)
-        cont_unit();
+        cont_unit(0);
 #ifdef LS_ABL_NO_RAYS
     if (dyn.nPass == 77)
 #else
     if (dyn.nPass == 2)
 #endif
     {
-        for (int mu = q0 >> 1; 2 * mu < q1; ++mu)
+        if (pairMode)
         {
-            if (2 * mu >= q0)
-                pass(std::false_type{}, mu, (unsigned)(mu * 2 + 1) * Ns8);
-            if (2 * mu + 1 < q1)
-                pass(std::true_type{}, mu, (unsigned)(mu * 2 + 2) * Ns8);
+            if constexpr (PAIRABLE)
+            {
+                for (int mu = 0; mu < Nmu; ++mu)
+                {
+                    cont_unit(mu);
+                    pass(std::false_type{}, std::true_type{}, mu, 0u);
+                    pass(std::true_type{}, std::true_type{}, mu, 0u);
+                }
+            }
+        }
+        else
+        {
+            for (int mu = q0 >> 1; 2 * mu < q1; ++mu)
+            {
+                if (2 * mu >= q0)
+                    pass(std::false_type{}, std::false_type{}, mu, (unsigned)(mu * 2 + 1) * Ns8);
+                if (2 * mu + 1 < q1)
+                    pass(std::true_type{}, std::false_type{}, mu, (unsigned)(mu * 2 + 2) * Ns8);
+            }
         }
     }
     else
@@ -1573,7 +1625,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
         if (dyn.nPass == 78)
 #endif
         for (int mu = q0; mu < q1; ++mu)
-            pass(std::true_type{}, mu, (unsigned)(mu * 2 + 3) * Ns8);
+            pass(std::true_type{}, std::false_type{}, mu, (unsigned)(mu * 2 + 3) * Ns8);
 #ifdef LS_ABL_NO_SLOTFIN
     if (MOM && dyn.nPass == 77)
 #else

@@ -403,12 +403,12 @@ int retile_profiles(lwhip_context* c)
 
 TileDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
 {
-    (void)c;
     TileDyn d{};
     d.nPass = upOnly ? 1 : 2;
     d.lambdaIterate = lambdaIterate;
     d.stopIter = 0;
     d.stopCtl = nullptr;
+    d.phiSym = (c && c->phiSym && env_int("LWHIP_PAIR_RAYS", 1) != 0) ? 1 : 0;
     return d;
 }
 
@@ -511,6 +511,7 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
     const size_t l0 = c->laStart;
     std::vector<double> rmuzHost; // (lives until the synchronisation at the end)
+    bool phiSymUp = true;         // (LWHIP_PROFILES: the uploaded profiles are the same for both directions of every angle)
     if (mask & LWHIP_GAMMA)
         c->prefillPending = false; // the host pre-fill being uploaded supersedes it
     if (mask & LWHIP_ATMOS)
@@ -525,7 +526,14 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         H2D(c->wmu.p, p.wmu, Nr);
         H2D(c->wavelength.p, p.wavelength + l0, Nla);
         if (p.vlosMu)
+        {
             H2D(c->vlosMu.p, p.vlosMu, Nr * Ns);
+            c->vlosZero = true;
+            for (size_t e = 0; e < Nr * Ns && c->vlosZero; ++e)
+                c->vlosZero = p.vlosMu[e] == 0.0;
+        }
+        else
+            c->vlosZero = false;
         if (c->tiled)
         {
             // per-depth geometry of the ray-column sweep (scalar loads): |h_k - h_k+1|, its reciprocal,
@@ -679,6 +687,12 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
                 {
                     if (nlt)
                         H2D(c->phi.p + h.phiOff, t.phi + (size_t)h.ltStart * Nr * 2 * Ns, nlt * Nr * 2 * Ns);
+                    // phi [lt][mu][down / up][k]: the same for both directions of every angle?  (one pass over what is uploaded)
+                    for (size_t e = 0; e < nlt * Nr && phiSymUp; ++e)
+                    {
+                        const double* ph = t.phi + ((size_t)h.ltStart * Nr + e) * 2 * Ns;
+                        phiSymUp = std::memcmp(ph, ph + Ns, Ns * sizeof(double)) == 0;
+                    }
                     H2D(c->wphi.p + (size_t)h.row * Ns, t.wphi, Ns);
                 }
                 if ((mask & LWHIP_NSTAR) && t.aDamp)
@@ -716,6 +730,7 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
         if (str != LWHIP_OK)
             return str;
         c->deviceProfiles = c->profilesStale = false; // the host's profiles are authoritative again
+        c->phiSym = phiSymUp;
     }
     else if ((mask & (LWHIP_ATMOS | LWHIP_NSTAR)) && c->deviceProfiles)
         c->profilesStale = true; // phi / wphi follow the new velocities and widths before the next sweep
