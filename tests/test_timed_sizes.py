@@ -92,6 +92,37 @@ def test_other_sizes_and_sweeps_vs_oracle(gpu, monkeypatch, nla, sweep):
     assert_iteration_matches(prob, q, tol=1e-9, tolGamma=1e-9)
 
 
+@pytest.mark.parametrize('moving', [False, True])
+def test_ray_pairs_of_a_static_atmosphere_vs_oracle(gpu, monkeypatch, moving):
+    """In a static atmosphere the two rays of an angle see the same line profile, so the lane sweep forms chi, S and the
+    stencils of a one-line tile once per ANGLE and mirrors them for the up ray (round 5; the host finds the symmetry when the
+    profiles are uploaded or generated).  Both ways (`LWHIP_PAIR_RAYS=0` is the general path) against the oracle; with a
+    velocity field the profiles differ, the library must find that out by itself, and the two settings are then the same
+    code path -- bit-identical J."""
+    from lightweaver_amd.context import Context
+    monkeypatch.setenv('LWHIP_LANE_SPLIT', '1')   # (whole rays per wavefront: only then does a wavefront hold both rays of an angle)
+    kw = dict(atmos=models.perturbed(models.falc82(), seed=5)) if moving else {}
+    prob = models.throughput_grid(NlambdaTarget=1024, Nrays=3, **kw)
+    q = prob.copy()
+    oc = OracleContext(q)
+    q.gamma_prefill()
+    oc.formal_sol_gamma_matrices(Nthreads=THREADS)
+    runs = []
+    for pair in ('1', '0'):
+        monkeypatch.setenv('LWHIP_PAIR_RAYS', pair)
+        p = prob.copy()
+        with Context(p) as ctx:
+            assert ctx.sweep_kind() == 'lanes'
+            ctx.formal_sol_gamma_matrices()
+        assert_iteration_matches(p, q, tol=1e-9, tolGamma=1e-9)
+        runs.append(p)
+    if moving:
+        assert np.array_equal(runs[0].J, runs[1].J) and np.array_equal(runs[0].I, runs[1].I)
+    else:
+        assert not np.array_equal(runs[0].J, runs[1].J)          # (another order of the same arithmetic: the pairs were used)
+        assert np.max(np.abs(runs[0].J - runs[1].J) / runs[1].J) < 1e-10
+
+
 @pytest.mark.parametrize('sweep', ['march', 'lanes'])
 def test_prd_at_timed_size_vs_oracle(gpu, monkeypatch, sweep):
     """BASELINE configs[2] as bench.py's aux entry C3 times it: the 10 240-wavelength grid with Ca II H & K as PRD lines
