@@ -1177,6 +1177,7 @@ int build_tables(lwhip_context* c)
                     const int rounds = (nch0 + slotsWg - 1) / slotsWg;
                     const int room = rounds * slotsWg - nch0;
                     int nCut = std::max(1, numCU / 2);
+                    nCut = std::max(0, dbg_env_int("LWHIP_LANE_CUT", nCut)); // (experiments: chunks of the tail cut in two)
                     if (room >= numCU / 8 && room < nCut)
                         nCut = room;
                     const int keepAuto = std::max(0, nch0 - nCut);
