@@ -47,7 +47,8 @@ def build_hip(force=False, verbose=False, defines=(), out=None, extra_flags=()):
     # (-save-temps=obj: the compiler leaves the device listing <unit>-hip-amdgcn-amd-amdhsa-gfx950.s next to the object -- the
     # listing of exactly the code that ships, for the spill check below)
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-save-temps=obj'] + [f'-D{d}' for d in defines] + list(extra_flags)
-    rebuilt = []
+    from concurrent.futures import ProcessPoolExecutor
+    lints = []   # (the spill check of a unit starts when its listing is there, next to the other units' compilations)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
@@ -56,12 +57,15 @@ def build_hip(force=False, verbose=False, defines=(), out=None, extra_flags=()):
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True, cwd=CSRC)
-            rebuilt.append(src)
+            lst = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+            if os.path.exists(lst):
+                lints.append(pool.submit(_lint_one, lst))
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, srcs))
-    check_spills(objdir, rebuilt, verbose=verbose)
+    with ProcessPoolExecutor(max_workers=2) as pool:
+        with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_one, srcs))
+        check_spills(objdir, [f.result() for f in lints], verbose=verbose)
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
         print(' '.join(cmd))
@@ -69,24 +73,16 @@ def build_hip(force=False, verbose=False, defines=(), out=None, extra_flags=()):
     return lib
 
 
-def check_spills(objdir, sources, verbose=False):
+def check_spills(objdir, results, verbose=False):
     """No kernel may reload a spilled register for lanes that were switched off when it was stored (spill_lint.py: what
-    ROCm 7.2's register allocator did to lanesweep_kernel in round 5).  Checked on the listings of the units just compiled;
-    the report of every kernel with spills goes to build/spill_lint.txt.  A reported kernel fails the build: restructure the
-    lane-divergent `if` the report points at (or relieve the register pressure) until it is clean."""
-    from . import spill_lint
-    from concurrent.futures import ProcessPoolExecutor
-    lst = []
-    for src in sources:
-        s = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '-hip-amdgcn-amd-amdhsa-gfx950.s')
-        if os.path.exists(s):
-            lst.append(s)
-    if not lst:
+    ROCm 7.2's register allocator did to lanesweep_kernel in round 5).  Checked on the listings of the units just compiled
+    (results: what _lint_one returned for each); the report of every kernel with spills goes to build/spill_lint.txt.  A
+    reported kernel fails the build: restructure the lane-divergent `if` the report points at (or relieve the register
+    pressure) until it is clean."""
+    if not results:
         return
-    with ProcessPoolExecutor(max_workers=min(len(lst), os.cpu_count() or 1)) as ex:
-        res = list(ex.map(_lint_one, lst))
     lines, nbad = [], 0
-    for path, bad, report in res:
+    for path, bad, report in results:
         nbad += bad
         for kernel, nsp, nslots in report:
             lines.append(f'{os.path.basename(path)}: {kernel}: {nsp} spill stores (dwords), {nslots} slot(s) reported')
