@@ -310,15 +310,18 @@ def test_rccl_allreduce_on_the_library_reduce_buffer(gpu):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('static', [False, True])
 @pytest.mark.parametrize('fused', [True, False])
-def test_column_batch_vs_oracle(gpu, fused, sweep):
+def test_column_batch_vs_oracle(gpu, fused, sweep, static):
     """BASELINE configs[3] in miniature: perturbed FAL-C columns as independent problems, profiles
     generated on the device, iterated as a batch -- fused (lwhip_batch_*: one grid slice per column in one set of
-    launches) or column by column; every column must match its own CPU run, dJMax included."""
+    launches) or column by column; every column must match its own CPU run, dJMax included.  static: the columns have no
+    velocity field, so the device-generated profiles do not depend on the direction and the lane sweep pairs the rays of an
+    angle (in the batch launch: only if every column is static)."""
     from lightweaver_amd.batch import ColumnBatch, columns_of_rank
     assert columns_of_rank(10, 4, 1) == [1, 5, 9]
     assert sorted(sum((columns_of_rank(10, 4, r) for r in range(4)), [])) == list(range(10))
-    probs = [models.build_problem(models.perturbed(models.falc82(), seed=100 + i),
+    probs = [models.build_problem(models.perturbed(models.falc82(), seed=100 + i, dv=0.0 if static else 2.0e3),
                                   [models.H_6(0.3), models.CaII_6(0.3)], Nrays=3) for i in range(4)]
     refs = [p.copy() for p in probs]
     dJref = []
