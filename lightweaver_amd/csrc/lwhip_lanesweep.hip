@@ -578,7 +578,7 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
 #else
     constexpr bool PAIRABLE = !GEN && HOLD && NL == 1 && SOLVER == LWHIP_FS_BEZIER3_1D;
 #endif
-    double hChi[D], hEta[D], hS[D], hRch[D], hDS[D]; // the lane's points, depth order
+    double hChi[D], hS[D], hRch[D], hDS[D]; // the lane's points, depth order
     double hPhi[D];                                  // (pairs: the line's profile of the angle, for the moments)
     double hT[D + 1], hRT[D + 1];                    // hT[q]: optical depth at mu = 1 of the interval (k0 + q - 1, k0 + q), and 1 / hT
     double hChiLo = 0.0, hChiHi = 0.0, hSLo = 0.0, hSHi = 0.0, hDSLo = 0.0, hDSHi = 0.0; // the neighbouring lanes' edge points
@@ -613,7 +613,6 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
             }
             const double rc = ls_rcp(cC);
             hChi[p] = cC;
-            hEta[p] = eC;
             hRch[p] = rc;
             hS[p] = (eC + sc) * rc;
         }
@@ -763,8 +762,12 @@ DEVINL int lane_rays(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevLa
                 for (int p = 0; p < D; ++p)
                     if (p < c.nV)
                     {
+                        // (eta formed again, with cont_unit's operations, instead of four registers held for a rare output)
+                        double eC = (c.sRow3 + c.lane * D)[64 * D + p];
+                        if constexpr (PAIRABLE)
+                            eC = fma(cer[0][p], hPhi[p], eC);
                         GD(a.depthChi)[o + p] = hChi[p];
-                        GD(a.depthEta)[o + p] = hEta[p];
+                        GD(a.depthEta)[o + p] = eC;
                     }
             }
         }
