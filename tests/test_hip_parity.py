@@ -215,6 +215,49 @@ def test_lane_sweep_ray_split_vs_oracle(gpu, monkeypatch, split, prd):
                             ks = np.nonzero(e > 1e-9)[0]
                             print(f'DIAG {name} run: atom {ia} transition {kr} (type {tx.type}, {tx.i}->{tx.j}, Nblue {tx.Nblue}, Nred {tx.Nred}) {nm}: '
                                   f'{len(ks)} depths off, k = {ks[:12].tolist()}, rel {e[ks[:6]].tolist()}, abs {(u - v)[ks[:6]].tolist()}, value {v[ks[:6]].tolist()}')
+        # (round 5: in the failing runs the three HIP runs agree with each other and with what the oracle gives elsewhere --
+        # it is the ORACLE's result of this process that is off.  Its inputs, then: are q's input arrays still those of prob,
+        # is prob still what the generator makes, and does the oracle give the same on a fresh copy?)
+        def arrays(obj, path, out, seen):
+            if id(obj) in seen:
+                return
+            seen.add(id(obj))
+            if isinstance(obj, np.ndarray):
+                out[path] = obj
+            elif isinstance(obj, (list, tuple)):
+                for i, v in enumerate(obj):
+                    arrays(v, f'{path}[{i}]', out, seen)
+            elif hasattr(obj, '__dict__'):
+                for k, v in vars(obj).items():
+                    if k != '_keepalive':
+                        arrays(v, f'{path}.{k}', out, seen)
+        def input_diffs(x, y):
+            ax, ay = {}, {}
+            arrays(x, 'p', ax, set())
+            arrays(y, 'p', ay, set())
+            outs = ('.J', '.I', '.Rij', '.Rji', '.Gamma', '.n', '.rhoPrd')
+            return [k for k in ax if not k.endswith(outs) and k in ay and ax[k].shape == ay[k].shape
+                    and not np.array_equal(ax[k], ay[k], equal_nan=True)]
+        atm2 = models.perturbed(models.falc82(), seed=7)
+        prob2 = (models.falc_h_ca(Nrays=5, lineScale=0.4, prd=True, atmos=atm2) if prd
+                 else models.build_problem(atm2, [models.H_6(0.5), models.CaII_6(0.5)], Nrays=5))
+        print('DIAG inputs of q that differ from prob:', input_diffs(q, prob))
+        print('DIAG inputs of prob that differ from a rebuilt problem:', input_diffs(prob, prob2))
+        print('DIAG inputs of the first HIP run that differ from prob:', input_diffs(a, prob))
+        for name, src in (('a fresh copy of prob', prob), ('the rebuilt problem', prob2)):
+            q2 = src.copy()
+            q2.gamma_prefill()
+            oc2 = OracleContext(q2)
+            oc2.formal_sol_gamma_matrices()
+            if prd:
+                oc2.redistribute_prd(2, 0.0)
+            same = all(np.array_equal(tx.Rij, ty.Rij) for x, y in zip(q2.atoms, q.atoms) for tx, ty in zip(x.trans, y.trans))
+            try:
+                compare_problems(a, q2)
+                ok = 'the HIP run agrees with it'
+            except AssertionError as e2:
+                ok = f'the HIP run differs from it too: {e2}'
+            print(f'DIAG the oracle on {name}: Rij bit-equal to the first oracle run: {same}; {ok}')
         raise
 
 

@@ -11,6 +11,6 @@ for i in $(seq 1 $N); do
   log=gpurun_out/flake/${TAG}_$i.log
   env "$@" python3 -m pytest tests/test_hip_parity.py -m gpu -q -x -s --tb=short -p no:cacheprovider > $log 2>&1
   rc=$?
-  if [ $rc -ne 0 ]; then fails=$((fails+1)); echo "run $i: FAIL $(grep -m1 -E '^(FAILED|E  )' $log)"; grep DIAG $log | head -12; else rm -f $log; fi
+  if [ $rc -ne 0 ]; then fails=$((fails+1)); echo "run $i: FAIL $(grep -m1 -E '^(FAILED|E  )' $log)"; grep DIAG $log | cut -c1-600 | head -24; else rm -f $log; fi
 done
 echo "$TAG ($*): $fails of $N runs failed" | tee -a gpurun_out/flake/summary.txt
