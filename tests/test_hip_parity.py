@@ -242,6 +242,15 @@ def test_lane_sweep_ray_split_vs_oracle(gpu, monkeypatch, split, prd):
         prob2 = (models.falc_h_ca(Nrays=5, lineScale=0.4, prd=True, atmos=atm2) if prd
                  else models.build_problem(atm2, [models.H_6(0.5), models.CaII_6(0.5)], Nrays=5))
         print('DIAG inputs of q that differ from prob:', input_diffs(q, prob))
+        aq, ap = {}, {}
+        arrays(q, 'p', aq, set())
+        arrays(prob, 'p', ap, set())
+        for k in input_diffs(q, prob):   # (which elements, and the bit patterns: a stray 4-byte store looks different from a stale copy)
+            x, y = aq[k].ravel(), ap[k].ravel()
+            idx = np.nonzero(x != y)[0]
+            print(f'DIAG {k}: {idx.size} of {x.size} elements differ, at {idx[:8].tolist()}: now '
+                  f'{[x[i].tobytes().hex() for i in idx[:8]]} was {[y[i].tobytes().hex() for i in idx[:8]]} (little-endian bytes); '
+                  f'address of the array 0x{aq[k].ctypes.data:x}')
         print('DIAG inputs of prob that differ from a rebuilt problem:', input_diffs(prob, prob2))
         print('DIAG inputs of the first HIP run that differ from prob:', input_diffs(a, prob))
         for name, src in (('a fresh copy of prob', prob), ('the rebuilt problem', prob2)):
