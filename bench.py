@@ -23,6 +23,10 @@ the first iteration of the `cpu_baseline` leg on identical inputs; `aux` carries
 with its own roofline block (not part of the metric): C3 the PRD sub-iteration, C4 a 512-column fused 1.5D batch,
 C5 the 256 x 82 2D iteration.  `--no-aux` skips them, `--aux-only NAME` runs just one (profiling).
 
+`--mode columns` is BASELINE configs[3] as a run of its own: `--columns` (512) perturbed FAL-C columns PER GPU, rank r owning
+columns r, r + N, ... of the seeded set as one fused batch, no collective; value = column-iterations/s over all ranks.  With
+N > 1 the default (lambda) line carries a short form of it as aux.C4_columns.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -59,7 +63,11 @@ def parse():
     ap.add_argument('--aux', action='store_true', help='(accepted for compatibility: aux entries are on by default)')
     ap.add_argument('--aux-only', choices=('prd', 'columns', '2d', 'fixed', 'realistic'), default=None,
                     help='run only this side measurement and print its entry (for rocprofv3)')
-    ap.add_argument('--columns', type=int, default=512, help='columns of the C4 batch')
+    ap.add_argument('--columns', type=int, default=512, help='columns of the C4 batch PER GPU (512 x 8 GPUs = the 4 096 of BASELINE configs[3])')
+    ap.add_argument('--mode', choices=('lambda', 'columns'), default='lambda',
+                    help="lambda (default): the headline -- one problem's wavelengths sharded over the ranks, one all-reduce per "
+                         'step; columns: BASELINE configs[3] -- rank r owns columns r, r + N, ... of --columns x N perturbed FAL-C '
+                         'columns as one fused batch, NO collective, value = column-iterations/s over all ranks (weak scaling)')
     ap.add_argument('--backend', default='nccl',
                     help="torch.distributed backend for N > 1 ('nccl' = RCCL, one rank per GPU; 'gloo' with --share-gpu "
                          'exercises the sharded path with several ranks on ONE GPU)')
@@ -363,6 +371,86 @@ def aux_realistic(args, device, stream, torch, models):
                                        else 'raymarch_kernel', alg, ms, 'whole step (host clock)')}
 
 
+def column_problems(models, ncol_total, world, rank, lineScale=3.1):
+    """The columns of rank `rank` (round robin: lightweaver_amd.batch.columns_of_rank) of the seeded set of C4: column c is
+    FAL-C perturbed with seed 1234 + c, whatever the number of ranks."""
+    from lightweaver_amd.batch import columns_of_rank
+    base = models.falc82()
+    mine = columns_of_rank(ncol_total, world, rank)
+    return mine, [models.falc_h_ca(Nrays=5, lineScale=lineScale, atmos=models.perturbed(base, seed=1234 + c), computeProfiles=False)
+                  for c in mine]
+
+
+def run_columns(args, rank, world, local_rank, stream, torch, dist, models, steps, warmup):
+    """BASELINE configs[3] across the ranks: every rank advances ITS columns as one fused batch on its GPU; the columns never
+    exchange radiation (independent Contexts in the reference: Source/SimdFullIterationTemplates.hpp:588-719 per column), so
+    there is no collective in the data path -- only the barrier that brackets the timed region.  Returns the whole-job figures
+    on every rank (elapsed = max over ranks)."""
+    from lightweaver_amd.batch import ColumnBatch
+    ncol_total = args.columns * world
+    t0 = time.perf_counter()
+    mine, probs = column_problems(models, ncol_total, world, rank)
+    t1 = time.perf_counter()
+    with ColumnBatch(probs, device=local_rank, stream=stream.cuda_stream) as batch:
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        step = lambda: batch.formal_sol_gamma_matrices(sync_host=False)   # noqa: E731
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - tt
+        last = batch.formal_sol_gamma_matrices(sync_host=True)
+        alg = float(sum(c.algorithmic_bytes() for c in batch.contexts))
+        fused = batch._batch is not None
+        kind = batch.contexts[0].sweep_kind()
+        nla = probs[0].Nlambda
+    own_ms = 1e3 * elapsed / steps
+    if world > 1:
+        # the slowest rank's clock; every rank's own time rides along (no data-path collective: these are the report's)
+        tv = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        elapsed = float(tv.item())
+        per = torch.zeros(world, dtype=torch.float64, device='cuda')
+        per[rank] = own_ms
+        dist.all_reduce(per)
+        per_rank_ms = [float(x) for x in per.tolist()]
+    else:
+        per_rank_ms = [own_ms]
+    return {'columns_total': ncol_total, 'columns_per_gpu': len(mine), 'Nlambda_per_column': nla, 'fused': fused, 'sweep': kind,
+            'elapsed': elapsed, 'ms_per_batch_iteration': 1e3 * elapsed / steps,
+            'column_iters_per_s': ncol_total * steps / elapsed, 'per_rank_ms': per_rank_ms,
+            'host_build_s': t1 - t0, 'contexts_and_profiles_s': t2 - t1,
+            'final_dJMax_max': max(u.dJMax for u in last),
+            'roofline': roofline_block(('lanesweep_kernel<BATCH> (+ tile_pre / reduce / apply)' if kind == 'lanes'
+                                        else 'raymarch_kernel<BATCH> (+ tile_pre / tile_post / reduce / apply)'), alg, own_ms,
+                                       "this rank's whole batch iteration (host clock); algorithmic bytes of ITS columns")}
+
+
+def columns_line(args, c, world):
+    """The bench line of --mode columns."""
+    return {
+        'metric': 'formal_sol_gamma_matrices column-iterations/sec (1.5D batch, BASELINE configs[3])',
+        'value': c['column_iters_per_s'], 'unit': 'column-iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': c['ms_per_batch_iteration'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic (FAL-C perturbed per column with seed 1234 + c, own H/CaII model atoms, generated in-process)',
+        'config': {'workload': f"1.5D batch: {c['columns_total']} perturbed FALC 82-depth columns, H(6)+CaII(6), 5 mu, Bezier3, "
+                               f"{c['Nlambda_per_column']} wavelengths each; {c['columns_per_gpu']} columns per GPU as one fused batch",
+                   'columns_total': c['columns_total'], 'columns_per_gpu': c['columns_per_gpu'],
+                   'parallelism': f'column replicas x{world}, no collective' if world > 1 else 'single GPU',
+                   'sweep': c['sweep'], 'fused': c['fused'], 'final_dJMax_max': c['final_dJMax_max']},
+        'roofline': c['roofline'], 'per_rank_ms_per_step': c['per_rank_ms'],
+        'host_build_s': c['host_build_s'], 'contexts_and_profiles_s': c['contexts_and_profiles_s'],
+    }
+
+
 AUX = {'prd': ('C3_prd', aux_prd), 'columns': ('C4_columns', aux_columns), '2d': ('C5_2d', aux_2d),
        'fixed': ('fixed_order', aux_fixed_order), 'realistic': ('realistic_1d', aux_realistic)}
 
@@ -424,6 +512,18 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(args.backend)
+
+    if args.mode == 'columns':
+        import gc
+        gc.collect()
+        gc.disable()
+        c = run_columns(args, rank, world, local_rank, stream, torch, dist, models, args.steps, args.warmup)
+        gc.enable()
+        if rank == 0:
+            print(json.dumps(columns_line(args, c, world)))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     Nla_total = args.nlambda * (world if args.scaling == 'weak' else 1)
     # the line profiles are generated on the device (lwhip_compute_profiles), shard by shard: the host
@@ -516,6 +616,16 @@ def main():
     if world == 1:
         aux['stat_eq_ms'] = timed(lambda: ctx.stat_equil(deviceResident=True), 20, torch)
     ctx.close()
+    if world > 1 and not args.no_aux:
+        # the split that scales by construction, beside the strong-scaling headline: every rank its own fused batch of columns
+        try:
+            cc = run_columns(args, rank, world, local_rank, stream, torch, dist, models, steps=10, warmup=2)
+            cc.pop('elapsed')
+            cc['config'] = (f"C4: {cc['columns_total']} perturbed FALC columns over {world} GPUs, {cc['columns_per_gpu']} per GPU, "
+                            'no collective (python bench.py --gpus N --mode columns is the full run)')
+            aux['C4_columns'] = cc
+        except Exception as e:
+            aux['C4_columns'] = {'failed': repr(e)}
     if world == 1 and not args.no_aux:
         for key, (name, fn) in AUX.items():
             try:

@@ -254,6 +254,19 @@ typedef struct lwhip_iter_result {
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* lwhip_last_error(void);
 
+/* Diagnosis (LWHIP_DEBUG set in the environment): the pinned host blocks of destroyed contexts are kept and filled with a
+ * pattern instead of being given back to the runtime; this returns the number of their bytes that no longer hold it (0 = nothing
+ * stored into host memory of a context that was gone) and prints the first few to stderr.  Without LWHIP_DEBUG there is no
+ * quarantine and the answer is 0.  Also run when the process ends.  No counterpart in the reference. */
+long lwhip_debug_check_quarantine(void);
+
+/* Streams the library has created with hipStreamCreate in this process so far.  Contexts' own streams are POOLED per device
+ * and never destroyed (a context that dies gives its stream to the next one): the HIP runtime's completion callback may store
+ * into a stream's queue object after hipStreamDestroy has freed it (profiles/r06_stray_write.md), i.e. into whatever host
+ * allocation reuses that block.  Making and closing contexts one after the other leaves this count at the number that were
+ * alive at the same time (tests/test_abi.py).  No counterpart in the reference. */
+long lwhip_debug_streams_created(void);
+
 /* ABI version the library was built with. */
 int lwhip_abi_version(void);
 
@@ -308,6 +321,30 @@ int lwhip_fs_finalise(lwhip_context* ctx, lwhip_iter_result* res);
 /* Device pointer and layout of the reduce buffer: [0,nSum) partial sums, [nSum,nSum+nGather) the
  * per-rank (dJMax, idx) slots. */
 int lwhip_reduce_buffer(lwhip_context* ctx, void** devPtr, size_t* nSum, size_t* nGather);
+
+/* The same exchange WITHOUT a collective call, for the ranks of one node (one process per GPU, or several contexts of one
+ * process): every rank owns a window in device memory; lwhip_fs_partial then stores the rank's partial sums into its slot of
+ * EVERY rank's window (peer-mapped stores: xGMI between GPUs) and raises its flag there, and lwhip_fs_finalise's launch waits for
+ * the worldSize flags of its own window and adds the slots IN RANK ORDER -- so sharded Gamma / rates are the same bits on every
+ * rank and from run to run (with the fixed-order mode for the sums inside a shard), which the summation tree of a library
+ * all-reduce does not promise.  Replaces AtomStorageFactory::accumulate_Gamma / TransitionStorageFactory::accumulate_rates
+ * across threads (Source/ThreadStorage.cpp:150-166, 334-396; called from Source/SimdFullIterationTemplates.hpp:675-703).
+ *   lwhip_peer_window           allocates (once) and returns this rank's window;
+ *   lwhip_peer_export           the window's inter-process handle (hipIpcMemHandle_t as 64 opaque bytes) -- the caller ships it
+ *                               to the other ranks (e.g. torch.distributed.all_gather_object) ...
+ *   lwhip_peer_attach           ... and hands in all worldSize handles, own rank's entry ignored: from now on fs_partial /
+ *                               fs_finalise exchange through the windows and the caller must NOT all-reduce the reduce buffer;
+ *   lwhip_peer_attach_pointers  the same for windows the process can address directly (contexts of ONE process: pointers
+ *                               from lwhip_peer_window, peer access enabled by the caller where they live on other devices);
+ *   lwhip_peer_detach           waits for the stream and goes back to the all-reduce contract.
+ * All ranks must make the same sequence of fs_partial / fs_finalise calls while attached.  A rank whose peers never publish
+ * (a dead process) does not hang the device: the launch gives up after ~2 s and lwhip_fs_finalise reports LWHIP_ERR_DEVICE.
+ * The PRD calls (lwhip_prd_pack / _partial / _finalise) keep the all-reduce contract. */
+int lwhip_peer_window(lwhip_context* ctx, void** devPtr, size_t* bytes);
+int lwhip_peer_export(lwhip_context* ctx, void* handle64);
+int lwhip_peer_attach(lwhip_context* ctx, const void* handles /* worldSize x 64 bytes */);
+int lwhip_peer_attach_pointers(lwhip_context* ctx, void* const* windows /* worldSize device pointers */);
+int lwhip_peer_detach(lwhip_context* ctx);
 
 /* formal_sol: chi/S/solve/I only, optionally up-going rays only (FsMode::FsOnly|UpOnly). */
 int lwhip_formal_sol(lwhip_context* ctx, int upOnly);

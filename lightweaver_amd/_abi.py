@@ -161,6 +161,13 @@ SYMBOLS = [
     ('lwhip_fs_finalise', C.c_int, [ctx_p, C.POINTER(lwhip_iter_result)]),
     ('lwhip_reduce_buffer', C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_size_t)]),
+    ('lwhip_peer_window', C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ('lwhip_peer_export', C.c_int, [ctx_p, C.c_void_p]),
+    ('lwhip_peer_attach', C.c_int, [ctx_p, C.c_void_p]),
+    ('lwhip_peer_attach_pointers', C.c_int, [ctx_p, C.POINTER(C.c_void_p)]),
+    ('lwhip_peer_detach', C.c_int, [ctx_p]),
+    ('lwhip_debug_check_quarantine', C.c_long, []),
+    ('lwhip_debug_streams_created', C.c_long, []),
     ('lwhip_formal_sol', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_stat_equil', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_stat_equil_async', C.c_int, [ctx_p, C.c_int]),

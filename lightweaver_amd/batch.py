@@ -47,6 +47,8 @@ class ColumnBatch:
             donor = self.contexts[0] if (fused and self.contexts) else None
             rest = self.problems[1:]
             nthr = max(1, min(int(os.environ.get('LWHIP_CREATE_THREADS', '8')), os.cpu_count() or 1, len(rest)))
+            if os.environ.get('LWHIP_DEBUG') and any(os.environ.get(k) for k in ('LWHIP_PAD_SENTINEL', 'LWHIP_TRACE_ALLOC')):
+                nthr = 1    # (those diagnoses number the allocations in creation order: one creating thread)
             make = lambda p: Context(p, device=device, stream=stream, batchHint=hint, like=donor)  # noqa: E731
             if nthr > 1:
                 from concurrent.futures import ThreadPoolExecutor

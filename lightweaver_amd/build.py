@@ -51,15 +51,21 @@ def build_hip(force=False, verbose=False, defines=(), out=None, extra_flags=()):
     lints = []   # (the spill check of a unit starts when its listing is there, next to the other units' compilations)
 
     def compile_one(src):
-        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
-        if force or _stale(obj, [src] + deps[len(srcs):]):
+        stem = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(objdir, stem + '.o')
+        lst = os.path.join(objdir, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+        if force or _stale(obj, [src] + deps[len(srcs):]) or not os.path.exists(lst):
             cmd = [_hipcc()] + flags + ['-c', '-o', obj, src]
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True, cwd=CSRC)
-            lst = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '-hip-amdgcn-amd-amdhsa-gfx950.s')
-            if os.path.exists(lst):
-                lints.append(pool.submit(_lint_one, lst))
+        # EVERY unit that goes into the link is checked, not only the ones compiled in this call: an object left behind by a
+        # build that failed the check (or was interrupted before it) is up to date for make-style staleness and would
+        # otherwise be linked unchecked.  A unit's verdict is remembered next to its listing (keyed by the listing's size and
+        # time stamp), so an unchanged unit is not parsed again.
+        if not os.path.exists(lst):
+            raise RuntimeError(f'spill check: no device listing {lst} for {src}: refusing to link an unchecked object')
+        lints.append(pool.submit(_lint_cached, lst))
         return obj
 
     with ProcessPoolExecutor(max_workers=2) as pool:
@@ -77,7 +83,8 @@ def check_spills(objdir, results, verbose=False):
     """No kernel may reload a spilled register for lanes that were switched off when it was stored (spill_lint.py: what
     ROCm 7.2's register allocator did to lanesweep_kernel in round 5).  Checked on the listings of the units just compiled
     (results: what _lint_one returned for each); the report of every kernel with spills goes to build/spill_lint.txt.  A
-    reported kernel fails the build: restructure the lane-divergent `if` the report points at (or relieve the register
+    reported kernel fails the build -- on every later call too, until its unit is recompiled clean: the link step is never
+    reached with a flagged or unchecked object (tests/test_spill_lint.py::test_failed_check_is_not_bypassed_by_rebuilding).  Restructure the lane-divergent `if` the report points at (or relieve the register
     pressure) until it is clean."""
     if not results:
         return
@@ -100,6 +107,26 @@ def _lint_one(path):
     from . import spill_lint
     report = []
     bad = spill_lint.lint_file(path, quiet=True, report=report)
+    return path, bad, report
+
+
+def _lint_cached(path):
+    """_lint_one with its result kept in <listing>.lint.json while the listing (size, mtime) and the checker are unchanged."""
+    import json
+    from . import spill_lint
+    st = os.stat(path)
+    key = [st.st_size, st.st_mtime_ns, os.stat(spill_lint.__file__).st_mtime_ns]
+    stamp = path + '.lint.json'
+    try:
+        with open(stamp) as f:
+            d = json.load(f)
+        if d['key'] == key:
+            return path, d['bad'], [tuple(r) for r in d['report']]
+    except (OSError, ValueError, KeyError):
+        pass
+    _, bad, report = _lint_one(path)
+    with open(stamp, 'w') as f:
+        json.dump({'key': key, 'bad': bad, 'report': report}, f)
     return path, bad, report
 
 

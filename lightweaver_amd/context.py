@@ -128,6 +128,7 @@ class Context:
         self.laEnd = laEnd if laEnd else prob.Nlambda
         self.crsw = 1.0
         self._ng = None
+        self.peers_attached = False
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -409,6 +410,37 @@ class Context:
         _check(self.lib, self.lib.lwhip_reduce_buffer(self._h, C.byref(ptr), C.byref(nsum),
                                                       C.byref(ngather)), 'lwhip_reduce_buffer')
         return ptr.value, nsum.value + ngather.value
+
+    # -- peer exchange of the sharded iteration (include/lwhip.h: lwhip_peer_*) ---------------------------------------
+    def peer_window(self):
+        """(device pointer, bytes) of this rank's exchange window."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib, self.lib.lwhip_peer_window(self._h, C.byref(ptr), C.byref(n)), 'lwhip_peer_window')
+        return ptr.value, n.value
+
+    def peer_export(self) -> bytes:
+        """The window's inter-process handle (64 opaque bytes) for the other ranks."""
+        buf = C.create_string_buffer(64)
+        _check(self.lib, self.lib.lwhip_peer_export(self._h, buf), 'lwhip_peer_export')
+        return buf.raw
+
+    def peer_attach(self, handles):
+        """`handles`: every rank's peer_export() in rank order (own entry ignored).  From now on fs_partial / fs_finalise
+        exchange through the windows: no all-reduce of the reduce buffer."""
+        blob = b''.join(bytes(h) for h in handles)
+        assert len(blob) == 64 * len(handles)
+        _check(self.lib, self.lib.lwhip_peer_attach(self._h, C.c_char_p(blob)), 'lwhip_peer_attach')
+        self.peers_attached = True
+
+    def peer_attach_pointers(self, windows):
+        """The same for windows this process can address (contexts of one process): device pointers in rank order."""
+        arr = (C.c_void_p * len(windows))(*windows)
+        _check(self.lib, self.lib.lwhip_peer_attach_pointers(self._h, arr), 'lwhip_peer_attach_pointers')
+        self.peers_attached = True
+
+    def peer_detach(self):
+        _check(self.lib, self.lib.lwhip_peer_detach(self._h), 'lwhip_peer_detach')
+        self.peers_attached = False
 
     # -- measurement -----------------------------------------------------------------------------------------
     def profile_enable(self, enable=True):

@@ -22,11 +22,340 @@ int fail(int code, const std::string& msg)
 }
 }
 
+namespace
+{
+// ---- the contexts' host blocks (lwhip_host.h: hostBlock) ---------------------------------------------------------------
+// layout (bytes): [0,32) tail (dJMax, idx, ticket, -) | [32] status | [40] zeroCheck | [48] popStatus | [64,80) prdCtl
+// | [96,104) canary | [128, ...) change records
+constexpr size_t HB_TAIL = 0, HB_STATUS = 32, HB_ZERO = 40, HB_POPSTATUS = 48, HB_PRDCTL = 64, HB_CANARY = 96, HB_CHANGE = 128;
+constexpr uint64_t HB_CANARY_WORD = 0x6c77686970424c4bull; // "lwhipBLK"
+constexpr unsigned char HB_DEAD = 0xC5;
+struct Quarantine
+{
+    std::mutex m;
+    std::vector<std::pair<unsigned char*, size_t>> blocks;
+    // bytes of released blocks that no longer hold the fill: something stored into host memory of a context that was gone
+    long check(bool report)
+    {
+        std::lock_guard<std::mutex> g(m);
+        long bad = 0;
+        for (auto& b : blocks)
+            for (size_t i = 0; i < b.second; ++i)
+                if (b.first[i] != HB_DEAD)
+                {
+                    if (report && bad < 16)
+                        std::fprintf(stderr, "lwhip: QUARANTINE: released host block %p (+%zu of %zu) holds 0x%02x: a late store into "
+                                             "host memory of a destroyed context\n", (void*)b.first, i, b.second, b.first[i]);
+                    ++bad;
+                }
+        return bad;
+    }
+    ~Quarantine() { (void)check(true); }
+};
+Quarantine& quarantine()
+{
+    static Quarantine* q = new Quarantine; // (never destroyed before the last context: checked from atexit below)
+    static const bool registered = (std::atexit([] { (void)quarantine().check(true); }), true);
+    (void)registered;
+    return *q;
+}
+}
+
+namespace lwhip
+{
+// ---- the library's streams are pooled, never destroyed ------------------------------------------------------------------
+// Round 6 located the stray 4-byte host store that rounds 3-5 chased (profiles/r06_stray_write.md): the HIP runtime's HSA
+// signal callback (libamdhip64.so of ROCm 7.0 as bundled with torch 2.10, at +0x3d598a / +0x3d5995 of that build:
+// `lock subq $1, 0x98(%rdi)` and `xchgl %eax(=0), 0x378(%rdi)` on the queue object of the command whose signal completed) can
+// run AFTER hipStreamDestroy has deleted that queue object -- on the runtime's own thread, a hipStreamSynchronize before the
+// destroy does not order it.  The two stores then land in whatever malloc() handed the freed 1 KB block to next: in the
+// tests, a 920-byte numpy array made right after three contexts were closed -- one double lost its low 32 bits, the oracle's
+// continuum rate moved by 1.77e-6.  In drop-in mode the block could be one of the USER's arrays.  A stream that is never
+// destroyed has no freed queue object to write into: a context's own stream goes back to a per-device pool when the context
+// dies and is handed to the next context made on that device (idle by then: lwhip_destroy has waited for it).  The pool's
+// streams live until the process ends.  LWHIP_DEBUG + LWHIP_DESTROY_STREAMS=1 restores the old behaviour (the A/B of
+// tools/guard/hunt.sh).
+namespace
+{
+std::mutex g_streamMutex;
+std::map<int, std::vector<hipStream_t>> g_streamPool;
+std::atomic<long> g_streamsCreated{ 0 };
+}
+hipError_t stream_acquire(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> g(g_streamMutex);
+        auto& pool = g_streamPool[device];
+        if (!pool.empty())
+        {
+            *out = pool.back();
+            pool.pop_back();
+            return hipSuccess;
+        }
+    }
+    ++g_streamsCreated;
+    return hipStreamCreate(out);
+}
+void stream_release(int device, hipStream_t s)
+{
+    static const bool destroy = dbg_env_int("LWHIP_DESTROY_STREAMS", 0) != 0;
+    if (destroy)
+    {
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    std::lock_guard<std::mutex> g(g_streamMutex);
+    g_streamPool[device].push_back(s);
+}
+
+int host_block_init(lwhip_context* c)
+{
+    int maxNl = 1, nActive = 0;
+    for (int ia = 0; ia < c->prob.Natom; ++ia)
+    {
+        maxNl = std::max(maxNl, (int)c->prob.atoms[ia].Nlevel);
+        ++nActive;
+    }
+    // change records: (value, index) per solved atom and solve block of stat_equil's report, per atom of the Ng step
+    const size_t nChange = (size_t)2 * std::max(nActive, 1) * (size_t)stat_eq_blocks(std::max((int)c->prob.Nspace, 1), std::min(maxNl, 64)) + 16;
+    c->hostBlockBytes = HB_CHANGE + nChange * sizeof(double);
+    unsigned char* dev = nullptr;
+    if (hipHostMalloc((void**)&c->hostBlock, c->hostBlockBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        || hipHostGetDevicePointer((void**)&dev, c->hostBlock, 0) != hipSuccess)
+        return fail(LWHIP_ERR_DEVICE, "lwhip_create: hipHostMalloc of the context's host block failed");
+    std::memset(c->hostBlock, 0, c->hostBlockBytes);
+    std::memcpy(c->hostBlock + HB_CANARY, &HB_CANARY_WORD, sizeof HB_CANARY_WORD);
+    c->tailMapped = (double*)(c->hostBlock + HB_TAIL);
+    c->tailMappedDev = (double*)(dev + HB_TAIL);
+    c->statusHost = (int32_t*)(c->hostBlock + HB_STATUS);
+    c->statusDev = (int32_t*)(dev + HB_STATUS);
+    if (dbg_env_int("LWHIP_CHECK_ZERO", 0) == 1)
+    {
+        c->zeroCheck = (int*)(c->hostBlock + HB_ZERO);
+        c->zeroCheckDev = (int*)(dev + HB_ZERO);
+    }
+    c->popStatusHost = (int32_t*)(c->hostBlock + HB_POPSTATUS);
+    c->prdCtlHost = (int32_t*)(c->hostBlock + HB_PRDCTL);
+    c->changeHost = (double*)(c->hostBlock + HB_CHANGE);
+    c->changeDev = (double*)(dev + HB_CHANGE);
+    c->changeCount = nChange;
+    return LWHIP_OK;
+}
+
+// (the destructor has waited for the stream and the null stream)
+void host_block_release(lwhip_context* c)
+{
+    if (!c->hostBlock)
+        return;
+    uint64_t canary = 0;
+    std::memcpy(&canary, c->hostBlock + HB_CANARY, sizeof canary);
+    if (canary != HB_CANARY_WORD)
+        std::fprintf(stderr, "lwhip: the canary of a context's host block reads %016llx: something stored past a status word\n",
+                     (unsigned long long)canary);
+    if (debug_knobs_on())
+    {
+        std::memset(c->hostBlock, HB_DEAD, c->hostBlockBytes);
+        std::lock_guard<std::mutex> g(quarantine().m);
+        quarantine().blocks.emplace_back(c->hostBlock, c->hostBlockBytes);
+    }
+    else
+        (void)hipHostFree(c->hostBlock);
+    c->hostBlock = nullptr;
+    c->tailMapped = c->tailMappedDev = c->changeHost = c->changeDev = nullptr;
+    c->statusHost = c->statusDev = c->popStatusHost = c->prdCtlHost = nullptr;
+    c->zeroCheck = c->zeroCheckDev = nullptr;
+}
+}
+
+namespace lwhip
+{
+// ---- peer exchange (include/lwhip.h: lwhip_peer_*) ----------------------------------------------------------------------
+constexpr size_t PEER_HDR = 2 * LWHIP_PEER_MAX * sizeof(unsigned long long); // the flags of both buffers
+
+void peer_release(lwhip_context* c)
+{
+    for (int r = 0; r < LWHIP_PEER_MAX; ++r)
+    {
+        if (c->peerIpc[r] && c->peerPtr[r])
+            (void)hipIpcCloseMemHandle(c->peerPtr[r]);
+        c->peerPtr[r] = nullptr;
+        c->peerIpc[r] = false;
+    }
+    c->peerOn = false;
+    if (c->peerWin)
+        (void)hipFree(c->peerWin);
+    c->peerWin = nullptr;
+}
+
+// this rank's reduce buffer into every window; the flag value is the exchange's number
+int peer_publish(lwhip_context* c)
+{
+    PeerPublishArgs a{};
+    a.red = c->red.p;
+    a.n = (int64_t)c->red.n;
+    a.world = c->worldSize;
+    a.rank = c->worldRank;
+    a.seq = c->peerSeq + 1;
+    a.arrive = c->peerArrive.p;
+    const size_t buf = (size_t)(c->peerSeq & 1);
+    for (int r = 0; r < c->worldSize; ++r)
+    {
+        a.slot[r] = (double*)(c->peerPtr[r] + PEER_HDR) + (buf * c->worldSize + c->worldRank) * c->peerStride;
+        a.flag[r] = (unsigned long long*)c->peerPtr[r] + buf * LWHIP_PEER_MAX + c->worldRank;
+    }
+    HIP_TRY(launch_peer_publish(a, c->stream));
+    c->peerSeq += 1;
+    return LWHIP_OK;
+}
+
+// the consumer side of the exchange published last
+void peer_apply_args(lwhip_context* c, ApplyArgs& a)
+{
+    const size_t buf = (size_t)((c->peerSeq - 1) & 1);
+    a.peerWorld = c->worldSize;
+    a.peerSlots = (const double*)(c->peerWin + PEER_HDR) + buf * c->worldSize * c->peerStride;
+    a.peerStride = (int64_t)c->peerStride;
+    a.peerFlags = (const unsigned long long*)c->peerWin + buf * LWHIP_PEER_MAX;
+    a.peerSeq = c->peerSeq;
+}
+}
+
 extern "C"
 {
+int lwhip_peer_window(lwhip_context* c, void** devPtr, size_t* bytes)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->worldSize < 1 || c->worldSize > LWHIP_PEER_MAX)
+        return fail(LWHIP_ERR_UNSUPPORTED, "peer exchange: at most 16 ranks");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->peerWin)
+    {
+        c->peerStride = (c->red.n + 31) & ~(size_t)31;
+        c->peerWinBytes = PEER_HDR + (size_t)2 * c->worldSize * c->peerStride * sizeof(double);
+        // (plain device memory: what hipIpcGetMemHandle exports; every access of a consumer is a system-scope one)
+        HIP_TRY(hipMalloc((void**)&c->peerWin, c->peerWinBytes));
+        HIP_TRY(hipMemset(c->peerWin, 0, c->peerWinBytes));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(c->peerArrive.alloc_zero(1));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    if (devPtr)
+        *devPtr = c->peerWin;
+    if (bytes)
+        *bytes = c->peerWinBytes;
+    return LWHIP_OK;
+}
+
+int lwhip_peer_export(lwhip_context* c, void* handle64)
+{
+    if (!c || !handle64)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI passes IPC handles as 64 opaque bytes");
+    const int st = lwhip_peer_window(c, nullptr, nullptr);
+    if (st != LWHIP_OK)
+        return st;
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, c->peerWin));
+    std::memcpy(handle64, &h, sizeof h);
+    return LWHIP_OK;
+}
+
+static int peer_attach_impl(lwhip_context* c, void* const* windows, const unsigned char* handles)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->is2d && false)
+        return fail(LWHIP_ERR_UNSUPPORTED, "peer exchange");
+    const int st = lwhip_peer_window(c, nullptr, nullptr);
+    if (st != LWHIP_OK)
+        return st;
+    if (c->peerOn)
+        return fail(LWHIP_ERR_INVALID, "lwhip_peer_attach: already attached (lwhip_peer_detach first)");
+    for (int r = 0; r < c->worldSize; ++r)
+    {
+        if (r == c->worldRank)
+        {
+            c->peerPtr[r] = c->peerWin;
+            continue;
+        }
+        if (windows)
+        {
+            if (!windows[r])
+                return fail(LWHIP_ERR_INVALID, "lwhip_peer_attach_pointers: null window");
+            c->peerPtr[r] = (unsigned char*)windows[r];
+        }
+        else
+        {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, handles + (size_t)r * 64, sizeof h);
+            void* p = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess)
+            {
+                for (int q = 0; q < r; ++q)
+                    if (c->peerIpc[q])
+                    {
+                        (void)hipIpcCloseMemHandle(c->peerPtr[q]);
+                        c->peerIpc[q] = false;
+                        c->peerPtr[q] = nullptr;
+                    }
+                return fail(LWHIP_ERR_DEVICE, std::string("lwhip_peer_attach: hipIpcOpenMemHandle of rank ") + std::to_string(r)
+                                                  + "'s window failed: " + hipGetErrorString(e));
+            }
+            c->peerPtr[r] = (unsigned char*)p;
+            c->peerIpc[r] = true;
+        }
+    }
+    c->peerOn = true;
+    c->peerSeq = 0;
+    return LWHIP_OK;
+}
+
+int lwhip_peer_attach(lwhip_context* c, const void* handles)
+{
+    if (!handles)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    return peer_attach_impl(c, nullptr, (const unsigned char*)handles);
+}
+
+int lwhip_peer_attach_pointers(lwhip_context* c, void* const* windows)
+{
+    if (!windows)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    return peer_attach_impl(c, windows, nullptr);
+}
+
+int lwhip_peer_detach(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < LWHIP_PEER_MAX; ++r)
+    {
+        if (c->peerIpc[r] && c->peerPtr[r])
+            (void)hipIpcCloseMemHandle(c->peerPtr[r]);
+        c->peerPtr[r] = nullptr;
+        c->peerIpc[r] = false;
+    }
+    c->peerOn = false;
+    return LWHIP_OK;
+}
+
 const char* lwhip_last_error(void)
 {
     return g_lastError.c_str();
+}
+
+long lwhip_debug_check_quarantine(void)
+{
+    return quarantine().check(true);
+}
+
+long lwhip_debug_streams_created(void)
+{
+    return g_streamsCreated.load();
 }
 
 int lwhip_abi_version(void)
@@ -125,17 +454,14 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
         c->stream = (hipStream_t)opts->stream;
     else
     {
-        if (hipStreamCreate(&c->ownStream) != hipSuccess)
+        if (stream_acquire(c->device, &c->ownStream) != hipSuccess)
             return bail(fail(LWHIP_ERR_DEVICE, "hipStreamCreate failed"));
         c->stream = c->ownStream;
     }
-    if (dbg_env_int("LWHIP_CHECK_ZERO", 0) == 1)
-    {
-        if (hipHostMalloc((void**)&c->zeroCheck, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
-            || hipHostGetDevicePointer((void**)&c->zeroCheckDev, c->zeroCheck, 0) != hipSuccess)
-            return bail(fail(LWHIP_ERR_DEVICE, "hipHostMalloc failed"));
-        *c->zeroCheck = 0;
-    }
+    if (host_block_init(c) != LWHIP_OK)
+        return bail(LWHIP_ERR_DEVICE);
+    c->pairRays = dbg_env_int("LWHIP_PAIR_RAYS", 1) != 0;
+    c->prdPipeline = dbg_env_int("LWHIP_PRD_PIPELINE", 1) != 0;
     const bool timing = std::getenv("LWHIP_CREATE_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -364,6 +690,12 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
         if (c->worldSize > 1 && !c->prdLines.empty())
             HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
                                    2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
+        if (c->peerOn && c->worldSize > 1)
+        {
+            const int stq = peer_publish(c);
+            if (stq != LWHIP_OK)
+                return stq;
+        }
         c->partialPending = true;
         return LWHIP_OK;
     }
@@ -396,6 +728,12 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
     if (c->worldSize > 1 && !c->prdLines.empty()) // the PRD slots of the tail ride in the same all-reduce: keep them finite
         HIP_TRY(hipMemsetAsync(c->red.p + (size_t)c->Ntrans * 4 * c->Ns + 2 * (size_t)c->worldSize, 0,
                                2 * (size_t)c->worldSize * c->prdLines.size() * sizeof(double), c->stream));
+    if (c->peerOn && c->worldSize > 1 && !partsOnly)
+    {
+        const int stq = peer_publish(c);
+        if (stq != LWHIP_OK)
+            return stq;
+    }
     c->partialPending = true;
     return LWHIP_OK;
 }
@@ -429,12 +767,6 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
             a.idxOffset = c->laStart;
             a.scalarIdx = c->djIdxMode;
             a.tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
-            if (!c->tailMapped)
-            {
-                HIP_TRY(hipHostMalloc((void**)&c->tailMapped, 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-                HIP_TRY(hipHostGetDevicePointer((void**)&c->tailMappedDev, c->tailMapped, 0));
-                c->tailMapped[2] = 0.0;
-            }
             a.tailHost = c->tailMappedDev;
             c->tailTicket += 1.0;
             a.tailTicket = c->tailTicket;
@@ -446,17 +778,15 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
             // their maximum and publishes it the same way -- no read-back copy, no wait for the end of the stream
             a.tail = c->red.p + (size_t)c->Ntrans * 4 * c->Ns;
             a.gatherWorld = c->worldSize;
-            if (!c->tailMapped)
-            {
-                HIP_TRY(hipHostMalloc((void**)&c->tailMapped, 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-                HIP_TRY(hipHostGetDevicePointer((void**)&c->tailMappedDev, c->tailMapped, 0));
-                c->tailMapped[2] = 0.0;
-            }
+            if (c->peerOn && c->worldSize > 1)
+                peer_apply_args(c, a);
             a.tailHost = c->tailMappedDev;
             c->tailTicket += 1.0;
             a.tailTicket = c->tailTicket;
             mapped = true;
         }
+        if (!c->partsOnly && c->peerOn && c->worldSize > 1 && a.peerWorld == 0)
+            peer_apply_args(c, a); // (no result wanted: the sums still come from the exchange, not from `red`)
         HIP_TRY(launch_apply(a, c->stream));
         c->prefillPending = false;
         c->partsOnly = false;
@@ -482,6 +812,12 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
         res->updatedJ = 1;
         res->dJMax = c->tailMapped[0];
         res->dJMaxIdx = (int32_t)c->tailMapped[1];
+        if (c->peerOn && c->tailMapped[3] != 0.0)
+        {
+            c->tailMapped[3] = 0.0;
+            return fail(LWHIP_ERR_DEVICE, "peer exchange: a rank's partial sums never arrived (its flag was not raised within the "
+                                          "wait of the apply launch): the results of this iteration are incomplete");
+        }
         return LWHIP_OK;
     }
     if (res)
@@ -608,11 +944,6 @@ int stat_equil_impl(lwhip_context* c, int atom, bool wait, double* dPops, int32_
     }
     // one launch for all requested atoms; the status word lives in host-mapped pinned memory, so the
     // call needs no memset kernel and no read-back copy, only the stream synchronisation
-    if (!c->statusHost)
-    {
-        HIP_TRY(hipHostMalloc((void**)&c->statusHost, sizeof(int32_t), hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&c->statusDev, c->statusHost, 0));
-    }
     std::vector<NrAtom> atoms;
     int maxNl = 0;
     for (int ia = 0; ia < c->Natom; ++ia)
@@ -654,15 +985,8 @@ int stat_equil_impl(lwhip_context* c, int atom, bool wait, double* dPops, int32_
     if (report)
     {
         const size_t need = atoms.size() * nBlocks * 2;
-        if (c->changeCount < need)
-        {
-            if (c->changeHost)
-                (void)hipHostFree(c->changeHost);
-            c->changeHost = nullptr;
-            HIP_TRY(hipHostMalloc((void**)&c->changeHost, need * sizeof(double), hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer((void**)&c->changeDev, c->changeHost, 0));
-            c->changeCount = need;
-        }
+        if (c->changeCount < need) // (sized for every active atom at lwhip_create: host_block_init)
+            return fail(LWHIP_ERR_INVALID, "stat_equil report: the context's host block is too small for the change records");
         sa.change = c->changeDev;
     }
     HIP_TRY(launch_stat_eq(sa, maxNl, c->stream));
@@ -756,20 +1080,8 @@ int lwhip_ng_accelerate(lwhip_context* c, int32_t* accelerated, double* dPops, i
     if (nAt == 0)
         return LWHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->statusHost)
-    {
-        HIP_TRY(hipHostMalloc((void**)&c->statusHost, sizeof(int32_t), hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&c->statusDev, c->statusHost, 0));
-    }
     if (c->changeCount < (size_t)2 * nAt)
-    {
-        if (c->changeHost)
-            (void)hipHostFree(c->changeHost);
-        c->changeHost = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&c->changeHost, (size_t)2 * nAt * sizeof(double), hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&c->changeDev, c->changeHost, 0));
-        c->changeCount = (size_t)2 * nAt;
-    }
+        return fail(LWHIP_ERR_INVALID, "Ng: the context's host block is too small for the change records");
     const int No = c->ngOrder, nslots = No + 2;
     NgArgs a{};
     a.atoms = c->ngAtoms.p;
@@ -850,9 +1162,12 @@ int lwhip_time_dep_update(lwhip_context* c, int atom, const double* nOld, double
     HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
     HIP_TRY(launch_time_dep(a.Nlevel, c->Ns, c->kLo, c->kHi < 0 ? c->Ns : c->kHi, c->n.p + (size_t)c->levelOff[atom] * c->Ns, c->popScratch.p,
                             c->Gamma.p + c->gammaOff[atom], dt, c->status.p, c->stream));
-    int32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    // (the copy's target is the context's own pinned word, not a stack variable: an early return cannot leave a copy in flight
+    // that aims at a dead frame)
+    *c->popStatusHost = 0;
+    HIP_TRY(hipMemcpyAsync(c->popStatusHost, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const int32_t st = *(volatile int32_t*)c->popStatusHost;
     if (st == LWHIP_ERR_SINGULAR)
         return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
     return LWHIP_OK;
@@ -961,10 +1276,16 @@ int lwhip_nr_post_update(lwhip_context* c, const lwhip_nr_args* args)
     a.k0 = c->kLo;
     a.k1 = c->kHi < 0 ? (int32_t)Ns : c->kHi;
     HIP_TRY(launch_nr_post(a, c->stream));
-    int32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    D2H(args->ne, dNe, Ns);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    *c->popStatusHost = 0;
+    HIP_TRY(hipMemcpyAsync(c->popStatusHost, c->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    {
+        // (the caller's array is the target of this copy: wait for the stream on EVERY path out)
+        const hipError_t ec = hipMemcpyAsync(args->ne, dNe, Ns * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        const hipError_t es = hipStreamSynchronize(c->stream);
+        HIP_TRY(ec);
+        HIP_TRY(es);
+    }
+    const int32_t st = *(volatile int32_t*)c->popStatusHost;
     if (st == LWHIP_ERR_SINGULAR)
         return fail(LWHIP_ERR_SINGULAR, "Singular Matrix");
     return LWHIP_OK;
@@ -1104,7 +1425,7 @@ int lwhip_set_stream(lwhip_context* c, void* stream)
     else
     {
         if (!c->ownStream)
-            HIP_TRY(hipStreamCreate(&c->ownStream));
+            HIP_TRY(stream_acquire(c->device, &c->ownStream));
         c->stream = c->ownStream;
     }
     return LWHIP_OK;

@@ -390,22 +390,25 @@ int lwhip_redistribute_prd(lwhip_context* c, int maxIter, double tol, lwhip_prd_
     // loop (PrdTemplates.hpp:250-275: stop after the sub-iteration whose largest |d rho / rho| is below tol) is kept ON THE
     // DEVICE: the apply launch of a sub-iteration records that it met the tolerance, and every launch of a later
     // sub-iteration returns at once, so nothing is computed or written that the reference's loop would not have.
-    const bool piped = c->worldSize == 1 && !c->is2d && !c->deterministic && c->laneSweep && !c->hprd && env_int("LWHIP_PRD_PIPELINE", 1) != 0;
+    const bool piped = c->worldSize == 1 && !c->is2d && !c->deterministic && c->laneSweep && !c->hprd && c->prdPipeline;
     if (piped)
     {
         const size_t nTail = 2 * (size_t)c->worldSize * (1 + Nprd);
-        if (c->prdPinnedPipeN < (size_t)PRD_PIPE_DEPTH * nTail + 4)
+        if (c->prdPinnedPipeN < (size_t)PRD_PIPE_DEPTH * nTail)
         {
             if (c->prdPinnedPipe)
+            {
+                HIP_TRY(hipStreamSynchronize(c->stream)); // (no queued copy may still aim at the block that goes)
                 HIP_TRY(hipHostFree(c->prdPinnedPipe));
+            }
             c->prdPinnedPipe = nullptr;
-            c->prdPinnedPipeN = (size_t)PRD_PIPE_DEPTH * nTail + 4;
+            c->prdPinnedPipeN = (size_t)PRD_PIPE_DEPTH * nTail;
             HIP_TRY(hipHostMalloc((void**)&c->prdPinnedPipe, c->prdPinnedPipeN * sizeof(double), hipHostMallocDefault));
         }
         if (c->prdCtl.n < 4)
             HIP_TRY(c->prdCtl.alloc_zero(4));
         HIP_TRY(hipMemsetAsync(c->prdCtl.p, 0, 4 * sizeof(int32_t), c->stream));
-        int32_t* ctlHost = (int32_t*)(c->prdPinnedPipe + (size_t)PRD_PIPE_DEPTH * nTail);
+        int32_t* ctlHost = c->prdCtlHost; // (a window of the context's host block)
         int st = LWHIP_OK;
         while (iter < maxIter)
         {

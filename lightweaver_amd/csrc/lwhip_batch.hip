@@ -149,12 +149,6 @@ int lwhip_batch_create(lwhip_context* const* ctxs, int n, lwhip_batch** out)
         for (int i = 0; i < n; ++i)
         {
             lwhip_context* c = ctxs[i];
-            if (!c->statusHost)
-            {
-                HIP_TRY(hipHostMalloc((void**)&c->statusHost, sizeof(int32_t), hipHostMallocMapped));
-                HIP_TRY(hipHostGetDevicePointer((void**)&c->statusDev, c->statusHost, 0));
-                *c->statusHost = 0;
-            }
             std::vector<NrAtom> atoms;
             int maxNl = 0;
             for (int ia = 0; ia < c->Natom; ++ia)

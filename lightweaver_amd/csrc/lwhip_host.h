@@ -27,6 +27,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -290,6 +291,18 @@ struct HostTrans
 }
 using namespace lwhip;
 
+struct lwhip_context;
+namespace lwhip
+{
+int host_block_init(lwhip_context* c);
+void host_block_release(lwhip_context* c);
+hipError_t stream_acquire(int device, hipStream_t* out);
+void stream_release(int device, hipStream_t s);
+void peer_release(lwhip_context* c);
+int peer_publish(lwhip_context* c);
+void peer_apply_args(lwhip_context* c, struct ApplyArgs& a);
+}
+
 struct lwhip_context
 {
     lwhip_problem prob;             // copy of the descriptor (host pointers borrowed)
@@ -377,7 +390,7 @@ struct lwhip_context
     int groups2d = 1, maxRowsLa = 1;
     int kLo = 0, kHi = -1; // depth range of the population updates (lwhip_set_depth_range); kHi < 0: to the end
     int djIdxMode = 0;     // lwhip_set_djmax_index_mode: 1 = the single-thread scheme's index bookkeeping
-    double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration
+    double* tailMapped = nullptr; // host-mapped (dJMax, idx) of the one-call iteration (a window of hostBlock)
     double* tailMappedDev = nullptr;
     double tailTicket = 0.0;      // ticket of the last launch that reports through tailMapped
     // line profiles generated on the device (lwhip_compute_profiles): re-derived before the next sweep whenever the
@@ -435,6 +448,9 @@ struct lwhip_context
     // every line's profile is the same for the two directions of an angle (static atmosphere): found when the profiles are
     // uploaded (the host's arrays are compared) or generated (all line-of-sight velocities zero); TileDyn::phiSym
     bool phiSym = false, vlosZero = false;
+    // LWHIP_PAIR_RAYS=0 / LWHIP_PRD_PIPELINE=0 (experiment knobs, read ONCE per context in lwhip_create and only under
+    // LWHIP_DEBUG like the other layout knobs: the first changes the order of the arithmetic)
+    bool pairRays = true, prdPipeline = true;
     double* prdPinnedPipe = nullptr;
     size_t prdPinnedPipeN = 0;
     int prdPipeIter = 0;     // > 0: the sub-iteration the calls of lwhip_prd_partial / _finalise belong to
@@ -450,7 +466,7 @@ struct lwhip_context
     bool atomicParts = false;     // the pending iteration's parts were accumulated by atomics
     bool red8Clean = false;       // red8 holds zeros (only the atomic path leaves it so)
     int* zeroCheck = nullptr;     // LWHIP_CHECK_ZERO=1 (diagnosis): host-mapped count of non-zero words found in red8 at sweep entry
-    int* zeroCheckDev = nullptr;
+    int* zeroCheckDev = nullptr;  // (windows of hostBlock; null unless the knob is set)
     DevBuf<int32_t> atomTrOffD, atomNlevel, atomDetailed, transLi, transLj;
     DevBuf<int64_t> atomGammaOff;
     DevBuf<double> red, red8, dJ;
@@ -472,31 +488,50 @@ struct lwhip_context
     double* stage = nullptr;
     size_t stageDoubles = 0;
 
+    // ONE pinned, host-mapped block per context holds every word the DEVICE stores into host memory (tailMapped, statusHost,
+    // changeHost, zeroCheck point into it) and every target of a small device-to-host copy the API used to aim at a stack
+    // variable (popStatusHost, prdCtlHost): made once in lwhip_create (host_block_init), released by the destructor AFTER the
+    // stream has drained -- so no kernel and no copy engine can hold an address of host memory that is not this context's own
+    // for the context's whole life, whatever path a call returns by.  LWHIP_DEBUG: the block is never given back to the
+    // runtime (quarantine, lwhip_api.hip) and its canary words are checked when the process ends.
+    // peer exchange of the sharded iteration (lwhip_peer_*, lwhip_api.hip): this rank's window [flags 2 x LWHIP_PEER_MAX |
+    // slots 2 x world x peerStride doubles] and the device addresses of every rank's window (own included)
+    unsigned char* peerWin = nullptr;
+    size_t peerWinBytes = 0, peerStride = 0;
+    unsigned char* peerPtr[LWHIP_PEER_MAX] = {};
+    bool peerIpc[LWHIP_PEER_MAX] = {};   // opened with hipIpcOpenMemHandle (closed in lwhip_peer_detach)
+    bool peerOn = false;
+    unsigned long long peerSeq = 0;      // exchanges so far (the next one uses buffer peerSeq & 1 with flag value peerSeq + 1)
+    DevBuf<int32_t> peerArrive;
+    unsigned char* hostBlock = nullptr;
+    size_t hostBlockBytes = 0;
+    int32_t* popStatusHost = nullptr; // device-to-host target of the status word of time_dep_update / nr_post_update
+    int32_t* prdCtlHost = nullptr;    // ... of the stopping-rule words of the pipelined PRD sub-iterations
+
     ~lwhip_context()
     {
+        // (a context that failed half-way through lwhip_create comes here without lwhip_destroy: nothing of it may be
+        // released while its stream -- or a clearing fill on the null stream -- still runs)
+        if (stream)
+            (void)hipStreamSynchronize(stream);
+        (void)hipStreamSynchronize(nullptr);
         for (auto& pr : pending)
         {
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
         if (ownStream)
-            (void)hipStreamDestroy(ownStream);
+            stream_release(device, ownStream); // (never hipStreamDestroy: see stream_acquire, lwhip_api.hip)
         if (gatherPinned)
             (void)hipHostFree(gatherPinned);
-        if (tailMapped)
-            (void)hipHostFree(tailMapped);
         if (stage)
             (void)hipHostFree(stage);
-        if (statusHost)
-            (void)hipHostFree(statusHost);
-        if (changeHost)
-            (void)hipHostFree(changeHost);
         if (prdPinned)
             (void)hipHostFree(prdPinned);
         if (prdPinnedPipe)
             (void)hipHostFree(prdPinnedPipe);
-        if (zeroCheck)
-            (void)hipHostFree(zeroCheck);
+        peer_release(this);
+        host_block_release(this);
     }
 };
 

@@ -440,6 +440,29 @@ struct ApplyArgs
     int32_t* prdCtl;
     double prdTol;
     int32_t prdIter;
+    // sharded iteration with the peer exchange (lwhip_peer_attach, lwhip_kernels.hip: peer_publish_kernel): instead of `red`
+    // after an all-reduce, the sums are taken from the `peerWorld` slots of THIS rank's window -- slot r holds what rank r's
+    // publish launch stored there -- added in rank order (the same on every rank: sharded Gamma / rates are then bit-reproducible).
+    // Every workgroup first waits until all `peerWorld` flags of the window have reached peerSeq.
+    int32_t peerWorld;
+    const double* peerSlots;                 // [peerWorld][peerStride] of the exchange's current buffer
+    int64_t peerStride;
+    const unsigned long long* peerFlags;     // [peerWorld] of the current buffer
+    unsigned long long peerSeq;
+};
+
+enum { LWHIP_PEER_MAX = 16 }; // ranks of one peer exchange (one node: 8 GPUs)
+
+// peer_publish_kernel: this rank's reduce buffer into its slot of every rank's window, then its flag there
+struct PeerPublishArgs
+{
+    const double* red;
+    int64_t n;                               // doubles to publish (sums + gather tail)
+    int32_t world, rank;
+    unsigned long long seq;
+    int32_t* arrive;                         // workgroup arrival counter (zero between launches)
+    double* slot[LWHIP_PEER_MAX];            // slot `rank` of rank r's window, current buffer
+    unsigned long long* flag[LWHIP_PEER_MAX]; // flag `rank` of rank r's window, current buffer
 };
 
 // One line's profile evaluation (lwhip_voigt.hip)
@@ -550,6 +573,7 @@ struct StatEqArgs
 hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream, const StatEqArgs* list = nullptr,
                           int nBatch = 0);
 int stat_eq_blocks(int Ns, int maxNlevel);
+hipError_t launch_peer_publish(const PeerPublishArgs& a, hipStream_t stream);
 // 2D formal solver (lwhip_fs2d.hip): one workgroup per problem
 struct Fs2dArgs
 {

@@ -169,6 +169,85 @@ hipError_t launch_reduce_sum(const ReduceArgs& a, hipStream_t stream, const Redu
     return hipGetLastError();
 }
 
+// ---- peer exchange of the shards' partial sums (one node; replaces the all-reduce of the reduce buffer) --------------------
+// What the reference does across threads (ThreadStorage.cpp:150-166, 334-396: every thread's private Gamma / rates added into
+// the main copies in thread order) across GPUs: rank r stores its [Ntrans, 4, Ns] sums + gather tail into slot r of EVERY
+// rank's window (peer-mapped device memory: xGMI stores, or plain stores when the ranks share a device), then raises flag r
+// there; every rank's apply launch waits for the `world` flags of its own window and adds the slots in rank order.  No
+// collective call, no host in the loop; the windows have two buffers used alternately (a rank can be at most one exchange
+// ahead of the slowest: its next publish needs its own apply, which needed everybody's previous publish).
+__global__ void __launch_bounds__(256) peer_publish_kernel(const PeerPublishArgs a)
+{
+    dbg_poison_lds();
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i0 < a.n)
+    {
+        const double v0 = a.red[i0], v1 = i0 + 1 < a.n ? a.red[i0 + 1] : 0.0;
+        for (int r = 0; r < a.world; ++r)
+        {
+            a.slot[r][i0] = v0;
+            if (i0 + 1 < a.n)
+                a.slot[r][i0 + 1] = v1;
+        }
+    }
+    // every storing wave waits for its stores, then one lane per workgroup releases them to the system and counts the
+    // workgroup in; the last one to arrive raises this rank's flag in every window
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (int)gridDim.x - 1)
+        {
+            __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+            for (int r = 0; r < a.world; ++r)
+                __hip_atomic_store(a.flag[r], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_peer_publish(const PeerPublishArgs& a, hipStream_t stream)
+{
+    const int64_t pairs = (a.n + 1) / 2;
+    LWHIP_LAUNCH(peer_publish_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// the wait of a consumer workgroup: lanes 0 .. world-1 poll one flag each; bounded (a peer that died must not hang the device:
+// ~2 s, then the sums are whatever the slots hold and the launch reports it through the mirror's fourth word)
+DEVINL bool peer_wait(const unsigned long long* flags, int world, unsigned long long seq)
+{
+    __shared__ int sLate;
+    if (threadIdx.x == 0)
+        sLate = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < world)
+    {
+        bool seen = false;
+        for (long spin = 0; spin < (1l << 24); ++spin)
+        {
+            if (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= seq)
+            {
+                seen = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!seen)
+            sLate = 1;
+    }
+    if (threadIdx.x < 64)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return sLate == 0;
+}
+
 // ---- apply: Gamma += radiative terms (Gamma keeps its collisional pre-fill), finalise_Gamma
 // (SimdFullIterationTemplates.hpp:491-508), Rij/Rji out ----------------------------------------------------
 // One block per (atom, slab of APPLY_K depth points): thread (e, kk) owns Gamma entry e = to*Nl+from
@@ -195,6 +274,23 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
                 return;
         }
     }
+    bool peersSeen = true;
+    if constexpr (std::is_same<A, ApplyArgs>::value)
+    {
+        if (a.peerWorld > 0)
+            peersSeen = peer_wait(a.peerFlags, a.peerWorld, a.peerSeq);
+    }
+    // element i of the exchanged buffer: the slots of this rank's window in rank order (loads that bypass the caches: the
+    // slots were written by other devices)
+    auto peerSum = [&](size_t i) -> double {
+        double s = 0.0;
+        if constexpr (std::is_same<A, ApplyArgs>::value)
+        {
+            for (int r = 0; r < a.peerWorld; ++r)
+                s += __hip_atomic_load(a.peerSlots + (size_t)r * a.peerStride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return s;
+    };
     if ((int)blockIdx.x >= a.Natom + 2) // PRD sub-iteration on one device: the lines' max |d rho / rho| (one wavefront each)
     {
         if (blockIdx.y == 0 && threadIdx.x < 64 && a.prdList && (int)blockIdx.x - (a.Natom + 2) < a.nPrdChange)
@@ -235,9 +331,16 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
             // sharded iteration: max over the shards' slots, first (lowest) wavelength index on ties (max_idx,
             // Constants.hpp:114-125), published like the single-device result
             double best = -1.0, bestIdx = 0.0;
+            bool peer = false;
+            size_t tailOff = 0;
+            if constexpr (std::is_same<A, ApplyArgs>::value)
+            {
+                peer = a.peerWorld > 0;
+                tailOff = (size_t)(a.tail - a.red);
+            }
             for (int r = 0; r < a.gatherWorld; ++r)
             {
-                const double v = a.tail[2 * r], i = a.tail[2 * r + 1];
+                const double v = peer ? peerSum(tailOff + 2 * r) : a.tail[2 * r], i = peer ? peerSum(tailOff + 2 * r + 1) : a.tail[2 * r + 1];
                 if (v > best || (v == best && i < bestIdx))
                 {
                     best = v;
@@ -246,12 +349,18 @@ template <int APPLY_K, class A> DEVINL void apply_kernel_body(const A& a)
             }
             __hip_atomic_store(&a.tailHost[0], best < 0.0 ? 0.0 : best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&a.tailHost[1], bestIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&a.tailHost[3], peersSeen ? 0.0 : 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (a peer's flag never came)
             __hip_atomic_store(&a.tailHost[2], a.tailTicket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
     // the reduced sum of transition tr, component q at depth k: from the reduce buffer, or from the stage-1 parts
     auto redAt = [&](int tr, int q, int k) -> double {
+        if constexpr (std::is_same<A, ApplyArgs>::value)
+        {
+            if (a.peerWorld > 0)
+                return peerSum(((size_t)tr * 4 + q) * Ns + k);
+        }
         if (!a.fromParts)
             return a.red[((size_t)tr * 4 + q) * Ns + k];
         double s = 0.0;

@@ -408,7 +408,7 @@ TileDyn make_dyn(lwhip_context* c, bool upOnly, int lambdaIterate)
     d.lambdaIterate = lambdaIterate;
     d.stopIter = 0;
     d.stopCtl = nullptr;
-    d.phiSym = (c && c->phiSym && env_int("LWHIP_PAIR_RAYS", 1) != 0) ? 1 : 0;
+    d.phiSym = (c && c->phiSym && c->pairRays) ? 1 : 0;
     return d;
 }
 
@@ -502,10 +502,20 @@ int collect_profile(lwhip_context* c)
 
 extern "C"
 {
+static int upload_impl(lwhip_context* c, uint32_t mask);
 int lwhip_upload(lwhip_context* c, uint32_t mask)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
+    // (the sources of the queued copies are the caller's arrays and this call's own temporaries: on an error path too the
+    // stream has drained before either can go away)
+    const int st = upload_impl(c, mask);
+    if (st != LWHIP_OK)
+        (void)hipStreamSynchronize(c->stream);
+    return st;
+}
+static int upload_impl(lwhip_context* c, uint32_t mask)
+{
     HIP_TRY(hipSetDevice(c->device));
     const lwhip_problem& p = c->prob;
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
@@ -738,10 +748,20 @@ int lwhip_upload(lwhip_context* c, uint32_t mask)
     return LWHIP_OK;
 }
 
+static int download_impl(lwhip_context* c, uint32_t mask);
 int lwhip_download(lwhip_context* c, uint32_t mask)
 {
     if (!c)
         return fail(LWHIP_ERR_INVALID, "null context");
+    // The caller's arrays are the targets of queued device-to-host copies: whatever path the call leaves by, none of them is
+    // still in flight when the caller has its arrays back (it may free them the next moment).
+    const int st = download_impl(c, mask);
+    if (st != LWHIP_OK)
+        (void)hipStreamSynchronize(c->stream);
+    return st;
+}
+static int download_impl(lwhip_context* c, uint32_t mask)
+{
     HIP_TRY(hipSetDevice(c->device));
     const lwhip_problem& p = c->prob;
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;

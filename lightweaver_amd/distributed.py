@@ -69,7 +69,16 @@ class ShardedIteration:
     by HIP's legacy default-stream semantics.
     """
 
-    def __init__(self, ctx, world: int = 1, rank: int = 0, group=None, force_collective=False):
+    def __init__(self, ctx, world: int = 1, rank: int = 0, group=None, force_collective=False, transport='auto'):
+        """`transport`: how the shards' partial sums meet --
+          'collective'  one all-reduce of the reduce buffer per iteration (RCCL / gloo);
+          'peer'        the library's peer exchange (include/lwhip.h lwhip_peer_*): every rank stores its sums into its slot
+                        of every rank's window and the apply launch adds the slots in rank order -- no collective call and
+                        no host in the loop, and the same bits on every rank.  The ranks must share a node (the windows are
+                        exchanged as hipIpc handles through `all_gather_object`); PRD sub-iterations keep the collectives;
+          'auto'        'peer' for HIP contexts when world > 1 and the handles can be opened on every rank, else 'collective'
+                        (LWHIP_SHARD_TRANSPORT=collective|peer overrides)."""
+        import os
         self.ctx = ctx
         self.world = world
         self.rank = rank
@@ -80,6 +89,37 @@ class ShardedIteration:
         self._side = None       # side stream of the host-authoritative mode (all-reduce overlapped with the J download)
         self.allreduce_s = 0.0  # host time spent issuing collectives (bench.py: allreduce_us)
         self._bind_stream()
+        self.transport = 'collective'
+        want = os.environ.get('LWHIP_SHARD_TRANSPORT', transport)
+        if want in ('peer', 'auto') and world > 1 and self._is_hip() and hasattr(ctx, 'peer_export'):
+            self._attach_peers(required=(want == 'peer'))
+
+    def _attach_peers(self, required):
+        """Exchange the windows' handles and attach; every rank learns whether ALL ranks succeeded (a partial attach would
+        deadlock the exchange), and everybody falls back together otherwise."""
+        import torch.distributed as dist
+        try:
+            mine = self.ctx.peer_export()
+            err = None
+        except Exception as e:   # noqa: BLE001
+            mine, err = None, e
+        got = [None] * self.world
+        dist.all_gather_object(got, mine, group=self.group)
+        ok = err is None and all(h is not None for h in got)
+        if ok:
+            try:
+                self.ctx.peer_attach(got)
+            except Exception as e:   # noqa: BLE001
+                ok, err = False, e
+        oks = [None] * self.world
+        dist.all_gather_object(oks, bool(ok), group=self.group)
+        if all(oks):
+            self.transport = 'peer'
+            return
+        if ok:
+            self.ctx.peer_detach()
+        if required:
+            raise RuntimeError(f'peer transport requested but not available on every rank (this rank: {err!r})')
 
     @property
     def _collective(self):
@@ -131,7 +171,7 @@ class ShardedIteration:
             ctx.prob.gamma_prefill(crsw)
             ctx.upload(abi.GAMMA | abi.J | abi.POPS | abi.BC | abi.RHOPRD)
         ctx.fs_partial(lambdaIterate)
-        if self._collective and not deviceResident and cur is not None:
+        if self._collective and not deviceResident and cur is not None and self.transport != 'peer':
             # host-authoritative mode: J and I are final once the sweep has run (they do not depend on the sums), so
             # the all-reduce runs on a side stream while this stream copies them to the host
             import torch
@@ -145,9 +185,9 @@ class ShardedIteration:
             up = ctx.fs_finalise()
             ctx.download(abi.ALL_OUTPUTS & ~(abi.J | abi.I))
             return up
-        if self._collective:
+        if self._collective and self.transport != 'peer':
             self._all_reduce(self._reduce_tensor())
-        up = ctx.fs_finalise()
+        up = ctx.fs_finalise()   # (peer transport: its launch waits for every rank's slot and adds them in rank order)
         if not deviceResident:
             ctx.download(abi.ALL_OUTPUTS)
         return up

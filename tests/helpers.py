@@ -124,3 +124,67 @@ def gamma_err_scaled(got, want_atom):
     nz = S > 0.0
     assert np.all(d[~nz] == 0.0)
     return float(np.max(d[nz] / S[nz])) if nz.any() else 0.0
+
+
+class ReadOnlyInputs:
+    """DIAGNOSIS (LWHIP_TEST_GUARD=1): every INPUT array of a problem moved into pages of its own and
+    made read-only for the lifetime of this object.  A CPU store into one of them dies with SIGSEGV at the store (pytest's
+    faulthandler and tools/guard/guardalloc.so print the stack); a device / SDMA write goes past the CPU's page protection,
+    so `changed()` naming an array with no fault in between means the writer is not a CPU thread."""
+    OUTPUTS = ('J', 'I', 'Rij', 'Rji', 'Gamma', 'n', 'rhoPrd', 'depthChi', 'depthEta', 'depthI')
+
+    def __init__(self, prob):
+        import ctypes
+        import mmap
+        self._libc = ctypes.CDLL(None, use_errno=True)
+        self._maps, self._saved = [], {}
+        seen = set()
+
+        def walk(obj, path):
+            if id(obj) in seen or obj is None:
+                return
+            seen.add(id(obj))
+            if isinstance(obj, (list, tuple)):
+                for i, v in enumerate(obj):
+                    if isinstance(v, np.ndarray):
+                        continue    # (arrays held in lists are not descriptor inputs of Problem)
+                    walk(v, f'{path}[{i}]')
+            elif hasattr(obj, '__dict__'):
+                for k, v in list(vars(obj).items()):
+                    if k == '_keepalive':
+                        continue
+                    if isinstance(v, np.ndarray):
+                        if k in self.OUTPUTS or v.nbytes == 0 or not v.flags.c_contiguous:
+                            continue
+                        n = (v.nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE
+                        mm = mmap.mmap(-1, n)
+                        w = np.frombuffer(mm, dtype=v.dtype, count=v.size).reshape(v.shape)
+                        w[...] = v
+                        setattr(obj, k, w)
+                        self._maps.append((f'{path}.{k}', mm, w, n))
+                        self._saved[f'{path}.{k}'] = v.copy()
+                    else:
+                        walk(v, f'{path}.{k}')
+        walk(prob, 'p')
+        self._protect(mmap.PROT_READ)
+
+    def _protect(self, prot):
+        import ctypes
+        for name, mm, w, n in self._maps:
+            rc = self._libc.mprotect(ctypes.c_void_p(w.ctypes.data), ctypes.c_size_t(n), ctypes.c_int(prot))
+            assert rc == 0, (name, ctypes.get_errno())
+
+    def changed(self):
+        """Names (+ element indices, old and new bytes) of the guarded arrays whose content is no longer what was put there."""
+        out = []
+        for name, mm, w, n in self._maps:
+            old = self._saved[name]
+            if not np.array_equal(w, old, equal_nan=True):
+                idx = np.nonzero(w.ravel() != old.ravel())[0]
+                out.append((name, idx[:8].tolist(), [w.ravel()[i].tobytes().hex() for i in idx[:8]],
+                            [old.ravel()[i].tobytes().hex() for i in idx[:8]], hex(w.ctypes.data)))
+        return out
+
+    def release(self):
+        import mmap
+        self._protect(mmap.PROT_READ | mmap.PROT_WRITE)

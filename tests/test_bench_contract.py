@@ -90,3 +90,49 @@ def test_bench_self_launch_two_ranks_on_one_gpu(gpu):
     assert d['value'] == pytest.approx(1e3 / d['ms_per_step'], rel=1e-9)
     assert abs(d['config']['Nlambda_total'] - 10240) <= 102 and d['config']['Nlambda_per_gpu'] < 6000
     assert 'allreduce_us' in d
+
+
+def test_column_sets_of_the_ranks_partition_the_seeded_set():
+    """--mode columns: column c of BASELINE configs[3] is FAL-C perturbed with seed 1234 + c whatever the number of ranks; the
+    ranks' round-robin shares are disjoint, cover the set, and a rank's problems are the ones a single rank builds for the
+    same column numbers (no rank-dependent input)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from lightweaver_amd.harness import models
+    whole_idx, whole = bench.column_problems(models, 6, 1, 0, lineScale=0.2)
+    assert whole_idx == list(range(6))
+    seen = []
+    for r in range(3):
+        idx, probs = bench.column_problems(models, 6, 3, r, lineScale=0.2)
+        assert idx == [r, r + 3]
+        for c, p in zip(idx, probs):
+            assert np.array_equal(p.temperature, whole[c].temperature) and np.array_equal(p.vlosMu, whole[c].vlosMu)
+            assert np.array_equal(p.atoms[1].n, whole[c].atoms[1].n)
+        seen += idx
+    assert sorted(seen) == list(range(6))
+    assert not np.array_equal(whole[0].temperature, whole[1].temperature)
+
+
+@pytest.mark.gpu
+def test_bench_columns_mode_two_ranks_on_one_gpu(gpu):
+    """`python3 bench.py --gpus 2 --mode columns` (BASELINE configs[3]'s split, two ranks sharing the box's one GPU under gloo):
+    every rank runs ITS columns as a fused batch, no collective in the data path; rank 0's line counts the column-iterations
+    of both ranks against the slower rank's clock."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--share-gpu',
+                          '--mode', 'columns', '--columns', '6', '--steps', '4', '--warmup', '1'], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak' and d['unit'] == 'column-iters/s'
+    assert d['config']['columns_total'] == 12 and d['config']['columns_per_gpu'] == 6 and d['config']['fused'] is True
+    assert d['value'] == pytest.approx(12 * 1e3 / d['ms_per_step'], rel=1e-9)
+    assert len(d['per_rank_ms_per_step']) == 2 and all(0.0 < x <= d['ms_per_step'] * 1.0001 for x in d['per_rank_ms_per_step'])
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['frac'] == pytest.approx(r['achieved'] / 8000.0, rel=1e-12) and 0.0 < r['frac'] < 1.0
+    assert 0.0 < d['config']['final_dJMax_max'] < 10.0

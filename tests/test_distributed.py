@@ -258,7 +258,7 @@ def test_two_rank_gloo_prd_matches_unsharded(tmp_path):
 
 
 # ---- the same split on the real device path: two processes share ONE GPU ------------------------------------------
-def _gpu_worker(rank, world, port, out, resident):
+def _gpu_worker(rank, world, port, out, resident, transport='collective'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
@@ -270,7 +270,8 @@ def _gpu_worker(rank, world, port, out, resident):
         la0, la1 = bounds[rank], bounds[rank + 1]
         # stream=None: the context starts on a library-owned stream; ShardedIteration must move it to torch's
         with Context(prob, device=0, laStart=la0, laEnd=la1, worldSize=world, worldRank=rank) as ctx:
-            it = ShardedIteration(ctx, world, rank)
+            it = ShardedIteration(ctx, world, rank, transport=transport)
+            assert it.transport == transport, (it.transport, transport)
             ups = []
             side = torch.cuda.Stream()
             for i in range(3):
@@ -291,17 +292,24 @@ def _gpu_worker(rank, world, port, out, resident):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('transport', ['collective', 'peer'])
 @pytest.mark.parametrize('resident', [True, False])
-def test_two_process_gloo_on_one_gpu_matches_unsharded(gpu, tmp_path, resident):
+def test_two_process_gloo_on_one_gpu_matches_unsharded(gpu, tmp_path, resident, transport):
     """The N > 1 data path with the real kernels: two processes, each with a wavelength-shard Context on the SAME
-    GPU, all-reduce the zero-copy view of the library's device reduce buffer (gloo stages device tensors through the
-    host; RCCL refuses two ranks on one device) between fs_partial and fs_finalise.  Contexts start on their own
-    stream, so this also covers the stream contract of ShardedIteration; resident=False covers the all-reduce
-    overlapped with the J / I download."""
+    GPU.  transport='collective': they all-reduce the zero-copy view of the library's device reduce buffer (gloo stages
+    device tensors through the host; RCCL refuses two ranks on one device) between fs_partial and fs_finalise;
+    transport='peer' (round 6, the default where it can be set up): no collective on the step -- each rank stores its sums
+    into its slot of both ranks' windows (opened through hipIpc handles) and the apply launch adds the slots in rank order,
+    so the two ranks' Gamma and rates are the same BITS.  Contexts start on their own stream, so this also covers the stream
+    contract of ShardedIteration; resident=False covers the host-authoritative mode."""
     from lightweaver_amd.context import Context
     world = 2
     port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path), resident), nprocs=world, join=True)
+    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path), resident, transport), nprocs=world, join=True)
+    if transport == 'peer':
+        za, zb = np.load(tmp_path / 'gpu0.npz'), np.load(tmp_path / 'gpu1.npz')
+        for k in ('G0', 'G1', 'R'):
+            assert np.array_equal(za[k], zb[k]), k
     prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
     ups = []
     with Context(prob) as ctx:

@@ -5,10 +5,12 @@ Every test here runs the gfx950 kernels; comparisons are against
   * the C oracle on seeded inputs that are not in the golden set, at sizes it finishes in seconds,
 at the stated fp64 tolerance: rel 1e-9 element-wise after one call, 1e-6 on the iterated J.
 """
+import os
+
 import numpy as np
 import pytest
 
-from helpers import (FIXTURES, TOL_CONVERGED, TOL_ONE_CALL, collect, compare_to_golden,
+from helpers import (FIXTURES, ReadOnlyInputs, TOL_CONVERGED, TOL_ONE_CALL, collect, compare_to_golden,
                      load_fixture, rel_err, variant_problem)
 from lightweaver_amd import _abi as abi
 from lightweaver_amd.context import Context, ExplodingMatrixError
@@ -197,10 +199,17 @@ def test_lane_sweep_ray_split_vs_oracle(gpu, monkeypatch, split, prd):
     compare_problems(a, runs[1][-1], tol=1e-10 if prd else 1e-12, what=('J', 'I'))
     q = prob.copy()
     q.gamma_prefill()
+    # (LWHIP_TEST_GUARD=1, tools/guard/hunt.sh: the oracle's inputs in read-only pages of their own from the copy until its run
+    # is over -- a CPU writer faults at the store, a device writer changes them with no fault)
+    guard = ReadOnlyInputs(q) if os.environ.get('LWHIP_TEST_GUARD') else None
     oc = OracleContext(q)
     oc.formal_sol_gamma_matrices()
     if prd:
         oc.redistribute_prd(2, 0.0)
+    if guard is not None:
+        hit = guard.changed()
+        guard.release()
+        assert not hit, f'GUARD: read-only input arrays of the oracle changed with no CPU fault (a device-side writer): {hit}'
     try:
         compare_problems(a, q)
     except AssertionError:
@@ -288,6 +297,69 @@ def test_sweep_variants_forced_on_small_problem(gpu, monkeypatch, env):
     with Context(p) as ctx:
         ctx.formal_sol_gamma_matrices()
     compare_to_golden(p, d, 'iter1')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_wavelength_shards_meet_through_the_peer_exchange(gpu, world):
+    """The sharded iteration with NO collective (lwhip_peer_*): `world` contexts of this process own the wavelength shards,
+    attach each other's windows by pointer, and each one's fs_finalise adds the ranks' slots in rank order -- Gamma and the
+    rates equal the unsharded run's to rounding and are the same bits on every rank; two iterations (both buffers of the
+    windows), dJMax and its index the unsharded ones."""
+    from lightweaver_amd.distributed import shard_bounds
+    prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
+    q = prob.copy()
+    with Context(q) as whole:
+        upsWhole = [whole.formal_sol_gamma_matrices(deviceResident=True) for _ in range(3)]
+        whole.download(abi.ALL_OUTPUTS)
+    b = shard_bounds(prob, world)
+    probs = [prob.copy() for _ in range(world)]
+    ctxs = [Context(p, laStart=b[r], laEnd=b[r + 1], worldSize=world, worldRank=r) for r, p in enumerate(probs)]
+    try:
+        wins = [c.peer_window()[0] for c in ctxs]
+        for c in ctxs:
+            c.peer_attach_pointers(wins)
+        for it in range(3):
+            for c in ctxs:           # (one host thread drives all ranks: every publish is queued before anybody waits)
+                c.gamma_prefill_from_C(1.0)
+                c.fs_partial()
+            ups = [c.fs_finalise() for c in ctxs]
+            for up in ups:
+                assert (up.dJMax, up.dJMaxIdx) == (upsWhole[it].dJMax, upsWhole[it].dJMaxIdx)
+        for c in ctxs:
+            c.download(abi.ALL_OUTPUTS)
+            c.peer_detach()
+    finally:
+        for c in ctxs:
+            c.close()
+    for r, p in enumerate(probs):
+        for ia in range(2):
+            assert rel_err(p.atoms[ia].Gamma, q.atoms[ia].Gamma) <= 1e-12
+            assert np.array_equal(p.atoms[ia].Gamma, probs[0].atoms[ia].Gamma)          # the same bits on every rank
+            for tp, t0, tq in zip(p.atoms[ia].trans, probs[0].atoms[ia].trans, q.atoms[ia].trans):
+                assert np.array_equal(tp.Rij, t0.Rij) and np.array_equal(tp.Rji, t0.Rji)
+                assert rel_err(tp.Rij, tq.Rij) <= 1e-12 and rel_err(tp.Rji, tq.Rji) <= 1e-12
+        assert np.array_equal(p.J[b[r]:b[r + 1]], q.J[b[r]:b[r + 1]]) and np.array_equal(p.I[b[r]:b[r + 1]], q.I[b[r]:b[r + 1]])
+
+
+def test_context_streams_are_pooled_not_destroyed(gpu, hip_lib):
+    """Round 6 (profiles/r06_stray_write.md): the HIP runtime's completion callback can store 4 bytes into a stream's queue
+    object after hipStreamDestroy freed it -- i.e. into whatever the process allocates there next (the oracle's wavelength
+    array in rounds 3-5; in drop-in mode possibly the user's arrays).  The library therefore never destroys a stream: a closed
+    context's stream serves the next context.  Opening and closing contexts one after the other creates no further streams;
+    two alive at once need two; nothing was stored into the host blocks of the closed contexts."""
+    prob = models.falc_h(Nrays=2, lineScale=0.2)
+    with Context(prob.copy()) as c0:
+        c0.formal_sol_gamma_matrices()
+    n0 = hip_lib.lwhip_debug_streams_created()
+    for _ in range(5):
+        with Context(prob.copy()) as c:
+            c.formal_sol_gamma_matrices()
+    assert hip_lib.lwhip_debug_streams_created() == n0
+    with Context(prob.copy()) as a, Context(prob.copy()) as b2:
+        a.formal_sol_gamma_matrices()
+        b2.formal_sol_gamma_matrices()
+    assert hip_lib.lwhip_debug_streams_created() <= n0 + 1
+    assert hip_lib.lwhip_debug_check_quarantine() == 0
 
 
 def test_wavelength_shards_sum_to_whole(gpu, sweep):

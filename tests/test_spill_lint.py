@@ -130,3 +130,32 @@ def test_the_listings_of_the_library_in_the_tree_are_clean():
     txt = os.path.join(ROOT, 'build', 'spill_lint.txt')
     if os.path.exists(txt):
         assert all(l.rstrip().endswith(' 0 slot(s) reported') for l in open(txt) if l.strip())
+
+
+def test_failed_check_is_not_bypassed_by_rebuilding(tmp_path):
+    """a build that failed the check left its objects behind, the next call found them up to date, compiled
+    nothing, checked nothing and linked.  The check now runs on every unit that is linked, with its verdict remembered next to
+    the listing: a flagged listing fails check_spills again on the second call (from the stamp), a listing that changed is
+    parsed again, and a missing listing is refused by the build (compile_one)."""
+    from lightweaver_amd import build
+    bad_listing = ('\t.type\tk,@function\nk:\n'
+                   '\ts_and_saveexec_b64 s[4:5], vcc\n'
+                   '\tscratch_store_dwordx2 off, v[12:13], off ; 8-byte Folded Spill\n'
+                   '\ts_or_b64 exec, exec, s[4:5]\n'
+                   '\tscratch_load_dwordx2 v[12:13], off, off ; 8-byte Folded Reload\n'
+                   '\ts_endpgm\n.Lfunc_end0:\n')
+    lst = tmp_path / 'unit-hip-amdgcn-amd-amdhsa-gfx950.s'
+    lst.write_text(bad_listing)
+    objdir = tmp_path / 'lib.obj'
+    objdir.mkdir()
+    first = build._lint_cached(str(lst))
+    assert first[1] > 0
+    with pytest.raises(RuntimeError, match='spill check'):
+        build.check_spills(str(objdir), [first])
+    assert os.path.exists(str(lst) + '.lint.json')
+    second = build._lint_cached(str(lst))          # the "rebuild": nothing recompiled, the verdict still stands
+    assert second[1] == first[1]
+    with pytest.raises(RuntimeError, match='spill check'):
+        build.check_spills(str(objdir), [second])
+    lst.write_text('\t.type\tk,@function\nk:\n\ts_endpgm\n.Lfunc_end0:\n')   # recompiled clean: parsed again
+    assert build._lint_cached(str(lst))[1] == 0
