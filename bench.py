@@ -61,7 +61,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-aux', action='store_true', help='skip the C3 / C4 / C5 side measurements')
     ap.add_argument('--aux', action='store_true', help='(accepted for compatibility: aux entries are on by default)')
-    ap.add_argument('--aux-only', choices=('prd', 'columns', '2d', 'fixed', 'realistic'), default=None,
+    ap.add_argument('--aux-only', choices=('prd', 'columns', '2d', 'fixed', 'realistic', 'moving', 'ref500', 'dropin'), default=None,
                     help='run only this side measurement and print its entry (for rocprofv3)')
     ap.add_argument('--columns', type=int, default=512, help='columns of the C4 batch PER GPU (512 x 8 GPUs = the 4 096 of BASELINE configs[3])')
     ap.add_argument('--mode', choices=('lambda', 'columns'), default='lambda',
@@ -451,8 +451,146 @@ def columns_line(args, c, world):
     }
 
 
+def aux_moving(args, device, stream, torch, models):
+    """The headline grid on a MOVING atmosphere (FAL-C perturbed with seed 1234: a smoothed 2 km/s line-of-sight velocity
+    field, the case of every RADYN / flare run): the line profiles differ between the two directions of an angle, so the
+    lane sweep cannot share a direction's gather and stencils between the rays of a pair as it does on the static headline
+    atmosphere.  Its kernel time gives roofline.frac_general; parity of its first iteration against the oracle in the run."""
+    import numpy as np
+    from lightweaver_amd.context import Context
+    atmos = models.perturbed(models.falc82(), seed=1234)
+    prob = models.throughput_grid(NlambdaTarget=args.nlambda, Nrays=5, computeProfiles=False, atmos=atmos)
+    with Context(prob, device=device, stream=stream) as c:
+        c.compute_profiles(deviceResident=True)
+        for _ in range(100):
+            c.formal_sol_gamma_matrices(deviceResident=True)
+        c.profile_enable(4)
+        ms = timed(lambda: c.formal_sol_gamma_matrices(deviceResident=True), 100, torch)
+        kms, nl = c.sweep_time()
+        c.profile_enable(False)
+        kind = c.sweep_kind()
+        alg = c.algorithmic_bytes()
+    out = {'config': f'the headline workload on a moving atmosphere (perturbed FAL-C, seed 1234, |v| up to '
+                     f'{float(np.max(np.abs(atmos.vlos))) * 1e-3:.1f} km/s), {prob.Nlambda} wavelengths',
+           'ms_per_step': ms, 'iters_per_s': 1e3 / ms, 'sweep': kind,
+           'roofline': roofline_block('lanesweep_kernel (general path: no ray pairs)' if kind == 'lanes' else 'raymarch_kernel',
+                                      alg, kms if kms > 0 else ms, f'HIP events around the sweep launch ({nl} timed)' if kms > 0 else 'whole step')}
+    if not args.no_cpu_baseline:
+        try:
+            from oracle.bindings import OracleContext
+            q = prob.copy()
+            models.compute_profiles_host(q)
+            g = q.copy()
+            oc = OracleContext(q)
+            q.gamma_prefill()
+            oc.formal_sol_gamma_matrices(Nthreads=min(os.cpu_count() or 1, 64))
+            with Context(g, device=device, stream=stream) as c2:
+                g.gamma_prefill()
+                c2.formal_sol_gamma_matrices()
+            a, b = snapshot(g), snapshot(q)
+            errs = {}
+            for k in b:
+                grp = ''.join(ch for ch in k.split('_')[0] if not ch.isdigit())
+                errs[grp] = max(errs.get(grp, 0.0), rel_err(a[k], b[k]))
+            out['parity'] = {'against': 'lw_oracle.c (pinned to the reference core bit for bit, tests/test_oracle_vs_reference.py)',
+                             'rel_err': errs, 'tolerance': PARITY_TOL}
+            out['max_rel_err'] = max(errs.values())
+            out['parity_checked'] = bool(out['max_rel_err'] <= PARITY_TOL)
+        except Exception as e:
+            out['parity_checked'] = False
+            out['parity_error'] = repr(e)
+    return out
+
+
+def aux_ref500(args, device, stream, torch, models):
+    """The configuration of the reference's ONLY shipped benchmark harness (lightweaver/benchmark.py:19-45): FAL-C resampled
+    to 500 depth points, H(6) + Ca II(6) active, quadrature(5), 50 x formal_sol_gamma_matrices; beside it the reference core
+    with its widest SIMD scheme timed the way that harness does (Nthreads = 1) and on all host cores."""
+    from lightweaver_amd.context import Context
+    atmos = models.resample(models.falc82(), 500)
+    prob = models.falc_h_ca(Nrays=5, lineScale=3.1, atmos=atmos, computeProfiles=False)
+    with Context(prob, device=device, stream=stream) as c:
+        c.compute_profiles(deviceResident=True)
+        for _ in range(30):
+            c.formal_sol_gamma_matrices(deviceResident=True)
+        c.profile_enable(2)
+        ms = timed(lambda: c.formal_sol_gamma_matrices(deviceResident=True), 50, torch)
+        kms, nl = c.sweep_time()
+        c.profile_enable(False)
+        kind = c.sweep_kind()
+        alg = c.algorithmic_bytes()
+    out = {'config': f'reference benchmark.py configuration: FALC resampled to 500 depths, H(6)+CaII(6), 5 mu, {prob.Nlambda} wavelengths, '
+                     '50 x formal_sol_gamma_matrices',
+           'ms_per_step': ms, 'iters_per_s': 1e3 / ms, 'sweep': kind,
+           'roofline': roofline_block('lanesweep_kernel' if kind == 'lanes' else 'raymarch_kernel', alg, kms if kms > 0 else ms,
+                                      f'HIP events around the sweep launch ({nl} timed)' if kms > 0 else 'whole step')}
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import bindings
+            if not bindings.ref_available():
+                raise RuntimeError('oracle/_ref is not on this box')
+            isa = next((i for i in ('AVX512', 'AVX2FMA', 'SSE2') if bindings.simd_plugin(i)), None)
+            ncpu = os.cpu_count() or 1
+            cpu = {}
+            host = prob.copy()
+            models.compute_profiles_host(host)   # (the CPU leg needs phi on the host)
+            for label, nthr, budget in (('Nthreads_1_as_benchmark_py', 1, 6.0), ('all_cores', min(ncpu, 64), 4.0)):
+                q = host.copy()
+                rc = bindings.RefContext(q, scheme=bindings.simd_plugin(isa) if isa else None, Nthreads=nthr)
+                q.gamma_prefill()
+                rc.formal_sol_gamma_matrices()
+                n, t0 = 0, time.perf_counter()
+                while True:
+                    q.gamma_prefill()
+                    rc.formal_sol_gamma_matrices()
+                    n += 1
+                    dt = time.perf_counter() - t0
+                    if dt >= budget or n >= 50:
+                        break
+                cpu[label] = {'iters_per_s': n / dt, 'ms_per_step': 1e3 * dt / n, 'threads': nthr, 'iterations_timed': n,
+                              'scheme': rc.scheme_name}
+            out['cpu_baseline'] = {'kind': 'reference', **cpu}
+            out['speedup_vs_reference_1_thread'] = cpu['Nthreads_1_as_benchmark_py']['ms_per_step'] / ms
+        except Exception as e:
+            out['cpu_baseline'] = {'failed': repr(e)}
+    return out
+
+
+def aux_dropin(args, device, stream, torch, models):
+    """The drop-in call as a Lightweaver user gets it: the REAL core (oracle/_ref/liblwref.so) loads LwHipIterScheme.so through
+    its own load_fns_from_path and calls ctx.iterFns.fs_iter -- formal_sol_gamma_matrices with every array the core owns kept
+    host-authoritative (Source/LwMiddleLayer.pyx:3152-3207), default environment: 50 calls at the headline size."""
+    from lightweaver_amd import build
+    from oracle import bindings
+    if not bindings.ref_available() or not build.PLUGIN or not os.path.exists(build.PLUGIN):
+        return {'failed': 'oracle/_ref or LwHipIterScheme.so is not on this box'}
+    prob = models.throughput_grid(NlambdaTarget=args.nlambda, Nrays=5)
+    rc = bindings.RefContext(prob, scheme=build.PLUGIN)
+    try:
+        def call():
+            prob.gamma_prefill()
+            rc.formal_sol_gamma_matrices()
+        for _ in range(5):
+            call()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            call()
+        ms = 1e3 * (time.perf_counter() - t0) / 50
+        t0 = time.perf_counter()
+        for _ in range(50):
+            prob.gamma_prefill()
+        pre = 1e3 * (time.perf_counter() - t0) / 50
+        name = rc.scheme_name
+    finally:
+        rc.close() if hasattr(rc, 'close') else None
+    return {'config': f'reference core -> load_fns_from_path(LwHipIterScheme.so) -> 50 x formal_sol_gamma_matrices, {prob.Nlambda} '
+                      'wavelengths, default environment, Gamma pre-filled on the host before every call as LwContext does',
+            'scheme': name, 'ms_per_call': ms - pre, 'ms_per_call_with_host_prefill': ms, 'calls_per_s': 1e3 / ms}
+
+
 AUX = {'prd': ('C3_prd', aux_prd), 'columns': ('C4_columns', aux_columns), '2d': ('C5_2d', aux_2d),
-       'fixed': ('fixed_order', aux_fixed_order), 'realistic': ('realistic_1d', aux_realistic)}
+       'fixed': ('fixed_order', aux_fixed_order), 'realistic': ('realistic_1d', aux_realistic),
+       'moving': ('moving_1d', aux_moving), 'ref500': ('ref_benchmark_500', aux_ref500), 'dropin': ('dropin', aux_dropin)}
 
 
 def rank_launch_command(ngpus, argv, port=None):
@@ -698,7 +836,16 @@ def main():
             out['allreduce_us'] = allreduce_us
         if weak:
             out.update(weak)
-        for name in ('fixed_order', 'realistic_1d'):
+        mv = aux.get('moving_1d')
+        if isinstance(mv, dict) and isinstance(mv.get('roofline'), dict):
+            out['roofline']['frac_general'] = mv['roofline']['frac']
+            out['roofline']['kernel_ms_general'] = mv['roofline']['kernel_ms']
+        out['roofline']['algorithmic_bytes_note'] = (
+            'SURVEY 8(d) counts phi of both directions of every angle; on this static atmosphere the lane sweep reads ONE '
+            "direction's phi for one-line tiles (ray pairs), so `achieved` is an upper bound on the bytes the kernel moves: "
+            'frac_general (aux.moving_1d: the same grid with a velocity field, both directions read) is the number a moving '
+            'atmosphere gets')
+        for name in ('fixed_order', 'realistic_1d', 'moving_1d'):
             if isinstance(aux.get(name), dict) and 'ms_per_step' in aux[name]:
                 aux[name]['ratio_to_headline'] = aux[name]['ms_per_step'] / out['ms_per_step']
         if aux:

@@ -347,6 +347,8 @@ def test_context_streams_are_pooled_not_destroyed(gpu, hip_lib):
     array in rounds 3-5; in drop-in mode possibly the user's arrays).  The library therefore never destroys a stream: a closed
     context's stream serves the next context.  Opening and closing contexts one after the other creates no further streams;
     two alive at once need two; nothing was stored into the host blocks of the closed contexts."""
+    if os.environ.get('LWHIP_DESTROY_STREAMS'):
+        pytest.skip('tools/guard/hunt_ab.sh, phase D: the old behaviour on purpose')
     prob = models.falc_h(Nrays=2, lineScale=0.2)
     with Context(prob.copy()) as c0:
         c0.formal_sol_gamma_matrices()
