@@ -254,6 +254,50 @@ typedef struct lwhip_iter_result {
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* lwhip_last_error(void);
 
+/* ---- the caller's J array as a direct output of the sweep (drop-in mode) -------------------------------------------------
+ * lwhip_map_host_J(ctx, 1) page-locks the problem's J array ([Nlambda, Nspace], hipHostRegister) and from then on the sweep
+ * stores every J it forms into the device's copy AND straight into that array (stores over PCIe, spread over the kernel's
+ * duration): `lwhip_download(LWHIP_J)` then moves nothing -- the 6.7 MB copy of J at 10 240 wavelengths was the largest part
+ * of a host-authoritative call.  The array holds the new J once the stream has been waited for (every download does).
+ * 1D problems on the depth-across-lanes sweep, unsharded; LWHIP_ERR_UNSUPPORTED otherwise or when the registration fails (the
+ * caller goes on with copies).  lwhip_map_host_J(ctx, 0) -- and lwhip_destroy -- release the registration; call it before
+ * the array is freed or replaced.  Contract served: `spect.J` overwritten for all wavelengths when fs_iter returns
+ * (Source/LwMiddleLayer.pyx:3198-3207, Source/SimdFullIterationTemplates.hpp:181-190). */
+int lwhip_map_host_J(lwhip_context* ctx, int enable);
+
+/* Exact change detection without reading J back: the 64-bit fingerprint lwhip_host_fingerprint(p, n) would give for the
+ * DEVICE's current J if it were copied into an array at address `p` (n = Nla * Nspace doubles of the shard), computed on the
+ * device (one pass over J in HBM, a few microseconds) -- so a host-authoritative caller can tell at its next call, from a
+ * fingerprint of its own array, whether anybody rewrote `spect.J` in between, and skip the upload of J when nobody did.
+ * The fingerprint is defined here: the array in blocks of LWHIP_FP_BLOCK doubles, per block a Fletcher-style pair of running
+ * sums over 8 interleaved 64-bit lanes (lwhip_fp_block_sums), folded with lwhip_fp_mix in block order.  Any change of one
+ * element changes it. */
+int lwhip_fingerprint_J(lwhip_context* ctx, const void* p, uint64_t* out);
+uint64_t lwhip_host_fingerprint(const double* p, size_t n);
+
+enum { LWHIP_FP_BLOCK = 32768 };
+static inline uint64_t lwhip_fp_mix(uint64_t h, uint64_t bits)
+{
+    h = (h ^ bits) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+/* one block's fingerprint from its 16 sums (s1[8], s2[8]), its length and its offset in the array */
+static inline uint64_t lwhip_fp_block_fold(const uint64_t* sums, size_t n, uint64_t offset)
+{
+    uint64_t h = lwhip_fp_mix(1469598103934665603ull ^ offset, (uint64_t)n);
+    for (int l = 0; l < 8; ++l)
+        h = lwhip_fp_mix(lwhip_fp_mix(h, sums[l]), sums[8 + l]);
+    return h;
+}
+/* the array's fingerprint from its blocks' fingerprints */
+static inline uint64_t lwhip_fp_array_fold(const uint64_t* blockHashes, size_t nBlocks, const void* p, size_t n)
+{
+    uint64_t h = lwhip_fp_mix((uint64_t)(uintptr_t)p, (uint64_t)n);
+    for (size_t b = 0; b < nBlocks; ++b)
+        h = lwhip_fp_mix(h, blockHashes[b]);
+    return h;
+}
+
 /* Diagnosis (LWHIP_DEBUG set in the environment): the pinned host blocks of destroyed contexts are kept and filled with a
  * pattern instead of being given back to the runtime; this returns the number of their bytes that no longer hold it (0 = nothing
  * stored into host memory of a context that was gone) and prints the first few to stderr.  Without LWHIP_DEBUG there is no

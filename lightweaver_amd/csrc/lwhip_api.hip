@@ -1405,6 +1405,103 @@ int lwhip_set_zplane_outputs(lwhip_context* c, double* zPlaneDown, double* zPlan
     return build_tile_args(c); // the sweep's argument block carries the pointers
 }
 
+int lwhip_map_host_J(lwhip_context* c, int enable)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->JhostReg)
+    {
+        (void)hipHostUnregister(c->JhostReg);
+        c->JhostReg = nullptr;
+        c->JhostDev = nullptr;
+        const int st = build_tile_args(c);
+        if (st != LWHIP_OK)
+            return st;
+    }
+    if (!enable)
+        return LWHIP_OK;
+    if (c->is2d || !c->laneSweep || c->worldSize > 1 || !c->prob.J)
+        return fail(LWHIP_ERR_UNSUPPORTED, "lwhip_map_host_J: a 1D problem on the depth-across-lanes sweep, unsharded");
+    const size_t bytes = (size_t)c->prob.Nlambda * c->Ns * sizeof(double);
+    hipError_t e = hipHostRegister(c->prob.J, bytes, hipHostRegisterMapped);
+    void* dev = nullptr;
+    if (e == hipSuccess)
+    {
+        e = hipHostGetDevicePointer(&dev, c->prob.J, 0);
+        if (e != hipSuccess)
+            (void)hipHostUnregister(c->prob.J);
+    }
+    if (e != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return fail(LWHIP_ERR_UNSUPPORTED, std::string("lwhip_map_host_J: the caller's J array cannot be page-locked: ") + hipGetErrorString(e));
+    }
+    c->JhostReg = c->prob.J;
+    c->JhostDev = (double*)dev + (size_t)c->laStart * c->Ns;
+    return build_tile_args(c); // the sweep's argument block carries the pointer
+}
+
+uint64_t lwhip_host_fingerprint(const double* p, size_t n)
+{
+    std::vector<uint64_t> hashes;
+    for (size_t off = 0; off < n; off += LWHIP_FP_BLOCK)
+    {
+        const size_t len = std::min<size_t>(LWHIP_FP_BLOCK, n - off);
+        uint64_t s[16] = { 1, 2, 3, 4, 5, 6, 7, 8, 0, 0, 0, 0, 0, 0, 0, 0 };
+        size_t i = 0;
+        for (; i + 8 <= len; i += 8)
+            for (int l = 0; l < 8; ++l)
+            {
+                uint64_t w;
+                std::memcpy(&w, p + off + i + l, 8);
+                s[l] += w;
+                s[8 + l] += s[l];
+            }
+        for (int l = 0; i < len; ++i, ++l)
+        {
+            uint64_t w;
+            std::memcpy(&w, p + off + i, 8);
+            s[l] += w;
+            s[8 + l] += s[l];
+        }
+        hashes.push_back(lwhip_fp_block_fold(s, len, (uint64_t)off));
+    }
+    return lwhip_fp_array_fold(hashes.data(), hashes.size(), p, p ? n : 0);
+}
+
+int lwhip_fingerprint_J(lwhip_context* c, const void* p, uint64_t* out)
+{
+    if (!c || !out)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->Nla * c->Ns;
+    const size_t nb = (n + LWHIP_FP_BLOCK - 1) / LWHIP_FP_BLOCK;
+    if (c->fpSums.n < nb * 16)
+        HIP_TRY(c->fpSums.alloc(nb * 16));
+    if (c->fpPinnedN < nb * 16)
+    {
+        if (c->fpPinned)
+        {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipHostFree(c->fpPinned));
+        }
+        c->fpPinned = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->fpPinned, nb * 16 * sizeof(unsigned long long), hipHostMallocDefault));
+        c->fpPinnedN = nb * 16;
+    }
+    HIP_TRY(launch_fp_blocks(c->J.p, n, c->fpSums.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fpPinned, c->fpSums.p, nb * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> hashes(nb);
+    for (size_t b = 0; b < nb; ++b)
+        hashes[b] = lwhip_fp_block_fold((const uint64_t*)c->fpPinned + b * 16, std::min<size_t>(LWHIP_FP_BLOCK, n - b * LWHIP_FP_BLOCK),
+                                        (uint64_t)(b * LWHIP_FP_BLOCK));
+    *out = lwhip_fp_array_fold(hashes.data(), nb, p, n);
+    return LWHIP_OK;
+}
+
 int lwhip_synchronize(lwhip_context* c)
 {
     if (!c)

@@ -503,6 +503,12 @@ struct lwhip_context
     bool peerOn = false;
     unsigned long long peerSeq = 0;      // exchanges so far (the next one uses buffer peerSeq & 1 with flag value peerSeq + 1)
     DevBuf<int32_t> peerArrive;
+    // lwhip_map_host_J: the caller's J array page-locked and mapped; the sweep stores J there too
+    void* JhostReg = nullptr;      // what was registered (prob.J)
+    double* JhostDev = nullptr;    // device address of this shard's first row in it
+    DevBuf<unsigned long long> fpSums; // lwhip_fingerprint_J: the blocks' sums
+    unsigned long long* fpPinned = nullptr;
+    size_t fpPinnedN = 0;
     unsigned char* hostBlock = nullptr;
     size_t hostBlockBytes = 0;
     int32_t* popStatusHost = nullptr; // device-to-host target of the status word of time_dep_update / nr_post_update
@@ -531,6 +537,10 @@ struct lwhip_context
         if (prdPinnedPipe)
             (void)hipHostFree(prdPinnedPipe);
         peer_release(this);
+        if (JhostReg)
+            (void)hipHostUnregister(JhostReg);
+        if (fpPinned)
+            (void)hipHostFree(fpPinned);
         host_block_release(this);
     }
 };

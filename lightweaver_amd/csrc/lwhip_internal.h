@@ -275,6 +275,7 @@ struct TileArgs
     const double* bgEta;
     const double* bgSca;
     double* J;                     // [Nla, Ns]
+    double* Jhost;                 // the same rows of the caller's page-locked J array, or null (lwhip_map_host_J): written beside J
     double* I;                     // [Nla, Nmu]
     double* depthChi;
     double* depthEta;
@@ -574,6 +575,7 @@ hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream
                           int nBatch = 0);
 int stat_eq_blocks(int Ns, int maxNlevel);
 hipError_t launch_peer_publish(const PeerPublishArgs& a, hipStream_t stream);
+hipError_t launch_fp_blocks(const double* p, size_t n, unsigned long long* sums /* [nBlocks][16] */, hipStream_t stream);
 // 2D formal solver (lwhip_fs2d.hip): one workgroup per problem
 struct Fs2dArgs
 {

@@ -545,6 +545,67 @@ hipError_t launch_apply(const ApplyArgs& a, hipStream_t stream, const ApplyArgs*
     return hipGetLastError();
 }
 
+// ---- the fingerprint of include/lwhip.h (lwhip_fingerprint_J) on the device ---------------------------------------------------
+// One workgroup per block of LWHIP_FP_BLOCK doubles.  The host's loop is, per lane l of 8 and row m (word 8 m + l):
+// s1 += w; s2 += s1, from s1 = l + 1, s2 = 0 -- so after R_l rows s1 = l + 1 + sum w_m and s2 = R_l (l + 1) + sum (R_l - m) w_m
+// (mod 2^64): two weighted sums, which threads form over rows m = t, t + T, ... and a tree adds up.
+__global__ void __launch_bounds__(256) fp_blocks_kernel(const double* __restrict__ p, size_t n, unsigned long long* __restrict__ sums)
+{
+    dbg_poison_lds();
+    __shared__ unsigned long long sh[256][16];
+    const size_t off = (size_t)blockIdx.x * LWHIP_FP_BLOCK;
+    const size_t len = min((size_t)LWHIP_FP_BLOCK, n - off);
+    const size_t rowsFull = len / 8, rem = len - rowsFull * 8;
+    unsigned long long a1[8], a2[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+        a1[l] = a2[l] = 0ull;
+    const unsigned long long* w = (const unsigned long long*)(p + off);
+    const size_t rows = rowsFull + (rem ? 1 : 0);
+    for (size_t m = threadIdx.x; m < rows; m += blockDim.x)
+    {
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+        {
+            const bool have = m < rowsFull || (size_t)l < rem;
+            const unsigned long long R = rowsFull + ((size_t)l < rem ? 1 : 0);
+            const unsigned long long x = have ? w[m * 8 + l] : 0ull;
+            a1[l] += x;
+            a2[l] += (R - m) * x;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+    {
+        sh[threadIdx.x][l] = a1[l];
+        sh[threadIdx.x][8 + l] = a2[l];
+    }
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1)
+    {
+        if ((int)threadIdx.x < s)
+            for (int q = 0; q < 16; ++q)
+                sh[threadIdx.x][q] += sh[threadIdx.x + s][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16)
+    {
+        const int l = threadIdx.x & 7;
+        const unsigned long long R = rowsFull + ((size_t)l < rem ? 1 : 0);
+        const unsigned long long init = (unsigned long long)(l + 1);
+        sums[(size_t)blockIdx.x * 16 + threadIdx.x] = threadIdx.x < 8 ? init + sh[0][threadIdx.x] : R * init + sh[0][threadIdx.x];
+    }
+}
+
+hipError_t launch_fp_blocks(const double* p, size_t n, unsigned long long* sums, hipStream_t stream)
+{
+    if (!n)
+        return hipSuccess;
+    const unsigned nb = (unsigned)((n + LWHIP_FP_BLOCK - 1) / LWHIP_FP_BLOCK);
+    LWHIP_LAUNCH(fp_blocks_kernel, dim3(nb), dim3(256), 0, stream, p, n, sums);
+    return hipGetLastError();
+}
+
 // ---- diagnosis (LWHIP_CHECK_ZERO=1): the invariant "the stage-1 buffer holds zeros when a sweep starts adding to it" checked
 // on the device: every non-zero (or NaN) word counts into a host-mapped counter that the library reads at its next
 // synchronising call and reports as LWHIP_ERR_DEVICE ------------------------------------------------------------------

@@ -2846,6 +2846,8 @@ DEVINL void lane_finish(const CONST_AS TileArgs& a, const TileDyn& dyn, const De
                 {
                     const double Jdag = Jrow[p];
                     GD(a.J)[(size_t)la * Ns + k0 + p] = Jk[p];
+                    if (a.Jhost) // (lwhip_map_host_J: the caller's array is an output of the sweep, no copy afterwards)
+                        GD(a.Jhost)[(size_t)la * Ns + k0 + p] = Jk[p];
                     dj = fmax(dj, fabs(1.0 - Jdag * ls_rcp(Jk[p]))); // :477-486 (the quotient by a refined reciprocal: 1e-16 of a convergence measure)
                 }
             // non-negative doubles order as integers
@@ -2985,6 +2987,8 @@ DEVINL void lane_finish_split(const CONST_AS TileArgs& a, const TileDyn& dyn, co
                         {
                             const double Jdag = Jrow[p];
                             GD(a.J)[(size_t)la * Ns + k0 + p] = Jk[p];
+                            if (a.Jhost)
+                                GD(a.Jhost)[(size_t)la * Ns + k0 + p] = Jk[p];
                             dj = fmax(dj, fabs(1.0 - Jdag * ls_rcp(Jk[p]))); // :477-486 (the quotient by a refined reciprocal: 1e-16 of a convergence measure)
                         }
                     }

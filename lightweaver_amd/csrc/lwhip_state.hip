@@ -299,6 +299,7 @@ int build_tile_args(lwhip_context* c)
     a.progEnts = c->progEnts.p;
     a.red8 = c->red8.p;
     a.dJ = c->dJ.p;
+    a.Jhost = c->JhostDev;
     if (c->laneSweep)
     {
         a.laneD = c->laneD;
@@ -774,7 +775,8 @@ static int download_impl(lwhip_context* c, uint32_t mask)
     }
     if (mask & LWHIP_J)
     {
-        D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
+        if (!c->JhostDev) // (lwhip_map_host_J: the sweep has stored J into the caller's array already)
+            D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
         if (c->hprd && c->JRest.p)
             D2H(c->hprd->JRest, c->JRest.p, c->JRest.n);
     }
