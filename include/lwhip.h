@@ -273,6 +273,11 @@ int lwhip_map_host_J(lwhip_context* ctx, int enable);
  * sums over 8 interleaved 64-bit lanes (lwhip_fp_block_sums), folded with lwhip_fp_mix in block order.  Any change of one
  * element changes it. */
 int lwhip_fingerprint_J(lwhip_context* ctx, const void* p, uint64_t* out);
+/* A copy of the device's J kept on the device / put back (stream-ordered, a few microseconds): with a mapped J array the sweep
+ * overwrites the caller's copy of the J an iteration starts from, so a caller that may have to run the iteration a second time
+ * on corrected inputs (the plugin's speculative run, lwhip_plugin.cpp fs_iter_hip) takes the starting J back from here. */
+int lwhip_j_snapshot(lwhip_context* ctx);
+int lwhip_j_restore(lwhip_context* ctx);
 uint64_t lwhip_host_fingerprint(const double* p, size_t n);
 
 enum { LWHIP_FP_BLOCK = 32768 };

@@ -169,6 +169,8 @@ SYMBOLS = [
     ('lwhip_map_host_J', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_fingerprint_J', C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     ('lwhip_host_fingerprint', C.c_uint64, [f64p, C.c_size_t]),
+    ('lwhip_j_snapshot', C.c_int, [ctx_p]),
+    ('lwhip_j_restore', C.c_int, [ctx_p]),
     ('lwhip_debug_check_quarantine', C.c_long, []),
     ('lwhip_debug_streams_created', C.c_long, []),
     ('lwhip_formal_sol', C.c_int, [ctx_p, C.c_int]),

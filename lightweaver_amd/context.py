@@ -442,6 +442,25 @@ class Context:
         _check(self.lib, self.lib.lwhip_peer_detach(self._h), 'lwhip_peer_detach')
         self.peers_attached = False
 
+    # -- the caller's J array as an output of the sweep (include/lwhip.h: lwhip_map_host_J) ------------------------------
+    def map_host_J(self, enable=True):
+        """Page-lock prob.J and let the sweep store J straight into it (no copy on download); returns False where the
+        library cannot (2D, shards, the march sweep, registration refused)."""
+        st = self.lib.lwhip_map_host_J(self._h, int(enable))
+        if st == abi.ERR_UNSUPPORTED:
+            return False
+        _check(self.lib, st, 'lwhip_map_host_J')
+        return bool(enable)
+
+    def fingerprint_J(self, array=None) -> int:
+        """Fingerprint of the device's J as it would read in `array` (default: prob.J's rows of this shard), formed on the
+        device; lightweaver_amd.context.host_fingerprint(array) is the host's side of the comparison."""
+        import numpy as np
+        ptr = (array if array is not None else self.prob.J[self.laStart:self.laEnd]).ctypes.data
+        out = C.c_uint64()
+        _check(self.lib, self.lib.lwhip_fingerprint_J(self._h, C.c_void_p(ptr), C.byref(out)), 'lwhip_fingerprint_J')
+        return out.value
+
     # -- measurement -----------------------------------------------------------------------------------------
     def profile_enable(self, enable=True):
         _check(self.lib, self.lib.lwhip_profile_enable(self._h, int(enable)), 'lwhip_profile_enable')
@@ -460,6 +479,13 @@ class Context:
         b = C.c_double()
         _check(self.lib, self.lib.lwhip_algorithmic_bytes(self._h, C.byref(b)), 'lwhip_algorithmic_bytes')
         return b.value
+
+
+def host_fingerprint(array) -> int:
+    """include/lwhip.h lwhip_host_fingerprint of a C-contiguous float64 array."""
+    import numpy as np
+    assert array.dtype == np.float64 and array.flags.c_contiguous
+    return load_library().lwhip_host_fingerprint(array.ctypes.data_as(abi.f64p), array.size)
 
 
 def device_count():

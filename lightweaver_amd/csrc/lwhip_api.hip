@@ -220,6 +220,46 @@ void peer_apply_args(lwhip_context* c, ApplyArgs& a)
 }
 }
 
+namespace lwhip
+{
+// the blocks' sums of the device's J into pinned memory, queued on the stream (lwhip_fingerprint_J, and every download of J
+// into a mapped array: one wait serves both)
+int fingerprint_J_enqueue(lwhip_context* c)
+{
+    const size_t n = (size_t)c->Nla * c->Ns;
+    const size_t nb = (n + LWHIP_FP_BLOCK - 1) / LWHIP_FP_BLOCK;
+    if (c->fpSums.n < nb * 16)
+        HIP_TRY(c->fpSums.alloc(nb * 16));
+    if (c->fpPinnedN < nb * 16)
+    {
+        if (c->fpPinned)
+        {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipHostFree(c->fpPinned));
+        }
+        c->fpPinned = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->fpPinned, nb * 16 * sizeof(unsigned long long), hipHostMallocDefault));
+        c->fpPinnedN = nb * 16;
+    }
+    HIP_TRY(launch_fp_blocks(c->J.p, n, c->fpSums.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fpPinned, c->fpSums.p, nb * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    return LWHIP_OK;
+}
+// (after the stream has been waited for)
+void fingerprint_J_fold(lwhip_context* c, const void* p)
+{
+    const size_t n = (size_t)c->Nla * c->Ns;
+    const size_t nb = (n + LWHIP_FP_BLOCK - 1) / LWHIP_FP_BLOCK;
+    std::vector<uint64_t> hashes(nb);
+    for (size_t b = 0; b < nb; ++b)
+        hashes[b] = lwhip_fp_block_fold((const uint64_t*)c->fpPinned + b * 16, std::min<size_t>(LWHIP_FP_BLOCK, n - b * LWHIP_FP_BLOCK),
+                                        (uint64_t)(b * LWHIP_FP_BLOCK));
+    c->fpJValue = lwhip_fp_array_fold(hashes.data(), nb, p, n);
+    c->fpJPtr = p;
+    c->fpJValid = true;
+}
+}
+
 extern "C"
 {
 int lwhip_peer_window(lwhip_context* c, void** devPtr, size_t* bytes)
@@ -677,6 +717,7 @@ static int fs_partial_impl(lwhip_context* c, int lambdaIterate, bool partsOnly)
         return fail(LWHIP_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     c->lastSweepUpOnly = false;
+    c->fpJValid = false; // (the sweep rewrites J)
     {
         const int stp = ensure_profiles(c);
         if (stp != LWHIP_OK)
@@ -1443,6 +1484,29 @@ int lwhip_map_host_J(lwhip_context* c, int enable)
     return build_tile_args(c); // the sweep's argument block carries the pointer
 }
 
+int lwhip_j_snapshot(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->Jsnap.n < c->J.n)
+        HIP_TRY(c->Jsnap.alloc(c->J.n, false));
+    HIP_TRY(hipMemcpyAsync(c->Jsnap.p, c->J.p, c->J.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return LWHIP_OK;
+}
+
+int lwhip_j_restore(lwhip_context* c)
+{
+    if (!c)
+        return fail(LWHIP_ERR_INVALID, "null context");
+    if (c->Jsnap.n < c->J.n || !c->Jsnap.p)
+        return fail(LWHIP_ERR_INVALID, "lwhip_j_restore without lwhip_j_snapshot");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->J.p, c->Jsnap.p, c->J.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->fpJValid = false;
+    return LWHIP_OK;
+}
+
 uint64_t lwhip_host_fingerprint(const double* p, size_t n)
 {
     std::vector<uint64_t> hashes;
@@ -1476,29 +1540,17 @@ int lwhip_fingerprint_J(lwhip_context* c, const void* p, uint64_t* out)
     if (!c || !out)
         return fail(LWHIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t n = (size_t)c->Nla * c->Ns;
-    const size_t nb = (n + LWHIP_FP_BLOCK - 1) / LWHIP_FP_BLOCK;
-    if (c->fpSums.n < nb * 16)
-        HIP_TRY(c->fpSums.alloc(nb * 16));
-    if (c->fpPinnedN < nb * 16)
+    if (c->fpJValid && c->fpJPtr == p) // (the last download of J left it: nothing has written the device's J since)
     {
-        if (c->fpPinned)
-        {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            HIP_TRY(hipHostFree(c->fpPinned));
-        }
-        c->fpPinned = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&c->fpPinned, nb * 16 * sizeof(unsigned long long), hipHostMallocDefault));
-        c->fpPinnedN = nb * 16;
+        *out = c->fpJValue;
+        return LWHIP_OK;
     }
-    HIP_TRY(launch_fp_blocks(c->J.p, n, c->fpSums.p, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->fpPinned, c->fpSums.p, nb * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    const int st = fingerprint_J_enqueue(c);
+    if (st != LWHIP_OK)
+        return st;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<uint64_t> hashes(nb);
-    for (size_t b = 0; b < nb; ++b)
-        hashes[b] = lwhip_fp_block_fold((const uint64_t*)c->fpPinned + b * 16, std::min<size_t>(LWHIP_FP_BLOCK, n - b * LWHIP_FP_BLOCK),
-                                        (uint64_t)(b * LWHIP_FP_BLOCK));
-    *out = lwhip_fp_array_fold(hashes.data(), nb, p, n);
+    fingerprint_J_fold(c, p);
+    *out = c->fpJValue;
     return LWHIP_OK;
 }
 

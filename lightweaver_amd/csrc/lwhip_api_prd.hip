@@ -60,6 +60,7 @@ int lwhip_prd_partial(lwhip_context* c)
     if (c->partialPending || c->prdPending)
         return fail(LWHIP_ERR_INVALID, "lwhip_prd_partial inside an unfinished iteration / sub-iteration");
     HIP_TRY(hipSetDevice(c->device));
+    c->fpJValid = false; // (the rates pass rewrites J at the PRD wavelengths)
     {
         const int stp = ensure_profiles(c);
         if (stp != LWHIP_OK)

@@ -300,6 +300,8 @@ hipError_t stream_acquire(int device, hipStream_t* out);
 void stream_release(int device, hipStream_t s);
 void peer_release(lwhip_context* c);
 int peer_publish(lwhip_context* c);
+int fingerprint_J_enqueue(lwhip_context* c);
+void fingerprint_J_fold(lwhip_context* c, const void* p);
 void peer_apply_args(lwhip_context* c, struct ApplyArgs& a);
 }
 
@@ -506,9 +508,13 @@ struct lwhip_context
     // lwhip_map_host_J: the caller's J array page-locked and mapped; the sweep stores J there too
     void* JhostReg = nullptr;      // what was registered (prob.J)
     double* JhostDev = nullptr;    // device address of this shard's first row in it
+    DevBuf<double> Jsnap;          // lwhip_j_snapshot
     DevBuf<unsigned long long> fpSums; // lwhip_fingerprint_J: the blocks' sums
     unsigned long long* fpPinned = nullptr;
     size_t fpPinnedN = 0;
+    bool fpJValid = false;         // fpJValue is the fingerprint of the device's current J as seen at address fpJPtr
+    uint64_t fpJValue = 0;
+    const void* fpJPtr = nullptr;
     unsigned char* hostBlock = nullptr;
     size_t hostBlockBytes = 0;
     int32_t* popStatusHost = nullptr; // device-to-host target of the status word of time_dep_update / nr_post_update

@@ -525,6 +525,8 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
     bool phiSymUp = true;         // (LWHIP_PROFILES: the uploaded profiles are the same for both directions of every angle)
     if (mask & LWHIP_GAMMA)
         c->prefillPending = false; // the host pre-fill being uploaded supersedes it
+    if (mask & LWHIP_J)
+        c->fpJValid = false;
     if (mask & LWHIP_ATMOS)
     {
         H2D(c->height.p, p.height, Ns);
@@ -763,6 +765,7 @@ int lwhip_download(lwhip_context* c, uint32_t mask)
 }
 static int download_impl(lwhip_context* c, uint32_t mask)
 {
+    bool fpPending = false;
     HIP_TRY(hipSetDevice(c->device));
     const lwhip_problem& p = c->prob;
     const size_t Ns = c->Ns, Nla = c->Nla, Nr = c->Nrays;
@@ -777,6 +780,14 @@ static int download_impl(lwhip_context* c, uint32_t mask)
     {
         if (!c->JhostDev) // (lwhip_map_host_J: the sweep has stored J into the caller's array already)
             D2H(p.J + l0 * Ns, c->J.p, Nla * Ns);
+        else if (!c->fpJValid)
+        {
+            // ... and the caller gets the fingerprint of what is there now without reading it (lwhip_fingerprint_J)
+            const int stf = fingerprint_J_enqueue(c);
+            if (stf != LWHIP_OK)
+                return stf;
+            fpPending = true;
+        }
         if (c->hprd && c->JRest.p)
             D2H(c->hprd->JRest, c->JRest.p, c->JRest.n);
     }
@@ -833,6 +844,8 @@ static int download_impl(lwhip_context* c, uint32_t mask)
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (fpPending)
+        fingerprint_J_fold(c, c->prob.J + (size_t)c->laStart * c->Ns);
     {
         const int stz = verify_zero_check(c);
         if (stz != LWHIP_OK)

@@ -307,7 +307,17 @@ struct PluginState
     double* zDown = nullptr;           // ZPlaneDecomposition outputs the device context currently writes
     double* zUp = nullptr;
     bool jDeviceAhead = false;         // LWHIP_RESIDENT_J: the device holds a newer J (JRest) than spect.J
+    // Round 6: spect.J is an OUTPUT of the sweep itself (lwhip_map_host_J: page-locked, the kernel stores into it), and its
+    // upload is skipped while nobody has rewritten it: fpJ is the fingerprint of what the device's J looks like in spect.J
+    // (lwhip_fingerprint_J after every download, formed on the device), compared at the next call with an exact fingerprint
+    // of the array as the host holds it then.  The contract stays the reference's: J is in spect.J when a call returns, and
+    // whatever the caller writes there between two calls is what the next call starts from.
+    bool jMapped = false;
+    bool jSynced = false;
+    uint64_t fpJ = 0;
 };
+
+bool resident_J();
 
 std::mutex g_mutex;
 std::map<const Atom*, std::pair<Context*, int>> g_atomOwner; // stat_eq receives only the Atom*
@@ -816,6 +826,12 @@ uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr, uint32_t 
         opts.hprd = st->hprdOn ? &st->hprd : nullptr;
         if (lwhip_create(&st->prob, &opts, &st->hip) != LWHIP_OK)
             fail("lwhip_create");
+        {
+            // (LWHIP_MAP_HOST_J=0: J comes back by a copy, as before round 6)
+            const char* mj = std::getenv("LWHIP_MAP_HOST_J");
+            st->jMapped = !(mj && mj[0] == '0') && !resident_J() && lwhip_map_host_J(st->hip, 1) == LWHIP_OK;
+            st->jSynced = false;
+        }
         dirty_mask(st, true); // create uploaded everything: just record the fingerprints
         register_atoms(&ctx);
         return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
@@ -869,8 +885,26 @@ bool resident_J()
 }
 
 // the upload mask of a call under that policy (before lwhip_upload); `fresh`: the device context was just (re)created
-uint32_t j_policy_upload(PluginState* st, uint32_t up)
+// exact fingerprint of spect.J as the host holds it now (the pool's threads; 6.7 MB at the bench size: ~0.03 ms)
+uint64_t host_J_fingerprint(PluginState* st)
 {
+    HashSet hs;
+    const int j = hs.add(st->prob.J, (size_t)st->prob.Nlambda * st->prob.Nspace);
+    hs.run();
+    return hs[j];
+}
+
+uint32_t j_policy_upload(PluginState* st, uint32_t up, bool force = false)
+{
+    if (st->jMapped && resident_J())
+    {
+        // (LWHIP_RESIDENT_J promises that spect.J is not written while it is set: the sweep must not store into it)
+        if (lwhip_map_host_J(st->hip, 0) != LWHIP_OK)
+            fail("lwhip_map_host_J");
+        st->jMapped = false;
+    }
+    if ((up & LWHIP_J) && st->jSynced && !force && !st->jDeviceAhead && host_J_fingerprint(st) == st->fpJ)
+        up &= ~(uint32_t)LWHIP_J; // nobody has rewritten spect.J since the device produced it: the device's copy is the same
     if (st->jDeviceAhead)
     {
         if (!resident_J())
@@ -893,6 +927,16 @@ uint32_t j_policy_download(PluginState* st, uint32_t down)
         st->jDeviceAhead = true;
     }
     return down;
+}
+
+// after a download that included J: what spect.J holds now, by the device's account
+void j_record_synced(PluginState* st, uint32_t down)
+{
+    st->jSynced = false;
+    if (!(down & LWHIP_J) || st->prob.grid2d)
+        return;
+    if (lwhip_fingerprint_J(st->hip, st->prob.J, &st->fpJ) == LWHIP_OK)
+        st->jSynced = true;
 }
 
 // ---- FsIterationFns members ----------------------------------------------------------------------
@@ -933,8 +977,15 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
     lwhip_iter_result r{};
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        if (lwhip_upload(st->hip, j_policy_upload(st, up)) != LWHIP_OK)
+        // (the second attempt: the first run's J is in spect.J already when the array is mapped -- the J this call started
+        // from comes back from the device's snapshot, not from the host)
+        const bool restoreJ = attempt == 1 && st->jMapped;
+        if (restoreJ && lwhip_j_restore(st->hip) != LWHIP_OK)
+            fail("lwhip_j_restore");
+        if (lwhip_upload(st->hip, restoreJ ? (up & ~(uint32_t)LWHIP_J) : j_policy_upload(st, up, force)) != LWHIP_OK)
             fail("lwhip_upload");
+        if (attempt == 0 && prints.active && st->jMapped && lwhip_j_snapshot(st->hip) != LWHIP_OK)
+            fail("lwhip_j_snapshot");
         lap("upload", tPrev);
         if (lwhip_formal_sol_gamma_matrices(st->hip, lambdaIterate ? 1 : 0, &r) != LWHIP_OK)
             fail("lwhip_formal_sol_gamma_matrices");
@@ -950,8 +1001,10 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
     uint32_t down = LWHIP_J | LWHIP_I | LWHIP_GAMMA | LWHIP_RATES;
     if (st->prob.storeDepthData)
         down |= LWHIP_DEPTHDATA;
-    if (lwhip_download(st->hip, j_policy_download(st, down)) != LWHIP_OK)
+    down = j_policy_download(st, down);
+    if (lwhip_download(st->hip, down) != LWHIP_OK)
         fail("lwhip_download");
+    j_record_synced(st, down);
     lap("download", tPrev);
     IterationResult result{};
     result.updatedJ = true;
@@ -972,7 +1025,7 @@ IterationResult simple_fs_hip(Context& ctx, bool upOnly, ExtraParams params)
     apply_zplane(ctx, st, params);
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        if (lwhip_upload(st->hip, j_policy_upload(st, up & ~(uint32_t)LWHIP_GAMMA)) != LWHIP_OK)
+        if (lwhip_upload(st->hip, j_policy_upload(st, up & ~(uint32_t)LWHIP_GAMMA, force)) != LWHIP_OK)
             fail("lwhip_upload");
         if (lwhip_formal_sol(st->hip, upOnly ? 1 : 0) != LWHIP_OK)
             fail("lwhip_formal_sol");
@@ -1153,8 +1206,14 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
     lwhip_prd_result r{ 0, 0, dRho.data(), dRhoIdx.data(), dJ.data(), dJIdx.data() };
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        if (lwhip_upload(st->hip, j_policy_upload(st, (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES)) != LWHIP_OK)
+        const bool restoreJ = attempt == 1 && st->jMapped; // (as in fs_iter: the rates passes have rewritten spect.J)
+        if (restoreJ && lwhip_j_restore(st->hip) != LWHIP_OK)
+            fail("lwhip_j_restore");
+        const uint32_t want = (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES;
+        if (lwhip_upload(st->hip, restoreJ ? (want & ~(uint32_t)LWHIP_J) : j_policy_upload(st, want, force)) != LWHIP_OK)
             fail("lwhip_upload");
+        if (attempt == 0 && prints.active && st->jMapped && lwhip_j_snapshot(st->hip) != LWHIP_OK)
+            fail("lwhip_j_snapshot");
         if (lwhip_redistribute_prd(st->hip, maxIter, tol, &r) != LWHIP_OK)
             fail("lwhip_redistribute_prd");
         if (!prints.active)
@@ -1166,8 +1225,12 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
     }
     // (the rates pass of every sub-iteration also rewrites spect.I of its wavelengths: intensity_core_opt,
     // SimdFullIterationTemplates.hpp:349)
-    if (lwhip_download(st->hip, j_policy_download(st, LWHIP_J | LWHIP_I | LWHIP_RATES | LWHIP_RHOPRD)) != LWHIP_OK)
-        fail("lwhip_download");
+    {
+        const uint32_t down = j_policy_download(st, LWHIP_J | LWHIP_I | LWHIP_RATES | LWHIP_RHOPRD);
+        if (lwhip_download(st->hip, down) != LWHIP_OK)
+            fail("lwhip_download");
+        j_record_synced(st, down);
+    }
     const size_t nEnt = (size_t)r.NprdSubIter * r.Nprd;
     result.updatedRho = true;
     result.NprdSubIter = r.NprdSubIter;

@@ -364,6 +364,56 @@ def test_context_streams_are_pooled_not_destroyed(gpu, hip_lib):
     assert hip_lib.lwhip_debug_check_quarantine() == 0
 
 
+@pytest.mark.parametrize('Nspace', [82, 77])
+def test_J_stored_into_the_callers_array_and_fingerprinted_on_the_device(gpu, Nspace, monkeypatch):
+    """lwhip_map_host_J: the sweep stores J into the page-locked caller array as it forms it -- after the iteration (and a
+    wait for the stream) prob.J holds exactly what a copy would have brought, also after PRD sub-iterations, which rewrite J at
+    the PRD wavelengths.  lwhip_fingerprint_J (blocks summed on the device) equals lwhip_host_fingerprint of that array (82
+    and 77 depth points: whole and ragged 8-word rows, a partial last block), follows a single-element edit uploaded to the
+    device, and differs from the host's fingerprint when only the host array is edited."""
+    from lightweaver_amd.context import host_fingerprint
+    monkeypatch.setenv('LWHIP_SWEEP', 'lanes')
+    atmos = models.resample(models.falc82(), Nspace)
+    prob = models.falc_h_ca(Nrays=3, lineScale=0.4, prd=True, atmos=atmos)
+    p, q = prob.copy(), prob.copy()
+    with Context(q) as plain:
+        q.gamma_prefill()
+        plain.formal_sol_gamma_matrices()
+        plain.redistribute_prd(2, 0.0)
+    with Context(p) as ctx:
+        assert ctx.map_host_J(True) is True
+        before = p.J.copy()
+        p.gamma_prefill()
+        ctx.upload(abi.GAMMA)
+        ctx.formal_sol_gamma_matrices(deviceResident=True)
+        ctx.synchronize()
+        assert not np.array_equal(p.J, before)          # nothing was downloaded: the kernel wrote it
+        ctx.download(abi.ALL_OUTPUTS)
+        first = p.J.copy()
+        ctx.redistribute_prd(2, 0.0)
+        assert np.array_equal(p.J, q.J) and not np.array_equal(first, p.J)
+        for a, b in zip(p.atoms, q.atoms):
+            for ta, tb in zip(a.trans, b.trans):
+                assert np.array_equal(ta.Rij, tb.Rij)
+        # fingerprints: device == host for what the device produced
+        assert ctx.fingerprint_J() == host_fingerprint(p.J)
+        other = p.J.copy()
+        assert ctx.fingerprint_J(other) == host_fingerprint(other)
+        # the host edits one element: the host's fingerprint moves, the device's does not, an upload realigns them
+        p.J[p.Nlambda // 3, Nspace // 2] *= 1.0 + 1e-15
+        assert ctx.fingerprint_J() != host_fingerprint(p.J)
+        ctx.upload(abi.J)
+        assert ctx.fingerprint_J() == host_fingerprint(p.J)
+        assert ctx.map_host_J(False) is False
+        ctx.formal_sol_gamma_matrices(deviceResident=True)   # unmapped again: the array is not touched until a download
+        ctx.synchronize()
+        keep = p.J.copy()
+        ctx.download(abi.J)
+        assert not np.array_equal(keep, p.J)
+    with Context(prob.copy(), laStart=0, laEnd=prob.Nlambda // 2, worldSize=2, worldRank=0) as shard:
+        assert shard.map_host_J(True) is False           # (refused loudly: shards keep the copy)
+
+
 def test_wavelength_shards_sum_to_whole(gpu, sweep):
     """Two contexts owning [0, m) and [m, Nlambda): their reduce buffers add up to the unsharded
     one and J/I rows are owner-exclusive (the multi-GPU split, on one device)."""

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import TOL_CONVERGED, TOL_ONE_CALL, collect, load_fixture, rel_err, variant_problem
+from helpers import TOL_CONVERGED, TOL_ONE_CALL, collect, gamma_err_scaled, load_fixture, rel_err, variant_problem
 from lightweaver_amd import _abi as abi
 from lightweaver_amd import build
 from oracle import bindings
@@ -189,6 +189,51 @@ def test_dropin_sees_host_side_changes(gpu, monkeypatch, sampled):
         ref.formal_sol_gamma_matrices()
         assert rel_err(p.J, q.J) <= TOL_ONE_CALL
         assert rel_err(p.atoms[0].Gamma, q.atoms[0].Gamma) <= TOL_ONE_CALL
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize('mapped', ['1', '0'])
+def test_dropin_J_is_an_output_of_the_sweep_and_host_edits_of_J_are_honoured(gpu, monkeypatch, mapped):
+    """Round 6: spect.J is page-locked and written by the sweep itself, and its upload is skipped while nobody has rewritten
+    it (exact fingerprint of the array against the device's own).  The reference's contract holds: J is in spect.J when a
+    call returns; a caller that rewrites spect.J between two calls -- all of it, or ONE element by one unit in the last place --
+    gets an iteration that starts from what it wrote, exactly like the scalar scheme; so does a PRD call; and a slow-group
+    change discovered by the speculative run (the background edited in place) re-runs the iteration from the RIGHT J although
+    the first run has overwritten the host's copy (LWHIP_MAP_HOST_J=0: the copying path of rounds 1-5, same results)."""
+    monkeypatch.setenv('LWHIP_MAP_HOST_J', mapped)
+    monkeypatch.setenv('LWHIP_DETERMINISTIC', '1')
+    base, d = load_fixture('falc_h_ca_small')
+    p, q = base.copy(), base.copy()
+    hipc, ref = RefContext(p, scheme=PLUGIN), RefContext(q)
+
+    def both(f):
+        for pr, c in ((p, hipc), (q, ref)):
+            f(pr, c)
+        assert rel_err(p.J, q.J) <= TOL_ONE_CALL and rel_err(p.I, q.I) <= TOL_ONE_CALL
+        for a, b in zip(p.atoms, q.atoms):
+            assert gamma_err_scaled(a.Gamma, b) <= TOL_ONE_CALL
+
+    def call(pr, c):
+        pr.gamma_prefill()
+        c.formal_sol_gamma_matrices()
+    both(call)
+    both(call)                                              # nothing touched in between: the upload of J is skipped
+    def edit_all(pr, c):
+        pr.J *= 1.0 + 1e-3 * np.cos(np.arange(pr.J.size)).reshape(pr.J.shape)
+        call(pr, c)
+    both(edit_all)
+    def edit_one(pr, c):
+        pr.J[pr.Nlambda // 2 + 1, pr.Nspace // 2] *= 3.0   # (a big change of one element: its effect is far above the tolerance)
+        call(pr, c)
+    both(edit_one)
+    Jp, Jq = p.J.copy(), q.J.copy()
+    def edit_bg_and_J(pr, c):
+        pr.bgChi[pr.Nlambda // 3, 5] *= 1.5                 # seen only by the fingerprints that run beside the speculative kernels
+        call(pr, c)
+    both(edit_bg_and_J)
+    assert not np.array_equal(Jp, p.J)
+    both(call)
 
 
 @needs_ref
