@@ -315,9 +315,13 @@ struct PluginState
     bool jMapped = false;
     bool jSynced = false;
     uint64_t fpJ = 0;
+    bool fpJHostFresh = false;         // fpJHost was formed in this call (sync_state, before the pool got the slow groups)
+    uint64_t fpJHost = 0;
 };
 
 bool resident_J();
+struct PluginState;
+uint64_t host_J_fingerprint(PluginState* st);
 
 std::mutex g_mutex;
 std::map<const Atom*, std::pair<Context*, int>> g_atomOwner; // stat_eq receives only the Atom*
@@ -829,12 +833,21 @@ uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr, uint32_t 
         {
             // (LWHIP_MAP_HOST_J=0: J comes back by a copy, as before round 6)
             const char* mj = std::getenv("LWHIP_MAP_HOST_J");
-            st->jMapped = !(mj && mj[0] == '0') && !resident_J() && lwhip_map_host_J(st->hip, 1) == LWHIP_OK;
+            // (hybrid PRD keeps the copies: JRest travels with J and a second run takes both from the host again)
+            st->jMapped = !(mj && mj[0] == '0') && !resident_J() && !st->hprdOn && lwhip_map_host_J(st->hip, 1) == LWHIP_OK;
             st->jSynced = false;
         }
         dirty_mask(st, true); // create uploaded everything: just record the fingerprints
         register_atoms(&ctx);
         return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
+    }
+    // (spect.J's own fingerprint first, with the whole pool: once the pool works on the 90 MB of the slow groups a second
+    // round would be hashed by this thread alone, ten times slower)
+    st->fpJHostFresh = false;
+    if (st->jSynced && !force && !st->jDeviceAhead && !resident_J())
+    {
+        st->fpJHost = host_J_fingerprint(st);
+        st->fpJHostFresh = true;
     }
     if (later)
     {
@@ -903,8 +916,10 @@ uint32_t j_policy_upload(PluginState* st, uint32_t up, bool force = false)
             fail("lwhip_map_host_J");
         st->jMapped = false;
     }
-    if ((up & LWHIP_J) && st->jSynced && !force && !st->jDeviceAhead && host_J_fingerprint(st) == st->fpJ)
+    if ((up & LWHIP_J) && st->jSynced && !force && !st->jDeviceAhead
+        && (st->fpJHostFresh ? st->fpJHost : host_J_fingerprint(st)) == st->fpJ)
         up &= ~(uint32_t)LWHIP_J; // nobody has rewritten spect.J since the device produced it: the device's copy is the same
+    st->fpJHostFresh = false;
     if (st->jDeviceAhead)
     {
         if (!resident_J())
@@ -977,14 +992,14 @@ IterationResult fs_iter_hip(Context& ctx, bool lambdaIterate, ExtraParams params
     lwhip_iter_result r{};
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        // (the second attempt: the first run's J is in spect.J already when the array is mapped -- the J this call started
-        // from comes back from the device's snapshot, not from the host)
-        const bool restoreJ = attempt == 1 && st->jMapped;
+        // (the second attempt: the first run has overwritten the device's J -- and spect.J itself when the array is mapped --,
+        // so the J this call started from comes back from the device's snapshot, not from the host)
+        const bool restoreJ = attempt == 1 && !st->hprdOn;
         if (restoreJ && lwhip_j_restore(st->hip) != LWHIP_OK)
             fail("lwhip_j_restore");
-        if (lwhip_upload(st->hip, restoreJ ? (up & ~(uint32_t)LWHIP_J) : j_policy_upload(st, up, force)) != LWHIP_OK)
+        if (lwhip_upload(st->hip, restoreJ ? (up & ~(uint32_t)LWHIP_J) : j_policy_upload(st, up, force || attempt == 1)) != LWHIP_OK)
             fail("lwhip_upload");
-        if (attempt == 0 && prints.active && st->jMapped && lwhip_j_snapshot(st->hip) != LWHIP_OK)
+        if (attempt == 0 && prints.active && !st->hprdOn && lwhip_j_snapshot(st->hip) != LWHIP_OK)
             fail("lwhip_j_snapshot");
         lap("upload", tPrev);
         if (lwhip_formal_sol_gamma_matrices(st->hip, lambdaIterate ? 1 : 0, &r) != LWHIP_OK)
@@ -1206,13 +1221,13 @@ IterationResult redistribute_prd_hip(Context& ctx, int maxIter, f64 tol, ExtraPa
     lwhip_prd_result r{ 0, 0, dRho.data(), dRhoIdx.data(), dJ.data(), dJIdx.data() };
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        const bool restoreJ = attempt == 1 && st->jMapped; // (as in fs_iter: the rates passes have rewritten spect.J)
+        const bool restoreJ = attempt == 1 && !st->hprdOn; // (as in fs_iter: the first run has rewritten the device's J -- and spect.J, if mapped)
         if (restoreJ && lwhip_j_restore(st->hip) != LWHIP_OK)
             fail("lwhip_j_restore");
         const uint32_t want = (up & ~(uint32_t)LWHIP_GAMMA) | LWHIP_RATES;
-        if (lwhip_upload(st->hip, restoreJ ? (want & ~(uint32_t)LWHIP_J) : j_policy_upload(st, want, force)) != LWHIP_OK)
+        if (lwhip_upload(st->hip, restoreJ ? (want & ~(uint32_t)LWHIP_J) : j_policy_upload(st, want, force || attempt == 1)) != LWHIP_OK)
             fail("lwhip_upload");
-        if (attempt == 0 && prints.active && st->jMapped && lwhip_j_snapshot(st->hip) != LWHIP_OK)
+        if (attempt == 0 && prints.active && !st->hprdOn && lwhip_j_snapshot(st->hip) != LWHIP_OK)
             fail("lwhip_j_snapshot");
         if (lwhip_redistribute_prd(st->hip, maxIter, tol, &r) != LWHIP_OK)
             fail("lwhip_redistribute_prd");
