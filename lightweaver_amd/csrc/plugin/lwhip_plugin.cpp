@@ -91,7 +91,9 @@ public:
     {
         owner = (long)getpid();
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned n = std::min(15u, hw > 2 ? hw / 2 - 1 : 0u); // (+ the calling thread)
+        // (round 6: up to 31 -- with J no longer crossing PCIe the fingerprints of the 90 MB are what a call waits for, and
+        // one thread streams ~20 GB/s of the host's memory bandwidth)
+        const unsigned n = std::min(31u, hw > 2 ? hw / 2 - 1 : 0u); // (+ the calling thread)
         for (unsigned t = 0; t < n; ++t)
         {
             threads.emplace_back([this] { loop(); });
@@ -218,12 +220,18 @@ struct HashSet
     }
     std::vector<Block> blocks;
     std::atomic<size_t> next{ 0 };
+    // the FIRST job's blocks are the first of the list: a caller that needs that one fingerprint before the rest (spect.J, on
+    // which the upload decision of a call hangs) takes part in them and waits only for them (wait_first)
+    size_t nFirst = 0;
+    std::atomic<size_t> doneFirst{ 0 };
     std::function<void()> worker;
     bool inFlight = false;
     size_t prepare()
     {
         blocks.clear();
         next = 0;
+        doneFirst = 0;
+        nFirst = jobs.empty() ? 0 : (jobs[0].n + BLOCK - 1) / BLOCK;
         size_t total = 0;
         for (size_t j = 0; j < jobs.size(); ++j)
             for (size_t off = 0; off < jobs[j].n; off += BLOCK)
@@ -233,10 +241,34 @@ struct HashSet
             }
         return total;
     }
+    void one(size_t b)
+    {
+        blocks[b].h = block_hash(jobs[blocks[b].job].p + blocks[b].off, blocks[b].len, blocks[b].off);
+        if (b < nFirst)
+            doneFirst.fetch_add(1, std::memory_order_release);
+    }
     void work()
     {
         for (size_t b = next.fetch_add(1); b < blocks.size(); b = next.fetch_add(1))
-            blocks[b].h = block_hash(jobs[blocks[b].job].p + blocks[b].off, blocks[b].len, blocks[b].off);
+            one(b);
+    }
+    // fingerprint of the first job as soon as ITS blocks are through (between start() and finish())
+    uint64_t wait_first()
+    {
+        for (;;)
+        {
+            size_t b = next.load();
+            if (b >= nFirst)
+                break;
+            if (next.compare_exchange_weak(b, b + 1))
+                one(b);
+        }
+        while (doneFirst.load(std::memory_order_acquire) < nFirst)
+            __builtin_ia32_pause();
+        uint64_t h = mix((uint64_t)(uintptr_t)jobs[0].p, jobs[0].n);
+        for (size_t b = 0; b < nFirst; ++b)
+            h = mix(h, blocks[b].h);
+        return h;
     }
     void fold()
     {
@@ -676,17 +708,19 @@ struct Prints
 {
     HashSet hs;
     std::vector<int> jProf, jNstar, jColl, jBg, jAt;
+    int jJ = -1;                   // spect.J's own job (first in the list), or -1
     uint32_t groups = kSlowGroups; // the groups looked at: a population update reads only two small ones and leaves the large
                                    // ones (profiles, background: 0.4 ms to read) to the next formal solution, unrecorded
     bool active = false;
 };
 
-void prints_begin(PluginState* st, Prints& pr, uint32_t groups = kSlowGroups)
+void prints_begin(PluginState* st, Prints& pr, uint32_t groups = kSlowGroups, bool withJ = false)
 {
     pr.groups = groups;
     const lwhip_problem& p = st->prob;
     const size_t Ns = p.Nspace, Nla = p.Nlambda, Nr = p.Nrays;
     HashSet& hs = pr.hs;
+    pr.jJ = withJ ? hs.add(p.J, Nla * Ns) : -1; // (the first job: HashSet::wait_first)
     const char* smp = std::getenv("LWHIP_SAMPLED_FINGERPRINTS");
     const bool sampled = smp && smp[0] == '1';
     for (int ia = 0; ia < p.Natom; ++ia)
@@ -844,14 +878,17 @@ uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr, uint32_t 
     // (spect.J's own fingerprint first, with the whole pool: once the pool works on the 90 MB of the slow groups a second
     // round would be hashed by this thread alone, ten times slower)
     st->fpJHostFresh = false;
-    if (st->jSynced && !force && !st->jDeviceAhead && !resident_J())
-    {
-        st->fpJHost = host_J_fingerprint(st);
-        st->fpJHostFresh = true;
-    }
+    const bool withJ = st->jSynced && !force && !st->jDeviceAhead && !resident_J() && groups == kSlowGroups;
     if (later)
     {
-        prints_begin(st, *later);
+        // (spect.J's blocks go first in the pool's round and this thread waits for them alone: the upload decision hangs on
+        // that one fingerprint, the 90 MB of the slow groups are read while the uploads and the kernels run)
+        prints_begin(st, *later, kSlowGroups, withJ);
+        if (withJ)
+        {
+            st->fpJHost = later->hs.wait_first();
+            st->fpJHostFresh = true;
+        }
         return LWHIP_GAMMA | LWHIP_J | LWHIP_POPS | LWHIP_BC | LWHIP_RHOPRD;
     }
     return dirty_mask(st, force, force ? kSlowGroups : groups);

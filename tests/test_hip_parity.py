@@ -391,10 +391,11 @@ def test_J_stored_into_the_callers_array_and_fingerprinted_on_the_device(gpu, Ns
         ctx.download(abi.ALL_OUTPUTS)
         first = p.J.copy()
         ctx.redistribute_prd(2, 0.0)
-        assert np.array_equal(p.J, q.J) and not np.array_equal(first, p.J)
+        # (rho of a sub-iteration comes from atomically summed rates: J of its rates pass agrees to the last bits only)
+        assert rel_err(p.J, q.J) <= 1e-10 and not np.array_equal(first, p.J)
         for a, b in zip(p.atoms, q.atoms):
             for ta, tb in zip(a.trans, b.trans):
-                assert np.array_equal(ta.Rij, tb.Rij)
+                assert rel_err(ta.Rij, tb.Rij) <= 1e-9
         # fingerprints: device == host for what the device produced
         assert ctx.fingerprint_J() == host_fingerprint(p.J)
         other = p.J.copy()
