@@ -532,6 +532,12 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
             Defer() { ++devbuf_defer_fill_sync(); }
             ~Defer() { --devbuf_defer_fill_sync(); }
         } defer;
+        struct Skip
+        {
+            const bool on;
+            explicit Skip(bool o) : on(o) { devbuf_skip_safety_clear() += on ? 1 : 0; }
+            ~Skip() { devbuf_skip_safety_clear() -= on ? 1 : 0; }
+        } skip(c->tablesFrom != nullptr);
         st = alloc_state(c);
         if (hipStreamSynchronize(nullptr) != hipSuccess && st == LWHIP_OK)
             st = fail(LWHIP_ERR_DEVICE, "lwhip_create: clearing the state allocations failed");

@@ -54,6 +54,16 @@ inline int& devbuf_defer_fill_sync()
     return depth;
 }
 
+// > 0: alloc(count) leaves out its safety-net clearing (alloc_zero still clears): the state buffers of a context made with
+// lwhip_create_like -- a column of a 1.5D batch: ~40 fills of a few KB each per column, a driver call apiece.  Every byte a
+// kernel reads of such a buffer is written first by an upload or a kernel (tests/test_padding.py runs the column batches under
+// the finite sentinel fills); the owner of the tables, and every ordinary context, keeps the net.
+inline int& devbuf_skip_safety_clear()
+{
+    static thread_local int depth = 0;
+    return depth;
+}
+
 template <typename T> struct DevBuf
 {
     T* p = nullptr;
@@ -143,7 +153,7 @@ template <typename T> struct DevBuf
                 e = hipMemsetD32((hipDeviceptr_t)p, std::atoi(std::getenv("LWHIP_PAD_SENTINEL_INT")), count * sizeof(T) / 4);
             what = " int-sentinel";
         }
-        else if (e == hipSuccess && (init == 2 || (init == 1 && !noClear)))
+        else if (e == hipSuccess && (init == 2 || (init == 1 && !noClear && devbuf_skip_safety_clear() == 0)))
         {
             e = hipMemset(p, 0, count * sizeof(T));
             what = " cleared";

@@ -652,11 +652,14 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
     std::vector<double> ratioHost;
     if (mask & LWHIP_NSTAR)
         ratioHost.assign((size_t)std::max(c->Ncont, 1) * Ns, 1.0);
-    // staging layout (doubles): [n pool][Gamma pool][C pool][Rij][Rji]
+    // staging layout (doubles): [n pool][Gamma pool][C pool][Rij][Rji][nTotal][vBroad][aDamp][Qelast]
+    // (round 6: the per-atom / per-line rows of the LWHIP_NSTAR group and C ride in it too -- a column of a 1.5D batch made
+    // ~40 pageable 656-byte copies for them at creation, each a driver call)
     const size_t nPool = (size_t)c->NlevTot * Ns, gPool = (size_t)c->gammaTot, rPool = (size_t)c->Ntrans * Ns;
+    const size_t aPool = (size_t)std::max(c->Natom, 1) * Ns, lPool = (size_t)std::max(c->Nline, 1) * Ns;
     if (!c->stage)
     {
-        c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 8;
+        c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 2 * aPool + 2 * lPool + 8;
         HIP_TRY(hipHostMalloc((void**)&c->stage, c->stageDoubles * sizeof(double), hipHostMallocDefault));
     }
     double* stN = c->stage;
@@ -664,7 +667,28 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
     double* stC = stG + gPool;
     double* stRij = stC + gPool;
     double* stRji = stRij + rPool;
+    double* stNT = stRji + rPool;
+    double* stVB = stNT + aPool;
+    double* stAD = stVB + aPool;
+    double* stQE = stAD + lPool;
     bool anyR = false;
+    // (a pool goes up as one copy when every row of it is given; otherwise row by row as before)
+    bool allC = (mask & LWHIP_COLLISIONS) != 0, allAD = (mask & LWHIP_NSTAR) != 0, allQE = (mask & LWHIP_NSTAR) != 0;
+    for (int ia = 0; ia < c->Natom; ++ia)
+    {
+        allC = allC && (c->atoms[ia].detailed || c->atoms[ia].C != nullptr);
+        for (int kr = 0; kr < c->atoms[ia].Ntrans; ++kr)
+        {
+            const lwhip_transition& t = c->trans[c->atomTrOff[ia] + kr].t;
+            if (t.type == LWHIP_LINE)
+            {
+                allAD = allAD && t.aDamp != nullptr;
+                allQE = allQE && t.Qelast != nullptr;
+            }
+        }
+    }
+    if (allC)
+        std::memset(stC, 0, gPool * sizeof(double));
     for (int ia = 0; ia < c->Natom; ++ia)
     {
         const lwhip_atom& a = c->atoms[ia];
@@ -672,15 +696,17 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
             std::memcpy(stN + (size_t)c->levelOff[ia] * Ns, a.n, (size_t)a.Nlevel * Ns * sizeof(double));
         if (mask & LWHIP_NSTAR)
         {
-            H2D(c->nTotal.p + (size_t)ia * Ns, a.nTotal, Ns);
-            H2D(c->vBroad.p + (size_t)ia * Ns, a.vBroad, Ns);
+            std::memcpy(stNT + (size_t)ia * Ns, a.nTotal, Ns * sizeof(double));
+            std::memcpy(stVB + (size_t)ia * Ns, a.vBroad, Ns * sizeof(double));
         }
         if (!a.detailed && (mask & LWHIP_GAMMA))
             std::memcpy(stG + c->gammaOff[ia], a.Gamma, (size_t)a.Nlevel * a.Nlevel * Ns * sizeof(double));
         if (!a.detailed && (mask & LWHIP_COLLISIONS) && a.C)
         {
-            // atoms without C keep whatever the pool holds: copy atom by atom, not the whole pool
-            H2D(c->Cmat.p + c->gammaOff[ia], a.C, (size_t)a.Nlevel * a.Nlevel * Ns);
+            if (allC)
+                std::memcpy(stC + c->gammaOff[ia], a.C, (size_t)a.Nlevel * a.Nlevel * Ns * sizeof(double));
+            else // atoms without C keep whatever the pool holds: copy atom by atom, not the whole pool
+                H2D(c->Cmat.p + c->gammaOff[ia], a.C, (size_t)a.Nlevel * a.Nlevel * Ns);
         }
         for (int kr = 0; kr < a.Ntrans; ++kr)
         {
@@ -709,9 +735,19 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
                     H2D(c->wphi.p + (size_t)h.row * Ns, t.wphi, Ns);
                 }
                 if ((mask & LWHIP_NSTAR) && t.aDamp)
-                    H2D(c->aDamp.p + (size_t)h.row * Ns, t.aDamp, Ns);
+                {
+                    if (allAD)
+                        std::memcpy(stAD + (size_t)h.row * Ns, t.aDamp, Ns * sizeof(double));
+                    else
+                        H2D(c->aDamp.p + (size_t)h.row * Ns, t.aDamp, Ns);
+                }
                 if ((mask & LWHIP_NSTAR) && t.Qelast)
-                    H2D(c->Qelast.p + (size_t)h.row * Ns, t.Qelast, Ns);
+                {
+                    if (allQE)
+                        std::memcpy(stQE + (size_t)h.row * Ns, t.Qelast, Ns * sizeof(double));
+                    else
+                        H2D(c->Qelast.p + (size_t)h.row * Ns, t.Qelast, Ns);
+                }
                 if ((mask & LWHIP_RHOPRD) && t.prd && h.rhoOff >= 0 && h.rhoRows > 0)
                     H2D(c->rho.p + h.rhoOff, t.rhoPrd + (size_t)h.rhoLt0 * Ns, (size_t)h.rhoRows * Ns);
             }
@@ -725,6 +761,17 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
             }
         }
     }
+    if ((mask & LWHIP_NSTAR) && c->Natom > 0)
+    {
+        H2D(c->nTotal.p, stNT, (size_t)c->Natom * Ns);
+        H2D(c->vBroad.p, stVB, (size_t)c->Natom * Ns);
+        if (allAD && c->Nline > 0)
+            H2D(c->aDamp.p, stAD, (size_t)c->Nline * Ns);
+        if (allQE && c->Nline > 0)
+            H2D(c->Qelast.p, stQE, (size_t)c->Nline * Ns);
+    }
+    if (allC && gPool)
+        H2D(c->Cmat.p, stC, gPool);
     if ((mask & LWHIP_POPS) && nPool)
         H2D(c->n.p, stN, nPool);
     if ((mask & LWHIP_GAMMA) && gPool)
@@ -810,7 +857,8 @@ static int download_impl(lwhip_context* c, uint32_t mask)
     const size_t nPool = (size_t)c->NlevTot * Ns, gPool = (size_t)c->gammaTot, rPool = (size_t)c->Ntrans * Ns;
     if (!c->stage)
     {
-        c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 8;
+        // (the same size as lwhip_upload's layout: whoever comes first allocates)
+        c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 2 * (size_t)std::max(c->Natom, 1) * Ns + 2 * (size_t)std::max(c->Nline, 1) * Ns + 8;
         HIP_TRY(hipHostMalloc((void**)&c->stage, c->stageDoubles * sizeof(double), hipHostMallocDefault));
     }
     double* stN = c->stage;

@@ -180,15 +180,19 @@ def test_512_column_fused_batch_sample_vs_oracle(gpu):
             for ta, tb in zip(a.trans, b.trans):
                 if ta.type == abi.LINE:
                     assert rel_err(ta.phi, tb.phi) <= 1e-9       # the device's Voigt profiles vs the harness's
+                    # (round 6: the oracle iterates on the DEVICE's profiles, so what is held to the one-call bound below is
+                    # the iteration itself -- two of them -- and not the 1e-9 between two Voigt evaluations carried through it)
+                    tb.phi[...] = ta.phi
+                    tb.wphi[...] = ta.wphi
         oc = OracleContext(q)
         for it in range(2):
             q.gamma_prefill()
             dJ, _ = oc.formal_sol_gamma_matrices(Nthreads=THREADS)
-        assert ups[c].dJMax == pytest.approx(dJ, rel=1e-7)
-        assert_iteration_matches(probs[c], q, tol=1e-8, tolGamma=1e-8)
+        assert ups[c].dJMax == pytest.approx(dJ, rel=1e-9)
+        assert_iteration_matches(probs[c], q, tol=1e-9, tolGamma=1e-9)
         assert oc.stat_equil() == 0
         for a, b in zip(probs[c].atoms, q.atoms):
-            assert rel_err(a.n, b.n) <= 1e-7
+            assert rel_err(a.n, b.n) <= 1e-8
 
 
 def test_2d_256x82_iteration_vs_oracle(gpu):
