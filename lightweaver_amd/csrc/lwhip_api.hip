@@ -25,9 +25,9 @@ int fail(int code, const std::string& msg)
 namespace
 {
 // ---- the contexts' host blocks (lwhip_host.h: hostBlock) ---------------------------------------------------------------
-// layout (bytes): [0,32) tail (dJMax, idx, ticket, -) | [32] status | [40] zeroCheck | [48] popStatus | [64,80) prdCtl
+// layout (bytes): [0,32) tail (dJMax, idx, ticket, -) | [32] status | [40] zeroCheck | [48] popStatus | [56] turnLate | [64,80) prdCtl
 // | [96,104) canary | [128, ...) change records
-constexpr size_t HB_TAIL = 0, HB_STATUS = 32, HB_ZERO = 40, HB_POPSTATUS = 48, HB_PRDCTL = 64, HB_CANARY = 96, HB_CHANGE = 128;
+constexpr size_t HB_TAIL = 0, HB_STATUS = 32, HB_ZERO = 40, HB_POPSTATUS = 48, HB_TURNLATE = 56, HB_PRDCTL = 64, HB_CANARY = 96, HB_CHANGE = 128;
 constexpr uint64_t HB_CANARY_WORD = 0x6c77686970424c4bull; // "lwhipBLK"
 constexpr unsigned char HB_DEAD = 0xC5;
 struct Quarantine
@@ -135,6 +135,8 @@ int host_block_init(lwhip_context* c)
         c->zeroCheckDev = (int*)(dev + HB_ZERO);
     }
     c->popStatusHost = (int32_t*)(c->hostBlock + HB_POPSTATUS);
+    c->turnLateHost = (int32_t*)(c->hostBlock + HB_TURNLATE);
+    c->turnLateDev = (int32_t*)(dev + HB_TURNLATE);
     c->prdCtlHost = (int32_t*)(c->hostBlock + HB_PRDCTL);
     c->changeHost = (double*)(c->hostBlock + HB_CHANGE);
     c->changeDev = (double*)(dev + HB_CHANGE);
@@ -162,7 +164,7 @@ void host_block_release(lwhip_context* c)
         (void)hipHostFree(c->hostBlock);
     c->hostBlock = nullptr;
     c->tailMapped = c->tailMappedDev = c->changeHost = c->changeDev = nullptr;
-    c->statusHost = c->statusDev = c->popStatusHost = c->prdCtlHost = nullptr;
+    c->statusHost = c->statusDev = c->popStatusHost = c->prdCtlHost = c->turnLateHost = c->turnLateDev = nullptr;
     c->zeroCheck = c->zeroCheckDev = nullptr;
 }
 }
@@ -859,6 +861,14 @@ int lwhip_fs_finalise(lwhip_context* c, lwhip_iter_result* res)
         res->updatedJ = 1;
         res->dJMax = c->tailMapped[0];
         res->dJMaxIdx = (int32_t)c->tailMapped[1];
+        if (c->deterministic && c->turnLateHost && *(volatile int32_t*)c->turnLateHost != 0)
+        {
+            // (the apply launch that published the result ran after the sweep: the count is final)
+            const int late = *(volatile int32_t*)c->turnLateHost;
+            *(volatile int32_t*)c->turnLateHost = 0;
+            return fail(LWHIP_ERR_DEVICE, "fixed-order mode: " + std::to_string(late) + " turn wait(s) of the sweep timed out -- the sums of this "
+                                          "iteration were formed out of order (results are valid to rounding, not bit-reproducible)");
+        }
         if (c->peerOn && c->tailMapped[3] != 0.0)
         {
             c->tailMapped[3] = 0.0;

@@ -527,6 +527,8 @@ struct lwhip_context
     const void* fpJPtr = nullptr;
     unsigned char* hostBlock = nullptr;
     size_t hostBlockBytes = 0;
+    int32_t* turnLateHost = nullptr;  // fixed-order mode: turn waits that timed out (device-written, TileArgs::turnLate)
+    int32_t* turnLateDev = nullptr;
     int32_t* popStatusHost = nullptr; // device-to-host target of the status word of time_dep_update / nr_post_update
     int32_t* prdCtlHost = nullptr;    // ... of the stopping-rule words of the pipelined PRD sub-iterations
 

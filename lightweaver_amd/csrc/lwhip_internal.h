@@ -328,6 +328,7 @@ struct TileArgs
     const uint8_t* laneFeedG;      // generic tiles: [gen][LWHIP_POST_MAXC][LWHIP_GEN_MAXS] which rows of slot e continuum q feeds (DevLaneFin::feed's byte)
     double* momS;                  // generic tiles: the moment scratch, [workgroup of the launch][wavefront][momA][laneD][64] (null: no generic tile)
     int32_t momA, _padM;           // arrays per wavefront: the most any generic tile needs (4 (nL - 1) + nL (nL - 1) / 2 moments + 4 nL coefficients)
+    int32_t* turnLate;             // fixed-order mode: host-mapped count of turn waits that timed out (lwhip_lanesweep.hip: ls_turn_wait)
     double* detSlab;               // deterministic mode: [workgroup][maxCT][4][Ns] partial sums (no atomics), else null
     double* lsDbg;                 // diagnostic builds (-DLS_TIMING): [nTiles][8] phase clocks, host-mapped; else null
 };

@@ -230,6 +230,13 @@ struct LaneCtx
 // wavefronts walk the shared continua in the same (transition) order, so they follow each other through the slots like a
 // pipeline.  The sums are then formed in ONE order, whatever the timing: bit-reproducible, with four wavefronts per
 // workgroup (round 3's fixed-order mode ran one, at a quarter of the occupancy: 2.7 x the default's time).
+// turn waits of this workgroup that gave up (see ls_turn_wait): the workgroup adds the count to TileArgs::turnLate when it ends,
+// and the host turns a non-zero total into an error instead of silently unordered sums
+DEVINL int* ls_late_counter()
+{
+    __shared__ int late;
+    return &late;
+}
 template <int D> DEVINL void ls_turn_wait(int* sTurn, const int cs, const int p0, const int np, const int turn, double* dbgClocks = nullptr)
 {
     if (!sTurn)
@@ -244,18 +251,24 @@ template <int D> DEVINL void ls_turn_wait(int* sTurn, const int cs, const int p0
     // (an LDS pointer, not a generic one: volatile loads through a generic pointer are flat_load ... sc0 sc1 with a wait for
     // ALL of the wavefront's global memory traffic behind each -- measured: 21 k clocks per hand-over instead of ~1 k)
     volatile __attribute__((address_space(3))) int* t = (volatile __attribute__((address_space(3))) int*)(sTurn + cs * D + p0);
+    bool seen = false;
     for (int spin = 0; spin < (1 << 20); ++spin)
     {
         int lo = 0x7fffffff;
         for (int p = 0; p < np; ++p)
             lo = min(lo, t[p]);
         if (__builtin_amdgcn_readfirstlane(lo) >= turn)
+        {
+            seen = true;
             break;
+        }
 #ifndef LS_TURN_SLEEP
 #define LS_TURN_SLEEP 1
 #endif
         __builtin_amdgcn_s_sleep(LS_TURN_SLEEP);
     }
+    if (!seen && (threadIdx.x & 63) == 0) // (the wait timed out: the add goes ahead out of turn -- counted, reported by the host)
+        __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)ls_late_counter(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
 #ifdef LS_TIMING
     if (dbgClocks && (threadIdx.x & 63) == 0)
@@ -3223,8 +3236,12 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
     constexpr bool HPRD_K = (MODE & 2) != 0;
     int* sTurn = (RATES && !HPRD_K && a.detSlab && nWaves > 1) ? (int*)((char*)sDep + a.depBytes) : nullptr;
     if (sTurn)
+    {
         for (int idx = t; idx < maxCT * D; idx += blockDim.x)
             sTurn[idx] = 0;
+        if (t == 0)
+            *ls_late_counter() = 0;
+    }
 #ifdef LS_TIMING
     if (t == 0 && a.lsDbg && !BATCH)
         a.lsDbg[(size_t)a.nTiles * 8 + (size_t)blockIdx.x * 4 + 3] = 0.0;
@@ -3307,6 +3324,12 @@ __global__ void __launch_bounds__(LS_MAX_WAVES * 64) __attribute__((amdgpu_waves
                 }
             }
         }
+    }
+    if (sTurn && t == 0 && a.turnLate)
+    {
+        const int late = *ls_late_counter();
+        if (late)
+            atomicAdd_system(a.turnLate, late);
     }
 #ifdef LS_TIMING
     if (t == 0 && a.lsDbg && !BATCH)

@@ -324,6 +324,7 @@ int build_tile_args(lwhip_context* c)
         a.hJCoef = c->hJCoef.p;
         a.JRest = c->JRest.p;
         a.detSlab = c->deterministic ? c->detSlab.p : nullptr;
+        a.turnLate = c->deterministic ? c->turnLateDev : nullptr;
         a.laneWg = c->laneWg.p;
         a.laneTiles = c->laneTiles.p;
         a.laneRays = c->laneRays.p;

@@ -299,6 +299,43 @@ def test_sweep_variants_forced_on_small_problem(gpu, monkeypatch, env):
     compare_to_golden(p, d, 'iter1')
 
 
+def test_peer_exchange_with_fixed_order_sums_is_bit_reproducible(gpu):
+    """Sharded Gamma / rates are the same BITS from run to run when the sums inside a shard are formed in a fixed order
+    (LWHIP_OPT_DETERMINISTIC) and the shards meet through the peer exchange (slots added in rank order) -- what a library
+    all-reduce's summation tree does not promise."""
+    from lightweaver_amd.distributed import shard_bounds
+    prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
+    world = 2
+    b = shard_bounds(prob, world)
+    runs = []
+    for rep in range(2):
+        probs = [prob.copy() for _ in range(world)]
+        ctxs = [Context(p, laStart=b[r], laEnd=b[r + 1], worldSize=world, worldRank=r, deterministic=True) for r, p in enumerate(probs)]
+        try:
+            wins = [c.peer_window()[0] for c in ctxs]
+            for c in ctxs:
+                c.peer_attach_pointers(wins)
+            for it in range(2):
+                for c in ctxs:
+                    c.gamma_prefill_from_C(1.0)
+                    c.fs_partial()
+                for c in ctxs:
+                    c.fs_finalise()
+            for c in ctxs:
+                c.download(abi.ALL_OUTPUTS)
+                c.peer_detach()
+        finally:
+            for c in ctxs:
+                c.close()
+        runs.append(probs)
+    for r in range(world):
+        for ia in range(2):
+            assert np.array_equal(runs[0][r].atoms[ia].Gamma, runs[1][r].atoms[ia].Gamma)
+            assert np.array_equal(runs[0][r].atoms[ia].Gamma, runs[0][0].atoms[ia].Gamma)
+            for ta, tb in zip(runs[0][r].atoms[ia].trans, runs[1][r].atoms[ia].trans):
+                assert np.array_equal(ta.Rij, tb.Rij) and np.array_equal(ta.Rji, tb.Rji)
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_wavelength_shards_meet_through_the_peer_exchange(gpu, world):
     """The sharded iteration with NO collective (lwhip_peer_*): `world` contexts of this process own the wavelength shards,
