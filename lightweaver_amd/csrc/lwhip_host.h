@@ -336,6 +336,7 @@ struct lwhip_context
     bool tiled = false;
     int tileL = 12, nTiles = 0, nTileChunks = 0, nTileChunksPrd = 0, nPostChunks = 0, nPostChunksPrd = 0, nTilesPrd = 0;
     bool tileFuse = false; // the sweep's workgroup = one tile, finished by the post-pass inside the sweep launch
+    int depthSplit = 1;    // the march on deep columns: a direction's depth points split over this many wavefronts (lwhip_raymarch.hip)
     // depth-across-lanes sweep (lwhip_lanesweep.hip): D points per lane, LR lanes per ray, R wavelengths per wavefront
     bool laneSweep = false;
     bool chunkOrderOn = false, chunkSplitOn = false;

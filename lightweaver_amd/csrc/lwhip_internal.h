@@ -276,6 +276,8 @@ struct TileArgs
     const double* bgSca;
     double* J;                     // [Nla, Ns]
     double* Jhost;                 // the same rows of the caller's page-locked J array, or null (lwhip_map_host_J): written beside J
+    int32_t depthSplit;            // the march, fused launches of deep columns: wavefronts a direction's depth points are split over (1, 2, 4)
+    int32_t _padDS;
     double* I;                     // [Nla, Nmu]
     double* depthChi;
     double* depthEta;

@@ -306,10 +306,18 @@ template <int NL> struct StepIn
 
 // One task = one tile in one direction.  NL / NM: lines / mixed continua of the tile at compile time, or (GENERIC)
 // their capacities with the counts taken from the tile.
-template <int SOLVER, int NL, int NM, bool RATES, bool GENERIC>
+// SEG (round 6, deep columns: TileArgs::depthSplit): the wavefront marches only the points m in [mA, mB) of the march order
+// (m = 0: the boundary the ray starts from).  A segment that does not start at the boundary gathers from point mA - 3 on --
+// five warm-up iterations after which every carried quantity (slopes, Steffen derivatives, optical depths) derives from real
+// data exactly as in the unsplit march -- and takes the intensity behind point mA - 1 from the caller (Iin).  PASS1 (with
+// RATES = false): nothing is stored; the segment's affine map I(mB - 1) = Eout * I(mA - 1) + Iout is formed instead, so that
+// the caller can hand every later segment its starting intensity before any of them has run its real pass.
+template <int SOLVER, int NL, int NM, bool RATES, bool GENERIC, bool SEG = false, bool PASS1 = false>
 DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const DevTile& td, const int toObs, double* sAcc,
-                       double* win, const int lane)
+                       double* win, const int lane, const int mA = 0, const int mB = 0, const double Iin = 0.0, double* Iout = nullptr,
+                       double* Eout = nullptr)
 {
+    static_assert(!PASS1 || (SEG && !RATES), "the first pass of a segment stores nothing");
     constexpr int NLc = NL > 0 ? NL : 1, NMc = NM > 0 ? NM : 1;
     const int Ns = a.Ns, L = a.L, Nmu = a.Nmu;
     const int nLine = GENERIC ? (int)td.nLine : NL;
@@ -510,6 +518,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     double dS2 = 0.0, dS3 = 0.0;                    // dS/dtau at point t-2, t-3
     double dtL = 1.0, dSL = 0.0;                    // linear end point
     double I = 0.0;
+    bool own = !SEG || mA == 0;                     // SEG: the point being finished belongs to this segment
+    double Etot = 1.0;                              // PASS1: product of the steps' attenuations over the segment
     double vijQ[3][NLc], vjiQ[3][NLc];
 #pragma unroll
     for (int s = 0; s < NLc; ++s)
@@ -718,6 +728,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 const double Cuw = s3 + x_3 * dS3;
                 const double C0 = s2 - x_3 * dS2;
                 I = I * edt + al * s3 + be * s2 + ga * Cuw + de * C0;
+                if (PASS1)
+                    Etot *= edt;
                 Psi = be + de;
             }
             if (PH == PH_N)
@@ -751,6 +763,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 double w0, w1;
                 d_w2(dt2, w0, w1);
                 I = (1.0 - w0) * I + w0 * s2 + w1 * sS2;
+                if (PASS1)
+                    Etot *= 1.0 - w0;
                 Psi = w0 - w1 * rdt2;
             }
         }
@@ -771,6 +785,8 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
                 double cM, cO, cC, edt;
                 d_besser_coeffs(dtauUw, cM, cO, cC, edt);
                 I = I * edt + cM * s3 + cO * s2 + cC * SC;
+                if (PASS1)
+                    Etot *= edt;
                 Psi = cO + cC;
             }
             else if (PH == PH_L)
@@ -787,7 +803,7 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
         }
 
         // ---- F. outputs and rate integrals of point m = t - 2 -----------------------------------------
-        if (DO_RATES)
+        if (DO_RATES && !PASS1 && (!SEG || own))
         {
             const double PsiStar = Psi * r2; // PsiStar :322-323
             if (active)
@@ -952,24 +968,56 @@ DEVINL void march_tile(const CONST_AS TileArgs& a, const TileDyn& dyn, const Dev
     };
 
     StepIn<NL> gA, gB;
-    load_step(0, gA);
-    gB = gA;
-    step(std::integral_constant<int, PH_0>{}, 0, gA, gB);
-    step(std::integral_constant<int, PH_1>{}, 1, gB, gA);
-    step(std::integral_constant<int, PH_2>{}, 2, gA, gB);
     int t = 3;
-    for (; t + 1 < Ns; t += 2) // ping-pong input buffers: no copies in the steady state
+    if (!SEG || mA == 0)
     {
+        load_step(0, gA);
+        gB = gA;
+        step(std::integral_constant<int, PH_0>{}, 0, gA, gB);
+        step(std::integral_constant<int, PH_1>{}, 1, gB, gA);
+        step(std::integral_constant<int, PH_2>{}, 2, gA, gB);
+    }
+    else
+    {
+        t = mA - 3; // (>= 3: segments are at least 64 points long)
+        load_step(t, gB);
+    }
+    const bool lastSeg = !SEG || mB >= Ns;
+    const int tStop = lastSeg ? Ns : mB + 2; // main iterations t < tStop: the one at t finishes point t - 2
+    // the iteration that finishes the segment's first point starts from the intensity behind it
+    auto enter = [&](int tt) {
+        if (SEG && mA > 0 && tt == mA + 2)
+        {
+            own = true;
+            I = PASS1 ? 0.0 : Iin;
+            Etot = 1.0;
+        }
+    };
+    for (; t + 1 < tStop; t += 2) // ping-pong input buffers: no copies in the steady state
+    {
+        enter(t);
         step(std::integral_constant<int, PH_MAIN>{}, t, gB, gA);
+        enter(t + 1);
         step(std::integral_constant<int, PH_MAIN>{}, t + 1, gA, gB);
     }
-    if (t < Ns)
+    if (t < tStop)
     {
+        enter(t);
         step(std::integral_constant<int, PH_MAIN>{}, t, gB, gA);
         gB = gA;
     }
-    step(std::integral_constant<int, PH_N>{}, Ns, gB, gA);
-    step(std::integral_constant<int, PH_L>{}, Ns + 1, gA, gB);
+    if (lastSeg)
+    {
+        step(std::integral_constant<int, PH_N>{}, Ns, gB, gA);
+        step(std::integral_constant<int, PH_L>{}, Ns + 1, gA, gB);
+    }
+    if (SEG)
+    {
+        if (Iout)
+            *Iout = I;
+        if (Eout)
+            *Eout = Etot;
+    }
 }
 
 // ---- post-pass: pure continua from the angle moments, J out, dJ ------------------------------------------------------
@@ -1333,6 +1381,110 @@ __global__ void __launch_bounds__(RM_MAX_WAVES * 64) RM_OCC raymarch_kernel(cons
     }
 }
 
+// The fused launch of a deep column with the depth points of a direction split over S wavefronts (see the comment inside): a
+// kernel of its own, so that the eight further inlined marches do not weigh on the registers of raymarch_kernel.
+template <int SOLVER>
+__global__ void __launch_bounds__(RM_MAX_WAVES * 64) raymarch_split_kernel(const TileArgs* __restrict__ ap, const TileDyn dyn)
+{
+    dbg_poison_lds();
+    extern __shared__ double lds[];
+    const CONST_AS TileArgs& a = *(const CONST_AS TileArgs*)ap;
+    const int Ns = a.Ns;
+    const int maxCT = a.maxCT;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nWaves = blockDim.x >> 6;
+    double* sAcc = lds;
+    double* win = lds + (size_t)maxCT * 4 * Ns + (size_t)wave * RM_WIN_DOUBLES;
+    const int chunk = blockIdx.x;
+    const int t0 = CTAB(int32_t, a.chunkTile)[chunk];
+    for (int idx = t; idx < maxCT * 4 * Ns; idx += blockDim.x)
+        sAcc[idx] = 0.0;
+    __syncthreads();
+    const CONST_AS int32_t* tileList = CTAB(int32_t, a.tileList);
+    // ---- deep columns (round 6, TileArgs::depthSplit = S > 1; fused launches of the compiled kinds): the workgroup is the
+    // 2 S wavefronts of ONE tile, wavefront (segment, direction) marches a quarter (S = 4) of the depth points.  The march is a
+    // chain of ~440 dependent-ish instructions per depth point: a 500-point column is 0.8 ms for ONE wavefront however few
+    // wavelengths there are (the reference benchmark's grid: 484 wavefronts on 1 024 SIMDs).  The recurrence is affine in the
+    // intensity, so the segments can run side by side: segment 0 of a direction does its real pass at once; the others first
+    // walk their points without rates (65 % of a step) to get the segment's map I_out = E I_in + B, everybody meets at ONE
+    // barrier, every later segment composes its starting intensity from segment 0's result and the maps in front of it and
+    // does its real pass.  Critical path 2 T / S instead of T.  Same arithmetic per point as the unsplit march (the warm-up
+    // reproduces the carried state exactly); the intensity entering a segment is formed through the composed map, i.e. in
+    // another order of roundings (1e-16).
+    {
+        {
+            const int S = a.depthSplit;
+            const int toObs = wave & 1, seg = wave >> 1;
+            const int ti = tileList ? tileList[t0] : t0;
+            const DevTile td = ld_c(CTAB(DevTile, a.tiles) + ti);
+            const int mLen = (((Ns + S - 1) / S) + 7) & ~7;
+            const int mA = seg * mLen, mB = min(Ns, mA + mLen);
+            double* xch = lds + (size_t)maxCT * 4 * Ns + (size_t)nWaves * RM_WIN_DOUBLES; // [direction][segment][E | B][64]
+            double* mine = xch + (size_t)((toObs * S + seg) * 2) * 64;
+            auto run = [&](auto pass1Tag, const double Iin, double* Io, double* Eo) {
+                constexpr bool P1 = decltype(pass1Tag)::value;
+                if (td.nLine == 0)
+                    march_tile<SOLVER, 0, 0, !P1, false, true, P1>(a, dyn, td, toObs, sAcc, win, lane, mA, mB, Iin, Io, Eo);
+                else if (td.nLine == 1 && td.nMixed == 0)
+                    march_tile<SOLVER, 1, 0, !P1, false, true, P1>(a, dyn, td, toObs, sAcc, win, lane, mA, mB, Iin, Io, Eo);
+                else if (td.nLine == 1)
+                    march_tile<SOLVER, 1, 1, !P1, false, true, P1>(a, dyn, td, toObs, sAcc, win, lane, mA, mB, Iin, Io, Eo);
+                else
+                    march_tile<SOLVER, 2, 0, !P1, false, true, P1>(a, dyn, td, toObs, sAcc, win, lane, mA, mB, Iin, Io, Eo);
+            };
+            // phase 0: segment 0 runs its real pass, the others their first pass; phase 1: the others' real pass (ONE call site of
+            // the real march: it is inlined once per tile kind)
+#pragma unroll 1
+            for (int phase = 0; phase < 2; ++phase)
+            {
+                if (phase == 0 && seg > 0 && mA < mB && mB < Ns)
+                {
+                    double Io = 0.0, Eo = 1.0;
+                    run(std::true_type{}, 0.0, &Io, &Eo);
+                    mine[lane] = Eo;
+                    mine[64 + lane] = Io;
+                }
+                if ((phase == 0) == (seg == 0) && mA < mB)
+                {
+                    double Iin = 0.0;
+                    if (seg > 0)
+                    {
+                        Iin = xch[(size_t)((toObs * S) * 2 + 1) * 64 + lane]; // what segment 0 ends with
+                        for (int q = 1; q < seg; ++q)
+                            Iin = fma(xch[(size_t)((toObs * S + q) * 2) * 64 + lane], Iin, xch[(size_t)((toObs * S + q) * 2 + 1) * 64 + lane]);
+                    }
+                    double Io = 0.0, Eo = 1.0;
+                    run(std::false_type{}, Iin, &Io, &Eo);
+                    if (seg == 0)
+                        mine[64 + lane] = Io;
+                }
+                if (phase == 0)
+                    __syncthreads();
+            }
+            __syncthreads(); // every segment's moment stores have left the wavefronts
+            unsigned long long* sDj = (unsigned long long*)(lds + (size_t)maxCT * 4 * Ns);
+            if (S == 2)
+                post_tile<256>(ap, td, !dyn.prdOnly, ti % LWHIP_REDUCE_SPLIT, (double*)(sDj + 16), sDj, t);
+            else
+                post_tile<512>(ap, td, !dyn.prdOnly, ti % LWHIP_REDUCE_SPLIT, (double*)(sDj + 16), sDj, t);
+            __syncthreads();
+            const CONST_AS int32_t* slotTr = CTAB(int32_t, a.slotTr) + (size_t)chunk * maxCT;
+            GLOBAL_AS double* r8 = GD(a.red8);
+            const int n4 = 4 * Ns;
+            const int part = chunk % LWHIP_REDUCE_SPLIT;
+            for (int idx = t; idx < maxCT * n4; idx += blockDim.x)
+            {
+                const int cs = idx / n4;
+                const int tr = slotTr[cs];
+                if (tr >= 0)
+                    unsafeAtomicAdd((double*)(r8 + ((size_t)tr * LWHIP_REDUCE_SPLIT + part) * n4 + (idx - cs * n4)), sAcc[idx]);
+            }
+        }
+    }
+}
+
 // ---- profiles into the tile layout ------------------------------------------------------------------------------------
 // grid (tile, line slot); phiT[phiOff + (dir * Ns + k) * 64 + mu * L + j] = phi[lt0 + j][mu][dir][k]
 // (blockIdx.z: the column of a batch, its arguments read from the list)
@@ -1387,8 +1539,10 @@ size_t raymarch_lds_bytes(const TileArgs& a, int waves, bool fuse)
 {
     // accumulators + the waves' moment windows; the fused post-pass reuses the windows' space for the dJ row and the
     // threads' level columns
-    const size_t win = (size_t)waves * RM_WIN_DOUBLES;
-    const size_t post = fuse ? 16 + (size_t)(a.Natom + 2 * a.NlevTot) * 128 : 0;
+    // (depth-split launches: 2 S wavefronts, the segments' exchange block behind the windows, the post-pass on all 128 S threads)
+    const int S = (fuse && a.depthSplit > 1) ? a.depthSplit : 1;
+    const size_t win = (size_t)waves * RM_WIN_DOUBLES + (S > 1 ? (size_t)2 * S * 2 * 64 : 0);
+    const size_t post = fuse ? 16 + (size_t)(a.Natom + 2 * a.NlevTot) * 128 * S : 0;
     return sizeof(double) * ((size_t)a.maxCT * 4 * a.Ns + std::max(win, post));
 }
 
@@ -1467,8 +1621,28 @@ hipError_t launch_tile_sweep(const TileArgs* devArgs, const TileArgs& a, const T
 {
     if (nChunks <= 0)
         return hipSuccess;
-    if (cap > 8 || waves < 1 || waves > RM_MAX_WAVES || (fuse && (waves != 2 || !rates || dyn.nPass != 2)))
+    const int S = (fuse && a.depthSplit > 1) ? a.depthSplit : 1;
+    if (cap > 8 || waves < 1 || waves > RM_MAX_WAVES || (fuse && (waves != 2 * S || !rates || dyn.nPass != 2)) || (S > 1 && (cap != 0 || apList)))
         return hipErrorInvalidValue;
+    if (S > 1)
+    {
+        const size_t lds = raymarch_lds_bytes(a, waves, true);
+        auto go = [&](auto kernel) -> hipError_t {
+            if (lds > 48 * 1024)
+            {
+                hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess)
+                    return e;
+            }
+            LWHIP_LAUNCH(kernel, dim3(nChunks), dim3(waves * 64), lds, stream, devArgs, dyn);
+            return hipGetLastError();
+        };
+        if (solver == LWHIP_FS_LINEAR_1D)
+            return go(raymarch_split_kernel<LWHIP_FS_LINEAR_1D>);
+        if (solver == LWHIP_FS_BESSER_1D)
+            return go(raymarch_split_kernel<LWHIP_FS_BESSER_1D>);
+        return go(raymarch_split_kernel<LWHIP_FS_BEZIER3_1D>);
+    }
     switch (solver)
     {
         case LWHIP_FS_LINEAR_1D:

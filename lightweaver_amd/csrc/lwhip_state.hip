@@ -300,6 +300,7 @@ int build_tile_args(lwhip_context* c)
     a.red8 = c->red8.p;
     a.dJ = c->dJ.p;
     a.Jhost = c->JhostDev;
+    a.depthSplit = c->depthSplit;
     if (c->laneSweep)
     {
         a.laneD = c->laneD;
@@ -362,6 +363,7 @@ int build_tile_args(lwhip_context* c)
     HIP_TRY(put(c->dtargs, c->htargs, a));
     if (c->nTileChunksPrd > 0)
     {
+        a.depthSplit = 1; // (the PRD rates pass keeps whole columns per wavefront)
         a.tslots = c->tslotsPrd.p;
         a.chunkTile = c->chunkTilePrd.p;
         a.tileList = c->tileListPrd.p;
@@ -453,7 +455,7 @@ hipError_t run_sweep(lwhip_context* c, const TileDyn& dyn, bool rates, hipEvent_
                               c->stream);
     else
         e = launch_tile_sweep(da, ha, td, c->prob.formalSolver, c->tileCap, rates, fuse, tprd ? c->nTileChunksPrd : c->nTileChunks,
-                              c->tileWaves, nullptr, 0, c->stream);
+                              (fuse && ha.depthSplit > 1) ? 2 * ha.depthSplit : c->tileWaves, nullptr, 0, c->stream);
     if (e1)
         (void)hipEventRecord(e1, c->stream);
     if (e == hipSuccess && rates && c->laneSweep && c->deterministic)

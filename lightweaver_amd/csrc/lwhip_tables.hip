@@ -1109,6 +1109,20 @@ int build_tables(lwhip_context* c)
             tgtSweep = c->nTiles;
         if (!c->tileFuse)
             tgtSweep = std::max(1, tgtSweep);
+        // Deep columns on the march (round 6): a wavefront's march is ~1.6 us per depth point whatever the number of wavelengths,
+        // so a launch of few tiles over many depth points -- the reference benchmark's 500-point FAL-C: 242 tiles -- leaves most of
+        // the chip idle for 0.8 ms.  While 2 S wavefronts per tile still fit the chip's two-per-SIMD, a direction's depth points
+        // are split over S wavefronts of the tile's workgroup (lwhip_raymarch.hip: raymarch_kernel, depthSplit).
+        // LWHIP_DEPTH_SPLIT=1|2|4 (LWHIP_DEBUG) forces it.
+        c->depthSplit = 1;
+        if (c->tileFuse && c->tileCap == 0 && c->batchHint <= 1 && !c->deterministic)
+        {
+            const long slots = 2L * 4 * numCU; // wavefronts the chip holds at the march's two per SIMD
+            int S = (Ns >= 256 && 8L * c->nTiles <= slots) ? 4 : (Ns >= 192 && 4L * c->nTiles <= slots) ? 2 : 1;
+            S = dbg_env_int("LWHIP_DEPTH_SPLIT", S);
+            if ((S == 2 || S == 4) && Ns >= 64 * S)
+                c->depthSplit = S;
+        }
         c->laneSplit = 1;
         if (c->laneSweep)
         {

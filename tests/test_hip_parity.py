@@ -166,6 +166,41 @@ def test_ragged_sizes_vs_oracle(gpu, Nspace, Nrays, sweep):
     compare_problems(p, q)
 
 
+@pytest.mark.parametrize('solver', [abi.FS_BEZIER3_1D, abi.FS_LINEAR_1D, abi.FS_BESSER_1D])
+@pytest.mark.parametrize('Nspace,S', [(500, 4), (500, 2), (333, 4), (200, 2), (257, 4)])
+def test_march_with_the_depth_points_split_over_wavefronts_vs_oracle(gpu, monkeypatch, Nspace, S, solver):
+    """Deep columns on the march (round 6): a direction's depth points split over S wavefronts of the tile's workgroup -- each
+    later segment first forms its affine map without rates, takes its starting intensity from the segments in front of it and
+    then runs its real pass.  The reference benchmark's 500-point FAL-C and ragged depth counts (segment lengths are multiples
+    of 8: 333 -> 88 + 88 + 88 + 69; 257 -> 72 x 3 + 41), H + Ca II with 5 mu (tiles with no line, one line, a line and a mixed
+    continuum), all three solvers, against the oracle at the one-call bound; the split and the unsplit march agree to 1e-12; the
+    library picks S = 4 by itself at 500 points."""
+    monkeypatch.setenv('LWHIP_SWEEP', 'march')
+    atmos = models.perturbed(models.resample(models.falc82(), Nspace), seed=3)
+    prob = models.build_problem(atmos, [models.H_6(0.3), models.CaII_6(0.3)], Nrays=5, formalSolver=solver)
+    q = prob.copy()
+    q.gamma_prefill()
+    OracleContext(q).formal_sol_gamma_matrices()
+    runs = {}
+    for split in (S, 1):
+        monkeypatch.setenv('LWHIP_DEPTH_SPLIT', str(split))
+        p = prob.copy()
+        with Context(p) as ctx:
+            assert ctx.sweep_kind() == 'march'
+            p.gamma_prefill()
+            ctx.formal_sol_gamma_matrices()
+        compare_problems(p, q)
+        runs[split] = p
+    compare_problems(runs[S], runs[1], tol=1e-12, what=('J', 'I'))
+    if Nspace == 500 and S == 4:
+        monkeypatch.delenv('LWHIP_DEPTH_SPLIT')
+        p = prob.copy()
+        with Context(p) as ctx:
+            p.gamma_prefill()
+            ctx.formal_sol_gamma_matrices()
+        assert np.array_equal(p.J, runs[4].J)      # the default at this size IS the four-way split
+
+
 @pytest.mark.parametrize('split', [1, 2, 4])
 @pytest.mark.parametrize('prd', [False, True])
 def test_lane_sweep_ray_split_vs_oracle(gpu, monkeypatch, split, prd):

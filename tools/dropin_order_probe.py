@@ -6,7 +6,7 @@ import torch
 import bench
 from lightweaver_amd.harness import models
 class A: pass
-args = A(); args.nlambda = 10240; args.no_cpu_baseline = False; args.columns = 64
+args = A(); args.nlambda = 10240; args.no_cpu_baseline = False; args.columns = 512
 torch.cuda.set_device(0)
 s = torch.cuda.current_stream().cuda_stream
 def dropin(tag):
