@@ -1118,7 +1118,11 @@ int build_tables(lwhip_context* c)
         if (c->tileFuse && c->tileCap == 0 && c->batchHint <= 1 && !c->deterministic)
         {
             const long slots = 2L * 4 * numCU; // wavefronts the chip holds at the march's two per SIMD
-            int S = (Ns >= 256 && 8L * c->nTiles <= slots) ? 4 : (Ns >= 192 && 4L * c->nTiles <= slots) ? 2 : 1;
+            // (measured at 500 points x 2 908 wavelengths, 242 tiles: S = 1 0.804 ms, S = 2 1.088, S = 4 0.652 per sweep -- every
+            // later segment walks its points twice, so the split turns a latency-bound launch (a quarter of the SIMDs busy) into
+            // a throughput-bound one with twice the instructions: a gain only where the unsplit launch leaves most of the chip
+            // idle and four-way; S = 2 is kept for the tests)
+            int S = (Ns >= 256 && 8L * c->nTiles <= slots) ? 4 : 1;
             S = dbg_env_int("LWHIP_DEPTH_SPLIT", S);
             if ((S == 2 || S == 4) && Ns >= 64 * S)
                 c->depthSplit = S;
