@@ -1122,7 +1122,8 @@ int build_tables(lwhip_context* c)
             // later segment walks its points twice, so the split turns a latency-bound launch (a quarter of the SIMDs busy) into
             // a throughput-bound one with twice the instructions: a gain only where the unsplit launch leaves most of the chip
             // idle and four-way; S = 2 is kept for the tests)
-            int S = (Ns >= 256 && 8L * c->nTiles <= slots) ? 4 : 1;
+            // (the reference benchmark's grid is 281 tiles = 2 248 wavefronts four-way: 1.10 x the slots, 0.65 against 0.80 ms per sweep)
+            int S = (Ns >= 256 && 8L * c->nTiles <= slots * 3 / 2) ? 4 : 1;
             S = dbg_env_int("LWHIP_DEPTH_SPLIT", S);
             if ((S == 2 || S == 4) && Ns >= 64 * S)
                 c->depthSplit = S;
