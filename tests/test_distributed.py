@@ -399,3 +399,75 @@ def test_two_process_gloo_prd_on_one_gpu(gpu, tmp_path, hybrid):
             else:                        # the shard's rows
                 lo, hi = max(la0 - t.Nblue, 0), max(min(la1, t.Nred) - t.Nblue, 0)
                 assert rel_err(z[f'rho{q}'][lo:hi], t.rhoPrd[lo:hi]) <= 1e-9
+
+
+# ---- the transport handshake of ShardedIteration (round 6) on CPU -----------------------------------------------------------
+class _FakePeerCtx:
+    """The surface _attach_peers touches, with a switch that makes one rank's attach fail."""
+    lib = object()
+
+    def __init__(self, rank, fail_attach=False, fail_export=False):
+        self.rank, self.fail_attach, self.fail_export = rank, fail_attach, fail_export
+        self.attached = self.detached = 0
+        self.handles = None
+
+    def set_stream(self, s):
+        pass
+
+    def peer_export(self):
+        if self.fail_export:
+            raise RuntimeError('no window')
+        return bytes([self.rank]) * 64
+
+    def peer_attach(self, handles):
+        if self.fail_attach:
+            raise RuntimeError('hipIpcOpenMemHandle failed')
+        self.handles = [bytes(h) for h in handles]
+        self.attached += 1
+
+    def peer_detach(self):
+        self.detached += 1
+
+
+def _handshake_worker(rank, world, port, out, scenario):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ctx = _FakePeerCtx(rank, fail_attach=(scenario == 'attach_fails_on_1' and rank == 1),
+                           fail_export=(scenario == 'export_fails_on_0' and rank == 0))
+        it = ShardedIteration.__new__(ShardedIteration)
+        it.ctx, it.world, it.rank, it.group, it.transport = ctx, world, rank, None, 'collective'
+        err = ''
+        try:
+            it._attach_peers(required=(scenario == 'required_but_fails' or False))
+        except RuntimeError as e:
+            err = str(e)
+        np.savez(os.path.join(out, f'hs{rank}.npz'), transport=it.transport, attached=ctx.attached, detached=ctx.detached,
+                 handles=np.frombuffer(b''.join(ctx.handles or []), dtype=np.uint8), err=err)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('scenario', ['ok', 'attach_fails_on_1', 'export_fails_on_0'])
+def test_peer_transport_handshake_is_all_or_nothing(tmp_path, scenario):
+    """ShardedIteration sets the peer exchange up with two all_gather_object rounds: every rank's 64-byte window handle to every
+    rank, then every rank's "I could open them all".  If ANY rank fails -- cannot export, cannot open a peer's window (ranks on
+    different nodes) -- EVERY rank stays on the collective (a rank that had attached detaches again): a mixed group would
+    deadlock, half of it waiting for flags nobody raises."""
+    world = 2
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_handshake_worker, args=(world, port, str(tmp_path), scenario), nprocs=world, join=True)
+    z = [np.load(tmp_path / f'hs{r}.npz') for r in range(world)]
+    if scenario == 'ok':
+        for r in range(world):
+            assert str(z[r]['transport']) == 'peer' and int(z[r]['attached']) == 1 and int(z[r]['detached']) == 0
+            assert z[r]['handles'].tobytes() == bytes([0]) * 64 + bytes([1]) * 64      # rank order, every rank's own included
+    else:
+        for r in range(world):
+            assert str(z[r]['transport']) == 'collective'
+        if scenario == 'attach_fails_on_1':
+            assert int(z[0]['attached']) == 1 and int(z[0]['detached']) == 1    # the rank that had attached let go again
+            assert int(z[1]['attached']) == 0
+        else:
+            assert int(z[0]['attached']) == 0 and int(z[1]['attached']) == 0    # nobody tries with a handle missing
