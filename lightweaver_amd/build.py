@@ -93,7 +93,8 @@ def check_spills(objdir, results, verbose=False):
         nbad += bad
         for kernel, nsp, nslots in report:
             lines.append(f'{os.path.basename(path)}: {kernel}: {nsp} spill stores (dwords), {nslots} slot(s) reported')
-    with open(os.path.join(os.path.dirname(objdir), 'spill_lint.txt'), 'a') as f:
+    # (every unit that is linked is in `results`: the report describes THIS library, not the history of the build directory)
+    with open(os.path.join(os.path.dirname(objdir), 'spill_lint.txt'), 'w') as f:
         f.write('\n'.join(lines) + '\n')
     if verbose:
         print('\n'.join(l for l in lines if not l.endswith(' 0 slot(s) reported')) or 'spill check: clean')
