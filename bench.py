@@ -147,6 +147,22 @@ def first_iteration(p, ctx, step):
     return first
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None: the GPU boxes of this pool show 256
+    cpus and grant 16 -- a 64-thread CPU baseline then runs on 16 cpus' worth of time, and says so."""
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 def cpu_baseline(prob, budget_s):
     """The reference core (oracle/_ref, kind 'reference') with its widest SIMD scheme -- or, where it is absent, the
     C oracle (kind 'port') -- timed on the host cores on a bounded number of iterations of the SAME workload.
@@ -186,9 +202,11 @@ def cpu_baseline(prob, budget_s):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 50:
             break
-    return ({'value': n / dt, 'unit': 'iters/s', 'cores': threads, 'kind': kind,
+    quota = cpu_quota()
+    return ({'value': n / dt, 'unit': 'iters/s', 'cores': threads, 'kind': kind, 'cpu_quota_cpus': quota,
              'sample': f'{n} iterations of the same {prob.Nlambda}-wavelength workload, scheme {name}, '
-                       f'Nthreads={threads} of {ncpu} host cpus'},
+                       f'Nthreads={threads} of {ncpu} host cpus'
+                       + (f" (the container's cpu quota is {quota:g} cpus' worth of time)" if quota else '')},
             {'name': scalar_name, 'first': scalar_first, 'simd_name': name, 'simd_first': simd_first})
 
 
@@ -569,7 +587,7 @@ def aux_ref500(args, device, stream, torch, models):
                         break
                 cpu[label] = {'iters_per_s': n / dt, 'ms_per_step': 1e3 * dt / n, 'threads': nthr, 'iterations_timed': n,
                               'scheme': rc.scheme_name}
-            out['cpu_baseline'] = {'kind': 'reference', **cpu}
+            out['cpu_baseline'] = {'kind': 'reference', 'cpu_quota_cpus': cpu_quota(), **cpu}
             out['speedup_vs_reference_1_thread'] = cpu['Nthreads_1_as_benchmark_py']['ms_per_step'] / ms
         except Exception as e:
             out['cpu_baseline'] = {'failed': repr(e)}
@@ -613,7 +631,7 @@ def aux_dropin(args, device, stream, torch, models):
 
 AUX = {'prd': ('C3_prd', aux_prd), 'columns': ('C4_columns', aux_columns), '2d': ('C5_2d', aux_2d),
        'fixed': ('fixed_order', aux_fixed_order), 'realistic': ('realistic_1d', aux_realistic),
-       'moving': ('moving_1d', aux_moving), 'ref500': ('ref_benchmark_500', aux_ref500), 'dropin': ('dropin', aux_dropin)}
+       'moving': ('moving_1d', aux_moving), 'dropin': ('dropin', aux_dropin), 'ref500': ('ref_benchmark_500', aux_ref500)}
 
 
 def rank_launch_command(ngpus, argv, port=None):
