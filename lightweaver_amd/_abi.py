@@ -143,6 +143,31 @@ class lwhip_iter_result(C.Structure):
     _fields_ = [('updatedJ', C.c_int32), ('dJMaxIdx', C.c_int32), ('dJMax', C.c_double)]
 
 
+_RAW = {}
+
+
+def raw_view(struct):
+    """The same memory as `struct` seen through a mirror type whose pointer fields are c_void_p: they take plain integer
+    addresses (`arr.ctypes.data`) -- filling a typed POINTER field costs a ctypes.cast per array, twice the time, and a column
+    batch fills a quarter of a million of them."""
+    cls = type(struct)
+    raw = _RAW.get(cls)
+    if raw is None:
+        fields = []
+        for name, tp in cls._fields_:
+            is_ptr = isinstance(tp, type) and issubclass(tp, C._Pointer)
+            fields.append((name, C.c_void_p if is_ptr else tp))
+        raw = type(cls.__name__ + '_raw', (C.Structure,), {'_fields_': fields})
+        assert C.sizeof(raw) == C.sizeof(cls)
+        _RAW[cls] = raw
+    return raw.from_buffer(struct)
+
+
+def addr(a):
+    """Address of a numpy array's data, or None."""
+    return None if a is None else a.ctypes.data
+
+
 # every symbol include/lwhip.h declares: (name, restype, argtypes)
 ctx_p = C.c_void_p
 SYMBOLS = [

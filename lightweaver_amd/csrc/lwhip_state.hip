@@ -506,6 +506,57 @@ int collect_profile(lwhip_context* c)
 
 extern "C"
 {
+namespace
+{
+// pinned staging blocks for the large uploads of column batches: taken from a pool for the duration of one lwhip_upload (the
+// call waits for its stream before it returns), given back afterwards; at most one per concurrently creating thread exists
+struct BigStage
+{
+    double* p = nullptr;
+    size_t n = 0;
+    static std::mutex& mtx()
+    {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<std::pair<double*, size_t>>& pool()
+    {
+        static std::vector<std::pair<double*, size_t>>* v = new std::vector<std::pair<double*, size_t>>();
+        return *v;
+    }
+    explicit BigStage(size_t doubles)
+    {
+        if (!doubles || doubles * sizeof(double) > ((size_t)64 << 20))
+            return;
+        {
+            std::lock_guard<std::mutex> g(mtx());
+            auto& v = pool();
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].second >= doubles)
+                {
+                    p = v[i].first;
+                    n = v[i].second;
+                    v.erase(v.begin() + (long)i);
+                    return;
+                }
+        }
+        if (hipHostMalloc((void**)&p, doubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            p = nullptr; // (no staging: the plain copies)
+            return;
+        }
+        n = doubles;
+    }
+    ~BigStage()
+    {
+        if (!p)
+            return;
+        std::lock_guard<std::mutex> g(mtx());
+        pool().emplace_back(p, n);
+    }
+};
+}
 static int upload_impl(lwhip_context* c, uint32_t mask);
 int lwhip_upload(lwhip_context* c, uint32_t mask)
 {
@@ -601,14 +652,26 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
             HIP_TRY(hipStreamSynchronize(c->stream)); // `geo`, `bcB` are locals
         }
     }
+    // Column batches (round 6): the four [Nla, Ns] arrays of a column -- 7.6 MB at 2 908 wavelengths -- go through a pinned
+    // staging block of this call (a pool of them, one per creating thread at a time): the host copy runs in parallel on the
+    // creating threads, while four pageable hipMemcpyAsync per column took ~1.5 ms each INSIDE the runtime's lock -- the
+    // serial part of setting up 512 columns.
+    BigStage big(c->batchHint > 1 ? (size_t)4 * Nla * Ns : 0);
+    auto h2d_big = [&](double* dst, const double* src, size_t count, size_t slot) -> hipError_t {
+        if (!big.p)
+            return hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        double* st = big.p + slot * Nla * Ns;
+        std::memcpy(st, src, count * sizeof(double));
+        return hipMemcpyAsync(dst, st, count * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    };
     if (mask & LWHIP_BACKGROUND)
     {
-        H2D(c->bgChi.p, p.bgChi + l0 * Ns, Nla * Ns);
-        H2D(c->bgEta.p, p.bgEta + l0 * Ns, Nla * Ns);
-        H2D(c->bgSca.p, p.bgSca + l0 * Ns, Nla * Ns);
+        HIP_TRY(h2d_big(c->bgChi.p, p.bgChi + l0 * Ns, Nla * Ns, 0));
+        HIP_TRY(h2d_big(c->bgEta.p, p.bgEta + l0 * Ns, Nla * Ns, 1));
+        HIP_TRY(h2d_big(c->bgSca.p, p.bgSca + l0 * Ns, Nla * Ns, 2));
     }
     if (mask & LWHIP_J)
-        H2D(c->J.p, p.J + l0 * Ns, Nla * Ns);
+        HIP_TRY(h2d_big(c->J.p, p.J + l0 * Ns, Nla * Ns, 3));
     if (mask & LWHIP_BC)
     {
         if (p.zLowerBc.type == LWHIP_BC_CALLABLE)

@@ -210,31 +210,32 @@ class Problem:
         for ia, a in enumerate(self.atoms):
             trans = (abi.lwhip_transition * max(len(a.trans), 1))()
             keep.append(trans)
+            adr = abi.addr
             for kr, t in enumerate(a.trans):
-                ct = trans[kr]
+                ct = abi.raw_view(trans[kr])    # (pointer fields take integer addresses: half the time of typed pointers)
                 ct.type, ct.i, ct.j = int(t.type), int(t.i), int(t.j)
                 ct.Nblue, ct.Nred = int(t.Nblue), int(t.Nred)
                 ct.prd = 1 if (t.type == abi.LINE and t.rhoPrd is not None) else 0
                 ct.Aji, ct.Bji, ct.Bij = float(t.Aji), float(t.Bji), float(t.Bij)
                 ct.lambda0, ct.dopplerWidth = float(t.lambda0), float(t.dopplerWidth)
-                ct.wavelength = _ptr(t.wavelength)
-                ct.alpha = _ptr(t.alpha)
-                ct.phi = _ptr(t.phi)
-                ct.wphi = _ptr(t.wphi)
-                ct.aDamp = _ptr(t.aDamp)
-                ct.rhoPrd = _ptr(t.rhoPrd)
-                ct.Rij = _ptr(t.Rij)
-                ct.Rji = _ptr(t.Rji)
-                ct.Qelast = _ptr(t.Qelast)
-            ca = atoms[ia]
+                ct.wavelength = adr(t.wavelength)
+                ct.alpha = adr(t.alpha)
+                ct.phi = adr(t.phi)
+                ct.wphi = adr(t.wphi)
+                ct.aDamp = adr(t.aDamp)
+                ct.rhoPrd = adr(t.rhoPrd)
+                ct.Rij = adr(t.Rij)
+                ct.Rji = adr(t.Rji)
+                ct.Qelast = adr(t.Qelast)
+            ca = abi.raw_view(atoms[ia])
             ca.Nlevel, ca.Ntrans, ca.detailed = int(a.Nlevel), len(a.trans), int(bool(a.detailed))
-            ca.n = _ptr(a.n)
-            ca.nStar = _ptr(a.nStar)
-            ca.nTotal = _ptr(a.nTotal)
-            ca.vBroad = _ptr(a.vBroad)
-            ca.Gamma = _ptr(a.Gamma)
-            ca.C = _ptr(a.C)
-            ca.trans = C.cast(trans, C.POINTER(abi.lwhip_transition))
+            ca.n = adr(a.n)
+            ca.nStar = adr(a.nStar)
+            ca.nTotal = adr(a.nTotal)
+            ca.vBroad = adr(a.vBroad)
+            ca.Gamma = adr(a.Gamma)
+            ca.C = adr(a.C)
+            ca.trans = C.addressof(trans)
         p = abi.lwhip_problem()
         p.abiVersion = abi.ABI_VERSION
         p.Nspace, p.Nrays, p.Nlambda = self.Nspace, self.Nrays, self.Nlambda
