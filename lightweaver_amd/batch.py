@@ -41,12 +41,14 @@ class ColumnBatch:
             # Columns 2 .. n are created concurrently: a borrower's lwhip_create is ~3 ms of host work (its own bookkeeping of
             # the shared structure) + ~2 ms of allocations and uploads, ctypes releases the interpreter lock for the call, and
             # the library's create path shares nothing writable between contexts (the donor's borrower count is atomic, the
-            # error text is per thread).  LWHIP_CREATE_THREADS=1 creates them one after the other.
+            # error text is per thread).  LWHIP_CREATE_THREADS=1 creates them one after the other (default 16).
             hint = len(self.problems) if fused else 0
             self.contexts = [Context(self.problems[0], device=device, stream=stream, batchHint=hint)] if self.problems else []
             donor = self.contexts[0] if (fused and self.contexts) else None
             rest = self.problems[1:]
-            nthr = max(1, min(int(os.environ.get('LWHIP_CREATE_THREADS', '8')), os.cpu_count() or 1, len(rest)))
+            # (round 6, tools/create_threads_time.py: 64 borrowers take 5.8 / 1.8 / 1.35 / 0.99 ms each on 1 / 4 / 8 / 16 threads --
+            # beyond that the HIP runtime's own locks around allocations and copies are what is left)
+            nthr = max(1, min(int(os.environ.get('LWHIP_CREATE_THREADS', '16')), os.cpu_count() or 1, len(rest)))
             if os.environ.get('LWHIP_DEBUG') and any(os.environ.get(k) for k in ('LWHIP_PAD_SENTINEL', 'LWHIP_TRACE_ALLOC')):
                 nthr = 1    # (those diagnoses number the allocations in creation order: one creating thread)
             make = lambda p: Context(p, device=device, stream=stream, batchHint=hint, like=donor)  # noqa: E731
