@@ -878,7 +878,7 @@ uint32_t sync_state(Context& ctx, bool force, Prints* later = nullptr, uint32_t 
     // (spect.J's own fingerprint first, with the whole pool: once the pool works on the 90 MB of the slow groups a second
     // round would be hashed by this thread alone, ten times slower)
     st->fpJHostFresh = false;
-    const bool withJ = st->jSynced && !force && !st->jDeviceAhead && !resident_J() && groups == kSlowGroups;
+    const bool withJ = st->jSynced && !force && !st->jDeviceAhead && !resident_J() && !st->hprdOn && groups == kSlowGroups;
     if (later)
     {
         // (spect.J's blocks go first in the pool's round and this thread waits for them alone: the upload decision hangs on
@@ -953,7 +953,8 @@ uint32_t j_policy_upload(PluginState* st, uint32_t up, bool force = false)
             fail("lwhip_map_host_J");
         st->jMapped = false;
     }
-    if ((up & LWHIP_J) && st->jSynced && !force && !st->jDeviceAhead
+    // (not with hybrid PRD: JRest travels in the same group and is not covered by J's fingerprint)
+    if ((up & LWHIP_J) && st->jSynced && !force && !st->jDeviceAhead && !st->hprdOn
         && (st->fpJHostFresh ? st->fpJHost : host_J_fingerprint(st)) == st->fpJ)
         up &= ~(uint32_t)LWHIP_J; // nobody has rewritten spect.J since the device produced it: the device's copy is the same
     st->fpJHostFresh = false;
