@@ -350,7 +350,8 @@ static int peer_attach_impl(lwhip_context* c, void* const* windows, const unsign
         }
     }
     c->peerOn = true;
-    c->peerSeq = 0;
+    // (peerSeq is NOT reset: the flags in the windows are monotonic exchange numbers, and ranks that detach and attach again --
+    // all of them, having made the same number of exchanges -- must not find the old, larger values satisfying a new wait)
     return LWHIP_OK;
 }
 

@@ -375,28 +375,36 @@ def test_peer_exchange_with_fixed_order_sums_is_bit_reproducible(gpu):
 def test_wavelength_shards_meet_through_the_peer_exchange(gpu, world):
     """The sharded iteration with NO collective (lwhip_peer_*): `world` contexts of this process own the wavelength shards,
     attach each other's windows by pointer, and each one's fs_finalise adds the ranks' slots in rank order -- Gamma and the
-    rates equal the unsharded run's to rounding and are the same bits on every rank; two iterations (both buffers of the
-    windows), dJMax and its index the unsharded ones."""
+    rates equal the unsharded run's to rounding and are the same bits on every rank; three iterations (both buffers of the
+    windows), dJMax and its index the unsharded ones; then the ranks detach, attach again and make a fourth exchange -- the
+    windows' flags are monotonic exchange numbers, so the old values must not satisfy the new wait."""
     from lightweaver_amd.distributed import shard_bounds
     prob = models.falc_h_ca(Nrays=3, lineScale=0.3)
     q = prob.copy()
     with Context(q) as whole:
-        upsWhole = [whole.formal_sol_gamma_matrices(deviceResident=True) for _ in range(3)]
+        upsWhole = [whole.formal_sol_gamma_matrices(deviceResident=True) for _ in range(4)]
         whole.download(abi.ALL_OUTPUTS)
     b = shard_bounds(prob, world)
     probs = [prob.copy() for _ in range(world)]
     ctxs = [Context(p, laStart=b[r], laEnd=b[r + 1], worldSize=world, worldRank=r) for r, p in enumerate(probs)]
+
+    def exchange(it):
+        for c in ctxs:           # (one host thread drives all ranks: every publish is queued before anybody waits)
+            c.gamma_prefill_from_C(1.0)
+            c.fs_partial()
+        for up in [c.fs_finalise() for c in ctxs]:
+            assert (up.dJMax, up.dJMaxIdx) == (upsWhole[it].dJMax, upsWhole[it].dJMaxIdx)
     try:
         wins = [c.peer_window()[0] for c in ctxs]
         for c in ctxs:
             c.peer_attach_pointers(wins)
         for it in range(3):
-            for c in ctxs:           # (one host thread drives all ranks: every publish is queued before anybody waits)
-                c.gamma_prefill_from_C(1.0)
-                c.fs_partial()
-            ups = [c.fs_finalise() for c in ctxs]
-            for up in ups:
-                assert (up.dJMax, up.dJMaxIdx) == (upsWhole[it].dJMax, upsWhole[it].dJMaxIdx)
+            exchange(it)
+        for c in ctxs:
+            c.peer_detach()
+        for c in ctxs:
+            c.peer_attach_pointers(wins)
+        exchange(3)
         for c in ctxs:
             c.download(abi.ALL_OUTPUTS)
             c.peer_detach()
