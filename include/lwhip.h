@@ -394,6 +394,12 @@ int lwhip_peer_export(lwhip_context* ctx, void* handle64);
 int lwhip_peer_attach(lwhip_context* ctx, const void* handles /* worldSize x 64 bytes */);
 int lwhip_peer_attach_pointers(lwhip_context* ctx, void* const* windows /* worldSize device pointers */);
 int lwhip_peer_detach(lwhip_context* ctx);
+/* One exchange of a known per-rank pattern instead of the partial sums -- called by ALL attached ranks together, before the
+ * exchange is relied on: *result = 0 every rank's slot arrived intact within timeoutMs, 1 a rank's flag never came, 2 a slot
+ * holds something else (stores of a peer not visible to this device's kernels).  What a caller does on a non-zero result is
+ * detach everywhere and fall back to the all-reduce (lightweaver_amd.distributed.ShardedIteration does).  The windows are
+ * uncached / fine-grained device memory where the runtime offers it, so that a peer's stores are seen by a running kernel. */
+int lwhip_peer_selftest(lwhip_context* ctx, int timeoutMs, int32_t* result);
 
 /* formal_sol: chi/S/solve/I only, optionally up-going rays only (FsMode::FsOnly|UpOnly). */
 int lwhip_formal_sol(lwhip_context* ctx, int upOnly);

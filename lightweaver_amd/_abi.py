@@ -191,6 +191,7 @@ SYMBOLS = [
     ('lwhip_peer_attach', C.c_int, [ctx_p, C.c_void_p]),
     ('lwhip_peer_attach_pointers', C.c_int, [ctx_p, C.POINTER(C.c_void_p)]),
     ('lwhip_peer_detach', C.c_int, [ctx_p]),
+    ('lwhip_peer_selftest', C.c_int, [ctx_p, C.c_int, C.POINTER(C.c_int32)]),
     ('lwhip_map_host_J', C.c_int, [ctx_p, C.c_int]),
     ('lwhip_fingerprint_J', C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     ('lwhip_host_fingerprint', C.c_uint64, [f64p, C.c_size_t]),

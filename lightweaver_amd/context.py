@@ -438,6 +438,12 @@ class Context:
         _check(self.lib, self.lib.lwhip_peer_attach_pointers(self._h, arr), 'lwhip_peer_attach_pointers')
         self.peers_attached = True
 
+    def peer_selftest(self, timeout_ms=200) -> int:
+        """One exchange of a known pattern (all attached ranks together): 0 = every rank's slot arrived intact."""
+        res = C.c_int32(-1)
+        _check(self.lib, self.lib.lwhip_peer_selftest(self._h, int(timeout_ms), C.byref(res)), 'lwhip_peer_selftest')
+        return res.value
+
     def peer_detach(self):
         _check(self.lib, self.lib.lwhip_peer_detach(self._h), 'lwhip_peer_detach')
         self.peers_attached = False

@@ -275,8 +275,21 @@ int lwhip_peer_window(lwhip_context* c, void** devPtr, size_t* bytes)
     {
         c->peerStride = (c->red.n + 31) & ~(size_t)31;
         c->peerWinBytes = PEER_HDR + (size_t)2 * c->worldSize * c->peerStride * sizeof(double);
-        // (plain device memory: what hipIpcGetMemHandle exports; every access of a consumer is a system-scope one)
-        HIP_TRY(hipMalloc((void**)&c->peerWin, c->peerWinBytes));
+        // Device memory the OTHER devices store into while this device's kernels poll it: uncached (else fine-grained) where
+        // the runtime offers it -- a coarse-grained allocation's lines may sit in this device's L2 and never show a peer's
+        // store within a kernel; plain hipMalloc as the last resort (ranks sharing one device).  The consumers' accesses are
+        // system-scope either way, and lwhip_peer_selftest checks the exchange on the actual topology before it is used.
+        if (hipExtMallocWithFlags((void**)&c->peerWin, c->peerWinBytes, hipDeviceMallocUncached) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            c->peerWin = nullptr;
+            if (hipExtMallocWithFlags((void**)&c->peerWin, c->peerWinBytes, hipDeviceMallocFinegrained) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                c->peerWin = nullptr;
+                HIP_TRY(hipMalloc((void**)&c->peerWin, c->peerWinBytes));
+            }
+        }
         HIP_TRY(hipMemset(c->peerWin, 0, c->peerWinBytes));
         HIP_TRY(hipStreamSynchronize(nullptr));
         HIP_TRY(c->peerArrive.alloc_zero(1));
@@ -367,6 +380,30 @@ int lwhip_peer_attach_pointers(lwhip_context* c, void* const* windows)
     if (!windows)
         return fail(LWHIP_ERR_INVALID, "null argument");
     return peer_attach_impl(c, windows, nullptr);
+}
+
+int lwhip_peer_selftest(lwhip_context* c, int timeoutMs, int32_t* result)
+{
+    if (!c || !result)
+        return fail(LWHIP_ERR_INVALID, "null argument");
+    if (!c->peerOn)
+        return fail(LWHIP_ERR_INVALID, "lwhip_peer_selftest: not attached");
+    HIP_TRY(hipSetDevice(c->device));
+    // one exchange with a known pattern in place of the partial sums (the reduce buffer is scratch between iterations)
+    HIP_TRY(launch_peer_pattern(c->red.p, (int64_t)c->red.n, c->worldRank, c->stream));
+    const int st = peer_publish(c);
+    if (st != LWHIP_OK)
+        return st;
+    ApplyArgs a{};
+    peer_apply_args(c, a);
+    *c->popStatusHost = -1;
+    int32_t* resDev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&resDev, c->popStatusHost, 0));
+    const long spins = std::max(1L, (long)timeoutMs) * 1500L; // (a poll with its sleep is ~0.6 us)
+    HIP_TRY(launch_peer_check(a.peerSlots, a.peerStride, a.peerFlags, c->worldSize, a.peerSeq, (int64_t)c->red.n, spins, resDev, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *result = *(volatile int32_t*)c->popStatusHost;
+    return LWHIP_OK;
 }
 
 int lwhip_peer_detach(lwhip_context* c)

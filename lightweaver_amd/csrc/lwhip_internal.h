@@ -578,6 +578,11 @@ hipError_t launch_stat_eq(const StatEqArgs& a, int maxNlevel, hipStream_t stream
                           int nBatch = 0);
 int stat_eq_blocks(int Ns, int maxNlevel);
 hipError_t launch_peer_publish(const PeerPublishArgs& a, hipStream_t stream);
+// self-test of the exchange: fill `buf` with the rank's pattern / wait for the world's flags (bounded by spinLimit polls) and
+// compare every slot with its rank's pattern; *result = 0 ok, 1 a flag never came, 2 a slot holds something else
+hipError_t launch_peer_pattern(double* buf, int64_t n, int rank, hipStream_t stream);
+hipError_t launch_peer_check(const double* slots, int64_t stride, const unsigned long long* flags, int world, unsigned long long seq, int64_t n,
+                             long spinLimit, int32_t* result, hipStream_t stream);
 hipError_t launch_fp_blocks(const double* p, size_t n, unsigned long long* sums /* [nBlocks][16] */, hipStream_t stream);
 // 2D formal solver (lwhip_fs2d.hip): one workgroup per problem
 struct Fs2dArgs

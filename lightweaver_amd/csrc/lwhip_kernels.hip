@@ -216,6 +216,61 @@ hipError_t launch_peer_publish(const PeerPublishArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// ---- self-test of the exchange on the actual topology (lwhip_peer_selftest) ---------------------------------------------------
+DEVINL double peer_pattern(int rank, int64_t i) { return (double)(rank + 1) * 1000.0 + (double)(i % 97); }
+__global__ void __launch_bounds__(256) peer_pattern_kernel(double* buf, int64_t n, int rank)
+{
+    dbg_poison_lds();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        buf[i] = peer_pattern(rank, i);
+}
+__global__ void __launch_bounds__(256) peer_check_kernel(const double* slots, int64_t stride, const unsigned long long* flags, int world,
+                                                         unsigned long long seq, int64_t n, long spinLimit, int32_t* result)
+{
+    dbg_poison_lds();
+    __shared__ int sBad;
+    if (threadIdx.x == 0)
+        sBad = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < world)
+    {
+        bool seen = false;
+        for (long spin = 0; spin < spinLimit; ++spin)
+        {
+            if (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= seq)
+            {
+                seen = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!seen)
+            atomicMax(&sBad, 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    if (sBad == 0)
+        for (int r = 0; r < world; ++r)
+            for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+                if (__hip_atomic_load(slots + (int64_t)r * stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != peer_pattern(r, i))
+                    atomicMax(&sBad, 2);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(result, (int32_t)sBad, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_peer_pattern(double* buf, int64_t n, int rank, hipStream_t stream)
+{
+    LWHIP_LAUNCH(peer_pattern_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, buf, n, rank);
+    return hipGetLastError();
+}
+hipError_t launch_peer_check(const double* slots, int64_t stride, const unsigned long long* flags, int world, unsigned long long seq, int64_t n,
+                             long spinLimit, int32_t* result, hipStream_t stream)
+{
+    LWHIP_LAUNCH(peer_check_kernel, dim3(1), dim3(256), 0, stream, slots, stride, flags, world, seq, n, spinLimit, result);
+    return hipGetLastError();
+}
+
 // the wait of a consumer workgroup: lanes 0 .. world-1 poll one flag each; bounded (a peer that died must not hang the device:
 // ~2 s, then the sums are whatever the slots hold and the launch reports it through the mirror's fourth word)
 DEVINL bool peer_wait(const unsigned long long* flags, int world, unsigned long long seq)

@@ -113,7 +113,21 @@ class ShardedIteration:
                 ok, err = False, e
         oks = [None] * self.world
         dist.all_gather_object(oks, bool(ok), group=self.group)
-        if all(oks):
+        if all(oks) and hasattr(self.ctx, 'peer_selftest'):
+            # every rank could open every window: now ONE exchange of a known pattern on the actual topology -- a rank whose
+            # kernels do not see a peer's stores (or whose flag never arrives) sends everybody back to the collective
+            try:
+                res = self.ctx.peer_selftest(200)
+            except Exception as e:   # noqa: BLE001
+                res, err = -1, e
+            results = [None] * self.world
+            dist.all_gather_object(results, int(res), group=self.group)
+            if all(r == 0 for r in results):
+                self.transport = 'peer'
+                return
+            err = err or RuntimeError(f'peer self-test results by rank: {results}')
+            oks = [False]
+        elif all(oks):
             self.transport = 'peer'
             return
         if ok:

@@ -428,6 +428,9 @@ class _FakePeerCtx:
     def peer_detach(self):
         self.detached += 1
 
+    def peer_selftest(self, timeout_ms=200):
+        return self.selftest_result
+
 
 def _handshake_worker(rank, world, port, out, scenario):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -436,6 +439,7 @@ def _handshake_worker(rank, world, port, out, scenario):
     try:
         ctx = _FakePeerCtx(rank, fail_attach=(scenario == 'attach_fails_on_1' and rank == 1),
                            fail_export=(scenario == 'export_fails_on_0' and rank == 0))
+        ctx.selftest_result = 2 if (scenario == 'selftest_fails_on_1' and rank == 1) else 0
         it = ShardedIteration.__new__(ShardedIteration)
         it.ctx, it.world, it.rank, it.group, it.transport = ctx, world, rank, None, 'collective'
         err = ''
@@ -449,11 +453,12 @@ def _handshake_worker(rank, world, port, out, scenario):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('scenario', ['ok', 'attach_fails_on_1', 'export_fails_on_0'])
+@pytest.mark.parametrize('scenario', ['ok', 'attach_fails_on_1', 'export_fails_on_0', 'selftest_fails_on_1'])
 def test_peer_transport_handshake_is_all_or_nothing(tmp_path, scenario):
     """ShardedIteration sets the peer exchange up with two all_gather_object rounds: every rank's 64-byte window handle to every
     rank, then every rank's "I could open them all".  If ANY rank fails -- cannot export, cannot open a peer's window (ranks on
-    different nodes) -- EVERY rank stays on the collective (a rank that had attached detaches again): a mixed group would
+    different nodes), or the self-test exchange of a known pattern does not arrive intact on it (a peer's stores not visible
+    to its kernels) -- EVERY rank stays on the collective (a rank that had attached detaches again): a mixed group would
     deadlock, half of it waiting for flags nobody raises."""
     world = 2
     port = 37500 + (os.getpid() % 2000)
@@ -469,5 +474,8 @@ def test_peer_transport_handshake_is_all_or_nothing(tmp_path, scenario):
         if scenario == 'attach_fails_on_1':
             assert int(z[0]['attached']) == 1 and int(z[0]['detached']) == 1    # the rank that had attached let go again
             assert int(z[1]['attached']) == 0
+        elif scenario == 'selftest_fails_on_1':
+            # both had attached; the exchange of a known pattern did not arrive intact on rank 1: both detach
+            assert [int(z[r]['attached']) for r in range(world)] == [1, 1] and [int(z[r]['detached']) for r in range(world)] == [1, 1]
         else:
             assert int(z[0]['attached']) == 0 and int(z[1]['attached']) == 0    # nobody tries with a handle missing

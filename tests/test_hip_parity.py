@@ -398,6 +398,9 @@ def test_wavelength_shards_meet_through_the_peer_exchange(gpu, world):
         wins = [c.peer_window()[0] for c in ctxs]
         for c in ctxs:
             c.peer_attach_pointers(wins)
+        # the self-test of the exchange (a known pattern instead of the sums), one rank after the other from this one host
+        # thread: a rank whose peers have not published yet gives up after its time-out (1), the last one finds every slot (0)
+        assert [c.peer_selftest(20) for c in ctxs] == [1] * (world - 1) + [0]
         for it in range(3):
             exchange(it)
         for c in ctxs:
