@@ -578,7 +578,35 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
             explicit Skip(bool o) : on(o) { devbuf_skip_safety_clear() += on ? 1 : 0; }
             ~Skip() { devbuf_skip_safety_clear() -= on ? 1 : 0; }
         } skip(c->tablesFrom != nullptr);
+        // one arena for a borrower's state (DevArena, lwhip_host.h); the owner counts what its own state takes
+        DevArena arena;
+        const bool plainAllocs = DevBuf<double>::poison_on() || DevBuf<double>::sentinel_on() || std::getenv("LWHIP_TRACE_ALLOC") != nullptr;
+        if (!plainAllocs)
+        {
+            if (c->tablesFrom && c->tablesFrom->stateBytes > 0)
+            {
+                arena.size = c->tablesFrom->stateBytes + (64u << 10);
+                if (hipMalloc((void**)&arena.base, arena.size) == hipSuccess && hipMemsetAsync(arena.base, 0, arena.size, nullptr) == hipSuccess)
+                    c->stateArena = arena.base;
+                else
+                {
+                    (void)hipGetLastError();
+                    if (arena.base)
+                        (void)hipFree(arena.base);
+                    arena = DevArena{};
+                }
+            }
+            else if (!c->tablesFrom)
+                arena.counting = true;
+        }
+        struct ArenaScope
+        {
+            explicit ArenaScope(DevArena* a) { devbuf_arena() = a; }
+            ~ArenaScope() { devbuf_arena() = nullptr; }
+        } arenaScope((arena.base || arena.counting) ? &arena : nullptr);
         st = alloc_state(c);
+        if (arena.counting)
+            c->stateBytes = arena.counted;
         if (hipStreamSynchronize(nullptr) != hipSuccess && st == LWHIP_OK)
             st = fail(LWHIP_ERR_DEVICE, "lwhip_create: clearing the state allocations failed");
     }

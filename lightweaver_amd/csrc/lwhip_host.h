@@ -64,6 +64,23 @@ inline int& devbuf_skip_safety_clear()
     return depth;
 }
 
+// The state allocations of a context made with lwhip_create_like come out of ONE device allocation (round 6): the owner of the
+// tables counts the bytes its own alloc_state asks for (count mode), a borrower gets an arena of that size, cleared with one
+// fill, and its DevBufs take consecutive 256-byte-aligned pieces of it -- ~60 hipMalloc and ~13 fills per column of a 1.5D
+// batch become one of each.  A piece that does not fit (or any allocation outside lwhip_create) takes the ordinary path.
+struct DevArena
+{
+    unsigned char* base = nullptr;
+    size_t size = 0, used = 0;
+    size_t counted = 0;   // count mode: bytes asked for
+    bool counting = false;
+};
+inline DevArena*& devbuf_arena()
+{
+    static thread_local DevArena* a = nullptr;
+    return a;
+}
+
 template <typename T> struct DevBuf
 {
     T* p = nullptr;
@@ -89,6 +106,20 @@ template <typename T> struct DevBuf
         n = count;
         if (count == 0)
             return hipSuccess;
+        if (DevArena* ar = devbuf_arena())
+        {
+            const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+            if (ar->counting)
+                ar->counted += bytes;
+            else if (ar->used + bytes <= ar->size)
+            {
+                // (the arena was cleared as a whole: zeros serve alloc_zero and the safety net alike)
+                p = (T*)(ar->base + ar->used);
+                ar->used += bytes;
+                owned = false;
+                return hipSuccess;
+            }
+        }
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         const int seq = alloc_seq()++;
         static const bool noClear = debug_knobs_on() && std::getenv("LWHIP_NO_CLEAR") != nullptr; // (no safety net: what hipMalloc returns)
@@ -516,6 +547,8 @@ struct lwhip_context
     bool peerOn = false;
     unsigned long long peerSeq = 0;      // exchanges so far (the next one uses buffer peerSeq & 1 with flag value peerSeq + 1)
     DevBuf<int32_t> peerArrive;
+    size_t stateBytes = 0;         // what this context's alloc_state asked for (the size of a borrower's arena)
+    unsigned char* stateArena = nullptr;
     // lwhip_map_host_J: the caller's J array page-locked and mapped; the sweep stores J there too
     void* JhostReg = nullptr;      // what was registered (prob.J)
     double* JhostDev = nullptr;    // device address of this shard's first row in it
@@ -556,6 +589,8 @@ struct lwhip_context
         if (prdPinnedPipe)
             (void)hipHostFree(prdPinnedPipe);
         peer_release(this);
+        if (stateArena) // (the DevBufs that point into it do not own their pieces)
+            (void)hipFree(stateArena);
         if (JhostReg)
             (void)hipHostUnregister(JhostReg);
         if (fpPinned)
