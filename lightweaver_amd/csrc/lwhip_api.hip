@@ -542,6 +542,7 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
         return bail(LWHIP_ERR_DEVICE);
     c->pairRays = dbg_env_int("LWHIP_PAIR_RAYS", 1) != 0;
     c->prdPipeline = dbg_env_int("LWHIP_PRD_PIPELINE", 1) != 0;
+    c->prdGeneral = dbg_env_int("LWHIP_PRD_GENERAL", 0) != 0;
     const bool timing = std::getenv("LWHIP_CREATE_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

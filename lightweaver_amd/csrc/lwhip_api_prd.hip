@@ -134,7 +134,10 @@ int lwhip_prd_partial(lwhip_context* c)
         a.laHi = h.rhoLt0 + h.rhoRows;
         a.rho = c->rho.p + h.rhoOff;
         // enough workgroups to fill the chip: Ns x slices >= ~8 per CU, at least 128 wavelengths each
-        a.slices = std::max(1, std::min({ (int)PRD_MAX_SLICES, (2048 + Ns - 1) / Ns, (a.laHi - a.laLo + 127) / 128 }));
+        {
+            static const int perSlice = std::max(1, dbg_env_int("LWHIP_PRD_SLICE_LA", 128));
+            a.slices = std::max(1, std::min({ (int)PRD_MAX_SLICES, (2048 * 128 / perSlice + Ns - 1) / Ns, (a.laHi - a.laLo + perSlice - 1) / perSlice }));
+        }
         // gII weights depend only on aDamp, vBroad and the grid: cached across sub-iterations and
         // iterations (the reference's t->gII), dropped when lwhip_upload(LWHIP_NSTAR) refreshes those
         if (c->gII.size() != (size_t)c->Ntrans)
@@ -149,7 +152,8 @@ int lwhip_prd_partial(lwhip_context* c)
             // the end-corrected gII weights of the line's fine grids and the bracketing indices as 16 bits (10 bytes per fine
             // point; the interpolation fraction is re-derived in the kernel)
             const size_t per = (size_t)Ns * 88 * a.Nl;
-            const size_t need = per + (per + 3) / 4;
+            const size_t nWin = (size_t)Ns * PRD_MAX_SLICES; // (first, last) bracket per (depth, slice): 8 bytes
+            const size_t need = per + (per + 3) / 4 + nWin;
             if (a.Nl > 32767)
                 return fail(LWHIP_ERR_UNSUPPORTED, "a PRD line with more than 32 767 wavelengths");
             if (!c->gII[tr])
@@ -166,8 +170,9 @@ int lwhip_prd_partial(lwhip_context* c)
             if (c->gII[tr])
             {
                 a.gII = c->gII[tr]->p;
-                a.gTT = nullptr;
                 a.gIT = (int32_t*)(a.gII + per);
+                // (LWHIP_PRD_GENERAL=1 under LWHIP_DEBUG: no windows, every sub-iteration through the general kernel)
+                a.gWin = c->prdGeneral ? nullptr : (int32_t*)(a.gII + per + (per + 3) / 4);
                 a.gIIFill = c->gIIValid[tr] ? 0 : 1;
                 c->gIIValid[tr] = 1;
             }

@@ -316,7 +316,6 @@ template <typename T> struct DevBuf
     ~DevBuf() { release(); }
 };
 
-enum { PRD_MAX_SLICES = 32 }; // workgroups per depth point in the PRD scattering integral
 
 struct HostTrans
 {
@@ -494,7 +493,7 @@ struct lwhip_context
     bool phiSym = false, vlosZero = false;
     // LWHIP_PAIR_RAYS=0 / LWHIP_PRD_PIPELINE=0 (experiment knobs, read ONCE per context in lwhip_create and only under
     // LWHIP_DEBUG like the other layout knobs: the first changes the order of the arithmetic)
-    bool pairRays = true, prdPipeline = true;
+    bool pairRays = true, prdPipeline = true, prdGeneral = false;
     double* prdPinnedPipe = nullptr;
     size_t prdPinnedPipeN = 0;
     int prdPipeIter = 0;     // > 0: the sub-iteration the calls of lwhip_prd_partial / _finalise belong to

@@ -494,6 +494,8 @@ hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream);
 // every line of the list in one launch pair (same Ns and slice count; hostList = what devList holds)
 hipError_t launch_voigt_lines(const VoigtLineArgs* devList, const VoigtLineArgs* hostList, int nLines, hipStream_t stream);
 
+enum { PRD_MAX_SLICES = 32 }; // workgroups per depth point in the PRD scattering integral
+
 // One PRD line's scattering integral (lwhip_prd.hip)
 struct PrdLineArgs
 {
@@ -521,7 +523,7 @@ struct PrdLineArgs
     const int32_t* transLj;
     double* rho;            // [laHi - laLo, Ns]: the shard's rows
     double* gII;            // [Ns, 88, Nl] cached gII weights of the line, or null (always recompute)
-    double* gTT;            // (unused since round 4: the fraction is re-derived from the index)
+    int32_t* gWin;          // [Ns, PRD_MAX_SLICES, 2] first / last bracket a slice's fine grids touch (written with the cache), or null
     int32_t* gIT;           // [Ns, 88, Nl] cached bracketing indices, 16 bits each
     int32_t gIIFill, _padG; // 1: compute (and store) the weights; 0: read them from the cache
     double* changeVal;      // [Ns * slices] scratch

@@ -252,6 +252,35 @@ def test_hip_prd_loop_stops_where_the_reference_loop_stops(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_hip_prd_cached_kernel_gives_the_general_kernels_rho(monkeypatch):
+    """Sub-iterations after the first run `prd_scatter_cached_kernel` (brackets of the slice's window straight from J, no
+    transposed copy); `LWHIP_PRD_GENERAL=1` keeps every sub-iteration on the general kernel.  Both evaluate the interpolation
+    through the same two functions: rho, and everything derived from it, is the same to the last bit (fixed-order contexts,
+    so that the rates entering Pj + Qj carry no run-to-run difference of their own)."""
+    from lightweaver_amd.context import Context
+    prob = prd_problem()
+
+    def run():
+        p = prob.copy()
+        with Context(p, deterministic=True) as ctx:
+            for _ in range(2):
+                p.gamma_prefill()
+                ctx.formal_sol_gamma_matrices()
+                u = ctx.redistribute_prd(4, 0.0)
+        rho = [t.rhoPrd.copy() for a in p.atoms for t in a.trans if t.rhoPrd is not None]
+        return rho, p.J.copy(), np.asarray(u.dRho).copy()
+
+    rc, Jc, dc = run()
+    monkeypatch.setenv('LWHIP_PRD_GENERAL', '1')
+    rg, Jg, dg = run()
+    assert len(rc) == len(rg) > 0
+    for a, b in zip(rc, rg):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(Jc, Jg)
+    np.testing.assert_array_equal(dc, dg)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('include', [True, False])
 def test_hip_prd_detailed_atoms_matches_oracle(include):
     """include_detailed_atoms on the device: a Context created with prdDetailed redistributes the detailed atom's PRD
