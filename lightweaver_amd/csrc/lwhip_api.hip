@@ -108,6 +108,263 @@ void stream_release(int device, hipStream_t s)
     g_streamPool[device].push_back(s);
 }
 
+// ---- a batch column's own stream is shared with the other columns its creating thread makes --------------------------------
+// 512 columns took 512 streams out of the pool (hipStreamCreate: 5 ms each under 16 creating threads, 18 % of a batch's set-up)
+// although a fused batch runs on ONE stream afterwards.  A borrower made with a batch hint and no stream of the caller's takes
+// the stream of its creating thread's slot (16 slots per device, counted references, back to the pool with the last one).
+namespace
+{
+struct SharedStream
+{
+    hipStream_t s = nullptr;
+    int refs = 0;
+};
+std::mutex g_sharedMutex;
+std::map<std::pair<int, int>, SharedStream> g_sharedStreams;
+std::atomic<int> g_threadSlots{ 0 };
+}
+hipError_t stream_acquire_shared(int device, hipStream_t* out)
+{
+    static thread_local const int slot = g_threadSlots++ % 16;
+    std::lock_guard<std::mutex> g(g_sharedMutex);
+    SharedStream& e = g_sharedStreams[{ device, slot }];
+    if (!e.s)
+    {
+        const hipError_t err = stream_acquire(device, &e.s);
+        if (err != hipSuccess)
+        {
+            e.s = nullptr;
+            return err;
+        }
+        e.refs = 0;
+    }
+    ++e.refs;
+    *out = e.s;
+    return hipSuccess;
+}
+void stream_release_shared(int device, hipStream_t s)
+{
+    std::lock_guard<std::mutex> g(g_sharedMutex);
+    for (auto& kv : g_sharedStreams)
+        if (kv.first.first == device && kv.second.s == s)
+        {
+            if (--kv.second.refs <= 0)
+            {
+                stream_release(device, s);
+                kv.second = SharedStream{};
+            }
+            return;
+        }
+}
+
+// ---- page-locked host memory out of slabs ---------------------------------------------------------------------------------
+// hipHostMalloc takes ~3 ms when 16 threads create columns (two per context -- the host block and the upload stage -- were 20 %
+// of a batch's set-up).  Blocks up to 512 KB are cut from 4 MB slabs (mapped, coherent: device-visible at the same offset of
+// the slab's device pointer); larger ones are slabs of their own.  A released block waits in a list of its rounded size for the
+// next request of that size; slabs live until the process ends.
+namespace
+{
+struct PinnedSlab
+{
+    unsigned char* host = nullptr;
+    unsigned char* dev = nullptr;
+    size_t cap = 0, used = 0;
+};
+struct PinnedPool
+{
+    std::mutex m;
+    std::vector<PinnedSlab> slabs;
+    std::map<size_t, std::vector<std::pair<void*, void*>>> freeBySize;
+};
+PinnedPool& pinned_pool(int device)
+{
+    static std::mutex mm;
+    static std::map<int, PinnedPool*>* pools = new std::map<int, PinnedPool*>();
+    std::lock_guard<std::mutex> g(mm);
+    PinnedPool*& p = (*pools)[device];
+    if (!p)
+        p = new PinnedPool();
+    return *p;
+}
+constexpr size_t PINNED_SLAB = (size_t)4 << 20, PINNED_SMALL = (size_t)512 << 10;
+inline size_t pinned_round(size_t bytes) { return (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; }
+}
+void* pinned_acquire(int device, size_t bytes, void** devPtr)
+{
+    const size_t sz = pinned_round(bytes);
+    PinnedPool& pool = pinned_pool(device);
+    std::lock_guard<std::mutex> g(pool.m);
+    auto it = pool.freeBySize.find(sz);
+    if (it != pool.freeBySize.end() && !it->second.empty())
+    {
+        const auto pr = it->second.back();
+        it->second.pop_back();
+        if (devPtr)
+            *devPtr = pr.second;
+        return pr.first;
+    }
+    PinnedSlab* slab = nullptr;
+    if (sz <= PINNED_SMALL)
+        for (auto& sl : pool.slabs)
+            if (sl.cap == PINNED_SLAB && sl.used + sz <= sl.cap)
+            {
+                slab = &sl;
+                break;
+            }
+    if (!slab)
+    {
+        PinnedSlab sl;
+        sl.cap = sz <= PINNED_SMALL ? PINNED_SLAB : sz;
+        if (hipHostMalloc((void**)&sl.host, sl.cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+            || hipHostGetDevicePointer((void**)&sl.dev, sl.host, 0) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            if (sl.host)
+                (void)hipHostFree(sl.host);
+            return nullptr;
+        }
+        pool.slabs.push_back(sl);
+        slab = &pool.slabs.back();
+    }
+    void* h = slab->host + slab->used;
+    if (devPtr)
+        *devPtr = slab->dev + slab->used;
+    slab->used += sz;
+    return h;
+}
+void pinned_release(int device, void* p, size_t bytes)
+{
+    if (!p)
+        return;
+    PinnedPool& pool = pinned_pool(device);
+    std::lock_guard<std::mutex> g(pool.m);
+    void* dev = nullptr;
+    for (const auto& sl : pool.slabs)
+        if ((unsigned char*)p >= sl.host && (unsigned char*)p < sl.host + sl.cap)
+            dev = sl.dev + ((unsigned char*)p - sl.host);
+    pool.freeBySize[pinned_round(bytes)].emplace_back(p, dev);
+}
+
+// ---- gathered uploads of a batch column's creation (H2DBatch, lwhip_host.h) -----------------------------------------------
+namespace
+{
+constexpr size_t H2D_BATCH_CAP = (size_t)24 << 20;
+struct H2DPair
+{
+    unsigned char* host = nullptr;
+    unsigned char* inbox = nullptr;
+};
+std::mutex g_h2dMutex;
+std::map<int, std::vector<H2DPair>>& h2d_pairs()
+{
+    static std::map<int, std::vector<H2DPair>>* m = new std::map<int, std::vector<H2DPair>>();
+    return *m;
+}
+}
+bool H2DBatch::add(void* dst, const void* src, size_t bytes)
+{
+    if (!host || bytes == 0)
+        return bytes == 0;
+    const size_t nRec = (bytes + H2D_CHUNK - 1) / H2D_CHUNK;
+    auto need = [&](size_t nMore) { return ((used + 15) & ~(size_t)15) + bytes + 16 + (recs.size() + nMore) * sizeof(H2DRec); };
+    if (need(nRec) > cap)
+    {
+        if (flush() != hipSuccess || need(nRec) > cap)
+            return false; // (larger than the stage: the ordinary copy)
+    }
+    if (inFlight)
+    {
+        // the stage is being read by the copy of the previous flush
+        if (hipStreamSynchronize(stream) != hipSuccess)
+            return false;
+        inFlight = false;
+    }
+    used = (used + 15) & ~(size_t)15;
+    std::memcpy(host + used, src, bytes);
+    for (size_t o = 0; o < bytes; o += H2D_CHUNK)
+        recs.push_back(H2DRec{ (unsigned long long)(uintptr_t)dst + o, (unsigned long long)(used + o),
+                               (unsigned long long)std::min<size_t>(H2D_CHUNK, bytes - o) });
+    used += bytes;
+    ++copies;
+    return true;
+}
+hipError_t H2DBatch::flush()
+{
+    if (recs.empty())
+        return hipSuccess;
+    const size_t recsOff = (used + 15) & ~(size_t)15;
+    std::memcpy(host + recsOff, recs.data(), recs.size() * sizeof(H2DRec));
+    const size_t total = recsOff + recs.size() * sizeof(H2DRec);
+    hipError_t e = hipMemcpyAsync(inbox, host, total, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess)
+        e = launch_h2d_scatter(inbox, recsOff, (int)recs.size(), stream);
+    recs.clear();
+    used = 0;
+    inFlight = true;
+    return e;
+}
+namespace
+{
+// open for the duration of one borrower's lwhip_create: the stage / inbox pair comes out of a per-device pool
+struct H2DBatchScope
+{
+    H2DBatch b;
+    int device = 0;
+    bool open = false;
+    void begin(int dev, hipStream_t stream)
+    {
+        device = dev;
+        H2DPair pr;
+        {
+            std::lock_guard<std::mutex> g(g_h2dMutex);
+            auto& v = h2d_pairs()[dev];
+            if (!v.empty())
+            {
+                pr = v.back();
+                v.pop_back();
+            }
+        }
+        if (!pr.host)
+        {
+            if (hipHostMalloc((void**)&pr.host, H2D_BATCH_CAP, hipHostMallocDefault) != hipSuccess
+                || hipMalloc((void**)&pr.inbox, H2D_BATCH_CAP) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                if (pr.host)
+                    (void)hipHostFree(pr.host);
+                return; // (no batch: the ordinary copies)
+            }
+        }
+        b.host = pr.host;
+        b.inbox = pr.inbox;
+        b.cap = H2D_BATCH_CAP;
+        b.stream = stream;
+        h2d_batch() = &b;
+        open = true;
+    }
+    // what was gathered goes out; the stage is free again when the stream has drained
+    hipError_t finish()
+    {
+        if (!open)
+            return hipSuccess;
+        hipError_t e = b.flush();
+        const hipError_t e2 = hipStreamSynchronize(b.stream);
+        b.inFlight = false;
+        return e != hipSuccess ? e : e2;
+    }
+    ~H2DBatchScope()
+    {
+        if (!open)
+            return;
+        h2d_batch() = nullptr;
+        if (b.inFlight || !b.recs.empty())
+            (void)hipStreamSynchronize(b.stream); // (an error path: nothing of the stage may still be in flight)
+        std::lock_guard<std::mutex> g(g_h2dMutex);
+        h2d_pairs()[device].push_back(H2DPair{ b.host, b.inbox });
+    }
+};
+}
+
 int host_block_init(lwhip_context* c)
 {
     int maxNl = 1, nActive = 0;
@@ -120,8 +377,8 @@ int host_block_init(lwhip_context* c)
     const size_t nChange = (size_t)2 * std::max(nActive, 1) * (size_t)stat_eq_blocks(std::max((int)c->prob.Nspace, 1), std::min(maxNl, 64)) + 16;
     c->hostBlockBytes = HB_CHANGE + nChange * sizeof(double);
     unsigned char* dev = nullptr;
-    if (hipHostMalloc((void**)&c->hostBlock, c->hostBlockBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
-        || hipHostGetDevicePointer((void**)&dev, c->hostBlock, 0) != hipSuccess)
+    c->hostBlock = (unsigned char*)pinned_acquire(c->device, c->hostBlockBytes, (void**)&dev);
+    if (!c->hostBlock || !dev)
         return fail(LWHIP_ERR_DEVICE, "lwhip_create: hipHostMalloc of the context's host block failed");
     std::memset(c->hostBlock, 0, c->hostBlockBytes);
     std::memcpy(c->hostBlock + HB_CANARY, &HB_CANARY_WORD, sizeof HB_CANARY_WORD);
@@ -161,7 +418,7 @@ void host_block_release(lwhip_context* c)
         quarantine().blocks.emplace_back(c->hostBlock, c->hostBlockBytes);
     }
     else
-        (void)hipHostFree(c->hostBlock);
+        pinned_release(c->device, c->hostBlock, c->hostBlockBytes);
     c->hostBlock = nullptr;
     c->tailMapped = c->tailMappedDev = c->changeHost = c->changeDev = nullptr;
     c->statusHost = c->statusDev = c->popStatusHost = c->prdCtlHost = c->turnLateHost = c->turnLateDev = nullptr;
@@ -534,7 +791,8 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
         c->stream = (hipStream_t)opts->stream;
     else
     {
-        if (stream_acquire(c->device, &c->ownStream) != hipSuccess)
+        c->ownStreamShared = like != nullptr && c->batchHint > 1;
+        if ((c->ownStreamShared ? stream_acquire_shared(c->device, &c->ownStream) : stream_acquire(c->device, &c->ownStream)) != hipSuccess)
             return bail(fail(LWHIP_ERR_DEVICE, "hipStreamCreate failed"));
         c->stream = c->ownStream;
     }
@@ -557,6 +815,41 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
                                                 "grid, or a transition's levels / range / coefficients / grid / cross-sections)"));
         c->tablesFrom = owner;
     }
+    // One arena for everything a borrower allocates between here and the end of its first upload (DevArena, lwhip_host.h); the
+    // owner counts what the same path takes in its own case.  (The structure tables that borrowers share are outside: see
+    // DevBuf::upload_or_borrow.)
+    DevArena arena;
+    const bool plainAllocs = DevBuf<double>::poison_on() || DevBuf<double>::sentinel_on() || std::getenv("LWHIP_TRACE_ALLOC") != nullptr;
+    if (!plainAllocs)
+    {
+        if (c->tablesFrom && c->tablesFrom->stateBytes > 0)
+        {
+            arena.size = c->tablesFrom->stateBytes + (64u << 10);
+            // (a batch column's uploads all run on its own stream -- the gathered upload below --, so its clearing fill does too;
+            // otherwise the null stream, which the synchronous table uploads of DevBuf::upload follow)
+            if (hipMalloc((void**)&arena.base, arena.size) == hipSuccess
+                && hipMemsetAsync(arena.base, 0, arena.size, c->batchHint > 1 ? c->stream : nullptr) == hipSuccess)
+                c->stateArena = arena.base;
+            else
+            {
+                (void)hipGetLastError();
+                if (arena.base)
+                    (void)hipFree(arena.base);
+                arena = DevArena{};
+            }
+        }
+        else if (!c->tablesFrom)
+            arena.counting = true;
+    }
+    struct ArenaScope
+    {
+        explicit ArenaScope(DevArena* a) { devbuf_arena() = a; }
+        ~ArenaScope() { devbuf_arena() = nullptr; }
+    } arenaScope((arena.base || arena.counting) ? &arena : nullptr);
+    // ... and, for a column of a batch, one gathered upload (H2DBatch, lwhip_host.h) on the column's stream
+    H2DBatchScope h2d;
+    if (arena.base && c->batchHint > 1 && dbg_env_int("LWHIP_H2D_BATCH", 1) != 0)
+        h2d.begin(c->device, c->stream);
     st = build_tables(c);
     if (st != LWHIP_OK)
     {
@@ -579,36 +872,10 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
             explicit Skip(bool o) : on(o) { devbuf_skip_safety_clear() += on ? 1 : 0; }
             ~Skip() { devbuf_skip_safety_clear() -= on ? 1 : 0; }
         } skip(c->tablesFrom != nullptr);
-        // one arena for a borrower's state (DevArena, lwhip_host.h); the owner counts what its own state takes
-        DevArena arena;
-        const bool plainAllocs = DevBuf<double>::poison_on() || DevBuf<double>::sentinel_on() || std::getenv("LWHIP_TRACE_ALLOC") != nullptr;
-        if (!plainAllocs)
-        {
-            if (c->tablesFrom && c->tablesFrom->stateBytes > 0)
-            {
-                arena.size = c->tablesFrom->stateBytes + (64u << 10);
-                if (hipMalloc((void**)&arena.base, arena.size) == hipSuccess && hipMemsetAsync(arena.base, 0, arena.size, nullptr) == hipSuccess)
-                    c->stateArena = arena.base;
-                else
-                {
-                    (void)hipGetLastError();
-                    if (arena.base)
-                        (void)hipFree(arena.base);
-                    arena = DevArena{};
-                }
-            }
-            else if (!c->tablesFrom)
-                arena.counting = true;
-        }
-        struct ArenaScope
-        {
-            explicit ArenaScope(DevArena* a) { devbuf_arena() = a; }
-            ~ArenaScope() { devbuf_arena() = nullptr; }
-        } arenaScope((arena.base || arena.counting) ? &arena : nullptr);
         st = alloc_state(c);
-        if (arena.counting)
-            c->stateBytes = arena.counted;
-        if (hipStreamSynchronize(nullptr) != hipSuccess && st == LWHIP_OK)
+        // (a batch column whose allocations all came out of its arena has queued nothing on the null stream -- and waiting for the
+        // null stream means waiting for every other creating thread's stream)
+        if (!(h2d_batch() && !arena.overflowed) && hipStreamSynchronize(nullptr) != hipSuccess && st == LWHIP_OK)
             st = fail(LWHIP_ERR_DEVICE, "lwhip_create: clearing the state allocations failed");
     }
     if (st != LWHIP_OK)
@@ -623,6 +890,11 @@ static int create_impl(const lwhip_problem* prob, const lwhip_options* opts, lwh
     st = lwhip_upload(c, LWHIP_ALL_INPUTS);
     if (st != LWHIP_OK)
         return bail(st);
+    if (arena.counting)
+        c->stateBytes = arena.counted;
+    devbuf_arena() = nullptr;
+    if (h2d.finish() != hipSuccess)
+        return bail(fail(LWHIP_ERR_DEVICE, "lwhip_create: the gathered upload of a batch column failed"));
     if (timing)
         std::fprintf(stderr, "lwhip_create: tables %.2f ms, allocations %.2f ms, upload %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
     if (std::getenv("LWHIP_VERBOSE"))

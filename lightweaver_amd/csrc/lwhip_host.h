@@ -74,11 +74,45 @@ struct DevArena
     size_t size = 0, used = 0;
     size_t counted = 0;   // count mode: bytes asked for
     bool counting = false;
+    bool overflowed = false; // a piece did not fit and took the ordinary path (with its clearing fill on the null stream)
 };
 inline DevArena*& devbuf_arena()
 {
     static thread_local DevArena* a = nullptr;
     return a;
+}
+
+// Host-to-device copies of a batch column's creation, gathered (round 6): while a borrower of a 1.5D batch is created, every
+// upload -- the H2D macro, the argument blocks, DevBuf::upload -- is copied into ONE page-locked stage and described by a record;
+// lwhip_create then sends the stage to a device inbox with one copy and lets one kernel (h2d_scatter_kernel) move the pieces to
+// their buffers.  A column made ~55 copies (several of them from pageable memory, which the runtime stages while holding its
+// lock) and one synchronous hipMemcpy that waited 6 ms for the other creating threads' streams; now one copy and one launch.
+struct H2DBatch
+{
+    hipStream_t stream = nullptr;
+    unsigned char* host = nullptr;  // page-locked stage
+    unsigned char* inbox = nullptr; // its landing place on the device
+    size_t cap = 0, used = 0;
+    std::vector<H2DRec> recs;
+    bool inFlight = false; // a flush was queued and the stage not yet known to be free again
+    long copies = 0;
+    bool add(void* dst, const void* src, size_t bytes);
+    hipError_t flush();
+};
+inline H2DBatch*& h2d_batch()
+{
+    static thread_local H2DBatch* b = nullptr;
+    return b;
+}
+// the copy every upload path calls: into the thread's batch when one is open on this stream, else the ordinary copy
+inline hipError_t h2d_copy(void* dst, const void* src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0)
+        return hipSuccess;
+    H2DBatch* b = h2d_batch();
+    if (b && b->stream == stream && b->add(dst, src, bytes))
+        return hipSuccess;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
 }
 
 template <typename T> struct DevBuf
@@ -119,6 +153,8 @@ template <typename T> struct DevBuf
                 owned = false;
                 return hipSuccess;
             }
+            else
+                ar->overflowed = true;
         }
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         const int seq = alloc_seq()++;
@@ -246,6 +282,9 @@ template <typename T> struct DevBuf
     {
         if (!p || sentinel_on())
             return hipSuccess;
+        if (const DevArena* ar = devbuf_arena())
+            if (!ar->counting && (unsigned char*)p >= ar->base && (unsigned char*)p < ar->base + ar->size)
+                return hipSuccess; // (a piece of the borrower's arena, cleared as a whole a moment ago)
         hipError_t e = hipMemset(p, 0, n * sizeof(T));
         return (e == hipSuccess && devbuf_defer_fill_sync() == 0) ? hipStreamSynchronize(nullptr) : e;
     }
@@ -288,7 +327,13 @@ template <typename T> struct DevBuf
             sig = from->sig;
             return hipSuccess;
         }
-        return upload(v);
+        // (a structure table: the owner's copy is what borrowers use, so it is neither counted into the size of a borrower's
+        // arena nor -- where a borrower has to keep a copy of its own after all -- taken out of one)
+        DevArena* const ar = devbuf_arena();
+        devbuf_arena() = nullptr;
+        const hipError_t e = upload(v);
+        devbuf_arena() = ar;
+        return e;
     }
     hipError_t upload(const std::vector<T>& v)
     {
@@ -296,6 +341,9 @@ template <typename T> struct DevBuf
         if (e != hipSuccess || v.empty())
             return e;
         sig = fingerprint(v);
+        if (H2DBatch* b = h2d_batch())
+            if (b->add(p, v.data(), v.size() * sizeof(T)))
+                return hipSuccess;
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     void release()
@@ -338,6 +386,10 @@ int host_block_init(lwhip_context* c);
 void host_block_release(lwhip_context* c);
 hipError_t stream_acquire(int device, hipStream_t* out);
 void stream_release(int device, hipStream_t s);
+hipError_t stream_acquire_shared(int device, hipStream_t* out); // the columns of a batch made by one thread share a stream
+void stream_release_shared(int device, hipStream_t s);
+void* pinned_acquire(int device, size_t bytes, void** devPtr);  // page-locked, device-mapped host memory out of pooled slabs
+void pinned_release(int device, void* p, size_t bytes);
 void peer_release(lwhip_context* c);
 int peer_publish(lwhip_context* c);
 int fingerprint_J_enqueue(lwhip_context* c);
@@ -419,6 +471,7 @@ struct lwhip_context
     int nContLa = 0;
     int64_t gammaTot = 0, phiTot = 0, rhoTot = 0, parTot = 0;
     hipStream_t ownStream = nullptr, stream = nullptr;
+    bool ownStreamShared = false;
 
     DevBuf<double> height, temperature, muz, wmu, wavelength, lowerBcData, upperBcData;
     DevBuf<int32_t> rayAll, rayUp, lowerIdx, upperIdx;
@@ -577,12 +630,14 @@ struct lwhip_context
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
-        if (ownStream)
+        if (ownStream && ownStreamShared)
+            stream_release_shared(device, ownStream);
+        else if (ownStream)
             stream_release(device, ownStream); // (never hipStreamDestroy: see stream_acquire, lwhip_api.hip)
         if (gatherPinned)
             (void)hipHostFree(gatherPinned);
         if (stage)
-            (void)hipHostFree(stage);
+            pinned_release(device, stage, stageDoubles * sizeof(double));
         if (prdPinned)
             (void)hipHostFree(prdPinned);
         if (prdPinnedPipe)
@@ -599,7 +654,7 @@ struct lwhip_context
 };
 
 #define H2D(dst, src, count)                                                                           \
-    HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyHostToDevice, c->stream))
+    HIP_TRY(lwhip::h2d_copy((dst), (src), (size_t)(count) * sizeof(double), c->stream))
 #define D2H(dst, src, count)                                                                           \
     HIP_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(double), hipMemcpyDeviceToHost, c->stream))
 

@@ -494,6 +494,15 @@ hipError_t launch_voigt_line(const VoigtLineArgs& a, hipStream_t stream);
 // every line of the list in one launch pair (same Ns and slice count; hostList = what devList holds)
 hipError_t launch_voigt_lines(const VoigtLineArgs* devList, const VoigtLineArgs* hostList, int nLines, hipStream_t stream);
 
+// one piece of a gathered upload (H2DBatch, lwhip_host.h): `bytes` from offset `off` of the inbox to `dst`
+struct H2DRec
+{
+    unsigned long long dst, off, bytes;
+};
+enum { H2D_CHUNK = 64 * 1024 }; // a record moves at most this much: one workgroup
+// recs = inbox + recsOff, n of them (lwhip_kernels.hip)
+hipError_t launch_h2d_scatter(const unsigned char* inbox, size_t recsOff, int n, hipStream_t stream);
+
 enum { PRD_MAX_SLICES = 32 }; // workgroups per depth point in the PRD scattering integral
 
 // One PRD line's scattering integral (lwhip_prd.hip)

@@ -699,3 +699,47 @@ hipError_t launch_prefill(double* Gamma, const double* C, double crsw, size_t n,
 }
 
 }
+
+namespace lwhip
+{
+// The pieces of a gathered upload from the inbox to their buffers: one workgroup per record (<= H2D_CHUNK bytes), the widest
+// access the three alignments allow.
+__global__ void __launch_bounds__(256) h2d_scatter_kernel(const unsigned char* __restrict__ inbox, const H2DRec* __restrict__ recs)
+{
+    const H2DRec r = recs[blockIdx.x];
+    const unsigned char* s = inbox + r.off;
+    unsigned char* d = (unsigned char*)r.dst;
+    const unsigned long long al = r.dst | r.off | r.bytes;
+    if ((al & 15) == 0)
+    {
+        const uint4* s4 = (const uint4*)s;
+        uint4* d4 = (uint4*)d;
+        for (size_t i = threadIdx.x; i < r.bytes / 16; i += blockDim.x)
+            d4[i] = s4[i];
+    }
+    else if ((al & 7) == 0)
+    {
+        const unsigned long long* s8 = (const unsigned long long*)s;
+        unsigned long long* d8 = (unsigned long long*)d;
+        for (size_t i = threadIdx.x; i < r.bytes / 8; i += blockDim.x)
+            d8[i] = s8[i];
+    }
+    else if ((al & 3) == 0)
+    {
+        const unsigned int* s1 = (const unsigned int*)s;
+        unsigned int* d1 = (unsigned int*)d;
+        for (size_t i = threadIdx.x; i < r.bytes / 4; i += blockDim.x)
+            d1[i] = s1[i];
+    }
+    else
+        for (size_t i = threadIdx.x; i < r.bytes; i += blockDim.x)
+            d[i] = s[i];
+}
+hipError_t launch_h2d_scatter(const unsigned char* inbox, size_t recsOff, int n, hipStream_t stream)
+{
+    if (n <= 0)
+        return hipSuccess;
+    LWHIP_LAUNCH(h2d_scatter_kernel, dim3(n), dim3(256), 0, stream, inbox, (const H2DRec*)(inbox + recsOff));
+    return hipGetLastError();
+}
+}

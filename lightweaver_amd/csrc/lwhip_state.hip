@@ -44,6 +44,14 @@ int alloc_state(lwhip_context* c)
     HIP_TRY(c->vBroad.alloc((size_t)std::max(c->Natom, 1) * Ns));
     HIP_TRY(c->aDamp.alloc_zero((size_t)std::max(c->Nline, 1) * Ns)); // (zero = the value of a line without damping data)
     HIP_TRY(c->Qelast.alloc_zero((size_t)std::max(c->Nline, 1) * Ns));
+    if (!c->is2d && c->batchHint > 1 && c->prob.vlosMu)
+    {
+        // a column of a 1.5D batch: the scratch of its device-side profiles (voigt_line_list, lwhip_api.hip -- same sizes) now,
+        // out of the column's arena, instead of two allocations and a fill per column at the batch's first profile launch
+        const size_t nLine = (size_t)std::max(c->Nline, 1);
+        HIP_TRY(c->wphiScratch.alloc(nLine * 16 * Ns));
+        HIP_TRY(c->wphiTicket.alloc_zero(nLine * ((Ns + 7) / 8 + 1)));
+    }
     if (c->laneSweep)
     {
         // the depth-only pools the lane sweep reads, back to back (+ padding: a ray's last block reads past its row)
@@ -358,7 +366,7 @@ int build_tile_args(lwhip_context* c)
             if (e != hipSuccess)
                 return e;
         }
-        return hipMemcpyAsync(dev.p, &host, sizeof(TileArgs), hipMemcpyHostToDevice, c->stream);
+        return h2d_copy(dev.p, &host, sizeof(TileArgs), c->stream);
     };
     HIP_TRY(put(c->dtargs, c->htargs, a));
     if (c->nTileChunksPrd > 0)
@@ -617,7 +625,7 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
                     geo[4 * k + 2] = 1.0 / (std::fabs(p.height[k - 1] - p.height[k]) + std::fabs(p.height[k] - p.height[k + 1]));
                 geo[4 * k + 3] = 1.0 / p.temperature[k];
             }
-            HIP_TRY(hipMemcpyAsync(c->geo.p, geo.data(), geo.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(h2d_copy(c->geo.p, geo.data(), geo.size() * sizeof(double), c->stream));
             std::vector<double> geoT;
             if (c->laneSweep)
             {
@@ -627,7 +635,7 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
                 for (size_t k = 0; k < Ns; ++k)
                     for (int q = 0; q < 4; ++q)
                         geoT[q * st + k + 1] = geo[4 * k + q];
-                HIP_TRY(hipMemcpyAsync(c->geoT.p, geoT.data(), geoT.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(h2d_copy(c->geoT.p, geoT.data(), geoT.size() * sizeof(double), c->stream));
             }
             std::vector<double> bcB;
             if (c->laneSweep)
@@ -647,17 +655,20 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
                         bcB[4 * la + q] = planck(p.temperature[kk[q]], p.wavelength[l0 + la]);
                 if (c->bcPlanck.n < bcB.size())
                     HIP_TRY(c->bcPlanck.alloc(bcB.size()));
-                HIP_TRY(hipMemcpyAsync(c->bcPlanck.p, bcB.data(), bcB.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(h2d_copy(c->bcPlanck.p, bcB.data(), bcB.size() * sizeof(double), c->stream));
             }
-            HIP_TRY(hipStreamSynchronize(c->stream)); // `geo`, `bcB` are locals
+            if (!h2d_batch()) // (a gathered upload has copied them already)
+                HIP_TRY(hipStreamSynchronize(c->stream)); // `geo`, `bcB` are locals
         }
     }
     // Column batches (round 6): the four [Nla, Ns] arrays of a column -- 7.6 MB at 2 908 wavelengths -- go through a pinned
     // staging block of this call (a pool of them, one per creating thread at a time): the host copy runs in parallel on the
     // creating threads, while four pageable hipMemcpyAsync per column took ~1.5 ms each INSIDE the runtime's lock -- the
     // serial part of setting up 512 columns.
-    BigStage big(c->batchHint > 1 ? (size_t)4 * Nla * Ns : 0);
+    BigStage big(c->batchHint > 1 && !h2d_batch() ? (size_t)4 * Nla * Ns : 0);
     auto h2d_big = [&](double* dst, const double* src, size_t count, size_t slot) -> hipError_t {
+        if (h2d_batch())
+            return h2d_copy(dst, src, count * sizeof(double), c->stream);
         if (!big.p)
             return hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream);
         double* st = big.p + slot * Nla * Ns;
@@ -726,7 +737,9 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
     if (!c->stage)
     {
         c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 2 * aPool + 2 * lPool + 8;
-        HIP_TRY(hipHostMalloc((void**)&c->stage, c->stageDoubles * sizeof(double), hipHostMallocDefault));
+        c->stage = (double*)pinned_acquire(c->device, c->stageDoubles * sizeof(double), nullptr);
+        if (!c->stage)
+            return fail(LWHIP_ERR_DEVICE, "lwhip_upload: no page-locked memory for the upload stage");
     }
     double* stN = c->stage;
     double* stG = stN + nPool;
@@ -852,6 +865,8 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
         H2D(c->ratio.p, ratioHost.data(), ratioHost.size());
     if (mask & LWHIP_PROFILES)
     {
+        if (H2DBatch* b = h2d_batch())
+            HIP_TRY(b->flush()); // (kernels that read what was uploaded follow)
         const int str = retile_profiles(c);
         if (str != LWHIP_OK)
             return str;
@@ -860,7 +875,8 @@ static int upload_impl(lwhip_context* c, uint32_t mask)
     }
     else if ((mask & (LWHIP_ATMOS | LWHIP_NSTAR)) && c->deviceProfiles)
         c->profilesStale = true; // phi / wphi follow the new velocities and widths before the next sweep
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!h2d_batch()) // (a gathered upload holds copies of the sources; lwhip_create sends it and waits)
+        HIP_TRY(hipStreamSynchronize(c->stream));
     return LWHIP_OK;
 }
 
@@ -925,7 +941,9 @@ static int download_impl(lwhip_context* c, uint32_t mask)
     {
         // (the same size as lwhip_upload's layout: whoever comes first allocates)
         c->stageDoubles = nPool + 2 * gPool + 2 * rPool + 2 * (size_t)std::max(c->Natom, 1) * Ns + 2 * (size_t)std::max(c->Nline, 1) * Ns + 8;
-        HIP_TRY(hipHostMalloc((void**)&c->stage, c->stageDoubles * sizeof(double), hipHostMallocDefault));
+        c->stage = (double*)pinned_acquire(c->device, c->stageDoubles * sizeof(double), nullptr);
+        if (!c->stage)
+            return fail(LWHIP_ERR_DEVICE, "lwhip_upload: no page-locked memory for the upload stage");
     }
     double* stN = c->stage;
     double* stG = stN + nPool;
