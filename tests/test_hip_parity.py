@@ -609,6 +609,35 @@ def test_column_batch_vs_oracle(gpu, fused, sweep, static):
         assert up.dJMax == pytest.approx(dj, rel=1e-6)
 
 
+def test_column_batch_gathered_upload_equals_separate_copies(gpu, hip_lib, monkeypatch):
+    """A borrower column of a batch uploads everything through ONE copy into a device inbox and ONE scatter kernel
+    (H2DBatch / h2d_scatter_kernel); LWHIP_H2D_BATCH=0 (a debug knob) makes the same uploads as separate copies.  Same J and I to
+    the last bit, Gamma to the atomics' run-to-run 1e-12 -- and the columns take at most one stream per creating thread out
+    of the pool, not one per column."""
+    from lightweaver_amd.batch import ColumnBatch
+    lib = hip_lib
+
+    def run():
+        probs = [models.build_problem(models.perturbed(models.falc82(), seed=300 + i, dv=2.0e3),
+                                      [models.H_6(0.3), models.CaII_6(0.3)], Nrays=3) for i in range(6)]
+        before = lib.lwhip_debug_streams_created()
+        with ColumnBatch(probs) as batch:
+            assert batch._batch is not None
+            made = lib.lwhip_debug_streams_created() - before
+            batch.iterate(2, nscatter=2)
+            batch.download()
+        return probs, made
+
+    monkeypatch.setenv('LWHIP_CREATE_THREADS', '2')
+    pa, made = run()
+    assert made <= 3, made          # the owner's + one per creating thread (fewer when the pool had idle ones)
+    monkeypatch.setenv('LWHIP_H2D_BATCH', '0')
+    pb, _ = run()
+    for a, b in zip(pa, pb):
+        assert np.array_equal(a.J, b.J) and np.array_equal(a.I, b.I)
+        compare_problems(a, b, tol=1e-11, what=('Gamma', 'n'))
+
+
 def test_create_like_borrows_structure_tables(gpu, sweep):
     """lwhip_create_like: a context of the same structure borrows the first one's structure tables (the columns of a batch);
     its results equal those of a context with tables of its own, a problem of another structure gets its own tables, and the
