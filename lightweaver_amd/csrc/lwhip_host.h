@@ -161,9 +161,10 @@ template <typename T> struct DevBuf
         static const bool noClear = debug_knobs_on() && std::getenv("LWHIP_NO_CLEAR") != nullptr; // (no safety net: what hipMalloc returns)
         const bool sentinel = init == 1 && std::is_same<T, double>::value && sentinel_for(seq);
         const char* what = "";
-        if (e == hipSuccess && poison_on())
+        if (e == hipSuccess && poison_on() && init != 2)
         {
-            // diagnosis (LWHIP_POISON=1): fresh allocations hold NaN / -1
+            // diagnosis (LWHIP_POISON=1): fresh allocations hold NaN / -1 (not alloc_zero's: their zero is a value -- counters,
+            // accumulators --, which round 6's peer-exchange arrival counter was the first to rely on without a clear of its own)
             e = hipMemset(p, 0xFF, count * sizeof(T));
             what = " poisoned";
         }

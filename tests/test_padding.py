@@ -45,6 +45,8 @@ PARITY = ['tests/test_hip_parity.py::test_lane_sweep_ray_split_vs_oracle', 'test
 def _child(env_extra, extra_args=()):
     env = dict(os.environ)
     env['LWHIP_DEBUG'] = '1'   # (the diagnosis knobs are read only with it)
+    for k in ('LWHIP_POISON', 'LWHIP_CHECK_ZERO'):   # (tools/parity_stress.sh sets these around the suite: LWHIP_POISON's fill takes
+        env.pop(k, None)                             # precedence over the sentinel this file is about)
     env.update(env_extra)
     return subprocess.run([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '--tb=short', '-p', 'no:cacheprovider', '-x']
                           + PARITY + list(extra_args), cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
@@ -76,6 +78,8 @@ def test_the_sentinel_is_applied(gpu):
     """The mode does what it says: the traced allocations of a parity test carry the sentinel (otherwise the test above
     would pass vacuously)."""
     env = dict(os.environ)
+    for k in ('LWHIP_POISON', 'LWHIP_CHECK_ZERO'):
+        env.pop(k, None)
     env.update({'LWHIP_DEBUG': '1', 'LWHIP_PAD_SENTINEL': 'all', 'LWHIP_PAD_SENTINEL_INT': '1', 'LWHIP_TRACE_ALLOC': '1'})
     out = subprocess.run([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '-s', '-p', 'no:cacheprovider',
                           'tests/test_hip_parity.py::test_lane_sweep_ray_split_vs_oracle'], cwd=ROOT, env=env,
