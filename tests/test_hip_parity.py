@@ -638,6 +638,30 @@ def test_column_batch_gathered_upload_equals_separate_copies(gpu, hip_lib, monke
         compare_problems(a, b, tol=1e-11, what=('Gamma', 'n'))
 
 
+def test_column_batch_upload_larger_than_the_stage(gpu, monkeypatch):
+    """Columns whose uploads exceed the gathered upload's 24 MB stage (four [Nlambda, Nspace] arrays at ~10 000 wavelengths are
+    27 MB): the batch is sent in the middle of the column's creation, the stage is reused behind a wait for that copy, and the
+    rest follows -- same results as with separate copies."""
+    from lightweaver_amd.batch import ColumnBatch
+
+    def run():
+        probs = [models.falc_h_ca(Nrays=3, lineScale=11.0, atmos=models.perturbed(models.falc82(), seed=500 + i), computeProfiles=False)
+                 for i in range(3)]
+        assert 4 * probs[0].Nlambda * probs[0].Nspace * 8 > 24 << 20
+        with ColumnBatch(probs) as batch:
+            assert batch._batch is not None
+            batch.iterate(2, nscatter=2)
+            batch.download()
+        return probs
+
+    pa = run()
+    monkeypatch.setenv('LWHIP_H2D_BATCH', '0')
+    pb = run()
+    for a, b in zip(pa, pb):
+        assert np.array_equal(a.J, b.J) and np.array_equal(a.I, b.I)
+        compare_problems(a, b, tol=1e-11, what=('Gamma', 'n'))
+
+
 def test_create_like_borrows_structure_tables(gpu, sweep):
     """lwhip_create_like: a context of the same structure borrows the first one's structure tables (the columns of a batch);
     its results equal those of a context with tables of its own, a problem of another structure gets its own tables, and the
