@@ -794,6 +794,13 @@ def main():
     aux = {}
     if world == 1:
         aux['stat_eq_ms'] = timed(lambda: ctx.stat_equil(deviceResident=True), 20, torch)
+
+        # what an iterate_ctx_se loop pays per iteration: the formal solution, then stat_equil of every atom, each with its result
+        # on the host (lightweaver/iterate_ctx.py:157-176; device-resident)
+        def se_iteration():
+            ctx.formal_sol_gamma_matrices(deviceResident=True)
+            ctx.stat_equil(deviceResident=True)
+        aux['iterate_se_ms'] = timed(se_iteration, 100, torch)
     ctx.close()
     if world > 1 and not args.no_aux:
         # the split that scales by construction, beside the strong-scaling headline: every rank its own fused batch of columns
