@@ -93,7 +93,12 @@ public:
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         // (round 6: up to 31 -- with J no longer crossing PCIe the fingerprints of the 90 MB are what a call waits for, and
         // one thread streams ~20 GB/s of the host's memory bandwidth)
-        const unsigned n = std::min(31u, hw > 2 ? hw / 2 - 1 : 0u); // (+ the calling thread)
+        unsigned n = std::min(31u, hw > 2 ? hw / 2 - 1 : 0u); // (+ the calling thread)
+        // LWHIP_HASH_THREADS=k: k pool threads (0: the calling thread alone) -- a host whose cores are contended may do better
+        // with fewer
+        if (const char* e = std::getenv("LWHIP_HASH_THREADS"))
+            if (*e)
+                n = (unsigned)std::min(255, std::max(0, std::atoi(e)));
         for (unsigned t = 0; t < n; ++t)
         {
             threads.emplace_back([this] { loop(); });
